@@ -1,0 +1,205 @@
+/*
+ * sixdof_hip.h — C ABI of the MI355X-native 6DOF rigid-body integrator.
+ *
+ * This is the drop-in boundary for ONE path of elodin-sys/elodin: the `six_dof`
+ * system (RK4 / semi-implicit) executed over ECS columns.  Every entry point
+ * names the reference interface it replaces (paths relative to the reference
+ * checkout).  Plain pointers and sizes only; no C++/torch types cross the ABI.
+ *
+ *   reference boundary                                        this header
+ *   --------------------------------------------------------  -----------------------
+ *   CraneliftExec::new            cranelift_exec.rs:54-127    sixdof_create + sixdof_bind_columns
+ *   CraneliftExec::invoke_batch   cranelift_exec.rs:129-195   sixdof_step
+ *   JaxExec H2D / D2H per batch   jax_exec.rs:130-177         sixdof_upload / sixdof_download
+ *   TickFn(inputs**, outputs**)   cranelift_exec.rs:11        sixdof_tick (+ sixdof_tick_bind)
+ *   ExecMetadata slot tables      exec.rs:17-29               sixdof_tick_slots
+ *   Error -> PyErr                error.rs                    negative sixdof_status + sixdof_last_error
+ *   ComponentId::new              impeller2/src/types.rs:39-44 sixdof_component_id
+ *   validate_rates dt quantise    world_builder.rs:211-243    sixdof_quantize_time_step
+ *   six_dof(time_step, sys, integrator)  six_dof.rs:161-203   sixdof_desc + sixdof_set_effectors
+ *   GraphQuery edges              graph.rs:17-41,113-175      sixdof_set_edges
+ *
+ * Column byte layout is the reference's (`World.host`, world.rs:23-45): row r of a
+ * component occupies bytes [r*size, (r+1)*size), little-endian, row-major, rows in
+ * spawn order, `entity_ids[r]` u64 LE.  The same bytes are kept resident in HBM.
+ *
+ * Threading: one handle = one GPU = one caller thread (mirrors the reference, where the
+ * exec is moved once into the sim thread, cranelift_exec.rs:31-51).  Handles on
+ * different GPUs may be driven from different threads.  Nothing throws across the ABI.
+ */
+#ifndef SIXDOF_HIP_H
+#define SIXDOF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIXDOF_ABI_VERSION 1
+
+typedef struct sixdof_handle sixdof_handle;
+
+/* 0 = ok, negative = error.  Mirrors nox-py `Error` (libs/nox-py/src/error.rs). */
+typedef enum sixdof_status {
+    SIXDOF_OK = 0,
+    SIXDOF_ERR_INVALID_ARGUMENT = -1,
+    SIXDOF_ERR_COMPONENT_NOT_FOUND = -2,  /* Error::ComponentNotFound   */
+    SIXDOF_ERR_VALUE_SIZE_MISMATCH = -3,  /* Error::ValueSizeMismatch   */
+    SIXDOF_ERR_BACKEND = -4,              /* Error::CraneliftBackend(String) analogue: HIP runtime failure */
+    SIXDOF_ERR_NO_DEVICE = -5,
+    SIXDOF_ERR_UNSUPPORTED = -6,
+    SIXDOF_ERR_ENTITY_MISMATCH = -7       /* Body columns do not share one entity-id vector */
+} sixdof_status;
+
+/* integrator/mod.rs:7-10 */
+typedef enum sixdof_integrator {
+    SIXDOF_INTEGRATOR_RK4 = 0,
+    SIXDOF_INTEGRATOR_SEMI_IMPLICIT = 1
+} sixdof_integrator;
+
+/* Arithmetic type of the state columns.  The reference six_dof is f64 only
+ * (six_dof.rs:12-14,133-135); F32 is an extension for BASELINE config 5. */
+typedef enum sixdof_dtype {
+    SIXDOF_F64 = 0,
+    SIXDOF_F32 = 1
+} sixdof_dtype;
+
+/* impeller2 PrimType subset used by this path */
+typedef enum sixdof_prim {
+    SIXDOF_PRIM_F64 = 0,
+    SIXDOF_PRIM_U64 = 1,
+    SIXDOF_PRIM_F32 = 2
+} sixdof_prim;
+
+/*
+ * Effector pipeline: the `sys` argument of six_dof(), i.e. what runs between
+ * clear_forces and calc_accel on every integrator stage (six_dof.rs:184-203).
+ * The reference takes arbitrary JAX; this backend takes a list of built-in ops
+ * applied in pipe order.  Each op cites the example effector it restates.
+ */
+typedef enum sixdof_effector_kind {
+    /* F += [tau(3), f(3)] = p[0..6), world frame.  test_all.py:342-364 constant_force */
+    SIXDOF_EFF_CONST_WRENCH = 1,
+    /* f += (p[0],p[1],p[2]) * mass.  examples/ball/sim.py:57-59 */
+    SIXDOF_EFF_UNIFORM_GRAVITY = 2,
+    /* tau += q * aux[i][0..3)  (body-frame torque column).  examples/apollo-lander/sim.py:396-398 */
+    SIXDOF_EFF_BODY_TORQUE = 3,
+    /* f += q * aux[i][0..3)  (body-frame force column).  examples/apollo-lander/sim.py:391-394 */
+    SIXDOF_EFF_BODY_FORCE = 4,
+    /* F = Force(linear = f + drag) with wind = aux[i][0..3), p = {Cd, rho, area}.
+     * NOTE: clears the torque, like the reference.  examples/ball/sim.py:96-116 */
+    SIXDOF_EFF_BALL_DRAG = 5,
+    /* edge_fold over sixdof_set_edges(): acc.f -= p[0]*M*m*r/|r|^3, r = a-b (p[0] = G).
+     * Result REPLACES Force for source rows.  examples/three-body/main.py:56-78 */
+    SIXDOF_EFF_EDGE_GRAVITY_NEWTON = 6,
+    /* edge_fold: acc.f += (p[0]*ma*mb*inv3)*r, r = b-a, inv = 1/sqrt(r.r+p[1]) (p = {K, eps}).
+     * examples/n-body/sim.py:344-369 */
+    SIXDOF_EFF_EDGE_GRAVITY_SOFTENED = 7,
+    /* Same fold as 7 over the complete graph (for i: for j != i, ascending), without
+     * materialising edges.  examples/n-body/sim.py:333-337 spawn order */
+    SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED = 8
+} sixdof_effector_kind;
+
+typedef struct sixdof_effector_op {
+    int32_t kind;               /* sixdof_effector_kind */
+    int32_t reserved;
+    uint64_t aux_component_id;  /* per-entity [n,3] f64 column for kinds 3,4,5; else 0 */
+    double p[6];
+} sixdof_effector_op;
+
+typedef struct sixdof_desc {
+    uint32_t struct_size;        /* = sizeof(sixdof_desc) */
+    int32_t device_ordinal;      /* HIP device */
+    int32_t integrator;          /* sixdof_integrator */
+    int32_t dtype;               /* sixdof_dtype */
+    uint64_t n_entities;         /* rows of every Body column */
+    double simulation_time_step; /* globals column value (ns-quantised, see sixdof_quantize_time_step) */
+    double time_step;            /* six_dof(time_step=...) override, used iff has_time_step */
+    int32_t has_time_step;
+    uint32_t ticks_per_launch;   /* ticks fused into one kernel launch (>=1). 1 = every tick
+                                    materialises all output columns in HBM (reference tick semantics);
+                                    K>1 = the reference's ticks_per_telemetry batch, state in registers */
+    uint32_t flags;              /* SIXDOF_FLAG_* */
+    uint32_t reserved;
+} sixdof_desc;
+
+#define SIXDOF_FLAG_USE_GRAPH 1u /* replay long sixdof_step batches from a captured hipGraph */
+
+/* One ECS column as the reference holds it (world.rs:26-30 + ExecSlotMetadata exec.rs:17-22). */
+typedef struct sixdof_column {
+    uint64_t component_id;       /* sixdof_component_id("world_pos") ... */
+    int32_t prim_type;           /* sixdof_prim */
+    uint32_t ndim;               /* 0 (scalar), 1 */
+    uint64_t dims[2];            /* e.g. {7} */
+    uint64_t n_rows;
+    const uint64_t* entity_ids;  /* [n_rows] */
+    void* host_ptr;              /* caller-owned row-major bytes; borrowed until destroy/rebind */
+} sixdof_column;
+
+/* profile.rs TickTimings analogue (ms) */
+typedef struct sixdof_timings {
+    double h2d_upload_ms;
+    double kernel_invoke_ms;   /* host wall time of the step call incl. stream sync */
+    double d2h_download_ms;
+    double kernel_device_ms;   /* HIP-event time of the launches of the last step, on the handle's stream */
+    uint64_t launches;         /* kernel launches issued by the last step */
+    uint64_t ticks;
+} sixdof_timings;
+
+typedef struct sixdof_slot {
+    uint64_t component_id;
+    uint64_t bytes;
+} sixdof_slot;
+
+/* download masks */
+#define SIXDOF_COL_WORLD_POS 1u
+#define SIXDOF_COL_WORLD_VEL 2u
+#define SIXDOF_COL_WORLD_ACCEL 4u
+#define SIXDOF_COL_FORCE 8u
+#define SIXDOF_COL_INERTIA 16u
+#define SIXDOF_COL_ALL 31u
+
+uint32_t sixdof_abi_version(void);
+/* FNV-1a-64(name) & ~(1<<63): impeller2/src/types.rs:39-44 */
+uint64_t sixdof_component_id(const char* name);
+/* Duration::from_secs_f64(1/rate).as_secs_f64(): world_builder.rs:221, world.rs:185-191 */
+double sixdof_quantize_time_step(double simulation_rate_hz);
+int sixdof_device_count(void);
+
+int sixdof_create(const sixdof_desc* desc, sixdof_handle** out);
+void sixdof_destroy(sixdof_handle* h);
+const char* sixdof_last_error(const sixdof_handle* h); /* h may be NULL: last create error */
+
+int sixdof_bind_columns(sixdof_handle* h, const sixdof_column* cols, size_t n_cols);
+int sixdof_set_effectors(sixdof_handle* h, const sixdof_effector_op* ops, size_t n_ops);
+/* Edges as (from entity id, to entity id) in spawn order; resolved to row indices against the
+ * bound Body entity ids (query.rs:599-621 gathers by constant u32 indices). */
+int sixdof_set_edges(sixdof_handle* h, const uint64_t* from_ids, const uint64_t* to_ids, size_t n_edges);
+/* Read back the resolved u32 row-index tables (bit-exact integer parity surface). */
+int sixdof_get_edge_rows(const sixdof_handle* h, uint32_t* src_rows, uint32_t* dst_rows, size_t cap, size_t* n_out);
+
+int sixdof_upload(sixdof_handle* h);
+int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* timings /* may be NULL */);
+int sixdof_download(sixdof_handle* h, uint32_t column_mask);
+int sixdof_get_tick(const sixdof_handle* h, uint64_t* tick);
+int sixdof_set_tick(sixdof_handle* h, uint64_t tick);
+int sixdof_set_ticks_per_launch(sixdof_handle* h, uint32_t k);
+/* Device-resident column (reference byte layout) for zero-copy consumers; NULL if unknown. */
+void* sixdof_device_column(sixdof_handle* h, uint64_t component_id);
+/* hipStream_t the handle launches on, as an opaque pointer */
+void* sixdof_stream(sixdof_handle* h);
+
+/* TickFn-compatible entry (cranelift_exec.rs:11): upload -> 1 tick -> download through the
+ * slot tables below.  sixdof_tick_bind selects the handle for the calling thread. */
+int sixdof_tick_bind(sixdof_handle* h);
+void sixdof_tick(const uint8_t* const* inputs, uint8_t* const* outputs);
+/* inputs: order of first use; outputs: ascending ComponentId (system.rs:139-153). */
+int sixdof_tick_slots(const sixdof_handle* h, sixdof_slot* inputs, size_t in_cap, size_t* n_in,
+                      sixdof_slot* outputs, size_t out_cap, size_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIXDOF_HIP_H */
