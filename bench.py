@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — entity-steps/s of the MI355X six_dof path (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one RK4 tick of the hot path over one rank's batch of 65,536 synthetic bodies
+(BASELINE configs[1]: constant gravity + body torque, f64).  Inputs are resident in HBM when the
+timed region starts.  Weak scaling: every rank owns its own 65,536-row shard of one larger world
+(rows [rank*65536, (rank+1)*65536)); the path has no per-step exchange, so the data path uses no
+collective — torch.distributed is only the launcher's barrier and the max-over-ranks of the time.
+
+Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel, ticks_per_launch = 1,
+algorithmic bytes 360 B/entity-step against the 8 TB/s HBM peak), `roofline_hbm` (same kernel at
+4,194,304 bodies, where the working set leaves the 256 MiB Infinity Cache and the kernel really
+streams from HBM), `fused` (ticks_per_launch = 64: state in registers, VALU-bound) and
+`cpu_baseline` (the CPU oracle on the host cores, bounded sample, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+ENTITIES = 65536
+BYTES_PER_ENTITY_STEP_F64 = 360  # read pos 56 + vel 48 + inertia 56, write pos 56 + vel 48 + accel 48 + force 48
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def make_exec(n, first_row, device, ticks_per_launch, use_graph):
+    import elodin_amd as ea
+    from elodin_amd import workloads
+    w = workloads.independent_bodies(n, first_row=first_row)
+    eff = workloads.gravity_torque_effectors(w["body_torque"])
+    return ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], entity_ids=w["entity_ids"],
+                      simulation_time_step=workloads.DT_120HZ, effectors=eff, device=device,
+                      ticks_per_launch=ticks_per_launch, use_graph=use_graph), w, eff
+
+
+def kernel_roofline(ex, n, steps, warmup):
+    """Average duration of ONE launch of the step kernel (ticks_per_launch = 1), each launch bracketed by
+    its own HIP event pair on the handle's stream, -> algorithmic GB/s against the HBM peak."""
+    from elodin_amd import _lib as L
+    ex.set_ticks_per_launch(1)
+    ex.set_flags(L.FLAG_TIME_EACH_LAUNCH)
+    ex.invoke_batch(min(warmup, 64))
+    steps = min(steps, 4096)
+    t = ex.invoke_batch(steps)
+    ex.set_flags(0)
+    avg_ms = t.kernel_sum_ms / max(1, t.launches)
+    bytes_per_launch = BYTES_PER_ENTITY_STEP_F64 * n
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "kernel": "sixdof_step_kernel<double, rk4>", "avg_launch_us": round(avg_ms * 1e3, 3),
+            "algorithmic_bytes_per_launch": bytes_per_launch, "entities": n, "ticks_per_launch": 1,
+            "launches_timed": int(t.launches)}
+
+
+def cpu_baseline(w, eff, target_seconds=10.0):
+    """The CPU oracle (a port of the reference arithmetic; the reference itself needs rustc + jax) timed
+    on this host's cores on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    cores = len(os.sched_getaffinity(0))
+    ops = [(e.kind, tuple(e.p), e.aux) for e in eff]
+
+    def run(ticks, threads):
+        o = orc.OracleWorld(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=0.008333333, ops=ops)
+        t0 = time.perf_counter()
+        o.step(ticks, threads=threads)
+        return time.perf_counter() - t0
+
+    n = w["world_pos"].shape[0]
+    probe = run(4, cores)
+    ticks = int(min(4096, max(8, target_seconds * 0.7 / (probe / 4))))
+    dt = run(ticks, cores)
+    st_ticks = max(2, int(min(64, 3.0 / max(1e-9, (run(1, 1))))))
+    st = run(st_ticks, 1)
+    return {"value": round(n * ticks / dt, 1), "unit": "entity-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} bodies x {ticks} RK4 ticks, oracle/sixdof_oracle.c -O2 -ffp-contract=off, "
+                      f"OpenMP over entity blocks on {cores} threads",
+            "single_thread_value": round(n * st_ticks / st, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4096)
+    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--entities", type=int, default=ENTITIES, help="bodies per GPU")
+    ap.add_argument("--ticks-per-launch", type=int, default=1)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline_hbm / fused legs")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the six_dof product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n = args.entities
+    K = max(1, args.ticks_per_launch)
+    ex, w, eff = make_exec(n, rank * n, local_rank, K, not args.no_graph)
+
+    # ---- timed region: W warmup steps, then exactly `steps` steps between barriers --------------------
+    ex.invoke_batch(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    tm = ex.invoke_batch(args.steps)      # enqueues every launch and synchronises the handle's stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    value = n * world * args.steps / elapsed
+    out = {
+        "metric": "entity-steps/s (6DOF RK4)", "value": round(value, 1), "unit": "entity-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "65536 independent 6DOF bodies (constant gravity + body torque), RK4 f64 "
+                               "(BASELINE configs[1])" if n == ENTITIES else f"{n} independent 6DOF bodies",
+                   "entities_per_gpu": n, "ticks_per_launch": K, "dt": 0.008333333,
+                   "graph_replay": not args.no_graph, "parallelism": f"entity shards x{world}, no collective"},
+        "device_ms_per_step": round(tm.kernel_device_ms / args.steps, 6),
+    }
+
+    if rank == 0:
+        out["roofline"] = kernel_roofline(ex, n, args.steps, args.warmup)
+        if not args.no_extras:
+            # fused batch: the reference's ticks_per_telemetry semantics, state held in VGPRs
+            ex.set_ticks_per_launch(64)
+            ex.invoke_batch(64 * 4)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ft = ex.invoke_batch(64 * 64)
+            fe = time.perf_counter() - t1
+            out["fused"] = {"ticks_per_launch": 64, "value": round(n * 64 * 64 / fe, 1), "unit": "entity-steps/s",
+                            "device_ms_per_tick": round(ft.kernel_device_ms / (64 * 64), 6)}
+    ex.close()
+
+    if rank == 0 and not args.no_extras:
+        big = 1 << 22
+        bex, _, _ = make_exec(big, 0, local_rank, 1, False)
+        r = kernel_roofline(bex, big, 64, 8)
+        bex.close()
+        out["roofline_hbm"] = r
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w, eff)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

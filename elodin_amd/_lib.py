@@ -1,0 +1,119 @@
+"""ctypes binding of the C ABI in include/sixdof_hip.h (elodin_amd/libsixdof_hip.so).
+
+This is the same stub a reference maintainer would write in Rust with `extern "C"` (see
+INTEGRATION.md).  There is no fallback: if the HIP library is missing or no GPU is present the
+product path raises — it never routes through the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "libsixdof_hip.so"
+
+OK = 0
+ERR_INVALID_ARGUMENT, ERR_COMPONENT_NOT_FOUND, ERR_VALUE_SIZE_MISMATCH = -1, -2, -3
+ERR_BACKEND, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ENTITY_MISMATCH = -4, -5, -6, -7
+
+RK4, SEMI_IMPLICIT = 0, 1
+F64, F32 = 0, 1
+PRIM_F64, PRIM_U64, PRIM_F32 = 0, 1, 2
+FLAG_USE_GRAPH = 1
+FLAG_TIME_EACH_LAUNCH = 2
+
+EFF_CONST_WRENCH = 1
+EFF_UNIFORM_GRAVITY = 2
+EFF_BODY_TORQUE = 3
+EFF_BODY_FORCE = 4
+EFF_BALL_DRAG = 5
+EFF_EDGE_GRAVITY_NEWTON = 6
+EFF_EDGE_GRAVITY_SOFTENED = 7
+EFF_ALLPAIRS_GRAVITY_SOFTENED = 8
+
+COL_WORLD_POS, COL_WORLD_VEL, COL_WORLD_ACCEL, COL_FORCE, COL_INERTIA, COL_ALL = 1, 2, 4, 8, 16, 31
+
+
+class EffectorOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("aux_component_id", C.c_uint64),
+                ("p", C.c_double * 6)]
+
+
+class Desc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device_ordinal", C.c_int32), ("integrator", C.c_int32),
+                ("dtype", C.c_int32), ("n_entities", C.c_uint64), ("simulation_time_step", C.c_double),
+                ("time_step", C.c_double), ("has_time_step", C.c_int32), ("ticks_per_launch", C.c_uint32),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Column(C.Structure):
+    _fields_ = [("component_id", C.c_uint64), ("prim_type", C.c_int32), ("ndim", C.c_uint32),
+                ("dims", C.c_uint64 * 2), ("n_rows", C.c_uint64), ("entity_ids", C.POINTER(C.c_uint64)),
+                ("host_ptr", C.c_void_p)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("h2d_upload_ms", C.c_double), ("kernel_invoke_ms", C.c_double), ("d2h_download_ms", C.c_double),
+                ("kernel_device_ms", C.c_double), ("launches", C.c_uint64), ("ticks", C.c_uint64),
+                ("kernel_sum_ms", C.c_double)]
+
+
+class Slot(C.Structure):
+    _fields_ = [("component_id", C.c_uint64), ("bytes", C.c_uint64)]
+
+
+# every symbol include/sixdof_hip.h declares: name -> (restype, argtypes)
+_H = C.c_void_p
+SYMBOLS = {
+    "sixdof_abi_version": (C.c_uint32, []),
+    "sixdof_component_id": (C.c_uint64, [C.c_char_p]),
+    "sixdof_quantize_time_step": (C.c_double, [C.c_double]),
+    "sixdof_device_count": (C.c_int, []),
+    "sixdof_create": (C.c_int, [C.POINTER(Desc), C.POINTER(_H)]),
+    "sixdof_destroy": (None, [_H]),
+    "sixdof_last_error": (C.c_char_p, [_H]),
+    "sixdof_bind_columns": (C.c_int, [_H, C.POINTER(Column), C.c_size_t]),
+    "sixdof_set_effectors": (C.c_int, [_H, C.POINTER(EffectorOp), C.c_size_t]),
+    "sixdof_set_edges": (C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t]),
+    "sixdof_get_edge_rows": (C.c_int, [_H, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t,
+                                       C.POINTER(C.c_size_t)]),
+    "sixdof_upload": (C.c_int, [_H]),
+    "sixdof_step": (C.c_int, [_H, C.c_uint64, C.POINTER(Timings)]),
+    "sixdof_download": (C.c_int, [_H, C.c_uint32]),
+    "sixdof_get_tick": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
+    "sixdof_set_tick": (C.c_int, [_H, C.c_uint64]),
+    "sixdof_set_ticks_per_launch": (C.c_int, [_H, C.c_uint32]),
+    "sixdof_set_flags": (C.c_int, [_H, C.c_uint32]),
+    "sixdof_device_column": (C.c_void_p, [_H, C.c_uint64]),
+    "sixdof_stream": (C.c_void_p, [_H]),
+    "sixdof_tick_bind": (C.c_int, [_H]),
+    "sixdof_tick": (None, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "sixdof_tick_slots": (C.c_int, [_H, C.POINTER(Slot), C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Slot),
+                                    C.c_size_t, C.POINTER(C.c_size_t)]),
+}
+
+_lib = None
+
+
+class BackendError(RuntimeError):
+    """HIP extension missing / no device / HIP runtime failure (Error::CraneliftBackend analogue)."""
+
+
+def lib() -> C.CDLL:
+    """Load libsixdof_hip.so; raise loudly if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise BackendError(f"{LIB_PATH} not built: run `make -C elodin_amd/csrc` "
+                               "(no CPU fallback exists for the product path)")
+        L = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError here = header/library skew
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def component_id(name: str) -> int:
+    return int(lib().sixdof_component_id(name.encode()))

@@ -1,0 +1,70 @@
+// kernels.hpp — launch interface between the C-ABI host layer (sixdof_capi.cpp) and the gfx950
+// kernels (sixdof_kernels.hip, nbody_kernels.hip).  Internal; not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sixdof {
+
+constexpr int kMaxOps = 4;       // per-entity effector ops fused into the step kernel
+constexpr int kBlock = 256;      // threads per workgroup = entities per workgroup (4 waves of 64)
+
+// One effector op as the kernel sees it (sixdof_effector_op with the aux column resolved).
+struct DevOp {
+    int32_t kind;
+    int32_t pad;
+    const void* aux;  // device [n,3] column (element type = state dtype) or nullptr
+    double p[6];
+};
+
+// Kernel argument block of the fused per-entity step.  Columns are device pointers in the
+// reference's row-major layout: pos [n,7], vel [n,6], accel [n,6], force [n,6], inertia [n,7].
+struct StepParams {
+    void* pos;
+    void* vel;
+    void* accel;
+    void* force;
+    const void* inertia;
+    uint32_t n;
+    uint32_t n_ticks;         // ticks fused into this launch
+    double dt_g;              // globals simulation_time_step (RK4 stage offsets)
+    double dt;                // six_dof(time_step=) override or dt_g (final combination / semi-implicit)
+    uint32_t n_ops;
+    uint32_t vel_independent; // 1: no op reads the stage velocity -> RK4 stages 1 and 2 share F and A
+    DevOp ops[kMaxOps];
+};
+
+enum : int { kRk4 = 0, kSemiImplicit = 1 };
+
+// Fused clear_forces | effectors | calc_accel | integrator over n entities, n_ticks ticks.
+// dtype: 0 = f64, 1 = f32.  Returns hipGetLastError() of the launch.
+hipError_t launch_step(const StepParams& p, int integrator, int dtype, hipStream_t stream);
+
+// ---- pairwise (edge_fold) path: one RK4/semi-implicit tick is a short kernel sequence -------------
+struct PairParams {
+    void* pos;            // [n,7]
+    void* vel;            // [n,6]
+    void* accel;          // [n,6]
+    void* force;          // [n,6]
+    const void* inertia;  // [n,7]
+    uint32_t n;
+    double dt_g, dt;
+    // per-stage scratch, device
+    void* xs;             // [n,7] stage transforms
+    void* vs;             // [n,6] stage velocities
+    void* sv;             // [n,6] running sum of stage velocities
+    void* sa;             // [n,6] running sum of stage accelerations
+    void* a_prev;         // [n,6] previous stage acceleration
+    void* pm;             // [n,4] packed (x,y,z,mass) of the stage positions for the pair kernels
+    // edge list in CSR-by-source form (spawn order preserved inside a source), device
+    const uint32_t* row_start;  // [n+1]
+    const uint32_t* dst;        // [n_edges]
+    uint32_t n_edges;
+    int32_t pair_kind;    // sixdof_effector_kind 6,7,8
+    double p0, p1;        // G | K, eps
+    uint32_t n_ops;       // per-entity ops applied BEFORE the pair op (pipe order)
+    DevOp ops[kMaxOps];
+};
+hipError_t launch_pair_tick(const PairParams& p, int integrator, hipStream_t stream, uint64_t* launches);
+
+}  // namespace sixdof

@@ -1,0 +1,658 @@
+// sixdof_capi.cpp — host side of the C ABI declared in include/sixdof_hip.h.
+//
+// Mirrors the reference's backend object (CraneliftExec / JaxExec,
+// libs/nox-py/src/cranelift_exec.rs:13-195, jax_exec.rs:118-185): it owns the slot tables and
+// the device-resident copies of the ECS columns, runs batches of ticks, and copies columns
+// back on request.  Differences that are the point of this backend: columns stay resident in
+// HBM between batches (the JAX backend re-uploads every input and downloads every output per
+// batch), and a batch is one or a few kernel launches instead of a per-tick host loop.
+//
+// No CPU fallback exists: every entry point that needs the GPU fails with SIXDOF_ERR_NO_DEVICE /
+// SIXDOF_ERR_BACKEND when HIP is unavailable.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/sixdof_hip.h"
+#include "kernels.hpp"
+
+using namespace sixdof;
+
+namespace {
+
+struct Column {
+    uint64_t id = 0;
+    int prim = SIXDOF_PRIM_F64;
+    uint64_t width = 1;  // elements per row
+    uint64_t n_rows = 0;
+    size_t elem = 8;
+    size_t bytes = 0;
+    std::vector<uint64_t> ids;
+    void* host = nullptr;  // borrowed
+    void* dev = nullptr;   // owned
+};
+
+thread_local std::string g_create_error;
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+uint64_t cid(const char* s) { return sixdof_component_id(s); }
+
+}  // namespace
+
+struct sixdof_handle {
+    sixdof_desc desc{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> launch_events;  // SIXDOF_FLAG_TIME_EACH_LAUNCH: 2 per launch
+    std::map<uint64_t, Column> cols;  // ascending ComponentId = reference BTreeMap order
+    std::vector<sixdof_effector_op> ops;
+    // edges
+    std::vector<uint32_t> edge_src, edge_dst;       // resolved rows, spawn order
+    std::vector<uint32_t> csr_start, csr_dst;       // by source, spawn order kept inside a source
+    uint32_t* d_csr_start = nullptr;
+    uint32_t* d_csr_dst = nullptr;
+    // pair-path scratch
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    uint64_t tick = 0;
+    bool bound = false;
+    // graph cache for long batches
+    hipGraphExec_t graph_exec = nullptr;
+    uint32_t graph_k = 0, graph_len = 0;
+    uint64_t graph_sig = 0;
+    mutable std::string err;
+
+    uint64_t id_pos, id_vel, id_accel, id_force, id_inertia, id_tick, id_dt;
+
+    int fail(int code, const std::string& msg) const {
+        err = msg;
+        return code;
+    }
+    int hip_fail(hipError_t e, const char* what) const {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return SIXDOF_ERR_BACKEND;
+    }
+    Column* col(uint64_t id) {
+        auto it = cols.find(id);
+        return it == cols.end() ? nullptr : &it->second;
+    }
+    const Column* col(uint64_t id) const {
+        auto it = cols.find(id);
+        return it == cols.end() ? nullptr : &it->second;
+    }
+    size_t elem_size() const { return desc.dtype == SIXDOF_F32 ? 4 : 8; }
+    int state_prim() const { return desc.dtype == SIXDOF_F32 ? SIXDOF_PRIM_F32 : SIXDOF_PRIM_F64; }
+    void drop_graph() {
+        if (graph_exec) {
+            hipGraphExecDestroy(graph_exec);
+            graph_exec = nullptr;
+        }
+    }
+    bool has_pair_op() const {
+        for (auto& o : ops)
+            if (o.kind >= SIXDOF_EFF_EDGE_GRAVITY_NEWTON) return true;
+        return false;
+    }
+};
+
+#define HIP_TRY(h, call)                                      \
+    do {                                                      \
+        hipError_t e_ = (call);                               \
+        if (e_ != hipSuccess) return (h)->hip_fail(e_, #call); \
+    } while (0)
+
+extern "C" {
+
+uint32_t sixdof_abi_version(void) { return SIXDOF_ABI_VERSION; }
+
+uint64_t sixdof_component_id(const char* name) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    if (name)
+        for (const unsigned char* p = reinterpret_cast<const unsigned char*>(name); *p; ++p) {
+            h ^= static_cast<uint64_t>(*p);
+            h *= 0x100000001b3ull;
+        }
+    return h & ~(1ull << 63);
+}
+
+double sixdof_quantize_time_step(double rate_hz) {
+    if (!(rate_hz > 0.0)) return std::nan("");
+    const long double ns = nearbyintl(static_cast<long double>(1.0 / rate_hz) * 1.0e9L);
+    const uint64_t total = static_cast<uint64_t>(ns);
+    return static_cast<double>(total / 1000000000ull) + static_cast<double>(total % 1000000000ull) / 1.0e9;
+}
+
+int sixdof_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* sixdof_last_error(const sixdof_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int sixdof_create(const sixdof_desc* d, sixdof_handle** out) {
+    if (!d || !out) {
+        g_create_error = "sixdof_create: null argument";
+        return SIXDOF_ERR_INVALID_ARGUMENT;
+    }
+    *out = nullptr;
+    if (d->struct_size != sizeof(sixdof_desc)) {
+        g_create_error = "sixdof_create: struct_size mismatch (ABI version skew)";
+        return SIXDOF_ERR_INVALID_ARGUMENT;
+    }
+    if (d->integrator != SIXDOF_INTEGRATOR_RK4 && d->integrator != SIXDOF_INTEGRATOR_SEMI_IMPLICIT) {
+        g_create_error = "sixdof_create: unknown integrator";
+        return SIXDOF_ERR_INVALID_ARGUMENT;
+    }
+    if (d->dtype != SIXDOF_F64 && d->dtype != SIXDOF_F32) {
+        g_create_error = "sixdof_create: unknown dtype";
+        return SIXDOF_ERR_INVALID_ARGUMENT;
+    }
+    if (d->n_entities > 0xFFFFFFF0ull) {
+        g_create_error = "sixdof_create: n_entities exceeds u32 row index range";
+        return SIXDOF_ERR_INVALID_ARGUMENT;
+    }
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev == 0) {
+        g_create_error = std::string("sixdof_create: no HIP device (") + hipGetErrorString(e) +
+                         "); this backend has no CPU fallback";
+        return SIXDOF_ERR_NO_DEVICE;
+    }
+    if (d->device_ordinal < 0 || d->device_ordinal >= n_dev) {
+        g_create_error = "sixdof_create: device_ordinal out of range";
+        return SIXDOF_ERR_INVALID_ARGUMENT;
+    }
+    auto* h = new sixdof_handle();
+    h->desc = *d;
+    if (h->desc.ticks_per_launch == 0) h->desc.ticks_per_launch = 1;
+    h->device = d->device_ordinal;
+    h->id_pos = cid("world_pos");
+    h->id_vel = cid("world_vel");
+    h->id_accel = cid("world_accel");
+    h->id_force = cid("force");
+    h->id_inertia = cid("inertia");
+    h->id_tick = cid("tick");
+    h->id_dt = cid("simulation_time_step");
+    if ((e = hipSetDevice(h->device)) != hipSuccess || (e = hipStreamCreate(&h->stream)) != hipSuccess ||
+        (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
+        g_create_error = std::string("sixdof_create: ") + hipGetErrorString(e);
+        delete h;
+        return SIXDOF_ERR_BACKEND;
+    }
+    *out = h;
+    return SIXDOF_OK;
+}
+
+void sixdof_destroy(sixdof_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    h->drop_graph();
+    for (auto& kv : h->cols)
+        if (kv.second.dev) hipFree(kv.second.dev);
+    if (h->d_csr_start) hipFree(h->d_csr_start);
+    if (h->d_csr_dst) hipFree(h->d_csr_dst);
+    if (h->d_scratch) hipFree(h->d_scratch);
+    for (hipEvent_t e : h->launch_events) hipEventDestroy(e);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int sixdof_bind_columns(sixdof_handle* h, const sixdof_column* cols, size_t n_cols) {
+    if (!h || (!cols && n_cols)) return SIXDOF_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->drop_graph();
+    for (size_t i = 0; i < n_cols; i++) {
+        const sixdof_column& c = cols[i];
+        if (c.ndim > 1) return h->fail(SIXDOF_ERR_UNSUPPORTED, "bind_columns: only scalar / 1-D components");
+        if (!c.host_ptr && c.n_rows) return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "bind_columns: null host_ptr");
+        Column col;
+        col.id = c.component_id;
+        col.prim = c.prim_type;
+        col.width = c.ndim == 0 ? 1 : c.dims[0];
+        col.n_rows = c.n_rows;
+        col.elem = c.prim_type == SIXDOF_PRIM_F32 ? 4 : 8;
+        col.bytes = static_cast<size_t>(col.width * col.n_rows) * col.elem;
+        col.host = c.host_ptr;
+        if (c.entity_ids) col.ids.assign(c.entity_ids, c.entity_ids + c.n_rows);
+        Column* old = h->col(c.component_id);
+        if (old && old->dev) {
+            if (old->bytes == col.bytes) col.dev = old->dev;
+            else hipFree(old->dev);
+        }
+        if (!col.dev && col.bytes) HIP_TRY(h, hipMalloc(&col.dev, col.bytes));
+        h->cols[c.component_id] = std::move(col);
+    }
+    // validate the Body archetype (six_dof.rs:152-159): five columns, one entity-id vector
+    const struct { uint64_t id; uint64_t width; const char* name; } body[5] = {
+        {h->id_pos, 7, "world_pos"}, {h->id_vel, 6, "world_vel"}, {h->id_accel, 6, "world_accel"},
+        {h->id_force, 6, "force"},   {h->id_inertia, 7, "inertia"}};
+    const Column* first = nullptr;
+    for (auto& b : body) {
+        const Column* c = h->col(b.id);
+        if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, std::string("bind_columns: missing Body column ") + b.name);
+        if (c->prim != h->state_prim())
+            return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, std::string("bind_columns: dtype mismatch on ") + b.name);
+        if (c->width != b.width || c->n_rows != h->desc.n_entities)
+            return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, std::string("bind_columns: shape mismatch on ") + b.name);
+        if (!first) first = c;
+        else if (c->ids != first->ids)
+            // reference joins iterate the id intersection (query.rs:136-208); this backend implements
+            // the fast path all examples use: every Body column shares one id vector (query.rs:673,702)
+            return h->fail(SIXDOF_ERR_ENTITY_MISMATCH, std::string("bind_columns: entity ids differ on ") + b.name);
+    }
+    h->bound = true;
+    return SIXDOF_OK;
+}
+
+int sixdof_set_effectors(sixdof_handle* h, const sixdof_effector_op* ops, size_t n_ops) {
+    if (!h || (!ops && n_ops)) return SIXDOF_ERR_INVALID_ARGUMENT;
+    size_t n_entity_ops = 0, n_pair = 0;
+    for (size_t i = 0; i < n_ops; i++) {
+        const int k = ops[i].kind;
+        if (k < SIXDOF_EFF_CONST_WRENCH || k > SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED)
+            return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "set_effectors: unknown effector kind");
+        if (k >= SIXDOF_EFF_EDGE_GRAVITY_NEWTON) {
+            n_pair++;
+            if (i + 1 != n_ops)
+                return h->fail(SIXDOF_ERR_UNSUPPORTED, "set_effectors: a pair (edge_fold) op must be last in the pipe");
+        } else {
+            n_entity_ops++;
+        }
+    }
+    if (n_entity_ops > static_cast<size_t>(kMaxOps))
+        return h->fail(SIXDOF_ERR_UNSUPPORTED, "set_effectors: at most 4 per-entity ops");
+    if (n_pair > 1) return h->fail(SIXDOF_ERR_UNSUPPORTED, "set_effectors: at most one pair op");
+    h->ops.assign(ops, ops + n_ops);
+    h->drop_graph();
+    return SIXDOF_OK;
+}
+
+int sixdof_set_edges(sixdof_handle* h, const uint64_t* from_ids, const uint64_t* to_ids, size_t n_edges) {
+    if (!h || ((!from_ids || !to_ids) && n_edges)) return SIXDOF_ERR_INVALID_ARGUMENT;
+    if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "set_edges: bind Body columns first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const Column* pos = h->col(h->id_pos);
+    std::unordered_map<uint64_t, uint32_t> row_of;
+    row_of.reserve(pos->ids.size() * 2);
+    for (size_t r = 0; r < pos->ids.size(); r++) row_of.emplace(pos->ids[r], static_cast<uint32_t>(r));
+    std::vector<uint32_t> src(n_edges), dst(n_edges);
+    for (size_t e = 0; e < n_edges; e++) {
+        auto a = row_of.find(from_ids[e]), b = row_of.find(to_ids[e]);
+        if (a == row_of.end() || b == row_of.end())
+            return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "set_edges: edge endpoint is not a Body entity");
+        src[e] = a->second;
+        dst[e] = b->second;
+    }
+    const uint32_t n = static_cast<uint32_t>(h->desc.n_entities);
+    // CSR by source; a stable counting sort keeps each source's out-edges in spawn order, which is
+    // the fold order of GraphQuery::edge_fold (graph.rs:113-175,239-361)
+    std::vector<uint32_t> start(n + 1, 0), cdst(n_edges);
+    for (size_t e = 0; e < n_edges; e++) start[src[e] + 1]++;
+    for (uint32_t i = 0; i < n; i++) start[i + 1] += start[i];
+    std::vector<uint32_t> cursor(start.begin(), start.end() - 1);
+    for (size_t e = 0; e < n_edges; e++) cdst[cursor[src[e]]++] = dst[e];
+    if (h->d_csr_start) hipFree(h->d_csr_start), h->d_csr_start = nullptr;
+    if (h->d_csr_dst) hipFree(h->d_csr_dst), h->d_csr_dst = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_csr_start), (n + 1) * sizeof(uint32_t)));
+    HIP_TRY(h, hipMemcpy(h->d_csr_start, start.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (n_edges) {
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_csr_dst), n_edges * sizeof(uint32_t)));
+        HIP_TRY(h, hipMemcpy(h->d_csr_dst, cdst.data(), n_edges * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    h->edge_src.swap(src);
+    h->edge_dst.swap(dst);
+    h->csr_start.swap(start);
+    h->csr_dst.swap(cdst);
+    return SIXDOF_OK;
+}
+
+int sixdof_get_edge_rows(const sixdof_handle* h, uint32_t* src_rows, uint32_t* dst_rows, size_t cap, size_t* n_out) {
+    if (!h || !n_out) return SIXDOF_ERR_INVALID_ARGUMENT;
+    *n_out = h->edge_src.size();
+    if (cap < h->edge_src.size()) return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, "get_edge_rows: buffer too small");
+    if (src_rows) std::memcpy(src_rows, h->edge_src.data(), h->edge_src.size() * sizeof(uint32_t));
+    if (dst_rows) std::memcpy(dst_rows, h->edge_dst.data(), h->edge_dst.size() * sizeof(uint32_t));
+    return SIXDOF_OK;
+}
+
+int sixdof_upload(sixdof_handle* h) {
+    if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
+    if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "upload: no columns bound");
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (auto& kv : h->cols) {
+        Column& c = kv.second;
+        if (c.bytes) HIP_TRY(h, hipMemcpyAsync(c.dev, c.host, c.bytes, hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SIXDOF_OK;
+}
+
+int sixdof_download(sixdof_handle* h, uint32_t mask) {
+    if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
+    if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "download: no columns bound");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const struct { uint32_t bit; uint64_t id; } sel[5] = {{SIXDOF_COL_WORLD_POS, h->id_pos},
+                                                        {SIXDOF_COL_WORLD_VEL, h->id_vel},
+                                                        {SIXDOF_COL_WORLD_ACCEL, h->id_accel},
+                                                        {SIXDOF_COL_FORCE, h->id_force},
+                                                        {SIXDOF_COL_INERTIA, h->id_inertia}};
+    for (auto& s : sel) {
+        if (!(mask & s.bit)) continue;
+        Column* c = h->col(s.id);
+        if (c && c->bytes) HIP_TRY(h, hipMemcpyAsync(c->host, c->dev, c->bytes, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SIXDOF_OK;
+}
+
+int sixdof_get_tick(const sixdof_handle* h, uint64_t* tick) {
+    if (!h || !tick) return SIXDOF_ERR_INVALID_ARGUMENT;
+    *tick = h->tick;
+    return SIXDOF_OK;
+}
+int sixdof_set_tick(sixdof_handle* h, uint64_t tick) {
+    if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
+    h->tick = tick;
+    return SIXDOF_OK;
+}
+int sixdof_set_ticks_per_launch(sixdof_handle* h, uint32_t k) {
+    if (!h || k == 0) return SIXDOF_ERR_INVALID_ARGUMENT;
+    h->desc.ticks_per_launch = k;
+    h->drop_graph();
+    return SIXDOF_OK;
+}
+
+int sixdof_set_flags(sixdof_handle* h, uint32_t flags) {
+    if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
+    h->desc.flags = flags;
+    return SIXDOF_OK;
+}
+
+void* sixdof_device_column(sixdof_handle* h, uint64_t component_id) {
+    if (!h) return nullptr;
+    Column* c = h->col(component_id);
+    return c ? c->dev : nullptr;
+}
+void* sixdof_stream(sixdof_handle* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
+
+}  // extern "C"
+
+// ---- step --------------------------------------------------------------------------------------------------
+
+namespace {
+
+int build_dev_ops(sixdof_handle* h, DevOp* out, uint32_t* n_out, uint32_t* vel_independent) {
+    uint32_t n = 0;
+    *vel_independent = 1;
+    for (auto& o : h->ops) {
+        if (o.kind >= SIXDOF_EFF_EDGE_GRAVITY_NEWTON) continue;
+        DevOp d{};
+        d.kind = o.kind;
+        std::memcpy(d.p, o.p, sizeof(d.p));
+        if (o.kind == SIXDOF_EFF_BODY_TORQUE || o.kind == SIXDOF_EFF_BODY_FORCE || o.kind == SIXDOF_EFF_BALL_DRAG) {
+            const Column* c = h->col(o.aux_component_id);
+            if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "step: effector aux column not bound");
+            if (c->width != 3 || c->n_rows != h->desc.n_entities || c->prim != h->state_prim())
+                return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, "step: effector aux column must be [n,3] of the state dtype");
+            if (c->ids != h->col(h->id_pos)->ids)
+                return h->fail(SIXDOF_ERR_ENTITY_MISMATCH, "step: effector aux column entity ids differ from Body");
+            d.aux = c->dev;
+        }
+        if (o.kind == SIXDOF_EFF_BALL_DRAG) *vel_independent = 0;
+        out[n++] = d;
+    }
+    *n_out = n;
+    return SIXDOF_OK;
+}
+
+int fill_step_params(sixdof_handle* h, StepParams* P) {
+    std::memset(P, 0, sizeof(*P));
+    P->pos = h->col(h->id_pos)->dev;
+    P->vel = h->col(h->id_vel)->dev;
+    P->accel = h->col(h->id_accel)->dev;
+    P->force = h->col(h->id_force)->dev;
+    P->inertia = h->col(h->id_inertia)->dev;
+    P->n = static_cast<uint32_t>(h->desc.n_entities);
+    P->dt_g = h->desc.simulation_time_step;
+    P->dt = h->desc.has_time_step ? h->desc.time_step : h->desc.simulation_time_step;
+    return build_dev_ops(h, P->ops, &P->n_ops, &P->vel_independent);
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int fill_pair_params(sixdof_handle* h, PairParams* P) {
+    std::memset(P, 0, sizeof(*P));
+    const size_t n = h->desc.n_entities;
+    const size_t es = h->elem_size();
+    // scratch layout: xs[n,7] vs[n,6] sv[n,6] sa[n,6] a_prev[n,6] pm[n,4]
+    const size_t sz[6] = {7 * n * es, 6 * n * es, 6 * n * es, 6 * n * es, 6 * n * es, 4 * n * es};
+    size_t total = 0;
+    for (size_t s : sz) total += align_up(s, 256);
+    if (total > h->scratch_bytes) {
+        if (h->d_scratch) hipFree(h->d_scratch), h->d_scratch = nullptr;
+        HIP_TRY(h, hipMalloc(&h->d_scratch, total ? total : 256));
+        h->scratch_bytes = total;
+    }
+    char* base = static_cast<char*>(h->d_scratch);
+    void* ptrs[6];
+    for (int i = 0; i < 6; i++) {
+        ptrs[i] = base;
+        base += align_up(sz[i], 256);
+    }
+    P->pos = h->col(h->id_pos)->dev;
+    P->vel = h->col(h->id_vel)->dev;
+    P->accel = h->col(h->id_accel)->dev;
+    P->force = h->col(h->id_force)->dev;
+    P->inertia = h->col(h->id_inertia)->dev;
+    P->n = static_cast<uint32_t>(n);
+    P->dt_g = h->desc.simulation_time_step;
+    P->dt = h->desc.has_time_step ? h->desc.time_step : h->desc.simulation_time_step;
+    P->xs = ptrs[0]; P->vs = ptrs[1]; P->sv = ptrs[2]; P->sa = ptrs[3]; P->a_prev = ptrs[4]; P->pm = ptrs[5];
+    const sixdof_effector_op& pop = h->ops.back();
+    P->pair_kind = pop.kind;
+    P->p0 = pop.p[0];
+    P->p1 = pop.p[1];
+    if (pop.kind != SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED) {
+        if (!h->d_csr_start) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "step: edge effector without sixdof_set_edges");
+        P->row_start = h->d_csr_start;
+        P->dst = h->d_csr_dst;
+        P->n_edges = static_cast<uint32_t>(h->edge_src.size());
+    }
+    uint32_t vi = 0;
+    return build_dev_ops(h, P->ops, &P->n_ops, &vi);
+}
+
+}  // namespace
+
+extern "C" {
+
+int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
+    if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
+    if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "step: no columns bound");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const double t0 = now_ms();
+    uint64_t launches = 0;
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    if (h->has_pair_op()) {
+        if (h->desc.dtype != SIXDOF_F64) return h->fail(SIXDOF_ERR_UNSUPPORTED, "step: pair effectors are f64 only");
+        PairParams P;
+        int rc = fill_pair_params(h, &P);
+        if (rc != SIXDOF_OK) return rc;
+        for (uint64_t t = 0; t < n_ticks; t++) {
+            hipError_t e = launch_pair_tick(P, h->desc.integrator, h->stream, &launches);
+            if (e != hipSuccess) return h->hip_fail(e, "launch_pair_tick");
+        }
+    } else {
+        StepParams P;
+        int rc = fill_step_params(h, &P);
+        if (rc != SIXDOF_OK) return rc;
+        const uint32_t K = h->desc.ticks_per_launch;
+        uint64_t full = n_ticks / K;
+        const uint32_t rem = static_cast<uint32_t>(n_ticks % K);
+        P.n_ticks = K;
+        // Long batches of identical launches replay from a hipGraph (launch-bound regime:
+        // a 65,536-entity tick is a few microseconds of device time).
+        constexpr uint32_t kGraphLen = 32;
+        const bool time_each = (h->desc.flags & SIXDOF_FLAG_TIME_EACH_LAUNCH) != 0;
+        if (time_each) {
+            const uint64_t need = 2 * (full + (rem ? 1 : 0));
+            if (need > 8192) return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "step: TIME_EACH_LAUNCH supports <= 4096 launches per call");
+            while (h->launch_events.size() < need) {
+                hipEvent_t e = nullptr;
+                HIP_TRY(h, hipEventCreate(&e));
+                h->launch_events.push_back(e);
+            }
+        }
+        if (!time_each && (h->desc.flags & SIXDOF_FLAG_USE_GRAPH) && full >= kGraphLen) {
+            const uint64_t sig = (static_cast<uint64_t>(K) << 32) ^ h->ops.size() ^ (h->desc.n_entities << 8);
+            if (!h->graph_exec || h->graph_k != K || h->graph_sig != sig) {
+                h->drop_graph();
+                hipGraph_t g = nullptr;
+                HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+                hipError_t le = hipSuccess;
+                for (uint32_t i = 0; i < kGraphLen && le == hipSuccess; i++)
+                    le = launch_step(P, h->desc.integrator, h->desc.dtype, h->stream);
+                hipError_t ce = hipStreamEndCapture(h->stream, &g);
+                if (le != hipSuccess) return h->hip_fail(le, "launch_step (capture)");
+                if (ce != hipSuccess) return h->hip_fail(ce, "hipStreamEndCapture");
+                hipError_t ie = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+                hipGraphDestroy(g);
+                if (ie != hipSuccess) return h->hip_fail(ie, "hipGraphInstantiate");
+                h->graph_k = K;
+                h->graph_len = kGraphLen;
+                h->graph_sig = sig;
+                // the capture recorded ev0 before it; re-record so the event pair brackets real work
+                HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+            }
+            while (full >= kGraphLen) {
+                HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
+                full -= kGraphLen;
+                launches += kGraphLen;
+            }
+        }
+        for (uint64_t i = 0; i < full; i++) {
+            if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches], h->stream));
+            hipError_t e = launch_step(P, h->desc.integrator, h->desc.dtype, h->stream);
+            if (e != hipSuccess) return h->hip_fail(e, "launch_step");
+            if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches + 1], h->stream));
+            launches++;
+        }
+        if (rem) {
+            P.n_ticks = rem;
+            if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches], h->stream));
+            hipError_t e = launch_step(P, h->desc.integrator, h->desc.dtype, h->stream);
+            if (e != hipSuccess) return h->hip_fail(e, "launch_step");
+            if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches + 1], h->stream));
+            launches++;
+        }
+    }
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->tick += n_ticks;  // increment_sim_tick (globals.rs:42-44), once per tick
+    if (tm) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, h->ev0, h->ev1);
+        tm->h2d_upload_ms = 0.0;
+        tm->d2h_download_ms = 0.0;
+        tm->kernel_device_ms = ms;
+        tm->kernel_invoke_ms = now_ms() - t0;
+        tm->launches = launches;
+        tm->ticks = n_ticks;
+        tm->kernel_sum_ms = 0.0;
+        if ((h->desc.flags & SIXDOF_FLAG_TIME_EACH_LAUNCH) && !h->has_pair_op()) {
+            double sum = 0.0;
+            for (uint64_t i = 0; i < launches && 2 * i + 1 < h->launch_events.size(); i++) {
+                float one = 0.f;
+                if (hipEventElapsedTime(&one, h->launch_events[2 * i], h->launch_events[2 * i + 1]) == hipSuccess) sum += one;
+            }
+            tm->kernel_sum_ms = sum;
+        }
+    }
+    return SIXDOF_OK;
+}
+
+// ---- TickFn-compatible shim (cranelift_exec.rs:11,129-195) -----------------------------------------------------
+
+static thread_local sixdof_handle* g_tick_handle = nullptr;
+
+int sixdof_tick_bind(sixdof_handle* h) {
+    g_tick_handle = h;
+    return SIXDOF_OK;
+}
+
+static void tick_slot_ids(const sixdof_handle* h, std::vector<uint64_t>* in, std::vector<uint64_t>* out) {
+    // inputs: first-use order of `increment_sim_tick | six_dof(sys)` (system.rs:172-200); then effector columns
+    *in = {h->id_tick, h->id_force, h->id_inertia, h->id_pos, h->id_dt, h->id_vel, h->id_accel};
+    for (auto& o : h->ops)
+        if (o.aux_component_id) in->push_back(o.aux_component_id);
+    // outputs: every variable of the builder in ascending ComponentId (BTreeMap, system.rs:139-153)
+    std::map<uint64_t, int> ordered;
+    for (uint64_t id : *in) ordered[id] = 1;
+    out->clear();
+    for (auto& kv : ordered) out->push_back(kv.first);
+}
+
+static uint64_t slot_bytes(const sixdof_handle* h, uint64_t id) {
+    if (id == h->id_tick || id == h->id_dt) return 8;
+    const Column* c = h->col(id);
+    return c ? c->bytes : 0;
+}
+
+int sixdof_tick_slots(const sixdof_handle* h, sixdof_slot* inputs, size_t in_cap, size_t* n_in, sixdof_slot* outputs,
+                      size_t out_cap, size_t* n_out) {
+    if (!h || !n_in || !n_out) return SIXDOF_ERR_INVALID_ARGUMENT;
+    std::vector<uint64_t> in, out;
+    tick_slot_ids(h, &in, &out);
+    *n_in = in.size();
+    *n_out = out.size();
+    if (in_cap < in.size() || out_cap < out.size())
+        return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, "tick_slots: buffer too small");
+    for (size_t i = 0; inputs && i < in.size(); i++) inputs[i] = {in[i], slot_bytes(h, in[i])};
+    for (size_t i = 0; outputs && i < out.size(); i++) outputs[i] = {out[i], slot_bytes(h, out[i])};
+    return SIXDOF_OK;
+}
+
+void sixdof_tick(const uint8_t* const* inputs, uint8_t* const* outputs) {
+    sixdof_handle* h = g_tick_handle;
+    if (!h || !h->bound || !inputs || !outputs) return;  // TickFn cannot fail (cranelift_exec.rs:163-165)
+    if (hipSetDevice(h->device) != hipSuccess) return;
+    std::vector<uint64_t> in, out;
+    tick_slot_ids(h, &in, &out);
+    uint64_t tick = 0;
+    for (size_t i = 0; i < in.size(); i++) {
+        if (in[i] == h->id_tick) std::memcpy(&tick, inputs[i], 8);
+        else if (in[i] == h->id_dt) std::memcpy(&h->desc.simulation_time_step, inputs[i], 8);
+        else if (Column* c = h->col(in[i]))
+            if (c->bytes) hipMemcpyAsync(c->dev, inputs[i], c->bytes, hipMemcpyHostToDevice, h->stream);
+    }
+    h->tick = tick;
+    const uint32_t k = h->desc.ticks_per_launch;
+    h->desc.ticks_per_launch = 1;
+    sixdof_step(h, 1, nullptr);
+    h->desc.ticks_per_launch = k;
+    for (size_t i = 0; i < out.size(); i++) {
+        if (out[i] == h->id_tick) std::memcpy(outputs[i], &h->tick, 8);
+        else if (out[i] == h->id_dt) std::memcpy(outputs[i], &h->desc.simulation_time_step, 8);
+        else if (Column* c = h->col(out[i]))
+            if (c->bytes) hipMemcpyAsync(outputs[i], c->dev, c->bytes, hipMemcpyDeviceToHost, h->stream);
+    }
+    hipStreamSynchronize(h->stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+// spatial.hpp — device-side spatial algebra for the MI355X six_dof kernels.
+//
+// Restates (does not copy) the arithmetic of the reference's
+//   libs/nox/src/quaternion.rs:141-155,268-305   (Hamilton product, inverse, normalize, q*v)
+//   libs/nox/src/spatial.rs:353-361,530-593      (F / I, transform + motion, q * spatial)
+// in forms chosen for CDNA4 rather than for a tracing compiler:
+//   * a rotation is two cross products (18 FMA-class ops) instead of two Hamilton products plus a
+//     recomputed inverse (~70 ops, 4 divides) — q v q^-1 is scale-invariant, so for the unit stage
+//     quaternions the results agree to ~1 ulp;
+//   * normalisation multiplies by one rsqrt instead of dividing four times by a sqrt;
+//   * divides by mass / inertia become multiplies by reciprocals computed once per launch.
+// These differ from the reference's rounding by O(1e-16) per operation; parity (<=1e-9 relative on
+// f64 state over the tested horizons) is checked against the operation-order-exact CPU oracle.
+// Quaternions are scalar-last [i,j,k,w], like the reference's columns.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sixdof {
+
+template <class T>
+struct Vec3 {
+    T x, y, z;
+};
+template <class T>
+struct Quat {
+    T i, j, k, w;
+};
+// SpatialMotion / SpatialForce: angular (or torque) part first, like the reference columns.
+template <class T>
+struct Spatial {
+    Vec3<T> ang, lin;
+};
+
+template <class T>
+__device__ __forceinline__ Vec3<T> operator+(Vec3<T> a, Vec3<T> b) {
+    return {a.x + b.x, a.y + b.y, a.z + b.z};
+}
+template <class T>
+__device__ __forceinline__ Vec3<T> operator-(Vec3<T> a, Vec3<T> b) {
+    return {a.x - b.x, a.y - b.y, a.z - b.z};
+}
+template <class T>
+__device__ __forceinline__ Vec3<T> operator*(T s, Vec3<T> a) {
+    return {s * a.x, s * a.y, s * a.z};
+}
+template <class T>
+__device__ __forceinline__ Vec3<T> hadamard(Vec3<T> a, Vec3<T> b) {
+    return {a.x * b.x, a.y * b.y, a.z * b.z};
+}
+template <class T>
+__device__ __forceinline__ Vec3<T> cross(Vec3<T> a, Vec3<T> b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <class T>
+__device__ __forceinline__ T dot(Vec3<T> a, Vec3<T> b) {
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+// fused a + s*b
+template <class T>
+__device__ __forceinline__ Vec3<T> axpy(T s, Vec3<T> b, Vec3<T> a) {
+    return {a.x + s * b.x, a.y + s * b.y, a.z + s * b.z};
+}
+template <class T>
+__device__ __forceinline__ Spatial<T> axpy(T s, Spatial<T> b, Spatial<T> a) {
+    return {axpy(s, b.ang, a.ang), axpy(s, b.lin, a.lin)};
+}
+template <class T>
+__device__ __forceinline__ Spatial<T> operator+(Spatial<T> a, Spatial<T> b) {
+    return {a.ang + b.ang, a.lin + b.lin};
+}
+
+__device__ __forceinline__ double fast_rsqrt(double x) { return rsqrt(x); }
+__device__ __forceinline__ float fast_rsqrt(float x) { return rsqrtf(x); }
+__device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
+
+// q * v for a UNIT quaternion:  v + 2w(u x v) + 2 u x (u x v)        (reference: quaternion.rs:283-305)
+template <class T>
+__device__ __forceinline__ Vec3<T> rotate(Quat<T> q, Vec3<T> v) {
+    const Vec3<T> u = {q.i, q.j, q.k};
+    const Vec3<T> t = T(2) * cross(u, v);
+    return axpy(q.w, t, v) + cross(u, t);
+}
+// q^-1 * v for a UNIT quaternion (conjugate rotation)
+template <class T>
+__device__ __forceinline__ Vec3<T> rotate_inv(Quat<T> q, Vec3<T> v) {
+    const Vec3<T> u = {q.i, q.j, q.k};
+    const Vec3<T> t = T(2) * cross(u, v);
+    return axpy(-q.w, t, v) + cross(u, t);
+}
+// scale-invariant forms for quaternions that may not be unit (first tick of semi-implicit on user data)
+template <class T>
+__device__ __forceinline__ Vec3<T> rotate_any(Quat<T> q, Vec3<T> v, T two_over_n2) {
+    const Vec3<T> u = {q.i, q.j, q.k};
+    const Vec3<T> t = two_over_n2 * cross(u, v);
+    return axpy(q.w, t, v) + cross(u, t);
+}
+template <class T>
+__device__ __forceinline__ Vec3<T> rotate_inv_any(Quat<T> q, Vec3<T> v, T two_over_n2) {
+    const Vec3<T> u = {q.i, q.j, q.k};
+    const Vec3<T> t = two_over_n2 * cross(u, v);
+    return axpy(-q.w, t, v) + cross(u, t);
+}
+
+// SpatialTransform + SpatialMotion, angular part: normalize(q + (d/2, 0) (x) q)   (spatial.rs:530-549)
+// `d` is the already-scaled angular increment (h * omega).
+template <class T>
+__device__ __forceinline__ Quat<T> integrate_world(Quat<T> q, Vec3<T> d) {
+    const T hx = T(0.5) * d.x, hy = T(0.5) * d.y, hz = T(0.5) * d.z;
+    Quat<T> r;
+    r.i = q.i + (hx * q.w + hy * q.k - hz * q.j);
+    r.j = q.j + (hy * q.w + hz * q.i - hx * q.k);
+    r.k = q.k + (hz * q.w + hx * q.j - hy * q.i);
+    r.w = q.w - (hx * q.i + hy * q.j + hz * q.k);
+    const T inv = fast_rsqrt(r.i * r.i + r.j * r.j + r.k * r.k + r.w * r.w);
+    return {r.i * inv, r.j * inv, r.k * inv, r.w * inv};
+}
+
+template <class T>
+__device__ __forceinline__ Quat<T> normalized(Quat<T> q) {
+    const T inv = fast_rsqrt(q.i * q.i + q.j * q.j + q.k * q.k + q.w * q.w);
+    return {q.i * inv, q.j * inv, q.k * inv, q.w * inv};
+}
+
+}  // namespace sixdof

@@ -1,0 +1,194 @@
+"""HipExec — the backend object a `WorldExec::Hip` variant would wrap.
+
+Mirrors the contract of the reference backends (libs/nox-py/src/exec.rs:53-93,
+cranelift_exec.rs:129-195 `invoke_batch(world, n, detailed) -> TickTimings`), over columns
+held as numpy arrays in the reference's row-major layout.  All compute goes through the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _raise(h, rc: int, what: str):
+    msg = L.lib().sixdof_last_error(h)
+    msg = msg.decode() if msg else ""
+    if rc == L.ERR_COMPONENT_NOT_FOUND:
+        raise KeyError(f"{what}: {msg}")           # Error::ComponentNotFound -> ValueError-class in PyO3
+    if rc in (L.ERR_VALUE_SIZE_MISMATCH, L.ERR_INVALID_ARGUMENT, L.ERR_ENTITY_MISMATCH, L.ERR_UNSUPPORTED):
+        raise ValueError(f"{what}: {msg}")
+    raise L.BackendError(f"{what}: {msg} (status {rc})")
+
+
+@dataclass
+class Effector:
+    """One op of the effector pipe (include/sixdof_hip.h sixdof_effector_kind)."""
+    kind: int
+    p: Sequence[float] = ()
+    aux_name: Optional[str] = None          # component name of a per-entity [n,3] column
+    aux: Optional[np.ndarray] = None        # its data
+
+
+@dataclass
+class TickTimings:  # profile.rs TickTimings
+    h2d_upload_ms: float = 0.0
+    kernel_invoke_ms: float = 0.0
+    d2h_download_ms: float = 0.0
+    kernel_device_ms: float = 0.0
+    launches: int = 0
+    ticks: int = 0
+    kernel_sum_ms: float = 0.0
+
+
+class HipExec:
+    def __init__(self, world_pos, world_vel, inertia, *, world_accel=None, force=None, entity_ids=None,
+                 simulation_time_step: float = 1.0 / 120.0, time_step: Optional[float] = None,
+                 integrator: int = L.RK4, dtype=np.float64, effectors: Sequence[Effector] = (),
+                 edges=None, ticks_per_launch: int = 1, use_graph: bool = False, device: int = 0,
+                 tick: int = 0):
+        lib = L.lib()
+        self._lib = lib
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError("dtype must be float64 or float32")
+        f = lambda a, w: np.array(a, dtype=self.dtype, order="C").reshape(-1, w)
+        self.world_pos = f(world_pos, 7)
+        n = self.world_pos.shape[0]
+        self.n = n
+        self.world_vel = f(world_vel, 6)
+        self.inertia = f(inertia, 7)
+        self.world_accel = np.zeros((n, 6), self.dtype) if world_accel is None else f(world_accel, 6)
+        self.force = np.zeros((n, 6), self.dtype) if force is None else f(force, 6)
+        # ids are sequential from 1 (0 = Globals) unless given: world.rs:193-196
+        self.entity_ids = (np.arange(1, n + 1, dtype=np.uint64) if entity_ids is None
+                           else np.ascontiguousarray(entity_ids, dtype=np.uint64))
+        self._aux = {}
+        d = L.Desc()
+        d.struct_size = C.sizeof(L.Desc)
+        d.device_ordinal = device
+        d.integrator = integrator
+        d.dtype = L.F64 if self.dtype == np.float64 else L.F32
+        d.n_entities = n
+        d.simulation_time_step = simulation_time_step
+        d.has_time_step = 0 if time_step is None else 1
+        d.time_step = 0.0 if time_step is None else float(time_step)
+        d.ticks_per_launch = ticks_per_launch
+        d.flags = L.FLAG_USE_GRAPH if use_graph else 0
+        self._h = C.c_void_p()
+        rc = lib.sixdof_create(C.byref(d), C.byref(self._h))
+        if rc != L.OK:
+            _raise(None, rc, "sixdof_create")
+        try:
+            cols = [("world_pos", self.world_pos), ("world_vel", self.world_vel), ("world_accel", self.world_accel),
+                    ("force", self.force), ("inertia", self.inertia)]
+            ops = (L.EffectorOp * max(1, len(effectors)))()
+            for k, e in enumerate(effectors):
+                ops[k].kind = e.kind
+                for j, v in enumerate(e.p):
+                    ops[k].p[j] = float(v)
+                if e.aux is not None:
+                    name = e.aux_name or f"effector_aux_{k}"
+                    arr = np.array(e.aux, dtype=self.dtype, order="C").reshape(n, 3)
+                    self._aux[name] = arr
+                    cols.append((name, arr))
+                    ops[k].aux_component_id = L.component_id(name)
+            self._bind(cols)
+            rc = lib.sixdof_set_effectors(self._h, ops, len(effectors))
+            if rc != L.OK:
+                _raise(self._h, rc, "sixdof_set_effectors")
+            if edges is not None:
+                frm = np.ascontiguousarray(edges[0], dtype=np.uint64)
+                to = np.ascontiguousarray(edges[1], dtype=np.uint64)
+                u64p = C.POINTER(C.c_uint64)
+                rc = lib.sixdof_set_edges(self._h, frm.ctypes.data_as(u64p), to.ctypes.data_as(u64p), len(frm))
+                if rc != L.OK:
+                    _raise(self._h, rc, "sixdof_set_edges")
+            lib.sixdof_set_tick(self._h, tick)
+            self.upload()
+        except Exception:
+            self.close()
+            raise
+
+    def _bind(self, named_arrays):
+        cols = (L.Column * len(named_arrays))()
+        prim = L.PRIM_F64 if self.dtype == np.float64 else L.PRIM_F32
+        for c, (name, arr) in zip(cols, named_arrays):
+            c.component_id = L.component_id(name)
+            c.prim_type = prim
+            c.ndim = 1
+            c.dims[0] = arr.shape[1]
+            c.n_rows = arr.shape[0]
+            c.entity_ids = self.entity_ids.ctypes.data_as(C.POINTER(C.c_uint64))
+            c.host_ptr = arr.ctypes.data
+        rc = self._lib.sixdof_bind_columns(self._h, cols, len(named_arrays))
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_bind_columns")
+
+    # -- reference-shaped surface -------------------------------------------------------------------
+    def upload(self):
+        rc = self._lib.sixdof_upload(self._h)
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_upload")
+
+    def invoke_batch(self, n_ticks: int) -> TickTimings:
+        """cranelift_exec.rs:129-195: run n ticks back to back; state stays in HBM."""
+        t = L.Timings()
+        rc = self._lib.sixdof_step(self._h, int(n_ticks), C.byref(t))
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_step")
+        return TickTimings(t.h2d_upload_ms, t.kernel_invoke_ms, t.d2h_download_ms, t.kernel_device_ms,
+                           int(t.launches), int(t.ticks), t.kernel_sum_ms)
+
+    def download(self, mask: int = L.COL_ALL):
+        rc = self._lib.sixdof_download(self._h, mask)
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_download")
+        return self
+
+    def run(self, ticks: int = 1) -> TickTimings:
+        """PyExec.run (exec.rs:110-172) without the DB commit: step, then refresh the host columns."""
+        t = self.invoke_batch(ticks)
+        self.download()
+        return t
+
+    @property
+    def tick(self) -> int:
+        v = C.c_uint64()
+        self._lib.sixdof_get_tick(self._h, C.byref(v))
+        return int(v.value)
+
+    def set_ticks_per_launch(self, k: int):
+        rc = self._lib.sixdof_set_ticks_per_launch(self._h, int(k))
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_set_ticks_per_launch")
+
+    def set_flags(self, flags: int):
+        self._lib.sixdof_set_flags(self._h, int(flags))
+
+    def edge_rows(self):
+        n = C.c_size_t()
+        self._lib.sixdof_get_edge_rows(self._h, None, None, 0, C.byref(n))
+        src = np.zeros(n.value, dtype=np.uint32)
+        dst = np.zeros(n.value, dtype=np.uint32)
+        u32p = C.POINTER(C.c_uint32)
+        rc = self._lib.sixdof_get_edge_rows(self._h, src.ctypes.data_as(u32p), dst.ctypes.data_as(u32p), n.value,
+                                            C.byref(n))
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_get_edge_rows")
+        return src, dst
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.sixdof_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

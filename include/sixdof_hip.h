@@ -126,6 +126,8 @@ typedef struct sixdof_desc {
 } sixdof_desc;
 
 #define SIXDOF_FLAG_USE_GRAPH 1u /* replay long sixdof_step batches from a captured hipGraph */
+#define SIXDOF_FLAG_TIME_EACH_LAUNCH 2u /* profiling: bracket every launch of sixdof_step with its own HIP
+                                           event pair (<= 4096 launches per call; disables graph replay) */
 
 /* One ECS column as the reference holds it (world.rs:26-30 + ExecSlotMetadata exec.rs:17-22). */
 typedef struct sixdof_column {
@@ -146,6 +148,7 @@ typedef struct sixdof_timings {
     double kernel_device_ms;   /* HIP-event time of the launches of the last step, on the handle's stream */
     uint64_t launches;         /* kernel launches issued by the last step */
     uint64_t ticks;
+    double kernel_sum_ms;      /* SIXDOF_FLAG_TIME_EACH_LAUNCH: sum of the per-launch event times (no gaps) */
 } sixdof_timings;
 
 typedef struct sixdof_slot {
@@ -186,6 +189,7 @@ int sixdof_download(sixdof_handle* h, uint32_t column_mask);
 int sixdof_get_tick(const sixdof_handle* h, uint64_t* tick);
 int sixdof_set_tick(sixdof_handle* h, uint64_t tick);
 int sixdof_set_ticks_per_launch(sixdof_handle* h, uint32_t k);
+int sixdof_set_flags(sixdof_handle* h, uint32_t flags);
 /* Device-resident column (reference byte layout) for zero-copy consumers; NULL if unknown. */
 void* sixdof_device_column(sixdof_handle* h, uint64_t component_id);
 /* hipStream_t the handle launches on, as an opaque pointer */

@@ -1,0 +1,182 @@
+"""GPU parity: the HIP path through the C ABI vs the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+import elodin_amd as ea
+from elodin_amd import _lib as L
+from elodin_amd import workloads
+from oracle import oracle as orc
+from tests import golden_util as gu
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(n, ticks, integrator=L.RK4, ticks_per_launch=1, seed=workloads.SEED, time_step=None, use_graph=False):
+    w = workloads.independent_bodies(n, seed=seed)
+    eff = workloads.gravity_torque_effectors(w["body_torque"])
+    hip = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], entity_ids=w["entity_ids"],
+                     simulation_time_step=workloads.DT_120HZ, time_step=time_step, integrator=integrator,
+                     effectors=eff, ticks_per_launch=ticks_per_launch, use_graph=use_graph)
+    ref = orc.OracleWorld(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ,
+                          time_step=time_step, integrator=integrator, ops=parity.to_oracle_ops(eff))
+    return hip, ref, w
+
+
+@pytest.mark.parametrize("n", [1, 3, 63, 64, 255, 256, 257, 1000, 4099])
+def test_rk4_ragged_sizes(n):
+    hip, ref, _ = _pair(n, 10)
+    hip.run(10)
+    ref.step(10, threads=4)
+    errs = parity.state_errors(hip, ref)
+    assert max(errs.values()) < parity.F64_RTOL, errs
+    assert hip.tick == ref.tick == 10
+
+
+def test_empty_world():
+    hip = ea.HipExec(np.zeros((0, 7)), np.zeros((0, 6)), np.zeros((0, 7)))
+    hip.run(5)
+    assert hip.tick == 5 and hip.world_pos.shape == (0, 7)
+
+
+@pytest.mark.parametrize("integrator", [L.RK4, L.SEMI_IMPLICIT])
+def test_config2_65536_bodies_1000_ticks(integrator):
+    """BASELINE config 2 at full size; oracle on 8 threads takes a few seconds."""
+    hip, ref, w = _pair(65536, 1000, integrator=integrator, ticks_per_launch=1, use_graph=True)
+    checkpoints = [1, 10, 100, 400, 1000]
+    done = 0
+    worst = {}
+    for cp in checkpoints:
+        hip.run(cp - done)
+        ref.step(cp - done, threads=8)
+        done = cp
+        for k, v in parity.state_errors(hip, ref).items():
+            worst[k] = max(worst.get(k, 0.0), v)
+    print("config2 worst rel err", integrator, worst)
+    assert max(worst.values()) < parity.F64_RTOL, worst
+    # entity indices are carried bit-exactly (row i <-> entity_ids[i])
+    assert np.array_equal(hip.entity_ids, w["entity_ids"])
+
+
+@pytest.mark.parametrize("k", [1, 7, 16, 256])
+def test_fused_ticks_match_single_tick_launches(k):
+    """ticks_per_launch (the reference's ticks_per_telemetry batch) must not change the result."""
+    a, _, _ = _pair(5000, 300, ticks_per_launch=1)
+    b, _, _ = _pair(5000, 300, ticks_per_launch=k)
+    a.run(300)
+    b.run(300)
+    for f in parity.FIELDS:
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert a.tick == b.tick == 300
+
+
+def test_graph_replay_is_identical():
+    a, _, _ = _pair(3000, 100, use_graph=False)
+    b, _, _ = _pair(3000, 100, use_graph=True)
+    a.run(100)
+    b.run(100)
+    for f in parity.FIELDS:
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+
+
+def test_determinism_across_runs():
+    a, _, _ = _pair(10000, 50)
+    b, _, _ = _pair(10000, 50)
+    a.run(50)
+    b.run(50)
+    for f in parity.FIELDS:
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+
+
+def test_time_step_override_quirk():
+    """RK4: stage offsets use the global dt, the final combination the override (rk4.rs:93-100,129)."""
+    hip, ref, _ = _pair(777, 20, time_step=1.0 / 60.0)
+    hip.run(20)
+    ref.step(20)
+    assert max(parity.state_errors(hip, ref).values()) < parity.F64_RTOL
+
+
+def test_ball_golden_on_gpu():
+    """G2 (scripts/ci/baseline/ball-csv) straight through the HIP path: gravity | drag, RK4."""
+    g = gu.load("ball")
+    wind = g["ball.wind"][1]
+    eff = [ea.Effector(L.EFF_UNIFORM_GRAVITY, (0.0, 0.0, -9.81)),
+           ea.Effector(L.EFF_BALL_DRAG, (0.5, 1.225, 2 * 3.1415 * 0.2**2), aux_name="wind", aux=wind[None, :])]
+    hip = ea.HipExec(g["ball.world_pos"][0], g["ball.world_vel"][0], g["ball.inertia"][0],
+                     simulation_time_step=float(g["globals.simulation_time_step"][0, 0]), effectors=eff)
+    worst = 0.0
+    for r in range(1, 101):
+        hip.run(1)
+        for comp in parity.FIELDS:
+            got, ref = getattr(hip, comp), g[f"ball.{comp}"][r][None, :]
+            if comp == "world_pos":
+                worst = max(worst, parity.pos_rel_err(got, ref))
+            else:
+                worst = max(worst, parity.field_rel_err(got[:, 3:], ref[:, 3:]))
+                assert np.all(got[:, :3] == 0.0)
+    print("ball golden on GPU worst rel err", worst)
+    assert worst < parity.F64_RTOL
+
+
+def test_kat_on_gpu():
+    """K8 (libs/nox-py/python/tests/test_all.py:67-83,228-292,342-364) through the HIP path."""
+    one = dict(world_pos=[[0, 0, 0, 1, 0, 0, 0]], inertia=[[1, 1, 1, 0, 0, 0, 1]],
+               simulation_time_step=workloads.DT_120HZ)
+    h = ea.HipExec(world_vel=[[0, 0, 0, 1, 0, 0]], time_step=1.0 / 60.0, **one)
+    h.run(1)
+    assert np.allclose(h.world_pos[0], [0, 0, 0, 1, 0.01666667, 0, 0])
+    for omega, q in [([0, 0, 1], [0.0, 0.0, 0.479425538604203, 0.8775825618903728]),
+                     ([0, 1, 0], [0.0, 0.479425538604203, 0.0, 0.8775825618903728]),
+                     ([1, 1, 0], [0.45936268493243, 0.45936268493243, 0.0, 0.76024459707606])]:
+        h = ea.HipExec(world_vel=[omega + [0, 0, 0]], time_step=1.0 / 120.0, **one)
+        h.run(120)
+        assert np.isclose(h.world_pos[0], q + [0, 0, 0], rtol=1e-5).all()
+    h = ea.HipExec(world_vel=[[0] * 6], time_step=1.0 / 120.0,
+                   effectors=[ea.Effector(L.EFF_CONST_WRENCH, (0, 0, 0, 1, 0, 0))], **one)
+    h.run(120)
+    assert np.isclose(h.world_pos[0], [0, 0, 0, 1, 0.5, 0, 0], rtol=1e-5).all()
+
+
+def test_f32_extension_tracks_f64_oracle():
+    """BASELINE config 5 dtype. Parity unpinned (reference six_dof is f64 only); f32-appropriate tolerance."""
+    w = workloads.independent_bodies(4096)
+    eff = workloads.gravity_torque_effectors(w["body_torque"])
+    hip = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=np.float32,
+                     simulation_time_step=workloads.DT_120HZ, effectors=eff)
+    ref = orc.OracleWorld(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ,
+                          ops=parity.to_oracle_ops(eff))
+    hip.run(20)
+    ref.step(20, threads=4)
+    errs = parity.state_errors(hip, ref)
+    assert max(errs.values()) < 2e-4, errs
+
+
+def test_tickfn_shim_roundtrip():
+    """sixdof_tick(inputs**, outputs**) — the reference's TickFn ABI (cranelift_exec.rs:11)."""
+    import ctypes as C
+    hip, ref, w = _pair(500, 1)
+    lib = L.lib()
+    n_in, n_out = C.c_size_t(), C.c_size_t()
+    ins, outs = (L.Slot * 16)(), (L.Slot * 16)()
+    assert lib.sixdof_tick_slots(hip._h, ins, 16, C.byref(n_in), outs, 16, C.byref(n_out)) == 0
+    by_id = {L.component_id(k): v for k, v in
+             dict(world_pos=hip.world_pos, world_vel=hip.world_vel, world_accel=hip.world_accel, force=hip.force,
+                  inertia=hip.inertia, body_torque=hip._aux["body_torque"]).items()}
+    tick = np.array([41], dtype=np.uint64)
+    dt = np.array([workloads.DT_120HZ])
+    by_id[L.component_id("tick")] = tick
+    by_id[L.component_id("simulation_time_step")] = dt
+    in_ptrs = (C.c_void_p * n_in.value)(*[by_id[ins[i].component_id].ctypes.data for i in range(n_in.value)])
+    out_bufs = [np.zeros(outs[i].bytes, dtype=np.uint8) for i in range(n_out.value)]
+    out_ptrs = (C.c_void_p * n_out.value)(*[b.ctypes.data for b in out_bufs])
+    # outputs come back in ascending ComponentId (system.rs:139-153)
+    ids = [outs[i].component_id for i in range(n_out.value)]
+    assert ids == sorted(ids)
+    lib.sixdof_tick_bind(hip._h)
+    lib.sixdof_tick(in_ptrs, out_ptrs)
+    ref.step(1)
+    got = {ids[i]: out_bufs[i] for i in range(n_out.value)}
+    assert got[L.component_id("tick")].view(np.uint64)[0] == 42
+    pos = got[L.component_id("world_pos")].view(np.float64).reshape(-1, 7)
+    assert parity.pos_rel_err(pos, ref.world_pos) < parity.F64_RTOL
+    assert np.array_equal(got[L.component_id("inertia")].view(np.float64).reshape(-1, 7), hip.inertia)
