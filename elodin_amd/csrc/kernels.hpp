@@ -40,7 +40,11 @@ enum : int { kRk4 = 0, kSemiImplicit = 1 };
 // dtype: 0 = f64, 1 = f32.  Returns hipGetLastError() of the launch.
 hipError_t launch_step(const StepParams& p, int integrator, int dtype, hipStream_t stream);
 
-// ---- pairwise (edge_fold) path: one RK4/semi-implicit tick is a short kernel sequence -------------
+// ---- pairwise (edge_fold) path -----------------------------------------------------------------------
+// One tick = pack -> accumulate -> integrate (3 launches).  See nbody_kernels.hip.
+constexpr int kPackWidth = 10;   // per source: p(c=0) p(c=1/2) p(c=1) mass
+constexpr int kPartialWidth = 9; // per target and source split: 3 stage positions x 3 force components
+
 struct PairParams {
     void* pos;            // [n,7]
     void* vel;            // [n,6]
@@ -49,22 +53,20 @@ struct PairParams {
     const void* inertia;  // [n,7]
     uint32_t n;
     double dt_g, dt;
-    // per-stage scratch, device
-    void* xs;             // [n,7] stage transforms
-    void* vs;             // [n,6] stage velocities
-    void* sv;             // [n,6] running sum of stage velocities
-    void* sa;             // [n,6] running sum of stage accelerations
-    void* a_prev;         // [n,6] previous stage acceleration
-    void* pm;             // [n,4] packed (x,y,z,mass) of the stage positions for the pair kernels
+    double* pack;         // [n,10] scratch
+    double* partial;      // [splits,n,9] scratch
+    uint32_t splits;      // source-range splits of the all-pairs kernel (1 for edge lists)
     // edge list in CSR-by-source form (spawn order preserved inside a source), device
     const uint32_t* row_start;  // [n+1]
     const uint32_t* dst;        // [n_edges]
     uint32_t n_edges;
     int32_t pair_kind;    // sixdof_effector_kind 6,7,8
     double p0, p1;        // G | K, eps
-    uint32_t n_ops;       // per-entity ops applied BEFORE the pair op (pipe order)
-    DevOp ops[kMaxOps];
+    uint32_t n_ops;       // per-entity ops applied BEFORE the pair op (pipe order); they survive only on
+    DevOp ops[kMaxOps];   // rows that are not edge sources (edge_fold replaces Force on source rows)
 };
+// Picks the number of source splits for n targets so the all-pairs grid fills 256 CUs.
+uint32_t pair_splits_for(uint32_t n);
 hipError_t launch_pair_tick(const PairParams& p, int integrator, hipStream_t stream, uint64_t* launches);
 
 }  // namespace sixdof

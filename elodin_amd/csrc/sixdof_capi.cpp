@@ -440,21 +440,19 @@ int fill_pair_params(sixdof_handle* h, PairParams* P) {
     std::memset(P, 0, sizeof(*P));
     const size_t n = h->desc.n_entities;
     const size_t es = h->elem_size();
-    // scratch layout: xs[n,7] vs[n,6] sv[n,6] sa[n,6] a_prev[n,6] pm[n,4]
-    const size_t sz[6] = {7 * n * es, 6 * n * es, 6 * n * es, 6 * n * es, 6 * n * es, 4 * n * es};
-    size_t total = 0;
-    for (size_t s : sz) total += align_up(s, 256);
+    const sixdof_effector_op& pop = h->ops.back();
+    const uint32_t splits = pop.kind == SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED ? pair_splits_for(static_cast<uint32_t>(n)) : 1;
+    (void)es;
+    // scratch layout: pack[n,10] | partial[splits,n,9]   (f64)
+    const size_t pack_bytes = align_up(sizeof(double) * kPackWidth * n, 256);
+    const size_t partial_bytes = align_up(sizeof(double) * kPartialWidth * n * splits, 256);
+    const size_t total = pack_bytes + partial_bytes;
     if (total > h->scratch_bytes) {
         if (h->d_scratch) hipFree(h->d_scratch), h->d_scratch = nullptr;
         HIP_TRY(h, hipMalloc(&h->d_scratch, total ? total : 256));
         h->scratch_bytes = total;
     }
     char* base = static_cast<char*>(h->d_scratch);
-    void* ptrs[6];
-    for (int i = 0; i < 6; i++) {
-        ptrs[i] = base;
-        base += align_up(sz[i], 256);
-    }
     P->pos = h->col(h->id_pos)->dev;
     P->vel = h->col(h->id_vel)->dev;
     P->accel = h->col(h->id_accel)->dev;
@@ -463,8 +461,9 @@ int fill_pair_params(sixdof_handle* h, PairParams* P) {
     P->n = static_cast<uint32_t>(n);
     P->dt_g = h->desc.simulation_time_step;
     P->dt = h->desc.has_time_step ? h->desc.time_step : h->desc.simulation_time_step;
-    P->xs = ptrs[0]; P->vs = ptrs[1]; P->sv = ptrs[2]; P->sa = ptrs[3]; P->a_prev = ptrs[4]; P->pm = ptrs[5];
-    const sixdof_effector_op& pop = h->ops.back();
+    P->pack = reinterpret_cast<double*>(base);
+    P->partial = reinterpret_cast<double*>(base + pack_bytes);
+    P->splits = splits;
     P->pair_kind = pop.kind;
     P->p0 = pop.p[0];
     P->p1 = pop.p[1];

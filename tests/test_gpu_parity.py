@@ -180,3 +180,123 @@ def test_tickfn_shim_roundtrip():
     pos = got[L.component_id("world_pos")].view(np.float64).reshape(-1, 7)
     assert parity.pos_rel_err(pos, ref.world_pos) < parity.F64_RTOL
     assert np.array_equal(got[L.component_id("inertia")].view(np.float64).reshape(-1, 7), hip.inertia)
+
+
+# ---- pairwise (edge_fold) path ---------------------------------------------------------------------------
+
+G_NEWTON = 6.6743e-11
+K_SQ = 2.9591220828e-4 / (86400.0 * 86400.0)   # examples/n-body/sim.py:14-17
+EPS_AU2 = 1.0e-10
+
+
+def test_three_body_golden_on_gpu():
+    """G1 (scripts/ci/baseline/three-body-csv) through the HIP edge_fold path, 100 ticks."""
+    g = gu.load("three_body")
+    names = "abc"
+    pos = np.stack([g[f"{e}.world_pos"][0] for e in names])
+    vel = np.stack([g[f"{e}.world_vel"][0] for e in names])
+    inertia = np.stack([g[f"{e}.inertia"][0] for e in names])
+    edge_names = ["a_>_b", "b_>_a", "a_>_c", "b_>_c", "c_>_a", "c_>_b"]
+    frm = np.array([g[f"{e}.gravity_edge"][0, 0] for e in edge_names], dtype=np.uint64)
+    to = np.array([g[f"{e}.gravity_edge"][0, 1] for e in edge_names], dtype=np.uint64)
+    hip = ea.HipExec(pos, vel, inertia, entity_ids=[1, 2, 3],
+                     simulation_time_step=float(g["globals.simulation_time_step"][0, 0]),
+                     effectors=[ea.Effector(L.EFF_EDGE_GRAVITY_NEWTON, (G_NEWTON,))], edges=(frm, to))
+    # integer parity: resolved row indices are bit-identical to the oracle's
+    src, dst = hip.edge_rows()
+    osrc, odst = orc.resolve_edges(np.array([1, 2, 3], dtype=np.uint64), frm, to)
+    assert src.dtype == np.uint32 and np.array_equal(src, osrc) and np.array_equal(dst, odst)
+    worst = {}
+    for r in range(1, 101):
+        hip.run(1)
+        assert hip.tick == int(g["globals.tick"][r, 0])
+        for i, e in enumerate(names):
+            worst["world_pos"] = max(worst.get("world_pos", 0), parity.pos_rel_err(hip.world_pos[i:i + 1], g[f"{e}.world_pos"][r][None]))
+            for comp in ("world_vel", "world_accel", "force"):
+                got, ref = getattr(hip, comp)[i:i + 1, 3:], g[f"{e}.{comp}"][r][None, 3:]
+                worst[comp] = max(worst.get(comp, 0), parity.field_rel_err(got, ref))
+    print("three-body golden on GPU worst rel err", worst)
+    assert max(worst.values()) < parity.F64_RTOL, worst
+
+
+def _plummer(n, seed=7):
+    rng = np.random.default_rng(seed)
+    # Plummer sphere, a = 1 AU (SURVEY §8d config 3); masses U(1e-9, 1e-3) solar masses
+    u = rng.uniform(0.05, 0.95, n)
+    r = 1.0 / np.sqrt(u ** (-2.0 / 3.0) - 1.0)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    p = d * r[:, None]
+    v = rng.normal(scale=1e-7, size=(n, 3))
+    m = rng.uniform(1e-9, 1e-3, n)
+    pos = np.concatenate([np.tile([0, 0, 0, 1.0], (n, 1)), p], axis=1)
+    vel = np.concatenate([np.zeros((n, 3)), v], axis=1)
+    inertia = np.concatenate([np.tile(m[:, None], (1, 3)), np.zeros((n, 3)), m[:, None]], axis=1)
+    return pos, vel, inertia
+
+
+@pytest.mark.parametrize("n,ticks", [(2, 5), (35, 10), (257, 5), (1000, 5), (2048, 3)])
+@pytest.mark.parametrize("integrator", [L.RK4, L.SEMI_IMPLICIT])
+def test_allpairs_nbody_vs_oracle(n, ticks, integrator):
+    pos, vel, inertia = _plummer(n)
+    op = (K_SQ, EPS_AU2)
+    hip = ea.HipExec(pos, vel, inertia, simulation_time_step=3600.0, integrator=integrator,
+                     effectors=[ea.Effector(L.EFF_ALLPAIRS_GRAVITY_SOFTENED, op)])
+    ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=3600.0, integrator=integrator,
+                          ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, op, None)])
+    hip.run(ticks)
+    ref.step(ticks)
+    errs = parity.state_errors(hip, ref)
+    assert max(errs.values()) < parity.F64_RTOL, errs
+
+
+def test_edge_list_equals_allpairs():
+    """The complete graph given as explicit edges (n-body spawn order) and the tiled all-pairs kernel agree."""
+    n = 300
+    pos, vel, inertia = _plummer(n, seed=3)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    frm = np.repeat(ids, n - 1)
+    to = np.concatenate([np.delete(ids, i) for i in range(n)])
+    op = (K_SQ, EPS_AU2)
+    a = ea.HipExec(pos, vel, inertia, simulation_time_step=3600.0,
+                   effectors=[ea.Effector(L.EFF_EDGE_GRAVITY_SOFTENED, op)], edges=(frm, to))
+    b = ea.HipExec(pos, vel, inertia, simulation_time_step=3600.0,
+                   effectors=[ea.Effector(L.EFF_ALLPAIRS_GRAVITY_SOFTENED, op)])
+    ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=3600.0,
+                          ops=[(orc.EFF_EDGE_GRAVITY_SOFTENED, op, None)],
+                          edges=orc.resolve_edges(ids, frm, to))
+    a.run(4); b.run(4); ref.step(4)
+    assert max(parity.state_errors(a, ref).values()) < parity.F64_RTOL
+    assert max(parity.state_errors(b, ref).values()) < parity.F64_RTOL
+
+
+def test_edge_fold_replaces_force_only_on_source_rows():
+    """Rows without out-edges keep the per-entity effectors' Force (graph.rs:239-361)."""
+    n = 6
+    pos, vel, inertia = _plummer(n, seed=11)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    frm = np.array([1, 1, 3, 4, 4, 4], dtype=np.uint64)   # sources: rows 0, 2, 3 ; rows 1, 4, 5 are not
+    to = np.array([2, 3, 1, 6, 5, 1], dtype=np.uint64)
+    op = (K_SQ, EPS_AU2)
+    eff = [ea.Effector(L.EFF_UNIFORM_GRAVITY, (0.0, 0.0, -1e-12)), ea.Effector(L.EFF_EDGE_GRAVITY_SOFTENED, op)]
+    hip = ea.HipExec(pos, vel, inertia, simulation_time_step=3600.0, effectors=eff, edges=(frm, to))
+    ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=3600.0,
+                          ops=[(orc.EFF_UNIFORM_GRAVITY, (0.0, 0.0, -1e-12), None),
+                               (orc.EFF_EDGE_GRAVITY_SOFTENED, op, None)],
+                          edges=orc.resolve_edges(ids, frm, to))
+    hip.run(7); ref.step(7)
+    assert max(parity.state_errors(hip, ref).values()) < parity.F64_RTOL
+    assert np.allclose(hip.force[1, 3:], [0, 0, -1e-12 * inertia[1, 6]], rtol=1e-12)
+
+
+def test_pair_op_errors():
+    pos, vel, inertia = _plummer(4)
+    with pytest.raises(KeyError):  # Error::ComponentNotFound: edge effector without edges
+        h = ea.HipExec(pos, vel, inertia, effectors=[ea.Effector(L.EFF_EDGE_GRAVITY_NEWTON, (1.0,))])
+        h.run(1)
+    with pytest.raises(KeyError):  # edge endpoint that is not a Body
+        ea.HipExec(pos, vel, inertia, effectors=[ea.Effector(L.EFF_EDGE_GRAVITY_NEWTON, (1.0,))],
+                   edges=(np.array([1], dtype=np.uint64), np.array([99], dtype=np.uint64)))
+    with pytest.raises(ValueError):  # pair op must be last in the pipe
+        ea.HipExec(pos, vel, inertia, effectors=[ea.Effector(L.EFF_ALLPAIRS_GRAVITY_SOFTENED, (1.0, 0.0)),
+                                                 ea.Effector(L.EFF_UNIFORM_GRAVITY, (0, 0, -1))])
