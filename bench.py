@@ -12,7 +12,7 @@ timed region starts.  Weak scaling: every rank owns its own 65,536-row shard of 
 collective — torch.distributed is only the launcher's barrier and the max-over-ranks of the time.
 
 Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel, ticks_per_launch = 1,
-algorithmic bytes 360 B/entity-step against the 8 TB/s HBM peak), `roofline_hbm` (same kernel at
+algorithmic bytes 360 + 24 = 384 B/entity-step against the 8 TB/s HBM peak), `roofline_hbm` (same kernel at
 4,194,304 bodies, where the working set leaves the 256 MiB Infinity Cache and the kernel really
 streams from HBM), `fused` (ticks_per_launch = 64: state in registers, VALU-bound) and
 `cpu_baseline` (the CPU oracle on the host cores, bounded sample, N=1 only).
@@ -32,8 +32,11 @@ sys.path.insert(0, str(ROOT))
 import numpy as np  # noqa: E402
 
 ENTITIES = 65536
-BYTES_PER_ENTITY_STEP_F64 = 360  # read pos 56 + vel 48 + inertia 56, write pos 56 + vel 48 + accel 48 + force 48
+# read pos 56 + vel 48 + inertia 56, write pos 56 + vel 48 + accel 48 + force 48 = 360 B per f64
+# entity-step, plus 24 B for the per-entity body-torque effector column this workload reads = 384 B.
+BYTES_PER_ENTITY_STEP_F64 = 360 + 24
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+PMC_FILE = ROOT / "profiles" / "pmc_traffic.json"  # written by profiles/collect.sh from separate --pmc passes
 
 
 def make_exec(n, first_row, device, ticks_per_launch, use_graph):
@@ -46,24 +49,34 @@ def make_exec(n, first_row, device, ticks_per_launch, use_graph):
                       ticks_per_launch=ticks_per_launch, use_graph=use_graph), w, eff
 
 
-def kernel_roofline(ex, n, steps, warmup):
-    """Average duration of ONE launch of the step kernel (ticks_per_launch = 1), each launch bracketed by
-    its own HIP event pair on the handle's stream, -> algorithmic GB/s against the HBM peak."""
-    from elodin_amd import _lib as L
-    ex.set_ticks_per_launch(1)
-    ex.set_flags(L.FLAG_TIME_EACH_LAUNCH)
-    ex.invoke_batch(min(warmup, 64))
-    steps = min(steps, 4096)
-    t = ex.invoke_batch(steps)
-    ex.set_flags(0)
-    avg_ms = t.kernel_sum_ms / max(1, t.launches)
+def pmc_traffic(n):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB),
+    or None when no profile of this entity count has been collected."""
+    try:
+        rec = json.loads(PMC_FILE.read_text()).get(str(n))
+        return rec and rec["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def roofline_from(avg_launch_ms, n, launches, how):
     bytes_per_launch = BYTES_PER_ENTITY_STEP_F64 * n
-    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-            "kernel": "sixdof_step_kernel<double, rk4>", "avg_launch_us": round(avg_ms * 1e3, 3),
-            "algorithmic_bytes_per_launch": bytes_per_launch, "entities": n, "ticks_per_launch": 1,
-            "launches_timed": int(t.launches)}
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(n),
+            "kernel": "sixdof_step_kernel<double, rk4, gravity|body_torque>",
+            "avg_launch_us": round(avg_launch_ms * 1e3, 3), "algorithmic_bytes_per_launch": bytes_per_launch,
+            "entities": n, "ticks_per_launch": 1, "launches_timed": int(launches), "timing": how}
+
+
+def kernel_roofline(ex, n, steps, warmup):
+    """Average duration of one launch of the step kernel at ticks_per_launch = 1: `steps` launches enqueued back
+    to back on the handle's stream between ONE HIP event pair (so inter-kernel gaps count against us)."""
+    ex.set_ticks_per_launch(1)
+    ex.invoke_batch(warmup)
+    t = ex.invoke_batch(steps)
+    return roofline_from(t.kernel_device_ms / max(1, t.launches), n, t.launches,
+                         "HIP events around the batch on the launch stream / launches")
 
 
 def cpu_baseline(w, eff, target_seconds=10.0):
@@ -152,7 +165,11 @@ def main():
     }
 
     if rank == 0:
-        out["roofline"] = kernel_roofline(ex, n, args.steps, args.warmup)
+        if K == 1:  # the timed region itself: HIP events bracket exactly the `steps` launches
+            out["roofline"] = roofline_from(tm.kernel_device_ms / max(1, tm.launches), n, tm.launches,
+                                            "HIP events around the timed region on the launch stream / launches")
+        else:
+            out["roofline"] = kernel_roofline(ex, n, args.steps, args.warmup)
         if not args.no_extras:
             # fused batch: the reference's ticks_per_telemetry semantics, state held in VGPRs
             ex.set_ticks_per_launch(64)

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
+#   gpurun -- 'bash profiles/collect.sh r01'
+# Three separate passes of the SAME command (kernel trace; FETCH_SIZE; WRITE_SIZE — the two TCC counters do
+# not fit one pass, and PMC passes must not be combined with other tracing).  Outputs land in
+# gpurun_out/prof_<tag>/ ; profiles/summarize.py condenses them into the files committed under profiles/.
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --steps 2048 --warmup 128 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.err
+# PMC passes: no graph replay (counters are attributed per dispatch), fewer steps
+CMDP="python $R/bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-graph"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $CMDP > $OUT/bench_fetch.json 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $CMDP > $OUT/bench_write.json 2> $OUT/write.err
+python $R/profiles/summarize.py $OUT $TAG
+find $OUT -type f | head -40

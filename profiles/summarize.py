@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 CSVs of profiles/collect.sh into small committed files:
+  <out>/summary_<tag>.md        per-kernel count / avg / min / max duration (from *_kernel_trace.csv), split by grid
+  <out>/pmc_traffic.json        HBM bytes per launch per entity count (FETCH_SIZE*2 + WRITE_SIZE, KiB units)
+FETCH_SIZE on gfx950 reports half of a wide coalesced read (MI355X_MICROARCH.md §HBM): doubled here; WRITE_SIZE
+matched the byte count of this kernel's stores exactly (200 B/entity) and is used as is."""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+out, tag = sys.argv[1], sys.argv[2]
+
+
+def rows(pattern):
+    for f in glob.glob(pattern, recursive=True):
+        with open(f, newline="") as fh:
+            yield from csv.DictReader(fh)
+
+
+stats = defaultdict(list)
+for r in rows(f"{out}/trace/**/*kernel_trace.csv"):
+    grid = int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0)
+    dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    stats[(r["Kernel_Name"], grid)].append(dur)
+
+lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
+         "Command: `python bench.py --steps 2048 --warmup 128 --no-cpu-baseline` (see profiles/collect.sh).",
+         "Durations in microseconds; `grid` = total work-items (= entities for the step kernel). The 65536-entity",
+         "step kernel appears with ticks_per_launch = 1 (timed region + warmup) and = 64 (the `fused` leg):",
+         "rows are split at 20 us.", "",
+         "| kernel | grid | launches | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|---|"]
+for (name, grid), d in sorted(stats.items(), key=lambda kv: -sum(kv[1])):
+    groups = [("", d)]
+    if "sixdof_step_kernel" in name and grid == 65536:
+        groups = [(" [1 tick/launch]", [x for x in d if x < 20000]), (" [64 ticks/launch]", [x for x in d if x >= 20000])]
+    for label, g in groups:
+        if g:
+            lines.append(f"| `{name}`{label} | {grid} | {len(g)} | {sum(g)/len(g)/1e3:.3f} | {min(g)/1e3:.3f} | "
+                         f"{max(g)/1e3:.3f} | {sum(g)/1e6:.3f} |")
+
+pmc = defaultdict(lambda: defaultdict(list))
+for which in ("fetch", "write"):
+    for r in rows(f"{out}/pmc_{which}/**/*counter_collection.csv"):
+        if "sixdof_step_kernel" not in r["Kernel_Name"]:
+            continue
+        grid = int(r.get("Grid_Size") or 0)
+        pmc[grid][r["Counter_Name"]].append(float(r["Counter_Value"]))
+traffic = {}
+lines += ["", "## HBM traffic per launch (separate --pmc passes)", "",
+          "| entities | FETCH_SIZE KiB (raw) | read bytes (x2, gfx950) | WRITE_SIZE KiB | write bytes | total bytes | algorithmic (384 B/entity) |",
+          "|---|---|---|---|---|---|---|"]
+for grid, c in sorted(pmc.items()):
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        f = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
+        w = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+        rd, wr = 2 * f * 1024, w * 1024
+        traffic[str(grid)] = {"fetch_size_kib_raw": f, "write_size_kib": w, "read_bytes": rd, "write_bytes": wr,
+                              "hbm_bytes_per_launch": rd + wr, "correction": "FETCH_SIZE x2 (gfx950), KiB units"}
+        lines.append(f"| {grid} | {f:.1f} | {rd:.0f} | {w:.1f} | {wr:.0f} | {rd+wr:.0f} | {384*grid} |")
+open(f"{out}/summary_{tag}.md", "w").write("\n".join(lines) + "\n")
+json.dump(traffic, open(f"{out}/pmc_traffic.json", "w"), indent=1)
+print("\n".join(lines))
