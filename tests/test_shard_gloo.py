@@ -1,0 +1,78 @@
+"""N>1 path on CPU: world_size-2 gloo process group exercising the same shard / broadcast / gather /
+max-over-ranks code bench.py and a Monte-Carlo campaign use on RCCL.  The stepping itself is done by the CPU
+oracle here (this is a test of the partitioning, not of the kernels)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from elodin_amd import shard, workloads
+from oracle import oracle as orc
+
+TOTAL, TICKS = 1000, 5
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _ops(w):
+    return [(orc.EFF_UNIFORM_GRAVITY, (0.0, 0.0, -9.81), None), (orc.EFF_BODY_TORQUE, (), w["body_torque"])]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard.shard_range(TOTAL, world, rank)
+        # campaign parameter table lives on rank 0 only
+        table = np.arange(TOTAL * 3, dtype=np.float64).reshape(TOTAL, 3) if rank == 0 else None
+        table = shard.broadcast_table(table, (TOTAL, 3))
+        w = workloads.independent_bodies(hi - lo, first_row=lo)
+        o = orc.OracleWorld(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ,
+                            ops=_ops(w)).step(TICKS)
+        result = np.concatenate([o.world_pos, table[lo:hi], w["entity_ids"][:, None].astype(np.float64)], axis=1)
+        gathered = shard.gather_rows(result, TOTAL)
+        t = shard.max_over_ranks(1.0 + rank)
+        if rank == 0:
+            q.put((gathered, t))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 65536, 8192 * 3 + 5):
+        for world in (1, 2, 3, 8):
+            r = [shard.shard_range(total, world, k) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert max(hi - lo for lo, hi in r) - min(hi - lo for lo, hi in r) <= 1
+    assert shard.run_id(41) == "run_0000041"
+    with pytest.raises(ValueError):
+        shard.shard_range(10, 2, 2)
+
+
+def test_two_rank_gloo_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gathered, t = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert t == 2.0  # MAX over ranks
+    w = workloads.independent_bodies(TOTAL)
+    o = orc.OracleWorld(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ,
+                        ops=_ops(w)).step(TICKS)
+    assert np.array_equal(gathered[:, :7], o.world_pos)            # sharding does not change a single bit
+    assert np.array_equal(gathered[:, 7:10], np.arange(TOTAL * 3, dtype=np.float64).reshape(TOTAL, 3))
+    assert np.array_equal(gathered[:, 10].astype(np.uint64), w["entity_ids"])  # entity indices bit-exact
