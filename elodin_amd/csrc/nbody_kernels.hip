@@ -32,6 +32,15 @@ namespace sixdof {
 
 constexpr int kTile = 256;  // sources staged per LDS tile = targets per workgroup
 
+// 1/sqrt(x) for x > 0 finite: hardware v_rsq_f64 seed plus one cubic correction
+// (y0 (1 + e/2 + 3e^2/8), e = 1 - x y0^2), full f64 accuracy without the 0/inf special-casing of the
+// library rsqrt.  x = 0 only occurs for the self pair with eps = 0, whose contribution is discarded.
+__device__ __forceinline__ double rsqrt_pos(double x) {
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y0, y0, 1.0);
+    return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
+
 uint32_t pair_splits_for(uint32_t n) {
     const uint32_t tblocks = (n + kTile - 1) / kTile;
     if (tblocks == 0) return 1;
@@ -74,7 +83,7 @@ __device__ __forceinline__ void tile_accumulate(const double* __restrict__ tile,
             const double ry = s[3 * st + 1] - pi[st][1];
             const double rz = s[3 * st + 2] - pi[st][2];
             const double d2 = fma(rz, rz, fma(ry, ry, fma(rx, rx, eps)));
-            const double inv = rsqrt(d2);
+            const double inv = rsqrt_pos(d2);
             double sc = mj * (inv * inv * inv);
             if (CHECK_SELF) sc = (j0 + jj == i) ? 0.0 : sc;  // i == j is not an edge (sim.py:333-337)
             acc[st][0] = fma(sc, rx, acc[st][0]);
