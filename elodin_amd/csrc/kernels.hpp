@@ -31,6 +31,8 @@ struct StepParams {
     double dt;                // six_dof(time_step=) override or dt_g (final combination / semi-implicit)
     uint32_t n_ops;
     uint32_t vel_independent; // 1: no op reads the stage velocity -> RK4 stages 1 and 2 share F and A
+    uint32_t streaming;       // host hint: working set >> Infinity Cache -> non-temporal loads/stores
+    uint32_t pad0;
     DevOp ops[kMaxOps];
 };
 

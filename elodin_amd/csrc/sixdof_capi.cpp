@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -431,6 +432,10 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
     P->n = static_cast<uint32_t>(h->desc.n_entities);
     P->dt_g = h->desc.simulation_time_step;
     P->dt = h->desc.has_time_step ? h->desc.time_step : h->desc.simulation_time_step;
+    // 25 state elements per entity; stream (non-temporal) once the world is well past the 256 MiB Infinity Cache
+    const char* force_nt = std::getenv("SIXDOF_STREAMING");
+    const size_t state_bytes = static_cast<size_t>(h->desc.n_entities) * 32 * h->elem_size();
+    P->streaming = force_nt ? (force_nt[0] == '1') : (state_bytes > (400ull << 20));
     return build_dev_ops(h, P->ops, &P->n_ops, &P->vel_independent);
 }
 

@@ -41,28 +41,38 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 // ---- slab movement ---------------------------------------------------------------------------------
 
 // Whole-wave slab of BYTES bytes (multiple of 16), global -> LDS by LDS-DMA.
-template <int BYTES>
+// NT = non-temporal cache policy (aux = 2) for worlds far larger than the 256 MiB Infinity Cache, where every
+// byte is touched exactly once per tick and retaining it only evicts useful lines.
+template <int BYTES, bool NT>
 __device__ __forceinline__ void slab_dma_in(const char* __restrict__ g, char* l, uint32_t lane) {
     constexpr int kFull = BYTES / 1024, kRem = (BYTES % 1024) / 16;
+    constexpr int kAux = NT ? 2 : 0;
 #pragma unroll
     for (int i = 0; i < kFull; i++)
-        __builtin_amdgcn_global_load_lds((global_cptr)(g + i * 1024 + lane * 16), (lds_ptr)(l + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((global_cptr)(g + i * 1024 + lane * 16), (lds_ptr)(l + i * 1024), 16, 0,
+                                         kAux);
     if (kRem && lane < (uint32_t)kRem)
         __builtin_amdgcn_global_load_lds((global_cptr)(g + kFull * 1024 + lane * 16), (lds_ptr)(l + kFull * 1024), 16,
-                                         0, 0);
+                                         0, kAux);
 }
 
 // Whole-wave slab, LDS -> global: read every chunk first, then issue the stores back to back.
-template <int BYTES>
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void store16(char* g, vfloat4 v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(g));
+    else *reinterpret_cast<vfloat4*>(g) = v;
+}
+template <int BYTES, bool NT>
 __device__ __forceinline__ void slab_out(const char* l, char* __restrict__ g, uint32_t lane) {
     constexpr int kFull = BYTES / 1024, kRem = (BYTES % 1024) / 16;
-    float4 tmp[kFull + 1];
+    vfloat4 tmp[kFull + 1];
 #pragma unroll
-    for (int i = 0; i < kFull; i++) tmp[i] = *reinterpret_cast<const float4*>(l + i * 1024 + lane * 16);
-    if (kRem && lane < (uint32_t)kRem) tmp[kFull] = *reinterpret_cast<const float4*>(l + kFull * 1024 + lane * 16);
+    for (int i = 0; i < kFull; i++) tmp[i] = *reinterpret_cast<const vfloat4*>(l + i * 1024 + lane * 16);
+    if (kRem && lane < (uint32_t)kRem) tmp[kFull] = *reinterpret_cast<const vfloat4*>(l + kFull * 1024 + lane * 16);
 #pragma unroll
-    for (int i = 0; i < kFull; i++) *reinterpret_cast<float4*>(g + i * 1024 + lane * 16) = tmp[i];
-    if (kRem && lane < (uint32_t)kRem) *reinterpret_cast<float4*>(g + kFull * 1024 + lane * 16) = tmp[kFull];
+    for (int i = 0; i < kFull; i++) store16<NT>(g + i * 1024 + lane * 16, tmp[i]);
+    if (kRem && lane < (uint32_t)kRem) store16<NT>(g + kFull * 1024 + lane * 16, tmp[kFull]);
 }
 
 // Ragged last wave (rows < 64): element-wise.
@@ -77,7 +87,7 @@ __device__ __forceinline__ void slab_out_tail(const T* l, T* __restrict__ g, uin
 
 // ---- the kernel --------------------------------------------------------------------------------------
 
-template <class T, int INTEGRATOR, class PIPE>
+template <class T, int INTEGRATOR, class PIPE, bool NT>
 __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) {
     // pos | vel | inertia on the way in (20 elems/entity); pos | vel | accel | force on the way out (25)
     __shared__ __attribute__((aligned(16))) T lds[kWave * 25];
@@ -98,9 +108,9 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     const T* const g_inertia = static_cast<const T*>(P.inertia) + (size_t)row0 * 7;
 
     if (full) {
-        slab_dma_in<kWave * 7 * sizeof(T)>(reinterpret_cast<const char*>(g_pos), reinterpret_cast<char*>(l_pos), t);
-        slab_dma_in<kWave * 6 * sizeof(T)>(reinterpret_cast<const char*>(g_vel), reinterpret_cast<char*>(l_vel), t);
-        slab_dma_in<kWave * 7 * sizeof(T)>(reinterpret_cast<const char*>(g_inertia), reinterpret_cast<char*>(l_c), t);
+        slab_dma_in<kWave * 7 * sizeof(T), NT>(reinterpret_cast<const char*>(g_pos), reinterpret_cast<char*>(l_pos), t);
+        slab_dma_in<kWave * 6 * sizeof(T), NT>(reinterpret_cast<const char*>(g_vel), reinterpret_cast<char*>(l_vel), t);
+        slab_dma_in<kWave * 7 * sizeof(T), NT>(reinterpret_cast<const char*>(g_inertia), reinterpret_cast<char*>(l_c), t);
     } else {
         slab_in_tail(g_pos, l_pos, rows * 7, t);
         slab_in_tail(g_vel, l_vel, rows * 6, t);
@@ -226,10 +236,10 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     }
     __syncthreads();
     if (full) {
-        slab_out<kWave * 7 * sizeof(T)>(reinterpret_cast<const char*>(l_pos), reinterpret_cast<char*>(g_pos), t);
-        slab_out<kWave * 6 * sizeof(T)>(reinterpret_cast<const char*>(l_vel), reinterpret_cast<char*>(g_vel), t);
-        slab_out<kWave * 6 * sizeof(T)>(reinterpret_cast<const char*>(l_c), reinterpret_cast<char*>(g_accel), t);
-        slab_out<kWave * 6 * sizeof(T)>(reinterpret_cast<const char*>(l_force), reinterpret_cast<char*>(g_force), t);
+        slab_out<kWave * 7 * sizeof(T), NT>(reinterpret_cast<const char*>(l_pos), reinterpret_cast<char*>(g_pos), t);
+        slab_out<kWave * 6 * sizeof(T), NT>(reinterpret_cast<const char*>(l_vel), reinterpret_cast<char*>(g_vel), t);
+        slab_out<kWave * 6 * sizeof(T), NT>(reinterpret_cast<const char*>(l_c), reinterpret_cast<char*>(g_accel), t);
+        slab_out<kWave * 6 * sizeof(T), NT>(reinterpret_cast<const char*>(l_force), reinterpret_cast<char*>(g_force), t);
     } else {
         slab_out_tail(l_pos, g_pos, rows * 7, t);
         slab_out_tail(l_vel, g_vel, rows * 6, t);
@@ -248,10 +258,16 @@ using PipeGravityTorque = PipeStatic<SIXDOF_EFF_UNIFORM_GRAVITY, SIXDOF_EFF_BODY
 using PipeGravityDrag = PipeStatic<SIXDOF_EFF_UNIFORM_GRAVITY, SIXDOF_EFF_BALL_DRAG>;
 using PipeGravityThrustTorque = PipeStatic<SIXDOF_EFF_UNIFORM_GRAVITY, SIXDOF_EFF_BODY_FORCE, SIXDOF_EFF_BODY_TORQUE>;
 
+template <class T, class PIPE, bool NT>
+void launch_i(const StepParams& p, int integrator, dim3 grid, hipStream_t s) {
+    if (integrator == kRk4) hipLaunchKernelGGL((sixdof_step_kernel<T, kRk4, PIPE, NT>), grid, dim3(kWave), 0, s, p);
+    else hipLaunchKernelGGL((sixdof_step_kernel<T, kSemiImplicit, PIPE, NT>), grid, dim3(kWave), 0, s, p);
+}
+
 template <class T, class PIPE>
 void launch_t(const StepParams& p, int integrator, dim3 grid, hipStream_t s) {
-    if (integrator == kRk4) hipLaunchKernelGGL((sixdof_step_kernel<T, kRk4, PIPE>), grid, dim3(kWave), 0, s, p);
-    else hipLaunchKernelGGL((sixdof_step_kernel<T, kSemiImplicit, PIPE>), grid, dim3(kWave), 0, s, p);
+    if (p.streaming) launch_i<T, PIPE, true>(p, integrator, grid, s);
+    else launch_i<T, PIPE, false>(p, integrator, grid, s);
 }
 
 template <class PIPE>
