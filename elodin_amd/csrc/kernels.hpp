@@ -71,4 +71,23 @@ struct PairParams {
 uint32_t pair_splits_for(uint32_t n);
 hipError_t launch_pair_tick(const PairParams& p, int integrator, hipStream_t stream, uint64_t* launches);
 
+// ---- Apollo-lander rollout model (include/sixdof_apollo.h) ---------------------------------------------
+struct ApolloParams {
+    double *pos, *vel, *accel, *force, *inertia;  // Body columns
+    double* state;           // [n,16]
+    const double* params;    // [n,17]
+    double* guidance;        // [n,8]
+    double* score;           // [n,4]
+    double* result;          // [n,12]
+    const double* tick_refs; // [n_ticks,8] per-tick reference profile values, device
+    uint32_t n;
+    uint32_t n_ticks;
+    uint64_t tick0;          // tick count before this launch
+    uint64_t max_ticks;
+    uint32_t guidance_period;
+    uint32_t pad;
+    double dt;               // globals simulation_time_step
+};
+hipError_t launch_apollo(const ApolloParams& p, hipStream_t stream);
+
 }  // namespace sixdof

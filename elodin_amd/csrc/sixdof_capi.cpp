@@ -11,6 +11,7 @@
 // SIXDOF_ERR_BACKEND when HIP is unavailable.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -22,6 +23,7 @@
 #include <vector>
 
 #include "../../include/sixdof_hip.h"
+#include "../../include/sixdof_apollo.h"
 #include "kernels.hpp"
 
 using namespace sixdof;
@@ -69,6 +71,13 @@ struct sixdof_handle {
     size_t scratch_bytes = 0;
     uint64_t tick = 0;
     bool bound = false;
+    // rollout model (0 = none, 1 = Apollo lander)
+    int model = 0;
+    std::vector<double> ap_time, ap_alt, ap_rate, ap_pitch, ap_hspeed, ap_downrange;
+    uint32_t ap_guidance_period = 5;
+    uint64_t ap_max_ticks = 0;
+    double* d_tick_refs = nullptr;
+    size_t tick_refs_cap = 0;
     // graph cache for long batches
     hipGraphExec_t graph_exec = nullptr;
     uint32_t graph_k = 0, graph_len = 0;
@@ -207,6 +216,7 @@ void sixdof_destroy(sixdof_handle* h) {
     if (h->d_csr_start) hipFree(h->d_csr_start);
     if (h->d_csr_dst) hipFree(h->d_csr_dst);
     if (h->d_scratch) hipFree(h->d_scratch);
+    if (h->d_tick_refs) hipFree(h->d_tick_refs);
     for (hipEvent_t e : h->launch_events) hipEventDestroy(e);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -482,9 +492,116 @@ int fill_pair_params(sixdof_handle* h, PairParams* P) {
     return build_dev_ops(h, P->ops, &P->n_ops, &vi);
 }
 
+// reference.py:164-175 (bisect_right interpolation), evaluated once per tick on the host: every rollout
+// of a campaign sees the same reference profile at a given tick.
+double ref_interp(double t, const std::vector<double>& xs, const std::vector<double>& ys) {
+    const size_t n = xs.size();
+    if (t <= xs[0]) return ys[0];
+    if (t >= xs[n - 1]) return ys[n - 1];
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (t < xs[mid]) hi = mid; else lo = mid + 1;
+    }
+    const size_t a = lo - 1, b = lo;
+    const double span = xs[b] - xs[a];
+    if (span <= 0.0) return ys[a];
+    const double frac = (t - xs[a]) / span;
+    return ys[a] + (ys[b] - ys[a]) * frac;
+}
+
+int step_apollo(sixdof_handle* h, uint64_t n_ticks, uint64_t* launches) {
+    const char* names[5] = {"apollo_state", "apollo_params", "apollo_guidance", "apollo_score", "apollo_result"};
+    const uint64_t widths[5] = {APOLLO_N_STATE, APOLLO_N_PARAMS, APOLLO_N_GUIDANCE, APOLLO_N_SCORE, APOLLO_N_RESULT};
+    Column* c[5];
+    for (int k = 0; k < 5; k++) {
+        c[k] = h->col(cid(names[k]));
+        if (!c[k]) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, std::string("step: Apollo model column not bound: ") + names[k]);
+        if (c[k]->width != widths[k] || c[k]->n_rows != h->desc.n_entities || c[k]->prim != SIXDOF_PRIM_F64)
+            return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, std::string("step: bad shape for ") + names[k]);
+    }
+    ApolloParams P{};
+    P.pos = static_cast<double*>(h->col(h->id_pos)->dev);
+    P.vel = static_cast<double*>(h->col(h->id_vel)->dev);
+    P.accel = static_cast<double*>(h->col(h->id_accel)->dev);
+    P.force = static_cast<double*>(h->col(h->id_force)->dev);
+    P.inertia = static_cast<double*>(h->col(h->id_inertia)->dev);
+    P.state = static_cast<double*>(c[0]->dev);
+    P.params = static_cast<const double*>(c[1]->dev);
+    P.guidance = static_cast<double*>(c[2]->dev);
+    P.score = static_cast<double*>(c[3]->dev);
+    P.result = static_cast<double*>(c[4]->dev);
+    P.n = static_cast<uint32_t>(h->desc.n_entities);
+    P.max_ticks = h->ap_max_ticks;
+    P.guidance_period = h->ap_guidance_period;
+    P.dt = h->desc.simulation_time_step;
+    const uint32_t K = h->desc.ticks_per_launch;
+    if (K > h->tick_refs_cap) {
+        if (h->d_tick_refs) hipFree(h->d_tick_refs), h->d_tick_refs = nullptr;
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tick_refs), static_cast<size_t>(K) * 8 * sizeof(double)));
+        h->tick_refs_cap = K;
+    }
+    std::vector<double> refs(static_cast<size_t>(K) * 8);
+    uint64_t done = 0;
+    while (done < n_ticks) {
+        const uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(K, n_ticks - done));
+        for (uint32_t j = 0; j < k; j++) {
+            const double t_s = static_cast<double>(h->tick + done + j + 1) * (1.0 / 120.0);  // tick * SIM_TIME_STEP
+            double* r = &refs[static_cast<size_t>(j) * 8];
+            r[0] = ref_interp(t_s, h->ap_time, h->ap_alt);
+            r[1] = ref_interp(t_s, h->ap_time, h->ap_rate);
+            r[2] = std::fabs(ref_interp(t_s, h->ap_time, h->ap_pitch));
+            r[3] = ref_interp(t_s, h->ap_time, h->ap_hspeed);
+            r[4] = ref_interp(t_s, h->ap_time, h->ap_downrange);
+            r[5] = r[3] - ref_interp(t_s + 1.0, h->ap_time, h->ap_hspeed);
+            r[6] = r[7] = 0.0;
+        }
+        // stream-ordered: the previous launch has consumed the buffer before this copy executes
+        HIP_TRY(h, hipMemcpyAsync(h->d_tick_refs, refs.data(), static_cast<size_t>(k) * 8 * sizeof(double),
+                                  hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));  // `refs` is reused by the next chunk
+        P.tick_refs = h->d_tick_refs;
+        P.n_ticks = k;
+        P.tick0 = h->tick + done;
+        hipError_t e = launch_apollo(P, h->stream);
+        if (e != hipSuccess) return h->hip_fail(e, "launch_apollo");
+        (*launches)++;
+        done += k;
+    }
+    return SIXDOF_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int sixdof_set_model_apollo(sixdof_handle* h, const sixdof_apollo_tables* t) {
+    if (!h || !t || t->n < 2 || !t->time_s || !t->altitude_m || !t->descent_rate_mps || !t->pitch_deg ||
+        !t->horizontal_speed_mps || !t->downrange_m)
+        return SIXDOF_ERR_INVALID_ARGUMENT;
+    if (h->desc.integrator != SIXDOF_INTEGRATOR_SEMI_IMPLICIT || h->desc.dtype != SIXDOF_F64)
+        return h->fail(SIXDOF_ERR_UNSUPPORTED, "set_model_apollo: the example uses el.Integrator.SemiImplicit in f64 (sim.py:523)");
+    h->ap_time.assign(t->time_s, t->time_s + t->n);
+    h->ap_alt.assign(t->altitude_m, t->altitude_m + t->n);
+    h->ap_rate.assign(t->descent_rate_mps, t->descent_rate_mps + t->n);
+    h->ap_pitch.assign(t->pitch_deg, t->pitch_deg + t->n);
+    h->ap_hspeed.assign(t->horizontal_speed_mps, t->horizontal_speed_mps + t->n);
+    h->ap_downrange.assign(t->downrange_m, t->downrange_m + t->n);
+    h->ap_guidance_period = t->guidance_period_ticks ? t->guidance_period_ticks : 5;
+    h->ap_max_ticks = t->max_ticks;
+    h->model = 1;
+    return SIXDOF_OK;
+}
+
+int sixdof_download_column(sixdof_handle* h, uint64_t component_id) {
+    if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
+    Column* c = h->col(component_id);
+    if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "download_column: unknown component");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (c->bytes) HIP_TRY(h, hipMemcpyAsync(c->host, c->dev, c->bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SIXDOF_OK;
+}
 
 int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
@@ -493,7 +610,10 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
     const double t0 = now_ms();
     uint64_t launches = 0;
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    if (h->has_pair_op()) {
+    if (h->model == 1) {
+        int rc = step_apollo(h, n_ticks, &launches);
+        if (rc != SIXDOF_OK) return rc;
+    } else if (h->has_pair_op()) {
         if (h->desc.dtype != SIXDOF_F64) return h->fail(SIXDOF_ERR_UNSUPPORTED, "step: pair effectors are f64 only");
         PairParams P;
         int rc = fill_pair_params(h, &P);

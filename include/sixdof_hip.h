@@ -203,6 +203,16 @@ void sixdof_tick(const uint8_t* const* inputs, uint8_t* const* outputs);
 int sixdof_tick_slots(const sixdof_handle* h, sixdof_slot* inputs, size_t in_cap, size_t* n_in,
                       sixdof_slot* outputs, size_t out_cap, size_t* n_out);
 
+/* ---- rollout models: systems piped AROUND six_dof, fused with it (the pipes of examples/<name>/sim.py) ------------- */
+struct sixdof_apollo_tables; /* include/sixdof_apollo.h */
+/* Select the Apollo-lander rollout model (examples/apollo-lander/sim.py:517-526 + the guidance sidecar
+ * controller/src/main.rs).  Needs, besides the Body columns, the columns "apollo_state" [n,16],
+ * "apollo_params" [n,17], "apollo_guidance" [n,8], "apollo_score" [n,4], "apollo_result" [n,12] bound
+ * with sixdof_bind_columns; integrator must be SEMI_IMPLICIT, dtype F64.  Tables are copied. */
+int sixdof_set_model_apollo(sixdof_handle* h, const struct sixdof_apollo_tables* tables);
+/* D2H of any bound column by id (model columns are not covered by the sixdof_download mask). */
+int sixdof_download_column(sixdof_handle* h, uint64_t component_id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,8 +50,8 @@ class _World(C.Structure):
 
 def build(force: bool = False) -> Path:
     """Compile the oracle with gcc (no-FMA).  Building the checker is not using it."""
-    src = HERE / "sixdof_oracle.c"
-    if force or not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < src.stat().st_mtime:
+    newest = max((HERE / f).stat().st_mtime for f in ("sixdof_oracle.c", "apollo_oracle.c", "sixdof_oracle.h", "apollo_oracle.h"))
+    if force or not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < newest:
         subprocess.run(["make", "-C", str(HERE), "-B", "libsixdof_oracle.so"], check=True,
                        stdout=subprocess.DEVNULL)
     return LIB_PATH

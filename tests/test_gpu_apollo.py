@@ -1,0 +1,87 @@
+"""GPU parity of the Apollo-lander rollout model vs its CPU restatement (same plan, same tables)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from elodin_amd import monte_carlo as mc
+from elodin_amd.models import apollo
+from oracle.apollo import ApolloOracle
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+PLANS = Path(__file__).resolve().parent / "golden" / "plans"
+
+
+def _plan_table(name):
+    return mc.materialize(mc.load_spec(PLANS / f"{name}.toml")).table()
+
+
+def _compare(hip, ref, rtol=parity.F64_RTOL):
+    errs = {"world_pos": parity.pos_rel_err(hip.world_pos, ref.world_pos)}
+    for f in ("world_vel", "world_accel", "force"):
+        g, r = getattr(hip, f), getattr(ref, f)
+        # landed rollouts have exactly zero velocity; scale by a floor so 0 vs 0 is fine
+        errs[f] = max(parity.field_rel_err(g[:, :3], r[:, :3]), parity.field_rel_err(g[:, 3:], r[:, 3:]))
+    st_h, st_r = hip.model["apollo_state"], ref.apollo_state
+    scale = np.maximum(np.abs(st_r), 1e-3)
+    errs["apollo_state"] = float(np.max(np.abs(st_h - st_r) / scale))
+    errs["inertia"] = parity.field_rel_err(hip.inertia, ref.inertia)
+    return errs
+
+
+@pytest.mark.parametrize("ticks_per_launch", [1, 7, 120])
+def test_apollo_512_rollouts_3000_ticks(ticks_per_launch):
+    """Braking phase: 512 LHS rollouts of the reference's spec, 25 s of flight, guidance at 24 Hz."""
+    ref_tab = apollo.load_reference()
+    P = _plan_table("apollo_512")
+    hip = apollo.ApolloExec(P, ref=ref_tab, ticks_per_launch=ticks_per_launch)
+    orc_w = ApolloOracle(apollo.initial_columns(P, ref_tab), ref_tab, max_ticks=apollo.max_ticks(ref_tab))
+    hip.run(3000)
+    orc_w.step(3000, threads=8)
+    errs = _compare(hip, orc_w)
+    print("apollo 3000 ticks", ticks_per_launch, errs)
+    assert max(errs.values()) < 1e-8, errs
+    assert hip.tick == orc_w.tick == 3000
+    # guidance latch / bookkeeping columns are exact
+    assert np.array_equal(hip.model["apollo_guidance"][:, 6:], orc_w.guidance[:, 6:])
+    assert np.array_equal(hip.model["apollo_score"][:, 2], orc_w.score[:, 2])
+
+
+def test_apollo_full_descent_results():
+    """The example's own 30-rollout plan flown to the surface; campaign results agree with the CPU restatement."""
+    ref_tab = apollo.load_reference()
+    P = _plan_table("apollo")
+    n_ticks = apollo.max_ticks(ref_tab)
+    hip = apollo.ApolloExec(P, ref=ref_tab, ticks_per_launch=240)
+    orc_w = ApolloOracle(apollo.initial_columns(P, ref_tab), ref_tab, max_ticks=n_ticks)
+    hip.run(n_ticks)
+    orc_w.step(n_ticks, threads=8)
+    res_h, res_o = hip.result, orc_w.result
+    # discrete outcomes identical; touchdown tick may not move
+    assert np.array_equal(res_h[:, 8], res_o[:, 8]) and np.all(res_h[:, 8] == 1.0)     # landed
+    assert np.array_equal(res_h[:, 10], res_o[:, 10])                                  # tick of touchdown
+    assert np.array_equal(res_h[:, 9], res_o[:, 9])                                    # soft_landing verdicts
+    # 55,000 ticks of closed-loop flight with clamps and latches: continuous results to 1e-6 relative
+    cont = [0, 1, 2, 3, 4, 5, 6, 7]
+    rel = np.abs(res_h[:, cont] - res_o[:, cont]) / np.maximum(np.abs(res_o[:, cont]), 1e-3)
+    print("apollo full descent: worst result rel err", rel.max(), "soft fraction", res_h[:, 9].mean())
+    assert rel.max() < 1e-6
+
+
+def test_apollo_requires_model_columns_and_semi_implicit():
+    import elodin_amd as ea
+    from elodin_amd import _lib as L
+    import ctypes as C
+    h = ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (4, 1)), np.zeros((4, 6)), np.ones((4, 7)))  # RK4
+    t = apollo.Tables()
+    a = np.arange(4, dtype=np.float64)
+    t.time_s = t.altitude_m = t.descent_rate_mps = t.pitch_deg = t.horizontal_speed_mps = t.downrange_m = a.ctypes.data
+    t.n = 4
+    fn = L.lib().sixdof_set_model_apollo
+    fn.argtypes, fn.restype = [C.c_void_p, C.POINTER(apollo.Tables)], C.c_int
+    assert fn(h._h, C.byref(t)) == L.ERR_UNSUPPORTED
+    h2 = ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (4, 1)), np.zeros((4, 6)), np.ones((4, 7)), integrator=L.SEMI_IMPLICIT)
+    assert fn(h2._h, C.byref(t)) == L.OK
+    with pytest.raises(KeyError):   # model columns not bound -> Error::ComponentNotFound
+        h2.invoke_batch(1)
