@@ -14,8 +14,9 @@ collective — torch.distributed is only the launcher's barrier and the max-over
 Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel, ticks_per_launch = 1,
 algorithmic bytes 360 + 24 = 384 B/entity-step against the 8 TB/s HBM peak), `roofline_hbm` (same kernel at
 4,194,304 bodies, where the working set leaves the 256 MiB Infinity Cache and the kernel really
-streams from HBM), `fused` (ticks_per_launch = 64: state in registers, VALU-bound) and
-`cpu_baseline` (the CPU oracle on the host cores, bounded sample, N=1 only).
+streams from HBM), `fused` (ticks_per_launch = 64: state in registers, VALU-bound), `nbody` / `apollo_mc`
+(timings of BASELINE configs[2] / configs[3] on this GPU) and `cpu_baseline` (the CPU oracle on the host
+cores, bounded sample, N=1 only).
 """
 from __future__ import annotations
 
@@ -77,6 +78,48 @@ def kernel_roofline(ex, n, steps, warmup):
     t = ex.invoke_batch(steps)
     return roofline_from(t.kernel_device_ms / max(1, t.launches), n, t.launches,
                          "HIP events around the batch on the launch stream / launches")
+
+
+def nbody_leg(device):
+    """BASELINE configs[2]: all-pairs softened gravity, 16,384 bodies, RK4 f64 (parity case; timing for reference)."""
+    import elodin_amd as ea
+    from elodin_amd import _lib as L
+    n = 16384
+    rng = np.random.default_rng(7)
+    u = rng.uniform(0.05, 0.95, n)
+    d = rng.normal(size=(n, 3))
+    p = d / np.linalg.norm(d, axis=1, keepdims=True) * (1.0 / np.sqrt(u ** (-2.0 / 3.0) - 1.0))[:, None]  # Plummer, a = 1 AU
+    m = rng.uniform(1e-9, 1e-3, n)
+    pos = np.concatenate([np.tile([0, 0, 0, 1.0], (n, 1)), p], axis=1)
+    vel = np.concatenate([np.zeros((n, 3)), rng.normal(scale=1e-7, size=(n, 3))], axis=1)
+    inertia = np.concatenate([np.tile(m[:, None], (1, 3)), np.zeros((n, 3)), m[:, None]], axis=1)
+    ex = ea.HipExec(pos, vel, inertia, simulation_time_step=3600.0, device=device,
+                    effectors=[ea.Effector(L.EFF_ALLPAIRS_GRAVITY_SOFTENED, (2.9591220828e-4 / 86400.0 ** 2, 1.0e-10))])
+    ex.invoke_batch(3)
+    t = ex.invoke_batch(20)
+    ex.close()
+    ms = t.kernel_device_ms / 20
+    evals = 3.0 * n * (n - 1)   # every pair is visited once per tick and accumulates the 3 distinct stage forces
+    return {"bodies": n, "ms_per_tick": round(ms, 4), "body_steps_per_s": round(n / ms * 1e3, 1),
+            "pair_evals_per_s": round(evals / ms * 1e3, 1), "bound": "f64 vector ALU",
+            "f64_instr_per_eval": 17, "frac_of_f64_fma_issue_peak": round(evals * 17 / (ms * 1e-3) / 39.3e12, 4)}
+
+
+def apollo_leg(device):
+    """BASELINE configs[3]: Apollo-lander Monte-Carlo, 8,192 rollouts x 10,000 steps (one GPU's worth here)."""
+    from elodin_amd import monte_carlo as mc
+    from elodin_amd.models import apollo
+    spec = mc.load_spec(ROOT / "tests" / "golden" / "plans" / "apollo.toml")
+    spec["monte_carlo"]["n_samples"] = 8192
+    P = mc.materialize(spec).table()
+    ex = apollo.ApolloExec(P, ticks_per_launch=1000, device=device)
+    ex.invoke_batch(1000)
+    t0 = time.perf_counter()
+    tm = ex.invoke_batch(10000)
+    dt = time.perf_counter() - t0
+    ex.close()
+    return {"rollouts": 8192, "steps": 10000, "seconds": round(dt, 5), "rollout_steps_per_s": round(8192 * 10000 / dt, 1),
+            "launches": tm.launches, "integrator": "semi-implicit", "guidance": "in-kernel, 24 Hz"}
 
 
 def cpu_baseline(w, eff, target_seconds=10.0):
@@ -188,6 +231,9 @@ def main():
         r = kernel_roofline(bex, big, 64, 8)
         bex.close()
         out["roofline_hbm"] = r
+    if rank == 0 and not args.no_extras:
+        out["nbody"] = nbody_leg(local_rank)
+        out["apollo_mc"] = apollo_leg(local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, eff)
     if distributed:

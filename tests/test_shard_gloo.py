@@ -76,3 +76,57 @@ def test_two_rank_gloo_matches_single_process():
     assert np.array_equal(gathered[:, :7], o.world_pos)            # sharding does not change a single bit
     assert np.array_equal(gathered[:, 7:10], np.arange(TOTAL * 3, dtype=np.float64).reshape(TOTAL, 3))
     assert np.array_equal(gathered[:, 10].astype(np.uint64), w["entity_ids"])  # entity indices bit-exact
+
+
+# ---- Apollo campaign over 2 gloo ranks (executor = CPU oracle; the GPU executor is covered by -m gpu tests) ----
+
+class _OracleExec:
+    def __init__(self, block, first_row):
+        from elodin_amd.models import apollo
+        from oracle.apollo import ApolloOracle
+        ref = apollo.load_reference()
+        self._o = ApolloOracle(apollo.initial_columns(block, ref), ref, max_ticks=apollo.max_ticks(ref))
+
+    def run(self, n):
+        self._o.step(n)
+
+    @property
+    def result(self):
+        return self._o.result
+
+
+def _campaign_worker(rank, world, port, q):
+    from pathlib import Path
+    from elodin_amd import monte_carlo as mc
+    from elodin_amd.models import apollo
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        table = None
+        if rank == 0:
+            table = mc.materialize(mc.load_spec(Path(__file__).parent / "golden" / "plans" / "apollo.toml")).table()
+        res = apollo.run_campaign(table, 30, 59041, make_exec=_OracleExec)
+        if rank == 0:
+            q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_apollo_campaign_two_ranks_equals_one():
+    from pathlib import Path
+    from elodin_amd import monte_carlo as mc
+    from elodin_amd.models import apollo
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_campaign_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res2 = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    table = mc.materialize(mc.load_spec(Path(__file__).parent / "golden" / "plans" / "apollo.toml")).table()
+    res1 = apollo.run_campaign(table, 30, 59041, make_exec=_OracleExec)
+    assert res2.shape == (30, 12) and np.array_equal(res1, res2)     # run-id order, bit-identical
+    assert np.all(res2[:, 8] == 1.0)

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import elodin_amd as ea
 from elodin_amd import _lib as L
 from tests.test_gpu_parity import _plummer, K_SQ, EPS_AU2

@@ -1,5 +1,5 @@
 import sys, os, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import elodin_amd as ea
 from elodin_amd import workloads
 for n in [int(x) for x in sys.argv[1:]] or (65536, 1 << 22):
