@@ -1,0 +1,319 @@
+"""Host-side mirror of the reference's Python surface for the six_dof path.
+
+Same names and argument meaning as `elodin` (libs/nox-py/python/elodin/__init__.py,
+elodin.pyi) for the pieces this backend covers, so a sim script / test for this path reads like the
+reference's:
+
+    w = World()
+    a = w.spawn(Body(world_pos=SpatialTransform(linear=[0.89, 0, 0]), inertia=SpatialInertia(1 / G)), name="A")
+    w.spawn(GravityEdge(a, b)) ...
+    sys = six_dof(sys=gravity_newton(G))
+    exec = w.build(sys, simulation_rate=120.0)
+    exec.run(100)
+    exec.column_array("world_pos")
+
+What differs, on purpose: `sys` is a pipe of built-in effector descriptors (include/sixdof_hip.h
+sixdof_effector_kind) instead of arbitrary JAX, and `build` returns an executor bound to the HIP
+backend (there is no other backend; no GPU -> BackendError).  Column storage follows
+libs/nox-py/src/world.rs:23-45,193-229: per component a row-major buffer + entity ids in spawn order,
+ids sequential from `entity_len`, entity 0 = "Globals" holding tick and simulation_time_step.
+"""
+from __future__ import annotations
+
+import enum
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib as L
+from .exec import Effector, HipExec, TickTimings
+
+
+# ---- spatial value types (libs/nox-py/src/spatial.rs:21-449) --------------------------------------------
+
+class Quaternion:
+    """Scalar-last [x, y, z, w] (libs/nox/src/quaternion.rs:90-102)."""
+
+    def __init__(self, arr=(0.0, 0.0, 0.0, 1.0)):
+        self.arr = np.asarray(arr, dtype=np.float64).reshape(4)
+
+    @staticmethod
+    def identity() -> "Quaternion":
+        return Quaternion()
+
+    @staticmethod
+    def from_axis_angle(axis, angle) -> "Quaternion":
+        axis = np.asarray(axis, dtype=np.float64)
+        axis = axis / np.sqrt(np.dot(axis, axis))
+        half = float(angle) / 2.0
+        return Quaternion(np.concatenate([axis * np.sin(half), [np.cos(half)]]))
+
+    def vector(self) -> np.ndarray:
+        return self.arr
+
+
+class SpatialTransform:
+    def __init__(self, arr=None, angular: Optional[Quaternion] = None, linear=None):
+        if arr is not None:
+            self.arr = np.asarray(arr, dtype=np.float64).reshape(7)
+        else:
+            q = (angular or Quaternion.identity()).vector()
+            p = np.zeros(3) if linear is None else np.asarray(linear, dtype=np.float64)
+            self.arr = np.concatenate([q, p])
+
+    def linear(self): return self.arr[4:]
+    def angular(self): return Quaternion(self.arr[:4])
+
+
+class _Spatial6:
+    def __init__(self, arr=None, first=None, linear=None):
+        if arr is not None:
+            self.arr = np.asarray(arr, dtype=np.float64).reshape(6)
+        else:
+            a = np.zeros(3) if first is None else np.asarray(first, dtype=np.float64)
+            b = np.zeros(3) if linear is None else np.asarray(linear, dtype=np.float64)
+            self.arr = np.concatenate([a, b])
+
+    def linear(self): return self.arr[3:]
+
+
+class SpatialMotion(_Spatial6):
+    def __init__(self, arr=None, angular=None, linear=None):
+        super().__init__(arr, angular, linear)
+
+    def angular(self): return self.arr[:3]
+
+
+class SpatialForce(_Spatial6):
+    def __init__(self, arr=None, torque=None, linear=None):
+        super().__init__(arr, torque, linear)
+
+    def torque(self): return self.arr[:3]
+    def force(self): return self.arr[3:]
+
+
+class SpatialInertia:
+    """[Ixx, Iyy, Izz, px, py, pz, m]; inertia defaults to ones(3) * mass (spatial.rs:392-405)."""
+
+    def __init__(self, mass, inertia=None):
+        mass = float(mass)
+        diag = np.ones(3) * mass if inertia is None else np.asarray(inertia, dtype=np.float64)
+        self.arr = np.concatenate([diag, np.zeros(3), [mass]])
+
+    def mass(self): return self.arr[6]
+    def inertia_diag(self): return self.arr[:3]
+
+
+class EntityId(int):
+    pass
+
+
+class Integrator(enum.Enum):  # integrator/mod.rs:7-10
+    Rk4 = L.RK4
+    SemiImplicit = L.SEMI_IMPLICIT
+
+
+# ---- archetypes ---------------------------------------------------------------------------------------------
+
+@dataclass
+class Body:
+    """six_dof.rs:152-159 / __init__.py:663-669: identity pose, zero velocity, unit mass by default."""
+    world_pos: SpatialTransform = field(default_factory=SpatialTransform)
+    world_vel: SpatialMotion = field(default_factory=SpatialMotion)
+    inertia: SpatialInertia = field(default_factory=lambda: SpatialInertia(1.0))
+    force: SpatialForce = field(default_factory=SpatialForce)
+    world_accel: SpatialMotion = field(default_factory=SpatialMotion)
+
+    def components(self):
+        return {"world_pos": self.world_pos.arr, "world_vel": self.world_vel.arr, "inertia": self.inertia.arr,
+                "force": self.force.arr, "world_accel": self.world_accel.arr}
+
+
+@dataclass
+class C:
+    """el.C(Component, value): one extra component on the entity being spawned (f64 vector)."""
+    name: str
+    value: Sequence[float]
+
+    def components(self):
+        return {self.name: np.atleast_1d(np.asarray(self.value, dtype=np.float64))}
+
+
+@dataclass
+class GravityEdge:
+    """An Edge component entity (el.Edge(from, to), graph.rs:17-41) — consumes an entity id like any spawn."""
+    a: int
+    b: int
+    component: str = "gravity_edge"
+
+
+# ---- systems --------------------------------------------------------------------------------------------------
+
+@dataclass
+class Effectors:
+    """A pipe of built-in effector descriptors; compose with `|` like reference systems (system.rs:1001-1011)."""
+    ops: List[Effector] = field(default_factory=list)
+    edge_component: Optional[str] = None
+
+    def __or__(self, other: "Effectors") -> "Effectors":
+        return Effectors(self.ops + other.ops, other.edge_component or self.edge_component)
+
+
+def uniform_gravity(g=(0.0, 0.0, -9.81)) -> Effectors:          # examples/ball/sim.py:57-59
+    return Effectors([Effector(L.EFF_UNIFORM_GRAVITY, tuple(g))])
+
+
+def constant_wrench(torque=(0, 0, 0), force=(0, 0, 0)) -> Effectors:   # test_all.py:353-356
+    return Effectors([Effector(L.EFF_CONST_WRENCH, tuple(torque) + tuple(force))])
+
+
+def body_torque(component: str) -> Effectors:                     # apollo-lander/sim.py:396-398
+    return Effectors([Effector(L.EFF_BODY_TORQUE, (), aux_name=component)])
+
+
+def body_force(component: str) -> Effectors:                      # apollo-lander/sim.py:391-394
+    return Effectors([Effector(L.EFF_BODY_FORCE, (), aux_name=component)])
+
+
+def ball_drag(wind_component: str, cd=0.5, rho=1.225, area=2 * 3.1415 * 0.2**2) -> Effectors:  # ball/sim.py:96-116
+    return Effectors([Effector(L.EFF_BALL_DRAG, (cd, rho, area), aux_name=wind_component)])
+
+
+def gravity_newton(G: float, edge_component: str = "gravity_edge") -> Effectors:   # three-body/main.py:56-78
+    return Effectors([Effector(L.EFF_EDGE_GRAVITY_NEWTON, (G,))], edge_component)
+
+
+def gravity_softened(K: float, eps: float, edge_component: Optional[str] = "gravity_edge") -> Effectors:
+    """examples/n-body/sim.py:344-369 over explicit edges; edge_component=None = complete graph, tiled kernel."""
+    kind = L.EFF_EDGE_GRAVITY_SOFTENED if edge_component else L.EFF_ALLPAIRS_GRAVITY_SOFTENED
+    return Effectors([Effector(kind, (K, eps))], edge_component)
+
+
+@dataclass
+class System:
+    time_step: Optional[float]
+    effectors: Effectors
+    integrator: Integrator
+
+
+def six_dof(time_step: Optional[float] = None, sys: Optional[Effectors] = None,
+            integrator: Integrator = Integrator.Rk4) -> System:
+    """elodin.six_dof(time_step=None, sys=None, integrator=Integrator.Rk4) — lib.rs:106-127, six_dof.rs:161-203."""
+    if not isinstance(integrator, Integrator):
+        raise TypeError("integrator must be an Integrator")
+    return System(time_step, sys or Effectors(), integrator)
+
+
+# ---- world ----------------------------------------------------------------------------------------------------
+
+class World:
+    def __init__(self):
+        self._cols: Dict[str, List[np.ndarray]] = {}
+        self._ids: Dict[str, List[int]] = {}
+        self._names: Dict[int, str] = {0: "Globals"}
+        self._edges: Dict[str, List[tuple]] = {}
+        self.entity_len = 1   # Globals took id 0 (world.rs:174-183)
+
+    def spawn(self, archetypes, name: Optional[str] = None) -> EntityId:
+        eid = EntityId(self.entity_len)
+        self.entity_len += 1
+        self.insert(eid, archetypes)
+        if name is not None:
+            self._names[int(eid)] = name
+        return eid
+
+    def insert(self, eid: EntityId, archetypes) -> None:
+        if not isinstance(archetypes, (list, tuple)):
+            archetypes = [archetypes]
+        for arch in archetypes:
+            if isinstance(arch, GravityEdge):
+                self._edges.setdefault(arch.component, []).append((int(arch.a), int(arch.b)))
+                continue
+            for cname, value in arch.components().items():
+                value = np.ascontiguousarray(value, dtype=np.float64)   # lib.rs:64-75: C-contiguous rows
+                rows = self._cols.setdefault(cname, [])
+                if rows and rows[0].shape != value.shape:
+                    raise ValueError(f"component {cname}: value size mismatch")   # Error::ValueSizeMismatch
+                rows.append(value)
+                self._ids.setdefault(cname, []).append(int(eid))
+
+    def column(self, name: str):
+        if name not in self._cols:
+            raise KeyError(name)   # Error::ComponentNotFound
+        return np.stack(self._cols[name]), np.asarray(self._ids[name], dtype=np.uint64)
+
+    def build(self, system: System, simulation_rate: float = 120.0, telemetry_rate: Optional[float] = None,
+              device: int = 0, backend: str = "hip") -> "Exec":
+        """World.build (world_builder.rs:1737-1780): validate rates, fix globals, bind the backend."""
+        if backend != "hip":
+            raise ValueError(f"unknown backend {backend!r}: this package provides 'hip' only")
+        if not simulation_rate > 0.0:
+            raise ValueError(f"simulation_rate must be > 0 Hz, got {simulation_rate}")
+        ticks_per_telemetry = 1
+        if telemetry_rate is not None:
+            ratio = simulation_rate / telemetry_rate
+            if telemetry_rate <= 0.0 or abs(ratio - round(ratio)) > 1e-9 or round(ratio) < 1:
+                raise ValueError(f"telemetry_rate ({telemetry_rate} Hz) must evenly divide simulation_rate "
+                                 f"({simulation_rate} Hz); got ratio {ratio}")   # world_builder.rs:223-240
+            ticks_per_telemetry = int(round(ratio))
+        dt = float(L.lib().sixdof_quantize_time_step(simulation_rate))
+        pos, ids = self.column("world_pos")
+        body = {k: self.column(k) for k in ("world_vel", "inertia", "world_accel", "force")}
+        for k, (_, kid) in body.items():
+            if not np.array_equal(kid, ids):
+                raise ValueError(f"Body columns must share one entity set (component {k})")
+        effs = []
+        for e in system.effectors.ops:
+            if e.aux_name is not None:
+                arr, aids = self.column(e.aux_name)
+                if not np.array_equal(aids, ids):
+                    raise ValueError(f"effector column {e.aux_name} must live on the Body entities")
+                e = Effector(e.kind, e.p, e.aux_name, arr)
+            effs.append(e)
+        edges = None
+        if system.effectors.edge_component:
+            pairs = self._edges.get(system.effectors.edge_component)
+            if pairs is None:
+                raise KeyError(system.effectors.edge_component)
+            edges = (np.array([a for a, _ in pairs], dtype=np.uint64), np.array([b for _, b in pairs], dtype=np.uint64))
+        hip = HipExec(pos, body["world_vel"][0], body["inertia"][0], world_accel=body["world_accel"][0],
+                      force=body["force"][0], entity_ids=ids, simulation_time_step=dt, time_step=system.time_step,
+                      integrator=system.integrator.value, effectors=effs, edges=edges,
+                      ticks_per_launch=ticks_per_telemetry, device=device)
+        return Exec(hip, self, ticks_per_telemetry, dt)
+
+
+class Exec:
+    """PyExec (exec.rs:95-240): run(ticks), column access, profile."""
+
+    def __init__(self, hip: HipExec, world: World, ticks_per_telemetry: int, dt: float):
+        self._hip, self._world, self._tpt, self._dt = hip, world, ticks_per_telemetry, dt
+        self._last = TickTimings()
+
+    def run(self, ticks: int = 1) -> None:
+        self._last = self._hip.run(ticks)
+
+    @property
+    def tick(self) -> int:
+        return self._hip.tick
+
+    def column_array(self, name: str) -> np.ndarray:
+        cols = {"world_pos": self._hip.world_pos, "world_vel": self._hip.world_vel, "world_accel": self._hip.world_accel,
+                "force": self._hip.force, "inertia": self._hip.inertia}
+        if name in cols:
+            return cols[name]
+        if name in self._hip._aux:
+            return self._hip._aux[name]
+        raise KeyError(name)
+
+    def entity_ids(self) -> np.ndarray:
+        return self._hip.entity_ids
+
+    def profile(self) -> Dict[str, float]:
+        t = self._last   # metric names of profile.rs:14-59
+        tick_ms = t.kernel_invoke_ms / max(1, t.ticks)
+        rtf = (self._dt * 1e3) / tick_ms if tick_ms > 0 else float("inf")   # real_time_factor, profile.rs:55
+        return {"kernel_invoke": t.kernel_invoke_ms, "h2d_upload": t.h2d_upload_ms, "d2h_download": t.d2h_download_ms,
+                "kernel_device": t.kernel_device_ms, "tick": tick_ms, "real_time_factor": rtf,
+                "launches": float(t.launches)}
