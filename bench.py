@@ -223,6 +223,19 @@ def main():
             fe = time.perf_counter() - t1
             out["fused"] = {"ticks_per_launch": 64, "value": round(n * 64 * 64 / fe, 1), "unit": "entity-steps/s",
                             "device_ms_per_tick": round(ft.kernel_device_ms / (64 * 64), 6)}
+            # fused + telemetry ring: EVERY tick's pos/vel/accel/force rows are written to HBM (200 B per
+            # entity-step, write-once), state carried in registers -> HBM-write bound
+            ex.enable_history(256)
+            ex.invoke_batch(256)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            rt = ex.invoke_batch(64 * 64)
+            re_ = time.perf_counter() - t2
+            wr = 200.0 * n / (rt.kernel_device_ms / (64 * 64) * 1e-3) / 1e9
+            out["recording"] = {"ticks_per_launch": 64, "ring_ticks": 256, "value": round(n * 64 * 64 / re_, 1),
+                                "unit": "entity-steps/s", "device_ms_per_tick": round(rt.kernel_device_ms / (64 * 64), 6),
+                                "write_GBps": round(wr, 1), "frac_of_hbm_peak": round(wr / HBM_PEAK_GBPS, 4)}
+            ex.enable_history(0)
     ex.close()
 
     if rank == 0 and not args.no_extras:

@@ -32,7 +32,12 @@ struct StepParams {
     uint32_t n_ops;
     uint32_t vel_independent; // 1: no op reads the stage velocity -> RK4 stages 1 and 2 share F and A
     uint32_t streaming;       // host hint: working set >> Infinity Cache -> non-temporal loads/stores
-    uint32_t pad0;
+    uint32_t hist_ring;       // history ring length in ticks (0 = off)
+    uint64_t hist_slot0;      // ring slot index (before modulo) of the first tick of this launch
+    void* hist_pos;           // [ring][n,7]   per-tick outputs, reference row layout; nullptr = no recording
+    void* hist_vel;           // [ring][n,6]
+    void* hist_accel;         // [ring][n,6]
+    void* hist_force;         // [ring][n,6]
     DevOp ops[kMaxOps];
 };
 

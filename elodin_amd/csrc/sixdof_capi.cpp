@@ -71,6 +71,10 @@ struct sixdof_handle {
     size_t scratch_bytes = 0;
     uint64_t tick = 0;
     bool bound = false;
+    // telemetry ring
+    uint32_t hist_ring = 0;
+    uint64_t hist_first_tick = 0;   // first tick (1-based count) recorded since the ring was enabled
+    void* d_hist[4] = {nullptr, nullptr, nullptr, nullptr};  // pos, vel, accel, force
     // rollout model (0 = none, 1 = Apollo lander)
     int model = 0;
     std::vector<double> ap_time, ap_alt, ap_rate, ap_pitch, ap_hspeed, ap_downrange;
@@ -217,6 +221,7 @@ void sixdof_destroy(sixdof_handle* h) {
     if (h->d_csr_dst) hipFree(h->d_csr_dst);
     if (h->d_scratch) hipFree(h->d_scratch);
     if (h->d_tick_refs) hipFree(h->d_tick_refs);
+    for (void* p : h->d_hist) if (p) hipFree(p);
     for (hipEvent_t e : h->launch_events) hipEventDestroy(e);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -380,6 +385,7 @@ int sixdof_get_tick(const sixdof_handle* h, uint64_t* tick) {
 int sixdof_set_tick(sixdof_handle* h, uint64_t tick) {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     h->tick = tick;
+    h->hist_first_tick = tick + 1;
     return SIXDOF_OK;
 }
 int sixdof_set_ticks_per_launch(sixdof_handle* h, uint32_t k) {
@@ -446,6 +452,13 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
     const char* force_nt = std::getenv("SIXDOF_STREAMING");
     const size_t state_bytes = static_cast<size_t>(h->desc.n_entities) * 32 * h->elem_size();
     P->streaming = force_nt ? (force_nt[0] == '1') : (state_bytes > (400ull << 20));
+    P->hist_ring = h->hist_ring;
+    if (h->hist_ring) {
+        P->hist_pos = h->d_hist[0];
+        P->hist_vel = h->d_hist[1];
+        P->hist_accel = h->d_hist[2];
+        P->hist_force = h->d_hist[3];
+    }
     return build_dev_ops(h, P->ops, &P->n_ops, &P->vel_independent);
 }
 
@@ -593,6 +606,56 @@ int sixdof_set_model_apollo(sixdof_handle* h, const sixdof_apollo_tables* t) {
     return SIXDOF_OK;
 }
 
+int sixdof_set_history(sixdof_handle* h, uint32_t ring_ticks) {
+    if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
+    if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "set_history: bind Body columns first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (void*& p : h->d_hist) {
+        if (p) hipFree(p);
+        p = nullptr;
+    }
+    h->hist_ring = 0;
+    h->drop_graph();
+    if (ring_ticks == 0) return SIXDOF_OK;
+    const size_t n = h->desc.n_entities, es = h->elem_size();
+    const size_t widths[4] = {7, 6, 6, 6};
+    for (int k = 0; k < 4; k++) {
+        const size_t bytes = static_cast<size_t>(ring_ticks) * n * widths[k] * es;
+        hipError_t e = hipMalloc(&h->d_hist[k], bytes ? bytes : 16);
+        if (e != hipSuccess) {
+            for (void*& p : h->d_hist) {
+                if (p) hipFree(p);
+                p = nullptr;
+            }
+            return h->hip_fail(e, "set_history: hipMalloc of the ring");
+        }
+    }
+    h->hist_ring = ring_ticks;
+    h->hist_first_tick = h->tick + 1;
+    return SIXDOF_OK;
+}
+
+int sixdof_history_read(sixdof_handle* h, uint64_t component_id, uint64_t tick, void* host_dst) {
+    if (!h || !host_dst) return SIXDOF_ERR_INVALID_ARGUMENT;
+    if (!h->hist_ring) return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "history_read: no history ring (sixdof_set_history)");
+    int k = -1;
+    size_t w = 6;
+    if (component_id == h->id_pos) k = 0, w = 7;
+    else if (component_id == h->id_vel) k = 1;
+    else if (component_id == h->id_accel) k = 2;
+    else if (component_id == h->id_force) k = 3;
+    if (k < 0) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "history_read: only world_pos/world_vel/world_accel/force are recorded");
+    if (tick < h->hist_first_tick || tick > h->tick || tick + h->hist_ring <= h->tick)
+        return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "history_read: tick is not in the ring");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t block = static_cast<size_t>(h->desc.n_entities) * w * h->elem_size();
+    const size_t slot = static_cast<size_t>((tick - 1) % h->hist_ring);
+    if (block) HIP_TRY(h, hipMemcpyAsync(host_dst, static_cast<char*>(h->d_hist[k]) + slot * block, block, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SIXDOF_OK;
+}
+
 int sixdof_download_column(sixdof_handle* h, uint64_t component_id) {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     Column* c = h->col(component_id);
@@ -643,7 +706,8 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
                 h->launch_events.push_back(e);
             }
         }
-        if (!time_each && (h->desc.flags & SIXDOF_FLAG_USE_GRAPH) && full >= kGraphLen) {
+        uint64_t ticks_issued = 0;   // history slot of a launch's first tick = ticks done before it
+        if (!time_each && !h->hist_ring && (h->desc.flags & SIXDOF_FLAG_USE_GRAPH) && full >= kGraphLen) {
             const uint64_t sig = (static_cast<uint64_t>(K) << 32) ^ h->ops.size() ^ (h->desc.n_entities << 8);
             if (!h->graph_exec || h->graph_k != K || h->graph_sig != sig) {
                 h->drop_graph();
@@ -670,8 +734,11 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
                 launches += kGraphLen;
             }
         }
+        ticks_issued = launches * K;
         for (uint64_t i = 0; i < full; i++) {
             if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches], h->stream));
+            P.hist_slot0 = h->tick + ticks_issued;
+            ticks_issued += K;
             hipError_t e = launch_step(P, h->desc.integrator, h->desc.dtype, h->stream);
             if (e != hipSuccess) return h->hip_fail(e, "launch_step");
             if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches + 1], h->stream));
@@ -679,6 +746,7 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
         }
         if (rem) {
             P.n_ticks = rem;
+            P.hist_slot0 = h->tick + ticks_issued;
             if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches], h->stream));
             hipError_t e = launch_step(P, h->desc.integrator, h->desc.dtype, h->stream);
             if (e != hipSuccess) return h->hip_fail(e, "launch_step");

@@ -139,9 +139,13 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA data has landed
     __syncthreads();
 
-    Quat<T> q0;
-    Vec3<T> p0;
-    Spatial<T> v0, A_out, F_out;
+    // Row state.  Inactive lanes of a ragged last wave carry a harmless identity body so the whole wave can
+    // run the tick loop (and its wave-level barriers) uniformly.
+    const Spatial<T> zero6 = {{T(0), T(0), T(0)}, {T(0), T(0), T(0)}};
+    Quat<T> q0 = {T(0), T(0), T(0), T(1)};
+    Vec3<T> p0 = {T(0), T(0), T(0)}, inv_I = {T(1), T(1), T(1)};
+    Spatial<T> v0 = zero6, A_out = zero6, F_out = zero6;
+    T mass = T(1), inv_m = T(1);
     if (active) {
         const T* r = l_pos + t * 7;
         q0 = Quat<T>{r[0], r[1], r[2], r[3]};
@@ -150,102 +154,124 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
         v0.ang = Vec3<T>{s[0], s[1], s[2]};
         v0.lin = Vec3<T>{s[3], s[4], s[5]};
         const T* m = l_c + t * 7;
-        const Vec3<T> inv_I = {T(1) / m[0], T(1) / m[1], T(1) / m[2]};
-        const T mass = m[6];
-        const T inv_m = T(1) / mass;
-
-        const T dt_g = T(P.dt_g), dt = T(P.dt);
-        Body<T> b;
-        b.mass = mass;
-        Wrench<T> F = zero_wrench<T>();
-        for (uint32_t tick = 0; tick < P.n_ticks; tick++) {
-            if constexpr (INTEGRATOR == kRk4) {
-                const T h1 = dt_g * T(0.5), h3 = dt_g;
-                Spatial<T> A, sv, sa;
-                // stage 0 (c = 0): x0 (+) 0 only renormalises the quaternion
-                b.q = normalized(q0);
-                b.p = p0;
-                b.v = v0;
-                F = zero_wrench<T>();
-                PIPE::apply(P, aux, b, F);
-                A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
-                sv = v0;
-                sa = A;
-                // stage 1 (c = 1/2): position advanced with v0 (reference quirk), velocity with A0
-                b.q = integrate_world(q0, h1 * v0.ang);
-                b.p = axpy(h1, v0.lin, p0);
-                b.v = axpy(h1, A, v0);
-                sv = axpy(T(2), b.v, sv);
-                F = zero_wrench<T>();
-                PIPE::apply(P, aux, b, F);
-                A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
-                sa = axpy(T(2), A, sa);
-                // stage 2 (c = 1/2): same transform as stage 1
-                b.v = axpy(h1, A, v0);
-                sv = axpy(T(2), b.v, sv);
-                if (!PIPE::vel_independent(P)) {
-                    F = zero_wrench<T>();
-                    PIPE::apply(P, aux, b, F);
-                    A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
-                }
-                sa = axpy(T(2), A, sa);
-                // stage 3 (c = 1)
-                b.q = integrate_world(q0, h3 * v0.ang);
-                b.p = axpy(h3, v0.lin, p0);
-                b.v = axpy(h3, A, v0);
-                sv = sv + b.v;
-                F = zero_wrench<T>();
-                PIPE::apply(P, aux, b, F);
-                A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
-                sa = sa + A;
-                // u' = u + (dt/6)(k1 + 2k2 + 2k3 + k4)
-                const T g = dt * T(1.0 / 6.0);
-                q0 = integrate_world(q0, g * sv.ang);
-                p0 = axpy(g, sv.lin, p0);
-                v0 = axpy(g, sa, v0);
-                A_out = A;
-            } else {
-                // semi-implicit: a = calc_accel(F(x0,v0)); v' = v0 + dt a; x' = x0 (+) dt v'
-                b.q = normalized(q0);  // q * v is scale-invariant; user data may not be unit on tick 0
-                b.p = p0;
-                b.v = v0;
-                F = zero_wrench<T>();
-                PIPE::apply(P, aux, b, F);
-                const Spatial<T> A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
-                v0 = axpy(dt, A, v0);
-                q0 = integrate_world(q0, dt * v0.ang);
-                p0 = axpy(dt, v0.lin, p0);
-                A_out = A;
-            }
-        }
-        F_out = world_wrench<PIPE>(b.q, F);  // wrench of the last stage evaluated, world frame
+        inv_I = Vec3<T>{T(1) / m[0], T(1) / m[1], T(1) / m[2]};
+        mass = m[6];
+        inv_m = T(1) / mass;
     }
     if (P.n_ticks == 0) return;
-    __syncthreads();  // every lane has consumed the input slabs
-    if (active) {
-        T* r = l_pos + t * 7;
-        r[0] = q0.i; r[1] = q0.j; r[2] = q0.k; r[3] = q0.w; r[4] = p0.x; r[5] = p0.y; r[6] = p0.z;
-        T* s = l_vel + t * 6;
-        s[0] = v0.ang.x; s[1] = v0.ang.y; s[2] = v0.ang.z; s[3] = v0.lin.x; s[4] = v0.lin.y; s[5] = v0.lin.z;
-        T* a = l_c + t * 6;
-        a[0] = A_out.ang.x; a[1] = A_out.ang.y; a[2] = A_out.ang.z;
-        a[3] = A_out.lin.x; a[4] = A_out.lin.y; a[5] = A_out.lin.z;
-        T* f = l_force + t * 6;
-        f[0] = F_out.ang.x; f[1] = F_out.ang.y; f[2] = F_out.ang.z;
-        f[3] = F_out.lin.x; f[4] = F_out.lin.y; f[5] = F_out.lin.z;
+    __syncthreads();  // every lane has consumed the input slabs; LDS is the output staging area from here on
+
+    auto stage_rows = [&]() {
+        if (active) {
+            T* r = l_pos + t * 7;
+            r[0] = q0.i; r[1] = q0.j; r[2] = q0.k; r[3] = q0.w; r[4] = p0.x; r[5] = p0.y; r[6] = p0.z;
+            T* s = l_vel + t * 6;
+            s[0] = v0.ang.x; s[1] = v0.ang.y; s[2] = v0.ang.z; s[3] = v0.lin.x; s[4] = v0.lin.y; s[5] = v0.lin.z;
+            T* a = l_c + t * 6;
+            a[0] = A_out.ang.x; a[1] = A_out.ang.y; a[2] = A_out.ang.z;
+            a[3] = A_out.lin.x; a[4] = A_out.lin.y; a[5] = A_out.lin.z;
+            T* f = l_force + t * 6;
+            f[0] = F_out.ang.x; f[1] = F_out.ang.y; f[2] = F_out.ang.z;
+            f[3] = F_out.lin.x; f[4] = F_out.lin.y; f[5] = F_out.lin.z;
+        }
+    };
+    // rows in LDS -> the four output columns at `base` pointers (live columns or one history slot)
+    auto flush_rows = [&](T* o_pos, T* o_vel, T* o_accel, T* o_force, auto nt) {
+        constexpr bool kNt = decltype(nt)::value;
+        if (full) {
+            slab_out<kWave * 7 * sizeof(T), kNt>(reinterpret_cast<const char*>(l_pos), reinterpret_cast<char*>(o_pos), t);
+            slab_out<kWave * 6 * sizeof(T), kNt>(reinterpret_cast<const char*>(l_vel), reinterpret_cast<char*>(o_vel), t);
+            slab_out<kWave * 6 * sizeof(T), kNt>(reinterpret_cast<const char*>(l_c), reinterpret_cast<char*>(o_accel), t);
+            slab_out<kWave * 6 * sizeof(T), kNt>(reinterpret_cast<const char*>(l_force), reinterpret_cast<char*>(o_force), t);
+        } else {
+            slab_out_tail(l_pos, o_pos, rows * 7, t);
+            slab_out_tail(l_vel, o_vel, rows * 6, t);
+            slab_out_tail(l_c, o_accel, rows * 6, t);
+            slab_out_tail(l_force, o_force, rows * 6, t);
+        }
+    };
+
+    const bool record = P.hist_pos != nullptr;  // wave-uniform: stream every tick's outputs to the history ring
+    const T dt_g = T(P.dt_g), dt = T(P.dt);
+    Body<T> b;
+    b.mass = mass;
+    Wrench<T> F = zero_wrench<T>();
+    for (uint32_t tick = 0; tick < P.n_ticks; tick++) {
+        if constexpr (INTEGRATOR == kRk4) {
+            const T h1 = dt_g * T(0.5), h3 = dt_g;
+            Spatial<T> A, sv, sa;
+            // stage 0 (c = 0): x0 (+) 0 only renormalises the quaternion
+            b.q = normalized(q0);
+            b.p = p0;
+            b.v = v0;
+            F = zero_wrench<T>();
+            PIPE::apply(P, aux, b, F);
+            A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+            sv = v0;
+            sa = A;
+            // stage 1 (c = 1/2): position advanced with v0 (reference quirk), velocity with A0
+            b.q = integrate_world(q0, h1 * v0.ang);
+            b.p = axpy(h1, v0.lin, p0);
+            b.v = axpy(h1, A, v0);
+            sv = axpy(T(2), b.v, sv);
+            F = zero_wrench<T>();
+            PIPE::apply(P, aux, b, F);
+            A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+            sa = axpy(T(2), A, sa);
+            // stage 2 (c = 1/2): same transform as stage 1
+            b.v = axpy(h1, A, v0);
+            sv = axpy(T(2), b.v, sv);
+            if (!PIPE::vel_independent(P)) {
+                F = zero_wrench<T>();
+                PIPE::apply(P, aux, b, F);
+                A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+            }
+            sa = axpy(T(2), A, sa);
+            // stage 3 (c = 1)
+            b.q = integrate_world(q0, h3 * v0.ang);
+            b.p = axpy(h3, v0.lin, p0);
+            b.v = axpy(h3, A, v0);
+            sv = sv + b.v;
+            F = zero_wrench<T>();
+            PIPE::apply(P, aux, b, F);
+            A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+            sa = sa + A;
+            // u' = u + (dt/6)(k1 + 2k2 + 2k3 + k4)
+            const T g = dt * T(1.0 / 6.0);
+            q0 = integrate_world(q0, g * sv.ang);
+            p0 = axpy(g, sv.lin, p0);
+            v0 = axpy(g, sa, v0);
+            A_out = A;
+        } else {
+            // semi-implicit: a = calc_accel(F(x0,v0)); v' = v0 + dt a; x' = x0 (+) dt v'
+            b.q = normalized(q0);  // q * v is scale-invariant; user data may not be unit on tick 0
+            b.p = p0;
+            b.v = v0;
+            F = zero_wrench<T>();
+            PIPE::apply(P, aux, b, F);
+            const Spatial<T> A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+            v0 = axpy(dt, A, v0);
+            q0 = integrate_world(q0, dt * v0.ang);
+            p0 = axpy(dt, v0.lin, p0);
+            A_out = A;
+        }
+        if (record) {
+            // telemetry: this tick's world_pos / world_vel / world_accel / force rows -> ring slot, in the
+            // reference's row layout, write-once (non-temporal); the stores drain under the next tick's math
+            F_out = world_wrench<PIPE>(b.q, F);
+            stage_rows();
+            __syncthreads();
+            const size_t slot = (size_t)((P.hist_slot0 + tick) % P.hist_ring);
+            const size_t r7 = (slot * P.n + row0) * 7, r6 = (slot * P.n + row0) * 6;
+            flush_rows(static_cast<T*>(P.hist_pos) + r7, static_cast<T*>(P.hist_vel) + r6,
+                       static_cast<T*>(P.hist_accel) + r6, static_cast<T*>(P.hist_force) + r6, std::true_type{});
+            __syncthreads();
+        }
     }
+    F_out = world_wrench<PIPE>(b.q, F);  // wrench of the last stage evaluated, world frame
+    stage_rows();
     __syncthreads();
-    if (full) {
-        slab_out<kWave * 7 * sizeof(T), NT>(reinterpret_cast<const char*>(l_pos), reinterpret_cast<char*>(g_pos), t);
-        slab_out<kWave * 6 * sizeof(T), NT>(reinterpret_cast<const char*>(l_vel), reinterpret_cast<char*>(g_vel), t);
-        slab_out<kWave * 6 * sizeof(T), NT>(reinterpret_cast<const char*>(l_c), reinterpret_cast<char*>(g_accel), t);
-        slab_out<kWave * 6 * sizeof(T), NT>(reinterpret_cast<const char*>(l_force), reinterpret_cast<char*>(g_force), t);
-    } else {
-        slab_out_tail(l_pos, g_pos, rows * 7, t);
-        slab_out_tail(l_vel, g_vel, rows * 6, t);
-        slab_out_tail(l_c, g_accel, rows * 6, t);
-        slab_out_tail(l_force, g_force, rows * 6, t);
-    }
+    flush_rows(g_pos, g_vel, g_accel, g_force, std::integral_constant<bool, NT>{});
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------------

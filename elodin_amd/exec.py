@@ -167,6 +167,22 @@ class HipExec:
         if rc != L.OK:
             _raise(self._h, rc, "sixdof_set_ticks_per_launch")
 
+    def enable_history(self, ring_ticks: int):
+        """Record every tick's world_pos/world_vel/world_accel/force in a device ring (sixdof_set_history)."""
+        rc = self._lib.sixdof_set_history(self._h, int(ring_ticks))
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_set_history")
+
+    def history(self, name: str, first_tick: int, last_tick: int) -> np.ndarray:
+        """exec.history() analogue: [last-first+1, n, w] block of component `name`, row k = state after tick first+k."""
+        w = 7 if name == "world_pos" else 6
+        out = np.empty((last_tick - first_tick + 1, self.n, w), dtype=self.dtype)
+        for k, tick in enumerate(range(first_tick, last_tick + 1)):
+            rc = self._lib.sixdof_history_read(self._h, L.component_id(name), tick, out[k].ctypes.data)
+            if rc != L.OK:
+                _raise(self._h, rc, "sixdof_history_read")
+        return out
+
     def set_flags(self, flags: int):
         self._lib.sixdof_set_flags(self._h, int(flags))
 

@@ -203,6 +203,17 @@ void sixdof_tick(const uint8_t* const* inputs, uint8_t* const* outputs);
 int sixdof_tick_slots(const sixdof_handle* h, sixdof_slot* inputs, size_t in_cap, size_t* n_in,
                       sixdof_slot* outputs, size_t out_cap, size_t* n_out);
 
+/* ---- telemetry: device-side history ring (the commit step either side of the path) ------------------------
+ * The reference commits every output column to its DB after each batch (exec.rs:110-172,
+ * impeller2_server.rs:390-438) and `exec.history()` reads it back.  With a ring enabled, sixdof_step writes
+ * world_pos / world_vel / world_accel / force of EVERY tick into slot (tick-1) % ring_ticks of a device ring
+ * (reference row layout, one contiguous [n,w] block per tick and column) from inside the fused kernel, so
+ * ticks_per_launch > 1 no longer drops intermediate ticks.  ring_ticks = 0 disables and frees the ring. */
+int sixdof_set_history(sixdof_handle* h, uint32_t ring_ticks);
+/* Copy the [n,w] block of `component_id` as it was after `tick` ticks into host_dst.  Fails with
+ * SIXDOF_ERR_INVALID_ARGUMENT if that tick is not (or no longer) in the ring. */
+int sixdof_history_read(sixdof_handle* h, uint64_t component_id, uint64_t tick, void* host_dst);
+
 /* ---- rollout models: systems piped AROUND six_dof, fused with it (the pipes of examples/<name>/sim.py) ------------- */
 struct sixdof_apollo_tables; /* include/sixdof_apollo.h */
 /* Select the Apollo-lander rollout model (examples/apollo-lander/sim.py:517-526 + the guidance sidecar

@@ -300,3 +300,41 @@ def test_pair_op_errors():
     with pytest.raises(ValueError):  # pair op must be last in the pipe
         ea.HipExec(pos, vel, inertia, effectors=[ea.Effector(L.EFF_ALLPAIRS_GRAVITY_SOFTENED, (1.0, 0.0)),
                                                  ea.Effector(L.EFF_UNIFORM_GRAVITY, (0, 0, -1))])
+
+
+# ---- telemetry ring -----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,k", [(1000, 16), (4099, 7), (64, 1)])
+def test_history_ring_records_every_tick_of_fused_launches(n, k):
+    """With a ring, ticks_per_launch > 1 keeps every intermediate tick: history == stepping one tick at a time."""
+    fused, _, _ = _pair(n, 50, ticks_per_launch=k)
+    single, _, _ = _pair(n, 50, ticks_per_launch=1)
+    fused.enable_history(64)
+    fused.run(50)
+    hist = {f: fused.history(f, 1, 50) for f in parity.FIELDS}
+    for tick in range(1, 51):
+        single.run(1)
+        for f in parity.FIELDS:
+            assert np.array_equal(hist[f][tick - 1], getattr(single, f)), (f, tick)
+    # the live columns hold the last tick as usual
+    for f in parity.FIELDS:
+        assert np.array_equal(getattr(fused, f), hist[f][-1])
+
+
+def test_history_ring_window_and_errors():
+    hip, _, _ = _pair(300, 1, ticks_per_launch=8)
+    with pytest.raises(ValueError):          # no ring yet
+        hip.history("world_pos", 1, 1)
+    hip.run(5)
+    hip.enable_history(10)                   # recording starts at tick 6
+    hip.run(25)                              # ticks 6..30 recorded, ring keeps 21..30
+    assert hip.tick == 30
+    hip.history("world_vel", 21, 30)
+    for bad in (20, 31, 5):
+        with pytest.raises(ValueError):
+            hip.history("world_vel", bad, bad)
+    with pytest.raises(KeyError):
+        hip.history("inertia", 30, 30)
+    hip.enable_history(0)
+    with pytest.raises(ValueError):
+        hip.history("world_pos", 30, 30)
