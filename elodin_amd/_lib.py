@@ -75,6 +75,7 @@ SYMBOLS = {
     "sixdof_bind_columns": (C.c_int, [_H, C.POINTER(Column), C.c_size_t]),
     "sixdof_set_effectors": (C.c_int, [_H, C.POINTER(EffectorOp), C.c_size_t]),
     "sixdof_set_edges": (C.c_int, [_H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t]),
+    "sixdof_get_join_rows": (C.c_int, [_H, C.c_uint64, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_size_t)]),
     "sixdof_get_edge_rows": (C.c_int, [_H, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t,
                                        C.POINTER(C.c_size_t)]),
     "sixdof_upload": (C.c_int, [_H]),

@@ -260,17 +260,17 @@ class World:
         dt = float(L.lib().sixdof_quantize_time_step(simulation_rate))
         pos, ids = self.column("world_pos")
         body = {k: self.column(k) for k in ("world_vel", "inertia", "world_accel", "force")}
-        for k, (_, kid) in body.items():
-            if not np.array_equal(kid, ids):
-                raise ValueError(f"Body columns must share one entity set (component {k})")
+        # components may live on different entity sets (a scene object with a world_pos but no Body):
+        # six_dof runs on the intersection (query.rs:136-208); each column keeps its own id vector
+        column_ids = {"world_pos": ids, **{k: v[1] for k, v in body.items()}}
         effs = []
         for e in system.effectors.ops:
             if e.aux_name is not None:
                 arr, aids = self.column(e.aux_name)
-                if not np.array_equal(aids, ids):
-                    raise ValueError(f"effector column {e.aux_name} must live on the Body entities")
+                column_ids[e.aux_name] = aids
                 e = Effector(e.kind, e.p, e.aux_name, arr)
             effs.append(e)
+        same = all(np.array_equal(v, ids) for v in column_ids.values())
         edges = None
         if system.effectors.edge_component:
             pairs = self._edges.get(system.effectors.edge_component)
@@ -280,7 +280,8 @@ class World:
         hip = HipExec(pos, body["world_vel"][0], body["inertia"][0], world_accel=body["world_accel"][0],
                       force=body["force"][0], entity_ids=ids, simulation_time_step=dt, time_step=system.time_step,
                       integrator=system.integrator.value, effectors=effs, edges=edges,
-                      ticks_per_launch=ticks_per_telemetry, device=device)
+                      ticks_per_launch=ticks_per_telemetry, device=device,
+                      column_entity_ids=None if same else column_ids)
         return Exec(hip, self, ticks_per_telemetry, dt)
 
 

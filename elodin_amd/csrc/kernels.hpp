@@ -76,6 +76,12 @@ struct PairParams {
 uint32_t pair_splits_for(uint32_t n);
 hipError_t launch_pair_tick(const PairParams& p, int integrator, hipStream_t stream, uint64_t* launches);
 
+// ---- joins (query.rs:599-725): gather / scatter of rows by constant u32 indices -----------------------------
+hipError_t launch_gather_rows(void* dst, const void* src, const uint32_t* rows, uint32_t m, uint32_t w, size_t elem,
+                              hipStream_t s);
+hipError_t launch_scatter_rows(void* dst, const void* src, const uint32_t* rows, uint32_t m, uint32_t w, size_t elem,
+                               hipStream_t s);
+
 // ---- Apollo-lander rollout model (include/sixdof_apollo.h) ---------------------------------------------
 struct ApolloParams {
     double *pos, *vel, *accel, *force, *inertia;  // Body columns

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -39,7 +40,14 @@ struct Column {
     size_t bytes = 0;
     std::vector<uint64_t> ids;
     void* host = nullptr;  // borrowed
-    void* dev = nullptr;   // owned
+    void* dev = nullptr;   // owned: the full column, reference byte layout
+    // join state: rows of this column that belong to the joined entity set, in joined order.  `live` is what
+    // the kernels read and write: == dev when the column IS the joined set, else an owned compact [m,w] copy.
+    std::vector<uint32_t> rows;
+    uint32_t* d_rows = nullptr;
+    void* compact = nullptr;
+    void* live = nullptr;
+    bool joined = false;   // join resolved for the current binding
 };
 
 thread_local std::string g_create_error;
@@ -69,6 +77,8 @@ struct sixdof_handle {
     // pair-path scratch
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    std::vector<uint64_t> joined_ids;  // intersection of the Body columns' entity ids (query.rs:136-208)
+    bool identity_join = true;         // every Body column already is the joined set (query.rs:673,702 fast path)
     uint64_t tick = 0;
     bool bound = false;
     // telemetry ring
@@ -108,6 +118,13 @@ struct sixdof_handle {
     }
     size_t elem_size() const { return desc.dtype == SIXDOF_F32 ? 4 : 8; }
     int state_prim() const { return desc.dtype == SIXDOF_F32 ? SIXDOF_PRIM_F32 : SIXDOF_PRIM_F64; }
+    void free_join(Column& c) {
+        if (c.d_rows) hipFree(c.d_rows), c.d_rows = nullptr;
+        if (c.compact) hipFree(c.compact), c.compact = nullptr;
+        c.rows.clear();
+        c.live = nullptr;
+        c.joined = false;
+    }
     void drop_graph() {
         if (graph_exec) {
             hipGraphExecDestroy(graph_exec);
@@ -126,6 +143,36 @@ struct sixdof_handle {
         hipError_t e_ = (call);                               \
         if (e_ != hipSuccess) return (h)->hip_fail(e_, #call); \
     } while (0)
+
+// Map the joined entity set onto one column: `rows[j]` = row of joined entity j in this column.  Identity ->
+// kernels work on the column itself; otherwise on a compact [m,w] copy (gathered on upload, scattered on download).
+static int resolve_join(sixdof_handle* h, Column* c) {
+    if (c->joined) return SIXDOF_OK;
+    const size_t m = h->joined_ids.size();
+    if (c->ids == h->joined_ids) {
+        c->live = c->dev;
+        c->joined = true;
+        return SIXDOF_OK;
+    }
+    std::unordered_map<uint64_t, uint32_t> row_of;
+    row_of.reserve(c->ids.size() * 2);
+    for (size_t r = 0; r < c->ids.size(); r++) row_of.emplace(c->ids[r], static_cast<uint32_t>(r));
+    c->rows.resize(m);
+    for (size_t j = 0; j < m; j++) {
+        auto it = row_of.find(h->joined_ids[j]);
+        if (it == row_of.end())
+            return h->fail(SIXDOF_ERR_ENTITY_MISMATCH, "join: a column does not cover the joined Body entity set");
+        c->rows[j] = it->second;
+    }
+    if (m) {
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&c->d_rows), m * sizeof(uint32_t)));
+        HIP_TRY(h, hipMemcpy(c->d_rows, c->rows.data(), m * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMalloc(&c->compact, m * c->width * c->elem));
+    }
+    c->live = c->compact;
+    c->joined = true;
+    return SIXDOF_OK;
+}
 
 extern "C" {
 
@@ -215,8 +262,10 @@ void sixdof_destroy(sixdof_handle* h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     h->drop_graph();
-    for (auto& kv : h->cols)
+    for (auto& kv : h->cols) {
+        h->free_join(kv.second);
         if (kv.second.dev) hipFree(kv.second.dev);
+    }
     if (h->d_csr_start) hipFree(h->d_csr_start);
     if (h->d_csr_dst) hipFree(h->d_csr_dst);
     if (h->d_scratch) hipFree(h->d_scratch);
@@ -247,30 +296,56 @@ int sixdof_bind_columns(sixdof_handle* h, const sixdof_column* cols, size_t n_co
         col.host = c.host_ptr;
         if (c.entity_ids) col.ids.assign(c.entity_ids, c.entity_ids + c.n_rows);
         Column* old = h->col(c.component_id);
-        if (old && old->dev) {
-            if (old->bytes == col.bytes) col.dev = old->dev;
-            else hipFree(old->dev);
+        if (old) {
+            h->free_join(*old);
+            if (old->dev) {
+                if (old->bytes == col.bytes) col.dev = old->dev;
+                else hipFree(old->dev);
+            }
         }
         if (!col.dev && col.bytes) HIP_TRY(h, hipMalloc(&col.dev, col.bytes));
         h->cols[c.component_id] = std::move(col);
     }
-    // validate the Body archetype (six_dof.rs:152-159): five columns, one entity-id vector
+    // The Body archetype (six_dof.rs:152-159): five columns.  six_dof's queries run over the INTERSECTION of
+    // their entity ids in ascending id order (query.rs:136-208); rows outside it are never touched.
     const struct { uint64_t id; uint64_t width; const char* name; } body[5] = {
         {h->id_pos, 7, "world_pos"}, {h->id_vel, 6, "world_vel"}, {h->id_accel, 6, "world_accel"},
         {h->id_force, 6, "force"},   {h->id_inertia, 7, "inertia"}};
     const Column* first = nullptr;
+    bool identical = true;
     for (auto& b : body) {
         const Column* c = h->col(b.id);
         if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, std::string("bind_columns: missing Body column ") + b.name);
         if (c->prim != h->state_prim())
             return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, std::string("bind_columns: dtype mismatch on ") + b.name);
-        if (c->width != b.width || c->n_rows != h->desc.n_entities)
+        if (c->width != b.width)
             return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, std::string("bind_columns: shape mismatch on ") + b.name);
+        if (c->ids.size() != c->n_rows)
+            return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, std::string("bind_columns: entity_ids missing on ") + b.name);
         if (!first) first = c;
-        else if (c->ids != first->ids)
-            // reference joins iterate the id intersection (query.rs:136-208); this backend implements
-            // the fast path all examples use: every Body column shares one id vector (query.rs:673,702)
-            return h->fail(SIXDOF_ERR_ENTITY_MISMATCH, std::string("bind_columns: entity ids differ on ") + b.name);
+        else if (c->ids != first->ids) identical = false;
+    }
+    if (identical) {
+        h->joined_ids = first->ids;   // fast path: column order as is (query.rs:673,702)
+    } else {
+        std::vector<uint64_t> acc(first->ids);
+        std::sort(acc.begin(), acc.end());
+        for (auto& b : body) {
+            std::vector<uint64_t> ids(h->col(b.id)->ids), out;
+            std::sort(ids.begin(), ids.end());
+            std::set_intersection(acc.begin(), acc.end(), ids.begin(), ids.end(), std::back_inserter(out));
+            acc.swap(out);
+        }
+        h->joined_ids.swap(acc);      // ascending entity id
+    }
+    h->identity_join = identical;
+    if (h->desc.n_entities == 0) h->desc.n_entities = h->joined_ids.size();
+    if (h->joined_ids.size() != h->desc.n_entities)
+        return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, "bind_columns: n_entities does not match the joined Body entity set");
+    for (auto& kv : h->cols) h->free_join(kv.second);
+    for (auto& b : body) {
+        int rc = resolve_join(h, h->col(b.id));
+        if (rc != SIXDOF_OK) return rc;
     }
     h->bound = true;
     return SIXDOF_OK;
@@ -303,10 +378,9 @@ int sixdof_set_edges(sixdof_handle* h, const uint64_t* from_ids, const uint64_t*
     if (!h || ((!from_ids || !to_ids) && n_edges)) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "set_edges: bind Body columns first");
     HIP_TRY(h, hipSetDevice(h->device));
-    const Column* pos = h->col(h->id_pos);
-    std::unordered_map<uint64_t, uint32_t> row_of;
-    row_of.reserve(pos->ids.size() * 2);
-    for (size_t r = 0; r < pos->ids.size(); r++) row_of.emplace(pos->ids[r], static_cast<uint32_t>(r));
+    std::unordered_map<uint64_t, uint32_t> row_of;   // entity id -> row of the joined Body set
+    row_of.reserve(h->joined_ids.size() * 2);
+    for (size_t r = 0; r < h->joined_ids.size(); r++) row_of.emplace(h->joined_ids[r], static_cast<uint32_t>(r));
     std::vector<uint32_t> src(n_edges), dst(n_edges);
     for (size_t e = 0; e < n_edges; e++) {
         auto a = row_of.find(from_ids[e]), b = row_of.find(to_ids[e]);
@@ -338,6 +412,19 @@ int sixdof_set_edges(sixdof_handle* h, const uint64_t* from_ids, const uint64_t*
     return SIXDOF_OK;
 }
 
+int sixdof_get_join_rows(const sixdof_handle* h, uint64_t component_id, uint32_t* rows, size_t cap, size_t* n_out) {
+    if (!h || !n_out) return SIXDOF_ERR_INVALID_ARGUMENT;
+    const Column* c = h->col(component_id);
+    if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "get_join_rows: unknown component");
+    const size_t m = h->joined_ids.size();
+    *n_out = m;
+    if (!rows) return SIXDOF_OK;
+    if (cap < m) return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, "get_join_rows: buffer too small");
+    if (!c->joined) return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "get_join_rows: column is not part of the join yet");
+    for (size_t j = 0; j < m; j++) rows[j] = c->rows.empty() ? static_cast<uint32_t>(j) : c->rows[j];
+    return SIXDOF_OK;
+}
+
 int sixdof_get_edge_rows(const sixdof_handle* h, uint32_t* src_rows, uint32_t* dst_rows, size_t cap, size_t* n_out) {
     if (!h || !n_out) return SIXDOF_ERR_INVALID_ARGUMENT;
     *n_out = h->edge_src.size();
@@ -354,8 +441,23 @@ int sixdof_upload(sixdof_handle* h) {
     for (auto& kv : h->cols) {
         Column& c = kv.second;
         if (c.bytes) HIP_TRY(h, hipMemcpyAsync(c.dev, c.host, c.bytes, hipMemcpyHostToDevice, h->stream));
+        if (c.joined && c.compact) {
+            hipError_t e = launch_gather_rows(c.compact, c.dev, c.d_rows, static_cast<uint32_t>(h->joined_ids.size()),
+                                              static_cast<uint32_t>(c.width), c.elem, h->stream);
+            if (e != hipSuccess) return h->hip_fail(e, "gather_rows");
+        }
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SIXDOF_OK;
+}
+
+// joined rows -> their places in the full column (before any D2H of that column)
+static int scatter_back(sixdof_handle* h, Column* c) {
+    if (c->joined && c->compact) {
+        hipError_t e = launch_scatter_rows(c->dev, c->compact, c->d_rows, static_cast<uint32_t>(h->joined_ids.size()),
+                                           static_cast<uint32_t>(c->width), c->elem, h->stream);
+        if (e != hipSuccess) return h->hip_fail(e, "scatter_rows");
+    }
     return SIXDOF_OK;
 }
 
@@ -371,7 +473,10 @@ int sixdof_download(sixdof_handle* h, uint32_t mask) {
     for (auto& s : sel) {
         if (!(mask & s.bit)) continue;
         Column* c = h->col(s.id);
-        if (c && c->bytes) HIP_TRY(h, hipMemcpyAsync(c->host, c->dev, c->bytes, hipMemcpyDeviceToHost, h->stream));
+        if (!c) continue;
+        int rc = scatter_back(h, c);
+        if (rc != SIXDOF_OK) return rc;
+        if (c->bytes) HIP_TRY(h, hipMemcpyAsync(c->host, c->dev, c->bytes, hipMemcpyDeviceToHost, h->stream));
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SIXDOF_OK;
@@ -404,7 +509,7 @@ int sixdof_set_flags(sixdof_handle* h, uint32_t flags) {
 void* sixdof_device_column(sixdof_handle* h, uint64_t component_id) {
     if (!h) return nullptr;
     Column* c = h->col(component_id);
-    return c ? c->dev : nullptr;
+    return c ? (c->live ? c->live : c->dev) : nullptr;
 }
 void* sixdof_stream(sixdof_handle* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
 
@@ -423,13 +528,19 @@ int build_dev_ops(sixdof_handle* h, DevOp* out, uint32_t* n_out, uint32_t* vel_i
         d.kind = o.kind;
         std::memcpy(d.p, o.p, sizeof(d.p));
         if (o.kind == SIXDOF_EFF_BODY_TORQUE || o.kind == SIXDOF_EFF_BODY_FORCE || o.kind == SIXDOF_EFF_BALL_DRAG) {
-            const Column* c = h->col(o.aux_component_id);
+            Column* c = h->col(o.aux_component_id);
             if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "step: effector aux column not bound");
-            if (c->width != 3 || c->n_rows != h->desc.n_entities || c->prim != h->state_prim())
+            if (c->width != 3 || c->prim != h->state_prim())
                 return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, "step: effector aux column must be [n,3] of the state dtype");
-            if (c->ids != h->col(h->id_pos)->ids)
-                return h->fail(SIXDOF_ERR_ENTITY_MISMATCH, "step: effector aux column entity ids differ from Body");
-            d.aux = c->dev;
+            if (!c->joined) {   // first use after binding: join it onto the Body set and bring its rows over
+                int rc = resolve_join(h, c);
+                if (rc != SIXDOF_OK) return rc;
+                if (c->compact) {
+                    hipError_t e = launch_gather_rows(c->compact, c->dev, c->d_rows, static_cast<uint32_t>(h->joined_ids.size()), 3, c->elem, h->stream);
+                    if (e != hipSuccess) return h->hip_fail(e, "gather_rows");
+                }
+            }
+            d.aux = c->live;
         }
         if (o.kind == SIXDOF_EFF_BALL_DRAG) *vel_independent = 0;
         out[n++] = d;
@@ -440,11 +551,11 @@ int build_dev_ops(sixdof_handle* h, DevOp* out, uint32_t* n_out, uint32_t* vel_i
 
 int fill_step_params(sixdof_handle* h, StepParams* P) {
     std::memset(P, 0, sizeof(*P));
-    P->pos = h->col(h->id_pos)->dev;
-    P->vel = h->col(h->id_vel)->dev;
-    P->accel = h->col(h->id_accel)->dev;
-    P->force = h->col(h->id_force)->dev;
-    P->inertia = h->col(h->id_inertia)->dev;
+    P->pos = h->col(h->id_pos)->live;
+    P->vel = h->col(h->id_vel)->live;
+    P->accel = h->col(h->id_accel)->live;
+    P->force = h->col(h->id_force)->live;
+    P->inertia = h->col(h->id_inertia)->live;
     P->n = static_cast<uint32_t>(h->desc.n_entities);
     P->dt_g = h->desc.simulation_time_step;
     P->dt = h->desc.has_time_step ? h->desc.time_step : h->desc.simulation_time_step;
@@ -481,11 +592,11 @@ int fill_pair_params(sixdof_handle* h, PairParams* P) {
         h->scratch_bytes = total;
     }
     char* base = static_cast<char*>(h->d_scratch);
-    P->pos = h->col(h->id_pos)->dev;
-    P->vel = h->col(h->id_vel)->dev;
-    P->accel = h->col(h->id_accel)->dev;
-    P->force = h->col(h->id_force)->dev;
-    P->inertia = h->col(h->id_inertia)->dev;
+    P->pos = h->col(h->id_pos)->live;
+    P->vel = h->col(h->id_vel)->live;
+    P->accel = h->col(h->id_accel)->live;
+    P->force = h->col(h->id_force)->live;
+    P->inertia = h->col(h->id_inertia)->live;
     P->n = static_cast<uint32_t>(n);
     P->dt_g = h->desc.simulation_time_step;
     P->dt = h->desc.has_time_step ? h->desc.time_step : h->desc.simulation_time_step;
@@ -530,20 +641,29 @@ int step_apollo(sixdof_handle* h, uint64_t n_ticks, uint64_t* launches) {
     for (int k = 0; k < 5; k++) {
         c[k] = h->col(cid(names[k]));
         if (!c[k]) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, std::string("step: Apollo model column not bound: ") + names[k]);
-        if (c[k]->width != widths[k] || c[k]->n_rows != h->desc.n_entities || c[k]->prim != SIXDOF_PRIM_F64)
+        if (c[k]->width != widths[k] || c[k]->prim != SIXDOF_PRIM_F64)
             return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, std::string("step: bad shape for ") + names[k]);
+        if (!c[k]->joined) {
+            int rc = resolve_join(h, c[k]);
+            if (rc != SIXDOF_OK) return rc;
+            if (c[k]->compact) {
+                hipError_t e = launch_gather_rows(c[k]->compact, c[k]->dev, c[k]->d_rows, static_cast<uint32_t>(h->joined_ids.size()),
+                                                  static_cast<uint32_t>(c[k]->width), c[k]->elem, h->stream);
+                if (e != hipSuccess) return h->hip_fail(e, "gather_rows");
+            }
+        }
     }
     ApolloParams P{};
-    P.pos = static_cast<double*>(h->col(h->id_pos)->dev);
-    P.vel = static_cast<double*>(h->col(h->id_vel)->dev);
-    P.accel = static_cast<double*>(h->col(h->id_accel)->dev);
-    P.force = static_cast<double*>(h->col(h->id_force)->dev);
-    P.inertia = static_cast<double*>(h->col(h->id_inertia)->dev);
-    P.state = static_cast<double*>(c[0]->dev);
-    P.params = static_cast<const double*>(c[1]->dev);
-    P.guidance = static_cast<double*>(c[2]->dev);
-    P.score = static_cast<double*>(c[3]->dev);
-    P.result = static_cast<double*>(c[4]->dev);
+    P.pos = static_cast<double*>(h->col(h->id_pos)->live);
+    P.vel = static_cast<double*>(h->col(h->id_vel)->live);
+    P.accel = static_cast<double*>(h->col(h->id_accel)->live);
+    P.force = static_cast<double*>(h->col(h->id_force)->live);
+    P.inertia = static_cast<double*>(h->col(h->id_inertia)->live);
+    P.state = static_cast<double*>(c[0]->live);
+    P.params = static_cast<const double*>(c[1]->live);
+    P.guidance = static_cast<double*>(c[2]->live);
+    P.score = static_cast<double*>(c[3]->live);
+    P.result = static_cast<double*>(c[4]->live);
     P.n = static_cast<uint32_t>(h->desc.n_entities);
     P.max_ticks = h->ap_max_ticks;
     P.guidance_period = h->ap_guidance_period;
@@ -661,6 +781,8 @@ int sixdof_download_column(sixdof_handle* h, uint64_t component_id) {
     Column* c = h->col(component_id);
     if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "download_column: unknown component");
     HIP_TRY(h, hipSetDevice(h->device));
+    int rc = scatter_back(h, c);
+    if (rc != SIXDOF_OK) return rc;
     if (c->bytes) HIP_TRY(h, hipMemcpyAsync(c->host, c->dev, c->bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SIXDOF_OK;
@@ -830,8 +952,12 @@ void sixdof_tick(const uint8_t* const* inputs, uint8_t* const* outputs) {
     for (size_t i = 0; i < in.size(); i++) {
         if (in[i] == h->id_tick) std::memcpy(&tick, inputs[i], 8);
         else if (in[i] == h->id_dt) std::memcpy(&h->desc.simulation_time_step, inputs[i], 8);
-        else if (Column* c = h->col(in[i]))
+        else if (Column* c = h->col(in[i])) {
             if (c->bytes) hipMemcpyAsync(c->dev, inputs[i], c->bytes, hipMemcpyHostToDevice, h->stream);
+            if (c->joined && c->compact)
+                launch_gather_rows(c->compact, c->dev, c->d_rows, static_cast<uint32_t>(h->joined_ids.size()),
+                                   static_cast<uint32_t>(c->width), c->elem, h->stream);
+        }
     }
     h->tick = tick;
     const uint32_t k = h->desc.ticks_per_launch;
@@ -841,8 +967,10 @@ void sixdof_tick(const uint8_t* const* inputs, uint8_t* const* outputs) {
     for (size_t i = 0; i < out.size(); i++) {
         if (out[i] == h->id_tick) std::memcpy(outputs[i], &h->tick, 8);
         else if (out[i] == h->id_dt) std::memcpy(outputs[i], &h->desc.simulation_time_step, 8);
-        else if (Column* c = h->col(out[i]))
+        else if (Column* c = h->col(out[i])) {
+            scatter_back(h, c);
             if (c->bytes) hipMemcpyAsync(outputs[i], c->dev, c->bytes, hipMemcpyDeviceToHost, h->stream);
+        }
     }
     hipStreamSynchronize(h->stream);
 }

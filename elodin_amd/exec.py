@@ -50,7 +50,7 @@ class HipExec:
                  simulation_time_step: float = 1.0 / 120.0, time_step: Optional[float] = None,
                  integrator: int = L.RK4, dtype=np.float64, effectors: Sequence[Effector] = (),
                  edges=None, ticks_per_launch: int = 1, use_graph: bool = False, device: int = 0,
-                 tick: int = 0):
+                 tick: int = 0, column_entity_ids=None):
         lib = L.lib()
         self._lib = lib
         self.dtype = np.dtype(dtype)
@@ -58,15 +58,18 @@ class HipExec:
             raise ValueError("dtype must be float64 or float32")
         f = lambda a, w: np.array(a, dtype=self.dtype, order="C").reshape(-1, w)
         self.world_pos = f(world_pos, 7)
-        n = self.world_pos.shape[0]
-        self.n = n
         self.world_vel = f(world_vel, 6)
         self.inertia = f(inertia, 7)
-        self.world_accel = np.zeros((n, 6), self.dtype) if world_accel is None else f(world_accel, 6)
-        self.force = np.zeros((n, 6), self.dtype) if force is None else f(force, 6)
-        # ids are sequential from 1 (0 = Globals) unless given: world.rs:193-196
-        self.entity_ids = (np.arange(1, n + 1, dtype=np.uint64) if entity_ids is None
+        nv = self.world_vel.shape[0]
+        self.world_accel = np.zeros((nv, 6), self.dtype) if world_accel is None else f(world_accel, 6)
+        self.force = np.zeros((nv, 6), self.dtype) if force is None else f(force, 6)
+        # ids are sequential from 1 (0 = Globals) unless given: world.rs:193-196.  `column_entity_ids` gives a
+        # column its own id vector when components live on different entity sets (six_dof then runs on the
+        # intersection, query.rs:136-208)
+        self.entity_ids = (np.arange(1, self.world_pos.shape[0] + 1, dtype=np.uint64) if entity_ids is None
                            else np.ascontiguousarray(entity_ids, dtype=np.uint64))
+        self._column_ids = {k: np.ascontiguousarray(v, dtype=np.uint64) for k, v in (column_entity_ids or {}).items()}
+        n = self.world_pos.shape[0] if not self._column_ids else 0   # 0 = let the library size the join
         self._aux = {}
         d = L.Desc()
         d.struct_size = C.sizeof(L.Desc)
@@ -93,7 +96,7 @@ class HipExec:
                     ops[k].p[j] = float(v)
                 if e.aux is not None:
                     name = e.aux_name or f"effector_aux_{k}"
-                    arr = np.array(e.aux, dtype=self.dtype, order="C").reshape(n, 3)
+                    arr = np.array(e.aux, dtype=self.dtype, order="C").reshape(-1, 3)
                     self._aux[name] = arr
                     cols.append((name, arr))
                     ops[k].aux_component_id = L.component_id(name)
@@ -123,11 +126,17 @@ class HipExec:
             c.ndim = 1
             c.dims[0] = arr.shape[1]
             c.n_rows = arr.shape[0]
-            c.entity_ids = self.entity_ids.ctypes.data_as(C.POINTER(C.c_uint64))
+            ids = self._column_ids.get(name, self.entity_ids)
+            if len(ids) != arr.shape[0]:
+                raise ValueError(f"column {name}: {arr.shape[0]} rows but {len(ids)} entity ids")
+            c.entity_ids = ids.ctypes.data_as(C.POINTER(C.c_uint64))
             c.host_ptr = arr.ctypes.data
         rc = self._lib.sixdof_bind_columns(self._h, cols, len(named_arrays))
         if rc != L.OK:
             _raise(self._h, rc, "sixdof_bind_columns")
+        m = C.c_size_t()
+        self._lib.sixdof_get_join_rows(self._h, L.component_id("world_pos"), None, 0, C.byref(m))
+        self.n = int(m.value)   # size of the joined Body entity set
 
     # -- reference-shaped surface -------------------------------------------------------------------
     def upload(self):
@@ -185,6 +194,16 @@ class HipExec:
 
     def set_flags(self, flags: int):
         self._lib.sixdof_set_flags(self._h, int(flags))
+
+    def join_rows(self, name: str) -> np.ndarray:
+        """Row of joined entity j inside column `name` (the reference's constant u32 gather indices)."""
+        rows = np.zeros(self.n, dtype=np.uint32)
+        m = C.c_size_t()
+        rc = self._lib.sixdof_get_join_rows(self._h, L.component_id(name), rows.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                            self.n, C.byref(m))
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_get_join_rows")
+        return rows
 
     def edge_rows(self):
         n = C.c_size_t()

@@ -114,7 +114,7 @@ typedef struct sixdof_desc {
     int32_t device_ordinal;      /* HIP device */
     int32_t integrator;          /* sixdof_integrator */
     int32_t dtype;               /* sixdof_dtype */
-    uint64_t n_entities;         /* rows of every Body column */
+    uint64_t n_entities;         /* size of the joined Body entity set; 0 = take it from the bound columns */
     double simulation_time_step; /* globals column value (ns-quantised, see sixdof_quantize_time_step) */
     double time_step;            /* six_dof(time_step=...) override, used iff has_time_step */
     int32_t has_time_step;
@@ -180,6 +180,11 @@ int sixdof_set_effectors(sixdof_handle* h, const sixdof_effector_op* ops, size_t
 /* Edges as (from entity id, to entity id) in spawn order; resolved to row indices against the
  * bound Body entity ids (query.rs:599-621 gathers by constant u32 indices). */
 int sixdof_set_edges(sixdof_handle* h, const uint64_t* from_ids, const uint64_t* to_ids, size_t n_edges);
+/* Join tables: row of joined entity j inside column `component_id` — the constant u32 gather indices the
+ * reference bakes at compile time (query.rs:599-621).  six_dof runs over the INTERSECTION of the Body columns'
+ * entity ids in ascending id order (query.rs:136-208); when every Body column already is that set the order is
+ * the columns' own (fast path query.rs:673,702) and rows[j] = j.  rows == NULL just returns the joined count. */
+int sixdof_get_join_rows(const sixdof_handle* h, uint64_t component_id, uint32_t* rows, size_t cap, size_t* n_out);
 /* Read back the resolved u32 row-index tables (bit-exact integer parity surface). */
 int sixdof_get_edge_rows(const sixdof_handle* h, uint32_t* src_rows, uint32_t* dst_rows, size_t cap, size_t* n_out);
 

@@ -73,3 +73,59 @@ def test_ball_example_with_telemetry_batches():
     exec.run(100)
     assert parity.pos_rel_err(exec.column_array("world_pos"), g["ball.world_pos"][100][None]) < parity.F64_RTOL
     assert parity.field_rel_err(exec.column_array("world_vel")[:, 3:], g["ball.world_vel"][100][None, 3:]) < parity.F64_RTOL
+
+
+def test_six_dof_runs_on_the_intersection_of_entity_sets():
+    """Entities with a world_pos but no Body (static scene objects / truth ghosts, apollo-lander/sim.py:312-332)
+    are never touched; joins iterate the id intersection in ascending id order (query.rs:136-208)."""
+    from elodin_amd import _lib as L
+    from oracle import oracle as orc
+    rng = np.random.default_rng(1)
+    w = el.World()
+    bodies, statics = [], []
+    for k in range(9):
+        if k % 3 == 1:   # world_pos only
+            statics.append(w.spawn(el.C("world_pos", np.concatenate([[0, 0, 0, 1.0], rng.normal(size=3)]))))
+        else:
+            q = rng.normal(size=4); q /= np.linalg.norm(q)
+            bodies.append(w.spawn([el.Body(world_pos=el.SpatialTransform(np.concatenate([q, rng.normal(size=3)])),
+                                           world_vel=el.SpatialMotion(rng.normal(size=6)),
+                                           inertia=el.SpatialInertia(rng.uniform(1, 5), rng.uniform(1, 3, 3))),
+                                   el.C("rcs", rng.uniform(-1, 1, 3))]))
+    assert [int(b) for b in bodies] == [1, 3, 4, 6, 7, 9] and [int(s) for s in statics] == [2, 5, 8]
+    pos0, pos_ids = w.column("world_pos")
+    vel0, vel_ids = w.column("world_vel")
+    exec = w.build(el.six_dof(sys=el.uniform_gravity() | el.body_torque("rcs")), simulation_rate=120.0)
+    hip = exec._hip
+    # integer parity: gather indices == positions of the intersection inside each column
+    joined = np.intersect1d(pos_ids, vel_ids)
+    assert hip.n == 6 and joined.tolist() == [1, 3, 4, 6, 7, 9]
+    assert hip.join_rows("world_pos").tolist() == [int(np.where(pos_ids == j)[0][0]) for j in joined] == [0, 2, 3, 5, 6, 8]
+    assert hip.join_rows("world_vel").tolist() == [0, 1, 2, 3, 4, 5] and hip.join_rows("world_vel").dtype == np.uint32
+    exec.run(25)
+    rows = hip.join_rows("world_pos")
+    inertia0, _ = w.column("inertia")
+    rcs, _ = w.column("rcs")
+    ref = orc.OracleWorld(pos0[rows], vel0, inertia0, simulation_time_step=0.008333333,
+                          ops=[(orc.EFF_UNIFORM_GRAVITY, (0, 0, -9.81), None), (orc.EFF_BODY_TORQUE, (), rcs)]).step(25)
+    got = exec.column_array("world_pos")
+    assert parity.pos_rel_err(got[rows], ref.world_pos) < parity.F64_RTOL
+    static_rows = [1, 4, 7]
+    assert np.array_equal(got[static_rows], pos0[static_rows])          # untouched, bit for bit
+    assert max(parity.field_rel_err(exec.column_array("world_vel")[:, :3], ref.world_vel[:, :3]),
+               parity.field_rel_err(exec.column_array("world_vel")[:, 3:], ref.world_vel[:, 3:])) < parity.F64_RTOL
+
+
+def test_join_in_ascending_id_order_when_components_were_inserted_late():
+    """insert() on an existing entity appends its row out of id order; the join still runs in ascending id order."""
+    w = el.World()
+    a = w.spawn(el.C("world_pos", [0, 0, 0, 1.0, 1, 0, 0]))                     # id 1: pose first ...
+    b = w.spawn(el.Body(world_pos=el.SpatialTransform(linear=[2.0, 0, 0]), world_vel=el.SpatialMotion(linear=[0, 1.0, 0])))
+    for name, val in (("world_vel", [0, 0, 0, 1.0, 0, 0]), ("inertia", [1, 1, 1, 0, 0, 0, 1.0]),
+                      ("force", [0] * 6), ("world_accel", [0] * 6)):
+        w.insert(a, el.C(name, val))                                            # ... the rest of the Body later
+    exec = w.build(el.six_dof(1.0))
+    hip = exec._hip
+    assert hip.join_rows("world_pos").tolist() == [0, 1] and hip.join_rows("world_vel").tolist() == [1, 0]
+    exec.run(1)
+    assert np.allclose(exec.column_array("world_pos")[:, 4:], [[2.0, 0, 0], [2.0, 1.0, 0]])
