@@ -102,7 +102,11 @@ def nbody_leg(device):
     evals = 3.0 * n * (n - 1)   # every pair is visited once per tick and accumulates the 3 distinct stage forces
     return {"bodies": n, "ms_per_tick": round(ms, 4), "body_steps_per_s": round(n / ms * 1e3, 1),
             "pair_evals_per_s": round(evals / ms * 1e3, 1), "bound": "f64 vector ALU",
-            "f64_instr_per_eval": 17, "frac_of_f64_fma_issue_peak": round(evals * 17 / (ms * 1e-3) / 39.3e12, 4)}
+            "f64_instr_per_eval": "17 VALU + 1 v_rsq_f64",
+            # spec: 39.3e12 lane-FMA/s at 2.4 GHz; measured sustained issue (profiles/r01_ubench_f64_rates.txt):
+            # 2.42 ns per f64 wave-op per SIMD, v_rsq_f64 7.0 ns -> 48.1 ns per wave-eval -> 1.36e12 evals/s
+            "frac_of_spec_f64_fma_peak": round(evals * 17 / (ms * 1e-3) / 39.3e12, 4),
+            "frac_of_measured_issue_bound": round(evals / (ms * 1e-3) / (1024 * 64 / 48.1e-9), 4)}
 
 
 def apollo_leg(device):
