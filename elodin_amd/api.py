@@ -193,16 +193,20 @@ def gravity_softened(K: float, eps: float, edge_component: Optional[str] = "grav
 @dataclass
 class System:
     time_step: Optional[float]
-    effectors: Effectors
+    effectors: object   # Effectors (built-in ops) or dsl.Pipe (generated)
     integrator: Integrator
 
 
-def six_dof(time_step: Optional[float] = None, sys: Optional[Effectors] = None,
-            integrator: Integrator = Integrator.Rk4) -> System:
-    """elodin.six_dof(time_step=None, sys=None, integrator=Integrator.Rk4) — lib.rs:106-127, six_dof.rs:161-203."""
+def six_dof(time_step: Optional[float] = None, sys=None, integrator: Integrator = Integrator.Rk4) -> System:
+    """elodin.six_dof(time_step=None, sys=None, integrator=Integrator.Rk4) — lib.rs:106-127, six_dof.rs:161-203.
+    `sys` is a pipe of built-in effector descriptors (`uniform_gravity() | ...`) or of user-written effectors
+    traced by elodin_amd.dsl (`dsl.pipe(f, g)` / `f | g`), which are compiled into the step kernel at build()."""
     if not isinstance(integrator, Integrator):
         raise TypeError("integrator must be an Integrator")
-    return System(time_step, sys or Effectors(), integrator)
+    from . import dsl as _dsl
+    if isinstance(sys, _dsl.Effector):
+        sys = _dsl.pipe(sys)
+    return System(time_step, sys if sys is not None else Effectors(), integrator)
 
 
 # ---- world ----------------------------------------------------------------------------------------------------
@@ -264,15 +268,25 @@ class World:
         # six_dof runs on the intersection (query.rs:136-208); each column keeps its own id vector
         column_ids = {"world_pos": ids, **{k: v[1] for k, v in body.items()}}
         effs = []
-        for e in system.effectors.ops:
-            if e.aux_name is not None:
-                arr, aids = self.column(e.aux_name)
-                column_ids[e.aux_name] = aids
-                e = Effector(e.kind, e.p, e.aux_name, arr)
-            effs.append(e)
+        extra_columns = None
+        from . import dsl as _dsl
+        if isinstance(system.effectors, _dsl.Pipe):
+            effs = system.effectors
+            extra_columns = {}
+            for name, _w in system.effectors.trace().columns:
+                arr, aids = self.column(name)
+                column_ids[name] = aids
+                extra_columns[name] = arr
+        else:
+            for e in system.effectors.ops:
+                if e.aux_name is not None:
+                    arr, aids = self.column(e.aux_name)
+                    column_ids[e.aux_name] = aids
+                    e = Effector(e.kind, e.p, e.aux_name, arr)
+                effs.append(e)
         same = all(np.array_equal(v, ids) for v in column_ids.values())
         edges = None
-        if system.effectors.edge_component:
+        if not isinstance(system.effectors, _dsl.Pipe) and system.effectors.edge_component:
             pairs = self._edges.get(system.effectors.edge_component)
             if pairs is None:
                 raise KeyError(system.effectors.edge_component)
@@ -281,7 +295,7 @@ class World:
                       force=body["force"][0], entity_ids=ids, simulation_time_step=dt, time_step=system.time_step,
                       integrator=system.integrator.value, effectors=effs, edges=edges,
                       ticks_per_launch=ticks_per_telemetry, device=device,
-                      column_entity_ids=None if same else column_ids)
+                      column_entity_ids=None if same else column_ids, columns=extra_columns)
         return Exec(hip, self, ticks_per_telemetry, dt)
 
 

@@ -26,6 +26,7 @@ struct Body {
     Vec3<T> p;     // stage position
     Spatial<T> v;  // stage velocity
     T mass;
+    Vec3<T> I;     // body-frame inertia diagonal (only read by generated pipes)
 };
 
 template <class T>

@@ -12,8 +12,8 @@ constexpr int kBlock = 256;      // threads per workgroup = entities per workgro
 // One effector op as the kernel sees it (sixdof_effector_op with the aux column resolved).
 struct DevOp {
     int32_t kind;
-    int32_t pad;
-    const void* aux;  // device [n,3] column (element type = state dtype) or nullptr
+    int32_t aux_width;  // row width of `aux` (1..3); 0 = 3
+    const void* aux;    // device [n,aux_width] column (element type = state dtype) or nullptr
     double p[6];
 };
 
@@ -46,6 +46,10 @@ enum : int { kRk4 = 0, kSemiImplicit = 1 };
 // Fused clear_forces | effectors | calc_accel | integrator over n entities, n_ticks ticks.
 // dtype: 0 = f64, 1 = f32.  Returns hipGetLastError() of the launch.
 hipError_t launch_step(const StepParams& p, int integrator, int dtype, hipStream_t stream);
+
+// Entry points of a run-time generated effector pipe (elodin_amd/codegen.py), resolved with dlsym.
+using CustomAbiFn = unsigned (*)();                                               // sizeof(StepParams) it was built with
+using CustomLaunchFn = int (*)(const StepParams*, int integrator, int dtype, void* stream);  // returns hipError_t
 
 // ---- pairwise (edge_fold) path -----------------------------------------------------------------------
 // One tick = pack -> accumulate -> integrate (3 launches).  See nbody_kernels.hip.

@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void pair_integrate_kernel(const PairParams P)
     }
     Body<T> b;
     b.mass = mass;
+    b.I = Vec3<T>{in[0], in[1], in[2]};
     Wrench<T> F;
     auto stage_force = [&](int st) {
         F = zero_wrench<T>();

@@ -9,6 +9,7 @@
 //
 // No CPU fallback exists: every entry point that needs the GPU fails with SIXDOF_ERR_NO_DEVICE /
 // SIXDOF_ERR_BACKEND when HIP is unavailable.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -81,6 +82,10 @@ struct sixdof_handle {
     bool identity_join = true;         // every Body column already is the joined set (query.rs:673,702 fast path)
     uint64_t tick = 0;
     bool bound = false;
+    // run-time generated effector pipe
+    void* custom_dl = nullptr;
+    CustomLaunchFn custom_launch = nullptr;
+    std::vector<uint64_t> custom_aux;
     // telemetry ring
     uint32_t hist_ring = 0;
     uint64_t hist_first_tick = 0;   // first tick (1-based count) recorded since the ring was enabled
@@ -271,6 +276,7 @@ void sixdof_destroy(sixdof_handle* h) {
     if (h->d_scratch) hipFree(h->d_scratch);
     if (h->d_tick_refs) hipFree(h->d_tick_refs);
     for (void* p : h->d_hist) if (p) hipFree(p);
+    if (h->custom_dl) dlclose(h->custom_dl);
     for (hipEvent_t e : h->launch_events) hipEventDestroy(e);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -522,6 +528,29 @@ namespace {
 int build_dev_ops(sixdof_handle* h, DevOp* out, uint32_t* n_out, uint32_t* vel_independent) {
     uint32_t n = 0;
     *vel_independent = 1;
+    if (h->custom_launch) {   // generated pipe: slots are just the columns its code reads
+        for (uint64_t id : h->custom_aux) {
+            Column* c = h->col(id);
+            if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "step: column read by the generated pipe is not bound");
+            if (c->width < 1 || c->width > 3 || c->prim != h->state_prim())
+                return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, "step: generated-pipe columns must be [n,1..3] of the state dtype");
+            if (!c->joined) {
+                int rc = resolve_join(h, c);
+                if (rc != SIXDOF_OK) return rc;
+                if (c->compact) {
+                    hipError_t e = launch_gather_rows(c->compact, c->dev, c->d_rows, static_cast<uint32_t>(h->joined_ids.size()),
+                                                      static_cast<uint32_t>(c->width), c->elem, h->stream);
+                    if (e != hipSuccess) return h->hip_fail(e, "gather_rows");
+                }
+            }
+            DevOp d{};
+            d.aux = c->live;
+            d.aux_width = static_cast<int32_t>(c->width);
+            out[n++] = d;
+        }
+        *n_out = n;
+        return SIXDOF_OK;
+    }
     for (auto& o : h->ops) {
         if (o.kind >= SIXDOF_EFF_EDGE_GRAVITY_NEWTON) continue;
         DevOp d{};
@@ -574,6 +603,12 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
 }
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// built-in pipes or the handle's generated pipe
+hipError_t launch_any(sixdof_handle* h, const StepParams& P) {
+    if (h->custom_launch) return static_cast<hipError_t>(h->custom_launch(&P, h->desc.integrator, h->desc.dtype, h->stream));
+    return launch_step(P, h->desc.integrator, h->desc.dtype, h->stream);
+}
 
 int fill_pair_params(sixdof_handle* h, PairParams* P) {
     std::memset(P, 0, sizeof(*P));
@@ -726,6 +761,26 @@ int sixdof_set_model_apollo(sixdof_handle* h, const sixdof_apollo_tables* t) {
     return SIXDOF_OK;
 }
 
+int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t* aux_ids, size_t n_aux) {
+    if (!h || !so_path || (!aux_ids && n_aux)) return SIXDOF_ERR_INVALID_ARGUMENT;
+    if (n_aux > static_cast<size_t>(kMaxOps)) return h->fail(SIXDOF_ERR_UNSUPPORTED, "set_custom_pipe: at most 4 columns");
+    void* dl = dlopen(so_path, RTLD_NOW | RTLD_LOCAL);
+    if (!dl) return h->fail(SIXDOF_ERR_BACKEND, std::string("set_custom_pipe: dlopen failed: ") + dlerror());
+    auto abi = reinterpret_cast<CustomAbiFn>(dlsym(dl, "sixdof_custom_abi"));
+    auto launch = reinterpret_cast<CustomLaunchFn>(dlsym(dl, "sixdof_custom_launch"));
+    if (!abi || !launch || abi() != sizeof(StepParams)) {
+        dlclose(dl);
+        return h->fail(SIXDOF_ERR_BACKEND, "set_custom_pipe: not a generated pipe for this library build (StepParams layout differs)");
+    }
+    if (h->custom_dl) dlclose(h->custom_dl);
+    h->custom_dl = dl;
+    h->custom_launch = launch;
+    h->custom_aux.assign(aux_ids, aux_ids + n_aux);
+    h->ops.clear();
+    h->drop_graph();
+    return SIXDOF_OK;
+}
+
 int sixdof_set_history(sixdof_handle* h, uint32_t ring_ticks) {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "set_history: bind Body columns first");
@@ -837,7 +892,7 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
                 HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
                 hipError_t le = hipSuccess;
                 for (uint32_t i = 0; i < kGraphLen && le == hipSuccess; i++)
-                    le = launch_step(P, h->desc.integrator, h->desc.dtype, h->stream);
+                    le = launch_any(h, P);
                 hipError_t ce = hipStreamEndCapture(h->stream, &g);
                 if (le != hipSuccess) return h->hip_fail(le, "launch_step (capture)");
                 if (ce != hipSuccess) return h->hip_fail(ce, "hipStreamEndCapture");
@@ -861,7 +916,7 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
             if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches], h->stream));
             P.hist_slot0 = h->tick + ticks_issued;
             ticks_issued += K;
-            hipError_t e = launch_step(P, h->desc.integrator, h->desc.dtype, h->stream);
+            hipError_t e = launch_any(h, P);
             if (e != hipSuccess) return h->hip_fail(e, "launch_step");
             if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches + 1], h->stream));
             launches++;
@@ -870,7 +925,7 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
             P.n_ticks = rem;
             P.hist_slot0 = h->tick + ticks_issued;
             if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches], h->stream));
-            hipError_t e = launch_step(P, h->desc.integrator, h->desc.dtype, h->stream);
+            hipError_t e = launch_any(h, P);
             if (e != hipSuccess) return h->hip_fail(e, "launch_step");
             if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches + 1], h->stream));
             launches++;

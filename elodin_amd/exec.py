@@ -50,7 +50,7 @@ class HipExec:
                  simulation_time_step: float = 1.0 / 120.0, time_step: Optional[float] = None,
                  integrator: int = L.RK4, dtype=np.float64, effectors: Sequence[Effector] = (),
                  edges=None, ticks_per_launch: int = 1, use_graph: bool = False, device: int = 0,
-                 tick: int = 0, column_entity_ids=None):
+                 tick: int = 0, column_entity_ids=None, columns=None):
         lib = L.lib()
         self._lib = lib
         self.dtype = np.dtype(dtype)
@@ -89,6 +89,22 @@ class HipExec:
         try:
             cols = [("world_pos", self.world_pos), ("world_vel", self.world_vel), ("world_accel", self.world_accel),
                     ("force", self.force), ("inertia", self.inertia)]
+            custom = None
+            from . import dsl as _dsl
+            if isinstance(effectors, _dsl.Effector):
+                effectors = _dsl.pipe(effectors)
+            if isinstance(effectors, _dsl.Pipe):
+                # user-written effectors: trace -> generate HIP -> hipcc -> sixdof_set_custom_pipe
+                from . import codegen
+                custom = effectors.trace()
+                so = codegen.build(custom, self.dtype.name, integrator)
+                for name, width in custom.columns:
+                    if columns is None or name not in columns:
+                        raise KeyError(f"effector reads component {name!r} which was not provided")
+                    arr = np.array(columns[name], dtype=self.dtype, order="C").reshape(-1, width)
+                    self._aux[name] = arr
+                    cols.append((name, arr))
+                effectors = ()
             ops = (L.EffectorOp * max(1, len(effectors)))()
             for k, e in enumerate(effectors):
                 ops[k].kind = e.kind
@@ -104,6 +120,11 @@ class HipExec:
             rc = lib.sixdof_set_effectors(self._h, ops, len(effectors))
             if rc != L.OK:
                 _raise(self._h, rc, "sixdof_set_effectors")
+            if custom is not None:
+                ids = (C.c_uint64 * max(1, len(custom.columns)))(*[L.component_id(n) for n, _ in custom.columns])
+                rc = lib.sixdof_set_custom_pipe(self._h, str(so).encode(), ids, len(custom.columns))
+                if rc != L.OK:
+                    _raise(self._h, rc, "sixdof_set_custom_pipe")
             if edges is not None:
                 frm = np.ascontiguousarray(edges[0], dtype=np.uint64)
                 to = np.ascontiguousarray(edges[1], dtype=np.uint64)

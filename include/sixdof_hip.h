@@ -208,6 +208,15 @@ void sixdof_tick(const uint8_t* const* inputs, uint8_t* const* outputs);
 int sixdof_tick_slots(const sixdof_handle* h, sixdof_slot* inputs, size_t in_cap, size_t* n_in,
                       sixdof_slot* outputs, size_t out_cap, size_t* n_out);
 
+/* ---- effector front-end: run-time generated pipes -------------------------------------------------------------
+ * The reference JIT-compiles whatever effector graph the user wrote (cranelift_compile.rs:13-162).  The analogue
+ * here: elodin_amd/codegen.py turns an effector pipe written against a jax.numpy-like tracer into HIP source that
+ * instantiates the SAME fused step kernel (csrc/step_kernel.hpp) with the user's code as its effector stage,
+ * builds it with hipcc for gfx950 and hands the shared object to this call.  `aux_component_ids` name the bound
+ * per-entity columns (row width 1..3) the generated code reads, in the order it indexes them (<= 4).
+ * Replaces the built-in op list (sixdof_set_effectors) for the per-entity path. */
+int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t* aux_component_ids, size_t n_aux);
+
 /* ---- telemetry: device-side history ring (the commit step either side of the path) ------------------------
  * The reference commits every output column to its DB after each batch (exec.rs:110-172,
  * impeller2_server.rs:390-438) and `exec.history()` reads it back.  With a ring enabled, sixdof_step writes

@@ -1,0 +1,78 @@
+"""Effector front-end, CPU side: tracing, code generation (hipcc cross-compiles here) and the numpy
+stepper that serves as oracle for user-written effectors."""
+import numpy as np
+import pytest
+
+from elodin_amd import codegen, dsl, workloads
+from oracle import oracle as orc
+from tests import dsl_numpy, np_sixdof
+
+np_ = dsl.np
+
+
+@dsl.effector
+def gravity(force, inertia):                                     # examples/ball/sim.py:57-59
+    return force + dsl.SpatialForce(linear=np_.array([0.0, 0.0, -9.81]) * inertia.mass())
+
+
+@dsl.effector(body_torque=3)
+def rcs(force, pos, body_torque):                                # apollo-lander/sim.py:396-398
+    return force + dsl.SpatialForce(torque=pos.angular() @ body_torque)
+
+
+def test_numpy_stepper_is_bit_identical_to_the_c_oracle():
+    w = workloads.independent_bodies(500)
+    ops = [(orc.EFF_UNIFORM_GRAVITY, (0, 0, -9.81), None), (orc.EFF_BODY_TORQUE, (), w["body_torque"])]
+    inertia = w["inertia"]
+
+    def eff(xs, vs):
+        F = np.zeros((len(xs), 6))
+        F[:, 3:] = F[:, 3:] + np.array([0.0, 0.0, -9.81]) * inertia[:, 6:7]
+        F[:, :3] = F[:, :3] + np_sixdof.rot(xs[:, :4], w["body_torque"])
+        return F
+    for integ in (0, 1):
+        o = orc.OracleWorld(w["world_pos"], w["world_vel"], inertia, simulation_time_step=workloads.DT_120HZ,
+                            integrator=integ, ops=ops)
+        pos, vel, acc = w["world_pos"].copy(), w["world_vel"].copy(), np.zeros((500, 6))
+        for _ in range(5):
+            o.step(1)
+            pos, vel, acc, F = np_sixdof.tick(pos, vel, acc, inertia, eff, workloads.DT_120HZ, integrator=integ)
+        assert np.array_equal(pos, o.world_pos) and np.array_equal(vel, o.world_vel)
+        assert np.array_equal(acc, o.world_accel) and np.array_equal(F, o.force)
+
+
+def test_trace_flags_columns_and_folding():
+    tp = (gravity | rcs).trace()
+    assert tp.columns == [("body_torque", 3)] and not tp.reads_velocity and tp.world_torque
+    assert "mass" in tp.leaves and "vx" not in tp.leaves
+    only_g = dsl.pipe(gravity).trace()
+    assert not only_g.world_torque and only_g.columns == []
+    assert only_g.outputs[3].op == "mul"               # 0.0 * mass is NOT folded (IEEE: mass may be inf/NaN)
+    assert all(t.is_const(0.0) for t in only_g.outputs[:3])
+
+    @dsl.effector(wind=3)
+    def drag(wind, vel, force):
+        fl = wind - vel.linear()
+        return dsl.SpatialForce(linear=force.force() + fl)
+    assert (gravity | drag).trace().reads_velocity
+    with pytest.raises(TypeError):
+        dsl.pipe(dsl.effector(lambda force: 3.0)).trace()
+    with pytest.raises(TypeError):
+        bool(dsl.leaf("x") < 1.0)
+
+
+def test_dag_matches_direct_numpy():
+    tp = (gravity | rcs).trace()
+    w = workloads.independent_bodies(64)
+    F = dsl_numpy.evaluate(tp, w["world_pos"], w["world_vel"], w["inertia"], {"body_torque": w["body_torque"]})
+    assert np.allclose(F[:, 5], -9.81 * w["inertia"][:, 6]) and np.all(F[:, 3:5] == 0)
+    assert np.allclose(F[:, :3], np_sixdof.rot(w["world_pos"][:, :4], w["body_torque"]), rtol=1e-13, atol=1e-15)
+
+
+def test_generated_source_compiles_for_gfx950():
+    tp = (gravity | rcs).trace()
+    src = codegen.generate_source(tp, "float64", 0)
+    assert "struct PipeCustom" in src and "sixdof_custom_launch" in src and "kWorldTorque = true" in src
+    so = codegen.build(tp, "float64", 0)
+    assert so.exists() and so.suffix == ".so"
+    assert codegen.build(tp, "float64", 0) == so          # cached by content hash
