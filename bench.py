@@ -166,7 +166,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = "WORLD_SIZE" in os.environ and "RANK" in os.environ   # launched by torch.distributed.run
 
     import torch
     if not torch.cuda.is_available():
@@ -179,7 +179,7 @@ def main():
 
     def barrier():
         if distributed:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     n = args.entities
@@ -194,9 +194,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        from elodin_amd import shard
+        elapsed = shard.max_over_ranks(elapsed, device=torch.device("cuda", local_rank))   # MAX over ranks
 
     value = n * world * args.steps / elapsed
     out = {
@@ -254,7 +253,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, eff)
     if distributed:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
