@@ -196,6 +196,15 @@ class System:
     effectors: object   # Effectors (built-in ops) or dsl.Pipe (generated)
     integrator: Integrator
 
+    # `pre_system | six_dof(...) | post_system` with systems written against elodin_amd.dsl
+    def __or__(self, other):
+        from . import dsl as _dsl
+        return _dsl.Stages([self]) | other
+
+    def __ror__(self, other):
+        from . import dsl as _dsl
+        return _dsl.Stages([other]) | self
+
 
 def six_dof(time_step: Optional[float] = None, sys=None, integrator: Integrator = Integrator.Rk4) -> System:
     """elodin.six_dof(time_step=None, sys=None, integrator=Integrator.Rk4) — lib.rs:106-127, six_dof.rs:161-203.
@@ -262,6 +271,17 @@ class World:
                                  f"({simulation_rate} Hz); got ratio {ratio}")   # world_builder.rs:223-240
             ticks_per_telemetry = int(round(ratio))
         dt = float(L.lib().sixdof_quantize_time_step(simulation_rate))
+        from . import dsl as _dsl
+        program_stages = None
+        if isinstance(system, _dsl.Stages):      # pre | six_dof(effectors) | post  -> one generated program
+            six = [k for k, it in enumerate(system.items) if isinstance(it, System)]
+            if len(six) != 1:
+                raise ValueError("a system pipe must contain exactly one six_dof(...)")
+            program_stages = (system.items[:six[0]], system.items[six[0] + 1:])
+            system = system.items[six[0]]
+            for it in program_stages[0] + program_stages[1]:
+                if not isinstance(it, _dsl.System):
+                    raise TypeError("systems piped around six_dof must be elodin_amd.dsl systems")
         pos, ids = self.column("world_pos")
         body = {k: self.column(k) for k in ("world_vel", "inertia", "world_accel", "force")}
         # components may live on different entity sets (a scene object with a world_pos but no Body):
@@ -269,8 +289,18 @@ class World:
         column_ids = {"world_pos": ids, **{k: v[1] for k, v in body.items()}}
         effs = []
         extra_columns = None
-        from . import dsl as _dsl
-        if isinstance(system.effectors, _dsl.Pipe):
+        if program_stages is not None:
+            eff_pipe = system.effectors if isinstance(system.effectors, _dsl.Pipe) else _dsl.Pipe([])
+            if not isinstance(system.effectors, _dsl.Pipe) and system.effectors.ops:
+                raise TypeError("inside a generated program the six_dof effectors must be dsl effectors")
+            widths = {name: int(np.atleast_2d(np.stack(rows)).shape[1]) for name, rows in self._cols.items()}
+            effs = _dsl.Program(program_stages[0], eff_pipe, program_stages[1])
+            extra_columns = {}
+            for name, _w in effs.trace(widths).columns:
+                arr, aids = self.column(name)
+                column_ids[name] = aids
+                extra_columns[name] = arr
+        elif isinstance(system.effectors, _dsl.Pipe):
             effs = system.effectors
             extra_columns = {}
             for name, _w in system.effectors.trace().columns:
@@ -286,7 +316,7 @@ class World:
                 effs.append(e)
         same = all(np.array_equal(v, ids) for v in column_ids.values())
         edges = None
-        if not isinstance(system.effectors, _dsl.Pipe) and system.effectors.edge_component:
+        if program_stages is None and not isinstance(system.effectors, _dsl.Pipe) and system.effectors.edge_component:
             pairs = self._edges.get(system.effectors.edge_component)
             if pairs is None:
                 raise KeyError(system.effectors.edge_component)
@@ -321,6 +351,10 @@ class Exec:
         if name in self._hip._aux:
             return self._hip._aux[name]
         raise KeyError(name)
+
+    def component(self, name: str) -> np.ndarray:
+        """Any bound component column after the last run (program columns are downloaded with the Body columns)."""
+        return self.column_array(name)
 
     def entity_ids(self) -> np.ndarray:
         return self._hip.entity_ids

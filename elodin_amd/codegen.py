@@ -37,12 +37,32 @@ _BOOL_OPS = {"lt", "le", "and", "or", "not"}
 
 def _literal(v: float) -> str:
     if v != v or v in (float("inf"), float("-inf")):
-        raise ValueError("non-finite constant in effector")
+        raise ValueError("non-finite constant in generated code")
     return f"T({v!r})"
 
 
-def emit_apply(tp: dsl.TracedPipe) -> List[str]:
-    """Straight-line C++ for the DAG, common sub-expressions emitted once, in dependency order."""
+# leaf -> C++ lvalue, per context
+_APPLY_LEAVES = dict(_LEAF_CPP)                                   # effector stage: the stage body `b`
+_SYSTEM_LEAVES = {"qi": "q.i", "qj": "q.j", "qk": "q.k", "qw": "q.w", "px": "p.x", "py": "p.y", "pz": "p.z",
+                  "wx": "v.ang.x", "wy": "v.ang.y", "wz": "v.ang.z", "vx": "v.lin.x", "vy": "v.lin.y", "vz": "v.lin.z",
+                  "Ix": "I.x", "Iy": "I.y", "Iz": "I.z", "mass": "mass", "tick": "T(tick)"}
+
+
+def _leaf_ref(name: str, table: Dict[str, str]) -> str:
+    if name in table:
+        return table[name]
+    if name.startswith("aux"):
+        slot, k = name[3:].split("_")
+        return f"aux[{slot}].{'xyz'[int(k)]}"
+    if name.startswith("c"):
+        slot, k = name[1:].split("_")
+        return f"r.c{slot}[{k}]"
+    raise KeyError(name)
+
+
+def emit_block(assign, leaves: Dict[str, str], indent: str = "        ") -> List[str]:
+    """Straight-line C++ for a list of (lvalue, Expr): every output is computed into a temporary first (a system may
+    read a component it also writes), common sub-expressions are emitted once, in dependency order."""
     names: Dict[int, str] = {}
     lines: List[str] = []
 
@@ -50,10 +70,7 @@ def emit_apply(tp: dsl.TracedPipe) -> List[str]:
         if e.op == "const":
             return _literal(e.value)
         if e.op == "leaf":
-            if e.name in _LEAF_CPP:
-                return _LEAF_CPP[e.name]
-            slot, k = e.name[3:].split("_")          # aux<slot>_<k>
-            return f"aux[{slot}].{'xyz'[int(k)]}"
+            return _leaf_ref(e.name, leaves)
         if id(e) in names:
             return names[id(e)]
         a = [ref(x) for x in e.args]
@@ -82,50 +99,121 @@ def emit_apply(tp: dsl.TracedPipe) -> List[str]:
         name = f"t{len(names)}"
         names[id(e)] = name
         ctype = "bool" if e.op in _BOOL_OPS else "T"
-        lines.append(f"        const {ctype} {name} = {rhs};")
+        lines.append(f"{indent}const {ctype} {name} = {rhs};")
         return name
 
-    outs = [ref(o) for o in tp.outputs]
-    lines.append(f"        F.tau_w = Vec3<T>{{{outs[0]}, {outs[1]}, {outs[2]}}};")
-    lines.append("        F.tau_b = Vec3<T>{T(0), T(0), T(0)};")
-    lines.append(f"        F.f = Vec3<T>{{{outs[3]}, {outs[4]}, {outs[5]}}};")
+    outs = []
+    for k, (lv, e) in enumerate(assign):
+        lines.append(f"{indent}const T o{k} = {ref(e)};")
+        outs.append((lv, f"o{k}"))
+    for lv, o in outs:
+        lines.append(f"{indent}{lv} = {o};")
     return lines
 
 
-def generate_source(tp: dsl.TracedPipe, dtype: str, integrator: int) -> str:
+def emit_apply(tp: dsl.TracedPipe) -> List[str]:
+    names = ["F.tau_w.x", "F.tau_w.y", "F.tau_w.z", "F.f.x", "F.f.y", "F.f.z"]
+    lines = emit_block(list(zip(names, tp.outputs)), _APPLY_LEAVES)
+    lines.append("        F.tau_b = Vec3<T>{T(0), T(0), T(0)};")
+    return lines
+
+
+def _emit_systems(systems) -> str:
+    out = []
+    for s in systems:
+        assign = [(_leaf_ref(t, _SYSTEM_LEAVES), e) for t, e in s.assign]
+        body = "\n".join(emit_block(assign, _SYSTEM_LEAVES, indent="            "))
+        guard = f"if (tick % {s.every}ull == 0ull) " if s.every > 1 else ""
+        out.append(f"        {guard}{{  // {s.name}\n{body}\n        }}")
+    return "\n".join(out)
+
+
+_PRELUDE = '''template <class T> __device__ __forceinline__ T m_sqrt(T x) { return fast_sqrt(x); }
+__device__ __forceinline__ double m_abs(double x) { return fabs(x); }
+__device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
+#define SIXDOF_M1(name, fd, ff) \\
+    __device__ __forceinline__ double name(double x) { return fd(x); } \\
+    __device__ __forceinline__ float name(float x) { return ff(x); }
+SIXDOF_M1(m_sin, sin, sinf) SIXDOF_M1(m_cos, cos, cosf) SIXDOF_M1(m_tan, tan, tanf) SIXDOF_M1(m_exp, exp, expf)
+SIXDOF_M1(m_log, log, logf) SIXDOF_M1(m_acos, acos, acosf) SIXDOF_M1(m_asin, asin, asinf)
+#define SIXDOF_M2(name, fd, ff) \\
+    __device__ __forceinline__ double name(double x, double y) { return fd(x, y); } \\
+    __device__ __forceinline__ float name(float x, float y) { return ff(x, y); }
+SIXDOF_M2(m_max, fmax, fmaxf) SIXDOF_M2(m_min, fmin, fminf) SIXDOF_M2(m_atan2, atan2, atan2f) SIXDOF_M2(m_hypot, hypot, hypotf)
+'''
+
+
+def generate_source(tp, dtype: str, integrator: int) -> str:
+    """tp: dsl.TracedPipe (effectors only) or dsl.TracedProgram (pre | six_dof(effectors) | post)."""
     T = {"float64": "double", "float32": "float"}[dtype]
-    body = "\n".join(emit_apply(tp))
     integ = "kRk4" if integrator == 0 else "kSemiImplicit"
-    return f'''// generated by elodin_amd/codegen.py — do not edit.  Effectors: {", ".join(e.__name__ for e in tp.effectors)}
+    is_prog = isinstance(tp, dsl.TracedProgram)
+    pipe_tp = tp.pipe if is_prog else tp
+    body = "\n".join(emit_apply(pipe_tp))
+    n_aux = 0 if is_prog else len(tp.columns)
+    model = ""
+    n_model = 0
+    if is_prog:
+        cols = tp.columns
+        n_model = len(cols)
+        regs = "\n".join(f"        T c{k}[{w}];" for k, (_, w) in enumerate(cols))
+        loads = "\n".join(
+            f"            {{ const T* g = static_cast<const T*>(P.model_cols[{k}]) + (size_t)row * {w}; "
+            + " ".join(f"r.c{k}[{j}] = g[{j}];" for j in range(w)) + " }" for k, (_, w) in enumerate(cols))
+        zero = " ".join(f"for (int j = 0; j < {w}; j++) r.c{k}[j] = T(0);" for k, (_, w) in enumerate(cols))
+        stores = "\n".join(
+            f"        {{ T* g = static_cast<T*>(P.model_cols[{k}]) + (size_t)row * {cols[k][1]}; "
+            + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(cols[k][1])) + " }" for k in tp.written_slots)
+        model = f'''
+    static constexpr bool kHasModel = true;
+    static constexpr bool kWritesInertia = {"true" if tp.writes_inertia else "false"};
+    template <class T>
+    struct Regs {{
+{regs}
+    }};
+    template <class T>
+    __device__ static __forceinline__ void load(const StepParams& P, uint32_t row, bool active, Regs<T>& r) {{
+        {zero}
+        if (active) {{
+{loads}
+        }}
+    }}
+    template <class T>
+    __device__ static __forceinline__ void store(const StepParams& P, uint32_t row, const Regs<T>& r) {{
+{stores}
+    }}
+    template <class T>
+    __device__ static __forceinline__ void pre(const StepParams& P, uint64_t tick, Regs<T>& r, Quat<T>& q, Vec3<T>& p,
+                                               Spatial<T>& v, Vec3<T>& I, T& mass) {{
+        (void)P; (void)tick;
+{_emit_systems(tp.pre)}
+    }}
+    template <class T>
+    __device__ static __forceinline__ void post(const StepParams& P, uint64_t tick, Regs<T>& r, Quat<T>& q, Vec3<T>& p,
+                                                Spatial<T>& v, Vec3<T>& I, T& mass) {{
+        (void)P; (void)tick;
+{_emit_systems(tp.post)}
+    }}'''
+    names = ", ".join(e.__name__ for e in pipe_tp.effectors)
+    return f'''// generated by elodin_amd/codegen.py — do not edit.  Effectors: {names}
 #include "step_kernel.hpp"
 
 namespace sixdof {{
 
-template <class T> __device__ __forceinline__ T m_sqrt(T x) {{ return fast_sqrt(x); }}
-__device__ __forceinline__ double m_abs(double x) {{ return fabs(x); }}
-__device__ __forceinline__ float m_abs(float x) {{ return fabsf(x); }}
-#define SIXDOF_M1(name, fd, ff) \\
-    __device__ __forceinline__ double name(double x) {{ return fd(x); }} \\
-    __device__ __forceinline__ float name(float x) {{ return ff(x); }}
-SIXDOF_M1(m_sin, sin, sinf) SIXDOF_M1(m_cos, cos, cosf) SIXDOF_M1(m_tan, tan, tanf) SIXDOF_M1(m_exp, exp, expf)
-SIXDOF_M1(m_log, log, logf) SIXDOF_M1(m_acos, acos, acosf) SIXDOF_M1(m_asin, asin, asinf)
-#define SIXDOF_M2(name, fd, ff) \\
-    __device__ __forceinline__ double name(double x, double y) {{ return fd(x, y); }} \\
-    __device__ __forceinline__ float name(float x, float y) {{ return ff(x, y); }}
-SIXDOF_M2(m_max, fmax, fmaxf) SIXDOF_M2(m_min, fmin, fminf) SIXDOF_M2(m_atan2, atan2, atan2f) SIXDOF_M2(m_hypot, hypot, hypotf)
-
-struct PipeCustom {{
-    static constexpr int kOps = {len(tp.columns)};
+{_PRELUDE}
+struct PipeCustom : NoModel {{
+    static constexpr int kOps = {n_aux};
     static constexpr bool kStatic = true;
-    static constexpr bool kWorldTorque = {"true" if tp.world_torque else "false"};
+    static constexpr bool kWorldTorque = {"true" if pipe_tp.world_torque else "false"};
     static constexpr bool kBodyTorque = false;
     template <int K>
     static constexpr bool uses_aux() {{ return K < kOps; }}
-    __device__ static __forceinline__ bool vel_independent(const StepParams&) {{ return {"false" if tp.reads_velocity else "true"}; }}
-    template <class T>
-    __device__ static __forceinline__ void apply(const StepParams& P, const Vec3<T> (&aux)[kMaxOps], const Body<T>& b,
-                                                 Wrench<T>& F) {{
-        (void)P;
+    __device__ static __forceinline__ bool vel_independent(const StepParams&) {{ return {"false" if pipe_tp.reads_velocity else "true"}; }}
+{model}
+    template <class T, class R>
+    __device__ static __forceinline__ void apply(const StepParams& P, const Vec3<T> (&aux)[kMaxOps], const R& r,
+                                                 const Body<T>& b, Wrench<T>& F) {{
+        (void)P; (void)r; (void)aux;
 {body}
     }}
 }};
@@ -133,6 +221,7 @@ struct PipeCustom {{
 }}  // namespace sixdof
 
 extern "C" unsigned sixdof_custom_abi() {{ return static_cast<unsigned>(sizeof(sixdof::StepParams)); }}
+extern "C" unsigned sixdof_custom_layout() {{ return {n_aux}u | ({n_model}u << 8) | ({1 if (is_prog and tp.writes_inertia) else 0}u << 16); }}
 
 extern "C" int sixdof_custom_launch(const sixdof::StepParams* p, int integrator, int dtype, void* stream) {{
     using namespace sixdof;

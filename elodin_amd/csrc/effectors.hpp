@@ -65,6 +65,25 @@ __device__ __forceinline__ void apply_one(const DevOp& op, const Vec3<T>& aux, c
     }
 }
 
+// Hooks for user systems piped AROUND six_dof (pre | six_dof(effectors) | post) that a generated program fuses
+// into the same kernel.  Pipes without such systems inherit these no-ops.
+struct NoModel {
+    static constexpr bool kHasModel = false;
+    static constexpr bool kWritesInertia = false;
+    template <class T>
+    struct Regs {};
+    template <class T>
+    __device__ static __forceinline__ void load(const StepParams&, uint32_t, bool, Regs<T>&) {}
+    template <class T>
+    __device__ static __forceinline__ void store(const StepParams&, uint32_t, const Regs<T>&) {}
+    template <class T>
+    __device__ static __forceinline__ void pre(const StepParams&, uint64_t, Regs<T>&, Quat<T>&, Vec3<T>&, Spatial<T>&,
+                                               Vec3<T>&, T&) {}
+    template <class T>
+    __device__ static __forceinline__ void post(const StepParams&, uint64_t, Regs<T>&, Quat<T>&, Vec3<T>&, Spatial<T>&,
+                                                Vec3<T>&, T&) {}
+};
+
 template <int KIND>
 struct KindTraits {
     static constexpr bool reads_velocity = (KIND == SIXDOF_EFF_BALL_DRAG);
@@ -76,7 +95,7 @@ struct KindTraits {
 
 // Compile-time op list.  Op k takes its constants from P.ops[k] and its column value from aux[k].
 template <int... KINDS>
-struct PipeStatic {
+struct PipeStatic : NoModel {
     static constexpr int kOps = sizeof...(KINDS);
     static constexpr bool kStatic = true;
     static constexpr bool kWorldTorque = (false || ... || KindTraits<KINDS>::world_torque);
@@ -93,15 +112,15 @@ struct PipeStatic {
                                                       const Body<T>& b, Wrench<T>& F, std::index_sequence<I...>) {
         (apply_one<KINDS>(P.ops[I], aux[I], b, F), ...);
     }
-    template <class T>
-    __device__ static __forceinline__ void apply(const StepParams& P, const Vec3<T> (&aux)[kMaxOps], const Body<T>& b,
-                                                 Wrench<T>& F) {
+    template <class T, class R>
+    __device__ static __forceinline__ void apply(const StepParams& P, const Vec3<T> (&aux)[kMaxOps], const R&,
+                                                 const Body<T>& b, Wrench<T>& F) {
         apply_impl(P, aux, b, F, std::make_index_sequence<sizeof...(KINDS)>{});
     }
 };
 
 // Run-time interpreter: wave-uniform branches on kernel arguments.
-struct PipeGeneric {
+struct PipeGeneric : NoModel {
     static constexpr int kOps = kMaxOps;
     static constexpr bool kStatic = false;
     static constexpr bool kWorldTorque = true;
@@ -109,9 +128,9 @@ struct PipeGeneric {
     template <int K>
     static constexpr bool uses_aux() { return true; }
     __device__ static __forceinline__ bool vel_independent(const StepParams& P) { return P.vel_independent != 0; }
-    template <class T>
-    __device__ static __forceinline__ void apply(const StepParams& P, const Vec3<T> (&aux)[kMaxOps], const Body<T>& b,
-                                                 Wrench<T>& F) {
+    template <class T, class R>
+    __device__ static __forceinline__ void apply(const StepParams& P, const Vec3<T> (&aux)[kMaxOps], const R&,
+                                                 const Body<T>& b, Wrench<T>& F) {
 #pragma unroll
         for (int k = 0; k < kMaxOps; k++) {
             if (k >= (int)P.n_ops) break;

@@ -7,6 +7,7 @@
 namespace sixdof {
 
 constexpr int kMaxOps = 4;       // per-entity effector ops fused into the step kernel
+constexpr int kMaxModelCols = 12; // component columns a generated program keeps in registers
 constexpr int kBlock = 256;      // threads per workgroup = entities per workgroup (4 waves of 64)
 
 // One effector op as the kernel sees it (sixdof_effector_op with the aux column resolved).
@@ -38,6 +39,8 @@ struct StepParams {
     void* hist_vel;           // [ring][n,6]
     void* hist_accel;         // [ring][n,6]
     void* hist_force;         // [ring][n,6]
+    uint64_t tick0;           // tick count before this launch (generated systems may read the tick)
+    void* model_cols[kMaxModelCols];  // generated programs: device [n,w] component columns, read and written
     DevOp ops[kMaxOps];
 };
 
@@ -49,6 +52,7 @@ hipError_t launch_step(const StepParams& p, int integrator, int dtype, hipStream
 
 // Entry points of a run-time generated effector pipe (elodin_amd/codegen.py), resolved with dlsym.
 using CustomAbiFn = unsigned (*)();                                               // sizeof(StepParams) it was built with
+using CustomLayoutFn = unsigned (*)();                                            // n_aux | n_model_cols << 8 | writes_inertia << 16
 using CustomLaunchFn = int (*)(const StepParams*, int integrator, int dtype, void* stream);  // returns hipError_t
 
 // ---- pairwise (edge_fold) path -----------------------------------------------------------------------

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void pair_integrate_kernel(const PairParams P)
     Wrench<T> F;
     auto stage_force = [&](int st) {
         F = zero_wrench<T>();
-        if (P.n_ops) PIPE::apply(SP, aux, b, F);
+        if (P.n_ops) PIPE::apply(SP, aux, NoModel::Regs<T>{}, b, F);
         if (is_source) {  // edge_fold output replaces Force; el.Force(linear=...) carries zero torque
             F = zero_wrench<T>();
             F.f = Vec3<T>{pf[st][0], pf[st][1], pf[st][2]};

@@ -85,7 +85,8 @@ struct sixdof_handle {
     // run-time generated effector pipe
     void* custom_dl = nullptr;
     CustomLaunchFn custom_launch = nullptr;
-    std::vector<uint64_t> custom_aux;
+    std::vector<uint64_t> custom_aux;      // read-only [n,1..3] columns of a generated effector pipe
+    std::vector<uint64_t> custom_model;    // read/write [n,1..8] component columns of a generated program
     // telemetry ring
     uint32_t hist_ring = 0;
     uint64_t hist_first_tick = 0;   // first tick (1-based count) recorded since the ring was enabled
@@ -599,6 +600,23 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
         P->hist_accel = h->d_hist[2];
         P->hist_force = h->d_hist[3];
     }
+    for (size_t k = 0; k < h->custom_model.size(); k++) {
+        Column* c = h->col(h->custom_model[k]);
+        if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "step: component column of the generated program is not bound");
+        if (c->width < 1 || c->width > 8 || c->prim != h->state_prim())
+            return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, "step: program columns must be [n,1..8] of the state dtype");
+        if (!c->joined) {
+            int rc = resolve_join(h, c);
+            if (rc != SIXDOF_OK) return rc;
+            if (c->compact) {
+                hipError_t e = launch_gather_rows(c->compact, c->dev, c->d_rows, static_cast<uint32_t>(h->joined_ids.size()),
+                                                  static_cast<uint32_t>(c->width), c->elem, h->stream);
+                if (e != hipSuccess) return h->hip_fail(e, "gather_rows");
+            }
+        }
+        P->model_cols[k] = c->live;
+    }
+    P->tick0 = h->tick;
     return build_dev_ops(h, P->ops, &P->n_ops, &P->vel_independent);
 }
 
@@ -763,19 +781,26 @@ int sixdof_set_model_apollo(sixdof_handle* h, const sixdof_apollo_tables* t) {
 
 int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t* aux_ids, size_t n_aux) {
     if (!h || !so_path || (!aux_ids && n_aux)) return SIXDOF_ERR_INVALID_ARGUMENT;
-    if (n_aux > static_cast<size_t>(kMaxOps)) return h->fail(SIXDOF_ERR_UNSUPPORTED, "set_custom_pipe: at most 4 columns");
     void* dl = dlopen(so_path, RTLD_NOW | RTLD_LOCAL);
     if (!dl) return h->fail(SIXDOF_ERR_BACKEND, std::string("set_custom_pipe: dlopen failed: ") + dlerror());
     auto abi = reinterpret_cast<CustomAbiFn>(dlsym(dl, "sixdof_custom_abi"));
+    auto layout = reinterpret_cast<CustomLayoutFn>(dlsym(dl, "sixdof_custom_layout"));
     auto launch = reinterpret_cast<CustomLaunchFn>(dlsym(dl, "sixdof_custom_launch"));
-    if (!abi || !launch || abi() != sizeof(StepParams)) {
+    if (!abi || !layout || !launch || abi() != sizeof(StepParams)) {
         dlclose(dl);
         return h->fail(SIXDOF_ERR_BACKEND, "set_custom_pipe: not a generated pipe for this library build (StepParams layout differs)");
+    }
+    const unsigned lay = layout();
+    const size_t k_aux = lay & 0xff, k_model = (lay >> 8) & 0xff;
+    if (k_aux > static_cast<size_t>(kMaxOps) || k_model > static_cast<size_t>(kMaxModelCols) || k_aux + k_model != n_aux) {
+        dlclose(dl);
+        return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, "set_custom_pipe: column list does not match the generated code's layout");
     }
     if (h->custom_dl) dlclose(h->custom_dl);
     h->custom_dl = dl;
     h->custom_launch = launch;
-    h->custom_aux.assign(aux_ids, aux_ids + n_aux);
+    h->custom_aux.assign(aux_ids, aux_ids + k_aux);
+    h->custom_model.assign(aux_ids + k_aux, aux_ids + k_aux + k_model);
     h->ops.clear();
     h->drop_graph();
     return SIXDOF_OK;
@@ -884,7 +909,7 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
             }
         }
         uint64_t ticks_issued = 0;   // history slot of a launch's first tick = ticks done before it
-        if (!time_each && !h->hist_ring && (h->desc.flags & SIXDOF_FLAG_USE_GRAPH) && full >= kGraphLen) {
+        if (!time_each && !h->hist_ring && h->custom_model.empty() && (h->desc.flags & SIXDOF_FLAG_USE_GRAPH) && full >= kGraphLen) {
             const uint64_t sig = (static_cast<uint64_t>(K) << 32) ^ h->ops.size() ^ (h->desc.n_entities << 8);
             if (!h->graph_exec || h->graph_k != K || h->graph_sig != sig) {
                 h->drop_graph();
@@ -915,6 +940,7 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
         for (uint64_t i = 0; i < full; i++) {
             if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches], h->stream));
             P.hist_slot0 = h->tick + ticks_issued;
+            P.tick0 = h->tick + ticks_issued;
             ticks_issued += K;
             hipError_t e = launch_any(h, P);
             if (e != hipSuccess) return h->hip_fail(e, "launch_step");
@@ -924,6 +950,7 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
         if (rem) {
             P.n_ticks = rem;
             P.hist_slot0 = h->tick + ticks_issued;
+            P.tick0 = h->tick + ticks_issued;
             if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches], h->stream));
             hipError_t e = launch_any(h, P);
             if (e != hipSuccess) return h->hip_fail(e, "launch_step");

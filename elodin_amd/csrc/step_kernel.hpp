@@ -143,6 +143,9 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     load_aux(std::integral_constant<int, 2>{});
     load_aux(std::integral_constant<int, 3>{});
 
+    typename PIPE::template Regs<T> regs;   // component columns of a generated program, one row per lane
+    if constexpr (PIPE::kHasModel) PIPE::load(P, row0 + t, active, regs);
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA data has landed
     __syncthreads();
 
@@ -206,6 +209,15 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     b.I = I_diag;
     Wrench<T> F = zero_wrench<T>();
     for (uint32_t tick = 0; tick < P.n_ticks; tick++) {
+        if constexpr (PIPE::kHasModel) {   // user systems piped in front of six_dof (may rewrite inertia, pose, velocity)
+            PIPE::pre(P, P.tick0 + tick + 1, regs, q0, p0, v0, I_diag, mass);
+            if constexpr (PIPE::kWritesInertia) {
+                inv_I = Vec3<T>{T(1) / I_diag.x, T(1) / I_diag.y, T(1) / I_diag.z};
+                inv_m = T(1) / mass;
+                b.mass = mass;
+                b.I = I_diag;
+            }
+        }
         if constexpr (INTEGRATOR == kRk4) {
             const T h1 = dt_g * T(0.5), h3 = dt_g;
             Spatial<T> A, sv, sa;
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             b.p = p0;
             b.v = v0;
             F = zero_wrench<T>();
-            PIPE::apply(P, aux, b, F);
+            PIPE::apply(P, aux, regs, b, F);
             A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
             sv = v0;
             sa = A;
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             b.v = axpy(h1, A, v0);
             sv = axpy(T(2), b.v, sv);
             F = zero_wrench<T>();
-            PIPE::apply(P, aux, b, F);
+            PIPE::apply(P, aux, regs, b, F);
             A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
             sa = axpy(T(2), A, sa);
             // stage 2 (c = 1/2): same transform as stage 1
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             sv = axpy(T(2), b.v, sv);
             if (!PIPE::vel_independent(P)) {
                 F = zero_wrench<T>();
-                PIPE::apply(P, aux, b, F);
+                PIPE::apply(P, aux, regs, b, F);
                 A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
             }
             sa = axpy(T(2), A, sa);
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             b.v = axpy(h3, A, v0);
             sv = sv + b.v;
             F = zero_wrench<T>();
-            PIPE::apply(P, aux, b, F);
+            PIPE::apply(P, aux, regs, b, F);
             A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
             sa = sa + A;
             // u' = u + (dt/6)(k1 + 2k2 + 2k3 + k4)
@@ -257,13 +269,14 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             b.p = p0;
             b.v = v0;
             F = zero_wrench<T>();
-            PIPE::apply(P, aux, b, F);
+            PIPE::apply(P, aux, regs, b, F);
             const Spatial<T> A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
             v0 = axpy(dt, A, v0);
             q0 = integrate_world(q0, dt * v0.ang);
             p0 = axpy(dt, v0.lin, p0);
             A_out = A;
         }
+        if constexpr (PIPE::kHasModel) PIPE::post(P, P.tick0 + tick + 1, regs, q0, p0, v0, I_diag, mass);
         if (record) {
             // telemetry: this tick's world_pos / world_vel / world_accel / force rows -> ring slot, in the
             // reference's row layout, write-once (non-temporal); the stores drain under the next tick's math
@@ -275,6 +288,15 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             flush_rows(static_cast<T*>(P.hist_pos) + r7, static_cast<T*>(P.hist_vel) + r6,
                        static_cast<T*>(P.hist_accel) + r6, static_cast<T*>(P.hist_force) + r6, std::true_type{});
             __syncthreads();
+        }
+    }
+    if constexpr (PIPE::kHasModel) {
+        if (active) {
+            PIPE::store(P, row0 + t, regs);
+            if constexpr (PIPE::kWritesInertia) {   // a system returned el.Inertia: the column is an output
+                T* gi = static_cast<T*>(const_cast<void*>(P.inertia)) + (size_t)(row0 + t) * 7;
+                gi[0] = I_diag.x; gi[1] = I_diag.y; gi[2] = I_diag.z; gi[6] = mass;
+            }
         }
     }
     F_out = world_wrench<PIPE>(b.q, F);  // wrench of the last stage evaluated, world frame

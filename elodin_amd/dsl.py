@@ -262,7 +262,7 @@ class SpatialForce:
 
 # ---- tracing -----------------------------------------------------------------------------------------------------
 
-_FIXED = {"force", "pos", "world_pos", "vel", "world_vel", "inertia"}
+_BODY_NAMES = {"force", "pos", "world_pos", "vel", "world_vel", "inertia", "tick"}
 
 
 class Effector:
@@ -277,7 +277,8 @@ class Effector:
 
 def effector(fn=None, **widths):
     """Decorator. Keyword arguments give the row width of component columns the function reads
-    (`@dsl.effector(thrust=1, rcs_torque=3)`); width defaults to 3."""
+    (`@dsl.effector(thrust=1, rcs_torque=3)`); otherwise the width comes from the bound column (World.build)
+    or defaults to 3."""
     if fn is None:
         return lambda f: Effector(f, widths)
     return Effector(fn, widths)
@@ -287,16 +288,61 @@ def leaf(name: str) -> Expr:
     return Expr("leaf", (), None, name)
 
 
-class TracedPipe:
-    """Result of tracing: output wrench nodes, the component columns read, and dependency flags."""
+def _body_symbols():
+    q = Quaternion(Vec([leaf(f"q{c}") for c in "ijkw"]))
+    pos = SpatialTransform(q, Vec([leaf(f"p{c}") for c in "xyz"]))
+    vel = SpatialMotion(Vec([leaf(f"w{c}") for c in "xyz"]), Vec([leaf(f"v{c}") for c in "xyz"]))
+    inertia = SpatialInertia(Vec([leaf(f"I{c}") for c in "xyz"]), leaf("mass"))
+    return pos, vel, inertia
 
-    def __init__(self, effectors: Sequence[Effector]):
+
+def _leaves_of(outputs: Sequence[Expr]) -> set:
+    deps, seen = set(), set()
+
+    def walk(e: Expr):
+        if id(e) in seen:
+            return
+        seen.add(id(e))
+        if e.op == "leaf":
+            deps.add(e.name)
+        for a in e.args:
+            walk(a)
+    for o in outputs:
+        walk(o)
+    return deps
+
+
+class ColumnTable:
+    """Component columns used by generated code, in first-use order: name -> (slot, width)."""
+
+    def __init__(self, prefix: str, limit: int, max_width: int, known: Optional[Dict[str, int]] = None):
+        self.prefix, self.limit, self.max_width = prefix, limit, max_width
+        self.known = dict(known or {})
+        self.cols: List[Tuple[str, int]] = []
+
+    def symbols(self, name: str, declared: Optional[int], default: int) -> Vec:
+        w = int(declared if declared is not None else self.known.get(name, default))
+        if not 1 <= w <= self.max_width:
+            raise ValueError(f"component {name}: width must be 1..{self.max_width}")
+        have = dict(self.cols)
+        if name in have and have[name] != w:
+            raise ValueError(f"component {name}: conflicting widths {have[name]} / {w}")
+        if name not in have:
+            if len(self.cols) >= self.limit:
+                raise ValueError(f"generated code can use at most {self.limit} component columns")
+            self.cols.append((name, w))
+        slot = [c for c, _ in self.cols].index(name)
+        return Vec([leaf(f"{self.prefix}{slot}_{k}") for k in range(w)])
+
+
+class TracedPipe:
+    """Result of tracing an effector pipe: output wrench nodes, the component columns read, dependency flags."""
+
+    def __init__(self, effectors: Sequence[Effector], table: Optional[ColumnTable] = None,
+                 widths: Optional[Dict[str, int]] = None):
         self.effectors = list(effectors)
-        self.columns: List[Tuple[str, int]] = []      # (component name, width) in first-use order
-        q = Quaternion(Vec([leaf(f"q{c}") for c in "ijkw"]))
-        pos = SpatialTransform(q, Vec([leaf(f"p{c}") for c in "xyz"]))
-        vel = SpatialMotion(Vec([leaf(f"w{c}") for c in "xyz"]), Vec([leaf(f"v{c}") for c in "xyz"]))
-        inertia = SpatialInertia(Vec([leaf(f"I{c}") for c in "xyz"]), leaf("mass"))
+        self.table = table or ColumnTable("aux", 4, 3, widths)
+        pos, vel, inertia = _body_symbols()
         force = SpatialForce()                          # clear_forces: the pipe starts from zero (six_dof.rs:148-150)
         for eff in self.effectors:
             kwargs = {}
@@ -310,40 +356,20 @@ class TracedPipe:
                 elif name == "inertia":
                     kwargs[name] = inertia
                 else:
-                    w = int(eff.widths.get(name, 3))
-                    if not 1 <= w <= 3:
-                        raise ValueError(f"component {name}: width must be 1..3")
-                    known = dict(self.columns)
-                    if name in known and known[name] != w:
-                        raise ValueError(f"component {name}: conflicting widths")
-                    if name not in known:
-                        self.columns.append((name, w))
-                    slot = [c for c, _ in self.columns].index(name)
-                    kwargs[name] = Vec([leaf(f"aux{slot}_{k}") for k in range(w)])
+                    kwargs[name] = self.table.symbols(name, eff.widths.get(name), 3)
             out = eff.fn(**kwargs)
             if not isinstance(out, SpatialForce):
                 raise TypeError(f"effector {eff.__name__} must return a dsl.SpatialForce")
             force = out
-        if len(self.columns) > 4:
-            raise ValueError("a generated pipe can read at most 4 component columns")
         self.torque, self.linear = force.torque(), force.force()
         self.outputs: List[Expr] = list(self.torque.e) + list(self.linear.e)
-        deps = set()
-        seen = set()
-
-        def walk(e: Expr):
-            if id(e) in seen:
-                return
-            seen.add(id(e))
-            if e.op == "leaf":
-                deps.add(e.name)
-            for a in e.args:
-                walk(a)
-        for o in self.outputs:
-            walk(o)
-        self.leaves = deps
-        self.reads_velocity = any(n[0] in "wv" and len(n) == 2 for n in deps)
+        self.leaves = _leaves_of(self.outputs)
+        self.reads_velocity = any(n[0] in "wv" and len(n) == 2 for n in self.leaves)
         self.world_torque = not all(t.is_const(0.0) for t in self.torque.e)
+
+    @property
+    def columns(self) -> List[Tuple[str, int]]:
+        return self.table.cols
 
 
 def pipe(*effectors: Effector) -> "Pipe":
@@ -362,7 +388,128 @@ class Pipe:
 
     def __or__(self, other): return pipe(self, other)
 
-    def trace(self) -> TracedPipe:
+    def trace(self, widths: Optional[Dict[str, int]] = None) -> TracedPipe:
         if self._traced is None:
-            self._traced = TracedPipe(self.effectors)
+            self._traced = TracedPipe(self.effectors, widths=widths)
         return self._traced
+
+
+# ---- systems piped around six_dof ----------------------------------------------------------------------------------
+
+class System:
+    """A per-entity system outside six_dof (`@el.map` in the reference, e.g. apollo-lander/sim.py:334-378,400-431):
+    reads components by parameter name (plus `pos`, `vel`, `inertia`, `tick`), returns {component: new value}.
+    `every=n` runs it only on ticks divisible by n (wave-uniform branch), e.g. a 24 Hz guidance law in a 120 Hz sim."""
+
+    def __init__(self, fn: Callable, widths: Optional[Dict[str, int]] = None, every: int = 1):
+        self.fn = fn
+        self.params = list(inspect.signature(fn).parameters)
+        self.widths = dict(widths or {})
+        self.every = int(every)
+        self.__name__ = getattr(fn, "__name__", "system")
+
+
+    def __or__(self, other): return Stages([self]) | other
+    def __ror__(self, other): return Stages([other]) | self
+
+
+class Stages:
+    """`a | b | six_dof(...) | c`: the reference's system pipe (system.rs:1001-1011), kept as a flat list."""
+
+    def __init__(self, items): self.items = list(items)
+    def __or__(self, other):
+        return Stages(self.items + (other.items if isinstance(other, Stages) else [other]))
+    def __ror__(self, other):
+        return Stages((other.items if isinstance(other, Stages) else [other]) + self.items)
+
+
+def system(fn=None, every: int = 1, **widths):
+    if fn is None:
+        return lambda f: System(f, widths, every)
+    return System(fn, widths, every)
+
+
+class TracedSystem:
+    """One system as (target, expression) assignments over the register file / body state."""
+
+    def __init__(self, sys_: System, table: ColumnTable):
+        self.name, self.every = sys_.__name__, sys_.every
+        pos, vel, inertia = _body_symbols()
+        kwargs = {}
+        for name in sys_.params:
+            if name in ("pos", "world_pos"):
+                kwargs[name] = pos
+            elif name in ("vel", "world_vel"):
+                kwargs[name] = vel
+            elif name == "inertia":
+                kwargs[name] = inertia
+            elif name == "tick":
+                kwargs[name] = leaf("tick")
+            elif name == "force":
+                raise TypeError("systems outside six_dof cannot read `force`")
+            else:
+                v = table.symbols(name, sys_.widths.get(name), 1)
+                kwargs[name] = v if len(v) > 1 else v[0]
+        out = sys_.fn(**kwargs)
+        if not isinstance(out, dict):
+            raise TypeError(f"system {self.name} must return a dict {{component: value}}")
+        self.assign: List[Tuple[str, Expr]] = []      # (leaf name written, value)
+        self.writes_inertia = False
+        for cname, val in out.items():
+            if cname in ("pos", "world_pos"):
+                if not isinstance(val, SpatialTransform):
+                    raise TypeError("world_pos must be a dsl.SpatialTransform")
+                for c, e in zip("ijkw", val.angular().vector().e):
+                    self.assign.append((f"q{c}", e))
+                for c, e in zip("xyz", val.linear().e):
+                    self.assign.append((f"p{c}", e))
+            elif cname in ("vel", "world_vel"):
+                for c, e in zip("xyz", val.angular().e):
+                    self.assign.append((f"w{c}", e))
+                for c, e in zip("xyz", val.linear().e):
+                    self.assign.append((f"v{c}", e))
+            elif cname == "inertia":
+                self.writes_inertia = True
+                for c, e in zip("xyz", val.inertia_diag().e):
+                    self.assign.append((f"I{c}", e))
+                self.assign.append(("mass", _lift(val.mass())))
+            else:
+                v = val if isinstance(val, Vec) else Vec([val])
+                cur = table.symbols(cname, sys_.widths.get(cname, len(v)), len(v))
+                if len(cur) != len(v):
+                    raise ValueError(f"system {self.name}: component {cname} has width {len(cur)}, got {len(v)} values")
+                for k, e in enumerate(v.e):
+                    self.assign.append((cur[k].name, e))
+        self.written = [t for t, _ in self.assign]
+
+
+class Program:
+    """`pre systems | six_dof(effectors) | post systems` — one whole tick, like the reference's compiled pipe."""
+
+    def __init__(self, pre: Sequence[System], effectors: Pipe, post: Sequence[System]):
+        self.pre, self.effectors, self.post = list(pre), effectors, list(post)
+        self._traced = None
+
+    def trace(self, widths: Optional[Dict[str, int]] = None) -> "TracedProgram":
+        if self._traced is None:
+            self._traced = TracedProgram(self, widths)
+        return self._traced
+
+
+class TracedProgram:
+    def __init__(self, prog: Program, widths: Optional[Dict[str, int]] = None):
+        self.table = ColumnTable("c", 12, 8, widths)
+        self.pre = [TracedSystem(s, self.table) for s in prog.pre]
+        self.pipe = TracedPipe(prog.effectors.effectors, table=self.table)
+        self.post = [TracedSystem(s, self.table) for s in prog.post]
+        self.writes_inertia = any(s.writes_inertia for s in self.pre + self.post)
+        written = set()
+        for s in self.pre + self.post:
+            written.update(t for t in s.written if t[0] == "c")
+        self.written_slots = sorted({int(t[1:].split("_")[0]) for t in written})
+        self.reads_velocity = self.pipe.reads_velocity
+        self.world_torque = self.pipe.world_torque
+
+    @property
+    def columns(self) -> List[Tuple[str, int]]:
+        return self.table.cols

@@ -93,10 +93,14 @@ class HipExec:
             from . import dsl as _dsl
             if isinstance(effectors, _dsl.Effector):
                 effectors = _dsl.pipe(effectors)
-            if isinstance(effectors, _dsl.Pipe):
-                # user-written effectors: trace -> generate HIP -> hipcc -> sixdof_set_custom_pipe
+            self._program_columns = []
+            if isinstance(effectors, (_dsl.Pipe, _dsl.Program)):
+                # user-written effectors / systems: trace -> generate HIP -> hipcc -> sixdof_set_custom_pipe
                 from . import codegen
-                custom = effectors.trace()
+                widths = {k: int(np.atleast_2d(np.asarray(v)).shape[-1]) for k, v in (columns or {}).items()}
+                custom = effectors.trace(widths)
+                if isinstance(effectors, _dsl.Program):
+                    self._program_columns = [n for n, _ in custom.columns]
                 so = codegen.build(custom, self.dtype.name, integrator)
                 for name, width in custom.columns:
                     if columns is None or name not in columns:
@@ -178,6 +182,10 @@ class HipExec:
         rc = self._lib.sixdof_download(self._h, mask)
         if rc != L.OK:
             _raise(self._h, rc, "sixdof_download")
+        for name in getattr(self, "_program_columns", ()):   # components a generated program writes
+            rc = self._lib.sixdof_download_column(self._h, L.component_id(name))
+            if rc != L.OK:
+                _raise(self._h, rc, "sixdof_download_column")
         return self
 
     def run(self, ticks: int = 1) -> TickTimings:

@@ -40,3 +40,76 @@ def evaluate(tp, xs, vs, inertia, columns):
 
     with np.errstate(all="ignore"):
         return np.stack([ev(o) for o in tp.outputs], axis=1)
+
+
+# ---- whole programs (pre systems | six_dof(effectors) | post systems) ------------------------------------------------
+
+def _leaf_arrays(pos, vel, inertia, comps, table, tick):
+    n = pos.shape[0]
+    lv = {"qi": pos[:, 0], "qj": pos[:, 1], "qk": pos[:, 2], "qw": pos[:, 3], "px": pos[:, 4], "py": pos[:, 5],
+          "pz": pos[:, 6], "wx": vel[:, 0], "wy": vel[:, 1], "wz": vel[:, 2], "vx": vel[:, 3], "vy": vel[:, 4],
+          "vz": vel[:, 5], "Ix": inertia[:, 0], "Iy": inertia[:, 1], "Iz": inertia[:, 2], "mass": inertia[:, 6],
+          "tick": np.full(n, float(tick))}
+    for slot, (name, w) in enumerate(table.cols):
+        for k in range(w):
+            lv[f"{table.prefix}{slot}_{k}"] = comps[name][:, k]
+    return lv
+
+
+def _eval(exprs, leaves, n):
+    memo = {}
+
+    def ev(e):
+        if id(e) in memo:
+            return memo[id(e)]
+        if e.op == "const":
+            r = np.full(n, e.value)
+        elif e.op == "leaf":
+            r = leaves[e.name]
+        elif e.op in _F1:
+            r = _F1[e.op](ev(e.args[0]))
+        elif e.op in _F2:
+            r = _F2[e.op](ev(e.args[0]), ev(e.args[1]))
+        elif e.op == "select":
+            r = np.where(ev(e.args[0]), ev(e.args[1]), ev(e.args[2]))
+        else:
+            raise ValueError(e.op)
+        memo[id(e)] = r
+        return r
+    with np.errstate(all="ignore"):
+        return [np.asarray(ev(e), dtype=np.float64) for e in exprs]
+
+
+def _run_systems(systems, pos, vel, inertia, comps, table, tick):
+    body = {"q": ("pos", {"i": 0, "j": 1, "k": 2, "w": 3}), "p": ("pos", {"x": 4, "y": 5, "z": 6}),
+            "w": ("vel", {"x": 0, "y": 1, "z": 2}), "v": ("vel", {"x": 3, "y": 4, "z": 5}),
+            "I": ("inertia", {"x": 0, "y": 1, "z": 2})}
+    arrays = {"pos": pos, "vel": vel, "inertia": inertia}
+    for s in systems:
+        if s.every > 1 and tick % s.every != 0:
+            continue
+        lv = _leaf_arrays(pos, vel, inertia, comps, table, tick)
+        vals = _eval([e for _, e in s.assign], lv, pos.shape[0])
+        for (target, _), val in zip(s.assign, vals):     # all outputs computed before any is written
+            if target == "mass":
+                inertia[:, 6] = val
+            elif target[0] == "c" and "_" in target:
+                slot, k = target[1:].split("_")
+                comps[table.cols[int(slot)][0]][:, int(k)] = val
+            else:
+                arr, idx = body[target[0]]
+                arrays[arr][:, idx[target[1]]] = val
+
+
+def program_tick(tp, pos, vel, accel, inertia, comps, tick, dt_g, integrator):
+    """One tick of a dsl.TracedProgram with numpy (in place on copies); `tick` = count after this tick."""
+    from tests import np_sixdof
+    _run_systems(tp.pre, pos, vel, inertia, comps, tp.table, tick)
+
+    def eff(xs, vs):
+        lv = _leaf_arrays(xs, vs, inertia, comps, tp.table, tick)
+        return np.stack(_eval(tp.pipe.outputs, lv, xs.shape[0]), axis=1)
+    pos2, vel2, acc2, F = np_sixdof.tick(pos, vel, accel, inertia, eff, dt_g, integrator=integrator)
+    pos[:], vel[:], accel[:] = pos2, vel2, acc2
+    _run_systems(tp.post, pos, vel, inertia, comps, tp.table, tick)
+    return F

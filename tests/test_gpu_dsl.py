@@ -130,3 +130,83 @@ def test_missing_component_column_is_reported():
     w = workloads.independent_bodies(8)
     with pytest.raises(KeyError, match="body_torque"):
         el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], effectors=gravity | rcs)
+
+
+# ---- whole programs: systems piped around six_dof, generated -----------------------------------------------------------
+
+def test_apollo_sim_written_as_user_code_matches_the_handwritten_model_and_numpy():
+    """examples/apollo-lander's pipe (sim.py:517-526) written against the dsl, compiled into the fused kernel, vs
+    (a) the numpy stepper evaluating the same program and (b) the hand-written apollo_rollout_kernel with guidance
+    switched off (commands constant) — two independent implementations of the same systems."""
+    from pathlib import Path
+    from elodin_amd import monte_carlo as mc
+    from elodin_amd.models import apollo
+    from tests import apollo_dsl as A
+    ref = apollo.load_reference()
+    P = mc.materialize(mc.load_spec(Path(__file__).parent / "golden" / "plans" / "apollo_512.toml")).table()
+    cols = apollo.initial_columns(P, ref)
+    comps = A.components_from(cols)
+    n, ticks = P.shape[0], 600
+    w = el.World()
+    # build through the C ABI directly: bodies + reference-named component columns
+    prog = dsl.Program(A.NON_EFFECTORS, A.EFFECTORS, A.POST)
+    hip = el.HipExec(cols["world_pos"], cols["world_vel"], cols["inertia"], simulation_time_step=0.008333333,
+                     integrator=L.SEMI_IMPLICIT, effectors=prog, columns=comps, ticks_per_launch=50)
+    tp = prog.trace()
+    assert tp.writes_inertia and len(tp.columns) == 11
+    hip.run(ticks)
+    # (a) numpy evaluation of the same program
+    pos, vel, acc, inertia = cols["world_pos"].copy(), cols["world_vel"].copy(), np.zeros((n, 6)), cols["inertia"].copy()
+    cn = {k: v.copy() for k, v in comps.items()}
+    for t in range(1, ticks + 1):
+        dsl_numpy.program_tick(tp, pos, vel, acc, inertia, cn, t, 0.008333333, 1)
+    assert parity.pos_rel_err(hip.world_pos, pos) < parity.F64_RTOL
+    # the setpoint equals the initial attitude, so body rates stay at rounding-noise level (exactly 0 in numpy,
+    # ~1e-18 with FMA contraction): absolute floor on the angular half
+    assert np.allclose(hip.world_vel[:, :3], vel[:, :3], rtol=1e-9, atol=1e-12)
+    assert parity.field_rel_err(hip.world_vel[:, 3:], vel[:, 3:]) < parity.F64_RTOL
+    assert parity.field_rel_err(hip.inertia, inertia) < parity.F64_RTOL
+    for name in ("throttle", "thrust", "propellant", "rcs_propellant", "rcs_torque", "pitch", "landed"):
+        got, want = hip._aux[name], cn[name]
+        assert np.allclose(got, want, rtol=1e-8, atol=1e-9), name
+    # (b) the hand-written model kernel, guidance never firing
+    hw = apollo.ApolloExec(P, ref=ref, ticks_per_launch=50)
+    t = apollo.Tables()
+    tabs = [np.ascontiguousarray(ref[k]) for k in ("time_s", "altitude_m", "descent_rate_mps", "pitch_deg", "horizontal_speed_mps", "downrange_m")]
+    t.time_s, t.altitude_m, t.descent_rate_mps, t.pitch_deg, t.horizontal_speed_mps, t.downrange_m = [a.ctypes.data for a in tabs]
+    t.n, t.guidance_period_ticks, t.max_ticks = len(tabs[0]), 10 ** 9, 10 ** 9
+    import ctypes as C
+    fn = hw._lib.sixdof_set_model_apollo
+    fn.argtypes, fn.restype = [C.c_void_p, C.POINTER(apollo.Tables)], C.c_int
+    assert fn(hw._h, C.byref(t)) == L.OK
+    hw.run(ticks)
+    assert parity.pos_rel_err(hip.world_pos, hw.world_pos) < parity.F64_RTOL
+    st = hw.model["apollo_state"]
+    assert np.max(np.abs(hip._aux["propellant"][:, 0] - st[:, 6]) / st[:, 6]) < 1e-9
+    assert np.max(np.abs(hip._aux["pitch"][:, 0] - st[:, 15]) / np.maximum(st[:, 15], 1e-3)) < 1e-8
+
+
+def test_system_pipe_through_the_world_api_with_cadenced_system():
+    """`pre | six_dof(effectors) | post` through World.build, with a system that only runs every 5th tick."""
+    @dsl.system(every=5)
+    def bump(counter, tick):
+        return {"counter": counter + 1.0, "last": tick}
+
+    @dsl.system
+    def drain(fuel):
+        return {"fuel": np_.maximum(fuel - 0.5, 0.0)}
+
+    @dsl.effector
+    def push(force, fuel, inertia):
+        return force + dsl.SpatialForce(linear=np_.array([1.0, 0.0, 0.0]) * np_.where(fuel[0] > 0.0, 2.0, 0.0) * inertia.mass())
+
+    w = el.World()
+    for k in range(3):
+        w.spawn([el.Body(inertia=el.SpatialInertia(1.0 + k)), el.C("fuel", [2.0 + k]), el.C("counter", [0.0]), el.C("last", [0.0])])
+    exec = w.build(bump | drain | el.six_dof(1.0, push, el.Integrator.SemiImplicit), simulation_rate=1.0)
+    exec.run(12)
+    assert exec.component("counter")[:, 0].tolist() == [2.0, 2.0, 2.0]          # ticks 5 and 10
+    assert exec.component("last")[:, 0].tolist() == [10.0, 10.0, 10.0]
+    assert exec.component("fuel")[:, 0].tolist() == [0.0, 0.0, 0.0]
+    # fuel lasts 4 / 6 / 8 half-unit drains -> thrust on for 3 / 5 / 7 ticks (drain runs before six_dof)
+    assert exec.column_array("world_vel")[:, 3].tolist() == [6.0, 10.0, 14.0]
