@@ -80,6 +80,36 @@ def kernel_roofline(ex, n, steps, warmup):
                          "HIP events around the batch on the launch stream / launches")
 
 
+def generated_leg(device, n):
+    """The same workload with its effectors written as user code (elodin_amd.dsl) and compiled into the step kernel
+    at build time — the effector front-end must not cost throughput against the hand-written pipe."""
+    import elodin_amd as ea
+    from elodin_amd import dsl, workloads
+    np_ = dsl.np
+
+    @dsl.effector
+    def gravity(force, inertia):
+        return force + dsl.SpatialForce(linear=np_.array([0.0, 0.0, -9.81]) * inertia.mass())
+
+    @dsl.effector(body_torque=3)
+    def rcs(force, pos, body_torque):
+        return force + dsl.SpatialForce(torque=pos.angular() @ body_torque)
+
+    w = workloads.independent_bodies(n)
+    t0 = time.perf_counter()
+    ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ,
+                    effectors=gravity | rcs, columns={"body_torque": w["body_torque"]}, device=device, use_graph=True)
+    build_s = time.perf_counter() - t0
+    out = {"build_seconds_incl_hipcc_or_cache": round(build_s, 3)}
+    for K in (1, 64):
+        ex.set_ticks_per_launch(K)
+        ex.invoke_batch(256)
+        t = ex.invoke_batch(2048)
+        out[f"entity_steps_per_s_k{K}"] = round(n * 2048 / (t.kernel_device_ms * 1e-3), 1)
+    ex.close()
+    return out
+
+
 def nbody_leg(device):
     """BASELINE configs[2]: all-pairs softened gravity, 16,384 bodies, RK4 f64 (parity case; timing for reference)."""
     import elodin_amd as ea
@@ -248,6 +278,7 @@ def main():
         bex.close()
         out["roofline_hbm"] = r
     if rank == 0 and not args.no_extras:
+        out["generated_pipe"] = generated_leg(local_rank, n)
         out["nbody"] = nbody_leg(local_rank)
         out["apollo_mc"] = apollo_leg(local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

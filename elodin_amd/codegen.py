@@ -60,6 +60,9 @@ def _leaf_ref(name: str, table: Dict[str, str]) -> str:
     raise KeyError(name)
 
 
+_TABLES: Dict[tuple, str] = {}    # (xp, fp) -> C++ symbol stem, filled while emitting one translation unit
+
+
 def emit_block(assign, leaves: Dict[str, str], indent: str = "        ") -> List[str]:
     """Straight-line C++ for a list of (lvalue, Expr): every output is computed into a temporary first (a system may
     read a component it also writes), common sub-expressions are emitted once, in dependency order."""
@@ -84,6 +87,9 @@ def emit_block(assign, leaves: Dict[str, str], indent: str = "        ") -> List
             rhs = f"{_FN2[e.op]}({a[0]}, {a[1]})"
         elif e.op == "select":
             rhs = f"{a[0]} ? {a[1]} : {a[2]}"
+        elif e.op == "interp":
+            stem = _TABLES.setdefault(e.value, f"tab{len(_TABLES)}")
+            rhs = f"m_interp<T, {len(e.value[0])}>({a[0]}, {stem}_x, {stem}_f)"
         elif e.op == "lt":
             rhs = f"{a[0]} < {a[1]}"
         elif e.op == "le":
@@ -112,10 +118,8 @@ def emit_block(assign, leaves: Dict[str, str], indent: str = "        ") -> List
 
 
 def emit_apply(tp: dsl.TracedPipe) -> List[str]:
-    names = ["F.tau_w.x", "F.tau_w.y", "F.tau_w.z", "F.f.x", "F.f.y", "F.f.z"]
-    lines = emit_block(list(zip(names, tp.outputs)), _APPLY_LEAVES)
-    lines.append("        F.tau_b = Vec3<T>{T(0), T(0), T(0)};")
-    return lines
+    names = ["F.tau_w.x", "F.tau_w.y", "F.tau_w.z", "F.f.x", "F.f.y", "F.f.z", "F.tau_b.x", "F.tau_b.y", "F.tau_b.z"]
+    return emit_block(list(zip(names, tp.outputs)), _APPLY_LEAVES)
 
 
 def _emit_systems(systems) -> str:
@@ -140,11 +144,34 @@ SIXDOF_M1(m_log, log, logf) SIXDOF_M1(m_acos, acos, acosf) SIXDOF_M1(m_asin, asi
     __device__ __forceinline__ double name(double x, double y) { return fd(x, y); } \\
     __device__ __forceinline__ float name(float x, float y) { return ff(x, y); }
 SIXDOF_M2(m_max, fmax, fmaxf) SIXDOF_M2(m_min, fmin, fminf) SIXDOF_M2(m_atan2, atan2, atan2f) SIXDOF_M2(m_hypot, hypot, hypotf)
+// jnp.interp over a constant table: i = clip(searchsorted(xp, x, 'right'), 1, N-1); fp[i-1] + (x-xp[i-1])/dx * df,
+// clamped to the end values outside the table.
+template <class T, int N>
+__device__ __forceinline__ T m_interp(T x, const double (&xp)[N], const double (&fp)[N]) {
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) c += (T(xp[k]) <= x) ? 1 : 0;
+    const int i = c < 1 ? 1 : (c > N - 1 ? N - 1 : c);
+    const T x0 = T(xp[i - 1]), f0 = T(fp[i - 1]);
+    const T dx = T(xp[i]) - x0, df = T(fp[i]) - f0;
+    T f = dx == T(0) ? f0 : f0 + ((x - x0) / dx) * df;
+    f = x < T(xp[0]) ? T(fp[0]) : f;
+    return x > T(xp[N - 1]) ? T(fp[N - 1]) : f;
+}
 '''
+
+
+def _emit_tables() -> str:
+    out = []
+    for (xs, fs), stem in _TABLES.items():
+        out.append(f"__device__ const double {stem}_x[{len(xs)}] = {{{', '.join(repr(v) for v in xs)}}};")
+        out.append(f"__device__ const double {stem}_f[{len(fs)}] = {{{', '.join(repr(v) for v in fs)}}};")
+    return "\n".join(out)
 
 
 def generate_source(tp, dtype: str, integrator: int) -> str:
     """tp: dsl.TracedPipe (effectors only) or dsl.TracedProgram (pre | six_dof(effectors) | post)."""
+    _TABLES.clear()
     T = {"float64": "double", "float32": "float"}[dtype]
     integ = "kRk4" if integrator == 0 else "kSemiImplicit"
     is_prog = isinstance(tp, dsl.TracedProgram)
@@ -195,17 +222,20 @@ def generate_source(tp, dtype: str, integrator: int) -> str:
 {_emit_systems(tp.post)}
     }}'''
     names = ", ".join(e.__name__ for e in pipe_tp.effectors)
+    tables = _emit_tables()
     return f'''// generated by elodin_amd/codegen.py — do not edit.  Effectors: {names}
 #include "step_kernel.hpp"
 
 namespace sixdof {{
 
 {_PRELUDE}
+{tables}
+
 struct PipeCustom : NoModel {{
     static constexpr int kOps = {n_aux};
     static constexpr bool kStatic = true;
     static constexpr bool kWorldTorque = {"true" if pipe_tp.world_torque else "false"};
-    static constexpr bool kBodyTorque = false;
+    static constexpr bool kBodyTorque = {"true" if pipe_tp.body_torque else "false"};
     template <int K>
     static constexpr bool uses_aux() {{ return K < kOps; }}
     __device__ static __forceinline__ bool vel_independent(const StepParams&) {{ return {"false" if pipe_tp.reads_velocity else "true"}; }}

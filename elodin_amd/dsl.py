@@ -188,6 +188,19 @@ class _Np:
     @staticmethod
     def hypot(x, y): return Expr("hypot", (_lift(x), _lift(y)))
     @staticmethod
+    def interp(x, xp, fp):
+        """jnp.interp(x, xp, fp) with CONSTANT tables (atmosphere / thrust-curve lookups, e.g. examples/rocket/main.py:356-375)."""
+        xs, fs = tuple(float(v) for v in xp), tuple(float(v) for v in fp)
+        if len(xs) != len(fs) or len(xs) < 2 or any(b < a for a, b in zip(xs, xs[1:])):
+            raise ValueError("interp tables must be equally long (>= 2) with non-decreasing xp")
+        return Expr("interp", (_lift(x),), (xs, fs))
+    @staticmethod
+    def sign(x): return _Np.where(x > 0.0, 1.0, _Np.where(x < 0.0, -1.0, 0.0))
+    @staticmethod
+    def tanh(x):
+        e = _Np.exp(x * -2.0)
+        return (1.0 - e) / (1.0 + e)
+    @staticmethod
     def deg2rad(x): return x * (math.pi / 180.0)
     @staticmethod
     def rad2deg(x): return x * (180.0 / math.pi)
@@ -211,11 +224,21 @@ np = _Np
 
 # ---- spatial types (thin mirrors of libs/nox-py/src/spatial.rs wrappers) ---------------------------------------
 
+class RotVec(Vec):
+    """`stage_attitude @ x`: remembers x so a torque built this way can be handed to calc_accel in the body frame
+    (alpha = q * ((q^-1 * tau) / I): q^-1 * (q * x) = x) instead of being rotated out and straight back."""
+
+    def __init__(self, elems, body: Vec):
+        super().__init__(elems)
+        self.body = body
+
+
 class Quaternion:
     """Scalar-last [x,y,z,w]; assumed unit (the stage attitude is renormalised every stage)."""
 
-    def __init__(self, v: Vec):
+    def __init__(self, v: Vec, stage_attitude: bool = False):
         self.v = v
+        self.stage_attitude = stage_attitude
 
     def vector(self) -> Vec: return self.v
     def inverse(self) -> "Quaternion":
@@ -224,7 +247,8 @@ class Quaternion:
         """q @ v: rotate a 3-vector (quaternion.rs:283-305), as v + w t + u x t with t = 2 u x v."""
         u = Vec(self.v.e[:3])
         t = np.cross(u, x) * 2.0
-        return x + t * self.v[3] + np.cross(u, t)
+        r = x + t * self.v[3] + np.cross(u, t)
+        return RotVec(r.e, x) if self.stage_attitude else r
     def __mul__(self, o: "Quaternion") -> "Quaternion":
         l, r = self.v, o.v
         return Quaternion(Vec([l[3] * r[0] + l[0] * r[3] + l[1] * r[2] - l[2] * r[1],
@@ -252,12 +276,30 @@ class SpatialInertia:
 
 
 class SpatialForce:
-    def __init__(self, torque: Optional[Vec] = None, linear: Optional[Vec] = None):
-        self._t = torque if torque is not None else Vec([0.0, 0.0, 0.0])
-        self._f = linear if linear is not None else Vec([0.0, 0.0, 0.0])
-    def torque(self): return self._t
+    """[torque, force], world frame.  A torque given as `pos.angular() @ x` is additionally tracked in the body
+    frame (`_tb`), so the generated kernel can skip the world-frame round trip."""
+
+    def __init__(self, torque: Optional[Vec] = None, linear: Optional[Vec] = None, _tw=None, _tb=None):
+        zero = Vec([0.0, 0.0, 0.0])
+        self._f = linear if linear is not None else zero
+        if _tw is not None or _tb is not None:
+            self._tw, self._tb = (_tw if _tw is not None else zero), (_tb if _tb is not None else zero)
+        elif isinstance(torque, RotVec):
+            self._tw, self._tb = zero, torque.body
+        else:
+            self._tw, self._tb = (torque if torque is not None else zero), zero
+        self._q = None   # stage attitude, set by the tracer when a body-frame part exists
+    def torque(self):
+        if all(e.is_const(0.0) for e in self._tb.e):
+            return self._tw
+        if self._q is None:
+            raise TypeError("reading back a body-frame torque needs the stage attitude")
+        return self._tw + Vec((self._q @ self._tb).e)
     def force(self): return self._f
-    def __add__(self, o: "SpatialForce"): return SpatialForce(self._t + o._t, self._f + o._f)
+    def __add__(self, o: "SpatialForce"):
+        r = SpatialForce(linear=self._f + o._f, _tw=self._tw + o._tw, _tb=self._tb + o._tb)
+        r._q = self._q or o._q
+        return r
 
 
 # ---- tracing -----------------------------------------------------------------------------------------------------
@@ -288,8 +330,8 @@ def leaf(name: str) -> Expr:
     return Expr("leaf", (), None, name)
 
 
-def _body_symbols():
-    q = Quaternion(Vec([leaf(f"q{c}") for c in "ijkw"]))
+def _body_symbols(stage: bool = False):
+    q = Quaternion(Vec([leaf(f"q{c}") for c in "ijkw"]), stage_attitude=stage)
     pos = SpatialTransform(q, Vec([leaf(f"p{c}") for c in "xyz"]))
     vel = SpatialMotion(Vec([leaf(f"w{c}") for c in "xyz"]), Vec([leaf(f"v{c}") for c in "xyz"]))
     inertia = SpatialInertia(Vec([leaf(f"I{c}") for c in "xyz"]), leaf("mass"))
@@ -342,8 +384,9 @@ class TracedPipe:
                  widths: Optional[Dict[str, int]] = None):
         self.effectors = list(effectors)
         self.table = table or ColumnTable("aux", 4, 3, widths)
-        pos, vel, inertia = _body_symbols()
+        pos, vel, inertia = _body_symbols(stage=True)
         force = SpatialForce()                          # clear_forces: the pipe starts from zero (six_dof.rs:148-150)
+        force._q = pos.angular()
         for eff in self.effectors:
             kwargs = {}
             for name in eff.params:
@@ -360,12 +403,16 @@ class TracedPipe:
             out = eff.fn(**kwargs)
             if not isinstance(out, SpatialForce):
                 raise TypeError(f"effector {eff.__name__} must return a dsl.SpatialForce")
+            if out._q is None:
+                out._q = pos.angular()
             force = out
-        self.torque, self.linear = force.torque(), force.force()
-        self.outputs: List[Expr] = list(self.torque.e) + list(self.linear.e)
+        self.torque_world, self.torque_body, self.linear = force._tw, force._tb, force.force()
+        # outputs: world torque (3), force (3), body-frame torque (3)
+        self.outputs: List[Expr] = list(self.torque_world.e) + list(self.linear.e) + list(self.torque_body.e)
         self.leaves = _leaves_of(self.outputs)
         self.reads_velocity = any(n[0] in "wv" and len(n) == 2 for n in self.leaves)
-        self.world_torque = not all(t.is_const(0.0) for t in self.torque.e)
+        self.world_torque = not all(t.is_const(0.0) for t in self.torque_world.e)
+        self.body_torque = not all(t.is_const(0.0) for t in self.torque_body.e)
 
     @property
     def columns(self) -> List[Tuple[str, int]]:

@@ -33,13 +33,24 @@ def evaluate(tp, xs, vs, inertia, columns):
             r = _F2[e.op](ev(e.args[0]), ev(e.args[1]))
         elif e.op == "select":
             r = np.where(ev(e.args[0]), ev(e.args[1]), ev(e.args[2]))
+        elif e.op == "interp":
+            r = np.interp(ev(e.args[0]), np.array(e.value[0]), np.array(e.value[1]))
         else:
             raise ValueError(e.op)
         memo[id(e)] = r
         return r
 
     with np.errstate(all="ignore"):
-        return np.stack([ev(o) for o in tp.outputs], axis=1)
+        return _world_wrench(np.stack([ev(o) for o in tp.outputs], axis=1), xs)
+
+
+def _world_wrench(out9, xs):
+    """[tau_world(3), f(3), tau_body(3)] -> the world-frame wrench [tau, f] the `force` column holds."""
+    from tests import np_sixdof
+    F = out9[:, :6].copy()
+    if np.any(out9[:, 6:] != 0.0):
+        F[:, :3] = F[:, :3] + np_sixdof.rot(xs[:, :4], out9[:, 6:])
+    return F
 
 
 # ---- whole programs (pre systems | six_dof(effectors) | post systems) ------------------------------------------------
@@ -72,6 +83,8 @@ def _eval(exprs, leaves, n):
             r = _F2[e.op](ev(e.args[0]), ev(e.args[1]))
         elif e.op == "select":
             r = np.where(ev(e.args[0]), ev(e.args[1]), ev(e.args[2]))
+        elif e.op == "interp":
+            r = np.interp(ev(e.args[0]), np.array(e.value[0]), np.array(e.value[1]))
         else:
             raise ValueError(e.op)
         memo[id(e)] = r
@@ -108,7 +121,7 @@ def program_tick(tp, pos, vel, accel, inertia, comps, tick, dt_g, integrator):
 
     def eff(xs, vs):
         lv = _leaf_arrays(xs, vs, inertia, comps, tp.table, tick)
-        return np.stack(_eval(tp.pipe.outputs, lv, xs.shape[0]), axis=1)
+        return _world_wrench(np.stack(_eval(tp.pipe.outputs, lv, xs.shape[0]), axis=1), xs)
     pos2, vel2, acc2, F = np_sixdof.tick(pos, vel, accel, inertia, eff, dt_g, integrator=integrator)
     pos[:], vel[:], accel[:] = pos2, vel2, acc2
     _run_systems(tp.post, pos, vel, inertia, comps, tp.table, tick)

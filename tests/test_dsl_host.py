@@ -43,12 +43,13 @@ def test_numpy_stepper_is_bit_identical_to_the_c_oracle():
 
 def test_trace_flags_columns_and_folding():
     tp = (gravity | rcs).trace()
-    assert tp.columns == [("body_torque", 3)] and not tp.reads_velocity and tp.world_torque
+    assert tp.columns == [("body_torque", 3)] and not tp.reads_velocity
+    assert tp.body_torque and not tp.world_torque      # `pos.angular() @ x` torque stays in the body frame
     assert "mass" in tp.leaves and "vx" not in tp.leaves
     only_g = dsl.pipe(gravity).trace()
     assert not only_g.world_torque and only_g.columns == []
     assert only_g.outputs[3].op == "mul"               # 0.0 * mass is NOT folded (IEEE: mass may be inf/NaN)
-    assert all(t.is_const(0.0) for t in only_g.outputs[:3])
+    assert all(t.is_const(0.0) for t in only_g.outputs[:3]) and not only_g.body_torque
 
     @dsl.effector(wind=3)
     def drag(wind, vel, force):
@@ -72,7 +73,8 @@ def test_dag_matches_direct_numpy():
 def test_generated_source_compiles_for_gfx950():
     tp = (gravity | rcs).trace()
     src = codegen.generate_source(tp, "float64", 0)
-    assert "struct PipeCustom" in src and "sixdof_custom_launch" in src and "kWorldTorque = true" in src
+    assert "struct PipeCustom" in src and "sixdof_custom_launch" in src
+    assert "kWorldTorque = false" in src and "kBodyTorque = true" in src
     so = codegen.build(tp, "float64", 0)
     assert so.exists() and so.suffix == ".so"
     assert codegen.build(tp, "float64", 0) == so          # cached by content hash

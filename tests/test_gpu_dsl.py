@@ -210,3 +210,44 @@ def test_system_pipe_through_the_world_api_with_cadenced_system():
     assert exec.component("fuel")[:, 0].tolist() == [0.0, 0.0, 0.0]
     # fuel lasts 4 / 6 / 8 half-unit drains -> thrust on for 3 / 5 / 7 ticks (drain runs before six_dof)
     assert exec.column_array("world_vel")[:, 3].tolist() == [6.0, 10.0, 14.0]
+
+
+def test_table_interpolation_atmosphere_drag():
+    """jnp.interp over constant tables, as the rocket example's `mach` system uses it (examples/rocket/main.py:356-375):
+    density and temperature from the standard-atmosphere table, quadratic drag against the local flow."""
+    H = [0.0, 11_000.0, 20_000.0, 32_000.0, 47_000.0, 51_000.0, 71_000.0, 84_852.0]
+    TEMP = [15.0, -56.5, -56.5, -44.5, -2.5, -2.5, -58.5, -86.2]
+    RHO = [1.225, 0.3639, 0.0880, 0.0132, 0.0014, 0.0009, 0.0001, 0.0]
+
+    @dsl.effector
+    def aero_drag(force, pos, vel):
+        altitude = pos.linear()[2]
+        temperature = np_.interp(altitude, H, TEMP) + 273.15
+        density = np_.interp(altitude, H, RHO)
+        speed_of_sound = np_.sqrt(1.4 * 287.05 * temperature)
+        v = vel.linear()
+        speed = np_.linalg.norm(v)
+        mach = speed / speed_of_sound
+        cd = 0.3 + 0.2 * np_.tanh(4.0 * (mach - 1.0))
+        q = np_.clip(0.5 * density * speed ** 2, 1e-6, 1e12)
+        return force + dsl.SpatialForce(linear=v * (-(cd * q * 0.01) / np_.maximum(speed, 1e-6)))
+
+    n = 4000
+    w = workloads.independent_bodies(n)
+    rng = np.random.default_rng(9)
+    pos = w["world_pos"].copy()
+    pos[:, 6] = rng.uniform(-2_000.0, 95_000.0, n)          # below, inside and above the table
+    pos[:8, 6] = H                                           # exactly on the breakpoints
+    vel = w["world_vel"].copy()
+    vel[:, 3:] *= rng.uniform(1.0, 60.0, (n, 1))
+    pipe = gravity | aero_drag
+    tp = pipe.trace()
+    hip = el.HipExec(pos, vel, w["inertia"], simulation_time_step=workloads.DT_120HZ, effectors=pipe)
+    pos_r, vel_r, acc_r = pos.copy(), vel.copy(), np.zeros((n, 6))
+    eff = lambda xs, vs: dsl_numpy.evaluate(tp, xs, vs, w["inertia"], {})
+    for _ in range(20):
+        pos_r, vel_r, acc_r, F_r = np_sixdof.tick(pos_r, vel_r, acc_r, w["inertia"], eff, workloads.DT_120HZ)
+    hip.run(20)
+    assert parity.pos_rel_err(hip.world_pos, pos_r) < parity.F64_RTOL
+    assert parity.field_rel_err(hip.world_vel[:, 3:], vel_r[:, 3:]) < parity.F64_RTOL
+    assert parity.field_rel_err(hip.force[:, 3:], F_r[:, 3:]) < parity.F64_RTOL
