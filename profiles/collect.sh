@@ -12,9 +12,12 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 2048 --warmup 128 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.err
-# PMC passes: no graph replay (counters are attributed per dispatch), fewer steps
-CMDP="python $R/bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-graph"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $CMDP > $OUT/bench_fetch.json 2> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $CMDP > $OUT/bench_write.json 2> $OUT/write.err
+# PMC passes: only the timed region's kernel (1 tick per launch), no graph replay (counters are attributed per
+# dispatch), fewer steps; once at the bench size and once at 4,194,304 bodies (the roofline_hbm leg's size)
+for SIZE in 65536 4194304; do
+  CMDP="python $R/bench.py --entities $SIZE --steps 32 --warmup 4 --no-cpu-baseline --no-extras --no-graph"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$SIZE -o bench -- $CMDP > $OUT/bench_fetch_$SIZE.json 2> $OUT/fetch_$SIZE.err
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$SIZE -o bench -- $CMDP > $OUT/bench_write_$SIZE.json 2> $OUT/write_$SIZE.err
+done
 python $R/profiles/summarize.py $OUT $TAG
 find $OUT -type f | head -40
