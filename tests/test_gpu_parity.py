@@ -338,3 +338,19 @@ def test_history_ring_window_and_errors():
     hip.enable_history(0)
     with pytest.raises(ValueError):
         hip.history("world_pos", 30, 30)
+
+
+def test_config2_full_baseline_horizon_10000_ticks():
+    """BASELINE configs[1] at its full size AND horizon: 65,536 bodies x 10,000 RK4 ticks, fused
+    100 ticks per launch, against the oracle on all host cores (~25 s).  Measured worst error 1.6e-12."""
+    import os
+    hip, ref, w = _pair(65536, 10000, ticks_per_launch=100)
+    th = len(os.sched_getaffinity(0))
+    worst = 0.0
+    for cp in (2500, 5000, 10000):
+        hip.run(cp - hip.tick)
+        ref.step(cp - ref.tick, threads=th)
+        worst = max(worst, max(parity.state_errors(hip, ref).values()))
+    print("config2 10,000 ticks worst rel err", worst)
+    assert worst < parity.F64_RTOL
+    assert hip.tick == ref.tick == 10000
