@@ -41,7 +41,7 @@ class _World(C.Structure):
         ("tick", C.c_uint64),
         ("simulation_time_step", C.c_double), ("time_step", C.c_double),
         ("has_time_step", C.c_int32), ("integrator", C.c_int32),
-        ("n_ops", C.c_uint32), ("pad", C.c_uint32),
+        ("n_ops", C.c_uint32), ("pair_threads", C.c_uint32),
         ("ops", EffectorOp * MAX_OPS),
         ("aux", C.c_void_p * MAX_OPS),
         ("edge_src", C.c_void_p), ("edge_dst", C.c_void_p), ("n_edges", C.c_uint64),
@@ -190,6 +190,7 @@ class OracleWorld:
         return int(self._w.tick)
 
     def step(self, n_ticks: int = 1, threads: int = 1):
+        self._w.pair_threads = max(1, int(threads))
         if threads > 1:
             rc = lib().orc_step_omp(C.byref(self._w), n_ticks, threads)
         else:

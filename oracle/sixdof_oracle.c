@@ -231,7 +231,10 @@ static void effectors(const orc_world* w, const double* xs, const double* vs, do
             break;
         }
         case SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED: /* complete graph in n-body spawn order */
-            for (uint64_t a = 0; a < n; a++) {
+            /* sources are independent; each source's fold over its targets stays sequential (the reference order) */
+#pragma omp parallel for schedule(static) num_threads(w->pair_threads > 0 ? w->pair_threads : 1)
+            for (int64_t a_ = 0; a_ < (int64_t)n; a_++) {
+                const uint64_t a = (uint64_t)a_;
                 double acc[6] = {0, 0, 0, 0, 0, 0};
                 const double* pa = xs + 7 * a + 4;
                 const double ma = w->inertia[7 * a + 6];

@@ -25,7 +25,7 @@ typedef struct orc_world {
     int32_t has_time_step;
     int32_t integrator;
     uint32_t n_ops;
-    uint32_t pad;
+    uint32_t pair_threads; /* OpenMP threads for the all-pairs fold (0/1 = serial); results are identical */
     sixdof_effector_op ops[ORC_MAX_OPS];
     const double* aux[ORC_MAX_OPS]; /* per-op [n,3] column or NULL */
     const uint32_t* edge_src;       /* resolved row indices, spawn order */

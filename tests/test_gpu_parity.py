@@ -354,3 +354,27 @@ def test_config2_full_baseline_horizon_10000_ticks():
     print("config2 10,000 ticks worst rel err", worst)
     assert worst < parity.F64_RTOL
     assert hip.tick == ref.tick == 10000
+
+
+def test_nbody_config3_full_size_vs_oracle_and_momentum():
+    """BASELINE configs[2] at full size: 16,384 bodies, all-pairs softened gravity, RK4, dt = 3600 s.
+    (a) 2 ticks against the sequential-fold oracle (sources spread over the host cores);
+    (b) size-independent property over 40 ticks: pair forces are antisymmetric, so total linear momentum is conserved."""
+    import os
+    n = 16384
+    pos, vel, inertia = _plummer(n, seed=16384)
+    op = (K_SQ, EPS_AU2)
+    hip = ea.HipExec(pos, vel, inertia, simulation_time_step=3600.0, effectors=[ea.Effector(L.EFF_ALLPAIRS_GRAVITY_SOFTENED, op)])
+    ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=3600.0, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, op, None)])
+    hip.run(2)
+    ref.step(2, threads=len(os.sched_getaffinity(0)))
+    errs = parity.state_errors(hip, ref)
+    print("n-body 16384 x 2 ticks", errs)
+    assert max(errs.values()) < parity.F64_RTOL, errs
+    m = inertia[:, 6:7]
+    p0 = (m * vel[:, 3:]).sum(axis=0)
+    hip.run(38)
+    p1 = (m * hip.world_vel[:, 3:]).sum(axis=0)
+    scale = np.abs(m * hip.world_vel[:, 3:]).sum(axis=0)
+    assert np.all(np.abs(p1 - p0) / scale < 1e-12), (p0, p1)
+    assert np.all(hip.force[:, :3] == 0.0)           # el.Force(linear=...) carries no torque
