@@ -110,6 +110,25 @@ def generated_leg(device, n):
     return out
 
 
+def f32_leg(device):
+    """The f32 instantiation (BASELINE configs[4] asks for f32 state): same kernel, 192 B per entity-step."""
+    import elodin_amd as ea
+    from elodin_amd import workloads
+    out = {}
+    for n, reps in ((65536, 2048), (1 << 22, 64)):
+        w = workloads.independent_bodies(n, dtype=np.float32)
+        eff = workloads.gravity_torque_effectors(w["body_torque"])
+        ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=np.float32, simulation_time_step=0.008333333,
+                        effectors=eff, device=device, use_graph=True)
+        ex.invoke_batch(reps // 8)
+        t = ex.invoke_batch(reps)
+        us = t.kernel_device_ms / reps * 1e3
+        out[str(n)] = {"us_per_tick": round(us, 3), "entity_steps_per_s": round(n / us * 1e6, 1),
+                       "algorithmic_GBps": round(192.0 * n / us / 1e3, 1)}
+        ex.close()
+    return out
+
+
 def nbody_leg(device):
     """BASELINE configs[2]: all-pairs softened gravity, 16,384 bodies, RK4 f64 (parity case; timing for reference)."""
     import elodin_amd as ea
@@ -291,6 +310,7 @@ def main():
 
     if rank == 0 and not args.no_extras:
         extra("generated_pipe", generated_leg, local_rank, n)
+        extra("f32", f32_leg, local_rank)
         extra("nbody", nbody_leg, local_rank)
         extra("apollo_mc", apollo_leg, local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
