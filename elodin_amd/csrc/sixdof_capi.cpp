@@ -592,7 +592,7 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
     // 25 state elements per entity; stream (non-temporal) once the world is well past the 256 MiB Infinity Cache
     const char* force_nt = std::getenv("SIXDOF_STREAMING");
     const size_t state_bytes = static_cast<size_t>(h->desc.n_entities) * 32 * h->elem_size();
-    P->streaming = force_nt ? (force_nt[0] == '1') : (state_bytes > (400ull << 20));
+    P->streaming = force_nt ? static_cast<uint32_t>(force_nt[0] - '0') : (state_bytes > (400ull << 20) ? 1u : 0u);
     P->hist_ring = h->hist_ring;
     if (h->hist_ring) {
         P->hist_pos = h->d_hist[0];

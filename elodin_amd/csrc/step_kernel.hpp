@@ -49,10 +49,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 // Whole-wave slab of BYTES bytes (multiple of 16), global -> LDS by LDS-DMA.
 // NT = non-temporal cache policy (aux = 2) for worlds far larger than the 256 MiB Infinity Cache, where every
 // byte is touched exactly once per tick and retaining it only evicts useful lines.
-template <int BYTES, bool NT>
+template <int BYTES, int NT>
 __device__ __forceinline__ void slab_dma_in(const char* __restrict__ g, char* l, uint32_t lane) {
     constexpr int kFull = BYTES / 1024, kRem = (BYTES % 1024) / 16;
-    constexpr int kAux = NT ? 2 : 0;
+    constexpr int kAux = NT == 1 ? 2 : 0;
 #pragma unroll
     for (int i = 0; i < kFull; i++)
         __builtin_amdgcn_global_load_lds((global_cptr)(g + i * 1024 + lane * 16), (lds_ptr)(l + i * 1024), 16, 0,
@@ -64,12 +64,16 @@ __device__ __forceinline__ void slab_dma_in(const char* __restrict__ g, char* l,
 
 // Whole-wave slab, LDS -> global: read every chunk first, then issue the stores back to back.
 typedef float vfloat4 __attribute__((ext_vector_type(4)));
-template <bool NT>
+// Store policy: 0 = plain (lines stay dirty in the XCD's L2 until the kernel-end write-back), 1 = non-temporal,
+// 2 = write-through (`sc1`): the bytes leave for memory as the store issues, so the end of the kernel has nothing
+// left to flush (MI355X_MICROARCH.md "publish-large").
+template <int NT>
 __device__ __forceinline__ void store16(char* g, vfloat4 v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(g));
+    if constexpr (NT == 1) __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(g));
+    else if constexpr (NT == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g), "v"(v) : "memory");
     else *reinterpret_cast<vfloat4*>(g) = v;
 }
-template <int BYTES, bool NT>
+template <int BYTES, int NT>
 __device__ __forceinline__ void slab_out(const char* l, char* __restrict__ g, uint32_t lane) {
     constexpr int kFull = BYTES / 1024, kRem = (BYTES % 1024) / 16;
     vfloat4 tmp[kFull + 1];
@@ -93,7 +97,7 @@ __device__ __forceinline__ void slab_out_tail(const T* l, T* __restrict__ g, uin
 
 // ---- the kernel --------------------------------------------------------------------------------------
 
-template <class T, int INTEGRATOR, class PIPE, bool NT>
+template <class T, int INTEGRATOR, class PIPE, int NT>
 __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) {
     // pos | vel | inertia on the way in (20 elems/entity); pos | vel | accel | force on the way out (25)
     __shared__ __attribute__((aligned(16))) T lds[kWave * 25];
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     };
     // rows in LDS -> the four output columns at `base` pointers (live columns or one history slot)
     auto flush_rows = [&](T* o_pos, T* o_vel, T* o_accel, T* o_force, auto nt) {
-        constexpr bool kNt = decltype(nt)::value;
+        constexpr int kNt = decltype(nt)::value;
         if (full) {
             slab_out<kWave * 7 * sizeof(T), kNt>(reinterpret_cast<const char*>(l_pos), reinterpret_cast<char*>(o_pos), t);
             slab_out<kWave * 6 * sizeof(T), kNt>(reinterpret_cast<const char*>(l_vel), reinterpret_cast<char*>(o_vel), t);
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             const size_t slot = (size_t)((P.hist_slot0 + tick) % P.hist_ring);
             const size_t r7 = (slot * P.n + row0) * 7, r6 = (slot * P.n + row0) * 6;
             flush_rows(static_cast<T*>(P.hist_pos) + r7, static_cast<T*>(P.hist_vel) + r6,
-                       static_cast<T*>(P.hist_accel) + r6, static_cast<T*>(P.hist_force) + r6, std::true_type{});
+                       static_cast<T*>(P.hist_accel) + r6, static_cast<T*>(P.hist_force) + r6, std::integral_constant<int, 1>{});
             __syncthreads();
         }
     }
@@ -302,12 +306,12 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     F_out = world_wrench<PIPE>(b.q, F);  // wrench of the last stage evaluated, world frame
     stage_rows();
     __syncthreads();
-    flush_rows(g_pos, g_vel, g_accel, g_force, std::integral_constant<bool, NT>{});
+    flush_rows(g_pos, g_vel, g_accel, g_force, std::integral_constant<int, NT>{});
 }
 
 // ---- launch helpers (shared with generated translation units) ----------------------------------------------
 
-template <class T, class PIPE, bool NT>
+template <class T, class PIPE, int NT>
 inline void launch_i(const StepParams& p, int integrator, dim3 grid, hipStream_t s) {
     if (integrator == kRk4) hipLaunchKernelGGL((sixdof_step_kernel<T, kRk4, PIPE, NT>), grid, dim3(kWave), 0, s, p);
     else hipLaunchKernelGGL((sixdof_step_kernel<T, kSemiImplicit, PIPE, NT>), grid, dim3(kWave), 0, s, p);
@@ -315,8 +319,9 @@ inline void launch_i(const StepParams& p, int integrator, dim3 grid, hipStream_t
 
 template <class T, class PIPE>
 inline void launch_t(const StepParams& p, int integrator, dim3 grid, hipStream_t s) {
-    if (p.streaming) launch_i<T, PIPE, true>(p, integrator, grid, s);
-    else launch_i<T, PIPE, false>(p, integrator, grid, s);
+    if (p.streaming == 1) launch_i<T, PIPE, 1>(p, integrator, grid, s);
+    else if (p.streaming == 2) launch_i<T, PIPE, 2>(p, integrator, grid, s);
+    else launch_i<T, PIPE, 0>(p, integrator, grid, s);
 }
 
 template <class PIPE>

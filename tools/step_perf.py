@@ -5,7 +5,7 @@ from elodin_amd import workloads
 for n in [int(x) for x in sys.argv[1:]] or (65536, 1 << 22):
     w = workloads.independent_bodies(n)
     eff = workloads.gravity_torque_effectors(w["body_torque"])
-    for nt in ("0", "1"):
+    for nt in ("0", "1", "2"):
         os.environ["SIXDOF_STREAMING"] = nt
         ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ, effectors=eff, use_graph=True)
         reps = 2048 if n == 65536 else 64
