@@ -149,8 +149,17 @@ SIXDOF_M2(m_max, fmax, fmaxf) SIXDOF_M2(m_min, fmin, fminf) SIXDOF_M2(m_atan2, a
 template <class T, int N>
 __device__ __forceinline__ T m_interp(T x, const double (&xp)[N], const double (&fp)[N]) {
     int c = 0;
+    if constexpr (N <= 32) {
 #pragma unroll
-    for (int k = 0; k < N; k++) c += (T(xp[k]) <= x) ? 1 : 0;
+        for (int k = 0; k < N; k++) c += (T(xp[k]) <= x) ? 1 : 0;
+    } else {   // long tables: bisect (searchsorted side='right')
+        int lo = 0, hi = N;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (x < T(xp[mid])) hi = mid; else lo = mid + 1;
+        }
+        c = lo;
+    }
     const int i = c < 1 ? 1 : (c > N - 1 ? N - 1 : c);
     const T x0 = T(xp[i - 1]), f0 = T(fp[i - 1]);
     const T dx = T(xp[i]) - x0, df = T(fp[i]) - f0;

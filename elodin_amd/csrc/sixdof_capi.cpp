@@ -209,6 +209,8 @@ int sixdof_device_count(void) {
 
 const char* sixdof_last_error(const sixdof_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+void sixdof_destroy(sixdof_handle* h);
+
 int sixdof_create(const sixdof_desc* d, sixdof_handle** out) {
     if (!d || !out) {
         g_create_error = "sixdof_create: null argument";
@@ -256,7 +258,7 @@ int sixdof_create(const sixdof_desc* d, sixdof_handle** out) {
     if ((e = hipSetDevice(h->device)) != hipSuccess || (e = hipStreamCreate(&h->stream)) != hipSuccess ||
         (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
         g_create_error = std::string("sixdof_create: ") + hipGetErrorString(e);
-        delete h;
+        sixdof_destroy(h);   // releases whatever part was created
         return SIXDOF_ERR_BACKEND;
     }
     *out = h;

@@ -545,7 +545,7 @@ class Program:
 
 class TracedProgram:
     def __init__(self, prog: Program, widths: Optional[Dict[str, int]] = None):
-        self.table = ColumnTable("c", 12, 8, widths)
+        self.table = ColumnTable("c", 16, 8, widths)
         self.pre = [TracedSystem(s, self.table) for s in prog.pre]
         self.pipe = TracedPipe(prog.effectors.effectors, table=self.table)
         self.post = [TracedSystem(s, self.table) for s in prog.post]

@@ -251,3 +251,37 @@ def test_table_interpolation_atmosphere_drag():
     assert parity.pos_rel_err(hip.world_pos, pos_r) < parity.F64_RTOL
     assert parity.field_rel_err(hip.world_vel[:, 3:], vel_r[:, 3:]) < parity.F64_RTOL
     assert parity.field_rel_err(hip.force[:, 3:], F_r[:, 3:]) < parity.F64_RTOL
+
+
+def test_whole_apollo_campaign_as_user_code_equals_the_handwritten_model():
+    """Sim systems + 24 Hz guidance law + command hold + campaign scoring, all written against the dsl and compiled
+    into ONE kernel, flown to the surface on the example's own 30-rollout plan: same touchdown ticks and verdicts as
+    the hand-written apollo_rollout_kernel (itself checked against the C restatement), continuous results to 1e-6."""
+    from pathlib import Path
+    from elodin_amd import monte_carlo as mc
+    from elodin_amd.models import apollo
+    from tests import apollo_dsl as A
+    ref = apollo.load_reference()
+    P = mc.materialize(mc.load_spec(Path(__file__).parent / "golden" / "plans" / "apollo.toml")).table()
+    n, n_ticks = P.shape[0], apollo.max_ticks(ref)
+    cols = apollo.initial_columns(P, ref)
+    comps = A.components_from(cols)
+    comps.update(guid=cols["apollo_guidance"].copy(), score=np.zeros((n, 4)), result=np.zeros((n, 8)),
+                 result2=np.zeros((n, 4)), cfg2=np.stack([P[:, 15], P[:, 16], P[:, 3], np.zeros(n)], axis=1))
+    guidance, hold, score = A.closed_loop_systems(ref, n_ticks)
+    # tick order of the hand-written model: sim systems, six_dof, contact, telemetry, then post_step (score, guidance, hold)
+    prog = dsl.Program(A.NON_EFFECTORS, A.EFFECTORS, A.POST + [score, guidance, hold])
+    hip = el.HipExec(cols["world_pos"], cols["world_vel"], cols["inertia"], simulation_time_step=0.008333333,
+                     integrator=L.SEMI_IMPLICIT, effectors=prog, columns=comps, ticks_per_launch=500)
+    hw = apollo.ApolloExec(P, ref=ref, ticks_per_launch=500)
+    t0 = hip.invoke_batch(n_ticks)
+    hip.download()
+    hw.run(n_ticks)
+    res = np.concatenate([hip._aux["result"], hip._aux["result2"]], axis=1)
+    assert np.array_equal(res[:, 8], hw.result[:, 8]) and np.all(res[:, 8] == 1.0)      # all landed
+    assert np.array_equal(res[:, 10], hw.result[:, 10])                                   # on the same tick
+    assert np.array_equal(res[:, 9], hw.result[:, 9])                                     # same soft-landing verdicts
+    rel = np.abs(res[:, :8] - hw.result[:, :8]) / np.maximum(np.abs(hw.result[:, :8]), 1e-3)
+    print("generated closed loop vs hand-written: worst result rel err", rel.max(),
+          "device ms", t0.kernel_device_ms, "launches", t0.launches)
+    assert rel.max() < 1e-6
