@@ -87,6 +87,7 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
     const V3 rcs_k = {4500.0 * ag, 5500.0 * ag, 4500.0 * ag};
     const V3 rcs_d = {19000.0, 21000.0, 19000.0};
     const V3 base_I = {78000.0, 72000.0, 45000.0};
+    const V3 inv_base_I = {1.0 / 78000.0, 1.0 / 72000.0, 1.0 / 45000.0};
     const double alpha = fmin(fmax(pr[APOLLO_P_THROTTLE_RESPONSE_HZ] * SIM_TIME_STEP, 0.0), 1.0);
     const double gravity = LUNAR_GRAVITY * pr[APOLLO_P_GRAVITY_SCALE];
     const double track_gain = pr[APOLLO_P_TRACK_GAIN], vertical_gain = pr[APOLLO_P_VERTICAL_GAIN];
@@ -94,8 +95,8 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
     const double inv_max_thrust = 1.0 / fmax(DPS_MAX_THRUST_N * thrust_scale, 1.0);
     const double dt = P.dt;
 
-    V3 I_diag = {0, 0, 0};
-    double mass = 0.0;
+    V3 I_diag = {0, 0, 0}, inv_I = {0, 0, 0};
+    double mass = 0.0, inv_m = 0.0;
     Spatial<double> A = {{0, 0, 0}, {0, 0, 0}}, Fw = {{0, 0, 0}, {0, 0, 0}};
 
     for (uint32_t k = 0; k < P.n_ticks; k++) {
@@ -132,6 +133,11 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
             mass = dry_mass + prop + rcs_prop;
             const double sc = mass * inv_total_mass;
             I_diag = is_landed ? V3{1.0e9, 1.0e9, 1.0e9} : V3{base_I.x * sc, base_I.y * sc, base_I.z * sc};
+            // one divide per tick: 1/m, and 1/I = (1/I_base) * (m_total / m)
+            inv_m = 1.0 / mass;
+            const double inv_sc = total_mass * inv_m;
+            inv_I = is_landed ? V3{1.0e-9, 1.0e-9, 1.0e-9}
+                              : V3{inv_base_I.x * inv_sc, inv_base_I.y * inv_sc, inv_base_I.z * inv_sc};
         }
         // six_dof(lunar_gravity | apply_main_thrust | apply_rcs_torque), semi-implicit (sim.py:380-398,523)
         {
@@ -139,8 +145,7 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
             V3 f = rotate(qn, V3{0.0, 0.0, thrust});
             f.z = fma(-g_eff, mass, f.z);
             // torque is given in the body frame: alpha = q * (tau_b / I)
-            const V3 alpha_w = rotate(qn, V3{torque.x / I_diag.x, torque.y / I_diag.y, torque.z / I_diag.z});
-            const double inv_m = 1.0 / mass;
+            const V3 alpha_w = rotate(qn, hadamard(torque, inv_I));
             A.ang = alpha_w;
             A.lin = inv_m * f;
             Fw.ang = rotate(qn, torque);
@@ -155,8 +160,10 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
             const bool contact = p.z <= FOOTPAD_HEIGHT_M;
             const bool first = !is_landed && contact;
             const bool now = is_landed || contact;
-            td_speed = first ? fabs(v.z) : td_speed;
-            td_hspeed = first ? sqrt(v.x * v.x + v.y * v.y) : td_hspeed;
+            if (first) {   // rare: latch the impact speeds before the velocity is zeroed
+                td_speed = fabs(v.z);
+                td_hspeed = sqrt(v.x * v.x + v.y * v.y);
+            }
             if (now) {
                 p.z = FOOTPAD_HEIGHT_M;
                 v = V3{0, 0, 0};
@@ -167,7 +174,6 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
         // derive_telemetry (sim.py:433-444): pitch = acos(body_up.z); body_up.z = 1 - 2(qi^2 + qj^2)
         pitch = acos(clampd(1.0 - 2.0 * (q.i * q.i + q.j * q.j), -1.0, 1.0)) * (180.0 / kPi);
         const double altitude = p.z, vertical_speed = v.z;
-        const double h_speed = sqrt(v.x * v.x + v.y * v.y);
 
         // ---- post_step (main.py:166-283) ---------------------------------------------------------------
         const bool landed_now = landed > 0.5;
@@ -179,6 +185,7 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
         }
         if (tick % P.guidance_period == 0 && !landed_now) {  // tick is wave-uniform; landed is per lane
             // controller/src/main.rs:188-262
+            const double h_speed = sqrt(v.x * v.x + v.y * v.y);
             const double m_now = dry_mass + prop + rcs_prop;
             const double g_eff = fmax(gravity - h_speed * h_speed * (1.0 / R_MOON_M), 0.05 * gravity);
             const double rate_track = clampd(track_gain * (ref[0] - altitude), -C_RATE_AUTH, C_RATE_AUTH);
@@ -251,7 +258,8 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
         setpoint = last_att;
         if (!(emitted > 0.5) && (landed_now || tick >= P.max_ticks - 1)) {  // main.py:240-272
             double* res = P.result + (size_t)i * APOLLO_N_RESULT;
-            const double td = landed_now ? td_speed : fabs(vertical_speed), tdh = landed_now ? td_hspeed : h_speed;
+            const double td = landed_now ? td_speed : fabs(vertical_speed);
+            const double tdh = landed_now ? td_hspeed : sqrt(v.x * v.x + v.y * v.y);
             const double nn = fmax(e_n, 1.0);
             const double upright = cos(fabs(pitch) * (kPi / 180.0));
             res[APOLLO_R_TOUCHDOWN_SPEED] = td;
