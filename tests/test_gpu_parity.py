@@ -378,3 +378,23 @@ def test_nbody_config3_full_size_vs_oracle_and_momentum():
     scale = np.abs(m * hip.world_vel[:, 3:]).sum(axis=0)
     assert np.all(np.abs(p1 - p0) / scale < 1e-12), (p0, p1)
     assert np.all(hip.force[:, :3] == 0.0)           # el.Force(linear=...) carries no torque
+
+
+def test_streaming_path_at_2m_bodies():
+    """Worlds past the Infinity Cache take the non-temporal instantiation of the step kernel (state > 400 MB):
+    2,097,152 bodies x 3 ticks against the oracle, plus bit-equality with the default cache policy."""
+    import os
+    n = 1 << 21
+    hip, ref, w = _pair(n, 3)
+    hip.run(3)
+    ref.step(3, threads=len(os.sched_getaffinity(0)))
+    errs = parity.state_errors(hip, ref)
+    assert max(errs.values()) < parity.F64_RTOL, errs
+    os.environ["SIXDOF_STREAMING"] = "0"
+    try:
+        plain, _, _ = _pair(n, 3)
+        plain.run(3)
+    finally:
+        del os.environ["SIXDOF_STREAMING"]
+    for f in parity.FIELDS:
+        assert np.array_equal(getattr(hip, f), getattr(plain, f)), f
