@@ -89,6 +89,21 @@ SYMBOLS = {
     "sixdof_stream": (C.c_void_p, [_H]),
     "sixdof_tick_bind": (C.c_int, [_H]),
     "sixdof_tick": (None, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "sixdof_world_create": (C.c_void_p, []),
+    "sixdof_world_destroy": (None, [C.c_void_p]),
+    "sixdof_world_last_error": (C.c_char_p, [C.c_void_p]),
+    "sixdof_world_spawn": (C.c_uint64, [C.c_void_p]),
+    "sixdof_world_entity_len": (C.c_uint64, [C.c_void_p]),
+    "sixdof_world_insert": (C.c_int, [C.c_void_p, C.c_uint64, C.c_char_p, C.c_int, C.POINTER(C.c_uint64), C.c_uint32,
+                                      C.c_void_p, C.c_size_t]),
+    "sixdof_world_column": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(Column)]),
+    "sixdof_world_components": (C.c_size_t, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]),
+    "sixdof_world_set_rates": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "sixdof_world_time_step": (C.c_double, [C.c_void_p]),
+    "sixdof_world_ticks_per_telemetry": (C.c_uint64, [C.c_void_p]),
+    "sixdof_world_tick": (C.c_uint64, [C.c_void_p]),
+    "sixdof_world_advance_tick": (None, [C.c_void_p, C.c_uint64]),
+    "sixdof_bind_world": (C.c_int, [_H, C.c_void_p]),
     "sixdof_set_custom_pipe": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_uint64), C.c_size_t]),
     "sixdof_set_history": (C.c_int, [_H, C.c_uint32]),
     "sixdof_history_read": (C.c_int, [_H, C.c_uint64, C.c_uint64, C.c_void_p]),

@@ -221,22 +221,36 @@ def six_dof(time_step: Optional[float] = None, sys=None, integrator: Integrator 
 # ---- world ----------------------------------------------------------------------------------------------------
 
 class World:
+    """Python face of the C++ column store (csrc/world.cpp, the analogue of libs/nox-py/src/world.rs)."""
+
     def __init__(self):
-        self._cols: Dict[str, List[np.ndarray]] = {}
-        self._ids: Dict[str, List[int]] = {}
+        import ctypes as C
+        self._lib = L.lib()
+        self._w = C.c_void_p(self._lib.sixdof_world_create())
         self._names: Dict[int, str] = {0: "Globals"}
         self._edges: Dict[str, List[tuple]] = {}
-        self.entity_len = 1   # Globals took id 0 (world.rs:174-183)
+        self._components: List[str] = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "_w", None) and self._w.value:
+                self._lib.sixdof_world_destroy(self._w)
+        except Exception:
+            pass
+
+    @property
+    def entity_len(self) -> int:
+        return int(self._lib.sixdof_world_entity_len(self._w))
 
     def spawn(self, archetypes, name: Optional[str] = None) -> EntityId:
-        eid = EntityId(self.entity_len)
-        self.entity_len += 1
+        eid = EntityId(self._lib.sixdof_world_spawn(self._w))
         self.insert(eid, archetypes)
         if name is not None:
             self._names[int(eid)] = name
         return eid
 
     def insert(self, eid: EntityId, archetypes) -> None:
+        import ctypes as C
         if not isinstance(archetypes, (list, tuple)):
             archetypes = [archetypes]
         for arch in archetypes:
@@ -245,32 +259,39 @@ class World:
                 continue
             for cname, value in arch.components().items():
                 value = np.ascontiguousarray(value, dtype=np.float64)   # lib.rs:64-75: C-contiguous rows
-                rows = self._cols.setdefault(cname, [])
-                if rows and rows[0].shape != value.shape:
+                dims = (C.c_uint64 * 2)(value.shape[0] if value.ndim else 1, 0)
+                rc = self._lib.sixdof_world_insert(self._w, int(eid), cname.encode(), L.PRIM_F64, dims, 1,
+                                                   value.ctypes.data, value.nbytes)
+                if rc == L.ERR_VALUE_SIZE_MISMATCH:
                     raise ValueError(f"component {cname}: value size mismatch")   # Error::ValueSizeMismatch
-                rows.append(value)
-                self._ids.setdefault(cname, []).append(int(eid))
+                if rc != L.OK:
+                    raise ValueError(self._lib.sixdof_world_last_error(self._w).decode())
+                if cname not in self._components:
+                    self._components.append(cname)
 
     def column(self, name: str):
-        if name not in self._cols:
-            raise KeyError(name)   # Error::ComponentNotFound
-        return np.stack(self._cols[name]), np.asarray(self._ids[name], dtype=np.uint64)
+        """(rows [n,w] float64 copy, entity ids [n] uint64) of a component; KeyError = Error::ComponentNotFound."""
+        import ctypes as C
+        c = L.Column()
+        if self._lib.sixdof_world_column(self._w, L.component_id(name), C.byref(c)) != L.OK:
+            raise KeyError(name)
+        n, w = int(c.n_rows), int(c.dims[0]) if c.ndim else 1
+        rows = np.ctypeslib.as_array(C.cast(c.host_ptr, C.POINTER(C.c_double)), shape=(n, w)).copy() if n else np.zeros((0, w))
+        ids = np.ctypeslib.as_array(c.entity_ids, shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint64)
+        return rows, ids.astype(np.uint64)
 
     def build(self, system: System, simulation_rate: float = 120.0, telemetry_rate: Optional[float] = None,
               device: int = 0, backend: str = "hip") -> "Exec":
         """World.build (world_builder.rs:1737-1780): validate rates, fix globals, bind the backend."""
         if backend != "hip":
             raise ValueError(f"unknown backend {backend!r}: this package provides 'hip' only")
-        if not simulation_rate > 0.0:
-            raise ValueError(f"simulation_rate must be > 0 Hz, got {simulation_rate}")
-        ticks_per_telemetry = 1
-        if telemetry_rate is not None:
-            ratio = simulation_rate / telemetry_rate
-            if telemetry_rate <= 0.0 or abs(ratio - round(ratio)) > 1e-9 or round(ratio) < 1:
-                raise ValueError(f"telemetry_rate ({telemetry_rate} Hz) must evenly divide simulation_rate "
-                                 f"({simulation_rate} Hz); got ratio {ratio}")   # world_builder.rs:223-240
-            ticks_per_telemetry = int(round(ratio))
-        dt = float(L.lib().sixdof_quantize_time_step(simulation_rate))
+        if telemetry_rate is not None and telemetry_rate <= 0.0:
+            raise ValueError(f"telemetry_rate must be > 0 Hz, got {telemetry_rate}")
+        # validate_rates + set_globals in the C++ world (world_builder.rs:211-243)
+        if self._lib.sixdof_world_set_rates(self._w, float(simulation_rate), float(telemetry_rate or 0.0)) != L.OK:
+            raise ValueError(self._lib.sixdof_world_last_error(self._w).decode())
+        ticks_per_telemetry = int(self._lib.sixdof_world_ticks_per_telemetry(self._w))
+        dt = float(self._lib.sixdof_world_time_step(self._w))
         from . import dsl as _dsl
         program_stages = None
         if isinstance(system, _dsl.Stages):      # pre | six_dof(effectors) | post  -> one generated program
@@ -293,7 +314,7 @@ class World:
             eff_pipe = system.effectors if isinstance(system.effectors, _dsl.Pipe) else _dsl.Pipe([])
             if not isinstance(system.effectors, _dsl.Pipe) and system.effectors.ops:
                 raise TypeError("inside a generated program the six_dof effectors must be dsl effectors")
-            widths = {name: int(np.atleast_2d(np.stack(rows)).shape[1]) for name, rows in self._cols.items()}
+            widths = {name: int(self.column(name)[0].shape[1]) for name in self._components}
             effs = _dsl.Program(program_stages[0], eff_pipe, program_stages[1])
             extra_columns = {}
             for name, _w in effs.trace(widths).columns:

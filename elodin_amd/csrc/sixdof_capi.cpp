@@ -360,6 +360,23 @@ int sixdof_bind_columns(sixdof_handle* h, const sixdof_column* cols, size_t n_co
     return SIXDOF_OK;
 }
 
+int sixdof_bind_world(sixdof_handle* h, sixdof_world* w) {
+    if (!h || !w) return SIXDOF_ERR_INVALID_ARGUMENT;
+    std::vector<uint64_t> ids(sixdof_world_components(w, nullptr, 0));
+    sixdof_world_components(w, ids.data(), ids.size());
+    std::vector<sixdof_column> cols;
+    for (uint64_t id : ids) {
+        sixdof_column c{};
+        if (sixdof_world_column(w, id, &c) != SIXDOF_OK) continue;
+        if (id == h->id_tick || id == h->id_dt) continue;   // globals travel in the descriptor / handle
+        if (c.prim_type != h->state_prim() || c.ndim > 1) continue;
+        cols.push_back(c);
+    }
+    h->desc.simulation_time_step = sixdof_world_time_step(w);
+    h->tick = sixdof_world_tick(w);
+    return sixdof_bind_columns(h, cols.data(), cols.size());
+}
+
 int sixdof_set_effectors(sixdof_handle* h, const sixdof_effector_op* ops, size_t n_ops) {
     if (!h || (!ops && n_ops)) return SIXDOF_ERR_INVALID_ARGUMENT;
     size_t n_entity_ops = 0, n_pair = 0;

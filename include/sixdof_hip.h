@@ -208,6 +208,31 @@ void sixdof_tick(const uint8_t* const* inputs, uint8_t* const* outputs);
 int sixdof_tick_slots(const sixdof_handle* h, sixdof_slot* inputs, size_t in_cap, size_t* n_in,
                       sixdof_slot* outputs, size_t out_cap, size_t* n_out);
 
+/* ---- host-side ECS column store: the `World` of libs/nox-py/src/world.rs:23-45,174-229 ---------------------------
+ * Per component a growing row-major buffer + the entity id of each row, rows in spawn order, ids sequential,
+ * entity 0 = "Globals" (tick u64, simulation_time_step f64).  Pure host code: needs no GPU. */
+typedef struct sixdof_world sixdof_world;
+sixdof_world* sixdof_world_create(void);
+void sixdof_world_destroy(sixdof_world* w);
+const char* sixdof_world_last_error(const sixdof_world* w);
+uint64_t sixdof_world_spawn(sixdof_world* w);                 /* World::spawn: next sequential EntityId */
+uint64_t sixdof_world_entity_len(const sixdof_world* w);
+/* World::insert_with_id for one component: append `row` (n_bytes = prod(dims) * sizeof(prim)) and the entity id. */
+int sixdof_world_insert(sixdof_world* w, uint64_t entity, const char* component, int prim_type, const uint64_t* dims,
+                        uint32_t ndim, const void* row, size_t n_bytes);
+/* World::column_by_id: a view (pointers stay valid until the next insert into that component). */
+int sixdof_world_column(sixdof_world* w, uint64_t component_id, sixdof_column* out);
+size_t sixdof_world_components(const sixdof_world* w, uint64_t* ids, size_t cap); /* ascending ComponentId */
+/* validate_rates + set_globals (world_builder.rs:211-243): telemetry_rate_hz = 0 means "same as simulation". */
+int sixdof_world_set_rates(sixdof_world* w, double simulation_rate_hz, double telemetry_rate_hz);
+double sixdof_world_time_step(const sixdof_world* w);
+uint64_t sixdof_world_ticks_per_telemetry(const sixdof_world* w);
+uint64_t sixdof_world_tick(const sixdof_world* w);
+void sixdof_world_advance_tick(sixdof_world* w, uint64_t n);
+/* Bind every 1-D f64/f32 component column of the world to the backend handle (CraneliftExec::new walks
+ * world.column_by_id the same way, cranelift_exec.rs:101-106).  Follow with sixdof_upload. */
+int sixdof_bind_world(sixdof_handle* h, sixdof_world* w);
+
 /* ---- effector front-end: run-time generated pipes -------------------------------------------------------------
  * The reference JIT-compiles whatever effector graph the user wrote (cranelift_compile.rs:13-162).  The analogue
  * here: elodin_amd/codegen.py turns an effector pipe written against a jax.numpy-like tracer into HIP source that

@@ -101,3 +101,44 @@ def test_many_handles_and_two_threads_on_one_gpu():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert np.array_equal(results[0], serial.world_pos) and np.array_equal(results[1], serial.world_pos)
+
+
+def test_c_world_bound_to_a_handle_end_to_end():
+    """Pure C-ABI host: sixdof_world_* builds the columns, sixdof_bind_world hands them to the backend
+    (what a non-Python host would do); K8 known answer test_six_dof_force through it."""
+    lib = L.lib()
+    w = C.c_void_p(lib.sixdof_world_create())
+
+    def insert(eid, name, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        dims = (C.c_uint64 * 2)(arr.shape[0], 0)
+        assert lib.sixdof_world_insert(w, eid, name.encode(), L.PRIM_F64, dims, 1, arr.ctypes.data, arr.nbytes) == L.OK
+    static = lib.sixdof_world_spawn(w)                      # a scene object: world_pos only
+    insert(static, "world_pos", [0, 0, 0, 1.0, 9, 9, 9])
+    e1 = lib.sixdof_world_spawn(w)
+    for name, val in (("world_pos", [0, 0, 0, 1.0, 0, 0, 0]), ("world_vel", [0] * 6), ("world_accel", [0] * 6),
+                      ("force", [0] * 6), ("inertia", [1, 1, 1, 0, 0, 0, 1.0])):
+        insert(e1, name, val)
+    assert lib.sixdof_world_set_rates(w, 120.0, 0.0) == L.OK
+    h = C.c_void_p()
+    d = _desc(0, has_time_step=1, time_step=1.0 / 120.0)    # n_entities = 0: sized by the join
+    assert lib.sixdof_create(C.byref(d), C.byref(h)) == L.OK
+    assert lib.sixdof_bind_world(h, w) == L.OK
+    op = (L.EffectorOp * 1)()
+    op[0].kind = L.EFF_CONST_WRENCH
+    op[0].p[3] = 1.0
+    assert lib.sixdof_set_effectors(h, op, 1) == L.OK
+    assert lib.sixdof_upload(h) == L.OK
+    assert lib.sixdof_step(h, 120, None) == L.OK
+    assert lib.sixdof_download(h, L.COL_ALL) == L.OK
+    lib.sixdof_world_advance_tick(w, 120)
+    c = L.Column()
+    lib.sixdof_world_column(w, L.component_id("world_pos"), C.byref(c))
+    pos = np.frombuffer(C.string_at(c.host_ptr, 2 * 56), dtype="<f8").reshape(2, 7)
+    assert pos[0].tolist() == [0, 0, 0, 1, 9, 9, 9]                                        # static object untouched
+    assert np.isclose(pos[1], [0, 0, 0, 1, 0.5, 0, 0], rtol=1e-5).all()                    # test_all.py:342-364
+    t = C.c_uint64()
+    lib.sixdof_get_tick(h, C.byref(t))
+    assert t.value == 120 == lib.sixdof_world_tick(w)
+    lib.sixdof_destroy(h)
+    lib.sixdof_world_destroy(w)
