@@ -83,6 +83,10 @@ struct PairParams {
 // Picks the number of source splits for n targets so the all-pairs grid fills 256 CUs.
 uint32_t pair_splits_for(uint32_t n);
 hipError_t launch_pair_tick(const PairParams& p, int integrator, hipStream_t stream, uint64_t* launches);
+// n <= kPairSmallMax: pack, fold and integrate n_ticks ticks in one single-workgroup launch (bit-identical results).
+constexpr uint32_t kPairSmallMax = 256;
+hipError_t launch_pair_small(const PairParams& p, int integrator, uint32_t n_ticks, hipStream_t stream,
+                             uint64_t* launches);
 
 // ---- joins (query.rs:599-725): gather / scatter of rows by constant u32 indices -----------------------------
 hipError_t launch_gather_rows(void* dst, const void* src, const uint32_t* rows, uint32_t m, uint32_t w, size_t elem,

@@ -137,16 +137,13 @@ __global__ __launch_bounds__(kTile) void allpairs_kernel(const double* __restric
 }
 
 // ---- 2b. explicit edge list, CSR by source (three-body and sparse graphs) ---------------------------------
+// One source's left fold over its out-edges (CSR range), spawn order, for the NS stage positions.
 template <int NS>
-__global__ __launch_bounds__(256) void edge_kernel(const double* __restrict__ pack, double* __restrict__ partial,
-                                                   const uint32_t* __restrict__ row_start,
-                                                   const uint32_t* __restrict__ dst, uint32_t n, int kind, double p0,
-                                                   double p1) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__device__ __forceinline__ void edge_accumulate(const double* pack, const uint32_t* __restrict__ row_start,
+                                                const uint32_t* __restrict__ dst, uint32_t i, int kind, double p0,
+                                                double p1, double (&acc)[3][3]) {
     const double* a = pack + (size_t)i * kPackWidth;
     const double ma = a[9];
-    double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (uint32_t e = row_start[i]; e < row_start[i + 1]; e++) {  // spawn order inside a source
         const double* b = pack + (size_t)dst[e] * kPackWidth;
         const double mb = b[9];
@@ -175,6 +172,17 @@ __global__ __launch_bounds__(256) void edge_kernel(const double* __restrict__ pa
             }
         }
     }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void edge_kernel(const double* __restrict__ pack, double* __restrict__ partial,
+                                                   const uint32_t* __restrict__ row_start,
+                                                   const uint32_t* __restrict__ dst, uint32_t n, int kind, double p0,
+                                                   double p1) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    edge_accumulate<NS>(pack, row_start, dst, i, kind, p0, p1, acc);
     double* o = partial + (size_t)i * kPartialWidth;
 #pragma unroll
     for (int st = 0; st < NS; st++)
@@ -183,52 +191,31 @@ __global__ __launch_bounds__(256) void edge_kernel(const double* __restrict__ pa
 
 // ---- 3. integrate ---------------------------------------------------------------------------------------
 // Per-entity half of the tick: same stage structure as sixdof_step_kernel, with the pair forces
-// taken from the partial sums.  Per-entity ops that precede the pair op in the pipe only survive on
+// taken from `pf`.  Per-entity ops that precede the pair op in the pipe only survive on
 // rows that are not edge sources.
+struct EntityState {
+    Quat<double> q0;
+    Vec3<double> p0;
+    Spatial<double> v0;
+    Vec3<double> I, inv_I;
+    double mass, inv_m;
+};
+
 template <int INTEGRATOR>
-__global__ __launch_bounds__(256) void pair_integrate_kernel(const PairParams P) {
+__device__ __forceinline__ void pair_integrate_entity(const PairParams& P, const StepParams& SP,
+                                                      const Vec3<double> (&aux)[kMaxOps], const double (&pf)[3][3],
+                                                      bool is_source, EntityState& e, Spatial<double>& A,
+                                                      Spatial<double>& Fw) {
     using T = double;
     using PIPE = PipeGeneric;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
-    T* pos = static_cast<T*>(P.pos) + (size_t)i * 7;
-    T* vel = static_cast<T*>(P.vel) + (size_t)i * 6;
-    const T* in = static_cast<const T*>(P.inertia) + (size_t)i * 7;
-    Quat<T> q0 = {pos[0], pos[1], pos[2], pos[3]};
-    Vec3<T> p0 = {pos[4], pos[5], pos[6]};
-    Spatial<T> v0 = {{vel[0], vel[1], vel[2]}, {vel[3], vel[4], vel[5]}};
-    const Vec3<T> inv_I = {T(1) / in[0], T(1) / in[1], T(1) / in[2]};
-    const T mass = in[6], inv_m = T(1) / mass;
-
-    const bool is_source = P.pair_kind == SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED
-                               ? (P.n > 1)
-                               : (P.row_start[i + 1] > P.row_start[i]);
-    constexpr int NS = INTEGRATOR == kRk4 ? 3 : 1;
-    T pf[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    for (uint32_t s = 0; s < P.splits; s++) {  // fixed order: deterministic
-        const T* part = P.partial + ((size_t)s * P.n + i) * kPartialWidth;
-#pragma unroll
-        for (int st = 0; st < NS; st++)
-            for (int c = 0; c < 3; c++) pf[st][c] += part[3 * st + c];
-    }
-
-    StepParams SP;  // view of the per-entity ops for the shared effector code
-    SP.n_ops = P.n_ops;
-    SP.vel_independent = 0;
-#pragma unroll
-    for (int k = 0; k < kMaxOps; k++) SP.ops[k] = P.ops[k];
-    Vec3<T> aux[kMaxOps];
-#pragma unroll
-    for (int k = 0; k < kMaxOps; k++) {
-        aux[k] = Vec3<T>{0, 0, 0};
-        if (k < (int)P.n_ops && P.ops[k].aux != nullptr) {
-            const T* a = static_cast<const T*>(P.ops[k].aux) + (size_t)i * 3;
-            aux[k] = Vec3<T>{a[0], a[1], a[2]};
-        }
-    }
+    Quat<T>& q0 = e.q0;
+    Vec3<T>& p0 = e.p0;
+    Spatial<T>& v0 = e.v0;
+    const Vec3<T> inv_I = e.inv_I;
+    const T inv_m = e.inv_m;
     Body<T> b;
-    b.mass = mass;
-    b.I = Vec3<T>{in[0], in[1], in[2]};
+    b.mass = e.mass;
+    b.I = e.I;
     Wrench<T> F;
     auto stage_force = [&](int st) {
         F = zero_wrench<T>();
@@ -239,7 +226,6 @@ __global__ __launch_bounds__(256) void pair_integrate_kernel(const PairParams P)
         }
     };
     const T dt_g = P.dt_g, dt = P.dt;
-    Spatial<T> A;
     if constexpr (INTEGRATOR == kRk4) {
         const T h1 = dt_g * 0.5, h3 = dt_g;
         Spatial<T> sv, sa;
@@ -274,13 +260,137 @@ __global__ __launch_bounds__(256) void pair_integrate_kernel(const PairParams P)
         q0 = integrate_world(q0, dt * v0.ang);
         p0 = axpy(dt, v0.lin, p0);
     }
-    const Spatial<T> Fw = world_wrench<PIPE>(b.q, F);
-    pos[0] = q0.i; pos[1] = q0.j; pos[2] = q0.k; pos[3] = q0.w; pos[4] = p0.x; pos[5] = p0.y; pos[6] = p0.z;
-    vel[0] = v0.ang.x; vel[1] = v0.ang.y; vel[2] = v0.ang.z; vel[3] = v0.lin.x; vel[4] = v0.lin.y; vel[5] = v0.lin.z;
-    T* ac = static_cast<T*>(P.accel) + (size_t)i * 6;
+    Fw = world_wrench<PIPE>(b.q, F);
+}
+
+__device__ __forceinline__ void load_entity(const PairParams& P, uint32_t i, EntityState& e, StepParams& SP,
+                                            Vec3<double> (&aux)[kMaxOps]) {
+    const double* pos = static_cast<const double*>(P.pos) + (size_t)i * 7;
+    const double* vel = static_cast<const double*>(P.vel) + (size_t)i * 6;
+    const double* in = static_cast<const double*>(P.inertia) + (size_t)i * 7;
+    e.q0 = {pos[0], pos[1], pos[2], pos[3]};
+    e.p0 = {pos[4], pos[5], pos[6]};
+    e.v0 = {{vel[0], vel[1], vel[2]}, {vel[3], vel[4], vel[5]}};
+    e.I = {in[0], in[1], in[2]};
+    e.inv_I = {1.0 / in[0], 1.0 / in[1], 1.0 / in[2]};
+    e.mass = in[6];
+    e.inv_m = 1.0 / in[6];
+    SP.n_ops = P.n_ops;   // view of the per-entity ops for the shared effector code
+    SP.vel_independent = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxOps; k++) SP.ops[k] = P.ops[k];
+#pragma unroll
+    for (int k = 0; k < kMaxOps; k++) {
+        aux[k] = Vec3<double>{0, 0, 0};
+        if (k < (int)P.n_ops && P.ops[k].aux != nullptr) {
+            const double* a = static_cast<const double*>(P.ops[k].aux) + (size_t)i * 3;
+            aux[k] = Vec3<double>{a[0], a[1], a[2]};
+        }
+    }
+}
+
+__device__ __forceinline__ void store_entity(const PairParams& P, uint32_t i, const EntityState& e,
+                                             const Spatial<double>& A, const Spatial<double>& Fw) {
+    double* pos = static_cast<double*>(P.pos) + (size_t)i * 7;
+    double* vel = static_cast<double*>(P.vel) + (size_t)i * 6;
+    pos[0] = e.q0.i; pos[1] = e.q0.j; pos[2] = e.q0.k; pos[3] = e.q0.w; pos[4] = e.p0.x; pos[5] = e.p0.y; pos[6] = e.p0.z;
+    vel[0] = e.v0.ang.x; vel[1] = e.v0.ang.y; vel[2] = e.v0.ang.z;
+    vel[3] = e.v0.lin.x; vel[4] = e.v0.lin.y; vel[5] = e.v0.lin.z;
+    double* ac = static_cast<double*>(P.accel) + (size_t)i * 6;
     ac[0] = A.ang.x; ac[1] = A.ang.y; ac[2] = A.ang.z; ac[3] = A.lin.x; ac[4] = A.lin.y; ac[5] = A.lin.z;
-    T* fo = static_cast<T*>(P.force) + (size_t)i * 6;
+    double* fo = static_cast<double*>(P.force) + (size_t)i * 6;
     fo[0] = Fw.ang.x; fo[1] = Fw.ang.y; fo[2] = Fw.ang.z; fo[3] = Fw.lin.x; fo[4] = Fw.lin.y; fo[5] = Fw.lin.z;
+}
+
+template <int INTEGRATOR>
+__global__ __launch_bounds__(256) void pair_integrate_kernel(const PairParams P) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    EntityState e;
+    StepParams SP;
+    Vec3<double> aux[kMaxOps];
+    load_entity(P, i, e, SP, aux);
+    const bool is_source = P.pair_kind == SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED
+                               ? (P.n > 1)
+                               : (P.row_start[i + 1] > P.row_start[i]);
+    constexpr int NS = INTEGRATOR == kRk4 ? 3 : 1;
+    double pf[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (uint32_t s = 0; s < P.splits; s++) {  // fixed order: deterministic
+        const double* part = P.partial + ((size_t)s * P.n + i) * kPartialWidth;
+#pragma unroll
+        for (int st = 0; st < NS; st++)
+            for (int c = 0; c < 3; c++) pf[st][c] += part[3 * st + c];
+    }
+    Spatial<double> A, Fw;
+    pair_integrate_entity<INTEGRATOR>(P, SP, aux, pf, is_source, e, A, Fw);
+    store_entity(P, i, e, A, Fw);
+}
+
+// ---- small graphs: the whole tick (and n_ticks of them) in ONE single-workgroup launch --------------------------
+// Three-body / solar-system sized worlds (n <= 256) are launch-bound, not math-bound: pack, fold and integrate
+// run in one workgroup with the packed sources in LDS and the entity state in registers across ticks.  Same device
+// functions as the three-kernel path, so results are bit-identical to it.
+template <int INTEGRATOR>
+__global__ __launch_bounds__(kTile) void pair_small_kernel(const PairParams P, uint32_t n_ticks) {
+    __shared__ __attribute__((aligned(16))) double pack[kTile * kPackWidth];
+    constexpr int NS = INTEGRATOR == kRk4 ? 3 : 1;
+    const uint32_t i = threadIdx.x;
+    const bool active = i < P.n;
+    EntityState e;
+    StepParams SP;
+    Vec3<double> aux[kMaxOps];
+    if (active) load_entity(P, i, e, SP, aux);
+    const bool allpairs = P.pair_kind == SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED;
+    const bool is_source = active && (allpairs ? (P.n > 1) : (P.row_start[i + 1] > P.row_start[i]));
+    const double h1 = P.dt_g * 0.5, h3 = P.dt_g;
+    Spatial<double> A = {{0, 0, 0}, {0, 0, 0}}, Fw = {{0, 0, 0}, {0, 0, 0}};
+    for (uint32_t t = 0; t < n_ticks; t++) {
+        if (active) {
+            double* o = pack + i * kPackWidth;
+            const double x[3] = {e.p0.x, e.p0.y, e.p0.z}, v[3] = {e.v0.lin.x, e.v0.lin.y, e.v0.lin.z};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                o[c] = x[c];
+                o[3 + c] = x[c] + h1 * v[c];
+                o[6 + c] = x[c] + h3 * v[c];
+            }
+            o[9] = e.mass;
+        }
+        __syncthreads();
+        double pf[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        if (active) {
+            double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            if (allpairs) {
+                double pi[3][3];
+                const double* s = pack + i * kPackWidth;
+#pragma unroll
+                for (int st = 0; st < 3; st++)
+                    for (int c = 0; c < 3; c++) pi[st][c] = st < NS ? s[3 * st + c] : 0.0;
+                tile_accumulate<NS, true>(pack, (int)P.n, 0, i, pi, P.p1, acc);
+                const double kmi = P.p0 * e.mass;
+#pragma unroll
+                for (int st = 0; st < NS; st++)
+                    for (int c = 0; c < 3; c++) pf[st][c] += kmi * acc[st][c];
+            } else {
+                edge_accumulate<NS>(pack, P.row_start, P.dst, i, P.pair_kind, P.p0, P.p1, acc);
+#pragma unroll
+                for (int st = 0; st < NS; st++)
+                    for (int c = 0; c < 3; c++) pf[st][c] += acc[st][c];
+            }
+        }
+        __syncthreads();   // every lane has read the packed sources before the next tick overwrites them
+        if (active) pair_integrate_entity<INTEGRATOR>(P, SP, aux, pf, is_source, e, A, Fw);
+    }
+    if (active && n_ticks) store_entity(P, i, e, A, Fw);
+}
+
+hipError_t launch_pair_small(const PairParams& p, int integrator, uint32_t n_ticks, hipStream_t stream,
+                             uint64_t* launches) {
+    if (p.n == 0 || n_ticks == 0) return hipSuccess;
+    if (integrator == kRk4) hipLaunchKernelGGL(pair_small_kernel<kRk4>, dim3(1), dim3(kTile), 0, stream, p, n_ticks);
+    else hipLaunchKernelGGL(pair_small_kernel<kSemiImplicit>, dim3(1), dim3(kTile), 0, stream, p, n_ticks);
+    if (launches) *launches += 1;
+    return hipGetLastError();
 }
 
 hipError_t launch_pair_tick(const PairParams& p, int integrator, hipStream_t stream, uint64_t* launches) {

@@ -902,9 +902,20 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
         PairParams P;
         int rc = fill_pair_params(h, &P);
         if (rc != SIXDOF_OK) return rc;
-        for (uint64_t t = 0; t < n_ticks; t++) {
-            hipError_t e = launch_pair_tick(P, h->desc.integrator, h->stream, &launches);
-            if (e != hipSuccess) return h->hip_fail(e, "launch_pair_tick");
+        const char* no_small = std::getenv("SIXDOF_PAIR_SMALL");   // "0": force the three-kernel path (tests)
+        if (P.n <= kPairSmallMax && !(no_small && no_small[0] == '0')) {   // small graphs: ticks_per_launch ticks per launch
+            const uint32_t K = h->desc.ticks_per_launch;
+            for (uint64_t done = 0; done < n_ticks;) {
+                const uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(K, n_ticks - done));
+                hipError_t e = launch_pair_small(P, h->desc.integrator, k, h->stream, &launches);
+                if (e != hipSuccess) return h->hip_fail(e, "launch_pair_small");
+                done += k;
+            }
+        } else {
+            for (uint64_t t = 0; t < n_ticks; t++) {
+                hipError_t e = launch_pair_tick(P, h->desc.integrator, h->stream, &launches);
+                if (e != hipSuccess) return h->hip_fail(e, "launch_pair_tick");
+            }
         }
     } else {
         StepParams P;

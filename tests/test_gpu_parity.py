@@ -398,3 +398,36 @@ def test_streaming_path_at_2m_bodies():
         del os.environ["SIXDOF_STREAMING"]
     for f in parity.FIELDS:
         assert np.array_equal(getattr(hip, f), getattr(plain, f)), f
+
+
+@pytest.mark.parametrize("kind", ["three_body", "allpairs"])
+def test_small_graph_single_launch_path_is_bit_identical(kind):
+    """n <= 256: pack + fold + integrate (and ticks_per_launch ticks) in one single-workgroup launch; must equal the
+    three-kernel path bit for bit."""
+    import os
+    if kind == "three_body":
+        g = gu.load("three_body")
+        pos = np.stack([g[f"{e}.world_pos"][0] for e in "abc"])
+        vel = np.stack([g[f"{e}.world_vel"][0] for e in "abc"])
+        inertia = np.stack([g[f"{e}.inertia"][0] for e in "abc"])
+        kw = dict(entity_ids=[1, 2, 3], simulation_time_step=0.008333333,
+                  effectors=[ea.Effector(L.EFF_EDGE_GRAVITY_NEWTON, (G_NEWTON,))],
+                  edges=(np.array([1, 2, 1, 2, 3, 3], dtype=np.uint64), np.array([2, 1, 3, 3, 1, 2], dtype=np.uint64)))
+    else:
+        pos, vel, inertia = _plummer(200, seed=5)
+        kw = dict(simulation_time_step=3600.0, effectors=[ea.Effector(L.EFF_ALLPAIRS_GRAVITY_SOFTENED, (K_SQ, EPS_AU2))])
+    runs = {}
+    for label, env, k in (("three_kernels", "0", 1), ("small_k1", None, 1), ("small_k16", None, 16)):
+        if env is not None:
+            os.environ["SIXDOF_PAIR_SMALL"] = env
+        try:
+            ex = ea.HipExec(pos, vel, inertia, ticks_per_launch=k, **kw)
+            t = ex.run(100)
+        finally:
+            os.environ.pop("SIXDOF_PAIR_SMALL", None)
+        runs[label] = (ex, t.launches)
+    assert runs["three_kernels"][1] == 300 and runs["small_k1"][1] == 100 and runs["small_k16"][1] == 7
+    for f in parity.FIELDS:
+        a = getattr(runs["three_kernels"][0], f)
+        assert np.array_equal(a, getattr(runs["small_k1"][0], f)), f
+        assert np.array_equal(a, getattr(runs["small_k16"][0], f)), f
