@@ -89,6 +89,8 @@ SYMBOLS = {
     "sixdof_stream": (C.c_void_p, [_H]),
     "sixdof_tick_bind": (C.c_int, [_H]),
     "sixdof_tick": (None, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "sixdof_count_nonfinite": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_void_p]),
+    "sixdof_last_timings": (C.c_int, [_H, C.POINTER(Timings)]),
     "sixdof_world_create": (C.c_void_p, []),
     "sixdof_world_destroy": (None, [C.c_void_p]),
     "sixdof_world_last_error": (C.c_char_p, [C.c_void_p]),

@@ -283,6 +283,8 @@ class World:
     def build(self, system: System, simulation_rate: float = 120.0, telemetry_rate: Optional[float] = None,
               device: int = 0, backend: str = "hip") -> "Exec":
         """World.build (world_builder.rs:1737-1780): validate rates, fix globals, bind the backend."""
+        import os
+        backend = os.environ.get("ELODIN_BACKEND", backend)    # same override as world_builder.rs:248
         if backend != "hip":
             raise ValueError(f"unknown backend {backend!r}: this package provides 'hip' only")
         if telemetry_rate is not None and telemetry_rate <= 0.0:
@@ -381,7 +383,7 @@ class Exec:
         return self._hip.entity_ids
 
     def profile(self) -> Dict[str, float]:
-        t = self._last   # metric names of profile.rs:14-59
+        t = self._hip.last_timings()   # metric names of profile.rs:14-59
         tick_ms = t.kernel_invoke_ms / max(1, t.ticks)
         rtf = (self._dt * 1e3) / tick_ms if tick_ms > 0 else float("inf")   # real_time_factor, profile.rs:55
         return {"kernel_invoke": t.kernel_invoke_ms, "h2d_upload": t.h2d_upload_ms, "d2h_download": t.d2h_download_ms,

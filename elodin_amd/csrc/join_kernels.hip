@@ -47,4 +47,28 @@ hipError_t launch_scatter_rows(void* dst, const void* src, const uint32_t* rows,
     return hipGetLastError();
 }
 
+// ---- failure sentinel: rows whose pose or velocity is no longer finite ------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void nonfinite_kernel(const T* __restrict__ pos, const T* __restrict__ vel, uint32_t n,
+                                                        uint8_t* __restrict__ flags, unsigned long long* __restrict__ count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        for (int c = 0; c < 7; c++) bad |= !isfinite(pos[(size_t)i * 7 + c]);
+        for (int c = 0; c < 6; c++) bad |= !isfinite(vel[(size_t)i * 6 + c]);
+        if (flags) flags[i] = bad ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(bad);   // 64-lane wave: one atomic per wave
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+
+hipError_t launch_nonfinite(const void* pos, const void* vel, uint32_t n, size_t elem, uint8_t* flags,
+                            unsigned long long* count, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const dim3 grid((n + 255) / 256);
+    if (elem == 8) hipLaunchKernelGGL(nonfinite_kernel<double>, grid, dim3(256), 0, s, (const double*)pos, (const double*)vel, n, flags, count);
+    else hipLaunchKernelGGL(nonfinite_kernel<float>, grid, dim3(256), 0, s, (const float*)pos, (const float*)vel, n, flags, count);
+    return hipGetLastError();
+}
+
 }  // namespace sixdof

@@ -94,6 +94,9 @@ hipError_t launch_gather_rows(void* dst, const void* src, const uint32_t* rows, 
 hipError_t launch_scatter_rows(void* dst, const void* src, const uint32_t* rows, uint32_t m, uint32_t w, size_t elem,
                                hipStream_t s);
 
+hipError_t launch_nonfinite(const void* pos, const void* vel, uint32_t n, size_t elem, uint8_t* flags,
+                            unsigned long long* count, hipStream_t s);
+
 // ---- Apollo-lander rollout model (include/sixdof_apollo.h) ---------------------------------------------
 struct ApolloParams {
     double *pos, *vel, *accel, *force, *inertia;  // Body columns

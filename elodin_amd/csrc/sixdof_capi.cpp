@@ -82,6 +82,7 @@ struct sixdof_handle {
     bool identity_join = true;         // every Body column already is the joined set (query.rs:673,702 fast path)
     uint64_t tick = 0;
     bool bound = false;
+    sixdof_timings last{};   // most recent upload / step / download
     // run-time generated effector pipe
     void* custom_dl = nullptr;
     CustomLaunchFn custom_launch = nullptr;
@@ -464,6 +465,7 @@ int sixdof_upload(sixdof_handle* h) {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "upload: no columns bound");
     HIP_TRY(h, hipSetDevice(h->device));
+    const double t_up = now_ms();
     for (auto& kv : h->cols) {
         Column& c = kv.second;
         if (c.bytes) HIP_TRY(h, hipMemcpyAsync(c.dev, c.host, c.bytes, hipMemcpyHostToDevice, h->stream));
@@ -474,6 +476,7 @@ int sixdof_upload(sixdof_handle* h) {
         }
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->last.h2d_upload_ms = now_ms() - t_up;
     return SIXDOF_OK;
 }
 
@@ -491,6 +494,7 @@ int sixdof_download(sixdof_handle* h, uint32_t mask) {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "download: no columns bound");
     HIP_TRY(h, hipSetDevice(h->device));
+    const double t_dn = now_ms();
     const struct { uint32_t bit; uint64_t id; } sel[5] = {{SIXDOF_COL_WORLD_POS, h->id_pos},
                                                         {SIXDOF_COL_WORLD_VEL, h->id_vel},
                                                         {SIXDOF_COL_WORLD_ACCEL, h->id_accel},
@@ -505,6 +509,7 @@ int sixdof_download(sixdof_handle* h, uint32_t mask) {
         if (c->bytes) HIP_TRY(h, hipMemcpyAsync(c->host, c->dev, c->bytes, hipMemcpyDeviceToHost, h->stream));
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->last.d2h_download_ms = now_ms() - t_dn;
     return SIXDOF_OK;
 }
 
@@ -798,6 +803,35 @@ int sixdof_set_model_apollo(sixdof_handle* h, const sixdof_apollo_tables* t) {
     return SIXDOF_OK;
 }
 
+int sixdof_last_timings(const sixdof_handle* h, sixdof_timings* out) {
+    if (!h || !out) return SIXDOF_ERR_INVALID_ARGUMENT;
+    *out = h->last;
+    return SIXDOF_OK;
+}
+
+int sixdof_count_nonfinite(sixdof_handle* h, uint64_t* count, uint8_t* row_flags) {
+    if (!h || !count) return SIXDOF_ERR_INVALID_ARGUMENT;
+    if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "count_nonfinite: no columns bound");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const uint32_t n = static_cast<uint32_t>(h->desc.n_entities);
+    unsigned long long* d_count = nullptr;
+    uint8_t* d_flags = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&d_count), sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_count, 0, sizeof(unsigned long long), h->stream);
+    if (e == hipSuccess && row_flags && n) e = hipMalloc(reinterpret_cast<void**>(&d_flags), n);
+    if (e == hipSuccess)
+        e = launch_nonfinite(h->col(h->id_pos)->live, h->col(h->id_vel)->live, n, h->elem_size(), d_flags, d_count, h->stream);
+    unsigned long long host_count = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&host_count, d_count, sizeof(host_count), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && d_flags) e = hipMemcpyAsync(row_flags, d_flags, n, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d_count);
+    if (d_flags) hipFree(d_flags);
+    if (e != hipSuccess) return h->hip_fail(e, "count_nonfinite");
+    *count = host_count;
+    return SIXDOF_OK;
+}
+
 int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t* aux_ids, size_t n_aux) {
     if (!h || !so_path || (!aux_ids && n_aux)) return SIXDOF_ERR_INVALID_ARGUMENT;
     void* dl = dlopen(so_path, RTLD_NOW | RTLD_LOCAL);
@@ -991,13 +1025,19 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->tick += n_ticks;  // increment_sim_tick (globals.rs:42-44), once per tick
+    {
+        float ms0 = 0.f;
+        hipEventElapsedTime(&ms0, h->ev0, h->ev1);
+        h->last.kernel_device_ms = ms0;
+        h->last.kernel_invoke_ms = now_ms() - t0;
+        h->last.launches = launches;
+        h->last.ticks = n_ticks;
+    }
     if (tm) {
-        float ms = 0.f;
-        hipEventElapsedTime(&ms, h->ev0, h->ev1);
-        tm->h2d_upload_ms = 0.0;
-        tm->d2h_download_ms = 0.0;
-        tm->kernel_device_ms = ms;
-        tm->kernel_invoke_ms = now_ms() - t0;
+        tm->h2d_upload_ms = h->last.h2d_upload_ms;
+        tm->d2h_download_ms = h->last.d2h_download_ms;
+        tm->kernel_device_ms = h->last.kernel_device_ms;
+        tm->kernel_invoke_ms = h->last.kernel_invoke_ms;
         tm->launches = launches;
         tm->ticks = n_ticks;
         tm->kernel_sum_ms = 0.0;

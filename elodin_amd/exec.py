@@ -205,6 +205,38 @@ class HipExec:
         if rc != L.OK:
             _raise(self._h, rc, "sixdof_set_ticks_per_launch")
 
+    def nonfinite_rows(self) -> np.ndarray:
+        """Failure sentinel: boolean [n], True where a row's world_pos / world_vel holds NaN or Inf."""
+        flags = np.zeros(self.n, dtype=np.uint8)
+        cnt = C.c_uint64()
+        rc = self._lib.sixdof_count_nonfinite(self._h, C.byref(cnt), flags.ctypes.data)
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_count_nonfinite")
+        assert int(cnt.value) == int(flags.sum())
+        return flags.astype(bool)
+
+    def checkpoint(self) -> dict:
+        """Sim state = the Body columns + tick (World is `Serialize` in the reference, world.rs:41-46)."""
+        self.download()
+        state = {k: getattr(self, k).copy() for k in ("world_pos", "world_vel", "world_accel", "force", "inertia")}
+        state.update({f"aux:{k}": v.copy() for k, v in self._aux.items()})
+        state["tick"] = self.tick
+        return state
+
+    def restore(self, state: dict):
+        for k in ("world_pos", "world_vel", "world_accel", "force", "inertia"):
+            getattr(self, k)[...] = state[k]
+        for k, v in self._aux.items():
+            v[...] = state[f"aux:{k}"]
+        self._lib.sixdof_set_tick(self._h, int(state["tick"]))
+        self.upload()
+
+    def last_timings(self) -> TickTimings:
+        t = L.Timings()
+        self._lib.sixdof_last_timings(self._h, C.byref(t))
+        return TickTimings(t.h2d_upload_ms, t.kernel_invoke_ms, t.d2h_download_ms, t.kernel_device_ms,
+                           int(t.launches), int(t.ticks), t.kernel_sum_ms)
+
     def enable_history(self, ring_ticks: int):
         """Record every tick's world_pos/world_vel/world_accel/force in a device ring (sixdof_set_history)."""
         rc = self._lib.sixdof_set_history(self._h, int(ring_ticks))

@@ -208,6 +208,14 @@ void sixdof_tick(const uint8_t* const* inputs, uint8_t* const* outputs);
 int sixdof_tick_slots(const sixdof_handle* h, sixdof_slot* inputs, size_t in_cap, size_t* n_in,
                       sixdof_slot* outputs, size_t out_cap, size_t* n_out);
 
+/* ---- health / profiling ------------------------------------------------------------------------------------------
+ * Per-rollout failure sentinel (a campaign's replacement for "the sim process exited non-zero",
+ * libs/monte-carlo/src/lib.rs:2083-2379): counts joined rows whose world_pos or world_vel holds a NaN/Inf and,
+ * if `row_flags` is non-NULL, writes one byte per joined row (1 = non-finite). */
+int sixdof_count_nonfinite(sixdof_handle* h, uint64_t* count, uint8_t* row_flags /* [n] or NULL */);
+/* Timings of the most recent upload / step / download (profile.rs:14-59 phases). */
+int sixdof_last_timings(const sixdof_handle* h, sixdof_timings* out);
+
 /* ---- host-side ECS column store: the `World` of libs/nox-py/src/world.rs:23-45,174-229 ---------------------------
  * Per component a growing row-major buffer + the entity id of each row, rows in spawn order, ids sequential,
  * entity 0 = "Globals" (tick u64, simulation_time_step f64).  Pure host code: needs no GPU. */

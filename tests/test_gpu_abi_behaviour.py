@@ -142,3 +142,28 @@ def test_c_world_bound_to_a_handle_end_to_end():
     assert t.value == 120 == lib.sixdof_world_tick(w)
     lib.sixdof_destroy(h)
     lib.sixdof_world_destroy(w)
+
+
+def test_failure_sentinel_checkpoint_and_timings():
+    w = workloads.independent_bodies(1000)
+    eff = workloads.gravity_torque_effectors(w["body_torque"])
+    inertia = w["inertia"].copy()
+    inertia[[7, 500], 6] = 0.0                      # zero mass -> f/m = inf -> the rollout "crashes"
+    ex = ea.HipExec(w["world_pos"], w["world_vel"], inertia, simulation_time_step=workloads.DT_120HZ, effectors=eff)
+    assert not ex.nonfinite_rows().any()
+    ex.run(3)
+    bad = ex.nonfinite_rows()
+    assert bad.sum() == 2 and bad[7] and bad[500]                          # only the broken rollouts are flagged
+    assert np.isfinite(ex.world_pos[~bad]).all()
+    # checkpoint / resume: 50 + 50 ticks == 100 ticks
+    a = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ, effectors=eff)
+    a.run(50)
+    state = a.checkpoint()
+    b = ea.HipExec(w["world_pos"] * 0 + [0, 0, 0, 1, 0, 0, 0], w["world_vel"] * 0, w["inertia"],
+                   simulation_time_step=workloads.DT_120HZ, effectors=eff)
+    b.restore(state)
+    a.run(50)
+    b.run(50)
+    assert b.tick == 100 and all(np.array_equal(getattr(a, f), getattr(b, f)) for f in parity.FIELDS)
+    t = a.last_timings()                                                   # profile.rs phases
+    assert t.h2d_upload_ms > 0 and t.d2h_download_ms > 0 and t.kernel_invoke_ms > 0 and t.ticks == 50
