@@ -38,3 +38,19 @@ def test_nbody_example_small():
 def test_apollo_campaign_example():
     res = _load("apollo_campaign").main(256)
     assert res.shape == (256, 12) and res[:, 8].mean() == 1.0 and res[:, 9].mean() > 0.6
+
+
+def test_plain_c_host_over_the_abi(tmp_path):
+    """examples/c_host.c: gcc-built host, no Python in the loop; its output must match the reference's golden row."""
+    import subprocess
+    from tests import golden_util as gu
+    root = EX.parent
+    exe = tmp_path / "c_host"
+    subprocess.run(["gcc", "-O2", f"-I{root / 'include'}", str(EX / "c_host.c"), f"-L{root / 'elodin_amd'}", "-lsixdof_hip",
+                    f"-Wl,-rpath,{root / 'elodin_amd'}", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe), "100"], check=True, capture_output=True, text=True).stdout.splitlines()
+    g = gu.load("three_body")
+    for line, e in zip(out[:3], "abc"):
+        got = np.array([float(x) for x in line.split()[2:]])
+        assert np.allclose(got, g[f"{e}.world_pos"][100][4:], rtol=1e-9, atol=1e-12)
+    assert out[3].startswith("tick 100, 10 launches")
