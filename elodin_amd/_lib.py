@@ -107,6 +107,7 @@ SYMBOLS = {
     "sixdof_world_advance_tick": (None, [C.c_void_p, C.c_uint64]),
     "sixdof_bind_world": (C.c_int, [_H, C.c_void_p]),
     "sixdof_set_custom_pipe": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_uint64), C.c_size_t]),
+    "sixdof_set_custom_pair": (C.c_int, [_H, C.c_char_p]),
     "sixdof_set_history": (C.c_int, [_H, C.c_uint32]),
     "sixdof_history_read": (C.c_int, [_H, C.c_uint64, C.c_uint64, C.c_void_p]),
     "sixdof_set_model_apollo": (C.c_int, [_H, C.c_void_p]),

@@ -156,7 +156,10 @@ class Effectors:
     ops: List[Effector] = field(default_factory=list)
     edge_component: Optional[str] = None
 
-    def __or__(self, other: "Effectors") -> "Effectors":
+    def __or__(self, other) -> "Effectors":
+        from . import dsl as _dsl
+        if isinstance(other, _dsl.EdgeFold):     # user-written fold function closes the pipe
+            return Effectors(self.ops + [other], other.edge_component)
         return Effectors(self.ops + other.ops, other.edge_component or self.edge_component)
 
 
@@ -215,6 +218,8 @@ def six_dof(time_step: Optional[float] = None, sys=None, integrator: Integrator 
     from . import dsl as _dsl
     if isinstance(sys, _dsl.Effector):
         sys = _dsl.pipe(sys)
+    if isinstance(sys, _dsl.EdgeFold):
+        sys = Effectors([sys], sys.edge_component)
     return System(time_step, sys if sys is not None else Effectors(), integrator)
 
 
@@ -332,7 +337,7 @@ class World:
                 extra_columns[name] = arr
         else:
             for e in system.effectors.ops:
-                if e.aux_name is not None:
+                if not isinstance(e, _dsl.EdgeFold) and e.aux_name is not None:
                     arr, aids = self.column(e.aux_name)
                     column_ids[e.aux_name] = aids
                     e = Effector(e.kind, e.p, e.aux_name, arr)

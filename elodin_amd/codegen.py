@@ -276,9 +276,58 @@ extern "C" int sixdof_custom_launch(const sixdof::StepParams* p, int integrator,
 '''
 
 
+_PAIR_LEAVES = {**{f"acc{k}": f"acc[{k}]" for k in range(6)},
+                "ax": "pa[0]", "ay": "pa[1]", "az": "pa[2]", "ma": "ma",
+                "bx": "pb[0]", "by": "pb[1]", "bz": "pb[2]", "mb": "mb"}
+
+
+def generate_pair_source(tf: "dsl.TracedFold") -> str:
+    """A user-written edge_fold function as the PAIR functor of csrc/pair_kernel.hpp (f64, both integrators)."""
+    _TABLES.clear()
+    body = "\n".join(emit_block([(f"acc[{k}]", e) for k, e in enumerate(tf.outputs)], _PAIR_LEAVES))
+    tables = _emit_tables()
+    return f'''// generated by elodin_amd/codegen.py — do not edit.  edge_fold function: {tf.fold.__name__}
+#include "pair_kernel.hpp"
+
+namespace sixdof {{
+
+{_PRELUDE}
+{tables}
+
+struct PairCustom {{
+    __device__ static __forceinline__ void fold(double (&acc)[6], const double* pa, double ma, const double* pb,
+                                                double mb, double, double) {{
+        using T = double;
+        (void)pa; (void)ma; (void)pb; (void)mb;
+{body}
+    }}
+}};
+
+}}  // namespace sixdof
+
+extern "C" unsigned sixdof_custom_pair_abi() {{ return static_cast<unsigned>(sizeof(sixdof::PairParams)); }}
+
+extern "C" int sixdof_custom_pair_launch(const sixdof::PairParams* p, int integrator, uint32_t n_ticks, int small,
+                                         void* stream, uint64_t* launches) {{
+    using namespace sixdof;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (small) return static_cast<int>(launch_pair_small_t<PairCustom>(*p, integrator, n_ticks, s, launches));
+    for (uint32_t t = 0; t < n_ticks; t++) {{
+        const hipError_t e = launch_pair_tick_t<PairCustom, false>(*p, integrator, s, launches);
+        if (e != hipSuccess) return static_cast<int>(e);
+    }}
+    return static_cast<int>(hipSuccess);
+}}
+'''
+
+
+def build_pair(tf: "dsl.TracedFold") -> Path:
+    return _compile(generate_pair_source(tf), "pair")
+
+
 def _headers_digest() -> str:
     h = hashlib.sha1()
-    for name in ("step_kernel.hpp", "effectors.hpp", "spatial.hpp", "kernels.hpp"):
+    for name in ("step_kernel.hpp", "pair_kernel.hpp", "effectors.hpp", "spatial.hpp", "kernels.hpp"):
         h.update((CSRC / name).read_bytes())
     h.update((PKG.parent / "include" / "sixdof_hip.h").read_bytes())
     return h.hexdigest()
@@ -286,18 +335,21 @@ def _headers_digest() -> str:
 
 def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0) -> Path:
     """Generate + compile (cached by content hash).  Returns the .so path."""
-    src = generate_source(tp, dtype, integrator)
+    return _compile(generate_source(tp, dtype, integrator), "pipe")
+
+
+def _compile(src: str, stem: str) -> Path:
     digest = hashlib.sha1((src + _headers_digest()).encode()).hexdigest()[:16]
     JIT_DIR.mkdir(exist_ok=True)
-    so = JIT_DIR / f"pipe_{digest}.so"
+    so = JIT_DIR / f"{stem}_{digest}.so"
     if so.exists():
         return so
-    hip = JIT_DIR / f"pipe_{digest}.hip"
+    hip = JIT_DIR / f"{stem}_{digest}.hip"
     hip.write_text(src)
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
            f"-I{CSRC}", str(hip), "-o", str(so) + ".tmp"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed for generated pipe {hip}:\n{res.stderr[-4000:]}")
+        raise RuntimeError(f"hipcc failed for generated code {hip}:\n{res.stderr[-4000:]}")
     os.replace(str(so) + ".tmp", so)
     return so

@@ -58,7 +58,8 @@ using CustomLaunchFn = int (*)(const StepParams*, int integrator, int dtype, voi
 // ---- pairwise (edge_fold) path -----------------------------------------------------------------------
 // One tick = pack -> accumulate -> integrate (3 launches).  See nbody_kernels.hip.
 constexpr int kPackWidth = 10;   // per source: p(c=0) p(c=1/2) p(c=1) mass
-constexpr int kPartialWidth = 9; // per target and source split: 3 stage positions x 3 force components
+constexpr int kPartialForce = 9;  // all-pairs gravity writes forces only
+constexpr int kPartialWidth = 18; // per target and source split: 3 stage positions x Force [tau(3), f(3)]
 
 struct PairParams {
     void* pos;            // [n,7]
@@ -69,8 +70,9 @@ struct PairParams {
     uint32_t n;
     double dt_g, dt;
     double* pack;         // [n,10] scratch
-    double* partial;      // [splits,n,9] scratch
+    double* partial;      // [splits,n,partial_width] scratch
     uint32_t splits;      // source-range splits of the all-pairs kernel (1 for edge lists)
+    uint32_t partial_width;  // kPartialForce (all-pairs: 3 stages x force) or kPartialWidth (3 stages x [tau, f])
     // edge list in CSR-by-source form (spawn order preserved inside a source), device
     const uint32_t* row_start;  // [n+1]
     const uint32_t* dst;        // [n_edges]
@@ -87,6 +89,10 @@ hipError_t launch_pair_tick(const PairParams& p, int integrator, hipStream_t str
 constexpr uint32_t kPairSmallMax = 256;
 hipError_t launch_pair_small(const PairParams& p, int integrator, uint32_t n_ticks, hipStream_t stream,
                              uint64_t* launches);
+// Entry points of a generated pair-fold translation unit (codegen.py: generate_pair_source).
+using CustomPairAbiFn = unsigned (*)();
+using CustomPairLaunchFn = int (*)(const PairParams* p, int integrator, uint32_t n_ticks, int small, void* stream,
+                                   uint64_t* launches);
 
 // ---- joins (query.rs:599-725): gather / scatter of rows by constant u32 indices -----------------------------
 hipError_t launch_gather_rows(void* dst, const void* src, const uint32_t* rows, uint32_t m, uint32_t w, size_t elem,

@@ -1,417 +1,21 @@
-// nbody_kernels.hip — pairwise (GraphQuery.edge_fold) effectors for gfx950: all-pairs and edge-list gravity.
-//
-// Reference semantics (libs/nox-py/src/graph.rs:239-361, python twin elodin/__init__.py:454-557): for
-// every source entity, a sequential left fold over its out-edges in spawn order,
-//     acc = f(acc, source components, target components),
-// whose result REPLACES `Force` on the source rows; it runs inside the six_dof pipe, i.e. on every
-// RK4 stage.  The reference materialises gathered operands [S, D, dim] — O(N^2) memory for a
-// complete graph — which is why its n-body example stops at 35 bodies.
-//
-// What this file does instead.  The reference's RK4 advances stage POSITIONS with the initial
-// velocity only (rk4.rs:95-121: x_s = x0 (+) c*dt*v0), and gravity reads positions and masses only,
-// so all stage forces of a tick are known from (x0, v0) before any acceleration is: F(c=0),
-// F(c=1/2) (shared by stages 1 and 2, bit-identical) and F(c=1).  One tick is therefore
-//   1. pair_pack_kernel      per source: p(c=0), p(c=1/2), p(c=1), mass -> pack[n,10]
-//   2. allpairs_kernel       LDS-tiled all-pairs: every (target, source) pair is visited ONCE and
-//      / edge_kernel         accumulates the three stage forces together (3 independent FMA chains)
-//   3. pair_integrate_kernel per entity: reduce the source splits in fixed order, calc_accel on each
-//                            stage, RK4 combination, write pos / vel / accel / force.
-// instead of four dependent all-pairs sweeps.  Bound: f64 vector ALU (about 21 instructions per pair
-// evaluation, of which one v_rsq_f64 + refinement); bytes are negligible.  MFMA is not used: gfx950's
-// f64 MFMA rate equals its f64 vector rate, and the |ri|^2+|rj|^2-2 ri.rj form a dense tile would
-// need cancels catastrophically for close pairs, breaking the 1e-9 parity bar.
-//
-// Summation order: the reference folds each source's targets sequentially; here a target range is
-// split over `splits` workgroup columns (partials reduced in fixed split order) — a different
-// association of the same sum (~1e-16 * sqrt(N) relative), deterministic run to run.
-#include "effectors.hpp"
-#include "kernels.hpp"
-#include "spatial.hpp"
+// nbody_kernels.hip — built-in pairwise gravity folds (kernels: pair_kernel.hpp).
+#include "pair_kernel.hpp"
 
 namespace sixdof {
 
-constexpr int kTile = 256;  // sources staged per LDS tile = targets per workgroup
-
-// 1/sqrt(x) for x > 0 finite: hardware v_rsq_f64 seed plus one cubic correction
-// (y0 (1 + e/2 + 3e^2/8), e = 1 - x y0^2), full f64 accuracy without the 0/inf special-casing of the
-// library rsqrt.  x = 0 only occurs for the self pair with eps = 0, whose contribution is discarded.
-__device__ __forceinline__ double rsqrt_pos(double x) {
-    const double y0 = __builtin_amdgcn_rsq(x);
-    const double e = fma(-x * y0, y0, 1.0);
-    return fma(y0 * e, fma(e, 0.375, 0.5), y0);
-}
-
-uint32_t pair_splits_for(uint32_t n) {
-    const uint32_t tblocks = (n + kTile - 1) / kTile;
-    if (tblocks == 0) return 1;
-    uint32_t s = (1024 + tblocks - 1) / tblocks;  // aim for >= 4 workgroups per CU
-    if (s > tblocks) s = tblocks;                 // at least one tile per split
-    return s ? s : 1;
-}
-
-// ---- 1. pack ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pair_pack_kernel(const double* __restrict__ pos, const double* __restrict__ vel,
-                                                        const double* __restrict__ inertia, double* __restrict__ pack,
-                                                        uint32_t n, double h1, double h3) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const double* x = pos + (size_t)j * 7 + 4;
-    const double* v = vel + (size_t)j * 6 + 3;
-    double* o = pack + (size_t)j * kPackWidth;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        o[c] = x[c];
-        o[3 + c] = x[c] + h1 * v[c];  // linear half of SpatialTransform + SpatialMotion (spatial.rs:546)
-        o[6 + c] = x[c] + h3 * v[c];
-    }
-    o[9] = inertia[(size_t)j * 7 + 6];
-}
-
-// ---- 2a. all-pairs, softened (examples/n-body/sim.py:344-369) -------------------------------------------
-// acc_s += mb * inv3 * r with r = pb - pa, inv = rsqrt(r.r + eps); the common factor K*ma is applied
-// once per target at the end (the reference applies it per pair: ((K*ma)*mb)*inv3).
-template <int NS, bool CHECK_SELF>
-__device__ __forceinline__ void tile_accumulate(const double* __restrict__ tile, int count, uint32_t j0, uint32_t i,
-                                                const double (&pi)[3][3], double eps, double (&acc)[3][3]) {
-#pragma unroll 2
-    for (int jj = 0; jj < count; jj++) {
-        const double* s = tile + jj * kPackWidth;  // same address in every lane: LDS broadcast
-        const double mj = s[9];
-#pragma unroll
-        for (int st = 0; st < NS; st++) {
-            const double rx = s[3 * st + 0] - pi[st][0];
-            const double ry = s[3 * st + 1] - pi[st][1];
-            const double rz = s[3 * st + 2] - pi[st][2];
-            const double d2 = fma(rz, rz, fma(ry, ry, fma(rx, rx, eps)));
-            const double inv = rsqrt_pos(d2);
-            double sc = mj * (inv * inv * inv);
-            if (CHECK_SELF) sc = (j0 + jj == i) ? 0.0 : sc;  // i == j is not an edge (sim.py:333-337)
-            acc[st][0] = fma(sc, rx, acc[st][0]);
-            acc[st][1] = fma(sc, ry, acc[st][1]);
-            acc[st][2] = fma(sc, rz, acc[st][2]);
-        }
-    }
-}
-
-template <int NS>
-__global__ __launch_bounds__(kTile) void allpairs_kernel(const double* __restrict__ pack, double* __restrict__ partial,
-                                                         uint32_t n, uint32_t splits, double K, double eps) {
-    __shared__ __attribute__((aligned(16))) double tile[kTile * kPackWidth];
-    const uint32_t i = blockIdx.x * kTile + threadIdx.x;
-    const uint32_t split = blockIdx.y;
-    const uint32_t tiles_total = (n + kTile - 1) / kTile;
-    const uint32_t tiles_per_split = (tiles_total + splits - 1) / splits;
-    const uint32_t tile_lo = split * tiles_per_split;
-    const uint32_t tile_hi = min(tiles_total, tile_lo + tiles_per_split);
-
-    double pi[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    double mi = 0.0;
-    if (i < n) {
-        const double* s = pack + (size_t)i * kPackWidth;
-#pragma unroll
-        for (int st = 0; st < NS; st++)
-            for (int c = 0; c < 3; c++) pi[st][c] = s[3 * st + c];
-        mi = s[9];
-    }
-    double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    for (uint32_t tl = tile_lo; tl < tile_hi; tl++) {
-        const uint32_t j0 = tl * kTile;
-        const int count = (int)min((uint32_t)kTile, n - j0);
-        __syncthreads();
-        {   // contiguous slab of count*10 doubles, 16 B per lane per iteration
-            const double2* g = reinterpret_cast<const double2*>(pack + (size_t)j0 * kPackWidth);
-            double2* l = reinterpret_cast<double2*>(tile);
-            for (int c = threadIdx.x; c < count * (kPackWidth / 2); c += kTile) l[c] = g[c];
-        }
-        __syncthreads();
-        if (tl == blockIdx.x) tile_accumulate<NS, true>(tile, count, j0, i, pi, eps, acc);
-        else tile_accumulate<NS, false>(tile, count, j0, i, pi, eps, acc);
-    }
-    if (i < n) {
-        double* o = partial + ((size_t)split * n + i) * kPartialWidth;
-        const double kmi = K * mi;
-#pragma unroll
-        for (int st = 0; st < NS; st++)
-            for (int c = 0; c < 3; c++) o[3 * st + c] = kmi * acc[st][c];
-    }
-}
-
-// ---- 2b. explicit edge list, CSR by source (three-body and sparse graphs) ---------------------------------
-// One source's left fold over its out-edges (CSR range), spawn order, for the NS stage positions.
-template <int NS>
-__device__ __forceinline__ void edge_accumulate(const double* pack, const uint32_t* __restrict__ row_start,
-                                                const uint32_t* __restrict__ dst, uint32_t i, int kind, double p0,
-                                                double p1, double (&acc)[3][3]) {
-    const double* a = pack + (size_t)i * kPackWidth;
-    const double ma = a[9];
-    for (uint32_t e = row_start[i]; e < row_start[i + 1]; e++) {  // spawn order inside a source
-        const double* b = pack + (size_t)dst[e] * kPackWidth;
-        const double mb = b[9];
-#pragma unroll
-        for (int st = 0; st < NS; st++) {
-            if (kind == SIXDOF_EFF_EDGE_GRAVITY_NEWTON) {
-                // examples/three-body/main.py:61-70: r = a - b; f = G*M*m*r / |r|^3; acc -= f
-                const double rx = a[3 * st] - b[3 * st], ry = a[3 * st + 1] - b[3 * st + 1],
-                             rz = a[3 * st + 2] - b[3 * st + 2];
-                const double nrm = sqrt(rx * rx + ry * ry + rz * rz);
-                const double gmm = p0 * mb * ma;
-                const double den = nrm * nrm * nrm;
-                acc[st][0] -= gmm * rx / den;
-                acc[st][1] -= gmm * ry / den;
-                acc[st][2] -= gmm * rz / den;
-            } else {
-                // examples/n-body/sim.py:356-361
-                const double rx = b[3 * st] - a[3 * st], ry = b[3 * st + 1] - a[3 * st + 1],
-                             rz = b[3 * st + 2] - a[3 * st + 2];
-                const double d2 = (rx * rx + ry * ry + rz * rz) + p1;
-                const double inv = 1.0 / sqrt(d2);
-                const double sc = p0 * ma * mb * (inv * inv * inv);
-                acc[st][0] += sc * rx;
-                acc[st][1] += sc * ry;
-                acc[st][2] += sc * rz;
-            }
-        }
-    }
-}
-
-template <int NS>
-__global__ __launch_bounds__(256) void edge_kernel(const double* __restrict__ pack, double* __restrict__ partial,
-                                                   const uint32_t* __restrict__ row_start,
-                                                   const uint32_t* __restrict__ dst, uint32_t n, int kind, double p0,
-                                                   double p1) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    edge_accumulate<NS>(pack, row_start, dst, i, kind, p0, p1, acc);
-    double* o = partial + (size_t)i * kPartialWidth;
-#pragma unroll
-    for (int st = 0; st < NS; st++)
-        for (int c = 0; c < 3; c++) o[3 * st + c] = acc[st][c];
-}
-
-// ---- 3. integrate ---------------------------------------------------------------------------------------
-// Per-entity half of the tick: same stage structure as sixdof_step_kernel, with the pair forces
-// taken from `pf`.  Per-entity ops that precede the pair op in the pipe only survive on
-// rows that are not edge sources.
-struct EntityState {
-    Quat<double> q0;
-    Vec3<double> p0;
-    Spatial<double> v0;
-    Vec3<double> I, inv_I;
-    double mass, inv_m;
-};
-
-template <int INTEGRATOR>
-__device__ __forceinline__ void pair_integrate_entity(const PairParams& P, const StepParams& SP,
-                                                      const Vec3<double> (&aux)[kMaxOps], const double (&pf)[3][3],
-                                                      bool is_source, EntityState& e, Spatial<double>& A,
-                                                      Spatial<double>& Fw) {
-    using T = double;
-    using PIPE = PipeGeneric;
-    Quat<T>& q0 = e.q0;
-    Vec3<T>& p0 = e.p0;
-    Spatial<T>& v0 = e.v0;
-    const Vec3<T> inv_I = e.inv_I;
-    const T inv_m = e.inv_m;
-    Body<T> b;
-    b.mass = e.mass;
-    b.I = e.I;
-    Wrench<T> F;
-    auto stage_force = [&](int st) {
-        F = zero_wrench<T>();
-        if (P.n_ops) PIPE::apply(SP, aux, NoModel::Regs<T>{}, b, F);
-        if (is_source) {  // edge_fold output replaces Force; el.Force(linear=...) carries zero torque
-            F = zero_wrench<T>();
-            F.f = Vec3<T>{pf[st][0], pf[st][1], pf[st][2]};
-        }
-    };
-    const T dt_g = P.dt_g, dt = P.dt;
-    if constexpr (INTEGRATOR == kRk4) {
-        const T h1 = dt_g * 0.5, h3 = dt_g;
-        Spatial<T> sv, sa;
-        b.q = normalized(q0); b.p = p0; b.v = v0;
-        stage_force(0);
-        A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
-        sv = v0; sa = A;
-        b.q = integrate_world(q0, h1 * v0.ang); b.p = axpy(h1, v0.lin, p0); b.v = axpy(h1, A, v0);
-        sv = axpy(T(2), b.v, sv);
-        stage_force(1);
-        A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
-        sa = axpy(T(2), A, sa);
-        b.v = axpy(h1, A, v0);
-        sv = axpy(T(2), b.v, sv);
-        stage_force(1);
-        A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
-        sa = axpy(T(2), A, sa);
-        b.q = integrate_world(q0, h3 * v0.ang); b.p = axpy(h3, v0.lin, p0); b.v = axpy(h3, A, v0);
-        sv = sv + b.v;
-        stage_force(2);
-        A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
-        sa = sa + A;
-        const T g = dt * T(1.0 / 6.0);
-        q0 = integrate_world(q0, g * sv.ang);
-        p0 = axpy(g, sv.lin, p0);
-        v0 = axpy(g, sa, v0);
-    } else {
-        b.q = normalized(q0); b.p = p0; b.v = v0;
-        stage_force(0);
-        A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
-        v0 = axpy(dt, A, v0);
-        q0 = integrate_world(q0, dt * v0.ang);
-        p0 = axpy(dt, v0.lin, p0);
-    }
-    Fw = world_wrench<PIPE>(b.q, F);
-}
-
-__device__ __forceinline__ void load_entity(const PairParams& P, uint32_t i, EntityState& e, StepParams& SP,
-                                            Vec3<double> (&aux)[kMaxOps]) {
-    const double* pos = static_cast<const double*>(P.pos) + (size_t)i * 7;
-    const double* vel = static_cast<const double*>(P.vel) + (size_t)i * 6;
-    const double* in = static_cast<const double*>(P.inertia) + (size_t)i * 7;
-    e.q0 = {pos[0], pos[1], pos[2], pos[3]};
-    e.p0 = {pos[4], pos[5], pos[6]};
-    e.v0 = {{vel[0], vel[1], vel[2]}, {vel[3], vel[4], vel[5]}};
-    e.I = {in[0], in[1], in[2]};
-    e.inv_I = {1.0 / in[0], 1.0 / in[1], 1.0 / in[2]};
-    e.mass = in[6];
-    e.inv_m = 1.0 / in[6];
-    SP.n_ops = P.n_ops;   // view of the per-entity ops for the shared effector code
-    SP.vel_independent = 0;
-#pragma unroll
-    for (int k = 0; k < kMaxOps; k++) SP.ops[k] = P.ops[k];
-#pragma unroll
-    for (int k = 0; k < kMaxOps; k++) {
-        aux[k] = Vec3<double>{0, 0, 0};
-        if (k < (int)P.n_ops && P.ops[k].aux != nullptr) {
-            const double* a = static_cast<const double*>(P.ops[k].aux) + (size_t)i * 3;
-            aux[k] = Vec3<double>{a[0], a[1], a[2]};
-        }
-    }
-}
-
-__device__ __forceinline__ void store_entity(const PairParams& P, uint32_t i, const EntityState& e,
-                                             const Spatial<double>& A, const Spatial<double>& Fw) {
-    double* pos = static_cast<double*>(P.pos) + (size_t)i * 7;
-    double* vel = static_cast<double*>(P.vel) + (size_t)i * 6;
-    pos[0] = e.q0.i; pos[1] = e.q0.j; pos[2] = e.q0.k; pos[3] = e.q0.w; pos[4] = e.p0.x; pos[5] = e.p0.y; pos[6] = e.p0.z;
-    vel[0] = e.v0.ang.x; vel[1] = e.v0.ang.y; vel[2] = e.v0.ang.z;
-    vel[3] = e.v0.lin.x; vel[4] = e.v0.lin.y; vel[5] = e.v0.lin.z;
-    double* ac = static_cast<double*>(P.accel) + (size_t)i * 6;
-    ac[0] = A.ang.x; ac[1] = A.ang.y; ac[2] = A.ang.z; ac[3] = A.lin.x; ac[4] = A.lin.y; ac[5] = A.lin.z;
-    double* fo = static_cast<double*>(P.force) + (size_t)i * 6;
-    fo[0] = Fw.ang.x; fo[1] = Fw.ang.y; fo[2] = Fw.ang.z; fo[3] = Fw.lin.x; fo[4] = Fw.lin.y; fo[5] = Fw.lin.z;
-}
-
-template <int INTEGRATOR>
-__global__ __launch_bounds__(256) void pair_integrate_kernel(const PairParams P) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
-    EntityState e;
-    StepParams SP;
-    Vec3<double> aux[kMaxOps];
-    load_entity(P, i, e, SP, aux);
-    const bool is_source = P.pair_kind == SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED
-                               ? (P.n > 1)
-                               : (P.row_start[i + 1] > P.row_start[i]);
-    constexpr int NS = INTEGRATOR == kRk4 ? 3 : 1;
-    double pf[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    for (uint32_t s = 0; s < P.splits; s++) {  // fixed order: deterministic
-        const double* part = P.partial + ((size_t)s * P.n + i) * kPartialWidth;
-#pragma unroll
-        for (int st = 0; st < NS; st++)
-            for (int c = 0; c < 3; c++) pf[st][c] += part[3 * st + c];
-    }
-    Spatial<double> A, Fw;
-    pair_integrate_entity<INTEGRATOR>(P, SP, aux, pf, is_source, e, A, Fw);
-    store_entity(P, i, e, A, Fw);
-}
-
-// ---- small graphs: the whole tick (and n_ticks of them) in ONE single-workgroup launch --------------------------
-// Three-body / solar-system sized worlds (n <= 256) are launch-bound, not math-bound: pack, fold and integrate
-// run in one workgroup with the packed sources in LDS and the entity state in registers across ticks.  Same device
-// functions as the three-kernel path, so results are bit-identical to it.
-template <int INTEGRATOR>
-__global__ __launch_bounds__(kTile) void pair_small_kernel(const PairParams P, uint32_t n_ticks) {
-    __shared__ __attribute__((aligned(16))) double pack[kTile * kPackWidth];
-    constexpr int NS = INTEGRATOR == kRk4 ? 3 : 1;
-    const uint32_t i = threadIdx.x;
-    const bool active = i < P.n;
-    EntityState e;
-    StepParams SP;
-    Vec3<double> aux[kMaxOps];
-    if (active) load_entity(P, i, e, SP, aux);
-    const bool allpairs = P.pair_kind == SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED;
-    const bool is_source = active && (allpairs ? (P.n > 1) : (P.row_start[i + 1] > P.row_start[i]));
-    const double h1 = P.dt_g * 0.5, h3 = P.dt_g;
-    Spatial<double> A = {{0, 0, 0}, {0, 0, 0}}, Fw = {{0, 0, 0}, {0, 0, 0}};
-    for (uint32_t t = 0; t < n_ticks; t++) {
-        if (active) {
-            double* o = pack + i * kPackWidth;
-            const double x[3] = {e.p0.x, e.p0.y, e.p0.z}, v[3] = {e.v0.lin.x, e.v0.lin.y, e.v0.lin.z};
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                o[c] = x[c];
-                o[3 + c] = x[c] + h1 * v[c];
-                o[6 + c] = x[c] + h3 * v[c];
-            }
-            o[9] = e.mass;
-        }
-        __syncthreads();
-        double pf[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        if (active) {
-            double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-            if (allpairs) {
-                double pi[3][3];
-                const double* s = pack + i * kPackWidth;
-#pragma unroll
-                for (int st = 0; st < 3; st++)
-                    for (int c = 0; c < 3; c++) pi[st][c] = st < NS ? s[3 * st + c] : 0.0;
-                tile_accumulate<NS, true>(pack, (int)P.n, 0, i, pi, P.p1, acc);
-                const double kmi = P.p0 * e.mass;
-#pragma unroll
-                for (int st = 0; st < NS; st++)
-                    for (int c = 0; c < 3; c++) pf[st][c] += kmi * acc[st][c];
-            } else {
-                edge_accumulate<NS>(pack, P.row_start, P.dst, i, P.pair_kind, P.p0, P.p1, acc);
-#pragma unroll
-                for (int st = 0; st < NS; st++)
-                    for (int c = 0; c < 3; c++) pf[st][c] += acc[st][c];
-            }
-        }
-        __syncthreads();   // every lane has read the packed sources before the next tick overwrites them
-        if (active) pair_integrate_entity<INTEGRATOR>(P, SP, aux, pf, is_source, e, A, Fw);
-    }
-    if (active && n_ticks) store_entity(P, i, e, A, Fw);
-}
+uint32_t pair_splits_for(uint32_t n) { return pair_splits_for_n(n); }
 
 hipError_t launch_pair_small(const PairParams& p, int integrator, uint32_t n_ticks, hipStream_t stream,
                              uint64_t* launches) {
-    if (p.n == 0 || n_ticks == 0) return hipSuccess;
-    if (integrator == kRk4) hipLaunchKernelGGL(pair_small_kernel<kRk4>, dim3(1), dim3(kTile), 0, stream, p, n_ticks);
-    else hipLaunchKernelGGL(pair_small_kernel<kSemiImplicit>, dim3(1), dim3(kTile), 0, stream, p, n_ticks);
-    if (launches) *launches += 1;
-    return hipGetLastError();
+    // the complete-graph softened fold runs the tiled accumulate inside the small kernel too (PAIR unused there)
+    if (p.pair_kind == SIXDOF_EFF_EDGE_GRAVITY_NEWTON) return launch_pair_small_t<PairNewton>(p, integrator, n_ticks, stream, launches);
+    return launch_pair_small_t<PairSoftened>(p, integrator, n_ticks, stream, launches);
 }
 
 hipError_t launch_pair_tick(const PairParams& p, int integrator, hipStream_t stream, uint64_t* launches) {
-    if (p.n == 0) return hipSuccess;
-    const uint32_t blocks = (p.n + 255) / 256;
-    const double h1 = p.dt_g * 0.5, h3 = p.dt_g;
-    hipLaunchKernelGGL(pair_pack_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<const double*>(p.pos),
-                       static_cast<const double*>(p.vel), static_cast<const double*>(p.inertia), p.pack, p.n, h1, h3);
-    const bool rk4 = integrator == kRk4;
-    if (p.pair_kind == SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED) {
-        const dim3 grid((p.n + kTile - 1) / kTile, p.splits);
-        if (rk4) hipLaunchKernelGGL(allpairs_kernel<3>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1);
-        else hipLaunchKernelGGL(allpairs_kernel<1>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1);
-    } else {
-        if (rk4) hipLaunchKernelGGL(edge_kernel<3>, dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.pair_kind, p.p0, p.p1);
-        else hipLaunchKernelGGL(edge_kernel<1>, dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.pair_kind, p.p0, p.p1);
-    }
-    if (rk4) hipLaunchKernelGGL(pair_integrate_kernel<kRk4>, dim3(blocks), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(pair_integrate_kernel<kSemiImplicit>, dim3(blocks), dim3(256), 0, stream, p);
-    if (launches) *launches += 3;
-    return hipGetLastError();
+    if (p.pair_kind == SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED) return launch_pair_tick_t<PairSoftened, true>(p, integrator, stream, launches);
+    if (p.pair_kind == SIXDOF_EFF_EDGE_GRAVITY_NEWTON) return launch_pair_tick_t<PairNewton, false>(p, integrator, stream, launches);
+    return launch_pair_tick_t<PairSoftened, false>(p, integrator, stream, launches);
 }
 
 }  // namespace sixdof

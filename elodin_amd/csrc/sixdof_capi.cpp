@@ -86,6 +86,8 @@ struct sixdof_handle {
     // run-time generated effector pipe
     void* custom_dl = nullptr;
     CustomLaunchFn custom_launch = nullptr;
+    void* pair_dl = nullptr;               // generated edge_fold function (sixdof_set_custom_pair)
+    CustomPairLaunchFn pair_launch = nullptr;
     std::vector<uint64_t> custom_aux;      // read-only [n,1..3] columns of a generated effector pipe
     std::vector<uint64_t> custom_model;    // read/write [n,1..8] component columns of a generated program
     // telemetry ring
@@ -281,6 +283,7 @@ void sixdof_destroy(sixdof_handle* h) {
     if (h->d_tick_refs) hipFree(h->d_tick_refs);
     for (void* p : h->d_hist) if (p) hipFree(p);
     if (h->custom_dl) dlclose(h->custom_dl);
+    if (h->pair_dl) dlclose(h->pair_dl);
     for (hipEvent_t e : h->launch_events) hipEventDestroy(e);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -659,9 +662,11 @@ int fill_pair_params(sixdof_handle* h, PairParams* P) {
     const sixdof_effector_op& pop = h->ops.back();
     const uint32_t splits = pop.kind == SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED ? pair_splits_for(static_cast<uint32_t>(n)) : 1;
     (void)es;
-    // scratch layout: pack[n,10] | partial[splits,n,9]   (f64)
+    // scratch layout: pack[n,10] | partial[splits,n,width]   (f64)
+    const bool allpairs = pop.kind == SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED;
+    const size_t pwidth = allpairs ? kPartialForce : kPartialWidth;
     const size_t pack_bytes = align_up(sizeof(double) * kPackWidth * n, 256);
-    const size_t partial_bytes = align_up(sizeof(double) * kPartialWidth * n * splits, 256);
+    const size_t partial_bytes = align_up(sizeof(double) * pwidth * n * splits, 256);
     const size_t total = pack_bytes + partial_bytes;
     if (total > h->scratch_bytes) {
         if (h->d_scratch) hipFree(h->d_scratch), h->d_scratch = nullptr;
@@ -680,6 +685,7 @@ int fill_pair_params(sixdof_handle* h, PairParams* P) {
     P->pack = reinterpret_cast<double*>(base);
     P->partial = reinterpret_cast<double*>(base + pack_bytes);
     P->splits = splits;
+    P->partial_width = static_cast<uint32_t>(pwidth);
     P->pair_kind = pop.kind;
     P->p0 = pop.p[0];
     P->p1 = pop.p[1];
@@ -859,6 +865,28 @@ int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t
     return SIXDOF_OK;
 }
 
+int sixdof_set_custom_pair(sixdof_handle* h, const char* so_path) {
+    if (!h || !so_path) return SIXDOF_ERR_INVALID_ARGUMENT;
+    if (h->custom_launch) return h->fail(SIXDOF_ERR_UNSUPPORTED, "set_custom_pair: a generated per-entity pipe is installed; pair folds combine with built-in ops only");
+    void* dl = dlopen(so_path, RTLD_NOW | RTLD_LOCAL);
+    if (!dl) return h->fail(SIXDOF_ERR_BACKEND, std::string("set_custom_pair: dlopen failed: ") + dlerror());
+    auto abi = reinterpret_cast<CustomPairAbiFn>(dlsym(dl, "sixdof_custom_pair_abi"));
+    auto launch = reinterpret_cast<CustomPairLaunchFn>(dlsym(dl, "sixdof_custom_pair_launch"));
+    if (!abi || !launch || abi() != sizeof(PairParams)) {
+        dlclose(dl);
+        return h->fail(SIXDOF_ERR_BACKEND, "set_custom_pair: not a generated pair fold for this library build (PairParams layout differs)");
+    }
+    if (h->pair_dl) dlclose(h->pair_dl);
+    h->pair_dl = dl;
+    h->pair_launch = launch;
+    while (!h->ops.empty() && h->ops.back().kind >= SIXDOF_EFF_EDGE_GRAVITY_NEWTON) h->ops.pop_back();
+    sixdof_effector_op op{};
+    op.kind = SIXDOF_EFF_EDGE_CUSTOM;
+    h->ops.push_back(op);
+    h->drop_graph();
+    return SIXDOF_OK;
+}
+
 int sixdof_set_history(sixdof_handle* h, uint32_t ring_ticks) {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "set_history: bind Body columns first");
@@ -937,7 +965,17 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
         int rc = fill_pair_params(h, &P);
         if (rc != SIXDOF_OK) return rc;
         const char* no_small = std::getenv("SIXDOF_PAIR_SMALL");   // "0": force the three-kernel path (tests)
-        if (P.n <= kPairSmallMax && !(no_small && no_small[0] == '0')) {   // small graphs: ticks_per_launch ticks per launch
+        if (P.pair_kind == SIXDOF_EFF_EDGE_CUSTOM) {
+            if (!h->pair_launch) return h->fail(SIXDOF_ERR_BACKEND, "step: custom pair op without sixdof_set_custom_pair");
+            const bool small = P.n <= kPairSmallMax && !(no_small && no_small[0] == '0');
+            const uint32_t K = small ? h->desc.ticks_per_launch : 1u << 20;
+            for (uint64_t done = 0; done < n_ticks;) {
+                const uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(K, n_ticks - done));
+                hipError_t e = static_cast<hipError_t>(h->pair_launch(&P, h->desc.integrator, k, small ? 1 : 0, h->stream, &launches));
+                if (e != hipSuccess) return h->hip_fail(e, "custom pair launch");
+                done += k;
+            }
+        } else if (P.n <= kPairSmallMax && !(no_small && no_small[0] == '0')) {   // small graphs: ticks_per_launch ticks per launch
             const uint32_t K = h->desc.ticks_per_launch;
             for (uint64_t done = 0; done < n_ticks;) {
                 const uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(K, n_ticks - done));

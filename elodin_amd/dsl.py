@@ -441,6 +441,66 @@ class Pipe:
         return self._traced
 
 
+# ---- GraphQuery.edge_fold with a user-written fold function ------------------------------------------------------
+
+class _EdgeTransform:
+    """WorldPos of one edge endpoint.  The pair kernels stage the three integrator-stage positions of every body
+    (csrc/pair_kernel.hpp: pack), not attitudes, so only `.linear()` is available inside a fold."""
+
+    def __init__(self, p: Vec): self._p = p
+    def linear(self): return self._p
+    def angular(self): raise TypeError("edge_fold functions can read pos.linear() only")
+
+
+class _EdgeInertia:
+    def __init__(self, m: Expr): self._m = m
+    def mass(self): return self._m
+    def inertia_diag(self): raise TypeError("edge_fold functions can read inertia.mass() only")
+
+
+class EdgeFold:
+    """`graph.edge_fold(query, query, el.Force, el.SpatialForce(), fn)` (graph.rs:177-282, used by
+    examples/three-body/main.py:56-78 and examples/n-body/sim.py:344-369) with left/right queries
+    `Query[WorldPos, Inertia]`: fn(acc, a_pos, a_inertia, b_pos, b_inertia) -> SpatialForce, folded from zero over
+    each source's out-edges in spawn order; the result REPLACES Force on source rows."""
+
+    def __init__(self, fn: Callable, edge_component: str = "gravity_edge"):
+        self.fn = fn
+        self.edge_component = edge_component
+        self.__name__ = getattr(fn, "__name__", "edge_fold")
+        if len(inspect.signature(fn).parameters) != 5:
+            raise TypeError("edge_fold function must take (acc, a_pos, a_inertia, b_pos, b_inertia)")
+        self._traced = None
+
+    def trace(self) -> "TracedFold":
+        if self._traced is None:
+            self._traced = TracedFold(self)
+        return self._traced
+
+
+def edge_fold(fn=None, edge_component: str = "gravity_edge"):
+    if fn is None:
+        return lambda f: EdgeFold(f, edge_component)
+    return EdgeFold(fn, edge_component)
+
+
+class TracedFold:
+    LEAVES = ["acc0", "acc1", "acc2", "acc3", "acc4", "acc5", "ax", "ay", "az", "ma", "bx", "by", "bz", "mb"]
+
+    def __init__(self, fold: EdgeFold):
+        self.fold = fold
+        acc = SpatialForce(torque=Vec([leaf(f"acc{k}") for k in range(3)]), linear=Vec([leaf(f"acc{k}") for k in range(3, 6)]))
+        a = (_EdgeTransform(Vec([leaf("a" + c) for c in "xyz"])), _EdgeInertia(leaf("ma")))
+        b = (_EdgeTransform(Vec([leaf("b" + c) for c in "xyz"])), _EdgeInertia(leaf("mb")))
+        out = fold.fn(acc, a[0], a[1], b[0], b[1])
+        if not isinstance(out, SpatialForce):
+            raise TypeError(f"edge_fold function {fold.__name__} must return a dsl.SpatialForce")
+        if not all(e.is_const(0.0) for e in out._tb.e):
+            raise TypeError("edge_fold functions cannot produce body-frame torques")
+        self.outputs: List[Expr] = list(out._tw.e) + list(out.force().e)   # new acc: [tau(3), f(3)]
+        self.leaves = _leaves_of(self.outputs)
+
+
 # ---- systems piped around six_dof ----------------------------------------------------------------------------------
 
 class System:

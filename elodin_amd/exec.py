@@ -109,6 +109,18 @@ class HipExec:
                     self._aux[name] = arr
                     cols.append((name, arr))
                 effectors = ()
+            pair_so = None
+            effectors = list(effectors)
+            if effectors and isinstance(effectors[-1], _dsl.EdgeFold):
+                # user-written edge_fold function: trace -> generate the PAIR functor -> hipcc -> sixdof_set_custom_pair
+                from . import codegen
+                if self.dtype != np.float64:
+                    raise ValueError("edge_fold effectors are float64 only")
+                if edges is None:
+                    raise ValueError("an edge_fold effector needs edges=(from_ids, to_ids)")
+                pair_so = codegen.build_pair(effectors.pop().trace())
+            if any(isinstance(e, _dsl.EdgeFold) for e in effectors):
+                raise ValueError("an edge_fold effector must be last in the pipe")
             ops = (L.EffectorOp * max(1, len(effectors)))()
             for k, e in enumerate(effectors):
                 ops[k].kind = e.kind
@@ -129,6 +141,10 @@ class HipExec:
                 rc = lib.sixdof_set_custom_pipe(self._h, str(so).encode(), ids, len(custom.columns))
                 if rc != L.OK:
                     _raise(self._h, rc, "sixdof_set_custom_pipe")
+            if pair_so is not None:
+                rc = lib.sixdof_set_custom_pair(self._h, str(pair_so).encode())
+                if rc != L.OK:
+                    _raise(self._h, rc, "sixdof_set_custom_pair")
             if edges is not None:
                 frm = np.ascontiguousarray(edges[0], dtype=np.uint64)
                 to = np.ascontiguousarray(edges[1], dtype=np.uint64)

@@ -99,7 +99,10 @@ typedef enum sixdof_effector_kind {
     SIXDOF_EFF_EDGE_GRAVITY_SOFTENED = 7,
     /* Same fold as 7 over the complete graph (for i: for j != i, ascending), without
      * materialising edges.  examples/n-body/sim.py:333-337 spawn order */
-    SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED = 8
+    SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED = 8,
+    /* edge_fold whose fold function is generated code (sixdof_set_custom_pair); never passed to
+     * sixdof_set_effectors directly.  graph.rs:177-282 edge_fold with an arbitrary `fn` */
+    SIXDOF_EFF_EDGE_CUSTOM = 9
 } sixdof_effector_kind;
 
 typedef struct sixdof_effector_op {
@@ -251,6 +254,11 @@ int sixdof_bind_world(sixdof_handle* h, sixdof_world* w);
  * columns its systems read AND write (row width 1..8, <= 16; fetch them back with sixdof_download_column).
  * Replaces the built-in op list (sixdof_set_effectors) for the per-entity path. */
 int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t* aux_component_ids, size_t n_aux);
+/* Same idea for GraphQuery.edge_fold (graph.rs:177-282) with a user-written fold function over
+ * (acc: Force, a: (WorldPos, Inertia), b: (WorldPos, Inertia)): the generated object instantiates the pair kernels
+ * (csrc/pair_kernel.hpp) with that function.  Appends the fold as the LAST op of the pipe set by
+ * sixdof_set_effectors (per-entity built-in ops before it are kept); edges come from sixdof_set_edges. */
+int sixdof_set_custom_pair(sixdof_handle* h, const char* so_path);
 
 /* ---- telemetry: device-side history ring (the commit step either side of the path) ------------------------
  * The reference commits every output column to its DB after each batch (exec.rs:110-172,

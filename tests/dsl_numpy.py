@@ -53,6 +53,32 @@ def _world_wrench(out9, xs):
     return F
 
 
+# ---- edge folds -------------------------------------------------------------------------------------------------
+
+def fold_force(tf, xs, inertia, src_rows, dst_rows, prior=None):
+    """Sequential left fold of a traced edge_fold function (elodin_amd.dsl.TracedFold) per source, edges in the
+    given (spawn) order, from a zero accumulator -> F [n,6]; rows that are not a source keep `prior` (or zero).
+    Vectorised by rounds: round k applies every source's k-th out-edge."""
+    n = xs.shape[0]
+    F = np.zeros((n, 6)) if prior is None else np.array(prior, dtype=np.float64)
+    src_rows, dst_rows = np.asarray(src_rows), np.asarray(dst_rows)
+    order = np.argsort(src_rows, kind="stable")
+    s, d = src_rows[order], dst_rows[order]
+    rank = np.arange(len(s)) - np.searchsorted(s, s, side="left")     # position of an edge inside its source's list
+    acc = np.zeros((n, 6))
+    for k in range(int(rank.max()) + 1 if len(s) else 0):
+        sel = rank == k
+        a, b = s[sel], d[sel]
+        lv = {f"acc{j}": acc[a, j] for j in range(6)}
+        lv.update({"ax": xs[a, 4], "ay": xs[a, 5], "az": xs[a, 6], "ma": inertia[a, 6],
+                   "bx": xs[b, 4], "by": xs[b, 5], "bz": xs[b, 6], "mb": inertia[b, 6]})
+        with np.errstate(all="ignore"):
+            acc[a] = np.stack(_eval(tf.outputs, lv, len(a)), axis=1)
+    srcs = np.unique(s)
+    F[srcs] = acc[srcs]                                               # the fold output replaces Force on source rows
+    return F
+
+
 # ---- whole programs (pre systems | six_dof(effectors) | post systems) ------------------------------------------------
 
 def _leaf_arrays(pos, vel, inertia, comps, table, tick):

@@ -78,3 +78,56 @@ def test_generated_source_compiles_for_gfx950():
     so = codegen.build(tp, "float64", 0)
     assert so.exists() and so.suffix == ".so"
     assert codegen.build(tp, "float64", 0) == so          # cached by content hash
+
+
+# ---- user-written edge_fold functions ------------------------------------------------------------------------------
+
+G_NEWTON = 6.6743e-11
+
+
+@dsl.edge_fold
+def gravity_fn(force, a_pos, a_inertia, b_pos, b_inertia):       # examples/three-body/main.py:61-70, verbatim structure
+    r = a_pos.linear() - b_pos.linear()
+    m = a_inertia.mass()
+    M = b_inertia.mass()
+    norm = np_.linalg.norm(r)
+    f = G_NEWTON * M * m * r / (norm * norm * norm)
+    return dsl.SpatialForce(linear=force.force() - f)
+
+
+def test_edge_fold_trace_against_the_c_oracle_fold():
+    """The traced fold, evaluated with numpy in spawn order, equals the oracle's built-in Newton fold on the golden
+    three-body initial state."""
+    from tests import golden_util as gu
+    g = gu.load("three_body")
+    pos = np.stack([g[f"{e}.world_pos"][0] for e in "abc"])
+    inertia = np.stack([g[f"{e}.inertia"][0] for e in "abc"])
+    src, dst = np.array([0, 1, 0, 1, 2, 2]), np.array([1, 0, 2, 2, 0, 1])
+    F = dsl_numpy.fold_force(gravity_fn.trace(), pos, inertia, src, dst)
+    assert np.all(F[:, :3] == 0.0) and np.all(np.isfinite(F))
+    vel = np.stack([g[f"{e}.world_vel"][0] for e in "abc"])
+    ow = orc.OracleWorld(pos, vel, inertia, integrator=orc.SEMI_IMPLICIT, edges=(src, dst),
+                         ops=[(orc.EFF_EDGE_GRAVITY_NEWTON, (G_NEWTON,), None)]).step(1)
+    assert np.array_equal(F, ow.force)            # semi-implicit: force column = the fold at the initial positions
+    # exact check against the formula, edge by edge
+    want = np.zeros((3, 3))
+    for a, b in zip(src, dst):
+        r = pos[a, 4:] - pos[b, 4:]
+        nrm = np.sqrt(np.sum(r * r))
+        want[a] = want[a] - G_NEWTON * inertia[b, 6] * inertia[a, 6] * r / (nrm * nrm * nrm)
+    assert np.allclose(F[:, 3:], want, rtol=1e-15, atol=0.0)
+
+
+def test_edge_fold_restrictions_and_codegen():
+    with pytest.raises(TypeError):
+        dsl.edge_fold(lambda acc, a_pos, a_in, b_pos, b_in: dsl.SpatialForce(linear=a_pos.angular() @ b_pos.linear())).trace()
+    with pytest.raises(TypeError):
+        dsl.edge_fold(lambda acc, a_pos, a_in, b_pos, b_in: dsl.SpatialForce(linear=a_in.inertia_diag())).trace()
+    with pytest.raises(TypeError):
+        dsl.edge_fold(lambda acc, a, b: acc)
+    tf = gravity_fn.trace()
+    assert tf.leaves == {"acc3", "acc4", "acc5", "ax", "ay", "az", "ma", "bx", "by", "bz", "mb"}
+    src = codegen.generate_pair_source(tf)
+    assert "struct PairCustom" in src and "sixdof_custom_pair_launch" in src
+    so = codegen.build_pair(tf)
+    assert so.exists() and codegen.build_pair(tf) == so

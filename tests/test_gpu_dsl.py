@@ -285,3 +285,128 @@ def test_whole_apollo_campaign_as_user_code_equals_the_handwritten_model():
     print("generated closed loop vs hand-written: worst result rel err", rel.max(),
           "device ms", t0.kernel_device_ms, "launches", t0.launches)
     assert rel.max() < 1e-6
+
+
+# ---- user-written edge_fold functions (GraphQuery.edge_fold with an arbitrary fn, graph.rs:177-282) ----------------
+
+G_NEWTON = 6.6743e-11
+
+
+@dsl.edge_fold
+def gravity_fn(force, a_pos, a_inertia, b_pos, b_inertia):       # examples/three-body/main.py:61-70, verbatim structure
+    r = a_pos.linear() - b_pos.linear()
+    m = a_inertia.mass()
+    M = b_inertia.mass()
+    norm = np_.linalg.norm(r)
+    f = G_NEWTON * M * m * r / (norm * norm * norm)
+    return dsl.SpatialForce(linear=force.force() - f)
+
+
+def _three_body_state():
+    g = gu.load("three_body")
+    pos = np.stack([g[f"{e}.world_pos"][0] for e in "abc"])
+    vel = np.stack([g[f"{e}.world_vel"][0] for e in "abc"])
+    inertia = np.stack([g[f"{e}.inertia"][0] for e in "abc"])
+    edge_names = ["a_>_b", "b_>_a", "a_>_c", "b_>_c", "c_>_a", "c_>_b"]
+    frm = np.array([g[f"{e}.gravity_edge"][0, 0] for e in edge_names], dtype=np.uint64)
+    to = np.array([g[f"{e}.gravity_edge"][0, 1] for e in edge_names], dtype=np.uint64)
+    return g, pos, vel, inertia, frm, to
+
+
+@pytest.mark.parametrize("small", [True, False])
+def test_three_body_gravity_written_by_the_user_matches_reference_golden(small, monkeypatch):
+    """The example's gravity_fn as user code -> generated PAIR functor -> the same pair kernels; checked against the
+    reference's golden CSV (scripts/ci/baseline/three-body-csv) and against the built-in Newton op."""
+    if not small:
+        monkeypatch.setenv("SIXDOF_PAIR_SMALL", "0")
+    g, pos, vel, inertia, frm, to = _three_body_state()
+    kw = dict(entity_ids=[1, 2, 3], simulation_time_step=float(g["globals.simulation_time_step"][0, 0]), edges=(frm, to))
+    user = el.HipExec(pos, vel, inertia, effectors=[gravity_fn], **kw)
+    builtin = el.HipExec(pos, vel, inertia, effectors=[el.Effector(L.EFF_EDGE_GRAVITY_NEWTON, (G_NEWTON,))], **kw)
+    worst = 0.0
+    for r in range(1, 101):
+        t = user.run(1)
+        assert t.launches == (1 if small else 3)
+        for i, e in enumerate("abc"):
+            worst = max(worst, parity.pos_rel_err(user.world_pos[i:i + 1], g[f"{e}.world_pos"][r][None]))
+            for comp in ("world_vel", "world_accel", "force"):
+                worst = max(worst, parity.field_rel_err(getattr(user, comp)[i:i + 1, 3:], g[f"{e}.{comp}"][r][None, 3:]))
+    builtin.run(100)
+    vs_builtin = max(parity.field_rel_err(getattr(user, f), getattr(builtin, f)) for f in parity.FIELDS)
+    print("user-written three-body fold: vs golden", worst, "vs built-in op", vs_builtin)
+    assert worst < parity.F64_RTOL and vs_builtin < 1e-12
+
+
+K_SPRING, L0 = 40.0, 1.5
+
+
+@dsl.edge_fold(edge_component="spring")
+def spring(acc, a_pos, a_inertia, b_pos, b_inertia):
+    """A fold that accumulates force AND torque and uses both masses: damped-length spring along the edge."""
+    r = b_pos.linear() - a_pos.linear()
+    d = np_.linalg.norm(r)
+    mu = a_inertia.mass() * b_inertia.mass() / (a_inertia.mass() + b_inertia.mass())
+    f = (K_SPRING * mu * np_.tanh(d - L0) / d) * r
+    arm = np_.array([0.0, 0.0, 0.25])
+    return acc + dsl.SpatialForce(torque=np_.cross(arm, f), linear=f)
+
+
+@pytest.mark.parametrize("integrator", [L.RK4, L.SEMI_IMPLICIT])
+@pytest.mark.parametrize("n", [200, 3000])
+def test_user_fold_with_torque_after_builtin_ops_vs_numpy_fold(integrator, n):
+    """Sparse random graph (some rows are no edge's source and keep the per-entity pipe's Force), user fold returning
+    a full wrench, both launch shapes (single-workgroup n <= 256, three-kernel otherwise) vs the numpy stepper
+    evaluating the same DAG sequentially in spawn order."""
+    w = workloads.independent_bodies(n, seed=11)
+    rng = np.random.default_rng(5)
+    m = 3 * n
+    src = rng.integers(0, n - n // 8, size=m)          # the last n/8 rows are never sources
+    dst = (src + 1 + rng.integers(0, n - 1, size=m)) % n
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    g_vec = (0.0, 0.0, -9.81)
+    hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=integrator, simulation_time_step=1 / 240.0,
+                     effectors=[el.Effector(L.EFF_UNIFORM_GRAVITY, g_vec), spring], edges=(ids[src], ids[dst]))
+    hs, hd = hip.edge_rows()
+    tf = spring.trace()
+
+    def effectors(xs, vs):
+        prior = np.zeros((n, 6))
+        prior[:, 3:] = np.array(g_vec) * w["inertia"][:, 6:7]
+        return dsl_numpy.fold_force(tf, xs, w["inertia"], src, dst, prior)
+
+    pos, vel, acc = w["world_pos"].copy(), w["world_vel"].copy(), np.zeros((n, 6))
+    for _ in range(6):
+        pos, vel, acc, F = np_sixdof.tick(pos, vel, acc, w["inertia"], effectors, 1 / 240.0, integrator=integrator)
+    hip.run(6)
+    assert np.array_equal(np.sort(hs.astype(np.int64) * n + hd), np.sort(src * n + dst))
+    errs = {"world_pos": parity.pos_rel_err(hip.world_pos, pos), "world_vel": parity.field_rel_err(hip.world_vel, vel),
+            "world_accel": parity.field_rel_err(hip.world_accel, acc), "force": parity.field_rel_err(hip.force, F)}
+    print("user fold with torque", n, integrator, errs)
+    assert max(errs.values()) < parity.F64_RTOL, errs
+    never = np.setdiff1d(np.arange(n), src)
+    assert len(never) >= n // 8 and np.all(hip.force[never, :3] == 0.0)
+    assert np.allclose(hip.force[never, 5], -9.81 * w["inertia"][never, 6], rtol=1e-15)
+    assert np.any(hip.force[np.unique(src), :3] != 0.0)
+
+
+def test_user_fold_through_the_world_api():
+    """three-body/main.py end to end on this framework: GravityEdge spawns + six_dof(sys=<user fold>)."""
+    g, pos, vel, inertia, frm, to = _three_body_state()
+    w = el.World()
+    bodies = [w.spawn(el.Body(world_pos=el.SpatialTransform(linear=pos[i, 4:]), world_vel=el.SpatialMotion(linear=vel[i, 3:]),
+                              inertia=el.SpatialInertia(inertia[i, 6])), name="abc"[i]) for i in range(3)]
+    for a, b in ((0, 1), (1, 0), (0, 2), (1, 2), (2, 0), (2, 1)):
+        w.spawn(el.GravityEdge(bodies[a], bodies[b]), name=f"{'abc'[a]} -> {'abc'[b]}")
+    ex = w.build(el.six_dof(sys=gravity_fn), simulation_rate=120.0)
+    ex.run(100)
+    got = ex.column_array("world_pos")
+    worst = max(parity.pos_rel_err(got[i:i + 1], g[f"{e}.world_pos"][100][None]) for i, e in enumerate("abc"))
+    assert worst < parity.F64_RTOL, worst
+
+
+def test_edge_fold_needs_edges_and_must_close_the_pipe():
+    g, pos, vel, inertia, frm, to = _three_body_state()
+    with pytest.raises(ValueError):
+        el.HipExec(pos, vel, inertia, effectors=[gravity_fn])
+    with pytest.raises(ValueError):
+        el.HipExec(pos, vel, inertia, effectors=[gravity_fn, el.Effector(L.EFF_UNIFORM_GRAVITY, (0, 0, -1))], edges=(frm, to))
