@@ -31,7 +31,7 @@ _LEAF_CPP = {
 _BIN = {"add": "+", "sub": "-", "mul": "*", "div": "/"}
 _FN1 = {"sqrt": "m_sqrt", "abs": "m_abs", "sin": "m_sin", "cos": "m_cos", "tan": "m_tan", "exp": "m_exp",
         "log": "m_log", "acos": "m_acos", "asin": "m_asin"}
-_FN2 = {"max": "m_max", "min": "m_min", "atan2": "m_atan2", "hypot": "m_hypot"}
+_FN2 = {"max": "m_max", "min": "m_min", "atan2": "m_atan2", "hypot": "m_hypot", "pow": "m_pow"}
 _BOOL_OPS = {"lt", "le", "and", "or", "not"}
 
 
@@ -144,6 +144,7 @@ SIXDOF_M1(m_log, log, logf) SIXDOF_M1(m_acos, acos, acosf) SIXDOF_M1(m_asin, asi
     __device__ __forceinline__ double name(double x, double y) { return fd(x, y); } \\
     __device__ __forceinline__ float name(float x, float y) { return ff(x, y); }
 SIXDOF_M2(m_max, fmax, fmaxf) SIXDOF_M2(m_min, fmin, fminf) SIXDOF_M2(m_atan2, atan2, atan2f) SIXDOF_M2(m_hypot, hypot, hypotf)
+SIXDOF_M2(m_pow, pow, powf)
 // jnp.interp over a constant table: i = clip(searchsorted(xp, x, 'right'), 1, N-1); fp[i-1] + (x-xp[i-1])/dx * df,
 // clamped to the end values outside the table.
 template <class T, int N>

@@ -7,7 +7,7 @@
 namespace sixdof {
 
 constexpr int kMaxOps = 4;       // per-entity effector ops fused into the step kernel
-constexpr int kMaxModelCols = 16; // component columns a generated program keeps in registers
+constexpr int kMaxModelCols = 48; // component columns a generated program keeps in registers
 constexpr int kBlock = 256;      // threads per workgroup = entities per workgroup (4 waves of 64)
 
 // One effector op as the kernel sees it (sixdof_effector_op with the aux column resolved).

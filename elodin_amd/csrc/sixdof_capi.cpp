@@ -89,7 +89,7 @@ struct sixdof_handle {
     void* pair_dl = nullptr;               // generated edge_fold function (sixdof_set_custom_pair)
     CustomPairLaunchFn pair_launch = nullptr;
     std::vector<uint64_t> custom_aux;      // read-only [n,1..3] columns of a generated effector pipe
-    std::vector<uint64_t> custom_model;    // read/write [n,1..8] component columns of a generated program
+    std::vector<uint64_t> custom_model;    // read/write [n,1..16] component columns of a generated program
     // telemetry ring
     uint32_t hist_ring = 0;
     uint64_t hist_first_tick = 0;   // first tick (1-based count) recorded since the ring was enabled
@@ -630,8 +630,8 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
     for (size_t k = 0; k < h->custom_model.size(); k++) {
         Column* c = h->col(h->custom_model[k]);
         if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "step: component column of the generated program is not bound");
-        if (c->width < 1 || c->width > 8 || c->prim != h->state_prim())
-            return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, "step: program columns must be [n,1..8] of the state dtype");
+        if (c->width < 1 || c->width > 16 || c->prim != h->state_prim())
+            return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, "step: program columns must be [n,1..16] of the state dtype");
         if (!c->joined) {
             int rc = resolve_join(h, c);
             if (rc != SIXDOF_OK) return rc;

@@ -63,7 +63,15 @@ class Expr:
             for _ in range(k - 1):
                 r = r * self
             return r
-        raise TypeError("only small positive integer powers are supported")
+        if isinstance(k, int) and k == 0:
+            return const(1.0)
+        return _Np.power(self, k)              # jnp.power for everything else
+    def __rpow__(self, b): return _Np.power(b, self)
+    def __and__(self, o): return Expr("and", (self, _lift(o)))
+    def __rand__(self, o): return Expr("and", (_lift(o), self))
+    def __or__(self, o): return Expr("or", (self, _lift(o)))
+    def __ror__(self, o): return Expr("or", (_lift(o), self))
+    def __invert__(self): return Expr("not", (self,))
     def __lt__(self, o): return _bin("lt", self, o)
     def __le__(self, o): return _bin("le", self, o)
     def __gt__(self, o): return _bin("lt", o, self)
@@ -131,6 +139,15 @@ class Vec:
     def __truediv__(self, o): return self._zip(o, lambda a, b: a / b)
     def __neg__(self): return Vec([-a for a in self.e])
     def __pow__(self, k): return Vec([a ** k for a in self.e])
+    def __lt__(self, o): return self._zip(o, lambda a, b: a < b)
+    def __le__(self, o): return self._zip(o, lambda a, b: a <= b)
+    def __gt__(self, o): return self._zip(o, lambda a, b: a > b)
+    def __ge__(self, o): return self._zip(o, lambda a, b: a >= b)
+    def __and__(self, o): return self._zip(o, lambda a, b: a & b)
+    def __rand__(self, o): return self._zip(o, lambda a, b: b & a)
+    def __or__(self, o): return self._zip(o, lambda a, b: a | b)
+    def __ror__(self, o): return self._zip(o, lambda a, b: b | a)
+    def __invert__(self): return Vec([~a for a in self.e])
 
 
 def _unary(op):
@@ -178,15 +195,27 @@ class _Np:
             return Vec([Expr("select", (_lift(k), x, y)) for k, x, y in zip(cv, av.e, bv.e)])
         return Expr("select", (_lift(c), _lift(a), _lift(b)))
     @staticmethod
-    def logical_and(a, b): return Expr("and", (_lift(a), _lift(b)))
+    def logical_and(a, b): return _zipv(a, b, lambda x, y: Expr("and", (_lift(x), _lift(y))))
     @staticmethod
-    def logical_or(a, b): return Expr("or", (_lift(a), _lift(b)))
+    def logical_or(a, b): return _zipv(a, b, lambda x, y: Expr("or", (_lift(x), _lift(y))))
     @staticmethod
-    def logical_not(a): return Expr("not", (_lift(a),))
+    def logical_not(a): return Vec([Expr("not", (x,)) for x in a.e]) if isinstance(a, Vec) else Expr("not", (_lift(a),))
     @staticmethod
     def arctan2(y, x): return Expr("atan2", (_lift(y), _lift(x)))
     @staticmethod
     def hypot(x, y): return Expr("hypot", (_lift(x), _lift(y)))
+    @staticmethod
+    def arctan(x): return _zipv(x, 1.0, lambda a, b: Expr("atan2", (_lift(a), _lift(b))))   # atan2(x, 1) == atan(x)
+    @staticmethod
+    def power(x, y): return _zipv(x, y, lambda a, b: Expr("pow", (_lift(a), _lift(b))))
+    @staticmethod
+    def concatenate(parts, axis=0):
+        out = []
+        for v in parts:
+            out.extend(v.e if isinstance(v, Vec) else [_lift(v)])
+        return Vec(out)
+    @staticmethod
+    def ones(n, dtype=None): return Vec([1.0] * int(n))
     @staticmethod
     def interp(x, xp, fp):
         """jnp.interp(x, xp, fp) with CONSTANT tables (atmosphere / thrust-curve lookups, e.g. examples/rocket/main.py:356-375)."""
@@ -605,7 +634,7 @@ class Program:
 
 class TracedProgram:
     def __init__(self, prog: Program, widths: Optional[Dict[str, int]] = None):
-        self.table = ColumnTable("c", 16, 8, widths)
+        self.table = ColumnTable("c", 48, 16, widths)
         self.pre = [TracedSystem(s, self.table) for s in prog.pre]
         self.pipe = TracedPipe(prog.effectors.effectors, table=self.table)
         self.post = [TracedSystem(s, self.table) for s in prog.post]

@@ -1,0 +1,790 @@
+"""Falcon 9 booster ascent Monte-Carlo (BASELINE config 5) as USER CODE on the generated-program path.
+
+The reference's example (examples/falcon9) is a 1 kHz plant in rotating WGS84 ECEF — point-mass gravity + Coriolis /
+centrifugal, nine Merlin engines with ignition gating and spool dynamics, TVC, propellant depletion with a cylinder-stack
+mass model, US Standard Atmosphere 1976, Mach-tabulated body aerodynamics with plume dominance, a hold-down clamp —
+integrated by `el.six_dof(integrator=SemiImplicit)` and flown by an external flight-software process (Rust,
+examples/falcon9/controller) exchanging sensor/command packets every 10 ticks.
+
+This module restates the ASCENT part of that stack (pad -> vertical rise -> pitch kick -> gravity turn -> MECO) against
+`elodin_amd.dsl`, so that the whole closed loop is traced, generated and fused into the step kernel
+(`pre | six_dof(effectors) | post`), one lane per Monte-Carlo rollout:
+
+  plant systems   sim.py:350-733 (attitude_control, valve_dynamics, tvc_actuators, engine_dynamics, mass_props,
+                  tank_dynamics, engine_wrench, aero_dynamics, gravity_and_frame_forces, apply_body_wrenches),
+                  pad_clamp sim.py:984-1013, derive_geodetic_telemetry sim.py:1128-1143
+  physics helpers frames.py:29-114, atmosphere.py:25-90, propulsion.py:46-149, aero.py:17-125
+  flight software controller/src/main.rs:384-533 (phases PadPress..Meco, parametric pitch program — the fallback the
+                  FSW flies without a recorded profile), math.rs:90-138,191-199
+  parameters      spec.toml (LHS, seed 20170814) / main.py:53-100 calibrated defaults
+
+Deliberate scope limits (stated, not hidden): the recovery half of the mission (flip, boostback, entry, landing: grid
+fins, cold-gas RCS allocation, landing legs, ZEM/ZEV guidance) is not built, so fin / RCS / leg wrenches are identically
+zero as they are during a real ascent; the FSW navigates on truth state instead of the noisy IMU/GPS models (those draw
+from jax.random, which has no counterpart here); the steady wind / gust model is off (spec.toml samples no wind).
+Parity is UNPINNED against reference trajectories (none are checked in, and the reference cannot run here); the
+helper functions and the passive / open-loop plant are pinned against the reference's own verification ladder
+(test_ladder.py, test_frames.py, test_propulsion.py, test_aero.py) in tests/test_falcon9_host.py and
+tests/test_gpu_falcon9.py.
+
+Every physics helper takes the array namespace `xp` first: `numpy` gives the host-side f64 evaluation (initial
+conditions, known-answer tests), `elodin_amd.dsl.np` traces the same code into the kernel.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from .. import dsl
+
+# ---- constants (constants.py; EST = public estimate / calibration prior) ------------------------------------------------
+WGS84_A_M = 6_378_137.0
+WGS84_F = 1.0 / 298.257223563
+WGS84_B_M = WGS84_A_M * (1.0 - WGS84_F)
+WGS84_E2 = WGS84_F * (2.0 - WGS84_F)
+WGS84_EP2 = WGS84_E2 / (1.0 - WGS84_E2)
+MU_EARTH_M3S2 = 3.986004418e14
+OMEGA_EARTH_RADPS = 7.292115e-5
+G0 = 9.80665
+
+SIM_RATE_HZ = 1000.0
+SIM_TIME_STEP = 1.0 / SIM_RATE_HZ
+GUIDANCE_PERIOD_TICKS = 10                       # main.py:187 (GUIDANCE_RATE_HZ = 100)
+
+PAD_LAT_DEG, PAD_LON_DEG, PAD_ALT_M = 28.60839, -80.60433, 3.0
+
+STAGE1_LENGTH_M = 47.0
+STAGE1_DIAMETER_M = 3.66
+S_REF_M2 = math.pi * STAGE1_DIAMETER_M ** 2 / 4.0
+STAGE1_DRY_MASS_KG = 25_600.0
+STAGE1_PROP_KG = 398_000.0
+OF_RATIO = 2.33
+LOX_LOAD_KG = STAGE1_PROP_KG * OF_RATIO / (1.0 + OF_RATIO)
+RP1_LOAD_KG = STAGE1_PROP_KG / (1.0 + OF_RATIO)
+STAGE2_WET_KG = 111_500.0
+PAYLOAD_KG = 7_100.0
+UPPER_KG = STAGE2_WET_KG + PAYLOAD_KG             # main.py:165
+LIFTOFF_MASS_KG = STAGE1_DRY_MASS_KG + STAGE1_PROP_KG + STAGE2_WET_KG + PAYLOAD_KG
+
+N_ENGINES = 9
+ENGINE_A_E_M2 = 0.681
+ENGINE_T_SL_N = 760e3
+P_SL_PA = 101_325.0
+ENGINE_T_VAC_N = ENGINE_T_SL_N + P_SL_PA * ENGINE_A_E_M2
+ENGINE_ISP_SL_S = 282.0
+ENGINE_ISP_VAC_S = ENGINE_ISP_SL_S * ENGINE_T_VAC_N / ENGINE_T_SL_N
+THROTTLE_MIN = 0.57
+RELIGHT_CAPABLE_ENGINES = 3
+ENGINE_SPINUP_TAU_S, ENGINE_SHUTDOWN_TAU_S, ENGINE_THROTTLE_TAU_S = 1.5, 0.35, 0.15
+TVC_MAX_RAD = math.radians(5.0)
+TVC_RATE_RADPS = math.radians(20.0)
+TVC_TAU_S = 0.030
+TANK_P_NOM_PA = 3.5e5
+VALVE_TAU_S = 0.015
+
+(VALVE_HE_INFILL_LOX, VALVE_HE_VENT_LOX, VALVE_HE_INFILL_RP1, VALVE_HE_VENT_RP1, VALVE_MAIN_LOX, VALVE_MAIN_RP1,
+ VALVE_TEATEB, VALVE_N2_PURGE) = range(8)
+N_VALVES = 8
+
+# propulsion.py:26-45
+DRY_CG_STATION_M = 18.8
+RHO_LOX, RHO_RP1 = 1220.0, 830.0
+TANK_AREA_M2 = S_REF_M2
+RP1_TANK_BOTTOM_M, LOX_TANK_BOTTOM_M = 3.0, 17.5
+TANK_ULLAGE_FRAC = 0.05
+V_TANK_LOX_M3 = LOX_LOAD_KG / RHO_LOX * (1.0 + TANK_ULLAGE_FRAC)
+V_TANK_RP1_M3 = RP1_LOAD_KG / RHO_RP1 * (1.0 + TANK_ULLAGE_FRAC)
+STAGE_RADIUS_M = 1.83
+P_REGULATOR_PA = TANK_P_NOM_PA + 0.2e5
+K_INFILL_PER_S, K_VENT_PER_S, P_AMBIENT_MIN_PA = 0.5, 0.3, 1.0e4
+STAGE2_CG_STATION_M, STAGE2_LENGTH_M = 58.0, 16.0
+
+# aero.py:17-50
+MACH_PTS = (0.0, 0.6, 0.9, 1.1, 1.5, 2.0, 3.0, 5.0, 10.0)
+CA_ASCENT = (0.30, 0.32, 0.45, 0.55, 0.50, 0.42, 0.35, 0.30, 0.28)
+CA_DESCENT = (1.90, 1.95, 2.10, 2.40, 2.30, 2.20, 2.10, 2.00, 1.90)
+CN_CROSS = (1.20, 1.20, 1.25, 1.35, 1.30, 1.25, 1.20, 1.15, 1.10)
+X_CP_ASCENT_M, X_CP_DESCENT_M = 28.0, 26.0
+CMQ_ASCENT, CMQ_DESCENT = -2.5, -12.0
+L_REF_DAMP_M = STAGE1_LENGTH_M
+PLUME_CT0 = 1.0
+
+# sim.py:640-646 attitude inner loop
+ATT_WN_TVC, ATT_WN_TVC_LANDING, ATT_ZETA_TVC, ATT_WN_RCS, ATT_ZETA_RCS = 0.9, 1.7, 0.9, 0.35, 0.8
+
+# atmosphere.py:19-47
+R_STAR, M_AIR = 8.31432, 28.9644e-3
+R_AIR = R_STAR / M_AIR
+GMR = G0 * M_AIR / R_STAR
+GAMMA = 1.4
+R0_GEOPOT_M = 6_356_766.0
+_H_B = (0.0, 11_000.0, 20_000.0, 32_000.0, 47_000.0, 51_000.0, 71_000.0, 84_852.0)
+_T_B = (288.15, 216.65, 216.65, 228.65, 270.65, 270.65, 214.65, 186.946)
+_L_B = (-6.5e-3, 0.0, 1.0e-3, 2.8e-3, 0.0, -2.8e-3, -2.0e-3, 0.0)
+
+
+def _base_pressures():
+    p = [P_SL_PA]
+    for i in range(1, len(_H_B)):
+        dh, t_b, lapse = _H_B[i] - _H_B[i - 1], _T_B[i - 1], _L_B[i - 1]
+        p.append(p[-1] * math.exp(-GMR * dh / t_b) if lapse == 0.0 else p[-1] * (t_b / (t_b + lapse * dh)) ** (GMR / lapse))
+    return tuple(p)
+
+
+_P_B = _base_pressures()
+
+# per-rollout parameter column (`params`, [n,16]); the first 14 are read inside the loop
+PARAM_NAMES = ["thrust_scale", "isp_scale", "ca_scale", "cn_scale", "kick_deg", "kick_start_s", "kick_ramp_s",
+               "ascent_throttle", "bucket_throttle", "bucket_q_on_pa", "meco_fpa_deg", "pitch_exp", "meco_speed_mps",
+               "azimuth_deg", "lox_kg", "rp1_kg"]
+P = {name: k for k, name in enumerate(PARAM_NAMES)}
+# main.py:53-100: the calibrated best fit against the recorded CRS-12 flight
+DEFAULT_PARAMS = dict(thrust_scale=1.0323, isp_scale=1.0215, ca_scale=0.9574, cn_scale=1.3038, kick_deg=6.17,
+                      kick_start_s=7.81, kick_ramp_s=11.74, ascent_throttle=0.9969, bucket_throttle=0.7105,
+                      bucket_q_on_pa=18_942.0, meco_fpa_deg=35.27, pitch_exp=0.5626, meco_speed_mps=1_645.1,
+                      azimuth_deg=47.67, lox_kg=275_357.0, rp1_kg=120_449.0)
+# spec.toml [monte_carlo.variables] (all uniform).  The whole table is sampled — the LHS draws depend on the variable
+# set — and the columns that reach the ascent are kept.
+SPEC_RANGES = dict(lox_kg=(272000.0, 285000.0), rp1_kg=(116000.0, 123000.0), thrust_scale=(0.98, 1.14),
+                   isp_scale=(0.97, 1.03), ca_scale=(0.6, 1.5), cn_scale=(0.6, 1.5), display_lag_s=(0.0, 2.5),
+                   kick_deg=(2.5, 6.5), kick_start_s=(6.0, 12.0), kick_ramp_s=(5.0, 12.0), ascent_throttle=(0.97, 1.0),
+                   bucket_throttle=(0.62, 0.85), bucket_q_on_pa=(14000.0, 24000.0), meco_fpa_deg=(34.0, 46.0),
+                   pitch_exp=(0.4, 0.75), meco_speed_mps=(1630.0, 1680.0), azimuth_deg=(40.0, 50.0),
+                   boostback_overshoot_m=(-2500.0, -500.0), entry_ignite_speed_mps=(1220.0, 1380.0),
+                   entry_ignite_alt_m=(46000.0, 56000.0), entry_dv_mps=(320.0, 430.0), entry_throttle=(0.57, 0.8),
+                   landing_arm_alt_m=(5000.0, 8000.0), landing_accel_margin=(1.05, 1.45), fsw_cd_s_m2=(15.0, 45.0),
+                   boostback_throttle=(0.57, 0.85), fin_wn=(0.9, 2.2), divert_speed_cap=(22.0, 45.0),
+                   steer_tilt_cap=(0.14, 0.24))
+SPEC_SEED = 20170814
+
+PHASE_PAD_PRESS, PHASE_VERTICAL_RISE, PHASE_PITCH_KICK, PHASE_GRAVITY_TURN, PHASE_MECO = 0.0, 1.0, 2.0, 3.0, 4.0
+METRIC_NAMES = ["max_qbar_pa", "t_max_qbar_s", "max_accel_mps2", "meco_t_s", "meco_alt_m", "meco_speed_mps",
+                "meco_fpa_deg", "meco_downrange_m"]
+
+
+# ---- geodesy and the rotating frame (frames.py) -------------------------------------------------------------------------
+
+def geodetic_to_ecef(xp, lat, lon, alt):                                   # frames.py:29-40
+    s, c = xp.sin(lat), xp.cos(lat)
+    n = WGS84_A_M / xp.sqrt(1.0 - WGS84_E2 * s ** 2)
+    return xp.array([(n + alt) * c * xp.cos(lon), (n + alt) * c * xp.sin(lon), (n * (1.0 - WGS84_E2) + alt) * s])
+
+
+def ecef_to_geodetic(xp, r):                                               # frames.py:43-66: Bowring, 4 fixed iterations
+    x, y, z = r[0], r[1], r[2]
+    lon = xp.arctan2(y, x)
+    p = xp.hypot(x, y)
+    beta = xp.arctan2(z, (1.0 - WGS84_F) * p)
+    lat = beta
+    for _ in range(4):
+        lat = xp.arctan2(z + WGS84_EP2 * WGS84_B_M * xp.sin(beta) ** 3, p - WGS84_E2 * WGS84_A_M * xp.cos(beta) ** 3)
+        beta = xp.arctan((1.0 - WGS84_F) * xp.tan(lat))
+    s = xp.sin(lat)
+    w = xp.sqrt(1.0 - WGS84_E2 * s ** 2)
+    alt = p * xp.cos(lat) + z * s - WGS84_A_M * w
+    return lat, lon, alt
+
+
+def ned_basis(xp, lat, lon):                                               # frames.py:74-84: rows north, east, down
+    sl, cl, so, co = xp.sin(lat), xp.cos(lat), xp.sin(lon), xp.cos(lon)
+    return (xp.array([-sl * co, -sl * so, cl]), xp.array([-so, co, 0.0]), xp.array([-cl * co, -cl * so, -sl]))
+
+
+def gravity_accel(xp, r):                                                  # frames.py:92-95
+    rn = xp.linalg.norm(r)
+    return -MU_EARTH_M3S2 * r / rn ** 3
+
+
+def frame_accel(xp, r, v):                                                 # frames.py:98-111: Coriolis + centrifugal
+    om = xp.array([0.0, 0.0, OMEGA_EARTH_RADPS])
+    return -2.0 * xp.cross(om, v) + -xp.cross(om, xp.cross(om, r))
+
+
+def apparent_gravity(xp, r):                                               # frames.py:113-114
+    om = xp.array([0.0, 0.0, OMEGA_EARTH_RADPS])
+    return gravity_accel(xp, r) + -xp.cross(om, xp.cross(om, r))
+
+
+# ---- US Standard Atmosphere 1976 (atmosphere.py) -------------------------------------------------------------------------
+
+def pressure_temperature_at_geopotential(xp, h_geopot):                    # atmosphere.py:55-69
+    h = xp.clip(h_geopot, 0.0, 250_000.0)
+    # searchsorted(H_B, h, 'right') - 1 as a select chain over the constant layer table
+    t_b, lapse, p_b, h_b = _T_B[0], _L_B[0], _P_B[0], _H_B[0]
+    iso, expo = 0.0, GMR / _L_B[0]
+    for i in range(1, len(_H_B)):
+        above = h >= _H_B[i]
+        t_b = xp.where(above, _T_B[i], t_b)
+        lapse = xp.where(above, _L_B[i], lapse)
+        p_b = xp.where(above, _P_B[i], p_b)
+        h_b = xp.where(above, _H_B[i], h_b)
+        iso = xp.where(above, 1.0 if _L_B[i] == 0.0 else 0.0, iso)
+        expo = xp.where(above, GMR / (_L_B[i] if _L_B[i] != 0.0 else 1.0), expo)   # lapse_safe
+    dh = h - h_b
+    temp = t_b + lapse * dh
+    p_gradient = p_b * (t_b / temp) ** expo
+    p_isothermal = p_b * xp.exp(-GMR * dh / t_b)
+    return xp.where(iso > 0.5, p_isothermal, p_gradient), temp
+
+
+def pressure_temperature(xp, h_geometric):                                 # atmosphere.py:51-52,72-73
+    return pressure_temperature_at_geopotential(xp, R0_GEOPOT_M * h_geometric / (R0_GEOPOT_M + h_geometric))
+
+
+def pressure(xp, h):
+    return pressure_temperature(xp, h)[0]
+
+
+def density(xp, h):                                                        # atmosphere.py:80-82
+    p, t = pressure_temperature(xp, h)
+    return p / (R_AIR * t)
+
+
+def speed_of_sound(xp, h):                                                 # atmosphere.py:85-87
+    return xp.sqrt(GAMMA * R_AIR * pressure_temperature(xp, h)[1])
+
+
+# ---- propulsion / actuators / mass properties (propulsion.py) ------------------------------------------------------------
+
+def engine_thrust_per_engine(xp, throttle, p_ambient):                     # propulsion.py:46-48
+    return xp.maximum(throttle * ENGINE_T_VAC_N - p_ambient * ENGINE_A_E_M2, 0.0)
+
+
+def cluster_mdot(xp, engines_lit, throttle):                               # propulsion.py:51-53
+    return engines_lit * throttle * ENGINE_T_VAC_N / (ENGINE_ISP_VAC_S * G0)
+
+
+def split_mdot(mdot_total):                                                # propulsion.py:56-59
+    mdot_lox = mdot_total * OF_RATIO / (1.0 + OF_RATIO)
+    return mdot_lox, mdot_total - mdot_lox
+
+
+def actuator_step(xp, x, cmd, dt, tau, rate_limit=None, lo=None, hi=None):  # propulsion.py:62-73
+    alpha = 1.0 - xp.exp(-dt / tau)
+    dx = alpha * (cmd - x)
+    if rate_limit is not None:
+        dx = xp.clip(dx, -rate_limit * dt, rate_limit * dt)
+    x_new = x + dx
+    if lo is not None or hi is not None:
+        x_new = xp.clip(x_new, lo, hi)
+    return x_new
+
+
+def _column(mass, rho, bottom):                                            # propulsion.py:76-84
+    length = mass / (rho * TANK_AREA_M2)
+    r2 = STAGE_RADIUS_M ** 2
+    return bottom + 0.5 * length, mass * (length ** 2 / 12.0 + r2 / 4.0), 0.5 * mass * r2
+
+
+def stack_mass_props(xp, m_lox, m_rp1, m_upper=0.0):                       # propulsion.py:92-128
+    r2 = STAGE_RADIUS_M ** 2
+    dry_i_trans = STAGE1_DRY_MASS_KG * STAGE1_LENGTH_M ** 2 / 12.0
+    dry_i_axial = 0.5 * STAGE1_DRY_MASS_KG * r2
+    cg_lox, it_lox, ia_lox = _column(m_lox, RHO_LOX, LOX_TANK_BOTTOM_M)
+    cg_rp1, it_rp1, ia_rp1 = _column(m_rp1, RHO_RP1, RP1_TANK_BOTTOM_M)
+    up_i_trans = m_upper * STAGE2_LENGTH_M ** 2 / 12.0
+    up_i_axial = 0.5 * m_upper * r2
+    mass = STAGE1_DRY_MASS_KG + m_lox + m_rp1 + m_upper
+    cg = (STAGE1_DRY_MASS_KG * DRY_CG_STATION_M + m_lox * cg_lox + m_rp1 * cg_rp1 + m_upper * STAGE2_CG_STATION_M) / mass
+
+    def par_axis(i_own, m, station):
+        return i_own + m * (station - cg) ** 2
+    i_trans = (par_axis(dry_i_trans, STAGE1_DRY_MASS_KG, DRY_CG_STATION_M) + par_axis(it_lox, m_lox, cg_lox)
+               + par_axis(it_rp1, m_rp1, cg_rp1) + par_axis(up_i_trans, m_upper, STAGE2_CG_STATION_M))
+    i_axial = dry_i_axial + ia_lox + ia_rp1 + up_i_axial
+    return mass, cg, xp.array([i_axial, i_trans, i_trans])
+
+
+def tank_pressure_step(xp, p, m_prop, mdot_out, v_tank, rho, infill, vent, dt):   # propulsion.py:131-142
+    v_ullage = xp.maximum(v_tank - m_prop / rho, 1e-2 * v_tank)
+    dv_ullage = mdot_out / rho * dt
+    p_drain = p * v_ullage / (v_ullage + dv_ullage)
+    dp_infill = K_INFILL_PER_S * (P_REGULATOR_PA - p_drain) * infill * dt
+    dp_vent = K_VENT_PER_S * (p_drain - P_AMBIENT_MIN_PA) * vent * dt
+    return xp.maximum(p_drain + xp.maximum(dp_infill, 0.0) - xp.maximum(dp_vent, 0.0), 0.0)
+
+
+def inlet_pressure(xp, p_tank, m_prop, rho, bottom, cg, a_axial, mdot):    # propulsion.py:145-149
+    head_height = bottom + m_prop / (rho * TANK_AREA_M2)
+    return p_tank + rho * xp.maximum(a_axial, 0.0) * head_height - 2.0e-2 * mdot ** 2
+
+
+# ---- aerodynamics (aero.py) ----------------------------------------------------------------------------------------------
+
+def config_blend(xp, v_axial_body):                                        # aero.py:75-81
+    return 0.5 * (1.0 + xp.tanh(v_axial_body / 50.0))
+
+
+def plume_dominance(xp, thrust, qbar):                                     # aero.py:84-87
+    ct = thrust / xp.maximum(qbar * S_REF_M2, 1.0)
+    return ct / (ct + PLUME_CT0)
+
+
+def body_aero_wrench(xp, v_air_body, mach, qbar, cg, omega_body=None, ca_scale=1.0, cn_scale=1.0):   # aero.py:90-125
+    speed = xp.linalg.norm(v_air_body)
+    v_hat = v_air_body / xp.maximum(speed, 1e-6)
+    blend = config_blend(xp, v_air_body[0])
+    ca = (blend * xp.interp(mach, MACH_PTS, CA_ASCENT) + (1.0 - blend) * xp.interp(mach, MACH_PTS, CA_DESCENT)) * ca_scale
+    cn = xp.interp(mach, MACH_PTS, CN_CROSS) * cn_scale
+    x_hat = xp.array([1.0, 0.0, 0.0])
+    axial = v_hat[0]
+    cross = v_hat - axial * x_hat
+    force = -qbar * S_REF_M2 * (ca * axial * x_hat + cn * cross)
+    x_cp = blend * X_CP_ASCENT_M + (1.0 - blend) * X_CP_DESCENT_M
+    torque = xp.cross((x_cp - cg) * x_hat, force)
+    if omega_body is not None:
+        cmq = blend * CMQ_ASCENT + (1.0 - blend) * CMQ_DESCENT
+        damp = qbar * S_REF_M2 * (L_REF_DAMP_M ** 2) / (2.0 * xp.maximum(speed, 1.0)) * cmq
+        torque = torque + damp * xp.array([0.0, omega_body[1], omega_body[2]])
+    return force, torque
+
+
+# ---- quaternions on plain 4-vectors [x, y, z, w] --------------------------------------------------------------------------
+
+def quat_mul(xp, l, r):                                                    # quaternion.rs:268-281
+    return xp.array([l[3] * r[0] + l[0] * r[3] + l[1] * r[2] - l[2] * r[1],
+                     l[3] * r[1] - l[0] * r[2] + l[1] * r[3] + l[2] * r[0],
+                     l[3] * r[2] + l[0] * r[1] - l[1] * r[0] + l[2] * r[3],
+                     l[3] * r[3] - l[0] * r[0] - l[1] * r[1] - l[2] * r[2]])
+
+
+def quat_inverse(xp, q):                                                   # quaternion.rs:141-155: conj / |q|^2
+    n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]
+    return xp.array([-q[0] / n2, -q[1] / n2, -q[2] / n2, q[3] / n2])
+
+
+def quat_rotate(xp, q, v):                                                 # quaternion.rs:283-305 (unit q)
+    u = xp.array([q[0], q[1], q[2]])
+    t = 2.0 * xp.cross(u, v)
+    return v + q[3] * t + xp.cross(u, t)
+
+
+def quat_between_x(xp, to):                                                # math.rs:122-138 with from = +X
+    """Shortest rotation taking body +X onto the unit vector `to`."""
+    c = xp.clip(to[0], -1.0, 1.0)
+    ay, az = -to[2], to[1]                                                 # cross([1,0,0], to) = [0, -to_z, to_y]
+    n = xp.sqrt(ay * ay + az * az)
+    n_safe = xp.where(n > 0.0, n, 1.0)
+    half = 0.5 * xp.arccos(c)
+    s, w = xp.sin(half), xp.cos(half)
+    q = xp.array([0.0, ay / n_safe * s, az / n_safe * s, w])
+    ident = xp.array([0.0, 0.0, 0.0, 1.0])
+    flip = xp.array([0.0, 0.0, 1.0, 0.0])                                   # antipodal: 180 deg about normalize(x cross y) = +Z
+    q = xp.where(c > 1.0 - 1e-12, ident, q)
+    return xp.where(c < -1.0 + 1e-12, flip, q)
+
+
+def fsw_density(xp, alt):                                                  # math.rs:191-199 (the FSW's own two-piece model)
+    h = xp.maximum(alt, 0.0)
+    return xp.where(h < 25_000.0, 1.225 * xp.exp(-h / 8_440.0), 0.0642 * xp.exp(-(h - 25_000.0) / 6_580.0))
+
+
+# ---- host-side frames (numpy) ------------------------------------------------------------------------------------------
+
+def pad_ecef() -> np.ndarray:                                              # sim.py:1187-1188
+    return np.asarray(geodetic_to_ecef(np, math.radians(PAD_LAT_DEG), math.radians(PAD_LON_DEG), PAD_ALT_M))
+
+
+def pad_up() -> np.ndarray:                                                # frames.py:87-89 at the pad
+    return -np.asarray(ned_basis(np, math.radians(PAD_LAT_DEG), math.radians(PAD_LON_DEG))[2])
+
+
+def upright_attitude() -> np.ndarray:                                      # sim.py:1204-1211: body +X along pad up
+    up, x = pad_up(), np.array([1.0, 0.0, 0.0])
+    axis = np.cross(x, up)
+    axis /= np.linalg.norm(axis)
+    ang = math.acos(float(np.clip(x @ up, -1.0, 1.0)))
+    return np.concatenate([axis * math.sin(ang / 2.0), [math.cos(ang / 2.0)]])
+
+
+# ---- the plant, as dsl systems (one function per reference system) ---------------------------------------------------------
+
+def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, scripted=None) -> dsl.Program:
+    """`propulsion_systems | six_dof(gravity_and_frame_forces | apply_body_wrenches) | pad_clamp | telemetry | fsw`
+    (sim.py:1433-1530) for the ascent.
+
+    `origin`: world_pos is stored RELATIVE to this ECEF point (None = plain ECEF like the reference).  f32 campaigns must
+    use the pad as origin: an f32 ECEF coordinate has a 0.5 m ulp, larger than a millisecond of flight.
+    `scripted(xp, t) -> (engine_cmd[9], valve_cmd[8])` replaces the flight software by an open-loop script
+    (test_propulsion.py:113-135 `_script`) for the reference's open-loop known-answer tests.
+    Run the returned program with the semi-implicit integrator at 1 kHz (build_powered's default, sim.py:1476).
+    """
+    xp = dsl.np
+    org = tuple(float(v) for v in (origin if origin is not None else (0.0, 0.0, 0.0)))
+    dt = SIM_TIME_STEP
+    pad_rel = tuple(float(a - b) for a, b in zip(pad_ecef(), org))
+
+    def ecef(pos):                      # stored coordinates -> ECEF
+        return pos.linear() + xp.array(org)
+
+    @dsl.system
+    def attitude_control(pos, vel, inertia, attitude_setpoint, ctrl_enable, thrust_total, cg_station, fsw_phase):
+        """sim.py:649-709: inertia-scaled quaternion-error PD -> TVC gimbal command (+ RCS torque request)."""
+        q = pos.angular().vector()
+        q_inv = quat_inverse(xp, q)
+        err = quat_mul(xp, q_inv, attitude_setpoint)
+        sign = xp.where(err[3] >= 0.0, 1.0, -1.0)
+        err_vec = sign * err[:3]
+        omega_body = quat_rotate(xp, q_inv, vel.angular())
+        i_diag = inertia.inertia_diag()
+        tvc_on = (ctrl_enable[0] > 0.5) & (thrust_total > 2.0e5)
+        rcs_on = ctrl_enable[1] > 0.5
+        landing_burn = (fsw_phase >= 10.0) & (fsw_phase < 11.0)
+        wn = xp.where(tvc_on, xp.where(landing_burn, ATT_WN_TVC_LANDING, ATT_WN_TVC), ATT_WN_RCS)
+        zeta = xp.where(tvc_on, ATT_ZETA_TVC, ATT_ZETA_RCS)
+        torque_des = i_diag * (wn ** 2 * err_vec - 2.0 * zeta * wn * omega_body)
+        lever = xp.maximum(cg_station * thrust_total, 1.0)
+        tvc_cmd = xp.where(tvc_on, xp.array([-torque_des[1] / lever, -torque_des[2] / lever]), xp.zeros(2))
+        in_deadband = (xp.linalg.norm(err_vec) < 0.009) & (xp.linalg.norm(omega_body) < 0.01)
+        rcs_torque = xp.where(tvc_on, xp.array([torque_des[0], 0.0, 0.0]), torque_des)
+        rcs_torque = xp.where(rcs_on & ~in_deadband, rcs_torque, xp.zeros(3))
+        return {"tvc_cmd": tvc_cmd, "rcs_torque_cmd": rcs_torque}
+
+    @dsl.system
+    def valve_dynamics(valve_state, valve_cmd):                             # sim.py:364-369
+        return {"valve_state": actuator_step(xp, valve_state, xp.clip(valve_cmd, 0.0, 1.0), dt, VALVE_TAU_S, lo=0.0, hi=1.0)}
+
+    @dsl.system
+    def tvc_actuators(tvc_state, tvc_cmd):                                  # sim.py:513-523
+        return {"tvc_state": actuator_step(xp, tvc_state, xp.clip(tvc_cmd, -TVC_MAX_RAD, TVC_MAX_RAD), dt, TVC_TAU_S,
+                                           rate_limit=TVC_RATE_RADPS, lo=-TVC_MAX_RAD, hi=TVC_MAX_RAD)}
+
+    @dsl.system
+    def engine_dynamics(pos, engine_cmd, engine_spool, engine_armed, teateb_charges, valve_state, propellant_lox,
+                        propellant_rp1, params):
+        """sim.py:372-430: ignition gating (TEA-TEB charge + feed + igniter valves), three-regime spool, thrust with
+        ambient back-pressure, mass flow."""
+        cmd_c = xp.clip(engine_cmd, 0.0, 1.0)
+        cmd_on = cmd_c >= THROTTLE_MIN * 0.5
+        feed_open = (valve_state[VALVE_MAIN_LOX] > 0.5) & (valve_state[VALVE_MAIN_RP1] > 0.5)
+        teateb_open = valve_state[VALVE_TEATEB] > 0.5
+        prop_ok = (propellant_lox > 0.0) & (propellant_rp1 > 0.0)
+        lighting = cmd_on & (engine_armed < 0.5) & (teateb_charges >= 1.0) & feed_open & teateb_open & prop_ok
+        charges_next = teateb_charges - xp.where(lighting, xp.ones(N_ENGINES), xp.zeros(N_ENGINES))
+        armed_next = xp.where(cmd_on & ((engine_armed > 0.5) | lighting), xp.ones(N_ENGINES), xp.zeros(N_ENGINES))
+        burn_ok = (armed_next > 0.5) & feed_open & prop_ok
+        target = xp.where(burn_ok, xp.maximum(cmd_c, THROTTLE_MIN), xp.zeros(N_ENGINES))
+        running = engine_spool > 0.5 * THROTTLE_MIN
+        tau = xp.where(target > engine_spool,
+                       xp.where(running, xp.ones(N_ENGINES) * ENGINE_THROTTLE_TAU_S, xp.ones(N_ENGINES) * ENGINE_SPINUP_TAU_S),
+                       xp.ones(N_ENGINES) * ENGINE_SHUTDOWN_TAU_S)
+        spool_next = dsl.Vec([actuator_step(xp, s, t, dt, ta, lo=0.0, hi=1.0) for s, t, ta in zip(engine_spool, target, tau)])
+        _, _, alt = ecef_to_geodetic(xp, ecef(pos))
+        p_amb = pressure(xp, xp.maximum(alt, 0.0))
+        lit = spool_next > 1e-3
+        thrust_scale, isp_scale = params[P["thrust_scale"]], params[P["isp_scale"]]
+        thrust_per = xp.where(lit, engine_thrust_per_engine(xp, spool_next, p_amb) * thrust_scale, xp.zeros(N_ENGINES))
+        mdot = cluster_mdot(xp, xp.where(lit, xp.ones(N_ENGINES), xp.zeros(N_ENGINES)), spool_next) * (thrust_scale / isp_scale)
+        return {"engine_spool": spool_next, "engine_armed": armed_next, "teateb_charges": charges_next,
+                "thrust_total": xp.sum(thrust_per), "mdot_total": xp.sum(mdot)}
+
+    @dsl.system
+    def mass_props(mdot_total, propellant_lox, propellant_rp1, thrust_total, upper_mass):
+        """sim.py:433-454: deplete propellant, rebuild mass / CG / inertia from the cylinder stack."""
+        mdot_lox, mdot_rp1 = split_mdot(mdot_total)
+        lox_next = xp.maximum(propellant_lox - mdot_lox * dt, 0.0)
+        rp1_next = xp.maximum(propellant_rp1 - mdot_rp1 * dt, 0.0)
+        mass, cg, inertia_diag = stack_mass_props(xp, lox_next, rp1_next, xp.maximum(upper_mass, 0.0))
+        return {"propellant_lox": lox_next, "propellant_rp1": rp1_next, "inertia": dsl.SpatialInertia(inertia_diag, mass),
+                "cg_station": cg, "axial_specific_force": thrust_total / mass}
+
+    @dsl.system
+    def tank_dynamics(tank_pressure_lox, tank_pressure_rp1, propellant_lox, propellant_rp1, mdot_total, valve_state,
+                      axial_specific_force, cg_station):
+        """sim.py:457-507: ullage and engine-inlet pressures (telemetry; nothing downstream in the ascent reads them)."""
+        mdot_lox, mdot_rp1 = split_mdot(mdot_total)
+        p_lox = tank_pressure_step(xp, tank_pressure_lox, propellant_lox, mdot_lox, V_TANK_LOX_M3, RHO_LOX,
+                                   valve_state[VALVE_HE_INFILL_LOX], valve_state[VALVE_HE_VENT_LOX], dt)
+        p_rp1 = tank_pressure_step(xp, tank_pressure_rp1, propellant_rp1, mdot_rp1, V_TANK_RP1_M3, RHO_RP1,
+                                   valve_state[VALVE_HE_INFILL_RP1], valve_state[VALVE_HE_VENT_RP1], dt)
+        return {"tank_pressure_lox": p_lox, "tank_pressure_rp1": p_rp1,
+                "inlet_pressure_lox": inlet_pressure(xp, p_lox, propellant_lox, RHO_LOX, LOX_TANK_BOTTOM_M, cg_station,
+                                                     axial_specific_force, mdot_lox),
+                "inlet_pressure_rp1": inlet_pressure(xp, p_rp1, propellant_rp1, RHO_RP1, RP1_TANK_BOTTOM_M, cg_station,
+                                                     axial_specific_force, mdot_rp1)}
+
+    @dsl.system
+    def engine_wrench_sys(thrust_total, tvc_state, cg_station):             # sim.py:541-550
+        d = xp.array([1.0, tvc_state[1], -tvc_state[0]])
+        d = d / xp.linalg.norm(d)
+        force = thrust_total * d
+        torque = xp.cross(xp.array([-cg_station, 0.0, 0.0]), force)
+        return {"engine_wrench": xp.concatenate([force, torque])}
+
+    @dsl.system
+    def aero_dynamics(pos, vel, thrust_total, cg_station, params):
+        """sim.py:596-636 with zero wind and stowed fins: air data, body aero wrench, plume dominance."""
+        _, _, alt = ecef_to_geodetic(xp, ecef(pos))
+        alt = xp.maximum(alt, 0.0)
+        rho = density(xp, alt)
+        a_sound = speed_of_sound(xp, alt)
+        q_inv = quat_inverse(xp, pos.angular().vector())
+        v_air_body = quat_rotate(xp, q_inv, vel.linear())
+        omega_body = quat_rotate(xp, q_inv, vel.angular())
+        speed = xp.linalg.norm(v_air_body)
+        qbar = 0.5 * rho * speed ** 2
+        mach = speed / a_sound
+        f_aero, t_aero = body_aero_wrench(xp, v_air_body, mach, qbar, cg_station, omega_body=omega_body,
+                                          ca_scale=params[P["ca_scale"]], cn_scale=params[P["cn_scale"]])
+        kappa = plume_dominance(xp, thrust_total, qbar)
+        return {"qbar": qbar, "mach": mach, "aero_wrench": xp.concatenate([f_aero * (1.0 - kappa), t_aero * (1.0 - kappa)])}
+
+    @dsl.effector
+    def gravity_and_frame_forces(force, inertia, pos, vel):                 # sim.py:350-358
+        r = ecef(pos)
+        accel = gravity_accel(xp, r) + frame_accel(xp, r, vel.linear())
+        return force + dsl.SpatialForce(linear=accel * inertia.mass())
+
+    @dsl.effector(engine_wrench=6, aero_wrench=6)
+    def apply_body_wrenches(engine_wrench, aero_wrench, force, pos):        # sim.py:619-633 (fin / rcs / leg wrenches = 0)
+        total = engine_wrench + aero_wrench
+        q = pos.angular()
+        return force + dsl.SpatialForce(linear=q @ total[:3], torque=q @ total[3:])
+
+    @dsl.system
+    def pad_clamp(pos, vel, lifted, liftoff_time, thrust_total, inertia, tick):
+        """sim.py:984-1013: hold-down clamps until thrust exceeds weight, latch the release time."""
+        t_s = tick * dt
+        weight = inertia.mass() * 9.79
+        was_lifted = lifted > 0.5
+        release = was_lifted | (thrust_total > weight)
+        first = ~was_lifted & release
+        held = dsl.SpatialTransform(pos.angular(), xp.where(release, pos.linear(), xp.array(pad_rel)))
+        held_vel = dsl.SpatialMotion(xp.where(release, vel.angular(), xp.zeros(3)), xp.where(release, vel.linear(), xp.zeros(3)))
+        return {"pos": held, "vel": held_vel, "lifted": xp.where(release, 1.0, 0.0),
+                "liftoff_time": xp.where(first, t_s, liftoff_time)}
+
+    @dsl.system
+    def derive_geodetic_telemetry(pos, vel):                                # sim.py:1128-1137
+        _, _, alt = ecef_to_geodetic(xp, ecef(pos))
+        return {"altitude_geodetic": alt, "ground_speed": xp.linalg.norm(vel.linear())}
+
+    @dsl.system
+    def ascent_metrics_latch(ascent_metrics, qbar, engine_wrench, aero_wrench, inertia, tick, fsw_phase, fsw_state,
+                             altitude_geodetic, ground_speed, pos, vel):
+        """Campaign observables the reference's hooks derive from DB telemetry afterwards (hooks/score.py): Max-Q, peak
+        sensed acceleration, and the state at MECO, latched in the loop."""
+        t_s = tick * dt
+        m = ascent_metrics
+        new_q = qbar > m[0]
+        f_body = (engine_wrench[:3] + aero_wrench[:3]) / inertia.mass()
+        a_sensed = xp.linalg.norm(f_body)
+        r = ecef(pos)
+        lat, lon, _ = ecef_to_geodetic(xp, r)
+        up = -ned_basis(xp, lat, lon)[2]
+        v = vel.linear()
+        fpa = xp.rad2deg(xp.arcsin(xp.clip(xp.dot(v, up) / xp.maximum(ground_speed, 1e-9), -1.0, 1.0)))
+        downrange = xp.linalg.norm(r - xp.array(tuple(float(a) for a in pad_ecef())))
+        at_meco = (fsw_state[3] > 0.5) & (m[3] <= 0.0)          # cutoff commanded, not latched yet
+        return {"ascent_metrics": xp.array([xp.where(new_q, qbar, m[0]), xp.where(new_q, t_s, m[1]), xp.maximum(m[2], a_sensed),
+                                            xp.where(at_meco, t_s, m[3]), xp.where(at_meco, altitude_geodetic, m[4]),
+                                            xp.where(at_meco, ground_speed, m[5]), xp.where(at_meco, fpa, m[6]),
+                                            xp.where(at_meco, downrange, m[7])])}
+
+    @dsl.system(every=GUIDANCE_PERIOD_TICKS)
+    def fsw_ascent(pos, vel, inertia, tick, params, fsw_state, engine_wrench, aero_wrench):
+        """controller/src/main.rs:384-533 on truth navigation.  fsw_state = [phase, phase_t0, purge_until, meco_latched];
+        the `fsw_phase` column carries the phase the command was computed in (Command.phase is set before the
+        transition, main.rs:386-390)."""
+        t = tick * dt
+        phase, phase_t0, purge_until, meco = fsw_state[0], fsw_state[1], fsw_state[2], fsw_state[3]
+        r, v = ecef(pos), vel.linear()
+        lat, lon, alt = ecef_to_geodetic(xp, r)
+        up_here = -ned_basis(xp, lat, lon)[2]
+        speed = xp.linalg.norm(v)
+        north, east, down = (np.asarray(b) for b in ned_basis(np, math.radians(PAD_LAT_DEG), math.radians(PAD_LON_DEG)))
+        up_pad = xp.array(tuple(-down))
+        az = xp.deg2rad(params[P["azimuth_deg"]])
+        track = xp.array(tuple(north)) * xp.cos(az) + xp.array(tuple(east)) * xp.sin(az)
+        track = track / xp.linalg.norm(track)
+        u_ascent = params[P["ascent_throttle"]]
+
+        in_pad, in_rise = phase < 0.5, (phase > 0.5) & (phase < 1.5)
+        in_kick, in_turn = (phase > 1.5) & (phase < 2.5), (phase > 2.5) & (phase < 3.5)
+        powered = phase < 3.5
+
+        # PitchKick: ramp the nose from vertical toward the track azimuth
+        f_kick = xp.clip((t - phase_t0) / params[P["kick_ramp_s"]], 0.0, 1.0)
+        ang = f_kick * xp.deg2rad(params[P["kick_deg"]])
+        dir_kick = up_pad * xp.cos(ang) + track * xp.sin(ang)
+        dir_kick = dir_kick / xp.linalg.norm(dir_kick)
+        # GravityTurn: flight-path angle as a function of speed (the parametric program)
+        v0 = 90.0
+        f_turn = xp.clip((speed - v0) / (params[P["meco_speed_mps"]] - v0), 0.0, 1.0)
+        gamma = xp.deg2rad(90.0 - (90.0 - params[P["meco_fpa_deg"]]) * xp.power(f_turn, params[P["pitch_exp"]]))
+        dir_turn = up_here * xp.sin(gamma) + track * xp.cos(gamma)
+        dir_turn = dir_turn / xp.linalg.norm(dir_turn)
+        speed_safe = xp.maximum(speed, 1e-9)
+        dir_meco = v / speed_safe
+        direction = xp.where(in_kick, dir_kick, xp.where(in_turn, dir_turn, xp.where(powered, up_pad, dir_meco)))
+        attitude = quat_between_x(xp, direction)
+
+        # throttle: bucket through Max-Q, 3.6 g limit toward MECO
+        qbar_est = 0.5 * fsw_density(xp, alt) * speed * speed
+        u = xp.where((qbar_est > params[P["bucket_q_on_pa"]]) & (speed < 500.0), xp.minimum(u_ascent, params[P["bucket_throttle"]]), u_ascent)
+        a_meas = xp.linalg.norm((engine_wrench[:3] + aero_wrench[:3]) / inertia.mass())
+        u = xp.where(a_meas > 34.0, xp.maximum(u * 34.0 / xp.maximum(a_meas, 1e-9), THROTTLE_MIN), u)
+        u_turn = u
+        meco_now = in_turn & (speed >= params[P["meco_speed_mps"]])
+        light = in_pad & (t >= 0.2)
+        throttle = xp.where(in_pad, xp.where(light, u_ascent, 0.0),
+                            xp.where(in_rise | in_kick, u_ascent, xp.where(in_turn & ~meco_now, u_turn, 0.0)))
+        purge_until_next = xp.where(meco_now, t + 5.0, purge_until)
+        main_open = xp.where(powered, 1.0, 0.0)
+        valve_cmd = xp.array([1.0, 0.0, 1.0, 0.0, main_open, main_open, main_open, xp.where(t < purge_until_next, 1.0, 0.0)])
+        # transitions (one per exchange, like the `match` in main.rs)
+        to_rise = light
+        to_kick = in_rise & (t >= params[P["kick_start_s"]])
+        to_turn = in_kick & (f_kick >= 1.0) & (speed > 80.0)
+        phase_next = xp.where(to_rise, PHASE_VERTICAL_RISE, xp.where(to_kick, PHASE_PITCH_KICK, xp.where(
+            to_turn, PHASE_GRAVITY_TURN, xp.where(meco_now, PHASE_MECO, phase))))
+        changed = to_rise | to_kick | to_turn | meco_now
+        return {"engine_cmd": xp.ones(N_ENGINES) * throttle, "valve_cmd": valve_cmd, "attitude_setpoint": attitude,
+                "ctrl_enable": xp.array([xp.where(powered, 1.0, 0.0), xp.where(powered, 0.0, 1.0)]), "fsw_phase": phase,
+                "fsw_state": xp.array([phase_next, xp.where(changed, t, phase_t0), purge_until_next,
+                                       xp.where(meco_now, 1.0, meco)])}
+
+    pre = [attitude_control, valve_dynamics, tvc_actuators, engine_dynamics, mass_props, tank_dynamics, engine_wrench_sys,
+           aero_dynamics]
+    post = [pad_clamp, derive_geodetic_telemetry]
+    if scripted is not None:
+        @dsl.system
+        def script(tick):
+            eng, valves = scripted(xp, tick * dt)
+            return {"engine_cmd": eng, "valve_cmd": valves}
+        pre = [script] + pre
+    elif fsw:
+        post = post + [ascent_metrics_latch, fsw_ascent]
+    return dsl.Program(pre, gravity_and_frame_forces | apply_body_wrenches, post)
+
+
+def passive_effector(origin: Optional[Sequence[float]] = None) -> dsl.Effector:
+    """build_passive (sim.py:1341-1378): gravitation + frame forces only — the plant of the reference's verification
+    ladder (test_ladder.py)."""
+    xp = dsl.np
+    org = tuple(float(v) for v in (origin if origin is not None else (0.0, 0.0, 0.0)))
+
+    @dsl.effector
+    def gravity_and_frame_forces(force, inertia, pos, vel):
+        r = pos.linear() + xp.array(org)
+        accel = gravity_accel(xp, r) + frame_accel(xp, r, vel.linear())
+        return force + dsl.SpatialForce(linear=accel * inertia.mass())
+    return gravity_and_frame_forces
+
+
+# ---- initial state and campaign ----------------------------------------------------------------------------------------------
+
+COLUMN_WIDTHS = dict(engine_cmd=9, valve_cmd=8, engine_spool=9, engine_armed=9, teateb_charges=9, valve_state=8,
+                     thrust_total=1, mdot_total=1, propellant_lox=1, propellant_rp1=1, tank_pressure_lox=1,
+                     tank_pressure_rp1=1, inlet_pressure_lox=1, inlet_pressure_rp1=1, cg_station=1, axial_specific_force=1,
+                     qbar=1, mach=1, tvc_cmd=2, tvc_state=2, rcs_torque_cmd=3, aero_wrench=6, engine_wrench=6,
+                     attitude_setpoint=4, ctrl_enable=2, fsw_phase=1, upper_mass=1, lifted=1, liftoff_time=1,
+                     altitude_geodetic=1, ground_speed=1, params=16, fsw_state=4, ascent_metrics=8)
+
+
+def initial_columns(params: np.ndarray, origin: Optional[Sequence[float]] = None, upper_kg: float = UPPER_KG,
+                    init_pos_ecef=None, init_vel_ecef=None, init_attitude=None) -> Dict[str, np.ndarray]:
+    """build_powered's spawn (sim.py:1384-1431,1461-1510) for `n = len(params)` rollouts: the booster on the pad, upright,
+    tanks loaded per rollout."""
+    params = np.asarray(params, dtype=np.float64).reshape(-1, len(PARAM_NAMES))
+    n = params.shape[0]
+    org = np.zeros(3) if origin is None else np.asarray(origin, dtype=np.float64)
+    r0 = pad_ecef() if init_pos_ecef is None else np.asarray(init_pos_ecef, dtype=np.float64)
+    att = upright_attitude() if init_attitude is None else np.asarray(init_attitude, dtype=np.float64)
+    on_pad = float(np.linalg.norm(r0 - pad_ecef())) < 100.0
+    lox, rp1 = params[:, P["lox_kg"]], params[:, P["rp1_kg"]]
+    mass, cg, idiag = stack_mass_props(np, lox, rp1, upper_kg)
+    cols = {k: np.zeros((n, w)) for k, w in COLUMN_WIDTHS.items()}
+    cols["world_pos"] = np.tile(np.concatenate([att, r0 - org]), (n, 1))
+    cols["world_vel"] = np.zeros((n, 6))
+    if init_vel_ecef is not None:
+        cols["world_vel"][:, 3:] = np.asarray(init_vel_ecef, dtype=np.float64)
+    cols["inertia"] = np.zeros((n, 7))
+    cols["inertia"][:, :3] = np.stack([np.broadcast_to(x, (n,)) for x in idiag], axis=1)
+    cols["inertia"][:, 6] = mass
+    cols["teateb_charges"][:] = [4.0] * RELIGHT_CAPABLE_ENGINES + [1.0] * (N_ENGINES - RELIGHT_CAPABLE_ENGINES)
+    cols["propellant_lox"][:, 0], cols["propellant_rp1"][:, 0] = lox, rp1
+    for k in ("tank_pressure_lox", "tank_pressure_rp1", "inlet_pressure_lox", "inlet_pressure_rp1"):
+        cols[k][:] = TANK_P_NOM_PA
+    cols["cg_station"][:] = DRY_CG_STATION_M
+    cols["attitude_setpoint"][:] = upright_attitude()
+    cols["upper_mass"][:] = upper_kg
+    cols["lifted"][:] = 0.0 if on_pad else 1.0
+    cols["params"][:] = params
+    return cols
+
+
+def default_param_row() -> np.ndarray:
+    return np.array([DEFAULT_PARAMS[k] for k in PARAM_NAMES])
+
+
+def sample_params(n: int, seed: int = SPEC_SEED) -> np.ndarray:
+    """spec.toml's LHS plan for the ascent variables through the same sampler as `elodin monte-carlo plan`
+    (elodin_amd.monte_carlo, byte-identical to sample.py:84-151); the remaining columns keep their calibrated default."""
+    from .. import monte_carlo as mc
+    plan = mc.materialize({"monte_carlo": {"n_samples": n, "seed": seed, "method": "lhs", "variables": {
+        k: {"dist": "uniform", "min": lo, "max": hi} for k, (lo, hi) in SPEC_RANGES.items()}}})
+    return plan.table(PARAM_NAMES, DEFAULT_PARAMS)
+
+
+ASCENT_TICKS = 170_000            # 170 s of flight at 1 kHz: every rollout of spec.toml's ranges reaches MECO by then
+
+
+class AscentExec:
+    """One block of ascent rollouts on one GPU: rows = rollouts, the closed loop runs as a generated program
+    (sixdof_set_custom_pipe) with `ticks_per_launch` ticks per launch and all state in registers in between."""
+
+    def __init__(self, params: np.ndarray, *, dtype=np.float64, local_origin: Optional[bool] = None,
+                 ticks_per_launch: int = 1000, device: int = 0, fsw: bool = True, scripted=None, columns=None):
+        from .. import _lib as L
+        from ..exec import HipExec
+        dtype = np.dtype(dtype)
+        # f32 state cannot hold ECEF metres (0.5 m ulp): integrate pad-relative coordinates instead
+        local = (dtype == np.float32) if local_origin is None else bool(local_origin)
+        self.origin = pad_ecef() if local else np.zeros(3)
+        self.program = build_program(origin=self.origin if local else None, fsw=fsw, scripted=scripted)
+        cols = initial_columns(params, origin=self.origin) if columns is None else dict(columns)
+        body = {k: cols.pop(k) for k in ("world_pos", "world_vel", "inertia")}
+        self.hip = HipExec(body["world_pos"], body["world_vel"], body["inertia"], integrator=L.SEMI_IMPLICIT, dtype=dtype,
+                           simulation_time_step=SIM_TIME_STEP, effectors=self.program, columns=cols,
+                           ticks_per_launch=ticks_per_launch, device=device)
+
+    def run(self, ticks: int):
+        return self.hip.run(ticks)
+
+    def column(self, name: str) -> np.ndarray:
+        if name in ("world_pos", "world_vel", "world_accel", "force", "inertia"):
+            return getattr(self.hip, name)
+        return self.hip._aux[name]
+
+    @property
+    def ecef(self) -> np.ndarray:
+        return self.hip.world_pos[:, 4:].astype(np.float64) + self.origin
+
+    @property
+    def result(self) -> np.ndarray:
+        """[n, 8] METRIC_NAMES."""
+        return np.asarray(self.hip._aux["ascent_metrics"], dtype=np.float64)
+
+    def close(self):
+        self.hip.close()
+
+
+def run_campaign(plan_table: Optional[np.ndarray], n_runs: int, n_ticks: int = ASCENT_TICKS, *, dtype=np.float32,
+                 ticks_per_launch: int = 1000, device: int = 0, comm_device="cpu") -> np.ndarray:
+    """One ascent campaign across the ranks of the current torch.distributed group (or one process): rank 0's plan table
+    ([n_runs, 16], sample_params) is broadcast, every rank flies its contiguous block of run ids with no per-step
+    exchange, result rows are gathered back in run-id order (same scheme as models/apollo.run_campaign)."""
+    from .. import shard
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    table = shard.broadcast_table(plan_table, (n_runs, len(PARAM_NAMES)), device=comm_device)
+    lo, hi = shard.shard_range(n_runs, world, rank)
+    ex = AscentExec(table[lo:hi], dtype=dtype, ticks_per_launch=ticks_per_launch, device=device)
+    ex.run(n_ticks)
+    local = np.ascontiguousarray(ex.result)
+    ex.close()
+    return shard.gather_rows(local, n_runs, device=comm_device)

@@ -251,7 +251,7 @@ int sixdof_bind_world(sixdof_handle* h, sixdof_world* w);
  * builds it with hipcc for gfx950 and hands the shared object to this call.  `aux_component_ids` name the bound
  * per-entity columns the generated code uses, in the order it indexes them: first the read-only effector
  * columns (row width 1..3, <= 4), then — for whole programs `pre | six_dof(effectors) | post` — the component
- * columns its systems read AND write (row width 1..8, <= 16; fetch them back with sixdof_download_column).
+ * columns its systems read AND write (row width 1..16, <= 48; fetch them back with sixdof_download_column).
  * Replaces the built-in op list (sixdof_set_effectors) for the per-entity path. */
 int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t* aux_component_ids, size_t n_aux);
 /* Same idea for GraphQuery.edge_fold (graph.rs:177-282) with a user-written fold function over

@@ -5,7 +5,7 @@ import numpy as np
 _F1 = {"sqrt": np.sqrt, "abs": np.abs, "sin": np.sin, "cos": np.cos, "tan": np.tan, "exp": np.exp, "log": np.log,
        "acos": np.arccos, "asin": np.arcsin, "neg": np.negative, "not": np.logical_not}
 _F2 = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "max": np.fmax, "min": np.fmin,
-       "atan2": np.arctan2, "hypot": np.hypot, "lt": np.less, "le": np.less_equal, "and": np.logical_and,
+       "atan2": np.arctan2, "hypot": np.hypot, "pow": np.power, "lt": np.less, "le": np.less_equal, "and": np.logical_and,
        "or": np.logical_or}
 
 
@@ -152,3 +152,30 @@ def program_tick(tp, pos, vel, accel, inertia, comps, tick, dt_g, integrator):
     pos[:], vel[:], accel[:] = pos2, vel2, acc2
     _run_systems(tp.post, pos, vel, inertia, comps, tp.table, tick)
     return F
+
+
+# ---- tracing plain helper functions (models/falcon9.py physics helpers) ----------------------------------------------------
+
+def trace_eval(fn, *args):
+    """Call `fn(dsl.np, *leaves)` with every numeric argument replaced by traced leaves (floats -> scalar nodes,
+    sequences -> Vec), then evaluate the resulting DAG with numpy.  Mirrors the structure of fn's return value
+    (scalar, vector or tuple of those) with floats / 1-D arrays: what the generated kernel code computes, on the host."""
+    from elodin_amd import dsl
+    leaves, traced = {}, []
+    for k, a in enumerate(args):
+        if np.ndim(a) == 0:
+            leaves[f"arg{k}"] = np.array([float(a)])
+            traced.append(dsl.leaf(f"arg{k}"))
+        else:
+            for j, v in enumerate(a):
+                leaves[f"arg{k}_{j}"] = np.array([float(v)])
+            traced.append(dsl.Vec([dsl.leaf(f"arg{k}_{j}") for j in range(len(a))]))
+    out = fn(dsl.np, *traced)
+
+    def value(o):
+        if isinstance(o, (tuple, list)):
+            return tuple(value(x) for x in o)
+        if isinstance(o, dsl.Vec):
+            return np.array([v[0] for v in _eval(list(o.e), leaves, 1)])
+        return float(_eval([dsl._lift(o)], leaves, 1)[0][0])
+    return value(out)
