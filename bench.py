@@ -14,8 +14,8 @@ collective — torch.distributed is only the launcher's barrier and the max-over
 Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel, ticks_per_launch = 1,
 algorithmic bytes 360 + 24 = 384 B/entity-step against the 8 TB/s HBM peak), `roofline_hbm` (same kernel at
 4,194,304 bodies, where the working set leaves the 256 MiB Infinity Cache and the kernel really
-streams from HBM), `fused` (ticks_per_launch = 64: state in registers, VALU-bound), `nbody` / `apollo_mc`
-(timings of BASELINE configs[2] / configs[3] on this GPU) and `cpu_baseline` (the CPU oracle on the host
+streams from HBM), `fused` (ticks_per_launch = 64: state in registers, VALU-bound), `nbody` / `apollo_mc` /
+`falcon9_mc` (timings of BASELINE configs[2] / configs[3] / configs[4] on this GPU) and `cpu_baseline` (the CPU oracle on the host
 cores, bounded sample, N=1 only).
 """
 from __future__ import annotations
@@ -175,6 +175,31 @@ def apollo_leg(device):
             "launches": tm.launches, "integrator": "semi-implicit", "guidance": "in-kernel, 24 Hz"}
 
 
+def falcon9_leg(device):
+    """BASELINE configs[4]: Falcon 9 ascent Monte-Carlo, 32,768 rollouts, f32, the whole ascent to past MECO (one GPU's
+    worth here; the closed loop is a generated program: models/falcon9.py)."""
+    from elodin_amd.models import falcon9 as f9
+    n = 32768
+    ex = f9.AscentExec(f9.sample_params(n), dtype=np.float32, ticks_per_launch=1000, device=device)
+    ex.hip.invoke_batch(1000)
+    t0 = time.perf_counter()
+    tm = ex.hip.invoke_batch(f9.ASCENT_TICKS - 1000)
+    dt = time.perf_counter() - t0
+    ex.hip.download()
+    res = ex.result
+    widths = dict(ex.program.trace().columns)
+    state_bytes = 4 * (sum(widths.values()) + 7 + 6 + 6 + 6 + 7)
+    ex.close()
+    steps = f9.ASCENT_TICKS - 1000
+    return {"rollouts": n, "steps": steps, "seconds": round(dt, 4), "rollout_steps_per_s": round(n * steps / dt, 1),
+            "dtype": "f32", "launches": tm.launches, "integrator": "semi-implicit @ 1 kHz", "guidance": "in-kernel, 100 Hz",
+            "bound": "valu (state stays in registers for 1000 ticks per launch)",
+            "state_bytes_per_rollout": state_bytes,
+            "hbm_GBps_if_every_tick_round_tripped": round(2 * state_bytes * n * steps / dt / 1e9, 1),
+            "reached_meco": int(np.sum(res[:, 3] > 0.0)), "meco_t_s": [round(float(res[:, 3].min()), 2), round(float(res[:, 3].max()), 2)],
+            "meco_alt_km": [round(float(res[:, 4].min()) / 1e3, 2), round(float(res[:, 4].max()) / 1e3, 2)]}
+
+
 def cpu_baseline(w, eff, target_seconds=10.0):
     """The CPU oracle (a port of the reference arithmetic; the reference itself needs rustc + jax) timed
     on this host's cores on a bounded sample of the same workload."""
@@ -313,6 +338,7 @@ def main():
         extra("f32", f32_leg, local_rank)
         extra("nbody", nbody_leg, local_rank)
         extra("apollo_mc", apollo_leg, local_rank)
+        extra("falcon9_mc", falcon9_leg, local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         extra("cpu_baseline", cpu_baseline, w, eff)
     if distributed:

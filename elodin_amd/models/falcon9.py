@@ -772,8 +772,20 @@ class AscentExec:
         self.hip.close()
 
 
+def prebuild() -> list:
+    """Generate + compile the campaign programs ahead of time (f32 pad-relative, f64 ECEF): __graft_entry__.build() calls
+    this so a GPU box finds them in elodin_amd/_jit instead of running hipcc at first use."""
+    from .. import codegen
+    out = []
+    cols = initial_columns(default_param_row()[None, :])
+    widths = {k: v.shape[1] for k, v in cols.items()}
+    for dtype, origin in (("float32", pad_ecef()), ("float64", None), ("float64", pad_ecef())):
+        out.append(codegen.build(build_program(origin=origin).trace(widths), dtype, 1))
+    return out
+
+
 def run_campaign(plan_table: Optional[np.ndarray], n_runs: int, n_ticks: int = ASCENT_TICKS, *, dtype=np.float32,
-                 ticks_per_launch: int = 1000, device: int = 0, comm_device="cpu") -> np.ndarray:
+                 ticks_per_launch: int = 1000, device: int = 0, comm_device="cpu", make_exec=None) -> np.ndarray:
     """One ascent campaign across the ranks of the current torch.distributed group (or one process): rank 0's plan table
     ([n_runs, 16], sample_params) is broadcast, every rank flies its contiguous block of run ids with no per-step
     exchange, result rows are gathered back in run-id order (same scheme as models/apollo.run_campaign)."""
@@ -783,8 +795,11 @@ def run_campaign(plan_table: Optional[np.ndarray], n_runs: int, n_ticks: int = A
     rank = dist.get_rank() if world > 1 else 0
     table = shard.broadcast_table(plan_table, (n_runs, len(PARAM_NAMES)), device=comm_device)
     lo, hi = shard.shard_range(n_runs, world, rank)
-    ex = AscentExec(table[lo:hi], dtype=dtype, ticks_per_launch=ticks_per_launch, device=device)
+    if make_exec is None:
+        make_exec = lambda block, first_row: AscentExec(block, dtype=dtype, ticks_per_launch=ticks_per_launch, device=device)
+    ex = make_exec(table[lo:hi], lo)
     ex.run(n_ticks)
     local = np.ascontiguousarray(ex.result)
-    ex.close()
+    if hasattr(ex, "close"):
+        ex.close()
     return shard.gather_rows(local, n_runs, device=comm_device)

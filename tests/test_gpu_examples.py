@@ -40,6 +40,11 @@ def test_apollo_campaign_example():
     assert res.shape == (256, 12) and res[:, 8].mean() == 1.0 and res[:, 9].mean() > 0.6
 
 
+def test_falcon9_ascent_example():
+    res = _load("falcon9_ascent").main(128, "f32")
+    assert res.shape == (128, 8) and np.all(res[:, 3] > 100.0) and np.all(res[:, 0] > 14_000.0)   # all reach MECO past Max-Q
+
+
 def test_plain_c_host_over_the_abi(tmp_path):
     """examples/c_host.c: gcc-built host, no Python in the loop; its output must match the reference's golden row."""
     import subprocess

@@ -130,3 +130,65 @@ def test_apollo_campaign_two_ranks_equals_one():
     res1 = apollo.run_campaign(table, 30, 59041, make_exec=_OracleExec)
     assert res2.shape == (30, 12) and np.array_equal(res1, res2)     # run-id order, bit-identical
     assert np.all(res2[:, 8] == 1.0)
+
+
+# ---- Falcon 9 ascent campaign (config 5): same sharding scheme, program stepped on the host by the numpy evaluator ----------
+
+class _NumpyAscentExec:
+    """Stand-in for models.falcon9.AscentExec on a CPU-only box: the SAME traced program, stepped by
+    tests/dsl_numpy.program_tick.  `result` = a few state columns (the metrics latch needs a whole flight)."""
+
+    def __init__(self, block, first_row):
+        from elodin_amd.models import falcon9 as f9
+        self.f9 = f9
+        cols = f9.initial_columns(block)
+        self.tp = f9.build_program().trace({k: v.shape[1] for k, v in cols.items()})
+        self.pos, self.vel, self.inertia = cols.pop("world_pos"), cols.pop("world_vel"), cols.pop("inertia")
+        self.acc = np.zeros_like(self.vel)
+        self.comps = {name: cols[name] for name, _ in self.tp.columns}
+        self.tick = 0
+
+    def run(self, n):
+        from elodin_amd import _lib as L
+        from tests import dsl_numpy
+        for _ in range(n):
+            self.tick += 1
+            dsl_numpy.program_tick(self.tp, self.pos, self.vel, self.acc, self.inertia, self.comps, self.tick,
+                                   self.f9.SIM_TIME_STEP, L.SEMI_IMPLICIT)
+
+    @property
+    def result(self):
+        c = self.comps
+        return np.concatenate([c["thrust_total"], c["propellant_lox"], c["engine_spool"][:, :1], c["valve_state"][:, 4:5],
+                               c["fsw_state"][:, :1], self.inertia[:, 6:7], c["tank_pressure_lox"], c["params"][:, :1]], axis=1)
+
+
+def _falcon9_worker(rank, world, port, q):
+    from elodin_amd.models import falcon9 as f9
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = f9.run_campaign(f9.sample_params(5) if rank == 0 else None, 5, 450, make_exec=_NumpyAscentExec)
+        if rank == 0:
+            q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_falcon9_campaign_two_ranks_equals_one():
+    from elodin_amd.models import falcon9 as f9
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_falcon9_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res2 = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    params = f9.sample_params(5)
+    res1 = f9.run_campaign(params, 5, 450, make_exec=_NumpyAscentExec)
+    assert res2.shape == (5, 8) and np.array_equal(res1, res2)         # run-id order, bit-identical (3 + 2 rows)
+    assert np.array_equal(res2[:, 7], params[:, 0])                    # every rank flew ITS rows of rank 0's table
+    assert np.all(res2[:, 0] > 1.0e5) and np.all(res2[:, 4] == 1.0)     # 0.25 s after ignition: engines spooling up, VerticalRise
