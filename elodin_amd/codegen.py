@@ -14,7 +14,7 @@ import hashlib
 import os
 import subprocess
 from pathlib import Path
-from typing import Dict, List
+from typing import Dict, List, Sequence
 
 from . import dsl
 
@@ -63,58 +63,94 @@ def _leaf_ref(name: str, table: Dict[str, str]) -> str:
 _TABLES: Dict[tuple, str] = {}    # (xp, fp) -> C++ symbol stem, filled while emitting one translation unit
 
 
+class _Emitter:
+    """Straight-line C++ for lists of (lvalue, Expr).  Every output of a block is computed into a temporary before any
+    is written (a system may read a component it also writes); common sub-expressions are emitted once — also ACROSS the
+    blocks of one function as long as none of the leaves they read has been written in between (two systems that both
+    convert the same position to geodetic coordinates share the conversion)."""
+
+    def __init__(self, leaves: Dict[str, str]):
+        self.leaves = leaves
+        self.names: Dict[int, str] = {}      # id(Expr) -> C++ temporary holding it
+        self.keep: Dict[int, dsl.Expr] = {}   # keeps the Exprs alive so ids stay unique
+        self.deps: Dict[int, frozenset] = {}
+        self.n = 0
+
+    def _deps(self, e: dsl.Expr) -> frozenset:
+        d = self.deps.get(id(e))
+        if d is None:
+            if e.op == "leaf":
+                d = frozenset((e.name,))
+            else:
+                d = frozenset().union(*[self._deps(a) for a in e.args]) if e.args else frozenset()
+            self.deps[id(e)] = d
+            self.keep[id(e)] = e
+        return d
+
+    def block(self, assign, indent: str = "        ", written: Sequence[str] = (), scoped: bool = False) -> List[str]:
+        """assign: [(lvalue, Expr)]; written: the leaf names those lvalues correspond to (invalidates dependants);
+        scoped: the block sits inside a conditional — temporaries created in it must not be reused outside."""
+        lines: List[str] = []
+        before = set(self.names)
+
+        def ref(e: dsl.Expr) -> str:
+            if e.op == "const":
+                return _literal(e.value)
+            if e.op == "leaf":
+                return _leaf_ref(e.name, self.leaves)
+            if id(e) in self.names:
+                return self.names[id(e)]
+            a = [ref(x) for x in e.args]
+            if e.op in _BIN:
+                rhs = f"{a[0]} {_BIN[e.op]} {a[1]}"
+            elif e.op == "neg":
+                rhs = f"-{a[0]}"
+            elif e.op in _FN1:
+                rhs = f"{_FN1[e.op]}({a[0]})"
+            elif e.op in _FN2:
+                rhs = f"{_FN2[e.op]}({a[0]}, {a[1]})"
+            elif e.op == "select":
+                rhs = f"{a[0]} ? {a[1]} : {a[2]}"
+            elif e.op == "interp":
+                stem = _TABLES.setdefault(e.value, f"tab{len(_TABLES)}")
+                rhs = f"m_interp<T, {len(e.value[0])}>({a[0]}, {stem}_x, {stem}_f)"
+            elif e.op == "lt":
+                rhs = f"{a[0]} < {a[1]}"
+            elif e.op == "le":
+                rhs = f"{a[0]} <= {a[1]}"
+            elif e.op == "and":
+                rhs = f"{a[0]} && {a[1]}"
+            elif e.op == "or":
+                rhs = f"{a[0]} || {a[1]}"
+            elif e.op == "not":
+                rhs = f"!{a[0]}"
+            else:
+                raise ValueError(f"unsupported op {e.op}")
+            name = f"t{self.n}"
+            self.n += 1
+            self.names[id(e)] = name
+            self._deps(e)
+            ctype = "bool" if e.op in _BOOL_OPS else "T"
+            lines.append(f"{indent}const {ctype} {name} = {rhs};")
+            return name
+
+        outs = []
+        for lv, e in assign:
+            o = f"o{self.n}"
+            self.n += 1
+            lines.append(f"{indent}const T {o} = {ref(e)};")
+            outs.append((lv, o))
+        for lv, o in outs:
+            lines.append(f"{indent}{lv} = {o};")
+        wr = set(written)
+        for k in list(self.names):
+            if (scoped and k not in before) or (wr and self.deps[k] & wr):
+                del self.names[k]
+        return lines
+
+
 def emit_block(assign, leaves: Dict[str, str], indent: str = "        ") -> List[str]:
-    """Straight-line C++ for a list of (lvalue, Expr): every output is computed into a temporary first (a system may
-    read a component it also writes), common sub-expressions are emitted once, in dependency order."""
-    names: Dict[int, str] = {}
-    lines: List[str] = []
-
-    def ref(e: dsl.Expr) -> str:
-        if e.op == "const":
-            return _literal(e.value)
-        if e.op == "leaf":
-            return _leaf_ref(e.name, leaves)
-        if id(e) in names:
-            return names[id(e)]
-        a = [ref(x) for x in e.args]
-        if e.op in _BIN:
-            rhs = f"{a[0]} {_BIN[e.op]} {a[1]}"
-        elif e.op == "neg":
-            rhs = f"-{a[0]}"
-        elif e.op in _FN1:
-            rhs = f"{_FN1[e.op]}({a[0]})"
-        elif e.op in _FN2:
-            rhs = f"{_FN2[e.op]}({a[0]}, {a[1]})"
-        elif e.op == "select":
-            rhs = f"{a[0]} ? {a[1]} : {a[2]}"
-        elif e.op == "interp":
-            stem = _TABLES.setdefault(e.value, f"tab{len(_TABLES)}")
-            rhs = f"m_interp<T, {len(e.value[0])}>({a[0]}, {stem}_x, {stem}_f)"
-        elif e.op == "lt":
-            rhs = f"{a[0]} < {a[1]}"
-        elif e.op == "le":
-            rhs = f"{a[0]} <= {a[1]}"
-        elif e.op == "and":
-            rhs = f"{a[0]} && {a[1]}"
-        elif e.op == "or":
-            rhs = f"{a[0]} || {a[1]}"
-        elif e.op == "not":
-            rhs = f"!{a[0]}"
-        else:
-            raise ValueError(f"unsupported op {e.op}")
-        name = f"t{len(names)}"
-        names[id(e)] = name
-        ctype = "bool" if e.op in _BOOL_OPS else "T"
-        lines.append(f"{indent}const {ctype} {name} = {rhs};")
-        return name
-
-    outs = []
-    for k, (lv, e) in enumerate(assign):
-        lines.append(f"{indent}const T o{k} = {ref(e)};")
-        outs.append((lv, f"o{k}"))
-    for lv, o in outs:
-        lines.append(f"{indent}{lv} = {o};")
-    return lines
+    return _Emitter(leaves).block(assign, indent)
 
 
 def emit_apply(tp: dsl.TracedPipe) -> List[str]:
@@ -124,11 +160,16 @@ def emit_apply(tp: dsl.TracedPipe) -> List[str]:
 
 def _emit_systems(systems) -> str:
     out = []
+    em = _Emitter(_SYSTEM_LEAVES)
     for s in systems:
         assign = [(_leaf_ref(t, _SYSTEM_LEAVES), e) for t, e in s.assign]
-        body = "\n".join(emit_block(assign, _SYSTEM_LEAVES, indent="            "))
-        guard = f"if (tick % {s.every}ull == 0ull) " if s.every > 1 else ""
-        out.append(f"        {guard}{{  // {s.name}\n{body}\n        }}")
+        written = [t for t, _ in s.assign]
+        if s.every > 1:     # wave-uniform cadence branch: its temporaries stay inside
+            body = "\n".join(em.block(assign, "            ", written, scoped=True))
+            out.append(f"        if (tick % {s.every}ull == 0ull) {{  // {s.name}\n{body}\n        }}")
+        else:
+            body = "\n".join(em.block(assign, "        ", written))
+            out.append(f"        // {s.name}\n{body}")
     return "\n".join(out)
 
 

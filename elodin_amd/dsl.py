@@ -56,7 +56,7 @@ class Expr:
     def __rmul__(self, o): return _bin("mul", o, self)
     def __truediv__(self, o): return NotImplemented if isinstance(o, Vec) else _bin("div", self, o)
     def __rtruediv__(self, o): return _bin("div", o, self)
-    def __neg__(self): return Expr("neg", (self,))
+    def __neg__(self): return const(-self.value) if self.op == "const" else Expr("neg", (self,))
     def __pow__(self, k):
         if isinstance(k, int) and k >= 1:      # jnp integer_pow: repeated multiply
             r = self
@@ -96,8 +96,42 @@ def _lift(x) -> Expr:
     raise TypeError(f"cannot use {type(x).__name__} in a traced effector")
 
 
+def _const_tree(e: "Expr") -> bool:
+    """const, or a select whose both branches are const trees (e.g. a time constant picked by regime)."""
+    return e.op == "const" or (e.op == "select" and _const_tree(e.args[1]) and _const_tree(e.args[2]))
+
+
+def _map_const_tree(e: "Expr", f) -> "Expr":
+    if e.op == "const":
+        return f(e)
+    return Expr("select", (e.args[0], _map_const_tree(e.args[1], f), _map_const_tree(e.args[2], f)))
+
+
+_FOLD1 = {"sqrt": math.sqrt, "abs": abs, "sin": math.sin, "cos": math.cos, "tan": math.tan, "exp": math.exp, "log": math.log,
+          "acos": math.acos, "asin": math.asin}
+
+
+def _un(op: str, x) -> "Expr":
+    """Unary node with constant folding, also through selects of constants: exp(-dt / where(c, tau1, tau2)) becomes
+    where(c, k1, k2) — what a JIT's constant propagation does with a regime-dependent time constant."""
+    x = _lift(x)
+    if x.op == "const" and op in _FOLD1:
+        try:
+            return const(_FOLD1[op](x.value))
+        except (ValueError, OverflowError):
+            pass
+    elif x.op == "select" and op in _FOLD1 and _const_tree(x):
+        return _map_const_tree(x, lambda c: _un(op, c))
+    return Expr(op, (x,))
+
+
 def _bin(op: str, a, b) -> Expr:
     a, b = _lift(a), _lift(b)
+    if op in ("add", "sub", "mul", "div"):
+        if a.op == "const" and b.op == "select" and _const_tree(b):
+            return _map_const_tree(b, lambda c: _bin(op, a, c))
+        if b.op == "const" and a.op == "select" and _const_tree(a):
+            return _map_const_tree(a, lambda c: _bin(op, c, b))
     # constant folding (Python float arithmetic = IEEE double, what a JIT would bake) and the identities
     # x+0, x-0, 0+x, x*1, 1*x, x/1 (exact up to the sign of zero)
     if a.op == "const" and b.op == "const" and op in ("add", "sub", "mul", "div"):
@@ -153,8 +187,8 @@ class Vec:
 def _unary(op):
     def f(x):
         if isinstance(x, Vec):
-            return Vec([Expr(op, (a,)) for a in x.e])
-        return Expr(op, (_lift(x),))
+            return Vec([_un(op, a) for a in x.e])
+        return _un(op, x)
     return f
 
 

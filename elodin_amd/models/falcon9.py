@@ -729,7 +729,7 @@ def sample_params(n: int, seed: int = SPEC_SEED) -> np.ndarray:
     return plan.table(PARAM_NAMES, DEFAULT_PARAMS)
 
 
-ASCENT_TICKS = 170_000            # 170 s of flight at 1 kHz: every rollout of spec.toml's ranges reaches MECO by then
+ASCENT_TICKS = 180_000            # 180 s of flight at 1 kHz: every rollout of spec.toml's ranges reaches MECO by then (latest ~T+170 s)
 
 
 class AscentExec:
