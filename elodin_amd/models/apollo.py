@@ -145,6 +145,15 @@ class ApolloExec(HipExec):
         return {name: self.model["apollo_result"][:, j] for j, name in enumerate(RESULT_NAMES[:-1])}
 
 
+def result_record(row: Mapping[str, float]) -> Dict[str, object]:
+    """One RESULT_NAMES row as the `result.json` the example's sim writes at touchdown (flags as booleans, the tick as an
+    integer), which `hooks/score.py` reads back (`landed`, `soft_landing`, `touchdown_speed`, ...)."""
+    rec: Dict[str, object] = {k: float(v) for k, v in row.items() if k != "reserved"}
+    rec["landed"], rec["soft_landing"] = bool(row["landed"]), bool(row["soft_landing"])
+    rec["tick"] = int(row["tick"])
+    return rec
+
+
 def run_campaign(plan_table: np.ndarray | None, n_runs: int, n_ticks: int, *, ticks_per_launch: int = 1000,
                  device: int = 0, comm_device="cpu", make_exec=None) -> np.ndarray:
     """One Monte-Carlo campaign across the ranks of the current torch.distributed group (or one process).

@@ -35,9 +35,15 @@ def test_nbody_example_small():
     assert np.all(np.abs(mom) < 1e-12)
 
 
-def test_apollo_campaign_example():
-    res = _load("apollo_campaign").main(256)
+def test_apollo_campaign_example(tmp_path):
+    import csv
+    import json
+    res = _load("apollo_campaign").main(256, tmp_path / "camp")
     assert res.shape == (256, 12) and res[:, 8].mean() == 1.0 and res[:, 9].mean() > 0.6
+    rows = list(csv.DictReader(open(tmp_path / "camp" / "results.csv")))
+    summary = json.loads((tmp_path / "camp" / "summary.json").read_text())
+    assert len(rows) == 256 and summary["passed"] == int(res[:, 9].sum()) == sum(r["passed"] == "true" for r in rows)
+    assert abs(float(rows[7]["touchdown_speed_mps"]) - res[7, 0]) < 1e-12
 
 
 def test_falcon9_ascent_example():
