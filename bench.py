@@ -175,6 +175,37 @@ def apollo_leg(device):
             "launches": tm.launches, "integrator": "semi-implicit", "guidance": "in-kernel, 24 Hz"}
 
 
+def telemetry_leg(device, n):
+    """The commit step either side of the path: every batch of ticks is followed by a copy of the four output columns
+    into the host columns (exec.rs:110-172 + commit_world_head).  `sync` = step, then a blocking download (what JaxExec
+    does, jax_exec.rs:150-178); `streaming` = sixdof_download_async, the copy overlapping the next batch.  Two batch
+    shapes: 8 ticks fused in one launch (compute << copy: PCIe-bound either way) and 48 single-tick launches (compute ~
+    copy: the overlap shows)."""
+    from elodin_amd import _lib as L
+    mask = L.COL_ALL & ~L.COL_INERTIA
+    mb = n * 8 * (7 + 6 + 6 + 6) / 1e6
+    out = {"entities": n, "column_MB_per_batch": round(mb, 2)}
+    for label, tpl, k, batches in (("fused8", 8, 8, 200), ("k1x48", 1, 48, 100)):
+        ex, w, eff = make_exec(n, 0, device, tpl, False)
+        ex.invoke_batch(k)
+        ex.download(mask)
+        t0 = time.perf_counter()
+        for _ in range(batches):
+            ex.invoke_batch(k)
+            ex.download(mask)
+        sync_s = time.perf_counter() - t0
+        ex.run_streaming(8, k)
+        stream_s = ex.run_streaming(batches, k)
+        ex.close()
+        out[label] = {"ticks_per_batch": k, "ticks_per_launch": tpl, "batches": batches,
+                      "sync_ms_per_batch": round(sync_s / batches * 1e3, 4),
+                      "streaming_ms_per_batch": round(stream_s / batches * 1e3, 4),
+                      "streaming_host_GBps": round(mb * batches / stream_s / 1e3, 2),
+                      "entity_steps_per_s_sync": round(n * k * batches / sync_s, 1),
+                      "entity_steps_per_s_streaming": round(n * k * batches / stream_s, 1)}
+    return out
+
+
 def falcon9_leg(device):
     """BASELINE configs[4]: Falcon 9 ascent Monte-Carlo, 32,768 rollouts, f32, the whole ascent to past MECO (one GPU's
     worth here; the closed loop is a generated program: models/falcon9.py)."""
@@ -337,6 +368,7 @@ def main():
         extra("generated_pipe", generated_leg, local_rank, n)
         extra("f32", f32_leg, local_rank)
         extra("nbody", nbody_leg, local_rank)
+        extra("telemetry_commit", telemetry_leg, local_rank, n)
         extra("apollo_mc", apollo_leg, local_rank)
         extra("falcon9_mc", falcon9_leg, local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -21,6 +21,7 @@ F64, F32 = 0, 1
 PRIM_F64, PRIM_U64, PRIM_F32 = 0, 1, 2
 FLAG_USE_GRAPH = 1
 FLAG_TIME_EACH_LAUNCH = 2
+FLAG_ASYNC_STEP = 4
 
 EFF_CONST_WRENCH = 1
 EFF_UNIFORM_GRAVITY = 2
@@ -108,6 +109,9 @@ SYMBOLS = {
     "sixdof_bind_world": (C.c_int, [_H, C.c_void_p]),
     "sixdof_set_custom_pipe": (C.c_int, [_H, C.c_char_p, C.POINTER(C.c_uint64), C.c_size_t]),
     "sixdof_set_custom_pair": (C.c_int, [_H, C.c_char_p]),
+    "sixdof_download_async": (C.c_int, [_H, C.c_uint32]),
+    "sixdof_download_wait": (C.c_int, [_H]),
+    "sixdof_sync": (C.c_int, [_H]),
     "sixdof_set_history": (C.c_int, [_H, C.c_uint32]),
     "sixdof_history_read": (C.c_int, [_H, C.c_uint64, C.c_uint64, C.c_void_p]),
     "sixdof_set_model_apollo": (C.c_int, [_H, C.c_void_p]),

@@ -208,7 +208,7 @@ def write_campaign(out_dir, plan, results: np.ndarray, result_names: Sequence[st
         run_dir.mkdir(exist_ok=True)
         row = {name: float(results[i, k]) for k, name in enumerate(result_names)}
         record = result_record(row) if result_record else row
-        (run_dir / "result.json").write_text(json.dumps(record, indent=2, sort_keys=True, allow_nan=False, default=float) + "\n")
+        (run_dir / "result.json").write_text(json.dumps(_jsonable(record), indent=2, sort_keys=True, allow_nan=False) + "\n")
         bad = bool(failed_rows[i]) if failed_rows is not None else False
         m = RunMetric(run_id, status="failed" if bad else "ok", exit_ok=not bad,
                       failure_reason="non-finite state" if bad else None, wall_ms=per_run_ms,

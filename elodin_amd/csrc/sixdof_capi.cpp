@@ -49,6 +49,8 @@ struct Column {
     void* compact = nullptr;
     void* live = nullptr;
     bool joined = false;   // join resolved for the current binding
+    void* snap = nullptr;  // owned: device snapshot the async telemetry copy reads (sixdof_download_async)
+    bool host_pinned = false;   // host buffer page-locked by us (hipHostRegister)
 };
 
 thread_local std::string g_create_error;
@@ -67,6 +69,10 @@ struct sixdof_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t copy_stream = nullptr;          // telemetry D2H, overlaps the compute stream
+    hipEvent_t ev_snap = nullptr, ev_copied = nullptr;
+    bool copy_pending = false;
+    bool step_pending = false;                  // SIXDOF_FLAG_ASYNC_STEP: ev1 of the last step not yet read
     std::vector<hipEvent_t> launch_events;  // SIXDOF_FLAG_TIME_EACH_LAUNCH: 2 per launch
     std::map<uint64_t, Column> cols;  // ascending ComponentId = reference BTreeMap order
     std::vector<sixdof_effector_op> ops;
@@ -273,10 +279,16 @@ void sixdof_destroy(sixdof_handle* h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     h->drop_graph();
+    if (h->copy_stream) hipStreamSynchronize(h->copy_stream);
     for (auto& kv : h->cols) {
         h->free_join(kv.second);
         if (kv.second.dev) hipFree(kv.second.dev);
+        if (kv.second.snap) hipFree(kv.second.snap);
+        if (kv.second.host_pinned) hipHostUnregister(kv.second.host);
     }
+    if (h->copy_stream) hipStreamDestroy(h->copy_stream);
+    if (h->ev_snap) hipEventDestroy(h->ev_snap);
+    if (h->ev_copied) hipEventDestroy(h->ev_copied);
     if (h->d_csr_start) hipFree(h->d_csr_start);
     if (h->d_csr_dst) hipFree(h->d_csr_dst);
     if (h->d_scratch) hipFree(h->d_scratch);
@@ -513,6 +525,71 @@ int sixdof_download(sixdof_handle* h, uint32_t mask) {
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->last.d2h_download_ms = now_ms() - t_dn;
+    return SIXDOF_OK;
+}
+
+int sixdof_download_async(sixdof_handle* h, uint32_t mask) {
+    if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
+    if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "download_async: no columns bound");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->copy_stream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_snap, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming));
+    }
+    const struct { uint32_t bit; uint64_t id; } sel[5] = {{SIXDOF_COL_WORLD_POS, h->id_pos},
+                                                        {SIXDOF_COL_WORLD_VEL, h->id_vel},
+                                                        {SIXDOF_COL_WORLD_ACCEL, h->id_accel},
+                                                        {SIXDOF_COL_FORCE, h->id_force},
+                                                        {SIXDOF_COL_INERTIA, h->id_inertia}};
+    // the previous copy must have drained the snapshot buffers before they are overwritten (device-side wait)
+    if (h->copy_pending) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_copied, 0));
+    Column* picked[5];
+    int n_picked = 0;
+    for (auto& s : sel) {
+        if (!(mask & s.bit)) continue;
+        Column* c = h->col(s.id);
+        if (!c || !c->bytes) continue;
+        int rc = scatter_back(h, c);
+        if (rc != SIXDOF_OK) return rc;
+        if (!c->snap) HIP_TRY(h, hipMalloc(&c->snap, c->bytes));
+        HIP_TRY(h, hipMemcpyAsync(c->snap, c->dev, c->bytes, hipMemcpyDeviceToDevice, h->stream));
+        if (!c->host_pinned) {   // page-lock once; if the range cannot be locked the copy below still works, staged
+            if (hipHostRegister(c->host, c->bytes, hipHostRegisterDefault) == hipSuccess) c->host_pinned = true;
+            else (void)hipGetLastError();
+        }
+        picked[n_picked++] = c;
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_snap, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->ev_snap, 0));
+    for (int k = 0; k < n_picked; k++)
+        HIP_TRY(h, hipMemcpyAsync(picked[k]->host, picked[k]->snap, picked[k]->bytes, hipMemcpyDeviceToHost, h->copy_stream));
+    HIP_TRY(h, hipEventRecord(h->ev_copied, h->copy_stream));
+    h->copy_pending = true;
+    return SIXDOF_OK;
+}
+
+int sixdof_download_wait(sixdof_handle* h) {
+    if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
+    if (!h->copy_pending) return SIXDOF_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const double t0 = now_ms();
+    HIP_TRY(h, hipEventSynchronize(h->ev_copied));
+    h->last.d2h_download_ms = now_ms() - t0;     // the part of the copy the host actually waited for
+    return SIXDOF_OK;
+}
+
+int sixdof_sync(sixdof_handle* h) {
+    if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->copy_stream) HIP_TRY(h, hipStreamSynchronize(h->copy_stream));
+    if (h->step_pending) {
+        float ms0 = 0.f;
+        if (hipEventElapsedTime(&ms0, h->ev0, h->ev1) == hipSuccess) h->last.kernel_device_ms = ms0;
+        h->step_pending = false;
+    }
+    h->copy_pending = false;
     return SIXDOF_OK;
 }
 
@@ -955,6 +1032,13 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
     HIP_TRY(h, hipSetDevice(h->device));
     const double t0 = now_ms();
     uint64_t launches = 0;
+    const bool async_step = (h->desc.flags & SIXDOF_FLAG_ASYNC_STEP) != 0;
+    if (h->step_pending) {   // timing of the previous asynchronous batch, if it has finished by now
+        float ms_prev = 0.f;
+        HIP_TRY(h, hipEventSynchronize(h->ev1));   // ev0 / ev1 are about to be re-recorded
+        if (hipEventElapsedTime(&ms_prev, h->ev0, h->ev1) == hipSuccess) h->last.kernel_device_ms = ms_prev;
+        h->step_pending = false;
+    }
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     if (h->model == 1) {
         int rc = step_apollo(h, n_ticks, &launches);
@@ -1061,12 +1145,15 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
         }
     }
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!async_step) HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->tick += n_ticks;  // increment_sim_tick (globals.rs:42-44), once per tick
+    h->step_pending = async_step;
     {
-        float ms0 = 0.f;
-        hipEventElapsedTime(&ms0, h->ev0, h->ev1);
-        h->last.kernel_device_ms = ms0;
+        if (!async_step) {
+            float ms0 = 0.f;
+            hipEventElapsedTime(&ms0, h->ev0, h->ev1);
+            h->last.kernel_device_ms = ms0;
+        }
         h->last.kernel_invoke_ms = now_ms() - t0;
         h->last.launches = launches;
         h->last.ticks = n_ticks;

@@ -272,6 +272,47 @@ class HipExec:
     def set_flags(self, flags: int):
         self._lib.sixdof_set_flags(self._h, int(flags))
 
+    # ---- telemetry commit overlapped with the next batch -------------------------------------------------------
+    def download_async(self, mask: int = L.COL_ALL & ~L.COL_INERTIA):
+        rc = self._lib.sixdof_download_async(self._h, int(mask))
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_download_async")
+
+    def download_wait(self):
+        rc = self._lib.sixdof_download_wait(self._h)
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_download_wait")
+
+    def sync(self):
+        rc = self._lib.sixdof_sync(self._h)
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_sync")
+
+    def run_streaming(self, n_batches: int, ticks_per_batch: int, consume=None, flags: int = 0) -> float:
+        """The run loop of exec.rs:110-172 (`run(ticks)` = batches of ticks_per_telemetry ticks, each followed by a
+        commit of the output columns) with the commit off the critical path: batch i+1 is enqueued before batch i's
+        columns are waited for, and they travel to the (page-locked) host columns on a second stream meanwhile.
+        `consume(batch_index)` is called when the host columns hold that batch's state (the DB commit goes there).
+        Returns the wall time in seconds."""
+        import time
+        self.set_flags(flags | L.FLAG_ASYNC_STEP)
+        t0 = time.perf_counter()
+        try:
+            for i in range(n_batches):
+                self.invoke_batch(ticks_per_batch)          # enqueue batch i (returns once batch i-1 has computed)
+                if i > 0:
+                    self.download_wait()                    # batch i-1 is in the host columns
+                    if consume is not None:
+                        consume(i - 1)
+                self.download_async()                       # snapshot of batch i; its copy overlaps batch i+1
+            self.download_wait()
+            if consume is not None and n_batches:
+                consume(n_batches - 1)
+            self.sync()
+        finally:
+            self.set_flags(flags)
+        return time.perf_counter() - t0
+
     def join_rows(self, name: str) -> np.ndarray:
         """Row of joined entity j inside column `name` (the reference's constant u32 gather indices)."""
         rows = np.zeros(self.n, dtype=np.uint32)

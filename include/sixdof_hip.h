@@ -131,6 +131,9 @@ typedef struct sixdof_desc {
 #define SIXDOF_FLAG_USE_GRAPH 1u /* replay long sixdof_step batches from a captured hipGraph */
 #define SIXDOF_FLAG_TIME_EACH_LAUNCH 2u /* profiling: bracket every launch of sixdof_step with its own HIP
                                            event pair (<= 4096 launches per call; disables graph replay) */
+#define SIXDOF_FLAG_ASYNC_STEP 4u /* sixdof_step only enqueues and returns (no stream sync): pair it with
+                                     sixdof_download_async so the telemetry copy of batch i overlaps batch i+1;
+                                     kernel_device_ms then reports the previous finished batch.  sixdof_sync joins. */
 
 /* One ECS column as the reference holds it (world.rs:26-30 + ExecSlotMetadata exec.rs:17-22). */
 typedef struct sixdof_column {
@@ -194,6 +197,16 @@ int sixdof_get_edge_rows(const sixdof_handle* h, uint32_t* src_rows, uint32_t* d
 int sixdof_upload(sixdof_handle* h);
 int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* timings /* may be NULL */);
 int sixdof_download(sixdof_handle* h, uint32_t column_mask);
+/* Telemetry commit without the per-batch stall (the step either side of the path: commit_world_head after
+ * every batch, impeller2_server.rs:390-438; JaxExec blocks on copy_to_host there, jax_exec.rs:150-178).
+ * download_async snapshots the selected columns on the compute stream (device-to-device, microseconds) and
+ * copies the snapshot into the bound host buffers on a second stream; the host buffers are page-locked on
+ * first use (hipHostRegister) so the copy is a real DMA.  The next sixdof_step may be issued immediately.
+ * download_wait blocks until the host buffers hold that snapshot.  One snapshot in flight: a second
+ * download_async first waits (on the device) for the previous copy to have left the snapshot buffers. */
+int sixdof_download_async(sixdof_handle* h, uint32_t column_mask);
+int sixdof_download_wait(sixdof_handle* h);
+int sixdof_sync(sixdof_handle* h);   /* both streams idle */
 int sixdof_get_tick(const sixdof_handle* h, uint64_t* tick);
 int sixdof_set_tick(sixdof_handle* h, uint64_t tick);
 int sixdof_set_ticks_per_launch(sixdof_handle* h, uint32_t k);
