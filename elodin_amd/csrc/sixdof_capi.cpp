@@ -69,6 +69,8 @@ struct sixdof_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evp0 = nullptr, evp1 = nullptr;  // the pair the PREVIOUS asynchronous step recorded (two pairs alternate)
+    bool prev_pending = false;
     hipStream_t copy_stream = nullptr;          // telemetry D2H, overlaps the compute stream
     hipEvent_t ev_snap = nullptr, ev_copied = nullptr;
     bool copy_pending = false;
@@ -265,7 +267,8 @@ int sixdof_create(const sixdof_desc* d, sixdof_handle** out) {
     h->id_tick = cid("tick");
     h->id_dt = cid("simulation_time_step");
     if ((e = hipSetDevice(h->device)) != hipSuccess || (e = hipStreamCreate(&h->stream)) != hipSuccess ||
-        (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
+        (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess ||
+        (e = hipEventCreate(&h->evp0)) != hipSuccess || (e = hipEventCreate(&h->evp1)) != hipSuccess) {
         g_create_error = std::string("sixdof_create: ") + hipGetErrorString(e);
         sixdof_destroy(h);   // releases whatever part was created
         return SIXDOF_ERR_BACKEND;
@@ -299,6 +302,8 @@ void sixdof_destroy(sixdof_handle* h) {
     for (hipEvent_t e : h->launch_events) hipEventDestroy(e);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->evp0) hipEventDestroy(h->evp0);
+    if (h->evp1) hipEventDestroy(h->evp1);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -584,11 +589,9 @@ int sixdof_sync(sixdof_handle* h) {
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->copy_stream) HIP_TRY(h, hipStreamSynchronize(h->copy_stream));
-    if (h->step_pending) {
-        float ms0 = 0.f;
-        if (hipEventElapsedTime(&ms0, h->ev0, h->ev1) == hipSuccess) h->last.kernel_device_ms = ms0;
-        h->step_pending = false;
-    }
+    float ms0 = 0.f;
+    if (h->step_pending && hipEventElapsedTime(&ms0, h->ev0, h->ev1) == hipSuccess) h->last.kernel_device_ms = ms0;
+    h->step_pending = h->prev_pending = false;
     h->copy_pending = false;
     return SIXDOF_OK;
 }
@@ -1033,11 +1036,18 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
     const double t0 = now_ms();
     uint64_t launches = 0;
     const bool async_step = (h->desc.flags & SIXDOF_FLAG_ASYNC_STEP) != 0;
-    if (h->step_pending) {   // timing of the previous asynchronous batch, if it has finished by now
-        float ms_prev = 0.f;
-        HIP_TRY(h, hipEventSynchronize(h->ev1));   // ev0 / ev1 are about to be re-recorded
-        if (hipEventElapsedTime(&ms_prev, h->ev0, h->ev1) == hipSuccess) h->last.kernel_device_ms = ms_prev;
-        h->step_pending = false;
+    if (h->step_pending || h->prev_pending) {
+        // asynchronous batches alternate between two event pairs, so the host may enqueue batch i+1 while batch i
+        // still computes; the pair about to be re-recorded belongs to batch i-1 (long finished): read its time
+        std::swap(h->ev0, h->evp0);
+        std::swap(h->ev1, h->evp1);
+        std::swap(h->step_pending, h->prev_pending);
+        if (h->step_pending) {
+            float ms_prev = 0.f;
+            HIP_TRY(h, hipEventSynchronize(h->ev1));
+            if (hipEventElapsedTime(&ms_prev, h->ev0, h->ev1) == hipSuccess) h->last.kernel_device_ms = ms_prev;
+            h->step_pending = false;
+        }
     }
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     if (h->model == 1) {

@@ -30,15 +30,19 @@ lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
          "Durations in microseconds; `grid` = total work-items (= entities for the step kernel). The 65536-entity",
          "step kernel appears with ticks_per_launch = 1 (timed region + warmup), = 64 (`fused`) and = 64 with the",
          "telemetry ring (`recording`): rows are split by duration.  PipeStatic<2, 3> = gravity | body_torque;",
-         "the trailing bool is the non-temporal (streaming) instantiation; PipeCustom = the generated pipe.", "",
+         "the trailing bool is the non-temporal (streaming) instantiation; PipeCustom = a generated pipe / program",
+         "(`<float, 1, PipeCustom, 0>` at grid 32768 = the Falcon 9 ascent campaign, 1000 ticks per launch).  The",
+         "1-tick rows include the `telemetry_commit` leg's launches, which share the device with concurrent D2H copies",
+         "(`__amd_rocclr_copyBuffer` = its device-side snapshots).", "",
          "| kernel | grid | launches | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|---|"]
 for (name, grid), d in sorted(stats.items(), key=lambda kv: -sum(kv[1])):
     groups = [("", d)]
     if "sixdof_step_kernel" in name and grid == 65536:
         # the bench runs this grid with 1 tick/launch (timed region), 64 ticks/launch (`fused`, ~40 us) and
         # 64 ticks/launch with the telemetry ring (`recording`, ~130-160 us)
-        groups = [(" [1 tick/launch]", [x for x in d if x < 20000]),
-                  (" [64 ticks/launch]", [x for x in d if 20000 <= x < 80000]),
+        groups = [(" [1 tick/launch]", [x for x in d if x < 15000]),
+                  (" [8 ticks/launch, `telemetry_commit` leg]", [x for x in d if 15000 <= x < 30000]),
+                  (" [64 ticks/launch]", [x for x in d if 30000 <= x < 80000]),
                   (" [64 ticks/launch + telemetry ring]", [x for x in d if x >= 80000])]
     for label, g in groups:
         if g:
