@@ -231,6 +231,46 @@ def falcon9_leg(device):
             "meco_alt_km": [round(float(res[:, 4].min()) / 1e3, 2), round(float(res[:, 4].max()) / 1e3, 2)]}
 
 
+def campaign_bench(which, rank, world, local_rank, comm_device, barrier):
+    """One whole campaign, weak-scaled: BASELINE's rollout count PER GPU (8,192 Apollo descents / 32,768 Falcon 9 ascents),
+    rank 0 samples the plan, the table is broadcast and the result rows are gathered over the process group (RCCL on
+    `nccl`); no exchange while the rollouts fly.  Timed region = broadcast + flight + gather, max over ranks."""
+    from elodin_amd import monte_carlo as mc
+    from elodin_amd import shard
+    if which == "apollo":
+        from elodin_amd.models import apollo as model
+        per_gpu, ticks, dtype = 8192, None, "f64"
+        spec = mc.load_spec(ROOT / "tests" / "golden" / "plans" / "apollo.toml")
+        spec["monte_carlo"]["n_samples"] = per_gpu * world
+        table = mc.materialize(spec).table() if rank == 0 else None
+        ticks = model.max_ticks(model.load_reference())
+        run = lambda: model.run_campaign(table, per_gpu * world, ticks, device=local_rank, comm_device=comm_device)
+        ok = lambda res: float(res[:, 8].mean())           # landed
+        desc = f"Apollo-lander Monte-Carlo, {per_gpu} rollouts per GPU x {ticks} ticks max, semi-implicit f64 (BASELINE configs[3])"
+    else:
+        from elodin_amd.models import falcon9 as model
+        per_gpu, ticks, dtype = 32768, model.ASCENT_TICKS, "f32"
+        table = model.sample_params(per_gpu * world) if rank == 0 else None
+        run = lambda: model.run_campaign(table, per_gpu * world, ticks, device=local_rank, comm_device=comm_device)
+        ok = lambda res: float((res[:, 3] > 0.0).mean())   # reached MECO
+        desc = f"Falcon 9 ascent Monte-Carlo, {per_gpu} rollouts per GPU x {ticks} ticks, semi-implicit f32 (BASELINE configs[4])"
+    if which == "falcon9":      # executor construction compiles / loads the generated program: keep it out of the timing
+        model.AscentExec(model.default_param_row()[None, :], dtype=np.float32, device=local_rank).close()
+    barrier()
+    t0 = time.perf_counter()
+    res = run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        elapsed = shard.max_over_ranks(elapsed, device=comm_device)
+    n_runs = per_gpu * world
+    return {"metric": "rollout-steps/s (whole campaign)", "value": round(n_runs * ticks / elapsed, 1), "unit": "rollout-steps/s",
+            "n_gpus": world, "steps": ticks, "warmup": 0, "ms_per_step": round(elapsed / ticks * 1e3, 6),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic (sampled plan)",
+            "config": {"workload": desc, "rollouts": n_runs, "parallelism": f"run-id shards x{world}; broadcast plan + gather results"},
+            "campaign_seconds": round(elapsed, 4), "success_fraction": round(ok(res), 4) if rank == 0 else None}
+
+
 def cpu_baseline(w, eff, target_seconds=10.0):
     """The CPU oracle (a port of the reference arithmetic; the reference itself needs rustc + jax) timed
     on this host's cores on a bounded sample of the same workload."""
@@ -266,6 +306,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_hbm / fused legs")
+    ap.add_argument("--campaign", choices=("apollo", "falcon9"), default=None,
+                    help="instead of the config-2 step: one whole Monte-Carlo campaign (BASELINE configs[3] / configs[4]) "
+                         "sharded over the ranks, plan broadcast + result gather over RCCL; --steps/--warmup are ignored")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -286,6 +329,16 @@ def main():
         if distributed:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
+
+    if args.campaign:
+        comm = torch.device("cuda", local_rank) if distributed else "cpu"
+        line = campaign_bench(args.campaign, rank, world, local_rank, comm, barrier)
+        if distributed:
+            dist.barrier(device_ids=[local_rank])
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        return
 
     n = args.entities
     K = max(1, args.ticks_per_launch)

@@ -47,7 +47,7 @@ def broadcast_table(table: np.ndarray | None, shape, dtype=np.float64, src: int 
     """Rank `src` holds the campaign parameter table (n_runs x n_params); everyone gets a copy."""
     import torch
     dist = _dist()
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return np.ascontiguousarray(table, dtype=dtype)
     t = torch.empty(tuple(shape), dtype=getattr(torch, np.dtype(dtype).name), device=device)
     if dist.get_rank() == src:
@@ -61,7 +61,7 @@ def gather_rows(local_rows: np.ndarray, total_rows: int, device="cpu") -> np.nda
     import torch
     dist = _dist()
     local_rows = np.ascontiguousarray(local_rows)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local_rows
     world = dist.get_world_size()
     width = local_rows.shape[1]
