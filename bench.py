@@ -211,7 +211,7 @@ def falcon9_leg(device):
     worth here; the closed loop is a generated program: models/falcon9.py)."""
     from elodin_amd.models import falcon9 as f9
     n = 32768
-    ex = f9.AscentExec(f9.sample_params(n), dtype=np.float32, ticks_per_launch=1000, device=device)
+    ex = f9.AscentExec(f9.sample_params(n), dtype=np.float32, ticks_per_launch=1000, device=device, fast_math=True)
     ex.hip.invoke_batch(1000)
     t0 = time.perf_counter()
     tm = ex.hip.invoke_batch(f9.ASCENT_TICKS - 1000)
@@ -223,7 +223,8 @@ def falcon9_leg(device):
     ex.close()
     steps = f9.ASCENT_TICKS - 1000
     return {"rollouts": n, "steps": steps, "seconds": round(dt, 4), "rollout_steps_per_s": round(n * steps / dt, 1),
-            "dtype": "f32", "launches": tm.launches, "integrator": "semi-implicit @ 1 kHz", "guidance": "in-kernel, 100 Hz",
+            "dtype": "f32", "math": "hardware transcendentals in the generated user code (codegen fast_math)",
+            "launches": tm.launches, "integrator": "semi-implicit @ 1 kHz", "guidance": "in-kernel, 100 Hz",
             "bound": "valu (state stays in registers for 1000 ticks per launch)",
             "state_bytes_per_rollout": state_bytes,
             "hbm_GBps_if_every_tick_round_tripped": round(2 * state_bytes * n * steps / dt / 1e9, 1),
@@ -255,7 +256,7 @@ def campaign_bench(which, rank, world, local_rank, comm_device, barrier):
         ok = lambda res: float((res[:, 3] > 0.0).mean())   # reached MECO
         desc = f"Falcon 9 ascent Monte-Carlo, {per_gpu} rollouts per GPU x {ticks} ticks, semi-implicit f32 (BASELINE configs[4])"
     if which == "falcon9":      # executor construction compiles / loads the generated program: keep it out of the timing
-        model.AscentExec(model.default_param_row()[None, :], dtype=np.float32, device=local_rank).close()
+        model.AscentExec(model.default_param_row()[None, :], dtype=np.float32, device=local_rank, fast_math=True).close()
     barrier()
     t0 = time.perf_counter()
     res = run()

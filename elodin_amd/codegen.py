@@ -101,7 +101,9 @@ class _Emitter:
             if id(e) in self.names:
                 return self.names[id(e)]
             a = [ref(x) for x in e.args]
-            if e.op in _BIN:
+            if e.op == "div":
+                rhs = f"m_div({a[0]}, {a[1]})"
+            elif e.op in _BIN:
                 rhs = f"{a[0]} {_BIN[e.op]} {a[1]}"
             elif e.op == "neg":
                 rhs = f"-{a[0]}"
@@ -173,19 +175,42 @@ def _emit_systems(systems) -> str:
     return "\n".join(out)
 
 
-_PRELUDE = '''template <class T> __device__ __forceinline__ T m_sqrt(T x) { return fast_sqrt(x); }
+_PRELUDE = '''// SIXDOF_FAST_MATH (f32 programs, opt-in): hardware transcendentals (v_sin / v_cos / v_exp / v_log / v_rcp /
+// v_sqrt, ~1e-6 relative) instead of the correctly rounded library calls — sinf+cosf alone are ~240 instructions, and a
+// tick of the Falcon 9 program makes 32 of them.  f64 programs and the default f32 mode keep the library functions.
+template <class T> __device__ __forceinline__ T m_div(T a, T b) { return a / b; }
+#ifdef SIXDOF_FAST_MATH
+__device__ __forceinline__ float m_div(float a, float b) { return __fdividef(a, b); }
+__device__ __forceinline__ float m_sqrt(float x) { return __fsqrt_rn(x); }
+__device__ __forceinline__ double m_sqrt(double x) { return fast_sqrt(x); }
+#else
+template <class T> __device__ __forceinline__ T m_sqrt(T x) { return fast_sqrt(x); }
+#endif
 __device__ __forceinline__ double m_abs(double x) { return fabs(x); }
 __device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
 #define SIXDOF_M1(name, fd, ff) \\
     __device__ __forceinline__ double name(double x) { return fd(x); } \\
     __device__ __forceinline__ float name(float x) { return ff(x); }
+#ifdef SIXDOF_FAST_MATH
+__device__ __forceinline__ float m_fast_tan(float x) { return __fdividef(__sinf(x), __cosf(x)); }
+SIXDOF_M1(m_sin, sin, __sinf) SIXDOF_M1(m_cos, cos, __cosf) SIXDOF_M1(m_tan, tan, m_fast_tan) SIXDOF_M1(m_exp, exp, __expf)
+SIXDOF_M1(m_log, log, __logf)
+#else
 SIXDOF_M1(m_sin, sin, sinf) SIXDOF_M1(m_cos, cos, cosf) SIXDOF_M1(m_tan, tan, tanf) SIXDOF_M1(m_exp, exp, expf)
-SIXDOF_M1(m_log, log, logf) SIXDOF_M1(m_acos, acos, acosf) SIXDOF_M1(m_asin, asin, asinf)
+SIXDOF_M1(m_log, log, logf)
+#endif
+SIXDOF_M1(m_acos, acos, acosf) SIXDOF_M1(m_asin, asin, asinf)
 #define SIXDOF_M2(name, fd, ff) \\
     __device__ __forceinline__ double name(double x, double y) { return fd(x, y); } \\
     __device__ __forceinline__ float name(float x, float y) { return ff(x, y); }
-SIXDOF_M2(m_max, fmax, fmaxf) SIXDOF_M2(m_min, fmin, fminf) SIXDOF_M2(m_atan2, atan2, atan2f) SIXDOF_M2(m_hypot, hypot, hypotf)
-SIXDOF_M2(m_pow, pow, powf)
+SIXDOF_M2(m_max, fmax, fmaxf) SIXDOF_M2(m_min, fmin, fminf) SIXDOF_M2(m_atan2, atan2, atan2f)
+#ifdef SIXDOF_FAST_MATH
+__device__ __forceinline__ float m_fast_pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }   // x > 0 (x = 0 -> 0 for y > 0)
+__device__ __forceinline__ float m_fast_hypot(float x, float y) { return __fsqrt_rn(x * x + y * y); }
+SIXDOF_M2(m_pow, pow, m_fast_pow) SIXDOF_M2(m_hypot, hypot, m_fast_hypot)
+#else
+SIXDOF_M2(m_pow, pow, powf) SIXDOF_M2(m_hypot, hypot, hypotf)
+#endif
 // jnp.interp over a constant table: i = clip(searchsorted(xp, x, 'right'), 1, N-1); fp[i-1] + (x-xp[i-1])/dx * df,
 // clamped to the end values outside the table.
 template <class T, int N>
@@ -220,8 +245,11 @@ def _emit_tables() -> str:
     return "\n".join(out)
 
 
-def generate_source(tp, dtype: str, integrator: int) -> str:
-    """tp: dsl.TracedPipe (effectors only) or dsl.TracedProgram (pre | six_dof(effectors) | post)."""
+def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) -> str:
+    """tp: dsl.TracedPipe (effectors only) or dsl.TracedProgram (pre | six_dof(effectors) | post).
+    fast_math: f32 only — hardware transcendentals / reciprocal division in the generated user code (see _PRELUDE)."""
+    if fast_math and dtype != "float32":
+        raise ValueError("fast_math applies to float32 programs only")
     _TABLES.clear()
     T = {"float64": "double", "float32": "float"}[dtype]
     integ = "kRk4" if integrator == 0 else "kSemiImplicit"
@@ -274,8 +302,9 @@ def generate_source(tp, dtype: str, integrator: int) -> str:
     }}'''
     names = ", ".join(e.__name__ for e in pipe_tp.effectors)
     tables = _emit_tables()
+    fast = "#define SIXDOF_FAST_MATH 1\n" if fast_math else ""
     return f'''// generated by elodin_amd/codegen.py — do not edit.  Effectors: {names}
-#include "step_kernel.hpp"
+{fast}#include "step_kernel.hpp"
 
 namespace sixdof {{
 
@@ -375,9 +404,9 @@ def _headers_digest() -> str:
     return h.hexdigest()
 
 
-def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0) -> Path:
+def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_math: bool = False) -> Path:
     """Generate + compile (cached by content hash).  Returns the .so path."""
-    return _compile(generate_source(tp, dtype, integrator), "pipe")
+    return _compile(generate_source(tp, dtype, integrator, fast_math), "pipe")
 
 
 def _compile(src: str, stem: str) -> Path:

@@ -50,7 +50,7 @@ class HipExec:
                  simulation_time_step: float = 1.0 / 120.0, time_step: Optional[float] = None,
                  integrator: int = L.RK4, dtype=np.float64, effectors: Sequence[Effector] = (),
                  edges=None, ticks_per_launch: int = 1, use_graph: bool = False, device: int = 0,
-                 tick: int = 0, column_entity_ids=None, columns=None):
+                 tick: int = 0, column_entity_ids=None, columns=None, fast_math: bool = False):
         lib = L.lib()
         self._lib = lib
         self.dtype = np.dtype(dtype)
@@ -101,7 +101,7 @@ class HipExec:
                 custom = effectors.trace(widths)
                 if isinstance(effectors, _dsl.Program):
                     self._program_columns = [n for n, _ in custom.columns]
-                so = codegen.build(custom, self.dtype.name, integrator)
+                so = codegen.build(custom, self.dtype.name, integrator, fast_math=fast_math)
                 for name, width in custom.columns:
                     if columns is None or name not in columns:
                         raise KeyError(f"effector reads component {name!r} which was not provided")

@@ -168,8 +168,10 @@ def test_closed_loop_traces_and_generates_for_both_dtypes():
     names = dict(tp.columns)
     assert names["engine_spool"] == 9 and names["valve_state"] == 8 and names["params"] == 16 and len(names) <= 48
     assert tp.writes_inertia and tp.reads_velocity
-    for dtype in ("float64", "float32"):
-        src = codegen.generate_source(tp, dtype, 1)
-        assert "m_pow(" in src and "m_interp<" in src and "fsw_ascent" in src
+    for dtype, fast in (("float64", False), ("float32", False), ("float32", True)):
+        src = codegen.generate_source(tp, dtype, 1, fast_math=fast)
+        assert "m_pow(" in src and "m_interp<" in src and "fsw_ascent" in src and ("#define SIXDOF_FAST_MATH" in src) == fast
+    with pytest.raises(ValueError):
+        codegen.generate_source(tp, "float64", 1, fast_math=True)
     mass = cols["inertia"][0, 6]
     assert abs(mass - (f9.STAGE1_DRY_MASS_KG + f9.DEFAULT_PARAMS["lox_kg"] + f9.DEFAULT_PARAMS["rp1_kg"] + f9.UPPER_KG)) < 1e-6
