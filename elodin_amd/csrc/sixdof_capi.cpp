@@ -90,6 +90,7 @@ struct sixdof_handle {
     bool identity_join = true;         // every Body column already is the joined set (query.rs:673,702 fast path)
     uint64_t tick = 0;
     bool bound = false;
+    bool resident = false;             // columns uploaded at least once since the last bind
     sixdof_timings last{};   // most recent upload / step / download
     // run-time generated effector pipe
     void* custom_dl = nullptr;
@@ -378,6 +379,7 @@ int sixdof_bind_columns(sixdof_handle* h, const sixdof_column* cols, size_t n_co
         if (rc != SIXDOF_OK) return rc;
     }
     h->bound = true;
+    h->resident = false;
     return SIXDOF_OK;
 }
 
@@ -481,6 +483,8 @@ int sixdof_get_edge_rows(const sixdof_handle* h, uint32_t* src_rows, uint32_t* d
     return SIXDOF_OK;
 }
 
+int prepare_graph(sixdof_handle* h);
+
 int sixdof_upload(sixdof_handle* h) {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "upload: no columns bound");
@@ -497,7 +501,8 @@ int sixdof_upload(sixdof_handle* h) {
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->last.h2d_upload_ms = now_ms() - t_up;
-    return SIXDOF_OK;
+    h->resident = true;
+    return prepare_graph(h);   // SIXDOF_FLAG_USE_GRAPH: capture now, not inside the first long step call
 }
 
 // joined rows -> their places in the full column (before any D2H of that column)
@@ -611,7 +616,7 @@ int sixdof_set_ticks_per_launch(sixdof_handle* h, uint32_t k) {
     if (!h || k == 0) return SIXDOF_ERR_INVALID_ARGUMENT;
     h->desc.ticks_per_launch = k;
     h->drop_graph();
-    return SIXDOF_OK;
+    return h->resident ? prepare_graph(h) : SIXDOF_OK;
 }
 
 int sixdof_set_flags(sixdof_handle* h, uint32_t flags) {
@@ -1029,6 +1034,48 @@ int sixdof_download_column(sixdof_handle* h, uint64_t component_id) {
     return SIXDOF_OK;
 }
 
+constexpr uint32_t kGraphLen = 32;
+
+bool graph_eligible(const sixdof_handle* h) {
+    return (h->desc.flags & SIXDOF_FLAG_USE_GRAPH) && !(h->desc.flags & SIXDOF_FLAG_TIME_EACH_LAUNCH) && !h->hist_ring &&
+           h->custom_model.empty() && h->model == 0 && !h->has_pair_op();
+}
+
+// Capture kGraphLen identical launches of the step kernel into an executable graph (once per (K, effectors, size)).
+int ensure_graph(sixdof_handle* h, const StepParams& P, uint32_t K) {
+    const uint64_t sig = (static_cast<uint64_t>(K) << 32) ^ h->ops.size() ^ (h->desc.n_entities << 8);
+    if (h->graph_exec && h->graph_k == K && h->graph_sig == sig) return SIXDOF_OK;
+    h->drop_graph();
+    hipGraph_t g = nullptr;
+    HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t le = hipSuccess;
+    for (uint32_t i = 0; i < kGraphLen && le == hipSuccess; i++) le = launch_any(h, P);
+    hipError_t ce = hipStreamEndCapture(h->stream, &g);
+    if (le != hipSuccess) return h->hip_fail(le, "launch_step (capture)");
+    if (ce != hipSuccess) return h->hip_fail(ce, "hipStreamEndCapture");
+    hipError_t ie = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (ie != hipSuccess) return h->hip_fail(ie, "hipGraphInstantiate");
+    (void)hipGraphUpload(h->graph_exec, h->stream);   // move the one-off device-side setup out of the first replay
+    h->graph_k = K;
+    h->graph_len = kGraphLen;
+    h->graph_sig = sig;
+    return SIXDOF_OK;
+}
+
+// Build the replay graph ahead of the first long batch (called when the columns become resident and when the batch
+// shape changes), so that no step call pays for capture + instantiation.
+int prepare_graph(sixdof_handle* h) {
+    if (!h->bound || !graph_eligible(h)) return SIXDOF_OK;
+    StepParams P;
+    int rc = fill_step_params(h, &P);
+    if (rc != SIXDOF_OK) return SIXDOF_OK;     // not steppable yet (columns missing): the step call will report it
+    P.n_ticks = h->desc.ticks_per_launch;
+    rc = ensure_graph(h, P, h->desc.ticks_per_launch);
+    if (rc == SIXDOF_OK) (void)hipStreamSynchronize(h->stream);
+    return rc;
+}
+
 int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "step: no columns bound");
@@ -1093,7 +1140,6 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
         P.n_ticks = K;
         // Long batches of identical launches replay from a hipGraph (launch-bound regime:
         // a 65,536-entity tick is a few microseconds of device time).
-        constexpr uint32_t kGraphLen = 32;
         const bool time_each = (h->desc.flags & SIXDOF_FLAG_TIME_EACH_LAUNCH) != 0;
         if (time_each) {
             const uint64_t need = 2 * (full + (rem ? 1 : 0));
@@ -1105,27 +1151,11 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
             }
         }
         uint64_t ticks_issued = 0;   // history slot of a launch's first tick = ticks done before it
-        if (!time_each && !h->hist_ring && h->custom_model.empty() && (h->desc.flags & SIXDOF_FLAG_USE_GRAPH) && full >= kGraphLen) {
-            const uint64_t sig = (static_cast<uint64_t>(K) << 32) ^ h->ops.size() ^ (h->desc.n_entities << 8);
-            if (!h->graph_exec || h->graph_k != K || h->graph_sig != sig) {
-                h->drop_graph();
-                hipGraph_t g = nullptr;
-                HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-                hipError_t le = hipSuccess;
-                for (uint32_t i = 0; i < kGraphLen && le == hipSuccess; i++)
-                    le = launch_any(h, P);
-                hipError_t ce = hipStreamEndCapture(h->stream, &g);
-                if (le != hipSuccess) return h->hip_fail(le, "launch_step (capture)");
-                if (ce != hipSuccess) return h->hip_fail(ce, "hipStreamEndCapture");
-                hipError_t ie = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
-                hipGraphDestroy(g);
-                if (ie != hipSuccess) return h->hip_fail(ie, "hipGraphInstantiate");
-                h->graph_k = K;
-                h->graph_len = kGraphLen;
-                h->graph_sig = sig;
-                // the capture recorded ev0 before it; re-record so the event pair brackets real work
-                HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-            }
+        if (graph_eligible(h) && full >= kGraphLen) {
+            int grc = ensure_graph(h, P, K);
+            if (grc != SIXDOF_OK) return grc;
+            // a capture may just have happened after ev0 was recorded: re-record so the pair brackets real work only
+            HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
             while (full >= kGraphLen) {
                 HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
                 full -= kGraphLen;
@@ -1155,7 +1185,16 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
         }
     }
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-    if (!async_step) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!async_step) {
+        // short batches finish in tens of microseconds: poll for that long before paying a blocking wait's wake-up
+        const double spin_until = now_ms() + 0.25;
+        hipError_t q = hipEventQuery(h->ev1);
+        while (q == hipErrorNotReady && now_ms() < spin_until) q = hipEventQuery(h->ev1);
+        if (q != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+        }
+    }
     h->tick += n_ticks;  // increment_sim_tick (globals.rs:42-44), once per tick
     h->step_pending = async_step;
     {
