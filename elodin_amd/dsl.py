@@ -285,6 +285,69 @@ def _zipv(a, b, f):
 np = _Np
 
 
+def _tree_select(c, a, b):
+    """Element-wise select over the value kinds systems exchange: scalars, Vec, spatial types, tuples / dicts of those."""
+    if isinstance(a, (tuple, list)):
+        return type(a)(_tree_select(c, x, y) for x, y in zip(a, b))
+    if isinstance(a, dict):
+        return {k: _tree_select(c, a[k], b[k]) for k in a}
+    if isinstance(a, SpatialMotion):
+        return SpatialMotion(_Np.where(c, a.angular(), b.angular()), _Np.where(c, a.linear(), b.linear()))
+    if isinstance(a, SpatialTransform):
+        return SpatialTransform(Quaternion(_Np.where(c, a.angular().vector(), b.angular().vector())),
+                                _Np.where(c, a.linear(), b.linear()))
+    if isinstance(a, Quaternion):
+        return Quaternion(_Np.where(c, a.vector(), b.vector()))
+    if isinstance(a, SpatialInertia):
+        return SpatialInertia(_Np.where(c, a.inertia_diag(), b.inertia_diag()), _Np.where(c, a.mass(), b.mass()))
+    if isinstance(a, SpatialForce) or isinstance(b, SpatialForce):
+        r = SpatialForce(linear=_Np.where(c, a._f, b._f), _tw=_Np.where(c, a._tw, b._tw), _tb=_Np.where(c, a._tb, b._tb))
+        r._q = a._q or b._q
+        return r
+    return _Np.where(c, a, b)
+
+
+class _Lax:
+    """The jax.lax control-flow calls the reference's examples use inside per-entity code.  Per lane there is no branch
+    to take: both sides are traced and the result is selected, which is also what a vmapped `lax.cond` lowers to."""
+
+    @staticmethod
+    def cond(pred, true_fun, false_fun, *operands, operand=None):
+        """jax.lax.cond(pred, true_fun, false_fun, *operands) — e.g. examples/ball/sim.py:66-71 (the bounce)."""
+        args = operands if operands else (operand,)
+        return _tree_select(pred, true_fun(*args), false_fun(*args))
+
+    @staticmethod
+    def select(pred, on_true, on_false):
+        return _tree_select(pred, on_true, on_false)
+
+    @staticmethod
+    def switch(index, branches, *operands):
+        """jax.lax.switch: index clamped to [0, len(branches) - 1]."""
+        out = branches[0](*operands)
+        for k in range(1, len(branches)):
+            out = _tree_select(_lift(index) >= (k - 0.5), branches[k](*operands), out)
+        return out
+
+    @staticmethod
+    def fori_loop(lower: int, upper: int, body_fun, init_val):
+        """jax.lax.fori_loop with STATIC bounds: unrolled at trace time (the loop index is a Python int)."""
+        if not (isinstance(lower, int) and isinstance(upper, int)):
+            raise TypeError("fori_loop bounds must be Python ints (the loop is unrolled while tracing)")
+        val = init_val
+        for i in range(lower, upper):
+            val = body_fun(i, val)
+        return val
+
+    @staticmethod
+    def max(a, b): return _Np.maximum(a, b)
+    @staticmethod
+    def min(a, b): return _Np.minimum(a, b)
+
+
+lax = _Lax
+
+
 # ---- spatial types (thin mirrors of libs/nox-py/src/spatial.rs wrappers) ---------------------------------------
 
 class RotVec(Vec):
@@ -321,13 +384,23 @@ class Quaternion:
 
 
 class SpatialTransform:
-    def __init__(self, q: Quaternion, p: Vec): self._q, self._p = q, p
+    def __init__(self, q: Optional[Quaternion] = None, p: Optional[Vec] = None, *, angular=None, linear=None):
+        """el.SpatialTransform(angular=identity, linear=0) (libs/nox-py/src/spatial.rs:21-44), also positional (q, p)."""
+        q = angular if q is None else q
+        p = linear if p is None else p
+        self._q = q if q is not None else Quaternion(Vec([0.0, 0.0, 0.0, 1.0]))
+        self._p = p if p is not None else Vec([0.0, 0.0, 0.0])
     def angular(self): return self._q
     def linear(self): return self._p
 
 
 class SpatialMotion:
-    def __init__(self, ang: Vec, lin: Vec): self._a, self._l = ang, lin
+    def __init__(self, ang: Optional[Vec] = None, lin: Optional[Vec] = None, *, angular=None, linear=None):
+        """el.SpatialMotion(angular=0, linear=0) (libs/nox-py/src/spatial.rs:121-140), also positional (ang, lin)."""
+        ang = angular if ang is None else ang
+        lin = linear if lin is None else lin
+        self._a = ang if ang is not None else Vec([0.0, 0.0, 0.0])
+        self._l = lin if lin is not None else Vec([0.0, 0.0, 0.0])
     def angular(self): return self._a
     def linear(self): return self._l
 

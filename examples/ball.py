@@ -26,11 +26,12 @@ def apply_drag(wind, vel, force):
 
 
 @dsl.system
-def bounce(pos, vel):                                   # examples/ball/sim.py:65-73
-    hit = np.maximum(pos.linear()[2], vel.linear()[2]) < 0.0
-    v = vel.linear()
-    return {"world_vel": dsl.SpatialMotion(np.where(hit, np.zeros(3), vel.angular()),
-                                           np.where(hit, np.array([v[0], v[1], -v[2]]) * BOUNCINESS, v))}
+def bounce(pos, vel):                                   # examples/ball/sim.py:65-73, same lax.cond
+    return {"world_vel": dsl.lax.cond(
+        dsl.lax.max(pos.linear()[2], vel.linear()[2]) < 0.0,
+        lambda _: dsl.SpatialMotion(linear=vel.linear() * np.array([1.0, 1.0, -1.0]) * BOUNCINESS),
+        lambda _: vel,
+        operand=None)}
 
 
 def build(wind=(-0.20584213947964347, -0.7847657764467412, 1.8160866726679834)):

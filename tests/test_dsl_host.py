@@ -131,3 +131,38 @@ def test_edge_fold_restrictions_and_codegen():
     assert "struct PairCustom" in src and "sixdof_custom_pair_launch" in src
     so = codegen.build_pair(tf)
     assert so.exists() and codegen.build_pair(tf) == so
+
+
+# ---- jax.lax-shaped control flow --------------------------------------------------------------------------------------
+
+def test_lax_cond_switch_select_and_static_fori_loop():
+    def f(xp, x, v):
+        a = dsl.lax.cond(x < 0.0, lambda t: t * 2.0, lambda t: t + 1.0, x)                     # scalar operand
+        b = dsl.lax.cond(x < 0.0, lambda _: v * xp.array([1.0, 1.0, -1.0]), lambda _: v, operand=None)   # closure style
+        c = dsl.lax.switch(x, [lambda t: t, lambda t: t * 10.0, lambda t: t * 100.0], x)
+        d = dsl.lax.fori_loop(0, 5, lambda i, acc: acc + (i + 1) * x, 0.0 * x)
+        e = dsl.lax.select(x > 1.5, v[0], v[1])
+        return a, b, c, d, e
+    for x, want_a, want_c in ((-2.0, -4.0, -2.0), (0.4, 1.4, 0.4), (1.0, 2.0, 10.0), (2.0, 3.0, 200.0), (7.0, 8.0, 700.0)):
+        a, b, c, d, e = dsl_numpy.trace_eval(f, x, [3.0, 4.0, 5.0])
+        assert a == want_a and c == want_c and d == 15.0 * x
+        assert np.array_equal(b, [3.0, 4.0, -5.0] if x < 0 else [3.0, 4.0, 5.0]) and e == (3.0 if x > 1.5 else 4.0)
+    with pytest.raises(TypeError):
+        dsl.lax.fori_loop(0, dsl.leaf("n"), lambda i, a: a, 0.0)
+
+
+def test_lax_cond_over_spatial_values_like_the_ball_examples_bounce():
+    """examples/ball/sim.py:64-71: cond(max(z, vz) < 0, v -> SpatialMotion(linear = v * [1, 1, -1] * 0.85), v -> v)."""
+    @dsl.system
+    def bounce(pos, vel):
+        return {"world_vel": dsl.lax.cond(dsl.lax.max(pos.linear()[2], vel.linear()[2]) < 0.0,
+                                          lambda _: dsl.SpatialMotion(linear=vel.linear() * np_.array([1.0, 1.0, -1.0]) * 0.85),
+                                          lambda _: vel, operand=None)}
+    ts = dsl.TracedSystem(bounce, dsl.ColumnTable("c", 48, 16))
+    pos = np.array([[0, 0, 0, 1.0, 1.0, 2.0, -0.1], [0, 0, 0, 1.0, 1.0, 2.0, 0.3], [0, 0, 0, 1.0, 0.0, 0.0, -0.2]])
+    vel = np.array([[0.1, 0.2, 0.3, 1.0, 2.0, -3.0], [0.1, 0.2, 0.3, 1.0, 2.0, -3.0], [0.0, 0.0, 0.0, 0.0, 0.0, 4.0]])
+    inertia = np.ones((3, 7))
+    dsl_numpy._run_systems([ts], pos, vel, inertia, {}, dsl.ColumnTable("c", 48, 16), 1)
+    assert np.allclose(vel[0], [0, 0, 0, 0.85, 1.7, 2.55])       # below ground and sinking: reflected, spin dropped
+    assert np.array_equal(vel[1], [0.1, 0.2, 0.3, 1.0, 2.0, -3.0])  # above ground: untouched
+    assert np.array_equal(vel[2], [0.0, 0.0, 0.0, 0.0, 0.0, 4.0])   # below ground but already rising: untouched
