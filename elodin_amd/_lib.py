@@ -16,7 +16,7 @@ OK = 0
 ERR_INVALID_ARGUMENT, ERR_COMPONENT_NOT_FOUND, ERR_VALUE_SIZE_MISMATCH = -1, -2, -3
 ERR_BACKEND, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ENTITY_MISMATCH = -4, -5, -6, -7
 
-RK4, SEMI_IMPLICIT = 0, 1
+RK4, SEMI_IMPLICIT, INTEGRATOR_NONE = 0, 1, 2
 F64, F32 = 0, 1
 PRIM_F64, PRIM_U64, PRIM_F32 = 0, 1, 2
 FLAG_USE_GRAPH = 1

@@ -301,12 +301,19 @@ class World:
         dt = float(self._lib.sixdof_world_time_step(self._w))
         from . import dsl as _dsl
         program_stages = None
+        if isinstance(system, _dsl.System):
+            system = _dsl.Stages([system])
         if isinstance(system, _dsl.Stages):      # pre | six_dof(effectors) | post  -> one generated program
             six = [k for k, it in enumerate(system.items) if isinstance(it, System)]
-            if len(six) != 1:
-                raise ValueError("a system pipe must contain exactly one six_dof(...)")
-            program_stages = (system.items[:six[0]], system.items[six[0] + 1:])
-            system = system.items[six[0]]
+            if len(six) > 1:
+                raise ValueError("a system pipe can contain at most one six_dof(...)")
+            if not six:     # `w.build(sys)` with per-entity systems only (test_all.py:86-114): no integration stage
+                program_stages = (system.items, [])
+                system = System(None, Effectors(), Integrator.Rk4)
+                system.no_six_dof = True
+            else:
+                program_stages = (system.items[:six[0]], system.items[six[0] + 1:])
+                system = system.items[six[0]]
             for it in program_stages[0] + program_stages[1]:
                 if not isinstance(it, _dsl.System):
                     raise TypeError("systems piped around six_dof must be elodin_amd.dsl systems")
@@ -351,7 +358,8 @@ class World:
             edges = (np.array([a for a, _ in pairs], dtype=np.uint64), np.array([b for _, b in pairs], dtype=np.uint64))
         hip = HipExec(pos, body["world_vel"][0], body["inertia"][0], world_accel=body["world_accel"][0],
                       force=body["force"][0], entity_ids=ids, simulation_time_step=dt, time_step=system.time_step,
-                      integrator=system.integrator.value, effectors=effs, edges=edges,
+                      integrator=L.INTEGRATOR_NONE if getattr(system, "no_six_dof", False) else system.integrator.value,
+                      effectors=effs, edges=edges,
                       ticks_per_launch=ticks_per_telemetry, device=device,
                       column_entity_ids=None if same else column_ids, columns=extra_columns)
         return Exec(hip, self, ticks_per_telemetry, dt)

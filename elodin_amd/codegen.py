@@ -252,8 +252,10 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) ->
         raise ValueError("fast_math applies to float32 programs only")
     _TABLES.clear()
     T = {"float64": "double", "float32": "float"}[dtype]
-    integ = "kRk4" if integrator == 0 else "kSemiImplicit"
+    integ = {0: "kRk4", 1: "kSemiImplicit", 2: "kNone"}[integrator]
     is_prog = isinstance(tp, dsl.TracedProgram)
+    if integrator == 2 and not is_prog:
+        raise ValueError("integrator NONE needs a program of systems (there is no six_dof stage for effectors to feed)")
     pipe_tp = tp.pipe if is_prog else tp
     body = "\n".join(emit_apply(pipe_tp))
     n_aux = 0 if is_prog else len(tp.columns)

@@ -44,7 +44,7 @@ struct StepParams {
     DevOp ops[kMaxOps];
 };
 
-enum : int { kRk4 = 0, kSemiImplicit = 1 };
+enum : int { kRk4 = 0, kSemiImplicit = 1, kNone = 2 };   // kNone: a pipe of systems without six_dof (generated programs only)
 
 // Fused clear_forces | effectors | calc_accel | integrator over n entities, n_ticks ticks.
 // dtype: 0 = f64, 1 = f32.  Returns hipGetLastError() of the launch.

@@ -233,7 +233,8 @@ int sixdof_create(const sixdof_desc* d, sixdof_handle** out) {
         g_create_error = "sixdof_create: struct_size mismatch (ABI version skew)";
         return SIXDOF_ERR_INVALID_ARGUMENT;
     }
-    if (d->integrator != SIXDOF_INTEGRATOR_RK4 && d->integrator != SIXDOF_INTEGRATOR_SEMI_IMPLICIT) {
+    if (d->integrator != SIXDOF_INTEGRATOR_RK4 && d->integrator != SIXDOF_INTEGRATOR_SEMI_IMPLICIT &&
+        d->integrator != SIXDOF_INTEGRATOR_NONE) {
         g_create_error = "sixdof_create: unknown integrator";
         return SIXDOF_ERR_INVALID_ARGUMENT;
     }
@@ -736,6 +737,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // built-in pipes or the handle's generated pipe
 hipError_t launch_any(sixdof_handle* h, const StepParams& P) {
+    if (h->desc.integrator == SIXDOF_INTEGRATOR_NONE && !h->custom_launch) return hipErrorInvalidValue;
     if (h->custom_launch) return static_cast<hipError_t>(h->custom_launch(&P, h->desc.integrator, h->desc.dtype, h->stream));
     return launch_step(P, h->desc.integrator, h->desc.dtype, h->stream);
 }
@@ -1097,6 +1099,8 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
         }
     }
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    if (h->desc.integrator == SIXDOF_INTEGRATOR_NONE && (!h->custom_launch || h->model != 0 || h->has_pair_op()))
+        return h->fail(SIXDOF_ERR_UNSUPPORTED, "step: SIXDOF_INTEGRATOR_NONE runs generated system programs only (sixdof_set_custom_pipe)");
     if (h->model == 1) {
         int rc = step_apollo(h, n_ticks, &launches);
         if (rc != SIXDOF_OK) return rc;

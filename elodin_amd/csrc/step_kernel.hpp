@@ -172,6 +172,12 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
         inv_I = Vec3<T>{T(1) / m[0], T(1) / m[1], T(1) / m[2]};
         mass = m[6];
         inv_m = T(1) / mass;
+        if constexpr (INTEGRATOR == kNone) {   // no six_dof in the pipe: world_accel / force pass through untouched
+            const T* a = g_accel + (size_t)t * 6;
+            const T* f = g_force + (size_t)t * 6;
+            A_out = Spatial<T>{{a[0], a[1], a[2]}, {a[3], a[4], a[5]}};
+            F_out = Spatial<T>{{f[0], f[1], f[2]}, {f[3], f[4], f[5]}};
+        }
     }
     if (P.n_ticks == 0) return;
     __syncthreads();  // every lane has consumed the input slabs; LDS is the output staging area from here on
@@ -267,6 +273,8 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             p0 = axpy(g, sv.lin, p0);
             v0 = axpy(g, sa, v0);
             A_out = A;
+        } else if constexpr (INTEGRATOR == kNone) {
+            // systems only (`World.build(system)` without six_dof): the pre / post hooks are the whole tick
         } else {
             // semi-implicit: a = calc_accel(F(x0,v0)); v' = v0 + dt a; x' = x0 (+) dt v'
             b.q = normalized(q0);  // q * v is scale-invariant; user data may not be unit on tick 0
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
         if (record) {
             // telemetry: this tick's world_pos / world_vel / world_accel / force rows -> ring slot, in the
             // reference's row layout, write-once (non-temporal); the stores drain under the next tick's math
-            F_out = world_wrench<PIPE>(b.q, F);
+            if constexpr (INTEGRATOR != kNone) F_out = world_wrench<PIPE>(b.q, F);
             stage_rows();
             __syncthreads();
             const size_t slot = (size_t)((P.hist_slot0 + tick) % P.hist_ring);
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             }
         }
     }
-    F_out = world_wrench<PIPE>(b.q, F);  // wrench of the last stage evaluated, world frame
+    if constexpr (INTEGRATOR != kNone) F_out = world_wrench<PIPE>(b.q, F);  // wrench of the last stage evaluated, world frame
     stage_rows();
     __syncthreads();
     flush_rows(g_pos, g_vel, g_accel, g_force, std::integral_constant<int, NT>{});
@@ -314,7 +322,9 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
 template <class T, class PIPE, int NT>
 inline void launch_i(const StepParams& p, int integrator, dim3 grid, hipStream_t s) {
     if (integrator == kRk4) hipLaunchKernelGGL((sixdof_step_kernel<T, kRk4, PIPE, NT>), grid, dim3(kWave), 0, s, p);
-    else hipLaunchKernelGGL((sixdof_step_kernel<T, kSemiImplicit, PIPE, NT>), grid, dim3(kWave), 0, s, p);
+    else if (integrator == kNone) {
+        if constexpr (PIPE::kHasModel) hipLaunchKernelGGL((sixdof_step_kernel<T, kNone, PIPE, NT>), grid, dim3(kWave), 0, s, p);
+    } else hipLaunchKernelGGL((sixdof_step_kernel<T, kSemiImplicit, PIPE, NT>), grid, dim3(kWave), 0, s, p);
 }
 
 template <class T, class PIPE>

@@ -368,7 +368,28 @@ class Quaternion:
 
     def vector(self) -> Vec: return self.v
     def inverse(self) -> "Quaternion":
+        """conj / |q|^2 (quaternion.rs:152-155).  The stage attitude inside six_dof is renormalised by the kernel before
+        the effectors see it, so there the division is by 1 and is dropped."""
+        c = Vec([-self.v[0], -self.v[1], -self.v[2], self.v[3]])
+        return Quaternion(c) if self.stage_attitude else Quaternion(c / np.dot(self.v, self.v))
+    def conjugate(self) -> "Quaternion":
         return Quaternion(Vec([-self.v[0], -self.v[1], -self.v[2], self.v[3]]))
+    def normalize(self) -> "Quaternion":                     # quaternion.rs:147-149
+        return Quaternion(self.v / np.linalg.norm(self.v))
+    @staticmethod
+    def identity() -> "Quaternion":
+        return Quaternion(Vec([0.0, 0.0, 0.0, 1.0]))
+    @staticmethod
+    def from_axis_angle(axis, angle) -> "Quaternion":         # quaternion.rs:158-171 (the axis is normalised)
+        axis = axis if isinstance(axis, Vec) else Vec(list(axis))
+        axis = axis / np.linalg.norm(axis)
+        half = _lift(angle) / 2.0
+        return Quaternion(np.concatenate([axis * np.sin(half), np.cos(half)]))
+    def integrate_body(self, body_delta: Vec) -> "Quaternion":   # quaternion.rs:176-182: q + q (x) (delta/2, 0), normalised
+        half = Quaternion(np.concatenate([body_delta / 2.0, 0.0]))
+        return Quaternion(self.v + (self * half).v).normalize()
+    def __add__(self, o: "Quaternion") -> "Quaternion":
+        return Quaternion(self.v + o.v)
     def __matmul__(self, x: Vec) -> Vec:
         """q @ v: rotate a 3-vector (quaternion.rs:283-305), as v + w t + u x t with t = 2 u x v."""
         u = Vec(self.v.e[:3])
@@ -392,6 +413,10 @@ class SpatialTransform:
         self._p = p if p is not None else Vec([0.0, 0.0, 0.0])
     def angular(self): return self._q
     def linear(self): return self._p
+    def __add__(self, m: "SpatialMotion") -> "SpatialTransform":
+        """SpatialTransform + SpatialMotion (spatial.rs:530-549): q' = normalize(q + (w/2, 0) (x) q), p' = p + v."""
+        half = Quaternion(np.concatenate([m.angular() / 2.0, 0.0]))
+        return SpatialTransform(Quaternion(self._q.v + (half * self._q).v).normalize(), self._p + m.linear())
 
 
 class SpatialMotion:
@@ -403,6 +428,9 @@ class SpatialMotion:
         self._l = lin if lin is not None else Vec([0.0, 0.0, 0.0])
     def angular(self): return self._a
     def linear(self): return self._l
+    def __add__(self, o: "SpatialMotion"): return SpatialMotion(self._a + o._a, self._l + o._l)
+    def __mul__(self, k): return SpatialMotion(self._a * k, self._l * k)
+    __rmul__ = __mul__
 
 
 class SpatialInertia:

@@ -56,7 +56,10 @@ typedef enum sixdof_status {
 /* integrator/mod.rs:7-10 */
 typedef enum sixdof_integrator {
     SIXDOF_INTEGRATOR_RK4 = 0,
-    SIXDOF_INTEGRATOR_SEMI_IMPLICIT = 1
+    SIXDOF_INTEGRATOR_SEMI_IMPLICIT = 1,
+    /* no six_dof stage: a pipe of per-entity systems only (`World.build(system)`, Query::map query.rs:504-545);
+     * valid only with a generated program (sixdof_set_custom_pipe); world_accel / force pass through unchanged */
+    SIXDOF_INTEGRATOR_NONE = 2
 } sixdof_integrator;
 
 /* Arithmetic type of the state columns.  The reference six_dof is f64 only

@@ -166,3 +166,39 @@ def test_lax_cond_over_spatial_values_like_the_ball_examples_bounce():
     assert np.allclose(vel[0], [0, 0, 0, 0.85, 1.7, 2.55])       # below ground and sinking: reflected, spin dropped
     assert np.array_equal(vel[1], [0.1, 0.2, 0.3, 1.0, 2.0, -3.0])  # above ground: untouched
     assert np.array_equal(vel[2], [0.0, 0.0, 0.0, 0.0, 0.0, 4.0])   # below ground but already rising: untouched
+
+
+# ---- spatial wrappers of SURVEY 8(a) a24 against the reference's own known answers ------------------------------------------
+
+def test_quaternion_and_spatial_wrappers_match_the_reference_known_answers():
+    Q = dsl.Quaternion
+    ev = lambda fn, *a: dsl_numpy.trace_eval(lambda xp, *t: fn(*t), *a)
+    x_axis = [1.0, 0.0, 0.0]
+    # quaternion.rs:353-361 test_quat_mult, :364-370 test_quat_inverse, :373-381 test_quat_vec_mult, :384-388 convention
+    out = ev(lambda ax, a, b: (Q.from_axis_angle(ax, a) * Q.from_axis_angle(ax, b)).vector(), x_axis, 3.0, 1.0)
+    assert np.array_equal(out, [0.9092974268256817, 0.0, 0.0, -0.4161468365471424])
+    out = ev(lambda ax, a: Q.from_axis_angle(ax, a).inverse().vector(), x_axis, 3.0)
+    assert np.allclose(out, [-0.9974949866040544, 0.0, 0.0, 0.0707372016677029], rtol=1e-15, atol=0)
+    out = ev(lambda ax, a, v: Q.from_axis_angle(ax, a) @ v, x_axis, 3.0, [1.0, 2.0, 3.0])
+    assert np.allclose(out, [1.0, -2.4033450173804924, -2.6877374736816018], rtol=1e-6)
+    out = ev(lambda i, j: (Q(i) * Q(j)).vector(), [1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0])
+    assert np.array_equal(out, [0.0, 0.0, 1.0, 0.0])                                     # i * j = k, scalar last
+    # spatial.rs:631-650 test_spatial_transform_add (exact), :653-676 test_spatial_transform_integrate (20 steps, 1e-5)
+    add = lambda q, p, w, v: (lambda t: dsl.np.concatenate([t.angular().vector(), t.linear()]))(
+        dsl.SpatialTransform(Q(q), p) + dsl.SpatialMotion(w, v))
+    out = ev(add, [0.0, 0.0, 0.0, 1.0], [0.0, 0.0, 0.0], [0.0, 0.0, 1.0], [0.0, 0.0, 0.0])
+    assert np.array_equal(out, [0.0, 0.0, 0.4472135954999579, 0.8944271909999159, 0.0, 0.0, 0.0])
+    def twenty(q, p, w, v):
+        t = dsl.SpatialTransform(Q(q), p)
+        t = dsl.lax.fori_loop(0, 20, lambda i, acc: acc + dsl.SpatialMotion(w, v), t)
+        return dsl.np.concatenate([t.angular().vector(), t.linear()])
+    out = ev(twenty, [0.0, 0.0, 0.0, 1.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.25 / 20.0], [0.0, 0.0, 0.0])
+    assert np.allclose(out, [0.0, 0.0, 0.12467473338522769, 0.992197667229329, 0.0, 0.0, 0.0], atol=1e-5)
+    # test_all.py:86-114 test_spatial_integration: integrate_body with w = (pi/2, 0, 0), twice from identity
+    def integ(q, w):
+        a = Q(q).integrate_body(w)
+        return a.integrate_body(w).vector()
+    out = ev(integ, [0.0, 0.0, 0.0, 1.0], [np.pi / 2, 0.0, 0.0])
+    assert np.allclose(out, [0.97151626, 0.0, 0.0, 0.23697292])
+    out = ev(lambda q: Q(q).normalize().vector(), [0.0, 3.0, 0.0, 4.0])
+    assert np.allclose(out, [0.0, 0.6, 0.0, 0.8], rtol=1e-15)

@@ -129,3 +129,62 @@ def test_join_in_ascending_id_order_when_components_were_inserted_late():
     assert hip.join_rows("world_pos").tolist() == [0, 1] and hip.join_rows("world_vel").tolist() == [1, 0]
     exec.run(1)
     assert np.allclose(exec.column_array("world_pos")[:, 4:], [[2.0, 0, 0], [2.0, 1.0, 0]])
+
+
+# ---- pipes of per-entity systems without six_dof (el.map over Body components) ----------------------------------------------
+
+def test_spatial_integration():  # test_all.py:86-114
+    from elodin_amd import dsl
+
+    @dsl.system
+    def integrate_velocity(world_pos, world_vel):
+        linear = world_pos.linear() + world_vel.linear()
+        angular = world_pos.angular().integrate_body(world_vel.angular())
+        return {"world_pos": dsl.SpatialTransform(linear=linear, angular=angular)}
+
+    w = el.World()
+    w.spawn(el.Body(world_pos=el.SpatialTransform(linear=np.array([0.0, 0.0, 0.0])),
+                    world_vel=el.SpatialMotion(linear=np.array([1.0, 0.0, 0.0]), angular=np.array([np.pi / 2, 0.0, 0.0])),
+                    inertia=el.SpatialInertia(1.0)), "e1")
+    exec = w.build(integrate_velocity)
+    exec.run()
+    exec.run()
+    pos = exec.column_array("world_pos")[-1]
+    assert (pos[4:] == [2.0, 0.0, 0.0]).all()
+    assert np.allclose(pos[:4], np.array([0.97151626, 0.0, 0.0, 0.23697292]))
+    assert exec.tick == 2
+    # nothing integrates: velocity, acceleration and force columns pass through
+    assert np.array_equal(exec.column_array("world_vel")[-1], [np.pi / 2, 0.0, 0.0, 1.0, 0.0, 0.0])
+    assert not exec.column_array("world_accel").any() and not exec.column_array("force").any()
+
+
+def test_spatial_vector_algebra():  # test_all.py:204-225
+    from elodin_amd import dsl
+
+    @dsl.system
+    def double_vec(world_vel):
+        return {"world_vel": world_vel + world_vel}
+
+    w = el.World()
+    w.spawn(el.Body(world_vel=el.SpatialMotion(linear=np.array([1.0, 0.0, 0.0]))), "e1")
+    exec = w.build(double_vec)
+    exec.run()
+    assert np.array_equal(exec.column_array("world_vel")[-1], [0.0, 0.0, 0.0, 2.0, 0.0, 0.0])
+
+
+def test_map_with_cond_over_a_component():  # test_all.py:731-772 (el.map + jax.lax.cond), on Body entities
+    from elodin_amd import dsl
+
+    @dsl.system
+    def cond_with_map(x):
+        result = dsl.lax.cond(x > 5.0, lambda _: x * 2.0, lambda _: x * 10.0, operand=None)
+        taken = dsl.lax.cond(x > 5.0, lambda _: 1.0, lambda _: 0.0, operand=None)
+        return {"x": result, "branch_taken": taken}
+
+    w = el.World()
+    w.spawn([el.Body(), el.C("x", [3.0]), el.C("branch_taken", [0.0])], "e1")
+    w.spawn([el.Body(), el.C("x", [10.0]), el.C("branch_taken", [0.0])], "e2")
+    exec = w.build(cond_with_map)
+    exec.run()
+    assert np.allclose(exec.column_array("x")[:, 0], [30.0, 20.0])
+    assert np.allclose(exec.column_array("branch_taken")[:, 0], [0.0, 1.0])
