@@ -317,8 +317,23 @@ class World:
             for it in program_stages[0] + program_stages[1]:
                 if not isinstance(it, _dsl.System):
                     raise TypeError("systems piped around six_dof must be elodin_amd.dsl systems")
-        pos, ids = self.column("world_pos")
-        body = {k: self.column(k) for k in ("world_vel", "inertia", "world_accel", "force")}
+        synthesized_body = None
+        if "world_pos" not in self._components and program_stages is not None and getattr(system, "no_six_dof", False):
+            # a world of plain components (no Body anywhere): the row set is every entity carrying a component the systems
+            # touch; the executor still wants Body columns, so identity ones stand in (never read by the systems)
+            widths0 = {name: int(self.column(name)[0].shape[1]) for name in self._components}
+            used = [n for n, _ in _dsl.Program(program_stages[0], _dsl.Pipe([]), program_stages[1]).trace(widths0).columns]
+            univ = np.unique(np.concatenate([self.column(n)[1] for n in used] or [np.zeros(0, np.uint64)])).astype(np.uint64)
+            nb = len(univ)
+            synthesized_body = {"world_pos": np.tile([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], (nb, 1)), "world_vel": np.zeros((nb, 6)),
+                                "inertia": np.tile([1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 1.0], (nb, 1)), "world_accel": np.zeros((nb, 6)),
+                                "force": np.zeros((nb, 6))}
+        if synthesized_body is not None:
+            pos, ids = synthesized_body["world_pos"], univ
+            body = {k: (synthesized_body[k], univ) for k in ("world_vel", "inertia", "world_accel", "force")}
+        else:
+            pos, ids = self.column("world_pos")
+            body = {k: self.column(k) for k in ("world_vel", "inertia", "world_accel", "force")}
         # components may live on different entity sets (a scene object with a world_pos but no Body):
         # six_dof runs on the intersection (query.rs:136-208); each column keeps its own id vector
         column_ids = {"world_pos": ids, **{k: v[1] for k, v in body.items()}}
@@ -329,12 +344,31 @@ class World:
             if not isinstance(system.effectors, _dsl.Pipe) and system.effectors.ops:
                 raise TypeError("inside a generated program the six_dof effectors must be dsl effectors")
             widths = {name: int(self.column(name)[0].shape[1]) for name in self._components}
+            # the executor's row set: the Body join (ascending id unless the Body columns already coincide, query.rs:673,702)
+            row_ids = ids
+            for v in column_ids.values():
+                if not np.array_equal(v, row_ids):
+                    row_ids = np.intersect1d(row_ids, v)
+            probe = _dsl.Program(program_stages[0], eff_pipe, program_stages[1]).trace(widths)
+            partial = [n for n, _ in probe.columns if not np.all(np.isin(row_ids, self.column(n)[1]))]
             effs = _dsl.Program(program_stages[0], eff_pipe, program_stages[1])
-            extra_columns = {}
-            for name, _w in effs.trace(widths).columns:
+            extra_columns, self_partial = {}, {}
+            for name, w_ in effs.trace(widths, partial).columns:
+                if name.startswith("has:"):
+                    continue
                 arr, aids = self.column(name)
-                column_ids[name] = aids
-                extra_columns[name] = arr
+                if name in partial:      # densify onto the row set + presence column (the system's query join mask)
+                    where = {int(e): k for k, e in enumerate(row_ids)}
+                    sel = np.array([k for k, e in enumerate(aids) if int(e) in where], dtype=np.int64)
+                    at = np.array([where[int(aids[k])] for k in sel], dtype=np.int64)
+                    dense, has = np.zeros((len(row_ids), w_)), np.zeros((len(row_ids), 1))
+                    dense[at], has[at] = arr[sel], 1.0
+                    extra_columns[name], extra_columns["has:" + name] = dense, has
+                    column_ids[name] = column_ids["has:" + name] = row_ids
+                    self_partial[name] = (at, sel, len(aids), arr)
+                else:
+                    column_ids[name] = aids
+                    extra_columns[name] = arr
         elif isinstance(system.effectors, _dsl.Pipe):
             effs = system.effectors
             extra_columns = {}
@@ -362,7 +396,9 @@ class World:
                       effectors=effs, edges=edges,
                       ticks_per_launch=ticks_per_telemetry, device=device,
                       column_entity_ids=None if same else column_ids, columns=extra_columns)
-        return Exec(hip, self, ticks_per_telemetry, dt)
+        ex = Exec(hip, self, ticks_per_telemetry, dt)
+        ex._partial = locals().get("self_partial", {})
+        return ex
 
 
 class Exec:
@@ -384,6 +420,11 @@ class Exec:
                 "force": self._hip.force, "inertia": self._hip.inertia}
         if name in cols:
             return cols[name]
+        if name in getattr(self, "_partial", {}):     # component on fewer entities than the row set: its own rows, own order
+            at, sel, n_own, original = self._partial[name]
+            out = np.array(original, dtype=np.float64)
+            out[sel] = self._hip._aux[name][at]
+            return out
         if name in self._hip._aux:
             return self._hip._aux[name]
         raise KeyError(name)

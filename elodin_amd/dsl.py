@@ -703,7 +703,7 @@ def system(fn=None, every: int = 1, **widths):
 class TracedSystem:
     """One system as (target, expression) assignments over the register file / body state."""
 
-    def __init__(self, sys_: System, table: ColumnTable):
+    def __init__(self, sys_: System, table: ColumnTable, partial: Sequence[str] = ()):
         self.name, self.every = sys_.__name__, sys_.every
         pos, vel, inertia = _body_symbols()
         kwargs = {}
@@ -751,6 +751,16 @@ class TracedSystem:
                     raise ValueError(f"system {self.name}: component {cname} has width {len(cur)}, got {len(v)} values")
                 for k, e in enumerate(v.e):
                     self.assign.append((cur[k].name, e))
+        # query join (query.rs:136-208): a system runs on the entities that HAVE every component it reads or writes.
+        # Components living on fewer entities than the executor's row set arrive densified with a presence column
+        # `has:<name>`; the system's writes are predicated on all of them.
+        need = [n for n in list(sys_.params) + list(out.keys()) if n in partial]
+        if need:
+            mask = None
+            for n in dict.fromkeys(need):
+                h = table.symbols("has:" + n, 1, 1)[0] > 0.5
+                mask = h if mask is None else (mask & h)
+            self.assign = [(t, Expr("select", (mask, e, leaf(t)))) for t, e in self.assign]
         self.written = [t for t, _ in self.assign]
 
 
@@ -761,18 +771,19 @@ class Program:
         self.pre, self.effectors, self.post = list(pre), effectors, list(post)
         self._traced = None
 
-    def trace(self, widths: Optional[Dict[str, int]] = None) -> "TracedProgram":
+    def trace(self, widths: Optional[Dict[str, int]] = None, partial: Sequence[str] = ()) -> "TracedProgram":
         if self._traced is None:
-            self._traced = TracedProgram(self, widths)
+            self._traced = TracedProgram(self, widths, partial)
         return self._traced
 
 
 class TracedProgram:
-    def __init__(self, prog: Program, widths: Optional[Dict[str, int]] = None):
+    def __init__(self, prog: Program, widths: Optional[Dict[str, int]] = None, partial: Sequence[str] = ()):
         self.table = ColumnTable("c", 48, 16, widths)
-        self.pre = [TracedSystem(s, self.table) for s in prog.pre]
+        self.partial = tuple(partial)
+        self.pre = [TracedSystem(s, self.table, self.partial) for s in prog.pre]
         self.pipe = TracedPipe(prog.effectors.effectors, table=self.table)
-        self.post = [TracedSystem(s, self.table) for s in prog.post]
+        self.post = [TracedSystem(s, self.table, self.partial) for s in prog.post]
         self.writes_inertia = any(s.writes_inertia for s in self.pre + self.post)
         written = set()
         for s in self.pre + self.post:

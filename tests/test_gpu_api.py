@@ -188,3 +188,50 @@ def test_map_with_cond_over_a_component():  # test_all.py:731-772 (el.map + jax.
     exec.run()
     assert np.allclose(exec.column_array("x")[:, 0], [30.0, 20.0])
     assert np.allclose(exec.column_array("branch_taken")[:, 0], [0.0, 1.0])
+
+
+def test_basic_system():  # test_all.py:18-64: three piped systems over plain components; each runs on its own query join
+    from elodin_amd import dsl
+
+    @dsl.system
+    def foo(x):
+        return {"x": x * 2}
+
+    @dsl.system
+    def bar(x, y):
+        return {"x": x * y}
+
+    @dsl.system
+    def baz(x, effect):
+        return {"x": x + effect}
+
+    w = el.World()
+    w.spawn([el.C("x", [1.0]), el.C("y", [500.0])], "e1")
+    w.spawn([el.C("x", [15.0]), el.C("y", [500.0]), el.C("effect", [15.0])], "e2")
+    exec = w.build(foo | bar | baz)
+    hist = {"x": [exec.column_array("x")[:, 0].copy()], "y": [exec.column_array("y")[:, 0].copy()]}
+    for _ in range(2):
+        exec.run()
+        hist["x"].append(exec.column_array("x")[:, 0].copy())
+        hist["y"].append(exec.column_array("y")[:, 0].copy())
+    assert np.array_equal(np.array(hist["x"])[:, 0], [1.0, 1000.0, 1000000.0])           # e1.x
+    assert np.array_equal(np.array(hist["x"])[:, 1], [15.0, 15015.0, 15015015.0])        # e2.x: baz only touches e2
+    assert np.array_equal(np.array(hist["y"]), [[500.0, 500.0]] * 3)
+    assert np.array_equal(exec.column_array("effect"), [[15.0]])                         # lives on e2 alone
+
+
+def test_map_over_multiple_entities_and_outputs():  # test_all.py:443-500 (map_seq == map results)
+    from elodin_amd import dsl
+
+    @dsl.system
+    def compute(x):
+        return {"x": x * 2, "y": x + 100.0}
+
+    w = el.World()
+    for k, v in enumerate((1.0, 2.0, 3.0)):
+        w.spawn([el.C("x", [v]), el.C("y", [0.0])], f"e{k + 1}")
+    exec = w.build(compute)
+    exec.run()
+    exec.run()
+    assert np.array_equal(exec.column_array("x")[:, 0], [4.0, 8.0, 12.0])
+    assert np.array_equal(exec.column_array("y")[:, 0], [102.0, 104.0, 106.0])
