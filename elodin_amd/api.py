@@ -148,6 +148,9 @@ class GravityEdge:
     component: str = "gravity_edge"
 
 
+Edge = GravityEdge      # el.Edge(a, b) under an archetype's own component name: Edge(a, b, component="e")
+
+
 # ---- systems --------------------------------------------------------------------------------------------------
 
 @dataclass
@@ -300,6 +303,14 @@ class World:
         ticks_per_telemetry = int(self._lib.sixdof_world_ticks_per_telemetry(self._w))
         dt = float(self._lib.sixdof_world_time_step(self._w))
         from . import dsl as _dsl
+        if isinstance(system, _dsl.GraphFold):     # a stand-alone edge_fold system over plain components (test_all.py:117-142)
+            from .graph_exec import GraphFoldExec
+            pairs = self._edges.get(system.edge_component)
+            if pairs is None:
+                raise KeyError(system.edge_component)
+            edges = (np.array([a for a, _ in pairs], dtype=np.uint64), np.array([b for _, b in pairs], dtype=np.uint64))
+            names = dict.fromkeys(system.left + system.right + (system.out,))
+            return GraphFoldExec(system, {n: self.column(n) for n in names}, edges, device=device)
         program_stages = None
         if isinstance(system, _dsl.System):
             system = _dsl.Stages([system])

@@ -398,6 +398,86 @@ def build_pair(tf: "dsl.TracedFold") -> Path:
     return _compile(generate_pair_source(tf), "pair")
 
 
+def generate_graph_fold_source(tf: "dsl.TracedGraphFold") -> str:
+    """A stand-alone GraphQuery.edge_fold over arbitrary components: one lane per source entity folds its out-edges
+    (CSR by source, spawn order) into a scratch row; a second kernel moves the rows into the output component, so every
+    fold sees the component values from before the system ran."""
+    _TABLES.clear()
+    f = tf.fold
+    leaves = {f"acc_{k}": f"acc[{k}]" for k in range(tf.widths[f.out])}
+    loads_a, loads_b = [], []
+    for i, n in enumerate(f.left):
+        for k in range(tf.widths[n]):
+            leaves[f"a{i}_{k}"] = f"a{i}[{k}]"
+        loads_a.append(f"    const double* a{i} = P.left[{i}] + (size_t)row * {tf.widths[n]};")
+    for i, n in enumerate(f.right):
+        for k in range(tf.widths[n]):
+            leaves[f"b{i}_{k}"] = f"b{i}[{k}]"
+        loads_b.append(f"        const double* b{i} = P.right[{i}] + (size_t)P.dst[e] * {tf.widths[n]};")
+    w = tf.widths[f.out]
+    body = "\n".join(emit_block([(f"acc[{k}]", e) for k, e in enumerate(tf.outputs)], leaves, indent="        "))
+    init = ", ".join(repr(v) for v in f.init)
+    nl = "\n"
+    return f'''// generated by elodin_amd/codegen.py — do not edit.  stand-alone edge_fold system: {f.__name__}
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cmath>
+namespace sixdof {{
+__device__ __forceinline__ double fast_sqrt(double x) {{ return sqrt(x); }}
+__device__ __forceinline__ float fast_sqrt(float x) {{ return sqrtf(x); }}
+{_PRELUDE}
+{_emit_tables()}
+struct GraphFoldParams {{
+    const double* left[8];
+    const double* right[8];
+    double* scratch;             // [n_src, {w}]
+    double* out;                 // the output component column, dense over the row set
+    const uint32_t* row_start;   // [n_src + 1]
+    const uint32_t* dst;         // [n_edges] target rows
+    const uint32_t* src_rows;    // [n_src] source rows
+    uint32_t n_src;
+}};
+
+__global__ __launch_bounds__(256) void graph_fold_kernel(const GraphFoldParams P) {{
+    using T = double;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_src) return;
+    const uint32_t row = P.src_rows[i];
+{nl.join(loads_a)}
+    double acc[{w}] = {{{init}}};
+    for (uint32_t e = P.row_start[i]; e < P.row_start[i + 1]; e++) {{
+{nl.join(loads_b)}
+{body}
+    }}
+    for (int k = 0; k < {w}; k++) P.scratch[(size_t)i * {w} + k] = acc[k];
+}}
+
+__global__ __launch_bounds__(256) void graph_fold_commit(const GraphFoldParams P) {{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_src) return;
+    for (int k = 0; k < {w}; k++) P.out[(size_t)P.src_rows[i] * {w} + k] = P.scratch[(size_t)i * {w} + k];
+}}
+}}  // namespace sixdof
+
+extern "C" unsigned graph_fold_abi() {{ return static_cast<unsigned>(sizeof(sixdof::GraphFoldParams)); }}
+extern "C" int graph_fold_launch(const sixdof::GraphFoldParams* p, unsigned n_ticks, void* stream) {{
+    using namespace sixdof;
+    if (p->n_src == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((p->n_src + 255) / 256);
+    for (unsigned t = 0; t < n_ticks; t++) {{
+        hipLaunchKernelGGL(graph_fold_kernel, grid, dim3(256), 0, s, *p);
+        hipLaunchKernelGGL(graph_fold_commit, grid, dim3(256), 0, s, *p);
+    }}
+    return static_cast<int>(hipGetLastError());
+}}
+'''
+
+
+def build_graph_fold(tf: "dsl.TracedGraphFold") -> Path:
+    return _compile(generate_graph_fold_source(tf), "gfold")
+
+
 def _headers_digest() -> str:
     h = hashlib.sha1()
     for name in ("step_kernel.hpp", "pair_kernel.hpp", "effectors.hpp", "spatial.hpp", "kernels.hpp"):

@@ -665,6 +665,47 @@ class TracedFold:
         self.leaves = _leaves_of(self.outputs)
 
 
+class GraphFold:
+    """`graph.edge_fold(left_query, right_query, return_type, init_value, fn)` as a STAND-ALONE system over arbitrary
+    components (libs/nox-py/python/elodin/__init__.py:454-557, e.g. test_all.py:117-142): for every entity with out-edges,
+    acc = init; for each out-edge in spawn order: acc = fn(acc, *left components of the source, *right components of the
+    target); the result replaces the `out` component on source rows.  All folds read the component values from BEFORE the
+    system ran (the reference's arrays are immutable)."""
+
+    def __init__(self, fn: Callable, edge_component: str, left: Sequence[str], right: Sequence[str], out: str, init):
+        self.fn, self.edge_component = fn, edge_component
+        self.left, self.right, self.out = tuple(left), tuple(right), out
+        self.init = tuple(float(v) for v in (init if isinstance(init, (list, tuple)) else [init]))
+        self.__name__ = getattr(fn, "__name__", "graph_fold")
+        if len(inspect.signature(fn).parameters) != 1 + len(self.left) + len(self.right):
+            raise TypeError("fold function must take (acc, *left components, *right components)")
+
+    def trace(self, widths: Dict[str, int]) -> "TracedGraphFold":
+        return TracedGraphFold(self, widths)
+
+
+def graph_fold(edge_component: str, left: Sequence[str], right: Sequence[str], out: str, init=0.0):
+    return lambda fn: GraphFold(fn, edge_component, left, right, out, init)
+
+
+class TracedGraphFold:
+    def __init__(self, fold: GraphFold, widths: Dict[str, int]):
+        self.fold = fold
+        self.widths = {n: int(widths[n]) for n in dict.fromkeys(fold.left + fold.right + (fold.out,))}
+        w_out = self.widths[fold.out]
+        if len(fold.init) != w_out:
+            raise ValueError(f"init has {len(fold.init)} values, component {fold.out} has width {w_out}")
+        sym = lambda prefix, w: (lambda v: v if w > 1 else v[0])(Vec([leaf(f"{prefix}_{k}") for k in range(w)]))
+        acc = sym("acc", w_out)
+        args = [sym(f"a{i}", self.widths[n]) for i, n in enumerate(fold.left)]
+        args += [sym(f"b{i}", self.widths[n]) for i, n in enumerate(fold.right)]
+        out = fold.fn(acc, *args)
+        out = out if isinstance(out, Vec) else Vec([out])
+        if len(out) != w_out:
+            raise ValueError(f"fold function returned {len(out)} values for component {fold.out} of width {w_out}")
+        self.outputs: List[Expr] = list(out.e)
+
+
 # ---- systems piped around six_dof ----------------------------------------------------------------------------------
 
 class System:

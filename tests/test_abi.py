@@ -59,3 +59,19 @@ def test_product_never_imports_oracle():
         if p.suffix in (".py", ".cpp", ".hip", ".hpp", ".h") and p.is_file():
             text = p.read_text()
             assert "sixdof_oracle" not in text and "from oracle" not in text and "import oracle" not in text, p
+
+
+def test_stand_alone_edge_fold_fails_loudly_without_gpu():
+    if L.lib().sixdof_device_count() > 0:
+        pytest.skip("GPU present")
+    import elodin_amd as ea
+    from elodin_amd import dsl
+
+    @dsl.graph_fold("e", left=("x",), right=("x",), out="x", init=5.0)
+    def fold_test(x, a, b):
+        return x + a + b
+    w = ea.World()
+    a, b = w.spawn(ea.C("x", [1.0])), w.spawn(ea.C("x", [2.0]))
+    w.spawn(ea.Edge(a, b, component="e"))
+    with pytest.raises(ea.BackendError):
+        w.build(fold_test)
