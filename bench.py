@@ -307,6 +307,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_hbm / fused legs")
+    ap.add_argument("--skip-legs", default="", help="comma-separated informational legs to leave out (e.g. telemetry_commit)")
     ap.add_argument("--campaign", choices=("apollo", "falcon9"), default=None,
                     help="instead of the config-2 step: one whole Monte-Carlo campaign (BASELINE configs[3] / configs[4]) "
                          "sharded over the ranks, plan broadcast + result gather over RCCL; --steps/--warmup are ignored")
@@ -413,6 +414,8 @@ def main():
             out["roofline_hbm"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     def extra(name, fn, *a):
         # informational legs must never take the headline line down with them
+        if name in args.skip_legs.split(","):
+            return
         try:
             out[name] = fn(*a)
         except Exception as e:  # noqa: BLE001
