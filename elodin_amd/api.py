@@ -350,6 +350,7 @@ class World:
         column_ids = {"world_pos": ids, **{k: v[1] for k, v in body.items()}}
         effs = []
         extra_columns = None
+        self_partial = {}      # components living on fewer entities than the row set: (rows in the set, own rows, n, original)
         if program_stages is not None:
             eff_pipe = system.effectors if isinstance(system.effectors, _dsl.Pipe) else _dsl.Pipe([])
             if not isinstance(system.effectors, _dsl.Pipe) and system.effectors.ops:
@@ -363,7 +364,7 @@ class World:
             probe = _dsl.Program(program_stages[0], eff_pipe, program_stages[1]).trace(widths)
             partial = [n for n, _ in probe.columns if not np.all(np.isin(row_ids, self.column(n)[1]))]
             effs = _dsl.Program(program_stages[0], eff_pipe, program_stages[1])
-            extra_columns, self_partial = {}, {}
+            extra_columns = {}
             for name, w_ in effs.trace(widths, partial).columns:
                 if name.startswith("has:"):
                     continue
@@ -408,7 +409,7 @@ class World:
                       ticks_per_launch=ticks_per_telemetry, device=device,
                       column_entity_ids=None if same else column_ids, columns=extra_columns)
         ex = Exec(hip, self, ticks_per_telemetry, dt)
-        ex._partial = locals().get("self_partial", {})
+        ex._partial = self_partial
         return ex
 
 
