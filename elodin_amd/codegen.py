@@ -180,7 +180,7 @@ _PRELUDE = '''// SIXDOF_FAST_MATH (f32 programs, opt-in): hardware transcendenta
 // tick of the Falcon 9 program makes 32 of them.  f64 programs and the default f32 mode keep the library functions.
 template <class T> __device__ __forceinline__ T m_div(T a, T b) { return a / b; }
 #ifdef SIXDOF_FAST_MATH
-__device__ __forceinline__ float m_div(float a, float b) { return __fdividef(a, b); }
+__device__ __forceinline__ float m_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }   // v_rcp_f32, 1 ulp
 __device__ __forceinline__ float m_sqrt(float x) { return __fsqrt_rn(x); }
 __device__ __forceinline__ double m_sqrt(double x) { return fast_sqrt(x); }
 #else
@@ -192,7 +192,7 @@ __device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
     __device__ __forceinline__ double name(double x) { return fd(x); } \\
     __device__ __forceinline__ float name(float x) { return ff(x); }
 #ifdef SIXDOF_FAST_MATH
-__device__ __forceinline__ float m_fast_tan(float x) { return __fdividef(__sinf(x), __cosf(x)); }
+__device__ __forceinline__ float m_fast_tan(float x) { return __sinf(x) * __builtin_amdgcn_rcpf(__cosf(x)); }
 SIXDOF_M1(m_sin, sin, __sinf) SIXDOF_M1(m_cos, cos, __cosf) SIXDOF_M1(m_tan, tan, m_fast_tan) SIXDOF_M1(m_exp, exp, __expf)
 SIXDOF_M1(m_log, log, __logf)
 #else
@@ -203,7 +203,28 @@ SIXDOF_M1(m_acos, acos, acosf) SIXDOF_M1(m_asin, asin, asinf)
 #define SIXDOF_M2(name, fd, ff) \\
     __device__ __forceinline__ double name(double x, double y) { return fd(x, y); } \\
     __device__ __forceinline__ float name(float x, float y) { return ff(x, y); }
-SIXDOF_M2(m_max, fmax, fmaxf) SIXDOF_M2(m_min, fmin, fminf) SIXDOF_M2(m_atan2, atan2, atan2f)
+SIXDOF_M2(m_max, fmax, fmaxf) SIXDOF_M2(m_min, fmin, fminf)
+#ifdef SIXDOF_FAST_MATH
+// atan2 without the library call (45 instructions, and ECEF->geodetic makes nine of them): octant reduction to
+// [0, 1], one more reduction about tan(pi/8), degree-7 odd minimax polynomial (the classic single-precision atan
+// kernel), quadrant fix-ups.  ~1e-7 absolute.
+__device__ __forceinline__ float m_fast_atan2(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mx > 0.0f ? mn * __builtin_amdgcn_rcpf(mx) : 0.0f;
+    const bool hi = t > 0.4142135623730950f;
+    const float u = (hi ? t - 1.0f : t) * __builtin_amdgcn_rcpf(hi ? t + 1.0f : 1.0f);   // branch-free second reduction
+    const float z = u * u;
+    const float p = ((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f;
+    float r = fmaf(p * z, u, u) + (hi ? 0.78539816339744831f : 0.0f);
+    r = ay > ax ? 1.57079632679489662f - r : r;
+    r = x < 0.0f ? 3.14159265358979323f - r : r;
+    return copysignf(r, y);
+}
+SIXDOF_M2(m_atan2, atan2, m_fast_atan2)
+#else
+SIXDOF_M2(m_atan2, atan2, atan2f)
+#endif
 #ifdef SIXDOF_FAST_MATH
 __device__ __forceinline__ float m_fast_pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }   // x > 0 (x = 0 -> 0 for y > 0)
 __device__ __forceinline__ float m_fast_hypot(float x, float y) { return __fsqrt_rn(x * x + y * y); }

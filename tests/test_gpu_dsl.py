@@ -114,9 +114,10 @@ def test_select_clip_and_transcendentals_f32_and_f64():
     w = workloads.independent_bodies(n)
     cmd = np.random.default_rng(0).uniform(-1, 1, (n, 2))
     tp = dsl.pipe(odd).trace()
-    for dtype, tol in ((np.float64, parity.F64_RTOL), (np.float32, 2e-4)):
+    # third leg: f32 with hardware transcendentals / polynomial atan2 (codegen fast_math), same f32 tolerance
+    for dtype, tol, fast in ((np.float64, parity.F64_RTOL, False), (np.float32, 2e-4, False), (np.float32, 2e-4, True)):
         hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=dtype, simulation_time_step=workloads.DT_120HZ,
-                         effectors=odd, columns={"cmd": cmd})
+                         effectors=odd, columns={"cmd": cmd}, fast_math=fast)
         pos_r, vel_r, acc_r = w["world_pos"].copy(), w["world_vel"].copy(), np.zeros((n, 6))
         eff = lambda xs, vs: dsl_numpy.evaluate(tp, xs, vs, w["inertia"], {"cmd": cmd})
         for _ in range(10):
@@ -410,3 +411,37 @@ def test_edge_fold_needs_edges_and_must_close_the_pipe():
         el.HipExec(pos, vel, inertia, effectors=[gravity_fn])
     with pytest.raises(ValueError):
         el.HipExec(pos, vel, inertia, effectors=[gravity_fn, el.Effector(L.EFF_UNIFORM_GRAVITY, (0, 0, -1))], edges=(frm, to))
+
+
+def test_fast_math_functions_over_their_domains():
+    """codegen fast_math (f32): every replaced function against numpy in f64 over a grid of arguments, through a program
+    that just evaluates them into a component column.  Bound: |err| <= 2e-6 + 4e-6 |value| for every function
+    (sin / cos / tan / atan2 / atan / exp / pow / log / division / sqrt / hypot) on the ranges the campaigns use."""
+    @dsl.system
+    def table(a, b):
+        x, y = a[0], a[1]
+        return {"b": np_.array([np_.sin(x), np_.cos(x), np_.tan(x * 0.4), np_.arctan2(y, x), np_.arctan2(x, y), np_.exp(-np_.abs(x)),
+                                np_.power(np_.abs(x) + 0.5, y), x / (np_.abs(y) + 0.25), np_.sqrt(np_.abs(x)), np_.hypot(x, y),
+                                np_.arctan(x * 3.0), np_.log(np_.abs(y) + 0.1)])}
+    rng = np.random.default_rng(4)
+    n = 4096
+    a = np.stack([rng.uniform(-3.1, 3.1, n), rng.uniform(-3.1, 3.1, n)], axis=1)
+    a[:8] = [[0, 1], [1, 0], [0, -1], [-1, 0], [1, 1], [-1, -1], [0.0, 0.0], [-2.5, 1e-3]]
+    w = workloads.independent_bodies(n)
+    x, y = a[:, 0], a[:, 1]
+    want = np.stack([np.sin(x), np.cos(x), np.tan(x * 0.4), np.arctan2(y, x), np.arctan2(x, y), np.exp(-np.abs(x)),
+                     np.power(np.abs(x) + 0.5, y), x / (np.abs(y) + 0.25), np.sqrt(np.abs(x)), np.hypot(x, y), np.arctan(x * 3.0),
+                     np.log(np.abs(y) + 0.1)], axis=1)
+    prog = dsl.Program([table], dsl.Pipe([]), [])
+    hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=np.float32, integrator=L.INTEGRATOR_NONE,
+                     effectors=prog, columns={"a": a, "b": np.zeros((n, 12))}, fast_math=True)
+    hip.run(1)
+    got = np.asarray(hip._aux["b"], dtype=np.float64)
+    a32 = a.astype(np.float32).astype(np.float64)       # the kernel sees the f32-rounded arguments
+    x, y = a32[:, 0], a32[:, 1]
+    want = np.stack([np.sin(x), np.cos(x), np.tan(x * 0.4), np.arctan2(y, x), np.arctan2(x, y), np.exp(-np.abs(x)),
+                     np.power(np.abs(x) + 0.5, y), x / (np.abs(y) + 0.25), np.sqrt(np.abs(x)), np.hypot(x, y), np.arctan(x * 3.0),
+                     np.log(np.abs(y) + 0.1)], axis=1)
+    err = np.abs(got - want)
+    excess = err - (2e-6 + 4e-6 * np.abs(want))
+    assert excess.max() <= 0.0, (np.unravel_index(np.argmax(excess), excess.shape), excess.max())
