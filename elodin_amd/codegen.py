@@ -115,7 +115,13 @@ class _Emitter:
                 rhs = f"{a[0]} ? {a[1]} : {a[2]}"
             elif e.op == "interp":
                 stem = _TABLES.setdefault(e.value, f"tab{len(_TABLES)}")
-                rhs = f"m_interp<T, {len(e.value[0])}>({a[0]}, {stem}_x, {stem}_f)"
+                xs = e.value[0]
+                step = (xs[-1] - xs[0]) / (len(xs) - 1)
+                uniform = len(xs) > 32 and step > 0 and all(abs((b - a) - step) <= 1e-9 * step for a, b in zip(xs, xs[1:]))
+                if uniform:   # evenly spaced long table: index by division instead of bisecting through memory
+                    rhs = f"m_interp_uniform<T, {len(xs)}>({a[0]}, {stem}_x, {stem}_f, T({1.0 / step!r}))"
+                else:
+                    rhs = f"m_interp<T, {len(xs)}>({a[0]}, {stem}_x, {stem}_f)"
             elif e.op == "lt":
                 rhs = f"{a[0]} < {a[1]}"
             elif e.op == "le":
@@ -251,6 +257,22 @@ __device__ __forceinline__ T m_interp(T x, const double (&xp)[N], const double (
     const int i = c < 1 ? 1 : (c > N - 1 ? N - 1 : c);
     const T x0 = T(xp[i - 1]), f0 = T(fp[i - 1]);
     const T dx = T(xp[i]) - x0, df = T(fp[i]) - f0;
+    T f = dx == T(0) ? f0 : f0 + ((x - x0) / dx) * df;
+    f = x < T(xp[0]) ? T(fp[0]) : f;
+    return x > T(xp[N - 1]) ? T(fp[N - 1]) : f;
+}
+// Same result for an evenly spaced table: the interval comes from one multiply (then is corrected against the stored
+// breakpoints, so it is exactly searchsorted's), instead of log2(N) dependent table loads.
+template <class T, int N>
+__device__ __forceinline__ T m_interp_uniform(T x, const double (&xp)[N], const double (&fp)[N], T inv_step) {
+    T k = (x - T(xp[0])) * inv_step;
+    k = k > T(0) ? (k < T(N) ? k : T(N)) : T(0);                      // also absorbs NaN and values far off the table
+    int c = static_cast<int>(k) + 1;                                  // ~ number of breakpoints <= x
+    c = c < 1 ? 1 : (c > N - 1 ? N - 1 : c);
+    c = (c > 1 && x < T(xp[c - 1])) ? c - 1 : c;
+    c = (c < N - 1 && T(xp[c]) <= x) ? c + 1 : c;
+    const T x0 = T(xp[c - 1]), f0 = T(fp[c - 1]);
+    const T dx = T(xp[c]) - x0, df = T(fp[c]) - f0;
     T f = dx == T(0) ? f0 : f0 + ((x - x0) / dx) * df;
     f = x < T(xp[0]) ? T(fp[0]) : f;
     return x > T(xp[N - 1]) ? T(fp[N - 1]) : f;

@@ -445,3 +445,36 @@ def test_fast_math_functions_over_their_domains():
     err = np.abs(got - want)
     excess = err - (2e-6 + 4e-6 * np.abs(want))
     assert excess.max() <= 0.0, (np.unravel_index(np.argmax(excess), excess.shape), excess.max())
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-13), (np.float32, 3e-6)])
+def test_interp_over_a_long_evenly_spaced_table_is_exactly_searchsorted(dtype, tol):
+    """Long evenly spaced tables are indexed by division (then corrected against the stored breakpoints) instead of
+    bisected: queries ON breakpoints, between them, at both ends, outside, and for a table whose step is not exactly
+    representable (0.1) must match np.interp."""
+    xs = tuple(0.1 * k - 3.0 for k in range(101))
+    fs = tuple(float(np.sin(1.7 * v) + 0.01 * k) for k, v in enumerate(xs))
+
+    @dsl.system
+    def look(q, r):
+        return {"r": np_.array([np_.interp(q[0], xs, fs), np_.interp(q[1], xs, fs)])}
+    rng = np.random.default_rng(9)
+    n = 2048
+    q = rng.uniform(-3.5, 7.6, (n, 2))
+    q[:101, 0] = xs                                   # exactly on every breakpoint
+    q[:100, 1] = np.nextafter(np.array(xs[1:]), -np.inf)   # just below every breakpoint
+    q[101:105, 0] = [-1e30, 1e30, -3.0, 7.0]
+    w = workloads.independent_bodies(n)
+    hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=dtype, integrator=L.INTEGRATOR_NONE,
+                     effectors=dsl.Program([look], dsl.Pipe([]), []), columns={"q": q, "r": np.zeros((n, 2))})
+    hip.run(1)
+    qq = q.astype(dtype).astype(np.float64)
+    want = np.stack([np.interp(qq[:, 0], xs, fs), np.interp(qq[:, 1], xs, fs)], axis=1)
+    assert "m_interp_uniform" in codegen_source_of(look)
+    assert np.max(np.abs(np.asarray(hip._aux["r"], dtype=np.float64) - want)) < tol
+
+
+def codegen_source_of(system):
+    from elodin_amd import codegen
+    tp = dsl.Program([system], dsl.Pipe([]), []).trace({"q": 2, "r": 2})
+    return codegen.generate_source(tp, "float64", 2)
