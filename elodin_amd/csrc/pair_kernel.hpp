@@ -35,6 +35,7 @@
 namespace sixdof {
 
 constexpr int kTile = 256;  // sources staged per LDS tile = targets per workgroup
+constexpr uint32_t kSmallEdgeCache = 2048;  // edges of a small graph (n <= 256) cached in LDS by the one-launch kernel
 
 // 1/sqrt(x) for x > 0 finite: hardware v_rsq_f64 seed plus one cubic correction
 // (y0 (1 + e/2 + 3e^2/8), e = 1 - x y0^2), full f64 accuracy without the 0/inf special-casing of the
@@ -162,6 +163,19 @@ __global__ __launch_bounds__(kTile) void allpairs_kernel(const double* __restric
 
 // ---- 2b. explicit edge list, CSR by source (three-body and sparse graphs) ---------------------------------
 // One source's left fold over its out-edges (CSR range), spawn order, for the NS stage positions.
+template <int NS, class PAIR>
+__device__ __forceinline__ void edge_accumulate_range(const double* pack, uint32_t e0, uint32_t e1, const uint32_t* dst,
+                                                      uint32_t i, double p0, double p1, double (&acc)[3][6]) {
+    const double* a = pack + (size_t)i * kPackWidth;
+    const double ma = a[9];
+    for (uint32_t e = e0; e < e1; e++) {  // spawn order inside a source
+        const double* b = pack + (size_t)dst[e] * kPackWidth;
+        const double mb = b[9];
+#pragma unroll
+        for (int st = 0; st < NS; st++) PAIR::fold(acc[st], a + 3 * st, ma, b + 3 * st, mb, p0, p1);
+    }
+}
+
 template <int NS, class PAIR>
 __device__ __forceinline__ void edge_accumulate(const double* pack, const uint32_t* __restrict__ row_start,
                                                 const uint32_t* __restrict__ dst, uint32_t i, double p0, double p1,
@@ -342,6 +356,7 @@ __global__ __launch_bounds__(256) void pair_integrate_kernel(const PairParams P)
 template <int INTEGRATOR, class PAIR>
 __global__ __launch_bounds__(kTile) void pair_small_kernel(const PairParams P, uint32_t n_ticks) {
     __shared__ __attribute__((aligned(16))) double pack[kTile * kPackWidth];
+    __shared__ uint32_t l_dst[kSmallEdgeCache];   // the edge list of a small graph lives in LDS for the whole launch
     constexpr int NS = INTEGRATOR == kRk4 ? 3 : 1;
     const uint32_t i = threadIdx.x;
     const bool active = i < P.n;
@@ -350,7 +365,16 @@ __global__ __launch_bounds__(kTile) void pair_small_kernel(const PairParams P, u
     Vec3<double> aux[kMaxOps];
     if (active) load_entity(P, i, e, SP, aux);
     const bool allpairs = P.pair_kind == SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED;
-    const bool is_source = active && (allpairs ? (P.n > 1) : (P.row_start[i + 1] > P.row_start[i]));
+    // CSR range of this source in registers, targets in LDS: the per-tick fold then touches no global memory
+    uint32_t e0 = 0, e1 = 0;
+    const bool cached = !allpairs && P.n_edges <= kSmallEdgeCache;
+    if (!allpairs) {
+        if (active) { e0 = P.row_start[i]; e1 = P.row_start[i + 1]; }
+        if (cached)
+            for (uint32_t k = threadIdx.x; k < P.n_edges; k += blockDim.x) l_dst[k] = P.dst[k];
+    }
+    const uint32_t* const dst = cached ? l_dst : P.dst;
+    const bool is_source = active && (allpairs ? (P.n > 1) : (e1 > e0));
     const double h1 = P.dt_g * 0.5, h3 = P.dt_g;
     Spatial<double> A = {{0, 0, 0}, {0, 0, 0}}, Fw = {{0, 0, 0}, {0, 0, 0}};
     for (uint32_t t = 0; t < n_ticks; t++) {
@@ -382,7 +406,7 @@ __global__ __launch_bounds__(kTile) void pair_small_kernel(const PairParams P, u
                     for (int c = 0; c < 3; c++) pf[st][3 + c] += kmi * acc[st][c];
             } else {
                 double acc[3][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
-                edge_accumulate<NS, PAIR>(pack, P.row_start, P.dst, i, P.p0, P.p1, acc);
+                edge_accumulate_range<NS, PAIR>(pack, e0, e1, dst, i, P.p0, P.p1, acc);
 #pragma unroll
                 for (int st = 0; st < NS; st++)
                     for (int c = 0; c < 6; c++) pf[st][c] += acc[st][c];
@@ -409,8 +433,9 @@ template <class PAIR>
 inline hipError_t launch_pair_small_t(const PairParams& p, int integrator, uint32_t n_ticks, hipStream_t stream,
                                       uint64_t* launches) {
     if (p.n == 0 || n_ticks == 0) return hipSuccess;
-    if (integrator == kRk4) hipLaunchKernelGGL((pair_small_kernel<kRk4, PAIR>), dim3(1), dim3(kTile), 0, stream, p, n_ticks);
-    else hipLaunchKernelGGL((pair_small_kernel<kSemiImplicit, PAIR>), dim3(1), dim3(kTile), 0, stream, p, n_ticks);
+    const dim3 block(p.n <= 64 ? 64 : kTile);   // one wave when it suffices: its barriers cost nothing
+    if (integrator == kRk4) hipLaunchKernelGGL((pair_small_kernel<kRk4, PAIR>), dim3(1), block, 0, stream, p, n_ticks);
+    else hipLaunchKernelGGL((pair_small_kernel<kSemiImplicit, PAIR>), dim3(1), block, 0, stream, p, n_ticks);
     if (launches) *launches += 1;
     return hipGetLastError();
 }
