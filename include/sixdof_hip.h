@@ -18,6 +18,10 @@
  *   validate_rates dt quantise    world_builder.rs:211-243    sixdof_quantize_time_step
  *   six_dof(time_step, sys, integrator)  six_dof.rs:161-203   sixdof_desc + sixdof_set_effectors
  *   GraphQuery edges              graph.rs:17-41,113-175      sixdof_set_edges
+ *   JIT of user systems           cranelift_compile.rs:13-162 sixdof_set_custom_pipe / sixdof_set_custom_pair
+ *   World / Column / spawn        world.rs:23-45,193-229      sixdof_world_* + sixdof_bind_world
+ *   commit_world_head per batch   impeller2_server.rs:390-438 sixdof_download_async / _wait, sixdof_set_history
+ *   failure detection / resume    (process exit, DB replay)   sixdof_count_nonfinite, sixdof_get/set_tick
  *
  * Column byte layout is the reference's (`World.host`, world.rs:23-45): row r of a
  * component occupies bytes [r*size, (r+1)*size), little-endian, row-major, rows in
