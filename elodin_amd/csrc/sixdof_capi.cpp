@@ -334,6 +334,11 @@ int sixdof_bind_columns(sixdof_handle* h, const sixdof_column* cols, size_t n_co
                 if (old->bytes == col.bytes) col.dev = old->dev;
                 else hipFree(old->dev);
             }
+            // async-commit state of the previous binding: the snapshot is sized per binding, the page lock belongs to
+            // the previous host buffer
+            if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+            if (old->snap) hipFree(old->snap);
+            if (old->host_pinned) (void)hipHostUnregister(old->host);
         }
         if (!col.dev && col.bytes) HIP_TRY(h, hipMalloc(&col.dev, col.bytes));
         h->cols[c.component_id] = std::move(col);
