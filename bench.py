@@ -206,6 +206,20 @@ def telemetry_leg(device, n):
     return out
 
 
+def history_stream_leg(device, n):
+    """EVERY tick's output columns to the host (what a full-rate telemetry consumer needs), overlapped with the stepper:
+    in-kernel recording into a two-batch device ring + sixdof_history_stream into page-locked host buffers."""
+    ex, w, eff = make_exec(n, 0, device, 16, False)
+    k, batches = 16, 40
+    ex.stream_history(4, k)
+    secs = ex.stream_history(batches, k)
+    ex.close()
+    mb = n * 8 * (7 + 6 + 6 + 6) / 1e6
+    return {"entities": n, "ticks_per_batch": k, "batches": batches, "MB_per_tick": round(mb, 2),
+            "ms_per_tick": round(secs / (k * batches) * 1e3, 4), "host_GBps": round(mb * k * batches / secs / 1e3, 2),
+            "entity_steps_per_s": round(n * k * batches / secs, 1), "bound": "PCIe (device to host)"}
+
+
 def falcon9_leg(device):
     """BASELINE configs[4]: Falcon 9 ascent Monte-Carlo, 32,768 rollouts, f32, the whole ascent to past MECO (one GPU's
     worth here; the closed loop is a generated program: models/falcon9.py)."""
@@ -426,6 +440,7 @@ def main():
         extra("f32", f32_leg, local_rank)
         extra("nbody", nbody_leg, local_rank)
         extra("telemetry_commit", telemetry_leg, local_rank, n)
+        extra("history_stream", history_stream_leg, local_rank, n)
         extra("apollo_mc", apollo_leg, local_rank)
         extra("falcon9_mc", falcon9_leg, local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -74,6 +74,8 @@ struct sixdof_handle {
     hipStream_t copy_stream = nullptr;          // telemetry D2H, overlaps the compute stream
     hipEvent_t ev_snap = nullptr, ev_copied = nullptr;
     bool copy_pending = false;
+    uint64_t stream_lo = 0, stream_hi = 0;      // ticks of the history run whose copy may still be in flight
+    std::vector<void*> pinned_user;             // host buffers page-locked by sixdof_history_stream
     bool step_pending = false;                  // SIXDOF_FLAG_ASYNC_STEP: ev1 of the last step not yet read
     std::vector<hipEvent_t> launch_events;  // SIXDOF_FLAG_TIME_EACH_LAUNCH: 2 per launch
     std::map<uint64_t, Column> cols;  // ascending ComponentId = reference BTreeMap order
@@ -291,6 +293,7 @@ void sixdof_destroy(sixdof_handle* h) {
         if (kv.second.snap) hipFree(kv.second.snap);
         if (kv.second.host_pinned) hipHostUnregister(kv.second.host);
     }
+    for (void* p : h->pinned_user) (void)hipHostUnregister(p);
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
     if (h->ev_snap) hipEventDestroy(h->ev_snap);
     if (h->ev_copied) hipEventDestroy(h->ev_copied);
@@ -604,6 +607,10 @@ int sixdof_sync(sixdof_handle* h) {
     if (h->step_pending && hipEventElapsedTime(&ms0, h->ev0, h->ev1) == hipSuccess) h->last.kernel_device_ms = ms0;
     h->step_pending = h->prev_pending = false;
     h->copy_pending = false;
+    h->stream_lo = 1, h->stream_hi = 0;
+    // page locks taken on the caller's history buffers end here: the caller may free them after sixdof_sync
+    for (void* p : h->pinned_user) (void)hipHostUnregister(p);
+    h->pinned_user.clear();
     return SIXDOF_OK;
 }
 
@@ -1029,6 +1036,46 @@ int sixdof_history_read(sixdof_handle* h, uint64_t component_id, uint64_t tick, 
     return SIXDOF_OK;
 }
 
+int sixdof_history_stream(sixdof_handle* h, uint64_t first_tick, uint64_t n_ticks, void* const host_dst[4]) {
+    if (!h || !host_dst) return SIXDOF_ERR_INVALID_ARGUMENT;
+    if (!h->hist_ring) return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "history_stream: no history ring (sixdof_set_history)");
+    if (n_ticks == 0) return SIXDOF_OK;
+    const uint64_t last = first_tick + n_ticks - 1;
+    if (first_tick < h->hist_first_tick || last > h->tick || first_tick + h->hist_ring <= h->tick || n_ticks > h->hist_ring)
+        return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "history_stream: ticks are not (all) in the ring");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->copy_stream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_snap, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_snap, h->stream));            // everything recorded so far is in the ring after this
+    HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->ev_snap, 0));
+    const size_t n = h->desc.n_entities, es = h->elem_size();
+    for (int k = 0; k < 4; k++) {
+        if (!host_dst[k]) continue;
+        const size_t block = n * (k == 0 ? 7 : 6) * es;
+        if (!block) continue;
+        if (std::find(h->pinned_user.begin(), h->pinned_user.end(), host_dst[k]) == h->pinned_user.end()) {
+            if (hipHostRegister(host_dst[k], block * n_ticks, hipHostRegisterDefault) == hipSuccess) h->pinned_user.push_back(host_dst[k]);
+            else (void)hipGetLastError();
+        }
+        // the run is contiguous in the ring except where it wraps: at most two copies per column
+        const size_t slot0 = static_cast<size_t>((first_tick - 1) % h->hist_ring);
+        const size_t head = std::min<size_t>(n_ticks, h->hist_ring - slot0);
+        char* dst = static_cast<char*>(host_dst[k]);
+        const char* ring = static_cast<const char*>(h->d_hist[k]);
+        HIP_TRY(h, hipMemcpyAsync(dst, ring + slot0 * block, head * block, hipMemcpyDeviceToHost, h->copy_stream));
+        if (head < n_ticks)
+            HIP_TRY(h, hipMemcpyAsync(dst + head * block, ring, (n_ticks - head) * block, hipMemcpyDeviceToHost, h->copy_stream));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_copied, h->copy_stream));
+    h->copy_pending = true;
+    h->stream_lo = first_tick;
+    h->stream_hi = last;
+    return SIXDOF_OK;
+}
+
 int sixdof_download_column(sixdof_handle* h, uint64_t component_id) {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     Column* c = h->col(component_id);
@@ -1102,6 +1149,15 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
             if (hipEventElapsedTime(&ms_prev, h->ev0, h->ev1) == hipSuccess) h->last.kernel_device_ms = ms_prev;
             h->step_pending = false;
         }
+    }
+    if (h->hist_ring && h->copy_pending && h->stream_hi >= h->stream_lo && n_ticks) {
+        // ticks tick+1 .. tick+n land in slots (t-1) % ring: hold the compute stream back only if that range reaches a
+        // slot the copy stream may still be reading
+        const uint64_t ring = h->hist_ring, in_flight = h->stream_hi - h->stream_lo + 1;
+        const uint64_t a = h->tick % ring, b = (h->stream_lo - 1) % ring;       // first slot written / first slot read
+        const uint64_t gap_ab = (b + ring - a) % ring, gap_ba = (a + ring - b) % ring;
+        const bool overlap = n_ticks + in_flight > ring || gap_ab < std::min<uint64_t>(n_ticks, ring) || gap_ba < in_flight;
+        if (overlap) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_copied, 0));
     }
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     if (h->desc.integrator == SIXDOF_INTEGRATOR_NONE && (!h->custom_launch || h->model != 0 || h->has_pair_op()))

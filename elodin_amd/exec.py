@@ -288,6 +288,43 @@ class HipExec:
         if rc != L.OK:
             _raise(self._h, rc, "sixdof_sync")
 
+    def stream_history(self, n_batches: int, ticks_per_batch: int, consume=None, columns=("world_pos", "world_vel", "world_accel", "force"),
+                       flags: int = 0) -> float:
+        """EVERY tick of every batch to the host, overlapped with the stepper: the kernel records each tick into the
+        device ring (two batches deep), sixdof_history_stream copies batch i's [ticks, n, w] blocks into one of two
+        page-locked host buffers on the copy stream while batch i+1 computes.  `consume(batch_index, first_tick,
+        {column: array [ticks, n, w]})` sees a batch once it has landed (the arrays are reused two batches later).
+        Returns the wall time in seconds."""
+        import time
+        names = ("world_pos", "world_vel", "world_accel", "force")
+        rc = self._lib.sixdof_set_history(self._h, 2 * int(ticks_per_batch))
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_set_history")
+        bufs = [{c: np.empty((ticks_per_batch, self.n, 7 if c == "world_pos" else 6), dtype=self.dtype) for c in columns}
+                for _ in range(2)]
+        ptrs = [(C.c_void_p * 4)(*[b[c].ctypes.data if c in b else None for c in names]) for b in bufs]
+        self.set_flags(flags | L.FLAG_ASYNC_STEP)
+        t0 = time.perf_counter()
+        try:
+            first = []
+            for i in range(n_batches):
+                first.append(self.tick + 1)
+                self.invoke_batch(ticks_per_batch)                       # enqueue batch i (records into ring half i % 2)
+                if i > 0:
+                    self.download_wait()                                 # batch i-1 has landed in bufs[(i-1) % 2]
+                    if consume is not None:
+                        consume(i - 1, first[i - 1], bufs[(i - 1) % 2])
+                rc = self._lib.sixdof_history_stream(self._h, first[i], ticks_per_batch, ptrs[i % 2])
+                if rc != L.OK:
+                    _raise(self._h, rc, "sixdof_history_stream")
+            self.download_wait()
+            if consume is not None and n_batches:
+                consume(n_batches - 1, first[-1], bufs[(n_batches - 1) % 2])
+            self.sync()
+        finally:
+            self.set_flags(flags)
+        return time.perf_counter() - t0
+
     def run_streaming(self, n_batches: int, ticks_per_batch: int, consume=None, flags: int = 0) -> float:
         """The run loop of exec.rs:110-172 (`run(ticks)` = batches of ticks_per_telemetry ticks, each followed by a
         commit of the output columns) with the commit off the critical path: batch i+1 is enqueued before batch i's

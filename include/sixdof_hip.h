@@ -290,6 +290,14 @@ int sixdof_set_history(sixdof_handle* h, uint32_t ring_ticks);
 /* Copy the [n,w] block of `component_id` as it was after `tick` ticks into host_dst.  Fails with
  * SIXDOF_ERR_INVALID_ARGUMENT if that tick is not (or no longer) in the ring. */
 int sixdof_history_read(sixdof_handle* h, uint64_t component_id, uint64_t tick, void* host_dst);
+/* Stream a run of recorded ticks to the host without stalling the stepper: the [n_ticks, n, w] blocks of
+ * world_pos / world_vel / world_accel / force for ticks first_tick .. first_tick + n_ticks - 1 are copied, on the
+ * copy stream, into host_dst[0..3] (a NULL entry skips that column; buffers are page-locked on first use).  Returns
+ * once the copies are enqueued; sixdof_download_wait blocks until they have landed.  With SIXDOF_FLAG_ASYNC_STEP and a
+ * ring of at least two batches the copy of batch i overlaps the compute of batch i+1: a later sixdof_step only waits
+ * (on the device) when it is about to overwrite ring slots that are still being read.  The host buffers must stay
+ * allocated until sixdof_sync, which also releases their page locks. */
+int sixdof_history_stream(sixdof_handle* h, uint64_t first_tick, uint64_t n_ticks, void* const host_dst[4]);
 
 /* ---- rollout models: systems piped AROUND six_dof, fused with it (the pipes of examples/<name>/sim.py) ------------- */
 struct sixdof_apollo_tables; /* include/sixdof_apollo.h */
