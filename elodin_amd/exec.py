@@ -320,9 +320,9 @@ class HipExec:
             self.download_wait()
             if consume is not None and n_batches:
                 consume(n_batches - 1, first[-1], bufs[(n_batches - 1) % 2])
-            self.sync()
         finally:
             self.set_flags(flags)
+            self.sync()          # also drops the page locks on `bufs` before they go out of scope
         return time.perf_counter() - t0
 
     def run_streaming(self, n_batches: int, ticks_per_batch: int, consume=None, flags: int = 0) -> float:
