@@ -83,6 +83,10 @@ class _Emitter:
                 d = frozenset((e.name,))
             else:
                 d = frozenset().union(*[self._deps(a) for a in e.args]) if e.args else frozenset()
+                if e.op == "while":      # plus what the condition / body read from outside the loop
+                    names, cond, body, _ = e.value
+                    inner = frozenset().union(self._deps(cond), *[self._deps(b) for b in body])
+                    d = d | (inner - frozenset(names))
             self.deps[id(e)] = d
             self.keep[id(e)] = e
         return d
@@ -92,54 +96,103 @@ class _Emitter:
         scoped: the block sits inside a conditional — temporaries created in it must not be reused outside."""
         lines: List[str] = []
         before = set(self.names)
+        outer = {"parent": None, "names": self.names, "lines": lines, "vars": {}, "varset": frozenset(), "indent": indent}
 
-        def ref(e: dsl.Expr) -> str:
-            if e.op == "const":
-                return _literal(e.value)
-            if e.op == "leaf":
-                return _leaf_ref(e.name, self.leaves)
-            if id(e) in self.names:
-                return self.names[id(e)]
-            a = [ref(x) for x in e.args]
+        def rhs_of(e: dsl.Expr, a: List[str]) -> str:
             if e.op == "div":
-                rhs = f"m_div({a[0]}, {a[1]})"
-            elif e.op in _BIN:
-                rhs = f"{a[0]} {_BIN[e.op]} {a[1]}"
-            elif e.op == "neg":
-                rhs = f"-{a[0]}"
-            elif e.op in _FN1:
-                rhs = f"{_FN1[e.op]}({a[0]})"
-            elif e.op in _FN2:
-                rhs = f"{_FN2[e.op]}({a[0]}, {a[1]})"
-            elif e.op == "select":
-                rhs = f"{a[0]} ? {a[1]} : {a[2]}"
-            elif e.op == "interp":
+                return f"m_div({a[0]}, {a[1]})"
+            if e.op in _BIN:
+                return f"{a[0]} {_BIN[e.op]} {a[1]}"
+            if e.op == "neg":
+                return f"-{a[0]}"
+            if e.op in _FN1:
+                return f"{_FN1[e.op]}({a[0]})"
+            if e.op in _FN2:
+                return f"{_FN2[e.op]}({a[0]}, {a[1]})"
+            if e.op == "select":
+                return f"{a[0]} ? {a[1]} : {a[2]}"
+            if e.op == "interp":
                 stem = _TABLES.setdefault(e.value, f"tab{len(_TABLES)}")
                 xs = e.value[0]
                 step = (xs[-1] - xs[0]) / (len(xs) - 1)
-                uniform = len(xs) > 32 and step > 0 and all(abs((b - a) - step) <= 1e-9 * step for a, b in zip(xs, xs[1:]))
+                uniform = len(xs) > 32 and step > 0 and all(abs((b - a_) - step) <= 1e-9 * step for a_, b in zip(xs, xs[1:]))
                 if uniform:   # evenly spaced long table: index by division instead of bisecting through memory
-                    rhs = f"m_interp_uniform<T, {len(xs)}>({a[0]}, {stem}_x, {stem}_f, T({1.0 / step!r}))"
-                else:
-                    rhs = f"m_interp<T, {len(xs)}>({a[0]}, {stem}_x, {stem}_f)"
-            elif e.op == "lt":
-                rhs = f"{a[0]} < {a[1]}"
-            elif e.op == "le":
-                rhs = f"{a[0]} <= {a[1]}"
-            elif e.op == "and":
-                rhs = f"{a[0]} && {a[1]}"
-            elif e.op == "or":
-                rhs = f"{a[0]} || {a[1]}"
-            elif e.op == "not":
-                rhs = f"!{a[0]}"
-            else:
-                raise ValueError(f"unsupported op {e.op}")
+                    return f"m_interp_uniform<T, {len(xs)}>({a[0]}, {stem}_x, {stem}_f, T({1.0 / step!r}))"
+                return f"m_interp<T, {len(xs)}>({a[0]}, {stem}_x, {stem}_f)"
+            if e.op == "lt":
+                return f"{a[0]} < {a[1]}"
+            if e.op == "le":
+                return f"{a[0]} <= {a[1]}"
+            if e.op == "and":
+                return f"{a[0]} && {a[1]}"
+            if e.op == "or":
+                return f"{a[0]} || {a[1]}"
+            if e.op == "not":
+                return f"!{a[0]}"
+            raise ValueError(f"unsupported op {e.op}")
+
+        def emit_loop(node: dsl.Expr, sc) -> List[str]:
+            """A data-dependent loop (dsl.lax.while_loop): carried values live in mutable locals of the scope the loop
+            belongs to; everything in the condition / body that does not depend on them is hoisted out."""
+            names, cond, body, max_iter = node.value
+            inits = [ref(x, sc) for x in node.args]
+            cvars = {}
+            for nm, init in zip(names, inits):
+                cvars[nm] = f"{nm}_{self.n}"
+                self.n += 1
+                sc["lines"].append(f"{sc['indent']}T {cvars[nm]} = {init};")
+            inner = {"parent": sc, "names": {}, "lines": [], "vars": cvars, "varset": frozenset(names), "indent": sc["indent"] + "    "}
+            c = ref(cond, inner)
+            inner["lines"].append(f"{inner['indent']}if (!({c})) break;")
+            new = [ref(b, inner) for b in body]
+            tmp = []
+            for k, v in enumerate(new):
+                tmp.append(f"nx{self.n}")
+                self.n += 1
+                inner["lines"].append(f"{inner['indent']}const T {tmp[-1]} = {v};")
+            for nm, t_ in zip(names, tmp):
+                inner["lines"].append(f"{inner['indent']}{cvars[nm]} = {t_};")
+            sc["lines"].append(f"{sc['indent']}for (int it_{self.n} = 0; it_{self.n} < {max_iter}; it_{self.n}++) {{")
+            self.n += 1
+            sc["lines"].extend(inner["lines"])
+            sc["lines"].append(f"{sc['indent']}}}")
+            return [cvars[nm] for nm in names]
+
+        def ref(e: dsl.Expr, sc=outer) -> str:
+            if e.op == "const":
+                return _literal(e.value)
+            if e.op == "leaf":
+                s_ = sc
+                while s_ is not None:
+                    if e.name in s_["vars"]:
+                        return s_["vars"][e.name]
+                    s_ = s_["parent"]
+                return _leaf_ref(e.name, self.leaves)
+            # a node that does not depend on this loop's carried values belongs to the enclosing scope
+            while sc["parent"] is not None and not (self._deps(e) & sc["varset"]):
+                sc = sc["parent"]
+            s_ = sc
+            while s_ is not None:                      # visible in this scope or any enclosing one
+                if id(e) in s_["names"]:
+                    return s_["names"][id(e)]
+                s_ = s_["parent"]
+            if e.op == "while_out":
+                node = e.args[0]
+                key = ("loop", id(node))
+                if key not in sc["names"]:
+                    sc["names"][key] = emit_loop(node, sc)
+                    self._deps(node)
+                name = sc["names"][key][e.value]
+                sc["names"][id(e)] = name
+                self._deps(e)
+                return name
+            a = [ref(x, sc) for x in e.args]
             name = f"t{self.n}"
             self.n += 1
-            self.names[id(e)] = name
+            sc["names"][id(e)] = name
             self._deps(e)
             ctype = "bool" if e.op in _BOOL_OPS else "T"
-            lines.append(f"{indent}const {ctype} {name} = {rhs};")
+            sc["lines"].append(f"{sc['indent']}const {ctype} {name} = {rhs_of(e, a)};")
             return name
 
         outs = []
@@ -152,7 +205,8 @@ class _Emitter:
             lines.append(f"{indent}{lv} = {o};")
         wr = set(written)
         for k in list(self.names):
-            if (scoped and k not in before) or (wr and self.deps[k] & wr):
+            dk = self.deps.get(k[1] if isinstance(k, tuple) else k, frozenset())
+            if (scoped and k not in before) or (wr and dk & wr):
                 del self.names[k]
         return lines
 

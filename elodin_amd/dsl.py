@@ -339,10 +339,48 @@ class _Lax:
             val = body_fun(i, val)
         return val
 
+    _loop_ids = [0]
+
+    @staticmethod
+    def while_loop(cond_fun, body_fun, init_val, max_iter: int = 1_000_000):
+        """jax.lax.while_loop with a data-dependent trip count (e.g. examples/stablehlo/sim.py:223, or a flight
+        computer propagating a ballistic arc until it meets the ground): becomes a real loop in the generated kernel,
+        lanes leave it independently.  `init_val`: a scalar, a Vec, or a tuple / list of those.  `max_iter` bounds the
+        loop (a lane whose condition never turns false stops there)."""
+        flat, rebuild = _flatten(init_val)
+        lid = _Lax._loop_ids[0]
+        _Lax._loop_ids[0] += 1
+        names = tuple(f"lv{lid}_{j}" for j in range(len(flat)))
+        carried = rebuild([leaf(nm) for nm in names])
+        cond = _lift(cond_fun(carried))
+        body, _ = _flatten(body_fun(carried))
+        if len(body) != len(flat):
+            raise TypeError("while_loop body must return the structure of init_val")
+        node = Expr("while", tuple(_lift(x) for x in flat), (names, cond, tuple(_lift(b) for b in body), int(max_iter)))
+        return rebuild([Expr("while_out", (node,), j) for j in range(len(flat))])
+
     @staticmethod
     def max(a, b): return _Np.maximum(a, b)
     @staticmethod
     def min(a, b): return _Np.minimum(a, b)
+
+
+def _flatten(tree):
+    """(flat list of scalar nodes, rebuild(list) -> same structure) for scalars, Vec and tuples / lists of those."""
+    if isinstance(tree, (tuple, list)):
+        parts = [_flatten(t) for t in tree]
+        sizes = [len(p[0]) for p in parts]
+
+        def rebuild(xs, parts=parts, sizes=sizes, kind=type(tree)):
+            out, k = [], 0
+            for (_, rb), sz in zip(parts, sizes):
+                out.append(rb(xs[k:k + sz]))
+                k += sz
+            return kind(out)
+        return [x for p in parts for x in p[0]], rebuild
+    if isinstance(tree, Vec):
+        return list(tree.e), (lambda xs: Vec(xs))
+    return [_lift(tree)], (lambda xs: xs[0])
 
 
 lax = _Lax
@@ -511,6 +549,10 @@ def _leaves_of(outputs: Sequence[Expr]) -> set:
         seen.add(id(e))
         if e.op == "leaf":
             deps.add(e.name)
+        if e.op == "while":              # free variables of the loop's condition and body, minus the carried ones
+            names, cond, body, _ = e.value
+            inner = _leaves_of([cond, *body]) - set(names)
+            deps.update(inner)
         for a in e.args:
             walk(a)
     for o in outputs:

@@ -18,30 +18,7 @@ def evaluate(tp, xs, vs, inertia, columns):
     for slot, (name, w) in enumerate(tp.columns):
         for k in range(w):
             leaves[f"aux{slot}_{k}"] = np.asarray(columns[name], dtype=np.float64).reshape(n, w)[:, k]
-    memo = {}
-
-    def ev(e):
-        if id(e) in memo:
-            return memo[id(e)]
-        if e.op == "const":
-            r = np.full(n, e.value)
-        elif e.op == "leaf":
-            r = leaves[e.name]
-        elif e.op in _F1:
-            r = _F1[e.op](ev(e.args[0]))
-        elif e.op in _F2:
-            r = _F2[e.op](ev(e.args[0]), ev(e.args[1]))
-        elif e.op == "select":
-            r = np.where(ev(e.args[0]), ev(e.args[1]), ev(e.args[2]))
-        elif e.op == "interp":
-            r = np.interp(ev(e.args[0]), np.array(e.value[0]), np.array(e.value[1]))
-        else:
-            raise ValueError(e.op)
-        memo[id(e)] = r
-        return r
-
-    with np.errstate(all="ignore"):
-        return _world_wrench(np.stack([ev(o) for o in tp.outputs], axis=1), xs)
+    return _world_wrench(np.stack(_eval(tp.outputs, leaves, n), axis=1), xs)
 
 
 def _world_wrench(out9, xs):
@@ -111,6 +88,23 @@ def _eval(exprs, leaves, n):
             r = np.where(ev(e.args[0]), ev(e.args[1]), ev(e.args[2]))
         elif e.op == "interp":
             r = np.interp(ev(e.args[0]), np.array(e.value[0]), np.array(e.value[1]))
+        elif e.op == "while_out":
+            r = ev(e.args[0])[e.value]
+        elif e.op == "while":
+            # dsl.lax.while_loop, lane by lane: a lane keeps iterating while ITS condition holds
+            names, cond, body, max_iter = e.value
+            vals = [np.array(np.broadcast_to(ev(x), (n,)), dtype=np.float64) for x in e.args]
+            active = np.ones(n, dtype=bool)
+            for _ in range(max_iter):
+                inner = dict(leaves)
+                inner.update({nm: v for nm, v in zip(names, vals)})
+                c = np.broadcast_to(_eval([cond], inner, n)[0].astype(bool), (n,))
+                active = active & c
+                if not active.any():
+                    break
+                new = _eval(list(body), inner, n)
+                vals = [np.where(active, nv, v) for nv, v in zip(new, vals)]
+            r = vals
         else:
             raise ValueError(e.op)
         memo[id(e)] = r

@@ -202,3 +202,65 @@ def test_quaternion_and_spatial_wrappers_match_the_reference_known_answers():
     assert np.allclose(out, [0.97151626, 0.0, 0.0, 0.23697292])
     out = ev(lambda q: Q(q).normalize().vector(), [0.0, 3.0, 0.0, 4.0])
     assert np.allclose(out, [0.0, 0.6, 0.0, 0.8], rtol=1e-15)
+
+
+# ---- data-dependent loops --------------------------------------------------------------------------------------------------------
+
+def kepler(xp, M, ecc):
+    """Newton iteration on E - e sin E = M until the step is below 1e-13 (a different trip count per lane)."""
+    def cond(c):
+        return xp.abs(c[1]) > 1e-13
+    def body(c):
+        E = c[0]
+        d = (E - ecc * xp.sin(E) - M) / (1.0 - ecc * xp.cos(E))
+        return (E - d, d, c[2] + 1.0)
+    E, _, iters = dsl.lax.while_loop(cond, body, (M, M * 0.0 + 1.0, M * 0.0), max_iter=60)
+    return E, iters
+
+
+def ballistic_impact(xp, alt0, vz0, vx0, cd_s_over_m):
+    """The shape of the flight software's impact predictor (examples/falcon9/controller/src/main.rs:746-775): propagate
+    a drag-affected arc in 0.5 s steps until it meets the ground, at most 2,400 steps."""
+    def cond(c):
+        return c[0] > 0.0
+    def body(c):
+        alt, x, vz, vx, k = c
+        speed = xp.sqrt(vz * vz + vx * vx)
+        rho = 1.225 * xp.exp(-xp.maximum(alt, 0.0) / 8440.0)
+        drag = 0.5 * rho * speed * cd_s_over_m
+        vz2 = vz + (-9.81 - drag * vz) * 0.5
+        vx2 = vx + (-drag * vx) * 0.5
+        return (alt + vz2 * 0.5, x + vx2 * 0.5, vz2, vx2, k + 1.0)
+    alt, x, vz, vx, k = dsl.lax.while_loop(cond, body, (alt0, alt0 * 0.0, vz0, vx0, alt0 * 0.0), max_iter=2400)
+    return x, k
+
+
+def test_while_loop_traces_and_evaluates_with_per_lane_trip_counts():
+    for M, ecc in ((0.3, 0.1), (2.5, 0.7), (1e-3, 0.95)):
+        E, iters = dsl_numpy.trace_eval(kepler, M, ecc)
+        assert abs(E - ecc * np.sin(E) - M) < 1e-12 and 2 <= iters <= 60
+    # straight Python for the impact predictor
+    def py(alt, vz, vx, c):
+        x = k = 0.0
+        while alt > 0.0 and k < 2400:
+            speed = np.sqrt(vz * vz + vx * vx)
+            drag = 0.5 * 1.225 * np.exp(-max(alt, 0.0) / 8440.0) * speed * c
+            vz = vz + (-9.81 - drag * vz) * 0.5
+            vx = vx + (-drag * vx) * 0.5
+            alt, x, k = alt + vz * 0.5, x + vx * 0.5, k + 1.0
+        return x, k
+    for case in ((60_000.0, 900.0, 1200.0, 1e-3), (500.0, -30.0, 10.0, 2e-3), (80_000.0, 1500.0, 500.0, 1e-4)):
+        got = dsl_numpy.trace_eval(ballistic_impact, *case)
+        want = py(*case)
+        assert got[1] == want[1] and abs(got[0] - want[0]) <= 1e-9 * abs(want[0]), (got, want)
+
+
+def test_while_loop_generates_a_real_loop_and_hoists_invariants():
+    @dsl.system
+    def solve(m_anom, ecc_anom):
+        E, iters = kepler(np_, m_anom[0], m_anom[1])
+        return {"ecc_anom": np_.array([E, iters])}
+    tp = dsl.Program([solve], dsl.Pipe([]), []).trace({"m_anom": 2, "ecc_anom": 2})
+    src = codegen.generate_source(tp, "float64", 2)
+    assert "for (int it_" in src and "break;" in src and src.count("m_sin(") == 1 and src.count("m_cos(") == 1
+    assert codegen.build(tp, "float64", 2).exists()

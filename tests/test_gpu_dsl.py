@@ -478,3 +478,41 @@ def codegen_source_of(system):
     from elodin_amd import codegen
     tp = dsl.Program([system], dsl.Pipe([]), []).trace({"q": 2, "r": 2})
     return codegen.generate_source(tp, "float64", 2)
+
+
+def test_while_loops_with_per_lane_trip_counts_on_the_gpu():
+    """dsl.lax.while_loop becomes a real loop in the kernel; lanes leave it independently.  Kepler's equation by Newton
+    (2..60 iterations depending on eccentricity) and the shape of the FSW's ballistic impact predictor (up to 2,400
+    half-second steps) against numpy evaluating the same traced program, f64 and f32."""
+    from tests.test_dsl_host import ballistic_impact, kepler
+
+    @dsl.system
+    def solve(q, r):
+        E, iters = kepler(np_, q[0], q[1])
+        x, k = ballistic_impact(np_, q[2], q[3], q[4], q[5])
+        return {"r": np_.array([E, iters, x, k])}
+    rng = np.random.default_rng(12)
+    n = 4096
+    q = np.stack([rng.uniform(0.0, 3.1, n), rng.uniform(0.0, 0.97, n), rng.uniform(200.0, 90_000.0, n), rng.uniform(-200.0, 1500.0, n),
+                  rng.uniform(0.0, 1500.0, n), rng.uniform(1e-4, 3e-3, n)], axis=1)
+    w = workloads.independent_bodies(n)
+    prog = dsl.Program([solve], dsl.Pipe([]), [])
+    tp = prog.trace({"q": 6, "r": 4})
+    for dtype, tol in ((np.float64, 1e-11), (np.float32, 2e-3)):
+        hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=dtype, integrator=L.INTEGRATOR_NONE, effectors=prog,
+                         columns={"q": q, "r": np.zeros((n, 4))})
+        hip.run(1)
+        got = np.asarray(hip._aux["r"], dtype=np.float64)
+        comps = {"q": q.astype(dtype).astype(np.float64), "r": np.zeros((n, 4))}
+        pos, vel, inertia = (np.array(w[k], dtype=np.float64) for k in ("world_pos", "world_vel", "inertia"))
+        dsl_numpy._run_systems(tp.pre, pos, vel, inertia, comps, tp.table, 1)
+        want = comps["r"]
+        if dtype == np.float64:
+            # same trip counts, except where the 1e-13 stop test sits on a rounding boundary (FMA contraction on the GPU)
+            assert np.abs(got[:, 1] - want[:, 1]).max() <= 1 and (got[:, 1] == want[:, 1]).mean() > 0.97
+            assert np.array_equal(got[:, 3], want[:, 3])
+            assert 2 <= got[:, 1].min() < got[:, 1].max() <= 60 and got[:, 3].min() < 100 < got[:, 3].max()
+        assert np.max(np.abs(got[:, 0] - want[:, 0])) < tol * 10                                  # eccentric anomaly
+        close = np.abs(got[:, 3] - want[:, 3]) <= (0 if dtype == np.float64 else 1)            # f32 may land one step apart
+        assert close.mean() > 0.999
+        assert np.max(np.abs(got[close, 2] - want[close, 2]) / np.maximum(np.abs(want[close, 2]), 1.0)) < max(tol, 1e-9) * 50
