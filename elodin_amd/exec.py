@@ -7,7 +7,7 @@ held as numpy arrays in the reference's row-major layout.  All compute goes thro
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Optional, Sequence
 
 import numpy as np

@@ -12,7 +12,7 @@ import csv
 import ctypes as C
 import math
 from pathlib import Path
-from typing import Dict, Mapping, Sequence
+from typing import Dict, Mapping
 
 import numpy as np
 
