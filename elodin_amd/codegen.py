@@ -32,7 +32,7 @@ _BIN = {"add": "+", "sub": "-", "mul": "*", "div": "/"}
 _FN1 = {"sqrt": "m_sqrt", "abs": "m_abs", "sin": "m_sin", "cos": "m_cos", "tan": "m_tan", "exp": "m_exp",
         "log": "m_log", "acos": "m_acos", "asin": "m_asin"}
 _FN2 = {"max": "m_max", "min": "m_min", "atan2": "m_atan2", "hypot": "m_hypot", "pow": "m_pow"}
-_BOOL_OPS = {"lt", "le", "and", "or", "not"}
+_BOOL_OPS = {"lt", "le", "eq", "and", "or", "not"}
 
 
 def _literal(v: float) -> str:
@@ -123,6 +123,8 @@ class _Emitter:
                 return f"{a[0]} < {a[1]}"
             if e.op == "le":
                 return f"{a[0]} <= {a[1]}"
+            if e.op == "eq":
+                return f"{a[0]} == {a[1]}"
             if e.op == "and":
                 return f"{a[0]} && {a[1]}"
             if e.op == "or":

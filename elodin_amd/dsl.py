@@ -229,6 +229,8 @@ class _Np:
             return Vec([Expr("select", (_lift(k), x, y)) for k, x, y in zip(cv, av.e, bv.e)])
         return Expr("select", (_lift(c), _lift(a), _lift(b)))
     @staticmethod
+    def equal(a, b): return _zipv(a, b, lambda x, y: Expr("eq", (_lift(x), _lift(y))))
+    @staticmethod
     def logical_and(a, b): return _zipv(a, b, lambda x, y: Expr("and", (_lift(x), _lift(y))))
     @staticmethod
     def logical_or(a, b): return _zipv(a, b, lambda x, y: Expr("or", (_lift(x), _lift(y))))

@@ -10,18 +10,20 @@ This module restates the ASCENT part of that stack (pad -> vertical rise -> pitc
 `elodin_amd.dsl`, so that the whole closed loop is traced, generated and fused into the step kernel
 (`pre | six_dof(effectors) | post`), one lane per Monte-Carlo rollout:
 
-  plant systems   sim.py:350-733 (attitude_control, valve_dynamics, tvc_actuators, engine_dynamics, mass_props,
-                  tank_dynamics, engine_wrench, aero_dynamics, gravity_and_frame_forces, apply_body_wrenches),
-                  pad_clamp sim.py:984-1013, derive_geodetic_telemetry sim.py:1128-1143
-  physics helpers frames.py:29-114, atmosphere.py:25-90, propulsion.py:46-149, aero.py:17-125
+  plant systems   sim.py:350-733 (attitude_control, valve_dynamics, tvc_actuators, fin_actuators, engine_dynamics,
+                  mass_props, tank_dynamics, rcs_dynamics, engine_wrench, wind_model (steady part), aero_dynamics incl.
+                  grid fins, gravity_and_frame_forces, apply_body_wrenches), pad_clamp sim.py:984-1013,
+                  derive_geodetic_telemetry sim.py:1128-1143
+  physics helpers frames.py:29-114, atmosphere.py:25-90, propulsion.py:46-149, aero.py:17-140, rcs.py:26-107
   flight software controller/src/main.rs:384-533 (phases PadPress..Meco, parametric pitch program — the fallback the
                   FSW flies without a recorded profile), math.rs:90-138,191-199
   parameters      spec.toml (LHS, seed 20170814) / main.py:53-100 calibrated defaults
 
-Deliberate scope limits (stated, not hidden): the recovery half of the mission (flip, boostback, entry, landing: grid
-fins, cold-gas RCS allocation, landing legs, ZEM/ZEV guidance) is not built, so fin / RCS / leg wrenches are identically
-zero as they are during a real ascent; the FSW navigates on truth state instead of the noisy IMU/GPS models (those draw
-from jax.random, which has no counterpart here); the steady wind / gust model is off (spec.toml samples no wind).
+Deliberate scope limits (stated, not hidden): the recovery half of the mission (flip, boostback, entry, landing) is not
+flown: its guidance phases, the landing-leg contact model and ground contact are not built, and fins / RCS — whose plant
+models ARE here — stay at rest because the ascent flight software never commands them; the FSW navigates on truth state
+instead of the noisy IMU/GPS models (those draw from jax.random, which has no counterpart here), and for the same reason
+the wind model carries its steady part only (per-rollout `wind_ned`, zero in spec.toml), not the gust process.
 Parity is UNPINNED against reference trajectories (none are checked in, and the reference cannot run here); the
 helper functions and the passive / open-loop plant are pinned against the reference's own verification ladder
 (test_ladder.py, test_frames.py, test_propulsion.py, test_aero.py) in tests/test_falcon9_host.py and
@@ -110,6 +112,22 @@ X_CP_ASCENT_M, X_CP_DESCENT_M = 28.0, 26.0
 CMQ_ASCENT, CMQ_DESCENT = -2.5, -12.0
 L_REF_DAMP_M = STAGE1_LENGTH_M
 PLUME_CT0 = 1.0
+
+# cold-gas RCS (constants.py:76-81, rcs.py:26-57) and grid fins (constants.py:83-87, aero.py:50-73)
+RCS_THRUST_PER_THRUSTER_N, RCS_VALVE_TAU_S, RCS_STATION_M = 7_500.0, 0.007, 46.0
+N_RCS = 8
+_RCS_R = STAGE1_DIAMETER_M / 2.0
+RCS_POS = tuple((RCS_STATION_M, y, 0.0) for y in (+_RCS_R, +_RCS_R, -_RCS_R, -_RCS_R, +_RCS_R, +_RCS_R, -_RCS_R, -_RCS_R))
+RCS_FORCE_DIR = ((0.0, 0.0, 1.0), (0.0, 0.0, -1.0), (0.0, 0.0, 1.0), (0.0, 0.0, -1.0),
+                 (0.0, 1.0, 0.0), (0.0, -1.0, 0.0), (0.0, -1.0, 0.0), (0.0, 1.0, 0.0))
+RCS_AXIS_GROUPS = ((0, (0, 3), (1, 2)), (1, (1, 3), (0, 2)), (2, (4, 7), (5, 6)))
+N2_INITIAL_KG, N2_ISP_S = 800.0, 70.0                     # sim.py:1381, :347
+FIN_MAX_RAD, FIN_RATE_RADPS, FIN_TAU_S = math.radians(20.0), math.radians(20.0), 0.050
+FIN_STATION_M, S_FIN_M2 = 44.0, 1.5
+CN_DELTA_FIN = (1.2, 1.2, 0.9, 0.8, 1.1, 1.3, 1.25, 1.2, 1.1)
+_FIN_AZ = tuple(math.radians(a) for a in (45.0, 135.0, 225.0, 315.0))
+FIN_FORCE_DIR = tuple((0.0, -math.sin(a), math.cos(a)) for a in _FIN_AZ)
+FIN_POS = tuple((FIN_STATION_M, 1.83 * math.cos(a), 1.83 * math.sin(a)) for a in _FIN_AZ)
 
 # sim.py:640-646 attitude inner loop
 ATT_WN_TVC, ATT_WN_TVC_LANDING, ATT_ZETA_TVC, ATT_WN_RCS, ATT_ZETA_RCS = 0.9, 1.7, 0.9, 0.35, 0.8
@@ -341,6 +359,58 @@ def body_aero_wrench(xp, v_air_body, mach, qbar, cg, omega_body=None, ca_scale=1
     return force, torque
 
 
+def fin_mix(xp, pitch_yaw_roll):                                            # aero.py:62-73,138-140: X-configuration mixing
+    p, y, r = pitch_yaw_roll[0], pitch_yaw_roll[1], pitch_yaw_roll[2]
+    return xp.array([d[2] * p + d[1] * y + r for d in FIN_FORCE_DIR])
+
+
+def fin_wrench(xp, deltas, mach, qbar, cg, eff_scale=1.0):                  # aero.py:128-135
+    cnd = xp.interp(mach, MACH_PTS, CN_DELTA_FIN) * eff_scale
+    force, torque = xp.array([0.0, 0.0, 0.0]), xp.array([0.0, 0.0, 0.0])
+    for i in range(4):
+        f = (qbar * S_FIN_M2 * cnd * deltas[i]) * xp.array(FIN_FORCE_DIR[i])
+        lever = xp.array([FIN_POS[i][0] - cg, FIN_POS[i][1], FIN_POS[i][2]])
+        force, torque = force + f, torque + xp.cross(lever, f)
+    return force, torque
+
+
+# ---- cold-gas RCS (rcs.py) -------------------------------------------------------------------------------------------------
+
+def rcs_wrench(xp, levels, cg, thrust=RCS_THRUST_PER_THRUSTER_N):           # rcs.py:60-65
+    force, torque = xp.array([0.0, 0.0, 0.0]), xp.array([0.0, 0.0, 0.0])
+    for i in range(N_RCS):
+        f = (levels[i] * thrust) * xp.array(RCS_FORCE_DIR[i])
+        lever = xp.array([RCS_POS[i][0] - cg, RCS_POS[i][1], RCS_POS[i][2]])
+        force, torque = force + f, torque + xp.cross(lever, f)
+    return force, torque
+
+
+def rcs_torque_authority(xp, cg, thrust=RCS_THRUST_PER_THRUSTER_N):         # rcs.py:68-76, torque rows of B (3 x 8)
+    cols = []
+    for i in range(N_RCS):
+        f = thrust * xp.array(RCS_FORCE_DIR[i])
+        cols.append(xp.cross(xp.array([RCS_POS[i][0] - cg, RCS_POS[i][1], RCS_POS[i][2]]), f))
+    return cols        # cols[i][axis]
+
+
+def allocate_torque(xp, torque_cmd, cg, thrust=RCS_THRUST_PER_THRUSTER_N):  # rcs.py:84-107
+    b = rcs_torque_authority(xp, cg, thrust)
+    levels = [0.0] * N_RCS
+    for axis, group_a, group_b in RCS_AXIS_GROUPS:
+        cmd = torque_cmd[axis]
+        auth_a = b[group_a[0]][axis] + b[group_a[1]][axis]
+        auth_b = b[group_b[0]][axis] + b[group_b[1]][axis]
+        use_a = xp.equal(xp.sign(cmd), xp.sign(auth_a))
+        auth = xp.where(use_a, xp.abs(auth_a), xp.abs(auth_b))
+        lvl = xp.clip(xp.abs(cmd) / xp.maximum(auth, 1e-9), 0.0, 1.0)
+        active = xp.abs(cmd) > 0.02 * auth
+        for i in group_a:
+            levels[i] = levels[i] + xp.where(xp.logical_and(active, use_a), lvl, 0.0)
+        for i in group_b:
+            levels[i] = levels[i] + xp.where(xp.logical_and(active, xp.logical_not(use_a)), lvl, 0.0)
+    return xp.clip(xp.array(levels), 0.0, 1.0)
+
+
 # ---- quaternions on plain 4-vectors [x, y, z, w] --------------------------------------------------------------------------
 
 def quat_mul(xp, l, r):                                                    # quaternion.rs:268-281
@@ -452,6 +522,33 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
                                            rate_limit=TVC_RATE_RADPS, lo=-TVC_MAX_RAD, hi=TVC_MAX_RAD)}
 
     @dsl.system
+    def fin_actuators(fin_state, fin_cmd):                                  # sim.py:526-538
+        deltas_cmd = fin_mix(xp, xp.clip(fin_cmd, -FIN_MAX_RAD, FIN_MAX_RAD))
+        return {"fin_state": actuator_step(xp, fin_state, xp.clip(deltas_cmd, -FIN_MAX_RAD, FIN_MAX_RAD), dt, FIN_TAU_S,
+                                           rate_limit=FIN_RATE_RADPS, lo=-FIN_MAX_RAD, hi=FIN_MAX_RAD)}
+
+    @dsl.system
+    def rcs_dynamics(rcs_levels, rcs_torque_cmd, cg_station, nitrogen_kg):
+        """sim.py:560-576: allocate the requested torque to the eight cold-gas thrusters, valve dynamics, meter N2."""
+        have_gas = nitrogen_kg > 0.0
+        cmd_levels = xp.where(have_gas, allocate_torque(xp, rcs_torque_cmd, cg_station), xp.zeros(N_RCS))
+        levels_next = actuator_step(xp, rcs_levels, cmd_levels, dt, RCS_VALVE_TAU_S, lo=0.0, hi=1.0)
+        force, torque = rcs_wrench(xp, levels_next, cg_station)
+        thrust_sum = xp.sum(levels_next) * RCS_THRUST_PER_THRUSTER_N
+        n2_next = xp.maximum(nitrogen_kg - thrust_sum / (N2_ISP_S * G0) * dt, 0.0)
+        return {"rcs_levels": levels_next, "rcs_wrench": xp.concatenate([force, torque]), "nitrogen_kg": n2_next}
+
+    @dsl.system
+    def wind_model(pos, wind_ned):
+        """sim.py:579-611 without the gust process (gust_sigma = 0 in every shipped spec; the gust draws from jax.random):
+        steady NED wind with the near-surface shear factor, rotated into ECEF."""
+        lat, lon, alt = ecef_to_geodetic(xp, ecef(pos))
+        north, east, down = ned_basis(xp, lat, lon)
+        shear = xp.clip(1.0 + 0.15 * (500.0 - xp.minimum(alt, 500.0)) / 500.0, 1.0, 1.15)
+        w = wind_ned * shear
+        return {"wind_ecef": north * w[0] + east * w[1] + down * w[2]}
+
+    @dsl.system
     def engine_dynamics(pos, engine_cmd, engine_spool, engine_armed, teateb_charges, valve_state, propellant_lox,
                         propellant_rp1, params):
         """sim.py:372-430: ignition gating (TEA-TEB charge + feed + igniter valves), three-regime spool, thrust with
@@ -514,14 +611,14 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
         return {"engine_wrench": xp.concatenate([force, torque])}
 
     @dsl.system
-    def aero_dynamics(pos, vel, thrust_total, cg_station, params):
-        """sim.py:596-636 with zero wind and stowed fins: air data, body aero wrench, plume dominance."""
+    def aero_dynamics(pos, vel, wind_ecef, thrust_total, fin_state, cg_station, params):
+        """sim.py:614-660: air data, body aero wrench with plume dominance, grid-fin wrench."""
         _, _, alt = ecef_to_geodetic(xp, ecef(pos))
         alt = xp.maximum(alt, 0.0)
         rho = density(xp, alt)
         a_sound = speed_of_sound(xp, alt)
         q_inv = quat_inverse(xp, pos.angular().vector())
-        v_air_body = quat_rotate(xp, q_inv, vel.linear())
+        v_air_body = quat_rotate(xp, q_inv, vel.linear() - wind_ecef)
         omega_body = quat_rotate(xp, q_inv, vel.angular())
         speed = xp.linalg.norm(v_air_body)
         qbar = 0.5 * rho * speed ** 2
@@ -529,7 +626,9 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
         f_aero, t_aero = body_aero_wrench(xp, v_air_body, mach, qbar, cg_station, omega_body=omega_body,
                                           ca_scale=params[P["ca_scale"]], cn_scale=params[P["cn_scale"]])
         kappa = plume_dominance(xp, thrust_total, qbar)
-        return {"qbar": qbar, "mach": mach, "aero_wrench": xp.concatenate([f_aero * (1.0 - kappa), t_aero * (1.0 - kappa)])}
+        f_fin, t_fin = fin_wrench(xp, fin_state, mach, qbar, cg_station)
+        return {"qbar": qbar, "mach": mach, "aero_wrench": xp.concatenate([f_aero * (1.0 - kappa), t_aero * (1.0 - kappa)]),
+                "fin_wrench": xp.concatenate([f_fin, t_fin])}
 
     @dsl.effector
     def gravity_and_frame_forces(force, inertia, pos, vel):                 # sim.py:350-358
@@ -537,9 +636,9 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
         accel = gravity_accel(xp, r) + frame_accel(xp, r, vel.linear())
         return force + dsl.SpatialForce(linear=accel * inertia.mass())
 
-    @dsl.effector(engine_wrench=6, aero_wrench=6)
-    def apply_body_wrenches(engine_wrench, aero_wrench, force, pos):        # sim.py:619-633 (fin / rcs / leg wrenches = 0)
-        total = engine_wrench + aero_wrench
+    @dsl.effector(engine_wrench=6, aero_wrench=6, fin_wrench=6, rcs_wrench=6)
+    def apply_body_wrenches(engine_wrench, aero_wrench, fin_wrench, rcs_wrench, force, pos):   # sim.py:663-676 (no leg contact)
+        total = engine_wrench + aero_wrench + fin_wrench + rcs_wrench
         q = pos.angular()
         return force + dsl.SpatialForce(linear=q @ total[:3], torque=q @ total[3:])
 
@@ -569,7 +668,7 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
         t_s = tick * dt
         m = ascent_metrics
         new_q = qbar > m[0]
-        f_body = (engine_wrench[:3] + aero_wrench[:3]) / inertia.mass()
+        f_body = (engine_wrench[:3] + aero_wrench[:3]) / inertia.mass()     # fin / rcs forces are zero during the ascent
         a_sensed = xp.linalg.norm(f_body)
         r = ecef(pos)
         lat, lon, _ = ecef_to_geodetic(xp, r)
@@ -642,12 +741,13 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
             to_turn, PHASE_GRAVITY_TURN, xp.where(meco_now, PHASE_MECO, phase))))
         changed = to_rise | to_kick | to_turn | meco_now
         return {"engine_cmd": xp.ones(N_ENGINES) * throttle, "valve_cmd": valve_cmd, "attitude_setpoint": attitude,
+                "fin_cmd": xp.zeros(3),
                 "ctrl_enable": xp.array([xp.where(powered, 1.0, 0.0), xp.where(powered, 0.0, 1.0)]), "fsw_phase": phase,
                 "fsw_state": xp.array([phase_next, xp.where(changed, t, phase_t0), purge_until_next,
                                        xp.where(meco_now, 1.0, meco)])}
 
-    pre = [attitude_control, valve_dynamics, tvc_actuators, engine_dynamics, mass_props, tank_dynamics, engine_wrench_sys,
-           aero_dynamics]
+    pre = [attitude_control, valve_dynamics, tvc_actuators, fin_actuators, engine_dynamics, mass_props, tank_dynamics,
+           rcs_dynamics, engine_wrench_sys, wind_model, aero_dynamics]       # propulsion_systems, sim.py:1433-1458 (no legs)
     post = [pad_clamp, derive_geodetic_telemetry]
     if scripted is not None:
         @dsl.system
@@ -681,7 +781,8 @@ COLUMN_WIDTHS = dict(engine_cmd=9, valve_cmd=8, engine_spool=9, engine_armed=9, 
                      tank_pressure_rp1=1, inlet_pressure_lox=1, inlet_pressure_rp1=1, cg_station=1, axial_specific_force=1,
                      qbar=1, mach=1, tvc_cmd=2, tvc_state=2, rcs_torque_cmd=3, aero_wrench=6, engine_wrench=6,
                      attitude_setpoint=4, ctrl_enable=2, fsw_phase=1, upper_mass=1, lifted=1, liftoff_time=1,
-                     altitude_geodetic=1, ground_speed=1, params=16, fsw_state=4, ascent_metrics=8)
+                     altitude_geodetic=1, ground_speed=1, params=16, fsw_state=4, ascent_metrics=8,
+                     fin_cmd=3, fin_state=4, fin_wrench=6, rcs_levels=8, rcs_wrench=6, nitrogen_kg=1, wind_ecef=3, wind_ned=3)
 
 
 def initial_columns(params: np.ndarray, origin: Optional[Sequence[float]] = None, upper_kg: float = UPPER_KG,
@@ -711,6 +812,7 @@ def initial_columns(params: np.ndarray, origin: Optional[Sequence[float]] = None
     cols["cg_station"][:] = DRY_CG_STATION_M
     cols["attitude_setpoint"][:] = upright_attitude()
     cols["upper_mass"][:] = upper_kg
+    cols["nitrogen_kg"][:] = N2_INITIAL_KG
     cols["lifted"][:] = 0.0 if on_pad else 1.0
     cols["params"][:] = params
     return cols

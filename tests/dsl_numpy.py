@@ -5,7 +5,7 @@ import numpy as np
 _F1 = {"sqrt": np.sqrt, "abs": np.abs, "sin": np.sin, "cos": np.cos, "tan": np.tan, "exp": np.exp, "log": np.log,
        "acos": np.arccos, "asin": np.arcsin, "neg": np.negative, "not": np.logical_not}
 _F2 = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "max": np.fmax, "min": np.fmin,
-       "atan2": np.arctan2, "hypot": np.hypot, "pow": np.power, "lt": np.less, "le": np.less_equal, "and": np.logical_and,
+       "atan2": np.arctan2, "hypot": np.hypot, "pow": np.power, "lt": np.less, "le": np.less_equal, "eq": np.equal, "and": np.logical_and,
        "or": np.logical_or}
 
 

@@ -175,3 +175,28 @@ def test_closed_loop_traces_and_generates_for_both_dtypes():
         codegen.generate_source(tp, "float64", 1, fast_math=True)
     mass = cols["inertia"][0, 6]
     assert abs(mass - (f9.STAGE1_DRY_MASS_KG + f9.DEFAULT_PARAMS["lox_kg"] + f9.DEFAULT_PARAMS["rp1_kg"] + f9.UPPER_KG)) < 1e-6
+
+
+def test_rcs_allocation_and_fin_mixing():
+    """test_aero.py:24-74: axis purity / authority of the cold-gas allocation, force-free roll, fin mixing axis purity."""
+    cg = 22.0
+    b = np.stack(f9.rcs_torque_authority(np, cg), axis=1)                      # 3 x 8 torque rows of the effectiveness matrix
+    authority = [np.abs(b[axis]).sum() / 2.0 for axis in range(3)]
+    for axis in range(3):
+        for sign in (1.0, -1.0):
+            cmd = [0.0, 0.0, 0.0]
+            cmd[axis] = sign * 0.5 * authority[axis]
+            levels = both(lambda xp, c: f9.allocate_torque(xp, c, cg), cmd)
+            _, torque = both(lambda xp, lv: f9.rcs_wrench(xp, lv, cg), list(levels))
+            assert abs(torque[axis] - cmd[axis]) < 1e-6 * abs(cmd[axis]) + 1e-9
+            assert np.all(np.abs(np.delete(torque, axis)) < 1e-6 * abs(cmd[axis]) + 1e-6)
+    for tx in (1e4, -1e4):
+        force, _ = f9.rcs_wrench(np, f9.allocate_torque(np, np.array([tx, 0.0, 0.0]), cg), cg)
+        assert np.all(np.abs(force) < 1e-9)
+    for axis, cmd in ((1, [0.1, 0.0, 0.0]), (2, [0.0, 0.1, 0.0]), (0, [0.0, 0.0, 0.1])):     # pitch -> My, yaw -> Mz, roll -> Mx
+        deltas = both(f9.fin_mix, cmd)
+        _, torque = both(lambda xp, d: f9.fin_wrench(xp, d, 2.0, 30_000.0, 20.0), list(deltas))
+        assert int(np.argmax(np.abs(torque))) == axis
+        assert np.all(np.abs(np.delete(torque, axis)) < 1e-9 * max(1.0, abs(torque[axis])))
+    force, _ = f9.fin_wrench(np, f9.fin_mix(np, np.array([0.0, 0.0, 0.2])), 2.0, 30_000.0, 20.0)
+    assert np.all(np.abs(force) < 1e-9)
