@@ -269,3 +269,49 @@ def test_generated_kernel_vs_numpy_stepper_on_the_same_program(start_tick):
     worst = max(errs, key=errs.get)
     print(f"falcon9 program vs numpy from tick {start_tick}: worst {worst} {errs[worst]:.2e}")
     assert errs[worst] < parity.F64_RTOL, errs
+
+
+def _coasting_booster(alt_m, speed_down):
+    up = f9.pad_up()
+    q_tail_first = f9.quat_between_x(np, -up)                                     # body +X pointing down: engines-first fall
+    params = f9.default_param_row()[None, :]
+    cols = f9.initial_columns(params, init_pos_ecef=f9.pad_ecef() + up * alt_m, init_vel_ecef=-up * speed_down,
+                              init_attitude=q_tail_first, upper_kg=0.0)
+    cols["propellant_lox"][:], cols["propellant_rp1"][:] = 20_000.0, 9_000.0
+    m, _, idiag = f9.stack_mass_props(np, 20_000.0, 9_000.0, 0.0)
+    cols["inertia"][:, :3], cols["inertia"][:, 6] = idiag, m
+    cols["attitude_setpoint"][:] = q_tail_first
+    return params, cols, q_tail_first
+
+
+def test_rcs_and_fin_plant_respond_when_commanded():
+    """The ascent never commands fins or cold-gas thrusters, so drive them open loop.  (1) A booster coasting at 90 km
+    (no air to speak of) with the RCS enabled and the attitude setpoint 15 deg off slews onto the setpoint, spending
+    nitrogen.  (2) At 12 km, falling engines-first at 400 m/s, a pitch fin command deflects the four fins at their rate
+    limit and produces a pitch moment of the sign and purity test_aero.py:60-71 pins."""
+    idle = lambda xp, t: (xp.zeros(9), xp.zeros(8))
+    params, cols, q0 = _coasting_booster(90_000.0, 50.0)
+    off = np.concatenate([np.array([0.0, 1.0, 0.0]) * math.sin(math.radians(7.5)), [math.cos(math.radians(7.5))]])   # 15 deg about body +Y
+    cols["attitude_setpoint"][:] = f9.quat_mul(np, q0, off)
+    cols["ctrl_enable"][:] = [0.0, 1.0]
+    ex = f9.AscentExec(params, scripted=idle, columns=cols)
+    ex.run(200)
+    assert np.any(ex.column("rcs_levels")[0] > 0.05) and ex.column("nitrogen_kg")[0, 0] < f9.N2_INITIAL_KG
+    ex.run(39_800)                                                               # 40 s in total
+    err = f9.quat_mul(np, f9.quat_inverse(np, ex.column("world_pos")[0, :4]), cols["attitude_setpoint"][0])
+    err_deg = 2.0 * math.degrees(math.asin(min(1.0, float(np.linalg.norm(err[:3])))))
+    n2 = ex.column("nitrogen_kg")[0, 0]
+    print(f"RCS capture: attitude error 15.0 deg -> {err_deg:.2f} deg in 40 s, N2 left {n2:.1f} of {f9.N2_INITIAL_KG:.0f} kg")
+    assert err_deg < 2.0 and 0.0 < n2 < f9.N2_INITIAL_KG - 1.0
+
+    params, cols, _ = _coasting_booster(12_000.0, 400.0)
+    cols["fin_cmd"][:] = [0.1, 0.0, 0.0]
+    ex = f9.AscentExec(params, scripted=idle, columns=cols)
+    ex.run(100)
+    early = ex.column("fin_state")[0].copy()
+    assert np.all(np.abs(early) <= f9.FIN_RATE_RADPS * 0.1 + 1e-12) and np.any(np.abs(early) > 0.01)      # rate-limited slew
+    ex.run(400)
+    assert np.allclose(ex.column("fin_state")[0], f9.fin_mix(np, np.array([0.1, 0.0, 0.0])), atol=2e-4)
+    fw = ex.column("fin_wrench")[0]
+    print(f"fin pitch command: deflections {np.degrees(ex.column('fin_state')[0]).round(2)} deg, moment {fw[3:].round(0)} N m, q-bar {ex.column('qbar')[0, 0]:.0f} Pa")
+    assert fw[4] < 0.0 and abs(fw[4]) > 100.0 * max(abs(fw[3]), abs(fw[5]), 1e-9) and np.all(np.abs(fw[[0, 1]]) < 1e-6 * abs(fw[2]) + 1e-9)
