@@ -235,8 +235,23 @@ def falcon9_leg(device):
     widths = dict(ex.program.trace().columns)
     state_bytes = 4 * (sum(widths.values()) + 7 + 6 + 6 + 6 + 7)
     ex.close()
+    # the same program with every tick round-tripping every column through HBM (the reference's per-tick column
+    # semantics), at a rollout count that fills the chip: the HBM-roofline statement BASELINE asks for on this config
+    n1 = 262144
+    k1 = f9.AscentExec(np.tile(f9.default_param_row(), (n1, 1)), dtype=np.float32, ticks_per_launch=1, device=device, fast_math=True)
+    tr = k1.program.trace()
+    written = {t.split("_")[0] for s_ in tr.pre + tr.post for t in s_.written if t[0] == "c"}
+    read_b = 4 * (sum(w for _, w in tr.columns) + 7 + 6 + 7)
+    write_b = 4 * (sum(w for k, (_, w) in enumerate(tr.columns) if f"c{k}" in written) + 7 + 6 + 6 + 6 + 7)
+    k1.hip.invoke_batch(20)
+    t1 = k1.hip.invoke_batch(200)
+    us1 = t1.kernel_device_ms / 200 * 1e3
+    k1.close()
+    hbm = {"rollouts": n1, "ticks_per_launch": 1, "us_per_tick": round(us1, 2), "bytes_per_rollout_tick": read_b + write_b,
+           "algorithmic_GBps": round((read_b + write_b) * n1 / us1 / 1e3, 1),
+           "frac_of_hbm_peak": round((read_b + write_b) * n1 / us1 / 1e3 / HBM_PEAK_GBPS, 4)}
     steps = f9.ASCENT_TICKS - 1000
-    return {"rollouts": n, "steps": steps, "seconds": round(dt, 4), "rollout_steps_per_s": round(n * steps / dt, 1),
+    return {"rollouts": n, "steps": steps, "roofline_hbm_k1": hbm, "seconds": round(dt, 4), "rollout_steps_per_s": round(n * steps / dt, 1),
             "dtype": "f32", "math": "hardware transcendentals in the generated user code (codegen fast_math)",
             "launches": tm.launches, "integrator": "semi-implicit @ 1 kHz", "guidance": "in-kernel, 100 Hz",
             "bound": "valu (state stays in registers for 1000 ticks per launch)",
