@@ -415,6 +415,14 @@ def main():
             fe = time.perf_counter() - t1
             out["fused"] = {"ticks_per_launch": 64, "value": round(n * 64 * 64 / fe, 1), "unit": "entity-steps/s",
                             "device_ms_per_tick": round(ft.kernel_device_ms / (64 * 64), 6)}
+            # K in {1, 16, 256} ticks per launch reported separately (K = 1 is the headline `value`)
+            for kk in (16, 256):
+                ex.set_ticks_per_launch(kk)
+                ex.invoke_batch(kk * 4)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ex.invoke_batch(kk * 32)
+                out["fused"][f"value_k{kk}"] = round(n * kk * 32 / (time.perf_counter() - t1), 1)
             # fused + telemetry ring: EVERY tick's pos/vel/accel/force rows are written to HBM (200 B per
             # entity-step, write-once), state carried in registers -> HBM-write bound
             ex.enable_history(256)
