@@ -431,3 +431,33 @@ def test_small_graph_single_launch_path_is_bit_identical(kind):
         a = getattr(runs["three_kernels"][0], f)
         assert np.array_equal(a, getattr(runs["small_k1"][0], f)), f
         assert np.array_equal(a, getattr(runs["small_k16"][0], f)), f
+
+
+@pytest.mark.parametrize("small", [True, False])
+def test_solar_system_833_days_matches_the_oracle_and_the_ephemeris(small, monkeypatch):
+    """SURVEY 8(d) config 3's physical sanity case: sun + nine planets from the example's truth CSV, 20,000 one-hour RK4
+    ticks of softened all-pairs gravity.  GPU (one-launch small-graph kernel and the three-kernel path) vs the CPU oracle
+    at 1e-9, and vs the JPL-derived truth through the example's own accuracy coefficient."""
+    from tests import solar_util as su
+    if not small:
+        monkeypatch.setenv("SIXDOF_PAIR_SMALL", "0")
+    d, pos, vel, inertia = su.load()
+    ops = [ea.Effector(L.EFF_ALLPAIRS_GRAVITY_SOFTENED, (su.K_SQUARED, su.SOFTENING_AU2))]
+    hip = ea.HipExec(pos, vel, inertia, simulation_time_step=su.DT, effectors=ops, ticks_per_launch=240)
+    ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=su.DT, ops=parity.to_oracle_ops(ops))
+    ticks = 20_000 if small else 2_400
+    days = [x for x in d["days"] if x * su.TICKS_PER_DAY <= ticks]
+    sim = np.zeros((len(d["bodies"]), len(days), 3))
+    done = 0
+    for k, day in enumerate(days):
+        step = day * su.TICKS_PER_DAY - done
+        if step:
+            hip.run(step)
+            ref.step(step)
+        done += step
+        sim[:, k] = hip.world_pos[1:, 4:]
+    errs = parity.state_errors(hip, ref)
+    rms, coeff, _ = su.accuracy(sim, np.array(d["truth_au"])[:, :len(days)])
+    print(f"solar system, {done} ticks ({'one-launch' if small else 'three-kernel'} path): vs oracle {errs}, vs ephemeris RMS {rms:.2e} AU, coefficient {coeff:.6f}")
+    assert max(errs.values()) < parity.F64_RTOL, errs
+    assert coeff > 0.999 and rms < 5e-3
