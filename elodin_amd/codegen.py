@@ -30,9 +30,11 @@ _LEAF_CPP = {
 }
 _BIN = {"add": "+", "sub": "-", "mul": "*", "div": "/"}
 _FN1 = {"sqrt": "m_sqrt", "abs": "m_abs", "sin": "m_sin", "cos": "m_cos", "tan": "m_tan", "exp": "m_exp",
-        "log": "m_log", "acos": "m_acos", "asin": "m_asin"}
-_FN2 = {"max": "m_max", "min": "m_min", "atan2": "m_atan2", "hypot": "m_hypot", "pow": "m_pow"}
-_BOOL_OPS = {"lt", "le", "eq", "and", "or", "not"}
+        "log": "m_log", "acos": "m_acos", "asin": "m_asin", "log1p": "m_log1p", "expm1": "m_expm1", "cbrt": "m_cbrt",
+        "floor": "m_floor", "ceil": "m_ceil", "trunc": "m_trunc", "rint": "m_rint", "sinh": "m_sinh", "cosh": "m_cosh",
+        "erfc": "m_erfc", "isfinite": "m_isfinite"}
+_FN2 = {"max": "m_max", "min": "m_min", "atan2": "m_atan2", "hypot": "m_hypot", "pow": "m_pow", "mod": "m_mod"}
+_BOOL_OPS = {"lt", "le", "eq", "and", "or", "not", "isfinite"}
 
 
 def _literal(v: float) -> str:
@@ -262,6 +264,11 @@ SIXDOF_M1(m_sin, sin, sinf) SIXDOF_M1(m_cos, cos, cosf) SIXDOF_M1(m_tan, tan, ta
 SIXDOF_M1(m_log, log, logf)
 #endif
 SIXDOF_M1(m_acos, acos, acosf) SIXDOF_M1(m_asin, asin, asinf)
+SIXDOF_M1(m_log1p, log1p, log1pf) SIXDOF_M1(m_expm1, expm1, expm1f) SIXDOF_M1(m_cbrt, cbrt, cbrtf) SIXDOF_M1(m_floor, floor, floorf)
+SIXDOF_M1(m_ceil, ceil, ceilf) SIXDOF_M1(m_trunc, trunc, truncf) SIXDOF_M1(m_rint, rint, rintf) SIXDOF_M1(m_sinh, sinh, sinhf)
+SIXDOF_M1(m_cosh, cosh, coshf) SIXDOF_M1(m_erfc, erfc, erfcf)
+template <class T> __device__ __forceinline__ bool m_isfinite(T x) { return isfinite(x); }
+template <class T> __device__ __forceinline__ T m_mod(T x, T y) { return x - m_floor(x / y) * y; }   // jnp.remainder: sign of y
 #define SIXDOF_M2(name, fd, ff) \\
     __device__ __forceinline__ double name(double x, double y) { return fd(x, y); } \\
     __device__ __forceinline__ float name(float x, float y) { return ff(x, y); }

@@ -67,6 +67,7 @@ class Expr:
             return const(1.0)
         return _Np.power(self, k)              # jnp.power for everything else
     def __rpow__(self, b): return _Np.power(b, self)
+    def __mod__(self, o): return Expr("mod", (self, _lift(o)))
     def __and__(self, o): return Expr("and", (self, _lift(o)))
     def __rand__(self, o): return Expr("and", (_lift(o), self))
     def __or__(self, o): return Expr("or", (self, _lift(o)))
@@ -108,7 +109,7 @@ def _map_const_tree(e: "Expr", f) -> "Expr":
 
 
 _FOLD1 = {"sqrt": math.sqrt, "abs": abs, "sin": math.sin, "cos": math.cos, "tan": math.tan, "exp": math.exp, "log": math.log,
-          "acos": math.acos, "asin": math.asin}
+          "acos": math.acos, "asin": math.asin, "floor": math.floor, "ceil": math.ceil, "trunc": math.trunc}
 
 
 def _un(op: str, x) -> "Expr":
@@ -171,8 +172,15 @@ class Vec:
     def __mul__(self, o): return self._zip(o, lambda a, b: a * b)
     def __rmul__(self, o): return self._zip(o, lambda a, b: b * a)
     def __truediv__(self, o): return self._zip(o, lambda a, b: a / b)
+    def __rtruediv__(self, o): return self._zip(o, lambda a, b: b / a)
     def __neg__(self): return Vec([-a for a in self.e])
     def __pow__(self, k): return Vec([a ** k for a in self.e])
+    def __mod__(self, o): return self._zip(o, lambda a, b: a % b)
+    def set(self, i: int, value) -> "Vec":
+        """x.at[i].set(value) of jax: a copy with element i replaced."""
+        e = list(self.e)
+        e[i] = _lift(value)
+        return Vec(e)
     def __lt__(self, o): return self._zip(o, lambda a, b: a < b)
     def __le__(self, o): return self._zip(o, lambda a, b: a <= b)
     def __gt__(self, o): return self._zip(o, lambda a, b: a > b)
@@ -197,6 +205,48 @@ class _Np:
     pi = math.pi
     sqrt, abs, sin, cos, tan, exp, log, arccos, arcsin = (_unary(k) for k in
                                                           ("sqrt", "abs", "sin", "cos", "tan", "exp", "log", "acos", "asin"))
+    log1p, expm1, cbrt, floor, ceil, trunc, sinh, cosh, erfc = (_unary(k) for k in
+                                                                ("log1p", "expm1", "cbrt", "floor", "ceil", "trunc", "sinh", "cosh", "erfc"))
+    round = rint = _unary("rint")          # jnp.round: half to even
+    isfinite = _unary("isfinite")
+
+    @staticmethod
+    def remainder(x, y): return _zipv(x, y, lambda a, b: Expr("mod", (_lift(a), _lift(b))))   # sign of the divisor, like jnp
+    mod = remainder
+
+    @staticmethod
+    def sort(v: "Vec") -> "Vec":
+        """jnp.sort of a fixed-length vector: an odd-even transposition network of min / max (n rounds, data-independent)."""
+        e = list(v.e)
+        n = len(e)
+        for rnd in range(n):
+            for i in range(rnd % 2, n - 1, 2):
+                lo, hi = Expr("min", (e[i], e[i + 1])), Expr("max", (e[i], e[i + 1]))
+                e[i], e[i + 1] = lo, hi
+        return Vec(e)
+
+    @staticmethod
+    def max(v: "Vec"):
+        acc = v.e[0]
+        for a in v.e[1:]:
+            acc = Expr("max", (acc, a))
+        return acc
+
+    @staticmethod
+    def min(v: "Vec"):
+        acc = v.e[0]
+        for a in v.e[1:]:
+            acc = Expr("min", (acc, a))
+        return acc
+
+    @staticmethod
+    def flip(v: "Vec") -> "Vec": return Vec(list(reversed(v.e)))
+    @staticmethod
+    def arange(n, dtype=None) -> "Vec": return Vec([float(k) for k in range(int(n))])
+    @staticmethod
+    def outer(a: "Vec", b: "Vec"): return [Vec([x * y for y in b.e]) for x in a.e]     # list of rows
+    @staticmethod
+    def matvec(rows, v: "Vec") -> "Vec": return Vec([_Np.dot(r, v) for r in rows])    # `mat @ v` for a list of rows
 
     @staticmethod
     def array(x, dtype=None): return Vec(list(x))
@@ -365,6 +415,8 @@ class _Lax:
     def max(a, b): return _Np.maximum(a, b)
     @staticmethod
     def min(a, b): return _Np.minimum(a, b)
+    @staticmethod
+    def rsqrt(x): return 1.0 / _Np.sqrt(x)
 
 
 def _flatten(tree):

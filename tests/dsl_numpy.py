@@ -2,10 +2,14 @@
 entities: the independent check of what elodin_amd/codegen.py generates.  TEST INFRASTRUCTURE."""
 import numpy as np
 
+from scipy.special import erfc as _erfc
+
 _F1 = {"sqrt": np.sqrt, "abs": np.abs, "sin": np.sin, "cos": np.cos, "tan": np.tan, "exp": np.exp, "log": np.log,
-       "acos": np.arccos, "asin": np.arcsin, "neg": np.negative, "not": np.logical_not}
+       "acos": np.arccos, "asin": np.arcsin, "neg": np.negative, "not": np.logical_not, "log1p": np.log1p, "expm1": np.expm1,
+       "cbrt": np.cbrt, "floor": np.floor, "ceil": np.ceil, "trunc": np.trunc, "rint": np.rint, "sinh": np.sinh, "cosh": np.cosh,
+       "erfc": _erfc, "isfinite": np.isfinite}
 _F2 = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "max": np.fmax, "min": np.fmin,
-       "atan2": np.arctan2, "hypot": np.hypot, "pow": np.power, "lt": np.less, "le": np.less_equal, "eq": np.equal, "and": np.logical_and,
+       "atan2": np.arctan2, "hypot": np.hypot, "pow": np.power, "mod": np.mod, "lt": np.less, "le": np.less_equal, "eq": np.equal, "and": np.logical_and,
        "or": np.logical_or}
 
 

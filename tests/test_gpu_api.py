@@ -285,3 +285,37 @@ def test_graph_fold_over_vector_components_against_numpy():
         want[s_] = want[s_] + r * (M[s_] / (1.0 + r @ r))
     got = exec.column_array("f")
     assert np.allclose(got, want, rtol=1e-12, atol=1e-14) and np.all(got[n - 50:] == 0.0) and exec.tick == 3
+
+
+def test_stablehlo_coverage_example_against_the_reference_baseline():
+    """examples/stablehlo (sim.py:330-353) as the reference builds it — eight entities with one component each, the
+    systems piped in its order — on the GPU, 100 ticks against the rows of scripts/ci/baseline/stablehlo
+    (tests/golden/stablehlo.json).  Every system runs on its own single-entity query join.  The int64 bitwise system is
+    outside the tracer's scope and `math_state`'s baseline predates the current math_step (tests/test_dsl_host.py), so six
+    float columns are compared with the baseline and math_state with the numpy evaluation of the same trace."""
+    import json
+    from pathlib import Path
+    from elodin_amd import dsl
+    from tests import dsl_numpy, stablehlo_dsl as S
+    gold = json.loads((Path(__file__).parent / "golden" / "stablehlo.json").read_text())["rows"]
+    w = el.World()
+    for name, init in S.INITIAL.items():
+        w.spawn(el.C(name, init), name)
+    pipe = S.SYSTEMS[0]
+    for s_ in S.SYSTEMS[1:]:
+        pipe = pipe | s_
+    exec = w.build(pipe, simulation_rate=120.0)
+    tm = dsl.ColumnTable("c", 48, 16, {"math_state": 4})
+    t_math = dsl.TracedSystem(S.math_step, tm)
+    math_ref = {"math_state": np.array([S.INITIAL["math_state"]])}
+    dummy = (np.array([[0, 0, 0, 1.0, 0, 0, 0]]), np.zeros((1, 6)), np.ones((1, 7)))
+    worst = {}
+    for tick in range(1, 101):
+        exec.run(1)
+        dsl_numpy._run_systems([t_math], *dummy, math_ref, tm, tick)
+        for name, rows in gold.items():
+            ref = math_ref["math_state"][0] if name == "math_state" else np.array(rows[tick])
+            got = exec.column_array(name)[0]
+            worst[name] = max(worst.get(name, 0.0), float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-12))))
+    print("stablehlo example on the GPU, worst relative error per component:", worst)
+    assert max(worst.values()) < 1e-12, worst
