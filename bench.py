@@ -171,8 +171,20 @@ def apollo_leg(device):
     tm = ex.invoke_batch(10000)
     dt = time.perf_counter() - t0
     ex.close()
-    return {"rollouts": 8192, "steps": 10000, "seconds": round(dt, 5), "rollout_steps_per_s": round(8192 * 10000 / dt, 1),
-            "launches": tm.launches, "integrator": "semi-implicit", "guidance": "in-kernel, 24 Hz"}
+    out = {"rollouts": 8192, "steps": 10000, "seconds": round(dt, 5), "rollout_steps_per_s": round(8192 * 10000 / dt, 1),
+           "launches": tm.launches, "integrator": "semi-implicit", "guidance": "in-kernel, 24 Hz"}
+    try:    # the CPU restatement of the same rollout model (oracle/apollo_oracle.c, one thread) on a bounded sample
+        from oracle.apollo import ApolloOracle
+        ref = apollo.load_reference()
+        o = ApolloOracle(apollo.initial_columns(P[:64], ref), ref, max_ticks=apollo.max_ticks(ref))
+        t0 = time.perf_counter()
+        o.step(10000)
+        cs = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(64 * 10000 / cs, 1), "unit": "rollout-steps/s", "cores": 1, "kind": "port",
+                               "sample": "64 rollouts x 10000 steps, oracle/apollo_oracle.c"}
+    except Exception as e:  # noqa: BLE001
+        out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
 
 
 def telemetry_leg(device, n):
