@@ -378,6 +378,9 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) ->
         stores = "\n".join(
             f"        {{ T* g = static_cast<T*>(P.model_cols[{k}]) + (size_t)row * {cols[k][1]}; "
             + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(cols[k][1])) + " }" for k in tp.written_slots)
+        records = "\n".join(
+            f"        if (P.model_hist[{k}]) {{ T* g = static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row) * {w}; "
+            + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(w)) + " }" for k, (_, w) in enumerate(cols))
         model = f'''
     static constexpr bool kHasModel = true;
     static constexpr bool kWritesInertia = {"true" if tp.writes_inertia else "false"};
@@ -395,6 +398,10 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) ->
     template <class T>
     __device__ static __forceinline__ void store(const StepParams& P, uint32_t row, const Regs<T>& r) {{
 {stores}
+    }}
+    template <class T>
+    __device__ static __forceinline__ void record(const StepParams& P, size_t slot, uint32_t row, const Regs<T>& r) {{
+{records}
     }}
     template <class T>
     __device__ static __forceinline__ void pre(const StepParams& P, uint64_t tick, Regs<T>& r, Quat<T>& q, Vec3<T>& p,

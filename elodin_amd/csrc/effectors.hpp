@@ -77,6 +77,8 @@ struct NoModel {
     template <class T>
     __device__ static __forceinline__ void store(const StepParams&, uint32_t, const Regs<T>&) {}
     template <class T>
+    __device__ static __forceinline__ void record(const StepParams&, size_t, uint32_t, const Regs<T>&) {}
+    template <class T>
     __device__ static __forceinline__ void pre(const StepParams&, uint64_t, Regs<T>&, Quat<T>&, Vec3<T>&, Spatial<T>&,
                                                Vec3<T>&, T&) {}
     template <class T>

@@ -41,6 +41,7 @@ struct StepParams {
     void* hist_force;         // [ring][n,6]
     uint64_t tick0;           // tick count before this launch (generated systems may read the tick)
     void* model_cols[kMaxModelCols];  // generated programs: device [n,w] component columns, read and written
+    void* model_hist[kMaxModelCols];  // their history rings [ring][n,w] (nullptr = not recorded)
     DevOp ops[kMaxOps];
 };
 

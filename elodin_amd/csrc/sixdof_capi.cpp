@@ -105,6 +105,7 @@ struct sixdof_handle {
     uint32_t hist_ring = 0;
     uint64_t hist_first_tick = 0;   // first tick (1-based count) recorded since the ring was enabled
     void* d_hist[4] = {nullptr, nullptr, nullptr, nullptr};  // pos, vel, accel, force
+    std::vector<void*> d_model_hist;      // one ring per component column of a generated program (same order as custom_model)
     // rollout model (0 = none, 1 = Apollo lander)
     int model = 0;
     std::vector<double> ap_time, ap_alt, ap_rate, ap_pitch, ap_hspeed, ap_downrange;
@@ -302,6 +303,7 @@ void sixdof_destroy(sixdof_handle* h) {
     if (h->d_scratch) hipFree(h->d_scratch);
     if (h->d_tick_refs) hipFree(h->d_tick_refs);
     for (void* p : h->d_hist) if (p) hipFree(p);
+    for (void* p : h->d_model_hist) if (p) hipFree(p);
     if (h->custom_dl) dlclose(h->custom_dl);
     if (h->pair_dl) dlclose(h->pair_dl);
     for (hipEvent_t e : h->launch_events) hipEventDestroy(e);
@@ -740,6 +742,7 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
             }
         }
         P->model_cols[k] = c->live;
+        P->model_hist[k] = (h->hist_ring && k < h->d_model_hist.size()) ? h->d_model_hist[k] : nullptr;
     }
     P->tick0 = h->tick;
     return build_dev_ops(h, P->ops, &P->n_ops, &P->vel_independent);
@@ -995,6 +998,8 @@ int sixdof_set_history(sixdof_handle* h, uint32_t ring_ticks) {
         if (p) hipFree(p);
         p = nullptr;
     }
+    for (void* p : h->d_model_hist) if (p) hipFree(p);
+    h->d_model_hist.clear();
     h->hist_ring = 0;
     h->drop_graph();
     if (ring_ticks == 0) return SIXDOF_OK;
@@ -1011,6 +1016,16 @@ int sixdof_set_history(sixdof_handle* h, uint32_t ring_ticks) {
             return h->hip_fail(e, "set_history: hipMalloc of the ring");
         }
     }
+    for (uint64_t id : h->custom_model) {      // component columns of a generated program are recorded too
+        const Column* c = h->col(id);
+        void* ring = nullptr;
+        if (c) {
+            const size_t bytes = static_cast<size_t>(ring_ticks) * n * c->width * es;
+            hipError_t e = hipMalloc(&ring, bytes ? bytes : 16);
+            if (e != hipSuccess) return h->hip_fail(e, "set_history: hipMalloc of a component ring");
+        }
+        h->d_model_hist.push_back(ring);
+    }
     h->hist_ring = ring_ticks;
     h->hist_first_tick = h->tick + 1;
     return SIXDOF_OK;
@@ -1025,13 +1040,22 @@ int sixdof_history_read(sixdof_handle* h, uint64_t component_id, uint64_t tick, 
     else if (component_id == h->id_vel) k = 1;
     else if (component_id == h->id_accel) k = 2;
     else if (component_id == h->id_force) k = 3;
-    if (k < 0) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "history_read: only world_pos/world_vel/world_accel/force are recorded");
+    const void* ring_base = k >= 0 ? h->d_hist[k] : nullptr;
+    if (k < 0) {
+        for (size_t m = 0; m < h->custom_model.size() && m < h->d_model_hist.size(); m++)
+            if (h->custom_model[m] == component_id && h->d_model_hist[m]) {
+                ring_base = h->d_model_hist[m];
+                w = h->col(component_id)->width;
+            }
+        if (!ring_base)
+            return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "history_read: only world_pos / world_vel / world_accel / force and the component columns of a generated program are recorded");
+    }
     if (tick < h->hist_first_tick || tick > h->tick || tick + h->hist_ring <= h->tick)
         return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "history_read: tick is not in the ring");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t block = static_cast<size_t>(h->desc.n_entities) * w * h->elem_size();
     const size_t slot = static_cast<size_t>((tick - 1) % h->hist_ring);
-    if (block) HIP_TRY(h, hipMemcpyAsync(host_dst, static_cast<char*>(h->d_hist[k]) + slot * block, block, hipMemcpyDeviceToHost, h->stream));
+    if (block) HIP_TRY(h, hipMemcpyAsync(host_dst, static_cast<const char*>(ring_base) + slot * block, block, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SIXDOF_OK;
 }

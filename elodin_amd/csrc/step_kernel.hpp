@@ -299,6 +299,8 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             const size_t r7 = (slot * P.n + row0) * 7, r6 = (slot * P.n + row0) * 6;
             flush_rows(static_cast<T*>(P.hist_pos) + r7, static_cast<T*>(P.hist_vel) + r6,
                        static_cast<T*>(P.hist_accel) + r6, static_cast<T*>(P.hist_force) + r6, std::integral_constant<int, 1>{});
+            if constexpr (PIPE::kHasModel)
+                if (active) PIPE::record(P, slot, row0 + t, regs);   // component columns of a generated program
             __syncthreads();
         }
     }

@@ -261,7 +261,7 @@ class HipExec:
 
     def history(self, name: str, first_tick: int, last_tick: int) -> np.ndarray:
         """exec.history() analogue: [last-first+1, n, w] block of component `name`, row k = state after tick first+k."""
-        w = 7 if name == "world_pos" else 6
+        w = 7 if name == "world_pos" else (self._aux[name].shape[1] if name in self._aux else 6)   # program columns too
         out = np.empty((last_tick - first_tick + 1, self.n, w), dtype=self.dtype)
         for k, tick in enumerate(range(first_tick, last_tick + 1)):
             rc = self._lib.sixdof_history_read(self._h, L.component_id(name), tick, out[k].ctypes.data)

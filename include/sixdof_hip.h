@@ -285,7 +285,9 @@ int sixdof_set_custom_pair(sixdof_handle* h, const char* so_path);
  * impeller2_server.rs:390-438) and `exec.history()` reads it back.  With a ring enabled, sixdof_step writes
  * world_pos / world_vel / world_accel / force of EVERY tick into slot (tick-1) % ring_ticks of a device ring
  * (reference row layout, one contiguous [n,w] block per tick and column) from inside the fused kernel, so
- * ticks_per_launch > 1 no longer drops intermediate ticks.  ring_ticks = 0 disables and frees the ring. */
+ * ticks_per_launch > 1 no longer drops intermediate ticks.  With a generated program installed
+ * (sixdof_set_custom_pipe) every component column of the program is recorded the same way and can be read
+ * back by its component id.  ring_ticks = 0 disables and frees the ring. */
 int sixdof_set_history(sixdof_handle* h, uint32_t ring_ticks);
 /* Copy the [n,w] block of `component_id` as it was after `tick` ticks into host_dst.  Fails with
  * SIXDOF_ERR_INVALID_ARGUMENT if that tick is not (or no longer) in the ring. */

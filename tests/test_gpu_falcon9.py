@@ -315,3 +315,23 @@ def test_rcs_and_fin_plant_respond_when_commanded():
     fw = ex.column("fin_wrench")[0]
     print(f"fin pitch command: deflections {np.degrees(ex.column('fin_state')[0]).round(2)} deg, moment {fw[3:].round(0)} N m, q-bar {ex.column('qbar')[0, 0]:.0f} Pa")
     assert fw[4] < 0.0 and abs(fw[4]) > 100.0 * max(abs(fw[3]), abs(fw[5]), 1e-9) and np.all(np.abs(fw[[0, 1]]) < 1e-6 * abs(fw[2]) + 1e-9)
+
+
+def test_component_columns_of_a_program_are_recorded_in_the_history_ring():
+    """sixdof_set_history with a generated program: besides the four Body outputs every component column of the program
+    is recorded each tick from inside the fused launch; reading the ring back equals stepping one tick at a time."""
+    params = f9.sample_params(6)
+    a = f9.AscentExec(params, dtype=np.float64, local_origin=False, ticks_per_launch=50)
+    b = f9.AscentExec(params, dtype=np.float64, local_origin=False, ticks_per_launch=1)
+    a.run(3_000)
+    b.run(3_000)
+    a.hip.enable_history(128)
+    a.run(100)                                         # two launches of 50 ticks, every tick recorded
+    names = ("altitude_geodetic", "thrust_total", "engine_spool", "fsw_state", "world_pos", "world_vel")
+    hist = {c: a.hip.history(c, 3_001, 3_100) for c in names}
+    for k in range(100):
+        b.run(1)
+        for c in names:
+            assert np.array_equal(hist[c][k], b.column(c)), (c, k)
+    with pytest.raises(ValueError):
+        a.hip.history("altitude_geodetic", 2_900, 2_901)       # before the ring was enabled
