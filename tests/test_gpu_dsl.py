@@ -516,3 +516,37 @@ def test_while_loops_with_per_lane_trip_counts_on_the_gpu():
         close = np.abs(got[:, 3] - want[:, 3]) <= (0 if dtype == np.float64 else 1)            # f32 may land one step apart
         assert close.mean() > 0.999
         assert np.max(np.abs(got[close, 2] - want[close, 2]) / np.maximum(np.abs(want[close, 2]), 1.0)) < max(tol, 1e-9) * 50
+
+
+def test_common_subexpressions_are_not_reused_across_a_write():
+    """The emitter shares temporaries across the systems of a tick only while no leaf they read has been written: here
+    system A evaluates sin(x) and then rewrites x, system B evaluates the (structurally identical) sin(x) again and must
+    see the new x; a third system, cadenced, reuses neither."""
+    @dsl.system
+    def a(x, y):
+        return {"y": np_.sin(x) + np_.cos(x * 2.0), "x": x + 1.0}
+
+    @dsl.system
+    def b(x, z):
+        return {"z": np_.sin(x) + np_.cos(x * 2.0)}
+
+    @dsl.system(every=2)
+    def c(x, z, u):
+        return {"u": np_.sin(x) + z}
+    n = 512
+    x0 = np.random.default_rng(2).uniform(-2, 2, (n, 1))
+    w = workloads.independent_bodies(n)
+    prog = dsl.Program([a, b, c], dsl.Pipe([]), [])
+    cols = {"x": x0, "y": np.zeros((n, 1)), "z": np.zeros((n, 1)), "u": np.zeros((n, 1))}
+    hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=L.INTEGRATOR_NONE, effectors=prog, columns=cols)
+    hip.run(3)
+    x = x0[:, 0].copy()
+    u = np.zeros(n)
+    for tick in (1, 2, 3):
+        y = np.sin(x) + np.cos(x * 2.0)
+        x = x + 1.0
+        z = np.sin(x) + np.cos(x * 2.0)
+        if tick % 2 == 0:
+            u = np.sin(x) + z
+    for name, want in (("x", x), ("y", y), ("z", z), ("u", u)):
+        assert np.allclose(hip._aux[name][:, 0], want, rtol=1e-13, atol=1e-15), name
