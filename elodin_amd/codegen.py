@@ -32,7 +32,7 @@ _BIN = {"add": "+", "sub": "-", "mul": "*", "div": "/"}
 _FN1 = {"sqrt": "m_sqrt", "abs": "m_abs", "sin": "m_sin", "cos": "m_cos", "tan": "m_tan", "exp": "m_exp",
         "log": "m_log", "acos": "m_acos", "asin": "m_asin", "log1p": "m_log1p", "expm1": "m_expm1", "cbrt": "m_cbrt",
         "floor": "m_floor", "ceil": "m_ceil", "trunc": "m_trunc", "rint": "m_rint", "sinh": "m_sinh", "cosh": "m_cosh",
-        "erfc": "m_erfc", "isfinite": "m_isfinite"}
+        "erfc": "m_erfc", "isfinite": "m_isfinite", "erfinv": "m_erfinv"}
 _FN2 = {"max": "m_max", "min": "m_min", "atan2": "m_atan2", "hypot": "m_hypot", "pow": "m_pow", "mod": "m_mod"}
 _BOOL_OPS = {"lt", "le", "eq", "and", "or", "not", "isfinite"}
 
@@ -121,6 +121,8 @@ class _Emitter:
                 if uniform:   # evenly spaced long table: index by division instead of bisecting through memory
                     return f"m_interp_uniform<T, {len(xs)}>({a[0]}, {stem}_x, {stem}_f, T({1.0 / step!r}))"
                 return f"m_interp<T, {len(xs)}>({a[0]}, {stem}_x, {stem}_f)"
+            if e.op == "threefry":
+                return f"m_threefry({a[0]}, {a[1]}, {a[2]}, {a[3]}, {int(e.value)})"
             if e.op == "lt":
                 return f"{a[0]} < {a[1]}"
             if e.op == "le":
@@ -267,7 +269,30 @@ SIXDOF_M1(m_acos, acos, acosf) SIXDOF_M1(m_asin, asin, asinf)
 SIXDOF_M1(m_log1p, log1p, log1pf) SIXDOF_M1(m_expm1, expm1, expm1f) SIXDOF_M1(m_cbrt, cbrt, cbrtf) SIXDOF_M1(m_floor, floor, floorf)
 SIXDOF_M1(m_ceil, ceil, ceilf) SIXDOF_M1(m_trunc, trunc, truncf) SIXDOF_M1(m_rint, rint, rintf) SIXDOF_M1(m_sinh, sinh, sinhf)
 SIXDOF_M1(m_cosh, cosh, coshf) SIXDOF_M1(m_erfc, erfc, erfcf)
+SIXDOF_M1(m_erfinv, erfinv, erfinvf)
 template <class T> __device__ __forceinline__ bool m_isfinite(T x) { return isfinite(x); }
+// threefry2x32 (the generator behind jax.random): key and counter words are uint32 values held exactly in doubles
+__device__ __forceinline__ double m_threefry(double k0d, double k1d, double c0d, double c1d, int which) {
+    const uint32_t k0 = static_cast<uint32_t>(k0d), k1 = static_cast<uint32_t>(k1d);
+    uint32_t x0 = static_cast<uint32_t>(c0d), x1 = static_cast<uint32_t>(c1d);
+    const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+    const int rot[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+    x0 += ks[0];
+    x1 += ks[1];
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            x0 += x1;
+            x1 = (x1 << rot[r & 1][j]) | (x1 >> (32 - rot[r & 1][j]));
+            x1 ^= x0;
+        }
+        x0 += ks[(r + 1) % 3];
+        x1 += ks[(r + 2) % 3] + static_cast<uint32_t>(r + 1);
+    }
+    return static_cast<double>(which ? x1 : x0);
+}
+__device__ __forceinline__ float m_threefry(float, float, float, float, int) { return 0.0f; }   // rejected at generation
 template <class T> __device__ __forceinline__ T m_mod(T x, T y) { return x - m_floor(x / y) * y; }   // jnp.remainder: sign of y
 #define SIXDOF_M2(name, fd, ff) \\
     __device__ __forceinline__ double name(double x, double y) { return fd(x, y); } \\
@@ -351,11 +376,36 @@ def _emit_tables() -> str:
     return "\n".join(out)
 
 
+def _uses_op(tp, op: str) -> bool:
+    seen = set()
+
+    def walk(e):
+        if id(e) in seen:
+            return False
+        seen.add(id(e))
+        if e.op == op:
+            return True
+        sub = list(e.args)
+        if e.op == "while":
+            sub += [e.value[1], *e.value[2]]
+        return any(walk(a) for a in sub)
+    roots = []
+    if isinstance(tp, dsl.TracedProgram):
+        for s_ in tp.pre + tp.post:
+            roots += [e for _, e in s_.assign]
+        roots += tp.pipe.outputs
+    else:
+        roots += tp.outputs
+    return any(walk(r) for r in roots)
+
+
 def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) -> str:
     """tp: dsl.TracedPipe (effectors only) or dsl.TracedProgram (pre | six_dof(effectors) | post).
     fast_math: f32 only — hardware transcendentals / reciprocal division in the generated user code (see _PRELUDE)."""
     if fast_math and dtype != "float32":
         raise ValueError("fast_math applies to float32 programs only")
+    if dtype == "float32" and _uses_op(tp, "threefry"):
+        raise ValueError("jax.random-compatible generators need float64 programs (uint32 words do not fit a float32)")
     _TABLES.clear()
     T = {"float64": "double", "float32": "float"}[dtype]
     integ = {0: "kRk4", 1: "kSemiImplicit", 2: "kNone"}[integrator]

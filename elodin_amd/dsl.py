@@ -440,6 +440,61 @@ def _flatten(tree):
 lax = _Lax
 
 
+class _Key:
+    """A jax.random key: two uint32 words (held exactly in f64 nodes)."""
+
+    def __init__(self, k0, k1): self.k0, self.k1 = _lift(k0), _lift(k1)
+
+
+class _Random:
+    """jax.random for per-entity code, bit-compatible with JAX's default threefry2x32 generator in its partitionable
+    layout (the default of the reference's JAX): examples/ball/sim.py:92-94 `random.normal(random.key(seed), shape=(3,))`
+    reproduces the wind row of the reference's golden CSV.  x64 semantics (64 random bits per sample), so programs using
+    it must be float64."""
+
+    @staticmethod
+    def key(seed) -> _Key:
+        seed = _lift(seed)
+        hi = _un("floor", seed / 4294967296.0)
+        return _Key(hi, seed - hi * 4294967296.0)
+
+    @staticmethod
+    def _threefry(key: _Key, c0, c1):
+        args = (key.k0, key.k1, _lift(c0), _lift(c1))
+        return Expr("threefry", args, 0), Expr("threefry", args, 1)
+
+    @staticmethod
+    def fold_in(key: _Key, data) -> _Key:
+        x0, x1 = _Random._threefry(key, 0.0, data)          # threefry_2x32(key, [0, uint32(data)])
+        return _Key(x0, x1)
+
+    @staticmethod
+    def _unit(key: _Key, n: int):
+        """n samples in [0, 1): 64 bits each, counter i as (hi = 0, lo = i); mantissa = bits >> 12."""
+        out = []
+        for i in range(n):
+            hi, lo = _Random._threefry(key, 0.0, float(i))
+            out.append((hi * 1048576.0 + _un("floor", lo / 4096.0)) * 2.220446049250313e-16)
+        return out
+
+    @staticmethod
+    def uniform(key: _Key, shape=(), minval=0.0, maxval=1.0):
+        n = int(shape[0]) if shape else 1
+        u = [np.maximum(minval, x * (maxval - minval) + minval) for x in _Random._unit(key, n)]
+        return Vec(u) if shape else u[0]
+
+    @staticmethod
+    def normal(key: _Key, shape=()):
+        lo = -0.9999999999999999                             # nextafter(-1, 0)
+        n = int(shape[0]) if shape else 1
+        u = [np.maximum(lo, x * (1.0 - lo) + lo) for x in _Random._unit(key, n)]
+        z = [_un("erfinv", x) * 1.4142135623730951 for x in u]
+        return Vec(z) if shape else z[0]
+
+
+random = _Random
+
+
 # ---- spatial types (thin mirrors of libs/nox-py/src/spatial.rs wrappers) ---------------------------------------
 
 class RotVec(Vec):

@@ -22,8 +22,9 @@ This module restates the ASCENT part of that stack (pad -> vertical rise -> pitc
 Deliberate scope limits (stated, not hidden): the recovery half of the mission (flip, boostback, entry, landing) is not
 flown: its guidance phases, the landing-leg contact model and ground contact are not built, and fins / RCS — whose plant
 models ARE here — stay at rest because the ascent flight software never commands them; the FSW navigates on truth state
-instead of the noisy IMU/GPS models (those draw from jax.random, which has no counterpart here), and for the same reason
-the wind model carries its steady part only (per-rollout `wind_ned`, zero in spec.toml), not the gust process.
+instead of the noisy IMU/GPS models, and the wind model carries its steady part only (per-rollout `wind_ned`, zero in
+spec.toml), not the gust process: both draw from jax.random, whose counterpart here (`dsl.random`, threefry words held in
+doubles) is float64-only while this campaign runs in float32.
 Parity is UNPINNED against reference trajectories (none are checked in, and the reference cannot run here); the
 helper functions and the passive / open-loop plant are pinned against the reference's own verification ladder
 (test_ladder.py, test_frames.py, test_propulsion.py, test_aero.py) in tests/test_falcon9_host.py and

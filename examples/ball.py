@@ -34,10 +34,17 @@ def bounce(pos, vel):                                   # examples/ball/sim.py:6
         operand=None)}
 
 
-def build(wind=(-0.20584213947964347, -0.7847657764467412, 1.8160866726679834)):
+@dsl.system
+def sample_wind(seed, wind):                            # examples/ball/sim.py:92-94: jax's own generator, same bits
+    return {"wind": dsl.random.normal(dsl.random.key(seed), shape=(3,))}
+
+
+def build(seed=0):
+    """examples/ball/sim.py:120-133: WindData(seed) + Body at 6 m; sample_wind | bounce | six_dof(gravity | apply_drag)."""
     w = el.World()
-    w.spawn([el.Body(world_pos=el.SpatialTransform(linear=[0.0, 0.0, 6.0])), el.C("wind", list(wind))], name="ball")
-    return w.build(bounce | el.six_dof(sys=gravity | apply_drag), simulation_rate=120.0)
+    w.spawn([el.Body(world_pos=el.SpatialTransform(linear=[0.0, 0.0, 6.0])), el.C("seed", [float(seed)]),
+             el.C("wind", [0.0, 0.0, 0.0])], name="ball")
+    return w.build(sample_wind | bounce | el.six_dof(sys=gravity | apply_drag), simulation_rate=120.0)
 
 
 def main(ticks=600):

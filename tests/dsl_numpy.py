@@ -3,11 +3,30 @@ entities: the independent check of what elodin_amd/codegen.py generates.  TEST I
 import numpy as np
 
 from scipy.special import erfc as _erfc
+from scipy.special import erfinv as _erfinv
+
+
+def _threefry(k0, k1, c0, c1):
+    """threefry2x32 on uint32 arrays (the generator behind jax.random)."""
+    k0, k1, x0, x1 = (np.asarray(v, dtype=np.float64).astype(np.uint32) for v in (k0, k1, c0, c1))
+    ks = [k0, k1, k0 ^ k1 ^ np.uint32(0x1BD11BDA)]
+    rot = ((13, 15, 26, 6), (17, 29, 16, 24))
+    with np.errstate(over="ignore"):
+        x0 = x0 + ks[0]
+        x1 = x1 + ks[1]
+        for r in range(5):
+            for d in rot[r % 2]:
+                x0 = x0 + x1
+                x1 = (x1 << np.uint32(d)) | (x1 >> np.uint32(32 - d))
+                x1 = x1 ^ x0
+            x0 = x0 + ks[(r + 1) % 3]
+            x1 = x1 + ks[(r + 2) % 3] + np.uint32(r + 1)
+    return x0.astype(np.float64), x1.astype(np.float64)
 
 _F1 = {"sqrt": np.sqrt, "abs": np.abs, "sin": np.sin, "cos": np.cos, "tan": np.tan, "exp": np.exp, "log": np.log,
        "acos": np.arccos, "asin": np.arcsin, "neg": np.negative, "not": np.logical_not, "log1p": np.log1p, "expm1": np.expm1,
        "cbrt": np.cbrt, "floor": np.floor, "ceil": np.ceil, "trunc": np.trunc, "rint": np.rint, "sinh": np.sinh, "cosh": np.cosh,
-       "erfc": _erfc, "isfinite": np.isfinite}
+       "erfc": _erfc, "isfinite": np.isfinite, "erfinv": _erfinv}
 _F2 = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "max": np.fmax, "min": np.fmin,
        "atan2": np.arctan2, "hypot": np.hypot, "pow": np.power, "mod": np.mod, "lt": np.less, "le": np.less_equal, "eq": np.equal, "and": np.logical_and,
        "or": np.logical_or}
@@ -92,6 +111,8 @@ def _eval(exprs, leaves, n):
             r = np.where(ev(e.args[0]), ev(e.args[1]), ev(e.args[2]))
         elif e.op == "interp":
             r = np.interp(ev(e.args[0]), np.array(e.value[0]), np.array(e.value[1]))
+        elif e.op == "threefry":
+            r = _threefry(*[np.broadcast_to(ev(a), (n,)) for a in e.args])[e.value]
         elif e.op == "while_out":
             r = ev(e.args[0])[e.value]
         elif e.op == "while":

@@ -550,3 +550,58 @@ def test_common_subexpressions_are_not_reused_across_a_write():
             u = np.sin(x) + z
     for name, want in (("x", x), ("y", y), ("z", z), ("u", u)):
         assert np.allclose(hip._aux[name][:, 0], want, rtol=1e-13, atol=1e-15), name
+
+
+def test_ball_example_end_to_end_from_the_seed():
+    """examples/ball exactly as the reference builds it: the wind is NOT read from the golden CSV but sampled in the
+    kernel by `sample_wind` from seed 0 with JAX's threefry2x32 generator (partitionable layout) + erfinv — it must equal
+    ball.wind.csv, and the whole 100-tick trajectory the golden columns."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("ball_example", Path(__file__).resolve().parents[1] / "examples" / "ball.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = gu.load("ball")
+    exec = mod.build(seed=0)
+    worst = 0.0
+    for r in range(1, 101):
+        exec.run(1)
+        assert np.allclose(exec.column_array("wind")[0], g["ball.wind"][r], rtol=1e-13, atol=0.0), r
+        worst = max(worst, parity.pos_rel_err(exec.column_array("world_pos"), g["ball.world_pos"][r][None]),
+                    parity.field_rel_err(exec.column_array("world_vel")[:, 3:], g["ball.world_vel"][r][None, 3:]),
+                    parity.field_rel_err(exec.column_array("force")[:, 3:], g["ball.force"][r][None, 3:]))
+    print("ball example from the seed: wind", exec.column_array("wind")[0], "worst rel err vs golden", worst)
+    assert worst < parity.F64_RTOL
+
+
+def test_random_streams_match_numpy_evaluation_and_differ_per_entity():
+    """jax.random-shaped generators in per-entity code: every entity has its own seed column, fold_in(key, tick) gives a
+    fresh key per tick (the pattern of the reference's sensor noise, examples/falcon9/sensors.py), uniform and normal."""
+    @dsl.system
+    def noise(seed, tick, sample):
+        key = dsl.random.fold_in(dsl.random.key(seed), tick)
+        z = dsl.random.normal(key, shape=(2,))
+        u = dsl.random.uniform(dsl.random.fold_in(key, 3.0), shape=(2,), minval=-1.0, maxval=3.0)
+        return {"sample": np_.concatenate([z, u])}
+    n = 1000
+    seeds = np.arange(n, dtype=np.float64)[:, None] * 7919.0 + 20170814.0
+    w = workloads.independent_bodies(n)
+    prog = dsl.Program([noise], dsl.Pipe([]), [])
+    hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=L.INTEGRATOR_NONE, effectors=prog,
+                     columns={"seed": seeds, "sample": np.zeros((n, 4))})
+    tp = prog.trace()
+    draws = []
+    for tick in (1, 2, 3):
+        hip.run(1)
+        comps = {"seed": seeds.copy(), "sample": np.zeros((n, 4))}
+        pos, vel, inertia = (np.array(w[k], dtype=np.float64) for k in ("world_pos", "world_vel", "inertia"))
+        dsl_numpy._run_systems(tp.pre, pos, vel, inertia, comps, tp.table, tick)
+        assert np.allclose(hip._aux["sample"], comps["sample"], rtol=1e-13, atol=1e-15)
+        draws.append(hip._aux["sample"].copy())
+    all_z = np.concatenate([d[:, :2].ravel() for d in draws])
+    all_u = np.concatenate([d[:, 2:].ravel() for d in draws])
+    assert abs(all_z.mean()) < 0.05 and abs(all_z.std() - 1.0) < 0.05 and -1.0 <= all_u.min() and all_u.max() < 3.0
+    assert abs(all_u.mean() - 1.0) < 0.06 and len(np.unique(all_z)) == all_z.size       # independent streams per entity and tick
+    with pytest.raises(ValueError):
+        el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=np.float32, integrator=L.INTEGRATOR_NONE, effectors=dsl.Program([noise], dsl.Pipe([]), []),
+                   columns={"seed": seeds, "sample": np.zeros((n, 4))})
