@@ -363,13 +363,23 @@ class World:
                     row_ids = np.intersect1d(row_ids, v)
             probe = _dsl.Program(program_stages[0], eff_pipe, program_stages[1]).trace(widths)
             partial = [n for n, _ in probe.columns if not np.all(np.isin(row_ids, self.column(n)[1]))]
+            written = {probe.table.cols[int(t[1:].split("_")[0])][0] for s_ in probe.pre + probe.post for t in s_.written if t[0] == "c"}
+            # a component living on exactly ONE entity and only read is a singleton query (`el.Query[el.Seed]`, `s[0]`,
+            # system.rs:12-23 entity axis elided): every row sees that one value
+            declared = {n for s_ in program_stages[0] + program_stages[1] for n in getattr(s_, "singletons", ())}
+            singletons = {n for n in partial if n in declared and len(self.column(n)[1]) == 1 and n not in written}
+            partial = [n for n in partial if n not in singletons]
             effs = _dsl.Program(program_stages[0], eff_pipe, program_stages[1])
             extra_columns = {}
             for name, w_ in effs.trace(widths, partial).columns:
                 if name.startswith("has:"):
                     continue
                 arr, aids = self.column(name)
-                if name in partial:      # densify onto the row set + presence column (the system's query join mask)
+                if name in singletons:
+                    extra_columns[name] = np.tile(arr[0], (len(row_ids), 1))
+                    column_ids[name] = row_ids
+                    self_partial[name] = (np.zeros(1, dtype=np.int64), np.zeros(1, dtype=np.int64), 1, arr)
+                elif name in partial:      # densify onto the row set + presence column (the system's query join mask)
                     where = {int(e): k for k, e in enumerate(row_ids)}
                     sel = np.array([k for k, e in enumerate(aids) if int(e) in where], dtype=np.int64)
                     at = np.array([where[int(aids[k])] for k in sel], dtype=np.int64)

@@ -864,11 +864,13 @@ class System:
     reads components by parameter name (plus `pos`, `vel`, `inertia`, `tick`), returns {component: new value}.
     `every=n` runs it only on ticks divisible by n (wave-uniform branch), e.g. a 24 Hz guidance law in a 120 Hz sim."""
 
-    def __init__(self, fn: Callable, widths: Optional[Dict[str, int]] = None, every: int = 1):
+    def __init__(self, fn: Callable, widths: Optional[Dict[str, int]] = None, every: int = 1, singletons: Sequence[str] = ()):
         self.fn = fn
         self.params = list(inspect.signature(fn).parameters)
         self.widths = dict(widths or {})
         self.every = int(every)
+        # components queried on their own (`s: el.Query[el.Seed]` ... `s[0]`): a one-entity column every row may read
+        self.singletons = tuple(singletons)
         self.__name__ = getattr(fn, "__name__", "system")
 
 
@@ -886,10 +888,10 @@ class Stages:
         return Stages((other.items if isinstance(other, Stages) else [other]) + self.items)
 
 
-def system(fn=None, every: int = 1, **widths):
+def system(fn=None, every: int = 1, singletons: Sequence[str] = (), **widths):
     if fn is None:
-        return lambda f: System(f, widths, every)
-    return System(fn, widths, every)
+        return lambda f: System(f, widths, every, singletons)
+    return System(fn, widths, every, singletons)
 
 
 class TracedSystem:

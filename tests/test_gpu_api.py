@@ -319,3 +319,35 @@ def test_stablehlo_coverage_example_against_the_reference_baseline():
             worst[name] = max(worst.get(name, 0.0), float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-12))))
     print("stablehlo example on the GPU, worst relative error per component:", worst)
     assert max(worst.values()) < 1e-12, worst
+
+
+def test_seed():  # test_all.py:145-193: a singleton Seed query read by per-entity systems, jax.random inside a map
+    from elodin_amd import dsl
+
+    @dsl.system
+    def foo(x):
+        return {"x": x * 2}
+
+    @dsl.system
+    def bar(x, y):
+        return {"x": x * y}
+
+    @dsl.system(singletons=("seed",))                                # s: el.Query[el.Seed] ... s[0]
+    def seed_mul(seed, x):
+        return {"x": x * seed}
+
+    @dsl.system(singletons=("seed",))
+    def seed_sample(seed, x, y):
+        key = dsl.random.fold_in(dsl.random.key(seed), x)
+        return {"y": y * dsl.random.uniform(key, minval=1.0, maxval=2.0)}
+
+    w = el.World()
+    w.spawn(el.C("seed", [2.0]))                                   # Globals(seed=2): lives on its own entity
+    w.spawn([el.C("x", [1.0]), el.C("y", [500.0])], "e1")
+    w.spawn([el.C("x", [15.0]), el.C("y", [500.0])], "e2")
+    exec = w.build(foo | bar | seed_mul | seed_sample)
+    exec.run()
+    x, y = exec.column_array("x")[:, 0], exec.column_array("y")[:, 0]
+    assert np.isclose(x[0], 2000.0) and np.isclose(x[1], 30000.0)
+    assert 500.0 <= y[0] <= 1000.0 and 500.0 <= y[1] <= 1000.0 and y[0] != y[1]
+    assert np.array_equal(exec.column_array("seed"), [[2.0]])
