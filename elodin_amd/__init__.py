@@ -7,7 +7,7 @@ from ._lib import (BackendError, RK4, SEMI_IMPLICIT, EFF_CONST_WRENCH, EFF_UNIFO
                    EFF_BODY_FORCE, EFF_BALL_DRAG, EFF_EDGE_GRAVITY_NEWTON, EFF_EDGE_GRAVITY_SOFTENED,
                    EFF_ALLPAIRS_GRAVITY_SOFTENED, component_id)
 from .exec import Effector, HipExec, TickTimings
-from .api import (Body, C, Edge, EntityId, Exec, GravityEdge, Integrator, Quaternion, SpatialForce, SpatialInertia,
+from .api import (Body, C, Edge, EntityId, Exec, GravityEdge, skew, Integrator, Quaternion, SpatialForce, SpatialInertia,
                   SpatialMotion, SpatialTransform, System, World, ball_drag, body_force, body_torque, constant_wrench,
                   gravity_newton, gravity_softened, six_dof, uniform_gravity)
 

@@ -148,6 +148,12 @@ class GravityEdge:
     component: str = "gravity_edge"
 
 
+def skew(v) -> np.ndarray:
+    """el.skew (libs/nox-py/python/elodin/__init__.py): the cross-product matrix of a 3-vector."""
+    x, y, z = (float(c) for c in np.asarray(v, dtype=np.float64).reshape(3))
+    return np.array([[0.0, -z, y], [z, 0.0, -x], [-y, x, 0.0]])
+
+
 Edge = GravityEdge      # el.Edge(a, b) under an archetype's own component name: Edge(a, b, component="e")
 
 

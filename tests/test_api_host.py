@@ -61,3 +61,8 @@ def test_value_size_mismatch_on_spawn():
     w.spawn(el.C("wind", [0.0, 0.0, 0.0]))
     with pytest.raises(ValueError, match="value size mismatch"):
         w.spawn(el.C("wind", [0.0, 0.0]))
+
+
+def test_skew():  # test_all.py:367-378
+    import elodin_amd as el
+    assert np.isclose(el.skew(np.array([1.0, 2.0, 3.0])), np.array([[0.0, -3.0, 2.0], [3.0, 0.0, -1.0], [-2.0, 1.0, 0.0]])).all()
