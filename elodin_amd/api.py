@@ -429,6 +429,60 @@ class World:
         return ex
 
 
+class _History:
+    """The rows `exec.history` reads back in the reference (a DB archive, exec.rs:189-213): every component column after
+    each telemetry commit, starting with the spawned state."""
+
+    def __init__(self, ex, world: "World", components: Sequence[str], dt: float):
+        self._ex, self._world, self._dt = ex, world, dt
+        self._components = list(components)
+        self.ticks: List[int] = []
+        self.rows: Dict[str, List[np.ndarray]] = {c: [] for c in self._components}
+        self.sample()
+
+    def sample(self) -> None:
+        self.ticks.append(int(self._ex.tick))
+        for c in self._components:
+            self.rows[c].append(np.array(self._ex.column_array(c), dtype=np.float64))
+
+    def frame(self, wanted) -> Dict[str, np.ndarray]:
+        wanted = [wanted] if isinstance(wanted, str) else list(wanted)
+        by_name = {v: k for k, v in self._world._names.items()}
+        out = {"time": np.asarray(self.ticks, dtype=np.float64) * self._dt}
+        for key in wanted:
+            ent, _, comp = key.partition(".")
+            if ent not in by_name or comp not in self.rows:
+                raise KeyError(key)
+            at = np.nonzero(self._ex.column_ids(comp) == by_name[ent])[0]
+            if not len(at):
+                raise KeyError(key)
+            series = np.stack([r[at[0]] for r in self.rows[comp]])
+            out[key] = series[:, 0] if series.ndim == 2 and series.shape[1] == 1 else series
+        return out
+
+
+def record_history(ex, world: "World") -> None:
+    """Start the telemetry log behind exec.history() on a freshly built executor."""
+    names = []
+    for c in ("world_pos", "world_vel", "world_accel", "force", "inertia") + tuple(world._components):
+        try:
+            ex.column_array(c)
+        except KeyError:
+            continue
+        if c not in names:
+            names.append(c)
+    dt = getattr(ex, "_dt", None) or float(world._lib.sixdof_world_time_step(world._w))
+    if not hasattr(ex, "_world"):        # GraphFoldExec: wrap its run
+        ex._world, run = world, ex.run
+        def logged_run(ticks: int = 1):
+            for _ in range(int(ticks)):
+                run(1)
+                ex._history.sample()
+        ex.run = logged_run
+        ex.history = lambda components: ex._history.frame(components)
+    ex._history = _History(ex, world, names, dt)
+
+
 class Exec:
     """PyExec (exec.rs:95-240): run(ticks), column access, profile."""
 
@@ -437,7 +491,32 @@ class Exec:
         self._last = TickTimings()
 
     def run(self, ticks: int = 1) -> None:
-        self._last = self._hip.run(ticks)
+        log = getattr(self, "_history", None)
+        if log is None:
+            self._last = self._hip.run(ticks)
+            return
+        done = 0                                   # exec.rs:110-172: batches of ticks_per_telemetry, a commit after each
+        while done < ticks:
+            step = min(self._tpt, ticks - done)
+            self._last = self._hip.run(step)
+            log.sample()
+            done += step
+
+    def history(self, components):
+        """exec.history("e1.x") / exec.history(["e1.x", "e2.x"]) (exec.rs:189-213): {"time": seconds, "<entity>.<component>":
+        one row per telemetry commit, the spawned state first}.  Needs build(..., history=True) of elodin_amd.frontend."""
+        if getattr(self, "_history", None) is None:
+            raise RuntimeError("history is not being recorded: build with elodin_amd.frontend.World (history=True)")
+        return self._history.frame(components)
+
+    def column_ids(self, name: str) -> np.ndarray:
+        """Entity id of each row of column_array(name)."""
+        n = len(self.column_array(name))
+        if name in self._world._components:
+            ids = self._world.column(name)[1]
+            if len(ids) == n:
+                return ids
+        return self._hip.entity_ids
 
     @property
     def tick(self) -> int:

@@ -738,6 +738,10 @@ def pipe(*effectors: Effector) -> "Pipe":
     flat: List[Effector] = []
     for e in effectors:
         flat.extend(e.effectors if isinstance(e, Pipe) else [e])
+    for e in flat:
+        if not isinstance(e, Effector):
+            raise TypeError(f"an effector pipe holds functions returning a force; {getattr(e, '__name__', e)!r} is a "
+                            f"{type(e).__name__} (pipe it around six_dof instead)")
     return Pipe(flat)
 
 

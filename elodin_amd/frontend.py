@@ -1,0 +1,492 @@
+"""The reference's decorator surface for the six_dof path, lowered onto this backend.
+
+`import elodin_amd.frontend as el` gives a sim script the names it uses with `import elodin as el`
+(libs/nox-py/python/elodin/__init__.py:160-400 system / Query / map / map_seq, :408-557 GraphQuery.edge_fold, :563-669
+Archetype / C / Body and the well-known component types, elodin.pyi:173-183,417-443 ComponentType / Edge / Component):
+
+    X = ty.Annotated[el.Array, el.Component("x", el.ComponentType.F64)]
+
+    @el.system
+    def bar(q: el.Query[X, Y]) -> el.Query[X]:
+        return q.map(X, lambda x, y: x * y)
+
+    @el.map
+    def gravity(f: el.Force, inertia: el.Inertia) -> el.Force:
+        return f + el.SpatialForce(linear=inertia.mass() * el.np.array([0.0, 0.0, -9.81]))
+
+    exec = w.build(foo.pipe(bar) | el.six_dof(sys=gravity))
+
+Nothing here computes.  A decorated function is called once on symbols (elodin_amd.dsl) to learn what it is, and becomes
+ * a dsl.System      — per-entity map over component columns, compiled into the step kernel around six_dof,
+ * a dsl.Effector    — a map whose output is el.Force, compiled into the RK4 stage loop as a six_dof effector,
+ * a dsl.EdgeFold    — edge_fold over Query[WorldPos, Inertia] returning el.Force (the pair kernels), or
+ * a dsl.GraphFold   — edge_fold over plain components (a stand-alone generated kernel).
+Inside the functions `el.np`, `el.lax` and `el.random` stand where the reference's scripts use jax.numpy, jax.lax and
+jax.random.  `map_seq` is `map`: one lane per entity, so `lax.cond` already runs one branch per entity and the
+results are identical (test_all.py:503-578 asserts exactly that of the reference)."""
+from __future__ import annotations
+
+import dataclasses
+import enum
+import inspect
+import re
+import typing
+from dataclasses import dataclass  # noqa: F401  (scripts write @el.dataclass)
+from typing import Annotated, Any, List, Optional, Sequence, Tuple  # noqa: F401
+
+import numpy as _np
+
+from . import api as _api
+from . import dsl as _dsl
+from .api import EntityId, Integrator, skew  # noqa: F401
+from ._lib import BackendError  # noqa: F401
+
+np, lax, random = _dsl.np, _dsl.lax, _dsl.random
+Array = _np.ndarray          # stands where the reference's annotations say jax.Array
+
+
+# ---- component metadata (elodin.pyi:165-183,424-443) ---------------------------------------------------------------
+
+class PrimitiveType(enum.Enum):
+    F64 = "f64"; F32 = "f32"; U64 = "u64"; U32 = "u32"; U16 = "u16"; U8 = "u8"      # noqa: E702
+    I64 = "i64"; I32 = "i32"; I16 = "i16"; I8 = "i8"; Bool = "bool"                # noqa: E702
+
+
+class ComponentType:
+    """Element type + shape.  Columns on this backend are floating point (the executor's dtype); integer components such
+    as el.Seed ride in them exactly up to 2**53."""
+
+    def __init__(self, ty: PrimitiveType, shape: Sequence[int] = ()):
+        self.ty, self.shape = ty, tuple(int(s) for s in shape)
+
+    @property
+    def width(self) -> int:
+        return int(_np.prod(self.shape)) if self.shape else 1
+
+    def __repr__(self): return f"ComponentType({self.ty.name}, {self.shape})"
+
+
+ComponentType.U64 = ComponentType(PrimitiveType.U64)
+ComponentType.F64 = ComponentType(PrimitiveType.F64)
+ComponentType.F32 = ComponentType(PrimitiveType.F32)
+ComponentType.Edge = ComponentType(PrimitiveType.U64, (2,))
+ComponentType.Quaternion = ComponentType(PrimitiveType.F64, (4,))
+ComponentType.SpatialPosF64 = ComponentType(PrimitiveType.F64, (7,))
+ComponentType.SpatialMotionF64 = ComponentType(PrimitiveType.F64, (6,))
+
+
+class Component:
+    def __init__(self, name: str, ty: Optional[ComponentType] = None, asset: bool = False, metadata: Optional[dict] = None):
+        self.name_, self.ty, self.asset, self.metadata = name, ty, asset, dict(metadata or {})
+
+    @staticmethod
+    def of(component: Any) -> "Component":
+        for m in getattr(component, "__metadata__", ()):
+            if isinstance(m, Component):
+                return m
+        raise TypeError(f"{component!r} is not an Annotated component type")
+
+    @staticmethod
+    def name(component: Any) -> str:
+        return Component.of(component).name_
+
+    id = name   # the deprecated spelling
+
+
+def _origin(component: Any):
+    return getattr(component, "__origin__", None)
+
+
+def _width(component: Any) -> Optional[int]:
+    c = Component.of(component)
+    if c.ty is not None:
+        return c.ty.width
+    return {SpatialTransform: 7, SpatialMotion: 6, SpatialForce: 6, SpatialInertia: 7, Quaternion: 4}.get(_origin(component))
+
+
+# ---- spatial values: numpy-backed when spawning, symbolic inside a traced function -------------------------------------
+
+_SYMBOLIC = (_dsl.Expr, _dsl.Vec, _dsl.Quaternion, _dsl.SpatialTransform, _dsl.SpatialMotion, _dsl.SpatialForce,
+             _dsl.SpatialInertia)
+
+
+def _symbolic(v) -> bool:
+    return isinstance(v, _SYMBOLIC)
+
+
+def _lift(v):
+    """A host value met inside a traced expression becomes a constant of the trace."""
+    if _symbolic(v) or v is None:
+        return v
+    vec = lambda a: _dsl.Vec([float(x) for x in a])
+    if isinstance(v, _api.Quaternion):
+        return _dsl.Quaternion(vec(v.arr))
+    if isinstance(v, _api.SpatialTransform):
+        return _dsl.SpatialTransform(_dsl.Quaternion(vec(v.arr[:4])), vec(v.arr[4:]))
+    if isinstance(v, _api.SpatialMotion):
+        return _dsl.SpatialMotion(vec(v.arr[:3]), vec(v.arr[3:]))
+    if isinstance(v, _api.SpatialForce):
+        return _dsl.SpatialForce(vec(v.arr[:3]), vec(v.arr[3:]))
+    if isinstance(v, _api.SpatialInertia):
+        return _dsl.SpatialInertia(vec(v.arr[:3]), float(v.arr[6]))
+    if isinstance(v, (_np.ndarray, list, tuple)):
+        a = _np.asarray(v, dtype=_np.float64)
+        return float(a) if a.ndim == 0 else _dsl.Vec([float(x) for x in a.reshape(-1)])
+    return v
+
+
+class _DualMeta(type):
+    def __call__(cls, *args, **kw):
+        if any(_symbolic(v) for v in list(args) + list(kw.values())):
+            return cls._traced(*[_lift(a) for a in args], **{k: _lift(v) for k, v in kw.items()})
+        return cls._host(*args, **kw)
+
+    def __instancecheck__(cls, obj):
+        return isinstance(obj, (cls._host, cls._traced_cls))
+
+
+def _dual(name, host, traced_cls, traced=None, **statics):
+    ns = {"_host": host, "_traced_cls": traced_cls, "_traced": staticmethod(traced or traced_cls), "__doc__": host.__doc__}
+    ns.update({k: staticmethod(v) for k, v in statics.items()})
+    return _DualMeta(name, (), ns)
+
+
+def _q_from_axis_angle(axis, angle):
+    if _symbolic(axis) or _symbolic(angle):
+        return _dsl.Quaternion.from_axis_angle(_lift(axis), _lift(angle))
+    return _api.Quaternion.from_axis_angle(axis, angle)
+
+
+def _traced_inertia(mass, inertia=None):     # spatial.rs:392-405: inertia defaults to ones(3) * mass
+    mass = _lift(mass)
+    return _dsl.SpatialInertia(_lift(inertia) if inertia is not None else _dsl.Vec([mass, mass, mass]), mass)
+
+
+Quaternion = _dual("Quaternion", _api.Quaternion, _dsl.Quaternion, identity=_api.Quaternion.identity,
+                   from_axis_angle=_q_from_axis_angle)
+SpatialTransform = _dual("SpatialTransform", _api.SpatialTransform, _dsl.SpatialTransform)
+SpatialMotion = _dual("SpatialMotion", _api.SpatialMotion, _dsl.SpatialMotion)
+SpatialForce = _dual("SpatialForce", _api.SpatialForce, _dsl.SpatialForce)
+SpatialInertia = _dual("SpatialInertia", _api.SpatialInertia, _dsl.SpatialInertia, traced=_traced_inertia)
+
+
+def Edge(left, right):
+    """el.Edge(left, right) (graph.rs:17-41); the edge component's name comes from the archetype field it is stored in."""
+    return _api.GravityEdge(int(left), int(right))
+
+
+Edge.__metadata__ = ()
+
+WorldPos = Annotated[SpatialTransform, Component("world_pos", metadata={"element_names": "q0,q1,q2,q3,x,y,z", "priority": 5})]
+WorldVel = Annotated[SpatialMotion, Component("world_vel", metadata={"element_names": "ωx,ωy,ωz,x,y,z", "priority": 5})]
+WorldAccel = Annotated[SpatialMotion, Component("world_accel", metadata={"element_names": "αx,αy,αz,x,y,z", "priority": 5})]
+Force = Annotated[SpatialForce, Component("force", metadata={"element_names": "τx,τy,τz,x,y,z", "priority": 5})]
+Inertia = Annotated[SpatialInertia, Component("inertia", metadata={"priority": 5})]
+Seed = Annotated[Array, Component("seed", ComponentType.U64, metadata={"priority": 5})]
+SimulationTick = Annotated[Array, Component("tick", ComponentType.F64, metadata={"priority": 7})]
+SimulationTimeStep = Annotated[Array, Component("simulation_time_step", ComponentType.F64, metadata={"priority": 8})]
+
+
+# ---- archetypes (__init__.py:560-669) ---------------------------------------------------------------------------------
+
+_snake = re.compile(r"(?<!^)(?=[A-Z])")
+
+
+def _host_rows(value) -> _np.ndarray:
+    return _np.atleast_1d(_np.asarray(value.arr if hasattr(value, "arr") else value, dtype=_np.float64)).reshape(-1)
+
+
+def _class_hints(cls) -> dict:
+    try:
+        return typing.get_type_hints(cls, include_extras=True)
+    except Exception:            # a class body naming types of an enclosing function: the annotations are the objects themselves
+        return {k: v for c in reversed(cls.__mro__) for k, v in getattr(c, "__annotations__", {}).items()}
+
+
+class Archetype:
+    """Base of user archetypes: a dataclass whose fields are annotated with component types."""
+
+    @classmethod
+    def archetype_name(cls) -> str:
+        return _snake.sub("_", cls.__name__).lower()
+
+    def component_data(self) -> List[Component]:
+        return [Component.of(h) for h in _class_hints(type(self)).values()]
+
+    def _fields(self):
+        for attr, hint in _class_hints(type(self)).items():
+            yield Component.name(hint), getattr(self, attr)
+
+    def components(self):
+        return {name: _host_rows(v) for name, v in self._fields() if not isinstance(v, _api.GravityEdge)}
+
+    def edges(self):
+        return [_api.GravityEdge(v.a, v.b, name) for name, v in self._fields() if isinstance(v, _api.GravityEdge)]
+
+
+class C(Archetype):
+    """el.C(X, value) / el.C((X, Y), (x, y)): components without declaring an archetype (__init__.py:643-661)."""
+
+    def __init__(self, tys, values):
+        if not isinstance(tys, tuple):
+            tys, values = (tys,), (values,)
+        self._items = [(Component.name(t), v) for t, v in zip(tys, values)]
+
+    def component_data(self): return [Component(n) for n, _ in self._items]
+    def _fields(self): return iter(self._items)
+
+
+@dataclass
+class Body(Archetype):
+    """six_dof.rs:152-159 / __init__.py:663-669: identity pose, zero velocity, unit mass by default."""
+    world_pos: WorldPos = dataclasses.field(default_factory=_api.SpatialTransform)
+    world_vel: WorldVel = dataclasses.field(default_factory=_api.SpatialMotion)
+    inertia: Inertia = dataclasses.field(default_factory=lambda: _api.SpatialInertia(1.0))
+    force: Force = dataclasses.field(default_factory=_api.SpatialForce)
+    world_accel: WorldAccel = dataclasses.field(default_factory=_api.SpatialMotion)
+
+
+# ---- queries ----------------------------------------------------------------------------------------------------------
+
+class _QueryType:
+    """`el.Query[X, Y]` as an annotation."""
+
+    def __init__(self, components: Tuple[Any, ...]):
+        self.components = tuple(components)
+        self.names = [Component.name(c) for c in self.components]
+
+
+class RevEdge: ...
+
+
+class TotalEdge: ...
+
+
+class _GraphQueryType:
+    def __init__(self, edge: Any):
+        if edge is TotalEdge or RevEdge in getattr(edge, "__metadata__", ()):
+            raise NotImplementedError("GraphQuery over TotalEdge / RevEdge: spawn explicit el.Edge entities "
+                                      "(api.gravity_softened(edge_component=None) is the built-in all-pairs fold)")
+        self.edge_component = Component.name(edge)
+
+
+class Query:
+    """The values of one query inside a system being traced: one symbol (or symbolic spatial value) per component, the
+    entity axis implicit — every entity of the query's join is one lane of the generated kernel."""
+
+    def __class_getitem__(cls, item):
+        item = item if isinstance(item, tuple) else (item,)
+        return _QueryType(tuple(x for it in item for x in (it if isinstance(it, tuple) else (it,))))
+
+    def __init__(self, components: Sequence[Any], values: Sequence[Any], indexed: Optional[set] = None):
+        self.components, self.values = list(components), list(values)
+        self._indexed = indexed if indexed is not None else set()
+
+    @property
+    def names(self): return [Component.name(c) for c in self.components]
+
+    def map(self, out_tps, f) -> "Query":
+        outs = out_tps if isinstance(out_tps, tuple) else (out_tps,)
+        res = f(*self.values)
+        res = tuple(res) if isinstance(res, (tuple, list)) and len(outs) > 1 else (res,)
+        if len(res) != len(outs):
+            raise TypeError(f"map function returned {len(res)} values for {len(outs)} output components")
+        return Query(outs, [_lift(r) for r in res], self._indexed)
+
+    map_seq = map
+
+    def join(self, other: "Query") -> "Query":
+        return Query(self.components + other.components, self.values + other.values, self._indexed)
+
+    def __getitem__(self, index: int):
+        if len(self.values) > 1:
+            raise Exception("Cannot index into a query with multiple inputs")
+        if index != 0:
+            raise IndexError("only q[0] — the value of a one-entity component such as el.Seed — is available: the entity "
+                             "axis of a query is the kernel's lane axis")
+        self._indexed.add(self.names[0])
+        return self.values[0]
+
+
+class _Fold:
+    """What `graph.edge_fold(...)` returns while a system is traced."""
+
+    def __init__(self, edge_component, left, right, out, init, fn):
+        self.edge_component, self.left, self.right, self.out, self.init, self.fn = edge_component, left, right, out, init, fn
+
+
+class GraphQuery:
+    def __class_getitem__(cls, item):
+        return _GraphQueryType(item)
+
+    def __init__(self, edge_component: str):
+        self.edge_component = edge_component
+
+    def edge_fold(self, left_query: Query, right_query: Query, return_type, init_value, fold_fn) -> _Fold:
+        return _Fold(self.edge_component, left_query.names, right_query.names, Component.name(return_type), init_value, fold_fn)
+
+
+# ---- system / map ------------------------------------------------------------------------------------------------------
+
+_BODY = ("world_pos", "world_vel", "inertia")
+
+
+def _probe_value(component):
+    """A symbol of the right shape for the decoration-time call (only the system's kind and its singleton queries are
+    read off that call; the real trace happens at World.build with the columns' actual widths)."""
+    name, w = Component.name(component), _width(component)
+    if name in _BODY:
+        return dict(zip(_BODY, _dsl._body_symbols()))[name]
+    if name == "force":
+        return _dsl.SpatialForce(_dsl.Vec([_dsl.leaf(f"acc{k}") for k in range(3)]), _dsl.Vec([_dsl.leaf(f"acc{k}") for k in range(3, 6)]))
+    if name == "tick":
+        return _dsl.leaf("tick")
+    v = _dsl.Vec([_dsl.leaf(f"probe:{name}:{k}") for k in range(w or 1)])
+    return v if len(v) > 1 else v[0]
+
+
+def _annotations(func):
+    try:
+        hints = typing.get_type_hints(func, include_extras=True)
+    except Exception:                                # annotations that only resolve in the defining scope
+        hints = {}
+    sig = inspect.signature(func)
+    params = [(n, hints.get(n, p.annotation)) for n, p in sig.parameters.items()]
+    return params, hints.get("return", sig.return_annotation)
+
+
+def system(func):
+    """@el.system (__init__.py:160-185): parameters annotated el.Query[...] / el.GraphQuery[...]; returns the query that
+    holds the written components."""
+    params, _ret = _annotations(func)
+    for pname, ann in params:
+        if not isinstance(ann, (_QueryType, _GraphQueryType)):
+            raise TypeError(f"system {func.__name__}: parameter {pname} must be annotated el.Query[...] or el.GraphQuery[...]")
+    q_components = list(dict.fromkeys(c for _, a in params if isinstance(a, _QueryType) for c in a.components))
+    by_name = {Component.name(c): c for c in q_components}
+
+    def call(values: dict, indexed: set):
+        args = [Query(a.components, [values[n] for n in a.names], indexed) if isinstance(a, _QueryType)
+                else GraphQuery(a.edge_component) for _, a in params]
+        return func(*args)
+
+    indexed: set = set()
+    probe = call({n: _probe_value(c) for n, c in by_name.items()}, indexed)
+    name = getattr(func, "__name__", "system")
+    if isinstance(probe, _Fold):
+        return _lower_fold(probe, name)
+    if not isinstance(probe, Query):
+        raise TypeError(f"system {name} must return a query (q.map(...)) or graph.edge_fold(...)")
+    out_names = probe.names
+    widths = {n: w for n, c in {**by_name, **{Component.name(c): c for c in probe.components}}.items()
+              if (w := _width(c)) is not None and n not in _BODY + ("force", "tick")}
+
+    if out_names == ["force"]:                       # `-> el.Force`: an effector of six_dof (six_dof.rs:161-203 `sys`)
+        def effector_fn(**cols):             # the pipe tracer hands every plain column over as a Vec; shape-() ones are scalars
+            cols = {n: (v[0] if isinstance(v, _dsl.Vec) and type(v) is _dsl.Vec and len(v) == 1 else v) for n, v in cols.items()}
+            return call(cols, set()).values[0]
+        eff = _dsl.Effector(effector_fn, widths)
+        eff.params, eff.__name__ = list(by_name), name
+        return eff
+    if "force" in out_names or "world_accel" in out_names:
+        raise TypeError(f"system {name}: force / world_accel are produced inside six_dof — return el.Force alone and pass "
+                        "the system as six_dof(sys=...)")
+
+    def system_fn(**cols):
+        out = call(cols, set())
+        return dict(zip(out.names, out.values))
+    s = _dsl.System(system_fn, widths, 1, tuple(sorted(indexed)))
+    s.params, s.__name__ = list(by_name), name
+    return s
+
+
+def _lower_fold(fold: _Fold, name: str):
+    body_pair = ["world_pos", "inertia"]
+    if fold.out == "force":
+        if fold.left != body_pair or fold.right != body_pair:
+            raise TypeError("an edge_fold returning el.Force folds over Query[el.WorldPos, el.Inertia] on both sides")
+        init = fold.init.arr if hasattr(fold.init, "arr") else None
+        if init is None or _np.any(init != 0.0):
+            raise ValueError("an edge_fold returning el.Force starts from el.SpatialForce() (zero)")
+        fn = fold.fn
+        ef = _dsl.EdgeFold(lambda acc, a_pos, a_inertia, b_pos, b_inertia: fn(acc, a_pos, a_inertia, b_pos, b_inertia),
+                           fold.edge_component)
+        ef.__name__ = name
+        return ef
+    init = [float(v) for v in _np.atleast_1d(_np.asarray(fold.init, dtype=_np.float64)).reshape(-1)]
+    fn, n_args = fold.fn, 1 + len(fold.left) + len(fold.right)
+    src = "lambda " + ", ".join(f"a{k}" for k in range(n_args)) + ": fn(" + ", ".join(f"a{k}" for k in range(n_args)) + ")"
+    gf = _dsl.GraphFold(eval(src, {"fn": fn}), fold.edge_component, fold.left, fold.right, fold.out, init)   # fixed arity
+    gf.__name__ = name
+    return gf
+
+
+def _map(func, seq: bool):
+    params, ret = _annotations(func)
+    if typing.get_origin(ret) is tuple:
+        ret = tuple(typing.get_args(ret))
+    query_t = _QueryType(tuple(a for _, a in params))
+
+    def inner(q):
+        return (q.map_seq if seq else q.map)(ret, func)
+    inner.__name__ = getattr(func, "__name__", "map")
+    inner.__annotations__ = {"q": query_t}
+    return system(inner)
+
+
+def map(func):          # noqa: A001  (the reference's name)
+    """@el.map (__init__.py:360-374): parameters and return annotated with component types."""
+    return _map(func, False)
+
+
+def map_seq(func):
+    """@el.map_seq (__init__.py:377-396)."""
+    return _map(func, True)
+
+
+# `a.pipe(b)` beside `a | b` (system.rs:1001-1011)
+def _pipe(self, other):
+    return self | other
+
+
+for _cls in (_dsl.System, _dsl.Stages, _dsl.Effector, _dsl.Pipe, _dsl.GraphFold, _api.System):
+    _cls.pipe = _pipe
+
+
+def six_dof(time_step: Optional[float] = None, sys=None, integrator: Integrator = Integrator.Rk4):
+    """elodin.six_dof (lib.rs:106-127): `sys` is what @el.map / @el.system made of functions returning el.Force —
+    effectors piped with `|`, optionally closed by one edge_fold system."""
+    if isinstance(sys, _dsl.Stages):                 # `gravity | drag` of two effector-kind systems
+        sys = sys.items
+    if isinstance(sys, (list, tuple)):
+        folds = [s for s in sys if isinstance(s, _dsl.EdgeFold)]
+        effs = [s for s in sys if not isinstance(s, _dsl.EdgeFold)]
+        if folds and effs:
+            raise TypeError("a user edge_fold cannot be piped with generated effectors: fold it in its own six_dof(sys=...)")
+        sys = folds[0] if folds else _dsl.pipe(*effs)
+    return _api.six_dof(time_step, sys, integrator)
+
+
+# ---- world --------------------------------------------------------------------------------------------------------------
+
+class World(_api.World):
+    """el.World(): spawn archetypes, build.  `exec.history([...])` works as in the reference (one row per telemetry
+    commit); pass history=False to build() for long runs that only read the final columns."""
+
+    def insert(self, eid, archetypes) -> None:
+        if not isinstance(archetypes, (list, tuple)):
+            archetypes = [archetypes]
+        flat = []
+        for a in archetypes:
+            flat.append(a)
+            flat.extend(a.edges() if isinstance(a, Archetype) else [])
+        super().insert(eid, flat)
+
+    def build(self, system, simulation_rate: float = 120.0, telemetry_rate: Optional[float] = None, device: int = 0,
+              backend: str = "hip", history: bool = True):
+        if isinstance(system, _dsl.Effector):
+            raise TypeError("a system returning el.Force is a six_dof effector: build(el.six_dof(sys=...))")
+        ex = super().build(system, simulation_rate=simulation_rate, telemetry_rate=telemetry_rate, device=device, backend=backend)
+        if history:
+            _api.record_history(ex, self)
+        return ex

@@ -115,6 +115,9 @@ class GraphFoldExec:
         """The component's own rows in its own entity order (what `exec.history` would show last)."""
         return self._dense[name][self._at[name]]
 
+    def column_ids(self, name: str) -> np.ndarray:
+        return self._own[name][1]
+
     def close(self):
         for ptr in self._bufs:
             self._hip.hipFree(ptr)

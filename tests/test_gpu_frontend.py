@@ -1,0 +1,440 @@
+"""libs/nox-py/python/tests/test_all.py as the reference wrote it — @el.system / @el.map / el.Query / el.Archetype /
+exec.history — executed by the HIP backend through elodin_amd.frontend.  Differences from the original file are the ones
+the frontend documents: `el.np` / `el.lax` / `el.random` inside traced functions instead of jax, and history frames that
+are dicts of numpy arrays (polars is not in this image)."""
+import typing as ty
+from dataclasses import dataclass
+
+import numpy as np
+import pytest
+
+import elodin_amd.frontend as el
+
+pytestmark = pytest.mark.gpu
+
+X = ty.Annotated[el.Array, el.Component("x", el.ComponentType.F64)]
+Y = ty.Annotated[el.Array, el.Component("y", el.ComponentType.F64)]
+Effect = ty.Annotated[el.Array, el.Component("e", el.ComponentType.F64)]
+E = ty.Annotated[el.Edge, el.Component("test_edge")]
+
+
+@dataclass
+class Test(el.Archetype):
+    __test__ = False
+    x: X
+    y: Y
+
+
+@dataclass
+class OnlyX(el.Archetype):
+    x: X
+
+
+def frame_equal(df, expected):
+    assert set(df) == set(expected) | {"time"}
+    for k, v in expected.items():
+        assert np.array_equal(df[k], np.asarray(v)), (k, df[k], v)
+
+
+def test_basic_system():  # test_all.py:18-64
+    @el.system
+    def foo(x: el.Query[X]) -> el.Query[X]:
+        return x.map(X, lambda x: x * 2)
+
+    @el.system
+    def bar(q: el.Query[X, Y]) -> el.Query[X]:
+        return q.map(X, lambda x, y: x * y)
+
+    @el.map
+    def baz(x: X, z: Effect) -> X:
+        return x + z
+
+    @dataclass
+    class EffectArchetype(el.Archetype):
+        e: Effect
+
+    sys = foo.pipe(bar).pipe(baz)
+    w = el.World()
+    w.spawn(Test(np.array([1.0]), np.array([500.0])), "e1")
+    w.spawn([Test(np.array([15.0]), np.array([500.0])), EffectArchetype(np.array([15.0]))], "e2")
+    exec = w.build(sys)
+    exec.run()
+    exec.run()
+    df = exec.history(["e1.x", "e2.x", "e1.y", "e2.y"])
+    frame_equal(df, {"e1.x": [1.0, 1000.0, 1000000.0], "e2.x": [15.0, 15015.0, 15015015.0],
+                     "e1.y": [500.0, 500.0, 500.0], "e2.y": [500.0, 500.0, 500.0]})
+    assert df["time"].tolist() == [0.0, exec._dt, 2 * exec._dt]
+
+
+def test_six_dof():  # test_all.py:67-83
+    w = el.World()
+    w.spawn(el.Body(world_pos=el.SpatialTransform(linear=np.array([0.0, 0.0, 0.0])),
+                    world_vel=el.SpatialMotion(linear=np.array([1.0, 0.0, 0.0])),
+                    inertia=el.SpatialInertia(1.0)), "e1")
+    sys = el.six_dof(1.0 / 60.0)
+    exec = w.build(sys)
+    exec.run()
+    df = exec.history("e1.world_pos")
+    x = df["e1.world_pos"][-1]
+    assert np.allclose(x[:4], np.array([0.0, 0.0, 0.0, 1.0]))
+    assert np.allclose(x[4:], np.array([0.01666667, 0.0, 0.0]))
+
+
+def test_spatial_integration():  # test_all.py:86-114
+    @el.map
+    def integrate_velocity(world_pos: el.WorldPos, world_vel: el.WorldVel) -> el.WorldPos:
+        linear = world_pos.linear() + world_vel.linear()
+        angular = world_pos.angular().integrate_body(world_vel.angular())
+        return el.SpatialTransform(linear=linear, angular=angular)
+
+    w = el.World()
+    w.spawn(el.Body(world_pos=el.SpatialTransform(linear=np.array([0.0, 0.0, 0.0])),
+                    world_vel=el.SpatialMotion(linear=np.array([1.0, 0.0, 0.0]), angular=np.array([np.pi / 2, 0.0, 0.0])),
+                    inertia=el.SpatialInertia(1.0)), "e1")
+    exec = w.build(integrate_velocity)
+    exec.run()
+    exec.run()
+    pos = exec.history("e1.world_pos")["e1.world_pos"][-1]
+    assert (pos[4:] == [2.0, 0.0, 0.0]).all()
+    assert np.allclose(pos[:4], np.array([0.97151626, 0.0, 0.0, 0.23697292]))
+
+
+def test_graph():  # test_all.py:117-142
+    @dataclass
+    class EdgeArchetype(el.Archetype):
+        edge: E
+
+    @el.system
+    def fold_test(graph: el.GraphQuery[E], x: el.Query[X]) -> el.Query[X]:
+        return graph.edge_fold(x, x, X, np.array(5.0), lambda x, a, b: x + a + b)
+
+    w = el.World()
+    a = w.spawn(OnlyX(np.array([1.0])), "e1")
+    b = w.spawn(OnlyX(np.array([2.0])), "e2")
+    c = w.spawn(OnlyX(np.array([2.0])), "e3")
+    w.spawn(EdgeArchetype(el.Edge(a, b)))
+    w.spawn(EdgeArchetype(el.Edge(a, c)))
+    w.spawn(EdgeArchetype(el.Edge(b, c)))
+    exec = w.build(fold_test)
+    exec.run()
+    frame_equal(exec.history(["e1.x", "e2.x", "e3.x"]), {"e1.x": [1.0, 11.0], "e2.x": [2.0, 9.0], "e3.x": [2.0, 2.0]})
+
+
+def test_seed():  # test_all.py:145-193
+    @el.system
+    def foo(x: el.Query[X]) -> el.Query[X]:
+        return x.map(X, lambda x: x * 2)
+
+    @el.system
+    def bar(q: el.Query[X, Y]) -> el.Query[X]:
+        return q.map(X, lambda x, y: x * y)
+
+    @el.system
+    def seed_mul(s: el.Query[el.Seed], q: el.Query[X]) -> el.Query[X]:
+        return q.map(X, lambda x: x * s[0])
+
+    @el.system
+    def seed_sample(s: el.Query[el.Seed], q: el.Query[X, Y]) -> el.Query[Y]:
+        def sample_inner(x, y):
+            key = el.random.key(s[0])
+            key = el.random.fold_in(key, x)
+            scaler = el.random.uniform(key, minval=1.0, maxval=2.0)
+            return y * scaler
+
+        return q.map(Y, sample_inner)
+
+    @dataclass
+    class Globals(el.Archetype):
+        seed: el.Seed
+
+    sys = foo.pipe(bar).pipe(seed_mul).pipe(seed_sample)
+    w = el.World()
+    w.spawn(Globals(seed=np.array(2)))
+    w.spawn(Test(np.array(1.0), np.array(500.0)), "e1")
+    w.spawn(Test(np.array(15.0), np.array(500.0)), "e2")
+    exec = w.build(sys)
+    exec.run()
+    df = exec.history(["e1.x", "e2.x", "e1.y", "e2.y"])
+    assert np.isclose(df["e1.x"][-1], 2000.0)
+    assert np.isclose(df["e2.x"][-1], 30000.0)
+    for k in ("e1.y", "e2.y"):
+        assert 500.0 <= df[k][-1] <= 1000.0
+    # and the draw is jax.random's: uniform(fold_in(key(2), x)) for x = 2000, 30000 (threefry2x32, partitionable)
+    from tests import dsl_numpy
+    for k, x in (("e1.y", 2000.0), ("e2.y", 30000.0)):
+        u = dsl_numpy.trace_eval(lambda np_, xv: el.random.uniform(el.random.fold_in(el.random.key(2), xv), minval=1.0, maxval=2.0), x)
+        assert np.isclose(df[k][-1], 500.0 * u, rtol=1e-15)
+
+
+def test_spatial_vector_algebra():  # test_all.py:204-225
+    @el.map
+    def double_vec(v: el.WorldVel) -> el.WorldVel:
+        return v + v
+
+    w = el.World()
+    w.spawn(el.Body(world_vel=el.SpatialMotion(linear=np.array([1.0, 0.0, 0.0]))), "e1")
+    exec = w.build(double_vec)
+    exec.run()
+    frame_equal(exec.history("e1.world_vel"), {"e1.world_vel": [[0.0, 0.0, 0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 0.0, 2.0, 0.0, 0.0]]})
+
+
+@pytest.mark.parametrize("omega,q", [([0, 0, 1.0], [0.0, 0.0, 0.479425538604203, 0.8775825618903728]),
+                                     ([0, 1.0, 0], [0.0, 0.479425538604203, 0.0, 0.8775825618903728]),
+                                     ([1.0, 1.0, 0], [0.45936268493243, 0.45936268493243, 0.0, 0.76024459707606])])
+def test_six_dof_ang_vel_int(omega, q):  # test_all.py:228-292, "value from Julia and Simulink"
+    w = el.World()
+    w.spawn(el.Body(world_pos=el.SpatialTransform(linear=np.array([0.0, 0.0, 0.0])),
+                    world_vel=el.SpatialMotion(angular=np.array(omega)), inertia=el.SpatialInertia(1.0)), "e1")
+    exec = w.build(el.six_dof(1.0 / 120.0))
+    exec.run(120)
+    df = exec.history("e1.world_pos")
+    assert len(df["time"]) == 121                      # one row per telemetry commit, the spawned state first
+    assert np.isclose(df["e1.world_pos"][-1], np.array(q + [0.0, 0.0, 0.0]), rtol=1e-5).all()
+
+
+def test_six_dof_force():  # test_all.py:342-364, "values taken from simulink"
+    w = el.World()
+    w.spawn(el.Body(world_pos=el.SpatialTransform(linear=np.array([0.0, 0.0, 0.0])),
+                    world_vel=el.SpatialMotion(angular=np.array([0.0, 0.0, 0.0])), inertia=el.SpatialInertia(1.0)), "e1")
+
+    @el.map
+    def constant_force(_: el.Force) -> el.Force:
+        return el.SpatialForce(linear=np.array([1.0, 0.0, 0.0]))
+
+    exec = w.build(el.six_dof(1.0 / 120.0, constant_force))
+    exec.run(120)
+    df = exec.history(["e1.world_pos", "e1.world_vel", "e1.world_accel"])
+    assert np.isclose(df["e1.world_pos"][-1], np.array([0.0, 0.0, 0.0, 1.0, 0.5, 0.0, 0.0]), rtol=1e-5).all()
+    assert np.isclose(df["e1.world_vel"][-1], np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0]), rtol=1e-5).all()
+    assert np.isclose(df["e1.world_accel"][-1], np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0]), rtol=1e-5).all()
+
+
+def test_map_seq_single_entity():  # test_all.py:421-440
+    @el.system
+    def double_x_seq(q: el.Query[X]) -> el.Query[X]:
+        return q.map_seq(X, lambda x: x * 2)
+
+    w = el.World()
+    w.spawn(OnlyX(np.array(5.0)), "e1")
+    exec = w.build(double_x_seq)
+    exec.run()
+    exec.run()
+    frame_equal(exec.history("e1.x"), {"e1.x": [5.0, 10.0, 20.0]})
+
+
+def test_map_seq_multiple_entities_and_outputs():  # test_all.py:443-500
+    @el.system
+    def add_xy_seq(q: el.Query[X, Y]) -> el.Query[X]:
+        return q.map_seq(X, lambda x, y: x + y)
+
+    @el.system
+    def swap_xy_seq(q: el.Query[X, Y]) -> el.Query[X, Y]:
+        return q.map_seq((X, Y), lambda x, y: (y, x))
+
+    for system, expected in ((add_xy_seq, {"e1.x": [1.0, 11.0], "e2.x": [2.0, 22.0], "e3.x": [3.0, 33.0]}),
+                             (swap_xy_seq, {"e1.x": [1.0, 10.0], "e1.y": [10.0, 1.0], "e2.x": [2.0, 20.0], "e2.y": [20.0, 2.0]})):
+        w = el.World()
+        w.spawn(Test(np.array(1.0), np.array(10.0)), "e1")
+        w.spawn(Test(np.array(2.0), np.array(20.0)), "e2")
+        w.spawn(Test(np.array(3.0), np.array(30.0)), "e3")
+        exec = w.build(system)
+        exec.run()
+        frame_equal(exec.history(list(expected)), expected)
+
+
+@pytest.mark.parametrize("values", [[(2.0, 3.0)], [(1.0, 5.0), (2.0, 10.0)], [(1.0, 2.0), (3.0, 4.0), (5.0, 6.0)]])
+def test_map_vs_map_seq_results_match(values):  # test_all.py:503-576, 629-678
+    @el.system
+    def compute_with_map(q: el.Query[X, Y]) -> el.Query[X, Y]:
+        return q.map((X, Y), lambda x, y: (x * y + 1.0, x * y))
+
+    @el.system
+    def compute_with_map_seq(q: el.Query[X, Y]) -> el.Query[X, Y]:
+        return q.map_seq((X, Y), lambda x, y: (x * y + 1.0, x * y))
+
+    frames = []
+    for system in (compute_with_map, compute_with_map_seq):
+        w = el.World()
+        names = []
+        for k, (x, y) in enumerate(values):
+            w.spawn(Test(np.array(x), np.array(y)), f"e{k + 1}")
+            names += [f"e{k + 1}.x", f"e{k + 1}.y"]
+        exec = w.build(system)
+        exec.run()
+        frames.append(exec.history(names))
+    for k in frames[0]:
+        assert np.array_equal(frames[0][k], frames[1][k])
+    for k, (x, y) in enumerate(values):
+        assert frames[0][f"e{k + 1}.x"].tolist() == [x, x * y + 1.0] and frames[0][f"e{k + 1}.y"].tolist() == [y, x * y]
+
+
+def test_query_of_a_component_no_entity_has():  # test_all.py:579-626: the reference panics at build; this raises
+    Z = ty.Annotated[el.Array, el.Component("z_unused", el.ComponentType.F64)]
+
+    @el.system
+    def compute_with_map(q: el.Query[Z]) -> el.Query[Z]:
+        return q.map(Z, lambda z: z * 2.0)
+
+    @el.system
+    def compute_with_map_seq(q: el.Query[Z]) -> el.Query[Z]:
+        return q.map_seq(Z, lambda z: z * 2.0)
+
+    for system in (compute_with_map, compute_with_map_seq):
+        w = el.World()
+        w.spawn(OnlyX(np.array(1.0)), "e1")
+        with pytest.raises(KeyError):
+            w.build(system)
+
+
+@pytest.mark.parametrize("seq", [True, False])
+def test_cond_semantics(seq):  # test_all.py:681-772
+    BranchTaken = ty.Annotated[el.Array, el.Component("branch_taken", el.ComponentType.F64)]
+
+    @el.system
+    def cond_system(q: el.Query[X]) -> el.Query[X, BranchTaken]:
+        def conditional_compute(x):
+            def true_branch(_):
+                return x * 2.0
+
+            def false_branch(_):
+                return x * 10.0
+
+            result = el.lax.cond(x > 5.0, true_branch, false_branch, operand=None)
+            branch_taken = el.lax.cond(x > 5.0, lambda _: 1.0, lambda _: 0.0, operand=None)
+            return result, branch_taken
+
+        return (q.map_seq if seq else q.map)((X, BranchTaken), conditional_compute)
+
+    @dataclass
+    class WithBranch(el.Archetype):
+        x: X
+        branch_taken: BranchTaken
+
+    w = el.World()
+    w.spawn(WithBranch(np.array(3.0), np.array(0.0)), "e1")
+    w.spawn(WithBranch(np.array(10.0), np.array(0.0)), "e2")
+    exec = w.build(cond_system)
+    exec.run()
+    df = exec.history(["e1.x", "e2.x", "e1.branch_taken", "e2.branch_taken"])
+    assert np.isclose(df["e1.x"][-1], 30.0) and np.isclose(df["e2.x"][-1], 20.0)
+    assert np.isclose(df["e1.branch_taken"][-1], 0.0) and np.isclose(df["e2.branch_taken"][-1], 1.0)
+
+
+def test_map_seq_decorators():  # test_all.py:775-860
+    @el.map_seq
+    def double_x(x: X) -> X:
+        return x * 2
+
+    @el.map_seq
+    def conditional_double(x: X) -> X:
+        return el.lax.cond(x > 5.0, lambda _: x * 2.0, lambda _: x * 10.0, operand=None)
+
+    @el.map_seq
+    def compute_xy(x: X, y: Y) -> tuple[X, Y]:
+        return x + y, x * y
+
+    w = el.World()
+    w.spawn(OnlyX(np.array(5.0)), "e1")
+    w.spawn(OnlyX(np.array(7.0)), "e2")
+    exec = w.build(double_x)
+    exec.run()
+    exec.run()
+    frame_equal(exec.history(["e1.x", "e2.x"]), {"e1.x": [5.0, 10.0, 20.0], "e2.x": [7.0, 14.0, 28.0]})
+
+    w = el.World()
+    for k, v in enumerate((3.0, 10.0, 1.0)):
+        w.spawn(OnlyX(np.array(v)), f"e{k + 1}")
+    exec = w.build(conditional_double)
+    exec.run()
+    df = exec.history(["e1.x", "e2.x", "e3.x"])
+    assert [df[k][-1] for k in ("e1.x", "e2.x", "e3.x")] == [30.0, 20.0, 10.0]
+
+    w = el.World()
+    w.spawn(Test(np.array(2.0), np.array(3.0)), "e1")
+    w.spawn(Test(np.array(4.0), np.array(5.0)), "e2")
+    exec = w.build(compute_xy)
+    exec.run()
+    frame_equal(exec.history(["e1.x", "e1.y", "e2.x", "e2.y"]), {"e1.x": [2.0, 5.0], "e1.y": [3.0, 6.0], "e2.x": [4.0, 9.0], "e2.y": [5.0, 20.0]})
+
+
+def test_three_body_gravity_system():
+    """examples/three-body/main.py:40-78 verbatim in shape: a GravityEdge component, a GravityConstraint archetype, the
+    gravity system as an edge_fold — against the built-in Newton pair functor on the same world."""
+    import elodin_amd as builtin
+    G = 6.6743e-11
+    GravityEdge = el.Annotated[el.Edge, el.Component("gravity_edge", el.ComponentType.Edge)]
+
+    @el.dataclass
+    class GravityConstraint(el.Archetype):
+        a: GravityEdge
+
+        def __init__(self, a: el.EntityId, b: el.EntityId):
+            self.a = GravityEdge(a, b)
+
+    @el.system
+    def gravity(graph: el.GraphQuery[GravityEdge], query: el.Query[el.WorldPos, el.Inertia]) -> el.Query[el.Force]:
+        def gravity_fn(force, a_pos, a_inertia, b_pos, b_inertia):
+            r = a_pos.linear() - b_pos.linear()
+            m = a_inertia.mass()
+            M = b_inertia.mass()
+            norm = el.np.linalg.norm(r)
+            f = G * M * m * r / (norm * norm * norm)
+            return el.Force(linear=force.force() - f)
+
+        return graph.edge_fold(left_query=query, right_query=query, return_type=el.Force, init_value=el.Force(), fold_fn=gravity_fn)
+
+    def world(mod):
+        w = mod.World()
+        ids = []
+        for name, p, v in (("A", [0.8822391241, 0, 0], [0, 1.0042424155, 0]), ("B", [-0.6432718586, 0, 0], [0, -1.6491842814, 0]),
+                           ("C", [-0.2389672654, 0, 0], [0, 0.6449418659, 0])):
+            ids.append(w.spawn(mod.Body(world_pos=mod.SpatialTransform(linear=np.array(p)), world_vel=mod.SpatialMotion(linear=np.array(v)),
+                                        inertia=mod.SpatialInertia(1.0 / G)), name))
+        return w, ids
+
+    w, (a, b, c) = world(el)
+    for s, d in ((a, b), (a, c), (b, c), (b, a), (c, a), (c, b)):
+        w.spawn(GravityConstraint(s, d))
+    exec = w.build(el.six_dof(sys=gravity), simulation_rate=120.0)
+    exec.run(240)
+    w2, (a, b, c) = world(builtin)
+    for s, d in ((a, b), (a, c), (b, c), (b, a), (c, a), (c, b)):
+        w2.spawn(builtin.GravityEdge(s, d))
+    ref = w2.build(builtin.six_dof(sys=builtin.gravity_newton(G)), simulation_rate=120.0)
+    ref.run(240)
+    for col in ("world_pos", "world_vel", "force"):
+        assert np.allclose(exec.column_array(col), ref.column_array(col), rtol=1e-10, atol=1e-12), col
+    assert len(exec.history("A.world_pos")["time"]) == 241 and not np.allclose(exec.column_array("world_pos")[0, 4:], [0.8822391241, 0, 0])
+
+
+def test_effector_maps_inside_six_dof():
+    """examples/ball/sim.py:57-59,96-116 in the reference's own spelling: @el.map functions over el.Force piped into six_dof."""
+    Wind = ty.Annotated[el.Array, el.Component("wind", el.ComponentType(el.PrimitiveType.F64, (3,)))]
+
+    @el.map
+    def gravity(f: el.Force, inertia: el.Inertia) -> el.Force:
+        return f + el.SpatialForce(linear=inertia.mass() * el.np.array([0.0, 0.0, -9.81]))
+
+    @el.map
+    def apply_drag(w: Wind, v: el.WorldVel, f: el.Force) -> el.Force:
+        fluid_vel = w - v.linear()
+        speed = el.np.linalg.norm(fluid_vel)
+        return f + el.SpatialForce(linear=0.5 * 1.225 * 0.5 * 0.25 * speed * fluid_vel)
+
+    @dataclass
+    class Windy(el.Archetype):
+        wind: Wind
+
+    import elodin_amd as builtin
+    w = el.World()
+    w.spawn([el.Body(world_pos=el.SpatialTransform(linear=np.array([0.0, 0.0, 6.0])), world_vel=el.SpatialMotion(linear=np.array([1.0, 0.0, 0.0]))),
+             Windy(np.array([0.5, -1.0, 0.0]))], "ball")
+    exec = w.build(el.six_dof(sys=gravity | apply_drag))
+    exec.run(60)
+    w2 = builtin.World()
+    w2.spawn([builtin.Body(world_pos=builtin.SpatialTransform(linear=[0.0, 0.0, 6.0]), world_vel=builtin.SpatialMotion(linear=[1.0, 0.0, 0.0])),
+              builtin.C("wind", [0.5, -1.0, 0.0])], "ball")
+    ref = w2.build(builtin.six_dof(sys=builtin.uniform_gravity() | builtin.ball_drag("wind", cd=0.5, rho=1.225, area=0.25)))
+    ref.run(60)
+    assert np.allclose(exec.column_array("world_pos"), ref.column_array("world_pos"), rtol=1e-12)
+    assert np.allclose(exec.history("ball.world_vel")["ball.world_vel"][-1], ref.column_array("world_vel")[0], rtol=1e-12)
