@@ -654,18 +654,74 @@ def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_
     return _compile(generate_source(tp, dtype, integrator, fast_math), "pipe")
 
 
+# Generated programs are one long straight-line tick body inside the kernel's tick loop.  Left alone, LLVM's MachineLICM
+# hoists every constant materialisation (hundreds of 64-bit literals: polynomial coefficients of the inlined libm
+# routines, the program's own constants) out of that loop; the kernel then wants far more than the 512 registers a
+# single-wave workgroup can have and spills VGPRs to scratch.  Besides the cost, a spilling build of a fuzz-generated
+# program computed wrong values on gfx950 (tests/test_gpu_fuzz.py, seed 2: low halves of spilled coefficients came back
+# as garbage whenever a cadenced system's block was skipped; the same source is exact at -O1 and with the flags below), so
+# register pressure is treated as a correctness matter: MachineLICM is off, and if VGPR spills remain a second build
+# that also sinks instructions back into the loop is tried; the build with fewer spills wins and what was chosen is
+# recorded next to the object (<name>.json) and in `last_resources`.
+_BASE_FLAGS = ["-mllvm", "-disable-machine-licm"]
+_RETRY_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills"]
+_CACHE_TAG = "rp1"           # bump when the flag policy changes: cached objects are keyed on it
+last_resources: Dict[str, int] = {}
+
+
+def _resources(stderr: str) -> Dict[str, int]:
+    """Worst case over the kernels of one translation unit, from -Rpass-analysis=kernel-resource-usage."""
+    out = {"vgprs": 0, "agprs": 0, "scratch_bytes_per_lane": 0, "sgpr_spills": 0, "vgpr_spills": 0}
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
+            "SGPRs Spill": "sgpr_spills", "VGPRs Spill": "vgpr_spills"}
+    for line in stderr.splitlines():
+        if "remark:" not in line:
+            continue
+        body = line.split("remark:", 1)[1].split("[-Rpass", 1)[0].strip()
+        name, _, val = body.rpartition(":")
+        if name.strip() in keys and val.strip().isdigit():
+            k = keys[name.strip()]
+            out[k] = max(out[k], int(val))
+    return out
+
+
 def _compile(src: str, stem: str) -> Path:
-    digest = hashlib.sha1((src + _headers_digest()).encode()).hexdigest()[:16]
+    import json
+    extra = os.environ.get("SIXDOF_JIT_FLAGS", "").split()       # debugging aid, e.g. "-O1" or "-ffp-contract=off"
+    digest = hashlib.sha1((src + _headers_digest() + " ".join(extra) + _CACHE_TAG).encode()).hexdigest()[:16]
     JIT_DIR.mkdir(exist_ok=True)
     so = JIT_DIR / f"{stem}_{digest}.so"
+    meta = JIT_DIR / f"{stem}_{digest}.json"
+    global last_resources
     if so.exists():
+        last_resources = json.loads(meta.read_text()) if meta.exists() else {}
         return so
     hip = JIT_DIR / f"{stem}_{digest}.hip"
     hip.write_text(src)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           f"-I{CSRC}", str(hip), "-o", str(so) + ".tmp"]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed for generated code {hip}:\n{res.stderr[-4000:]}")
-    os.replace(str(so) + ".tmp", so)
+
+    def run(flags, out):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+               "-Rpass-analysis=kernel-resource-usage", *flags, *extra, f"-I{CSRC}", str(hip), "-o", out]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed for generated code {hip}:\n{res.stderr[-4000:]}")
+        return _resources(res.stderr)
+    tmp = str(so) + ".tmp"
+    used = run(_BASE_FLAGS, tmp)
+    used["flags"] = " ".join(_BASE_FLAGS)
+    if used["vgpr_spills"] > 0:
+        alt = run(_BASE_FLAGS + _RETRY_FLAGS, tmp + "2")
+        if alt["vgpr_spills"] < used["vgpr_spills"]:
+            os.replace(tmp + "2", tmp)
+            used = dict(alt, flags=" ".join(_BASE_FLAGS + _RETRY_FLAGS))
+        else:
+            os.unlink(tmp + "2")
+    if used["vgpr_spills"] > 0:
+        import warnings
+        warnings.warn(f"generated kernel {so.name} spills {used['vgpr_spills']} VGPRs to scratch "
+                      f"({used['scratch_bytes_per_lane']} B/lane): the program holds more state than a wave's 512 registers; "
+                      "consider splitting it or narrowing its columns", RuntimeWarning, stacklevel=3)
+    meta.write_text(json.dumps(used))
+    os.replace(tmp, so)
+    last_resources = used
     return so

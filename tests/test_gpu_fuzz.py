@@ -1,0 +1,177 @@
+"""Randomly generated programs through the tracer + code generator + hipcc + the fused step kernel, against the numpy
+interpreter evaluating the SAME traced DAG (tests/dsl_numpy.py).  The generator is seeded, so the set of programs is
+fixed; it mixes every scalar op family the front-end offers, vector helpers, selects, cadenced systems and writes that
+invalidate shared sub-expressions — the combinations a hand-written test would not think of."""
+import numpy as np
+import pytest
+
+import elodin_amd as el
+from elodin_amd import _lib as L
+from elodin_amd import dsl, workloads
+from tests import dsl_numpy
+
+pytestmark = pytest.mark.gpu
+np_ = dsl.np
+
+
+class Gen:
+    """Random expressions whose values stay O(1) (every partial function is fed through a guard), so the comparison
+    measures the generated code and not the conditioning of the expression."""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+
+    def pick(self, xs):
+        return xs[int(self.rng.integers(len(xs)))]
+
+    def const(self):
+        return float(np.round(self.rng.uniform(-2.0, 2.0), 3))
+
+    def scalar(self, leaves, depth):
+        r = self.rng
+        if depth == 0 or r.random() < 0.12:
+            return self.pick(leaves) if r.random() < 0.8 else dsl.const(self.const())
+        s = lambda: self.scalar(leaves, depth - 1)
+        kind = self.pick(["bin", "bin", "un", "un", "sel", "vec", "pow", "cmpmix", "lax"])
+        if kind == "bin":
+            a, b = s(), s()
+            return self.pick([lambda: a + b, lambda: a - b, lambda: a * b, lambda: a / (np_.abs(b) + 0.5),
+                              lambda: np_.maximum(a, b), lambda: np_.minimum(a, b), lambda: np_.hypot(a, b),
+                              lambda: np_.arctan2(a, b + 2.5 * np_.sign(b) + 0.1), lambda: a * self.const() + b,
+                              lambda: np_.remainder(a, np_.abs(b) + 0.7)])()
+        if kind == "un":
+            a = s()
+            return self.pick([lambda: np_.sin(a), lambda: np_.cos(a), lambda: np_.tanh(a), lambda: np_.sqrt(np_.abs(a) + 0.1),
+                              lambda: np_.exp(np_.clip(a, -3.0, 2.0)), lambda: np_.log(np_.abs(a) + 0.5), lambda: np_.abs(a) - 0.3,
+                              lambda: np_.arccos(np_.clip(a, -0.95, 0.95)), lambda: np_.arcsin(np_.clip(a * 0.5, -0.95, 0.95)),
+                              lambda: np_.arctan(a), lambda: np_.tan(np_.clip(a, -1.2, 1.2)), lambda: np_.log1p(np_.abs(a)),
+                              lambda: np_.expm1(np_.clip(a, -2.0, 1.0)), lambda: np_.cbrt(np_.abs(a) + 0.2), lambda: np_.sinh(np_.clip(a, -2.0, 2.0)),
+                              lambda: np_.cosh(np_.clip(a, -2.0, 2.0)), lambda: np_.erfc(a), lambda: -a, lambda: np_.sign(a) * 0.5 + a,
+                              lambda: np_.clip(a, -0.7, 0.9), lambda: a ** 2, lambda: a ** 3])()
+        if kind == "sel":
+            c = self.cond(leaves, depth - 1)
+            return np_.where(c, s(), s())
+        if kind == "lax":
+            c, a, b = self.cond(leaves, depth - 1), s(), s()
+            return self.pick([lambda: dsl.lax.cond(c, lambda _: a * 2.0, lambda _: b - 1.0, operand=None),
+                              lambda: dsl.lax.select(c, a, b),
+                              lambda: dsl.lax.switch(np_.floor(np_.clip(a, 0.0, 2.9)), [lambda: a, lambda: b, lambda: a * b]),
+                              lambda: dsl.lax.fori_loop(0, 3, lambda i, v: v * 0.5 + np_.sin(v + float(i)), a)])()
+        if kind == "pow":
+            return np_.power(np_.abs(s()) + 0.5, self.pick([-2.0, -1.5, -0.5, 0.5, 1.5, 2.0, 3.0, self.const()]))
+        if kind == "cmpmix":       # staircase functions of an exactly representable argument
+            leaf = self.pick(leaves)
+            return self.pick([np_.floor, np_.ceil, np_.trunc, np_.rint])(leaf * 4.0) * 0.25 + s()
+        u, v = self.vec3(leaves, depth - 1), self.vec3(leaves, depth - 1)
+        return self.pick([lambda: np_.dot(u, v), lambda: np_.linalg.norm(u), lambda: np_.cross(u, v)[int(self.rng.integers(3))],
+                          lambda: np_.sum(u * v + u), lambda: np_.max(u) - np_.min(v), lambda: np_.sort(u)[1],
+                          lambda: np_.interp(np_.clip(u[0], -1.0, 1.0), [-1.0, -0.2, 0.3, 1.0], [0.5, -1.0, 2.0, 0.25])])()
+
+    def vec3(self, leaves, depth):
+        return dsl.Vec([self.scalar(leaves, depth) for _ in range(3)])
+
+    def cond(self, leaves, depth):
+        a, b = self.scalar(leaves, depth), self.scalar(leaves, depth)
+        c = self.pick([lambda: a > b, lambda: a < b + 0.25, lambda: a >= -b])()
+        if self.rng.random() < 0.3:
+            d = self.scalar(leaves, depth) > 0.1
+            c = self.pick([np_.logical_and, np_.logical_or])(c, d) if self.rng.random() < 0.7 else np_.logical_not(c)
+        return c
+
+
+def make_program(seed, depth=4):
+    g = Gen(seed)
+
+    @dsl.system(x=8, y=8, a=16)
+    def sys_a(x, y, a):
+        leaves = list(x.e) + list(y.e)
+        return {"a": dsl.Vec([g.scalar(leaves, depth) for _ in range(16)])}
+
+    @dsl.system(x=8, a=16, b=16)
+    def sys_b(x, a, b, tick):
+        leaves = list(x.e) + list(a.e) + [np_.sin(tick * 0.37)]
+        out = dsl.Vec([g.scalar(leaves, depth) for _ in range(16)])
+        return {"b": out, "x": x * 0.5 + dsl.Vec([np_.tanh(e) for e in out.e[:8]])}     # x rewritten: later reads must see it
+
+    @dsl.system(every=2, x=8, a=16, b=16, c=8)
+    def sys_c(x, a, b, c):
+        leaves = list(x.e) + list(a.e[:4]) + list(b.e[:4]) + list(c.e[:2])
+        return {"c": dsl.Vec([g.scalar(leaves, depth - 1) for _ in range(8)])}
+    return dsl.Program([sys_a, sys_b], dsl.Pipe([]), [sys_c])
+
+
+def columns(seed, n):
+    rng = np.random.default_rng(1000 + seed)
+    quant = lambda a: np.round(a * 64.0) / 64.0           # exactly representable in f32 too
+    return {"x": quant(rng.uniform(-1.5, 1.5, (n, 8))), "y": quant(rng.uniform(-1.5, 1.5, (n, 8))),
+            "a": np.zeros((n, 16)), "b": np.zeros((n, 16)), "c": np.zeros((n, 8))}
+
+
+def run_both(prog, cols, ticks, dtype):
+    n = len(cols["x"])
+    w = workloads.independent_bodies(n)
+    hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=dtype, integrator=L.INTEGRATOR_NONE, effectors=prog,
+                     columns={k: v.copy() for k, v in cols.items()})
+    hip.run(ticks)
+    tp = prog.trace({k: v.shape[1] for k, v in cols.items()})
+    pos, vel, inertia = (np.array(w[k], dtype=np.float64) for k in ("world_pos", "world_vel", "inertia"))
+    want = {k: v.copy() for k, v in cols.items()}
+    for t in range(1, ticks + 1):
+        dsl_numpy._run_systems(tp.pre, pos, vel, inertia, want, tp.table, t)
+        dsl_numpy._run_systems(tp.post, pos, vel, inertia, want, tp.table, t)
+    return {k: np.asarray(hip._aux[k], dtype=np.float64) for k in cols}, want
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_programs_f64(seed):
+    prog, cols = make_program(seed), columns(seed, 2048)
+    got, want = run_both(prog, cols, 2, np.float64)
+    for k in ("a", "b", "c", "x"):
+        assert np.isfinite(want[k]).all(), k
+        err = np.abs(got[k] - want[k]) / np.maximum(np.abs(want[k]), 1.0)
+        # a select whose two sides differ may flip where its comparison sits on a rounding boundary (FMA contraction,
+        # 1-ulp libm differences): allow a handful of such lanes, none of them may be an outright blow-up of the others
+        assert (err < 1e-10).mean() > 0.9995, (seed, k, float(err.max()), float((err >= 1e-10).mean()))
+        assert np.median(err) < 1e-14, (seed, k)
+    assert np.abs(want["c"]).max() > 0.0 and not np.array_equal(want["x"], cols["x"])
+
+
+def test_random_program_f32():
+    prog, cols = make_program(101, depth=3), columns(101, 2048)
+    got, want = run_both(prog, cols, 1, np.float32)
+    for k in ("a", "b", "x"):
+        err = np.abs(got[k] - want[k]) / np.maximum(np.abs(want[k]), 1.0)
+        assert (err < 2e-3).mean() > 0.995 and np.median(err) < 5e-6, (k, float(err.max()), float(np.median(err)))
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_effector_pipes_through_the_integrator(seed):
+    """Random wrenches (world torque, body-frame torque, force) out of pose / velocity / inertia / a component column,
+    integrated semi-implicitly for a few ticks: state vs tests/dsl_numpy.program_tick on the same trace."""
+    g = Gen(500 + seed)
+
+    @dsl.effector(k=3)
+    def first(force, pos, vel, inertia, k):
+        leaves = list(pos.linear().e) + list(vel.linear().e) + list(vel.angular().e) + list(k.e) + [inertia.mass()]
+        return force + dsl.SpatialForce(linear=dsl.Vec([g.scalar(leaves, 3) for _ in range(3)]),
+                                        torque=dsl.Vec([g.scalar(leaves, 2) * 0.1 for _ in range(3)]))
+
+    @dsl.effector(k=3)
+    def second(force, pos, k):
+        leaves = list(k.e) + list(force.force().e)
+        return force + dsl.SpatialForce(torque=pos.angular() @ dsl.Vec([g.scalar(leaves, 2) * 0.05 for _ in range(3)]))
+    n, dt = 1024, 1.0 / 120.0
+    w = workloads.independent_bodies(n, seed=seed)
+    kcol = np.random.default_rng(seed).uniform(-1.0, 1.0, (n, 3))
+    prog = dsl.Program([], first | second, [])
+    hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=dt, integrator=L.SEMI_IMPLICIT,
+                     effectors=prog, columns={"k": kcol})
+    hip.run(5)
+    tp = prog.trace({"k": 3})
+    pos, vel, inertia = (np.array(w[k], dtype=np.float64) for k in ("world_pos", "world_vel", "inertia"))
+    acc, comps = np.zeros((n, 6)), {"k": kcol.copy()}
+    for t in range(1, 6):
+        dsl_numpy.program_tick(tp, pos, vel, acc, inertia, comps, t, dt, L.SEMI_IMPLICIT)
+    for name, got, want in (("world_pos", hip.world_pos, pos), ("world_vel", hip.world_vel, vel), ("world_accel", hip.world_accel, acc)):
+        err = np.abs(got - want) / np.maximum(np.abs(want), 1.0)
+        assert (err < 1e-9).mean() > 0.999 and np.median(err) < 1e-14, (seed, name, float(err.max()))
