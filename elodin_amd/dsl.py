@@ -313,8 +313,9 @@ class _Np:
     def sign(x): return _Np.where(x > 0.0, 1.0, _Np.where(x < 0.0, -1.0, 0.0))
     @staticmethod
     def tanh(x):
-        e = _Np.exp(x * -2.0)
-        return (1.0 - e) / (1.0 + e)
+        em = _Np.expm1(_Np.abs(x) * -2.0)        # in (-1, 0]: saturates to +-1 for large |x|, keeps the relative accuracy near 0
+        r = -em / (em + 2.0)
+        return _Np.where(x < 0.0, -r, r)
     @staticmethod
     def deg2rad(x): return x * (math.pi / 180.0)
     @staticmethod

@@ -175,3 +175,58 @@ def test_random_effector_pipes_through_the_integrator(seed):
     for name, got, want in (("world_pos", hip.world_pos, pos), ("world_vel", hip.world_vel, vel), ("world_accel", hip.world_accel, acc)):
         err = np.abs(got - want) / np.maximum(np.abs(want), 1.0)
         assert (err < 1e-9).mean() > 0.999 and np.median(err) < 1e-14, (seed, name, float(err.max()))
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_edge_folds(seed):
+    """Random pair functions (force and world torque out of both endpoints' positions and masses, plus a smooth
+    feedback of the accumulator) as the PAIR functor of the generated pair kernels, over a sparse random graph in both launch shapes, one
+    RK4 tick: Force against tests/dsl_numpy.fold_force walking the same DAG edge by edge in spawn order."""
+    from tests import np_sixdof
+    g = Gen(900 + seed)
+
+    @dsl.edge_fold(edge_component="fuzz")
+    def fold(acc, a_pos, a_inertia, b_pos, b_inertia):
+        r = b_pos.linear() - a_pos.linear()
+        # the accumulator feeds back smoothly only: a staircase or remainder of a value that is itself folded over ~8
+        # edges amplifies rounding differences into different branches, which says nothing about the generated code
+        # (and the generator's inputs are squashed to O(1): separations and masses of the workload are not)
+        # with x / (1 + |x|), which unlike tanh does not round to exactly 1 for the workload's heavier bodies
+        squash = lambda v: v / (1.0 + np_.abs(v))
+        leaves = [squash(e * 0.3) for e in r.e] + [squash(a_inertia.mass() * 0.1), squash(b_inertia.mass() * 0.1)]
+        return acc + dsl.SpatialForce(linear=dsl.Vec([g.scalar(leaves, 3) * 0.2 + 0.05 * np_.tanh(acc.force()[k]) for k in range(3)]),
+                                      torque=dsl.Vec([g.scalar(leaves[:3] + leaves[4:], 2) * 0.05 for _ in range(3)]))
+    tf = fold.trace()
+    for n in (150, 2000):
+        w = workloads.independent_bodies(n, seed=seed)
+        rng = np.random.default_rng(50 + seed)
+        m = 4 * n
+        src = rng.integers(0, n, size=m)
+        dst = (src + 1 + rng.integers(0, n - 1, size=m)) % n
+        ids = np.arange(1, n + 1, dtype=np.uint64)
+        hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=L.RK4, simulation_time_step=1 / 240.0,
+                         effectors=[fold], edges=(ids[src], ids[dst]))
+        hip.run(1)
+        pos, vel, acc, F = np_sixdof.tick(w["world_pos"].copy(), w["world_vel"].copy(), np.zeros((n, 6)), w["inertia"],
+                                          lambda xs, vs: dsl_numpy.fold_force(tf, xs, w["inertia"], src, dst, np.zeros((n, 6))),
+                                          1 / 240.0, integrator=L.RK4)
+        for name, got, want in (("force", hip.force, F), ("world_vel", hip.world_vel, vel), ("world_pos", hip.world_pos, pos)):
+            err = np.abs(got - want) / np.maximum(np.abs(want), 1.0)
+            # a staircase sitting on a rounding boundary may flip for an isolated row
+            assert (err >= 1e-9).sum() <= max(3, err.size // 1000) and np.median(err) < 1e-13, (seed, n, name, float(err.max()))
+
+
+def test_random_program_f32_fast_math():
+    """The opt-in hardware-transcendental mode on a random program: same structure, the tolerance of v_sin / v_exp / v_log
+    / v_rcp (1e-6-ish absolute on O(1) values, amplified by the expression depth)."""
+    prog, cols = make_program(202, depth=3), columns(202, 2048)
+    n = len(cols["x"])
+    w = workloads.independent_bodies(n)
+    hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=np.float32, integrator=L.INTEGRATOR_NONE, effectors=prog,
+                     columns={k: v.copy() for k, v in cols.items()}, fast_math=True)
+    hip.run(1)
+    _, want = run_both(prog, cols, 1, np.float32)
+    for k in ("a", "b", "x"):
+        got = np.asarray(hip._aux[k], dtype=np.float64)
+        err = np.abs(got - want[k]) / np.maximum(np.abs(want[k]), 1.0)
+        assert (err < 5e-3).mean() > 0.99 and np.median(err) < 2e-5, (k, float(err.max()), float(np.median(err)))
