@@ -302,6 +302,49 @@ class _Np:
         return Vec(out)
     @staticmethod
     def ones(n, dtype=None): return Vec([1.0] * int(n))
+    # ---- the remaining array-construction / cast / reduction calls the reference's scripts make on this path ----------
+    @staticmethod
+    def asarray(x, dtype=None):
+        """jnp.asarray: sequences become vectors, traced values and scalars pass through."""
+        if isinstance(x, (Vec, Expr)) or not hasattr(x, "__len__"):
+            return x if isinstance(x, (Vec, Expr)) else _lift(x)
+        return Vec(list(x))
+    @staticmethod
+    def float64(x): return x if isinstance(x, (Vec, Expr)) else _lift(x)      # columns already compute in the executor's dtype
+    float32 = float64
+    @staticmethod
+    def int32(x): return _Np.trunc(x if isinstance(x, (Vec, Expr)) else _lift(x))   # astype(int): toward zero, kept as a float
+    int64 = int32
+    @staticmethod
+    def stack(parts, axis=0):
+        """jnp.stack of scalars -> a vector; of vectors -> a matrix as a list of rows (usable with matvec / outer results)."""
+        parts = list(parts)
+        return list(parts) if parts and isinstance(parts[0], Vec) else Vec(parts)
+    @staticmethod
+    def zeros_like(x): return Vec([0.0] * len(x)) if isinstance(x, Vec) else const(0.0)
+    @staticmethod
+    def ones_like(x): return Vec([1.0] * len(x)) if isinstance(x, Vec) else const(1.0)
+    @staticmethod
+    def full(n, value, dtype=None): return Vec([value] * int(n[0] if hasattr(n, "__len__") else n))
+    @staticmethod
+    def reciprocal(x): return 1.0 / x
+    @staticmethod
+    def square(x): return x * x
+    @staticmethod
+    def negative(x): return -x
+    @staticmethod
+    def mean(v: Vec): return _Np.sum(v) / float(len(v))
+    @staticmethod
+    def degrees(x): return _Np.rad2deg(x)
+    @staticmethod
+    def radians(x): return _Np.deg2rad(x)
+    @staticmethod
+    def searchsorted(a, v, side="left"):
+        """jnp.searchsorted over a CONSTANT sorted table: the count of entries below (side='left') / not above (side='right') v."""
+        v = _lift(v)
+        table = [float(t) for t in a]
+        hits = [(_Np.where(v > t, 1.0, 0.0) if side == "left" else _Np.where(v >= t, 1.0, 0.0)) for t in table]
+        return _Np.sum(Vec(hits)) if hits else const(0.0)
     @staticmethod
     def interp(x, xp, fp):
         """jnp.interp(x, xp, fp) with CONSTANT tables (atmosphere / thrust-curve lookups, e.g. examples/rocket/main.py:356-375)."""
@@ -324,6 +367,14 @@ class _Np:
     class linalg:
         @staticmethod
         def norm(v: Vec): return _Np.sqrt(_Np.sum(v * v))   # jnp.linalg.norm, ord=None
+        @staticmethod
+        def det(rows):
+            """Determinant of a 2x2 / 3x3 matrix given as a list of rows (np.stack of vectors, np.outer)."""
+            if len(rows) == 2:
+                return rows[0][0] * rows[1][1] - rows[0][1] * rows[1][0]
+            if len(rows) != 3:
+                raise ValueError("linalg.det: 2x2 or 3x3 only")
+            return _Np.dot(rows[0], _Np.cross(rows[1], rows[2]))
 
 
 def _zipv(a, b, f):

@@ -162,8 +162,12 @@ def _traced_inertia(mass, inertia=None):     # spatial.rs:392-405: inertia defau
     return _dsl.SpatialInertia(_lift(inertia) if inertia is not None else _dsl.Vec([mass, mass, mass]), mass)
 
 
+def _q_from_array(arr):
+    return _dsl.Quaternion(_lift(arr)) if _symbolic(arr) else _api.Quaternion(arr)
+
+
 Quaternion = _dual("Quaternion", _api.Quaternion, _dsl.Quaternion, identity=_api.Quaternion.identity,
-                   from_axis_angle=_q_from_axis_angle)
+                   from_axis_angle=_q_from_axis_angle, from_array=_q_from_array)
 SpatialTransform = _dual("SpatialTransform", _api.SpatialTransform, _dsl.SpatialTransform)
 SpatialMotion = _dual("SpatialMotion", _api.SpatialMotion, _dsl.SpatialMotion)
 SpatialForce = _dual("SpatialForce", _api.SpatialForce, _dsl.SpatialForce)
@@ -467,6 +471,9 @@ def six_dof(time_step: Optional[float] = None, sys=None, integrator: Integrator 
     return _api.six_dof(time_step, sys, integrator)
 
 
+System = (_dsl.System, _dsl.Stages, _dsl.Effector, _dsl.Pipe, _dsl.EdgeFold, _dsl.GraphFold, _api.System)   # `-> el.System` annotations / isinstance
+
+
 # ---- world --------------------------------------------------------------------------------------------------------------
 
 class World(_api.World):
@@ -490,3 +497,6 @@ class World(_api.World):
         if history:
             _api.record_history(ex, self)
         return ex
+
+
+WorldBuilder = World

@@ -309,3 +309,27 @@ def test_stablehlo_coverage_example_matches_the_reference_baseline_rows():
         x = r * 0.01
         dsl_numpy._run_systems([t_math], pos, vel, inertia, comps, tm, tick)
         assert np.allclose(comps["math_state"][0], x, rtol=1e-14)
+
+
+def test_construction_cast_and_reduction_helpers_match_numpy():
+    """jnp calls the reference's scripts make besides arithmetic: asarray / stack / full / *_like, float and int casts,
+    reciprocal / square / mean / degrees, searchsorted over a constant table, linalg.det."""
+    from tests import dsl_numpy
+    rng = np.random.default_rng(8)
+    for _ in range(20):
+        v, u, w = rng.normal(size=3), rng.normal(size=3), rng.normal(size=3)
+        s = float(rng.normal() * 3.0)
+        table = [-2.0, -0.5, 0.0, 0.75, 2.5]
+        got = dsl_numpy.trace_eval(lambda np_, v, u, w, s: (
+            np_.asarray([s, 1.0, v[0]]), np_.stack([v[0], u[1], s]), np_.full(3, s) + np_.zeros_like(v) + np_.ones_like(v),
+            np_.float64(s) + np_.int32(s * 2.0) + np_.int64(-s), np_.reciprocal(v[0]) + np_.square(u[1]) + np_.negative(s),
+            np_.mean(v) + np_.degrees(s) - np_.radians(s), np_.searchsorted(table, s), np_.searchsorted(table, s, side="right"),
+            np_.linalg.det(np_.stack([v, u, w])), np_.linalg.det([v[:2], u[:2]]), np_.matvec(np_.stack([v, u, w]), w)), v, u, w, s)
+        want = (np.array([s, 1.0, v[0]]), np.array([v[0], u[1], s]), np.full(3, s) + 1.0, s + np.trunc(s * 2.0) + np.trunc(-s),
+                1.0 / v[0] + u[1] ** 2 - s, v.mean() + np.degrees(s) - np.radians(s), float(np.searchsorted(table, s)),
+                float(np.searchsorted(table, s, side="right")), np.linalg.det(np.stack([v, u, w])), np.linalg.det(np.stack([v[:2], u[:2]])),
+                np.stack([v, u, w]) @ w)
+        for g, e in zip(got, want):
+            assert np.allclose(g, e, rtol=1e-13, atol=1e-13), (g, e)
+    assert dsl_numpy.trace_eval(lambda np_, s: np_.searchsorted([0.0, 1.0], s), 1.0) == 1.0      # ties: left
+    assert dsl_numpy.trace_eval(lambda np_, s: np_.searchsorted([0.0, 1.0], s, side="right"), 1.0) == 2.0
