@@ -438,3 +438,54 @@ def test_effector_maps_inside_six_dof():
     ref.run(60)
     assert np.allclose(exec.column_array("world_pos"), ref.column_array("world_pos"), rtol=1e-12)
     assert np.allclose(exec.history("ball.world_vel")["ball.world_vel"][-1], ref.column_array("world_vel")[0], rtol=1e-12)
+
+
+def test_n_body_gravity_system():
+    """examples/n-body/sim.py:344-369 in the reference's spelling (softened gravity as an edge_fold over a complete set of
+    GravityEdge entities, typed fold arguments, `acc + el.SpatialForce(...)`) against the built-in softened pair functor."""
+    import elodin_amd as builtin
+    K_SQUARED, SOFTENING_AU2 = 2.9591220828559115e-04, 1.0e-8
+    GravityEdge = el.Annotated[el.Edge, el.Component("gravity_edge", el.ComponentType.Edge)]
+
+    @el.dataclass
+    class GravityConstraint(el.Archetype):
+        a: GravityEdge
+
+        def __init__(self, a: el.EntityId, b: el.EntityId):
+            self.a = GravityEdge(a, b)
+
+    @el.system
+    def gravity(graph: el.GraphQuery[GravityEdge], q: el.Query[el.WorldPos, el.Inertia]) -> el.Query[el.Force]:
+        def gravity_fn(acc: el.Force, a_pos: el.WorldPos, a_inertia: el.Inertia, b_pos: el.WorldPos, b_inertia: el.Inertia) -> el.Force:
+            r = b_pos.linear() - a_pos.linear()
+            dist_sq = el.np.dot(r, r) + SOFTENING_AU2
+            inv_dist = el.np.reciprocal(el.np.sqrt(dist_sq))
+            inv_dist3 = inv_dist * inv_dist * inv_dist
+            scalar = K_SQUARED * a_inertia.mass() * b_inertia.mass() * inv_dist3
+            return acc + el.SpatialForce(linear=scalar * r)
+
+        return graph.edge_fold(left_query=q, right_query=q, return_type=el.Force, init_value=el.SpatialForce(), fold_fn=gravity_fn)
+
+    rng = np.random.default_rng(12)
+    n = 24
+    P, V, M = rng.normal(size=(n, 3)) * 3.0, rng.normal(size=(n, 3)) * 0.01, rng.uniform(1e-6, 1.0, size=n)
+
+    def world(mod, edge):
+        w = mod.World()
+        ids = [w.spawn(mod.Body(world_pos=mod.SpatialTransform(linear=P[k]), world_vel=mod.SpatialMotion(linear=V[k]),
+                                inertia=mod.SpatialInertia(M[k])), f"b{k}") for k in range(n)]
+        for i in range(n):
+            for j in range(n):
+                if i != j:
+                    w.spawn(edge(ids[i], ids[j]))
+        return w
+
+    exec = world(el, GravityConstraint).build(el.six_dof(sys=gravity, integrator=el.Integrator.Rk4), simulation_rate=60.0, history=False)
+    ref = world(builtin, builtin.GravityEdge).build(builtin.six_dof(sys=builtin.gravity_softened(K_SQUARED, SOFTENING_AU2)), simulation_rate=60.0)
+    exec.run(50)
+    ref.run(50)
+    for col in ("world_pos", "world_vel", "force"):
+        err = np.abs(exec.column_array(col) - ref.column_array(col)) / np.maximum(np.abs(ref.column_array(col)), 1e-30)
+        assert np.nanmax(np.where(np.abs(ref.column_array(col)) > 1e-12, err, 0.0)) < 1e-9, col
+    with pytest.raises(RuntimeError):
+        exec.history("b0.world_pos")                    # built with history=False
