@@ -213,3 +213,59 @@ def test_every_tick_streamed_to_the_host_equals_single_tick_runs():
             assert np.array_equal(got[t][c], getattr(b, c)), (t, c)
     a.download()
     assert np.array_equal(a.world_pos, b.world_pos)
+
+
+def test_handle_lifecycles_return_their_device_and_pinned_memory():
+    """Every buffer a handle owns goes back at destroy: columns, telemetry rings (body + program columns), the async
+    snapshot, pair packs / partials / CSR tables, page-locked registrations.  Device-wide free memory (hipMemGetInfo)
+    after many create -> use -> destroy cycles of every flavour must be where it was after the first cycle."""
+    import ctypes as C
+    from elodin_amd import dsl
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    n = 200_000
+    w = workloads.independent_bodies(n)
+    eff = workloads.gravity_torque_effectors(w["body_torque"])
+
+    @dsl.system(temp=4)
+    def heat(temp, vel):
+        return {"temp": temp * 0.999 + dsl.np.linalg.norm(vel.linear()) * 0.001}
+    m = 2000
+    ids = np.arange(1, m + 1, dtype=np.uint64)
+
+    def cycle():
+        ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], effectors=eff, ticks_per_launch=8)
+        ex._lib.sixdof_set_history(ex._h, 16)
+        ex.run(16)
+        ex.history("world_pos", 9, 16)
+        ex.run_streaming(3, 8)
+        ex.stream_history(2, 8)
+        ex.close()
+        ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=np.float32, integrator=L.SEMI_IMPLICIT,
+                        effectors=dsl.Program([heat], dsl.Pipe([]), []), columns={"temp": np.ones((n, 4))})
+        ex._lib.sixdof_set_history(ex._h, 4)
+        ex.run(4)
+        ex.close()
+        ex = ea.HipExec(w["world_pos"][:m], w["world_vel"][:m], w["inertia"][:m],
+                        effectors=[ea.Effector(L.EFF_EDGE_GRAVITY_SOFTENED, (1e-3, 1e-2))], edges=(ids, np.roll(ids, 1)))
+        ex.run(2)
+        ex.close()
+        ex = ea.HipExec(w["world_pos"][:m], w["world_vel"][:m], w["inertia"][:m],
+                        effectors=[ea.Effector(L.EFF_ALLPAIRS_GRAVITY_SOFTENED, (1e-3, 1e-2))])
+        ex.run(2)
+        ex.close()
+
+    cycle()                              # first use pays one-off costs (code objects, scratch, runtime pools)
+    cycle()
+    base = free_bytes()
+    for _ in range(12):
+        cycle()
+    lost = base - free_bytes()
+    per_cycle = (n * (7 + 6 * 4 + 7) * 8) * 2          # what one cycle allocates at least: columns + a ring, twice
+    print(f"device memory after 12 more cycles: {lost / 2**20:+.1f} MiB (one cycle allocates > {per_cycle / 2**20:.0f} MiB)")
+    assert lost < 32 * 2**20
