@@ -230,3 +230,78 @@ def test_random_program_f32_fast_math():
         got = np.asarray(hip._aux[k], dtype=np.float64)
         err = np.abs(got - want[k]) / np.maximum(np.abs(want[k]), 1.0)
         assert (err < 5e-3).mean() > 0.99 and np.median(err) < 2e-5, (k, float(err.max()), float(np.median(err)))
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_random_configurations_of_the_handwritten_path_vs_the_oracle(seed):
+    """The library kernels under seeded random CONFIGURATIONS: body count (around the wave / tile boundaries), integrator,
+    ticks per launch not dividing the horizon, time-step override, a random pipe of built-in effectors with their aux
+    columns, optionally closed by a pair op over a random sparse graph / the complete graph, graph replay, the async
+    step flag and the telemetry ring — full state against the C oracle at the north-star tolerance."""
+    from oracle import oracle as orc
+    from tests import parity
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([1, 2, 7, 63, 64, 65, 130, 257, 1000, 4097, 20000]))
+    integrator = int(rng.choice([L.RK4, L.SEMI_IMPLICIT]))
+    k = int(rng.choice([1, 2, 3, 5, 16, 32]))
+    ticks = int(rng.integers(1, 41))
+    dt = float(rng.choice([1 / 120.0, 1 / 60.0, 0.01]))
+    time_step = None if rng.random() < 0.7 else dt * float(rng.choice([0.5, 2.0]))
+    w = workloads.independent_bodies(n, seed=100 + seed)
+    w["world_pos"][:, 4:] *= 0.01                                     # bring bodies within reach of each other for pair ops
+    ops = []
+    for kind in rng.permutation([L.EFF_UNIFORM_GRAVITY, L.EFF_CONST_WRENCH, L.EFF_BODY_TORQUE, L.EFF_BODY_FORCE, L.EFF_BALL_DRAG])[:int(rng.integers(0, 5))]:
+        if kind == L.EFF_UNIFORM_GRAVITY:
+            ops.append(el.Effector(kind, tuple(rng.normal(size=3) * 5.0)))
+        elif kind == L.EFF_CONST_WRENCH:
+            ops.append(el.Effector(kind, tuple(rng.normal(size=6))))
+        elif kind == L.EFF_BALL_DRAG:
+            ops.append(el.Effector(kind, (0.5, 1.2, 0.3), aux_name="wind", aux=rng.normal(size=(n, 3)) * 3.0))
+        else:
+            name = "tq" if kind == L.EFF_BODY_TORQUE else "thrust"
+            ops.append(el.Effector(kind, (), aux_name=name, aux=rng.normal(size=(n, 3))))
+    edges = oracle_edges = None
+    pair = rng.choice(["none", "newton", "softened", "allpairs"]) if n >= 2 else "none"
+    if pair == "allpairs" and n > 1100:
+        pair = "softened"
+    if pair in ("newton", "softened"):
+        m = int(min(6 * n, 20000))
+        src = rng.integers(0, n, size=m)
+        dst = (src + 1 + rng.integers(0, n - 1, size=m)) % n
+        ids = w["entity_ids"]
+        edges = (ids[src], ids[dst])
+        oracle_edges = orc.resolve_edges(ids, *edges)
+        ops.append(el.Effector(L.EFF_EDGE_GRAVITY_NEWTON, (1e-3,)) if pair == "newton"
+                   else el.Effector(L.EFF_EDGE_GRAVITY_SOFTENED, (1e-3, 1e-2)))
+    elif pair == "allpairs":
+        ops.append(el.Effector(L.EFF_ALLPAIRS_GRAVITY_SOFTENED, (1e-3, 1e-2)))
+        frm = np.repeat(w["entity_ids"], n - 1)
+        to = np.concatenate([np.delete(w["entity_ids"], i) for i in range(n)])
+        oracle_edges = orc.resolve_edges(w["entity_ids"], frm, to)
+    use_graph, async_step, ring = bool(rng.random() < 0.4), bool(rng.random() < 0.4), bool(rng.random() < 0.4)
+    label = dict(n=n, integrator=integrator, k=k, ticks=ticks, dt=dt, time_step=time_step, ops=[o.kind for o in ops], pair=str(pair),
+                 graph=use_graph, async_step=async_step, ring=ring)
+    hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], entity_ids=w["entity_ids"], simulation_time_step=dt, time_step=time_step,
+                     integrator=integrator, effectors=ops, edges=edges, ticks_per_launch=k, use_graph=use_graph)
+    if ring and pair == "none":
+        assert hip._lib.sixdof_set_history(hip._h, ticks) == L.OK
+    if async_step:
+        hip.set_flags(L.FLAG_ASYNC_STEP)
+    first = ticks // 2
+    hip.run(first)
+    hip.run(ticks - first)
+    oracle_ops = [(orc.EFF_EDGE_GRAVITY_SOFTENED, o.p, None) if o.kind == L.EFF_ALLPAIRS_GRAVITY_SOFTENED else (o.kind, tuple(o.p), o.aux) for o in ops]
+    ref = orc.OracleWorld(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=dt, time_step=time_step, integrator=integrator,
+                          ops=oracle_ops, edges=oracle_edges)
+    mid = None
+    if ring and pair == "none" and ticks >= 2:
+        ref.step(ticks - 1, threads=4)
+        mid = ref.world_pos.copy()
+        ref.step(1, threads=4)
+    else:
+        ref.step(ticks, threads=4)
+    errs = parity.state_errors(hip, ref)
+    assert max(errs.values()) < parity.F64_RTOL and hip.tick == ref.tick == ticks, (label, errs)
+    if mid is not None:
+        got = hip.history("world_pos", ticks - 1, ticks)
+        assert parity.pos_rel_err(got[0], mid) < parity.F64_RTOL and parity.pos_rel_err(got[1], ref.world_pos) < parity.F64_RTOL, label
