@@ -305,3 +305,76 @@ def test_random_configurations_of_the_handwritten_path_vs_the_oracle(seed):
     if mid is not None:
         got = hip.history("world_pos", ticks - 1, ticks)
         assert parity.pos_rel_err(got[0], mid) < parity.F64_RTOL and parity.pos_rel_err(got[1], ref.world_pos) < parity.F64_RTOL, label
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_entity_set_joins_vs_the_oracle(seed):
+    """Every Body column and every effector column on its OWN random entity set, some with rows out of id order (components
+    inserted late): six_dof runs on the ascending-id intersection (query.rs:136-208).  Integer surface: the gather tables
+    equal the positions of the joined ids inside each column.  Float surface: joined rows against the oracle stepped on
+    the gathered world, every other row of every column untouched bit for bit."""
+    from oracle import oracle as orc
+    from tests import parity
+    rng = np.random.default_rng(8100 + seed)
+    universe = np.arange(1, int(rng.choice([5, 40, 64, 65, 300, 3000])) + 1, dtype=np.uint64)
+    widths = {"world_pos": 7, "world_vel": 6, "inertia": 7, "world_accel": 6, "force": 6, "tq": 3, "wind": 3}
+    ids, data = {}, {}
+    for name, wd in widths.items():
+        keep = universe[rng.random(len(universe)) < rng.uniform(0.8, 1.0)]
+        if len(keep) == 0:
+            keep = universe[:1]
+        if rng.random() < 0.4:                                   # a few rows appended out of id order
+            tail = rng.choice(len(keep), size=min(len(keep), 3), replace=False)
+            keep = np.concatenate([np.delete(keep, tail), keep[tail]])
+        ids[name] = keep
+        a = rng.normal(size=(len(keep), wd))
+        if name == "world_pos":
+            a[:, :4] /= np.linalg.norm(a[:, :4], axis=1, keepdims=True)
+        if name == "inertia":
+            a = np.concatenate([rng.uniform(0.5, 3.0, (len(keep), 3)), np.zeros((len(keep), 3)), rng.uniform(1.0, 9.0, (len(keep), 1))], axis=1)
+        data[name] = a
+    joined = universe
+    for name in ("world_pos", "world_vel", "inertia", "world_accel", "force"):
+        joined = np.intersect1d(joined, ids[name])
+    if len(joined) == 0:
+        pytest.skip("empty join for this seed")
+    for name in ("tq", "wind"):       # effector columns must cover the Body join (a superset in any order is fine)
+        extra = np.setdiff1d(ids[name], joined)
+        keep = np.concatenate([joined, extra])
+        keep = keep[rng.permutation(len(keep))] if rng.random() < 0.5 else np.sort(keep)
+        ids[name], data[name] = keep, rng.normal(size=(len(keep), 3))
+    integrator = int(rng.choice([L.RK4, L.SEMI_IMPLICIT]))
+    k, ticks = int(rng.choice([1, 4, 7])), int(rng.integers(1, 20))
+    ops = [el.Effector(L.EFF_UNIFORM_GRAVITY, (0.0, 0.3, -9.81)), el.Effector(L.EFF_BODY_TORQUE, (), aux_name="tq", aux=data["tq"]),
+           el.Effector(L.EFF_BALL_DRAG, (0.5, 1.2, 0.3), aux_name="wind", aux=data["wind"])]
+    hip = el.HipExec(data["world_pos"], data["world_vel"], data["inertia"], world_accel=data["world_accel"], force=data["force"],
+                     entity_ids=ids["world_pos"], integrator=integrator, effectors=ops, ticks_per_launch=k, column_entity_ids=ids)
+    assert hip.n == len(joined)
+    if len(joined) > 1:               # ... and one that does not is refused, loudly
+        short = dict(ids, tq=ids["tq"][ids["tq"] != joined[0]])
+        with pytest.raises(Exception, match="does not cover"):
+            el.HipExec(data["world_pos"], data["world_vel"], data["inertia"], world_accel=data["world_accel"], force=data["force"],
+                       entity_ids=ids["world_pos"], effectors=[el.Effector(L.EFF_BODY_TORQUE, (), aux_name="tq", aux=data["tq"][ids["tq"] != joined[0]])],
+                       column_entity_ids=short).run(1)          # effector columns are joined when the pipe is first assembled
+    rows = {}
+
+    def check_rows(names):
+        for name in names:
+            rows[name] = hip.join_rows(name)
+            where = {int(e): r for r, e in enumerate(ids[name])}
+            assert rows[name].dtype == np.uint32 and rows[name].tolist() == [where[int(j)] for j in joined], name
+    check_rows(("world_pos", "world_vel", "inertia", "world_accel", "force"))
+    hip.run(ticks)
+    check_rows(("tq", "wind"))                  # effector columns join when the pipe is first assembled
+    g = {name: data[name][rows[name]] for name in widths}
+    ref = orc.OracleWorld(g["world_pos"], g["world_vel"], g["inertia"], world_accel=g["world_accel"], force=g["force"], integrator=integrator,
+                          ops=[(orc.EFF_UNIFORM_GRAVITY, (0.0, 0.3, -9.81), None), (orc.EFF_BODY_TORQUE, (), g["tq"]),
+                               (orc.EFF_BALL_DRAG, (0.5, 1.2, 0.3), g["wind"])]).step(ticks)
+    assert parity.pos_rel_err(hip.world_pos[rows["world_pos"]], ref.world_pos) < parity.F64_RTOL
+    for name in ("world_vel", "world_accel", "force"):
+        got, want = getattr(hip, name)[rows[name]], getattr(ref, name)
+        assert max(parity.field_rel_err(got[:, :3], want[:, :3]), parity.field_rel_err(got[:, 3:], want[:, 3:])) < parity.F64_RTOL, name
+    for name in ("world_pos", "world_vel", "world_accel", "force", "inertia"):
+        others = np.setdiff1d(np.arange(len(ids[name])), rows[name])
+        assert np.array_equal(getattr(hip, name)[others], data[name][others]), name      # not in the join: untouched
+    assert np.array_equal(hip.inertia, data["inertia"])
