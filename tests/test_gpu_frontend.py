@@ -489,3 +489,81 @@ def test_n_body_gravity_system():
         assert np.nanmax(np.where(np.abs(ref.column_array(col)) > 1e-12, err, 0.0)) < 1e-9, col
     with pytest.raises(RuntimeError):
         exec.history("b0.world_pos")                    # built with history=False
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_worlds_of_plain_components_follow_the_query_join_rules(seed):
+    """Components scattered over entities at random, a random pipe of systems each with its own query: a system touches
+    exactly the entities that carry every component it reads or writes (query.rs:136-208), reads the values its
+    predecessors left, and leaves everything else alone — against a dictionary-based evaluation of those rules."""
+    rng = np.random.default_rng(9300 + seed)
+    Z = ty.Annotated[el.Array, el.Component("z", el.ComponentType.F64)]
+    W = ty.Annotated[el.Array, el.Component("w", el.ComponentType(el.PrimitiveType.F64, (3,)))]
+
+    @el.system
+    def s1(q: el.Query[X]) -> el.Query[X]:
+        return q.map(X, lambda x: x * 1.5 + 0.125)
+
+    @el.system
+    def s2(q: el.Query[X, Y]) -> el.Query[X]:
+        return q.map(X, lambda x, y: x + y)
+
+    @el.system
+    def s3(q: el.Query[Y, Z]) -> el.Query[Y, Z]:
+        return q.map((Y, Z), lambda y, z: (z, y * 0.5))
+
+    @el.system
+    def s4(q: el.Query[X, Z]) -> el.Query[Z]:
+        return q.map(Z, lambda x, z: el.np.where(x > z, x, z - 1.0))
+
+    @el.system
+    def s5(q: el.Query[W, X]) -> el.Query[W]:
+        return q.map(W, lambda w, x: w * x + el.np.array([1.0, 0.0, -1.0]))
+
+    @el.map
+    def s6(w: W, z: Z) -> Z:
+        return z + el.np.sum(w) * 0.25
+
+    py = {"s1": (("x",), ("x",), lambda v: {"x": v["x"] * 1.5 + 0.125}),
+          "s2": (("x", "y"), ("x",), lambda v: {"x": v["x"] + v["y"]}),
+          "s3": (("y", "z"), ("y", "z"), lambda v: {"y": v["z"], "z": v["y"] * 0.5}),
+          "s4": (("x", "z"), ("z",), lambda v: {"z": np.where(v["x"] > v["z"], v["x"], v["z"] - 1.0)}),
+          "s5": (("w", "x"), ("w",), lambda v: {"w": v["w"] * v["x"] + np.array([1.0, 0.0, -1.0])}),
+          "s6": (("w", "z"), ("z",), lambda v: {"z": v["z"] + np.sum(v["w"]) * 0.25})}
+    systems = {"s1": s1, "s2": s2, "s3": s3, "s4": s4, "s5": s5, "s6": s6}
+    order = [str(k) for k in rng.permutation(list(systems))[:int(rng.integers(2, 7))]]
+    used = sorted({c for k in order for c in py[k][0] + py[k][1]})
+    n_entities = int(rng.choice([3, 10, 70, 300]))
+    types = {"x": X, "y": Y, "z": Z, "w": W}
+    state = {}
+    w = el.World()
+    names = []
+    member = [[c for c in used if rng.random() < 0.7] or [used[0]] for _ in range(n_entities)]
+    for k, c in enumerate(used):                           # every component the pipe names lives somewhere
+        if not any(c in m for m in member):
+            member[k % n_entities].append(c)
+    for e in range(n_entities):
+        have = member[e]
+        vals = {c: (np.round(rng.normal(size=3), 3) if c == "w" else np.array(np.round(rng.normal(), 3))) for c in have}
+        w.spawn(el.C(tuple(types[c] for c in have), tuple(vals[c] for c in have)), f"e{e}")
+        state[f"e{e}"] = {c: np.array(v, dtype=np.float64) for c, v in vals.items()}
+        names.append(f"e{e}")
+    pipe = systems[order[0]]
+    for k in order[1:]:
+        pipe = pipe | systems[k]
+    exec = w.build(pipe)
+    ticks = 3
+    exec.run(ticks)
+    for _ in range(ticks):
+        for k in order:
+            reads, writes, fn = py[k]
+            for ent in names:
+                comps = state[ent]
+                if all(c in comps for c in reads + writes):
+                    comps.update({c: np.asarray(v, dtype=np.float64) for c, v in fn({c: comps[c] for c in reads}).items()})
+    keys = [f"{ent}.{c}" for ent in names for c in state[ent]]
+    df = exec.history(keys)
+    for key in keys:
+        ent, c = key.split(".")
+        assert np.allclose(df[key][-1], state[ent][c], rtol=1e-13, atol=1e-13), (seed, order, key, df[key][-1], state[ent][c])
+    assert len(df["time"]) == ticks + 1
