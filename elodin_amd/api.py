@@ -375,6 +375,24 @@ class World:
             declared = {n for s_ in program_stages[0] + program_stages[1] for n in getattr(s_, "singletons", ())}
             singletons = {n for n in partial if n in declared and len(self.column(n)[1]) == 1 and n not in written}
             partial = [n for n in partial if n not in singletons]
+            # The executor's rows are the Body join.  A system whose query names no Body component would, in the
+            # reference, also run on entities OUTSIDE that join (a Globals-like entity carrying only plain components):
+            # that is not built when a six_dof stage is in the pipe — refuse it rather than leave those rows stale.
+            body_names = set(_dsl._BODY_NAMES)
+            for s_, t_ in zip(program_stages[0] + program_stages[1], probe.pre + probe.post):
+                touched = set(s_.params) | {probe.table.cols[int(t[1:].split("_")[0])][0] for t in t_.written if t[0] == "c"}
+                touched = {n for n in touched if not n.startswith("has:")}
+                if touched & body_names or not touched:
+                    continue
+                members = None
+                for n in touched - singletons:
+                    members = self.column(n)[1] if members is None else np.intersect1d(members, self.column(n)[1])
+                stray = np.setdiff1d(members, row_ids) if members is not None else []
+                if len(stray):
+                    raise NotImplementedError(
+                        f"system {s_.__name__} queries {sorted(touched)} and {len(stray)} matching entities (e.g. id {int(stray[0])}) are "
+                        "not Bodies: with a six_dof stage in the pipe the executor runs on the Body entity set only. Build the "
+                        "plain-component systems as their own world / pipe, or give those entities a Body.")
             effs = _dsl.Program(program_stages[0], eff_pipe, program_stages[1])
             extra_columns = {}
             for name, w_ in effs.trace(widths, partial).columns:

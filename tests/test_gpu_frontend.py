@@ -567,3 +567,32 @@ def test_random_worlds_of_plain_components_follow_the_query_join_rules(seed):
         ent, c = key.split(".")
         assert np.allclose(df[key][-1], state[ent][c], rtol=1e-13, atol=1e-13), (seed, order, key, df[key][-1], state[ent][c])
     assert len(df["time"]) == ticks + 1
+
+
+def test_plain_component_entities_beside_bodies_are_refused_not_skipped():
+    """A system over plain components matches an entity that is no Body while a six_dof stage is in the pipe: the
+    reference would update it; this backend's rows are the Body join, so it says so instead of leaving the row stale.
+    The same component on Body entities only (or a system that also names a Body component) is fine."""
+    @el.system
+    def count(q: el.Query[X]) -> el.Query[X]:
+        return q.map(X, lambda x: x + 1.0)
+
+    @el.map
+    def speed(v: el.WorldVel, x: X) -> X:
+        return x + el.np.linalg.norm(v.linear())
+
+    def world(stray):
+        w = el.World()
+        w.spawn([el.Body(world_vel=el.SpatialMotion(linear=np.array([3.0, 4.0, 0.0]))), OnlyX(np.array(1.0))], "ball")
+        if stray:
+            w.spawn(OnlyX(np.array(10.0)), "globals")
+        return w
+
+    with pytest.raises(NotImplementedError, match="not Bodies"):
+        world(True).build(count | el.six_dof(1 / 120.0))
+    exec = world(True).build(speed | el.six_dof(1 / 120.0))             # its query needs WorldVel: the stray entity is not in it
+    exec.run(2)
+    assert exec.history("ball.x")["ball.x"].tolist() == [1.0, 6.0, 11.0] and exec.column_array("x")[:, 0].tolist() == [11.0, 10.0]
+    exec = world(False).build(count | el.six_dof(1 / 120.0))
+    exec.run(3)
+    assert exec.history("ball.x")["ball.x"].tolist() == [1.0, 2.0, 3.0, 4.0]
