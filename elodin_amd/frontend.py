@@ -38,6 +38,7 @@ import numpy as _np
 
 from . import api as _api
 from . import dsl as _dsl
+from . import monte_carlo  # noqa: F401  (el.monte_carlo.Param / params_spec / params / result / port)
 from .api import EntityId, Integrator, skew  # noqa: F401
 from ._lib import BackendError  # noqa: F401
 

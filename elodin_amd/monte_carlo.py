@@ -17,7 +17,7 @@ import math
 import random
 from dataclasses import dataclass, field
 from statistics import NormalDist
-from typing import Any, Dict, List, Mapping, Sequence
+from typing import Any, Dict, List, Mapping, Optional, Sequence
 
 import numpy as np
 
@@ -125,6 +125,19 @@ class Plan:
                 out[r, c] = float(v)
         return out
 
+    def context(self, index: int, run_dir: Optional[str] = None, **fields) -> Dict[str, Any]:
+        """The per-run context document the reference's runner writes for rollout `index` and points
+        $ELODIN_MONTE_CARLO_CONTEXT at (libs/nox-py/src/monte_carlo.rs:29-43 `ContextData`; the row -> params / meta split
+        and the cell parsing are `read_plan`'s, libs/monte-carlo/src/lib.rs:2615-2661): what `params()` below reads."""
+        row = self.rows[index]
+        cell = lambda v: _parse_cell(v) if isinstance(v, str) else v
+        ctx = {"run_id": self.run_ids[index], "seed": int(self.seeds[index]), "db_path": None, "db_addr": None, "cache_dir": None,
+               "run_dir": None if run_dir is None else str(run_dir),
+               "params": {k[len("param."):]: cell(v) for k, v in row.items() if k.startswith("param.") and v != ""},
+               "meta": {k[len("meta."):]: cell(v) for k, v in row.items() if k.startswith("meta.") and v != ""}, "slots": {}}
+        ctx.update(fields)
+        return ctx
+
     def to_csv(self) -> str:
         """Same text `python -m elodin.monte_carlo.sample` writes (csv.DictWriter defaults)."""
         import csv
@@ -170,3 +183,150 @@ def load_spec(path) -> Dict[str, Any]:
         import tomli as tomllib
     with open(path, "rb") as f:
         return tomllib.load(f)
+
+
+# ---- the sim side of a campaign: el.monte_carlo.{Param, params_spec, params, result, port, spec_json} ------------------
+# (libs/nox-py/src/monte_carlo.rs:12-331).  A sim script declares its parameters with defaults, asks `params()` for the
+# values of THIS run — defaults overlaid with what the runner put in the context document — and reports scalars back with
+# `result(...)`.  On this backend a whole campaign is one GPU job over `Plan.table()`; this API is what keeps a
+# reference sim script importable and lets a single rollout be replayed from its context file.
+
+CONTEXT_ENV = "ELODIN_MONTE_CARLO_CONTEXT"
+_declared_spec: Optional["ParamsSpec"] = None
+
+
+def _parse_cell(value: str):
+    import json
+    try:
+        return json.loads(value)
+    except ValueError:
+        return value
+
+
+def _jsonable(v):
+    if v is None or isinstance(v, (bool, int, str)):
+        return v
+    if isinstance(v, float):
+        if not np.isfinite(v):
+            raise ValueError("float values must be finite")
+        return v
+    if isinstance(v, list):
+        return [_jsonable(x) for x in v]
+    if isinstance(v, dict):
+        return {str(k): _jsonable(x) for k, x in v.items()}
+    raise TypeError(f"value is not JSON serializable: {type(v).__name__}")
+
+
+class Param:
+    def __init__(self, type_, default=None, min=None, max=None):
+        self.type_name = type_.__name__ if isinstance(type_, type) else (type_ if isinstance(type_, str) else repr(type_))
+        self.default, self.min, self.max = _jsonable(default), _jsonable(min), _jsonable(max)
+
+    def data(self) -> Dict[str, Any]:
+        return {"type_name": self.type_name, "default": self.default, "min": self.min, "max": self.max}
+
+
+class ParamsSpec:
+    def __init__(self, params: Mapping[str, Param]):
+        self.params = dict(params)
+
+    def to_json(self) -> str:
+        import json
+        return json.dumps({"params": {k: v.data() for k, v in self.params.items()}}, indent=2)
+
+
+def params_spec(**kwargs) -> ParamsSpec:
+    for key, value in kwargs.items():
+        if not isinstance(value, Param):
+            raise TypeError(f"params_spec value for `{key}` must be el.monte_carlo.Param")
+    global _declared_spec
+    _declared_spec = ParamsSpec(kwargs)
+    return _declared_spec
+
+
+def spec_json() -> str:
+    return (_declared_spec or ParamsSpec({})).to_json()
+
+
+class Params:
+    def __init__(self, values: Mapping[str, Any], ctx: Optional[Mapping[str, Any]] = None):
+        ctx = ctx or {}
+        self._params = dict(values)
+        self.run_id, self.seed = ctx.get("run_id"), ctx.get("seed")
+        self.db_path, self.db_addr = ctx.get("db_path"), ctx.get("db_addr")
+        self.cache_dir, self.run_dir = ctx.get("cache_dir"), ctx.get("run_dir")
+        self._meta, self._slots = dict(ctx.get("meta") or {}), dict(ctx.get("slots") or {})
+
+    def get(self, key: str, default=None):
+        return self._params.get(key, default)
+
+    def __getitem__(self, key: str):
+        return self._params[key]
+
+    def as_overrides_dict(self) -> Dict[str, Any]:
+        return dict(self._params)
+
+    @property
+    def meta(self) -> Dict[str, Any]:
+        return dict(self._meta)
+
+    def slots(self) -> Dict[str, Any]:
+        return dict(self._slots)
+
+    def ports(self) -> Dict[str, int]:
+        ok = lambda v: isinstance(v, int) and not isinstance(v, bool) and 0 <= v <= 0xFFFF
+        out = {k: v for k, v in (self._slots.get("ports") or {}).items() if ok(v)} if isinstance(self._slots.get("ports"), dict) else {}
+        for name, v in self._slots.items():
+            if name.endswith("_port") and ok(v):
+                out.setdefault(name[:-len("_port")], v)
+        return out
+
+
+def params(spec: Optional[ParamsSpec] = None) -> Params:
+    import json
+    import os
+    spec = spec or _declared_spec
+    values = {k: p.default for k, p in spec.params.items()} if spec else {}
+    path = os.environ.get(CONTEXT_ENV)
+    if path is None:
+        return Params(values)
+    try:
+        with open(path) as f:
+            text = f.read()
+    except OSError as err:
+        raise RuntimeError(f"failed to read {CONTEXT_ENV}={path}: {err}") from None
+    ctx = json.loads(text)
+    values.update(ctx.get("params") or {})
+    return Params(values, ctx)
+
+
+def port(name: str, default: Optional[int] = None) -> int:
+    import os
+    env = "ELODIN_MC_PORT_" + "".join(ch.upper() if ch.isascii() and ch.isalnum() else "_" for ch in name)
+    raw = os.environ.get(env)
+    if raw is not None:
+        try:
+            v = int(raw)
+            if not 0 <= v <= 0xFFFF:
+                raise ValueError("out of range")
+            return v
+        except ValueError as err:
+            raise ValueError(f"invalid port value for `{name}`: {err}") from None
+    found = params(None).ports().get(name)
+    if found is not None:
+        return found
+    if default is None:
+        raise KeyError(name)
+    return default
+
+
+def result(**kwargs) -> None:
+    """Write the run's scalars to <run_dir>/result.json, where the campaign's post_run hook reads them."""
+    import json
+    from pathlib import Path
+    if not kwargs:
+        return
+    run_dir = params(None).run_dir
+    if run_dir is None:
+        raise RuntimeError("result() requires ELODIN_MONTE_CARLO_CONTEXT with run_dir")
+    (Path(run_dir) / "result.json").write_text(json.dumps({k: _jsonable(v) for k, v in kwargs.items()}, indent=2))

@@ -6,6 +6,7 @@ import json
 from pathlib import Path
 
 import numpy as np
+import pytest
 
 from elodin_amd import campaign as cp
 from elodin_amd import monte_carlo as mc
@@ -100,3 +101,50 @@ def test_campaign_directory_layout(tmp_path):
     assert set(s["phase_attribution"]) == {"samples", "average_python_import_ms", "average_compile_ms", "average_loop_ms",
                                            "average_teardown_ms", "average_process_shutdown_ms", "p95_python_import_ms",
                                            "p95_compile_ms", "p95_loop_ms", "p95_teardown_ms", "p95_process_shutdown_ms"}
+
+
+def test_sim_side_context_api(tmp_path, monkeypatch):
+    """el.monte_carlo.{Param, params_spec, params, result, port, spec_json} (libs/nox-py/src/monte_carlo.rs): declared
+    defaults overlaid with the run's context document, which `Plan.context(i)` writes exactly as the runner's read_plan
+    splits a plan row (param.* / meta.* columns, JSON-parsed cells)."""
+    import json
+    import elodin_amd.frontend as el
+    from elodin_amd import monte_carlo as mc
+    spec = el.monte_carlo.params_spec(mass_kg=el.monte_carlo.Param(float, 15103.0, min=14000.0, max=16000.0),
+                                      engine=el.monte_carlo.Param(str, "descent"), n_jets=el.monte_carlo.Param(int, 16))
+    assert json.loads(spec.to_json())["params"]["mass_kg"] == {"type_name": "float", "default": 15103.0, "min": 14000.0, "max": 16000.0}
+    assert json.loads(el.monte_carlo.spec_json()) == json.loads(spec.to_json())
+    with pytest.raises(TypeError, match="must be el.monte_carlo.Param"):
+        el.monte_carlo.params_spec(x=3.0)
+    with pytest.raises(ValueError, match="finite"):
+        el.monte_carlo.Param(float, float("inf"))
+    # no context: the declared defaults
+    monkeypatch.delenv(mc.CONTEXT_ENV, raising=False)
+    p = el.monte_carlo.params(spec)
+    assert (p["mass_kg"], p.get("engine"), p.get("missing", 7), p.run_id, p.seed, p.run_dir) == (15103.0, "descent", 7, None, None, None)
+    with pytest.raises(KeyError):
+        p["missing"]
+    with pytest.raises(RuntimeError, match="requires ELODIN_MONTE_CARLO_CONTEXT"):
+        el.monte_carlo.result(ok=True)
+    # a plan row -> context document -> params()
+    plan = mc.materialize({"sim_sweep": {"engine": ["descent", "ascent"]}, "meta_sweep": {"wind": [0, 5]},
+                           "monte_carlo": {"n_samples": 3, "seed": 4, "variables": {"mass_kg": {"dist": "uniform", "min": 14000.0, "max": 16000.0}}}})
+    ctx = plan.context(7, run_dir=tmp_path, slots={"ports": {"db": 2240}, "ctrl_port": 9001, "bad_port": 70000})
+    assert ctx["run_id"] == "run_0000007" and ctx["seed"] == 8 and set(ctx["params"]) == {"engine", "mass_kg"} and set(ctx["meta"]) == {"wind"}
+    path = tmp_path / "context.json"
+    path.write_text(json.dumps(ctx))
+    monkeypatch.setenv(mc.CONTEXT_ENV, str(path))
+    p = el.monte_carlo.params()                      # the spec declared last
+    assert p.run_id == "run_0000007" and p.seed == 8 and p.run_dir == str(tmp_path) and p["n_jets"] == 16
+    assert p["mass_kg"] == plan.rows[7]["param.mass_kg"] and p["engine"] == plan.rows[7]["param.engine"] and p.meta == {"wind": plan.rows[7]["meta.wind"]}
+    assert p.as_overrides_dict()["mass_kg"] == p["mass_kg"] and p.ports() == {"db": 2240, "ctrl": 9001}
+    assert el.monte_carlo.port("db") == 2240 and el.monte_carlo.port("nope", 5) == 5
+    monkeypatch.setenv("ELODIN_MC_PORT_MY_SVC", "4000")
+    assert el.monte_carlo.port("my-svc") == 4000
+    with pytest.raises(KeyError):
+        el.monte_carlo.port("nope")
+    el.monte_carlo.result(landed=True, touchdown_speed=1.25, notes=["a", 2])
+    assert json.loads((tmp_path / "result.json").read_text()) == {"landed": True, "touchdown_speed": 1.25, "notes": ["a", 2]}
+    monkeypatch.setenv(mc.CONTEXT_ENV, str(tmp_path / "gone.json"))
+    with pytest.raises(RuntimeError, match="failed to read"):
+        el.monte_carlo.params()
