@@ -375,24 +375,28 @@ class World:
             declared = {n for s_ in program_stages[0] + program_stages[1] for n in getattr(s_, "singletons", ())}
             singletons = {n for n in partial if n in declared and len(self.column(n)[1]) == 1 and n not in written}
             partial = [n for n in partial if n not in singletons]
-            # The executor's rows are the Body join.  A system whose query names no Body component would, in the
-            # reference, also run on entities OUTSIDE that join (a Globals-like entity carrying only plain components):
-            # that is not built when a six_dof stage is in the pipe — refuse it rather than leave those rows stale.
-            body_names = set(_dsl._BODY_NAMES)
-            for s_, t_ in zip(program_stages[0] + program_stages[1], probe.pre + probe.post):
-                touched = set(s_.params) | {probe.table.cols[int(t[1:].split("_")[0])][0] for t in t_.written if t[0] == "c"}
-                touched = {n for n in touched if not n.startswith("has:")}
-                if touched & body_names or not touched:
-                    continue
-                members = None
-                for n in touched - singletons:
-                    members = self.column(n)[1] if members is None else np.intersect1d(members, self.column(n)[1])
-                stray = np.setdiff1d(members, row_ids) if members is not None else []
-                if len(stray):
-                    raise NotImplementedError(
-                        f"system {s_.__name__} queries {sorted(touched)} and {len(stray)} matching entities (e.g. id {int(stray[0])}) are "
-                        "not Bodies: with a six_dof stage in the pipe the executor runs on the Body entity set only. Build the "
-                        "plain-component systems as their own world / pipe, or give those entities a Body.")
+            # The executor's rows are the Body join.  A system whose query names no Body component also runs, in the
+            # reference, on matching entities OUTSIDE that join (a Globals-like entity carrying only plain components).
+            # Those entities and systems form an independent little world (systems are per-entity maps; the only thing
+            # shared across entities, a singleton, is read-only): it gets an executor of its own, stepped in lockstep.
+            side_systems, side_entities = [], set()
+            if not getattr(system, "no_six_dof", False):
+                body_names = set(_dsl._BODY_NAMES)
+                for s_, t_ in zip(program_stages[0] + program_stages[1], probe.pre + probe.post):
+                    touched = set(s_.params) | {probe.table.cols[int(t[1:].split("_")[0])][0] for t in t_.written if t[0] == "c"}
+                    touched = {n for n in touched if not n.startswith("has:")}
+                    if touched & body_names or not touched:
+                        continue
+                    members = None
+                    for n in touched - singletons:
+                        members = self.column(n)[1] if members is None else np.intersect1d(members, self.column(n)[1])
+                    stray = np.setdiff1d(members, row_ids) if members is not None else []
+                    if len(stray):
+                        if touched & singletons:
+                            raise NotImplementedError(f"system {s_.__name__} reads a one-entity component and matches entities that "
+                                                      "are not Bodies while six_dof is in the pipe")
+                        side_systems.append(s_)
+                        side_entities.update(int(e) for e in stray)
             effs = _dsl.Program(program_stages[0], eff_pipe, program_stages[1])
             extra_columns = {}
             for name, w_ in effs.trace(widths, partial).columns:
@@ -444,6 +448,21 @@ class World:
                       column_entity_ids=None if same else column_ids, columns=extra_columns)
         ex = Exec(hip, self, ticks_per_telemetry, dt)
         ex._partial = self_partial
+        if program_stages is not None and side_systems:
+            sub = World()
+            while sub.entity_len <= max(side_entities):      # same entity ids as in this world
+                sub._lib.sixdof_world_spawn(sub._w)
+            touched = sorted({n for s_ in side_systems for n in s_.params} | {n for n, _ in probe.columns if not n.startswith("has:")})
+            for name in touched:
+                if name not in self._components:
+                    continue
+                arr, aids = self.column(name)
+                for row, e in zip(arr, aids):
+                    if int(e) in side_entities:
+                        sub.insert(EntityId(int(e)), C(name, row))
+            sub._names = {k: v for k, v in self._names.items() if k in side_entities}
+            side = sub.build(_dsl.Stages(side_systems), simulation_rate=simulation_rate, telemetry_rate=telemetry_rate, device=device)
+            ex._side = side
         return ex
 
 
@@ -511,14 +530,20 @@ class Exec:
     def run(self, ticks: int = 1) -> None:
         log = getattr(self, "_history", None)
         if log is None:
-            self._last = self._hip.run(ticks)
+            self._advance(ticks)
             return
         done = 0                                   # exec.rs:110-172: batches of ticks_per_telemetry, a commit after each
         while done < ticks:
             step = min(self._tpt, ticks - done)
-            self._last = self._hip.run(step)
+            self._advance(step)
             log.sample()
             done += step
+
+    def _advance(self, ticks: int) -> None:
+        self._last = self._hip.run(ticks)
+        side = getattr(self, "_side", None)        # plain-component entities beside the Bodies: same number of ticks
+        if side is not None:
+            side.run(ticks)
 
     def history(self, components):
         """exec.history("e1.x") / exec.history(["e1.x", "e2.x"]) (exec.rs:189-213): {"time": seconds, "<entity>.<component>":
@@ -529,7 +554,7 @@ class Exec:
 
     def column_ids(self, name: str) -> np.ndarray:
         """Entity id of each row of column_array(name)."""
-        n = len(self.column_array(name))
+        n = len(self._main_column_array(name))
         if name in self._world._components:
             ids = self._world.column(name)[1]
             if len(ids) == n:
@@ -541,6 +566,18 @@ class Exec:
         return self._hip.tick
 
     def column_array(self, name: str) -> np.ndarray:
+        out = self._main_column_array(name)
+        side = getattr(self, "_side", None)
+        if side is not None and name in side._world._components:
+            ids = self.column_ids(name)
+            if len(ids) == len(out):
+                out = np.array(out)
+                where = {int(e): r for r, e in enumerate(ids)}
+                for row, e in zip(side.column_array(name), side.column_ids(name)):
+                    out[where[int(e)]] = row
+        return out
+
+    def _main_column_array(self, name: str) -> np.ndarray:
         cols = {"world_pos": self._hip.world_pos, "world_vel": self._hip.world_vel, "world_accel": self._hip.world_accel,
                 "force": self._hip.force, "inertia": self._hip.inertia}
         if name in cols:

@@ -569,10 +569,10 @@ def test_random_worlds_of_plain_components_follow_the_query_join_rules(seed):
     assert len(df["time"]) == ticks + 1
 
 
-def test_plain_component_entities_beside_bodies_are_refused_not_skipped():
-    """A system over plain components matches an entity that is no Body while a six_dof stage is in the pipe: the
-    reference would update it; this backend's rows are the Body join, so it says so instead of leaving the row stale.
-    The same component on Body entities only (or a system that also names a Body component) is fine."""
+def test_plain_component_entities_beside_bodies_run_too():
+    """A system over plain components also matches an entity that is no Body while a six_dof stage is in the pipe: the
+    reference updates it like any other row of the query.  Here the Body join is the main executor's row set and such
+    entities get a lockstepped executor of their own; columns and history read back merged."""
     @el.system
     def count(q: el.Query[X]) -> el.Query[X]:
         return q.map(X, lambda x: x + 1.0)
@@ -586,13 +586,78 @@ def test_plain_component_entities_beside_bodies_are_refused_not_skipped():
         w.spawn([el.Body(world_vel=el.SpatialMotion(linear=np.array([3.0, 4.0, 0.0]))), OnlyX(np.array(1.0))], "ball")
         if stray:
             w.spawn(OnlyX(np.array(10.0)), "globals")
+            w.spawn(el.Body(), "rock")                                    # a Body without x: in neither query
         return w
 
-    with pytest.raises(NotImplementedError, match="not Bodies"):
-        world(True).build(count | el.six_dof(1 / 120.0))
-    exec = world(True).build(speed | el.six_dof(1 / 120.0))             # its query needs WorldVel: the stray entity is not in it
+    exec = world(True).build(count | speed | el.six_dof(1 / 120.0))
+    exec.run(2)
+    df = exec.history(["ball.x", "globals.x", "ball.world_pos", "rock.world_pos"])
+    assert df["ball.x"].tolist() == [1.0, 7.0, 13.0] and df["globals.x"].tolist() == [10.0, 11.0, 12.0]
+    assert exec.column_array("x")[:, 0].tolist() == [13.0, 12.0] and exec.tick == 2
+    assert np.allclose(df["ball.world_pos"][-1][4:], [3.0 * 2 / 120, 4.0 * 2 / 120, 0.0]) and np.all(df["rock.world_pos"][-1][4:] == 0.0)
+    exec = world(True).build(speed | el.six_dof(1 / 120.0))                # its query needs WorldVel: the stray entity is not in it
     exec.run(2)
     assert exec.history("ball.x")["ball.x"].tolist() == [1.0, 6.0, 11.0] and exec.column_array("x")[:, 0].tolist() == [11.0, 10.0]
     exec = world(False).build(count | el.six_dof(1 / 120.0))
     exec.run(3)
     assert exec.history("ball.x")["ball.x"].tolist() == [1.0, 2.0, 3.0, 4.0]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_worlds_mixing_bodies_and_plain_entities(seed):
+    """Bodies (some carrying plain components) next to plain-component entities, body-free systems and one reading the
+    body state piped around six_dof: plain components follow the query-join rules on every entity, Bodies integrate."""
+    rng = np.random.default_rng(9700 + seed)
+
+    @el.system
+    def s1(q: el.Query[X]) -> el.Query[X]:
+        return q.map(X, lambda x: x * 1.5 + 0.125)
+
+    @el.system
+    def s2(q: el.Query[X, Y]) -> el.Query[Y]:
+        return q.map(Y, lambda x, y: y - x * 0.25)
+
+    @el.map
+    def s3(v: el.WorldVel, y: Y) -> Y:
+        return y + v.linear()[0]
+
+    n_entities = int(rng.choice([4, 20, 150]))
+    w = el.World()
+    state, bodies = {}, {}
+    for e in range(n_entities):
+        name, arch = f"e{e}", []
+        comps = {c: np.array(np.round(rng.normal(), 3)) for c in ("x", "y") if rng.random() < 0.6}
+        if rng.random() < 0.5 or e == 0:
+            vx = float(np.round(rng.normal(), 3))
+            arch.append(el.Body(world_vel=el.SpatialMotion(linear=np.array([vx, 0.0, 0.0]))))
+            bodies[name] = vx
+        if e == 1:
+            comps.setdefault("x", np.array(0.5))
+            comps.setdefault("y", np.array(-0.5))
+        if comps:
+            arch.append(el.C(tuple({"x": X, "y": Y}[c] for c in comps), tuple(comps.values())))
+        if not arch:
+            arch.append(el.C(X, np.array(1.0)))
+            comps = {"x": np.array(1.0)}
+        w.spawn(arch, name)
+        state[name] = {c: float(v) for c, v in comps.items()}
+    exec = w.build(s1 | s2 | el.six_dof(1 / 60.0) | s3)
+    ticks = 3
+    exec.run(ticks)
+    for _ in range(ticks):
+        for ent, comps in state.items():
+            if "x" in comps:
+                comps["x"] = comps["x"] * 1.5 + 0.125
+        for ent, comps in state.items():
+            if "x" in comps and "y" in comps:
+                comps["y"] = comps["y"] - comps["x"] * 0.25
+        for ent, comps in state.items():
+            if ent in bodies and "y" in comps:
+                comps["y"] = comps["y"] + bodies[ent]
+    keys = [f"{ent}.{c}" for ent, comps in state.items() for c in comps]
+    df = exec.history(keys + [f"{ent}.world_pos" for ent in bodies])
+    for key in keys:
+        ent, c = key.split(".")
+        assert np.isclose(df[key][-1], state[ent][c], rtol=1e-13, atol=1e-13), (seed, key, df[key][-1], state[ent][c])
+    for ent, vx in bodies.items():
+        assert np.isclose(df[f"{ent}.world_pos"][-1][4], vx * ticks / 60.0, rtol=1e-12, atol=1e-15), ent
