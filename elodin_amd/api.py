@@ -334,6 +334,13 @@ class World:
             for it in program_stages[0] + program_stages[1]:
                 if not isinstance(it, _dsl.System):
                     raise TypeError("systems piped around six_dof must be elodin_amd.dsl systems")
+        if program_stages is None and isinstance(system.effectors, _dsl.Pipe) and "world_pos" in self._components:
+            # generated effectors reading a component that only some Bodies carry: the program path knows presence masks
+            body_ids = self.column("world_pos")[1]
+            for name, _w in system.effectors.trace().columns:
+                if name in self._components and not np.all(np.isin(body_ids, self.column(name)[1])):
+                    program_stages = ([], [])
+                    break
         synthesized_body = None
         if "world_pos" not in self._components and program_stages is not None and getattr(system, "no_six_dof", False):
             # a world of plain components (no Body anywhere): the row set is every entity carrying a component the systems

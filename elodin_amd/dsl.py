@@ -748,7 +748,7 @@ class TracedPipe:
     """Result of tracing an effector pipe: output wrench nodes, the component columns read, dependency flags."""
 
     def __init__(self, effectors: Sequence[Effector], table: Optional[ColumnTable] = None,
-                 widths: Optional[Dict[str, int]] = None):
+                 widths: Optional[Dict[str, int]] = None, partial: Sequence[str] = ()):
         self.effectors = list(effectors)
         self.table = table or ColumnTable("aux", 4, 3, widths)
         pos, vel, inertia = _body_symbols(stage=True)
@@ -772,6 +772,18 @@ class TracedPipe:
                 raise TypeError(f"effector {eff.__name__} must return a dsl.SpatialForce")
             if out._q is None:
                 out._q = pos.angular()
+            # an effector is a map over ITS query (query.rs:136-208): an entity lacking one of the components it reads
+            # keeps the force its predecessors left.  Such columns arrive densified with a presence column `has:<name>`.
+            need = [n for n in eff.params if n in partial]
+            if need:
+                mask = None
+                for n in dict.fromkeys(need):
+                    h = self.table.symbols("has:" + n, 1, 1)[0] > 0.5
+                    mask = h if mask is None else (mask & h)
+                pick = lambda a, b: Vec([Expr("select", (mask, _lift(x), _lift(y))) for x, y in zip(a.e, b.e)])
+                kept = SpatialForce(linear=pick(out._f, force._f), _tw=pick(out._tw, force._tw), _tb=pick(out._tb, force._tb))
+                kept._q = out._q
+                out = kept
             force = out
         self.torque_world, self.torque_body, self.linear = force._tw, force._tb, force.force()
         # outputs: world torque (3), force (3), body-frame torque (3)
@@ -1032,7 +1044,7 @@ class TracedProgram:
         self.table = ColumnTable("c", 48, 16, widths)
         self.partial = tuple(partial)
         self.pre = [TracedSystem(s, self.table, self.partial) for s in prog.pre]
-        self.pipe = TracedPipe(prog.effectors.effectors, table=self.table)
+        self.pipe = TracedPipe(prog.effectors.effectors, table=self.table, partial=self.partial)
         self.post = [TracedSystem(s, self.table, self.partial) for s in prog.post]
         self.writes_inertia = any(s.writes_inertia for s in self.pre + self.post)
         written = set()

@@ -661,3 +661,43 @@ def test_random_worlds_mixing_bodies_and_plain_entities(seed):
         assert np.isclose(df[key][-1], state[ent][c], rtol=1e-13, atol=1e-13), (seed, key, df[key][-1], state[ent][c])
     for ent, vx in bodies.items():
         assert np.isclose(df[f"{ent}.world_pos"][-1][4], vx * ticks / 60.0, rtol=1e-12, atol=1e-15), ent
+
+
+def test_effector_reading_a_component_only_some_bodies_carry():
+    """examples/ball's drag as the reference spells it, in a world where one ball has no `wind`: apply_drag's query is
+    (Wind, WorldVel, Force), so that ball falls under gravity alone while the others feel their wind."""
+    import elodin_amd as builtin
+    Wind = ty.Annotated[el.Array, el.Component("wind", el.ComponentType(el.PrimitiveType.F64, (3,)))]
+
+    @el.map
+    def gravity(f: el.Force, inertia: el.Inertia) -> el.Force:
+        return f + el.SpatialForce(linear=inertia.mass() * el.np.array([0.0, 0.0, -9.81]))
+
+    @el.map
+    def apply_drag(w: Wind, v: el.WorldVel, f: el.Force) -> el.Force:
+        fluid_vel = w - v.linear()
+        return f + el.SpatialForce(linear=0.5 * 1.225 * 0.5 * 0.25 * el.np.linalg.norm(fluid_vel) * fluid_vel)
+
+    winds = {"a": [0.5, -1.0, 0.0], "b": None, "c": [0.0, 2.0, 0.1]}
+    for sys_ in (lambda: el.six_dof(sys=gravity | apply_drag), lambda: el.six_dof(sys=apply_drag | gravity)):
+        w = el.World()
+        for k, (name, wind) in enumerate(winds.items()):
+            arch = [el.Body(world_pos=el.SpatialTransform(linear=np.array([float(k), 0.0, 6.0])), world_vel=el.SpatialMotion(linear=np.array([1.0, 0.0, 0.0])))]
+            if wind is not None:
+                arch.append(el.C(Wind, np.array(wind)))
+            w.spawn(arch, name)
+        exec = w.build(sys_())
+        exec.run(40)
+        for k, (name, wind) in enumerate(winds.items()):
+            w2 = builtin.World()
+            arch = [builtin.Body(world_pos=builtin.SpatialTransform(linear=[float(k), 0.0, 6.0]), world_vel=builtin.SpatialMotion(linear=[1.0, 0.0, 0.0]))]
+            ops = builtin.uniform_gravity()
+            if wind is not None:
+                arch.append(builtin.C("wind", wind))
+                ops = ops | builtin.ball_drag("wind", cd=0.5, rho=1.225, area=0.25)
+            w2.spawn(arch, name)
+            ref = w2.build(builtin.six_dof(sys=ops))
+            ref.run(40)
+            assert np.allclose(exec.column_array("world_pos")[k], ref.column_array("world_pos")[0], rtol=1e-12), name
+            assert np.allclose(exec.column_array("force")[k], ref.column_array("force")[0], rtol=1e-11, atol=1e-15), name
+        assert exec.column_array("wind").tolist() == [winds["a"], winds["c"]]
