@@ -420,8 +420,11 @@ def _lower_fold(fold: _Fold, name: str):
         return ef
     init = [float(v) for v in _np.atleast_1d(_np.asarray(fold.init, dtype=_np.float64)).reshape(-1)]
     fn, n_args = fold.fn, 1 + len(fold.left) + len(fold.right)
-    src = "lambda " + ", ".join(f"a{k}" for k in range(n_args)) + ": fn(" + ", ".join(f"a{k}" for k in range(n_args)) + ")"
-    gf = _dsl.GraphFold(eval(src, {"fn": fn}), fold.edge_component, fold.left, fold.right, fold.out, init)   # fixed arity
+
+    def fixed_arity(*args):
+        return fn(*args)
+    fixed_arity.__signature__ = inspect.Signature([inspect.Parameter(f"a{k}", inspect.Parameter.POSITIONAL_ONLY) for k in range(n_args)])
+    gf = _dsl.GraphFold(fixed_arity, fold.edge_component, fold.left, fold.right, fold.out, init)
     gf.__name__ = name
     return gf
 
