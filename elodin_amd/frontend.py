@@ -393,6 +393,9 @@ def system(func):
         eff = _dsl.Effector(effector_fn, widths)
         eff.params, eff.__name__ = list(by_name), name
         return eff
+    if "world_accel" in by_name or "force" in by_name:
+        raise TypeError(f"system {name}: world_accel / force are stage values of the integrator and are not readable from systems "
+                        "piped around six_dof on this backend (read them back with exec.history / column_array)")
     if "force" in out_names or "world_accel" in out_names:
         raise TypeError(f"system {name}: force / world_accel are produced inside six_dof — return el.Force alone and pass "
                         "the system as six_dof(sys=...)")
