@@ -375,6 +375,10 @@ def system(func):
                 else GraphQuery(a.edge_component) for _, a in params]
         return func(*args)
 
+    unreadable = "world_accel / force are stage values of the integrator: not readable from systems piped around six_dof on this " \
+                 "backend (read them back with exec.history / column_array)"
+    if "world_accel" in by_name:
+        raise TypeError(f"system {getattr(func, '__name__', 'system')}: {unreadable}")
     indexed: set = set()
     probe = call({n: _probe_value(c) for n, c in by_name.items()}, indexed)
     name = getattr(func, "__name__", "system")
@@ -393,9 +397,8 @@ def system(func):
         eff = _dsl.Effector(effector_fn, widths)
         eff.params, eff.__name__ = list(by_name), name
         return eff
-    if "world_accel" in by_name or "force" in by_name:
-        raise TypeError(f"system {name}: world_accel / force are stage values of the integrator and are not readable from systems "
-                        "piped around six_dof on this backend (read them back with exec.history / column_array)")
+    if "force" in by_name:
+        raise TypeError(f"system {name}: {unreadable}")
     if "force" in out_names or "world_accel" in out_names:
         raise TypeError(f"system {name}: force / world_accel are produced inside six_dof — return el.Force alone and pass "
                         "the system as six_dof(sys=...)")
