@@ -47,7 +47,9 @@ def _literal(v: float) -> str:
 _APPLY_LEAVES = dict(_LEAF_CPP)                                   # effector stage: the stage body `b`
 _SYSTEM_LEAVES = {"qi": "q.i", "qj": "q.j", "qk": "q.k", "qw": "q.w", "px": "p.x", "py": "p.y", "pz": "p.z",
                   "wx": "v.ang.x", "wy": "v.ang.y", "wz": "v.ang.z", "vx": "v.lin.x", "vy": "v.lin.y", "vz": "v.lin.z",
-                  "Ix": "I.x", "Iy": "I.y", "Iz": "I.z", "mass": "mass", "tick": "T(tick)"}
+                  "Ix": "I.x", "Iy": "I.y", "Iz": "I.z", "mass": "mass", "tick": "T(tick)",
+                  # world_accel of the tick just integrated: post systems only (an IMU model after six_dof)
+                  "aax": "accel.ang.x", "aay": "accel.ang.y", "aaz": "accel.ang.z", "alx": "accel.lin.x", "aly": "accel.lin.y", "alz": "accel.lin.z"}
 
 
 def _leaf_ref(name: str, table: Dict[str, str]) -> str:
@@ -461,8 +463,8 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) ->
     }}
     template <class T>
     __device__ static __forceinline__ void post(const StepParams& P, uint64_t tick, Regs<T>& r, Quat<T>& q, Vec3<T>& p,
-                                                Spatial<T>& v, Vec3<T>& I, T& mass) {{
-        (void)P; (void)tick;
+                                                Spatial<T>& v, Vec3<T>& I, T& mass, const Spatial<T>& accel) {{
+        (void)P; (void)tick; (void)accel;
 {_emit_systems(tp.post)}
     }}'''
     names = ", ".join(e.__name__ for e in pipe_tp.effectors)

@@ -83,7 +83,7 @@ struct NoModel {
                                                Vec3<T>&, T&) {}
     template <class T>
     __device__ static __forceinline__ void post(const StepParams&, uint64_t, Regs<T>&, Quat<T>&, Vec3<T>&, Spatial<T>&,
-                                                Vec3<T>&, T&) {}
+                                                Vec3<T>&, T&, const Spatial<T>&) {}
 };
 
 template <int KIND>

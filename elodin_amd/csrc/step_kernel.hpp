@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             p0 = axpy(dt, v0.lin, p0);
             A_out = A;
         }
-        if constexpr (PIPE::kHasModel) PIPE::post(P, P.tick0 + tick + 1, regs, q0, p0, v0, I_diag, mass);
+        if constexpr (PIPE::kHasModel) PIPE::post(P, P.tick0 + tick + 1, regs, q0, p0, v0, I_diag, mass, A_out);   // A_out: this tick's world_accel
         if (record) {
             // telemetry: this tick's world_pos / world_vel / world_accel / force rows -> ring slot, in the
             // reference's row layout, write-once (non-temporal); the stores drain under the next tick's math

@@ -667,7 +667,7 @@ class SpatialForce:
 
 # ---- tracing -----------------------------------------------------------------------------------------------------
 
-_BODY_NAMES = {"force", "pos", "world_pos", "vel", "world_vel", "inertia", "tick"}
+_BODY_NAMES = {"force", "pos", "world_pos", "vel", "world_vel", "inertia", "tick", "accel", "world_accel"}
 
 
 class Effector:
@@ -965,11 +965,17 @@ def system(fn=None, every: int = 1, singletons: Sequence[str] = (), **widths):
 class TracedSystem:
     """One system as (target, expression) assignments over the register file / body state."""
 
-    def __init__(self, sys_: System, table: ColumnTable, partial: Sequence[str] = ()):
+    def __init__(self, sys_: System, table: ColumnTable, partial: Sequence[str] = (), after_six_dof: bool = False):
         self.name, self.every = sys_.__name__, sys_.every
         pos, vel, inertia = _body_symbols()
         kwargs = {}
         for name in sys_.params:
+            if name in ("accel", "world_accel"):
+                if not after_six_dof:
+                    raise TypeError(f"system {self.name}: world_accel is the acceleration six_dof just produced — readable from "
+                                    "systems piped AFTER six_dof only")
+                kwargs[name] = SpatialMotion(Vec([leaf("aa" + c) for c in "xyz"]), Vec([leaf("al" + c) for c in "xyz"]))
+                continue
             if name in ("pos", "world_pos"):
                 kwargs[name] = pos
             elif name in ("vel", "world_vel"):
@@ -1045,7 +1051,7 @@ class TracedProgram:
         self.partial = tuple(partial)
         self.pre = [TracedSystem(s, self.table, self.partial) for s in prog.pre]
         self.pipe = TracedPipe(prog.effectors.effectors, table=self.table, partial=self.partial)
-        self.post = [TracedSystem(s, self.table, self.partial) for s in prog.post]
+        self.post = [TracedSystem(s, self.table, self.partial, after_six_dof=True) for s in prog.post]
         self.writes_inertia = any(s.writes_inertia for s in self.pre + self.post)
         written = set()
         for s in self.pre + self.post:

@@ -342,6 +342,8 @@ def _probe_value(component):
     name, w = Component.name(component), _width(component)
     if name in _BODY:
         return dict(zip(_BODY, _dsl._body_symbols()))[name]
+    if name == "world_accel":
+        return _dsl.SpatialMotion(_dsl.Vec([_dsl.leaf("aa" + c) for c in "xyz"]), _dsl.Vec([_dsl.leaf("al" + c) for c in "xyz"]))
     if name == "force":
         return _dsl.SpatialForce(_dsl.Vec([_dsl.leaf(f"acc{k}") for k in range(3)]), _dsl.Vec([_dsl.leaf(f"acc{k}") for k in range(3, 6)]))
     if name == "tick":
@@ -375,10 +377,7 @@ def system(func):
                 else GraphQuery(a.edge_component) for _, a in params]
         return func(*args)
 
-    unreadable = "world_accel / force are stage values of the integrator: not readable from systems piped around six_dof on this " \
-                 "backend (read them back with exec.history / column_array)"
-    if "world_accel" in by_name:
-        raise TypeError(f"system {getattr(func, '__name__', 'system')}: {unreadable}")
+    unreadable = "force is a stage value of the integrator: readable by effectors inside six_dof(sys=...) only"
     indexed: set = set()
     probe = call({n: _probe_value(c) for n, c in by_name.items()}, indexed)
     name = getattr(func, "__name__", "system")
@@ -388,7 +387,7 @@ def system(func):
         raise TypeError(f"system {name} must return a query (q.map(...)) or graph.edge_fold(...)")
     out_names = probe.names
     widths = {n: w for n, c in {**by_name, **{Component.name(c): c for c in probe.components}}.items()
-              if (w := _width(c)) is not None and n not in _BODY + ("force", "tick")}
+              if (w := _width(c)) is not None and n not in _BODY + ("force", "tick", "world_accel")}
 
     if out_names == ["force"]:                       # `-> el.Force`: an effector of six_dof (six_dof.rs:161-203 `sys`)
         def effector_fn(**cols):             # the pipe tracer hands every plain column over as a Vec; shape-() ones are scalars

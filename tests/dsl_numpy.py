@@ -81,12 +81,14 @@ def fold_force(tf, xs, inertia, src_rows, dst_rows, prior=None):
 
 # ---- whole programs (pre systems | six_dof(effectors) | post systems) ------------------------------------------------
 
-def _leaf_arrays(pos, vel, inertia, comps, table, tick):
+def _leaf_arrays(pos, vel, inertia, comps, table, tick, accel=None):
     n = pos.shape[0]
     lv = {"qi": pos[:, 0], "qj": pos[:, 1], "qk": pos[:, 2], "qw": pos[:, 3], "px": pos[:, 4], "py": pos[:, 5],
           "pz": pos[:, 6], "wx": vel[:, 0], "wy": vel[:, 1], "wz": vel[:, 2], "vx": vel[:, 3], "vy": vel[:, 4],
           "vz": vel[:, 5], "Ix": inertia[:, 0], "Iy": inertia[:, 1], "Iz": inertia[:, 2], "mass": inertia[:, 6],
           "tick": np.full(n, float(tick))}
+    if accel is not None:
+        lv.update({"aax": accel[:, 0], "aay": accel[:, 1], "aaz": accel[:, 2], "alx": accel[:, 3], "aly": accel[:, 4], "alz": accel[:, 5]})
     for slot, (name, w) in enumerate(table.cols):
         for k in range(w):
             lv[f"{table.prefix}{slot}_{k}"] = comps[name][:, k]
@@ -138,7 +140,7 @@ def _eval(exprs, leaves, n):
         return [np.asarray(ev(e), dtype=np.float64) for e in exprs]
 
 
-def _run_systems(systems, pos, vel, inertia, comps, table, tick):
+def _run_systems(systems, pos, vel, inertia, comps, table, tick, accel=None):
     body = {"q": ("pos", {"i": 0, "j": 1, "k": 2, "w": 3}), "p": ("pos", {"x": 4, "y": 5, "z": 6}),
             "w": ("vel", {"x": 0, "y": 1, "z": 2}), "v": ("vel", {"x": 3, "y": 4, "z": 5}),
             "I": ("inertia", {"x": 0, "y": 1, "z": 2})}
@@ -146,7 +148,7 @@ def _run_systems(systems, pos, vel, inertia, comps, table, tick):
     for s in systems:
         if s.every > 1 and tick % s.every != 0:
             continue
-        lv = _leaf_arrays(pos, vel, inertia, comps, table, tick)
+        lv = _leaf_arrays(pos, vel, inertia, comps, table, tick, accel)
         vals = _eval([e for _, e in s.assign], lv, pos.shape[0])
         for (target, _), val in zip(s.assign, vals):     # all outputs computed before any is written
             if target == "mass":
@@ -169,7 +171,7 @@ def program_tick(tp, pos, vel, accel, inertia, comps, tick, dt_g, integrator):
         return _world_wrench(np.stack(_eval(tp.pipe.outputs, lv, xs.shape[0]), axis=1), xs)
     pos2, vel2, acc2, F = np_sixdof.tick(pos, vel, accel, inertia, eff, dt_g, integrator=integrator)
     pos[:], vel[:], accel[:] = pos2, vel2, acc2
-    _run_systems(tp.post, pos, vel, inertia, comps, tp.table, tick)
+    _run_systems(tp.post, pos, vel, inertia, comps, tp.table, tick, accel)
     return F
 
 

@@ -213,3 +213,27 @@ def test_spatial_map_values():  # test_all.py:86-114 and 204-225 on the interpre
     tp = dsl.Program([double_vec], dsl.Pipe([]), []).trace({})
     dsl_numpy._run_systems(tp.pre, pos, vel, inertia, {}, tp.table, 1)
     assert vel[0].tolist() == [np.pi, 0, 0, 2.0, 0, 0]
+
+
+def test_world_accel_is_readable_after_six_dof_only():
+    Meas = ty.Annotated[el.Array, el.Component("meas", el.ComponentType(el.PrimitiveType.F64, (3,)))]
+
+    @el.map
+    def imu(a: el.WorldAccel, p: el.WorldPos, _m: Meas) -> Meas:
+        return p.angular().inverse() @ a.linear()
+
+    assert isinstance(imu, dsl.System) and imu.params == ["world_accel", "world_pos", "meas"]
+    tp = dsl.Program([], dsl.Pipe([]), [imu]).trace({"meas": 3})
+    pos = np.array([[0.0, 0.0, np.sin(0.25), np.cos(0.25), 0, 0, 0]])
+    vel, inertia, accel = np.zeros((1, 6)), np.array([[1.0, 1, 1, 0, 0, 0, 1]]), np.array([[0.0, 0, 0, 1.0, 2.0, 3.0]])
+    comps = {"meas": np.zeros((1, 3))}
+    dsl_numpy._run_systems(tp.post, pos, vel, inertia, comps, tp.table, 1, accel)
+    c, s_ = np.cos(0.5), np.sin(0.5)
+    assert np.allclose(comps["meas"][0], [c * 1.0 + s_ * 2.0, -s_ * 1.0 + c * 2.0, 3.0])
+    with pytest.raises(TypeError, match="AFTER six_dof"):
+        dsl.Program([imu], dsl.Pipe([]), []).trace({"meas": 3})
+
+    def peek(f: el.Force, m: Meas) -> Meas:
+        return m + f.force()
+    with pytest.raises(TypeError, match="effectors inside six_dof"):
+        el.map(peek)

@@ -701,3 +701,50 @@ def test_effector_reading_a_component_only_some_bodies_carry():
             assert np.allclose(exec.column_array("world_pos")[k], ref.column_array("world_pos")[0], rtol=1e-12), name
             assert np.allclose(exec.column_array("force")[k], ref.column_array("force")[0], rtol=1e-11, atol=1e-15), name
         assert exec.column_array("wind").tolist() == [winds["a"], winds["c"]]
+
+
+@pytest.mark.parametrize("integrator", [el.Integrator.Rk4, el.Integrator.SemiImplicit])
+def test_imu_model_after_six_dof_reads_world_accel(integrator):
+    """An accelerometer / gyro model piped AFTER six_dof (the reference's sensor systems read el.WorldAccel the integrator
+    just wrote): specific force in the body frame = q^-1 (a - g).  Checked against the same formula on the world_accel and
+    world_pos rows the executor reports for that tick; piping it BEFORE six_dof is refused."""
+    Accel = ty.Annotated[el.Array, el.Component("accel_meas", el.ComponentType(el.PrimitiveType.F64, (3,)))]
+    Gyro = ty.Annotated[el.Array, el.Component("gyro_meas", el.ComponentType(el.PrimitiveType.F64, (3,)))]
+    G = np.array([0.0, 0.0, -9.81])
+
+    @el.map
+    def gravity(f: el.Force, inertia: el.Inertia) -> el.Force:
+        return f + el.SpatialForce(linear=inertia.mass() * el.np.array(G))
+
+    @el.map
+    def thrust(f: el.Force, p: el.WorldPos) -> el.Force:
+        return f + el.SpatialForce(linear=p.angular() @ el.np.array([0.0, 0.0, 30.0]), torque=p.angular() @ el.np.array([0.02, 0.0, 0.01]))
+
+    @el.map
+    def imu(a: el.WorldAccel, p: el.WorldPos, v: el.WorldVel, _acc: Accel, _gyro: Gyro) -> tuple[Accel, Gyro]:
+        q_inv = p.angular().inverse()
+        return q_inv @ (a.linear() - el.np.array(G)), q_inv @ v.angular()
+
+    def world():
+        w = el.World()
+        w.spawn([el.Body(world_pos=el.SpatialTransform(angular=el.Quaternion.from_axis_angle(np.array([1.0, 0.2, 0.0]), 0.3)),
+                         world_vel=el.SpatialMotion(angular=np.array([0.1, -0.2, 0.05])), inertia=el.SpatialInertia(2.0, np.array([0.5, 0.6, 0.7]))),
+                 el.C((Accel, Gyro), (np.zeros(3), np.zeros(3)))], "probe")
+        return w
+
+    exec = world().build(el.six_dof(sys=gravity | thrust, integrator=integrator) | imu)
+    exec.run(25)
+    df = exec.history(["probe.accel_meas", "probe.gyro_meas", "probe.world_accel", "probe.world_pos", "probe.world_vel"])
+
+    def rot_inv(q, v):                                   # q^-1 v for a unit scalar-last quaternion
+        u, w_ = -q[:3], q[3]
+        t = 2.0 * np.cross(u, v)
+        return v + w_ * t + np.cross(u, t)
+    for k in range(1, 26):
+        q = df["probe.world_pos"][k][:4]
+        q = q / np.linalg.norm(q)
+        assert np.allclose(df["probe.accel_meas"][k], rot_inv(q, df["probe.world_accel"][k][3:] - G), rtol=1e-11, atol=1e-12), k
+        assert np.allclose(df["probe.gyro_meas"][k], rot_inv(q, df["probe.world_vel"][k][:3]), rtol=1e-11, atol=1e-13), k
+    assert np.allclose(np.linalg.norm(df["probe.accel_meas"][-1]), 15.0, rtol=1e-9)      # thrust / mass, whatever the attitude
+    with pytest.raises(TypeError, match="AFTER six_dof"):
+        world().build(imu | el.six_dof(sys=gravity | thrust))
