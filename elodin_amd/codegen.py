@@ -699,7 +699,9 @@ def _compile(src: str, stem: str) -> Path:
         last_resources = json.loads(meta.read_text()) if meta.exists() else {}
         return so
     hip = JIT_DIR / f"{stem}_{digest}.hip"
-    hip.write_text(src)
+    if not hip.exists():
+        Path(f"{hip}.{os.getpid()}.tmp").write_text(src)
+        os.replace(f"{hip}.{os.getpid()}.tmp", hip)
 
     def run(flags, out):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
@@ -708,7 +710,7 @@ def _compile(src: str, stem: str) -> Path:
         if res.returncode != 0:
             raise RuntimeError(f"hipcc failed for generated code {hip}:\n{res.stderr[-4000:]}")
         return _resources(res.stderr)
-    tmp = str(so) + ".tmp"
+    tmp = f"{so}.{os.getpid()}.tmp"           # ranks of one job may build the same program at the same time
     used = run(_BASE_FLAGS, tmp)
     used["flags"] = " ".join(_BASE_FLAGS)
     if used["vgpr_spills"] > 0:
@@ -723,7 +725,8 @@ def _compile(src: str, stem: str) -> Path:
         warnings.warn(f"generated kernel {so.name} spills {used['vgpr_spills']} VGPRs to scratch "
                       f"({used['scratch_bytes_per_lane']} B/lane): the program holds more state than a wave's 512 registers; "
                       "consider splitting it or narrowing its columns", RuntimeWarning, stacklevel=3)
-    meta.write_text(json.dumps(used))
+    Path(tmp + ".json").write_text(json.dumps(used))
+    os.replace(tmp + ".json", meta)
     os.replace(tmp, so)
     last_resources = used
     return so

@@ -333,3 +333,31 @@ def test_construction_cast_and_reduction_helpers_match_numpy():
             assert np.allclose(g, e, rtol=1e-13, atol=1e-13), (g, e)
     assert dsl_numpy.trace_eval(lambda np_, s: np_.searchsorted([0.0, 1.0], s), 1.0) == 1.0      # ties: left
     assert dsl_numpy.trace_eval(lambda np_, s: np_.searchsorted([0.0, 1.0], s, side="right"), 1.0) == 2.0
+
+
+def test_concurrent_builds_of_one_program_share_the_cache_safely():
+    """Ranks of one job trace the same program and may all miss the cache at once: every builder writes under its own
+    temporary name and publishes with an atomic rename, so all of them end up loading one intact object."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent('''
+        import sys, ctypes
+        sys.path.insert(0, %r)
+        from elodin_amd import dsl, codegen
+        @dsl.system(x=2)
+        def f(x):
+            return {"x": dsl.np.cos(x) * 0.4321 + 0.25}
+        so = codegen.build(dsl.Program([f], dsl.Pipe([]), []).trace({"x": 2}), "float64", 2)
+        ctypes.CDLL(str(so))
+        print(so.name, codegen.last_resources["vgpr_spills"])
+    ''') % str(codegen.PKG.parent)
+    for stale in codegen.JIT_DIR.glob("pipe_*"):      # this test's program only: force a miss
+        if stale.suffix == ".hip" and "0.4321" in stale.read_text():
+            for f in codegen.JIT_DIR.glob(stale.stem + ".*"):
+                f.unlink()
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(3)]
+    outs = [p.communicate() + (p.returncode,) for p in procs]
+    assert all(rc == 0 for _, _, rc in outs), outs
+    assert len({o.strip() for o, _, _ in outs}) == 1 and outs[0][0].split()[1] == "0"
+    assert not list(codegen.JIT_DIR.glob("*.tmp*"))
