@@ -748,3 +748,23 @@ def test_imu_model_after_six_dof_reads_world_accel(integrator):
     assert np.allclose(np.linalg.norm(df["probe.accel_meas"][-1]), 15.0, rtol=1e-9)      # thrust / mass, whatever the attitude
     with pytest.raises(TypeError, match="AFTER six_dof"):
         world().build(imu | el.six_dof(sys=gravity | thrust))
+
+
+def test_history_rows_follow_the_telemetry_rate():
+    """simulation_rate 120 Hz, telemetry_rate 30 Hz: the executor steps four ticks per batch (world_builder.rs:211-243) and
+    exec.history has one row per batch — the state after ticks 0, 4, 8, ... — with run(ticks) stopping wherever asked."""
+    @el.map
+    def count(x: X) -> X:
+        return x + 1.0
+
+    w = el.World()
+    w.spawn([el.Body(world_vel=el.SpatialMotion(linear=np.array([1.2, 0.0, 0.0]))), OnlyX(np.array(0.0))], "e")
+    exec = w.build(count | el.six_dof(), simulation_rate=120.0, telemetry_rate=30.0)
+    exec.run(10)                                         # batches of 4, 4 and the remaining 2
+    df = exec.history(["e.x", "e.world_pos"])
+    assert exec.tick == 10 and df["e.x"].tolist() == [0.0, 4.0, 8.0, 10.0]
+    assert np.allclose(df["time"], np.array([0, 4, 8, 10]) * exec._dt) and np.allclose(df["e.world_pos"][:, 4], np.array([0, 4, 8, 10]) * 1.2 * exec._dt)
+    with pytest.raises(ValueError):
+        w.build(count | el.six_dof(), simulation_rate=120.0, telemetry_rate=50.0)      # not a divisor of the simulation rate
+    with pytest.raises(KeyError):
+        exec.history("nobody.x")
