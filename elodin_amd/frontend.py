@@ -498,11 +498,22 @@ class World(_api.World):
             flat.extend(a.edges() if isinstance(a, Archetype) else [])
         super().insert(eid, flat)
 
+    HISTORY_AUTO_LIMIT = 32 << 20        # bytes of component data per telemetry sample up to which history defaults to on
+
     def build(self, system, simulation_rate: float = 120.0, telemetry_rate: Optional[float] = None, device: int = 0,
-              backend: str = "hip", history: bool = True):
+              backend: str = "hip", history: Optional[bool] = None):
+        """history=None: record telemetry samples for exec.history() unless one sample of this world exceeds
+        HISTORY_AUTO_LIMIT (then a warning says so); True / False force it."""
         if isinstance(system, _dsl.Effector):
             raise TypeError("a system returning el.Force is a six_dof effector: build(el.six_dof(sys=...))")
         ex = super().build(system, simulation_rate=simulation_rate, telemetry_rate=telemetry_rate, device=device, backend=backend)
+        if history is None:
+            sample = sum(self.column(c)[0].nbytes for c in self._components)
+            history = sample <= self.HISTORY_AUTO_LIMIT
+            if not history:
+                import warnings
+                warnings.warn(f"exec.history() is off: one telemetry sample of this world is {sample >> 20} MiB "
+                              "(pass history=True to record anyway, history=False to silence this)", RuntimeWarning, stacklevel=2)
         if history:
             _api.record_history(ex, self)
         return ex
