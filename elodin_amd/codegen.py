@@ -78,7 +78,27 @@ class _Emitter:
         self.names: Dict[int, str] = {}      # id(Expr) -> C++ temporary holding it
         self.keep: Dict[int, dsl.Expr] = {}   # keeps the Exprs alive so ids stay unique
         self.deps: Dict[int, frozenset] = {}
+        self.wide: Dict[int, bool] = {}
         self.n = 0
+
+    # jax.random's threefry words are uint32 values and its samples carry 52 random bits: everything between the key
+    # words and the finished sample is evaluated in double, whatever the program's dtype — a float32 program casts the
+    # seed / tick in, and the sample out (and so draws the SAME noise as its float64 twin, rounded).
+    _WIDE_ARITH = {"add", "sub", "mul", "div", "neg", "floor", "max", "min", "erfinv"}
+
+    def _is_wide(self, e: dsl.Expr) -> bool:
+        w = self.wide.get(id(e))
+        if w is None:
+            if e.op == "threefry":
+                w = True
+            elif e.op in self._WIDE_ARITH:
+                kinds = [("const" if a.op == "const" else self._is_wide(a)) for a in e.args]
+                w = any(k is True for k in kinds) and all(k is True or k == "const" for k in kinds)
+            else:
+                w = False
+            self.wide[id(e)] = w
+            self.keep[id(e)] = e
+        return w
 
     def _deps(self, e: dsl.Expr) -> frozenset:
         d = self.deps.get(id(e))
@@ -194,12 +214,21 @@ class _Emitter:
                 sc["names"][id(e)] = name
                 self._deps(e)
                 return name
-            a = [ref(x, sc) for x in e.args]
+            wide = self._is_wide(e)
+            a = []
+            for x in e.args:
+                if wide:        # double island: literals as doubles, state-typed operands cast in
+                    if x.op == "leaf" and x.name == "tick" and self.leaves.get("tick") == "T(tick)":
+                        a.append("double(tick)")                      # the integer itself, not its float32 rounding
+                    else:
+                        a.append(repr(float(x.value)) if x.op == "const" else (ref(x, sc) if self._is_wide(x) else f"double({ref(x, sc)})"))
+                else:
+                    a.append(f"T({ref(x, sc)})" if x.op != "const" and self._is_wide(x) else ref(x, sc))
             name = f"t{self.n}"
             self.n += 1
             sc["names"][id(e)] = name
             self._deps(e)
-            ctype = "bool" if e.op in _BOOL_OPS else "T"
+            ctype = "bool" if e.op in _BOOL_OPS else ("double" if wide else "T")
             sc["lines"].append(f"{sc['indent']}const {ctype} {name} = {rhs_of(e, a)};")
             return name
 
@@ -207,7 +236,7 @@ class _Emitter:
         for lv, e in assign:
             o = f"o{self.n}"
             self.n += 1
-            lines.append(f"{indent}const T {o} = {ref(e)};")
+            lines.append(f"{indent}const T {o} = {('T(' + ref(e) + ')') if e.op not in ('const', 'leaf') and self._is_wide(e) else ref(e)};")
             outs.append((lv, o))
         for lv, o in outs:
             lines.append(f"{indent}{lv} = {o};")
@@ -406,8 +435,6 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) ->
     fast_math: f32 only — hardware transcendentals / reciprocal division in the generated user code (see _PRELUDE)."""
     if fast_math and dtype != "float32":
         raise ValueError("fast_math applies to float32 programs only")
-    if dtype == "float32" and _uses_op(tp, "threefry"):
-        raise ValueError("jax.random-compatible generators need float64 programs (uint32 words do not fit a float32)")
     _TABLES.clear()
     T = {"float64": "double", "float32": "float"}[dtype]
     integ = {0: "kRk4", 1: "kSemiImplicit", 2: "kNone"}[integrator]

@@ -501,8 +501,10 @@ class _Key:
 class _Random:
     """jax.random for per-entity code, bit-compatible with JAX's default threefry2x32 generator in its partitionable
     layout (the default of the reference's JAX): examples/ball/sim.py:92-94 `random.normal(random.key(seed), shape=(3,))`
-    reproduces the wind row of the reference's golden CSV.  x64 semantics (64 random bits per sample), so programs using
-    it must be float64."""
+    reproduces the wind row of the reference's golden CSV.  x64 semantics (64 random bits per sample): the generated code
+    evaluates everything between the key words and the finished sample in double, also inside a float32 program, which
+    therefore draws the same noise as its float64 twin, rounded (seeds and fold_in data must be exact in the program's
+    dtype on entry: below 2**24 for float32; the tick is taken as the integer it is)."""
 
     @staticmethod
     def key(seed) -> _Key:

@@ -23,8 +23,8 @@ Deliberate scope limits (stated, not hidden): the recovery half of the mission (
 flown: its guidance phases, the landing-leg contact model and ground contact are not built, and fins / RCS — whose plant
 models ARE here — stay at rest because the ascent flight software never commands them; the FSW navigates on truth state
 instead of the noisy IMU/GPS models, and the wind model carries its steady part only (per-rollout `wind_ned`, zero in
-spec.toml), not the gust process: both draw from jax.random, whose counterpart here (`dsl.random`, threefry words held in
-doubles) is float64-only while this campaign runs in float32.
+spec.toml), not the gust process (gust_sigma_mps is 0 in the ascent spec.toml; only spec.landing.toml, i.e. the recovery
+half, turns it on).
 Parity is UNPINNED against reference trajectories (none are checked in, and the reference cannot run here); the
 helper functions and the passive / open-loop plant are pinned against the reference's own verification ladder
 (test_ladder.py, test_frames.py, test_propulsion.py, test_aero.py) in tests/test_falcon9_host.py and

@@ -602,6 +602,15 @@ def test_random_streams_match_numpy_evaluation_and_differ_per_entity():
     all_u = np.concatenate([d[:, 2:].ravel() for d in draws])
     assert abs(all_z.mean()) < 0.05 and abs(all_z.std() - 1.0) < 0.05 and -1.0 <= all_u.min() and all_u.max() < 3.0
     assert abs(all_u.mean() - 1.0) < 0.06 and len(np.unique(all_z)) == all_z.size       # independent streams per entity and tick
-    with pytest.raises(ValueError):
-        el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=np.float32, integrator=L.INTEGRATOR_NONE, effectors=dsl.Program([noise], dsl.Pipe([]), []),
-                   columns={"seed": seeds, "sample": np.zeros((n, 4))})
+    # a float32 program: the generator runs in a double island (uint32 words do not fit a float32), the sample is rounded
+    # on the way out — the same noise as the float64 program draws for the same seed and tick
+    seeds32 = np.arange(n, dtype=np.float64)[:, None] * 7.0 + 1234.0               # exact in float32
+    hip32 = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=np.float32, integrator=L.INTEGRATOR_NONE,
+                       effectors=dsl.Program([noise], dsl.Pipe([]), []), columns={"seed": seeds32, "sample": np.zeros((n, 4))})
+    for tick in (1, 2):
+        hip32.run(1)
+        comps = {"seed": seeds32.copy(), "sample": np.zeros((n, 4))}
+        pos, vel, inertia = (np.array(w[k], dtype=np.float64) for k in ("world_pos", "world_vel", "inertia"))
+        dsl_numpy._run_systems(tp.pre, pos, vel, inertia, comps, tp.table, tick)
+        assert hip32._aux["sample"].dtype == np.float32
+        assert np.allclose(hip32._aux["sample"], comps["sample"], rtol=3e-7, atol=1e-7), tick
