@@ -417,7 +417,7 @@ def main():
                                             "HIP events around the timed region on the launch stream / launches")
         else:
             out["roofline"] = kernel_roofline(ex, n, args.steps, args.warmup)
-        if not args.no_extras:
+        if not args.no_extras and world == 1:
             # fused batch: the reference's ticks_per_telemetry semantics, state held in VGPRs
             ex.set_ticks_per_launch(64)
             ex.invoke_batch(64 * 4)
@@ -450,7 +450,7 @@ def main():
             ex.enable_history(0)
     ex.close()
 
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:
         def hbm_leg():
             big = 1 << 22
             bex, _, _ = make_exec(big, 0, local_rank, 1, False)
@@ -470,7 +470,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:      # informational single-GPU legs: not while other ranks wait
         extra("generated_pipe", generated_leg, local_rank, n)
         extra("f32", f32_leg, local_rank)
         extra("nbody", nbody_leg, local_rank)
