@@ -31,6 +31,9 @@ EFF_BALL_DRAG = 5
 EFF_EDGE_GRAVITY_NEWTON = 6
 EFF_EDGE_GRAVITY_SOFTENED = 7
 EFF_ALLPAIRS_GRAVITY_SOFTENED = 8
+EFF_EDGE_CUSTOM = 9
+EFF_WORLD_TORQUE = 10
+EFF_WORLD_FORCE = 11
 
 COL_WORLD_POS, COL_WORLD_VEL, COL_WORLD_ACCEL, COL_FORCE, COL_INERTIA, COL_ALL = 1, 2, 4, 8, 16, 31
 

@@ -188,6 +188,14 @@ def body_force(component: str) -> Effectors:                      # apollo-lande
     return Effectors([Effector(L.EFF_BODY_FORCE, (), aux_name=component)])
 
 
+def world_torque(component: str) -> Effectors:                    # force + SpatialForce(torque=<component column>)
+    return Effectors([Effector(L.EFF_WORLD_TORQUE, (), aux_name=component)])
+
+
+def world_force(component: str) -> Effectors:                     # force + SpatialForce(linear=<component column>)
+    return Effectors([Effector(L.EFF_WORLD_FORCE, (), aux_name=component)])
+
+
 def ball_drag(wind_component: str, cd=0.5, rho=1.225, area=2 * 3.1415 * 0.2**2) -> Effectors:  # ball/sim.py:96-116
     return Effectors([Effector(L.EFF_BALL_DRAG, (cd, rho, area), aux_name=wind_component)])
 

@@ -53,6 +53,10 @@ __device__ __forceinline__ void apply_one(const DevOp& op, const Vec3<T>& aux, c
         F.tau_b = F.tau_b + aux;
     } else if constexpr (KIND == SIXDOF_EFF_BODY_FORCE) {
         F.f = F.f + rotate(b.q, aux);
+    } else if constexpr (KIND == SIXDOF_EFF_WORLD_TORQUE) {
+        F.tau_w = F.tau_w + aux;
+    } else if constexpr (KIND == SIXDOF_EFF_WORLD_FORCE) {
+        F.f = F.f + aux;
     } else if constexpr (KIND == SIXDOF_EFF_BALL_DRAG) {
         // examples/ball/sim.py:96-116; el.SpatialForce(linear=...) drops whatever torque was there
         const Vec3<T> fl = aux - b.v.lin;
@@ -89,10 +93,11 @@ struct NoModel {
 template <int KIND>
 struct KindTraits {
     static constexpr bool reads_velocity = (KIND == SIXDOF_EFF_BALL_DRAG);
-    static constexpr bool world_torque = (KIND == SIXDOF_EFF_CONST_WRENCH);
+    static constexpr bool world_torque = (KIND == SIXDOF_EFF_CONST_WRENCH || KIND == SIXDOF_EFF_WORLD_TORQUE);
     static constexpr bool body_torque = (KIND == SIXDOF_EFF_BODY_TORQUE);
     static constexpr bool uses_aux =
-        (KIND == SIXDOF_EFF_BODY_TORQUE || KIND == SIXDOF_EFF_BODY_FORCE || KIND == SIXDOF_EFF_BALL_DRAG);
+        (KIND == SIXDOF_EFF_BODY_TORQUE || KIND == SIXDOF_EFF_BODY_FORCE || KIND == SIXDOF_EFF_BALL_DRAG ||
+         KIND == SIXDOF_EFF_WORLD_TORQUE || KIND == SIXDOF_EFF_WORLD_FORCE);
 };
 
 // Compile-time op list.  Op k takes its constants from P.ops[k] and its column value from aux[k].
@@ -142,6 +147,8 @@ struct PipeGeneric : NoModel {
             case SIXDOF_EFF_BODY_TORQUE: apply_one<SIXDOF_EFF_BODY_TORQUE>(P.ops[k], aux[k], b, F); break;
             case SIXDOF_EFF_BODY_FORCE: apply_one<SIXDOF_EFF_BODY_FORCE>(P.ops[k], aux[k], b, F); break;
             case SIXDOF_EFF_BALL_DRAG: apply_one<SIXDOF_EFF_BALL_DRAG>(P.ops[k], aux[k], b, F); break;
+            case SIXDOF_EFF_WORLD_TORQUE: apply_one<SIXDOF_EFF_WORLD_TORQUE>(P.ops[k], aux[k], b, F); break;
+            case SIXDOF_EFF_WORLD_FORCE: apply_one<SIXDOF_EFF_WORLD_FORCE>(P.ops[k], aux[k], b, F); break;
             default: break;
             }
         }

@@ -154,7 +154,7 @@ struct sixdof_handle {
     }
     bool has_pair_op() const {
         for (auto& o : ops)
-            if (o.kind >= SIXDOF_EFF_EDGE_GRAVITY_NEWTON) return true;
+            if (SIXDOF_EFF_IS_PAIR(o.kind)) return true;
         return false;
     }
 };
@@ -416,9 +416,9 @@ int sixdof_set_effectors(sixdof_handle* h, const sixdof_effector_op* ops, size_t
     size_t n_entity_ops = 0, n_pair = 0;
     for (size_t i = 0; i < n_ops; i++) {
         const int k = ops[i].kind;
-        if (k < SIXDOF_EFF_CONST_WRENCH || k > SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED)
+        if (k < SIXDOF_EFF_CONST_WRENCH || k > SIXDOF_EFF_WORLD_FORCE || k == SIXDOF_EFF_EDGE_CUSTOM)
             return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "set_effectors: unknown effector kind");
-        if (k >= SIXDOF_EFF_EDGE_GRAVITY_NEWTON) {
+        if (SIXDOF_EFF_IS_PAIR(k)) {
             n_pair++;
             if (i + 1 != n_ops)
                 return h->fail(SIXDOF_ERR_UNSUPPORTED, "set_effectors: a pair (edge_fold) op must be last in the pipe");
@@ -680,11 +680,12 @@ int build_dev_ops(sixdof_handle* h, DevOp* out, uint32_t* n_out, uint32_t* vel_i
         return SIXDOF_OK;
     }
     for (auto& o : h->ops) {
-        if (o.kind >= SIXDOF_EFF_EDGE_GRAVITY_NEWTON) continue;
+        if (SIXDOF_EFF_IS_PAIR(o.kind)) continue;
         DevOp d{};
         d.kind = o.kind;
         std::memcpy(d.p, o.p, sizeof(d.p));
-        if (o.kind == SIXDOF_EFF_BODY_TORQUE || o.kind == SIXDOF_EFF_BODY_FORCE || o.kind == SIXDOF_EFF_BALL_DRAG) {
+        if (o.kind == SIXDOF_EFF_BODY_TORQUE || o.kind == SIXDOF_EFF_BODY_FORCE || o.kind == SIXDOF_EFF_BALL_DRAG ||
+            o.kind == SIXDOF_EFF_WORLD_TORQUE || o.kind == SIXDOF_EFF_WORLD_FORCE) {
             Column* c = h->col(o.aux_component_id);
             if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "step: effector aux column not bound");
             if (c->width != 3 || c->prim != h->state_prim())
@@ -981,7 +982,7 @@ int sixdof_set_custom_pair(sixdof_handle* h, const char* so_path) {
     if (h->pair_dl) dlclose(h->pair_dl);
     h->pair_dl = dl;
     h->pair_launch = launch;
-    while (!h->ops.empty() && h->ops.back().kind >= SIXDOF_EFF_EDGE_GRAVITY_NEWTON) h->ops.pop_back();
+    while (!h->ops.empty() && SIXDOF_EFF_IS_PAIR(h->ops.back().kind)) h->ops.pop_back();
     sixdof_effector_op op{};
     op.kind = SIXDOF_EFF_EDGE_CUSTOM;
     h->ops.push_back(op);

@@ -109,13 +109,22 @@ typedef enum sixdof_effector_kind {
     SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED = 8,
     /* edge_fold whose fold function is generated code (sixdof_set_custom_pair); never passed to
      * sixdof_set_effectors directly.  graph.rs:177-282 edge_fold with an arbitrary `fn` */
-    SIXDOF_EFF_EDGE_CUSTOM = 9
+    SIXDOF_EFF_EDGE_CUSTOM = 9,
+    /* per-entity ops again (kinds 6..9 are the pair ops): */
+    /* tau += aux[i][0..3)  (world-frame torque column): `force + el.SpatialForce(torque=c)` with c a per-entity
+     * component, the shape of every effector that applies an externally computed load; it is also what a
+     * teacher-forced replay of a recorded `force` column (scripts/ci/baseline/cube-sat-csv) feeds the step */
+    SIXDOF_EFF_WORLD_TORQUE = 10,
+    /* f += aux[i][0..3)  (world-frame force column).  Same pattern, linear half */
+    SIXDOF_EFF_WORLD_FORCE = 11
 } sixdof_effector_kind;
+/* kinds 6..9 fold over edges / pairs; every other kind is a per-entity op */
+#define SIXDOF_EFF_IS_PAIR(k) ((k) >= SIXDOF_EFF_EDGE_GRAVITY_NEWTON && (k) <= SIXDOF_EFF_EDGE_CUSTOM)
 
 typedef struct sixdof_effector_op {
     int32_t kind;               /* sixdof_effector_kind */
     int32_t reserved;
-    uint64_t aux_component_id;  /* per-entity [n,3] f64 column for kinds 3,4,5; else 0 */
+    uint64_t aux_component_id;  /* per-entity [n,3] f64 column for kinds 3,4,5,10,11; else 0 */
     double p[6];
 } sixdof_effector_op;
 

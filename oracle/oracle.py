@@ -25,6 +25,8 @@ EFF_BALL_DRAG = 5
 EFF_EDGE_GRAVITY_NEWTON = 6
 EFF_EDGE_GRAVITY_SOFTENED = 7
 EFF_ALLPAIRS_GRAVITY_SOFTENED = 8
+EFF_WORLD_TORQUE = 10
+EFF_WORLD_FORCE = 11
 RK4, SEMI_IMPLICIT = 0, 1
 
 

@@ -15,8 +15,11 @@
  * PARITY PINNED by the reference's own golden data (tests/test_oracle_golden.py):
  *   G1 scripts/ci/baseline/three-body-csv  (RK4 + edge_fold gravity, 100 ticks)
  *   G2 scripts/ci/baseline/ball-csv        (RK4 + gravity + drag, 100 ticks)
+ *   G3 scripts/ci/baseline/cube-sat-csv    (SemiImplicit, torque != 0, non-uniform inertia diagonal; 100 ticks of
+ *      ore_sat + earth, teacher-forced with the recorded `force` rows: tests/test_oracle_semi_implicit_golden.py
+ *      — pins semi_implicit_tick and the angular half of calc_accel to 5e-16)
  *   K1-K8 unit-test known answers (tests/test_oracle_kat.py)
- * NOT pinned by golden data: semi-implicit in isolation, the softened n-body term at N>35.
+ * NOT pinned by golden data: the softened n-body term at N>35.
  *
  * Each function cites the reference file:line it follows (paths relative to the reference).
  */
@@ -175,6 +178,20 @@ static void effectors(const orc_world* w, const double* xs, const double* vs, do
                     F[6 * i + 3 + c] = F[6 * i + 3 + c] + r[c];
                 }
             }
+            break;
+        case SIXDOF_EFF_WORLD_TORQUE: /* force + SpatialForce(torque=t), t a per-entity world-frame column */
+            for (uint64_t i = 0; i < n; i++)
+                for (int c = 0; c < 3; c++) {
+                    F[6 * i + c] = F[6 * i + c] + aux[3 * i + c];
+                    F[6 * i + 3 + c] = F[6 * i + 3 + c] + 0.0;
+                }
+            break;
+        case SIXDOF_EFF_WORLD_FORCE: /* force + SpatialForce(linear=f) */
+            for (uint64_t i = 0; i < n; i++)
+                for (int c = 0; c < 3; c++) {
+                    F[6 * i + c] = F[6 * i + c] + 0.0;
+                    F[6 * i + 3 + c] = F[6 * i + 3 + c] + aux[3 * i + c];
+                }
             break;
         case SIXDOF_EFF_BALL_DRAG: /* examples/ball/sim.py:92-116 */
             for (uint64_t i = 0; i < n; i++) {
@@ -370,7 +387,7 @@ int orc_resolve_edges(const uint64_t* body_ids, uint64_t n, const uint64_t* from
  * libs/cranelift-mlir/ARCHITECTURE.md:25-27).  Results are identical to orc_step. */
 int orc_step_omp(orc_world* w, uint64_t n_ticks, int threads) {
     for (uint32_t k = 0; k < w->n_ops; k++)
-        if (w->ops[k].kind >= SIXDOF_EFF_EDGE_GRAVITY_NEWTON) return orc_step(w, n_ticks);
+        if (SIXDOF_EFF_IS_PAIR(w->ops[k].kind)) return orc_step(w, n_ticks);
     if (threads < 1) threads = 1;
     int rc = 0;
 #pragma omp parallel for num_threads(threads) schedule(static)

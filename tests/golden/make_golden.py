@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Regenerate tests/golden/*.csv from the reference's own regression baselines.
 
-Source (reference checkout, read-only): scripts/ci/baseline/{three-body-csv,ball-csv}/ —
+Source (reference checkout, read-only): scripts/ci/baseline/{three-body,ball,cube-sat}-csv/ —
 the CSVs `scripts/ci/regress.sh` gates CI on (tolerance 1e-4; they carry 17 significant
 digits).  This script only re-packs them: one file per example, wall-clock `time` column
 dropped (the reference comparator ignores it too, scripts/ci/compare_baseline_csv.py:21),
@@ -26,6 +26,15 @@ EXAMPLES = {
     "ball": ("scripts/ci/baseline/ball-csv",
              [f"ball.{c}" for c in ("world_pos", "world_vel", "world_accel", "force", "inertia", "wind", "seed")]
              + ["globals.tick", "globals.simulation_time_step"]),
+    # SemiImplicit run (examples/cube-sat/main.py:699-710) with non-zero torque and a non-uniform inertia diagonal:
+    # the Body columns of the satellite and of the (purely rotating) earth.  Used teacher-forced — the recorded
+    # `force` row r is fed to a one-tick step from rows r-1 — so none of the example's effectors is restated.
+    # drone-csv is NOT usable that way: it records every 3rd tick and each tick chains three six_dof sub-steps
+    # (examples/drone/sim.py:173-208), so the forces between two rows are not in the data.
+    "cube_sat": ("scripts/ci/baseline/cube-sat-csv",
+                 [f"{e}.{c}" for e in ("ore_sat", "earth")
+                  for c in ("world_pos", "world_vel", "world_accel", "force", "inertia")]
+                 + ["globals.tick", "globals.simulation_time_step"]),
 }
 
 
