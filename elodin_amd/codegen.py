@@ -533,9 +533,9 @@ extern "C" int sixdof_custom_launch(const sixdof::StepParams* p, int integrator,
     if (p->n == 0) return static_cast<int>(hipSuccess);
     const dim3 grid((p->n + kWave - 1) / kWave);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (p->streaming == 1) hipLaunchKernelGGL((sixdof_step_kernel<{T}, {integ}, PipeCustom, 1>), grid, dim3(kWave), 0, s, *p);
-    else if (p->streaming == 2) hipLaunchKernelGGL((sixdof_step_kernel<{T}, {integ}, PipeCustom, 2>), grid, dim3(kWave), 0, s, *p);
-    else hipLaunchKernelGGL((sixdof_step_kernel<{T}, {integ}, PipeCustom, 0>), grid, dim3(kWave), 0, s, *p);
+    if ((p->streaming & 255u) == kPolNt) hipLaunchKernelGGL((sixdof_step_kernel<{T}, {integ}, PipeCustom, kPolNt>), grid, dim3(kWave), 0, s, *p);
+    else if ((p->streaming & 255u) == kPolNtStores) hipLaunchKernelGGL((sixdof_step_kernel<{T}, {integ}, PipeCustom, kPolNtStores>), grid, dim3(kWave), 0, s, *p);
+    else hipLaunchKernelGGL((sixdof_step_kernel<{T}, {integ}, PipeCustom, kPolPlain>), grid, dim3(kWave), 0, s, *p);
     return static_cast<int>(hipGetLastError());
 }}
 '''

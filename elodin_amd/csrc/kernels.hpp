@@ -32,7 +32,7 @@ struct StepParams {
     double dt;                // six_dof(time_step=) override or dt_g (final combination / semi-implicit)
     uint32_t n_ops;
     uint32_t vel_independent; // 1: no op reads the stage velocity -> RK4 stages 1 and 2 share F and A
-    uint32_t streaming;       // host hint: working set >> Infinity Cache -> non-temporal loads/stores
+    uint32_t streaming;       // cache-policy code of the launch: load policy * 8 + store policy (step_kernel.hpp)
     uint32_t hist_ring;       // history ring length in ticks (0 = off)
     uint64_t hist_slot0;      // ring slot index (before modulo) of the first tick of this launch
     void* hist_pos;           // [ring][n,7]   per-tick outputs, reference row layout; nullptr = no recording

@@ -720,7 +720,12 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
     // 25 state elements per entity; stream (non-temporal) once the world is well past the 256 MiB Infinity Cache
     const char* force_nt = std::getenv("SIXDOF_STREAMING");
     const size_t state_bytes = static_cast<size_t>(h->desc.n_entities) * 32 * h->elem_size();
-    P->streaming = force_nt ? static_cast<uint32_t>(force_nt[0] - '0') : (state_bytes > (400ull << 20) ? 1u : 0u);
+    // cache-policy code of the launch (step_kernel.hpp: load * 8 + store).  Output columns always leave with non-temporal
+    // stores (every byte is written once per tick); the input columns are read with the default policy while the
+    // world fits the 256 MiB Infinity Cache — the next tick finds them there — and non-temporally beyond it
+    // (profiles/r02_step_ab_load_x_store_policy.txt: 65,536 bodies 5.48 -> 4.93 us, 131,072 7.94 -> 7.14 us with plain
+    // loads + nt stores; 4.2M bodies 300 -> 263 us with both nt).  SIXDOF_STREAMING=<code> overrides it for A/B runs.
+    P->streaming = force_nt ? static_cast<uint32_t>(std::atoi(force_nt)) : (state_bytes > (192ull << 20) ? 9u : 1u);
     P->hist_ring = h->hist_ring;
     if (h->hist_ring) {
         P->hist_pos = h->d_hist[0];

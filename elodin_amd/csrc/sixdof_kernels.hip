@@ -33,7 +33,7 @@ hipError_t launch_step(const StepParams& p, int integrator, int dtype, hipStream
     if (kinds_are(p, {})) launch_p<PipeNone>(p, integrator, dtype, grid, stream);
     else if (kinds_are(p, {SIXDOF_EFF_UNIFORM_GRAVITY})) launch_p<PipeGravity>(p, integrator, dtype, grid, stream);
     else if (kinds_are(p, {SIXDOF_EFF_UNIFORM_GRAVITY, SIXDOF_EFF_BODY_TORQUE}))
-        launch_p<PipeGravityTorque>(p, integrator, dtype, grid, stream);
+        launch_p<PipeGravityTorque, true>(p, integrator, dtype, grid, stream);
     else if (kinds_are(p, {SIXDOF_EFF_UNIFORM_GRAVITY, SIXDOF_EFF_BALL_DRAG}))
         launch_p<PipeGravityDrag>(p, integrator, dtype, grid, stream);
     else if (kinds_are(p, {SIXDOF_EFF_UNIFORM_GRAVITY, SIXDOF_EFF_BODY_FORCE, SIXDOF_EFF_BODY_TORQUE}))

@@ -69,6 +69,15 @@ __device__ __forceinline__ Spatial<T> operator+(Spatial<T> a, Spatial<T> b) {
     return {a.ang + b.ang, a.lin + b.lin};
 }
 
+// 1/x for the once-per-launch reciprocal mass / inertia: v_rcp_f64 + two Newton steps (each squares the error, so
+// the result is correctly rounded or 1 ulp off) = 5 instructions against the 11 of an IEEE f64 divide.
+__device__ __forceinline__ double recip(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ float recip(float x) { return 1.0f / x; }
 __device__ __forceinline__ double fast_rsqrt(double x) { return rsqrt(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return rsqrtf(x); }
 __device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }

@@ -46,13 +46,20 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 
 // ---- slab movement ---------------------------------------------------------------------------------
 
+// Cache policy of a launch, one template parameter POL = load policy * 8 + store policy:
+//   loads  0 = default, 1 = non-temporal (LDS-DMA aux = 2: a byte that is touched once per tick is not worth a line)
+//   stores 0 = plain (lines stay dirty in the XCD's L2 until the kernel-end write-back), 1 = non-temporal,
+//          2 = write-through `sc1`, 3 = `sc0 sc1`, 4 = `sc1 nt`
+// profiles/r02_step_ab_*.txt hold the A/B of these at 65,536 / 131,072 / 4.2M bodies.
+constexpr int kPolPlain = 0, kPolNtStores = 1, kPolNt = 9;
+constexpr int pol_ld(int pol) { return pol / 8; }
+constexpr int pol_st(int pol) { return pol % 8; }
+
 // Whole-wave slab of BYTES bytes (multiple of 16), global -> LDS by LDS-DMA.
-// NT = non-temporal cache policy (aux = 2) for worlds far larger than the 256 MiB Infinity Cache, where every
-// byte is touched exactly once per tick and retaining it only evicts useful lines.
-template <int BYTES, int NT>
+template <int BYTES, int POL>
 __device__ __forceinline__ void slab_dma_in(const char* __restrict__ g, char* l, uint32_t lane) {
     constexpr int kFull = BYTES / 1024, kRem = (BYTES % 1024) / 16;
-    constexpr int kAux = NT == 1 ? 2 : 0;
+    constexpr int kAux = pol_ld(POL) == 1 ? 2 : 0;
 #pragma unroll
     for (int i = 0; i < kFull; i++)
         __builtin_amdgcn_global_load_lds((global_cptr)(g + i * 1024 + lane * 16), (lds_ptr)(l + i * 1024), 16, 0,
@@ -64,13 +71,13 @@ __device__ __forceinline__ void slab_dma_in(const char* __restrict__ g, char* l,
 
 // Whole-wave slab, LDS -> global: read every chunk first, then issue the stores back to back.
 typedef float vfloat4 __attribute__((ext_vector_type(4)));
-// Store policy: 0 = plain (lines stay dirty in the XCD's L2 until the kernel-end write-back), 1 = non-temporal,
-// 2 = write-through (`sc1`): the bytes leave for memory as the store issues, so the end of the kernel has nothing
-// left to flush (MI355X_MICROARCH.md "publish-large").
-template <int NT>
+template <int POL>
 __device__ __forceinline__ void store16(char* g, vfloat4 v) {
-    if constexpr (NT == 1) __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(g));
-    else if constexpr (NT == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g), "v"(v) : "memory");
+    constexpr int ST = pol_st(POL);
+    if constexpr (ST == 1) __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(g));
+    else if constexpr (ST == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g), "v"(v) : "memory");
+    else if constexpr (ST == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(g), "v"(v) : "memory");
+    else if constexpr (ST == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(g), "v"(v) : "memory");
     else *reinterpret_cast<vfloat4*>(g) = v;
 }
 template <int BYTES, int NT>
@@ -97,7 +104,7 @@ __device__ __forceinline__ void slab_out_tail(const T* l, T* __restrict__ g, uin
 
 // ---- the kernel --------------------------------------------------------------------------------------
 
-template <class T, int INTEGRATOR, class PIPE, int NT>
+template <class T, int INTEGRATOR, class PIPE, int POL>
 __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) {
     // pos | vel | inertia on the way in (20 elems/entity); pos | vel | accel | force on the way out (25)
     __shared__ __attribute__((aligned(16))) T lds[kWave * 25];
@@ -118,9 +125,9 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     const T* const g_inertia = static_cast<const T*>(P.inertia) + (size_t)row0 * 7;
 
     if (full) {
-        slab_dma_in<kWave * 7 * sizeof(T), NT>(reinterpret_cast<const char*>(g_pos), reinterpret_cast<char*>(l_pos), t);
-        slab_dma_in<kWave * 6 * sizeof(T), NT>(reinterpret_cast<const char*>(g_vel), reinterpret_cast<char*>(l_vel), t);
-        slab_dma_in<kWave * 7 * sizeof(T), NT>(reinterpret_cast<const char*>(g_inertia), reinterpret_cast<char*>(l_c), t);
+        slab_dma_in<kWave * 7 * sizeof(T), POL>(reinterpret_cast<const char*>(g_pos), reinterpret_cast<char*>(l_pos), t);
+        slab_dma_in<kWave * 6 * sizeof(T), POL>(reinterpret_cast<const char*>(g_vel), reinterpret_cast<char*>(l_vel), t);
+        slab_dma_in<kWave * 7 * sizeof(T), POL>(reinterpret_cast<const char*>(g_inertia), reinterpret_cast<char*>(l_c), t);
     } else {
         slab_in_tail(g_pos, l_pos, rows * 7, t);
         slab_in_tail(g_vel, l_vel, rows * 6, t);
@@ -169,9 +176,9 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
         v0.lin = Vec3<T>{s[3], s[4], s[5]};
         const T* m = l_c + t * 7;
         I_diag = Vec3<T>{m[0], m[1], m[2]};
-        inv_I = Vec3<T>{T(1) / m[0], T(1) / m[1], T(1) / m[2]};
+        inv_I = Vec3<T>{recip(m[0]), recip(m[1]), recip(m[2])};
         mass = m[6];
-        inv_m = T(1) / mass;
+        inv_m = recip(mass);
         if constexpr (INTEGRATOR == kNone) {   // no six_dof in the pipe: world_accel / force pass through untouched
             const T* a = g_accel + (size_t)t * 6;
             const T* f = g_force + (size_t)t * 6;
@@ -182,48 +189,53 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     if (P.n_ticks == 0) return;
     __syncthreads();  // every lane has consumed the input slabs; LDS is the output staging area from here on
 
-    auto stage_rows = [&]() {
+    // One output column at a time: rows -> LDS staging area -> 16-B-per-lane coalesced stores.  Each column has its
+    // own LDS region, so a column can leave as soon as its rows exist (see `early` below).
+    auto stage_pos = [&](const Quat<T>& q, const Vec3<T>& p) {
         if (active) {
             T* r = l_pos + t * 7;
-            r[0] = q0.i; r[1] = q0.j; r[2] = q0.k; r[3] = q0.w; r[4] = p0.x; r[5] = p0.y; r[6] = p0.z;
-            T* s = l_vel + t * 6;
-            s[0] = v0.ang.x; s[1] = v0.ang.y; s[2] = v0.ang.z; s[3] = v0.lin.x; s[4] = v0.lin.y; s[5] = v0.lin.z;
-            T* a = l_c + t * 6;
-            a[0] = A_out.ang.x; a[1] = A_out.ang.y; a[2] = A_out.ang.z;
-            a[3] = A_out.lin.x; a[4] = A_out.lin.y; a[5] = A_out.lin.z;
-            T* f = l_force + t * 6;
-            f[0] = F_out.ang.x; f[1] = F_out.ang.y; f[2] = F_out.ang.z;
-            f[3] = F_out.lin.x; f[4] = F_out.lin.y; f[5] = F_out.lin.z;
+            r[0] = q.i; r[1] = q.j; r[2] = q.k; r[3] = q.w; r[4] = p.x; r[5] = p.y; r[6] = p.z;
         }
     };
-    // rows in LDS -> the four output columns at `base` pointers (live columns or one history slot)
-    auto flush_rows = [&](T* o_pos, T* o_vel, T* o_accel, T* o_force, auto nt) {
-        constexpr int kNt = decltype(nt)::value;
-        if (full) {
-            slab_out<kWave * 7 * sizeof(T), kNt>(reinterpret_cast<const char*>(l_pos), reinterpret_cast<char*>(o_pos), t);
-            slab_out<kWave * 6 * sizeof(T), kNt>(reinterpret_cast<const char*>(l_vel), reinterpret_cast<char*>(o_vel), t);
-            slab_out<kWave * 6 * sizeof(T), kNt>(reinterpret_cast<const char*>(l_c), reinterpret_cast<char*>(o_accel), t);
-            slab_out<kWave * 6 * sizeof(T), kNt>(reinterpret_cast<const char*>(l_force), reinterpret_cast<char*>(o_force), t);
-        } else {
-            slab_out_tail(l_pos, o_pos, rows * 7, t);
-            slab_out_tail(l_vel, o_vel, rows * 6, t);
-            slab_out_tail(l_c, o_accel, rows * 6, t);
-            slab_out_tail(l_force, o_force, rows * 6, t);
+    auto stage6 = [&](T* l, const Spatial<T>& m) {
+        if (active) {
+            T* s = l + t * 6;
+            s[0] = m.ang.x; s[1] = m.ang.y; s[2] = m.ang.z; s[3] = m.lin.x; s[4] = m.lin.y; s[5] = m.lin.z;
         }
     };
+    auto flush7 = [&](const T* l, T* o, auto pol) {
+        if (full) slab_out<kWave * 7 * sizeof(T), decltype(pol)::value>(reinterpret_cast<const char*>(l), reinterpret_cast<char*>(o), t);
+        else slab_out_tail(l, o, rows * 7, t);
+    };
+    auto flush6 = [&](const T* l, T* o, auto pol) {
+        if (full) slab_out<kWave * 6 * sizeof(T), decltype(pol)::value>(reinterpret_cast<const char*>(l), reinterpret_cast<char*>(o), t);
+        else slab_out_tail(l, o, rows * 6, t);
+    };
+    constexpr std::integral_constant<int, POL> kLive{};   // cache policy of the live columns
+    constexpr std::integral_constant<int, 1> kRing{};     // history ring slots are write-once: non-temporal stores
 
     const bool record = P.hist_pos != nullptr;  // wave-uniform: stream every tick's outputs to the history ring
+    // At one tick per launch the launch is a latency chain (dispatch -> loads -> math -> stores -> write-back), so on
+    // the LAST tick of a launch every output column is staged and stored the moment its rows exist instead of all four
+    // after the tick: world_pos is known before the last stage's force evaluation (the stage positions never see a
+    // stage velocity, rk4.rs:110-121, and sum(v_s) needs only A of stage 2), force before calc_accel, world_accel
+    // before the velocity update.  Same arithmetic in the same order -> same bits as the late flush.
+    // Not with a generated program's post hook (it may still rewrite the pose) nor while recording.
+    // (StepParams::streaming bit 8 turns it off: the A/B knob of tools/step_ab.py.)
+    const bool early_ok = !PIPE::kHasModel && !record && !(P.streaming & 256u);
     const T dt_g = T(P.dt_g), dt = T(P.dt);
     Body<T> b;
     b.mass = mass;
     b.I = I_diag;
     Wrench<T> F = zero_wrench<T>();
+    bool flushed = false;   // wave-uniform: the live columns already left on the early path
     for (uint32_t tick = 0; tick < P.n_ticks; tick++) {
+        const bool early = early_ok && tick + 1 == P.n_ticks;
         if constexpr (PIPE::kHasModel) {   // user systems piped in front of six_dof (may rewrite inertia, pose, velocity)
             PIPE::pre(P, P.tick0 + tick + 1, regs, q0, p0, v0, I_diag, mass);
             if constexpr (PIPE::kWritesInertia) {
-                inv_I = Vec3<T>{T(1) / I_diag.x, T(1) / I_diag.y, T(1) / I_diag.z};
-                inv_m = T(1) / mass;
+                inv_I = Vec3<T>{recip(I_diag.x), recip(I_diag.y), recip(I_diag.z)};
+                inv_m = recip(mass);
                 b.mass = mass;
                 b.I = I_diag;
             }
@@ -263,16 +275,40 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             b.p = axpy(h3, v0.lin, p0);
             b.v = axpy(h3, A, v0);
             sv = sv + b.v;
+            // x' = x0 (+) (dt/6) sum(v_s): complete here, before the last force evaluation
+            const T g = dt * T(1.0 / 6.0);
+            const Quat<T> q_new = integrate_world(q0, g * sv.ang);
+            const Vec3<T> p_new = axpy(g, sv.lin, p0);
+            if (early) {
+                stage_pos(q_new, p_new);
+                __syncthreads();
+                flush7(l_pos, g_pos, kLive);
+            }
             F = zero_wrench<T>();
             PIPE::apply(P, aux, regs, b, F);
+            if (early) {
+                stage6(l_force, world_wrench<PIPE>(b.q, F));
+                __syncthreads();
+                flush6(l_force, g_force, kLive);
+            }
             A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+            if (early) {
+                stage6(l_c, A);
+                __syncthreads();
+                flush6(l_c, g_accel, kLive);
+            }
             sa = sa + A;
-            // u' = u + (dt/6)(k1 + 2k2 + 2k3 + k4)
-            const T g = dt * T(1.0 / 6.0);
-            q0 = integrate_world(q0, g * sv.ang);
-            p0 = axpy(g, sv.lin, p0);
+            // v' = v0 + (dt/6)(k1 + 2k2 + 2k3 + k4)
             v0 = axpy(g, sa, v0);
+            q0 = q_new;
+            p0 = p_new;
             A_out = A;
+            if (early) {
+                stage6(l_vel, v0);
+                __syncthreads();
+                flush6(l_vel, g_vel, kLive);
+                flushed = true;
+            }
         } else if constexpr (INTEGRATOR == kNone) {
             // systems only (`World.build(system)` without six_dof): the pre / post hooks are the whole tick
         } else {
@@ -282,23 +318,49 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             b.v = v0;
             F = zero_wrench<T>();
             PIPE::apply(P, aux, regs, b, F);
+            if (early) {
+                stage6(l_force, world_wrench<PIPE>(b.q, F));
+                __syncthreads();
+                flush6(l_force, g_force, kLive);
+            }
             const Spatial<T> A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+            if (early) {
+                stage6(l_c, A);
+                __syncthreads();
+                flush6(l_c, g_accel, kLive);
+            }
             v0 = axpy(dt, A, v0);
+            if (early) {
+                stage6(l_vel, v0);
+                __syncthreads();
+                flush6(l_vel, g_vel, kLive);
+            }
             q0 = integrate_world(q0, dt * v0.ang);
             p0 = axpy(dt, v0.lin, p0);
             A_out = A;
+            if (early) {
+                stage_pos(q0, p0);
+                __syncthreads();
+                flush7(l_pos, g_pos, kLive);
+                flushed = true;
+            }
         }
         if constexpr (PIPE::kHasModel) PIPE::post(P, P.tick0 + tick + 1, regs, q0, p0, v0, I_diag, mass, A_out);   // A_out: this tick's world_accel
         if (record) {
             // telemetry: this tick's world_pos / world_vel / world_accel / force rows -> ring slot, in the
             // reference's row layout, write-once (non-temporal); the stores drain under the next tick's math
             if constexpr (INTEGRATOR != kNone) F_out = world_wrench<PIPE>(b.q, F);
-            stage_rows();
+            stage_pos(q0, p0);
+            stage6(l_vel, v0);
+            stage6(l_c, A_out);
+            stage6(l_force, F_out);
             __syncthreads();
             const size_t slot = (size_t)((P.hist_slot0 + tick) % P.hist_ring);
             const size_t r7 = (slot * P.n + row0) * 7, r6 = (slot * P.n + row0) * 6;
-            flush_rows(static_cast<T*>(P.hist_pos) + r7, static_cast<T*>(P.hist_vel) + r6,
-                       static_cast<T*>(P.hist_accel) + r6, static_cast<T*>(P.hist_force) + r6, std::integral_constant<int, 1>{});
+            flush7(l_pos, static_cast<T*>(P.hist_pos) + r7, kRing);
+            flush6(l_vel, static_cast<T*>(P.hist_vel) + r6, kRing);
+            flush6(l_c, static_cast<T*>(P.hist_accel) + r6, kRing);
+            flush6(l_force, static_cast<T*>(P.hist_force) + r6, kRing);
             if constexpr (PIPE::kHasModel)
                 if (active) PIPE::record(P, slot, row0 + t, regs);   // component columns of a generated program
             __syncthreads();
@@ -313,33 +375,58 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             }
         }
     }
+    if (flushed) return;
     if constexpr (INTEGRATOR != kNone) F_out = world_wrench<PIPE>(b.q, F);  // wrench of the last stage evaluated, world frame
-    stage_rows();
+    stage_pos(q0, p0);
+    stage6(l_vel, v0);
+    stage6(l_c, A_out);
+    stage6(l_force, F_out);
     __syncthreads();
-    flush_rows(g_pos, g_vel, g_accel, g_force, std::integral_constant<int, NT>{});
+    flush7(l_pos, g_pos, kLive);
+    flush6(l_vel, g_vel, kLive);
+    flush6(l_c, g_accel, kLive);
+    flush6(l_force, g_force, kLive);
 }
 
 // ---- launch helpers (shared with generated translation units) ----------------------------------------------
 
-template <class T, class PIPE, int NT>
+template <class T, class PIPE, int POL>
 inline void launch_i(const StepParams& p, int integrator, dim3 grid, hipStream_t s) {
-    if (integrator == kRk4) hipLaunchKernelGGL((sixdof_step_kernel<T, kRk4, PIPE, NT>), grid, dim3(kWave), 0, s, p);
+    if (integrator == kRk4) hipLaunchKernelGGL((sixdof_step_kernel<T, kRk4, PIPE, POL>), grid, dim3(kWave), 0, s, p);
     else if (integrator == kNone) {
-        if constexpr (PIPE::kHasModel) hipLaunchKernelGGL((sixdof_step_kernel<T, kNone, PIPE, NT>), grid, dim3(kWave), 0, s, p);
-    } else hipLaunchKernelGGL((sixdof_step_kernel<T, kSemiImplicit, PIPE, NT>), grid, dim3(kWave), 0, s, p);
+        if constexpr (PIPE::kHasModel) hipLaunchKernelGGL((sixdof_step_kernel<T, kNone, PIPE, POL>), grid, dim3(kWave), 0, s, p);
+    } else hipLaunchKernelGGL((sixdof_step_kernel<T, kSemiImplicit, PIPE, POL>), grid, dim3(kWave), 0, s, p);
 }
 
-template <class T, class PIPE>
+// StepParams::streaming is the cache-policy code (load * 8 + store).  Every pipe has the three shipped policies;
+// SWEEP adds the rest of the matrix for A/B runs (tools/step_ab.py) on the pipes that ask for it.
+template <class T, class PIPE, bool SWEEP>
 inline void launch_t(const StepParams& p, int integrator, dim3 grid, hipStream_t s) {
-    if (p.streaming == 1) launch_i<T, PIPE, 1>(p, integrator, grid, s);
-    else if (p.streaming == 2) launch_i<T, PIPE, 2>(p, integrator, grid, s);
-    else launch_i<T, PIPE, 0>(p, integrator, grid, s);
+    const uint32_t pol = p.streaming & 255u;   // bit 8 = late flush (A/B knob), see the kernel
+    switch (pol) {
+    case kPolNt: return launch_i<T, PIPE, kPolNt>(p, integrator, grid, s);
+    case kPolNtStores: return launch_i<T, PIPE, kPolNtStores>(p, integrator, grid, s);
+    default: break;
+    }
+    if constexpr (SWEEP) {
+        switch (pol) {
+        case 2: return launch_i<T, PIPE, 2>(p, integrator, grid, s);
+        case 3: return launch_i<T, PIPE, 3>(p, integrator, grid, s);
+        case 4: return launch_i<T, PIPE, 4>(p, integrator, grid, s);
+        case 8: return launch_i<T, PIPE, 8>(p, integrator, grid, s);
+        case 10: return launch_i<T, PIPE, 10>(p, integrator, grid, s);
+        case 11: return launch_i<T, PIPE, 11>(p, integrator, grid, s);
+        case 12: return launch_i<T, PIPE, 12>(p, integrator, grid, s);
+        default: break;
+        }
+    }
+    launch_i<T, PIPE, kPolPlain>(p, integrator, grid, s);
 }
 
-template <class PIPE>
+template <class PIPE, bool SWEEP = false>
 inline void launch_p(const StepParams& p, int integrator, int dtype, dim3 grid, hipStream_t s) {
-    if (dtype == SIXDOF_F64) launch_t<double, PIPE>(p, integrator, grid, s);
-    else launch_t<float, PIPE>(p, integrator, grid, s);
+    if (dtype == SIXDOF_F64) launch_t<double, PIPE, SWEEP>(p, integrator, grid, s);
+    else launch_t<float, PIPE, false>(p, integrator, grid, s);
 }
 
 }  // namespace sixdof

@@ -1,0 +1,363 @@
+"""Test-only shims that let the REFERENCE's own Python example code run on plain numpy in the build container.
+
+Used by the fixture generators in this directory (make_falcon9_fixtures.py, make_apollo_fixtures.py) to produce golden
+vectors from the reference's functions themselves — examples/falcon9/{atmosphere,aero,propulsion,frames,rcs,sim}.py,
+examples/apollo-lander/sim.py — which are written against `jax.numpy` and the compiled `elodin` wheel, neither of which
+exists here.  Nothing below is product code and nothing under elodin_amd/ imports it; it never travels to
+the GPU box as anything but a dormant file (the generators need /root/reference).
+
+* `jax` / `jax.numpy` / `jax.random` / `jax.lax`: numpy with an ndarray subclass that has `.at[i].set/.add`, a loop
+  `vmap`, and `random.normal` returning zeros (the only call site, the wind gust, multiplies it by sigma = 0 in every
+  configuration used here; a non-zero sigma raises).
+* `elodin`: decorators that hand back the undecorated function (`el.map`, `el.system`), inert component declarations,
+  and the spatial types `Quaternion / SpatialTransform / SpatialMotion / SpatialForce / SpatialInertia` whose arithmetic
+  is NOT restated here but delegated to the pinned C oracle (oracle/sixdof_oracle.c: orc_quat_mul, orc_quat_inverse,
+  orc_quat_rotate, orc_quat_from_axis_angle, orc_transform_add_motion — K1-K8 + golden CSVs pin those), mirroring
+  libs/nox-py/src/spatial.rs:21-107,121-176,190-262,276-379,392-449.
+"""
+from __future__ import annotations
+
+import sys
+import types
+
+import numpy as np
+
+from oracle import oracle as orc
+
+
+# ---- jax.numpy over numpy ------------------------------------------------------------------------------------------
+
+class _At:
+    def __init__(self, arr):
+        self._a = arr
+
+    def __getitem__(self, idx):
+        return _AtIdx(self._a, idx)
+
+
+class _AtIdx:
+    def __init__(self, arr, idx):
+        self._a, self._i = arr, idx
+
+    def set(self, v):
+        out = np.array(self._a, dtype=np.float64, copy=True).view(JArray)
+        out[self._i] = v
+        return out
+
+    def add(self, v):
+        out = np.array(self._a, dtype=np.float64, copy=True).view(JArray)
+        out[self._i] = out[self._i] + v
+        return out
+
+
+class JArray(np.ndarray):
+    """ndarray with jax's functional-update surface."""
+
+    @property
+    def at(self):
+        return _At(self)
+
+
+def _wrap(x):
+    if isinstance(x, np.ndarray) and not isinstance(x, JArray):
+        return x.view(JArray)
+    if isinstance(x, tuple):
+        return tuple(_wrap(v) for v in x)
+    return x
+
+
+def _unwrap_args(a):
+    return a
+
+
+class _JnpModule(types.ModuleType):
+    """`jax.numpy`: every attribute is numpy's, results re-viewed as JArray; f64 everywhere (jax_enable_x64)."""
+
+    def __init__(self):
+        super().__init__("jax.numpy")
+        self.ndarray = JArray
+        self.float64, self.float32, self.int32, self.int64 = np.float64, np.float32, np.int32, np.int64
+        self.pi, self.inf, self.nan, self.newaxis = np.pi, np.inf, np.nan, np.newaxis
+        self.linalg = _Wrapped(np.linalg)
+
+    def __getattr__(self, name):
+        fn = getattr(np, name)
+        if not callable(fn) or isinstance(fn, type):
+            return fn
+
+        def call(*a, **k):
+            return _wrap(fn(*a, **k))
+        call.__name__ = name
+        return call
+
+    def array(self, x, dtype=None):
+        return np.array(x, dtype=np.float64 if dtype is None else dtype).view(JArray)
+
+    def asarray(self, x, dtype=None):
+        return np.asarray(x, dtype=np.float64 if dtype is None else dtype).view(JArray)
+
+    def zeros(self, shape, dtype=None):
+        return np.zeros(shape, dtype=np.float64 if dtype is None else dtype).view(JArray)
+
+    def ones(self, shape, dtype=None):
+        return np.ones(shape, dtype=np.float64 if dtype is None else dtype).view(JArray)
+
+    def full(self, shape, v, dtype=None):
+        return np.full(shape, v, dtype=np.float64 if dtype is None else dtype).view(JArray)
+
+    def arange(self, *a, **k):
+        return np.arange(*a, **k).astype(np.float64).view(JArray)
+
+
+class _Wrapped:
+    def __init__(self, mod):
+        self._m = mod
+
+    def __getattr__(self, name):
+        fn = getattr(self._m, name)
+
+        def call(*a, **k):
+            return _wrap(fn(*a, **k))
+        return call
+
+
+def _vmap(fn):
+    """jax.vmap over axis 0 of every argument, stacking every output."""
+    def mapped(*args):
+        outs = [fn(*[a[i] for a in args]) for i in range(len(args[0]))]
+        if isinstance(outs[0], tuple):
+            return tuple(np.stack([np.asarray(o[k]) for o in outs]).view(JArray) for k in range(len(outs[0])))
+        return np.stack([np.asarray(o) for o in outs]).view(JArray)
+    return mapped
+
+
+def _make_jax():
+    jax = types.ModuleType("jax")
+    jnp = _JnpModule()
+    jax.numpy = jnp
+    jax.Array = np.ndarray
+    jax.vmap = _vmap
+    jax.config = types.SimpleNamespace(update=lambda *a, **k: None)
+    rnd = types.ModuleType("jax.random")
+    rnd.key = lambda seed: int(seed)
+    rnd.PRNGKey = rnd.key
+    rnd.fold_in = lambda key, data: (int(key), int(data))
+    # the only consumer (examples/falcon9/sim.py:603-606 wind gust) scales the draw by sigma; the fixtures keep sigma = 0
+    rnd.normal = lambda key, shape=(): np.zeros(shape).view(JArray)
+    jax.random = rnd
+    lax = types.ModuleType("jax.lax")
+    lax.cond = lambda pred, t, f, *ops: (t(*ops) if bool(pred) else f(*ops))
+    lax.select = lambda p, a, b: _wrap(np.where(p, a, b))
+    jax.lax = lax
+    return jax, jnp, rnd, lax
+
+
+# ---- elodin over the pinned oracle ----------------------------------------------------------------------------------------
+
+def _v(x, n=None):
+    a = np.asarray(x, dtype=np.float64).reshape(-1)
+    assert n is None or a.size == n, (a.shape, n)
+    return a
+
+
+class Quaternion:                                        # libs/nox-py/src/spatial.rs:276-379, scalar-last [i,j,k,w]
+    def __init__(self, arr):
+        self._q = _v(arr, 4).copy()
+
+    @staticmethod
+    def identity():
+        return Quaternion([0.0, 0.0, 0.0, 1.0])
+
+    @staticmethod
+    def from_array(arr):
+        return Quaternion(arr)
+
+    @staticmethod
+    def from_axis_angle(axis, angle):                     # quaternion.rs:157-169
+        return Quaternion(orc.quat_from_axis_angle(_v(axis, 3), float(angle)))
+
+    def vector(self):
+        return self._q.copy().view(JArray)
+
+    def inverse(self):                                    # quaternion.rs:141-155: conj / |q|^2
+        return Quaternion(orc.quat_inverse(self._q))
+
+    def normalize(self):
+        return Quaternion(orc.quat_normalize(self._q))
+
+    def integrate_body(self, delta):                      # quaternion.rs:176-182
+        return Quaternion(orc.quat_integrate_body(self._q, _v(delta, 3)))
+
+    def __mul__(self, other):                             # Hamilton product, quaternion.rs:268-281
+        if isinstance(other, Quaternion):
+            return Quaternion(orc.quat_mul(self._q, other._q))
+        return NotImplemented
+
+    def __matmul__(self, other):                          # q (x) (v,0) (x) q^-1, quaternion.rs:283-305; spatial.rs:571-593
+        if isinstance(other, SpatialMotion):
+            return SpatialMotion(angular=self @ other.angular(), linear=self @ other.linear())
+        if isinstance(other, SpatialForce):
+            return SpatialForce(torque=self @ other.torque(), linear=self @ other.force())
+        return orc.quat_rotate(self._q, _v(other, 3)).view(JArray)
+
+
+class SpatialTransform:                                   # spatial.rs:21-107: [q(4), p(3)]
+    def __init__(self, arr=None, angular=None, linear=None):
+        if arr is not None:
+            a = _v(arr, 7)
+            self._q, self._p = Quaternion(a[:4]), a[4:].copy()
+        else:
+            self._q = Quaternion.identity() if angular is None else (angular if isinstance(angular, Quaternion) else Quaternion(angular))
+            self._p = np.zeros(3) if linear is None else _v(linear, 3).copy()
+
+    def angular(self):
+        return self._q
+
+    def linear(self):
+        return self._p.copy().view(JArray)
+
+    def asarray(self):
+        return np.concatenate([self._q._q, self._p])
+
+    def __add__(self, m):                                 # spatial.rs:530-549
+        assert isinstance(m, SpatialMotion)
+        return SpatialTransform(orc.transform_add_motion(self.asarray(), m.asarray()))
+
+
+class SpatialMotion:                                      # spatial.rs:121-176: [omega(3), v(3)]
+    def __init__(self, angular=None, linear=None):
+        self._w = np.zeros(3) if angular is None else _v(angular, 3).copy()
+        self._l = np.zeros(3) if linear is None else _v(linear, 3).copy()
+
+    def angular(self):
+        return self._w.copy().view(JArray)
+
+    def linear(self):
+        return self._l.copy().view(JArray)
+
+    def asarray(self):
+        return np.concatenate([self._w, self._l])
+
+    def __add__(self, o):
+        return SpatialMotion(self._w + o._w, self._l + o._l)
+
+
+class SpatialForce:                                       # spatial.rs:190-262: [tau(3), f(3)]
+    def __init__(self, arr=None, torque=None, linear=None):
+        if arr is not None:
+            a = _v(arr, 6)
+            torque, linear = a[:3], a[3:]
+        self._t = np.zeros(3) if torque is None else _v(torque, 3).copy()
+        self._f = np.zeros(3) if linear is None else _v(linear, 3).copy()
+
+    def torque(self):
+        return self._t.copy().view(JArray)
+
+    def force(self):
+        return self._f.copy().view(JArray)
+
+    linear = force
+
+    def asarray(self):
+        return np.concatenate([self._t, self._f])
+
+    def __add__(self, o):
+        return SpatialForce(torque=self._t + o._t, linear=self._f + o._f)
+
+
+class SpatialInertia:                                     # spatial.rs:392-449: inertia defaults to ones(3) * mass
+    def __init__(self, mass, inertia=None):
+        self._m = float(np.asarray(mass).reshape(-1)[0])
+        self._i = np.ones(3) * self._m if inertia is None else _v(inertia, 3).copy()
+
+    def mass(self):
+        return self._m
+
+    def inertia_diag(self):
+        return self._i.copy().view(JArray)
+
+    def asarray(self):
+        return np.concatenate([self._i, np.zeros(3), [self._m]])
+
+
+class _Query:
+    """el.Query stand-in for @el.system bodies: `q[0]` and `q.map(out_types, fn)` over ONE entity's values."""
+
+    def __init__(self, *values):
+        self._v = values
+
+    def __class_getitem__(cls, item):
+        return cls
+
+    def __getitem__(self, i):
+        return self._v[i]
+
+    def map(self, out_types, fn):
+        return fn(*self._v)
+
+
+class _Inert:
+    """Anything declarative (Component, ComponentType, PrimitiveType.F64, Integrator.SemiImplicit, Archetype ...)."""
+
+    def __init__(self, *a, **k):
+        self.args, self.kw = a, k
+
+    def __call__(self, *a, **k):
+        return _Inert(*a, **k)
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Inert(name)
+
+    def __getitem__(self, item):
+        return self
+
+    def __or__(self, other):
+        return self
+
+    __ror__ = __or__
+
+    def __mro_entries__(self, bases):
+        return (object,)
+
+
+def _make_elodin(jnp):
+    el = types.ModuleType("elodin")
+    el.__path__ = []   # so `import elodin.x` style probes fail cleanly
+    passthrough = lambda fn=None, **k: (fn if fn is not None else (lambda f: f))
+    el.map = passthrough
+    el.map_seq = passthrough
+    el.system = passthrough
+    el.dataclass = lambda cls: cls
+    el.Query = _Query
+    el.GraphQuery = _Query
+    for name in ("Quaternion", "SpatialTransform", "SpatialMotion", "SpatialForce", "SpatialInertia"):
+        setattr(el, name, globals()[name])
+    # well-known component aliases: used as annotations, and (rarely) as constructors of the underlying spatial type
+    el.WorldPos = SpatialTransform
+    el.WorldVel = SpatialMotion
+    el.WorldAccel = SpatialMotion
+    el.Force = SpatialForce
+    el.Inertia = SpatialInertia
+    for name in ("Component", "ComponentType", "PrimitiveType", "Integrator", "System", "World", "Body", "C", "Archetype",
+                 "SimulationTick", "SimulationTimeStep", "Seed", "Edge", "Time", "six_dof", "Panel", "Mesh", "Material",
+                 "Shape", "Color", "Glb", "Scene", "Line3d", "BodyAxes", "VectorArrow", "monte_carlo"):
+        setattr(el, name, _Inert(name))
+    el.linear = lambda v: SpatialMotion(linear=v)          # legacy helpers some examples use in spawn code
+    el.angular = lambda v: SpatialMotion(angular=v)
+    return el
+
+
+def install(example_dir: str):
+    """Inject the shims and put the reference example on sys.path.  Returns (jax, jnp, el)."""
+    jax, jnp, rnd, lax = _make_jax()
+    sys.modules["jax"] = jax
+    sys.modules["jax.numpy"] = jnp
+    sys.modules["jax.random"] = rnd
+    sys.modules["jax.lax"] = lax
+    el = _make_elodin(jnp)
+    sys.modules["elodin"] = el
+    if example_dir not in sys.path:
+        sys.path.insert(0, example_dir)
+    return jax, jnp, el
