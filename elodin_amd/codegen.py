@@ -265,7 +265,8 @@ def _emit_systems(systems) -> str:
         written = [t for t, _ in s.assign]
         if s.every > 1:     # wave-uniform cadence branch: its temporaries stay inside
             body = "\n".join(em.block(assign, "            ", written, scoped=True))
-            out.append(f"        if (tick % {s.every}ull == 0ull) {{  // {s.name}\n{body}\n        }}")
+            cond = f"tick % {s.every}ull == {s.phase}ull" + (f" || tick == {s.also_at}ull" if s.also_at is not None else "")
+            out.append(f"        if ({cond}) {{  // {s.name}\n{body}\n        }}")
         else:
             body = "\n".join(em.block(assign, "        ", written))
             out.append(f"        // {s.name}\n{body}")

@@ -4,10 +4,10 @@
 //   truth_playback | engine_response | attitude_control | mass_props | thrust_visualization
 //     | six_dof(lunar_gravity | apply_main_thrust | apply_rcs_torque, SemiImplicit) | ground_contact
 //     | derive_telemetry                                      examples/apollo-lander/sim.py:517-526
-// and closing the loop through a sidecar guidance process over UDP at 24 Hz
+// and closing the loop through a sidecar guidance process over UDP, polled from post_step once per telemetry batch
 //   examples/apollo-lander/controller/src/main.rs:188-262 (command), main.py:166-283 (post_step).
 // Here a rollout is one lane: its whole state lives in VGPRs for `n_ticks` ticks, the guidance law
-// runs in-line every `guidance_period` ticks, and a campaign of N rollouts is ceil(N/64) waves.
+// runs in-line at the batch ends whose end_tick is a multiple of `guidance_period`, and a campaign of N rollouts is ceil(N/64) waves.
 // Column layout: include/sixdof_apollo.h.  Visualisation-only systems are not modelled.
 //
 // The descent reference profile is identical for every rollout at a given tick, so the host
@@ -175,7 +175,12 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
         pitch = acos(clampd(1.0 - 2.0 * (q.i * q.i + q.j * q.j), -1.0, 1.0)) * (180.0 / kPi);
         const double altitude = p.z, vertical_speed = v.z;
 
-        // ---- post_step (main.py:166-283) ---------------------------------------------------------------
+        // ---- post_step (main.py:166-283), once per telemetry batch (impeller2_server.rs:553-678): the server loop runs
+        // ticks_per_telemetry ticks, then calls post_step(end_tick) with end_tick = ticks completed - 1 — that is the
+        // `tick` main.py sees (its t_s, its `tick % guidance_period_ticks`, its `tick >= max_ticks - 1`).  The last batch
+        // of a run is cut short at max_ticks.  Wave-uniform condition.
+        if (!(tick % P.ticks_per_telemetry == 0 || tick == P.max_ticks)) continue;
+        const uint64_t end_tick = tick - 1;
         const bool landed_now = landed > 0.5;
         {
             const double da = altitude - ref[0], dp = pitch - ref[2];
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
             e_pitch = fma(dp, dp, e_pitch);
             e_n += 1.0;
         }
-        if (tick % P.guidance_period == 0 && !landed_now) {  // tick is wave-uniform; landed is per lane
+        if (end_tick % P.guidance_period == 0 && !landed_now) {  // end_tick is wave-uniform; landed is per lane
             // controller/src/main.rs:188-262
             const double h_speed = sqrt(v.x * v.x + v.y * v.y);
             const double m_now = dry_mass + prop + rcs_prop;
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
         }
         throttle_cmd = last_throttle;
         setpoint = last_att;
-        if (!(emitted > 0.5) && (landed_now || tick >= P.max_ticks - 1)) {  // main.py:240-272
+        if (!(emitted > 0.5) && (landed_now || end_tick >= P.max_ticks - 1)) {  // main.py:240-272
             double* res = P.result + (size_t)i * APOLLO_N_RESULT;
             const double td = landed_now ? td_speed : fabs(vertical_speed);
             const double tdh = landed_now ? td_hspeed : sqrt(v.x * v.x + v.y * v.y);
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
             res[APOLLO_R_UPRIGHT_DOT] = upright;
             res[APOLLO_R_LANDED] = landed_now ? 1.0 : 0.0;
             res[APOLLO_R_SOFT_LANDING] = (landed_now && td <= 3.0 && tdh <= 1.0 && upright >= 0.94 && prop > 0.0) ? 1.0 : 0.0;
-            res[APOLLO_R_TICK] = (double)tick;
+            res[APOLLO_R_TICK] = (double)end_tick;   // the tick main.py's post_step was called with
             emitted = 1.0;
         }
     }

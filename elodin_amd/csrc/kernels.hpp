@@ -118,7 +118,7 @@ struct ApolloParams {
     uint64_t tick0;          // tick count before this launch
     uint64_t max_ticks;
     uint32_t guidance_period;
-    uint32_t pad;
+    uint32_t ticks_per_telemetry;  // post_step runs when a batch of this many ticks has completed (impeller2_server.rs:553-678)
     double dt;               // globals simulation_time_step
 };
 hipError_t launch_apollo(const ApolloParams& p, hipStream_t stream);

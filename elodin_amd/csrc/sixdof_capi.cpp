@@ -109,6 +109,7 @@ struct sixdof_handle {
     // rollout model (0 = none, 1 = Apollo lander)
     int model = 0;
     std::vector<double> ap_time, ap_alt, ap_rate, ap_pitch, ap_hspeed, ap_downrange;
+    uint32_t ap_ticks_per_telemetry = 3;
     uint32_t ap_guidance_period = 5;
     uint64_t ap_max_ticks = 0;
     double* d_tick_refs = nullptr;
@@ -858,6 +859,7 @@ int step_apollo(sixdof_handle* h, uint64_t n_ticks, uint64_t* launches) {
     P.n = static_cast<uint32_t>(h->desc.n_entities);
     P.max_ticks = h->ap_max_ticks;
     P.guidance_period = h->ap_guidance_period;
+    P.ticks_per_telemetry = h->ap_ticks_per_telemetry;
     P.dt = h->desc.simulation_time_step;
     const uint32_t K = h->desc.ticks_per_launch;
     if (K > h->tick_refs_cap) {
@@ -870,7 +872,8 @@ int step_apollo(sixdof_handle* h, uint64_t n_ticks, uint64_t* launches) {
     while (done < n_ticks) {
         const uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(K, n_ticks - done));
         for (uint32_t j = 0; j < k; j++) {
-            const double t_s = static_cast<double>(h->tick + done + j + 1) * (1.0 / 120.0);  // tick * SIM_TIME_STEP
+            // post_step's t_s = end_tick * SIM_TIME_STEP with end_tick = ticks completed - 1 (impeller2_server.rs:566,671)
+            const double t_s = static_cast<double>(h->tick + done + j) * (1.0 / 120.0);
             double* r = &refs[static_cast<size_t>(j) * 8];
             r[0] = ref_interp(t_s, h->ap_time, h->ap_alt);
             r[1] = ref_interp(t_s, h->ap_time, h->ap_rate);
@@ -912,6 +915,7 @@ int sixdof_set_model_apollo(sixdof_handle* h, const sixdof_apollo_tables* t) {
     h->ap_hspeed.assign(t->horizontal_speed_mps, t->horizontal_speed_mps + t->n);
     h->ap_downrange.assign(t->downrange_m, t->downrange_m + t->n);
     h->ap_guidance_period = t->guidance_period_ticks ? t->guidance_period_ticks : 5;
+    h->ap_ticks_per_telemetry = t->ticks_per_telemetry ? t->ticks_per_telemetry : 3;
     h->ap_max_ticks = t->max_ticks;
     h->model = 1;
     return SIXDOF_OK;

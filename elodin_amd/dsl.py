@@ -932,13 +932,20 @@ class TracedGraphFold:
 class System:
     """A per-entity system outside six_dof (`@el.map` in the reference, e.g. apollo-lander/sim.py:334-378,400-431):
     reads components by parameter name (plus `pos`, `vel`, `inertia`, `tick`), returns {component: new value}.
-    `every=n` runs it only on ticks divisible by n (wave-uniform branch), e.g. a 24 Hz guidance law in a 120 Hz sim."""
+    `every=n` runs it only on ticks with `tick % n == phase` (wave-uniform branch; `tick` counts completed ticks, 1-based) and,
+    if `also_at` is given, on that tick too.  That is how the reference's post_step cadence is written as a system: the
+    server loop runs `ticks_per_telemetry` ticks per batch and calls post_step(end_tick = ticks completed - 1) after each
+    batch, cutting the last batch at max_ticks (impeller2_server.rs:553-678) -> `every=ticks_per_telemetry, also_at=max_ticks`,
+    and a `tick % 5 == 0` test inside post_step becomes `every=15, phase=6` for a 3-tick batch."""
 
-    def __init__(self, fn: Callable, widths: Optional[Dict[str, int]] = None, every: int = 1, singletons: Sequence[str] = ()):
+    def __init__(self, fn: Callable, widths: Optional[Dict[str, int]] = None, every: int = 1, singletons: Sequence[str] = (),
+                 phase: int = 0, also_at: Optional[int] = None):
         self.fn = fn
         self.params = list(inspect.signature(fn).parameters)
         self.widths = dict(widths or {})
         self.every = int(every)
+        self.phase = int(phase) % max(self.every, 1)
+        self.also_at = None if also_at is None else int(also_at)
         # components queried on their own (`s: el.Query[el.Seed]` ... `s[0]`): a one-entity column every row may read
         self.singletons = tuple(singletons)
         self.__name__ = getattr(fn, "__name__", "system")
@@ -958,17 +965,17 @@ class Stages:
         return Stages((other.items if isinstance(other, Stages) else [other]) + self.items)
 
 
-def system(fn=None, every: int = 1, singletons: Sequence[str] = (), **widths):
+def system(fn=None, every: int = 1, singletons: Sequence[str] = (), phase: int = 0, also_at: Optional[int] = None, **widths):
     if fn is None:
-        return lambda f: System(f, widths, every, singletons)
-    return System(fn, widths, every, singletons)
+        return lambda f: System(f, widths, every, singletons, phase, also_at)
+    return System(fn, widths, every, singletons, phase, also_at)
 
 
 class TracedSystem:
     """One system as (target, expression) assignments over the register file / body state."""
 
     def __init__(self, sys_: System, table: ColumnTable, partial: Sequence[str] = (), after_six_dof: bool = False):
-        self.name, self.every = sys_.__name__, sys_.every
+        self.name, self.every, self.phase, self.also_at = sys_.__name__, sys_.every, sys_.phase, sys_.also_at
         pos, vel, inertia = _body_symbols()
         kwargs = {}
         for name in sys_.params:

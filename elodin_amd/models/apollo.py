@@ -21,7 +21,7 @@ from ..exec import HipExec, _raise
 
 DATA = Path(__file__).resolve().parents[1] / "data" / "apollo_reference.csv"
 
-SIMULATION_RATE_HZ, GUIDANCE_RATE_HZ = 120.0, 24.0
+SIMULATION_RATE_HZ, GUIDANCE_RATE_HZ, TELEMETRY_RATE_HZ = 120.0, 24.0, 40.0   # sim.py:15-18
 DPS_FTP_THROTTLE = 0.925
 # sorted names = column order of a plan table (sample.py:112) = include/sixdof_apollo.h APOLLO_P_*
 PARAM_NAMES = ["attitude_gain", "dry_mass_kg", "gravity_scale", "horizontal_gain", "init_altitude_m",
@@ -36,7 +36,8 @@ N_STATE, N_PARAMS, N_GUIDANCE, N_SCORE, N_RESULT = 16, 17, 8, 4, 12
 class Tables(C.Structure):  # sixdof_apollo_tables
     _fields_ = [("time_s", C.c_void_p), ("altitude_m", C.c_void_p), ("descent_rate_mps", C.c_void_p),
                 ("pitch_deg", C.c_void_p), ("horizontal_speed_mps", C.c_void_p), ("downrange_m", C.c_void_p),
-                ("n", C.c_uint32), ("guidance_period_ticks", C.c_uint32), ("max_ticks", C.c_uint64)]
+                ("n", C.c_uint32), ("guidance_period_ticks", C.c_uint32), ("max_ticks", C.c_uint64),
+                ("ticks_per_telemetry", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 def load_reference() -> Dict[str, np.ndarray]:
@@ -96,7 +97,7 @@ class ApolloExec(HipExec):
     MODEL_COLUMNS = ("apollo_state", "apollo_params", "apollo_guidance", "apollo_score", "apollo_result")
 
     def __init__(self, params: np.ndarray, *, ref=None, ticks_per_launch: int = 120, device: int = 0,
-                 max_ticks_override: int | None = None, first_row: int = 0):
+                 max_ticks_override: int | None = None, first_row: int = 0, ticks_per_telemetry: int | None = None):
         self.ref = ref or load_reference()
         cols = initial_columns(params, self.ref)
         n = cols["world_pos"].shape[0]
@@ -114,6 +115,10 @@ class ApolloExec(HipExec):
         t.n = len(self._tab[0])
         t.guidance_period_ticks = max(1, round(SIMULATION_RATE_HZ / GUIDANCE_RATE_HZ))
         t.max_ticks = max_ticks_override if max_ticks_override is not None else max_ticks(self.ref)
+        # world.run(simulation_rate=120, telemetry_rate=40) (main.py:274-283): the server loop runs 3 ticks per batch and
+        # calls post_step once per batch (impeller2_server.rs:553-678) — guidance, RMSE samples, result check happen there
+        t.ticks_per_telemetry = (ticks_per_telemetry if ticks_per_telemetry is not None
+                                 else max(1, round(SIMULATION_RATE_HZ / TELEMETRY_RATE_HZ)))
         fn = self._lib.sixdof_set_model_apollo
         fn.argtypes, fn.restype = [C.c_void_p, C.POINTER(Tables)], C.c_int
         rc = fn(self._h, C.byref(t))

@@ -478,8 +478,10 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
 
     `origin`: world_pos is stored RELATIVE to this ECEF point (None = plain ECEF like the reference).  f32 campaigns must
     use the pad as origin: an f32 ECEF coordinate has a 0.5 m ulp, larger than a millisecond of flight.
-    `scripted(xp, t) -> (engine_cmd[9], valve_cmd[8])` replaces the flight software by an open-loop script
-    (test_propulsion.py:113-135 `_script`) for the reference's open-loop known-answer tests.
+    `scripted(xp, t) -> (engine_cmd[9], valve_cmd[8])` — or a dict of any of the command columns engine_cmd, valve_cmd,
+    attitude_setpoint, ctrl_enable, fin_cmd, fsw_phase — replaces the flight software by an open-loop script
+    (test_propulsion.py:113-135 `_script`) for the reference's open-loop known-answer tests and for the plant
+    trajectories tests/golden/make_falcon9_fixtures.py records from the reference's own systems.
     Run the returned program with the semi-implicit integrator at 1 kHz (build_powered's default, sim.py:1476).
     """
     xp = dsl.np
@@ -753,7 +755,10 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
     if scripted is not None:
         @dsl.system
         def script(tick):
-            eng, valves = scripted(xp, tick * dt)
+            out = scripted(xp, tick * dt)
+            if isinstance(out, dict):     # any of the flight software's command columns (sim.py:97-137,285-300)
+                return out
+            eng, valves = out
             return {"engine_cmd": eng, "valve_cmd": valves}
         pre = [script] + pre
     elif fsw:

@@ -96,6 +96,13 @@ typedef struct sixdof_apollo_tables {
     uint32_t n;
     uint32_t guidance_period_ticks; /* round(120 / 24) = 5 */
     uint64_t max_ticks;             /* result is emitted at tick >= max_ticks - 1 if not landed */
+    /* Telemetry batch of the server loop (libs/nox-py/src/impeller2_server.rs:553-678,790-791): the world runs
+     * `ticks_per_telemetry` = simulation_rate / telemetry_rate = 120 / 40 = 3 ticks back to back, THEN main.py's post_step
+     * is called once with end_tick = (ticks completed) - 1.  So the guidance exchange (end_tick % 5 == 0), the RMSE
+     * samples and the result check happen at batch ends only, and the command columns change between batches only.
+     * 0 = 3.  1 reproduces a post_step after every tick. */
+    uint32_t ticks_per_telemetry;
+    uint32_t reserved;
 } sixdof_apollo_tables;
 
 #ifdef __cplusplus

@@ -19,14 +19,14 @@ class _World(C.Structure):
                                            "guidance", "score", "result", "ref_time", "ref_altitude", "ref_rate",
                                            "ref_pitch", "ref_hspeed", "ref_downrange")] +
                 [("n_ref", C.c_uint32), ("guidance_period", C.c_uint32), ("max_ticks", C.c_uint64),
-                 ("tick", C.c_uint64), ("simulation_time_step", C.c_double)])
+                 ("tick", C.c_uint64), ("simulation_time_step", C.c_double), ("ticks_per_telemetry", C.c_uint32)])
 
 
 class ApolloOracle:
     """Takes the same initial columns as the product (packed apollo_state etc.), unpacks them into the
     reference's separate components, steps on the CPU, and re-packs for comparison."""
 
-    def __init__(self, cols, ref, *, max_ticks, guidance_period=5, simulation_time_step=0.008333333):
+    def __init__(self, cols, ref, *, max_ticks, guidance_period=5, simulation_time_step=0.008333333, ticks_per_telemetry=3):
         c = lambda a: np.array(a, dtype=np.float64, order="C")
         self.world_pos, self.world_vel, self.inertia = c(cols["world_pos"]), c(cols["world_vel"]), c(cols["inertia"])
         n = self.n = self.world_pos.shape[0]
@@ -57,6 +57,7 @@ class ApolloOracle:
         w.n_ref = len(self._ref[0])
         w.guidance_period, w.max_ticks, w.tick = guidance_period, max_ticks, 0
         w.simulation_time_step = simulation_time_step
+        w.ticks_per_telemetry = ticks_per_telemetry
         lib = orc.lib()
         lib.apollo_step.argtypes = [C.POINTER(_World), C.c_uint64, C.c_int]
         lib.apollo_step.restype = C.c_int

@@ -14,12 +14,15 @@
  *   examples/apollo-lander/controller/src/main.rs:100-262  guidance law (command, ThrottleLogic, tilt caps)
  *   examples/apollo-lander/main.py:147-163,166-283        post_step: state packing, 3-deg attitude slew, result
  *
- * PARITY UNPINNED: the reference holds no golden trajectory for this example, and its closed loop is
- * paced by wall-clock UDP lock-step (not reproducible bit for bit even by itself).  Documented
- * deviations of this restatement (shared with the GPU model so the two can be compared):
- *   - post_step runs after EVERY tick (the reference runs it once per telemetry batch of 3 ticks);
- *     guidance fires when tick % guidance_period == 0 (5 ticks = 24 Hz) and the vehicle has not landed;
- *   - the visualisation-only systems (thrust_visualization, truth_playback) are not modelled.
+ *   libs/nox-py/src/impeller2_server.rs:553-678,790-791    server loop: ticks_per_telemetry (= 120 / 40 = 3) ticks per
+ *                                                          batch, then post_step(end_tick = ticks completed - 1)
+ *
+ * PINNED (tests/test_apollo_reference_fixtures.py) against tests/golden/apollo_reference_runs.json: full descents flown by
+ * the reference's OWN sim.py systems and main.py post_step, executed on numpy under tests/golden/refshim.py with the
+ * server loop's batching restated from impeller2_server.rs.  NOT pinned by reference code: the guidance law itself
+ * (controller/src/main.rs is Rust with no tests or vectors; the fixture generator carries a line-by-line Python port of
+ * `command()` as the stand-in for the UDP bridge), and the lock-step timing of that bridge (assumed never to time out).
+ * The visualisation-only systems (thrust_visualization, truth_playback) are not modelled.
  */
 #include "apollo_oracle.h"
 
@@ -296,7 +299,7 @@ static void tick_one(apollo_world* w, uint64_t i) {
     }
 }
 
-/* main.py:166-283 post_step for one rollout, `tick` = tick count after the step */
+/* main.py:166-283 post_step for one rollout; `tick` = the end_tick the server loop hands over (ticks completed - 1) */
 static void post_step_one(apollo_world* w, uint64_t i, uint64_t tick) {
     double* gd = w->guidance + APOLLO_N_GUIDANCE * i;
     double* sc = w->score + APOLLO_N_SCORE * i;
@@ -350,10 +353,13 @@ int apollo_step(apollo_world* w, uint64_t n_ticks, int threads) {
 #pragma omp parallel for num_threads(threads) schedule(static)
     for (int64_t i = 0; i < (int64_t)w->n; i++) {
         uint64_t tick = w->tick;
+        const uint64_t tpt = w->ticks_per_telemetry ? w->ticks_per_telemetry : 3;
         for (uint64_t t = 0; t < n_ticks; t++) {
-            tick += 1;
+            tick += 1;   /* ticks completed */
             tick_one(w, (uint64_t)i);
-            post_step_one(w, (uint64_t)i, tick);
+            /* impeller2_server.rs:553-678: post_step once per batch of ticks_per_telemetry ticks (the last batch is cut
+             * at max_ticks), with end_tick = batch start + batch - 1 = ticks completed - 1 */
+            if (tick % tpt == 0 || tick == w->max_ticks) post_step_one(w, (uint64_t)i, tick - 1);
         }
     }
     w->tick += n_ticks;

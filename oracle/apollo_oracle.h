@@ -21,6 +21,7 @@ typedef struct apollo_world {
     uint64_t max_ticks;
     uint64_t tick;
     double simulation_time_step;
+    uint32_t ticks_per_telemetry; /* 0 = 3 (simulation_rate 120 / telemetry_rate 40, main.py:274-283) */
 } apollo_world;
 
 int apollo_step(apollo_world* w, uint64_t n_ticks, int threads);

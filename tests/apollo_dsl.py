@@ -113,9 +113,14 @@ def components_from(cols):
 # ---- the closed loop: main.py's post_step + the external guidance computer (controller/src/main.rs) as systems ------
 
 def closed_loop_systems(ref, max_ticks):
-    """Guidance (24 Hz), command hold and campaign scoring as dsl systems.  `ref` = elodin_amd.models.apollo
-    reference tables.  Extra components: guid[8] = last_throttle, last_att(4), last_rate, ftp_latched, emitted;
-    score[4]; result[12]; cfg2[4] = track_gain, vertical_gain, horizontal_gain, 0."""
+    """main.py's post_step — guidance exchange, command hold, campaign scoring — as dsl systems on the reference's cadence:
+    the server loop runs ticks_per_telemetry = 120 / 40 = 3 ticks per batch and calls post_step(end_tick = ticks completed - 1)
+    after each (impeller2_server.rs:553-678; last batch cut at max_ticks), so everything here runs when `tick % 3 == 0` and
+    sees the reference's tick as `tick - 1`; the exchange `end_tick % 5 == 0` is `tick % 15 == 6`.  `ref` =
+    elodin_amd.models.apollo reference tables.  Extra components: guid[8] = last_throttle, last_att(4), last_rate,
+    ftp_latched, emitted; score[4]; result[12]; cfg2[4] = track_gain, vertical_gain, horizontal_gain, 0."""
+    TPT, PERIOD = 3, 5
+    phase = next(k for k in range(TPT, TPT * PERIOD + 1, TPT) if (k - 1) % PERIOD == 0) % (TPT * PERIOD)   # = 6
     T, ALT, RATE, PITCH = ref["time_s"], ref["altitude_m"], ref["descent_rate_mps"], ref["pitch_deg"]
     HS, DR = ref["horizontal_speed_mps"], ref["downrange_m"]
     C_MIN_THROTTLE, C_FTP, C_EROSION = 4670.0 / 45040.0, 0.925, 0.65
@@ -124,9 +129,9 @@ def closed_loop_systems(ref, max_ticks):
     def clamp(x, lo, hi):
         return np_.minimum(np_.maximum(x, lo), hi)
 
-    @dsl.system(every=5)
+    @dsl.system(every=TPT * PERIOD, phase=phase, also_at=max_ticks if (max_ticks - 1) % PERIOD == 0 else None)
     def guidance(tick, pos, vel, propellant, rcs_propellant, landed, cfg, cfg2, guid):
-        t_s = tick * SIM_TIME_STEP
+        t_s = (tick - 1.0) * SIM_TIME_STEP
         altitude, vertical_speed = pos.linear()[2], vel.linear()[2]
         vx, vy = vel.linear()[0], vel.linear()[1]
         ref_alt, ref_rate = np_.interp(t_s, T, ALT), np_.interp(t_s, T, RATE)
@@ -199,18 +204,19 @@ def closed_loop_systems(ref, max_ticks):
         return {"guid": np_.array([np_.where(fire, throttle, guid[0]), out_att[0], out_att[1], out_att[2], out_att[3],
                                    np_.where(fire, rate_cmd, guid[5]), np_.where(fire, lat, guid[6]), guid[7]])}
 
-    @dsl.system
+    @dsl.system(every=TPT, also_at=max_ticks)
     def hold_commands(guid):                                  # main.py:232-237: written back every post_step
         return {"throttle_cmd": guid[0], "attitude_setpoint": np_.array([guid[1], guid[2], guid[3], guid[4]])}
 
-    @dsl.system
+    @dsl.system(every=TPT, also_at=max_ticks)
     def score_and_result(tick, pos, vel, pitch, propellant, rcs_propellant, landed, touchdown, score, result, result2, guid):
-        t_s = tick * SIM_TIME_STEP
+        end_tick = tick - 1.0                                 # what post_step is called with
+        t_s = end_tick * SIM_TIME_STEP
         da = pos.linear()[2] - np_.interp(t_s, T, ALT)
         dp = pitch - np_.abs(np_.interp(t_s, T, PITCH))
         e_alt, e_pitch, e_n = score[0] + da * da, score[1] + dp * dp, score[2] + 1.0
         is_landed = landed > 0.5
-        emit = np_.logical_and(np_.logical_not(guid[7] > 0.5), np_.logical_or(is_landed, tick >= float(max_ticks - 1)))
+        emit = np_.logical_and(np_.logical_not(guid[7] > 0.5), np_.logical_or(is_landed, end_tick >= float(max_ticks - 1)))
         h_speed = np_.linalg.norm(vel.linear()[:2])
         td = np_.where(is_landed, touchdown[0], np_.abs(vel.linear()[2]))
         tdh = np_.where(is_landed, touchdown[1], h_speed)
@@ -220,7 +226,7 @@ def closed_loop_systems(ref, max_ticks):
                                np_.logical_and(np_.logical_and(tdh <= 1.0, upright >= 0.94), propellant > 0.0))
         new = [td, tdh, propellant, rcs_propellant, np_.sqrt(e_alt / nn), np_.sqrt(e_pitch / nn),
                np_.hypot(pos.linear()[0], pos.linear()[1]), upright, np_.where(is_landed, 1.0, 0.0),
-               np_.where(soft, 1.0, 0.0), tick, 0.0]
+               np_.where(soft, 1.0, 0.0), end_tick, 0.0]
         return {"score": np_.array([e_alt, e_pitch, e_n, 0.0]),
                 "result": np_.array([np_.where(emit, new[k], result[k]) for k in range(8)]),
                 "result2": np_.array([np_.where(emit, new[8 + k], result2[k]) for k in range(4)]),

@@ -146,7 +146,7 @@ def _run_systems(systems, pos, vel, inertia, comps, table, tick, accel=None):
             "I": ("inertia", {"x": 0, "y": 1, "z": 2})}
     arrays = {"pos": pos, "vel": vel, "inertia": inertia}
     for s in systems:
-        if s.every > 1 and tick % s.every != 0:
+        if s.every > 1 and tick % s.every != s.phase and tick != s.also_at:
             continue
         lv = _leaf_arrays(pos, vel, inertia, comps, table, tick, accel)
         vals = _eval([e for _, e in s.assign], lv, pos.shape[0])

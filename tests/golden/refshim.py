@@ -9,7 +9,9 @@ the GPU box as anything but a dormant file (the generators need /root/reference)
 * `jax` / `jax.numpy` / `jax.random` / `jax.lax`: numpy with an ndarray subclass that has `.at[i].set/.add`, a loop
   `vmap`, and `random.normal` returning zeros (the only call site, the wind gust, multiplies it by sigma = 0 in every
   configuration used here; a non-zero sigma raises).
-* `elodin`: decorators that hand back the undecorated function (`el.map`, `el.system`), inert component declarations,
+* `elodin`: decorators that hand back the undecorated function in a callable, `|`-pipeable wrapper (`el.map`,
+  `el.system`, `el.six_dof` remembering its effectors), a World that remembers what was spawned, a tiny
+  `el.monte_carlo` (params context in, result(...) out), inert declarations for everything else,
   and the spatial types `Quaternion / SpatialTransform / SpatialMotion / SpatialForce / SpatialInertia` whose arithmetic
   is NOT restated here but delegated to the pinned C oracle (oracle/sixdof_oracle.c: orc_quat_mul, orc_quat_inverse,
   orc_quat_rotate, orc_quat_from_axis_angle, orc_transform_add_motion — K1-K8 + golden CSVs pin those), mirroring
@@ -297,7 +299,7 @@ class _Query:
 
 
 class _Inert:
-    """Anything declarative (Component, ComponentType, PrimitiveType.F64, Integrator.SemiImplicit, Archetype ...)."""
+    """Anything declarative (ComponentType, PrimitiveType.F64, Integrator.SemiImplicit, Archetype, s10 recipes ...)."""
 
     def __init__(self, *a, **k):
         self.args, self.kw = a, k
@@ -322,14 +324,138 @@ class _Inert:
         return (object,)
 
 
+class Component:
+    """el.Component(name, type, metadata=...): only the name matters here."""
+
+    def __init__(self, name, ty=None, metadata=None, **k):
+        self.name, self.metadata = name, metadata or {}
+
+
+def component_name(annot):
+    """`ty.Annotated[jax.Array, el.Component("thrust", ...)]` -> "thrust"."""
+    for m in getattr(annot, "__metadata__", ()):
+        if isinstance(m, Component):
+            return m.name
+    raise KeyError(f"no el.Component in {annot!r}")
+
+
+class _Sys:
+    """What @el.map / @el.system hand back: the undecorated function, callable, and pipeable with `|`."""
+
+    def __init__(self, fn):
+        self.fn, self.__name__ = fn, getattr(fn, "__name__", "system")
+
+    def __call__(self, *a, **k):
+        return self.fn(*a, **k)
+
+    def __or__(self, other):
+        return _Pipe(_flatten(self) + _flatten(other))
+
+    def __ror__(self, other):
+        return _Pipe(_flatten(other) + _flatten(self))
+
+
+class _SixDof(_Sys):
+    """el.six_dof(time_step=None, sys=None, integrator=...) (six_dof.rs:161-203): remembered, run by the generator."""
+
+    def __init__(self, time_step=None, sys=None, integrator=None):
+        self.time_step, self.integrator, self.__name__ = time_step, integrator, "six_dof"
+        self.effectors = _flatten(sys) if sys is not None else []
+        self.fn = None
+
+
+class _Pipe(_Sys):
+    def __init__(self, systems):
+        self.systems, self.fn, self.__name__ = list(systems), None, "pipe"
+
+    def names(self):
+        return [s.__name__ for s in self.systems]
+
+    def __getitem__(self, name):
+        return next(s for s in self.systems if s.__name__ == name)
+
+
+def _flatten(x):
+    if x is None or isinstance(x, _Inert):
+        return []
+    if isinstance(x, _Pipe):
+        return list(x.systems)
+    return [x]
+
+
+class _Body:
+    def __init__(self, world_pos=None, world_vel=None, inertia=None, **k):
+        self.world_pos = world_pos if world_pos is not None else SpatialTransform()
+        self.world_vel = world_vel if world_vel is not None else SpatialMotion()
+        self.inertia = inertia if inertia is not None else SpatialInertia(1.0)
+
+
+class World:
+    """el.World: remembers what was spawned (component name -> initial value per entity), ignores the rest."""
+
+    def __init__(self, *a, **k):
+        self.entities = {}
+
+    def spawn(self, components, name=None, **k):
+        comps = {}
+        for c in (components if isinstance(components, (list, tuple)) else [components]):
+            if isinstance(c, _Body):
+                comps.update(world_pos=c.world_pos, world_vel=c.world_vel, inertia=c.inertia)
+            elif isinstance(c, tuple) and len(c) == 2 and isinstance(c[0], str):
+                comps[c[0]] = c[1]
+        self.entities[name or f"entity{len(self.entities)}"] = comps
+        return len(self.entities)
+
+    def __getattr__(self, name):      # insert / recipe / schematic / run / ...: nothing to do without a runtime
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return lambda *a, **k: None
+
+
+def _C(annot, value):
+    """el.C(ComponentType, value) -> (component name, value)."""
+    try:
+        return (component_name(annot), value)
+    except KeyError:
+        return ("?", value)
+
+
+class _McParams(dict):
+    db_path = None
+
+
+def _make_monte_carlo():
+    mc = types.ModuleType("elodin.monte_carlo")
+    mc.CONTEXT = {}       # the current rollout's parameter overrides (set by the generator before importing main.py)
+    mc.RESULTS = []       # what the sim handed to el.monte_carlo.result(...)
+
+    class Param:
+        def __init__(self, ty=float, default=None, min=None, max=None, **k):
+            self.ty, self.default, self.min, self.max = ty, default, min, max
+
+    def params_spec(**spec):
+        return dict(spec)
+
+    def params(spec=None):
+        out = _McParams({k: p.default for k, p in (spec or {}).items()})
+        out.update(mc.CONTEXT)          # defaults overlaid by the run's context, like the reference
+        return out
+
+    mc.Param, mc.Params, mc.params_spec, mc.params = Param, _McParams, params_spec, params
+    mc.port = lambda name, default=0: default
+    mc.result = lambda **kw: mc.RESULTS.append(dict(kw))
+    return mc
+
+
 def _make_elodin(jnp):
     el = types.ModuleType("elodin")
     el.__path__ = []   # so `import elodin.x` style probes fail cleanly
-    passthrough = lambda fn=None, **k: (fn if fn is not None else (lambda f: f))
-    el.map = passthrough
-    el.map_seq = passthrough
-    el.system = passthrough
-    el.dataclass = lambda cls: cls
+    wrap = lambda fn=None, **k: (_Sys(fn) if fn is not None else (lambda f: _Sys(f)))
+    el.map = wrap
+    el.map_seq = wrap
+    el.system = wrap
+    import dataclasses
+    el.dataclass = dataclasses.dataclass
     el.Query = _Query
     el.GraphQuery = _Query
     for name in ("Quaternion", "SpatialTransform", "SpatialMotion", "SpatialForce", "SpatialInertia"):
@@ -340,10 +466,12 @@ def _make_elodin(jnp):
     el.WorldAccel = SpatialMotion
     el.Force = SpatialForce
     el.Inertia = SpatialInertia
-    for name in ("Component", "ComponentType", "PrimitiveType", "Integrator", "System", "World", "Body", "C", "Archetype",
-                 "SimulationTick", "SimulationTimeStep", "Seed", "Edge", "Time", "six_dof", "Panel", "Mesh", "Material",
-                 "Shape", "Color", "Glb", "Scene", "Line3d", "BodyAxes", "VectorArrow", "monte_carlo"):
+    el.Component, el.World, el.Body, el.C, el.six_dof = Component, World, _Body, _C, _SixDof
+    for name in ("ComponentType", "PrimitiveType", "Integrator", "System", "Archetype", "StepContext",
+                 "SimulationTick", "SimulationTimeStep", "Seed", "Edge", "Time", "Panel", "Mesh", "Material",
+                 "Shape", "Color", "Glb", "Scene", "Line3d", "BodyAxes", "VectorArrow", "s10"):
         setattr(el, name, _Inert(name))
+    el.monte_carlo = _make_monte_carlo()
     el.linear = lambda v: SpatialMotion(linear=v)          # legacy helpers some examples use in spawn code
     el.angular = lambda v: SpatialMotion(angular=v)
     return el
@@ -358,6 +486,7 @@ def install(example_dir: str):
     sys.modules["jax.lax"] = lax
     el = _make_elodin(jnp)
     sys.modules["elodin"] = el
+    sys.modules["elodin.monte_carlo"] = el.monte_carlo
     if example_dir not in sys.path:
         sys.path.insert(0, example_dir)
     return jax, jnp, el

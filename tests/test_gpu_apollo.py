@@ -7,7 +7,7 @@ import pytest
 from elodin_amd import monte_carlo as mc
 from elodin_amd.models import apollo
 from oracle.apollo import ApolloOracle
-from tests import parity
+from tests import apollo_fixture_util as fx, parity
 
 pytestmark = pytest.mark.gpu
 PLANS = Path(__file__).resolve().parent / "golden" / "plans"
@@ -32,7 +32,8 @@ def _compare(hip, ref, rtol=parity.F64_RTOL):
 
 @pytest.mark.parametrize("ticks_per_launch", [1, 7, 120])
 def test_apollo_512_rollouts_3000_ticks(ticks_per_launch):
-    """Braking phase: 512 LHS rollouts of the reference's spec, 25 s of flight, guidance at 24 Hz."""
+    """Braking phase: 512 LHS rollouts of the reference's spec, 25 s of flight (guidance every 15 ticks: post_step runs
+    once per 3-tick telemetry batch and exchanges when end_tick % 5 == 0)."""
     ref_tab = apollo.load_reference()
     P = _plan_table("apollo_512")
     hip = apollo.ApolloExec(P, ref=ref_tab, ticks_per_launch=ticks_per_launch)
@@ -67,6 +68,54 @@ def test_apollo_full_descent_results():
     rel = np.abs(res_h[:, cont] - res_o[:, cont]) / np.maximum(np.abs(res_o[:, cont]), 1e-3)
     print("apollo full descent: worst result rel err", rel.max(), "soft fraction", res_h[:, 9].mean())
     assert rel.max() < 1e-6
+
+
+@pytest.mark.parametrize("ticks_per_launch", [1, 240])
+def test_hip_kernel_follows_the_reference_flown_descents(ticks_per_launch):
+    """tests/golden/apollo_reference_runs.json: four full descents flown by the reference's own sim.py systems and
+    main.py post_step on numpy (tests/golden/make_apollo_fixtures.py), batched like the server loop.  The HIP rollout
+    kernel must pass through every checkpoint and emit the same result record on the same post_step tick."""
+    ref_tab = apollo.load_reference()
+    hip = apollo.ApolloExec(fx.param_table(), ref=ref_tab, ticks_per_launch=ticks_per_launch)
+    worst, done = {}, 0
+    ticks = fx.checkpoint_ticks() if ticks_per_launch > 1 else fx.checkpoint_ticks()[:2]   # K=1: first 6,000 ticks
+    for t in ticks:
+        hip.run(t - done)
+        done = t
+        get = lambda k: getattr(hip, k) if k in ("world_pos", "world_vel", "inertia") else hip.model[k]
+        for k, e in fx.compare_state(get, t).items():
+            worst[k] = max(worst.get(k, 0.0), e)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    print(f"apollo HIP kernel (K={ticks_per_launch}) vs reference-flown descents:", ", ".join(f"{k} {e:.1e}" for k, e in top))
+    assert max(worst.values()) < parity.F64_RTOL, top
+    if ticks_per_launch > 1:
+        res = fx.compare_results(hip.result)     # asserts landed / soft_landing / emission tick equal
+        print("result records:", {k: f"{e:.1e}" for k, e in res.items()})
+        assert max(res.values()) < 1e-7, res
+
+
+def test_config4_full_size_8192_rollouts_10000_steps():
+    """BASELINE config 4 at its stated size: 8,192 rollouts (spec.toml's 17 variables, LHS, seed 19690720, n_samples
+    raised to 8,192) x 10,000 steps against the pinned CPU oracle on all host threads, every column, 1e-9."""
+    import os
+    ref_tab = apollo.load_reference()
+    spec = mc.load_spec(PLANS / "apollo.toml")
+    spec["monte_carlo"]["n_samples"] = 8192
+    P = mc.materialize(spec).table()
+    assert P.shape == (8192, 17)
+    hip = apollo.ApolloExec(P, ref=ref_tab, ticks_per_launch=1000)
+    orc_w = ApolloOracle(apollo.initial_columns(P, ref_tab), ref_tab, max_ticks=apollo.max_ticks(ref_tab))
+    worst = {}
+    for _ in range(4):
+        hip.run(2500)
+        orc_w.step(2500, threads=os.cpu_count() or 8)
+        for k, e in _compare(hip, orc_w).items():
+            worst[k] = max(worst.get(k, 0.0), e)
+    print("config 4 at 8,192 x 10,000:", worst)
+    assert max(worst.values()) < parity.F64_RTOL, worst
+    assert np.array_equal(hip.model["apollo_guidance"][:, 6:], orc_w.guidance[:, 6:])
+    assert np.array_equal(hip.model["apollo_score"][:, 2], orc_w.score[:, 2])
+    assert hip.tick == orc_w.tick == 10_000
 
 
 def test_apollo_requires_model_columns_and_semi_implicit():
