@@ -4,7 +4,9 @@ post-processing (`elodin monte-carlo report`, example `hooks/score.py` / `report
     <out>/plan.csv                       the plan that was flown (monte_carlo.Plan.to_csv, byte-identical to sample.py's)
     <out>/runs/<run_id>/result.json      the sim's own result record of that rollout (what e.g. apollo-lander/main.py
                                          writes at touchdown; here: the rollout's row of in-kernel result scoring)
+    <out>/runs/<run_id>/post_run_context.json  what the runner hands the post_run hook (lib.rs:2264-2277)
     <out>/runs/<run_id>/post_run_result.json   the scoring hook's outcome, when a `post_run` hook is given
+    <out>/campaign_hook_context.json     what the runner hands the post_campaign hook (lib.rs:1335-1347)
     <out>/results.csv                    one row per run: fixed columns + sorted hook scalar columns (lib.rs:3109-3187)
     <out>/summary.json                   CampaignSummary (lib.rs:348-376, built like summarize_campaign lib.rs:1715-1787)
 
@@ -179,6 +181,52 @@ def summarize_campaign(out_dir, metrics: Sequence[RunMetric], started_at: _dt.da
     }
 
 
+def load_hook(path, name: str) -> Callable:
+    """A lifecycle hook from a user file, loaded the way the reference's hook runner does (`python -m
+    elodin.monte_carlo.run_hook HOOK.py post_run|post_campaign CTX.json`, libs/nox-py/python/elodin/monte_carlo/run_hook.py:12-58):
+    the file's own directory goes on sys.path so sibling helpers (`mc_metrics.py`) import, a missing function is an error."""
+    import importlib.util
+    import sys
+    path = Path(path)
+    spec = importlib.util.spec_from_file_location(f"elodin_user_monte_carlo_hook_{path.stem}", path)
+    if spec is None or spec.loader is None:
+        raise RuntimeError(f"could not load hook: {path}")
+    module = importlib.util.module_from_spec(spec)
+    hook_dir = str(path.resolve().parent)
+    if hook_dir not in sys.path:
+        sys.path.insert(0, hook_dir)
+    spec.loader.exec_module(module)
+    hook = getattr(module, name, None)
+    if hook is None or not callable(hook):
+        raise RuntimeError(f"hook {path} does not define a callable `{name}`")
+    return hook
+
+
+def _namespace(value):
+    """run_hook.py:26-31: the hook sees its JSON context as nested attribute namespaces."""
+    if isinstance(value, dict):
+        return SimpleNamespace(**{k: _namespace(v) for k, v in value.items()})
+    if isinstance(value, list):
+        return [_namespace(v) for v in value]
+    return value
+
+
+def run_post_campaign(out_dir, hook) -> Any:
+    """The post_campaign step of `elodin monte-carlo run` (lib.rs:1335-1347): write campaign_hook_context.json, call
+    `hook(ctx)` (a callable or a path to a hook file defining `post_campaign`), write post_campaign_result.json."""
+    out = Path(out_dir)
+    if not callable(hook):
+        hook = load_hook(hook, "post_campaign")
+    payload = {"out_dir": str(out), "results": str(out / "results.csv"), "perf": str(out / "perf.csv"), "memory": None,
+               "resources": str(out / "resources.csv"), "summary": str(out / "summary.json")}
+    context = out / "campaign_hook_context.json"
+    context.write_text(json.dumps(payload, indent=2) + "\n")
+    result = hook(_namespace(payload))
+    if result is not None:
+        context.with_name("post_campaign_result.json").write_text(json.dumps(_jsonable(result), indent=2, sort_keys=True))
+    return result
+
+
 def write_campaign(out_dir, plan, results: np.ndarray, result_names: Sequence[str], *, wall_ms: float, workers: int = 1,
                    post_run: Optional[Callable] = None, result_record: Optional[Callable] = None,
                    failed_rows: Optional[np.ndarray] = None, rows_per_worker: Optional[int] = None,
@@ -188,8 +236,10 @@ def write_campaign(out_dir, plan, results: np.ndarray, result_names: Sequence[st
     plan            monte_carlo.Plan (run ids, seeds, parameters) — row i of `results` belongs to plan.run_ids[i]
     results         [n_runs, len(result_names)] in-kernel result rows (e.g. models.apollo.RESULT_NAMES)
     result_record   (row dict) -> dict written as result.json (default: the row with 0/1 flags left numeric)
-    post_run        scoring hook with the reference's signature `post_run(ctx) -> dict`, ctx.run_dir / ctx.run_id /
-                    ctx.params; its outcome decides pass / valid like lib.rs:2269-2290
+    post_run        scoring hook with the reference's signature `post_run(ctx) -> dict` — a callable, or the path of a hook
+                    file defining `post_run` (e.g. the reference's examples/apollo-lander/hooks/score.py, unmodified).  It
+                    gets the context the runner writes to post_run_context.json (lib.rs:2264-2277: run_id, params, meta,
+                    metrics, db_path, run_dir); its outcome decides pass / valid like lib.rs:2269-2290
     failed_rows     bool [n_runs]: rollouts whose state went non-finite (sixdof_count_nonfinite) -> status "failed"
     """
     out = Path(out_dir)
@@ -202,6 +252,8 @@ def write_campaign(out_dir, plan, results: np.ndarray, result_names: Sequence[st
     if results.shape[0] != n:
         raise ValueError(f"{results.shape[0]} result rows for a plan of {n} runs")
     per_run_ms = int(round(float(wall_ms) / max(n, 1)))
+    if post_run is not None and not callable(post_run):
+        post_run = load_hook(post_run, "post_run")
     metrics: List[RunMetric] = []
     for i, run_id in enumerate(plan.run_ids):
         run_dir = out / "runs" / run_id
@@ -215,8 +267,17 @@ def write_campaign(out_dir, plan, results: np.ndarray, result_names: Sequence[st
                       worker_id=(i // rows_per_worker) if rows_per_worker else 0,
                       db_path=str(Path("runs") / run_id / "db"), run_dir=str(run_dir))
         if post_run is not None and not bad:
-            ctx = SimpleNamespace(run_dir=str(run_dir), run_id=run_id, out_dir=str(out), seed=int(plan.seeds[i]),
-                                  params={k[len("param."):]: v for k, v in plan.rows[i].items() if k.startswith("param.")})
+            row_i = plan.rows[i]
+            payload = {"run_id": run_id,
+                       "params": {k[len("param."):]: _plan_cell(v) for k, v in row_i.items() if k.startswith("param.")},
+                       "meta": {k[len("meta."):]: _plan_cell(v) for k, v in row_i.items() if k.startswith("meta.")},
+                       "metrics": {"run_id": run_id, "status": m.status, "exit_ok": m.exit_ok, "wall_ms": m.wall_ms,
+                                   "worker_id": m.worker_id, "db_path": m.db_path, "run_dir": m.run_dir},
+                       "db_path": m.db_path, "run_dir": str(run_dir)}
+            (run_dir / "post_run_context.json").write_text(json.dumps(payload, indent=2) + "\n")
+            ctx = _namespace(payload)
+            ctx.params = payload["params"]          # hooks index params as a mapping too (report.py reads it back from the file)
+            ctx.out_dir, ctx.seed = str(out), int(plan.seeds[i])
             outcome_json = post_run(ctx)
             (run_dir / "post_run_result.json").write_text(json.dumps(_jsonable(outcome_json), indent=2, sort_keys=True) + "\n")
             outcome = read_post_run_outcome(_jsonable(outcome_json))
@@ -228,6 +289,17 @@ def write_campaign(out_dir, plan, results: np.ndarray, result_names: Sequence[st
     summary = summarize_campaign(out, metrics, started, finished, int(round(wall_ms)), workers)
     (out / "summary.json").write_text(json.dumps(summary, indent=2) + "\n")
     return {"summary": summary, "results_header": header, "metrics": metrics}
+
+
+def _plan_cell(v):
+    """A plan.csv cell as the JSON value the runner's context carries (numbers as numbers, anything else as text)."""
+    if isinstance(v, (int, float, np.integer, np.floating)) and not isinstance(v, bool):
+        return _jsonable(v)
+    try:
+        f = float(v)
+        return int(v) if str(v).lstrip("+-").isdigit() else f
+    except (TypeError, ValueError):
+        return v
 
 
 def _jsonable(obj):
