@@ -59,7 +59,7 @@ class Column(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("h2d_upload_ms", C.c_double), ("kernel_invoke_ms", C.c_double), ("d2h_download_ms", C.c_double),
                 ("kernel_device_ms", C.c_double), ("launches", C.c_uint64), ("ticks", C.c_uint64),
-                ("kernel_sum_ms", C.c_double)]
+                ("kernel_sum_ms", C.c_double), ("graph_launches", C.c_uint64)]
 
 
 class Slot(C.Structure):
@@ -83,6 +83,7 @@ SYMBOLS = {
     "sixdof_get_edge_rows": (C.c_int, [_H, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t,
                                        C.POINTER(C.c_size_t)]),
     "sixdof_upload": (C.c_int, [_H]),
+    "sixdof_prepare_step": (C.c_int, [_H, C.c_uint64]),
     "sixdof_step": (C.c_int, [_H, C.c_uint64, C.POINTER(Timings)]),
     "sixdof_download": (C.c_int, [_H, C.c_uint32]),
     "sixdof_get_tick": (C.c_int, [_H, C.POINTER(C.c_uint64)]),

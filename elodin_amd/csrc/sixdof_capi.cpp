@@ -115,8 +115,8 @@ struct sixdof_handle {
     double* d_tick_refs = nullptr;
     size_t tick_refs_cap = 0;
     // graph cache for long batches
-    hipGraphExec_t graph_exec = nullptr;
-    uint32_t graph_k = 0, graph_len = 0;
+    std::map<uint32_t, hipGraphExec_t> graphs;   // replay graphs by chain length (launches per replay), one StepParams signature
+    uint32_t graph_k = 0;
     uint64_t graph_sig = 0;
     mutable std::string err;
 
@@ -148,10 +148,8 @@ struct sixdof_handle {
         c.joined = false;
     }
     void drop_graph() {
-        if (graph_exec) {
-            hipGraphExecDestroy(graph_exec);
-            graph_exec = nullptr;
-        }
+        for (auto& kv : graphs) hipGraphExecDestroy(kv.second);
+        graphs.clear();
     }
     bool has_pair_op() const {
         for (auto& o : ops)
@@ -826,6 +824,25 @@ double ref_interp(double t, const std::vector<double>& xs, const std::vector<dou
     return ys[a] + (ys[b] - ys[a]) * frac;
 }
 
+// Telemetry ring for the paths whose kernels do not record in-line (pair / edge_fold ticks, the Apollo model): with a
+// ring enabled those paths are stepped ONE tick per launch and the four live output columns are copied, device to
+// device on the compute stream, into the tick's ring slot — every tick is there, in the layout sixdof_history_read /
+// _stream expect.  (The fused per-entity kernel records from registers instead, step_kernel.hpp.)
+int snapshot_tick_to_ring(sixdof_handle* h, uint64_t ticks_done) {
+    if (!h->hist_ring) return SIXDOF_OK;
+    const size_t n = h->desc.n_entities, es = h->elem_size();
+    const size_t slot = static_cast<size_t>((ticks_done - 1) % h->hist_ring);
+    const uint64_t ids[4] = {h->id_pos, h->id_vel, h->id_accel, h->id_force};
+    const size_t widths[4] = {7, 6, 6, 6};
+    for (int k = 0; k < 4; k++) {
+        const size_t block = n * widths[k] * es;
+        if (!block) continue;
+        HIP_TRY(h, hipMemcpyAsync(static_cast<char*>(h->d_hist[k]) + slot * block, h->col(ids[k])->live, block,
+                                  hipMemcpyDeviceToDevice, h->stream));
+    }
+    return SIXDOF_OK;
+}
+
 int step_apollo(sixdof_handle* h, uint64_t n_ticks, uint64_t* launches) {
     const char* names[5] = {"apollo_state", "apollo_params", "apollo_guidance", "apollo_score", "apollo_result"};
     const uint64_t widths[5] = {APOLLO_N_STATE, APOLLO_N_PARAMS, APOLLO_N_GUIDANCE, APOLLO_N_SCORE, APOLLO_N_RESULT};
@@ -861,7 +878,7 @@ int step_apollo(sixdof_handle* h, uint64_t n_ticks, uint64_t* launches) {
     P.guidance_period = h->ap_guidance_period;
     P.ticks_per_telemetry = h->ap_ticks_per_telemetry;
     P.dt = h->desc.simulation_time_step;
-    const uint32_t K = h->desc.ticks_per_launch;
+    const uint32_t K = h->hist_ring ? 1u : h->desc.ticks_per_launch;   // recording: one tick per launch, see snapshot_tick_to_ring
     if (K > h->tick_refs_cap) {
         if (h->d_tick_refs) hipFree(h->d_tick_refs), h->d_tick_refs = nullptr;
         HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_tick_refs), static_cast<size_t>(K) * 8 * sizeof(double)));
@@ -894,6 +911,10 @@ int step_apollo(sixdof_handle* h, uint64_t n_ticks, uint64_t* launches) {
         if (e != hipSuccess) return h->hip_fail(e, "launch_apollo");
         (*launches)++;
         done += k;
+        if (h->hist_ring) {
+            int rc = snapshot_tick_to_ring(h, h->tick + done);
+            if (rc != SIXDOF_OK) return rc;
+        }
     }
     return SIXDOF_OK;
 }
@@ -1129,25 +1150,61 @@ bool graph_eligible(const sixdof_handle* h) {
            h->custom_model.empty() && h->model == 0 && !h->has_pair_op();
 }
 
-// Capture kGraphLen identical launches of the step kernel into an executable graph (once per (K, effectors, size)).
-int ensure_graph(sixdof_handle* h, const StepParams& P, uint32_t K) {
-    const uint64_t sig = (static_cast<uint64_t>(K) << 32) ^ h->ops.size() ^ (h->desc.n_entities << 8);
-    if (h->graph_exec && h->graph_k == K && h->graph_sig == sig) return SIXDOF_OK;
-    h->drop_graph();
+constexpr uint32_t kGraphMinLen = 4;   // shorter chains are launched eagerly (a replay costs ~10-16 us of host time)
+constexpr size_t kGraphCacheMax = 8;
+
+// Everything a captured launch bakes in: the whole argument block (column pointers, n, both time steps, effector ops
+// and their column pointers, cache policy) plus integrator and dtype.  Any change re-captures — e.g. sixdof_tick
+// overwriting simulation_time_step from its input slot, or a rebind.  tick0 / hist_slot0 differ per launch but are
+// only read by paths that are not graph-eligible.
+uint64_t step_signature(const sixdof_handle* h, StepParams P, uint32_t K) {
+    P.tick0 = 0;
+    P.hist_slot0 = 0;
+    P.n_ticks = K;
+    uint64_t sig = 0xcbf29ce484222325ull;
+    auto mix = [&](const void* p, size_t n) {
+        const unsigned char* b = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < n; i++) sig = (sig ^ b[i]) * 0x100000001b3ull;
+    };
+    mix(&P, sizeof(P));
+    const int32_t extra[2] = {h->desc.integrator, h->desc.dtype};
+    mix(extra, sizeof(extra));
+    return sig;
+}
+
+// An executable graph of `len` identical launches of the step kernel (cached per chain length; all cached graphs share
+// one signature and are dropped together when it changes).
+int ensure_graph(sixdof_handle* h, const StepParams& P, uint32_t K, uint32_t len, hipGraphExec_t* out) {
+    const uint64_t sig = step_signature(h, P, K);
+    if (h->graph_sig != sig || h->graph_k != K) h->drop_graph();
+    auto it = h->graphs.find(len);
+    if (it != h->graphs.end()) {
+        *out = it->second;
+        return SIXDOF_OK;
+    }
+    if (h->graphs.size() >= kGraphCacheMax) {   // many distinct batch lengths: keep the long chain, drop the rest
+        for (auto g = h->graphs.begin(); g != h->graphs.end();) {
+            if (g->first == kGraphLen) { ++g; continue; }
+            hipGraphExecDestroy(g->second);
+            g = h->graphs.erase(g);
+        }
+    }
     hipGraph_t g = nullptr;
     HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     hipError_t le = hipSuccess;
-    for (uint32_t i = 0; i < kGraphLen && le == hipSuccess; i++) le = launch_any(h, P);
+    for (uint32_t i = 0; i < len && le == hipSuccess; i++) le = launch_any(h, P);
     hipError_t ce = hipStreamEndCapture(h->stream, &g);
     if (le != hipSuccess) return h->hip_fail(le, "launch_step (capture)");
     if (ce != hipSuccess) return h->hip_fail(ce, "hipStreamEndCapture");
-    hipError_t ie = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+    hipGraphExec_t exec = nullptr;
+    hipError_t ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
     hipGraphDestroy(g);
     if (ie != hipSuccess) return h->hip_fail(ie, "hipGraphInstantiate");
-    (void)hipGraphUpload(h->graph_exec, h->stream);   // move the one-off device-side setup out of the first replay
+    (void)hipGraphUpload(exec, h->stream);   // move the one-off device-side setup out of the first replay
+    h->graphs[len] = exec;
     h->graph_k = K;
-    h->graph_len = kGraphLen;
     h->graph_sig = sig;
+    *out = exec;
     return SIXDOF_OK;
 }
 
@@ -1159,9 +1216,29 @@ int prepare_graph(sixdof_handle* h) {
     int rc = fill_step_params(h, &P);
     if (rc != SIXDOF_OK) return SIXDOF_OK;     // not steppable yet (columns missing): the step call will report it
     P.n_ticks = h->desc.ticks_per_launch;
-    rc = ensure_graph(h, P, h->desc.ticks_per_launch);
+    hipGraphExec_t unused = nullptr;
+    rc = ensure_graph(h, P, h->desc.ticks_per_launch, kGraphLen, &unused);
     if (rc == SIXDOF_OK) (void)hipStreamSynchronize(h->stream);
     return rc;
+}
+
+int sixdof_prepare_step(sixdof_handle* h, uint64_t n_ticks) {
+    if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
+    if (!h->bound || !h->resident) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "prepare_step: upload the columns first");
+    if (!graph_eligible(h)) return SIXDOF_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    StepParams P;
+    int rc = fill_step_params(h, &P);
+    if (rc != SIXDOF_OK) return rc;
+    const uint32_t K = h->desc.ticks_per_launch;
+    P.n_ticks = K;
+    const uint64_t full = n_ticks / K;
+    hipGraphExec_t unused = nullptr;
+    if (full >= kGraphLen && (rc = ensure_graph(h, P, K, kGraphLen, &unused)) != SIXDOF_OK) return rc;
+    const uint32_t tail_len = static_cast<uint32_t>(full % kGraphLen);
+    if (full >= kGraphMinLen && tail_len >= kGraphMinLen && (rc = ensure_graph(h, P, K, tail_len, &unused)) != SIXDOF_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SIXDOF_OK;
 }
 
 int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
@@ -1208,25 +1285,28 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
         if (P.pair_kind == SIXDOF_EFF_EDGE_CUSTOM) {
             if (!h->pair_launch) return h->fail(SIXDOF_ERR_BACKEND, "step: custom pair op without sixdof_set_custom_pair");
             const bool small = P.n <= kPairSmallMax && !(no_small && no_small[0] == '0');
-            const uint32_t K = small ? h->desc.ticks_per_launch : 1u << 20;
+            const uint32_t K = h->hist_ring ? 1u : (small ? h->desc.ticks_per_launch : 1u << 20);
             for (uint64_t done = 0; done < n_ticks;) {
                 const uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(K, n_ticks - done));
                 hipError_t e = static_cast<hipError_t>(h->pair_launch(&P, h->desc.integrator, k, small ? 1 : 0, h->stream, &launches));
                 if (e != hipSuccess) return h->hip_fail(e, "custom pair launch");
                 done += k;
+                if (int src = snapshot_tick_to_ring(h, h->tick + done); src != SIXDOF_OK) return src;
             }
         } else if (P.n <= kPairSmallMax && !(no_small && no_small[0] == '0')) {   // small graphs: ticks_per_launch ticks per launch
-            const uint32_t K = h->desc.ticks_per_launch;
+            const uint32_t K = h->hist_ring ? 1u : h->desc.ticks_per_launch;
             for (uint64_t done = 0; done < n_ticks;) {
                 const uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(K, n_ticks - done));
                 hipError_t e = launch_pair_small(P, h->desc.integrator, k, h->stream, &launches);
                 if (e != hipSuccess) return h->hip_fail(e, "launch_pair_small");
                 done += k;
+                if (int src = snapshot_tick_to_ring(h, h->tick + done); src != SIXDOF_OK) return src;
             }
         } else {
             for (uint64_t t = 0; t < n_ticks; t++) {
                 hipError_t e = launch_pair_tick(P, h->desc.integrator, h->stream, &launches);
                 if (e != hipSuccess) return h->hip_fail(e, "launch_pair_tick");
+                if (int src = snapshot_tick_to_ring(h, h->tick + t + 1); src != SIXDOF_OK) return src;
             }
         }
     } else {
@@ -1250,17 +1330,36 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
             }
         }
         uint64_t ticks_issued = 0;   // history slot of a launch's first tick = ticks done before it
-        if (graph_eligible(h) && full >= kGraphLen) {
-            int grc = ensure_graph(h, P, K);
-            if (grc != SIXDOF_OK) return grc;
+        uint64_t graph_launches = 0;
+        if (graph_eligible(h) && full >= kGraphMinLen) {
+            // long batches replay 32-launch chains; what is left (or a short batch as a whole, e.g. 20 ticks) replays as
+            // ONE chain of exactly that length, captured on first use and cached — so a short timed region is
+            // steady-state device work too, not eager launches racing the host.
+            hipGraphExec_t big = nullptr, tail = nullptr;
+            const uint32_t tail_len = static_cast<uint32_t>(full % kGraphLen);
+            if (full >= kGraphLen) {
+                int grc = ensure_graph(h, P, K, kGraphLen, &big);
+                if (grc != SIXDOF_OK) return grc;
+            }
+            if (tail_len >= kGraphMinLen) {
+                int grc = ensure_graph(h, P, K, tail_len, &tail);
+                if (grc != SIXDOF_OK) return grc;
+            }
             // a capture may just have happened after ev0 was recorded: re-record so the pair brackets real work only
             HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
             while (full >= kGraphLen) {
-                HIP_TRY(h, hipGraphLaunch(h->graph_exec, h->stream));
+                HIP_TRY(h, hipGraphLaunch(big, h->stream));
                 full -= kGraphLen;
                 launches += kGraphLen;
             }
+            if (tail) {
+                HIP_TRY(h, hipGraphLaunch(tail, h->stream));
+                full -= tail_len;
+                launches += tail_len;
+            }
+            graph_launches = launches;
         }
+        h->last.graph_launches = graph_launches;
         ticks_issued = launches * K;
         for (uint64_t i = 0; i < full; i++) {
             if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches], h->stream));
@@ -1314,6 +1413,7 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
         tm->launches = launches;
         tm->ticks = n_ticks;
         tm->kernel_sum_ms = 0.0;
+        tm->graph_launches = h->last.graph_launches;
         if ((h->desc.flags & SIXDOF_FLAG_TIME_EACH_LAUNCH) && !h->has_pair_op()) {
             double sum = 0.0;
             for (uint64_t i = 0; i < launches && 2 * i + 1 < h->launch_events.size(); i++) {

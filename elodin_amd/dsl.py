@@ -561,40 +561,46 @@ class RotVec(Vec):
 
 
 class Quaternion:
-    """Scalar-last [x,y,z,w]; assumed unit (the stage attitude is renormalised every stage)."""
+    """Scalar-last [x,y,z,w].  `unit` marks values known to have norm 1 by construction (the stage attitude, which the
+    kernel renormalises every stage; normalize(), from_axis_angle(), identity(), and inverses / products of those): only
+    for them may `q @ v` and `inverse()` drop the division by |q|^2 the reference always performs
+    (quaternion.rs:152-155,283-305 — q @ v is scale-invariant there).  Anything else — a quaternion built from an array,
+    raw spawn data a system sees on tick 0 — keeps it."""
 
-    def __init__(self, v: Vec, stage_attitude: bool = False):
+    def __init__(self, v: Vec, stage_attitude: bool = False, unit: bool = False):
         self.v = v
         self.stage_attitude = stage_attitude
+        self.unit = bool(unit or stage_attitude)
 
     def vector(self) -> Vec: return self.v
     def inverse(self) -> "Quaternion":
         """conj / |q|^2 (quaternion.rs:152-155).  The stage attitude inside six_dof is renormalised by the kernel before
         the effectors see it, so there the division is by 1 and is dropped."""
         c = Vec([-self.v[0], -self.v[1], -self.v[2], self.v[3]])
-        return Quaternion(c) if self.stage_attitude else Quaternion(c / np.dot(self.v, self.v))
+        return Quaternion(c, unit=True) if self.unit else Quaternion(c / np.dot(self.v, self.v))
     def conjugate(self) -> "Quaternion":
-        return Quaternion(Vec([-self.v[0], -self.v[1], -self.v[2], self.v[3]]))
+        return Quaternion(Vec([-self.v[0], -self.v[1], -self.v[2], self.v[3]]), unit=self.unit)
     def normalize(self) -> "Quaternion":                     # quaternion.rs:147-149
-        return Quaternion(self.v / np.linalg.norm(self.v))
+        return Quaternion(self.v / np.linalg.norm(self.v), unit=True)
     @staticmethod
     def identity() -> "Quaternion":
-        return Quaternion(Vec([0.0, 0.0, 0.0, 1.0]))
+        return Quaternion(Vec([0.0, 0.0, 0.0, 1.0]), unit=True)
     @staticmethod
     def from_axis_angle(axis, angle) -> "Quaternion":         # quaternion.rs:158-171 (the axis is normalised)
         axis = axis if isinstance(axis, Vec) else Vec(list(axis))
         axis = axis / np.linalg.norm(axis)
         half = _lift(angle) / 2.0
-        return Quaternion(np.concatenate([axis * np.sin(half), np.cos(half)]))
+        return Quaternion(np.concatenate([axis * np.sin(half), np.cos(half)]), unit=True)
     def integrate_body(self, body_delta: Vec) -> "Quaternion":   # quaternion.rs:176-182: q + q (x) (delta/2, 0), normalised
         half = Quaternion(np.concatenate([body_delta / 2.0, 0.0]))
         return Quaternion(self.v + (self * half).v).normalize()
     def __add__(self, o: "Quaternion") -> "Quaternion":
         return Quaternion(self.v + o.v)
     def __matmul__(self, x: Vec) -> Vec:
-        """q @ v: rotate a 3-vector (quaternion.rs:283-305), as v + w t + u x t with t = 2 u x v."""
+        """q @ v: rotate a 3-vector, (q (x) (v,0) (x) q^-1).xyz with q^-1 = conj / |q|^2 (quaternion.rs:283-305), written
+        as v + w t + u x t with t = (2 / |q|^2) u x v — the 1 / |q|^2 is dropped only for quaternions known to be unit."""
         u = Vec(self.v.e[:3])
-        t = np.cross(u, x) * 2.0
+        t = np.cross(u, x) * (2.0 if self.unit else 2.0 / np.dot(self.v, self.v))
         r = x + t * self.v[3] + np.cross(u, t)
         return RotVec(r.e, x) if self.stage_attitude else r
     def __mul__(self, o: "Quaternion") -> "Quaternion":
@@ -602,7 +608,7 @@ class Quaternion:
         return Quaternion(Vec([l[3] * r[0] + l[0] * r[3] + l[1] * r[2] - l[2] * r[1],
                                l[3] * r[1] - l[0] * r[2] + l[1] * r[3] + l[2] * r[0],
                                l[3] * r[2] + l[0] * r[1] - l[1] * r[0] + l[2] * r[3],
-                               l[3] * r[3] - l[0] * r[0] - l[1] * r[1] - l[2] * r[2]]))
+                               l[3] * r[3] - l[0] * r[0] - l[1] * r[1] - l[2] * r[2]]), unit=self.unit and o.unit)
 
 
 class SpatialTransform:

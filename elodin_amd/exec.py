@@ -43,6 +43,7 @@ class TickTimings:  # profile.rs TickTimings
     launches: int = 0
     ticks: int = 0
     kernel_sum_ms: float = 0.0
+    graph_launches: int = 0    # how many of `launches` were replayed from a captured hipGraph
 
 
 class HipExec:
@@ -192,7 +193,13 @@ class HipExec:
         if rc != L.OK:
             _raise(self._h, rc, "sixdof_step")
         return TickTimings(t.h2d_upload_ms, t.kernel_invoke_ms, t.d2h_download_ms, t.kernel_device_ms,
-                           int(t.launches), int(t.ticks), t.kernel_sum_ms)
+                           int(t.launches), int(t.ticks), t.kernel_sum_ms, int(t.graph_launches))
+
+    def prepare(self, n_ticks: int):
+        """Capture the replay graphs a later invoke_batch(n_ticks) uses (use_graph=True), outside any timed region."""
+        rc = self._lib.sixdof_prepare_step(self._h, int(n_ticks))
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_prepare_step")
 
     def download(self, mask: int = L.COL_ALL):
         rc = self._lib.sixdof_download(self._h, mask)
@@ -251,7 +258,7 @@ class HipExec:
         t = L.Timings()
         self._lib.sixdof_last_timings(self._h, C.byref(t))
         return TickTimings(t.h2d_upload_ms, t.kernel_invoke_ms, t.d2h_download_ms, t.kernel_device_ms,
-                           int(t.launches), int(t.ticks), t.kernel_sum_ms)
+                           int(t.launches), int(t.ticks), t.kernel_sum_ms, int(t.graph_launches))
 
     def enable_history(self, ring_ticks: int):
         """Record every tick's world_pos/world_vel/world_accel/force in a device ring (sixdof_set_history)."""

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SIXDOF_ABI_VERSION 1
+#define SIXDOF_ABI_VERSION 2   /* 2: sixdof_timings.graph_launches, sixdof_apollo_tables.ticks_per_telemetry, effector kinds 10-11 */
 
 typedef struct sixdof_handle sixdof_handle;
 
@@ -144,7 +144,8 @@ typedef struct sixdof_desc {
     uint32_t reserved;
 } sixdof_desc;
 
-#define SIXDOF_FLAG_USE_GRAPH 1u /* replay long sixdof_step batches from a captured hipGraph */
+#define SIXDOF_FLAG_USE_GRAPH 1u /* replay sixdof_step batches of >= 4 launches from captured hipGraphs (chains of 32 + one
+                                    chain of the remainder, cached per length) */
 #define SIXDOF_FLAG_TIME_EACH_LAUNCH 2u /* profiling: bracket every launch of sixdof_step with its own HIP
                                            event pair (<= 4096 launches per call; disables graph replay) */
 #define SIXDOF_FLAG_ASYNC_STEP 4u /* sixdof_step only enqueues and returns (no stream sync): pair it with
@@ -171,6 +172,7 @@ typedef struct sixdof_timings {
     uint64_t launches;         /* kernel launches issued by the last step */
     uint64_t ticks;
     double kernel_sum_ms;      /* SIXDOF_FLAG_TIME_EACH_LAUNCH: sum of the per-launch event times (no gaps) */
+    uint64_t graph_launches;   /* how many of `launches` were replayed from a captured hipGraph (SIXDOF_FLAG_USE_GRAPH) */
 } sixdof_timings;
 
 typedef struct sixdof_slot {
@@ -212,6 +214,9 @@ int sixdof_get_edge_rows(const sixdof_handle* h, uint32_t* src_rows, uint32_t* d
 
 int sixdof_upload(sixdof_handle* h);
 int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* timings /* may be NULL */);
+/* SIXDOF_FLAG_USE_GRAPH: capture (and cache) the launch chains a later sixdof_step(h, n_ticks) replays, without stepping —
+ * the one-off cost CraneliftExec::new pays at build time (cranelift_exec.rs:54-127), kept out of the first timed batch. */
+int sixdof_prepare_step(sixdof_handle* h, uint64_t n_ticks);
 int sixdof_download(sixdof_handle* h, uint32_t column_mask);
 /* Telemetry commit without the per-batch stall (the step either side of the path: commit_world_head after
  * every batch, impeller2_server.rs:390-438; JaxExec blocks on copy_to_host there, jax_exec.rs:150-178).
@@ -296,7 +301,9 @@ int sixdof_set_custom_pair(sixdof_handle* h, const char* so_path);
  * (reference row layout, one contiguous [n,w] block per tick and column) from inside the fused kernel, so
  * ticks_per_launch > 1 no longer drops intermediate ticks.  With a generated program installed
  * (sixdof_set_custom_pipe) every component column of the program is recorded the same way and can be read
- * back by its component id.  ring_ticks = 0 disables and frees the ring. */
+ * back by its component id.  Worlds stepped by the pair (edge_fold / all-pairs) kernels or by a rollout model are
+ * recorded too: with a ring enabled they run one tick per launch and the four output columns are copied into the
+ * tick's slot on the device (the model's own columns are not recorded).  ring_ticks = 0 disables and frees the ring. */
 int sixdof_set_history(sixdof_handle* h, uint32_t ring_ticks);
 /* Copy the [n,w] block of `component_id` as it was after `tick` ticks into host_dst.  Fails with
  * SIXDOF_ERR_INVALID_ARGUMENT if that tick is not (or no longer) in the ring. */

@@ -62,6 +62,19 @@ def build(force: bool = False) -> Path:
 _lib = None
 
 
+def use_native_build() -> Path:
+    """bench.py's cpu_baseline: (re)build the oracle -O3 -march=native ON THIS MACHINE (oracle/Makefile `native`) and bind
+    to it from here on.  Returns the library path actually in use (the portable -O2 build if the native one fails)."""
+    global _lib, LIB_PATH
+    native = HERE / "_native" / "libsixdof_oracle_native.so"
+    try:
+        subprocess.run(["make", "-C", str(HERE), "native"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        LIB_PATH, _lib = native, None
+    except (OSError, subprocess.CalledProcessError):
+        pass
+    return LIB_PATH
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:

@@ -16,6 +16,10 @@ FLOORS = {"tvc_cmd": 1e-3, "tvc_state": 1e-3, "rcs_torque_cmd": 1.0, "aero_wrenc
           "rcs_wrench": 1.0, "qbar": 1e-3, "mach": 1e-6, "fin_state": 1e-3, "fin_cmd": 1e-3, "rcs_levels": 1e-3, "wind_ecef": 1e-3,
           "world_accel": 1e-3, "force": 1.0, "liftoff_time": 1e-3, "axial_specific_force": 1e-3, "thrust_total": 1.0,
           "mdot_total": 1e-3, "engine_spool": 1e-6, "valve_state": 1e-6}
+# f32 state (config 5's arithmetic): an f32 ECEF / pad-relative metre resolves ~0.25-0.5 m, so quantities that are small
+# differences of large ones get floors at that resolution times their gain instead of their own (tiny) magnitude
+FLOORS_F32 = dict({k: v * 1e3 for k, v in FLOORS.items()}, altitude_geodetic=100.0, rcs_torque_cmd=2.0e4, ground_speed=1.0,
+                  tvc_cmd=2e-2, tvc_state=2e-2, liftoff_time=1.0)
 BODY = ("world_pos", "world_vel", "world_accel", "force", "inertia")
 
 
@@ -48,7 +52,7 @@ def script(case):
     return fs.make_script(case, PLANT[case]["base_attitude"])
 
 
-def compare(case, tick, get):
+def compare(case, tick, get, floors=None):
     """get(name) -> [1, w] current column of this repo's run; returns {column: rel err} against the fixture checkpoint."""
     ref = next(c for c in PLANT[case]["checkpoints"] if c["tick"] == tick)["state"]
     errs = {}
@@ -66,7 +70,7 @@ def compare(case, tick, get):
             parts = [(got, want)]
         e = 0.0
         for g, w in parts:
-            scale = max(float(np.max(np.abs(w))), FLOORS.get(name, 1e-300))
+            scale = max(float(np.max(np.abs(w))), (floors or FLOORS).get(name, 1e-300))
             e = max(e, float(np.max(np.abs(g - w))) / scale)
         errs[name] = e
     return errs

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_host_helpers_match_oracle():
     lib = L.lib()
-    assert lib.sixdof_abi_version() == 1
+    assert lib.sixdof_abi_version() == 2
     for name in ("world_pos", "world_vel", "world_accel", "force", "inertia", "tick", "simulation_time_step",
                  "gravity_edge", "seed", "a.world_pos"):
         assert L.component_id(name) == orc.component_id(name)
@@ -42,7 +42,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(L.EffectorOp) == 64
     assert C.sizeof(L.Desc) == 56
     assert C.sizeof(L.Column) == 56
-    assert C.sizeof(L.Timings) == 56
+    assert C.sizeof(L.Timings) == 64      # ABI 2: + graph_launches
 
 
 def test_product_fails_loudly_without_gpu():

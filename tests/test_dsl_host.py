@@ -202,6 +202,16 @@ def test_quaternion_and_spatial_wrappers_match_the_reference_known_answers():
     assert np.allclose(out, [0.97151626, 0.0, 0.0, 0.23697292])
     out = ev(lambda q: Q(q).normalize().vector(), [0.0, 3.0, 0.0, 4.0])
     assert np.allclose(out, [0.0, 0.6, 0.0, 0.8], rtol=1e-15)
+    # a NON-unit quaternion (built from an array, or raw spawn data seen on tick 0): the reference's q @ v = q (x) (v,0) (x)
+    # conj(q)/|q|^2 is scale-invariant (quaternion.rs:283-305) and inverse() divides by |q|^2 — against the pinned C oracle
+    from oracle import oracle as orc
+    rng = np.random.default_rng(3)
+    for _ in range(5):
+        q, v = rng.normal(size=4) * rng.uniform(0.2, 5.0), rng.normal(size=3)
+        assert np.allclose(ev(lambda q, v: Q(q) @ v, q, v), orc.quat_rotate(q, v), rtol=1e-13, atol=1e-14)
+        assert np.allclose(ev(lambda q, v: Q(q).inverse() @ v, q, v), orc.quat_rotate(orc.quat_inverse(q), v), rtol=1e-13, atol=1e-14)
+        assert np.allclose(ev(lambda q: Q(q).inverse().vector(), q), orc.quat_inverse(q), rtol=1e-14)
+        assert np.allclose(ev(lambda q, v: Q(q).normalize() @ v, q, v), orc.quat_rotate(q, v), rtol=1e-13, atol=1e-14)
 
 
 # ---- data-dependent loops --------------------------------------------------------------------------------------------------------

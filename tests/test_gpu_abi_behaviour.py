@@ -269,3 +269,43 @@ def test_handle_lifecycles_return_their_device_and_pinned_memory():
     per_cycle = (n * (7 + 6 * 4 + 7) * 8) * 2          # what one cycle allocates at least: columns + a ring, twice
     print(f"device memory after 12 more cycles: {lost / 2**20:+.1f} MiB (one cycle allocates > {per_cycle / 2**20:.0f} MiB)")
     assert lost < 32 * 2**20
+
+
+@pytest.mark.parametrize("n", [3, 700])
+def test_history_ring_on_pair_path_worlds_holds_every_tick(n):
+    """the pair (edge_fold / all-pairs) kernels do not record in-line; with a ring enabled such worlds run one
+    tick per launch and the live columns are snapshot into the ring on the device — history() must equal what single-tick
+    runs leave in the columns (n = 3: the one-workgroup small-graph kernel, n = 700: pack / all-pairs / integrate)."""
+    from elodin_amd.exec import Effector
+    rng = np.random.default_rng(5)
+    pos = np.concatenate([np.tile([0, 0, 0, 1.0], (n, 1)), rng.normal(size=(n, 3)) * 10.0], axis=1)
+    vel = np.concatenate([np.zeros((n, 3)), rng.normal(size=(n, 3))], axis=1)
+    inertia = np.concatenate([np.ones((n, 3)), np.zeros((n, 3)), rng.uniform(1.0, 5.0, (n, 1))], axis=1)
+    eff = [Effector(L.EFF_ALLPAIRS_GRAVITY_SOFTENED, (0.5, 1e-2))]
+    a = ea.HipExec(pos, vel, inertia, simulation_time_step=0.01, effectors=eff, ticks_per_launch=8)
+    a.enable_history(16)
+    a.run(12)
+    b = ea.HipExec(pos, vel, inertia, simulation_time_step=0.01, effectors=eff)
+    for tick in range(1, 13):
+        b.run(1)
+        for name in ("world_pos", "world_vel", "world_accel", "force"):
+            assert np.array_equal(a.history(name, tick, tick)[0], getattr(b, name)), (name, tick)
+    assert np.array_equal(a.world_pos, b.world_pos)          # recording did not change the flight
+
+
+def test_history_ring_on_the_apollo_model_holds_every_tick():
+    from elodin_amd.models import apollo
+    ref = apollo.load_reference()
+    d = apollo.default_params(ref)
+    P = np.tile([d[k] for k in apollo.PARAM_NAMES], (5, 1))
+    P[:, apollo.PARAM_NAMES.index("init_altitude_m")] += np.arange(5) * 10.0
+    a = apollo.ApolloExec(P, ref=ref, ticks_per_launch=60)
+    a.enable_history(32)
+    a.run(30)
+    b = apollo.ApolloExec(P, ref=ref, ticks_per_launch=1)
+    for tick in range(1, 31):
+        b.run(1)
+        for name in ("world_pos", "world_vel", "world_accel", "force"):
+            assert np.array_equal(a.history(name, tick, tick)[0], getattr(b, name)), (name, tick)
+    with pytest.raises(KeyError):                            # the model's own columns are not recorded: a clear refusal
+        a.history("apollo_state", 1, 1)

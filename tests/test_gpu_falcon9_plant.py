@@ -29,7 +29,7 @@ def _fly(case, dtype, ticks_per_launch):
                 x[:, 4:] += ex.origin
                 return x
             return ex.column(name)
-        for k, e in pu.compare(case, cp["tick"], get).items():
+        for k, e in pu.compare(case, cp["tick"], get, pu.FLOORS_F32 if local else None).items():
             worst[k] = max(worst.get(k, 0.0), e)
     ex.close()
     return worst
@@ -48,9 +48,10 @@ def test_generated_kernel_follows_the_reference_plant_f64(case, ticks_per_launch
 @pytest.mark.parametrize("case", sorted(pu.PLANT))
 def test_generated_kernel_f32_tracks_the_reference_plant(case):
     """Config 5's arithmetic type.  The reference has no f32 six_dof (six_dof.rs:12-14), so the bound is this build's:
-    f32 state over 10,000 ticks of a feedback loop stays within 2e-3 of the f64 reference flight on every column
-    (relative to the column's scale, floors as in falcon9_plant_util.FLOORS x 1e3)."""
+    f32 state over 10,000 ticks of a feedback loop stays within 1e-2 of the f64 reference flight on every column
+    (relative to the column's scale; floors falcon9_plant_util.FLOORS_F32, i.e. the f64 floors x 1e3 and the
+    half-metre resolution of an f32 position for the quantities derived from it)."""
     worst = _fly(case, np.float32, 250)
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
     print(f"{case} f32: worst of {len(worst)} columns over 10,000 ticks:", ", ".join(f"{k} {e:.1e}" for k, e in top))
-    assert max(worst.values()) < 5e-2, top
+    assert max(worst.values()) < 1e-2, top
