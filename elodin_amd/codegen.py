@@ -451,16 +451,67 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) ->
         cols = tp.columns
         n_model = len(cols)
         regs = "\n".join(f"        T c{k}[{w}];" for k, (_, w) in enumerate(cols))
-        loads = "\n".join(
+        zero = " ".join(f"for (int j = 0; j < {w}; j++) r.c{k}[j] = T(0);" for k, (_, w) in enumerate(cols))
+        elem = 8 if dtype == "float64" else 4
+        lds_cap = _MODEL_LDS_F64 if dtype == "float64" else _MODEL_LDS_F32
+
+        def batches(slots):
+            """Pack columns into staging batches of at most lds_cap elements per row."""
+            out, cur, used = [], [], 0
+            for k in slots:
+                w = cols[k][1]
+                if cur and used + w > lds_cap:     # (a slab starts at used * 64 * elem bytes: always 16-B aligned)
+                    out.append(cur)
+                    cur, used = [], 0
+                cur.append((k, used))
+                used += w
+            if cur:
+                out.append(cur)
+            return out
+
+        def slab_in(slots):
+            code = []
+            for batch in batches(slots):
+                code.append("            __syncthreads();   // the staging area is free")
+                for k, off in batch:
+                    w = cols[k][1]
+                    code.append(f"            slab_dma_in<kWave * {w} * sizeof(T), kPolPlain>(reinterpret_cast<const char*>(static_cast<const T*>(P.model_cols[{k}]) + (size_t)row0 * {w}), "
+                                f"reinterpret_cast<char*>(lds + kWave * {off}), lane);")
+                code.append('            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
+                code.append("            __syncthreads();")
+                for k, off in batch:
+                    w = cols[k][1]
+                    code.append(f"            {{ const T* l = lds + kWave * {off} + lane * {w}; " + " ".join(f"r.c{k}[{j}] = l[{j}];" for j in range(w)) + " }")
+            return "\n".join(code)
+
+        def slab_out_code(slots, dst):
+            """dst(k, w) -> C expression of the column's destination base pointer (T*) for this wave's slab."""
+            code = []
+            for batch in batches(slots):
+                code.append("            __syncthreads();   // the staging area is free")
+                for k, off in batch:
+                    w = cols[k][1]
+                    code.append(f"            {{ T* l = lds + kWave * {off} + lane * {w}; " + " ".join(f"l[{j}] = r.c{k}[{j}];" for j in range(w)) + " }")
+                code.append("            __syncthreads();")
+                for k, off in batch:
+                    w = cols[k][1]
+                    code.append(f"            if ({dst(k, w)} != nullptr) slab_out<kWave * {w} * sizeof(T), kPolNtStores>(reinterpret_cast<const char*>(lds + kWave * {off}), "
+                                f"reinterpret_cast<char*>({dst(k, w)}), lane);")
+            return "\n".join(code)
+
+        all_slots = list(range(len(cols)))
+        loads_tail = "\n".join(
             f"            {{ const T* g = static_cast<const T*>(P.model_cols[{k}]) + (size_t)row * {w}; "
             + " ".join(f"r.c{k}[{j}] = g[{j}];" for j in range(w)) + " }" for k, (_, w) in enumerate(cols))
-        zero = " ".join(f"for (int j = 0; j < {w}; j++) r.c{k}[j] = T(0);" for k, (_, w) in enumerate(cols))
-        stores = "\n".join(
-            f"        {{ T* g = static_cast<T*>(P.model_cols[{k}]) + (size_t)row * {cols[k][1]}; "
+        stores_tail = "\n".join(
+            f"            {{ T* g = static_cast<T*>(P.model_cols[{k}]) + (size_t)row * {cols[k][1]}; "
             + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(cols[k][1])) + " }" for k in tp.written_slots)
-        records = "\n".join(
-            f"        if (P.model_hist[{k}]) {{ T* g = static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row) * {w}; "
+        records_tail = "\n".join(
+            f"            if (P.model_hist[{k}]) {{ T* g = static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row) * {w}; "
             + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(w)) + " }" for k, (_, w) in enumerate(cols))
+        loads = slab_in(all_slots)
+        stores = slab_out_code(list(tp.written_slots), lambda k, w: f"(static_cast<T*>(P.model_cols[{k}]) + (size_t)row0 * {w})")
+        records = slab_out_code(all_slots, lambda k, w: f"(P.model_hist[{k}] ? static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row0) * {w} : nullptr)")
         model = f'''
     static constexpr bool kHasModel = true;
     static constexpr bool kWritesInertia = {"true" if tp.writes_inertia else "false"};
@@ -468,20 +519,37 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) ->
     struct Regs {{
 {regs}
     }};
+    static constexpr int kModelLds = {lds_cap};
+    // Component columns move like the Body columns (step_kernel.hpp): a wave's 64 rows of a column are one contiguous
+    // slab, pulled HBM -> LDS by LDS-DMA and pushed back with 16-B-per-lane stores, {lds_cap} elements per row at a time;
+    // each lane reads / writes its own row in LDS.  A ragged last wave falls back to per-lane row accesses.
     template <class T>
-    __device__ static __forceinline__ void load(const StepParams& P, uint32_t row, bool active, Regs<T>& r) {{
+    __device__ static __forceinline__ void load(const StepParams& P, uint32_t row0, uint32_t rows, uint32_t lane, T* lds, Regs<T>& r) {{
         {zero}
-        if (active) {{
+        if (rows == kWave) {{
 {loads}
+        }} else if (lane < rows) {{
+            const uint32_t row = row0 + lane;
+{loads_tail}
         }}
     }}
     template <class T>
-    __device__ static __forceinline__ void store(const StepParams& P, uint32_t row, const Regs<T>& r) {{
+    __device__ static __forceinline__ void store(const StepParams& P, uint32_t row0, uint32_t rows, uint32_t lane, T* lds, const Regs<T>& r) {{
+        if (rows == kWave) {{
 {stores}
+        }} else if (lane < rows) {{
+            const uint32_t row = row0 + lane;
+{stores_tail}
+        }}
     }}
     template <class T>
-    __device__ static __forceinline__ void record(const StepParams& P, size_t slot, uint32_t row, const Regs<T>& r) {{
+    __device__ static __forceinline__ void record(const StepParams& P, size_t slot, uint32_t row0, uint32_t rows, uint32_t lane, T* lds, const Regs<T>& r) {{
+        if (rows == kWave) {{
 {records}
+        }} else if (lane < rows) {{
+            const uint32_t row = row0 + lane;
+{records_tail}
+        }}
     }}
     template <class T>
     __device__ static __forceinline__ void pre(const StepParams& P, uint64_t tick, Regs<T>& r, Quat<T>& q, Vec3<T>& p,
@@ -535,7 +603,7 @@ extern "C" int sixdof_custom_launch(const sixdof::StepParams* p, int integrator,
     const dim3 grid((p->n + kWave - 1) / kWave);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((p->streaming & 255u) == kPolNt) hipLaunchKernelGGL((sixdof_step_kernel<{T}, {integ}, PipeCustom, kPolNt>), grid, dim3(kWave), 0, s, *p);
-    else if ((p->streaming & 255u) == kPolNtStores) hipLaunchKernelGGL((sixdof_step_kernel<{T}, {integ}, PipeCustom, kPolNtStores>), grid, dim3(kWave), 0, s, *p);
+    else if ((p->streaming & 255u) == kPolNtStores || (p->streaming & 255u) == kPolSc1Stores) hipLaunchKernelGGL((sixdof_step_kernel<{T}, {integ}, PipeCustom, kPolNtStores>), grid, dim3(kWave), 0, s, *p);
     else hipLaunchKernelGGL((sixdof_step_kernel<{T}, {integ}, PipeCustom, kPolPlain>), grid, dim3(kWave), 0, s, *p);
     return static_cast<int>(hipGetLastError());
 }}
@@ -698,7 +766,8 @@ _RETRY_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills"]
 # Builds are tried in this order and the FIRST without VGPR spills is kept.  The last resort trades speed for a smaller
 # live set (-O1: no unrolling / less hoisting); the fuzz program that miscomputed when spilling is exact at -O1.
 _ATTEMPTS = (("-O3", _BASE_FLAGS), ("-O3", _BASE_FLAGS + _RETRY_FLAGS), ("-O1", []))
-_CACHE_TAG = "rp2"           # bump when the flag policy changes: cached objects are keyed on it
+_CACHE_TAG = "rp2"
+_MODEL_LDS_F64, _MODEL_LDS_F32 = 32, 64     # staging elements per row for a program's component columns: 16 KiB of LDS per wave           # bump when the flag policy changes: cached objects are keyed on it
 ALLOW_SPILLS_ENV = "SIXDOF_ALLOW_SPILLS"   # "1": accept a build that still spills VGPRs (known-unsafe on gfx950, see above)
 last_resources: Dict[str, int] = {}
 

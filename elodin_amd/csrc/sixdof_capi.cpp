@@ -716,15 +716,22 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
     P->n = static_cast<uint32_t>(h->desc.n_entities);
     P->dt_g = h->desc.simulation_time_step;
     P->dt = h->desc.has_time_step ? h->desc.time_step : h->desc.simulation_time_step;
-    // 25 state elements per entity; stream (non-temporal) once the world is well past the 256 MiB Infinity Cache
+    // Cache policy of the launch (step_kernel.hpp: load * 8 + store, bit 8 = one flush after the tick instead of columns
+    // stored as they complete), by working-set size, from the A/B matrices in profiles/r02_step_ab_load_x_store_policy.txt
+    // and r02_step_ab_policy_by_size.txt (f64 body counts in brackets):
+    //   <=  48 MiB [<= 196,608]   plain loads, nt stores, early     65,536: 5.48 -> 4.93 us   131,072: 7.94 -> 7.14 us
+    //   <= 192 MiB [<= 786,432]   plain loads, sc1 stores, late     262,144: 16.6 -> 15.1 us  524,288: 31.5 -> 29.6 us
+    //   <= 768 MiB [<= 3.1M]      plain loads, nt stores, early     1,048,576: 61.9 -> 60.0   2,097,152: 136 -> 123 us
+    //   beyond                    nt loads,    nt stores, early     4,194,304: 300 -> 263 us
+    // (inputs are re-read next tick: keep them cacheable while the 256 MiB Infinity Cache can hold them; outputs are
+    // written once per tick: never worth a line).  SIXDOF_STREAMING=<code> overrides it for A/B runs (tools/step_ab.py).
     const char* force_nt = std::getenv("SIXDOF_STREAMING");
     const size_t state_bytes = static_cast<size_t>(h->desc.n_entities) * 32 * h->elem_size();
-    // cache-policy code of the launch (step_kernel.hpp: load * 8 + store).  Output columns always leave with non-temporal
-    // stores (every byte is written once per tick); the input columns are read with the default policy while the
-    // world fits the 256 MiB Infinity Cache — the next tick finds them there — and non-temporally beyond it
-    // (profiles/r02_step_ab_load_x_store_policy.txt: 65,536 bodies 5.48 -> 4.93 us, 131,072 7.94 -> 7.14 us with plain
-    // loads + nt stores; 4.2M bodies 300 -> 263 us with both nt).  SIXDOF_STREAMING=<code> overrides it for A/B runs.
-    P->streaming = force_nt ? static_cast<uint32_t>(std::atoi(force_nt)) : (state_bytes > (192ull << 20) ? 9u : 1u);
+    uint32_t policy = 9u;
+    if (state_bytes <= (48ull << 20)) policy = 1u;
+    else if (state_bytes <= (192ull << 20)) policy = 2u | 256u;
+    else if (state_bytes <= (768ull << 20)) policy = 1u;
+    P->streaming = force_nt ? static_cast<uint32_t>(std::atoi(force_nt)) : policy;
     P->hist_ring = h->hist_ring;
     if (h->hist_ring) {
         P->hist_pos = h->d_hist[0];

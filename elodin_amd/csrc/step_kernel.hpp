@@ -51,7 +51,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 //   stores 0 = plain (lines stay dirty in the XCD's L2 until the kernel-end write-back), 1 = non-temporal,
 //          2 = write-through `sc1`, 3 = `sc0 sc1`, 4 = `sc1 nt`
 // profiles/r02_step_ab_*.txt hold the A/B of these at 65,536 / 131,072 / 4.2M bodies.
-constexpr int kPolPlain = 0, kPolNtStores = 1, kPolNt = 9;
+constexpr int kPolPlain = 0, kPolNtStores = 1, kPolSc1Stores = 2, kPolNt = 9;
 constexpr int pol_ld(int pol) { return pol / 8; }
 constexpr int pol_st(int pol) { return pol % 8; }
 
@@ -155,7 +155,10 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     load_aux(std::integral_constant<int, 3>{});
 
     typename PIPE::template Regs<T> regs;   // component columns of a generated program, one row per lane
-    if constexpr (PIPE::kHasModel) PIPE::load(P, row0 + t, active, regs);
+    // their slabs go through an LDS staging area of their own (64 rows x kModelLds elements), batch by batch: same
+    // LDS-DMA in / 16-B-per-lane out as the Body columns instead of per-lane strided row accesses
+    __shared__ __attribute__((aligned(16))) T model_lds[PIPE::kHasModel ? kWave * PIPE::kModelLds : 1];
+    if constexpr (PIPE::kHasModel) PIPE::load(P, row0, rows, t, model_lds, regs);
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA data has landed
     __syncthreads();
@@ -361,14 +364,13 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             flush6(l_vel, static_cast<T*>(P.hist_vel) + r6, kRing);
             flush6(l_c, static_cast<T*>(P.hist_accel) + r6, kRing);
             flush6(l_force, static_cast<T*>(P.hist_force) + r6, kRing);
-            if constexpr (PIPE::kHasModel)
-                if (active) PIPE::record(P, slot, row0 + t, regs);   // component columns of a generated program
+            if constexpr (PIPE::kHasModel) PIPE::record(P, slot, row0, rows, t, model_lds, regs);   // component columns of a generated program
             __syncthreads();
         }
     }
     if constexpr (PIPE::kHasModel) {
+        PIPE::store(P, row0, rows, t, model_lds, regs);
         if (active) {
-            PIPE::store(P, row0 + t, regs);
             if constexpr (PIPE::kWritesInertia) {   // a system returned el.Inertia: the column is an output
                 T* gi = static_cast<T*>(const_cast<void*>(P.inertia)) + (size_t)(row0 + t) * 7;
                 gi[0] = I_diag.x; gi[1] = I_diag.y; gi[2] = I_diag.z; gi[6] = mass;
@@ -406,11 +408,11 @@ inline void launch_t(const StepParams& p, int integrator, dim3 grid, hipStream_t
     switch (pol) {
     case kPolNt: return launch_i<T, PIPE, kPolNt>(p, integrator, grid, s);
     case kPolNtStores: return launch_i<T, PIPE, kPolNtStores>(p, integrator, grid, s);
+    case kPolSc1Stores: return launch_i<T, PIPE, kPolSc1Stores>(p, integrator, grid, s);
     default: break;
     }
     if constexpr (SWEEP) {
         switch (pol) {
-        case 2: return launch_i<T, PIPE, 2>(p, integrator, grid, s);
         case 3: return launch_i<T, PIPE, 3>(p, integrator, grid, s);
         case 4: return launch_i<T, PIPE, 4>(p, integrator, grid, s);
         case 8: return launch_i<T, PIPE, 8>(p, integrator, grid, s);

@@ -24,7 +24,11 @@ def _compare(hip, ref, rtol=parity.F64_RTOL):
         # landed rollouts have exactly zero velocity; scale by a floor so 0 vs 0 is fine
         errs[f] = max(parity.field_rel_err(g[:, :3], r[:, :3]), parity.field_rel_err(g[:, 3:], r[:, 3:]))
     st_h, st_r = hip.model["apollo_state"], ref.apollo_state
-    scale = np.maximum(np.abs(st_r), 1e-3)
+    # rcs_torque (slots 9-11) is a PD law's difference of two nearly equal terms while the vehicle sits on its setpoint
+    # (a few N m against a 3,560 N m authority): measured against 1 N m, like tests/apollo_fixture_util.FLOORS
+    floor = np.full(st_r.shape[1], 1e-3)
+    floor[9:12] = 1.0
+    scale = np.maximum(np.abs(st_r), floor)
     errs["apollo_state"] = float(np.max(np.abs(st_h - st_r) / scale))
     errs["inertia"] = parity.field_rel_err(hip.inertia, ref.inertia)
     return errs
