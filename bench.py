@@ -275,7 +275,7 @@ def falcon9_leg(device):
             "meco_alt_km": [round(float(res[:, 4].min()) / 1e3, 2), round(float(res[:, 4].max()) / 1e3, 2)]}
 
 
-def campaign_bench(which, rank, world, local_rank, comm_device, barrier):
+def campaign_bench(which, rank, world, local_rank, comm_device, barrier, capi_comm=None):
     """One whole campaign, weak-scaled: BASELINE's rollout count PER GPU (8,192 Apollo descents / 32,768 Falcon 9 ascents),
     rank 0 samples the plan, the table is broadcast and the result rows are gathered over the process group (RCCL on
     `nccl`); no exchange while the rollouts fly.  Timed region = broadcast + flight + gather, max over ranks."""
@@ -288,14 +288,14 @@ def campaign_bench(which, rank, world, local_rank, comm_device, barrier):
         spec["monte_carlo"]["n_samples"] = per_gpu * world
         table = mc.materialize(spec).table() if rank == 0 else None
         ticks = model.max_ticks(model.load_reference())
-        run = lambda: model.run_campaign(table, per_gpu * world, ticks, device=local_rank, comm_device=comm_device)
+        run = lambda: model.run_campaign(table, per_gpu * world, ticks, device=local_rank, comm_device=comm_device, comm=capi_comm)
         ok = lambda res: float(res[:, 8].mean())           # landed
         desc = f"Apollo-lander Monte-Carlo, {per_gpu} rollouts per GPU x {ticks} ticks max, semi-implicit f64 (BASELINE configs[3])"
     else:
         from elodin_amd.models import falcon9 as model
         per_gpu, ticks, dtype = 32768, model.ASCENT_TICKS, "f32"
         table = model.sample_params(per_gpu * world) if rank == 0 else None
-        run = lambda: model.run_campaign(table, per_gpu * world, ticks, device=local_rank, comm_device=comm_device)
+        run = lambda: model.run_campaign(table, per_gpu * world, ticks, device=local_rank, comm_device=comm_device, comm=capi_comm)
         ok = lambda res: float((res[:, 3] > 0.0).mean())   # reached MECO
         desc = f"Falcon 9 ascent Monte-Carlo, {per_gpu} rollouts per GPU x {ticks} ticks, semi-implicit f32 (BASELINE configs[4])"
     if which == "falcon9":      # executor construction compiles / loads the generated program: keep it out of the timing
@@ -311,7 +311,8 @@ def campaign_bench(which, rank, world, local_rank, comm_device, barrier):
     return {"metric": "rollout-steps/s (whole campaign)", "value": round(n_runs * ticks / elapsed, 1), "unit": "rollout-steps/s",
             "n_gpus": world, "steps": ticks, "warmup": 0, "ms_per_step": round(elapsed / ticks * 1e3, 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic (sampled plan)",
-            "config": {"workload": desc, "rollouts": n_runs, "parallelism": f"run-id shards x{world}; broadcast plan + gather results"},
+            "config": {"workload": desc, "rollouts": n_runs, "parallelism": f"run-id shards x{world}; broadcast plan + gather results",
+                       "collectives": "C ABI (sixdof_campaign_broadcast / _gather over RCCL)" if capi_comm is not None else "torch.distributed"},
             "campaign_seconds": round(elapsed, 4), "success_fraction": round(ok(res), 4) if rank == 0 else None}
 
 
@@ -389,6 +390,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_hbm / fused legs")
     ap.add_argument("--skip-legs", default="", help="comma-separated informational legs to leave out (e.g. telemetry_commit)")
+    ap.add_argument("--capi-comm", action="store_true",
+                    help="with --campaign: plan broadcast / result gather through the C ABI's own RCCL entry points "
+                         "(sixdof_comm_*), the id shipped over the launcher's process group, instead of torch collectives")
     ap.add_argument("--campaign", choices=("apollo", "falcon9"), default=None,
                     help="instead of the config-2 step: one whole Monte-Carlo campaign (BASELINE configs[3] / configs[4]) "
                          "sharded over the ranks, plan broadcast + result gather over RCCL; --steps/--warmup are ignored")
@@ -415,7 +419,16 @@ def main():
 
     if args.campaign:
         comm = torch.device("cuda", local_rank) if distributed else "cpu"
-        line = campaign_bench(args.campaign, rank, world, local_rank, comm, barrier)
+        capi = None
+        if args.capi_comm:
+            from elodin_amd import shard
+            box = [shard.CapiComm.unique_id() if (rank == 0 and world > 1) else None]
+            if distributed:
+                dist.broadcast_object_list(box, src=0, device=torch.device("cuda", local_rank))
+            capi = shard.CapiComm(box[0], world, rank, local_rank)
+        line = campaign_bench(args.campaign, rank, world, local_rank, comm, barrier, capi)
+        if capi is not None:
+            capi.close()
         if distributed:
             dist.barrier(device_ids=[local_rank])
             dist.destroy_process_group()

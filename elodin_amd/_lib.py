@@ -84,6 +84,13 @@ SYMBOLS = {
                                        C.POINTER(C.c_size_t)]),
     "sixdof_upload": (C.c_int, [_H]),
     "sixdof_prepare_step": (C.c_int, [_H, C.c_uint64]),
+    "sixdof_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "sixdof_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int]),
+    "sixdof_comm_destroy": (None, [C.c_void_p]),
+    "sixdof_comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "sixdof_shard_range": (None, [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "sixdof_campaign_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
+    "sixdof_campaign_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.c_uint64]),
     "sixdof_step": (C.c_int, [_H, C.c_uint64, C.POINTER(Timings)]),
     "sixdof_download": (C.c_int, [_H, C.c_uint32]),
     "sixdof_get_tick": (C.c_int, [_H, C.POINTER(C.c_uint64)]),

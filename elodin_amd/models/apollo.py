@@ -160,19 +160,24 @@ def result_record(row: Mapping[str, float]) -> Dict[str, object]:
 
 
 def run_campaign(plan_table: np.ndarray | None, n_runs: int, n_ticks: int, *, ticks_per_launch: int = 1000,
-                 device: int = 0, comm_device="cpu", make_exec=None) -> np.ndarray:
+                 device: int = 0, comm_device="cpu", make_exec=None, comm=None) -> np.ndarray:
     """One Monte-Carlo campaign across the ranks of the current torch.distributed group (or one process).
 
     Rank 0 holds the plan table ([n_runs, 17], plan.table()); it is broadcast (RCCL over xGMI on "nccl"),
     every rank flies its contiguous block of run ids with no per-step exchange, and the result rows are
     all-gathered back into run-id order — the GPU counterpart of `elodin monte-carlo run`
     (libs/monte-carlo/src/lib.rs:1066-1140: one process per run, results.csv per campaign).
-    `make_exec(params_block, first_row)` builds the executor (default: ApolloExec on `device`)."""
+    `make_exec(params_block, first_row)` builds the executor (default: ApolloExec on `device`).
+    `comm`: a shard.CapiComm — the same broadcast / gather through the C ABI's RCCL entry points instead of torch."""
     from .. import shard
     import torch.distributed as dist
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
-    table = shard.broadcast_table(plan_table, (n_runs, N_PARAMS), device=comm_device)
+    if comm is not None:
+        world, rank = comm.world, comm.rank
+        table = comm.broadcast_table(plan_table, (n_runs, N_PARAMS))
+    else:
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        table = shard.broadcast_table(plan_table, (n_runs, N_PARAMS), device=comm_device)
     lo, hi = shard.shard_range(n_runs, world, rank)
     if make_exec is None:
         make_exec = lambda block, first_row: ApolloExec(block, ticks_per_launch=ticks_per_launch, device=device,
@@ -182,4 +187,4 @@ def run_campaign(plan_table: np.ndarray | None, n_runs: int, n_ticks: int, *, ti
     local = np.ascontiguousarray(ex.result)
     if hasattr(ex, "close"):
         ex.close()
-    return shard.gather_rows(local, n_runs, device=comm_device)
+    return comm.gather_rows(local, n_runs) if comm is not None else shard.gather_rows(local, n_runs, device=comm_device)

@@ -896,15 +896,19 @@ def prebuild() -> list:
 
 def run_campaign(plan_table: Optional[np.ndarray], n_runs: int, n_ticks: int = ASCENT_TICKS, *, dtype=np.float32,
                  ticks_per_launch: int = 1000, device: int = 0, comm_device="cpu", make_exec=None,
-                 fast_math: Optional[bool] = None) -> np.ndarray:
+                 fast_math: Optional[bool] = None, comm=None) -> np.ndarray:
     """One ascent campaign across the ranks of the current torch.distributed group (or one process): rank 0's plan table
     ([n_runs, 16], sample_params) is broadcast, every rank flies its contiguous block of run ids with no per-step
     exchange, result rows are gathered back in run-id order (same scheme as models/apollo.run_campaign)."""
     from .. import shard
     import torch.distributed as dist
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
-    table = shard.broadcast_table(plan_table, (n_runs, len(PARAM_NAMES)), device=comm_device)
+    if comm is not None:      # shard.CapiComm: the C ABI's RCCL collectives instead of torch.distributed
+        world, rank = comm.world, comm.rank
+        table = comm.broadcast_table(plan_table, (n_runs, len(PARAM_NAMES)))
+    else:
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        table = shard.broadcast_table(plan_table, (n_runs, len(PARAM_NAMES)), device=comm_device)
     lo, hi = shard.shard_range(n_runs, world, rank)
     if make_exec is None:
         fast = (np.dtype(dtype) == np.float32) if fast_math is None else bool(fast_math)   # hardware transcendentals in f32:
@@ -916,4 +920,4 @@ def run_campaign(plan_table: Optional[np.ndarray], n_runs: int, n_ticks: int = A
     local = np.ascontiguousarray(ex.result)
     if hasattr(ex, "close"):
         ex.close()
-    return shard.gather_rows(local, n_runs, device=comm_device)
+    return comm.gather_rows(local, n_runs) if comm is not None else shard.gather_rows(local, n_runs, device=comm_device)

@@ -72,3 +72,61 @@ def gather_rows(local_rows: np.ndarray, total_rows: int, device="cpu") -> np.nda
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
     return np.concatenate([o.cpu().numpy()[: hi - lo] for o, (lo, hi) in zip(out, sizes)], axis=0)
+
+
+class CapiComm:
+    """The same two campaign collectives through the C ABI (sixdof_comm_* / sixdof_campaign_* over RCCL, no torch): what a
+    non-Python host of the path calls.  `unique_id()` on rank 0, ship the 128 bytes to the other ranks, then every rank
+    constructs `CapiComm(id, world, rank, device)`."""
+
+    def __init__(self, comm_id: bytes | None, world: int, rank: int, device: int = 0):
+        import ctypes as C
+        from . import _lib as L
+        self._lib, self._C = L.lib(), C
+        self.world, self.rank = int(world), int(rank)
+        self._h = C.c_void_p()
+        idbuf = (C.c_uint8 * 128)(*(comm_id or bytes(128)))
+        rc = self._lib.sixdof_comm_init(C.byref(self._h), idbuf, self.world, self.rank, int(device))
+        if rc != L.OK:
+            msg = self._lib.sixdof_comm_last_error(None)
+            raise L.BackendError(f"sixdof_comm_init: {msg.decode() if msg else ''} (status {rc})")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib as L
+        buf = (C.c_uint8 * 128)()
+        rc = L.lib().sixdof_comm_unique_id(buf)
+        if rc != L.OK:
+            msg = L.lib().sixdof_comm_last_error(None)
+            raise L.BackendError(f"sixdof_comm_unique_id: {msg.decode() if msg else ''} (status {rc})")
+        return bytes(buf)
+
+    def _check(self, rc, what):
+        from . import _lib as L
+        if rc != L.OK:
+            msg = self._lib.sixdof_comm_last_error(self._h)
+            raise L.BackendError(f"{what}: {msg.decode() if msg else ''} (status {rc})")
+
+    def broadcast_table(self, table: np.ndarray | None, shape, dtype=np.float64, src: int = 0) -> np.ndarray:
+        buf = (np.ascontiguousarray(table, dtype=dtype).reshape(shape).copy() if self.rank == src
+               else np.empty(tuple(shape), dtype=dtype))
+        self._check(self._lib.sixdof_campaign_broadcast(self._h, buf.ctypes.data, buf.nbytes, int(src)), "sixdof_campaign_broadcast")
+        return buf
+
+    def gather_rows(self, local_rows: np.ndarray, total_rows: int) -> np.ndarray:
+        C = self._C
+        local = np.ascontiguousarray(local_rows, dtype=np.float64)
+        width = local.shape[1]
+        out = np.empty((int(total_rows), width), dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        self._check(self._lib.sixdof_campaign_gather(self._h, local.ctypes.data_as(dp), local.shape[0], width, out.ctypes.data_as(dp),
+                                                     int(total_rows)), "sixdof_campaign_gather")
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.sixdof_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close

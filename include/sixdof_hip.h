@@ -22,6 +22,7 @@
  *   World / Column / spawn        world.rs:23-45,193-229      sixdof_world_* + sixdof_bind_world
  *   commit_world_head per batch   impeller2_server.rs:390-438 sixdof_download_async / _wait, sixdof_set_history
  *   failure detection / resume    (process exit, DB replay)   sixdof_count_nonfinite, sixdof_get/set_tick
+ *   campaign fan-out / fan-in     monte-carlo/src/lib.rs:1066-1140,2083  sixdof_comm_*, sixdof_campaign_broadcast / _gather
  *
  * Column byte layout is the reference's (`World.host`, world.rs:23-45): row r of a
  * component occupies bytes [r*size, (r+1)*size), little-endian, row-major, rows in
@@ -326,6 +327,29 @@ struct sixdof_apollo_tables; /* include/sixdof_apollo.h */
 int sixdof_set_model_apollo(sixdof_handle* h, const struct sixdof_apollo_tables* tables);
 /* D2H of any bound column by id (model columns are not covered by the sixdof_download mask). */
 int sixdof_download_column(sixdof_handle* h, uint64_t component_id);
+
+/* ---- campaign collectives: Monte-Carlo rollouts sharded over the GPUs of one node ---------------------------------------
+ * The reference runs one OS process per rollout with nothing exchanged between them (libs/monte-carlo/src/lib.rs:2083): the
+ * plan row reaches a run through its context file and result.json comes back through the file system.  With rollouts as
+ * column rows on several GPUs the two movements are ONE broadcast of the plan table from rank 0 and ONE gather of the
+ * result rows, in run-id order (row = idx, run_id = run_%07d, seed = idx + 1: sample.py:149) — RCCL over xGMI, loaded
+ * with dlopen (a single-GPU host never needs it).  No exchange per step.  One communicator = one rank = one GPU = one
+ * caller thread, like a handle.  The 128-byte id is RCCL's ncclUniqueId: rank 0 makes it, the host ships it to the other
+ * ranks by whatever channel it already has (the runner's job file, an env var, a socket). */
+typedef struct sixdof_comm sixdof_comm;
+#define SIXDOF_COMM_ID_BYTES 128
+int sixdof_comm_unique_id(uint8_t id[SIXDOF_COMM_ID_BYTES]);                       /* SIXDOF_ERR_UNSUPPORTED: no RCCL here */
+int sixdof_comm_init(sixdof_comm** out, const uint8_t id[SIXDOF_COMM_ID_BYTES], int world, int rank, int device_ordinal);
+void sixdof_comm_destroy(sixdof_comm* c);
+const char* sixdof_comm_last_error(const sixdof_comm* c);                          /* c may be NULL: last init error */
+/* Rank r's contiguous block [lo, hi) of n_rows run ids (blocks differ by at most one row). */
+void sixdof_shard_range(uint64_t n_rows, int world, int rank, uint64_t* lo, uint64_t* hi);
+/* `root`'s host buffer of n_bytes (the plan table [n_runs, n_params] f64, a reference profile ...) -> every rank's. */
+int sixdof_campaign_broadcast(sixdof_comm* c, void* table, uint64_t n_bytes, int root);
+/* Every rank contributes its block's result rows [n_local, width] f64 (n_local = its sixdof_shard_range of n_total);
+ * every rank receives all [n_total, width] rows in run-id order. */
+int sixdof_campaign_gather(sixdof_comm* c, const double* local_rows, uint64_t n_local, uint64_t width, double* all_rows,
+                           uint64_t n_total);
 
 #ifdef __cplusplus
 }
