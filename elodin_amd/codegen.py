@@ -451,87 +451,16 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) ->
         cols = tp.columns
         n_model = len(cols)
         regs = "\n".join(f"        T c{k}[{w}];" for k, (_, w) in enumerate(cols))
-        zero = " ".join(f"for (int j = 0; j < {w}; j++) r.c{k}[j] = T(0);" for k, (_, w) in enumerate(cols))
-        elem = 8 if dtype == "float64" else 4
-        lds_cap = _MODEL_LDS_F64 if dtype == "float64" else _MODEL_LDS_F32
-
-        def batches(slots):
-            """Pack columns into staging batches of at most lds_cap elements per row."""
-            out, cur, used = [], [], 0
-            for k in slots:
-                w = cols[k][1]
-                if cur and used + w > lds_cap:     # (a slab starts at used * 64 * elem bytes: always 16-B aligned)
-                    out.append(cur)
-                    cur, used = [], 0
-                cur.append((k, used))
-                used += w
-            if cur:
-                out.append(cur)
-            return out
-
-        def slab_in(slots):
-            """Double-buffered: the staging area is two halves; batch b+1's LDS-DMA is in flight while batch b is read, so
-            the load phase costs about one memory round trip, not one per batch."""
-            bs = batches(slots)
-            half = f"kWave * {lds_cap}"
-            code = []
-
-            def issue(b):
-                buf = f"(lds + {b % 2} * {half})"
-                for k, off in bs[b]:
-                    w = cols[k][1]
-                    code.append(f"            slab_dma_in<kWave * {w} * sizeof(T), kPolPlain>(reinterpret_cast<const char*>(static_cast<const T*>(P.model_cols[{k}]) + (size_t)row0 * {w}), "
-                                f"reinterpret_cast<char*>({buf} + kWave * {off}), lane);")
-
-            def n_dma(b):   # wave-level LDS-DMA instructions of a batch (1 KiB each + a partial one)
-                return sum((64 * cols[k][1] * elem + 1023) // 1024 for k, _ in bs[b])
-            code.append("            __syncthreads();   // the staging area is free")
-            for b in range(min(2, len(bs))):
-                issue(b)
-            for b in range(len(bs)):
-                pending = n_dma(b + 1) if b + 1 < len(bs) else 0     # batch b+1 may still be in flight
-                code.append(f'            asm volatile("s_waitcnt vmcnt({min(pending, 63)})" ::: "memory");')
-                code.append("            __syncthreads();")
-                buf = f"(lds + {b % 2} * {half})"
-                for k, off in bs[b]:
-                    w = cols[k][1]
-                    code.append(f"            {{ const T* l = {buf} + kWave * {off} + lane * {w}; " + " ".join(f"r.c{k}[{j}] = l[{j}];" for j in range(w)) + " }")
-                if b + 2 < len(bs):
-                    code.append("            __syncthreads();   // every lane has read this half")
-                    issue(b + 2)
-            return "\n".join(code)
-
-        def slab_out_code(slots, dst):
-            """dst(k, w) -> C expression of the column's destination base pointer (T*) for this wave's slab."""
-            code = []
-            for batch in batches(slots):
-                code.append("            __syncthreads();   // the staging area is free")
-                for k, off in batch:
-                    w = cols[k][1]
-                    code.append(f"            {{ T* l = lds + kWave * {off} + lane * {w}; " + " ".join(f"l[{j}] = r.c{k}[{j}];" for j in range(w)) + " }")
-                code.append("            __syncthreads();")
-                for k, off in batch:
-                    w = cols[k][1]
-                    code.append(f"            if ({dst(k, w)} != nullptr) slab_out<kWave * {w} * sizeof(T), kPolNtStores>(reinterpret_cast<const char*>(lds + kWave * {off}), "
-                                f"reinterpret_cast<char*>({dst(k, w)}), lane);")
-            return "\n".join(code)
-
-        all_slots = list(range(len(cols)))
-        loads_tail = "\n".join(
+        loads = "\n".join(
             f"            {{ const T* g = static_cast<const T*>(P.model_cols[{k}]) + (size_t)row * {w}; "
             + " ".join(f"r.c{k}[{j}] = g[{j}];" for j in range(w)) + " }" for k, (_, w) in enumerate(cols))
-        stores_tail = "\n".join(
-            f"            {{ T* g = static_cast<T*>(P.model_cols[{k}]) + (size_t)row * {cols[k][1]}; "
+        zero = " ".join(f"for (int j = 0; j < {w}; j++) r.c{k}[j] = T(0);" for k, (_, w) in enumerate(cols))
+        stores = "\n".join(
+            f"        {{ T* g = static_cast<T*>(P.model_cols[{k}]) + (size_t)row * {cols[k][1]}; "
             + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(cols[k][1])) + " }" for k in tp.written_slots)
-        records_tail = "\n".join(
-            f"            if (P.model_hist[{k}]) {{ T* g = static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row) * {w}; "
+        records = "\n".join(
+            f"        if (P.model_hist[{k}]) {{ T* g = static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row) * {w}; "
             + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(w)) + " }" for k, (_, w) in enumerate(cols))
-        io_mode = os.environ.get("SIXDOF_CODEGEN_IO", _CODEGEN_IO)     # "<loads>,<stores>": lane | slab
-        ld_mode, st_mode = (io_mode.split(",") + ["slab"])[:2]
-        loads = slab_in(all_slots) if ld_mode == "slab" else "            if (lane < rows) { const uint32_t row = row0 + lane;\n" + loads_tail + "\n            }"
-        stores = (slab_out_code(list(tp.written_slots), lambda k, w: f"(static_cast<T*>(P.model_cols[{k}]) + (size_t)row0 * {w})")
-                  if st_mode == "slab" else "            if (lane < rows) { const uint32_t row = row0 + lane;\n" + stores_tail + "\n            }")
-        records = slab_out_code(all_slots, lambda k, w: f"(P.model_hist[{k}] ? static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row0) * {w} : nullptr)")
         model = f'''
     static constexpr bool kHasModel = true;
     static constexpr bool kWritesInertia = {"true" if tp.writes_inertia else "false"};
@@ -539,37 +468,20 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) ->
     struct Regs {{
 {regs}
     }};
-    static constexpr int kModelLds = 2 * {lds_cap};   // two halves: double-buffered loads
-    // Component columns move like the Body columns (step_kernel.hpp): a wave's 64 rows of a column are one contiguous
-    // slab, pulled HBM -> LDS by LDS-DMA and pushed back with 16-B-per-lane stores, {lds_cap} elements per row at a time;
-    // each lane reads / writes its own row in LDS.  A ragged last wave falls back to per-lane row accesses.
     template <class T>
-    __device__ static __forceinline__ void load(const StepParams& P, uint32_t row0, uint32_t rows, uint32_t lane, T* lds, Regs<T>& r) {{
+    __device__ static __forceinline__ void load(const StepParams& P, uint32_t row, bool active, Regs<T>& r) {{
         {zero}
-        if (rows == kWave) {{
+        if (active) {{
 {loads}
-        }} else if (lane < rows) {{
-            const uint32_t row = row0 + lane;
-{loads_tail}
         }}
     }}
     template <class T>
-    __device__ static __forceinline__ void store(const StepParams& P, uint32_t row0, uint32_t rows, uint32_t lane, T* lds, const Regs<T>& r) {{
-        if (rows == kWave) {{
+    __device__ static __forceinline__ void store(const StepParams& P, uint32_t row, const Regs<T>& r) {{
 {stores}
-        }} else if (lane < rows) {{
-            const uint32_t row = row0 + lane;
-{stores_tail}
-        }}
     }}
     template <class T>
-    __device__ static __forceinline__ void record(const StepParams& P, size_t slot, uint32_t row0, uint32_t rows, uint32_t lane, T* lds, const Regs<T>& r) {{
-        if (rows == kWave) {{
+    __device__ static __forceinline__ void record(const StepParams& P, size_t slot, uint32_t row, const Regs<T>& r) {{
 {records}
-        }} else if (lane < rows) {{
-            const uint32_t row = row0 + lane;
-{records_tail}
-        }}
     }}
     template <class T>
     __device__ static __forceinline__ void pre(const StepParams& P, uint64_t tick, Regs<T>& r, Quat<T>& q, Vec3<T>& p,
@@ -786,9 +698,7 @@ _RETRY_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills"]
 # Builds are tried in this order and the FIRST without VGPR spills is kept.  The last resort trades speed for a smaller
 # live set (-O1: no unrolling / less hoisting); the fuzz program that miscomputed when spilling is exact at -O1.
 _ATTEMPTS = (("-O3", _BASE_FLAGS), ("-O3", _BASE_FLAGS + _RETRY_FLAGS), ("-O1", []))
-_CACHE_TAG = "rp2"
-_MODEL_LDS_F64, _MODEL_LDS_F32 = 32, 64     # staging elements per row and half for a program's component columns: 2 x 16 KiB of LDS per wave
-_CODEGEN_IO = "slab,slab"                   # how generated programs move their component columns (loads, stores)           # bump when the flag policy changes: cached objects are keyed on it
+_CACHE_TAG = "rp2"           # bump when the flag policy changes: cached objects are keyed on it
 ALLOW_SPILLS_ENV = "SIXDOF_ALLOW_SPILLS"   # "1": accept a build that still spills VGPRs (known-unsafe on gfx950, see above)
 last_resources: Dict[str, int] = {}
 

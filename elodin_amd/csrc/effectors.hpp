@@ -74,16 +74,14 @@ __device__ __forceinline__ void apply_one(const DevOp& op, const Vec3<T>& aux, c
 struct NoModel {
     static constexpr bool kHasModel = false;
     static constexpr bool kWritesInertia = false;
-    static constexpr int kModelLds = 1;   // LDS staging elements per row for the component columns of a generated program
     template <class T>
     struct Regs {};
-    // (row0, rows, lane) = the wave's slab; `lds` = kWave * kModelLds elements of staging space
     template <class T>
-    __device__ static __forceinline__ void load(const StepParams&, uint32_t, uint32_t, uint32_t, T*, Regs<T>&) {}
+    __device__ static __forceinline__ void load(const StepParams&, uint32_t, bool, Regs<T>&) {}
     template <class T>
-    __device__ static __forceinline__ void store(const StepParams&, uint32_t, uint32_t, uint32_t, T*, const Regs<T>&) {}
+    __device__ static __forceinline__ void store(const StepParams&, uint32_t, const Regs<T>&) {}
     template <class T>
-    __device__ static __forceinline__ void record(const StepParams&, size_t, uint32_t, uint32_t, uint32_t, T*, const Regs<T>&) {}
+    __device__ static __forceinline__ void record(const StepParams&, size_t, uint32_t, const Regs<T>&) {}
     template <class T>
     __device__ static __forceinline__ void pre(const StepParams&, uint64_t, Regs<T>&, Quat<T>&, Vec3<T>&, Spatial<T>&,
                                                Vec3<T>&, T&) {}

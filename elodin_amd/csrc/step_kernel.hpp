@@ -155,10 +155,10 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     load_aux(std::integral_constant<int, 3>{});
 
     typename PIPE::template Regs<T> regs;   // component columns of a generated program, one row per lane
-    // their slabs go through an LDS staging area of their own (64 rows x kModelLds elements), batch by batch: same
-    // LDS-DMA in / 16-B-per-lane out as the Body columns instead of per-lane strided row accesses
-    __shared__ __attribute__((aligned(16))) T model_lds[PIPE::kHasModel ? kWave * PIPE::kModelLds : 1];
-    if constexpr (PIPE::kHasModel) PIPE::load(P, row0, rows, t, model_lds, regs);
+    // each lane reads / writes its own rows straight from global memory: for programs with dozens of narrow columns that
+    // beats staging their slabs through LDS (profiles/r02_generated_io_ab.txt: Falcon 9 at one tick per launch, 1M
+    // rollouts: 287 us per-lane vs 360 us with LDS-DMA slabs, double-buffered) — everything is in flight at once
+    if constexpr (PIPE::kHasModel) PIPE::load(P, row0 + t, active, regs);
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA data has landed
     __syncthreads();
@@ -364,13 +364,14 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             flush6(l_vel, static_cast<T*>(P.hist_vel) + r6, kRing);
             flush6(l_c, static_cast<T*>(P.hist_accel) + r6, kRing);
             flush6(l_force, static_cast<T*>(P.hist_force) + r6, kRing);
-            if constexpr (PIPE::kHasModel) PIPE::record(P, slot, row0, rows, t, model_lds, regs);   // component columns of a generated program
+            if constexpr (PIPE::kHasModel)
+                if (active) PIPE::record(P, slot, row0 + t, regs);   // component columns of a generated program
             __syncthreads();
         }
     }
     if constexpr (PIPE::kHasModel) {
-        PIPE::store(P, row0, rows, t, model_lds, regs);
         if (active) {
+            PIPE::store(P, row0 + t, regs);
             if constexpr (PIPE::kWritesInertia) {   // a system returned el.Inertia: the column is an output
                 T* gi = static_cast<T*>(const_cast<void*>(P.inertia)) + (size_t)(row0 + t) * 7;
                 gi[0] = I_diag.x; gi[1] = I_diag.y; gi[2] = I_diag.z; gi[6] = mass;

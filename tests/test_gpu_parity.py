@@ -151,6 +151,28 @@ def test_f32_extension_tracks_f64_oracle():
     assert max(errs.values()) < 2e-4, errs
 
 
+def test_f32_config2_full_size_1000_ticks_drift_bound():
+    """The f32 instantiation at BASELINE configs[1] size over a long horizon: 65,536 bodies x 1,000 RK4 ticks against the
+    f64 oracle.  The reference has no f32 six_dof (six_dof.rs:12-14), so this bound is this build's own statement of f32
+    drift: positions (|p| ~ 1e3 m, moving ~1e2 m) and velocities within 5e-5 of their scale, attitudes within 2e-3 (the
+    quaternion integrates ~1e3 rotations of ~4e-3 rad, one f32 rounding each)."""
+    import os
+    w = workloads.independent_bodies(65536)
+    eff = workloads.gravity_torque_effectors(w["body_torque"])
+    hip = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=np.float32, simulation_time_step=workloads.DT_120HZ,
+                     effectors=eff, ticks_per_launch=50)
+    ref = orc.OracleWorld(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ,
+                          ops=parity.to_oracle_ops(eff))
+    hip.run(1000)
+    ref.step(1000, threads=len(os.sched_getaffinity(0)))
+    q_err = parity.field_rel_err(hip.world_pos[:, :4], ref.world_pos[:, :4])
+    p_err = parity.field_rel_err(hip.world_pos[:, 4:], ref.world_pos[:, 4:])
+    errs = parity.state_errors(hip, ref)
+    print(f"f32 config 2, 65,536 x 1,000 ticks: attitude {q_err:.2e}, position {p_err:.2e}, rest {errs}")
+    assert q_err < 2e-3 and p_err < 5e-5, (q_err, p_err)
+    assert errs["world_vel"] < 2e-3 and errs["world_accel"] < 2e-3 and errs["force"] < 2e-3, errs
+
+
 def test_tickfn_shim_roundtrip():
     """sixdof_tick(inputs**, outputs**) — the reference's TickFn ABI (cranelift_exec.rs:11)."""
     import ctypes as C
@@ -354,6 +376,27 @@ def test_config2_full_baseline_horizon_10000_ticks():
     print("config2 10,000 ticks worst rel err", worst)
     assert worst < parity.F64_RTOL
     assert hip.tick == ref.tick == 10000
+
+
+def test_nbody_config3_full_size_100_ticks_vs_oracle():
+    """BASELINE configs[2] at its stated size AND horizon: 16,384 bodies, all-pairs softened gravity, RK4,
+    dt = 3600 s, 100 ticks against the sequential-fold oracle (its all-pairs fold spread over the host cores), checked at
+    ticks 1, 10, 50 and 100."""
+    import os
+    n = 16384
+    pos, vel, inertia = _plummer(n, seed=16384)
+    op = (K_SQ, EPS_AU2)
+    hip = ea.HipExec(pos, vel, inertia, simulation_time_step=3600.0, effectors=[ea.Effector(L.EFF_ALLPAIRS_GRAVITY_SOFTENED, op)])
+    ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=3600.0, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, op, None)])
+    th = len(os.sched_getaffinity(0))
+    worst = {}
+    for cp in (1, 10, 50, 100):
+        hip.run(cp - hip.tick)
+        ref.step(cp - ref.tick, threads=th)
+        for k, e in parity.state_errors(hip, ref).items():
+            worst[k] = max(worst.get(k, 0.0), e)
+    print("n-body 16,384 x 100 ticks worst rel err", worst)
+    assert max(worst.values()) < parity.F64_RTOL, worst
 
 
 def test_nbody_config3_full_size_vs_oracle_and_momentum():

@@ -7,7 +7,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
 from elodin_amd.models import falcon9 as f9
 
-for n in (32768, 262144, 1048576):
+for n in [int(x) for x in sys.argv[1:]] or (32768, 262144, 1048576):
     ex = f9.AscentExec(np.tile(f9.default_param_row(), (n, 1)), dtype=np.float32, fast_math=True, ticks_per_launch=1)
     widths = dict(ex.program.trace().columns)
     read_b = 4 * (sum(widths.values()) + 7 + 6 + 7)
