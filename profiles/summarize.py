@@ -30,8 +30,9 @@ lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
          "Durations in microseconds; `grid` = total work-items (= entities for the step kernel). The 65536-entity",
          "step kernel appears with ticks_per_launch = 1 (timed region + warmup), = 64 (`fused`) and = 64 with the",
          "telemetry ring (`recording`): rows are split by duration.  PipeStatic<2, 3> = gravity | body_torque;",
-         "the trailing bool is the non-temporal (streaming) instantiation; PipeCustom = a generated pipe / program",
-         "(`<float, 1, PipeCustom, 0>` at grid 32768 = the Falcon 9 ascent campaign, 1000 ticks per launch).", "",
+         "the trailing int is the cache-policy code of the instantiation (load * 8 + store: 1 = plain loads + nt stores,",
+         "2 = plain loads + sc1 stores, 9 = nt both ways; csrc/step_kernel.hpp); PipeCustom = a generated pipe / program",
+         "(`<float, 1, PipeCustom, 1>` at grid 32768 = the Falcon 9 ascent campaign, 1000 ticks per launch).", "",
          "| kernel | grid | launches | avg us | min us | max us | total ms |", "|---|---|---|---|---|---|---|"]
 for (name, grid), d in sorted(stats.items(), key=lambda kv: -sum(kv[1])):
     groups = [("", d)]
