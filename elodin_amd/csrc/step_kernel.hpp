@@ -232,8 +232,10 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     b.I = I_diag;
     Wrench<T> F = zero_wrench<T>();
     bool flushed = false;   // wave-uniform: the live columns already left on the early path
-    for (uint32_t tick = 0; tick < P.n_ticks; tick++) {
-        const bool early = early_ok && tick + 1 == P.n_ticks;
+    // One tick.  EARLY is a compile-time flag so that the per-tick body of a fused launch (n_ticks > 1) carries none of
+    // the early-store branches: only the last tick of a launch is instantiated with them.
+    auto one_tick = [&](auto early_tag, uint32_t tick) {
+        constexpr bool early = decltype(early_tag)::value;
         if constexpr (PIPE::kHasModel) {   // user systems piped in front of six_dof (may rewrite inertia, pose, velocity)
             PIPE::pre(P, P.tick0 + tick + 1, regs, q0, p0, v0, I_diag, mass);
             if constexpr (PIPE::kWritesInertia) {
@@ -282,20 +284,20 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             const T g = dt * T(1.0 / 6.0);
             const Quat<T> q_new = integrate_world(q0, g * sv.ang);
             const Vec3<T> p_new = axpy(g, sv.lin, p0);
-            if (early) {
+            if constexpr (early) {
                 stage_pos(q_new, p_new);
                 __syncthreads();
                 flush7(l_pos, g_pos, kLive);
             }
             F = zero_wrench<T>();
             PIPE::apply(P, aux, regs, b, F);
-            if (early) {
+            if constexpr (early) {
                 stage6(l_force, world_wrench<PIPE>(b.q, F));
                 __syncthreads();
                 flush6(l_force, g_force, kLive);
             }
             A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
-            if (early) {
+            if constexpr (early) {
                 stage6(l_c, A);
                 __syncthreads();
                 flush6(l_c, g_accel, kLive);
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             q0 = q_new;
             p0 = p_new;
             A_out = A;
-            if (early) {
+            if constexpr (early) {
                 stage6(l_vel, v0);
                 __syncthreads();
                 flush6(l_vel, g_vel, kLive);
@@ -321,19 +323,19 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             b.v = v0;
             F = zero_wrench<T>();
             PIPE::apply(P, aux, regs, b, F);
-            if (early) {
+            if constexpr (early) {
                 stage6(l_force, world_wrench<PIPE>(b.q, F));
                 __syncthreads();
                 flush6(l_force, g_force, kLive);
             }
             const Spatial<T> A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
-            if (early) {
+            if constexpr (early) {
                 stage6(l_c, A);
                 __syncthreads();
                 flush6(l_c, g_accel, kLive);
             }
             v0 = axpy(dt, A, v0);
-            if (early) {
+            if constexpr (early) {
                 stage6(l_vel, v0);
                 __syncthreads();
                 flush6(l_vel, g_vel, kLive);
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             q0 = integrate_world(q0, dt * v0.ang);
             p0 = axpy(dt, v0.lin, p0);
             A_out = A;
-            if (early) {
+            if constexpr (early) {
                 stage_pos(q0, p0);
                 __syncthreads();
                 flush7(l_pos, g_pos, kLive);
@@ -368,6 +370,11 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
                 if (active) PIPE::record(P, slot, row0 + t, regs);   // component columns of a generated program
             __syncthreads();
         }
+    };
+    if (P.n_ticks) {
+        for (uint32_t tick = 0; tick + 1 < P.n_ticks; tick++) one_tick(std::false_type{}, tick);
+        if (early_ok) one_tick(std::true_type{}, P.n_ticks - 1);
+        else one_tick(std::false_type{}, P.n_ticks - 1);
     }
     if constexpr (PIPE::kHasModel) {
         if (active) {

