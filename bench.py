@@ -154,10 +154,41 @@ def nbody_leg(device):
     return {"bodies": n, "ms_per_tick": round(ms, 4), "body_steps_per_s": round(n / ms * 1e3, 1),
             "pair_evals_per_s": round(evals / ms * 1e3, 1), "bound": "f64 vector ALU",
             "f64_instr_per_eval": "17 VALU + 1 v_rsq_f64",
+            # ALGORITHMIC flops of config 3 = 4 N (N - 1) 20 per tick, against the 78.6 TF f64 vector peak
+            "roofline": {"bound": "f64 vector ALU", "achieved": round(4.0 * n * (n - 1) * 20 / (ms * 1e-3) / 1e12, 2), "peak": 78.6,
+                         "unit": "TFLOP/s", "frac": round(4.0 * n * (n - 1) * 20 / (ms * 1e-3) / 78.6e12, 4),
+                         "note": "three stage sweeps executed for the reference's four (stages 1 and 2 see the same positions)"},
             # spec: 39.3e12 lane-FMA/s at 2.4 GHz; measured sustained issue (profiles/r01_ubench_f64_rates.txt):
             # 2.42 ns per f64 wave-op per SIMD, v_rsq_f64 7.0 ns -> 48.1 ns per wave-eval -> 1.36e12 evals/s
             "frac_of_spec_f64_fma_peak": round(evals * 17 / (ms * 1e-3) / 39.3e12, 4),
             "frac_of_measured_issue_bound": round(evals / (ms * 1e-3) / (1024 * 64 / 48.1e-9), 4)}
+
+
+def sparse_edges_leg(device):
+    """A sparse GraphQuery.edge_fold: 65,536 bodies on a ring lattice, 16 out-edges each (1,048,576
+    directed edges in spawn order), Newton gravity, RK4 — the CSR edge kernel (one lane per source, sequential fold over
+    its out-edges, 80-byte gathers of the packed targets)."""
+    import elodin_amd as ea
+    from elodin_amd import _lib as L
+    n, deg = 65536, 16
+    rng = np.random.default_rng(11)
+    pos = np.concatenate([np.tile([0, 0, 0, 1.0], (n, 1)), rng.normal(size=(n, 3)) * 1e3], axis=1)
+    vel = np.concatenate([np.zeros((n, 3)), rng.normal(size=(n, 3))], axis=1)
+    m = rng.uniform(1.0, 10.0, n)
+    inertia = np.concatenate([np.tile(m[:, None], (1, 3)), np.zeros((n, 3)), m[:, None]], axis=1)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    offs = np.array([k for k in range(-deg // 2, deg // 2 + 1) if k != 0][:deg])
+    frm = np.repeat(ids, deg)
+    to = ((np.repeat(np.arange(n), deg) + np.tile(offs, n)) % n + 1).astype(np.uint64)
+    ex = ea.HipExec(pos, vel, inertia, entity_ids=ids, simulation_time_step=0.01, device=device, edges=(frm, to),
+                    effectors=[ea.Effector(L.EFF_EDGE_GRAVITY_NEWTON, (6.6743e-11,))])
+    ex.invoke_batch(5)
+    t = ex.invoke_batch(50)
+    ex.close()
+    ms = t.kernel_device_ms / 50
+    return {"bodies": n, "edges": int(n * deg), "ms_per_tick": round(ms, 4), "edge_evals_per_s": round(3.0 * n * deg / ms * 1e3, 1),
+            "body_steps_per_s": round(n / ms * 1e3, 1), "launches_per_tick": 3,
+            "gather_GBps": round(n * deg * 80 / (ms * 1e-3) / 1e9, 1)}
 
 
 def apollo_leg(device):
@@ -174,7 +205,7 @@ def apollo_leg(device):
     dt = time.perf_counter() - t0
     ex.close()
     out = {"rollouts": 8192, "steps": 10000, "seconds": round(dt, 5), "rollout_steps_per_s": round(8192 * 10000 / dt, 1),
-           "launches": tm.launches, "integrator": "semi-implicit", "guidance": "in-kernel, 24 Hz"}
+           "launches": tm.launches, "integrator": "semi-implicit", "guidance": "in-kernel, on the reference cadence: post_step once per 3-tick telemetry batch, exchange when end_tick % 5 == 0 (every 15 ticks)"}
     try:    # the CPU restatement of the same rollout model (oracle/apollo_oracle.c, one thread) on a bounded sample
         from oracle.apollo import ApolloOracle
         ref = apollo.load_reference()
@@ -533,6 +564,7 @@ def main():
         extra("generated_pipe", generated_leg, local_rank, n)
         extra("f32", f32_leg, local_rank)
         extra("nbody", nbody_leg, local_rank)
+        extra("sparse_edges", sparse_edges_leg, local_rank)
         extra("telemetry_commit", telemetry_leg, local_rank, n)
         extra("history_stream", history_stream_leg, local_rank, n)
         extra("apollo_mc", apollo_leg, local_rank)
