@@ -7,10 +7,11 @@ product path raises — it never routes through the CPU oracle.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libsixdof_hip.so"
+LIB_PATH = Path(os.environ["SIXDOF_LIBRARY"]) if os.environ.get("SIXDOF_LIBRARY") else PKG / "libsixdof_hip.so"   # override: A/B of library builds
 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_COMPONENT_NOT_FOUND, ERR_VALUE_SIZE_MISMATCH = -1, -2, -3

@@ -4,6 +4,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Floating-point contraction is decided per SOURCE EXPRESSION (a * b + c written as one expression becomes one FMA) and
+// nowhere else.  hipcc's default for device code ("fast") also fuses a multiply and an add that merely end up in the
+// same basic block after inlining — so two inlined copies of the same tick body (loop body vs last tick, one launch
+// shape vs another) could round differently.  With "on" every instantiation of the kernels computes the same bits:
+// results do not depend on ticks_per_launch, graph replay, cache policy or which copy of the body ran a tick
+// (tests/test_gpu_parity.py::test_fused_ticks_match_single_tick_launches).  Applies to everything that includes this
+// header, generated translation units included.
+#pragma clang fp contract(on)
+
 namespace sixdof {
 
 constexpr int kMaxOps = 4;       // per-entity effector ops fused into the step kernel

@@ -232,8 +232,9 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     b.I = I_diag;
     Wrench<T> F = zero_wrench<T>();
     bool flushed = false;   // wave-uniform: the live columns already left on the early path
-    // One tick.  EARLY is a compile-time flag so that the per-tick body of a fused launch (n_ticks > 1) carries none of
-    // the early-store branches: only the last tick of a launch is instantiated with them.
+    // One tick.  `early` is a compile-time flag so that the per-tick body of a fused launch (n_ticks > 1) carries none of
+    // the early-store code: only the last tick of a launch is instantiated with it.  The copies compute the same bits
+    // because contraction is per source expression (kernels.hpp: #pragma clang fp contract(on)).
     auto one_tick = [&](auto early_tag, uint32_t tick) {
         constexpr bool early = decltype(early_tag)::value;
         if constexpr (PIPE::kHasModel) {   // user systems piped in front of six_dof (may rewrite inertia, pose, velocity)
