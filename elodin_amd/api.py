@@ -302,6 +302,28 @@ class World:
         ids = np.ctypeslib.as_array(c.entity_ids, shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint64)
         return rows, ids.astype(np.uint64)
 
+    TOTAL_EDGE, REV_SUFFIX = "*total_edge", "~rev"   # edge-component spellings of el.TotalEdge / Annotated[E, el.RevEdge]
+
+    def edge_pairs(self, edge_component: str):
+        """(from ids, to ids) of a GraphQuery's edges, spawn order (graph.rs:113-175).  `E~rev` = every edge of component E
+        reversed (GraphQueryInner.from_builder(builder, edge_id, reverse=True), elodin/__init__.py:432-439); `*total_edge`
+        = every ordered pair of distinct entities of the world, ascending (graph.rs:144-158, GraphQuery<TotalEdge>) —
+        endpoints that do not carry the queried components drop out when the fold joins them."""
+        if edge_component == self.TOTAL_EDGE:
+            n = int(self.entity_len)
+            a = np.repeat(np.arange(n, dtype=np.uint64), n)
+            b = np.tile(np.arange(n, dtype=np.uint64), n)
+            keep = a != b
+            return a[keep], b[keep]
+        reverse = edge_component.endswith(self.REV_SUFFIX)
+        name = edge_component[: -len(self.REV_SUFFIX)] if reverse else edge_component
+        pairs = self._edges.get(name)
+        if pairs is None:
+            raise KeyError(name)
+        frm = np.array([a for a, _ in pairs], dtype=np.uint64)
+        to = np.array([b for _, b in pairs], dtype=np.uint64)
+        return (to, frm) if reverse else (frm, to)
+
     def build(self, system: System, simulation_rate: float = 120.0, telemetry_rate: Optional[float] = None,
               device: int = 0, backend: str = "hip") -> "Exec":
         """World.build (world_builder.rs:1737-1780): validate rates, fix globals, bind the backend."""
@@ -319,10 +341,7 @@ class World:
         from . import dsl as _dsl
         if isinstance(system, _dsl.GraphFold):     # a stand-alone edge_fold system over plain components (test_all.py:117-142)
             from .graph_exec import GraphFoldExec
-            pairs = self._edges.get(system.edge_component)
-            if pairs is None:
-                raise KeyError(system.edge_component)
-            edges = (np.array([a for a, _ in pairs], dtype=np.uint64), np.array([b for _, b in pairs], dtype=np.uint64))
+            edges = self.edge_pairs(system.edge_component)
             names = dict.fromkeys(system.left + system.right + (system.out,))
             return GraphFoldExec(system, {n: self.column(n) for n in names}, edges, device=device)
         program_stages = None
@@ -451,10 +470,13 @@ class World:
         same = all(np.array_equal(v, ids) for v in column_ids.values())
         edges = None
         if program_stages is None and not isinstance(system.effectors, _dsl.Pipe) and system.effectors.edge_component:
-            pairs = self._edges.get(system.effectors.edge_component)
-            if pairs is None:
-                raise KeyError(system.effectors.edge_component)
-            edges = (np.array([a for a, _ in pairs], dtype=np.uint64), np.array([b for _, b in pairs], dtype=np.uint64))
+            edges = self.edge_pairs(system.effectors.edge_component)
+            if system.effectors.edge_component == self.TOTAL_EDGE:   # only pairs of Body entities can join the fold's queries
+                body_ids = set(int(e) for e in ids)
+                for v in column_ids.values():
+                    body_ids &= set(int(e) for e in v)
+                keep = np.array([int(a) in body_ids and int(b) in body_ids for a, b in zip(*edges)], dtype=bool)
+                edges = (edges[0][keep], edges[1][keep])
         hip = HipExec(pos, body["world_vel"][0], body["inertia"][0], world_accel=body["world_accel"][0],
                       force=body["force"][0], entity_ids=ids, simulation_time_step=dt, time_step=system.time_step,
                       integrator=L.INTEGRATOR_NONE if getattr(system, "no_six_dof", False) else system.integrator.value,

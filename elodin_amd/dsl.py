@@ -443,6 +443,52 @@ class _Lax:
             val = body_fun(i, val)
         return val
 
+    @staticmethod
+    def scan(f, init, xs=None, length: Optional[int] = None):
+        """jax.lax.scan(f, init, xs) -> (carry, ys) over a STATIC-length leading axis, unrolled at trace time — the shape
+        the reference's own `edge_fold` lowers to (vmap of scan over the gathered out-edges,
+        libs/nox-py/python/elodin/__init__.py:524-544) and what a filter bank over a short sample window looks like.
+        `xs`: a Vec (one scalar per step), a list / tuple of per-step values (rows), or a tuple / dict of those (every
+        leaf indexed by the step); None with `length` = scan over range(length).  `ys` come back stacked: scalars as one
+        Vec, Vec rows as a list of rows (`np.stack`-able), tuples / dicts leaf by leaf; a step returning None for y is fine."""
+        def n_steps(x):
+            if isinstance(x, Vec):
+                return len(x)
+            if isinstance(x, dict):
+                return n_steps(next(iter(x.values())))
+            if isinstance(x, tuple) and x and isinstance(x[0], (Vec, list, tuple, dict)):
+                return n_steps(x[0])
+            return len(x)
+
+        def at(x, i):
+            if isinstance(x, Vec):
+                return x[i]
+            if isinstance(x, dict):
+                return {k: at(v, i) for k, v in x.items()}
+            if isinstance(x, tuple):          # a tuple of scanned operands, like jax pytrees
+                return tuple(at(v, i) for v in x)
+            return x[i]                        # list of per-step rows
+        L = int(length) if xs is None else n_steps(xs)
+        if length is not None and xs is not None and int(length) != L:
+            raise ValueError("scan: length disagrees with the leading axis of xs")
+        carry, ys = init, []
+        for i in range(L):
+            carry, y = f(carry, None if xs is None else at(xs, i))
+            ys.append(y)
+
+        def stack(vals):
+            v0 = vals[0] if vals else None
+            if v0 is None:
+                return None
+            if isinstance(v0, dict):
+                return {k: stack([v[k] for v in vals]) for k in v0}
+            if isinstance(v0, tuple):
+                return tuple(stack([v[j] for v in vals]) for j in range(len(v0)))
+            if isinstance(v0, Vec):
+                return list(vals)             # [L] rows of width w
+            return Vec([_lift(v) for v in vals])
+        return carry, stack(ys)
+
     _loop_ids = [0]
 
     @staticmethod

@@ -268,11 +268,16 @@ class TotalEdge: ...
 
 
 class _GraphQueryType:
+    """`el.GraphQuery[E]`, `el.GraphQuery[Annotated[E, el.RevEdge]]` (E's edges reversed) or `el.GraphQuery[el.TotalEdge]`
+    (every ordered pair of distinct entities) as an annotation (elodin/__init__.py:427-439, graph.rs:113-158)."""
+
     def __init__(self, edge: Any):
-        if edge is TotalEdge or RevEdge in getattr(edge, "__metadata__", ()):
-            raise NotImplementedError("GraphQuery over TotalEdge / RevEdge: spawn explicit el.Edge entities "
-                                      "(api.gravity_softened(edge_component=None) is the built-in all-pairs fold)")
-        self.edge_component = Component.name(edge)
+        if edge is TotalEdge:
+            self.edge_component = _api.World.TOTAL_EDGE
+            return
+        meta = getattr(edge, "__metadata__", ())
+        name = Component.name(edge)
+        self.edge_component = name + _api.World.REV_SUFFIX if (len(meta) > 1 and meta[1] is RevEdge) else name
 
 
 class Query:

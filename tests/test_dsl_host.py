@@ -214,6 +214,39 @@ def test_quaternion_and_spatial_wrappers_match_the_reference_known_answers():
         assert np.allclose(ev(lambda q, v: Q(q).normalize() @ v, q, v), orc.quat_rotate(q, v), rtol=1e-13, atol=1e-14)
 
 
+def test_scan_with_stacked_outputs_matches_numpy():
+    """lax.scan over a static leading axis, carry + stacked ys (the reference's edge_fold is vmap of scan,
+    elodin/__init__.py:524-544): an exponential smoother over 8 samples and a running fold over rows."""
+    def smooth(xp, x, alpha):
+        carry, ys = dsl.lax.scan(lambda c, xi: ((1.0 - alpha) * c + alpha * xi,) * 2, x[0], x)
+        return xp.concatenate([ys, xp.array([carry])])
+    x = np.array([1.0, 4.0, 2.0, 8.0, 5.0, 7.0, 1.0, 3.0])
+    want, c = [], x[0]
+    for xi in x:
+        c = 0.7 * c + 0.3 * xi
+        want.append(c)
+    got = dsl_numpy.trace_eval(smooth, x, 0.3)
+    assert np.allclose(got, want + [want[-1]], rtol=1e-15)
+
+    def fold_rows(xp, a, b):            # xs as a tuple of two scanned Vecs; ys are (scalar, Vec) tuples
+        def step(acc, ab):
+            ai, bi = ab
+            acc = acc + ai * bi
+            return acc, (acc, xp.array([ai, bi]) * acc)
+        total, (running, rows) = dsl.lax.scan(step, 0.0, (a, b))
+        return xp.concatenate([xp.array([total]), running, xp.concatenate(rows)])
+    a, b = np.array([1.0, 2.0, 3.0]), np.array([0.5, -1.0, 2.0])
+    acc, run, rows = 0.0, [], []
+    for ai, bi in zip(a, b):
+        acc += ai * bi
+        run.append(acc)
+        rows += [ai * acc, bi * acc]
+    assert np.allclose(dsl_numpy.trace_eval(fold_rows, a, b), [acc] + run + rows, rtol=1e-15)
+    # length-only form
+    got = dsl_numpy.trace_eval(lambda xp, x0: dsl.lax.scan(lambda c, _: (c * 2.0, c), x0, None, length=5)[1], 1.5)
+    assert np.allclose(got, [1.5, 3.0, 6.0, 12.0, 24.0])
+
+
 # ---- data-dependent loops --------------------------------------------------------------------------------------------------------
 
 def kepler(xp, M, ecc):

@@ -134,8 +134,22 @@ def test_what_decorated_functions_lower_to():
         @el.system
         def untyped(q):
             return q
-    with pytest.raises(NotImplementedError):
-        el.GraphQuery[el.TotalEdge]
+    from typing import Annotated
+    assert el.GraphQuery[el.TotalEdge].edge_component == "*total_edge"                       # graph.rs:144-158
+    assert el.GraphQuery[Annotated[E, el.RevEdge]].edge_component == "test_edge~rev"        # elodin/__init__.py:432-439
+    w = el.World()
+    a, b, c = (w.spawn(el.C(X, np.array([float(k)]))) for k in range(3))
+
+    @dataclass
+    class _EdgeArch(el.Archetype):
+        edge: E
+    w.spawn(_EdgeArch(el.Edge(a, b)))
+    w.spawn(_EdgeArch(el.Edge(a, c)))
+    assert [list(map(int, v)) for v in w.edge_pairs("test_edge")] == [[1, 1], [2, 3]]
+    assert [list(map(int, v)) for v in w.edge_pairs("test_edge~rev")] == [[2, 3], [1, 1]]
+    frm, to = w.edge_pairs("*total_edge")
+    n = w.entity_len
+    assert len(frm) == n * (n - 1) and not np.any(frm == to) and (int(frm[0]), int(to[0])) == (0, 1)
     with pytest.raises(Exception, match="multiple inputs"):
         @el.system
         def bad_index(q: el.Query[X, Y]) -> el.Query[X]:

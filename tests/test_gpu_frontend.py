@@ -768,3 +768,42 @@ def test_history_rows_follow_the_telemetry_rate():
         w.build(count | el.six_dof(), simulation_rate=120.0, telemetry_rate=50.0)      # not a divisor of the simulation rate
     with pytest.raises(KeyError):
         exec.history("nobody.x")
+
+
+def test_graph_reversed_and_total_edges():
+    """el.GraphQuery[Annotated[E, el.RevEdge]] folds over E's edges reversed (cube-sat's sensor -> satellite folds,
+    examples/cube-sat/main.py:137,422; elodin/__init__.py:432-439) and el.GraphQuery[el.TotalEdge] over every ordered
+    pair of distinct entities (graph.rs:144-158): same worlds as test_graph, expected values by hand."""
+    from typing import Annotated
+
+    @dataclass
+    class EdgeArchetype(el.Archetype):
+        edge: E
+
+    def world():
+        w = el.World()
+        a = w.spawn(OnlyX(np.array([1.0])), "e1")
+        b = w.spawn(OnlyX(np.array([2.0])), "e2")
+        c = w.spawn(OnlyX(np.array([4.0])), "e3")
+        w.spawn(EdgeArchetype(el.Edge(a, b)))
+        w.spawn(EdgeArchetype(el.Edge(a, c)))
+        w.spawn(EdgeArchetype(el.Edge(b, c)))
+        return w
+
+    @el.system
+    def fold_rev(graph: el.GraphQuery[Annotated[E, el.RevEdge]], x: el.Query[X]) -> el.Query[X]:
+        return graph.edge_fold(x, x, X, np.array(5.0), lambda acc, a, b: acc + a + b)
+
+    # reversed edges: b->a, c->a, c->b.  e2: 5 + (2+1) = 8; e3: 5 + (4+1) + (4+2) = 16; e1 has no out-edge now
+    exec = world().build(fold_rev)
+    exec.run()
+    frame_equal(exec.history(["e1.x", "e2.x", "e3.x"]), {"e1.x": [1.0, 1.0], "e2.x": [2.0, 8.0], "e3.x": [4.0, 16.0]})
+
+    @el.system
+    def fold_total(graph: el.GraphQuery[el.TotalEdge], x: el.Query[X]) -> el.Query[X]:
+        return graph.edge_fold(x, x, X, np.array(0.0), lambda acc, a, b: acc + b)
+
+    # every entity sums the OTHER entities' x (edge entities and Globals carry no x and drop out of the join)
+    exec = world().build(fold_total)
+    exec.run()
+    frame_equal(exec.history(["e1.x", "e2.x", "e3.x"]), {"e1.x": [1.0, 6.0], "e2.x": [2.0, 5.0], "e3.x": [4.0, 3.0]})
