@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -150,7 +151,10 @@ int sixdof_comm_init(sixdof_comm** out, const uint8_t id[SIXDOF_COMM_ID_BYTES], 
         delete c;
         return SIXDOF_ERR_BACKEND;
     }
-    if (world > 1) {   // a single rank needs no communicator (and no RCCL on the machine)
+    // a single rank needs no communicator (and no RCCL on the machine); SIXDOF_COMM_FORCE_RCCL=1 builds a one-rank RCCL
+    // communicator anyway, so the RCCL code path can be exercised on a one-GPU box (tests)
+    const char* force = std::getenv("SIXDOF_COMM_FORCE_RCCL");
+    if (world > 1 || (force && force[0] == '1')) {
         Rccl& r = rccl();
         if (!r.error.empty()) {
             g_comm_error = r.error;
@@ -159,7 +163,13 @@ int sixdof_comm_init(sixdof_comm** out, const uint8_t id[SIXDOF_COMM_ID_BYTES], 
             return SIXDOF_ERR_UNSUPPORTED;
         }
         NcclUniqueId u;
-        std::memcpy(&u, id, sizeof(u));
+        if (id) std::memcpy(&u, id, sizeof(u));
+        else if (r.get_unique_id(&u) != kNcclSuccess) {   // world == 1 only (checked above): make our own
+            g_comm_error = "ncclGetUniqueId failed";
+            hipStreamDestroy(c->stream);
+            delete c;
+            return SIXDOF_ERR_BACKEND;
+        }
         const int rc = r.comm_init_rank(&c->comm, world, u, rank);
         if (rc != kNcclSuccess) {
             g_comm_error = std::string("ncclCommInitRank: ") + (r.error_string ? r.error_string(rc) : "error");
@@ -185,7 +195,7 @@ const char* sixdof_comm_last_error(const sixdof_comm* c) { return c ? c->error.c
 
 int sixdof_campaign_broadcast(sixdof_comm* c, void* table, uint64_t n_bytes, int root) {
     if (!c || (!table && n_bytes) || root < 0 || root >= c->world) return SIXDOF_ERR_INVALID_ARGUMENT;
-    if (c->world == 1 || n_bytes == 0) return SIXDOF_OK;
+    if (c->comm == nullptr || n_bytes == 0) return SIXDOF_OK;   // single rank without a communicator: nothing to move
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) return c->hip(e, "hipSetDevice");
     int rc = c->reserve(n_bytes);
@@ -207,7 +217,7 @@ int sixdof_campaign_gather(sixdof_comm* c, const double* local_rows, uint64_t n_
     sixdof_shard_range(n_total, c->world, c->rank, &lo, &hi);
     if (hi - lo != n_local)
         return c->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, "campaign_gather: n_local is not this rank's block of n_total rows (sixdof_shard_range)");
-    if (c->world == 1) {
+    if (c->comm == nullptr) {   // single rank without a communicator
         if (n_local * width) std::memcpy(all_rows, local_rows, n_local * width * sizeof(double));
         return SIXDOF_OK;
     }

@@ -49,6 +49,23 @@ def test_single_rank_comm_is_a_copy():
     c.close()
 
 
+@pytest.mark.gpu
+def test_one_rank_rccl_communicator_really_goes_through_rccl(monkeypatch):
+    """SIXDOF_COMM_FORCE_RCCL=1: a ONE-rank RCCL communicator (dlopen, ncclGetUniqueId, ncclCommInitRank) and the
+    collectives through ncclBroadcast / ncclAllGather on the GPU — the same code a multi-rank campaign runs, on the one
+    GPU a gpurun box has."""
+    monkeypatch.setenv("SIXDOF_COMM_FORCE_RCCL", "1")
+    assert len(shard.CapiComm.unique_id()) == 128
+    c = shard.CapiComm(None, 1, 0, 0)
+    table = np.random.default_rng(1).normal(size=(8192, 17))
+    got = c.broadcast_table(table, table.shape)
+    assert np.array_equal(got, table)
+    rows = np.random.default_rng(2).normal(size=(8192, 12))
+    assert np.array_equal(c.gather_rows(rows, 8192), rows)
+    assert np.array_equal(c.gather_rows(rows[:0].reshape(0, 12), 0), rows[:0])
+    c.close()
+
+
 def _rank_main(rank, world, id_path, out_path):
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     if rank == 0:
