@@ -18,7 +18,8 @@ FLOORS = {"tvc_cmd": 1e-3, "tvc_state": 1e-3, "rcs_torque_cmd": 1.0, "aero_wrenc
           "mdot_total": 1e-3, "engine_spool": 1e-6, "valve_state": 1e-6}
 # f32 state (config 5's arithmetic): an f32 ECEF / pad-relative metre resolves ~0.25-0.5 m, so quantities that are small
 # differences of large ones get floors at that resolution times their gain instead of their own (tiny) magnitude
-FLOORS_F32 = dict({k: v * 1e3 for k, v in FLOORS.items()}, altitude_geodetic=100.0, rcs_torque_cmd=2.0e4, ground_speed=1.0,
+# (geodetic altitude: ECEF -> geodetic on f32 coordinates of magnitude 6.4e6 m is good to a few metres: measured 2.7 m)
+FLOORS_F32 = dict({k: v * 1e3 for k, v in FLOORS.items()}, altitude_geodetic=500.0, rcs_torque_cmd=2.0e4, ground_speed=1.0,
                   tvc_cmd=2e-2, tvc_state=2e-2, liftoff_time=1.0)
 BODY = ("world_pos", "world_vel", "world_accel", "force", "inertia")
 
