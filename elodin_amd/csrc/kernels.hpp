@@ -49,6 +49,8 @@ struct StepParams {
     void* hist_accel;         // [ring][n,6]
     void* hist_force;         // [ring][n,6]
     uint64_t tick0;           // tick count before this launch (generated systems may read the tick)
+    uint32_t accel_in_check;  // 1: the world_accel column holds HOST data (first launch after an upload): RK4 stage 0 reads it
+    uint32_t reserved0;       //    the way the reference does, v_s = v0 + 0 * a_in (rk4.rs:96-100), so a non-finite row poisons the tick
     void* model_cols[kMaxModelCols];  // generated programs: device [n,w] component columns, read and written
     void* model_hist[kMaxModelCols];  // their history rings [ring][n,w] (nullptr = not recorded)
     DevOp ops[kMaxOps];

@@ -37,15 +37,6 @@ namespace sixdof {
 constexpr int kTile = 256;  // sources staged per LDS tile = targets per workgroup
 constexpr uint32_t kSmallEdgeCache = 2048;  // edges of a small graph (n <= 256) cached in LDS by the one-launch kernel
 
-// 1/sqrt(x) for x > 0 finite: hardware v_rsq_f64 seed plus one cubic correction
-// (y0 (1 + e/2 + 3e^2/8), e = 1 - x y0^2), full f64 accuracy without the 0/inf special-casing of the
-// library rsqrt.  x = 0 only occurs for the self pair with eps = 0, whose contribution is discarded.
-__device__ __forceinline__ double rsqrt_pos(double x) {
-    const double y0 = __builtin_amdgcn_rsq(x);
-    const double e = fma(-x * y0, y0, 1.0);
-    return fma(y0 * e, fma(e, 0.375, 0.5), y0);
-}
-
 // ---- PAIR functors: one directed edge a -> b folded into a's Force accumulator [tau(3), f(3)] ----------------
 // fold(acc, pa, ma, pb, mb, p0, p1): pa / pb = the two bodies' positions at ONE stage, ma / mb their masses.
 struct PairNewton {   // examples/three-body/main.py:61-70: r = a - b; f = G*M*m*r / |r|^3; Force(linear = acc.f - f)
@@ -216,6 +207,8 @@ struct EntityState {
     double mass, inv_m;
 };
 
+// `A` comes in holding the world_accel column of this entity (a_in): RK4 stage 0 forms v_s = v0 + 0 * a_in like the
+// reference (rk4.rs:96-100), so non-finite input poisons the tick the same way; it goes out as this tick's acceleration.
 template <int INTEGRATOR>
 __device__ __forceinline__ void pair_integrate_entity(const PairParams& P, const StepParams& SP,
                                                       const Vec3<double> (&aux)[kMaxOps], const double (&pf)[3][6],
@@ -245,10 +238,11 @@ __device__ __forceinline__ void pair_integrate_entity(const PairParams& P, const
     if constexpr (INTEGRATOR == kRk4) {
         const T h1 = dt_g * 0.5, h3 = dt_g;
         Spatial<T> sv, sa;
-        b.q = normalized(q0); b.p = p0; b.v = v0;
+        b.q = normalized(q0); b.p = p0;
+        b.v = Spatial<T>{v0.ang + T(0) * A.ang, v0.lin + T(0) * A.lin};
         stage_force(0);
         A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
-        sv = v0; sa = A;
+        sv = b.v; sa = A;
         b.q = integrate_world(q0, h1 * v0.ang); b.p = axpy(h1, v0.lin, p0); b.v = axpy(h1, A, v0);
         sv = axpy(T(2), b.v, sv);
         stage_force(1);
@@ -345,6 +339,10 @@ __global__ __launch_bounds__(256) void pair_integrate_kernel(const PairParams P)
             for (int c = 0; c < 6; c++) pf[st][c] = part[6 * st + c];
     }
     Spatial<double> A, Fw;
+    {
+        const double* ac = static_cast<const double*>(P.accel) + (size_t)i * 6;
+        A = Spatial<double>{{ac[0], ac[1], ac[2]}, {ac[3], ac[4], ac[5]}};
+    }
     pair_integrate_entity<INTEGRATOR>(P, SP, aux, pf, is_source, e, A, Fw);
     store_entity(P, i, e, A, Fw);
 }
@@ -377,6 +375,10 @@ __global__ __launch_bounds__(kTile) void pair_small_kernel(const PairParams P, u
     const bool is_source = active && (allpairs ? (P.n > 1) : (e1 > e0));
     const double h1 = P.dt_g * 0.5, h3 = P.dt_g;
     Spatial<double> A = {{0, 0, 0}, {0, 0, 0}}, Fw = {{0, 0, 0}, {0, 0, 0}};
+    if (active) {   // a_in of the first tick = the world_accel column; of later ticks = the previous tick's A, in registers
+        const double* ac = static_cast<const double*>(P.accel) + (size_t)i * 6;
+        A = Spatial<double>{{ac[0], ac[1], ac[2]}, {ac[3], ac[4], ac[5]}};
+    }
     for (uint32_t t = 0; t < n_ticks; t++) {
         if (active) {
             double* o = pack + i * kPackWidth;

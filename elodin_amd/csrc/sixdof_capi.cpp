@@ -109,6 +109,7 @@ struct sixdof_handle {
     // rollout model (0 = none, 1 = Apollo lander)
     int model = 0;
     std::vector<double> ap_time, ap_alt, ap_rate, ap_pitch, ap_hspeed, ap_downrange;
+    bool accel_is_host_data = false;   // set by an upload: the next RK4 launch reads world_accel once (see sixdof_step)
     uint32_t ap_ticks_per_telemetry = 3;
     uint32_t ap_guidance_period = 5;
     uint64_t ap_max_ticks = 0;
@@ -512,6 +513,7 @@ int sixdof_upload(sixdof_handle* h) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->last.h2d_upload_ms = now_ms() - t_up;
     h->resident = true;
+    h->accel_is_host_data = true;
     return prepare_graph(h);   // SIXDOF_FLAG_USE_GRAPH: capture now, not inside the first long step call
 }
 
@@ -1323,6 +1325,7 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
         const uint32_t K = h->desc.ticks_per_launch;
         uint64_t full = n_ticks / K;
         const uint32_t rem = static_cast<uint32_t>(n_ticks % K);
+        uint32_t rem_left = rem;
         P.n_ticks = K;
         // Long batches of identical launches replay from a hipGraph (launch-bound regime:
         // a 65,536-entity tick is a few microseconds of device time).
@@ -1338,6 +1341,27 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
         }
         uint64_t ticks_issued = 0;   // history slot of a launch's first tick = ticks done before it
         uint64_t graph_launches = 0;
+        if (h->accel_is_host_data && n_ticks > 0) {
+            // First launch after an upload: the world_accel column holds whatever the host put there.  The reference's RK4
+            // forms v_s = v0 + 0 * a_in on stage 0 (rk4.rs:96-100), so a non-finite row poisons that tick; this one launch
+            // reads the column to do the same (step_kernel.hpp).  Every later a_in is this kernel's own output and is
+            // already folded into v0.  A launch of its own, eager, so the replay graphs never carry the flag.
+            h->accel_is_host_data = false;
+            if (h->desc.integrator == SIXDOF_INTEGRATOR_RK4) {
+                StepParams P1 = P;
+                P1.accel_in_check = 1;
+                P1.n_ticks = static_cast<uint32_t>(std::min<uint64_t>(K, n_ticks));
+                P1.hist_slot0 = h->tick;
+                P1.tick0 = h->tick;
+                if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[0], h->stream));
+                hipError_t e = launch_any(h, P1);
+                if (e != hipSuccess) return h->hip_fail(e, "launch_step");
+                if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[1], h->stream));
+                launches = 1;
+                if (n_ticks >= K) full -= 1;   // that launch was one of the K-tick launches ...
+                else rem_left = 0;             // ... or the whole (short) batch
+            }
+        }
         if (graph_eligible(h) && full >= kGraphMinLen) {
             // long batches replay 32-launch chains; what is left (or a short batch as a whole, e.g. 20 ticks) replays as
             // ONE chain of exactly that length, captured on first use and cached — so a short timed region is
@@ -1378,8 +1402,8 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
             if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches + 1], h->stream));
             launches++;
         }
-        if (rem) {
-            P.n_ticks = rem;
+        if (rem_left) {
+            P.n_ticks = rem_left;
             P.hist_slot0 = h->tick + ticks_issued;
             P.tick0 = h->tick + ticks_issued;
             if (time_each) HIP_TRY(h, hipEventRecord(h->launch_events[2 * launches], h->stream));

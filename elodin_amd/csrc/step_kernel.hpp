@@ -29,7 +29,8 @@
 // six_dof(time_step=) override.  Consequence used here: stages 1 and 2 see the same transform, so
 // when no effector reads the stage velocity their wrench and acceleration are bit-identical and are
 // computed once.  The reference multiplies the incoming world_accel column by 0 in stage 0
-// (rk4.rs:96-100); that column is therefore not read (finite input assumed).
+// (rk4.rs:96-100); the column is read only on the first tick after an upload, where it can hold non-finite host data
+// (0 * NaN = NaN poisons that tick like the reference's); later ticks' a_in is already folded into v0.
 #pragma once
 #include <type_traits>
 
@@ -249,14 +250,23 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
         if constexpr (INTEGRATOR == kRk4) {
             const T h1 = dt_g * T(0.5), h3 = dt_g;
             Spatial<T> A, sv, sa;
-            // stage 0 (c = 0): x0 (+) 0 only renormalises the quaternion
+            // stage 0 (c = 0): x0 (+) 0 only renormalises the quaternion; v_s = v0 + 0 * a_in.  a_in is the world_accel
+            // COLUMN: from the second tick on it is this kernel's own A of the previous tick, which already sits inside
+            // v0 (a non-finite A made v0 non-finite), so 0 * a_in adds nothing; only host data handed over by an upload
+            // can be non-finite on its own — then the reference's tick turns NaN through exactly this product
+            // (rk4.rs:96-100), and so does this one: the column is read once, on the first tick after an upload.
             b.q = normalized(q0);
             b.p = p0;
             b.v = v0;
+            if (P.accel_in_check && tick == 0 && active) {
+                const T* a = g_accel + (size_t)t * 6;
+                b.v.ang = b.v.ang + T(0) * Vec3<T>{a[0], a[1], a[2]};
+                b.v.lin = b.v.lin + T(0) * Vec3<T>{a[3], a[4], a[5]};
+            }
             F = zero_wrench<T>();
             PIPE::apply(P, aux, regs, b, F);
             A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
-            sv = v0;
+            sv = b.v;   // = v0 (+ 0 * a_in on the first tick after an upload)
             sa = A;
             // stage 1 (c = 1/2): position advanced with v0 (reference quirk), velocity with A0
             b.q = integrate_world(q0, h1 * v0.ang);

@@ -506,3 +506,38 @@ def test_solar_system_833_days_matches_the_oracle_and_the_ephemeris(small, monke
     print(f"solar system, {done} ticks ({'one-launch' if small else 'three-kernel'} path): vs oracle {errs}, vs ephemeris RMS {rms:.2e} AU, coefficient {coeff:.6f}")
     assert max(errs.values()) < parity.F64_RTOL, errs
     assert coeff > 0.999 and rms < 5e-3
+
+
+@pytest.mark.parametrize("path", ["entity", "pair"])
+def test_non_finite_world_accel_input_poisons_the_tick_like_the_reference(path):
+    """rk4.rs:96-100: stage 0 forms v_s = v0 + 0 * a_in with a_in the world_accel COLUMN; a NaN / Inf there turns that
+    stage velocity — and with it sum(v_s), i.e. the new world_pos — into NaN while v' = v0 + (dt/6) sum(A_s) stays finite
+    when the forces do not read the velocity.  The HIP path reads the column on the first tick after an upload (later
+    ticks' a_in is its own output, already inside v0) and must end up where the oracle does, NaNs included."""
+    n = 300
+    w = workloads.independent_bodies(n)
+    accel = np.zeros((n, 6))
+    accel[7, 4] = np.nan
+    accel[100, 1] = np.inf
+    accel[299, 5] = -np.inf
+    if path == "entity":
+        eff = workloads.gravity_torque_effectors(w["body_torque"])
+        kw = dict(effectors=eff)
+        okw = dict(ops=parity.to_oracle_ops(eff))
+    else:
+        kw = dict(effectors=[ea.Effector(L.EFF_ALLPAIRS_GRAVITY_SOFTENED, (1e-3, 1e-2))])
+        okw = dict(ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, (1e-3, 1e-2), None)])
+    hip = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], world_accel=accel, simulation_time_step=workloads.DT_120HZ, **kw)
+    ref = orc.OracleWorld(w["world_pos"], w["world_vel"], w["inertia"], world_accel=accel, simulation_time_step=workloads.DT_120HZ, **okw)
+    for _ in range(3):
+        hip.run(1)
+        ref.step(1)
+        for f in parity.FIELDS:
+            g, r = getattr(hip, f), getattr(ref, f)
+            assert np.array_equal(np.isnan(g), np.isnan(r)), f
+            ok = ~np.isnan(r).any(axis=1)
+            assert parity.field_rel_err(g[ok][:, -3:], r[ok][:, -3:]) < parity.F64_RTOL, f
+    bad = [7, 100, 299]
+    assert np.isnan(hip.world_pos[bad]).any(axis=1).all()
+    if path == "entity":       # independent rows: the damage stays where it was (a pair fold spreads it to every body by tick 2)
+        assert np.isfinite(hip.world_pos[[0, 8, 150]]).all() and np.isfinite(hip.world_vel[bad]).all()
