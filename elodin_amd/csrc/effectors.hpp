@@ -156,14 +156,18 @@ struct PipeGeneric : NoModel {
 };
 
 // calc_accel (six_dof.rs:137-146): alpha = q * ((q^-1 * tau) / I_diag); a = q * ((q^-1 * f) / m) = f / m.
+// The reference carries BOTH halves through the attitude, so a non-finite quaternion poisons the whole acceleration even
+// where the rotation cancels algebraically; `taint` (= 0 for any finite q, NaN otherwise) keeps that propagation without
+// the two rotations.
 template <class PIPE, class T>
 __device__ __forceinline__ Spatial<T> calc_accel(const Quat<T>& q, const Wrench<T>& F, const Vec3<T>& inv_I, T inv_m) {
+    const T taint = T(0) * ((q.w + q.i) + (q.j + q.k));
     Vec3<T> bt = F.tau_b;
     if constexpr (PIPE::kWorldTorque) bt = bt + rotate_inv(q, F.tau_w);
     Spatial<T> a;
     if constexpr (PIPE::kWorldTorque || PIPE::kBodyTorque) a.ang = rotate(q, hadamard(bt, inv_I));
-    else a.ang = Vec3<T>{T(0), T(0), T(0)};
-    a.lin = inv_m * F.f;
+    else a.ang = Vec3<T>{taint, taint, taint};
+    a.lin = Vec3<T>{inv_m * F.f.x + taint, inv_m * F.f.y + taint, inv_m * F.f.z + taint};
     return a;
 }
 
