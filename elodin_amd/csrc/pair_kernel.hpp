@@ -109,21 +109,16 @@ __device__ __forceinline__ void tile_accumulate(const double* __restrict__ tile,
     }
 }
 
-// BLOCK = targets (threads) per workgroup: 256 for large worlds (four waves share every LDS tile), 64 when 256-target
-// workgroups would leave SIMDs idle (N of a few thousand: ceil(N/256) x splits < 1,024 workgroups).  The LDS tile is 256
-// sources either way and the split boundaries are whole tiles, so every target accumulates its sources in the same order
-// and both shapes give the same bits.
-template <int NS, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void allpairs_kernel(const double* __restrict__ pack, double* __restrict__ partial,
+template <int NS>
+__global__ __launch_bounds__(kTile) void allpairs_kernel(const double* __restrict__ pack, double* __restrict__ partial,
                                                          uint32_t n, uint32_t splits, double K, double eps) {
     __shared__ __attribute__((aligned(16))) double tile[kTile * kPackWidth];
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t i = blockIdx.x * kTile + threadIdx.x;
     const uint32_t split = blockIdx.y;
     const uint32_t tiles_total = (n + kTile - 1) / kTile;
     const uint32_t tiles_per_split = (tiles_total + splits - 1) / splits;
     const uint32_t tile_lo = split * tiles_per_split;
     const uint32_t tile_hi = min(tiles_total, tile_lo + tiles_per_split);
-    const uint32_t own_tile = (blockIdx.x * BLOCK) / kTile;   // the tile that holds this workgroup's own bodies (i == j test)
 
     double pi[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     double mi = 0.0;
@@ -142,10 +137,10 @@ __global__ __launch_bounds__(BLOCK) void allpairs_kernel(const double* __restric
         {   // contiguous slab of count*10 doubles, 16 B per lane per iteration
             const double2* g = reinterpret_cast<const double2*>(pack + (size_t)j0 * kPackWidth);
             double2* l = reinterpret_cast<double2*>(tile);
-            for (int c = threadIdx.x; c < count * (kPackWidth / 2); c += BLOCK) l[c] = g[c];
+            for (int c = threadIdx.x; c < count * (kPackWidth / 2); c += kTile) l[c] = g[c];
         }
         __syncthreads();
-        if (tl == own_tile) tile_accumulate<NS, true>(tile, count, j0, i, pi, eps, acc);
+        if (tl == blockIdx.x) tile_accumulate<NS, true>(tile, count, j0, i, pi, eps, acc);
         else tile_accumulate<NS, false>(tile, count, j0, i, pi, eps, acc);
     }
     if (i < n) {
@@ -457,16 +452,9 @@ inline hipError_t launch_pair_tick_t(const PairParams& p, int integrator, hipStr
                        static_cast<const double*>(p.vel), static_cast<const double*>(p.inertia), p.pack, p.n, h1, h3);
     const bool rk4 = integrator == kRk4;
     if (ALLPAIRS) {
-        const uint32_t tblocks = (p.n + kTile - 1) / kTile;
-        if (tblocks * p.splits >= 1024) {   // enough four-wave workgroups to fill 256 CUs four deep
-            const dim3 grid(tblocks, p.splits);
-            if (rk4) hipLaunchKernelGGL((allpairs_kernel<3, kTile>), grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1);
-            else hipLaunchKernelGGL((allpairs_kernel<1, kTile>), grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1);
-        } else {                            // mid-size worlds: single-wave workgroups, four times as many of them
-            const dim3 grid((p.n + 63) / 64, p.splits);
-            if (rk4) hipLaunchKernelGGL((allpairs_kernel<3, 64>), grid, dim3(64), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1);
-            else hipLaunchKernelGGL((allpairs_kernel<1, 64>), grid, dim3(64), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1);
-        }
+        const dim3 grid((p.n + kTile - 1) / kTile, p.splits);
+        if (rk4) hipLaunchKernelGGL(allpairs_kernel<3>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1);
+        else hipLaunchKernelGGL(allpairs_kernel<1>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1);
     } else {
         if (rk4) hipLaunchKernelGGL((edge_kernel<3, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1);
         else hipLaunchKernelGGL((edge_kernel<1, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1);
