@@ -157,18 +157,33 @@ struct PipeGeneric : NoModel {
 
 // calc_accel (six_dof.rs:137-146): alpha = q * ((q^-1 * tau) / I_diag); a = q * ((q^-1 * f) / m) = f / m.
 // The reference carries BOTH halves through the attitude, so a non-finite quaternion poisons the whole acceleration even
-// where the rotation cancels algebraically; `taint` (= 0 for any finite q, NaN otherwise) keeps that propagation without
-// the two rotations.
+// where the rotation cancels algebraically.  `taint` (accel_taint below: +-0 for a finite attitude, NaN otherwise) keeps
+// that propagation without the two rotations: the caller folds it into the reciprocal mass (inv_m_t = inv_m + taint,
+// exact for +-0), so the product below is all it costs.
 template <class PIPE, class T>
-__device__ __forceinline__ Spatial<T> calc_accel(const Quat<T>& q, const Wrench<T>& F, const Vec3<T>& inv_I, T inv_m) {
-    const T taint = T(0) * ((q.w + q.i) + (q.j + q.k));
+__device__ __forceinline__ Spatial<T> calc_accel(const Quat<T>& q, const Wrench<T>& F, const Vec3<T>& inv_I, T inv_m_t, T taint) {
     Vec3<T> bt = F.tau_b;
     if constexpr (PIPE::kWorldTorque) bt = bt + rotate_inv(q, F.tau_w);
     Spatial<T> a;
     if constexpr (PIPE::kWorldTorque || PIPE::kBodyTorque) a.ang = rotate(q, hadamard(bt, inv_I));
     else a.ang = Vec3<T>{taint, taint, taint};
-    a.lin = Vec3<T>{inv_m * F.f.x + taint, inv_m * F.f.y + taint, inv_m * F.f.z + taint};
+    a.lin = inv_m_t * F.f;
     return a;
+}
+// norm2 = |q|^2 of the attitude calc_accel is about to see, before normalisation (integrate_world / normalized hand it out):
+// NaN or inf exactly when the attitude is not finite.
+//   RK4: every stage attitude is q0 (+) c*dt*v0.ang (the stage positions advance with the INITIAL velocity, rk4.rs:110-121),
+//   so the four are finite together; the LAST stage's taint is enough: it poisons A_3 (the world_accel output and, through
+//   sum(A_s), the new velocity), and the caller adds it to the (dt/6) factor of the position update, which the reference
+//   poisons through v_s = v0 + c*dt*A_(s-1).  One multiply and two adds per tick instead of work in every stage.
+//   Semi-implicit: the one calc_accel sees q0.
+template <class T>
+__device__ __forceinline__ T accel_taint(T norm2) {
+#ifdef SIXDOF_AB_NO_TAINT
+    return T(0);
+#else
+    return T(0) * norm2;
+#endif
 }
 
 // The `force` column holds the world-frame wrench [tau, f] of the last stage.

@@ -241,31 +241,35 @@ __device__ __forceinline__ void pair_integrate_entity(const PairParams& P, const
         b.q = normalized(q0); b.p = p0;
         b.v = Spatial<T>{v0.ang + T(0) * A.ang, v0.lin + T(0) * A.lin};
         stage_force(0);
-        A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+        A = calc_accel<PIPE>(b.q, F, inv_I, inv_m, T(0));
         sv = b.v; sa = A;
         b.q = integrate_world(q0, h1 * v0.ang); b.p = axpy(h1, v0.lin, p0); b.v = axpy(h1, A, v0);
         sv = axpy(T(2), b.v, sv);
         stage_force(1);
-        A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+        A = calc_accel<PIPE>(b.q, F, inv_I, inv_m, T(0));
         sa = axpy(T(2), A, sa);
         b.v = axpy(h1, A, v0);
         sv = axpy(T(2), b.v, sv);
         stage_force(1);
-        A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+        A = calc_accel<PIPE>(b.q, F, inv_I, inv_m, T(0));
         sa = axpy(T(2), A, sa);
-        b.q = integrate_world(q0, h3 * v0.ang); b.p = axpy(h3, v0.lin, p0); b.v = axpy(h3, A, v0);
+        T n3;
+        b.q = integrate_world(q0, h3 * v0.ang, &n3); b.p = axpy(h3, v0.lin, p0); b.v = axpy(h3, A, v0);
+        const T taint = accel_taint(n3);   // effectors.hpp: the last stage carries a non-finite attitude into A, v' and x'
         sv = sv + b.v;
         stage_force(2);
-        A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+        A = calc_accel<PIPE>(b.q, F, inv_I, inv_m + taint, taint);
         sa = sa + A;
         const T g = dt * T(1.0 / 6.0);
         q0 = integrate_world(q0, g * sv.ang);
-        p0 = axpy(g, sv.lin, p0);
+        p0 = axpy(g + taint, sv.lin, p0);
         v0 = axpy(g, sa, v0);
     } else {
-        b.q = normalized(q0); b.p = p0; b.v = v0;
+        T n0;
+        b.q = normalized(q0, &n0); b.p = p0; b.v = v0;
+        const T taint = accel_taint(n0);
         stage_force(0);
-        A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+        A = calc_accel<PIPE>(b.q, F, inv_I, inv_m + taint, taint);
         v0 = axpy(dt, A, v0);
         q0 = integrate_world(q0, dt * v0.ang);
         p0 = axpy(dt, v0.lin, p0);

@@ -123,20 +123,26 @@ __device__ __forceinline__ Vec3<T> rotate_inv_any(Quat<T> q, Vec3<T> v, T two_ov
 // SpatialTransform + SpatialMotion, angular part: normalize(q + (d/2, 0) (x) q)   (spatial.rs:530-549)
 // `d` is the already-scaled angular increment (h * omega).
 template <class T>
-__device__ __forceinline__ Quat<T> integrate_world(Quat<T> q, Vec3<T> d) {
+__device__ __forceinline__ Quat<T> integrate_world(Quat<T> q, Vec3<T> d, T* norm2 = nullptr) {
     const T hx = T(0.5) * d.x, hy = T(0.5) * d.y, hz = T(0.5) * d.z;
     Quat<T> r;
     r.i = q.i + (hx * q.w + hy * q.k - hz * q.j);
     r.j = q.j + (hy * q.w + hz * q.i - hx * q.k);
     r.k = q.k + (hz * q.w + hx * q.j - hy * q.i);
     r.w = q.w - (hx * q.i + hy * q.j + hz * q.k);
-    const T inv = fast_rsqrt(r.i * r.i + r.j * r.j + r.k * r.k + r.w * r.w);
+    const T n2 = r.i * r.i + r.j * r.j + r.k * r.k + r.w * r.w;
+    if (norm2) *norm2 = n2;
+    const T inv = fast_rsqrt(n2);
     return {r.i * inv, r.j * inv, r.k * inv, r.w * inv};
 }
 
+// `norm2` (optional) receives |q|^2 before normalisation: finite exactly when the quaternion is (0 * norm2 is the
+// NaN-taint calc_accel uses, effectors.hpp).
 template <class T>
-__device__ __forceinline__ Quat<T> normalized(Quat<T> q) {
-    const T inv = fast_rsqrt(q.i * q.i + q.j * q.j + q.k * q.k + q.w * q.w);
+__device__ __forceinline__ Quat<T> normalized(Quat<T> q, T* norm2 = nullptr) {
+    const T n2 = q.i * q.i + q.j * q.j + q.k * q.k + q.w * q.w;
+    if (norm2) *norm2 = n2;
+    const T inv = fast_rsqrt(n2);
     return {q.i * inv, q.j * inv, q.k * inv, q.w * inv};
 }
 

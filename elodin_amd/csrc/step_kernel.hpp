@@ -105,7 +105,11 @@ __device__ __forceinline__ void slab_out_tail(const T* l, T* __restrict__ g, uin
 
 // ---- the kernel --------------------------------------------------------------------------------------
 
-template <class T, int INTEGRATOR, class PIPE, int POL>
+// CHECK: the instantiation a launch with StepParams::accel_in_check uses (first RK4 launch after an upload, once): its
+// first tick reads the incoming world_accel row for stage 0.  A kernel of its own so that the everyday kernels carry
+// neither the branch nor a third copy of the tick body (measured: +0.25 us per one-tick launch at 65,536 bodies when it
+// lived in the same kernel, profiles/r02_step_taint_check_ab.txt).  Generated programs (kHasModel) keep it in their one kernel.
+template <class T, int INTEGRATOR, class PIPE, int POL, bool CHECK = false>
 __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) {
     // pos | vel | inertia on the way in (20 elems/entity); pos | vel | accel | force on the way out (25)
     __shared__ __attribute__((aligned(16))) T lds[kWave * 25];
@@ -236,8 +240,11 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     // One tick.  `early` is a compile-time flag so that the per-tick body of a fused launch (n_ticks > 1) carries none of
     // the early-store code: only the last tick of a launch is instantiated with it.  The copies compute the same bits
     // because contraction is per source expression (kernels.hpp: #pragma clang fp contract(on)).
-    auto one_tick = [&](auto early_tag, uint32_t tick) {
+    // `check` (first tick of the first launch after an upload only, StepParams::accel_in_check) reads the incoming
+    // world_accel row for stage 0; also compile-time, so no other tick carries the branch or the load.
+    auto one_tick = [&](auto early_tag, auto check_tag, uint32_t tick) {
         constexpr bool early = decltype(early_tag)::value;
+        constexpr bool check = decltype(check_tag)::value;
         if constexpr (PIPE::kHasModel) {   // user systems piped in front of six_dof (may rewrite inertia, pose, velocity)
             PIPE::pre(P, P.tick0 + tick + 1, regs, q0, p0, v0, I_diag, mass);
             if constexpr (PIPE::kWritesInertia) {
@@ -258,14 +265,14 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             b.q = normalized(q0);
             b.p = p0;
             b.v = v0;
-            if (P.accel_in_check && tick == 0 && active) {
+            if (check && active) {
                 const T* a = g_accel + (size_t)t * 6;
                 b.v.ang = b.v.ang + T(0) * Vec3<T>{a[0], a[1], a[2]};
                 b.v.lin = b.v.lin + T(0) * Vec3<T>{a[3], a[4], a[5]};
             }
             F = zero_wrench<T>();
             PIPE::apply(P, aux, regs, b, F);
-            A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+            A = calc_accel<PIPE>(b.q, F, inv_I, inv_m, T(0));
             sv = b.v;   // = v0 (+ 0 * a_in on the first tick after an upload)
             sa = A;
             // stage 1 (c = 1/2): position advanced with v0 (reference quirk), velocity with A0
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             sv = axpy(T(2), b.v, sv);
             F = zero_wrench<T>();
             PIPE::apply(P, aux, regs, b, F);
-            A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+            A = calc_accel<PIPE>(b.q, F, inv_I, inv_m, T(0));
             sa = axpy(T(2), A, sa);
             // stage 2 (c = 1/2): same transform as stage 1
             b.v = axpy(h1, A, v0);
@@ -283,18 +290,20 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             if (!PIPE::vel_independent(P)) {
                 F = zero_wrench<T>();
                 PIPE::apply(P, aux, regs, b, F);
-                A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+                A = calc_accel<PIPE>(b.q, F, inv_I, inv_m, T(0));
             }
             sa = axpy(T(2), A, sa);
             // stage 3 (c = 1)
-            b.q = integrate_world(q0, h3 * v0.ang);
+            T n3;
+            b.q = integrate_world(q0, h3 * v0.ang, &n3);
+            const T taint = accel_taint(n3);   // NaN when q0 or v0.ang is not finite (effectors.hpp), +-0 otherwise
             b.p = axpy(h3, v0.lin, p0);
             b.v = axpy(h3, A, v0);
             sv = sv + b.v;
             // x' = x0 (+) (dt/6) sum(v_s): complete here, before the last force evaluation
             const T g = dt * T(1.0 / 6.0);
             const Quat<T> q_new = integrate_world(q0, g * sv.ang);
-            const Vec3<T> p_new = axpy(g, sv.lin, p0);
+            const Vec3<T> p_new = axpy(g + taint, sv.lin, p0);
             if constexpr (early) {
                 stage_pos(q_new, p_new);
                 __syncthreads();
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
                 __syncthreads();
                 flush6(l_force, g_force, kLive);
             }
-            A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+            A = calc_accel<PIPE>(b.q, F, inv_I, inv_m + taint, taint);
             if constexpr (early) {
                 stage6(l_c, A);
                 __syncthreads();
@@ -329,7 +338,9 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             // systems only (`World.build(system)` without six_dof): the pre / post hooks are the whole tick
         } else {
             // semi-implicit: a = calc_accel(F(x0,v0)); v' = v0 + dt a; x' = x0 (+) dt v'
-            b.q = normalized(q0);  // q * v is scale-invariant; user data may not be unit on tick 0
+            T n0;
+            b.q = normalized(q0, &n0);  // q * v is scale-invariant; user data may not be unit on tick 0
+            const T taint = accel_taint(n0);
             b.p = p0;
             b.v = v0;
             F = zero_wrench<T>();
@@ -339,7 +350,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
                 __syncthreads();
                 flush6(l_force, g_force, kLive);
             }
-            const Spatial<T> A = calc_accel<PIPE>(b.q, F, inv_I, inv_m);
+            const Spatial<T> A = calc_accel<PIPE>(b.q, F, inv_I, inv_m + taint, taint);
             if constexpr (early) {
                 stage6(l_c, A);
                 __syncthreads();
@@ -382,10 +393,17 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             __syncthreads();
         }
     };
-    if (P.n_ticks) {
-        for (uint32_t tick = 0; tick + 1 < P.n_ticks; tick++) one_tick(std::false_type{}, tick);
-        if (early_ok) one_tick(std::true_type{}, P.n_ticks - 1);
-        else one_tick(std::false_type{}, P.n_ticks - 1);
+    {
+        constexpr std::false_type no{};
+        constexpr std::true_type yes{};
+        uint32_t tick = 0;
+        if constexpr (INTEGRATOR == kRk4 && (CHECK || PIPE::kHasModel))
+            if (P.accel_in_check && P.n_ticks) one_tick(no, yes, tick++);   // once per upload: late flush, speed is no concern
+        for (; tick + 1 < P.n_ticks; tick++) one_tick(no, no, tick);
+        if (tick < P.n_ticks) {
+            if (early_ok) one_tick(yes, no, tick);
+            else one_tick(no, no, tick);
+        }
     }
     if constexpr (PIPE::kHasModel) {
         if (active) {
@@ -413,8 +431,15 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
 
 template <class T, class PIPE, int POL>
 inline void launch_i(const StepParams& p, int integrator, dim3 grid, hipStream_t s) {
-    if (integrator == kRk4) hipLaunchKernelGGL((sixdof_step_kernel<T, kRk4, PIPE, POL>), grid, dim3(kWave), 0, s, p);
-    else if (integrator == kNone) {
+    if (integrator == kRk4) {
+        if constexpr (!PIPE::kHasModel) {
+            if (p.accel_in_check) {   // one launch per upload: a single cache policy is plenty
+                hipLaunchKernelGGL((sixdof_step_kernel<T, kRk4, PIPE, kPolPlain, true>), grid, dim3(kWave), 0, s, p);
+                return;
+            }
+        }
+        hipLaunchKernelGGL((sixdof_step_kernel<T, kRk4, PIPE, POL>), grid, dim3(kWave), 0, s, p);
+    } else if (integrator == kNone) {
         if constexpr (PIPE::kHasModel) hipLaunchKernelGGL((sixdof_step_kernel<T, kNone, PIPE, POL>), grid, dim3(kWave), 0, s, p);
     } else hipLaunchKernelGGL((sixdof_step_kernel<T, kSemiImplicit, PIPE, POL>), grid, dim3(kWave), 0, s, p);
 }

@@ -85,7 +85,9 @@ class CapiComm:
         self._lib, self._C = L.lib(), C
         self.world, self.rank = int(world), int(rank)
         self._h = C.c_void_p()
-        idbuf = (C.c_uint8 * 128)(*(comm_id or bytes(128)))
+        if comm_id is not None and len(comm_id) != 128:
+            raise ValueError("comm_id is the 128 bytes unique_id() returned on rank 0")
+        idbuf = (C.c_uint8 * 128)(*comm_id) if comm_id is not None else None   # None: one rank, the library makes its own id
         rc = self._lib.sixdof_comm_init(C.byref(self._h), idbuf, self.world, self.rank, int(device))
         if rc != L.OK:
             msg = self._lib.sixdof_comm_last_error(None)
