@@ -61,10 +61,15 @@ def _leaf_ref(name: str, table: Dict[str, str]) -> str:
     if name.startswith("c"):
         slot, k = name[1:].split("_")
         return f"r.c{slot}[{k}]"
+    if name.startswith("wst"):      # window push: row `head` (the oldest) of the ring; `@w_act@`: store only from lanes that own a row
+        slot, j = (int(x) for x in name[3:].split("_"))
+        _, width, head_slot = _WINDOWS[slot]
+        return f"@w_act@W{slot}[static_cast<int>(r.c{head_slot}[0]) * {width} + {j}]"
     raise KeyError(name)
 
 
 _TABLES: Dict[tuple, str] = {}    # (xp, fp) -> C++ symbol stem, filled while emitting one translation unit
+_WINDOWS: Dict[int, tuple] = {}    # window slot -> (rows, width, head slot) of the program being emitted (dsl.Window)
 
 
 class _Emitter:
@@ -107,6 +112,8 @@ class _Emitter:
                 d = frozenset((e.name,))
             else:
                 d = frozenset().union(*[self._deps(a) for a in e.args]) if e.args else frozenset()
+                if e.op == "wload":      # memory-resident: goes stale when its window is pushed (pseudo-leaf win<slot>)
+                    d = d | frozenset((f"win{e.value[0]}",))
                 if e.op == "while":      # plus what the condition / body read from outside the loop
                     names, cond, body, _ = e.value
                     inner = frozenset().union(self._deps(cond), *[self._deps(b) for b in body])
@@ -143,6 +150,9 @@ class _Emitter:
                 if uniform:   # evenly spaced long table: index by division instead of bisecting through memory
                     return f"m_interp_uniform<T, {len(xs)}>({a[0]}, {stem}_x, {stem}_f, T({1.0 / step!r}))"
                 return f"m_interp<T, {len(xs)}>({a[0]}, {stem}_x, {stem}_f)"
+            if e.op == "wload":     # logical row a[1] of the ring whose oldest row sits at physical row a[0]
+                slot, rows, width, j, _ = e.value
+                return f"W{slot}[((static_cast<int>({a[0]}) + static_cast<int>({a[1]})) % {rows}) * {width} + {j}]"
             if e.op == "threefry":
                 return f"m_threefry({a[0]}, {a[1]}, {a[2]}, {a[3]}, {int(e.value)})"
             if e.op == "lt":
@@ -239,7 +249,10 @@ class _Emitter:
             lines.append(f"{indent}const T {o} = {('T(' + ref(e) + ')') if e.op not in ('const', 'leaf') and self._is_wide(e) else ref(e)};")
             outs.append((lv, o))
         for lv, o in outs:
-            lines.append(f"{indent}{lv} = {o};")
+            if lv.startswith("@w_act@"):
+                lines.append(f"{indent}if (w_act) {lv[7:]} = {o};")
+            else:
+                lines.append(f"{indent}{lv} = {o};")
         wr = set(written)
         for k in list(self.names):
             dk = self.deps.get(k[1] if isinstance(k, tuple) else k, frozenset())
@@ -447,23 +460,39 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) ->
     n_aux = 0 if is_prog else len(tp.columns)
     model = ""
     n_model = 0
+    _WINDOWS.clear()
+    win_setup = ""
+    col_widths = "{0u}"
     if is_prog:
         cols = tp.columns
         n_model = len(cols)
-        regs = "\n".join(f"        T c{k}[{w}];" for k, (_, w) in enumerate(cols))
+        names_ = [c for c, _ in cols]
+        for wname, (wslot, wrows, wwidth) in tp.windows.items():
+            _WINDOWS[wslot] = (wrows, wwidth, names_.index(wname + "#head"))
+        reg_cols = [(k, w) for k, (_, w) in enumerate(cols) if k not in _WINDOWS]     # windows stay in HBM
+        regs = "\n".join(f"        T c{k}[{w}];" for k, w in reg_cols)
         loads = "\n".join(
             f"            {{ const T* g = static_cast<const T*>(P.model_cols[{k}]) + (size_t)row * {w}; "
-            + " ".join(f"r.c{k}[{j}] = g[{j}];" for j in range(w)) + " }" for k, (_, w) in enumerate(cols))
-        zero = " ".join(f"for (int j = 0; j < {w}; j++) r.c{k}[j] = T(0);" for k, (_, w) in enumerate(cols))
+            + " ".join(f"r.c{k}[{j}] = g[{j}];" for j in range(w)) + " }" for k, w in reg_cols)
+        zero = " ".join(f"for (int j = 0; j < {w}; j++) r.c{k}[j] = T(0);" for k, w in reg_cols)
         stores = "\n".join(
             f"        {{ T* g = static_cast<T*>(P.model_cols[{k}]) + (size_t)row * {cols[k][1]}; "
             + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(cols[k][1])) + " }" for k in tp.written_slots)
         records = "\n".join(
             f"        if (P.model_hist[{k}]) {{ T* g = static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row) * {w}; "
-            + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(w)) + " }" for k, (_, w) in enumerate(cols))
+            + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(w)) + " }" for k, w in reg_cols)
+        col_widths = "{" + ", ".join(f"{w}u" + (" | 0x80000000u" if k in _WINDOWS else "") for k, (_, w) in enumerate(cols)) + "}"
+        if _WINDOWS:
+            # one lane = one entity, a workgroup is one wave (step_kernel.hpp): this lane's row of every window column.
+            # Lanes past the last row read the last row and store nothing.
+            win_setup = ("        const uint32_t w_row = blockIdx.x * kWave + threadIdx.x;\n"
+                         "        const bool w_act = w_row < P.n;\n"
+                         + "".join(f"        T* const W{k} = static_cast<T*>(P.model_cols[{k}]) + (size_t)(w_act ? w_row : P.n - 1) * {rows * width};\n"
+                                   for k, (rows, width, _) in _WINDOWS.items()))
         model = f'''
     static constexpr bool kHasModel = true;
     static constexpr bool kWritesInertia = {"true" if tp.writes_inertia else "false"};
+    static constexpr bool kPreReadsAccel = {"true" if tp.pre_reads_accel else "false"};
     template <class T>
     struct Regs {{
 {regs}
@@ -485,15 +514,15 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) ->
     }}
     template <class T>
     __device__ static __forceinline__ void pre(const StepParams& P, uint64_t tick, Regs<T>& r, Quat<T>& q, Vec3<T>& p,
-                                               Spatial<T>& v, Vec3<T>& I, T& mass) {{
-        (void)P; (void)tick;
-{_emit_systems(tp.pre)}
+                                               Spatial<T>& v, Vec3<T>& I, T& mass, const Spatial<T>& accel) {{
+        (void)P; (void)tick; (void)accel;
+{win_setup}{_emit_systems(tp.pre)}
     }}
     template <class T>
     __device__ static __forceinline__ void post(const StepParams& P, uint64_t tick, Regs<T>& r, Quat<T>& q, Vec3<T>& p,
                                                 Spatial<T>& v, Vec3<T>& I, T& mass, const Spatial<T>& accel) {{
         (void)P; (void)tick; (void)accel;
-{_emit_systems(tp.post)}
+{win_setup}{_emit_systems(tp.post)}
     }}'''
     names = ", ".join(e.__name__ for e in pipe_tp.effectors)
     tables = _emit_tables()
@@ -527,6 +556,11 @@ struct PipeCustom : NoModel {{
 
 extern "C" unsigned sixdof_custom_abi() {{ return static_cast<unsigned>(sizeof(sixdof::StepParams)); }}
 extern "C" unsigned sixdof_custom_layout() {{ return {n_aux}u | ({n_model}u << 8) | ({1 if (is_prog and tp.writes_inertia) else 0}u << 16); }}
+// row width of every program column, in slot order (bit 31: window column, kept in HBM) — checked against the bound columns
+extern "C" void sixdof_custom_column_widths(unsigned* out) {{
+    static const unsigned w[] = {col_widths};
+    for (unsigned k = 0; k < {n_model}u; k++) out[k] = w[k];
+}}
 
 extern "C" int sixdof_custom_launch(const sixdof::StepParams* p, int integrator, int dtype, void* stream) {{
     using namespace sixdof;

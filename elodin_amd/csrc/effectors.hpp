@@ -74,6 +74,7 @@ __device__ __forceinline__ void apply_one(const DevOp& op, const Vec3<T>& aux, c
 struct NoModel {
     static constexpr bool kHasModel = false;
     static constexpr bool kWritesInertia = false;
+    static constexpr bool kPreReadsAccel = false;   // a system in front of six_dof reads world_accel (the previous tick's)
     template <class T>
     struct Regs {};
     template <class T>
@@ -84,7 +85,7 @@ struct NoModel {
     __device__ static __forceinline__ void record(const StepParams&, size_t, uint32_t, const Regs<T>&) {}
     template <class T>
     __device__ static __forceinline__ void pre(const StepParams&, uint64_t, Regs<T>&, Quat<T>&, Vec3<T>&, Spatial<T>&,
-                                               Vec3<T>&, T&) {}
+                                               Vec3<T>&, T&, const Spatial<T>&) {}
     template <class T>
     __device__ static __forceinline__ void post(const StepParams&, uint64_t, Regs<T>&, Quat<T>&, Vec3<T>&, Spatial<T>&,
                                                 Vec3<T>&, T&, const Spatial<T>&) {}

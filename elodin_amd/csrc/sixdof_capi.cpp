@@ -106,6 +106,7 @@ struct sixdof_handle {
     uint64_t hist_first_tick = 0;   // first tick (1-based count) recorded since the ring was enabled
     void* d_hist[4] = {nullptr, nullptr, nullptr, nullptr};  // pos, vel, accel, force
     std::vector<void*> d_model_hist;      // one ring per component column of a generated program (same order as custom_model)
+    std::vector<unsigned> custom_model_width;   // what the generated code expects per column (0 = unknown), bit 31 = window
     // rollout model (0 = none, 1 = Apollo lander)
     int model = 0;
     std::vector<double> ap_time, ap_alt, ap_rate, ap_pitch, ap_hspeed, ap_downrange;
@@ -744,8 +745,13 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
     for (size_t k = 0; k < h->custom_model.size(); k++) {
         Column* c = h->col(h->custom_model[k]);
         if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "step: component column of the generated program is not bound");
-        if (c->width < 1 || c->width > 16 || c->prim != h->state_prim())
-            return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, "step: program columns must be [n,1..16] of the state dtype");
+        const unsigned expect = k < h->custom_model_width.size() ? h->custom_model_width[k] : 0u;
+        const bool window = (expect >> 31) != 0;
+        const size_t want = expect & 0x7fffffffu;
+        if (c->prim != h->state_prim() || c->width < 1 || (!window && c->width > 16) || (want && c->width != want))
+            return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH,
+                           "step: program columns must be of the state dtype and as wide as the generated code expects "
+                           "([n,1..16]; a window column [n, rows*width])");
         if (!c->joined) {
             int rc = resolve_join(h, c);
             if (rc != SIXDOF_OK) return rc;
@@ -991,6 +997,7 @@ int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t
         dlclose(dl);
         return h->fail(SIXDOF_ERR_BACKEND, "set_custom_pipe: not a generated pipe for this library build (StepParams layout differs)");
     }
+    auto col_widths = reinterpret_cast<void (*)(unsigned*)>(dlsym(dl, "sixdof_custom_column_widths"));
     const unsigned lay = layout();
     const size_t k_aux = lay & 0xff, k_model = (lay >> 8) & 0xff;
     if (k_aux > static_cast<size_t>(kMaxOps) || k_model > static_cast<size_t>(kMaxModelCols) || k_aux + k_model != n_aux) {
@@ -1002,6 +1009,9 @@ int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t
     h->custom_launch = launch;
     h->custom_aux.assign(aux_ids, aux_ids + k_aux);
     h->custom_model.assign(aux_ids + k_aux, aux_ids + k_aux + k_model);
+    // row widths the generated code was built for (bit 31: a window column — memory-resident, any width, not recorded)
+    h->custom_model_width.assign(k_model, 0u);
+    if (col_widths && k_model) col_widths(h->custom_model_width.data());
     h->ops.clear();
     h->drop_graph();
     return SIXDOF_OK;
@@ -1059,7 +1069,9 @@ int sixdof_set_history(sixdof_handle* h, uint32_t ring_ticks) {
     for (uint64_t id : h->custom_model) {      // component columns of a generated program are recorded too
         const Column* c = h->col(id);
         void* ring = nullptr;
-        if (c) {
+        const size_t m_idx = h->d_model_hist.size();
+        const bool window = m_idx < h->custom_model_width.size() && (h->custom_model_width[m_idx] >> 31);
+        if (c && !window) {   // a window column is its own history (and far too wide to copy per tick)
             const size_t bytes = static_cast<size_t>(ring_ticks) * n * c->width * es;
             hipError_t e = hipMalloc(&ring, bytes ? bytes : 16);
             if (e != hipSuccess) return h->hip_fail(e, "set_history: hipMalloc of a component ring");

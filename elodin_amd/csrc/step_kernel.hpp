@@ -187,10 +187,15 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
         inv_I = Vec3<T>{recip(m[0]), recip(m[1]), recip(m[2])};
         mass = m[6];
         inv_m = recip(mass);
-        if constexpr (INTEGRATOR == kNone) {   // no six_dof in the pipe: world_accel / force pass through untouched
+        if constexpr (INTEGRATOR == kNone || PIPE::kPreReadsAccel) {
+            // no six_dof in the pipe: world_accel / force pass through untouched.  With six_dof: a system piped in front of
+            // it that reads world_accel sees what the previous tick left there (the reference's column semantics) — later
+            // ticks of this launch find it in A_out.
             const T* a = g_accel + (size_t)t * 6;
-            const T* f = g_force + (size_t)t * 6;
             A_out = Spatial<T>{{a[0], a[1], a[2]}, {a[3], a[4], a[5]}};
+        }
+        if constexpr (INTEGRATOR == kNone) {
+            const T* f = g_force + (size_t)t * 6;
             F_out = Spatial<T>{{f[0], f[1], f[2]}, {f[3], f[4], f[5]}};
         }
     }
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
         constexpr bool early = decltype(early_tag)::value;
         constexpr bool check = decltype(check_tag)::value;
         if constexpr (PIPE::kHasModel) {   // user systems piped in front of six_dof (may rewrite inertia, pose, velocity)
-            PIPE::pre(P, P.tick0 + tick + 1, regs, q0, p0, v0, I_diag, mass);
+            PIPE::pre(P, P.tick0 + tick + 1, regs, q0, p0, v0, I_diag, mass, A_out);
             if constexpr (PIPE::kWritesInertia) {
                 inv_I = Vec3<T>{recip(I_diag.x), recip(I_diag.y), recip(I_diag.z)};
                 inv_m = recip(mass);

@@ -775,6 +775,71 @@ def _leaves_of(outputs: Sequence[Expr]) -> set:
     return deps
 
 
+class Window:
+    """A WIDE component — `rows` x `width` values per entity, e.g. the 4 s sample buffer of the reference's rocket example
+    (`el.ComponentType(F64, (480, 3))`, examples/rocket/main.py:91-98) — that stays in HBM instead of the register file.
+    Declared by giving the system a (rows, width) tuple for the component: `@dsl.system(v_rel_accel_buffer=(480, 3))`.
+
+    The generated kernel keeps it as a RING in the component's own column (`[n, rows*width]`, the reference's row layout) with
+    a per-entity head (hidden 1-wide component `<name>#head` = physical index of the oldest row): `push` overwrites the oldest
+    row and advances the head — 3 stores per tick where `concatenate((buffer[1:], row))` moves the whole buffer; the host
+    un-rotates on download (HipExec.column), so callers always see the reference's order, oldest row first.
+
+    Reads: `w[i]` (static row, negative from the end) -> Vec of `width`; `w.row(i)` with a traced index (inside loops);
+    `w.scan(f, init, start, stop)` = jax.lax.scan over rows start..stop-1 as a REAL loop (carry only — what an IIR filter over
+    the window needs); `w.push(row)` -> the value to return for the component."""
+
+    def __init__(self, name: str, slot: int, rows: int, width: int, head: "Expr", version: int):
+        self.name, self.slot, self.rows, self.width, self.head, self.version = name, slot, rows, width, head, version
+
+    def __len__(self): return self.rows
+
+    def row(self, index) -> "Vec":
+        idx = _lift(index)
+        return Vec([Expr("wload", (self.head, idx), (self.slot, self.rows, self.width, j, self.version)) for j in range(self.width)])
+
+    def __getitem__(self, i):
+        if not isinstance(i, int):
+            raise TypeError("window[i] takes a Python int (use .row(index) for a traced index, .scan(...) for a loop)")
+        if not -self.rows <= i < self.rows:
+            raise IndexError(i)
+        return self.row(float(i % self.rows))
+
+    def push(self, row) -> "WindowPush":
+        row = row if isinstance(row, Vec) else Vec([row])
+        if len(row) != self.width:
+            raise ValueError(f"window {self.name}: a row has {self.width} values, got {len(row)}")
+        return WindowPush(self, row)
+
+    def scan(self, f, init, start: int = 0, stop: Optional[int] = None):
+        """carry = init; for r in range(start, stop): carry, _ = f(carry, window[r]) -> carry.  A real loop in the kernel."""
+        stop = self.rows if stop is None else int(stop)
+        start = int(start)
+        if not 0 <= start <= stop <= self.rows:
+            raise IndexError((start, stop))
+        flat, rebuild = _flatten(init)
+
+        def cond(c):
+            return c[0] < float(stop)
+
+        def body(c):
+            out = f(rebuild(list(c[1:])), self.row(c[0]))
+            new_carry = out[0] if isinstance(out, tuple) and len(out) == 2 else out
+            nf, _ = _flatten(new_carry)
+            if len(nf) != len(flat):
+                raise TypeError("window.scan: the step must return (carry, y) with the carry structure of init")
+            return [c[0] + 1.0] + list(nf)
+        res = _Lax.while_loop(cond, body, [const(float(start))] + list(flat), max_iter=stop - start + 1)
+        return rebuild(list(res[1:]))
+
+
+class WindowPush:
+    """What a system returns for a window component after `window.push(row)`."""
+
+    def __init__(self, window: Window, row: "Vec"):
+        self.window, self.row = window, row
+
+
 class ColumnTable:
     """Component columns used by generated code, in first-use order: name -> (slot, width)."""
 
@@ -782,11 +847,37 @@ class ColumnTable:
         self.prefix, self.limit, self.max_width = prefix, limit, max_width
         self.known = dict(known or {})
         self.cols: List[Tuple[str, int]] = []
+        self.windows: Dict[str, List[int]] = {}      # name -> [slot, rows, width, version]
+
+    def window(self, name: str, rows: int, width: int) -> Window:
+        """The memory-resident component `name` ([rows, width] per entity) at its current version, plus its hidden head."""
+        rows, width = int(rows), int(width)
+        if rows < 2 or width < 1:
+            raise ValueError(f"window {name}: need rows >= 2 and width >= 1")
+        have = dict(self.cols)
+        if name in have and name not in self.windows:
+            raise ValueError(f"component {name} is already used as a register column")
+        if name not in self.windows:
+            if len(self.cols) >= self.limit:
+                raise ValueError(f"generated code can use at most {self.limit} component columns")
+            self.cols.append((name, rows * width))
+            self.windows[name] = [len(self.cols) - 1, rows, width, 0]
+        slot, r0, w0, version = self.windows[name]
+        if (r0, w0) != (rows, width):
+            raise ValueError(f"window {name}: conflicting shapes {(r0, w0)} / {(rows, width)}")
+        head = self.symbols(name + "#head", 1, 1)[0]
+        return Window(name, slot, rows, width, head, version)
+
+    def bump(self, name: str):
+        self.windows[name][3] += 1
 
     def symbols(self, name: str, declared: Optional[int], default: int) -> Vec:
+        if name in self.windows:
+            raise ValueError(f"component {name} is a window: give the system its (rows, width) shape")
         w = int(declared if declared is not None else self.known.get(name, default))
         if not 1 <= w <= self.max_width:
-            raise ValueError(f"component {name}: width must be 1..{self.max_width}")
+            raise ValueError(f"component {name}: width must be 1..{self.max_width} (a wider one is a window: declare its "
+                             "(rows, width) shape)")
         have = dict(self.cols)
         if name in have and have[name] != w:
             raise ValueError(f"component {name}: conflicting widths {have[name]} / {w}")
@@ -1028,13 +1119,18 @@ class TracedSystem:
 
     def __init__(self, sys_: System, table: ColumnTable, partial: Sequence[str] = (), after_six_dof: bool = False):
         self.name, self.every, self.phase, self.also_at = sys_.__name__, sys_.every, sys_.phase, sys_.also_at
+        self.reads_accel = False
         pos, vel, inertia = _body_symbols()
         kwargs = {}
+
+        def shape_of(name):
+            d = sys_.widths.get(name, table.known.get(name))
+            return tuple(int(x) for x in d) if isinstance(d, (tuple, list)) else None
         for name in sys_.params:
             if name in ("accel", "world_accel"):
-                if not after_six_dof:
-                    raise TypeError(f"system {self.name}: world_accel is the acceleration six_dof just produced — readable from "
-                                    "systems piped AFTER six_dof only")
+                # after six_dof: the acceleration it just produced; before: the column as the previous tick left it
+                # (what a reference system piped in front of six_dof reads, e.g. examples/rocket/main.py:452-462)
+                self.reads_accel = True
                 kwargs[name] = SpatialMotion(Vec([leaf("aa" + c) for c in "xyz"]), Vec([leaf("al" + c) for c in "xyz"]))
                 continue
             if name in ("pos", "world_pos"):
@@ -1047,6 +1143,10 @@ class TracedSystem:
                 kwargs[name] = leaf("tick")
             elif name == "force":
                 raise TypeError("systems outside six_dof cannot read `force`")
+            elif shape_of(name) is not None:
+                if name in partial:
+                    raise TypeError(f"system {self.name}: window component {name} must live on every row of the executor")
+                kwargs[name] = table.window(name, *shape_of(name))
             else:
                 v = table.symbols(name, sys_.widths.get(name), 1)
                 kwargs[name] = v if len(v) > 1 else v[0]
@@ -1055,7 +1155,24 @@ class TracedSystem:
             raise TypeError(f"system {self.name} must return a dict {{component: value}}")
         self.assign: List[Tuple[str, Expr]] = []      # (leaf name written, value)
         self.writes_inertia = False
+        touched: List[str] = []                        # pseudo-leaves `win<slot>`: loads of a pushed window go stale
         for cname, val in out.items():
+            if isinstance(val, (Window, WindowPush)):
+                if isinstance(val, Window):
+                    raise TypeError(f"system {self.name}: return window.push(row) for {cname} (a window cannot be rewritten whole)")
+                w = val.window
+                if w.name != cname or cname in partial:
+                    raise TypeError(f"system {self.name}: {cname} must be returned as ITS OWN window's push, on every row")
+                if w.version != table.windows[cname][3]:
+                    raise TypeError(f"system {self.name}: window {cname} was pushed twice from the same handle")
+                # the new row replaces the oldest (physical row `head`), then the head moves on: stores first, head last
+                for j, e in enumerate(val.row.e):
+                    self.assign.append((f"wst{w.slot}_{j}", e))
+                nxt = w.head + 1.0
+                self.assign.append((w.head.name, Expr("select", (nxt < float(w.rows), nxt, const(0.0)))))
+                table.bump(cname)
+                touched.append(f"win{w.slot}")
+                continue
             if cname in ("pos", "world_pos"):
                 if not isinstance(val, SpatialTransform):
                     raise TypeError("world_pos must be a dsl.SpatialTransform")
@@ -1090,7 +1207,7 @@ class TracedSystem:
                 h = table.symbols("has:" + n, 1, 1)[0] > 0.5
                 mask = h if mask is None else (mask & h)
             self.assign = [(t, Expr("select", (mask, e, leaf(t)))) for t, e in self.assign]
-        self.written = [t for t, _ in self.assign]
+        self.written = [t for t, _ in self.assign] + touched
 
 
 class Program:
@@ -1114,6 +1231,8 @@ class TracedProgram:
         self.pipe = TracedPipe(prog.effectors.effectors, table=self.table, partial=self.partial)
         self.post = [TracedSystem(s, self.table, self.partial, after_six_dof=True) for s in prog.post]
         self.writes_inertia = any(s.writes_inertia for s in self.pre + self.post)
+        self.pre_reads_accel = any(s.reads_accel for s in self.pre)
+        self.windows = {name: tuple(v[:3]) for name, v in self.table.windows.items()}     # name -> (slot, rows, width)
         written = set()
         for s in self.pre + self.post:
             written.update(t for t in s.written if t[0] == "c")

@@ -72,6 +72,7 @@ class HipExec:
         self._column_ids = {k: np.ascontiguousarray(v, dtype=np.uint64) for k, v in (column_entity_ids or {}).items()}
         n = self.world_pos.shape[0] if not self._column_ids else 0   # 0 = let the library size the join
         self._aux = {}
+        self._windows = {}
         d = L.Desc()
         d.struct_size = C.sizeof(L.Desc)
         d.device_ordinal = device
@@ -98,13 +99,19 @@ class HipExec:
             if isinstance(effectors, (_dsl.Pipe, _dsl.Program)):
                 # user-written effectors / systems: trace -> generate HIP -> hipcc -> sixdof_set_custom_pipe
                 from . import codegen
-                widths = {k: int(np.atleast_2d(np.asarray(v)).shape[-1]) for k, v in (columns or {}).items()}
+                # [n, w] columns give their row width; an [n, rows, w] column is a window component (dsl.Window)
+                widths = {k: (tuple(int(x) for x in np.shape(v)[1:]) if np.ndim(v) == 3 else int(np.atleast_2d(np.asarray(v)).shape[-1]))
+                          for k, v in (columns or {}).items()}
                 custom = effectors.trace(widths)
                 if isinstance(effectors, _dsl.Program):
                     self._program_columns = [n for n, _ in custom.columns]
+                    self._windows = {name: (rows, width) for name, (_, rows, width) in custom.windows.items()}
+                    columns = dict(columns or {})
+                    for name in self._windows:       # the ring's head (physical index of the oldest row): starts at 0
+                        columns.setdefault(name + "#head", np.zeros((np.shape(columns[name])[0], 1)) if name in columns else None)
                 so = codegen.build(custom, self.dtype.name, integrator, fast_math=fast_math)
                 for name, width in custom.columns:
-                    if columns is None or name not in columns:
+                    if columns is None or columns.get(name) is None:
                         raise KeyError(f"effector reads component {name!r} which was not provided")
                     arr = np.array(columns[name], dtype=self.dtype, order="C").reshape(-1, width)
                     self._aux[name] = arr
@@ -210,6 +217,18 @@ class HipExec:
             if rc != L.OK:
                 _raise(self._h, rc, "sixdof_download_column")
         return self
+
+    def component(self, name: str) -> np.ndarray:
+        """A generated program's component column as the reference lays it out.  Plain columns: the [n, w] host array
+        itself.  Window components (dsl.Window) are kept as a ring on the device: un-rotated here to [n, rows, w], oldest
+        row first — what `concatenate((buffer[1:], row))` leaves in the reference's column."""
+        if name not in self._windows:
+            return self._aux[name]
+        rows, width = self._windows[name]
+        ring = self._aux[name].reshape(-1, rows, width)
+        head = self._aux[name + "#head"][:, 0].astype(np.int64)
+        idx = (head[:, None] + np.arange(rows)[None, :]) % rows
+        return ring[np.arange(ring.shape[0])[:, None], idx]
 
     def run(self, ticks: int = 1) -> TickTimings:
         """PyExec.run (exec.rs:110-172) without the DB commit: step, then refresh the host columns."""

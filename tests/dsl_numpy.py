@@ -89,10 +89,22 @@ def _leaf_arrays(pos, vel, inertia, comps, table, tick, accel=None):
           "tick": np.full(n, float(tick))}
     if accel is not None:
         lv.update({"aax": accel[:, 0], "aay": accel[:, 1], "aaz": accel[:, 2], "alx": accel[:, 3], "aly": accel[:, 4], "alz": accel[:, 5]})
+    wins = {v[0]: comps[name] for name, v in getattr(table, "windows", {}).items()}
     for slot, (name, w) in enumerate(table.cols):
+        if slot in wins:
+            continue                      # a window stays in its [n, rows*width] array (ring order, see window_rows)
         for k in range(w):
             lv[f"{table.prefix}{slot}_{k}"] = comps[name][:, k]
+    lv["@win"] = wins
     return lv
+
+
+def window_rows(comps, name, rows, width):
+    """The window component `name` in the reference's order (oldest row first): [n, rows, width] from the ring + head."""
+    ring = comps[name].reshape(-1, rows, width)
+    head = comps[name + "#head"][:, 0].astype(int)
+    idx = (head[:, None] + np.arange(rows)[None, :]) % rows
+    return ring[np.arange(ring.shape[0])[:, None], idx]
 
 
 def _eval(exprs, leaves, n):
@@ -115,6 +127,11 @@ def _eval(exprs, leaves, n):
             r = np.interp(ev(e.args[0]), np.array(e.value[0]), np.array(e.value[1]))
         elif e.op == "threefry":
             r = _threefry(*[np.broadcast_to(ev(a), (n,)) for a in e.args])[e.value]
+        elif e.op == "wload":
+            slot, rows, width, j, _ = e.value
+            head = np.broadcast_to(ev(e.args[0]), (n,)).astype(int)
+            idx = np.broadcast_to(ev(e.args[1]), (n,)).astype(int)
+            r = leaves["@win"][slot][np.arange(n), ((head + idx) % rows) * width + j]
         elif e.op == "while_out":
             r = ev(e.args[0])[e.value]
         elif e.op == "while":
@@ -153,6 +170,12 @@ def _run_systems(systems, pos, vel, inertia, comps, table, tick, accel=None):
         for (target, _), val in zip(s.assign, vals):     # all outputs computed before any is written
             if target == "mass":
                 inertia[:, 6] = val
+            elif target.startswith("wst"):           # window push: the new row lands on the oldest (physical row = head)
+                slot, j = (int(x) for x in target[3:].split("_"))
+                name = table.cols[slot][0]
+                _, _, width = table.windows[name][:3]
+                head = comps[name + "#head"][:, 0].astype(int)      # still the old head: it is assigned after the stores
+                comps[name][np.arange(pos.shape[0]), head * width + j] = val
             elif target[0] == "c" and "_" in target:
                 slot, k = target[1:].split("_")
                 comps[table.cols[int(slot)][0]][:, int(k)] = val
@@ -164,7 +187,7 @@ def _run_systems(systems, pos, vel, inertia, comps, table, tick, accel=None):
 def program_tick(tp, pos, vel, accel, inertia, comps, tick, dt_g, integrator):
     """One tick of a dsl.TracedProgram with numpy (in place on copies); `tick` = count after this tick."""
     from tests import np_sixdof
-    _run_systems(tp.pre, pos, vel, inertia, comps, tp.table, tick)
+    _run_systems(tp.pre, pos, vel, inertia, comps, tp.table, tick, accel if getattr(tp, "pre_reads_accel", False) else None)
 
     def eff(xs, vs):
         lv = _leaf_arrays(xs, vs, inertia, comps, tp.table, tick)

@@ -229,7 +229,7 @@ def test_spatial_map_values():  # test_all.py:86-114 and 204-225 on the interpre
     assert vel[0].tolist() == [np.pi, 0, 0, 2.0, 0, 0]
 
 
-def test_world_accel_is_readable_after_six_dof_only():
+def test_world_accel_after_six_dof_is_this_ticks_and_in_front_of_it_the_previous_ticks():
     Meas = ty.Annotated[el.Array, el.Component("meas", el.ComponentType(el.PrimitiveType.F64, (3,)))]
 
     @el.map
@@ -244,8 +244,13 @@ def test_world_accel_is_readable_after_six_dof_only():
     dsl_numpy._run_systems(tp.post, pos, vel, inertia, comps, tp.table, 1, accel)
     c, s_ = np.cos(0.5), np.sin(0.5)
     assert np.allclose(comps["meas"][0], [c * 1.0 + s_ * 2.0, -s_ * 1.0 + c * 2.0, 3.0])
-    with pytest.raises(TypeError, match="AFTER six_dof"):
-        dsl.Program([imu], dsl.Pipe([]), []).trace({"meas": 3})
+    # piped IN FRONT of six_dof the same system reads the column as the previous tick left it (examples/rocket/main.py:452-462
+    # does exactly that); the program is flagged so the kernel loads the column at launch start
+    tp_pre = dsl.Program([imu], dsl.Pipe([]), []).trace({"meas": 3})
+    assert tp_pre.pre_reads_accel and not tp.pre_reads_accel
+    comps = {"meas": np.zeros((1, 3))}
+    dsl_numpy._run_systems(tp_pre.pre, pos, vel, inertia, comps, tp_pre.table, 1, accel)
+    assert np.allclose(comps["meas"][0], [c * 1.0 + s_ * 2.0, -s_ * 1.0 + c * 2.0, 3.0])
 
     def peek(f: el.Force, m: Meas) -> Meas:
         return m + f.force()

@@ -1,0 +1,50 @@
+"""The reference's rocket example through the generated gfx950 kernel against the reference's own CI baseline rows
+(scripts/ci/baseline/rocket-csv; see tests/test_rocket_reference.py for what the example exercises): one tick per launch so
+every golden row is compared, then fused launches and a wave-and-a-bit of identical rockets for the same end state."""
+import numpy as np
+import pytest
+
+import elodin_amd as ea
+from elodin_amd import _lib as L
+from tests import rocket_dsl as R, rocket_util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def _exec(n, **kw):
+    pos, vel, inertia, comps = R.spawn(n)
+    comps["v_rel_accel_buffer"] = comps["v_rel_accel_buffer"].reshape(n, R.LP_BUFFER_SIZE, 3)    # [n, rows, w] = a window
+    return ea.HipExec(pos, vel, inertia, simulation_time_step=R.SIM_TIME_STEP, integrator=L.RK4, effectors=R.program(),
+                      columns=comps, **kw)
+
+
+def _row(hip, k=0):
+    got = {name: hip.component(name)[k] for name in U.GOLDEN["rows"] if name in hip._aux}
+    got.update(world_pos=hip.world_pos[k], world_vel=hip.world_vel[k], world_accel=hip.world_accel[k], force=hip.force[k], inertia=hip.inertia[k])
+    return got
+
+
+def test_rocket_every_golden_row_one_tick_per_launch():
+    hip = _exec(1)
+    worst = {}
+    for tick in range(1, 101):
+        hip.run(1)
+        U.check_row(tick, _row(hip), worst)
+    print("rocket vs reference baseline, HIP:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
+    U.assert_all_columns(worst)
+    want = np.array(U.GOLDEN["v_rel_accel_buffer_final"])
+    assert np.abs(hip.component("v_rel_accel_buffer")[0].ravel() - want).max() < 1e-9 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("n,k", [(1, 25), (97, 100), (97, 7)])
+def test_rocket_fused_launches_and_many_rockets_end_on_the_golden_row(n, k):
+    """The window and the previous tick's world_accel carry across the ticks of one launch (and across launches when 100 is not
+    a multiple of k); 97 rockets = one full wave + a ragged one, every row must be the golden rocket."""
+    hip = _exec(n, ticks_per_launch=k)
+    hip.run(100)
+    for row in (0, n - 1, n // 2):
+        worst = {}
+        U.check_row(100, _row(hip, row), worst)
+        U.assert_all_columns(worst)
+    want = np.array(U.GOLDEN["v_rel_accel_buffer_final"])
+    assert np.abs(hip.component("v_rel_accel_buffer")[n - 1].ravel() - want).max() < 1e-9 * np.abs(want).max()
