@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def _exec(n, **kw):
     pos, vel, inertia, comps = R.spawn(n)
     comps["v_rel_accel_buffer"] = comps["v_rel_accel_buffer"].reshape(n, R.LP_BUFFER_SIZE, 3)    # [n, rows, w] = a window
-    return ea.HipExec(pos, vel, inertia, simulation_time_step=R.SIM_TIME_STEP, integrator=L.RK4, effectors=R.program(),
+    return ea.HipExec(pos, vel, inertia, simulation_time_step=U.GOLDEN["simulation_time_step"], integrator=L.RK4, effectors=R.program(),
                       columns=comps, **kw)
 
 
