@@ -287,7 +287,11 @@ int sixdof_bind_world(sixdof_handle* h, sixdof_world* w);
  * per-entity columns the generated code uses, in the order it indexes them: first the read-only effector
  * columns (row width 1..3, <= 4), then — for whole programs `pre | six_dof(effectors) | post` — the component
  * columns its systems read AND write (row width 1..16, <= 48; fetch them back with sixdof_download_column).
- * Replaces the built-in op list (sixdof_set_effectors) for the per-entity path. */
+ * A WINDOW column (a wide component such as the rocket example's 480 x 3 sample buffer, examples/rocket/main.py:91-98)
+ * is bound like any other, [n, rows*width] in the reference's row layout, but stays in HBM: the kernel uses it as a ring
+ * whose head (physical index of the oldest row) lives in a hidden [n,1] column `<name>#head` — un-rotate with it after a
+ * download.  The generated object exports the row width it was built for per column; sixdof_step refuses columns bound
+ * with another width.  Replaces the built-in op list (sixdof_set_effectors) for the per-entity path. */
 int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t* aux_component_ids, size_t n_aux);
 /* Same idea for GraphQuery.edge_fold (graph.rs:177-282) with a user-written fold function over
  * (acc: Force, a: (WorldPos, Inertia), b: (WorldPos, Inertia)): the generated object instantiates the pair kernels
