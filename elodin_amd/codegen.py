@@ -115,7 +115,7 @@ class _Emitter:
                 if e.op == "wload":      # memory-resident: goes stale when its window is pushed (pseudo-leaf win<slot>)
                     d = d | frozenset((f"win{e.value[0]}",))
                 if e.op == "while":      # plus what the condition / body read from outside the loop
-                    names, cond, body, _ = e.value
+                    names, cond, body = e.value[:3]
                     inner = frozenset().union(self._deps(cond), *[self._deps(b) for b in body])
                     d = d | (inner - frozenset(names))
             self.deps[id(e)] = d
@@ -172,7 +172,8 @@ class _Emitter:
         def emit_loop(node: dsl.Expr, sc) -> List[str]:
             """A data-dependent loop (dsl.lax.while_loop): carried values live in mutable locals of the scope the loop
             belongs to; everything in the condition / body that does not depend on them is hoisted out."""
-            names, cond, body, max_iter = node.value
+            names, cond, body, max_iter = node.value[:4]
+            counted = node.value[4] if len(node.value) > 4 else None
             inits = [ref(x, sc) for x in node.args]
             cvars = {}
             for nm, init in zip(names, inits):
@@ -180,8 +181,9 @@ class _Emitter:
                 self.n += 1
                 sc["lines"].append(f"{sc['indent']}T {cvars[nm]} = {init};")
             inner = {"parent": sc, "names": {}, "lines": [], "vars": cvars, "varset": frozenset(names), "indent": sc["indent"] + "    "}
-            c = ref(cond, inner)
-            inner["lines"].append(f"{inner['indent']}if (!({c})) break;")
+            if counted is None:
+                c = ref(cond, inner)
+                inner["lines"].append(f"{inner['indent']}if (!({c})) break;")
             new = [ref(b, inner) for b in body]
             tmp = []
             for k, v in enumerate(new):
@@ -190,7 +192,11 @@ class _Emitter:
                 inner["lines"].append(f"{inner['indent']}const T {tmp[-1]} = {v};")
             for nm, t_ in zip(names, tmp):
                 inner["lines"].append(f"{inner['indent']}{cvars[nm]} = {t_};")
-            sc["lines"].append(f"{sc['indent']}for (int it_{self.n} = 0; it_{self.n} < {max_iter}; it_{self.n}++) {{")
+            if counted is not None:   # static trip count, no early exit: let the compiler overlap the loads of several rows
+                sc["lines"].append(f"{sc['indent']}#pragma unroll 8")
+                sc["lines"].append(f"{sc['indent']}for (int it_{self.n} = {counted[0]}; it_{self.n} < {counted[1]}; it_{self.n}++) {{")
+            else:
+                sc["lines"].append(f"{sc['indent']}for (int it_{self.n} = 0; it_{self.n} < {max_iter}; it_{self.n}++) {{")
             self.n += 1
             sc["lines"].extend(inner["lines"])
             sc["lines"].append(f"{sc['indent']}}}")

@@ -492,7 +492,7 @@ class _Lax:
     _loop_ids = [0]
 
     @staticmethod
-    def while_loop(cond_fun, body_fun, init_val, max_iter: int = 1_000_000):
+    def while_loop(cond_fun, body_fun, init_val, max_iter: int = 1_000_000, counted: Optional[Tuple[int, int]] = None):
         """jax.lax.while_loop with a data-dependent trip count (e.g. examples/stablehlo/sim.py:223, or a flight
         computer propagating a ballistic arc until it meets the ground): becomes a real loop in the generated kernel,
         lanes leave it independently.  `init_val`: a scalar, a Vec, or a tuple / list of those.  `max_iter` bounds the
@@ -506,7 +506,10 @@ class _Lax:
         body, _ = _flatten(body_fun(carried))
         if len(body) != len(flat):
             raise TypeError("while_loop body must return the structure of init_val")
-        node = Expr("while", tuple(_lift(x) for x in flat), (names, cond, tuple(_lift(b) for b in body), int(max_iter)))
+        # counted=(start, stop): the first carried value is a counter start, start+1, ... and the condition is `counter < stop`
+        # (Window.scan) — the code generator may then emit a plain counted loop it can unroll and software-pipeline
+        node = Expr("while", tuple(_lift(x) for x in flat),
+                    (names, cond, tuple(_lift(b) for b in body), int(max_iter)) + ((tuple(counted),) if counted else ()))
         return rebuild([Expr("while_out", (node,), j) for j in range(len(flat))])
 
     @staticmethod
@@ -765,7 +768,7 @@ def _leaves_of(outputs: Sequence[Expr]) -> set:
         if e.op == "leaf":
             deps.add(e.name)
         if e.op == "while":              # free variables of the loop's condition and body, minus the carried ones
-            names, cond, body, _ = e.value
+            names, cond, body = e.value[:3]
             inner = _leaves_of([cond, *body]) - set(names)
             deps.update(inner)
         for a in e.args:
@@ -829,7 +832,7 @@ class Window:
             if len(nf) != len(flat):
                 raise TypeError("window.scan: the step must return (carry, y) with the carry structure of init")
             return [c[0] + 1.0] + list(nf)
-        res = _Lax.while_loop(cond, body, [const(float(start))] + list(flat), max_iter=stop - start + 1)
+        res = _Lax.while_loop(cond, body, [const(float(start))] + list(flat), max_iter=stop - start + 1, counted=(start, stop))
         return rebuild(list(res[1:]))
 
 

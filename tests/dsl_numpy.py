@@ -136,7 +136,7 @@ def _eval(exprs, leaves, n):
             r = ev(e.args[0])[e.value]
         elif e.op == "while":
             # dsl.lax.while_loop, lane by lane: a lane keeps iterating while ITS condition holds
-            names, cond, body, max_iter = e.value
+            names, cond, body, max_iter = e.value[:4]
             vals = [np.array(np.broadcast_to(ev(x), (n,)), dtype=np.float64) for x in e.args]
             active = np.ones(n, dtype=bool)
             for _ in range(max_iter):
