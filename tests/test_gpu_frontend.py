@@ -704,7 +704,7 @@ def test_effector_reading_a_component_only_some_bodies_carry():
 
 
 @pytest.mark.parametrize("integrator", [el.Integrator.Rk4, el.Integrator.SemiImplicit])
-def test_imu_model_after_six_dof_reads_world_accel(integrator):
+def test_imu_model_reads_world_accel_after_and_in_front_of_six_dof(integrator):
     """An accelerometer / gyro model piped AFTER six_dof (the reference's sensor systems read el.WorldAccel the integrator
     just wrote): specific force in the body frame = q^-1 (a - g).  Checked against the same formula on the world_accel and
     world_pos rows the executor reports for that tick; piping it BEFORE six_dof is refused."""
@@ -746,8 +746,16 @@ def test_imu_model_after_six_dof_reads_world_accel(integrator):
         assert np.allclose(df["probe.accel_meas"][k], rot_inv(q, df["probe.world_accel"][k][3:] - G), rtol=1e-11, atol=1e-12), k
         assert np.allclose(df["probe.gyro_meas"][k], rot_inv(q, df["probe.world_vel"][k][:3]), rtol=1e-11, atol=1e-13), k
     assert np.allclose(np.linalg.norm(df["probe.accel_meas"][-1]), 15.0, rtol=1e-9)      # thrust / mass, whatever the attitude
-    with pytest.raises(TypeError, match="AFTER six_dof"):
-        world().build(imu | el.six_dof(sys=gravity | thrust))
+    # piped IN FRONT of six_dof the same system measures the state the tick starts from and the world_accel column as the
+    # previous tick left it (the reference's column semantics; examples/rocket/main.py:452-462 relies on it)
+    exec = world().build(imu | el.six_dof(sys=gravity | thrust, integrator=integrator))
+    exec.run(25)
+    df = exec.history(["probe.accel_meas", "probe.gyro_meas", "probe.world_accel", "probe.world_pos", "probe.world_vel"])
+    for k in range(1, 26):
+        q = df["probe.world_pos"][k - 1][:4]
+        q = q / np.linalg.norm(q)
+        assert np.allclose(df["probe.accel_meas"][k], rot_inv(q, df["probe.world_accel"][k - 1][3:] - G), rtol=1e-11, atol=1e-12), k
+        assert np.allclose(df["probe.gyro_meas"][k], rot_inv(q, df["probe.world_vel"][k - 1][:3]), rtol=1e-11, atol=1e-13), k
 
 
 def test_history_rows_follow_the_telemetry_rate():
