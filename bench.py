@@ -164,10 +164,11 @@ def nbody_leg(device):
             "frac_of_measured_issue_bound": round(evals / (ms * 1e-3) / (1024 * 64 / 48.1e-9), 4)}
 
 
-def sparse_edges_leg(device):
+def sparse_edges_leg(device, hubs: int = 0):
     """A sparse GraphQuery.edge_fold: 65,536 bodies on a ring lattice, 16 out-edges each (1,048,576
     directed edges in spawn order), Newton gravity, RK4 — the CSR edge kernel (one lane per source, sequential fold over
-    its out-edges, 80-byte gathers of the packed targets)."""
+    its out-edges, 80-byte gathers of the packed targets).  `hubs` > 0 adds that many sources with an edge to EVERY other
+    body (65,535 out-edges each): folded by whole waves in 256-edge chunks (pair_kernel.hpp 2c)."""
     import elodin_amd as ea
     from elodin_amd import _lib as L
     n, deg = 65536, 16
@@ -180,15 +181,20 @@ def sparse_edges_leg(device):
     offs = np.array([k for k in range(-deg // 2, deg // 2 + 1) if k != 0][:deg])
     frm = np.repeat(ids, deg)
     to = ((np.repeat(np.arange(n), deg) + np.tile(offs, n)) % n + 1).astype(np.uint64)
+    for hub in range(hubs):
+        row = (hub * 7919 + 13) % n
+        frm = np.concatenate([frm, np.full(n - 1, row + 1, dtype=np.uint64)])
+        to = np.concatenate([to, np.delete(ids, row)])
     ex = ea.HipExec(pos, vel, inertia, entity_ids=ids, simulation_time_step=0.01, device=device, edges=(frm, to),
                     effectors=[ea.Effector(L.EFF_EDGE_GRAVITY_NEWTON, (6.6743e-11,))])
     ex.invoke_batch(5)
     t = ex.invoke_batch(50)
     ex.close()
     ms = t.kernel_device_ms / 50
-    return {"bodies": n, "edges": int(n * deg), "ms_per_tick": round(ms, 4), "edge_evals_per_s": round(3.0 * n * deg / ms * 1e3, 1),
-            "body_steps_per_s": round(n / ms * 1e3, 1), "launches_per_tick": 3,
-            "gather_GBps": round(n * deg * 80 / (ms * 1e-3) / 1e9, 1)}
+    ne = int(len(frm))
+    return {"bodies": n, "edges": ne, "hubs": hubs, "ms_per_tick": round(ms, 4), "edge_evals_per_s": round(3.0 * ne / ms * 1e3, 1),
+            "body_steps_per_s": round(n / ms * 1e3, 1), "launches_per_tick": int(t.launches // 50),
+            "gather_GBps": round(ne * 80 / (ms * 1e-3) / 1e9, 1)}
 
 
 def apollo_leg(device):
@@ -565,6 +571,7 @@ def main():
         extra("f32", f32_leg, local_rank)
         extra("nbody", nbody_leg, local_rank)
         extra("sparse_edges", sparse_edges_leg, local_rank)
+        extra("sparse_edges_hubs", sparse_edges_leg, local_rank, 8)
         extra("telemetry_commit", telemetry_leg, local_rank, n)
         extra("history_stream", history_stream_leg, local_rank, n)
         extra("apollo_mc", apollo_leg, local_rank)

@@ -587,11 +587,31 @@ _PAIR_LEAVES = {**{f"acc{k}": f"acc[{k}]" for k in range(6)},
                 "bx": "pb[0]", "by": "pb[1]", "bz": "pb[2]", "mb": "mb"}
 
 
+def _fold_is_additive(tf: "dsl.TracedFold") -> bool:
+    """True when every output k of the traced fold is `acc_k`, `acc_k + g`, `g + acc_k` or `acc_k - g` with g free of the
+    accumulator — or the constant 0 (el.Force(linear=...) zeroes the torque on every edge)."""
+    acc = {f"acc{k}" for k in range(6)}
+
+    def free(e):
+        return not (dsl._leaves_of([e]) & acc)
+    for k, e in enumerate(tf.outputs):
+        own = lambda x: x.op == "leaf" and x.name == f"acc{k}"
+        if (e.op == "const" and e.value == 0.0) or own(e):     # a constant other than 0 would be counted once per partial
+            continue
+        if e.op == "add" and ((own(e.args[0]) and free(e.args[1])) or (own(e.args[1]) and free(e.args[0]))):
+            continue
+        if e.op == "sub" and own(e.args[0]) and free(e.args[1]):
+            continue
+        return False
+    return True
+
+
 def generate_pair_source(tf: "dsl.TracedFold") -> str:
     """A user-written edge_fold function as the PAIR functor of csrc/pair_kernel.hpp (f64, both integrators)."""
     _TABLES.clear()
     body = "\n".join(emit_block([(f"acc[{k}]", e) for k, e in enumerate(tf.outputs)], _PAIR_LEAVES))
     tables = _emit_tables()
+    additive = _fold_is_additive(tf)
     return f'''// generated by elodin_amd/codegen.py — do not edit.  edge_fold function: {tf.fold.__name__}
 #include "pair_kernel.hpp"
 
@@ -601,6 +621,9 @@ namespace sixdof {{
 {tables}
 
 struct PairCustom {{
+    // every component is acc_k +/- g_k(a, b) or the constant 0: partial folds over disjoint edge subsets may be summed, so hub
+    // sources are folded by whole waves (pair_kernel.hpp 2c); anything else keeps the sequential fold per source
+    static constexpr bool kAdditive = {"true" if additive else "false"};
     __device__ static __forceinline__ void fold(double (&acc)[6], const double* pa, double ma, const double* pb,
                                                 double mb, double, double) {{
         using T = double;

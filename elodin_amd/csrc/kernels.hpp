@@ -89,6 +89,14 @@ struct PairParams {
     const uint32_t* row_start;  // [n+1]
     const uint32_t* dst;        // [n_edges]
     uint32_t n_edges;
+    // hub sources (out-degree >= kHubDegree), folded by whole waves instead of one lane each (pair_kernel.hpp 2c):
+    // their edge ranges cut into chunks of <= kHubChunk edges
+    uint32_t n_hubs, n_hub_chunks;
+    const uint32_t* hub_rows;          // [n_hubs] source rows
+    const uint32_t* hub_chunk_start;   // [n_hubs+1] first chunk of each hub
+    const uint32_t* chunk_e0;          // [n_hub_chunks] first edge of each chunk (it ends kHubChunk later or with its source)
+    const uint32_t* chunk_row;         // [n_hub_chunks] the chunk's source row
+    double* chunk_partial;             // [n_hub_chunks, kPartialWidth] scratch
     int32_t pair_kind;    // sixdof_effector_kind 6,7,8
     double p0, p1;        // G | K, eps
     uint32_t n_ops;       // per-entity ops applied BEFORE the pair op (pipe order); they survive only on
@@ -99,6 +107,8 @@ uint32_t pair_splits_for(uint32_t n);
 hipError_t launch_pair_tick(const PairParams& p, int integrator, hipStream_t stream, uint64_t* launches);
 // n <= kPairSmallMax: pack, fold and integrate n_ticks ticks in one single-workgroup launch (bit-identical results).
 constexpr uint32_t kPairSmallMax = 256;
+constexpr uint32_t kHubDegree = 32;    // a source with this many out-edges or more is a hub
+constexpr uint32_t kHubChunk = 256;    // edges one wave folds (4 per lane: a short dependent-gather chain)
 hipError_t launch_pair_small(const PairParams& p, int integrator, uint32_t n_ticks, hipStream_t stream,
                              uint64_t* launches);
 // Entry points of a generated pair-fold translation unit (codegen.py: generate_pair_source).

@@ -39,7 +39,10 @@ constexpr uint32_t kSmallEdgeCache = 2048;  // edges of a small graph (n <= 256)
 
 // ---- PAIR functors: one directed edge a -> b folded into a's Force accumulator [tau(3), f(3)] ----------------
 // fold(acc, pa, ma, pb, mb, p0, p1): pa / pb = the two bodies' positions at ONE stage, ma / mb their masses.
+// kAdditive: fold(acc, ...) = acc + g(a, b) component by component (or the constant 0), so partial
+// accumulators over disjoint edge subsets may be summed — what lets a hub's out-edges be folded by many lanes (2c).
 struct PairNewton {   // examples/three-body/main.py:61-70: r = a - b; f = G*M*m*r / |r|^3; Force(linear = acc.f - f)
+    static constexpr bool kAdditive = true;
     __device__ static __forceinline__ void fold(double (&acc)[6], const double* pa, double ma, const double* pb,
                                                 double mb, double p0, double) {
         const double rx = pa[0] - pb[0], ry = pa[1] - pb[1], rz = pa[2] - pb[2];
@@ -53,6 +56,7 @@ struct PairNewton {   // examples/three-body/main.py:61-70: r = a - b; f = G*M*m
     }
 };
 struct PairSoftened {   // examples/n-body/sim.py:356-361: acc + SpatialForce(linear = K ma mb inv^3 r), r = b - a
+    static constexpr bool kAdditive = true;
     __device__ static __forceinline__ void fold(double (&acc)[6], const double* pa, double ma, const double* pb,
                                                 double mb, double p0, double p1) {
         const double rx = pb[0] - pa[0], ry = pb[1] - pa[1], rz = pb[2] - pa[2];
@@ -181,18 +185,77 @@ __device__ __forceinline__ void edge_accumulate(const double* pack, const uint32
     }
 }
 
+// `skip_hubs`: sources with kHubDegree or more out-edges are left to the hub kernels (2c), which write the same rows.
 template <int NS, class PAIR>
 __global__ __launch_bounds__(256) void edge_kernel(const double* __restrict__ pack, double* __restrict__ partial,
                                                    const uint32_t* __restrict__ row_start,
-                                                   const uint32_t* __restrict__ dst, uint32_t n, double p0, double p1) {
+                                                   const uint32_t* __restrict__ dst, uint32_t n, double p0, double p1,
+                                                   uint32_t skip_hubs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (skip_hubs && row_start[i + 1] - row_start[i] >= kHubDegree) return;
     double acc[3][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
     edge_accumulate<NS, PAIR>(pack, row_start, dst, i, p0, p1, acc);
     double* o = partial + (size_t)i * kPartialWidth;
 #pragma unroll
     for (int st = 0; st < NS; st++)
         for (int c = 0; c < 6; c++) o[6 * st + c] = acc[st][c];
+}
+
+// ---- 2c. hub sources ----------------------------------------------------------------------------------------
+// One lane per source serialises on a source's out-degree: a hub with 10^5 out-edges would hold its wave for 10^5
+// dependent gathers while every other lane idles.  The reference buckets sources by out-degree for the same reason
+// (graph.rs:290-328).  Here, for additive folds, a hub's edge range is cut into chunks of kHubChunk edges and ONE WAVE folds
+// a chunk: lane l takes edges l, l+64, ... (each lane its own accumulator, in edge order), the 64 accumulators are summed
+// by a fixed shuffle tree, and a second small kernel (one wave per hub) adds the hub's chunk sums the same way.  Same sum, different
+// association than the sequential fold (~1e-16 * sqrt(degree) relative), identical from run to run.
+template <int NS, class PAIR>
+__global__ __launch_bounds__(64) void edge_hub_chunk_kernel(const double* __restrict__ pack, const uint32_t* __restrict__ row_start,
+                                                            const uint32_t* __restrict__ dst, const uint32_t* __restrict__ chunk_e0,
+                                                            const uint32_t* __restrict__ chunk_row, double* __restrict__ chunk_partial,
+                                                            double p0, double p1) {
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    const uint32_t i = chunk_row[c];
+    const uint32_t e0 = chunk_e0[c], e1 = min(e0 + kHubChunk, row_start[i + 1]);
+    const double* a = pack + (size_t)i * kPackWidth;
+    const double ma = a[9];
+    double acc[3][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
+    for (uint32_t e = e0 + lane; e < e1; e += 64) {
+        const double* b = pack + (size_t)dst[e] * kPackWidth;
+        const double mb = b[9];
+#pragma unroll
+        for (int st = 0; st < NS; st++) PAIR::fold(acc[st], a + 3 * st, ma, b + 3 * st, mb, p0, p1);
+    }
+#pragma unroll
+    for (int st = 0; st < NS; st++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            double v = acc[st][k];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) chunk_partial[(size_t)c * kPartialWidth + 6 * st + k] = v;
+        }
+}
+
+// One wave per hub: lane l adds chunk sums l, l+64, ... in chunk order, then the same shuffle tree.
+template <int NS>
+__global__ __launch_bounds__(64) void edge_hub_reduce_kernel(const uint32_t* __restrict__ hub_rows, const uint32_t* __restrict__ hub_chunk_start,
+                                                             const double* __restrict__ chunk_partial, double* __restrict__ partial) {
+    const uint32_t hb = blockIdx.x, lane = threadIdx.x;
+    double acc[NS * 6];
+#pragma unroll
+    for (int k = 0; k < NS * 6; k++) acc[k] = 0.0;
+    for (uint32_t c = hub_chunk_start[hb] + lane; c < hub_chunk_start[hb + 1]; c += 64)
+#pragma unroll
+        for (int k = 0; k < NS * 6; k++) acc[k] += chunk_partial[(size_t)c * kPartialWidth + k];
+    double* o = partial + (size_t)hub_rows[hb] * kPartialWidth;
+#pragma unroll
+    for (int k = 0; k < NS * 6; k++) {
+        double v = acc[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) o[k] = v;
+    }
 }
 
 // ---- 3. integrate ---------------------------------------------------------------------------------------
@@ -460,8 +523,19 @@ inline hipError_t launch_pair_tick_t(const PairParams& p, int integrator, hipStr
         if (rk4) hipLaunchKernelGGL(allpairs_kernel<3>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1);
         else hipLaunchKernelGGL(allpairs_kernel<1>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1);
     } else {
-        if (rk4) hipLaunchKernelGGL((edge_kernel<3, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1);
-        else hipLaunchKernelGGL((edge_kernel<1, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1);
+        const uint32_t hubs = PAIR::kAdditive ? p.n_hubs : 0u;   // a fold that is not a plain sum stays sequential per source
+        if (rk4) hipLaunchKernelGGL((edge_kernel<3, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1, hubs);
+        else hipLaunchKernelGGL((edge_kernel<1, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1, hubs);
+        if (hubs) {
+            if (rk4) {
+                hipLaunchKernelGGL((edge_hub_chunk_kernel<3, PAIR>), dim3(p.n_hub_chunks), dim3(64), 0, stream, p.pack, p.row_start, p.dst, p.chunk_e0, p.chunk_row, p.chunk_partial, p.p0, p.p1);
+                hipLaunchKernelGGL(edge_hub_reduce_kernel<3>, dim3(hubs), dim3(64), 0, stream, p.hub_rows, p.hub_chunk_start, p.chunk_partial, p.partial);
+            } else {
+                hipLaunchKernelGGL((edge_hub_chunk_kernel<1, PAIR>), dim3(p.n_hub_chunks), dim3(64), 0, stream, p.pack, p.row_start, p.dst, p.chunk_e0, p.chunk_row, p.chunk_partial, p.p0, p.p1);
+                hipLaunchKernelGGL(edge_hub_reduce_kernel<1>, dim3(hubs), dim3(64), 0, stream, p.hub_rows, p.hub_chunk_start, p.chunk_partial, p.partial);
+            }
+            if (launches) *launches += 2;
+        }
     }
     if (rk4) hipLaunchKernelGGL(pair_integrate_kernel<kRk4>, dim3(blocks), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(pair_integrate_kernel<kSemiImplicit>, dim3(blocks), dim3(256), 0, stream, p);

@@ -85,6 +85,10 @@ struct sixdof_handle {
     std::vector<uint32_t> csr_start, csr_dst;       // by source, spawn order kept inside a source
     uint32_t* d_csr_start = nullptr;
     uint32_t* d_csr_dst = nullptr;
+    // hub sources of the edge list (out-degree >= kHubDegree): one device block [hub_rows | hub_chunk_start | chunk_e0 | chunk_row]
+    uint32_t* d_hub = nullptr;
+    double* d_chunk_partial = nullptr;
+    uint32_t n_hubs = 0, n_hub_chunks = 0;
     // pair-path scratch
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -301,6 +305,8 @@ void sixdof_destroy(sixdof_handle* h) {
     if (h->ev_copied) hipEventDestroy(h->ev_copied);
     if (h->d_csr_start) hipFree(h->d_csr_start);
     if (h->d_csr_dst) hipFree(h->d_csr_dst);
+    if (h->d_hub) hipFree(h->d_hub);
+    if (h->d_chunk_partial) hipFree(h->d_chunk_partial);
     if (h->d_scratch) hipFree(h->d_scratch);
     if (h->d_tick_refs) hipFree(h->d_tick_refs);
     for (void* p : h->d_hist) if (p) hipFree(p);
@@ -466,10 +472,38 @@ int sixdof_set_edges(sixdof_handle* h, const uint64_t* from_ids, const uint64_t*
         HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_csr_dst), n_edges * sizeof(uint32_t)));
         HIP_TRY(h, hipMemcpy(h->d_csr_dst, cdst.data(), n_edges * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    // hub sources: the fold kernels give them whole waves (pair_kernel.hpp 2c)
+    if (h->d_hub) hipFree(h->d_hub), h->d_hub = nullptr;
+    if (h->d_chunk_partial) hipFree(h->d_chunk_partial), h->d_chunk_partial = nullptr;
+    std::vector<uint32_t> hub_rows, hub_chunk_start{0}, chunk_e0, chunk_row;
+    const char* no_hubs = std::getenv("SIXDOF_NO_HUBS");   // A/B knob: "1" folds every source with one lane
+    for (uint32_t i = 0; i < n && !(no_hubs && no_hubs[0] == '1'); i++) {
+        const uint32_t deg = start[i + 1] - start[i];
+        if (deg < kHubDegree) continue;
+        hub_rows.push_back(i);
+        for (uint32_t e = start[i]; e < start[i + 1]; e += kHubChunk) {
+            chunk_e0.push_back(e);
+            chunk_row.push_back(i);
+        }
+        hub_chunk_start.push_back(static_cast<uint32_t>(chunk_e0.size()));
+    }
+    h->n_hubs = static_cast<uint32_t>(hub_rows.size());
+    h->n_hub_chunks = static_cast<uint32_t>(chunk_e0.size());
+    if (h->n_hubs) {
+        std::vector<uint32_t> blob;
+        blob.insert(blob.end(), hub_rows.begin(), hub_rows.end());
+        blob.insert(blob.end(), hub_chunk_start.begin(), hub_chunk_start.end());
+        blob.insert(blob.end(), chunk_e0.begin(), chunk_e0.end());
+        blob.insert(blob.end(), chunk_row.begin(), chunk_row.end());
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_hub), blob.size() * sizeof(uint32_t)));
+        HIP_TRY(h, hipMemcpy(h->d_hub, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->d_chunk_partial), static_cast<size_t>(h->n_hub_chunks) * kPartialWidth * sizeof(double)));
+    }
     h->edge_src.swap(src);
     h->edge_dst.swap(dst);
     h->csr_start.swap(start);
     h->csr_dst.swap(cdst);
+    h->drop_graph();
     return SIXDOF_OK;
 }
 
@@ -816,6 +850,15 @@ int fill_pair_params(sixdof_handle* h, PairParams* P) {
         P->row_start = h->d_csr_start;
         P->dst = h->d_csr_dst;
         P->n_edges = static_cast<uint32_t>(h->edge_src.size());
+        P->n_hubs = h->n_hubs;
+        P->n_hub_chunks = h->n_hub_chunks;
+        if (h->n_hubs) {
+            P->hub_rows = h->d_hub;
+            P->hub_chunk_start = h->d_hub + h->n_hubs;
+            P->chunk_e0 = h->d_hub + h->n_hubs + (h->n_hubs + 1);
+            P->chunk_row = P->chunk_e0 + h->n_hub_chunks;
+            P->chunk_partial = h->d_chunk_partial;
+        }
     }
     uint32_t vi = 0;
     return build_dev_ops(h, P->ops, &P->n_ops, &vi);

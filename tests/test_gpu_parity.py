@@ -292,6 +292,35 @@ def test_edge_list_equals_allpairs():
     assert max(parity.state_errors(b, ref).values()) < parity.F64_RTOL
 
 
+@pytest.mark.parametrize("kind,integrator", [("newton", L.RK4), ("softened", L.RK4), ("softened", L.SEMI_IMPLICIT)])
+def test_hub_sources_are_folded_by_whole_waves_and_match_the_sequential_fold(kind, integrator):
+    """A graph with hubs (the reference buckets sources by out-degree, graph.rs:290-328): two sources with thousands of
+    out-edges (a dozen or more 256-edge chunks each), a band of sources around the 32-edge hub threshold, leaves with none.  Hubs
+    are folded by whole waves + a fixed-order reduction (pair_kernel.hpp 2c); the oracle folds every source sequentially."""
+    n = 5000
+    rng = np.random.default_rng(5)
+    pos, vel, inertia = _plummer(n, seed=9)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    frm, to = [], []
+    for src, deg in [(7, n - 1), (4321, 3000)] + [(int(s), int(d)) for s, d in zip(rng.choice(np.arange(100, 4000), 300, replace=False), rng.integers(1, 70, 300))]:
+        targets = rng.permutation(np.delete(np.arange(n), src))[:deg]
+        frm += [src + 1] * deg
+        to += list(targets + 1)
+    order = rng.permutation(len(frm))                      # spawn order interleaves the sources; CSR keeps it per source
+    frm, to = np.array(frm, dtype=np.uint64)[order], np.array(to, dtype=np.uint64)[order]
+    if kind == "newton":
+        op, hk, ok = (K_SQ,), L.EFF_EDGE_GRAVITY_NEWTON, orc.EFF_EDGE_GRAVITY_NEWTON
+    else:
+        op, hk, ok = (K_SQ, EPS_AU2), L.EFF_EDGE_GRAVITY_SOFTENED, orc.EFF_EDGE_GRAVITY_SOFTENED
+    hip = ea.HipExec(pos, vel, inertia, simulation_time_step=3600.0, integrator=integrator, effectors=[ea.Effector(hk, op)], edges=(frm, to))
+    ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=3600.0, integrator=integrator, ops=[(ok, op, None)],
+                          edges=orc.resolve_edges(ids, frm, to))
+    hip.run(5); ref.step(5)
+    errs = parity.state_errors(hip, ref)
+    assert max(errs.values()) < parity.F64_RTOL, errs
+    assert hip.last_timings().launches == 5 * 5            # pack, lane fold, hub chunks, hub reduce, integrate
+
+
 def test_edge_fold_replaces_force_only_on_source_rows():
     """Rows without out-edges keep the per-entity effectors' Force (graph.rs:239-361)."""
     n = 6
