@@ -359,8 +359,8 @@ class World:
                 program_stages = (system.items[:six[0]], system.items[six[0] + 1:])
                 system = system.items[six[0]]
             for it in program_stages[0] + program_stages[1]:
-                if not isinstance(it, _dsl.System):
-                    raise TypeError("systems piped around six_dof must be elodin_amd.dsl systems")
+                if not isinstance(it, (_dsl.System, _dsl.GraphFold)):
+                    raise TypeError("systems piped around six_dof must be elodin_amd.dsl systems (or stand-alone edge folds)")
         if program_stages is None and isinstance(system.effectors, _dsl.Pipe) and "world_pos" in self._components:
             # generated effectors reading a component that only some Bodies carry: the program path knows presence masks
             body_ids = self.column("world_pos")[1]
@@ -373,7 +373,10 @@ class World:
             # a world of plain components (no Body anywhere): the row set is every entity carrying a component the systems
             # touch; the executor still wants Body columns, so identity ones stand in (never read by the systems)
             widths0 = {name: int(self.column(name)[0].shape[1]) for name in self._components}
-            used = [n for n, _ in _dsl.Program(program_stages[0], _dsl.Pipe([]), program_stages[1]).trace(widths0).columns]
+            plain = [[it for it in part if not isinstance(it, _dsl.GraphFold)] for part in program_stages]
+            used = [n for n, _ in _dsl.Program(plain[0], _dsl.Pipe([]), plain[1]).trace(widths0).columns]
+            used += [n for it in program_stages[0] + program_stages[1] if isinstance(it, _dsl.GraphFold)
+                     for n in it.left + it.right + (it.out,) if n in self._components]
             univ = np.unique(np.concatenate([self.column(n)[1] for n in used] or [np.zeros(0, np.uint64)])).astype(np.uint64)
             nb = len(univ)
             synthesized_body = {"world_pos": np.tile([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], (nb, 1)), "world_vel": np.zeros((nb, 6)),
@@ -401,8 +404,19 @@ class World:
             for v in column_ids.values():
                 if not np.array_equal(v, row_ids):
                     row_ids = np.intersect1d(row_ids, v)
-            probe = _dsl.Program(program_stages[0], eff_pipe, program_stages[1]).trace(widths)
-            partial = [n for n, _ in probe.columns if not np.all(np.isin(row_ids, self.column(n)[1]))]
+            # stand-alone folds inside the pipe (graph.rs:239-361): their edges as row pairs of the row set, spawn order; an
+            # edge whose endpoint is no row cannot join the fold's queries
+            folds = [it for it in program_stages[0] + program_stages[1] if isinstance(it, _dsl.GraphFold)]
+            fold_rows = None
+            if folds:
+                where_row = {int(e): k for k, e in enumerate(row_ids)}
+                fold_rows = {}
+                for it in folds:
+                    frm, to = self.edge_pairs(it.edge_component)
+                    keep = [k for k in range(len(frm)) if int(frm[k]) in where_row and int(to[k]) in where_row]
+                    fold_rows[it.edge_component] = ([where_row[int(frm[k])] for k in keep], [where_row[int(to[k])] for k in keep])
+            probe = _dsl.Program(program_stages[0], eff_pipe, program_stages[1]).trace(widths, fold_edges=fold_rows)
+            partial = [n for n, _ in probe.columns if "#fold" not in n and not np.all(np.isin(row_ids, self.column(n)[1]))]
             written = {probe.table.cols[int(t[1:].split("_")[0])][0] for s_ in probe.pre + probe.post for t in s_.written if t[0] == "c"}
             # a component living on exactly ONE entity and only read is a singleton query (`el.Query[el.Seed]`, `s[0]`,
             # system.rs:12-23 entity axis elided): every row sees that one value
@@ -417,6 +431,8 @@ class World:
             if not getattr(system, "no_six_dof", False):
                 body_names = set(_dsl._BODY_NAMES)
                 for s_, t_ in zip(program_stages[0] + program_stages[1], probe.pre + probe.post):
+                    if isinstance(s_, _dsl.GraphFold):
+                        continue
                     touched = set(s_.params) | {probe.table.cols[int(t[1:].split("_")[0])][0] for t in t_.written if t[0] == "c"}
                     touched = {n for n in touched if not n.startswith("has:")}
                     if touched & body_names or not touched:
@@ -433,8 +449,8 @@ class World:
                         side_entities.update(int(e) for e in stray)
             effs = _dsl.Program(program_stages[0], eff_pipe, program_stages[1])
             extra_columns = {}
-            for name, w_ in effs.trace(widths, partial).columns:
-                if name.startswith("has:"):
+            for name, w_ in effs.trace(widths, partial, fold_edges=fold_rows).columns:
+                if name.startswith("has:") or "#fold" in name:       # presence columns / fold scratch rows: made below / by HipExec
                     continue
                 arr, aids = self.column(name)
                 if name in singletons:

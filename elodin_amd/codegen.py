@@ -14,7 +14,7 @@ import hashlib
 import os
 import subprocess
 from pathlib import Path
-from typing import Dict, List, Sequence
+from typing import Optional, Dict, List, Sequence
 
 from . import dsl
 
@@ -450,32 +450,28 @@ def _uses_op(tp, op: str) -> bool:
     return any(walk(r) for r in roots)
 
 
-def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) -> str:
-    """tp: dsl.TracedPipe (effectors only) or dsl.TracedProgram (pre | six_dof(effectors) | post).
-    fast_math: f32 only — hardware transcendentals / reciprocal division in the generated user code (see _PRELUDE)."""
-    if fast_math and dtype != "float32":
-        raise ValueError("fast_math applies to float32 programs only")
-    _TABLES.clear()
-    T = {"float64": "double", "float32": "float"}[dtype]
-    integ = {0: "kRk4", 1: "kSemiImplicit", 2: "kNone"}[integrator]
-    is_prog = isinstance(tp, dsl.TracedProgram)
-    if integrator == 2 and not is_prog:
-        raise ValueError("integrator NONE needs a program of systems (there is no six_dof stage for effectors to feed)")
-    pipe_tp = tp.pipe if is_prog else tp
-    body = "\n".join(emit_apply(pipe_tp))
-    n_aux = 0 if is_prog else len(tp.columns)
+def _slots_of(systems, extra_exprs=()) -> set:
+    """Program column slots the given traced systems (and expressions) read or write."""
+    names = set()
+    for s_ in systems:
+        names |= dsl._leaves_of([e for _, e in s_.assign])
+        names |= set(s_.written)
+    names |= dsl._leaves_of(list(extra_exprs))
+    return {int(n[1:].split("_")[0]) for n in names if n[0] == "c" and "_" in n and n[1:].split("_")[0].isdigit()}
+
+
+def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pre_reads_accel: bool, n_aux: int) -> str:
+    """One PIPE struct of csrc/step_kernel.hpp: effector stage from `pipe_tp` (None: no effectors), `pre` / `post` hooks from
+    traced systems.  `used`: the program column slots this struct keeps in registers (None: all of tp.columns)."""
+    body = "\n".join(emit_apply(pipe_tp)) if pipe_tp is not None else ""
     model = ""
-    n_model = 0
-    _WINDOWS.clear()
+    is_prog = tp is not None and isinstance(tp, dsl.TracedProgram)
     win_setup = ""
-    col_widths = "{0u}"
     if is_prog:
         cols = tp.columns
-        n_model = len(cols)
-        names_ = [c for c, _ in cols]
-        for wname, (wslot, wrows, wwidth) in tp.windows.items():
-            _WINDOWS[wslot] = (wrows, wwidth, names_.index(wname + "#head"))
-        reg_cols = [(k, w) for k, (_, w) in enumerate(cols) if k not in _WINDOWS]     # windows stay in HBM
+        reg_cols = [(k, w) for k, (_, w) in enumerate(cols) if k not in _WINDOWS and (used is None or k in used)]     # windows stay in HBM
+        written = sorted(_slots_of(pre + post) & {int(t[1:].split("_")[0]) for s_ in pre + post for t in s_.written if t[0] == "c"}) \
+            if used is not None else list(tp.written_slots)
         regs = "\n".join(f"        T c{k}[{w}];" for k, w in reg_cols)
         loads = "\n".join(
             f"            {{ const T* g = static_cast<const T*>(P.model_cols[{k}]) + (size_t)row * {w}; "
@@ -483,11 +479,10 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) ->
         zero = " ".join(f"for (int j = 0; j < {w}; j++) r.c{k}[j] = T(0);" for k, w in reg_cols)
         stores = "\n".join(
             f"        {{ T* g = static_cast<T*>(P.model_cols[{k}]) + (size_t)row * {cols[k][1]}; "
-            + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(cols[k][1])) + " }" for k in tp.written_slots)
+            + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(cols[k][1])) + " }" for k in written)
         records = "\n".join(
             f"        if (P.model_hist[{k}]) {{ T* g = static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row) * {w}; "
             + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(w)) + " }" for k, w in reg_cols)
-        col_widths = "{" + ", ".join(f"{w}u" + (" | 0x80000000u" if k in _WINDOWS else "") for k, (_, w) in enumerate(cols)) + "}"
         if _WINDOWS:
             # one lane = one entity, a workgroup is one wave (step_kernel.hpp): this lane's row of every window column.
             # Lanes past the last row read the last row and store nothing.
@@ -495,10 +490,11 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) ->
                          "        const bool w_act = w_row < P.n;\n"
                          + "".join(f"        T* const W{k} = static_cast<T*>(P.model_cols[{k}]) + (size_t)(w_act ? w_row : P.n - 1) * {rows * width};\n"
                                    for k, (rows, width, _) in _WINDOWS.items()))
+        writes_inertia = any(s_.writes_inertia for s_ in pre + post)
         model = f'''
     static constexpr bool kHasModel = true;
-    static constexpr bool kWritesInertia = {"true" if tp.writes_inertia else "false"};
-    static constexpr bool kPreReadsAccel = {"true" if tp.pre_reads_accel else "false"};
+    static constexpr bool kWritesInertia = {"true" if writes_inertia else "false"};
+    static constexpr bool kPreReadsAccel = {"true" if pre_reads_accel else "false"};
     template <class T>
     struct Regs {{
 {regs}
@@ -522,42 +518,189 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) ->
     __device__ static __forceinline__ void pre(const StepParams& P, uint64_t tick, Regs<T>& r, Quat<T>& q, Vec3<T>& p,
                                                Spatial<T>& v, Vec3<T>& I, T& mass, const Spatial<T>& accel) {{
         (void)P; (void)tick; (void)accel;
-{win_setup}{_emit_systems(tp.pre)}
+{win_setup}{_emit_systems(pre)}
     }}
     template <class T>
     __device__ static __forceinline__ void post(const StepParams& P, uint64_t tick, Regs<T>& r, Quat<T>& q, Vec3<T>& p,
                                                 Spatial<T>& v, Vec3<T>& I, T& mass, const Spatial<T>& accel) {{
         (void)P; (void)tick; (void)accel;
-{win_setup}{_emit_systems(tp.post)}
+{win_setup}{_emit_systems(post)}
     }}'''
+    wt = pipe_tp.world_torque if pipe_tp is not None else False
+    bt = pipe_tp.body_torque if pipe_tp is not None else False
+    rv = pipe_tp.reads_velocity if pipe_tp is not None else False
+    return f'''struct {name} : NoModel {{
+    static constexpr int kOps = {n_aux};
+    static constexpr bool kStatic = true;
+    static constexpr bool kWorldTorque = {"true" if wt else "false"};
+    static constexpr bool kBodyTorque = {"true" if bt else "false"};
+    template <int K>
+    static constexpr bool uses_aux() {{ return K < kOps; }}
+    __device__ static __forceinline__ bool vel_independent(const StepParams&) {{ return {"false" if rv else "true"}; }}
+{model}
+    template <class T, class R>
+    __device__ static __forceinline__ void apply(const StepParams& P, const Vec3<T> (&aux)[kMaxOps], const R& r,
+                                                 const Body<T>& b, Wrench<T>& F) {{
+        (void)P; (void)r; (void)aux; (void)b; (void)F;
+{body}
+    }}
+}};
+'''
+
+
+def _emit_fold_stage(fs: "dsl.TracedFoldStage") -> str:
+    """A stand-alone fold inside a program (dsl.TracedFoldStage): one lane per SOURCE folds its out-edges in spawn order into
+    the scratch column, a second kernel commits scratch -> out on source rows (every fold reads the values from before it
+    ran).  Components come from the program's columns (P.model_cols) or the Body columns; the CSR is baked in."""
+    j = fs.index
+    f = fs.traced.fold
+    w = fs.out[2]
+    body_ptr = {"world_pos": "P.pos", "world_vel": "P.vel", "inertia": "P.inertia"}
+    ptr = lambda name, slot: f"static_cast<const T*>({body_ptr[name]})" if slot is None else f"static_cast<const T*>(P.model_cols[{slot}])"
+    leaves = {f"acc_{k}": f"acc[{k}]" for k in range(w)}
+    loads_a, loads_b = [], []
+    for i, (n, slot, wn) in enumerate(fs.left):
+        for k in range(wn):
+            leaves[f"a{i}_{k}"] = f"a{i}[{k}]"
+        loads_a.append(f"    const T* a{i} = {ptr(n, slot)} + (size_t)row * {wn};")
+    for i, (n, slot, wn) in enumerate(fs.right):
+        for k in range(wn):
+            leaves[f"b{i}_{k}"] = f"b{i}[{k}]"
+        loads_b.append(f"        const T* b{i} = {ptr(n, slot)} + (size_t)fold{j}_dst[e] * {wn};")
+    body = "\n".join(emit_block([(f"acc[{k}]", e) for k, e in enumerate(fs.traced.outputs)], leaves, indent="        "))
+    init = ", ".join(f"T({v!r})" for v in f.init)
+    nl = "\n"
+    n_src = len(fs.src_rows)
+    arr = lambda xs: ", ".join(str(int(x)) for x in xs) if xs else "0"
+    return f'''// ---- fold stage {j}: {fs.name} ({len(fs.dst)} edges, {n_src} sources) ----
+__device__ const uint32_t fold{j}_src[{max(n_src, 1)}] = {{{arr(fs.src_rows)}}};
+__device__ const uint32_t fold{j}_start[{n_src + 1}] = {{{arr(fs.row_start)}}};
+__device__ const uint32_t fold{j}_dst[{max(len(fs.dst), 1)}] = {{{arr(fs.dst)}}};
+template <class T>
+__global__ __launch_bounds__(64) void fold{j}_kernel(const StepParams P) {{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= {n_src}u) return;
+    const uint32_t row = fold{j}_src[i];
+    if (row >= P.n) return;
+{nl.join(loads_a)}
+    T acc[{w}] = {{{init}}};
+    for (uint32_t e = fold{j}_start[i]; e < fold{j}_start[i + 1]; e++) {{
+{nl.join(loads_b)}
+{body}
+    }}
+    T* sc = static_cast<T*>(P.model_cols[{fs.scratch_slot}]) + (size_t)row * {w};
+    for (int k = 0; k < {w}; k++) sc[k] = acc[k];
+}}
+template <class T>
+__global__ __launch_bounds__(64) void fold{j}_commit(const StepParams P) {{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= {n_src}u) return;
+    const uint32_t row = fold{j}_src[i];
+    if (row >= P.n) return;
+    const T* sc = static_cast<const T*>(P.model_cols[{fs.scratch_slot}]) + (size_t)row * {w};
+    T* o = static_cast<T*>(P.model_cols[{fs.out[1]}]) + (size_t)row * {w};
+    for (int k = 0; k < {w}; k++) o[k] = sc[k];
+}}
+'''
+
+
+def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) -> str:
+    """tp: dsl.TracedPipe (effectors only) or dsl.TracedProgram (pre | six_dof(effectors) | post).
+    fast_math: f32 only — hardware transcendentals / reciprocal division in the generated user code (see _PRELUDE)."""
+    if fast_math and dtype != "float32":
+        raise ValueError("fast_math applies to float32 programs only")
+    _TABLES.clear()
+    T = {"float64": "double", "float32": "float"}[dtype]
+    integ = {0: "kRk4", 1: "kSemiImplicit", 2: "kNone"}[integrator]
+    is_prog = isinstance(tp, dsl.TracedProgram)
+    if integrator == 2 and not is_prog:
+        raise ValueError("integrator NONE needs a program of systems (there is no six_dof stage for effectors to feed)")
+    pipe_tp = tp.pipe if is_prog else tp
+    n_aux = 0 if is_prog else len(tp.columns)
+    n_model = len(tp.columns) if is_prog else 0
+    _WINDOWS.clear()
+    col_widths = "{0u}"
+    if is_prog:
+        names_ = [c for c, _ in tp.columns]
+        for wname, (wslot, wrows, wwidth) in tp.windows.items():
+            _WINDOWS[wslot] = (wrows, wwidth, names_.index(wname + "#head"))
+        col_widths = "{" + ", ".join(f"{w}u" + (" | 0x80000000u" if k in _WINDOWS else "") for k, (_, w) in enumerate(tp.columns)) + "}"
     names = ", ".join(e.__name__ for e in pipe_tp.effectors)
-    tables = _emit_tables()
     fast = "#define SIXDOF_FAST_MATH 1\n" if fast_math else ""
+    launch_k = lambda pipe, ig, params: (
+        f"    if (({params}.streaming & 255u) == kPolNt) hipLaunchKernelGGL((sixdof_step_kernel<{T}, {ig}, {pipe}, kPolNt>), grid, dim3(kWave), 0, s, {params});\n"
+        f"    else if (({params}.streaming & 255u) == kPolNtStores || ({params}.streaming & 255u) == kPolSc1Stores) hipLaunchKernelGGL((sixdof_step_kernel<{T}, {ig}, {pipe}, kPolNtStores>), grid, dim3(kWave), 0, s, {params});\n"
+        f"    else hipLaunchKernelGGL((sixdof_step_kernel<{T}, {ig}, {pipe}, kPolPlain>), grid, dim3(kWave), 0, s, {params});\n")
+    staged = is_prog and bool(tp.fold_stages)
+    if not staged:
+        structs = _emit_pipe_struct("PipeCustom", tp if is_prog else None, pipe_tp, tp.pre if is_prog else [], tp.post if is_prog else [],
+                                    None, tp.pre_reads_accel if is_prog else False, n_aux)
+        launch = launch_k("PipeCustom", integ, "(*p)")
+        stage_comment = ""
+    else:
+        # the tick as a chain of launches: systems | fold | systems | ... | (systems | six_dof | systems) | fold | ...
+        chain, cur, seen_six = [], [], False
+        for s_ in tp.pre:
+            if isinstance(s_, dsl.TracedFoldStage):
+                if cur:
+                    chain.append(("seg", cur, [], False))
+                chain.append(("fold", s_))
+                cur = []
+            else:
+                cur.append(s_)
+        post_head, k = [], 0
+        while k < len(tp.post) and not isinstance(tp.post[k], dsl.TracedFoldStage):
+            post_head.append(tp.post[k])
+            k += 1
+        chain.append(("seg", cur, post_head, True))
+        cur = []
+        for s_ in tp.post[k:]:
+            if isinstance(s_, dsl.TracedFoldStage):
+                if cur:
+                    chain.append(("seg", cur, [], False))
+                chain.append(("fold", s_))
+                cur = []
+            else:
+                cur.append(s_)
+        if cur:
+            chain.append(("seg", cur, [], False))
+        parts, calls = [], []
+        last_seg = max(i for i, c in enumerate(chain) if c[0] == "seg")
+        for i, c in enumerate(chain):
+            if c[0] == "fold":
+                fs = c[1]
+                parts.append(_emit_fold_stage(fs))
+                nb = (len(fs.src_rows) + 63) // 64
+                if nb:
+                    calls.append(f"        hipLaunchKernelGGL(fold{fs.index}_kernel<{T}>, dim3({nb}), dim3(64), 0, s, q);\n"
+                                 f"        hipLaunchKernelGGL(fold{fs.index}_commit<{T}>, dim3({nb}), dim3(64), 0, s, q);")
+                continue
+            _, pre, post, six = c
+            used = _slots_of(pre + post, pipe_tp.outputs if six else ())
+            if i == last_seg:       # the link that records the tick into the history ring holds every column
+                used = set(range(len(tp.columns)))
+            reads_accel = any(s_.reads_accel for s_ in pre)
+            parts.append(_emit_pipe_struct(f"PipeSeg{i}", tp, pipe_tp if six else None, pre, post, used, reads_accel, 0))
+            ig = integ if six else "kNone"
+            tweak = "" if i == last_seg else " qs.hist_ring = 0;"          # only the last link records the tick
+            tweak += "" if six else " qs.accel_in_check = 0;"
+            calls.append(f"        {{ StepParams qs = q;{tweak}\n" + launch_k(f"PipeSeg{i}", ig, "qs").replace("    if", "          if", 1).replace("\n    else", "\n          else") + "        }")
+        structs = "\n".join(parts)
+        stage_comment = "// tick = " + " | ".join(("fold:" + c[1].name) if c[0] == "fold" else ("[" + " | ".join([s_.name for s_ in c[1]] + (["six_dof"] if c[3] and integrator != 2 else []) + [s_.name for s_ in c[2]]) + "]") for c in chain) + "\n"
+        launch = ("    for (uint32_t t = 0; t < p->n_ticks; t++) {   // a fold needs every row of the link in front of it: one chain per tick\n"
+                  "        StepParams q = *p;\n        q.n_ticks = 1;\n        q.tick0 = p->tick0 + t;\n        q.hist_slot0 = p->hist_slot0 + t;\n"
+                  "        if (t) q.accel_in_check = 0;\n"
+                  + "\n".join(calls) + "\n    }\n")
+    tables = _emit_tables()
     return f'''// generated by elodin_amd/codegen.py — do not edit.  Effectors: {names}
-{fast}#include "step_kernel.hpp"
+{stage_comment}{fast}#include "step_kernel.hpp"
 
 namespace sixdof {{
 
 {_PRELUDE}
 {tables}
 
-struct PipeCustom : NoModel {{
-    static constexpr int kOps = {n_aux};
-    static constexpr bool kStatic = true;
-    static constexpr bool kWorldTorque = {"true" if pipe_tp.world_torque else "false"};
-    static constexpr bool kBodyTorque = {"true" if pipe_tp.body_torque else "false"};
-    template <int K>
-    static constexpr bool uses_aux() {{ return K < kOps; }}
-    __device__ static __forceinline__ bool vel_independent(const StepParams&) {{ return {"false" if pipe_tp.reads_velocity else "true"}; }}
-{model}
-    template <class T, class R>
-    __device__ static __forceinline__ void apply(const StepParams& P, const Vec3<T> (&aux)[kMaxOps], const R& r,
-                                                 const Body<T>& b, Wrench<T>& F) {{
-        (void)P; (void)r; (void)aux;
-{body}
-    }}
-}};
-
+{structs}
 }}  // namespace sixdof
 
 extern "C" unsigned sixdof_custom_abi() {{ return static_cast<unsigned>(sizeof(sixdof::StepParams)); }}
@@ -574,10 +717,7 @@ extern "C" int sixdof_custom_launch(const sixdof::StepParams* p, int integrator,
     if (p->n == 0) return static_cast<int>(hipSuccess);
     const dim3 grid((p->n + kWave - 1) / kWave);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if ((p->streaming & 255u) == kPolNt) hipLaunchKernelGGL((sixdof_step_kernel<{T}, {integ}, PipeCustom, kPolNt>), grid, dim3(kWave), 0, s, *p);
-    else if ((p->streaming & 255u) == kPolNtStores || (p->streaming & 255u) == kPolSc1Stores) hipLaunchKernelGGL((sixdof_step_kernel<{T}, {integ}, PipeCustom, kPolNtStores>), grid, dim3(kWave), 0, s, *p);
-    else hipLaunchKernelGGL((sixdof_step_kernel<{T}, {integ}, PipeCustom, kPolPlain>), grid, dim3(kWave), 0, s, *p);
-    return static_cast<int>(hipGetLastError());
+{launch}    return static_cast<int>(hipGetLastError());
 }}
 '''
 

@@ -1214,28 +1214,104 @@ class TracedSystem:
 
 
 class Program:
-    """`pre systems | six_dof(effectors) | post systems` — one whole tick, like the reference's compiled pipe."""
+    """`pre systems | six_dof(effectors) | post systems` — one whole tick, like the reference's compiled pipe.
 
-    def __init__(self, pre: Sequence[System], effectors: Pipe, post: Sequence[System]):
+    `pre` / `post` may also hold stand-alone folds (`dsl.GraphFold`, the reference's `graph.edge_fold` over arbitrary
+    components, graph.rs:239-361): a fold reads OTHER entities' rows, so every lane must have finished the systems in front
+    of it — the tick then runs as a chain of launches (systems | fold | systems | ... | six_dof | ...), all generated into one
+    translation unit and driven by one launch call, the columns staying in HBM between the links (codegen.py).  The edges of
+    each fold's edge component are given as ROW pairs of the executor's row set when tracing (`fold_edges`, spawn order;
+    HipExec resolves them from entity ids) and are baked into the generated code, like the reference bakes its gather
+    indices into the compiled tick."""
+
+    def __init__(self, pre: Sequence, effectors: Pipe, post: Sequence):
         self.pre, self.effectors, self.post = list(pre), effectors, list(post)
         self._traced = None
 
-    def trace(self, widths: Optional[Dict[str, int]] = None, partial: Sequence[str] = ()) -> "TracedProgram":
+    @property
+    def folds(self) -> List["GraphFold"]:
+        return [s for s in self.pre + self.post if isinstance(s, GraphFold)]
+
+    def trace(self, widths: Optional[Dict[str, int]] = None, partial: Sequence[str] = (), fold_edges=None) -> "TracedProgram":
         if self._traced is None:
-            self._traced = TracedProgram(self, widths, partial)
+            self._traced = TracedProgram(self, widths, partial, fold_edges)
         return self._traced
 
 
+class TracedFoldStage:
+    """A stand-alone fold as one link of a program's launch chain: the traced fold function, where its components live
+    (program column slots, or the Body columns) and its edges as CSR over the executor's rows."""
+
+    BODY_WIDTH = {"world_pos": 7, "world_vel": 6, "inertia": 7}
+
+    def __init__(self, fold: GraphFold, table: ColumnTable, index: int, edges, partial: Sequence[str] = ()):
+        self.name, self.index = fold.__name__, index
+        names = list(dict.fromkeys(fold.left + fold.right + (fold.out,)))
+        if fold.out in self.BODY_WIDTH:
+            raise TypeError(f"fold {self.name}: a stand-alone fold writes a plain component (use an edge_fold effector for Force)")
+        if any(n in partial for n in names):
+            raise TypeError(f"fold {self.name}: its components must live on every row of the executor")
+        widths = {}
+        for n in names:
+            widths[n] = self.BODY_WIDTH[n] if n in self.BODY_WIDTH else len(table.symbols(n, None, 1))
+        self.traced = TracedGraphFold(fold, widths)
+        self.widths = widths
+        slot_of = lambda n: None if n in self.BODY_WIDTH else [c for c, _ in table.cols].index(n)
+        self.left = [(n, slot_of(n), widths[n]) for n in fold.left]
+        self.right = [(n, slot_of(n), widths[n]) for n in fold.right]
+        self.out = (fold.out, slot_of(fold.out), widths[fold.out])
+        # every fold reads the values from BEFORE it ran: results go to a scratch column first, then are committed
+        self.scratch_name = f"{fold.out}#fold{index}"
+        table.symbols(self.scratch_name, widths[fold.out], widths[fold.out])
+        self.scratch_slot = slot_of(self.scratch_name)
+        if edges is None:
+            raise ValueError(f"fold {self.name}: no edges given for edge component {fold.edge_component!r} (fold_edges)")
+        src = [int(x) for x in edges[0]]
+        dst = [int(x) for x in edges[1]]
+        if len(src) != len(dst):
+            raise ValueError("fold edges: from / to lengths differ")
+        if len(src) > 65536:
+            raise ValueError(f"fold {self.name}: {len(src)} edges — folds inside a program bake their edges into the generated "
+                             "code (<= 65,536); run a larger graph as a stand-alone fold (World.build(fold))")
+        order = sorted(range(len(src)), key=lambda k: src[k])       # stable: spawn order inside a source (graph.rs:113-175)
+        self.src_rows = sorted(set(src))
+        self.row_start, self.dst = [0], []
+        for r in self.src_rows:
+            self.dst += [dst[k] for k in order if src[k] == r]
+            self.row_start.append(len(self.dst))
+        self.written = [f"c{self.out[1]}_{k}" for k in range(self.out[2])] + [f"c{self.scratch_slot}_{k}" for k in range(self.out[2])]
+        self.every, self.phase, self.also_at, self.reads_accel, self.writes_inertia = 1, 0, None, False, False
+
+
 class TracedProgram:
-    def __init__(self, prog: Program, widths: Optional[Dict[str, int]] = None, partial: Sequence[str] = ()):
+    def __init__(self, prog: Program, widths: Optional[Dict[str, int]] = None, partial: Sequence[str] = (), fold_edges=None):
         self.table = ColumnTable("c", 48, 16, widths)
         self.partial = tuple(partial)
-        self.pre = [TracedSystem(s, self.table, self.partial) for s in prog.pre]
+        fold_edges = fold_edges or {}
+        n_folds = [0]
+
+        def trace_item(s, after):
+            if isinstance(s, GraphFold):
+                n_folds[0] += 1
+                return TracedFoldStage(s, self.table, n_folds[0] - 1, fold_edges.get(s.edge_component), self.partial)
+            return TracedSystem(s, self.table, self.partial, after_six_dof=after)
+        self.pre = [trace_item(s, False) for s in prog.pre]
         self.pipe = TracedPipe(prog.effectors.effectors, table=self.table, partial=self.partial)
-        self.post = [TracedSystem(s, self.table, self.partial, after_six_dof=True) for s in prog.post]
+        self.post = [trace_item(s, True) for s in prog.post]
+        self.fold_stages = [s for s in self.pre + self.post if isinstance(s, TracedFoldStage)]
         self.writes_inertia = any(s.writes_inertia for s in self.pre + self.post)
-        self.pre_reads_accel = any(s.reads_accel for s in self.pre)
+        # world_accel read in front of six_dof = the previous tick's; a system BEHIND a post fold runs in a launch of its own
+        # and finds this tick's there, loaded the same way
+        seen_fold = False
+        behind = []
+        for s in self.post:
+            seen_fold = seen_fold or isinstance(s, TracedFoldStage)
+            if seen_fold and not isinstance(s, TracedFoldStage):
+                behind.append(s)
+        self.pre_reads_accel = any(s.reads_accel for s in self.pre) or any(s.reads_accel for s in behind)
         self.windows = {name: tuple(v[:3]) for name, v in self.table.windows.items()}     # name -> (slot, rows, width)
+        if self.fold_stages and self.windows:
+            raise TypeError("a program with stand-alone folds cannot also hold window components")
         written = set()
         for s in self.pre + self.post:
             written.update(t for t in s.written if t[0] == "c")

@@ -51,7 +51,7 @@ class HipExec:
                  simulation_time_step: float = 1.0 / 120.0, time_step: Optional[float] = None,
                  integrator: int = L.RK4, dtype=np.float64, effectors: Sequence[Effector] = (),
                  edges=None, ticks_per_launch: int = 1, use_graph: bool = False, device: int = 0,
-                 tick: int = 0, column_entity_ids=None, columns=None, fast_math: bool = False):
+                 tick: int = 0, column_entity_ids=None, columns=None, fast_math: bool = False, graph_edges=None):
         lib = L.lib()
         self._lib = lib
         self.dtype = np.dtype(dtype)
@@ -102,7 +102,24 @@ class HipExec:
                 # [n, w] columns give their row width; an [n, rows, w] column is a window component (dsl.Window)
                 widths = {k: (tuple(int(x) for x in np.shape(v)[1:]) if np.ndim(v) == 3 else int(np.atleast_2d(np.asarray(v)).shape[-1]))
                           for k, v in (columns or {}).items()}
-                custom = effectors.trace(widths)
+                fold_rows = None
+                if isinstance(effectors, _dsl.Program) and effectors.folds:
+                    # stand-alone folds inside the program: their edges as row pairs of this executor (spawn order)
+                    if self._column_ids:
+                        raise ValueError("a program with stand-alone folds needs every column on the executor's own entity ids")
+                    row_of = {int(e): k for k, e in enumerate(self.entity_ids)}
+                    fold_rows = {}
+                    for name, (frm, to) in (graph_edges or {}).items():
+                        try:
+                            fold_rows[name] = ([row_of[int(a)] for a in frm], [row_of[int(b)] for b in to])
+                        except KeyError as e:
+                            raise KeyError(f"graph_edges[{name!r}]: edge endpoint {e} is not an entity of this executor") from None
+                    custom = effectors.trace(widths, fold_edges=fold_rows)
+                    columns = dict(columns or {})
+                    for fs in custom.fold_stages:       # scratch rows: a fold reads the values from before it ran
+                        columns.setdefault(fs.scratch_name, np.zeros((self.world_pos.shape[0], fs.out[2])))
+                else:
+                    custom = effectors.trace(widths)
                 if isinstance(effectors, _dsl.Program):
                     self._program_columns = [n for n, _ in custom.columns]
                     self._windows = {name: (rows, width) for name, (_, rows, width) in custom.windows.items()}

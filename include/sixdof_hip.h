@@ -291,7 +291,10 @@ int sixdof_bind_world(sixdof_handle* h, sixdof_world* w);
  * is bound like any other, [n, rows*width] in the reference's row layout, but stays in HBM: the kernel uses it as a ring
  * whose head (physical index of the oldest row) lives in a hidden [n,1] column `<name>#head` — un-rotate with it after a
  * download.  The generated object exports the row width it was built for per column; sixdof_step refuses columns bound
- * with another width.  Replaces the built-in op list (sixdof_set_effectors) for the per-entity path. */
+ * with another width.  A program may hold stand-alone folds between its systems (graph.rs:239-361): the generated launch
+ * entry then issues a chain of kernels per tick (systems | fold | systems | six_dof | ...) over the same columns; the fold's
+ * scratch rows are one more program column `<out>#fold<k>`.  Replaces the built-in op list (sixdof_set_effectors) for the
+ * per-entity path. */
 int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t* aux_component_ids, size_t n_aux);
 /* Same idea for GraphQuery.edge_fold (graph.rs:177-282) with a user-written fold function over
  * (acc: Force, a: (WorldPos, Inertia), b: (WorldPos, Inertia)): the generated object instantiates the pair kernels

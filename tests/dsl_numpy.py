@@ -163,6 +163,9 @@ def _run_systems(systems, pos, vel, inertia, comps, table, tick, accel=None):
             "I": ("inertia", {"x": 0, "y": 1, "z": 2})}
     arrays = {"pos": pos, "vel": vel, "inertia": inertia}
     for s in systems:
+        if hasattr(s, "row_start"):          # a stand-alone fold inside the program (dsl.TracedFoldStage)
+            _run_fold_stage(s, pos, vel, inertia, comps)
+            continue
         if s.every > 1 and tick % s.every != s.phase and tick != s.also_at:
             continue
         lv = _leaf_arrays(pos, vel, inertia, comps, table, tick, accel)
@@ -184,6 +187,29 @@ def _run_systems(systems, pos, vel, inertia, comps, table, tick, accel=None):
                 arrays[arr][:, idx[target[1]]] = val
 
 
+def _run_fold_stage(fs, pos, vel, inertia, comps):
+    """acc = init; for each out-edge of a source, in spawn order: acc = fn(acc, *left(source), *right(target)); every source's
+    result replaces `out` on its row — all folds reading the values from before the stage ran.  Edge by edge (test sizes)."""
+    body = {"world_pos": pos, "world_vel": vel, "inertia": inertia}
+    col = lambda name: body[name] if name in body else comps[name]
+    snap = {n: col(n).copy() for n, _, _ in fs.left + fs.right}
+    f = fs.traced.fold
+    results = []
+    for i, row in enumerate(fs.src_rows):
+        acc = np.array(f.init, dtype=np.float64)
+        for e in range(fs.row_start[i], fs.row_start[i + 1]):
+            lv = {f"acc_{k}": np.array([acc[k]]) for k in range(len(acc))}
+            for j, (n, _, w) in enumerate(fs.left):
+                lv.update({f"a{j}_{k}": np.array([snap[n][row, k]]) for k in range(w)})
+            for j, (n, _, w) in enumerate(fs.right):
+                lv.update({f"b{j}_{k}": np.array([snap[n][fs.dst[e], k]]) for k in range(w)})
+            acc = np.array([v[0] for v in _eval(fs.traced.outputs, lv, 1)])
+        results.append(acc)
+    for row, acc in zip(fs.src_rows, results):
+        comps[fs.out[0]][row] = acc
+        comps[fs.scratch_name][row] = acc
+
+
 def program_tick(tp, pos, vel, accel, inertia, comps, tick, dt_g, integrator):
     """One tick of a dsl.TracedProgram with numpy (in place on copies); `tick` = count after this tick."""
     from tests import np_sixdof
@@ -196,6 +222,12 @@ def program_tick(tp, pos, vel, accel, inertia, comps, tick, dt_g, integrator):
     pos[:], vel[:], accel[:] = pos2, vel2, acc2
     _run_systems(tp.post, pos, vel, inertia, comps, tp.table, tick, accel)
     return F
+
+
+def program_tick_systems_only(tp, pos, vel, accel, inertia, comps, tick):
+    """A program without six_dof (integrator NONE): the systems and folds of `pre` then `post`, nothing integrated."""
+    _run_systems(tp.pre, pos, vel, inertia, comps, tp.table, tick, accel)
+    _run_systems(tp.post, pos, vel, inertia, comps, tp.table, tick, accel)
 
 
 # ---- tracing plain helper functions (models/falcon9.py physics helpers) ----------------------------------------------------

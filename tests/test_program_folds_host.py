@@ -1,0 +1,67 @@
+"""CPU side of stand-alone folds inside a program: the trace splits the tick into a chain of launches, the generated source
+holds one PIPE struct per link and bakes the CSR, and the numpy walker (the GPU tests' reference) folds in spawn order reading
+the values from before the fold ran."""
+import numpy as np
+import pytest
+
+from elodin_amd import codegen, dsl
+from tests import dsl_numpy
+
+
+@dsl.system
+def double(x):
+    return {"x": x * 2.0}
+
+
+@dsl.graph_fold("e", left=("x",), right=("x",), out="x", init=5.0)
+def fold_test(x, a, b):
+    return x + a + b
+
+
+@dsl.system
+def add_one(x, n):
+    return {"x": x + 1.0, "n": n + 1.0}
+
+
+EDGES = {"e": ([0, 0, 1], [1, 2, 2])}          # rows: e1 -> e2, e1 -> e3, e2 -> e3 (test_all.py:117-142's graph)
+
+
+def test_trace_and_generated_chain():
+    tp = dsl.Program([double, fold_test, add_one], dsl.pipe(), []).trace({"x": 1, "n": 1}, fold_edges=EDGES)
+    fs = tp.fold_stages[0]
+    assert (fs.src_rows, fs.row_start, fs.dst) == ([0, 1], [0, 2, 3], [1, 2, 2])
+    assert [n for n, _ in tp.columns] == ["x", "x#fold0", "n"] and fs.scratch_name == "x#fold0"
+    src = codegen.generate_source(tp, "float64", 2)
+    assert "// tick = [double] | fold:fold_test | [add_one]" in src
+    assert src.count("struct PipeSeg") == 2 and "fold0_kernel<double>" in src and "fold0_commit<double>" in src
+    assert "__device__ const uint32_t fold0_dst[3] = {1, 2, 2};" in src
+    assert "qs.hist_ring = 0;" in src                     # only the last link records the tick
+    plain = codegen.generate_source(dsl.Program([double, add_one], dsl.pipe(), []).trace({"x": 1, "n": 1}), "float64", 2)
+    assert "struct PipeCustom" in plain and "PipeSeg" not in plain and "fold0" not in plain
+
+
+def test_walker_folds_in_spawn_order_on_pre_fold_values():
+    tp = dsl.Program([double, fold_test, add_one], dsl.pipe(), []).trace({"x": 1, "n": 1}, fold_edges=EDGES)
+    pos = np.tile([0.0, 0, 0, 1, 0, 0, 0], (3, 1))
+    vel, inertia, acc = np.zeros((3, 6)), np.ones((3, 7)), np.zeros((3, 6))
+    comps = {"x": np.array([[1.0], [2.0], [2.0]]), "n": np.zeros((3, 1)), "x#fold0": np.zeros((3, 1))}
+    x = np.array([1.0, 2.0, 2.0])
+    for tick in range(1, 4):
+        dsl_numpy.program_tick_systems_only(tp, pos, vel, acc, inertia, comps, tick)
+        x = x * 2.0
+        x = np.array([5.0 + (x[0] + x[1]) + (x[0] + x[2]), 5.0 + (x[1] + x[2]), x[2]]) + 1.0
+        assert np.array_equal(comps["x"][:, 0], x)
+
+
+def test_fold_stage_guards():
+    with pytest.raises(ValueError, match="no edges given"):
+        dsl.Program([fold_test], dsl.pipe(), []).trace({"x": 1})
+    big = {"e": (list(range(70000)), list(range(70000)))}
+    with pytest.raises(ValueError, match="bake their edges"):
+        dsl.Program([fold_test], dsl.pipe(), []).trace({"x": 1}, fold_edges=big)
+
+    @dsl.graph_fold("e", left=("x",), right=("x",), out="world_pos", init=[0.0] * 7)
+    def bad(acc, a, b):
+        return acc
+    with pytest.raises(TypeError, match="plain component"):
+        dsl.Program([bad], dsl.pipe(), []).trace({"x": 1}, fold_edges=EDGES)
