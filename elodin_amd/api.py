@@ -408,15 +408,44 @@ class World:
             # edge whose endpoint is no row cannot join the fold's queries
             folds = [it for it in program_stages[0] + program_stages[1] if isinstance(it, _dsl.GraphFold)]
             fold_rows = None
+            body_rows = None       # rows of the executor that are real Bodies, when it also holds stand-in rows
             if folds:
-                where_row = {int(e): k for k, e in enumerate(row_ids)}
-                fold_rows = {}
+                # an edge joins a fold when its source carries the left query + the output and its target the right query
+                # (query.rs:136-208); the Body columns count as components of the Body entities
+                body_set = set(int(e) for e in row_ids)
+                def carries(e, names):
+                    return all((int(e) in body_set) if n in ("world_pos", "world_vel", "inertia")
+                               else (n in self._components and int(e) in set(int(x) for x in self.column(n)[1])) for n in names)
+                fold_pairs = {}
                 for it in folds:
                     frm, to = self.edge_pairs(it.edge_component)
-                    keep = [k for k in range(len(frm)) if int(frm[k]) in where_row and int(to[k]) in where_row]
-                    fold_rows[it.edge_component] = ([where_row[int(frm[k])] for k in keep], [where_row[int(to[k])] for k in keep])
+                    keep = [k for k in range(len(frm)) if carries(frm[k], it.left + (it.out,)) and carries(to[k], it.right)]
+                    fold_pairs[it.edge_component] = ([int(frm[k]) for k in keep], [int(to[k]) for k in keep])
+                extra = sorted({e for f_, t_ in fold_pairs.values() for e in f_ + t_} - body_set)
+                if extra and synthesized_body is None:
+                    # folds between Bodies and plain entities (cube-sat's sensors -> satellite): the plain entities become
+                    # rows of the executor too, with stand-in Body values nothing reads (systems that touch the Body are
+                    # masked to the real ones through `has:world_pos`); six_dof integrates the stand-ins at rest
+                    ext_ids = np.union1d(row_ids, np.array(extra, dtype=np.uint64)).astype(np.uint64)
+                    at_real = np.searchsorted(ext_ids, row_ids)
+                    stand_in = {"world_pos": [0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], "world_vel": [0.0] * 6, "inertia": [1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 1.0],
+                                "world_accel": [0.0] * 6, "force": [0.0] * 6}
+                    def extend(arr, own_ids, fill):
+                        out = np.tile(np.array(fill, dtype=np.float64), (len(ext_ids), 1))
+                        sel = np.isin(own_ids, row_ids)
+                        out[np.searchsorted(ext_ids, own_ids[sel])] = arr[sel]
+                        return out
+                    pos = extend(pos, ids, stand_in["world_pos"])
+                    body = {k: (extend(v[0], v[1], stand_in[k]), ext_ids) for k, v in body.items()}
+                    ids = ext_ids
+                    column_ids = {"world_pos": ids, **{k: ids for k in body}}
+                    body_rows, row_ids = at_real, ext_ids
+                where_row = {int(e): k for k, e in enumerate(row_ids)}
+                fold_rows = {name: ([where_row[a] for a in f_], [where_row[b] for b in t_]) for name, (f_, t_) in fold_pairs.items()}
             probe = _dsl.Program(program_stages[0], eff_pipe, program_stages[1]).trace(widths, fold_edges=fold_rows)
             partial = [n for n, _ in probe.columns if "#fold" not in n and not np.all(np.isin(row_ids, self.column(n)[1]))]
+            if body_rows is not None:
+                partial.append("world_pos")
             written = {probe.table.cols[int(t[1:].split("_")[0])][0] for s_ in probe.pre + probe.post for t in s_.written if t[0] == "c"}
             # a component living on exactly ONE entity and only read is a singleton query (`el.Query[el.Seed]`, `s[0]`,
             # system.rs:12-23 entity axis elided): every row sees that one value
@@ -450,6 +479,12 @@ class World:
             effs = _dsl.Program(program_stages[0], eff_pipe, program_stages[1])
             extra_columns = {}
             for name, w_ in effs.trace(widths, partial, fold_edges=fold_rows).columns:
+                if name == "has:world_pos":                      # which rows are real Bodies (the others are stand-ins)
+                    mask = np.zeros((len(row_ids), 1))
+                    mask[body_rows] = 1.0
+                    extra_columns[name] = mask
+                    column_ids[name] = row_ids
+                    continue
                 if name.startswith("has:") or "#fold" in name:       # presence columns / fold scratch rows: made below / by HipExec
                     continue
                 arr, aids = self.column(name)
@@ -501,6 +536,7 @@ class World:
                       column_entity_ids=None if same else column_ids, columns=extra_columns)
         ex = Exec(hip, self, ticks_per_telemetry, dt)
         ex._partial = self_partial
+        ex._body_rows = body_rows if program_stages is not None else None
         if program_stages is not None and side_systems:
             sub = World()
             while sub.entity_len <= max(side_entities):      # same entity ids as in this world
@@ -634,7 +670,8 @@ class Exec:
         cols = {"world_pos": self._hip.world_pos, "world_vel": self._hip.world_vel, "world_accel": self._hip.world_accel,
                 "force": self._hip.force, "inertia": self._hip.inertia}
         if name in cols:
-            return cols[name]
+            rows = getattr(self, "_body_rows", None)       # the executor also holds stand-in rows for plain entities
+            return cols[name] if rows is None else cols[name][rows]
         if name in getattr(self, "_partial", {}):     # component on fewer entities than the row set: its own rows, own order
             at, sel, n_own, original = self._partial[name]
             out = np.array(original, dtype=np.float64)

@@ -1204,6 +1204,11 @@ class TracedSystem:
         # Components living on fewer entities than the executor's row set arrive densified with a presence column
         # `has:<name>`; the system's writes are predicated on all of them.
         need = [n for n in list(sys_.params) + list(out.keys()) if n in partial]
+        # the Body columns themselves may be partial: an executor whose rows also hold non-Body entities (folds between
+        # Bodies and plain entities) carries stand-in Body values on those rows, and a system that touches the Body runs on
+        # Bodies only
+        if "world_pos" in partial and any(n in _BODY_NAMES - {"tick", "force"} for n in list(sys_.params) + list(out.keys())):
+            need.append("world_pos")
         if need:
             mask = None
             for n in dict.fromkeys(need):
@@ -1249,8 +1254,8 @@ class TracedFoldStage:
         names = list(dict.fromkeys(fold.left + fold.right + (fold.out,)))
         if fold.out in self.BODY_WIDTH:
             raise TypeError(f"fold {self.name}: a stand-alone fold writes a plain component (use an edge_fold effector for Force)")
-        if any(n in partial for n in names):
-            raise TypeError(f"fold {self.name}: its components must live on every row of the executor")
+        # components living on fewer entities than the row set arrive densified; the caller keeps only the edges whose
+        # endpoints carry what the fold's queries name (the reference's query join, query.rs:136-208)
         widths = {}
         for n in names:
             widths[n] = self.BODY_WIDTH[n] if n in self.BODY_WIDTH else len(table.symbols(n, None, 1))

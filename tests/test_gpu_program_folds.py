@@ -186,3 +186,47 @@ def test_fold_in_front_of_six_dof_through_world_build():
     got = exec.column_array("world_pos")
     assert np.allclose(got[:, 4:], p, rtol=1e-9, atol=1e-12)
     assert np.allclose(exec.column_array("pull"), pull, rtol=1e-9, atol=1e-12)
+
+
+def _sensor_world(sensors_are_bodies: bool):
+    import elodin_amd as el
+    rng = np.random.default_rng(3)
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=float)
+    w = el.World()
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    sat = w.spawn([el.Body(world_pos=el.SpatialTransform(angular=el.Quaternion(q), linear=np.array([1.0, 2.0, 3.0])),
+                           world_vel=el.SpatialMotion(angular=np.array([0.02, -0.01, 0.03])), inertia=el.SpatialInertia(4.0, np.array([0.4, 0.5, 0.6]))),
+                   el.C("sun", np.zeros(3)), el.C("estimate", np.zeros(3)), el.C("torque_cmd", np.zeros(3)), el.C("log", [0.0])], "sat")
+    sensors = []
+    for k in rng.permutation(6):
+        comps = [el.C("sun", np.zeros(3)), el.C("normal", axes[k]), el.C("reading", [0.0]), el.C("echo", [0.0]), el.C("seen", [0.0])]
+        if sensors_are_bodies:
+            comps = [el.Body(world_pos=el.SpatialTransform(linear=np.array([100.0 + k, 0.0, 0.0])))] + comps
+        sensors.append(w.spawn(comps, f"css_{k}"))
+    for s_ in sensors:
+        w.spawn(el.Edge(s_, sat, component="sensor_to_sat"))
+    for s_ in sensors:
+        w.spawn(el.Edge(sat, s_, component="sat_to_sensor"))
+    return w
+
+
+def test_folds_between_a_body_and_plain_entities_through_world_build():
+    """cube-sat's shape (examples/cube-sat/main.py:98-146,587-655): the sun sensors are entities WITHOUT a Body, their
+    edges run to the satellite and back.  The executor then also holds the sensors as rows (stand-in Body values, systems that
+    touch the Body masked to the real one) — same satellite trajectory and same sensor components as when the sensors are
+    spawned as Bodies of their own."""
+    import elodin_amd as el
+    pipe = lambda: (sun_direction | sensor_reading | sun_estimate | point_at_sun
+                    | el.six_dof(sys=apply_torque, integrator=el.Integrator.Rk4) | log_alignment | echo_to_sensors | count_seen)
+    a = _sensor_world(False).build(pipe(), simulation_rate=120.0)
+    b = _sensor_world(True).build(pipe(), simulation_rate=120.0)
+    a.run(30)
+    b.run(30)
+    assert a.column_array("world_pos").shape == (1, 7) and b.column_array("world_pos").shape == (7, 7)
+    assert np.allclose(a.column_array("world_pos")[0], b.column_array("world_pos")[0], rtol=1e-12, atol=1e-14)
+    assert np.allclose(a.column_array("world_vel")[0], b.column_array("world_vel")[0], rtol=1e-12, atol=1e-16)
+    for name in ("reading", "echo", "seen", "estimate", "torque_cmd", "log"):
+        assert np.array_equal(a.column_array(name), b.column_array(name)), name
+    assert a.column_array("seen").max() > 0 and np.abs(a.column_array("estimate")).sum() > 0.1
+    assert np.linalg.norm(a.column_array("world_vel")[0][:3] - [0.02, -0.01, 0.03]) > 1e-6     # the control torque acted
