@@ -431,8 +431,18 @@ def _lower_fold(fold: _Fold, name: str):
     init = [float(v) for v in _np.atleast_1d(_np.asarray(fold.init, dtype=_np.float64)).reshape(-1)]
     fn, n_args = fold.fn, 1 + len(fold.left) + len(fold.right)
 
+    def spatial(name, v):      # Body components reach the fold function as the reference's spatial types
+        if name == "world_pos":
+            return _dsl.SpatialTransform(_dsl.Quaternion(_dsl.Vec(v.e[:4])), _dsl.Vec(v.e[4:]))
+        if name == "world_vel":
+            return _dsl.SpatialMotion(_dsl.Vec(v.e[:3]), _dsl.Vec(v.e[3:]))
+        if name == "inertia":
+            return _dsl.SpatialInertia(_dsl.Vec(v.e[:3]), v.e[6])
+        return v
+
     def fixed_arity(*args):
-        return fn(*args)
+        names = (None,) + tuple(fold.left) + tuple(fold.right)
+        return fn(*[spatial(n, a) for n, a in zip(names, args)])
     fixed_arity.__signature__ = inspect.Signature([inspect.Parameter(f"a{k}", inspect.Parameter.POSITIONAL_ONLY) for k in range(n_args)])
     gf = _dsl.GraphFold(fixed_arity, fold.edge_component, fold.left, fold.right, fold.out, init)
     gf.__name__ = name

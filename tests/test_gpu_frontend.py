@@ -815,3 +815,79 @@ def test_graph_reversed_and_total_edges():
     exec = world().build(fold_total)
     exec.run()
     frame_equal(exec.history(["e1.x", "e2.x", "e3.x"]), {"e1.x": [1.0, 6.0], "e2.x": [2.0, 5.0], "e3.x": [4.0, 3.0]})
+
+
+def test_cube_sat_sun_sensor_folds_in_the_reference_spelling():
+    """examples/cube-sat/main.py:112-146,587-655: `sun_pos | sun_sensor | sun_sensor_value` — a map, a fold over CSSEdge
+    (sensor -> satellite, reading the satellite's WorldPos) and a fold over the REVERSED edges (satellite <- sensors), the
+    sensors being entities without a Body — piped in front of six_dof, decorators and queries as the reference spells them
+    (minus the sensor noise; the trailing `.map` of sun_sensor_value is a separate @el.map)."""
+    la = el.np.linalg
+    SunPos = ty.Annotated[el.Array, el.Component("sun_pos", el.ComponentType(el.PrimitiveType.F64, (3,)))]
+    CssReading = ty.Annotated[el.Array, el.Component("css_reading", el.ComponentType(el.PrimitiveType.F64, (3,)))]
+    CssValue = ty.Annotated[el.Array, el.Component("css_value", el.ComponentType(el.PrimitiveType.F64, ()))]
+    CssFov = ty.Annotated[el.Array, el.Component("css_fov", el.ComponentType(el.PrimitiveType.F64, (1,)))]
+    CssNormal = ty.Annotated[el.Array, el.Component("css_normal", el.ComponentType(el.PrimitiveType.F64, (3,)))]
+    CSSEdge = ty.Annotated[el.Edge, el.Component("css_edge")]
+
+    @dataclass
+    class CSSRel(el.Archetype):
+        edge: CSSEdge
+
+    @el.map
+    def sun_pos(pos: el.WorldPos) -> SunPos:
+        pos = pos.linear()
+        return pos / la.norm(pos)
+
+    @el.system
+    def sun_sensor(sensor: el.GraphQuery[CSSEdge], css_normal: el.Query[CssNormal, CssFov],
+                   sun_pos: el.Query[SunPos, el.WorldPos]) -> el.Query[CssValue]:
+        def inner(acc, css_normal, fov, sun_pos, world_pos):
+            sun_pos_b = world_pos.angular().inverse() @ sun_pos
+            cos = el.np.dot(css_normal, sun_pos_b)
+            return acc + el.lax.select(el.np.abs(el.np.arccos(cos)) < fov, cos, 0.0)
+        return sensor.edge_fold(css_normal, sun_pos, CssValue, np.array(0.0), inner)
+
+    @el.system
+    def sun_sensor_value(graph: el.GraphQuery[ty.Annotated[CSSEdge, el.RevEdge]], css: el.Query[CssValue, CssNormal],
+                         sat: el.Query[el.WorldPos]) -> el.Query[CssReading]:
+        return graph.edge_fold(sat, css, CssReading, np.array([0.0, 0.0, 0.0]), lambda acc, _, value, norm: acc + value * norm)
+
+    @el.map
+    def normalise(x: CssReading) -> CssReading:
+        return x / el.np.maximum(la.norm(x), 1e-12)
+
+    rng = np.random.default_rng(12)
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    p0 = np.array([7.0e6, 1.0e6, -2.0e6])
+    w = el.World()
+    sat = w.spawn([el.Body(world_pos=el.SpatialTransform(angular=el.Quaternion(q), linear=p0),
+                           world_vel=el.SpatialMotion(angular=np.array([0.01, 0.02, -0.015]), linear=np.array([0.0, 7.5e3, 0.0]))),
+                   el.C((SunPos, CssReading), (np.zeros(3), np.zeros(3)))], "sat")
+    normals = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=float)
+    css = [w.spawn([el.C((CssValue, CssFov, CssNormal), (np.array(0.0), np.array([np.pi / 4]), normals[k]))], f"css_{k}") for k in range(6)]
+    for c_ in css:
+        w.spawn(CSSRel(el.Edge(c_, sat)))
+    exec = w.build(sun_pos | sun_sensor | sun_sensor_value | normalise | el.six_dof(integrator=el.Integrator.SemiImplicit), simulation_rate=120.0)
+    exec.run(12)
+    df = exec.history(["sat.world_pos", "sat.css_reading", "sat.sun_pos"] + [f"css_{k}.css_value" for k in range(6)])
+
+    def rot_inv(qv, v):
+        u, w_ = -qv[:3], qv[3]
+        t = 2.0 * np.cross(u, v)
+        return v + w_ * t + np.cross(u, t)
+    for k in range(1, 13):
+        pos_before = df["sat.world_pos"][k - 1]               # the systems run in front of six_dof: on the pose the tick starts from
+        qn = pos_before[:4] / np.linalg.norm(pos_before[:4])
+        sun = pos_before[4:] / np.linalg.norm(pos_before[4:])
+        sun_b = rot_inv(qn, sun)
+        cosines = normals @ sun_b
+        values = np.where(np.abs(np.arccos(cosines)) < np.pi / 4, cosines, 0.0)
+        got = np.array([df[f"css_{j}.css_value"][k] for j in range(6)])
+        assert np.allclose(got, values, rtol=1e-10, atol=1e-13), k
+        reading = (values[:, None] * normals).sum(axis=0)
+        reading = reading / max(np.linalg.norm(reading), 1e-12)
+        assert np.allclose(df["sat.css_reading"][k], reading, rtol=1e-10, atol=1e-13), k
+        assert np.allclose(df["sat.sun_pos"][k], sun, rtol=1e-12)
+    assert np.abs(df["sat.css_reading"][-1]).max() > 0.1
