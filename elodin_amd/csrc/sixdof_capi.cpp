@@ -756,18 +756,19 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
     // Cache policy of the launch (step_kernel.hpp: load * 8 + store, bit 8 = one flush after the tick instead of columns
     // stored as they complete), by working-set size, from the A/B matrices in profiles/r02_step_ab_load_x_store_policy.txt
     // and r02_step_ab_policy_by_size.txt (f64 body counts in brackets):
-    //   <=  48 MiB [<= 196,608]   plain loads, nt stores, early     65,536: 5.48 -> 4.93 us   131,072: 7.94 -> 7.14 us
-    //   <= 192 MiB [<= 786,432]   plain loads, sc1 stores, late     262,144: 16.6 -> 15.1 us  524,288: 31.5 -> 29.6 us
-    //   <= 768 MiB [<= 3.1M]      plain loads, nt stores, early     1,048,576: 61.9 -> 60.0   2,097,152: 136 -> 123 us
+    //   <= 768 MiB [<= 3.1M]      plain loads, nt stores, early     65,536: 5.48 -> 4.93 us   262,144: 16.6 -> 16.3 us
+    //                                                               1,048,576: 61.9 -> 60.0   2,097,152: 136 -> 123 us
     //   beyond                    nt loads,    nt stores, early     4,194,304: 300 -> 263 us
     // (inputs are re-read next tick: keep them cacheable while the 256 MiB Infinity Cache can hold them; outputs are
     // written once per tick: never worth a line).  SIXDOF_STREAMING=<code> overrides it for A/B runs (tools/step_ab.py).
     const char* force_nt = std::getenv("SIXDOF_STREAMING");
     const size_t state_bytes = static_cast<size_t>(h->desc.n_entities) * 32 * h->elem_size();
+    // NOT the write-through (`sc1`) store policy, although it measured 7 % faster between 48 and 192 MiB of state: the next
+    // launch can read STALE rows after it (262,144 bodies: ~10 % of the rows differ from the fused run, differently every
+    // run — tools/debug_midsize_determinism.py, profiles/r02_sc1_store_policy_is_unsafe.txt).  It stays reachable through
+    // SIXDOF_STREAMING=2 for that demonstration only.
     uint32_t policy = 9u;
-    if (state_bytes <= (48ull << 20)) policy = 1u;
-    else if (state_bytes <= (192ull << 20)) policy = 2u | 256u;
-    else if (state_bytes <= (768ull << 20)) policy = 1u;
+    if (state_bytes <= (768ull << 20)) policy = 1u;
     P->streaming = force_nt ? static_cast<uint32_t>(std::atoi(force_nt)) : policy;
     P->hist_ring = h->hist_ring;
     if (h->hist_ring) {

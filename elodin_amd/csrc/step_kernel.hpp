@@ -457,7 +457,7 @@ inline void launch_t(const StepParams& p, int integrator, dim3 grid, hipStream_t
     switch (pol) {
     case kPolNt: return launch_i<T, PIPE, kPolNt>(p, integrator, grid, s);
     case kPolNtStores: return launch_i<T, PIPE, kPolNtStores>(p, integrator, grid, s);
-    case kPolSc1Stores: return launch_i<T, PIPE, kPolSc1Stores>(p, integrator, grid, s);
+    case kPolSc1Stores: return launch_i<T, PIPE, kPolSc1Stores>(p, integrator, grid, s);   // UNSAFE across launches (stale reads), A/B and demonstration only: never chosen by the library
     default: break;
     }
     if constexpr (SWEEP) {

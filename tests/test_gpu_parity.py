@@ -70,6 +70,30 @@ def test_fused_ticks_match_single_tick_launches(k):
     assert a.tick == b.tick == 300
 
 
+@pytest.mark.parametrize("n", [131_072, 262_144, 786_432, 3_200_000])
+def test_one_tick_launches_match_fused_launches_in_every_cache_policy_range(n):
+    """The launch's cache policy is picked by state size (sixdof_capi.cpp): a policy that lets the NEXT launch read stale rows
+    shows as one-tick launches (eager and replayed) drifting from a fused run of the same ticks — which is how the
+    write-through `sc1` store policy, briefly shipped for 48-192 MiB of state, was caught (262,144 bodies: 10 % of the rows
+    wrong).  Sizes: one per range of the table + the old sc1 range."""
+    w = workloads.independent_bodies(n)
+    eff = workloads.gravity_torque_effectors(w["body_torque"])
+    ticks = 64 if n < 1_000_000 else 24
+
+    def run(**kw):
+        ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ, effectors=eff, **kw)
+        if kw.get("use_graph"):
+            ex.prepare(ticks)
+        ex.run(ticks)
+        out = [getattr(ex, f).copy() for f in parity.FIELDS]
+        ex.close()
+        return out
+    fused = run(ticks_per_launch=ticks)
+    for kw in (dict(ticks_per_launch=1), dict(ticks_per_launch=1, use_graph=True), dict(ticks_per_launch=8, use_graph=True)):
+        for f, a, b in zip(parity.FIELDS, run(**kw), fused):
+            assert np.array_equal(a, b), (kw, f, int((a != b).any(axis=1).sum()))
+
+
 def test_graph_replay_is_identical():
     a, _, _ = _pair(3000, 100, use_graph=False)
     b, _, _ = _pair(3000, 100, use_graph=True)
