@@ -70,18 +70,21 @@ def test_fused_ticks_match_single_tick_launches(k):
     assert a.tick == b.tick == 300
 
 
-@pytest.mark.parametrize("n", [131_072, 262_144, 786_432, 3_200_000])
-def test_one_tick_launches_match_fused_launches_in_every_cache_policy_range(n):
+@pytest.mark.parametrize("n,dtype,integrator", [(131_072, np.float64, L.RK4), (262_144, np.float64, L.RK4), (786_432, np.float64, L.RK4),
+                                                (3_200_000, np.float64, L.RK4), (262_147, np.float64, L.SEMI_IMPLICIT),
+                                                (524_288, np.float32, L.RK4), (6_400_001, np.float32, L.RK4)])
+def test_one_tick_launches_match_fused_launches_in_every_cache_policy_range(n, dtype, integrator):
     """The launch's cache policy is picked by state size (sixdof_capi.cpp): a policy that lets the NEXT launch read stale rows
     shows as one-tick launches (eager and replayed) drifting from a fused run of the same ticks — which is how the
     write-through `sc1` store policy, briefly shipped for 48-192 MiB of state, was caught (262,144 bodies: 10 % of the rows
-    wrong).  Sizes: one per range of the table + the old sc1 range."""
+    wrong).  Sizes: one per range of the table + the old sc1 range, f64 and f32 (half the bytes per body), a ragged last wave."""
     w = workloads.independent_bodies(n)
     eff = workloads.gravity_torque_effectors(w["body_torque"])
     ticks = 64 if n < 1_000_000 else 24
 
     def run(**kw):
-        ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ, effectors=eff, **kw)
+        ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ, effectors=eff,
+                        dtype=dtype, integrator=integrator, **kw)
         if kw.get("use_graph"):
             ex.prepare(ticks)
         ex.run(ticks)
