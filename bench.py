@@ -484,8 +484,10 @@ def main():
         ex.prepare(args.steps)
     ex.invoke_batch(args.warmup)
     barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     tm = ex.invoke_batch(args.steps)      # enqueues every launch and synchronises the handle's stream
+    torch.cuda.synchronize()              # (the library's stream is already drained; the contract's bracket, literally)
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
