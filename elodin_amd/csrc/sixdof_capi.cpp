@@ -1208,7 +1208,12 @@ int sixdof_download_column(sixdof_handle* h, uint64_t component_id) {
     return SIXDOF_OK;
 }
 
+// Launches per replayed chain.  A long chain amortises the gap between two replays (4,096 launches: 4.96 -> 4.83 us each with
+// 128-launch chains) but starts later (100 launches as one chain: 8 % slower than 32 + 32 + 32 + 4), so a batch OPENS with a
+// 32-launch chain and, when at least four fit, continues with 128-launch ones (profiles/r02_graph_len_ab.txt).  SIXDOF_GRAPH_LONG=<n> overrides the
+// long length for A/B runs (n <= 32: short chains only).
 constexpr uint32_t kGraphLen = 32;
+static const uint32_t kGraphLong = [] { const char* e = std::getenv("SIXDOF_GRAPH_LONG"); const int v = e ? std::atoi(e) : 128; return v > 32 ? static_cast<uint32_t>(v) : 0u; }();
 
 bool graph_eligible(const sixdof_handle* h) {
     return (h->desc.flags & SIXDOF_FLAG_USE_GRAPH) && !(h->desc.flags & SIXDOF_FLAG_TIME_EACH_LAUNCH) && !h->hist_ring &&
@@ -1249,7 +1254,7 @@ int ensure_graph(sixdof_handle* h, const StepParams& P, uint32_t K, uint32_t len
     }
     if (h->graphs.size() >= kGraphCacheMax) {   // many distinct batch lengths: keep the long chain, drop the rest
         for (auto g = h->graphs.begin(); g != h->graphs.end();) {
-            if (g->first == kGraphLen) { ++g; continue; }
+            if (g->first == kGraphLen || g->first == kGraphLong) { ++g; continue; }
             hipGraphExecDestroy(g->second);
             g = h->graphs.erase(g);
         }
@@ -1297,9 +1302,13 @@ int sixdof_prepare_step(sixdof_handle* h, uint64_t n_ticks) {
     if (rc != SIXDOF_OK) return rc;
     const uint32_t K = h->desc.ticks_per_launch;
     P.n_ticks = K;
-    const uint64_t full = n_ticks / K;
+    uint64_t full = n_ticks / K;
     hipGraphExec_t unused = nullptr;
     if (full >= kGraphLen && (rc = ensure_graph(h, P, K, kGraphLen, &unused)) != SIXDOF_OK) return rc;
+    if (kGraphLong && full >= kGraphLen + 4 * kGraphLong) {
+        if ((rc = ensure_graph(h, P, K, kGraphLong, &unused)) != SIXDOF_OK) return rc;
+        full = (full - kGraphLen) % kGraphLong;     // what the opening chain and the long ones leave
+    }
     const uint32_t tail_len = static_cast<uint32_t>(full % kGraphLen);
     if (full >= kGraphMinLen && tail_len >= kGraphMinLen && (rc = ensure_graph(h, P, K, tail_len, &unused)) != SIXDOF_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1422,8 +1431,15 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
             // long batches replay 32-launch chains; what is left (or a short batch as a whole, e.g. 20 ticks) replays as
             // ONE chain of exactly that length, captured on first use and cached — so a short timed region is
             // steady-state device work too, not eager launches racing the host.
-            hipGraphExec_t big = nullptr, tail = nullptr;
-            const uint32_t tail_len = static_cast<uint32_t>(full % kGraphLen);
+            hipGraphExec_t big = nullptr, tail = nullptr, longer = nullptr;
+            uint64_t n_long = 0;
+            if (kGraphLong && full >= kGraphLen + 4 * kGraphLong) {   // open with one short chain, then long ones (long batches only:
+                                                                    // 200 launches as 32 + 128 + 40 measured 5 % slower)
+                int grc = ensure_graph(h, P, K, kGraphLong, &longer);
+                if (grc != SIXDOF_OK) return grc;
+                n_long = (full - kGraphLen) / kGraphLong;
+            }
+            const uint32_t tail_len = static_cast<uint32_t>((full - n_long * kGraphLong) % kGraphLen);
             if (full >= kGraphLen) {
                 int grc = ensure_graph(h, P, K, kGraphLen, &big);
                 if (grc != SIXDOF_OK) return grc;
@@ -1434,6 +1450,16 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
             }
             // a capture may just have happened after ev0 was recorded: re-record so the pair brackets real work only
             HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+            if (n_long) {
+                HIP_TRY(h, hipGraphLaunch(big, h->stream));
+                full -= kGraphLen;
+                launches += kGraphLen;
+                for (uint64_t i = 0; i < n_long; i++) {
+                    HIP_TRY(h, hipGraphLaunch(longer, h->stream));
+                    full -= kGraphLong;
+                    launches += kGraphLong;
+                }
+            }
             while (full >= kGraphLen) {
                 HIP_TRY(h, hipGraphLaunch(big, h->stream));
                 full -= kGraphLen;
