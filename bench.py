@@ -512,7 +512,10 @@ def main():
                    "entities_per_gpu": n, "ticks_per_launch": K, "dt": 0.008333333,
                    "graph_replay": bool(tm.launches and tm.graph_launches == tm.launches),
                    "graph_launches": tm.graph_launches, "launches": tm.launches,
-                   "parallelism": f"entity shards x{world}, no collective"},
+                   "parallelism": f"entity shards x{world}, no collective",
+                   "sync": ("timed region = barrier, device synchronize, t0, K steps, hipStreamSynchronize of the launch stream "
+                            "(inside sixdof_step), t1, device synchronize, barrier" if not distributed else
+                            "timed region = barrier, device synchronize, t0, K steps, stream + device synchronize, barrier, t1; MAX over ranks")},
         "device_ms_per_step": round(tm.kernel_device_ms / args.steps, 6),
     }
 
