@@ -323,6 +323,14 @@ class _Fold:
 
     def __init__(self, edge_component, left, right, out, init, fn):
         self.edge_component, self.left, self.right, self.out, self.init, self.fn = edge_component, left, right, out, init, fn
+        self.then = []          # maps chained on the fold's result: [(out component, fn)]
+        self.out_type = None
+
+    def map(self, out_tp, f) -> "_Fold":
+        """`graph.edge_fold(...).map(T, f)` (examples/cube-sat/main.py:141-146): a per-entity map over the fold's output
+        component, run right behind the fold."""
+        self.then.append((out_tp, f))
+        return self
 
 
 class GraphQuery:
@@ -333,7 +341,9 @@ class GraphQuery:
         self.edge_component = edge_component
 
     def edge_fold(self, left_query: Query, right_query: Query, return_type, init_value, fold_fn) -> _Fold:
-        return _Fold(self.edge_component, left_query.names, right_query.names, Component.name(return_type), init_value, fold_fn)
+        f = _Fold(self.edge_component, left_query.names, right_query.names, Component.name(return_type), init_value, fold_fn)
+        f.out_type = return_type
+        return f
 
 
 # ---- system / map ------------------------------------------------------------------------------------------------------
@@ -446,7 +456,21 @@ def _lower_fold(fold: _Fold, name: str):
     fixed_arity.__signature__ = inspect.Signature([inspect.Parameter(f"a{k}", inspect.Parameter.POSITIONAL_ONLY) for k in range(n_args)])
     gf = _dsl.GraphFold(fixed_arity, fold.edge_component, fold.left, fold.right, fold.out, init)
     gf.__name__ = name
-    return gf
+    if not fold.then:
+        return gf
+    stages = [gf]                                     # fold | map | map ...: a pipe of its own (dsl.Stages)
+    in_tp = fold.out_type
+    def make(out_tp, f):
+        def mapped(q):
+            return q.map(out_tp, f)
+        return mapped
+    for k, (out_tp, f) in enumerate(fold.then):
+        mapped = make(out_tp, f)
+        mapped.__name__ = f"{name}_map{k}"
+        mapped.__annotations__ = {"q": _QueryType((in_tp,))}
+        stages.append(system(mapped))
+        in_tp = out_tp
+    return _dsl.Stages(stages)
 
 
 def _map(func, seq: bool):
