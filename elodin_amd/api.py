@@ -413,9 +413,11 @@ class World:
                 # an edge joins a fold when its source carries the left query + the output and its target the right query
                 # (query.rs:136-208); the Body columns count as components of the Body entities
                 body_set = set(int(e) for e in row_ids)
+                members = {n: set(int(x) for x in self.column(n)[1]) for it in folds for n in it.left + it.right + (it.out,)
+                           if n in self._components}
                 def carries(e, names):
                     return all((int(e) in body_set) if n in ("world_pos", "world_vel", "inertia")
-                               else (n in self._components and int(e) in set(int(x) for x in self.column(n)[1])) for n in names)
+                               else int(e) in members.get(n, ()) for n in names)
                 fold_pairs = {}
                 for it in folds:
                     frm, to = self.edge_pairs(it.edge_component)

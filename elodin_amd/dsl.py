@@ -1278,11 +1278,13 @@ class TracedFoldStage:
         if len(src) > 65536:
             raise ValueError(f"fold {self.name}: {len(src)} edges — folds inside a program bake their edges into the generated "
                              "code (<= 65,536); run a larger graph as a stand-alone fold (World.build(fold))")
-        order = sorted(range(len(src)), key=lambda k: src[k])       # stable: spawn order inside a source (graph.rs:113-175)
-        self.src_rows = sorted(set(src))
+        by_src: Dict[int, List[int]] = {}                            # spawn order kept inside a source (graph.rs:113-175)
+        for a, b in zip(src, dst):
+            by_src.setdefault(a, []).append(b)
+        self.src_rows = sorted(by_src)
         self.row_start, self.dst = [0], []
         for r in self.src_rows:
-            self.dst += [dst[k] for k in order if src[k] == r]
+            self.dst += by_src[r]
             self.row_start.append(len(self.dst))
         self.written = [f"c{self.out[1]}_{k}" for k in range(self.out[2])] + [f"c{self.scratch_slot}_{k}" for k in range(self.out[2])]
         self.every, self.phase, self.also_at, self.reads_accel, self.writes_inertia = 1, 0, None, False, False

@@ -65,3 +65,34 @@ def test_fold_stage_guards():
         return acc
     with pytest.raises(TypeError, match="plain component"):
         dsl.Program([bad], dsl.pipe(), []).trace({"x": 1}, fold_edges=EDGES)
+
+
+def test_additive_folds_are_recognised_for_the_hub_path():
+    """pair_kernel.hpp 2c sums partial folds of a hub's out-edges: only sound when every component of the fold is
+    acc +/- g(a, b) or the constant 0 — decided on the traced DAG (codegen._fold_is_additive)."""
+    np_ = dsl.np
+
+    @dsl.edge_fold
+    def newton(acc, a_pos, a_inertia, b_pos, b_inertia):          # three-body's gravity_fn: Force(linear = acc.f - f), torque zeroed
+        r = a_pos.linear() - b_pos.linear()
+        n = np_.linalg.norm(r)
+        return dsl.SpatialForce(linear=acc.force() - r * (a_inertia.mass() * b_inertia.mass() / (n * n * n)))
+
+    @dsl.edge_fold
+    def damped(acc, a_pos, a_inertia, b_pos, b_inertia):          # acc * 0.5 + g: order matters, stays sequential
+        return dsl.SpatialForce(linear=acc.force() * 0.5 + (b_pos.linear() - a_pos.linear()))
+
+    @dsl.edge_fold
+    def offset(acc, a_pos, a_inertia, b_pos, b_inertia):          # a non-zero constant would be counted once per partial
+        return dsl.SpatialForce(torque=np_.array([1.0, 0.0, 0.0]), linear=acc.force() + b_pos.linear())
+    assert codegen._fold_is_additive(newton.trace())
+    assert not codegen._fold_is_additive(damped.trace())
+    assert not codegen._fold_is_additive(offset.trace())
+    assert "kAdditive = true" in codegen.generate_pair_source(newton.trace())
+    assert "kAdditive = false" in codegen.generate_pair_source(damped.trace())
+
+
+def test_fold_stage_csr_keeps_spawn_order_per_source():
+    tp = dsl.Program([fold_test], dsl.pipe(), []).trace({"x": 1}, fold_edges={"e": ([2, 0, 2, 0, 2], [1, 2, 0, 1, 2])})
+    fs = tp.fold_stages[0]
+    assert fs.src_rows == [0, 2] and fs.row_start == [0, 2, 5] and fs.dst == [2, 1, 1, 0, 2]
