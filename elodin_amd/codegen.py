@@ -64,12 +64,19 @@ def _leaf_ref(name: str, table: Dict[str, str]) -> str:
     if name.startswith("wst"):      # window push: row `head` (the oldest) of the ring; `@w_act@`: store only from lanes that own a row
         slot, j = (int(x) for x in name[3:].split("_"))
         _, width, head_slot = _WINDOWS[slot]
-        return f"@w_act@W{slot}[static_cast<int>(r.c{head_slot}[0]) * {width} + {j}]"
+        return f"@w_act@W{slot}[(size_t)(static_cast<int>(r.c{head_slot}[0]) * {width} + {j}) * w_n]"
     raise KeyError(name)
 
 
 _TABLES: Dict[tuple, str] = {}    # (xp, fp) -> C++ symbol stem, filled while emitting one translation unit
 _WINDOWS: Dict[int, tuple] = {}    # window slot -> (rows, width, head slot) of the program being emitted (dsl.Window)
+# Device layout of a window column by executor size, fixed when the program is built (HipExec knows its row count; the object
+# says which one it was built for, bit 30 of sixdof_custom_column_widths): from this many entities on it is ELEMENT-major, [rows*width][n] — a wave reads 512 contiguous bytes per element (65,536 rockets:
+# 0.221 -> 0.158 ms per tick, 4.8 TB/s of window traffic); below, each entity's window is contiguous like in the reference's
+# column — a small batch is a chain of dependent loads per lane and the neighbouring elements it finds in cache matter more
+# (8,192 rockets: 0.070 ms per tick against 0.088 element-major).
+WINDOW_SOA_MIN_ROWS = 32768
+_WINDOW_SOA = [False]                # layout of the program being emitted
 
 
 class _Emitter:
@@ -152,7 +159,7 @@ class _Emitter:
                 return f"m_interp<T, {len(xs)}>({a[0]}, {stem}_x, {stem}_f)"
             if e.op == "wload":     # logical row a[1] of the ring whose oldest row sits at physical row a[0]
                 slot, rows, width, j, _ = e.value
-                return f"W{slot}[((static_cast<int>({a[0]}) + static_cast<int>({a[1]})) % {rows}) * {width} + {j}]"
+                return f"W{slot}[(size_t)(((static_cast<int>({a[0]}) + static_cast<int>({a[1]})) % {rows}) * {width} + {j}) * w_n]"
             if e.op == "threefry":
                 return f"m_threefry({a[0]}, {a[1]}, {a[2]}, {a[3]}, {int(e.value)})"
             if e.op == "lt":
@@ -484,11 +491,14 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
             f"        if (P.model_hist[{k}]) {{ T* g = static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row) * {w}; "
             + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(w)) + " }" for k, w in reg_cols)
         if _WINDOWS:
-            # one lane = one entity, a workgroup is one wave (step_kernel.hpp): this lane's row of every window column.
-            # Lanes past the last row read the last row and store nothing.
+            # one lane = one entity, a workgroup is one wave (step_kernel.hpp).  Element e of this lane's window sits at
+            # W[e * w_n]: w_n = n for the element-major layout of large executors, 1 (a compile-time constant, so the addresses
+            # fold) for the entity-major one (see WINDOW_SOA_MIN_ROWS).  Lanes past the last row read the last row's elements and store nothing.
             win_setup = ("        const uint32_t w_row = blockIdx.x * kWave + threadIdx.x;\n"
                          "        const bool w_act = w_row < P.n;\n"
-                         + "".join(f"        T* const W{k} = static_cast<T*>(P.model_cols[{k}]) + (size_t)(w_act ? w_row : P.n - 1) * {rows * width};\n"
+                         + ("        const size_t w_n = P.n;                    // element-major: stride between two elements of one entity\n" if _WINDOW_SOA[0]
+                            else "        constexpr size_t w_n = 1;                  // entity-major: an entity's window is contiguous\n")
+                         + "".join(f"        T* const W{k} = static_cast<T*>(P.model_cols[{k}]) + (size_t)(w_act ? w_row : P.n - 1) * (size_t){1 if _WINDOW_SOA[0] else rows * width};\n"
                                    for k, (rows, width, _) in _WINDOWS.items()))
         writes_inertia = any(s_.writes_inertia for s_ in pre + post)
         model = f'''
@@ -604,9 +614,11 @@ __global__ __launch_bounds__(64) void fold{j}_commit(const StepParams P) {{
 '''
 
 
-def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) -> str:
+def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, window_soa: bool = False) -> str:
     """tp: dsl.TracedPipe (effectors only) or dsl.TracedProgram (pre | six_dof(effectors) | post).
-    fast_math: f32 only — hardware transcendentals / reciprocal division in the generated user code (see _PRELUDE)."""
+    fast_math: f32 only — hardware transcendentals / reciprocal division in the generated user code (see _PRELUDE).
+    window_soa: window columns are element-major on the device (executors of WINDOW_SOA_MIN_ROWS entities or more)."""
+    _WINDOW_SOA[0] = bool(window_soa)
     if fast_math and dtype != "float32":
         raise ValueError("fast_math applies to float32 programs only")
     _TABLES.clear()
@@ -624,7 +636,8 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False) ->
         names_ = [c for c, _ in tp.columns]
         for wname, (wslot, wrows, wwidth) in tp.windows.items():
             _WINDOWS[wslot] = (wrows, wwidth, names_.index(wname + "#head"))
-        col_widths = "{" + ", ".join(f"{w}u" + (" | 0x80000000u" if k in _WINDOWS else "") for k, (_, w) in enumerate(tp.columns)) + "}"
+        col_widths = "{" + ", ".join(f"{w}u" + ((" | 0x80000000u" + (" | 0x40000000u" if window_soa else "")) if k in _WINDOWS else "")
+                                      for k, (_, w) in enumerate(tp.columns)) + "}"
     names = ", ".join(e.__name__ for e in pipe_tp.effectors)
     fast = "#define SIXDOF_FAST_MATH 1\n" if fast_math else ""
     launch_k = lambda pipe, ig, params: (
@@ -705,7 +718,8 @@ namespace sixdof {{
 
 extern "C" unsigned sixdof_custom_abi() {{ return static_cast<unsigned>(sizeof(sixdof::StepParams)); }}
 extern "C" unsigned sixdof_custom_layout() {{ return {n_aux}u | ({n_model}u << 8) | ({1 if (is_prog and tp.writes_inertia) else 0}u << 16); }}
-// row width of every program column, in slot order (bit 31: window column, kept in HBM) — checked against the bound columns
+// row width of every program column, in slot order (bit 31: window column, kept in HBM; bit 30: built for the element-major
+// layout) — checked against the bound columns
 extern "C" void sixdof_custom_column_widths(unsigned* out) {{
     static const unsigned w[] = {col_widths};
     for (unsigned k = 0; k < {n_model}u; k++) out[k] = w[k];
@@ -882,9 +896,9 @@ def _headers_digest() -> str:
     return h.hexdigest()
 
 
-def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_math: bool = False) -> Path:
+def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_math: bool = False, window_soa: bool = False) -> Path:
     """Generate + compile (cached by content hash).  Returns the .so path."""
-    return _compile(generate_source(tp, dtype, integrator, fast_math), "pipe")
+    return _compile(generate_source(tp, dtype, integrator, fast_math, window_soa), "pipe")
 
 
 # Generated programs are one long straight-line tick body inside the kernel's tick loop.  Left alone, LLVM's MachineLICM

@@ -782,7 +782,7 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
         if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "step: component column of the generated program is not bound");
         const unsigned expect = k < h->custom_model_width.size() ? h->custom_model_width[k] : 0u;
         const bool window = (expect >> 31) != 0;
-        const size_t want = expect & 0x7fffffffu;
+        const size_t want = expect & 0x3fffffffu;     // bit 30: the object was built for the element-major window layout
         if (c->prim != h->state_prim() || c->width < 1 || (!window && c->width > 16) || (want && c->width != want))
             return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH,
                            "step: program columns must be of the state dtype and as wide as the generated code expects "

@@ -73,6 +73,7 @@ class HipExec:
         n = self.world_pos.shape[0] if not self._column_ids else 0   # 0 = let the library size the join
         self._aux = {}
         self._windows = {}
+        self._window_soa = False
         d = L.Desc()
         d.struct_size = C.sizeof(L.Desc)
         d.device_ordinal = device
@@ -126,11 +127,14 @@ class HipExec:
                     columns = dict(columns or {})
                     for name in self._windows:       # the ring's head (physical index of the oldest row): starts at 0
                         columns.setdefault(name + "#head", np.zeros((np.shape(columns[name])[0], 1)) if name in columns else None)
-                so = codegen.build(custom, self.dtype.name, integrator, fast_math=fast_math)
+                self._window_soa = bool(self._windows) and self.world_pos.shape[0] >= codegen.WINDOW_SOA_MIN_ROWS
+                so = codegen.build(custom, self.dtype.name, integrator, fast_math=fast_math, window_soa=self._window_soa)
                 for name, width in custom.columns:
                     if columns is None or columns.get(name) is None:
                         raise KeyError(f"effector reads component {name!r} which was not provided")
                     arr = np.array(columns[name], dtype=self.dtype, order="C").reshape(-1, width)
+                    if name in self._windows and self._window_soa:
+                        arr = np.ascontiguousarray(arr.T).reshape(arr.shape)   # large executors: element-major [rows*width][n] (codegen.py)
                     self._aux[name] = arr
                     cols.append((name, arr))
                 effectors = ()
@@ -242,7 +246,8 @@ class HipExec:
         if name not in self._windows:
             return self._aux[name]
         rows, width = self._windows[name]
-        ring = self._aux[name].reshape(-1, rows, width)
+        n = self._aux[name].shape[0]
+        ring = (self._aux[name].reshape(rows * width, n).T if self._window_soa else self._aux[name]).reshape(n, rows, width)
         head = self._aux[name + "#head"][:, 0].astype(np.int64)
         idx = (head[:, None] + np.arange(rows)[None, :]) % rows
         return ring[np.arange(ring.shape[0])[:, None], idx]

@@ -288,9 +288,11 @@ int sixdof_bind_world(sixdof_handle* h, sixdof_world* w);
  * columns (row width 1..3, <= 4), then — for whole programs `pre | six_dof(effectors) | post` — the component
  * columns its systems read AND write (row width 1..16, <= 48; fetch them back with sixdof_download_column).
  * A WINDOW column (a wide component such as the rocket example's 480 x 3 sample buffer, examples/rocket/main.py:91-98)
- * is bound like any other, [n, rows*width] in the reference's row layout, but stays in HBM: the kernel uses it as a ring
- * whose head (physical index of the oldest row) lives in a hidden [n,1] column `<name>#head` — un-rotate with it after a
- * download.  The generated object exports the row width it was built for per column; sixdof_step refuses columns bound
+ * is bound like any other ([n, rows*width] elements) but stays in HBM, in the layout the generated object was built for: entity-major
+ * (the reference's rows; small executors) or ELEMENT-major — buffer[e * n + entity] for e < rows*width, so that lane-adjacent
+ * entities read adjacent addresses; executors of 32,768 entities or more —, used as a ring whose head
+ * (physical index of the oldest row) lives in a hidden [n,1] column `<name>#head` — transpose + un-rotate after a download
+ * (elodin_amd/exec.py HipExec.component does).  The generated object exports the row width it was built for per column; sixdof_step refuses columns bound
  * with another width.  A program may hold stand-alone folds between its systems (graph.rs:239-361): the generated launch
  * entry then issues a chain of kernels per tick (systems | fold | systems | six_dof | ...) over the same columns; the fold's
  * scratch rows are one more program column `<out>#fold<k>`.  Replaces the built-in op list (sixdof_set_effectors) for the

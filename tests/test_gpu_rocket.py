@@ -48,3 +48,18 @@ def test_rocket_fused_launches_and_many_rockets_end_on_the_golden_row(n, k):
         U.assert_all_columns(worst)
     want = np.array(U.GOLDEN["v_rel_accel_buffer_final"])
     assert np.abs(hip.component("v_rel_accel_buffer")[n - 1].ravel() - want).max() < 1e-9 * np.abs(want).max()
+
+
+def test_rocket_window_in_both_device_layouts():
+    """A window column is entity-major below codegen.WINDOW_SOA_MIN_ROWS entities and element-major from there on (the host lays it
+    out, the kernel picks its strides from n): a batch just past the switch ends on the golden row like the small ones do."""
+    from elodin_amd import codegen
+    n = codegen.WINDOW_SOA_MIN_ROWS + 5
+    hip = _exec(n, ticks_per_launch=10)
+    hip.run(100)
+    for row in (0, n - 1, 12345):
+        worst = {}
+        U.check_row(100, _row(hip, row), worst)
+        U.assert_all_columns(worst)
+    want = np.array(U.GOLDEN["v_rel_accel_buffer_final"])
+    assert np.abs(hip.component("v_rel_accel_buffer")[n - 1].ravel() - want).max() < 1e-9 * np.abs(want).max()
