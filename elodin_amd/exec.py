@@ -309,6 +309,8 @@ class HipExec:
 
     def history(self, name: str, first_tick: int, last_tick: int) -> np.ndarray:
         """exec.history() analogue: [last-first+1, n, w] block of component `name`, row k = state after tick first+k."""
+        if name in self._windows:
+            raise ValueError(f"{name} is a window component: it is its own history (HipExec.component), the ring does not copy it per tick")
         w = 7 if name == "world_pos" else (self._aux[name].shape[1] if name in self._aux else 6)   # program columns too
         out = np.empty((last_tick - first_tick + 1, self.n, w), dtype=self.dtype)
         for k, tick in enumerate(range(first_tick, last_tick + 1)):
