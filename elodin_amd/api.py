@@ -445,7 +445,8 @@ class World:
                 where_row = {int(e): k for k, e in enumerate(row_ids)}
                 fold_rows = {name: ([where_row[a] for a in f_], [where_row[b] for b in t_]) for name, (f_, t_) in fold_pairs.items()}
             probe = _dsl.Program(program_stages[0], eff_pipe, program_stages[1]).trace(widths, fold_edges=fold_rows)
-            partial = [n for n, _ in probe.columns if "#fold" not in n and not np.all(np.isin(row_ids, self.column(n)[1]))]
+            partial = [n for n, _ in probe.columns if "#fold" not in n and not n.endswith("#head")
+                       and not np.all(np.isin(row_ids, self.column(n)[1]))]
             if body_rows is not None:
                 partial.append("world_pos")
             written = {probe.table.cols[int(t[1:].split("_")[0])][0] for s_ in probe.pre + probe.post for t in s_.written if t[0] == "c"}
@@ -465,7 +466,7 @@ class World:
                     if isinstance(s_, _dsl.GraphFold):
                         continue
                     touched = set(s_.params) | {probe.table.cols[int(t[1:].split("_")[0])][0] for t in t_.written if t[0] == "c"}
-                    touched = {n for n in touched if not n.startswith("has:")}
+                    touched = {n for n in touched if not n.startswith("has:") and not n.endswith("#head")}
                     if touched & body_names or not touched:
                         continue
                     members = None
@@ -487,8 +488,8 @@ class World:
                     extra_columns[name] = mask
                     column_ids[name] = row_ids
                     continue
-                if name.startswith("has:") or "#fold" in name:       # presence columns / fold scratch rows: made below / by HipExec
-                    continue
+                if name.startswith("has:") or "#fold" in name or name.endswith("#head"):   # presence columns / fold scratch rows /
+                    continue                                                                # window heads: made below / by HipExec
                 arr, aids = self.column(name)
                 if name in singletons:
                     extra_columns[name] = np.tile(arr[0], (len(row_ids), 1))
@@ -674,6 +675,9 @@ class Exec:
         if name in cols:
             rows = getattr(self, "_body_rows", None)       # the executor also holds stand-in rows for plain entities
             return cols[name] if rows is None else cols[name][rows]
+        if name in getattr(self._hip, "_windows", {}):     # a window component: the reference's order, flattened like its column
+            w = self._hip.component(name)
+            return w.reshape(w.shape[0], -1)
         if name in getattr(self, "_partial", {}):     # component on fewer entities than the row set: its own rows, own order
             at, sel, n_own, original = self._partial[name]
             out = np.array(original, dtype=np.float64)

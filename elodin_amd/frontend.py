@@ -98,6 +98,15 @@ def _origin(component: Any):
     return getattr(component, "__origin__", None)
 
 
+def _window_shape(component: Any) -> Optional[Tuple[int, int]]:
+    """(rows, width) of a component declared with a 2-D shape, e.g. `el.ComponentType(F64, (480, 3))`
+    (examples/rocket/main.py:91-98): kept in HBM as a window (dsl.Window), not in the register file."""
+    c = Component.of(component)
+    if c.ty is not None and len(c.ty.shape) == 2:
+        return int(c.ty.shape[0]), int(c.ty.shape[1])
+    return None
+
+
 def _width(component: Any) -> Optional[int]:
     c = Component.of(component)
     if c.ty is not None:
@@ -363,6 +372,9 @@ def _probe_value(component):
         return _dsl.SpatialForce(_dsl.Vec([_dsl.leaf(f"acc{k}") for k in range(3)]), _dsl.Vec([_dsl.leaf(f"acc{k}") for k in range(3, 6)]))
     if name == "tick":
         return _dsl.leaf("tick")
+    if _window_shape(component) is not None:
+        rows, width = _window_shape(component)
+        return _dsl.Window(name, 0, rows, width, _dsl.leaf(f"probe:{name}:head"), 0)
     v = _dsl.Vec([_dsl.leaf(f"probe:{name}:{k}") for k in range(w or 1)])
     return v if len(v) > 1 else v[0]
 
@@ -401,7 +413,7 @@ def system(func):
     if not isinstance(probe, Query):
         raise TypeError(f"system {name} must return a query (q.map(...)) or graph.edge_fold(...)")
     out_names = probe.names
-    widths = {n: w for n, c in {**by_name, **{Component.name(c): c for c in probe.components}}.items()
+    widths = {n: (_window_shape(c) or w) for n, c in {**by_name, **{Component.name(c): c for c in probe.components}}.items()
               if (w := _width(c)) is not None and n not in _BODY + ("force", "tick", "world_accel")}
 
     if out_names == ["force"]:                       # `-> el.Force`: an effector of six_dof (six_dof.rs:161-203 `sys`)

@@ -256,3 +256,36 @@ def test_world_accel_after_six_dof_is_this_ticks_and_in_front_of_it_the_previous
         return m + f.force()
     with pytest.raises(TypeError, match="effectors inside six_dof"):
         el.map(peek)
+
+
+def test_two_dimensional_components_are_windows():
+    """examples/rocket/main.py:91-98,464-472: a component declared with a 2-D shape reaches @el.map functions as a dsl.Window
+    (push / row access / scan), not as 1,440 registers."""
+    Sample = ty.Annotated[el.Array, el.Component("sample", el.ComponentType(el.PrimitiveType.F64, (3,)))]
+    Buf = ty.Annotated[el.Array, el.Component("sample_buffer", el.ComponentType(el.PrimitiveType.F64, (16, 3)))]
+    Filt = ty.Annotated[el.Array, el.Component("sample_filtered", el.ComponentType(el.PrimitiveType.F64, (3,)))]
+
+    @el.map
+    def push(a: Sample, buffer: Buf) -> Buf:
+        return buffer.push(a)
+
+    @el.map
+    def low_pass(s: Buf) -> Filt:
+        return s.scan(lambda c, row: (c * 0.5 + row, None), s[0], start=1)
+
+    assert push.widths["sample_buffer"] == (16, 3) and low_pass.widths["sample_buffer"] == (16, 3)
+    tp = dsl.Program([push, low_pass], dsl.Pipe([]), []).trace({"sample": 3, "sample_buffer": 48, "sample_filtered": 3})
+    assert tp.windows == {"sample_buffer": (tp.windows["sample_buffer"][0], 16, 3)}
+    n = 2
+    comps = {"sample": np.array([[1.0, 2.0, 3.0], [-1.0, 0.5, 4.0]]), "sample_buffer": np.zeros((n, 48)), "sample_buffer#head": np.zeros((n, 1)),
+             "sample_filtered": np.zeros((n, 3))}
+    pos = np.tile([0.0, 0, 0, 1, 0, 0, 0], (n, 1))
+    logical = np.zeros((n, 16, 3))
+    for tick in range(1, 21):
+        dsl_numpy._run_systems(tp.pre, pos, np.zeros((n, 6)), np.ones((n, 7)), comps, tp.table, tick)
+        logical = np.concatenate([logical[:, 1:], comps["sample"][:, None, :]], axis=1)
+        c = logical[:, 0]
+        for r in range(1, 16):
+            c = c * 0.5 + logical[:, r]
+        assert np.array_equal(dsl_numpy.window_rows(comps, "sample_buffer", 16, 3), logical)
+        assert np.allclose(comps["sample_filtered"], c, rtol=1e-15)

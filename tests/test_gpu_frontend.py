@@ -888,3 +888,45 @@ def test_cube_sat_sun_sensor_folds_in_the_reference_spelling():
         assert np.allclose(df["sat.css_reading"][k], reading, rtol=1e-10, atol=1e-13), k
         assert np.allclose(df["sat.sun_pos"][k], sun, rtol=1e-12)
     assert np.abs(df["sat.css_reading"][-1]).max() > 0.1
+
+
+def test_window_component_through_world_build():
+    """A 2-D component (rocket's sample buffer shape) spawned with el.C, pushed and filtered by @el.map systems in front of
+    six_dof, through World.build: the exec hands the window back in the reference's order."""
+    Sample = ty.Annotated[el.Array, el.Component("sample", el.ComponentType(el.PrimitiveType.F64, (3,)))]
+    Buf = ty.Annotated[el.Array, el.Component("sample_buffer", el.ComponentType(el.PrimitiveType.F64, (16, 3)))]
+    Filt = ty.Annotated[el.Array, el.Component("sample_filtered", el.ComponentType(el.PrimitiveType.F64, (3,)))]
+
+    @el.map
+    def sample(v: el.WorldVel) -> Sample:
+        return v.linear()
+
+    @el.map
+    def push(a: Sample, buffer: Buf) -> Buf:
+        return buffer.push(a)
+
+    @el.map
+    def low_pass(s: Buf) -> Filt:
+        return s.scan(lambda c, row: (c * 0.5 + row, None), s[0], start=1)
+
+    @el.map
+    def gravity(f: el.Force, inertia: el.Inertia) -> el.Force:
+        return f + el.SpatialForce(linear=inertia.mass() * el.np.array([0.0, 0.0, -9.81]))
+
+    w = el.World()
+    for k in range(3):
+        w.spawn([el.Body(world_vel=el.SpatialMotion(linear=np.array([1.0 + k, 0.0, 2.0]))),
+                 el.C((Sample, Buf, Filt), (np.zeros(3), np.zeros((16, 3)), np.zeros(3)))], f"b{k}")
+    exec = w.build(sample | push | low_pass | el.six_dof(sys=gravity, integrator=el.Integrator.SemiImplicit), simulation_rate=120.0)
+    exec.run(20)
+    dt = 0.008333333
+    logical = np.zeros((3, 16, 3))
+    v = np.array([[1.0 + k, 0.0, 2.0] for k in range(3)])
+    for _ in range(20):
+        logical = np.concatenate([logical[:, 1:], v[:, None, :]], axis=1)      # the systems see the velocity the tick starts from
+        v = v + dt * np.array([0.0, 0.0, -9.81])
+    c = logical[:, 0]
+    for r in range(1, 16):
+        c = c * 0.5 + logical[:, r]
+    assert np.allclose(exec.column_array("sample_buffer"), logical.reshape(3, -1), rtol=1e-12, atol=1e-15)
+    assert np.allclose(exec.column_array("sample_filtered"), c, rtol=1e-12)
