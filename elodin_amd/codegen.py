@@ -576,21 +576,23 @@ def _emit_fold_stage(fs: "dsl.TracedFoldStage") -> str:
     for i, (n, slot, wn) in enumerate(fs.right):
         for k in range(wn):
             leaves[f"b{i}_{k}"] = f"b{i}[{k}]"
-        loads_b.append(f"        const T* b{i} = {ptr(n, slot)} + (size_t)fold{j}_dst[e] * {wn};")
+        loads_b.append(f"        const T* b{i} = {ptr(n, slot)} + (size_t)(base + fold{j}_dst[e]) * {wn};")
     body = "\n".join(emit_block([(f"acc[{k}]", e) for k, e in enumerate(fs.traced.outputs)], leaves, indent="        "))
     init = ", ".join(f"T({v!r})" for v in f.init)
     nl = "\n"
     n_src = len(fs.src_rows)
+    count, stride = fs.replicas if fs.replicas else (1, 0)
     arr = lambda xs: ", ".join(str(int(x)) for x in xs) if xs else "0"
-    return f'''// ---- fold stage {j}: {fs.name} ({len(fs.dst)} edges, {n_src} sources) ----
+    return f'''// ---- fold stage {j}: {fs.name} ({len(fs.dst)} edges, {n_src} sources{f", x {count} replicas of {stride} rows" if fs.replicas else ""}) ----
 __device__ const uint32_t fold{j}_src[{max(n_src, 1)}] = {{{arr(fs.src_rows)}}};
 __device__ const uint32_t fold{j}_start[{n_src + 1}] = {{{arr(fs.row_start)}}};
 __device__ const uint32_t fold{j}_dst[{max(len(fs.dst), 1)}] = {{{arr(fs.dst)}}};
 template <class T>
 __global__ __launch_bounds__(64) void fold{j}_kernel(const StepParams P) {{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= {n_src}u) return;
-    const uint32_t row = fold{j}_src[i];
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= {n_src * count}u) return;
+    const uint32_t i = gi % {max(n_src, 1)}u, base = (gi / {max(n_src, 1)}u) * {stride}u;   // source within the template, replica's first row
+    const uint32_t row = base + fold{j}_src[i];
     if (row >= P.n) return;
 {nl.join(loads_a)}
     T acc[{w}] = {{{init}}};
@@ -603,9 +605,9 @@ __global__ __launch_bounds__(64) void fold{j}_kernel(const StepParams P) {{
 }}
 template <class T>
 __global__ __launch_bounds__(64) void fold{j}_commit(const StepParams P) {{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= {n_src}u) return;
-    const uint32_t row = fold{j}_src[i];
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= {n_src * count}u) return;
+    const uint32_t row = (gi / {max(n_src, 1)}u) * {stride}u + fold{j}_src[gi % {max(n_src, 1)}u];
     if (row >= P.n) return;
     const T* sc = static_cast<const T*>(P.model_cols[{fs.scratch_slot}]) + (size_t)row * {w};
     T* o = static_cast<T*>(P.model_cols[{fs.out[1]}]) + (size_t)row * {w};
@@ -683,7 +685,7 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
             if c[0] == "fold":
                 fs = c[1]
                 parts.append(_emit_fold_stage(fs))
-                nb = (len(fs.src_rows) + 63) // 64
+                nb = (len(fs.src_rows) * (fs.replicas[0] if fs.replicas else 1) + 63) // 64
                 if nb:
                     calls.append(f"        hipLaunchKernelGGL(fold{fs.index}_kernel<{T}>, dim3({nb}), dim3(64), 0, s, q);\n"
                                  f"        hipLaunchKernelGGL(fold{fs.index}_commit<{T}>, dim3({nb}), dim3(64), 0, s, q);")

@@ -1237,9 +1237,13 @@ class Program:
     def folds(self) -> List["GraphFold"]:
         return [s for s in self.pre + self.post if isinstance(s, GraphFold)]
 
-    def trace(self, widths: Optional[Dict[str, int]] = None, partial: Sequence[str] = (), fold_edges=None) -> "TracedProgram":
+    def trace(self, widths: Optional[Dict[str, int]] = None, partial: Sequence[str] = (), fold_edges=None,
+              fold_replicas: Optional[Tuple[int, int]] = None) -> "TracedProgram":
+        """fold_replicas=(count, stride): the executor holds `count` copies of one small world, `stride` rows each (a
+        Monte-Carlo batch of graph worlds); `fold_edges` then describe replica 0 only (rows < stride) and every replica folds
+        over the same template, shifted by its base row — one baked CSR for the whole batch."""
         if self._traced is None:
-            self._traced = TracedProgram(self, widths, partial, fold_edges)
+            self._traced = TracedProgram(self, widths, partial, fold_edges, fold_replicas)
         return self._traced
 
 
@@ -1249,8 +1253,10 @@ class TracedFoldStage:
 
     BODY_WIDTH = {"world_pos": 7, "world_vel": 6, "inertia": 7}
 
-    def __init__(self, fold: GraphFold, table: ColumnTable, index: int, edges, partial: Sequence[str] = ()):
+    def __init__(self, fold: GraphFold, table: ColumnTable, index: int, edges, partial: Sequence[str] = (),
+                 replicas: Optional[Tuple[int, int]] = None):
         self.name, self.index = fold.__name__, index
+        self.replicas = (int(replicas[0]), int(replicas[1])) if replicas else None
         names = list(dict.fromkeys(fold.left + fold.right + (fold.out,)))
         if fold.out in self.BODY_WIDTH:
             raise TypeError(f"fold {self.name}: a stand-alone fold writes a plain component (use an edge_fold effector for Force)")
@@ -1275,6 +1281,8 @@ class TracedFoldStage:
         dst = [int(x) for x in edges[1]]
         if len(src) != len(dst):
             raise ValueError("fold edges: from / to lengths differ")
+        if self.replicas and any(not 0 <= r < self.replicas[1] for r in src + dst):
+            raise ValueError(f"fold {self.name}: with fold_replicas the edges describe replica 0 (rows 0..{self.replicas[1] - 1})")
         if len(src) > 65536:
             raise ValueError(f"fold {self.name}: {len(src)} edges — folds inside a program bake their edges into the generated "
                              "code (<= 65,536); run a larger graph as a stand-alone fold (World.build(fold))")
@@ -1291,7 +1299,8 @@ class TracedFoldStage:
 
 
 class TracedProgram:
-    def __init__(self, prog: Program, widths: Optional[Dict[str, int]] = None, partial: Sequence[str] = (), fold_edges=None):
+    def __init__(self, prog: Program, widths: Optional[Dict[str, int]] = None, partial: Sequence[str] = (), fold_edges=None,
+                 fold_replicas: Optional[Tuple[int, int]] = None):
         self.table = ColumnTable("c", 48, 16, widths)
         self.partial = tuple(partial)
         fold_edges = fold_edges or {}
@@ -1300,7 +1309,7 @@ class TracedProgram:
         def trace_item(s, after):
             if isinstance(s, GraphFold):
                 n_folds[0] += 1
-                return TracedFoldStage(s, self.table, n_folds[0] - 1, fold_edges.get(s.edge_component), self.partial)
+                return TracedFoldStage(s, self.table, n_folds[0] - 1, fold_edges.get(s.edge_component), self.partial, fold_replicas)
             return TracedSystem(s, self.table, self.partial, after_six_dof=after)
         self.pre = [trace_item(s, False) for s in prog.pre]
         self.pipe = TracedPipe(prog.effectors.effectors, table=self.table, partial=self.partial)

@@ -51,7 +51,8 @@ class HipExec:
                  simulation_time_step: float = 1.0 / 120.0, time_step: Optional[float] = None,
                  integrator: int = L.RK4, dtype=np.float64, effectors: Sequence[Effector] = (),
                  edges=None, ticks_per_launch: int = 1, use_graph: bool = False, device: int = 0,
-                 tick: int = 0, column_entity_ids=None, columns=None, fast_math: bool = False, graph_edges=None):
+                 tick: int = 0, column_entity_ids=None, columns=None, fast_math: bool = False, graph_edges=None,
+                 graph_replicas=None):
         lib = L.lib()
         self._lib = lib
         self.dtype = np.dtype(dtype)
@@ -115,7 +116,9 @@ class HipExec:
                             fold_rows[name] = ([row_of[int(a)] for a in frm], [row_of[int(b)] for b in to])
                         except KeyError as e:
                             raise KeyError(f"graph_edges[{name!r}]: edge endpoint {e} is not an entity of this executor") from None
-                    custom = effectors.trace(widths, fold_edges=fold_rows)
+                    if graph_replicas is not None and int(graph_replicas[0]) * int(graph_replicas[1]) != len(self.entity_ids):
+                        raise ValueError("graph_replicas=(count, rows per replica) must cover the executor's rows exactly")
+                    custom = effectors.trace(widths, fold_edges=fold_rows, fold_replicas=graph_replicas)
                     columns = dict(columns or {})
                     for fs in custom.fold_stages:       # scratch rows: a fold reads the values from before it ran
                         columns.setdefault(fs.scratch_name, np.zeros((self.world_pos.shape[0], fs.out[2])))

@@ -194,18 +194,23 @@ def _run_fold_stage(fs, pos, vel, inertia, comps):
     col = lambda name: body[name] if name in body else comps[name]
     snap = {n: col(n).copy() for n, _, _ in fs.left + fs.right}
     f = fs.traced.fold
-    results = []
-    for i, row in enumerate(fs.src_rows):
-        acc = np.array(f.init, dtype=np.float64)
-        for e in range(fs.row_start[i], fs.row_start[i + 1]):
-            lv = {f"acc_{k}": np.array([acc[k]]) for k in range(len(acc))}
-            for j, (n, _, w) in enumerate(fs.left):
-                lv.update({f"a{j}_{k}": np.array([snap[n][row, k]]) for k in range(w)})
-            for j, (n, _, w) in enumerate(fs.right):
-                lv.update({f"b{j}_{k}": np.array([snap[n][fs.dst[e], k]]) for k in range(w)})
-            acc = np.array([v[0] for v in _eval(fs.traced.outputs, lv, 1)])
-        results.append(acc)
-    for row, acc in zip(fs.src_rows, results):
+    results, rows_out = [], []
+    count, stride = fs.replicas if getattr(fs, "replicas", None) else (1, 0)     # replicas: the same edge template per copy
+    for rep in range(count):
+        base = rep * stride
+        for i, row0 in enumerate(fs.src_rows):
+            row = base + row0
+            rows_out.append(row)
+            acc = np.array(f.init, dtype=np.float64)
+            for e in range(fs.row_start[i], fs.row_start[i + 1]):
+                lv = {f"acc_{k}": np.array([acc[k]]) for k in range(len(acc))}
+                for j, (n, _, w) in enumerate(fs.left):
+                    lv.update({f"a{j}_{k}": np.array([snap[n][row, k]]) for k in range(w)})
+                for j, (n, _, w) in enumerate(fs.right):
+                    lv.update({f"b{j}_{k}": np.array([snap[n][base + fs.dst[e], k]]) for k in range(w)})
+                acc = np.array([v[0] for v in _eval(fs.traced.outputs, lv, 1)])
+            results.append(acc)
+    for row, acc in zip(rows_out, results):
         comps[fs.out[0]][row] = acc
         comps[fs.scratch_name][row] = acc
 

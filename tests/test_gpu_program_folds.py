@@ -107,6 +107,35 @@ def test_folds_between_systems_around_six_dof_match_the_numpy_walker(integrator,
     assert hip.component("seen").max() > 0
 
 
+def test_replicated_graph_world_uses_one_edge_template():
+    """A Monte-Carlo batch of small graph worlds: 300 satellites with six sensors each (2,100 rows), the edges given for
+    replica 0 only and `graph_replicas=(300, 7)` — one baked CSR for the whole batch — vs the numpy walker."""
+    n_sats = 300
+    w, comps, edges, ids = _world(n_sats)
+    first = {name: (f_[:6], t_[:6]) for name, (f_, t_) in edges.items()}      # _world spawns satellite 0's six edges first
+    assert all(int(x) <= 7 for f_, t_ in first.values() for x in list(f_) + list(t_))
+    prog = dsl.Program([sun_direction, sensor_reading, sun_estimate, point_at_sun], apply_torque | dsl.pipe(),
+                       [log_alignment, echo_to_sensors, count_seen])
+    hip = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], entity_ids=ids, simulation_time_step=workloads.DT_120HZ,
+                     integrator=L.RK4, effectors=prog, columns=comps, graph_edges=first, graph_replicas=(n_sats, 7), ticks_per_launch=4)
+    tp = prog.trace()
+    assert all(fs.replicas == (n_sats, 7) and len(fs.dst) == 6 for fs in tp.fold_stages)
+    pos, vel, acc, inertia = w["world_pos"].copy(), w["world_vel"].copy(), np.zeros_like(w["world_vel"]), w["inertia"].copy()
+    cn = {name: v.copy() for name, v in comps.items()}
+    for fs in tp.fold_stages:
+        cn[fs.scratch_name] = np.zeros((pos.shape[0], fs.out[2]))
+    for t in range(1, 9):
+        dsl_numpy.program_tick(tp, pos, vel, acc, inertia, cn, t, workloads.DT_120HZ, L.RK4)
+    hip.run(8)
+    assert parity.pos_rel_err(hip.world_pos, pos) < parity.F64_RTOL
+    for name in ("reading", "estimate", "torque_cmd", "log", "echo", "seen"):
+        assert np.allclose(hip.component(name), cn[name], rtol=1e-9, atol=1e-12), name
+    assert np.all(np.abs(hip.component("estimate")[np.arange(0, 7 * n_sats, 7)]).sum(axis=1) > 0.1)
+    with pytest.raises(ValueError, match="cover the executor's rows"):
+        ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], entity_ids=ids, effectors=dsl.Program([sun_direction, sensor_reading], dsl.pipe(), []),
+                   columns=comps, graph_edges=first, graph_replicas=(299, 7))
+
+
 def test_program_fold_errors():
     w, comps, edges, ids = _world(1)
     prog = dsl.Program([sun_direction, sensor_reading], dsl.pipe(), [])
