@@ -53,3 +53,20 @@ def test_window_component_api_guards():
         return {"buf": buf}
     with pytest.raises(ValueError, match="window"):
         dsl.Program([too_wide], dsl.Pipe([]), []).trace()
+
+
+def test_generated_window_code_in_both_layouts():
+    """The window column's device layout is fixed when the program is built (codegen.WINDOW_SOA_MIN_ROWS): element stride n for
+    large executors, a compile-time 1 below; the object says which (bit 30 of its column widths) next to the window bit."""
+    from elodin_amd import codegen
+    tp = R.program().trace()
+    small = codegen.generate_source(tp, "float64", 0, window_soa=False)
+    large = codegen.generate_source(tp, "float64", 0, window_soa=True)
+    slot = tp.windows["v_rel_accel_buffer"][0]
+    assert "constexpr size_t w_n = 1;" in small and "const size_t w_n = P.n;" in large
+    assert f"* (size_t)1440;" in small and f"W{slot} = static_cast<T*>(P.model_cols[{slot}]) + (size_t)(w_act ? w_row : P.n - 1) * (size_t)1;" in large
+    assert "1440u | 0x80000000u}" in small.replace(", 1u", "") or "1440u | 0x80000000u," in small
+    assert "1440u | 0x80000000u | 0x40000000u" in large
+    for src in (small, large):
+        assert "#pragma unroll 8" in src and "if (w_act) W" in src          # counted scan loop; stores only from lanes that own a row
+        assert "kPreReadsAccel = true" in src                               # v_rel_accel reads world_accel in front of six_dof
