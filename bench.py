@@ -525,6 +525,17 @@ def main():
                                             "HIP events around the timed region on the launch stream / launches")
         else:
             out["roofline"] = kernel_roofline(ex, n, args.steps, args.warmup)
+        if not args.no_extras and world == 1 and K == 1 and args.steps < 2048:
+            # A short timed region carries the batch's start-up (~20 us of device time before the first launch of a replayed
+            # chain runs at speed, profiles/r02_short_batch_ab.txt) in its average.  The same kernel, same handle, same
+            # measurement over a long batch, reported beside it — not instead of it.
+            if not args.no_graph:
+                ex.prepare(4096)
+            ex.invoke_batch(256)
+            st = ex.invoke_batch(4096)
+            ss = roofline_from(st.kernel_device_ms / max(1, st.launches), n, st.launches,
+                               "HIP events around a 4,096-launch batch on the launch stream / launches")
+            out["roofline"]["steady_state"] = {k: ss[k] for k in ("achieved", "frac", "frac_360B", "avg_launch_us", "launches_timed", "timing")}
         if not args.no_extras and world == 1:
             # fused batch: the reference's ticks_per_telemetry semantics, state held in VGPRs
             ex.set_ticks_per_launch(64)
