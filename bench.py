@@ -15,8 +15,9 @@ Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel, ticks_
 algorithmic bytes 360 + 24 = 384 B/entity-step against the 8 TB/s HBM peak), `roofline_hbm` (same kernel at
 4,194,304 bodies, where the working set leaves the 256 MiB Infinity Cache and the kernel really
 streams from HBM), `fused` (ticks_per_launch = 64: state in registers, VALU-bound), `nbody` / `apollo_mc` /
-`falcon9_mc` (timings of BASELINE configs[2] / configs[3] / configs[4] on this GPU) and `cpu_baseline` (the CPU oracle on the host
-cores, bounded sample, N=1 only).
+`falcon9_mc` (timings of BASELINE configs[2] / configs[3] / configs[4] on this GPU), `parity` (max |dState| vs the oracle on
+a 4,096-row world, outside the timed region — the second half of BASELINE.json's metric) and `cpu_baseline` (the CPU oracle
+on the host cores, single thread first, bounded sample, N=1 only).  The timed window is the same code at every N.
 """
 from __future__ import annotations
 
@@ -370,50 +371,78 @@ def cpu_quota():
 
 
 def cpu_baseline(w, eff, target_seconds=10.0):
-    """The CPU oracle (a port of the reference arithmetic; the reference itself needs rustc + jax) timed
-    on this host's cores on a bounded sample of the same workload, built -O3 -march=native on this host."""
+    """The CPU oracle (a port of the reference arithmetic; the reference itself needs rustc + jax) timed on this host's
+    cores on a bounded sample of the same workload.  `value` is the SINGLE-THREAD figure — the like-for-like stand-in for
+    the reference's tick, which is one native function call on one thread (cranelift_exec.rs:163-165); the OpenMP figure
+    over entity blocks is reported beside it with threads = min(visible cores, cgroup CPU quota)."""
     from oracle import oracle as orc
-    cores = len(os.sched_getaffinity(0))
+    visible = len(os.sched_getaffinity(0))
+    quota = cpu_quota()
+    threads = max(1, min(visible, int(quota))) if quota else visible
     ops = [(e.kind, tuple(e.p), e.aux) for e in eff]
+    n = w["world_pos"].shape[0]
 
-    def run(ticks, threads):
+    def run(ticks, th):
         o = orc.OracleWorld(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=0.008333333, ops=ops)
         t0 = time.perf_counter()
-        o.step(ticks, threads=threads)
+        o.step(ticks, threads=th)
         return time.perf_counter() - t0
 
-    # two builds of the same source: the portable -O2 one the tests use and -O3 -march=native made on this host
-    # (BASELINE.md section 3); the faster single-thread build is the one timed
-    st_ticks = max(2, int(min(64, 1.5 / max(1e-9, (run(1, 1))))))
-    builds = {"-O2": w["world_pos"].shape[0] * st_ticks / run(st_ticks, 1)}
+    # two builds of the same source: the portable -O2 one the tests use and the one made ON THIS HOST
+    # (-O3 -march=native -fno-tree-vectorize, oracle/Makefile says why); the faster single-thread build is the one timed
+    st_ticks = max(2, int(min(256, target_seconds * 0.25 / max(1e-9, run(1, 1)))))
+    builds = {"-O2": n * st_ticks / run(st_ticks, 1)}
     portable = orc.LIB_PATH
     lib_path = orc.use_native_build()
-    native = lib_path.name.endswith("_native.so")
-    if native:
-        builds["-O3 -march=native"] = w["world_pos"].shape[0] * st_ticks / run(st_ticks, 1)
-        if builds["-O3 -march=native"] < builds["-O2"]:
+    if lib_path.name.endswith("_native.so"):
+        builds["-O3 -march=native -fno-tree-vectorize"] = n * st_ticks / run(st_ticks, 1)
+        if builds["-O3 -march=native -fno-tree-vectorize"] < builds["-O2"]:
             orc.LIB_PATH, orc._lib = portable, None
     flags = max(builds, key=builds.get)
-    n = w["world_pos"].shape[0]
-    probe = run(4, cores)
-    ticks = int(min(4096, max(8, target_seconds * 0.7 / (probe / 4))))
-    dt = run(ticks, cores)
     st = run(st_ticks, 1)
-    # thread sweep: the all-core figure alone says nothing when a CPU quota caps the process
-    sweep = {}
-    for th in sorted({1, 2, 4, 8, 16, 32, 64, cores} & set(range(1, cores + 1))):
-        if th in (1, cores):
-            continue
-        tk = max(4, int(ticks * min(1.0, 2.0 * th / cores)))
-        sweep[str(th)] = round(n * tk / run(tk, th), 1)
-    best_threads, best = max([(cores, n * ticks / dt)] + [(int(k), v) for k, v in sweep.items()], key=lambda kv: kv[1])
-    return {"value": round(best, 1), "unit": "entity-steps/s", "cores": best_threads, "kind": "port",
-            "sample": f"{n} bodies x {ticks} RK4 ticks, oracle/sixdof_oracle.c "
-                      f"{flags} -ffp-contract=off, "
-                      f"OpenMP over entity blocks; best of the thread sweep",
-            "visible_cores": cores, "cgroup_cpu_quota": cpu_quota(), "all_visible_cores_value": round(n * ticks / dt, 1),
-            "threads_sweep": sweep, "single_thread_value": round(n * st_ticks / st, 1),
-            "single_thread_by_build": {k: round(v, 1) for k, v in builds.items()}}
+    out = {"value": round(n * st_ticks / st, 1), "unit": "entity-steps/s", "cores": 1, "kind": "port",
+           "sample": f"{n} bodies x {st_ticks} RK4 ticks, oracle/sixdof_oracle.c {flags} -ffp-contract=off, one thread "
+                     f"(the reference's tick is single-threaded)",
+           "single_thread_by_build": {k: round(v, 1) for k, v in builds.items()},
+           "visible_cores": visible, "cgroup_cpu_quota": quota}
+    if threads > 1:
+        probe = run(4, threads)
+        ticks = int(min(4096, max(8, target_seconds * 0.5 / (probe / 4))))
+        dt = run(ticks, threads)
+        out["multi_thread"] = {"value": round(n * ticks / dt, 1), "unit": "entity-steps/s", "cores": threads,
+                               "threads_rule": "min(visible cores, cgroup CPU quota)",
+                               "sample": f"{n} bodies x {ticks} RK4 ticks, OpenMP over entity blocks"}
+    return out
+
+
+def parity_figure(device, rows=4096, ticks=16):
+    """BASELINE.json's metric ends in "max |dState| vs ref": the same workload at `rows` bodies stepped `ticks` RK4 ticks
+    through the HIP path and through the oracle (the checker; pinned bit-exact on the reference's golden CSVs), OUTSIDE
+    the timed region.  Relative per entity and field, scaled by the field vector's largest component (tests/parity.py)."""
+    from oracle import oracle as orc
+    import elodin_amd as ea
+    from elodin_amd import workloads
+    w = workloads.independent_bodies(rows)
+    eff = workloads.gravity_torque_effectors(w["body_torque"])
+    hip = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], entity_ids=w["entity_ids"],
+                     simulation_time_step=workloads.DT_120HZ, effectors=eff, device=device)
+    hip.run(ticks)
+    ref = orc.OracleWorld(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ,
+                          ops=[(e.kind, tuple(e.p), e.aux) for e in eff]).step(ticks)
+    worst = {}
+    for f in ("world_pos", "world_vel", "world_accel", "force"):
+        g, r = getattr(hip, f), getattr(ref, f)
+        e = 0.0
+        for sl in ((slice(0, 4), slice(4, 7)) if f == "world_pos" else (slice(0, 3), slice(3, 6))):
+            scale = np.maximum(np.max(np.abs(r[:, sl]), axis=1, keepdims=True), 1e-300)
+            e = max(e, float(np.max(np.abs(g[:, sl] - r[:, sl]) / scale)))
+        worst[f] = e
+    # integer surface: the gather rows the C ABI resolved for the joined entity ids (identity here) — bit-exact or wrong
+    ids_equal = bool(np.array_equal(hip.join_rows("world_pos"), np.arange(rows, dtype=np.uint32)))
+    hip.close()
+    return {"max_rel_err": max(worst.values()), "by_column": worst, "ticks": ticks, "rows": rows, "tolerance": 1e-9,
+            "entity_rows_bit_exact": ids_equal,
+            "vs": "oracle/sixdof_oracle.c (reference operation order, no FMA; bit-exact on the reference's three-body / ball golden CSVs)"}
 
 
 def main():
@@ -483,23 +512,26 @@ def main():
     if not args.no_graph:
         ex.prepare(args.steps)
     ex.invoke_batch(args.warmup)
+    # ONE rule at every N (the same lines run for N = 1 and N > 1; `barrier` is only a device synchronise without a
+    # process group):  barrier + device synchronise | t0 | K steps + hipStreamSynchronize of the stream they ran on (inside
+    # sixdof_step: nothing else is in flight on this device) | t1 | device synchronise + barrier | t2 ;  MAX over ranks of
+    # (t1 - t0) AFTER the clocks have stopped.  `value` uses t1 - t0.  The closing device-wide synchronise and the barrier
+    # are host bookkeeping with nothing left to wait for (~60 us + ~50-100 us on ROCm, 40 %+ of a 20-step window,
+    # profiles/r02_short_batch_ab.txt); the window that includes them (t2 - t0, MAX over ranks) is reported beside it as
+    # `window_incl_device_sync_and_barrier`, also at every N.
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    tm = ex.invoke_batch(args.steps)      # enqueues every launch and SYNCHRONISES the stream they run on (hipStreamSynchronize)
-    if not distributed:
-        elapsed = time.perf_counter() - t0
-    # Nothing else is in flight on this device, so the device-wide torch.cuda.synchronize() of the contract's closing bracket
-    # has nothing left to wait for; on ROCm it still costs ~60 us of host time walking every queue, 40 % of a 20-step timed
-    # region (profiles/r02_short_batch_ab.txt).  At N = 1 the clock therefore stops on the stream synchronisation and the
-    # device-wide one follows as a check; at N > 1 it stays inside the window, before the barrier.
+    tm = ex.invoke_batch(args.steps)      # enqueues every launch and SYNCHRONISES the stream they run on
+    t1 = time.perf_counter()
     torch.cuda.synchronize()
     barrier()
-    if distributed:
-        elapsed = time.perf_counter() - t0
+    t2 = time.perf_counter()
+    elapsed, elapsed_incl = t1 - t0, t2 - t0
     if distributed:
         from elodin_amd import shard
-        elapsed = shard.max_over_ranks(elapsed, device=torch.device("cuda", local_rank))   # MAX over ranks
+        elapsed = shard.max_over_ranks(elapsed, device=torch.device("cuda", local_rank))        # MAX over ranks
+        elapsed_incl = shard.max_over_ranks(elapsed_incl, device=torch.device("cuda", local_rank))
 
     value = n * world * args.steps / elapsed
     out = {
@@ -513,9 +545,12 @@ def main():
                    "graph_replay": bool(tm.launches and tm.graph_launches == tm.launches),
                    "graph_launches": tm.graph_launches, "launches": tm.launches,
                    "parallelism": f"entity shards x{world}, no collective",
-                   "sync": ("timed region = barrier, device synchronize, t0, K steps, hipStreamSynchronize of the launch stream "
-                            "(inside sixdof_step), t1, device synchronize, barrier" if not distributed else
-                            "timed region = barrier, device synchronize, t0, K steps, stream + device synchronize, barrier, t1; MAX over ranks")},
+                   "sync": "every N: barrier, device synchronize, t0, K steps, hipStreamSynchronize of the launch stream (inside "
+                           "sixdof_step), t1, device synchronize, barrier, t2; value = MAX over ranks of t1 - t0",
+                   "excluded": "the final D2H download of the columns (amortised over the config's 10,000 ticks; 13 MB = "
+                               "0.3 ms over PCIe, which would dominate a 20-step window) and the H2D upload"},
+        "window_incl_device_sync_and_barrier": {"value": round(n * world * args.steps / elapsed_incl, 1), "unit": "entity-steps/s",
+                                                "ms_per_step": round(elapsed_incl / args.steps * 1e3, 6)},
         "device_ms_per_step": round(tm.kernel_device_ms / args.steps, 6),
     }
 
@@ -599,8 +634,11 @@ def main():
         extra("history_stream", history_stream_leg, local_rank, n)
         extra("apollo_mc", apollo_leg, local_rank)
         extra("falcon9_mc", falcon9_leg, local_rank)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        extra("cpu_baseline", cpu_baseline, w, eff)
+    if rank == 0 and not args.no_cpu_baseline:
+        # the oracle legs (the checker and the reported CPU baseline; nothing timed above touches the oracle)
+        extra("parity", parity_figure, local_rank)
+        if world == 1:
+            extra("cpu_baseline", cpu_baseline, w, eff)
     if distributed:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()

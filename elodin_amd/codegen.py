@@ -697,7 +697,7 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
             reads_accel = any(s_.reads_accel for s_ in pre)
             parts.append(_emit_pipe_struct(f"PipeSeg{i}", tp, pipe_tp if six else None, pre, post, used, reads_accel, 0))
             ig = integ if six else "kNone"
-            tweak = "" if i == last_seg else " qs.hist_ring = 0;"          # only the last link records the tick
+            tweak = "" if i == last_seg else " qs.hist_ring = 0; qs.hist_pos = qs.hist_vel = qs.hist_accel = qs.hist_force = nullptr;"          # only the last link records the tick
             tweak += "" if six else " qs.accel_in_check = 0;"
             calls.append(f"        {{ StepParams qs = q;{tweak}\n" + launch_k(f"PipeSeg{i}", ig, "qs").replace("    if", "          if", 1).replace("\n    else", "\n          else") + "        }")
         structs = "\n".join(parts)

@@ -765,11 +765,21 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
     const size_t state_bytes = static_cast<size_t>(h->desc.n_entities) * 32 * h->elem_size();
     // NOT the write-through (`sc1`) store policy, although it measured 7 % faster between 48 and 192 MiB of state: the next
     // launch can read STALE rows after it (262,144 bodies: ~10 % of the rows differ from the fused run, differently every
-    // run — tools/debug_midsize_determinism.py, profiles/r02_sc1_store_policy_is_unsafe.txt).  It stays reachable through
-    // SIXDOF_STREAMING=2 for that demonstration only.
+    // run — tools/debug_midsize_determinism.py, profiles/r02_sc1_store_policy_is_unsafe.txt).  It is compiled into the A/B
+    // library only (`make ab`, -DSIXDOF_AB_BUILD); the product ignores any SIXDOF_STREAMING code outside {0, 1, 9}.
     uint32_t policy = 9u;
     if (state_bytes <= (768ull << 20)) policy = 1u;
-    P->streaming = force_nt ? static_cast<uint32_t>(std::atoi(force_nt)) : policy;
+    if (force_nt) {
+        const uint32_t code = static_cast<uint32_t>(std::atoi(force_nt));
+#ifdef SIXDOF_AB_BUILD
+        policy = code;
+#else
+        // the product library carries the three safe policies only (plain / nt stores / nt both ways, + the late-flush bit)
+        const uint32_t pol = code & 255u;
+        if ((code & ~0x1ffu) == 0 && (pol == 0u || pol == 1u || pol == 9u)) policy = code;
+#endif
+    }
+    P->streaming = policy;
     P->hist_ring = h->hist_ring;
     if (h->hist_ring) {
         P->hist_pos = h->d_hist[0];
@@ -1303,6 +1313,8 @@ int sixdof_prepare_step(sixdof_handle* h, uint64_t n_ticks) {
     const uint32_t K = h->desc.ticks_per_launch;
     P.n_ticks = K;
     uint64_t full = n_ticks / K;
+    // the first RK4 step after an upload takes one eager launch out of `full` (sixdof_step: accel_in_check)
+    if (h->accel_is_host_data && h->desc.integrator == SIXDOF_INTEGRATOR_RK4 && full > 0) full -= 1;
     hipGraphExec_t unused = nullptr;
     if (full >= kGraphLen && (rc = ensure_graph(h, P, K, kGraphLen, &unused)) != SIXDOF_OK) return rc;
     if (kGraphLong && full >= kGraphLen + 4 * kGraphLong) {
@@ -1433,6 +1445,7 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
             // steady-state device work too, not eager launches racing the host.
             hipGraphExec_t big = nullptr, tail = nullptr, longer = nullptr;
             uint64_t n_long = 0;
+            const uint64_t eager_before = launches;
             if (kGraphLong && full >= kGraphLen + 4 * kGraphLong) {   // open with one short chain, then long ones (long batches only:
                                                                     // 200 launches as 32 + 128 + 40 measured 5 % slower)
                 int grc = ensure_graph(h, P, K, kGraphLong, &longer);
@@ -1470,7 +1483,7 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
                 full -= tail_len;
                 launches += tail_len;
             }
-            graph_launches = launches;
+            graph_launches = launches - eager_before;
         }
         h->last.graph_launches = graph_launches;
         ticks_issued = launches * K;
@@ -1592,6 +1605,7 @@ void sixdof_tick(const uint8_t* const* inputs, uint8_t* const* outputs) {
         else if (in[i] == h->id_dt) std::memcpy(&h->desc.simulation_time_step, inputs[i], 8);
         else if (Column* c = h->col(in[i])) {
             if (c->bytes) hipMemcpyAsync(c->dev, inputs[i], c->bytes, hipMemcpyHostToDevice, h->stream);
+            if (in[i] == h->id_accel) h->accel_is_host_data = true;   // a_in is host data on every TickFn call (rk4.rs:96-100)
             if (c->joined && c->compact)
                 launch_gather_rows(c->compact, c->dev, c->d_rows, static_cast<uint32_t>(h->joined_ids.size()),
                                    static_cast<uint32_t>(c->width), c->elem, h->stream);

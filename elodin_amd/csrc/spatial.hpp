@@ -71,11 +71,14 @@ __device__ __forceinline__ Spatial<T> operator+(Spatial<T> a, Spatial<T> b) {
 
 // 1/x for the once-per-launch reciprocal mass / inertia: v_rcp_f64 + two Newton steps (each squares the error, so
 // the result is correctly rounded or 1 ulp off) = 5 instructions against the 11 of an IEEE f64 divide.
+// x = 0 and x = +-inf (a static anchor's mass) keep the seed (+-inf, +-0) — what `1 / x` gives and what the reference's
+// `f / m` then produces (0 for an infinite mass); the refinement alone would turn both into NaN (0 * inf).
 __device__ __forceinline__ double recip(double x) {
-    double r = __builtin_amdgcn_rcp(x);
+    const double r0 = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r0, 1.0);
+    double r = fma(e, r0, r0);
     r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
+    return e == e ? r : r0;
 }
 __device__ __forceinline__ float recip(float x) { return 1.0f / x; }
 // 1/sqrt(x) for finite x > 0: hardware v_rsq_f64 seed plus one cubic correction (y0 (1 + e/2 + 3e^2/8), e = 1 - x y0^2):

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     constexpr std::integral_constant<int, POL> kLive{};   // cache policy of the live columns
     constexpr std::integral_constant<int, 1> kRing{};     // history ring slots are write-once: non-temporal stores
 
-    const bool record = P.hist_pos != nullptr;  // wave-uniform: stream every tick's outputs to the history ring
+    const bool record = P.hist_pos != nullptr && P.hist_ring != 0;  // wave-uniform: stream every tick's outputs to the history ring
     // At one tick per launch the launch is a latency chain (dispatch -> loads -> math -> stores -> write-back), so on
     // the LAST tick of a launch every output column is staged and stored the moment its rows exist instead of all four
     // after the tick: world_pos is known before the last stage's force evaluation (the stage positions never see a
@@ -449,17 +449,21 @@ inline void launch_i(const StepParams& p, int integrator, dim3 grid, hipStream_t
     } else hipLaunchKernelGGL((sixdof_step_kernel<T, kSemiImplicit, PIPE, POL>), grid, dim3(kWave), 0, s, p);
 }
 
-// StepParams::streaming is the cache-policy code (load * 8 + store).  Every pipe has the three shipped policies;
-// SWEEP adds the rest of the matrix for A/B runs (tools/step_ab.py) on the pipes that ask for it.
+// StepParams::streaming is the cache-policy code (load * 8 + store).  Every pipe has the three shipped policies
+// (plain, nt stores, nt both ways) and the product library has nothing else; an A/B build (-DSIXDOF_AB_BUILD) adds the
+// rest of the matrix (SWEEP, tools/step_ab.py) on the pipes that ask for it.
 template <class T, class PIPE, bool SWEEP>
 inline void launch_t(const StepParams& p, int integrator, dim3 grid, hipStream_t s) {
     const uint32_t pol = p.streaming & 255u;   // bit 8 = late flush (A/B knob), see the kernel
     switch (pol) {
     case kPolNt: return launch_i<T, PIPE, kPolNt>(p, integrator, grid, s);
     case kPolNtStores: return launch_i<T, PIPE, kPolNtStores>(p, integrator, grid, s);
-    case kPolSc1Stores: return launch_i<T, PIPE, kPolSc1Stores>(p, integrator, grid, s);   // UNSAFE across launches (stale reads), A/B and demonstration only: never chosen by the library
     default: break;
     }
+#ifdef SIXDOF_AB_BUILD
+    // A/B library only (make ab -> libsixdof_hip_ab.so, never shipped).  kPolSc1Stores is UNSAFE across launches
+    // (the next launch reads stale rows, profiles/r02_sc1_store_policy_is_unsafe.txt): it exists to demonstrate that.
+    if (pol == kPolSc1Stores) return launch_i<T, PIPE, kPolSc1Stores>(p, integrator, grid, s);
     if constexpr (SWEEP) {
         switch (pol) {
         case 3: return launch_i<T, PIPE, 3>(p, integrator, grid, s);
@@ -471,6 +475,7 @@ inline void launch_t(const StepParams& p, int integrator, dim3 grid, hipStream_t
         default: break;
         }
     }
+#endif
     launch_i<T, PIPE, kPolPlain>(p, integrator, grid, s);
 }
 

@@ -63,7 +63,7 @@ _lib = None
 
 
 def use_native_build() -> Path:
-    """bench.py's cpu_baseline: (re)build the oracle -O3 -march=native ON THIS MACHINE (oracle/Makefile `native`) and bind
+    """bench.py's cpu_baseline: (re)build the oracle -O3 -march=native -fno-tree-vectorize ON THIS MACHINE (oracle/Makefile `native`) and bind
     to it from here on.  Returns the library path actually in use (the portable -O2 build if the native one fails)."""
     global _lib, LIB_PATH
     native = HERE / "_native" / "libsixdof_oracle_native.so"

@@ -605,3 +605,55 @@ def test_non_finite_world_accel_input_poisons_the_tick_like_the_reference(path):
         # NaN, and calc_accel carries the linear half through the attitude (six_dof.rs:137-146), so its velocity goes too.
         assert np.isfinite(hip.world_pos[[0, 8, 150]]).all() and np.isfinite(hip.world_vel[[7, 299]]).all()
         assert np.isnan(hip.world_vel[100]).all()
+
+
+@pytest.mark.parametrize("integrator", [L.RK4, L.SEMI_IMPLICIT])
+def test_infinite_and_zero_mass_rows_follow_the_reference_division(integrator):
+    """six_dof.rs:137-146 divides: a static anchor (mass and inertia +inf) gets acceleration f / inf = 0 and keeps
+    coasting; zero mass under a non-zero force gets +-inf.  The kernel multiplies by a reciprocal computed once per launch
+    (spatial.hpp `recip`), whose Newton refinement must not turn those into NaN.  A constant world-frame force and a
+    body-frame torque, so no effector multiplies by the mass."""
+    n = 200
+    w = workloads.independent_bodies(n)
+    inertia = w["inertia"].copy()
+    inertia[3, 6] = np.inf                 # infinite mass only
+    inertia[50, [0, 1, 2, 6]] = np.inf     # a static anchor
+    inertia[120, 1] = np.inf               # one infinite principal moment
+    inertia[199, 6] = 0.0                  # zero mass under a force
+    eff = [ea.Effector(L.EFF_CONST_WRENCH, (0.0, 0.0, 0.0, 1.0, -2.0, 3.0)), ea.Effector(L.EFF_BODY_TORQUE, (), aux_name="body_torque", aux=w["body_torque"])]
+    hip = ea.HipExec(w["world_pos"], w["world_vel"], inertia, simulation_time_step=workloads.DT_120HZ, effectors=eff, integrator=integrator)
+    ref = orc.OracleWorld(w["world_pos"], w["world_vel"], inertia, simulation_time_step=workloads.DT_120HZ, ops=parity.to_oracle_ops(eff),
+                          integrator=integrator)
+    hip.run(5)
+    ref.step(5)
+    for f in parity.FIELDS:
+        g, r = getattr(hip, f), getattr(ref, f)
+        assert np.array_equal(np.isfinite(g), np.isfinite(r)), (f, np.argwhere(np.isfinite(g) != np.isfinite(r))[:5])
+        assert np.array_equal(np.isnan(g), np.isnan(r)), f
+    ok = np.isfinite(ref.world_pos).all(axis=1) & np.isfinite(ref.world_vel).all(axis=1) & np.isfinite(ref.world_accel).all(axis=1)
+    assert ok[[3, 50, 120]].all() and not ok[199]
+    assert np.all(hip.world_accel[50] == 0.0) and np.all(hip.world_accel[3, 3:] == 0.0)
+    for f in parity.FIELDS:
+        g, r = getattr(hip, f)[ok], getattr(ref, f)[ok]
+        err = parity.pos_rel_err(g, r) if f == "world_pos" else max(parity.field_rel_err(g[:, :3], r[:, :3]), parity.field_rel_err(g[:, 3:], r[:, 3:]))
+        assert err < parity.F64_RTOL, (f, err)
+
+
+def test_unsafe_cache_policy_is_not_selectable_in_the_product_library():
+    """SIXDOF_STREAMING=2 (write-through `sc1` stores: stale rows in the next launch, profiles/r02_sc1_store_policy_is_unsafe.txt)
+    is compiled into the A/B library only; the product ignores the code, so 256 one-tick launches at the size where the
+    policy failed equal a fused run bit for bit."""
+    import os
+    n, ticks = 262_144, 256
+    w = workloads.independent_bodies(n)
+    eff = workloads.gravity_torque_effectors(w["body_torque"])
+    fused = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ, effectors=eff, ticks_per_launch=ticks)
+    fused.run(ticks)
+    os.environ["SIXDOF_STREAMING"] = "2"
+    try:
+        one = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ, effectors=eff, ticks_per_launch=1, use_graph=True)
+        one.run(ticks)
+    finally:
+        del os.environ["SIXDOF_STREAMING"]
+    for f in parity.FIELDS:
+        assert np.array_equal(getattr(one, f), getattr(fused, f)), f

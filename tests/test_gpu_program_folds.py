@@ -259,3 +259,32 @@ def test_folds_between_a_body_and_plain_entities_through_world_build():
         assert np.array_equal(a.column_array(name), b.column_array(name)), name
     assert a.column_array("seen").max() > 0 and np.abs(a.column_array("estimate")).sum() > 0.1
     assert np.linalg.norm(a.column_array("world_vel")[0][:3] - [0.02, -0.01, 0.03]) > 1e-6     # the control torque acted
+
+
+@pytest.mark.parametrize("k", [1, 4])
+def test_history_ring_on_a_program_with_folds_records_every_tick_once(k):
+    """Only the LAST link of a staged tick records (codegen: the other links get no ring and no ring pointers — a link
+    with pointers but ring length 0 used to take `slot % 0`): every tick's row in the ring equals the state a run stopped
+    at that tick reads back, and nothing outside the ring is written (the run completes and the live columns agree)."""
+    w, comps, edges, ids = _world(2)
+
+    def make():
+        prog = dsl.Program([sun_direction, sensor_reading, sun_estimate, point_at_sun], apply_torque | dsl.pipe(),
+                           [log_alignment, echo_to_sensors, count_seen])
+        return ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], entity_ids=ids, simulation_time_step=workloads.DT_120HZ,
+                          integrator=L.RK4, effectors=prog, columns={n_: v.copy() for n_, v in comps.items()}, graph_edges=edges,
+                          ticks_per_launch=k)
+    ticks = 12
+    rec = make()
+    rec.enable_history(16)
+    rec.run(ticks)
+    hist = {f: rec.history(f, 1, ticks) for f in ("world_pos", "world_vel", "world_accel", "force")}
+    hist_log = rec.history("log", 1, ticks)
+    plain = make()
+    for t in range(1, ticks + 1):
+        plain.run(1)
+        for f in hist:
+            assert np.array_equal(hist[f][t - 1], getattr(plain, f)), (f, t)
+        assert np.array_equal(hist_log[t - 1], plain.component("log")), t
+    for f in hist:
+        assert np.array_equal(getattr(rec, f), getattr(plain, f)), f

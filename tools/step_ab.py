@@ -2,11 +2,17 @@
 
     python tools/step_ab.py [n ...]      # default 65536
 Prints us/launch (HIP events around graph-replayed batches, best of 5) and algorithmic GB/s (384 B x n per launch).
-Policy code = load * 8 + store (csrc/step_kernel.hpp); the library ships 0, 2 and 9, the rest of the matrix is compiled
-for the config-2 pipe only.
+Policy code = load * 8 + store (csrc/step_kernel.hpp); the product library ships 0, 1 and 9 and ignores every other code.
+The rest of the matrix (incl. the UNSAFE sc1 stores) exists in the A/B library only: `make -C elodin_amd/csrc ab`, which
+this script loads through SIXDOF_LIBRARY.
 """
 import os
 import sys
+
+_AB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "elodin_amd", "libsixdof_hip_ab.so")
+if not os.path.exists(_AB):
+    sys.exit("build the A/B library first: make -C elodin_amd/csrc ab")
+os.environ.setdefault("SIXDOF_LIBRARY", _AB)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
