@@ -1312,17 +1312,25 @@ int sixdof_prepare_step(sixdof_handle* h, uint64_t n_ticks) {
     if (rc != SIXDOF_OK) return rc;
     const uint32_t K = h->desc.ticks_per_launch;
     P.n_ticks = K;
-    uint64_t full = n_ticks / K;
-    // the first RK4 step after an upload takes one eager launch out of `full` (sixdof_step: accel_in_check)
-    if (h->accel_is_host_data && h->desc.integrator == SIXDOF_INTEGRATOR_RK4 && full > 0) full -= 1;
-    hipGraphExec_t unused = nullptr;
-    if (full >= kGraphLen && (rc = ensure_graph(h, P, K, kGraphLen, &unused)) != SIXDOF_OK) return rc;
-    if (kGraphLong && full >= kGraphLen + 4 * kGraphLong) {
-        if ((rc = ensure_graph(h, P, K, kGraphLong, &unused)) != SIXDOF_OK) return rc;
-        full = (full - kGraphLen) % kGraphLong;     // what the opening chain and the long ones leave
-    }
-    const uint32_t tail_len = static_cast<uint32_t>(full % kGraphLen);
-    if (full >= kGraphMinLen && tail_len >= kGraphMinLen && (rc = ensure_graph(h, P, K, tail_len, &unused)) != SIXDOF_OK) return rc;
+    // the chains a batch of `full` K-tick launches replays (the same arithmetic as sixdof_step)
+    auto prepare = [&](uint64_t full) -> int {
+        hipGraphExec_t unused = nullptr;
+        int prc;
+        if (full >= kGraphLen && (prc = ensure_graph(h, P, K, kGraphLen, &unused)) != SIXDOF_OK) return prc;
+        if (kGraphLong && full >= kGraphLen + 4 * kGraphLong) {
+            if ((prc = ensure_graph(h, P, K, kGraphLong, &unused)) != SIXDOF_OK) return prc;
+            full = (full - kGraphLen) % kGraphLong;     // what the opening chain and the long ones leave
+        }
+        const uint32_t tail_len = static_cast<uint32_t>(full % kGraphLen);
+        if (full >= kGraphMinLen && tail_len >= kGraphMinLen && (prc = ensure_graph(h, P, K, tail_len, &unused)) != SIXDOF_OK) return prc;
+        return SIXDOF_OK;
+    };
+    const uint64_t full = n_ticks / K;
+    if ((rc = prepare(full)) != SIXDOF_OK) return rc;
+    // the first RK4 step after an upload takes one eager launch out of `full` (sixdof_step: accel_in_check), so that
+    // batch replays `full - 1` launches; whether the batch being prepared is that one the library cannot know (a warm-up
+    // may come first), so both shapes are captured
+    if (h->accel_is_host_data && h->desc.integrator == SIXDOF_INTEGRATOR_RK4 && full > 0 && (rc = prepare(full - 1)) != SIXDOF_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SIXDOF_OK;
 }

@@ -71,16 +71,19 @@ __device__ __forceinline__ Spatial<T> operator+(Spatial<T> a, Spatial<T> b) {
 
 // 1/x for the once-per-launch reciprocal mass / inertia: v_rcp_f64 + two Newton steps (each squares the error, so
 // the result is correctly rounded or 1 ulp off) = 5 instructions against the 11 of an IEEE f64 divide.
-// x = 0 and x = +-inf (a static anchor's mass) keep the seed (+-inf, +-0) — what `1 / x` gives and what the reference's
-// `f / m` then produces (0 for an infinite mass); the refinement alone would turn both into NaN (0 * inf).
+// The two values a Newton step cannot handle (0 * inf) follow what the reference's calc_accel PRODUCES for them
+// (six_dof.rs:137-146, a = q * ((q^-1 * f) / m)): m = +-inf (a static anchor) divides to 0 and stays 0 through the
+// rotation -> the reciprocal is 0; m = 0 divides to +-inf (or 0/0), and rotating a vector with infinite components forms
+// inf * u - inf * u' -> the reference's acceleration is NaN in every component, whatever the attitude -> the reciprocal is
+// NaN (a bare 1/0 = inf would leave a +-inf acceleration where the reference has NaN).  Same rule in both dtypes.
 __device__ __forceinline__ double recip(double x) {
     const double r0 = __builtin_amdgcn_rcp(x);
     const double e = fma(-x, r0, 1.0);
     double r = fma(e, r0, r0);
     r = fma(fma(-x, r, 1.0), r, r);
-    return e == e ? r : r0;
+    return e == e ? r : (r0 == 0.0 ? r0 : __builtin_nan(""));
 }
-__device__ __forceinline__ float recip(float x) { return 1.0f / x; }
+__device__ __forceinline__ float recip(float x) { return x == 0.0f ? __builtin_nanf("") : 1.0f / x; }
 // 1/sqrt(x) for finite x > 0: hardware v_rsq_f64 seed plus one cubic correction (y0 (1 + e/2 + 3e^2/8), e = 1 - x y0^2):
 // full f64 accuracy in 5 instructions, without the 0 / inf / denormal special-casing of the library rsqrt (4 more
 // instructions and a v_cmp_class per call).  Arguments here are squared norms of quaternions (~1) and softened pair

@@ -52,7 +52,7 @@ class _World(C.Structure):
 
 def build(force: bool = False) -> Path:
     """Compile the oracle with gcc (no-FMA).  Building the checker is not using it."""
-    newest = max((HERE / f).stat().st_mtime for f in ("sixdof_oracle.c", "apollo_oracle.c", "sixdof_oracle.h", "apollo_oracle.h"))
+    newest = max((HERE / f).stat().st_mtime for f in ("sixdof_oracle.c", "apollo_oracle.c", "falcon9_fsw.c", "sixdof_oracle.h", "apollo_oracle.h", "falcon9_fsw.h"))
     if force or not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < newest:
         subprocess.run(["make", "-C", str(HERE), "-B", "libsixdof_oracle.so"], check=True,
                        stdout=subprocess.DEVNULL)

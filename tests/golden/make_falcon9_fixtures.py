@@ -185,13 +185,59 @@ def flat(s):
     return out
 
 
+def plant_tick(s, tick, S=None):
+    """ONE tick of build_powered's plant (sim.py:1433-1530) on the component dict `s`, in the reference's pipe order:
+    propulsion_systems | six_dof(gravity_and_frame_forces | apply_body_wrenches, SemiImplicit) | pad_clamp |
+    ground_contact | derive_geodetic_telemetry.  `S` maps a system name to the callable to use for it (the closures
+    make_engine_dynamics / make_wind_model / make_aero_dynamics build per rollout); everything else is sim.<name>."""
+    S = S or {}
+    g = lambda name: S.get(name) or getattr(sim, name)
+    s["tvc_cmd"], s["rcs_torque_cmd"] = g("attitude_control")(s["world_pos"], s["world_vel"], s["attitude_setpoint"], s["ctrl_enable"],
+                                                              s["inertia"], s["thrust_total"], s["cg_station"], s["fsw_phase"])
+    s["valve_state"] = g("valve_dynamics")(s["valve_state"], s["valve_cmd"])
+    s["tvc_state"] = g("tvc_actuators")(s["tvc_state"], s["tvc_cmd"])
+    s["fin_state"] = g("fin_actuators")(s["fin_state"], s["fin_cmd"])
+    (s["engine_spool"], s["engine_armed"], s["teateb_charges"], s["thrust_total"], s["mdot_total"]) = g("engine_dynamics")(
+        s["world_pos"], s["engine_cmd"], s["engine_spool"], s["engine_armed"], s["teateb_charges"], s["valve_state"],
+        s["propellant_lox"], s["propellant_rp1"])
+    (s["propellant_lox"], s["propellant_rp1"], s["inertia"], s["cg_station"], s["axial_specific_force"]) = g("mass_props")(
+        s["mdot_total"], s["propellant_lox"], s["propellant_rp1"], s["thrust_total"], s["upper_mass"])
+    (s["tank_pressure_lox"], s["tank_pressure_rp1"], s["inlet_pressure_lox"], s["inlet_pressure_rp1"]) = g("tank_dynamics")(
+        s["tank_pressure_lox"], s["tank_pressure_rp1"], s["propellant_lox"], s["propellant_rp1"], s["mdot_total"],
+        s["valve_state"], s["axial_specific_force"], s["cg_station"])
+    s["rcs_levels"], s["rcs_wrench"], s["nitrogen_kg"] = g("rcs_dynamics")(s["rcs_levels"], s["rcs_torque_cmd"], s["cg_station"], s["nitrogen_kg"])
+    s["engine_wrench"] = g("engine_wrench")(s["thrust_total"], s["tvc_state"], s["cg_station"])
+    s["leg_wrench"] = g("leg_contact_wrench")(s["world_pos"], s["world_vel"], s["cg_station"], s["lifted"], s["landed"])
+    assert not np.any(np.asarray(s["leg_wrench"])), "legs must be inactive in these windows"
+    s["wind_ecef"], s["wind_gust_ned"] = g("wind_model")(s["world_pos"], s["wind_ecef"], s["wind_gust_ned"], A1(tick))
+    s["qbar"], s["mach"], s["aero_wrench"], s["fin_wrench"] = g("aero_dynamics")(s["world_pos"], s["world_vel"], s["wind_ecef"],
+                                                                                 s["thrust_total"], s["fin_state"], s["cg_station"])
+    # six_dof(sys = gravity_and_frame_forces | apply_body_wrenches, SemiImplicit): six_dof.rs:137-150,176-180
+    F = el.SpatialForce()
+    F = g("gravity_and_frame_forces")(F, s["inertia"], s["world_pos"], s["world_vel"])
+    F = g("apply_body_wrenches")(s["engine_wrench"], s["aero_wrench"], s["fin_wrench"], s["rcs_wrench"], s["leg_wrench"], F, s["world_pos"])
+    x, v = s["world_pos"].asarray(), s["world_vel"].asarray()
+    a = orc.calc_accel(F.asarray(), s["inertia"].asarray(), x)
+    v = v + DT * a                                                      # semi_implicit.rs:17-31
+    x = orc.transform_add_motion(x, DT * v)
+    s["world_pos"], s["world_vel"] = el.SpatialTransform(x), el.SpatialMotion(angular=v[:3], linear=v[3:])
+    s["world_accel"], s["force"] = a, F.asarray()
+    # pad_clamp | ground_contact | derive_geodetic_telemetry, sim.py:1511-1530
+    s["world_pos"], s["world_vel"], s["lifted"], s["liftoff_time"] = g("pad_clamp")(
+        refshim._Query(float(tick)), refshim._Query(s["world_pos"], s["world_vel"], s["lifted"], s["liftoff_time"], s["thrust_total"], s["inertia"]))
+    gp, gv, landed, tm, dm = g("ground_contact")(s["world_pos"], s["world_vel"], s["landed"], s["touchdown_metrics"], s["deck_metrics"],
+                                                 s["lifted"], s["tvc_state"], s["cg_station"])
+    assert float(np.asarray(landed).reshape(-1)[0]) == 0.0 and np.array_equal(gp.asarray(), s["world_pos"].asarray()) \
+        and np.array_equal(gv.asarray(), s["world_vel"].asarray()), "ground contact must be a no-op in these windows"
+    s["altitude_geodetic"], s["ground_speed"] = g("derive_geodetic_telemetry")(s["world_pos"], s["world_vel"])
+
+
 def run_case(case):
     c = fs.CASES[case]
     s, att0 = spawn(case)
     script = fs.make_script(case, att0.vector())
-    engine_dynamics = sim.make_engine_dynamics(c["thrust_scale"], c["isp_scale"])
-    wind_model = sim.make_wind_model(*c["wind_ned"], 0.0)
-    aero_dynamics = sim.make_aero_dynamics(c["ca_scale"], c["cn_scale"])
+    S = dict(engine_dynamics=sim.make_engine_dynamics(c["thrust_scale"], c["isp_scale"]), wind_model=sim.make_wind_model(*c["wind_ned"], 0.0),
+             aero_dynamics=sim.make_aero_dynamics(c["ca_scale"], c["cn_scale"]))
     init = flat(s)
     checkpoints = []
     for tick in range(1, c["ticks"] + 1):
@@ -199,45 +245,7 @@ def run_case(case):
         cmd = script(jnp, t)
         for k, v in cmd.items():
             s[k] = el.Quaternion(v) if k == "attitude_setpoint" else jnp.asarray(v)
-        # propulsion_systems, sim.py:1433-1458
-        s["tvc_cmd"], s["rcs_torque_cmd"] = sim.attitude_control(s["world_pos"], s["world_vel"], s["attitude_setpoint"], s["ctrl_enable"],
-                                                                 s["inertia"], s["thrust_total"], s["cg_station"], s["fsw_phase"])
-        s["valve_state"] = sim.valve_dynamics(s["valve_state"], s["valve_cmd"])
-        s["tvc_state"] = sim.tvc_actuators(s["tvc_state"], s["tvc_cmd"])
-        s["fin_state"] = sim.fin_actuators(s["fin_state"], s["fin_cmd"])
-        (s["engine_spool"], s["engine_armed"], s["teateb_charges"], s["thrust_total"], s["mdot_total"]) = engine_dynamics(
-            s["world_pos"], s["engine_cmd"], s["engine_spool"], s["engine_armed"], s["teateb_charges"], s["valve_state"],
-            s["propellant_lox"], s["propellant_rp1"])
-        (s["propellant_lox"], s["propellant_rp1"], s["inertia"], s["cg_station"], s["axial_specific_force"]) = sim.mass_props(
-            s["mdot_total"], s["propellant_lox"], s["propellant_rp1"], s["thrust_total"], s["upper_mass"])
-        (s["tank_pressure_lox"], s["tank_pressure_rp1"], s["inlet_pressure_lox"], s["inlet_pressure_rp1"]) = sim.tank_dynamics(
-            s["tank_pressure_lox"], s["tank_pressure_rp1"], s["propellant_lox"], s["propellant_rp1"], s["mdot_total"],
-            s["valve_state"], s["axial_specific_force"], s["cg_station"])
-        s["rcs_levels"], s["rcs_wrench"], s["nitrogen_kg"] = sim.rcs_dynamics(s["rcs_levels"], s["rcs_torque_cmd"], s["cg_station"], s["nitrogen_kg"])
-        s["engine_wrench"] = sim.engine_wrench(s["thrust_total"], s["tvc_state"], s["cg_station"])
-        s["leg_wrench"] = sim.leg_contact_wrench(s["world_pos"], s["world_vel"], s["cg_station"], s["lifted"], s["landed"])
-        assert not np.any(np.asarray(s["leg_wrench"])), "legs must be inactive in these windows"
-        s["wind_ecef"], s["wind_gust_ned"] = wind_model(s["world_pos"], s["wind_ecef"], s["wind_gust_ned"], A1(tick))
-        s["qbar"], s["mach"], s["aero_wrench"], s["fin_wrench"] = aero_dynamics(s["world_pos"], s["world_vel"], s["wind_ecef"],
-                                                                                s["thrust_total"], s["fin_state"], s["cg_station"])
-        # six_dof(sys = gravity_and_frame_forces | apply_body_wrenches, SemiImplicit): six_dof.rs:137-150,176-180
-        F = el.SpatialForce()
-        F = sim.gravity_and_frame_forces(F, s["inertia"], s["world_pos"], s["world_vel"])
-        F = sim.apply_body_wrenches(s["engine_wrench"], s["aero_wrench"], s["fin_wrench"], s["rcs_wrench"], s["leg_wrench"], F, s["world_pos"])
-        x, v = s["world_pos"].asarray(), s["world_vel"].asarray()
-        a = orc.calc_accel(F.asarray(), s["inertia"].asarray(), x)
-        v = v + DT * a                                                      # semi_implicit.rs:17-31
-        x = orc.transform_add_motion(x, DT * v)
-        s["world_pos"], s["world_vel"] = el.SpatialTransform(x), el.SpatialMotion(angular=v[:3], linear=v[3:])
-        s["world_accel"], s["force"] = a, F.asarray()
-        # pad_clamp | ground_contact | derive_geodetic_telemetry, sim.py:1511-1530
-        s["world_pos"], s["world_vel"], s["lifted"], s["liftoff_time"] = sim.pad_clamp(
-            refshim._Query(float(tick)), refshim._Query(s["world_pos"], s["world_vel"], s["lifted"], s["liftoff_time"], s["thrust_total"], s["inertia"]))
-        gp, gv, landed, tm, dm = sim.ground_contact(s["world_pos"], s["world_vel"], s["landed"], s["touchdown_metrics"], s["deck_metrics"],
-                                                    s["lifted"], s["tvc_state"], s["cg_station"])
-        assert float(np.asarray(landed).reshape(-1)[0]) == 0.0 and np.array_equal(gp.asarray(), s["world_pos"].asarray()) \
-            and np.array_equal(gv.asarray(), s["world_vel"].asarray()), "ground contact must be a no-op in these windows"
-        s["altitude_geodetic"], s["ground_speed"] = sim.derive_geodetic_telemetry(s["world_pos"], s["world_vel"])
+        plant_tick(s, tick, S)
         if tick % fs.CHECKPOINT_EVERY == 0 or tick in (1, 2, 10):
             checkpoints.append({"tick": tick, "state": flat(s)})
     print(f"  {case}: {c['ticks']} ticks, final alt {float(s['altitude_geodetic'][0]):.1f} m, speed {float(s['ground_speed'][0]):.2f} m/s, "

@@ -7,8 +7,12 @@ exists here.  Nothing below is product code and nothing under elod
 the GPU box as anything but a dormant file (the generators need /root/reference).
 
 * `jax` / `jax.numpy` / `jax.random` / `jax.lax`: numpy with an ndarray subclass that has `.at[i].set/.add`, a loop
-  `vmap`, and `random.normal` returning zeros (the only call site, the wind gust, multiplies it by sigma = 0 in every
-  configuration used here; a non-zero sigma raises).
+  `vmap`, and `jax.random.key / fold_in / normal` as JAX's default generator computes them: threefry2x32 in the
+  partitionable layout (jax >= 0.5 default; the reference pins jax 0.10.0, libs/nox-py/pyproject.toml:14), 64 random bits
+  per float64 sample, `sqrt(2) * erfinv(uniform(nextafter(-1, 0), 1))`.  JAX itself is not installed; the restatement
+  follows jax/_src/prng.py (`threefry_2x32`, `threefry_fold_in`, `_threefry_random_bits_partitionable`) and
+  jax/_src/random.py (`_uniform`, `_normal_real`), and is anchored on the one reference-held draw there is: the wind row
+  of scripts/ci/baseline/ball-csv (`random.normal(random.key(seed), shape=(3,))`, tests/test_refshim_random.py).
 * `elodin`: decorators that hand back the undecorated function in a callable, `|`-pipeable wrapper (`el.map`,
   `el.system`, `el.six_dof` remembering its effectors), a World that remembers what was spawned, a tiny
   `el.monte_carlo` (params context in, result(...) out), inert declarations for everything else,
@@ -133,6 +137,55 @@ def _vmap(fn):
     return mapped
 
 
+# ---- jax.random (threefry2x32, partitionable layout) -------------------------------------------------------------------
+
+def _threefry2x32(k0, k1, x0, x1):
+    """jax/_src/prng.py `_threefry2x32_lowering`: 20 rounds in five groups of four, key schedule injected after each."""
+    u32 = np.uint32
+    k0, k1 = u32(k0), u32(k1)
+    x0, x1 = np.asarray(x0, dtype=u32).copy(), np.asarray(x1, dtype=u32).copy()
+    ks = (k0, k1, k0 ^ k1 ^ u32(0x1BD11BDA))
+    rotations = ((13, 15, 26, 6), (17, 29, 16, 24))
+    with np.errstate(over="ignore"):
+        x0 += ks[0]
+        x1 += ks[1]
+        for g in range(5):
+            for r in rotations[g % 2]:
+                x0 += x1
+                x1 = (x1 << u32(r)) | (x1 >> u32(32 - r))
+                x1 ^= x0
+            x0 += ks[(g + 1) % 3]
+            x1 += ks[(g + 2) % 3] + u32(g + 1)
+    return x0, x1
+
+
+def _rng_key(seed):
+    """`random.key(seed)` / threefry_seed: the 64-bit seed split into (high, low) uint32 words."""
+    seed = int(seed)
+    return (np.uint32((seed >> 32) & 0xFFFFFFFF), np.uint32(seed & 0xFFFFFFFF))
+
+
+def _rng_fold_in(key, data):
+    """threefry_fold_in: threefry_2x32(key, threefry_seed(uint32(data))) = block (0, data) under `key`."""
+    d = int(np.asarray(data).astype(np.int64)) & 0xFFFFFFFF
+    x0, x1 = _threefry2x32(key[0], key[1], np.array([0], dtype=np.uint32), np.array([d], dtype=np.uint32))
+    return (np.uint32(x0[0]), np.uint32(x1[0]))
+
+
+def _rng_normal(key, shape=(), dtype=np.float64):
+    """_normal_real for float64: counters (hi = 0, lo = i) -> 64 bits each -> mantissa = bits >> 12 -> [1, 2) - 1 ->
+    uniform on [nextafter(-1, 0), 1) -> sqrt(2) * erfinv."""
+    from scipy.special import erfinv
+    n = int(np.prod(shape)) if shape else 1
+    hi, lo = _threefry2x32(key[0], key[1], np.zeros(n, dtype=np.uint32), np.arange(n, dtype=np.uint32))
+    bits = (hi.astype(np.uint64) << np.uint64(32)) | lo.astype(np.uint64)
+    floats = ((bits >> np.uint64(12)) | np.uint64(0x3FF0000000000000)).view(np.float64) - 1.0
+    lo_ = np.nextafter(-1.0, 0.0)
+    u = np.maximum(lo_, floats * (1.0 - lo_) + lo_)
+    z = np.sqrt(2.0) * erfinv(u)
+    return (z.reshape(shape) if shape else np.float64(z[0])).view(JArray) if shape else np.float64(z[0])
+
+
 def _make_jax():
     jax = types.ModuleType("jax")
     jnp = _JnpModule()
@@ -141,11 +194,10 @@ def _make_jax():
     jax.vmap = _vmap
     jax.config = types.SimpleNamespace(update=lambda *a, **k: None)
     rnd = types.ModuleType("jax.random")
-    rnd.key = lambda seed: int(seed)
-    rnd.PRNGKey = rnd.key
-    rnd.fold_in = lambda key, data: (int(key), int(data))
-    # the only consumer (examples/falcon9/sim.py:603-606 wind gust) scales the draw by sigma; the fixtures keep sigma = 0
-    rnd.normal = lambda key, shape=(): np.zeros(shape).view(JArray)
+    rnd.key = _rng_key
+    rnd.PRNGKey = _rng_key
+    rnd.fold_in = _rng_fold_in
+    rnd.normal = _rng_normal
     jax.random = rnd
     lax = types.ModuleType("jax.lax")
     lax.cond = lambda pred, t, f, *ops: (t(*ops) if bool(pred) else f(*ops))

@@ -610,8 +610,9 @@ def test_non_finite_world_accel_input_poisons_the_tick_like_the_reference(path):
 @pytest.mark.parametrize("integrator", [L.RK4, L.SEMI_IMPLICIT])
 def test_infinite_and_zero_mass_rows_follow_the_reference_division(integrator):
     """six_dof.rs:137-146 divides: a static anchor (mass and inertia +inf) gets acceleration f / inf = 0 and keeps
-    coasting; zero mass under a non-zero force gets +-inf.  The kernel multiplies by a reciprocal computed once per launch
-    (spatial.hpp `recip`), whose Newton refinement must not turn those into NaN.  A constant world-frame force and a
+    coasting; zero mass gives +-inf components that the reference then ROTATES (q * ((q^-1 f) / m)), i.e. NaN.  The kernel
+    multiplies by a reciprocal computed once per launch (spatial.hpp `recip`), whose Newton refinement must not turn the
+    anchor into NaN and whose 1/0 must end where the reference does.  A constant world-frame force and a
     body-frame torque, so no effector multiplies by the mass."""
     n = 200
     w = workloads.independent_bodies(n)
@@ -631,7 +632,7 @@ def test_infinite_and_zero_mass_rows_follow_the_reference_division(integrator):
         assert np.array_equal(np.isfinite(g), np.isfinite(r)), (f, np.argwhere(np.isfinite(g) != np.isfinite(r))[:5])
         assert np.array_equal(np.isnan(g), np.isnan(r)), f
     ok = np.isfinite(ref.world_pos).all(axis=1) & np.isfinite(ref.world_vel).all(axis=1) & np.isfinite(ref.world_accel).all(axis=1)
-    assert ok[[3, 50, 120]].all() and not ok[199]
+    assert ok[[3, 50, 120]].all() and not ok[199] and np.isnan(hip.world_accel[199, 3:]).all()
     assert np.all(hip.world_accel[50] == 0.0) and np.all(hip.world_accel[3, 3:] == 0.0)
     for f in parity.FIELDS:
         g, r = getattr(hip, f)[ok], getattr(ref, f)[ok]
