@@ -283,16 +283,45 @@ def emit_apply(tp: dsl.TracedPipe) -> List[str]:
     return emit_block(list(zip(names, tp.outputs)), _APPLY_LEAVES)
 
 
-def _emit_systems(systems) -> str:
+def _col_slots(names) -> set:
+    return {int(n[1:].split("_")[0]) for n in names if n[0] == "c" and "_" in n and n[1:].split("_")[0].isdigit()}
+
+
+def _cold_slots(tp, pipe_tp, pre, post, reg_cols) -> Dict[int, int]:
+    """Program columns that only CADENCED systems (`every > 1`) touch: {slot: width}.  They need not occupy registers
+    across the ticks in between — a guidance computer's navigator state, say, is read and written on every 10th tick only —
+    so the cadence block loads them from their HBM column on entry and stores what it wrote on exit (same lane, program
+    order: later blocks see the stores), and the launch-level load / store skips them.  On the Falcon 9 program that takes
+    31 values (62 f64 registers) out of the tick loop."""
+    if os.environ.get("SIXDOF_NO_COLD_COLUMNS", "") == "1":
+        return {}
+    hot = _col_slots(dsl._leaves_of(list(pipe_tp.outputs))) if pipe_tp is not None else set()
+    touched = set()
+    for s_ in pre + post:
+        slots = _col_slots(dsl._leaves_of([e for _, e in s_.assign])) | _col_slots(s_.written)
+        touched |= slots
+        if s_.every <= 1:
+            hot |= slots
+    return {k: w for k, w in reg_cols if k in touched and k not in hot}
+
+
+def _emit_systems(systems, cold: Optional[Dict[int, int]] = None) -> str:
     out = []
     em = _Emitter(_SYSTEM_LEAVES)
+    cold = cold or {}
     for s in systems:
         assign = [(_leaf_ref(t, _SYSTEM_LEAVES), e) for t, e in s.assign]
         written = [t for t, _ in s.assign]
         if s.every > 1:     # wave-uniform cadence branch: its temporaries stay inside
             body = "\n".join(em.block(assign, "            ", written, scoped=True))
             cond = f"tick % {s.every}ull == {s.phase}ull" + (f" || tick == {s.also_at}ull" if s.also_at is not None else "")
-            out.append(f"        if ({cond}) {{  // {s.name}\n{body}\n        }}")
+            w_slots = sorted(_col_slots(written) & set(cold))
+            r_slots = sorted((_col_slots(dsl._leaves_of([e for _, e in s.assign])) | set(w_slots)) & set(cold))
+            ld = "".join(f"            if (c_act) {{ const T* g = static_cast<const T*>(P.model_cols[{k}]) + (size_t)c_row * {cold[k]}; "
+                         + " ".join(f"r.c{k}[{j}] = g[{j}];" for j in range(cold[k])) + " }\n" for k in r_slots)
+            st = "".join(f"\n            if (c_act) {{ T* g = static_cast<T*>(P.model_cols[{k}]) + (size_t)c_row * {cold[k]}; "
+                         + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(cold[k])) + " }" for k in w_slots)
+            out.append(f"        if ({cond}) {{  // {s.name}\n{ld}{body}{st}\n        }}")
         else:
             body = "\n".join(em.block(assign, "        ", written))
             out.append(f"        // {s.name}\n{body}")
@@ -479,17 +508,22 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
         reg_cols = [(k, w) for k, (_, w) in enumerate(cols) if k not in _WINDOWS and (used is None or k in used)]     # windows stay in HBM
         written = sorted(_slots_of(pre + post) & {int(t[1:].split("_")[0]) for s_ in pre + post for t in s_.written if t[0] == "c"}) \
             if used is not None else list(tp.written_slots)
-        regs = "\n".join(f"        T c{k}[{w}];" for k, w in reg_cols)
+        cold = _cold_slots(tp, pipe_tp, pre, post, reg_cols)
+        regs = "\n".join(f"        T c{k}[{w}];" + ("   // cold: lives in its HBM column between cadence blocks" if k in cold else "") for k, w in reg_cols)
         loads = "\n".join(
             f"            {{ const T* g = static_cast<const T*>(P.model_cols[{k}]) + (size_t)row * {w}; "
-            + " ".join(f"r.c{k}[{j}] = g[{j}];" for j in range(w)) + " }" for k, w in reg_cols)
+            + " ".join(f"r.c{k}[{j}] = g[{j}];" for j in range(w)) + " }" for k, w in reg_cols if k not in cold)
         zero = " ".join(f"for (int j = 0; j < {w}; j++) r.c{k}[j] = T(0);" for k, w in reg_cols)
         stores = "\n".join(
             f"        {{ T* g = static_cast<T*>(P.model_cols[{k}]) + (size_t)row * {cols[k][1]}; "
-            + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(cols[k][1])) + " }" for k in written)
+            + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(cols[k][1])) + " }" for k in written if k not in cold)
         records = "\n".join(
-            f"        if (P.model_hist[{k}]) {{ T* g = static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row) * {w}; "
-            + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(w)) + " }" for k, w in reg_cols)
+            (f"        if (P.model_hist[{k}]) {{ T* g = static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row) * {w}; "
+             f"const T* g0 = static_cast<const T*>(P.model_cols[{k}]) + (size_t)row * {w}; "
+             + " ".join(f"g[{j}] = g0[{j}];" for j in range(w)) + " }") if k in cold else
+            (f"        if (P.model_hist[{k}]) {{ T* g = static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row) * {w}; "
+             + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(w)) + " }") for k, w in reg_cols)
+        cold_setup = ("        const uint32_t c_row = blockIdx.x * kWave + threadIdx.x;\n        const bool c_act = c_row < P.n;\n" if cold else "")
         if _WINDOWS:
             # one lane = one entity, a workgroup is one wave (step_kernel.hpp).  Element e of this lane's window sits at
             # W[e * w_n]: w_n = n for the element-major layout of large executors, 1 (a compile-time constant, so the addresses
@@ -528,13 +562,13 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
     __device__ static __forceinline__ void pre(const StepParams& P, uint64_t tick, Regs<T>& r, Quat<T>& q, Vec3<T>& p,
                                                Spatial<T>& v, Vec3<T>& I, T& mass, const Spatial<T>& accel) {{
         (void)P; (void)tick; (void)accel;
-{win_setup}{_emit_systems(pre)}
+{win_setup}{cold_setup}{_emit_systems(pre, cold)}
     }}
     template <class T>
     __device__ static __forceinline__ void post(const StepParams& P, uint64_t tick, Regs<T>& r, Quat<T>& q, Vec3<T>& p,
                                                 Spatial<T>& v, Vec3<T>& I, T& mass, const Spatial<T>& accel) {{
         (void)P; (void)tick; (void)accel;
-{win_setup}{_emit_systems(post)}
+{win_setup}{cold_setup}{_emit_systems(post, cold)}
     }}'''
     wt = pipe_tp.world_torque if pipe_tp is not None else False
     bt = pipe_tp.body_torque if pipe_tp is not None else False

@@ -16,7 +16,7 @@
 namespace sixdof {
 
 constexpr int kMaxOps = 4;       // per-entity effector ops fused into the step kernel
-constexpr int kMaxModelCols = 48; // component columns a generated program keeps in registers
+constexpr int kMaxModelCols = 64; // component columns a generated program keeps in registers
 constexpr int kBlock = 256;      // threads per workgroup = entities per workgroup (4 waves of 64)
 
 // One effector op as the kernel sees it (sixdof_effector_op with the aux column resolved).
@@ -51,9 +51,11 @@ struct StepParams {
     uint64_t tick0;           // tick count before this launch (generated systems may read the tick)
     uint32_t accel_in_check;  // 1: the world_accel column holds HOST data (first launch after an upload): RK4 stage 0 reads it
     uint32_t reserved0;       //    the way the reference does, v_s = v0 + 0 * a_in (rk4.rs:96-100), so a non-finite row poisons the tick
-    void* model_cols[kMaxModelCols];  // generated programs: device [n,w] component columns, read and written
-    void* model_hist[kMaxModelCols];  // their history rings [ring][n,w] (nullptr = not recorded)
     DevOp ops[kMaxOps];
+    // generated programs only — behind everything the hand-written kernels read, so their kernarg loads stay within the
+    // first 400 bytes whatever kMaxModelCols is
+    void* model_cols[kMaxModelCols];  // device [n,w] component columns, read and written
+    void* model_hist[kMaxModelCols];  // their history rings [ring][n,w] (nullptr = not recorded)
 };
 
 enum : int { kRk4 = 0, kSemiImplicit = 1, kNone = 2 };   // kNone: a pipe of systems without six_dof (generated programs only)

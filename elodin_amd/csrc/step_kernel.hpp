@@ -249,7 +249,12 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     // world_accel row for stage 0; also compile-time, so no other tick carries the branch or the load.
     auto one_tick = [&](auto early_tag, auto check_tag, uint32_t tick) {
         constexpr bool early = decltype(early_tag)::value;
-        constexpr bool check = decltype(check_tag)::value;
+        // hand-written pipes: compile-time.  Generated programs: decided at run time (a wave-uniform branch around one
+        // load), so that their kernel has exactly ONE call site of the tick body — a second copy of a 40,000-instruction
+        // body doubles the code the instruction cache has to stream, and once the body is too big to inline twice the
+        // compiler turns it into a real function whose call spills the whole register state to scratch (4 KB per lane
+        // per tick on the Falcon 9 program).
+        const bool check = decltype(check_tag)::value || (PIPE::kHasModel && P.accel_in_check && tick == 0);
         if constexpr (PIPE::kHasModel) {   // user systems piped in front of six_dof (may rewrite inertia, pose, velocity)
             PIPE::pre(P, P.tick0 + tick + 1, regs, q0, p0, v0, I_diag, mass, A_out);
             if constexpr (PIPE::kWritesInertia) {
@@ -402,12 +407,16 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
         constexpr std::false_type no{};
         constexpr std::true_type yes{};
         uint32_t tick = 0;
-        if constexpr (INTEGRATOR == kRk4 && (CHECK || PIPE::kHasModel))
-            if (P.accel_in_check && P.n_ticks) one_tick(no, yes, tick++);   // once per upload: late flush, speed is no concern
-        for (; tick + 1 < P.n_ticks; tick++) one_tick(no, no, tick);
-        if (tick < P.n_ticks) {
-            if (early_ok) one_tick(yes, no, tick);
-            else one_tick(no, no, tick);
+        if constexpr (PIPE::kHasModel) {
+            for (; tick < P.n_ticks; tick++) one_tick(no, no, tick);        // the one call site (see `check` above)
+        } else {
+            if constexpr (INTEGRATOR == kRk4 && CHECK)
+                if (P.accel_in_check && P.n_ticks) one_tick(no, yes, tick++);   // once per upload: late flush, speed is no concern
+            for (; tick + 1 < P.n_ticks; tick++) one_tick(no, no, tick);
+            if (tick < P.n_ticks) {
+                if (early_ok) one_tick(yes, no, tick);
+                else one_tick(no, no, tick);
+            }
         }
     }
     if constexpr (PIPE::kHasModel) {

@@ -547,6 +547,23 @@ class _Key:
     def __init__(self, k0, k1): self.k0, self.k1 = _lift(k0), _lift(k1)
 
 
+def _threefry2x32_host(k0: int, k1: int, x0: int, x1: int):
+    """threefry2x32 on Python ints (the block function behind jax.random; the generated kernels carry the same rounds as
+    m_threefry, codegen.py): 20 rounds in five groups of four, a key-schedule word injected after each group."""
+    m = 0xFFFFFFFF
+    ks = (k0 & m, k1 & m, (k0 ^ k1 ^ 0x1BD11BDA) & m)
+    rot = ((13, 15, 26, 6), (17, 29, 16, 24))
+    x0, x1 = (x0 + ks[0]) & m, (x1 + ks[1]) & m
+    for g in range(5):
+        for r in rot[g % 2]:
+            x0 = (x0 + x1) & m
+            x1 = ((x1 << r) | (x1 >> (32 - r))) & m
+            x1 ^= x0
+        x0 = (x0 + ks[(g + 1) % 3]) & m
+        x1 = (x1 + ks[(g + 2) % 3] + g + 1) & m
+    return x0, x1
+
+
 class _Random:
     """jax.random for per-entity code, bit-compatible with JAX's default threefry2x32 generator in its partitionable
     layout (the default of the reference's JAX): examples/ball/sim.py:92-94 `random.normal(random.key(seed), shape=(3,))`
@@ -564,6 +581,9 @@ class _Random:
     @staticmethod
     def _threefry(key: _Key, c0, c1):
         args = (key.k0, key.k1, _lift(c0), _lift(c1))
+        if all(a.op == "const" for a in args):       # a constant key folded with a constant (fold_in(key(seed), salt)): done here
+            x0, x1 = _threefry2x32_host(*[int(a.value) for a in args])
+            return const(float(x0)), const(float(x1))
         return Expr("threefry", args, 0), Expr("threefry", args, 1)
 
     @staticmethod
@@ -1301,7 +1321,7 @@ class TracedFoldStage:
 class TracedProgram:
     def __init__(self, prog: Program, widths: Optional[Dict[str, int]] = None, partial: Sequence[str] = (), fold_edges=None,
                  fold_replicas: Optional[Tuple[int, int]] = None):
-        self.table = ColumnTable("c", 48, 16, widths)
+        self.table = ColumnTable("c", 64, 16, widths)
         self.partial = tuple(partial)
         fold_edges = fold_edges or {}
         n_folds = [0]

@@ -178,7 +178,14 @@ SPEC_RANGES = dict(lox_kg=(272000.0, 285000.0), rp1_kg=(116000.0, 123000.0), thr
                    steer_tilt_cap=(0.14, 0.24))
 SPEC_SEED = 20170814
 
-PHASE_PAD_PRESS, PHASE_VERTICAL_RISE, PHASE_PITCH_KICK, PHASE_GRAVITY_TURN, PHASE_MECO = 0.0, 1.0, 2.0, 3.0, 4.0
+PHASE_PAD_PRESS, PHASE_VERTICAL_RISE, PHASE_PITCH_KICK, PHASE_GRAVITY_TURN, PHASE_MECO, PHASE_FLIP = 0.0, 1.0, 2.0, 3.0, 4.0, 5.0
+
+# sensors.py:23-40 (error model EST; noise keyed by jax.random.key(20170814), salt, sample counter)
+SENSOR_SEED = 20170814
+GPS_DT_S, RADAR_DT_S = 1.0 / 25.0, 1.0 / 40.0                     # constants.py GPS_RATE_HZ / ALTIMETER_RATE_HZ
+IMU_ACCEL_SIGMA, IMU_GYRO_SIGMA, GPS_POS_SIGMA, GPS_VEL_SIGMA, PRESSURE_SIGMA_PA = 0.02, 1.0e-3, 1.5, 0.05, 1.0e3
+RADAR_MAX_RANGE_M, RADAR_FOV_COS, RADAR_SIGMA_M = 500.0, math.cos(math.radians(35.0)), 0.15
+BLACKOUT_MACH_MIN, BLACKOUT_THRUST_MIN_N = 2.5, 1.0e5
 METRIC_NAMES = ["max_qbar_pa", "t_max_qbar_s", "max_accel_mps2", "meco_t_s", "meco_alt_m", "meco_speed_mps",
                 "meco_fpa_deg", "meco_downrange_m"]
 
@@ -452,6 +459,58 @@ def fsw_density(xp, alt):                                                  # mat
     return xp.where(h < 25_000.0, 1.225 * xp.exp(-h / 8_440.0), 0.0642 * xp.exp(-(h - 25_000.0) / 6_580.0))
 
 
+# ---- the recorded ascent profile the flight software flies (controller/src/profile.rs) ------------------------------------
+
+def resample_profile(time_s, velocity_mps, altitude_km):
+    """AscentProfile::load after the JSON parse (profile.rs:44-85): the recorded webcast telemetry on a uniform 0.5 s grid,
+    a 9-point moving average (window [i-4, i+5) clipped to the table) over speed and altitude, central differences of the
+    smoothed altitude for the vertical speed.  Returns (time, speed, alt_m, vspeed)."""
+    time_s, velocity_mps, altitude_km = (np.asarray(a, dtype=np.float64) for a in (time_s, velocity_mps, altitude_km))
+    n = int(time_s[-1] / 0.5) + 1
+    grid = np.arange(n, dtype=np.float64) * 0.5
+
+    def interp(x, xs, ys):                                                  # profile.rs:23-38 (bisection on `xs[mid] <= x`)
+        if x <= xs[0]:
+            return ys[0]
+        if x >= xs[-1]:
+            return ys[-1]
+        lo = int(np.searchsorted(xs, x, side="right")) - 1
+        return ys[lo] + (x - xs[lo]) / (xs[lo + 1] - xs[lo]) * (ys[lo + 1] - ys[lo])
+
+    def smooth(v):
+        out = np.empty(n)
+        for i in range(n):
+            lo, hi = max(i - 4, 0), min(i + 5, n)
+            acc = 0.0
+            for k in range(lo, hi):                                         # left-to-right, like iter().sum()
+                acc += v[k]
+            out[i] = acc / (hi - lo)
+        return out
+
+    speed = smooth(np.array([interp(t, time_s, velocity_mps) for t in grid]))
+    alt_m = smooth(np.array([interp(t, time_s, altitude_km) * 1000.0 for t in grid]))
+    vspeed = np.zeros(n)
+    for i in range(n):
+        lo, hi = max(i - 1, 0), min(i + 1, n - 1)
+        vspeed[i] = 0.0 if hi == lo else (alt_m[hi] - alt_m[lo]) / ((hi - lo) * 0.5)
+    return grid, speed, alt_m, vspeed
+
+
+_PROFILE_CACHE: dict = {}
+
+
+def ascent_profile(mission: str = "crs12"):
+    """(time, speed, alt_m, vspeed) tuples of the mission's resampled profile, from elodin_amd/data/falcon9_<mission>_profile.csv
+    (written by tests/golden/make_falcon9_profile.py: `resample_profile` over the reference's data/<mission>/stage1_raw.json,
+    the file ELODIN_F9_PROFILE points the flight software at, main.py:193-199)."""
+    if mission not in _PROFILE_CACHE:
+        from pathlib import Path
+        path = Path(__file__).resolve().parents[1] / "data" / f"falcon9_{mission}_profile.csv"
+        tab = np.loadtxt(path, delimiter=",", skiprows=1)
+        _PROFILE_CACHE[mission] = tuple(tuple(float(v) for v in tab[:, k]) for k in range(4))
+    return _PROFILE_CACHE[mission]
+
+
 # ---- host-side frames (numpy) ------------------------------------------------------------------------------------------
 
 def pad_ecef() -> np.ndarray:                                              # sim.py:1187-1188
@@ -685,69 +744,191 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
                                             xp.where(at_meco, ground_speed, m[5]), xp.where(at_meco, fpa, m[6]),
                                             xp.where(at_meco, downrange, m[7])])}
 
-    @dsl.system(every=GUIDANCE_PERIOD_TICKS)
-    def fsw_ascent(pos, vel, inertia, tick, params, fsw_state, engine_wrench, aero_wrench):
-        """controller/src/main.rs:384-533 on truth navigation.  fsw_state = [phase, phase_t0, purge_until, meco_latched];
-        the `fsw_phase` column carries the phase the command was computed in (Command.phase is set before the
-        transition, main.rs:386-390)."""
-        t = tick * dt
-        phase, phase_t0, purge_until, meco = fsw_state[0], fsw_state[1], fsw_state[2], fsw_state[3]
-        r, v = ecef(pos), vel.linear()
-        lat, lon, alt = ecef_to_geodetic(xp, r)
-        up_here = -ned_basis(xp, lat, lon)[2]
-        speed = xp.linalg.norm(v)
-        north, east, down = (np.asarray(b) for b in ned_basis(np, math.radians(PAD_LAT_DEG), math.radians(PAD_LON_DEG)))
-        up_pad = xp.array(tuple(-down))
-        az = xp.deg2rad(params[P["azimuth_deg"]])
-        track = xp.array(tuple(north)) * xp.cos(az) + xp.array(tuple(east)) * xp.sin(az)
-        track = track / xp.linalg.norm(track)
-        u_ascent = params[P["ascent_throttle"]]
+    # ---- sensors (sensors.py, sim.py:1016-1110): what the flight software flies on ---------------------------------------------
+    sensor_key = dsl.random.key(SENSOR_SEED)
 
+    def noise(count, salt, n, sigma):                                        # sensors.py:105-107
+        key = dsl.random.fold_in(dsl.random.fold_in(sensor_key, salt), count)
+        return (dsl.random.normal(key, shape=(n,)) if n else dsl.random.normal(key)) * sigma
+
+    # The IMU and the pressure transducers sample every tick in the reference; their samples are consumed at the guidance
+    # exchanges only (main.py:280-303) and depend on nothing but the tick they are taken on (noise keyed by the sample
+    # counter = ticks done), so they are evaluated on the exchange ticks: same packets, a tenth of the draws.
+    @dsl.system(every=GUIDANCE_PERIOD_TICKS, phase=1)
+    def imu_model(tick, pos, vel, inertia, engine_wrench, aero_wrench, fin_wrench, rcs_wrench):
+        """sim.py:1019-1038: specific force = summed non-gravitational body force / mass; the gyro measures the inertial
+        rate (frame rate + Earth rate)."""
+        count = tick                                                        # sensor_tick + 1 = ticks done
+        f_body = (engine_wrench[:3] + aero_wrench[:3] + fin_wrench[:3] + rcs_wrench[:3]) / inertia.mass()
+        q_inv = quat_inverse(xp, pos.angular().vector())
+        gyro = quat_rotate(xp, q_inv, vel.angular() + xp.array([0.0, 0.0, OMEGA_EARTH_RADPS]))
+        return {"sensor_tick": count, "imu_accel": f_body + noise(count, 1, 3, IMU_ACCEL_SIGMA),
+                "imu_gyro": gyro + noise(count, 2, 3, IMU_GYRO_SIGMA)}
+
+    @dsl.system
+    def gps_model(gps_timer, pos, vel, mach, thrust_total, gps_pos, gps_vel, gps_count):
+        """sim.py:1041-1068: 25 Hz position / velocity on a timer-accumulator + hold, blacked out under a supersonic
+        plume.  gps_pos is in the executor's coordinates (ECEF minus `origin`)."""
+        t = gps_timer + dt
+        fired = t >= GPS_DT_S
+        t = xp.where(fired, t - GPS_DT_S, t)
+        blackout = (mach > BLACKOUT_MACH_MIN) & (thrust_total > BLACKOUT_THRUST_MIN_N)
+        fresh = fired & ~blackout
+        n = gps_count + xp.where(fresh, 1.0, 0.0)
+        pos_meas = pos.linear() + noise(n, 3, 3, GPS_POS_SIGMA)
+        vel_meas = vel.linear() + noise(n, 4, 3, GPS_VEL_SIGMA)
+        return {"gps_timer": t, "gps_pos": xp.where(fresh, pos_meas, gps_pos), "gps_vel": xp.where(fresh, vel_meas, gps_vel),
+                "gps_count": n}
+
+    @dsl.system
+    def radar_altimeter_model(radar_timer, pos, radar_range, radar_count):
+        """sim.py:1071-1096: boresight (-X body) range to the ellipsoid at 40 Hz inside the FOV / range gates, -1 otherwise."""
+        t = radar_timer + dt
+        fired = t >= RADAR_DT_S
+        t = xp.where(fired, t - RADAR_DT_S, t)
+        lat, lon, alt = ecef_to_geodetic(xp, ecef(pos))
+        up = xp.array([xp.cos(lat) * xp.cos(lon), xp.cos(lat) * xp.sin(lon), xp.sin(lat)])
+        bore_world = quat_rotate(xp, pos.angular().vector(), xp.array([-1.0, 0.0, 0.0]))
+        cos_tilt = xp.dot(bore_world, -up)
+        slant = alt / xp.maximum(cos_tilt, 1e-3)
+        n = radar_count + xp.where(fired, 1.0, 0.0)
+        valid = (cos_tilt > RADAR_FOV_COS) & (slant <= RADAR_MAX_RANGE_M) & (alt > 0.0)
+        meas = xp.where(valid, slant + noise(n, 5, 0, RADAR_SIGMA_M), -1.0)
+        return {"radar_timer": t, "radar_range": xp.where(fired, meas, radar_range), "radar_count": n}
+
+    @dsl.system(every=GUIDANCE_PERIOD_TICKS, phase=1)
+    def pressure_transducers(sensor_tick, tank_pressure_lox, tank_pressure_rp1, inlet_pressure_lox, inlet_pressure_rp1):
+        truth = xp.array([tank_pressure_lox, tank_pressure_rp1, inlet_pressure_lox, inlet_pressure_rp1])   # sim.py:1099-1109
+        return {"pressure_meas": truth + noise(sensor_tick, 6, 4, PRESSURE_SIGMA_PA)}
+
+    # ---- the flight software (controller/src/main.rs), one exchange per 10 ticks ---------------------------------------------
+    prof_t, prof_speed, prof_alt, prof_vspeed = ascent_profile()
+
+    def up_and_ned(r_ecef):
+        lat, lon, alt = ecef_to_geodetic(xp, r_ecef)
+        north, east, down = ned_basis(xp, lat, lon)
+        return -down, north, east, alt
+
+    def normalize(v):                                                       # math.rs:41-48
+        n = xp.linalg.norm(v)
+        return xp.where(n < 1e-12, xp.zeros(3), v * (1.0 / xp.maximum(n, 1e-300)))
+
+    @dsl.system(every=GUIDANCE_PERIOD_TICKS, phase=1)
+    def fsw_ascent(tick, params, fsw_state, fsw_frame, nav_pos, nav_vel, nav_att, nav_aux, imu_accel, imu_gyro, gps_pos,
+                   gps_vel, gps_count, radar_range):
+        """controller/src/main.rs:384-533 with its navigator (main.rs:213-327), called where main.py's post_step exchanges
+        packets: after ticks 1, 11, 21, ... with t = (ticks done - 1) * dt (impeller2_server.rs:553-678: post_step gets the
+        index of the tick just finished; main.py:276-281).  Branch-free: every `if` of the Rust is a select.
+        fsw_state = [phase, phase_t0, purge_until, meco latched, t_liftoff, pad frame set]; nav_aux = [initialized,
+        last_gps_count, last_t, radar_alt_m]; fsw_frame = [up_pad, track_dir].  The `fsw_phase` column carries the phase the
+        command was computed in (Command.phase is set before the transition, main.rs:386-390).  Positions are in the
+        executor's coordinates (ECEF minus `origin`); `ecef()` is applied where the Rust needs the geocentric vector."""
+        t = (tick - 1.0) * dt
+        phase, phase_t0, purge_until, meco, t_liftoff, pad_set = (fsw_state[k] for k in range(6))
+        inited, last_gps, last_t, radar_alt = nav_aux[0] > 0.5, nav_aux[1], nav_aux[2], nav_aux[3]
+        org_v = xp.array(org)
+        x_axis = xp.array([1.0, 0.0, 0.0])
+
+        # -- Navigator::step (main.rs:241-295) on an initialised navigator
+        dtn = xp.clip(t - last_t, 0.0, 0.1)
+        att_conj = xp.array([-nav_att[0], -nav_att[1], -nav_att[2], nav_att[3]])
+        omega_frame = imu_gyro - quat_rotate(xp, att_conj, xp.array([0.0, 0.0, OMEGA_EARTH_RADPS]))
+        wn = xp.linalg.norm(omega_frame)
+        angle = wn * dtn
+        axis = normalize(omega_frame)
+        sh, ch = xp.sin(angle * 0.5), xp.cos(angle * 0.5)
+        att_q = quat_mul(xp, nav_att, xp.array([axis[0] * sh, axis[1] * sh, axis[2] * sh, ch]))
+        att_n = xp.sqrt(att_q[0] * att_q[0] + att_q[1] * att_q[1] + att_q[2] * att_q[2] + att_q[3] * att_q[3])
+        att_p = xp.where(angle < 1e-12, nav_att, att_q / att_n)
+        f_e = quat_rotate(xp, att_p, imu_accel)
+        r_nav = nav_pos + org_v
+        acc = f_e + gravity_accel(xp, r_nav) + frame_accel(xp, r_nav, nav_vel)
+        vel_p = nav_vel + acc * dtn
+        pos_p = nav_pos + vel_p * dtn
+        fresh = gps_count > last_gps                                        # complementary GPS blend
+        pos_b = xp.where(fresh, pos_p + (gps_pos - pos_p) * 0.20, pos_p)
+        vel_b = xp.where(fresh, vel_p + (gps_vel - vel_p) * 0.50, vel_p)
+        radar_ok = (radar_range >= 0.0) & (radar_range < 500.0)             # radar altimeter below 500 m
+        up_b, _, _, geo_alt_b = up_and_ned(pos_b + org_v)
+        radar_alt_new = xp.where(radar_alt < 0.0, radar_range, 0.7 * radar_alt + 0.3 * radar_range)
+        dh = radar_alt_new - geo_alt_b
+        pos_r = xp.where(radar_ok & (xp.abs(dh) < 50.0), pos_b + up_b * (0.35 * dh), pos_b)
+        radar_alt_p = xp.where(radar_ok, radar_alt_new, -1.0)
+        # -- Navigator::init (main.rs:227-239) on the first packet that carries a GPS fix
+        init_now = ~inited & (gps_count > 0.0)
+        up_gps, _, _, _ = up_and_ned(gps_pos + org_v)
+        pos_n = xp.where(inited, pos_r, xp.where(init_now, gps_pos, nav_pos))
+        vel_n = xp.where(inited, vel_b, xp.where(init_now, xp.zeros(3), nav_vel))
+        att_nx = xp.where(inited, att_p, xp.where(init_now, quat_between_x(xp, up_gps), nav_att))
+        last_gps_n = xp.where(inited, xp.where(fresh, gps_count, last_gps), xp.where(init_now, gps_count, last_gps))
+        last_t_n = xp.where(inited | init_now, t, last_t)
+        radar_alt_n = xp.where(inited, radar_alt_p, xp.where(init_now, -1.0, radar_alt))
+        ready = inited | init_now                                           # `if !self.nav.initialized { return cmd; }`
+
+        # -- Fsw::step (main.rs:384-533)
+        up_here, north, east, geo_alt = up_and_ned(pos_n + org_v)
+        alt = xp.where(radar_alt_n >= 0.0, radar_alt_n, geo_alt)            # Navigator::altitude
+        speed = xp.linalg.norm(vel_n)
+        set_pad = ready & (phase < 0.5) & (pad_set < 0.5)                   # the pad frame, once (main.rs:405-413)
+        az = xp.deg2rad(params[P["azimuth_deg"]])
+        up_pad = xp.where(set_pad, up_here, fsw_frame[:3])
+        track = xp.where(set_pad, normalize(north * xp.cos(az) + east * xp.sin(az)), fsw_frame[3:])
+        t_liftoff_n = xp.where(ready & (t_liftoff < 0.0) & (xp.dot(vel_n, up_here) > 1.0), t, t_liftoff)
+        u_ascent = params[P["ascent_throttle"]]
         in_pad, in_rise = phase < 0.5, (phase > 0.5) & (phase < 1.5)
         in_kick, in_turn = (phase > 1.5) & (phase < 2.5), (phase > 2.5) & (phase < 3.5)
         powered = phase < 3.5
-
         # PitchKick: ramp the nose from vertical toward the track azimuth
         f_kick = xp.clip((t - phase_t0) / params[P["kick_ramp_s"]], 0.0, 1.0)
         ang = f_kick * xp.deg2rad(params[P["kick_deg"]])
-        dir_kick = up_pad * xp.cos(ang) + track * xp.sin(ang)
-        dir_kick = dir_kick / xp.linalg.norm(dir_kick)
-        # GravityTurn: flight-path angle as a function of speed (the parametric program)
+        dir_kick = normalize(up_pad * xp.cos(ang) + track * xp.sin(ang))
+        # GravityTurn: the recorded profile's flight-path angle with an altitude trim, speed closed by throttle
+        t_ref = t - t_liftoff_n
+        v_ref = xp.interp(t_ref, prof_t, prof_speed)
+        gamma_ref = xp.arcsin(xp.clip(xp.interp(t_ref, prof_t, prof_vspeed) / xp.maximum(v_ref, 30.0), -1.0, 1.0))
+        alt_err = xp.interp(t_ref, prof_t, prof_alt) - alt
+        gamma_cmd = xp.clip(gamma_ref + xp.clip(alt_err * 2.0e-4, -0.12, 0.12), 0.0, 1.55)
+        u_prof = xp.clip(u_ascent + (v_ref - speed) * 2.0e-3, 0.62, 1.0)
+        # ... and the parametric pitch program it falls back to until the profile clock runs (t_liftoff still unset)
         v0 = 90.0
         f_turn = xp.clip((speed - v0) / (params[P["meco_speed_mps"]] - v0), 0.0, 1.0)
-        gamma = xp.deg2rad(90.0 - (90.0 - params[P["meco_fpa_deg"]]) * xp.power(f_turn, params[P["pitch_exp"]]))
-        dir_turn = up_here * xp.sin(gamma) + track * xp.cos(gamma)
-        dir_turn = dir_turn / xp.linalg.norm(dir_turn)
-        speed_safe = xp.maximum(speed, 1e-9)
-        dir_meco = v / speed_safe
+        gamma_par = xp.deg2rad(90.0 - (90.0 - params[P["meco_fpa_deg"]]) * xp.power(f_turn, params[P["pitch_exp"]]))
+        on_profile = t_liftoff_n >= 0.0
+        gamma = xp.where(on_profile, gamma_cmd, gamma_par)
+        dir_turn = normalize(up_here * xp.sin(gamma) + track * xp.cos(gamma))
+        u = xp.where(on_profile, u_prof, u_ascent)
+        qbar_est = 0.5 * fsw_density(xp, alt) * speed * speed               # throttle bucket through Max-Q
+        u = xp.where((qbar_est > params[P["bucket_q_on_pa"]]) & (speed < 500.0), xp.minimum(u, params[P["bucket_throttle"]]), u)
+        a_meas = xp.linalg.norm(imu_accel)                                  # ~3.5 g limit toward MECO
+        u_turn = xp.where(a_meas > 34.0, xp.maximum(u * 34.0 / xp.maximum(a_meas, 1e-9), THROTTLE_MIN), u)
+        dir_meco = normalize(vel_n)
         direction = xp.where(in_kick, dir_kick, xp.where(in_turn, dir_turn, xp.where(powered, up_pad, dir_meco)))
-        attitude = quat_between_x(xp, direction)
-
-        # throttle: bucket through Max-Q, 3.6 g limit toward MECO
-        qbar_est = 0.5 * fsw_density(xp, alt) * speed * speed
-        u = xp.where((qbar_est > params[P["bucket_q_on_pa"]]) & (speed < 500.0), xp.minimum(u_ascent, params[P["bucket_throttle"]]), u_ascent)
-        a_meas = xp.linalg.norm((engine_wrench[:3] + aero_wrench[:3]) / inertia.mass())
-        u = xp.where(a_meas > 34.0, xp.maximum(u * 34.0 / xp.maximum(a_meas, 1e-9), THROTTLE_MIN), u)
-        u_turn = u
-        meco_now = in_turn & (speed >= params[P["meco_speed_mps"]])
-        light = in_pad & (t >= 0.2)
+        attitude = xp.where(ready, quat_between_x(xp, direction), nav_att)  # an uninitialised navigator answers with its attitude
+        meco_now = ready & in_turn & (speed >= params[P["meco_speed_mps"]])
+        light = ready & in_pad & (t >= 0.2)
         throttle = xp.where(in_pad, xp.where(light, u_ascent, 0.0),
                             xp.where(in_rise | in_kick, u_ascent, xp.where(in_turn & ~meco_now, u_turn, 0.0)))
-        purge_until_next = xp.where(meco_now, t + 5.0, purge_until)
-        main_open = xp.where(powered, 1.0, 0.0)
-        valve_cmd = xp.array([1.0, 0.0, 1.0, 0.0, main_open, main_open, main_open, xp.where(t < purge_until_next, 1.0, 0.0)])
-        # transitions (one per exchange, like the `match` in main.rs)
+        throttle = xp.where(ready, throttle, 0.0)
+        main_open = xp.where(ready & powered, 1.0, 0.0)
+        # valves: helium pressurisation always; the purge bit is decided BEFORE this step's cutoff moves the deadline
+        valve_cmd = xp.array([1.0, 0.0, 1.0, 0.0, main_open, main_open, main_open, xp.where(t < purge_until, 1.0, 0.0)])
+        purge_until_n = xp.where(meco_now, t + 5.0, purge_until)            # cutoff_with_purge
         to_rise = light
-        to_kick = in_rise & (t >= params[P["kick_start_s"]])
-        to_turn = in_kick & (f_kick >= 1.0) & (speed > 80.0)
-        phase_next = xp.where(to_rise, PHASE_VERTICAL_RISE, xp.where(to_kick, PHASE_PITCH_KICK, xp.where(
-            to_turn, PHASE_GRAVITY_TURN, xp.where(meco_now, PHASE_MECO, phase))))
-        changed = to_rise | to_kick | to_turn | meco_now
+        to_kick = ready & in_rise & (t >= params[P["kick_start_s"]])
+        to_turn = ready & in_kick & (f_kick >= 1.0) & (speed > 80.0)
+        to_flip = ready & (phase > 3.5) & (phase < 4.5) & (t - phase_t0 > 3.0)   # Meco -> Flip: the ascent is over (not flown further)
+        phase_n = xp.where(to_rise, PHASE_VERTICAL_RISE, xp.where(to_kick, PHASE_PITCH_KICK, xp.where(
+            to_turn, PHASE_GRAVITY_TURN, xp.where(meco_now, PHASE_MECO, xp.where(to_flip, PHASE_FLIP, phase)))))
+        changed = to_rise | to_kick | to_turn | meco_now | to_flip
+        tvc_on = xp.where(ready & powered, 1.0, 0.0)
+        rcs_on = xp.where(ready & ~powered, 1.0, 0.0)
         return {"engine_cmd": xp.ones(N_ENGINES) * throttle, "valve_cmd": valve_cmd, "attitude_setpoint": attitude,
-                "fin_cmd": xp.zeros(3),
-                "ctrl_enable": xp.array([xp.where(powered, 1.0, 0.0), xp.where(powered, 0.0, 1.0)]), "fsw_phase": phase,
-                "fsw_state": xp.array([phase_next, xp.where(changed, t, phase_t0), purge_until_next,
-                                       xp.where(meco_now, 1.0, meco)])}
+                "fin_cmd": xp.zeros(3), "ctrl_enable": xp.array([tvc_on, rcs_on]), "fsw_phase": phase,
+                "nav_pos": pos_n, "nav_vel": vel_n, "nav_att": att_nx,
+                "nav_aux": xp.array([xp.where(ready, 1.0, 0.0), last_gps_n, last_t_n, radar_alt_n]),
+                "fsw_frame": xp.concatenate([up_pad, track]),
+                "fsw_state": xp.array([phase_n, xp.where(changed, t, phase_t0), purge_until_n, xp.where(meco_now, 1.0, meco),
+                                       t_liftoff_n, xp.where(set_pad, 1.0, pad_set)])}
 
     pre = [attitude_control, valve_dynamics, tvc_actuators, fin_actuators, engine_dynamics, mass_props, tank_dynamics,
            rcs_dynamics, engine_wrench_sys, wind_model, aero_dynamics]       # propulsion_systems, sim.py:1433-1458 (no legs)
@@ -762,7 +943,7 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
             return {"engine_cmd": eng, "valve_cmd": valves}
         pre = [script] + pre
     elif fsw:
-        post = post + [ascent_metrics_latch, fsw_ascent]
+        post = post + [imu_model, gps_model, radar_altimeter_model, pressure_transducers, ascent_metrics_latch, fsw_ascent]
     return dsl.Program(pre, gravity_and_frame_forces | apply_body_wrenches, post)
 
 
@@ -787,7 +968,9 @@ COLUMN_WIDTHS = dict(engine_cmd=9, valve_cmd=8, engine_spool=9, engine_armed=9, 
                      tank_pressure_rp1=1, inlet_pressure_lox=1, inlet_pressure_rp1=1, cg_station=1, axial_specific_force=1,
                      qbar=1, mach=1, tvc_cmd=2, tvc_state=2, rcs_torque_cmd=3, aero_wrench=6, engine_wrench=6,
                      attitude_setpoint=4, ctrl_enable=2, fsw_phase=1, upper_mass=1, lifted=1, liftoff_time=1,
-                     altitude_geodetic=1, ground_speed=1, params=16, fsw_state=4, ascent_metrics=8,
+                     altitude_geodetic=1, ground_speed=1, params=16, fsw_state=6, fsw_frame=6, ascent_metrics=8,
+                     nav_pos=3, nav_vel=3, nav_att=4, nav_aux=4, sensor_tick=1, imu_accel=3, imu_gyro=3, gps_timer=1, gps_pos=3,
+                     gps_vel=3, gps_count=1, radar_timer=1, radar_range=1, radar_count=1, pressure_meas=4,
                      fin_cmd=3, fin_state=4, fin_wrench=6, rcs_levels=8, rcs_wrench=6, nitrogen_kg=1, wind_ecef=3, wind_ned=3)
 
 
@@ -820,6 +1003,11 @@ def initial_columns(params: np.ndarray, origin: Optional[Sequence[float]] = None
     cols["upper_mass"][:] = upper_kg
     cols["nitrogen_kg"][:] = N2_INITIAL_KG
     cols["lifted"][:] = 0.0 if on_pad else 1.0
+    cols["radar_range"][:] = -1.0                                           # sensors.py:119 / Navigator::new, Fsw::new (main.rs:214-225,355-381)
+    cols["nav_att"][:] = [0.0, 0.0, 0.0, 1.0]
+    cols["nav_aux"][:] = [0.0, 0.0, 0.0, -1.0]
+    cols["fsw_state"][:] = [PHASE_PAD_PRESS, 0.0, -1.0, 0.0, -1.0, 0.0]
+    cols["fsw_frame"][:] = [0.0, 0.0, 1.0, 1.0, 0.0, 0.0]
     cols["params"][:] = params
     return cols
 

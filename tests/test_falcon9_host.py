@@ -166,7 +166,7 @@ def test_closed_loop_traces_and_generates_for_both_dtypes():
     cols = f9.initial_columns(f9.default_param_row()[None, :], origin=f9.pad_ecef())
     tp = prog.trace({k: v.shape[1] for k, v in cols.items()})
     names = dict(tp.columns)
-    assert names["engine_spool"] == 9 and names["valve_state"] == 8 and names["params"] == 16 and len(names) <= 48
+    assert names["engine_spool"] == 9 and names["valve_state"] == 8 and names["params"] == 16 and len(names) <= 64
     assert tp.writes_inertia and tp.reads_velocity
     for dtype, fast in (("float64", False), ("float32", False), ("float32", True)):
         src = codegen.generate_source(tp, dtype, 1, fast_math=fast)

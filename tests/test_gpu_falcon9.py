@@ -206,7 +206,7 @@ def test_nominal_ascent_follows_the_recorded_crs12_timeline(nominal):
     assert 50_000.0 < m["meco_alt_m"] < 75_000.0 and 34.0 < m["meco_fpa_deg"] < 50.0
     assert 3.3 * f9.G0 < m["max_accel_mps2"] < 3.75 * f9.G0
     assert nominal.column("lifted")[0, 0] == 1.0 and 0.5 < nominal.column("liftoff_time")[0, 0] < 6.0
-    assert nominal.column("fsw_state")[0, 0] == f9.PHASE_MECO and nominal.column("thrust_total")[0, 0] == 0.0
+    assert nominal.column("fsw_state")[0, 0] == f9.PHASE_FLIP and nominal.column("thrust_total")[0, 0] == 0.0   # MECO + 3 s: the ascent software hands over
 
 
 def test_pad_relative_coordinates_fly_the_same_ascent(nominal):
