@@ -426,6 +426,31 @@ class _Lax:
         return _tree_select(pred, on_true, on_false)
 
     @staticmethod
+    def branch_cond(pred, true_fun, false_fun, *operands):
+        """`cond` with a REAL branch in the kernel (not in jax.lax): `true_fun(*operands)` is evaluated only by waves with a
+        lane whose `pred` holds, instead of by every lane on every tick with the result selected away.  For rare, expensive
+        branches — a sensor that draws its noise on one tick in forty (threefry + erfinv per sample), a relight sequence.
+        Built on the loop machinery: a `while_loop` of at most one iteration whose carried values are the operands, so
+        everything in `true_fun` that depends on an operand stays inside the branch (what does not is hoisted in front of it
+        like any loop-invariant code).  `false_fun(*operands)` supplies the values of the lanes that do not branch and is
+        evaluated by all: keep it cheap.  Both must return the same structure."""
+        ops_flat, ops_rebuild = _flatten(list(operands))
+        out_false, out_rebuild = _flatten(false_fun(*operands))
+        n_ops = len(ops_flat)
+        limit = _Np.where(pred, 1.0, 0.0)
+
+        def cond(c):
+            return c[0] < limit
+
+        def body(c):
+            out_true, _ = _flatten(true_fun(*ops_rebuild(list(c[1:1 + n_ops]))))
+            if len(out_true) != len(out_false):
+                raise TypeError("branch_cond: true_fun and false_fun must return the same structure")
+            return [c[0] + 1.0] + list(c[1:1 + n_ops]) + list(out_true)
+        res = _Lax.while_loop(cond, body, [const(0.0)] + list(ops_flat) + list(out_false), max_iter=1)
+        return out_rebuild(list(res[1 + n_ops:]))
+
+    @staticmethod
     def switch(index, branches, *operands):
         """jax.lax.switch: index clamped to [0, len(branches) - 1]."""
         out = branches[0](*operands)

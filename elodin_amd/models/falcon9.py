@@ -15,20 +15,30 @@ This module restates the ASCENT part of that stack (pad -> vertical rise -> pitc
                   grid fins, gravity_and_frame_forces, apply_body_wrenches), pad_clamp sim.py:984-1013,
                   derive_geodetic_telemetry sim.py:1128-1143
   physics helpers frames.py:29-114, atmosphere.py:25-90, propulsion.py:46-149, aero.py:17-140, rcs.py:26-107
-  flight software controller/src/main.rs:384-533 (phases PadPress..Meco, parametric pitch program — the fallback the
-                  FSW flies without a recorded profile), math.rs:90-138,191-199
+  sensors         sensors.py:23-120, sim.py:1016-1110 (IMU, 25 Hz GPS with the plume blackout, 40 Hz radar altimeter, pressure
+                  transducers; noise = jax.random threefry keyed by (20170814, salt, sample counter), drawn in the kernel)
+  flight software controller/src/main.rs:213-327 (IMU + GPS + radar navigator in the rotating frame), :384-533 (phases
+                  PadPress..Meco, flying the recorded CRS-12 profile: flight-path-angle feed-forward with an altitude trim,
+                  speed closed by throttle, Max-Q bucket, 3.5 g limit), profile.rs (the profile's resampling), math.rs; called
+                  on main.py's cadence: after ticks 1, 11, 21, ... with t = (ticks done - 1) dt (impeller2_server.rs:553-678)
   parameters      spec.toml (LHS, seed 20170814) / main.py:53-100 calibrated defaults
 
+Parity: the whole closed loop is pinned on flights flown by the REFERENCE's own plant, sensors and post_step bridge (imported
+unmodified) with an independent C restatement of the Rust flight software (oracle/falcon9_fsw.c): five ascents, pad to MECO + 3 s
+— every phase transition on the same tick, every component and the navigator's private state within 1.5e-10 of its scale at 133
+checkpoints through the generated f64 kernel (tests/test_gpu_falcon9_closed_loop.py, profiles/r03_falcon9_closed_loop.txt;
+tests/test_falcon9_closed_loop_reference.py walks the traced program through the first 3 s on the CPU: 4e-15).  Helpers and the
+open-loop plant are pinned separately (tests/test_falcon9_reference_fixtures.py, test_falcon9_plant_reference.py) and the
+reference's own verification ladder is reproduced (tests/test_falcon9_host.py, tests/test_gpu_falcon9.py).
+
 Deliberate scope limits (stated, not hidden): the recovery half of the mission (flip, boostback, entry, landing) is not
-flown: its guidance phases, the landing-leg contact model and ground contact are not built, and fins / RCS — whose plant
-models ARE here — stay at rest because the ascent flight software never commands them; the FSW navigates on truth state
-instead of the noisy IMU/GPS models, and the wind model carries its steady part only (per-rollout `wind_ned`, zero in
-spec.toml), not the gust process (gust_sigma_mps is 0 in the ascent spec.toml; only spec.landing.toml, i.e. the recovery
-half, turns it on).
-Parity is UNPINNED against reference trajectories (none are checked in, and the reference cannot run here); the
-helper functions and the passive / open-loop plant are pinned against the reference's own verification ladder
-(test_ladder.py, test_frames.py, test_propulsion.py, test_aero.py) in tests/test_falcon9_host.py and
-tests/test_gpu_falcon9.py.
+flown — the state machine stops at Meco -> Flip (3 s after cutoff), its guidance phases, the landing-leg contact model and
+ground contact are not built, and fins / RCS, whose plant models ARE here, stay at rest because the ascent flight software
+never commands them (RCS attitude hold runs in the Meco phase).  The navigator's wind estimate (main.rs:272, read by the
+landing burn only) is not carried.  The wind model carries its steady part only (per-rollout `wind_ned`, zero in spec.toml),
+not the gust process (gust_sigma_mps = 0 in the ascent spec.toml; spec.landing.toml, i.e. the recovery half, turns it on).
+The IMU and the pressure transducers are sampled on the guidance-exchange ticks only (the only ticks their samples are
+consumed on; their noise is keyed by the tick, so those samples equal the reference's).
 
 Every physics helper takes the array namespace `xp` first: `numpy` gives the host-side f64 evaluation (initial
 conditions, known-answer tests), `elodin_amd.dsl.np` traces the same code into the kernel.
@@ -775,10 +785,11 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
         blackout = (mach > BLACKOUT_MACH_MIN) & (thrust_total > BLACKOUT_THRUST_MIN_N)
         fresh = fired & ~blackout
         n = gps_count + xp.where(fresh, 1.0, 0.0)
-        pos_meas = pos.linear() + noise(n, 3, 3, GPS_POS_SIGMA)
-        vel_meas = vel.linear() + noise(n, 4, 3, GPS_VEL_SIGMA)
-        return {"gps_timer": t, "gps_pos": xp.where(fresh, pos_meas, gps_pos), "gps_vel": xp.where(fresh, vel_meas, gps_vel),
-                "gps_count": n}
+        # the fix (six normal draws) is computed on the ticks that deliver one — a real branch, taken once in 40 ticks
+        pos_new, vel_new = dsl.lax.branch_cond(
+            fresh, lambda n_, p_, v_: (p_ + noise(n_, 3, 3, GPS_POS_SIGMA), v_ + noise(n_, 4, 3, GPS_VEL_SIGMA)),
+            lambda n_, p_, v_: (gps_pos, gps_vel), n, pos.linear(), vel.linear())
+        return {"gps_timer": t, "gps_pos": pos_new, "gps_vel": vel_new, "gps_count": n}
 
     @dsl.system
     def radar_altimeter_model(radar_timer, pos, radar_range, radar_count):
@@ -793,8 +804,10 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
         slant = alt / xp.maximum(cos_tilt, 1e-3)
         n = radar_count + xp.where(fired, 1.0, 0.0)
         valid = (cos_tilt > RADAR_FOV_COS) & (slant <= RADAR_MAX_RANGE_M) & (alt > 0.0)
-        meas = xp.where(valid, slant + noise(n, 5, 0, RADAR_SIGMA_M), -1.0)
-        return {"radar_timer": t, "radar_range": xp.where(fired, meas, radar_range), "radar_count": n}
+        # a valid return draws its noise on the ticks the altimeter fires inside its gates (the first seconds of an ascent)
+        rng_new = dsl.lax.branch_cond(fired & valid, lambda n_, s_: s_ + noise(n_, 5, 0, RADAR_SIGMA_M),
+                                      lambda n_, s_: xp.where(fired, -1.0, radar_range), n, slant)
+        return {"radar_timer": t, "radar_range": rng_new, "radar_count": n}
 
     @dsl.system(every=GUIDANCE_PERIOD_TICKS, phase=1)
     def pressure_transducers(sensor_tick, tank_pressure_lox, tank_pressure_rp1, inlet_pressure_lox, inlet_pressure_rp1):

@@ -54,14 +54,14 @@ def test_generated_kernel_flies_the_reference_ascents_f64(ticks_per_launch):
                     assert errs["fsw.phase"] == 0.0, (ROWS[i], stop, cp["state"]["fsw"]["phase"], ex.column("fsw_state")[i, 0])
                     for k, e in errs.items():
                         if e > worst.get(k, (0.0,))[0]:
-                            worst[k] = (e, ROWS[i], stop)
+                            worst[k] = (e, ROWS[i], stop, cu.DETAIL.get(k.replace("fsw.", "")))
                     n_cp += 1
     ex.close()
-    top = sorted(worst.items(), key=lambda kv: -kv[1][0])[:6]
+    top = sorted(worst.items(), key=lambda kv: -kv[1][0])[:12]
     print(f"f64 K={ticks_per_launch}: {len(flights)} flights, {n_cp} checkpoints, {n_tr} transitions on their tick; worst of {len(worst)} quantities:",
-          ", ".join(f"{k} {e:.1e} (row {r} tick {t})" for k, (e, r, t) in top))
+          ", ".join(f"{k} {e:.1e} (row {r} tick {t}; abs, scale, part {d})" for k, (e, r, t, d) in top))
     assert n_cp >= (60 if ticks_per_launch > 1 else 30) and n_tr >= (4 * len(flights) if ticks_per_launch > 1 else len(flights))
-    assert max(e for e, _, _ in worst.values()) < 1e-9, top
+    assert max(v[0] for v in worst.values()) < 1e-9, top
 
 
 @pytest.mark.parametrize("fast_math", [False, True])
@@ -85,7 +85,7 @@ def test_generated_kernel_f32_tracks_the_reference_ascents(fast_math):
     for i, fl in enumerate(flights):
         for p, t in fl["transitions"].items():
             got = seen[i].get(int(p))
-            assert got is not None and abs(got - t) <= 250, (ROWS[i], p, t, got)
+            assert got is not None and abs(got - t) <= 250, (ROWS[i], p, t, got)      # measured: <= 20 ticks (two exchanges)
         meco_cp = next(c for c in fl["checkpoints"] if c["tick"] == fl["transitions"]["4"])["state"]
         alt_ref, v_ref = meco_cp["altitude_geodetic"][0], meco_cp["ground_speed"][0]
         # ascent_metrics latch MECO on the tick after the cutoff command: [3] t, [4] altitude, [5] speed
