@@ -281,6 +281,8 @@ class World:
                 continue
             for cname, value in arch.components().items():
                 value = np.ascontiguousarray(value, dtype=np.float64)   # lib.rs:64-75: C-contiguous rows
+                if value.ndim == 2:        # a matrix component ((3, 3) covariance, (480, 3) sample window): its row-major bytes
+                    value = value.reshape(-1)
                 dims = (C.c_uint64 * 2)(value.shape[0] if value.ndim else 1, 0)
                 rc = self._lib.sixdof_world_insert(self._w, int(eid), cname.encode(), L.PRIM_F64, dims, 1,
                                                    value.ctypes.data, value.nbytes)

@@ -276,7 +276,7 @@ def write_campaign(out_dir, plan, results: np.ndarray, result_names: Sequence[st
                        "db_path": m.db_path, "run_dir": str(run_dir)}
             (run_dir / "post_run_context.json").write_text(json.dumps(payload, indent=2) + "\n")
             ctx = _namespace(payload)
-            ctx.params = payload["params"]          # hooks index params as a mapping too (report.py reads it back from the file)
+            ctx.params = _ParamsView(payload["params"])   # `ctx.params.x` like run_hook.py's namespace AND `ctx.params["x"]`
             ctx.out_dir, ctx.seed = str(out), int(plan.seeds[i])
             outcome_json = post_run(ctx)
             (run_dir / "post_run_result.json").write_text(json.dumps(_jsonable(outcome_json), indent=2, sort_keys=True) + "\n")
@@ -289,6 +289,17 @@ def write_campaign(out_dir, plan, results: np.ndarray, result_names: Sequence[st
     summary = summarize_campaign(out, metrics, started, finished, int(round(wall_ms)), workers)
     (out / "summary.json").write_text(json.dumps(summary, indent=2) + "\n")
     return {"summary": summary, "results_header": header, "metrics": metrics}
+
+
+class _ParamsView(dict):
+    """The run's parameters for a hook: attribute access like the namespace the reference's run_hook.py builds
+    (`_namespace` recursion, elodin/monte_carlo/run_hook.py) and a mapping as well (`ctx.params["x"]`, `.items()`)."""
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
 
 
 def _plan_cell(v):

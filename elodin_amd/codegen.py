@@ -255,6 +255,24 @@ class _Emitter:
             sc["lines"].append(f"{sc['indent']}const {ctype} {name} = {rhs_of(e, a)};")
             return name
 
+        # PROGRAM ORDER.  Emitting on demand, depth-first from the outputs, postpones every value to its first use: in an
+        # unrolled Jacobi SVD the V-accumulation is needed only when the decomposition is finished, so all 150 rotations'
+        # (c, s) pairs stayed live until then — 443 live values at the peak of a 6-state EKF step, ~1,000 VGPR spills.  So the
+        # nodes the outputs need are emitted in the order the user's program created them (`Expr.seq`; arguments always
+        # precede their users), which is the order a person would have written the code in: the same step then peaks at a
+        # few matrices' worth of registers.  (Nodes inside loop bodies keep their own scopes and are emitted with their loop.)
+        need, stack = {}, [e for _, e in assign]
+        while stack:
+            x = stack.pop()
+            if id(x) in need or x.op in ("const", "leaf"):
+                continue
+            if x.op == "while":            # emitted through its while_out users; its initial values are ordinary nodes
+                stack.extend(x.args)
+                continue
+            need[id(x)] = x
+            stack.extend(x.args)
+        for x in sorted(need.values(), key=lambda n_: n_.seq):
+            ref(x)
         outs = []
         for lv, e in assign:
             o = f"o{self.n}"
@@ -281,6 +299,17 @@ def emit_block(assign, leaves: Dict[str, str], indent: str = "        ") -> List
 def emit_apply(tp: dsl.TracedPipe) -> List[str]:
     names = ["F.tau_w.x", "F.tau_w.y", "F.tau_w.z", "F.f.x", "F.f.y", "F.f.z", "F.tau_b.x", "F.tau_b.y", "F.tau_b.z"]
     return emit_block(list(zip(names, tp.outputs)), _APPLY_LEAVES)
+
+
+# Fallback layout of a program whose state does not fit a wave's 512 registers (the f64 Falcon 9 closed loop: ~250 doubles
+# of component state + the temporaries of 20 systems): the register image `Regs` is declared `volatile`, i.e. it lives in
+# the lane's private (scratch) memory and every access is a real load / store — deliberate, compiler-independent placement
+# instead of register-allocator spills (a spilling build miscomputed on gfx950 before, see _compile).  The launch-level
+# column load / store and the cold-column scheme stay as they are.  Costs scratch traffic (L1 / L2 resident) on every
+# access: a parity build, not a fast one.  build() switches to it by itself when no register-resident build is spill-free.
+# (Tried first: keeping every column in HBM and wrapping each system in loads / stores — the optimiser forwards the stored
+# values to the next system's loads and the live set stays where it was: 150+ spills with every flag set.)
+_MEMORY_COLUMNS = [False]
 
 
 def _col_slots(names) -> set:
@@ -324,7 +353,13 @@ def _emit_systems(systems, cold: Optional[Dict[int, int]] = None) -> str:
             out.append(f"        if ({cond}) {{  // {s.name}\n{ld}{body}{st}\n        }}")
         else:
             body = "\n".join(em.block(assign, "        ", written))
-            out.append(f"        // {s.name}\n{body}")
+            w_slots = sorted(_col_slots(written) & set(cold))
+            r_slots = sorted((_col_slots(dsl._leaves_of([e for _, e in s.assign])) | set(w_slots)) & set(cold))
+            ld = "".join(f"        if (c_act) {{ const T* g = static_cast<const T*>(P.model_cols[{k}]) + (size_t)c_row * {cold[k]}; "
+                         + " ".join(f"r.c{k}[{j}] = g[{j}];" for j in range(cold[k])) + " }\n" for k in r_slots)
+            st = "".join(f"\n        if (c_act) {{ T* g = static_cast<T*>(P.model_cols[{k}]) + (size_t)c_row * {cold[k]}; "
+                         + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(cold[k])) + " }" for k in w_slots)
+            out.append(f"        // {s.name}\n{ld}{body}{st}")
     return "\n".join(out)
 
 
@@ -500,6 +535,7 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
     """One PIPE struct of csrc/step_kernel.hpp: effector stage from `pipe_tp` (None: no effectors), `pre` / `post` hooks from
     traced systems.  `used`: the program column slots this struct keeps in registers (None: all of tp.columns)."""
     body = "\n".join(emit_apply(pipe_tp)) if pipe_tp is not None else ""
+    apply_loads = ""
     model = ""
     is_prog = tp is not None and isinstance(tp, dsl.TracedProgram)
     win_setup = ""
@@ -509,11 +545,14 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
         written = sorted(_slots_of(pre + post) & {int(t[1:].split("_")[0]) for s_ in pre + post for t in s_.written if t[0] == "c"}) \
             if used is not None else list(tp.written_slots)
         cold = _cold_slots(tp, pipe_tp, pre, post, reg_cols)
-        regs = "\n".join(f"        T c{k}[{w}];" + ("   // cold: lives in its HBM column between cadence blocks" if k in cold else "") for k, w in reg_cols)
+        vol = "volatile " if _MEMORY_COLUMNS[0] else ""
+        regs = "\n".join(f"        {vol}T c{k}[{w}];" + ("   // cold: lives in its HBM column between cadence blocks" if k in cold else "") for k, w in reg_cols)
         loads = "\n".join(
             f"            {{ const T* g = static_cast<const T*>(P.model_cols[{k}]) + (size_t)row * {w}; "
             + " ".join(f"r.c{k}[{j}] = g[{j}];" for j in range(w)) + " }" for k, w in reg_cols if k not in cold)
-        zero = " ".join(f"for (int j = 0; j < {w}; j++) r.c{k}[j] = T(0);" for k, w in reg_cols)
+        # element by element, not a loop: a loop the optimiser does not unroll (-O1, the low-register-pressure fallback build)
+        # indexes the array dynamically, which pins the whole register file image in scratch memory
+        zero = " ".join(" ".join(f"r.c{k}[{j}] = T(0);" for j in range(w)) for k, w in reg_cols)
         stores = "\n".join(
             f"        {{ T* g = static_cast<T*>(P.model_cols[{k}]) + (size_t)row * {cols[k][1]}; "
             + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(cols[k][1])) + " }" for k in written if k not in cold)
@@ -524,6 +563,12 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
             (f"        if (P.model_hist[{k}]) {{ T* g = static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row) * {w}; "
              + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(w)) + " }") for k, w in reg_cols)
         cold_setup = ("        const uint32_t c_row = blockIdx.x * kWave + threadIdx.x;\n        const bool c_act = c_row < P.n;\n" if cold else "")
+        if pipe_tp is not None:
+            a_slots = sorted(_col_slots(dsl._leaves_of(list(pipe_tp.outputs))) & set(cold))
+            if a_slots:      # memory-resident columns the effector stage reads (`r` is the kernel's own register image)
+                apply_loads = (cold_setup + "        auto& rw = const_cast<R&>(r);\n" + "".join(
+                    f"        if (c_act) {{ const T* g = static_cast<const T*>(P.model_cols[{k}]) + (size_t)c_row * {cold[k]}; "
+                    + " ".join(f"rw.c{k}[{j}] = g[{j}];" for j in range(cold[k])) + " }\n" for k in a_slots))
         if _WINDOWS:
             # one lane = one entity, a workgroup is one wave (step_kernel.hpp).  Element e of this lane's window sits at
             # W[e * w_n]: w_n = n for the element-major layout of large executors, 1 (a compile-time constant, so the addresses
@@ -586,7 +631,7 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
     __device__ static __forceinline__ void apply(const StepParams& P, const Vec3<T> (&aux)[kMaxOps], const R& r,
                                                  const Body<T>& b, Wrench<T>& F) {{
         (void)P; (void)r; (void)aux; (void)b; (void)F;
-{body}
+{apply_loads}{body}
     }}
 }};
 '''
@@ -933,8 +978,18 @@ def _headers_digest() -> str:
 
 
 def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_math: bool = False, window_soa: bool = False) -> Path:
-    """Generate + compile (cached by content hash).  Returns the .so path."""
-    return _compile(generate_source(tp, dtype, integrator, fast_math, window_soa), "pipe")
+    """Generate + compile (cached by content hash).  Returns the .so path.  A program that no flag set builds without VGPR
+    spills is generated again with its columns memory-resident (_MEMORY_COLUMNS) before giving up."""
+    try:
+        return _compile(generate_source(tp, dtype, integrator, fast_math, window_soa), "pipe")
+    except SpillError:
+        if not isinstance(tp, dsl.TracedProgram) or os.environ.get(ALLOW_SPILLS_ENV, "") == "1":
+            raise
+    _MEMORY_COLUMNS[0] = True
+    try:
+        return _compile(generate_source(tp, dtype, integrator, fast_math, window_soa), "pipe")
+    finally:
+        _MEMORY_COLUMNS[0] = False
 
 
 # Generated programs are one long straight-line tick body inside the kernel's tick loop.  Left alone, LLVM's MachineLICM
@@ -1015,6 +1070,9 @@ def _compile(src: str, stem: str) -> Path:
                                  "set it again to use it)")
             warnings.warn(_spill_message(so.name, last_resources), RuntimeWarning, stacklevel=3)
         return so
+    if meta.exists() and json.loads(meta.read_text()).get("refused") and not allow_spills:
+        # no flag set built this source without spills before: do not spend minutes finding that out again
+        raise SpillError(_spill_message(so.name, json.loads(meta.read_text())) + " (cached verdict)")
     hip = JIT_DIR / f"{stem}_{digest}.hip"
     temps = []
 
@@ -1040,12 +1098,17 @@ def _compile(src: str, stem: str) -> Path:
         for opt, flags in _ATTEMPTS:
             obj = temp(".so.tmp")
             used = run(opt, flags, obj)
+            if used["vgpr_spills"] and not used.get("scratch_bytes_per_lane", 1):
+                used["vgpr_spills"] = 0      # spill slots that never reached memory (parked in AGPRs / eliminated): no scratch, no spill
             if best is None or used["vgpr_spills"] < best["vgpr_spills"]:
                 best, best_obj = used, obj
             if used["vgpr_spills"] == 0:
                 break
         if best["vgpr_spills"] > 0:
             if not allow_spills:
+                mt = temp(".json.tmp")
+                Path(mt).write_text(json.dumps(dict(best, refused=True)))
+                os.replace(mt, meta)
                 raise SpillError(_spill_message(so.name, best) + f"; no build ({', '.join(o for o, _ in _ATTEMPTS)}) is spill-free. "
                                  f"A spilling build miscomputed on gfx950 before, so it is refused; {ALLOW_SPILLS_ENV}=1 accepts it.")
             warnings.warn(_spill_message(so.name, best), RuntimeWarning, stacklevel=3)

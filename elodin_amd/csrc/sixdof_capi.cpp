@@ -793,10 +793,10 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
         const unsigned expect = k < h->custom_model_width.size() ? h->custom_model_width[k] : 0u;
         const bool window = (expect >> 31) != 0;
         const size_t want = expect & 0x3fffffffu;     // bit 30: the object was built for the element-major window layout
-        if (c->prim != h->state_prim() || c->width < 1 || (!window && c->width > 16) || (want && c->width != want))
+        if (c->prim != h->state_prim() || c->width < 1 || (!window && c->width > 64) || (want && c->width != want))
             return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH,
                            "step: program columns must be of the state dtype and as wide as the generated code expects "
-                           "([n,1..16]; a window column [n, rows*width])");
+                           "([n,1..64]; a window column [n, rows*width])");
         if (!c->joined) {
             int rc = resolve_join(h, c);
             if (rc != SIXDOF_OK) return rc;

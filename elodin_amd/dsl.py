@@ -34,8 +34,9 @@ Number = Union[int, float]
 
 class Expr:
     """One scalar node of the DAG."""
-    __slots__ = ("op", "args", "value", "name")
+    __slots__ = ("op", "args", "value", "name", "seq")
     _interned: Dict[tuple, "Expr"] = {}
+    _count = [0]      # creation counter: `seq` orders nodes the way the user's program created them (arguments first)
 
     def __new__(cls, op: str, args: tuple = (), value=None, name: Optional[str] = None):
         key = (op, tuple(id(a) for a in args), value, name)
@@ -44,6 +45,8 @@ class Expr:
             return hit
         self = object.__new__(cls)
         self.op, self.args, self.value, self.name = op, args, value, name
+        self.seq = cls._count[0]
+        cls._count[0] += 1
         cls._interned[key] = self
         return self
 
@@ -181,6 +184,25 @@ class Vec:
         e = list(self.e)
         e[i] = _lift(value)
         return Vec(e)
+    @property
+    def at(self): return _VecAt(self)
+    @property
+    def T(self): return self                       # a 1-D array is its own transpose
+    @property
+    def shape(self): return (len(self.e),)
+    def transpose(self, *axes): return self
+    def dot(self, o): return self @ o
+    def flatten(self): return self
+    ravel = flatten
+    def reshape(self, *shape):
+        from . import dsl_mat
+        return dsl_mat.reshape(self, shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape)
+    def __matmul__(self, o):
+        from . import dsl_mat
+        return dsl_mat.matmul(self, o)
+    def __rmatmul__(self, o):
+        from . import dsl_mat
+        return dsl_mat.matmul(o, self)
     def __lt__(self, o): return self._zip(o, lambda a, b: a < b)
     def __le__(self, o): return self._zip(o, lambda a, b: a <= b)
     def __gt__(self, o): return self._zip(o, lambda a, b: a > b)
@@ -192,10 +214,42 @@ class Vec:
     def __invert__(self): return Vec([~a for a in self.e])
 
 
+class _VecAt:
+    """`v.at[i].set(x)` / `.add(x)` of jax for a static index or slice — or a TRACED index (`result.at[idx].set(1)`,
+    examples/linalg/sim.py:371-372): every element becomes a select on `idx == k`, indices wrapping like jax's negative ones do not
+    (an index outside [0, n) leaves the vector unchanged, jax's default scatter mode drops it)."""
+
+    def __init__(self, v): self.v = v
+    def __getitem__(self, idx): return _VecAtIdx(self.v, idx)
+
+
+class _VecAtIdx:
+    def __init__(self, v, idx): self.v, self.idx = v, idx
+
+    def _apply(self, value, combine):
+        e = list(self.v.e)
+        if isinstance(self.idx, (Expr,)):
+            val = _lift(value)
+            return Vec([Expr("select", (Expr("eq", (self.idx, const(float(k)))), combine(x, val), x)) for k, x in enumerate(e)])
+        ks = list(range(len(e)))[self.idx] if isinstance(self.idx, slice) else [range(len(e))[int(self.idx)]]
+        vals = list(value.e) if isinstance(value, Vec) else [_lift(value)] * len(ks)
+        if len(vals) != len(ks):
+            raise ValueError("at[...]: value does not fit the slice")
+        for k, x in zip(ks, vals):
+            e[k] = combine(e[k], x)
+        return Vec(e)
+
+    def set(self, value): return self._apply(value, lambda old, new: new)
+    def add(self, value): return self._apply(value, lambda old, new: old + new)
+
+
 def _unary(op):
     def f(x):
         if isinstance(x, Vec):
             return Vec([_un(op, a) for a in x.e])
+        if isinstance(x, list) and x and isinstance(x[0], Vec):          # a matrix (dsl_mat.Mat): element-wise
+            from . import dsl_mat
+            return dsl_mat.Mat([[_un(op, a) for a in r.e] for r in x])
         return _un(op, x)
     return f
 
@@ -244,14 +298,60 @@ class _Np:
     @staticmethod
     def arange(n, dtype=None) -> "Vec": return Vec([float(k) for k in range(int(n))])
     @staticmethod
-    def outer(a: "Vec", b: "Vec"): return [Vec([x * y for y in b.e]) for x in a.e]     # list of rows
+    def outer(a: "Vec", b: "Vec"):
+        from . import dsl_mat
+        return dsl_mat.Mat([[x * y for y in b.e] for x in a.e])
     @staticmethod
     def matvec(rows, v: "Vec") -> "Vec": return Vec([_Np.dot(r, v) for r in rows])    # `mat @ v` for a list of rows
 
     @staticmethod
-    def array(x, dtype=None): return Vec(list(x))
+    def array(x, dtype=None):
+        """jnp.array of a flat sequence -> Vec; of a sequence of rows -> a matrix (dsl_mat.Mat)."""
+        from . import dsl_mat
+        if isinstance(x, (Vec, dsl_mat.Mat)):
+            return x
+        x = list(x)
+        if x and isinstance(x[0], (list, tuple, Vec)):
+            return dsl_mat.Mat(x)
+        return Vec(x)
     @staticmethod
-    def zeros(n, dtype=None): return Vec([0.0] * int(n))
+    def zeros(n, dtype=None, shape=None):
+        from . import dsl_mat
+        n = shape if shape is not None else n
+        if isinstance(n, (tuple, list)):
+            return dsl_mat.zeros2(*n) if len(n) == 2 else Vec([0.0] * int(n[0]))
+        return Vec([0.0] * int(n))
+    @staticmethod
+    def eye(n, m=None, dtype=None):
+        from . import dsl_mat
+        return dsl_mat.eye(n, m)
+    identity = eye
+    @staticmethod
+    def diag(x):
+        from . import dsl_mat
+        return dsl_mat.diag(x)
+    @staticmethod
+    def block(blocks):
+        from . import dsl_mat
+        return dsl_mat.block(blocks)
+    @staticmethod
+    def transpose(x, axes=None): return x.T
+    @staticmethod
+    def swapaxes(x, a, b): return x.T
+    @staticmethod
+    def trace(x):
+        from . import dsl_mat
+        return dsl_mat.trace(x)
+    @staticmethod
+    def matmul(a, b):
+        from . import dsl_mat
+        return dsl_mat.matmul(a, b)
+    @staticmethod
+    def reshape(x, shape):
+        from . import dsl_mat
+        return dsl_mat.reshape(x, shape)
+    @staticmethod
+    def concat(parts, axis=0): return _Np.concatenate(parts, axis)
     @staticmethod
     def sum(v: Vec):
         acc = v.e[0]
@@ -259,7 +359,11 @@ class _Np:
             acc = acc + a
         return acc
     @staticmethod
-    def dot(a: Vec, b: Vec): return _Np.sum(a * b)
+    def dot(a, b):
+        if isinstance(a, Vec) and isinstance(b, Vec):
+            return _Np.sum(a * b)
+        from . import dsl_mat
+        return dsl_mat.matmul(a, b)
     @staticmethod
     def cross(a: Vec, b: Vec):
         return Vec([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]])
@@ -271,6 +375,13 @@ class _Np:
     def clip(x, lo, hi): return _Np.minimum(_Np.maximum(x, lo), hi)
     @staticmethod
     def where(c, a, b):
+        if (isinstance(a, list) and a and isinstance(a[0], Vec)) or (isinstance(b, list) and b and isinstance(b[0], Vec)):
+            from . import dsl_mat
+            m = a if isinstance(a, list) else b
+            am = a if isinstance(a, list) else [Vec([a] * len(m[0]))] * len(m)
+            bm = b if isinstance(b, list) else [Vec([b] * len(m[0]))] * len(m)
+            cm = c if isinstance(c, list) else [c] * len(m)
+            return dsl_mat.Mat([_Np.where(ck, x, y) for ck, x, y in zip(cm, am, bm)])
         if isinstance(a, Vec) or isinstance(b, Vec):
             n = len(a) if isinstance(a, Vec) else len(b)
             av = a if isinstance(a, Vec) else Vec([a] * n)
@@ -301,7 +412,11 @@ class _Np:
             out.extend(v.e if isinstance(v, Vec) else [_lift(v)])
         return Vec(out)
     @staticmethod
-    def ones(n, dtype=None): return Vec([1.0] * int(n))
+    def ones(n, dtype=None):
+        from . import dsl_mat
+        if isinstance(n, (tuple, list)):
+            return dsl_mat.Mat([[1.0] * int(n[1]) for _ in range(int(n[0]))]) if len(n) == 2 else Vec([1.0] * int(n[0]))
+        return Vec([1.0] * int(n))
     # ---- the remaining array-construction / cast / reduction calls the reference's scripts make on this path ----------
     @staticmethod
     def asarray(x, dtype=None):
@@ -319,7 +434,10 @@ class _Np:
     def stack(parts, axis=0):
         """jnp.stack of scalars -> a vector; of vectors -> a matrix as a list of rows (usable with matvec / outer results)."""
         parts = list(parts)
-        return list(parts) if parts and isinstance(parts[0], Vec) else Vec(parts)
+        if parts and isinstance(parts[0], Vec):
+            from . import dsl_mat
+            return dsl_mat.Mat(parts)
+        return Vec(parts)
     @staticmethod
     def zeros_like(x): return Vec([0.0] * len(x)) if isinstance(x, Vec) else const(0.0)
     @staticmethod
@@ -365,16 +483,60 @@ class _Np:
     def rad2deg(x): return x * (180.0 / math.pi)
 
     class linalg:
+        """jax.numpy.linalg for per-entity matrices (elodin_amd/dsl_mat.py: every factorisation unrolled into the kernel)."""
         @staticmethod
-        def norm(v: Vec): return _Np.sqrt(_Np.sum(v * v))   # jnp.linalg.norm, ord=None
+        def norm(v, ord=None, axis=None):                 # jnp.linalg.norm, ord=None: 2-norm of a vector, Frobenius of a matrix
+            if isinstance(v, Vec):
+                return _Np.sqrt(_Np.sum(v * v))
+            from . import dsl_mat
+            return dsl_mat.fro_norm(v)
         @staticmethod
         def det(rows):
-            """Determinant of a 2x2 / 3x3 matrix given as a list of rows (np.stack of vectors, np.outer)."""
+            """Determinant: cofactor form for 2x2 / 3x3 (no pivoting needed), LU with partial pivoting beyond."""
             if len(rows) == 2:
                 return rows[0][0] * rows[1][1] - rows[0][1] * rows[1][0]
-            if len(rows) != 3:
-                raise ValueError("linalg.det: 2x2 or 3x3 only")
-            return _Np.dot(rows[0], _Np.cross(rows[1], rows[2]))
+            if len(rows) == 3:
+                return _Np.dot(rows[0], _Np.cross(rows[1], rows[2]))
+            from . import dsl_mat
+            return dsl_mat.det(rows)
+        @staticmethod
+        def solve(a, b):
+            from . import dsl_mat
+            return dsl_mat.solve(a, b)
+        @staticmethod
+        def inv(a):
+            from . import dsl_mat
+            return dsl_mat.inv(a)
+        @staticmethod
+        def pinv(a, rcond=None, rtol=None, hermitian=False):
+            from . import dsl_mat
+            return dsl_mat.pinv(a, rcond if rcond is not None else rtol)
+        @staticmethod
+        def slogdet(a):
+            from . import dsl_mat
+            return dsl_mat.slogdet(a)
+        @staticmethod
+        def cholesky(a, upper=False):
+            from . import dsl_mat
+            return dsl_mat.cholesky(a, lower=not upper)
+        @staticmethod
+        def qr(a, mode="reduced"):
+            from . import dsl_mat
+            return dsl_mat.qr(a)
+        @staticmethod
+        def svd(a, full_matrices=True, compute_uv=True):
+            from . import dsl_mat
+            return dsl_mat.svd(a, full_matrices, compute_uv)
+        @staticmethod
+        def eigh(a, UPLO=None, symmetrize_input=True):
+            from . import dsl_mat
+            return dsl_mat.eigh(a)
+        @staticmethod
+        def eigvalsh(a, UPLO=None):
+            from . import dsl_mat
+            return dsl_mat.eigvalsh(a)
+        @staticmethod
+        def matrix_transpose(a): return a.T
 
 
 def _zipv(a, b, f):
@@ -391,6 +553,8 @@ np = _Np
 
 def _tree_select(c, a, b):
     """Element-wise select over the value kinds systems exchange: scalars, Vec, spatial types, tuples / dicts of those."""
+    if isinstance(a, list) and a and isinstance(a[0], Vec):       # a matrix: before the generic sequence case, keeps its type
+        return _Np.where(c, a, b)
     if isinstance(a, (tuple, list)):
         return type(a)(_tree_select(c, x, y) for x, y in zip(a, b))
     if isinstance(a, dict):
@@ -888,6 +1052,35 @@ class WindowPush:
         self.window, self.row = window, row
 
 
+# A component declared with a 2-D shape is a MATRIX held in registers (dsl_mat.Mat: a 3 x 3 / 6 x 6 filter covariance,
+# examples/linalg/sim.py:33-58) when it has at most _MAT_AUTO_ELEMS values, otherwise a WINDOW kept in HBM (dsl.Window: the
+# rocket example's 480 x 3 sample buffer).  `dsl.matrix(r, c)` / `dsl.window(r, c)` as the declared shape say it explicitly
+# (a register matrix may have up to _MAT_MAX_ELEMS values).
+_MAT_AUTO_ELEMS = 36
+_MAT_MAX_ELEMS = 64
+
+
+class matrix(tuple):
+    """`@dsl.system(p=dsl.matrix(8, 8))`: a 2-D component as a register matrix whatever its size (<= 64 values)."""
+    def __new__(cls, rows, cols): return tuple.__new__(cls, (int(rows), int(cols)))
+
+
+class window(tuple):
+    """`@dsl.system(buf=dsl.window(16, 3))`: a 2-D component as a memory-resident window whatever its size."""
+    def __new__(cls, rows, cols): return tuple.__new__(cls, (int(rows), int(cols)))
+
+
+def _is_matrix_shape(d) -> bool:
+    if isinstance(d, window) or not isinstance(d, (tuple, list)) or len(d) != 2:
+        return False
+    n = int(d[0]) * int(d[1])
+    if isinstance(d, matrix):
+        if n > _MAT_MAX_ELEMS:
+            raise ValueError(f"a register matrix holds at most {_MAT_MAX_ELEMS} values, got {tuple(d)}")
+        return True
+    return n <= _MAT_AUTO_ELEMS
+
+
 class ColumnTable:
     """Component columns used by generated code, in first-use order: name -> (slot, width)."""
 
@@ -896,6 +1089,7 @@ class ColumnTable:
         self.known = dict(known or {})
         self.cols: List[Tuple[str, int]] = []
         self.windows: Dict[str, List[int]] = {}      # name -> [slot, rows, width, version]
+        self.mats: Dict[str, Tuple[int, int]] = {}    # name -> (rows, cols) of a small 2-D component held in registers
 
     def window(self, name: str, rows: int, width: int) -> Window:
         """The memory-resident component `name` ([rows, width] per entity) at its current version, plus its hidden head."""
@@ -918,6 +1112,17 @@ class ColumnTable:
 
     def bump(self, name: str):
         self.windows[name][3] += 1
+
+    def matrix(self, name: str, rows: int, cols: int):
+        """A SMALL 2-D component (`el.ComponentType(F64, (3, 3))`: a filter covariance, examples/linalg/sim.py:33-36): a
+        register column of rows * cols values in the reference's row-major order, handed to the system as a dsl_mat.Mat."""
+        from . import dsl_mat
+        rows, cols = int(rows), int(cols)
+        have = self.mats.get(name)
+        if have is not None and have != (rows, cols):
+            raise ValueError(f"matrix component {name}: conflicting shapes {have} / {(rows, cols)}")
+        self.mats[name] = (rows, cols)
+        return dsl_mat.reshape(self.symbols(name, rows * cols, rows * cols), (rows, cols))
 
     def symbols(self, name: str, declared: Optional[int], default: int) -> Vec:
         if name in self.windows:
@@ -1171,8 +1376,11 @@ class TracedSystem:
         pos, vel, inertia = _body_symbols()
         kwargs = {}
 
+        def declared(name):
+            return sys_.widths.get(name, table.known.get(name))
+
         def shape_of(name):
-            d = sys_.widths.get(name, table.known.get(name))
+            d = declared(name)
             return tuple(int(x) for x in d) if isinstance(d, (tuple, list)) else None
         for name in sys_.params:
             if name in ("accel", "world_accel"):
@@ -1191,6 +1399,8 @@ class TracedSystem:
                 kwargs[name] = leaf("tick")
             elif name == "force":
                 raise TypeError("systems outside six_dof cannot read `force`")
+            elif _is_matrix_shape(declared(name)) and name not in table.windows:
+                kwargs[name] = table.matrix(name, *shape_of(name))      # a small matrix: registers, not a window
             elif shape_of(name) is not None:
                 if name in partial:
                     raise TypeError(f"system {self.name}: window component {name} must live on every row of the executor")
@@ -1239,8 +1449,14 @@ class TracedSystem:
                     self.assign.append((f"I{c}", e))
                 self.assign.append(("mass", _lift(val.mass())))
             else:
+                if isinstance(val, list) and val and isinstance(val[0], Vec):      # a matrix (dsl_mat.Mat / list of rows): row-major
+                    table.mats.setdefault(cname, (len(val), len(val[0])))
+                    val = Vec([e for row in val for e in row.e])
                 v = val if isinstance(val, Vec) else Vec([val])
-                cur = table.symbols(cname, sys_.widths.get(cname, len(v)), len(v))
+                declared = sys_.widths.get(cname, len(v))
+                if isinstance(declared, (tuple, list)):
+                    declared = int(declared[0]) * int(declared[1])
+                cur = table.symbols(cname, declared, len(v))
                 if len(cur) != len(v):
                     raise ValueError(f"system {self.name}: component {cname} has width {len(cur)}, got {len(v)} values")
                 for k, e in enumerate(v.e):
@@ -1346,7 +1562,7 @@ class TracedFoldStage:
 class TracedProgram:
     def __init__(self, prog: Program, widths: Optional[Dict[str, int]] = None, partial: Sequence[str] = (), fold_edges=None,
                  fold_replicas: Optional[Tuple[int, int]] = None):
-        self.table = ColumnTable("c", 64, 16, widths)
+        self.table = ColumnTable("c", 64, _MAT_MAX_ELEMS, widths)
         self.partial = tuple(partial)
         fold_edges = fold_edges or {}
         n_folds = [0]

@@ -127,6 +127,7 @@ class HipExec:
                 if isinstance(effectors, _dsl.Program):
                     self._program_columns = [n for n, _ in custom.columns]
                     self._windows = {name: (rows, width) for name, (_, rows, width) in custom.windows.items()}
+                    self._mats = dict(custom.table.mats)       # small 2-D components held as register matrices
                     columns = dict(columns or {})
                     for name in self._windows:       # the ring's head (physical index of the oldest row): starts at 0
                         columns.setdefault(name + "#head", np.zeros((np.shape(columns[name])[0], 1)) if name in columns else None)
@@ -246,6 +247,8 @@ class HipExec:
         """A generated program's component column as the reference lays it out.  Plain columns: the [n, w] host array
         itself.  Window components (dsl.Window) are kept as a ring on the device: un-rotated here to [n, rows, w], oldest
         row first — what `concatenate((buffer[1:], row))` leaves in the reference's column."""
+        if name in getattr(self, "_mats", {}):
+            return self._aux[name].reshape(self._aux[name].shape[0], *self._mats[name])
         if name not in self._windows:
             return self._aux[name]
         rows, width = self._windows[name]

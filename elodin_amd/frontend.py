@@ -99,8 +99,9 @@ def _origin(component: Any):
 
 
 def _window_shape(component: Any) -> Optional[Tuple[int, int]]:
-    """(rows, width) of a component declared with a 2-D shape, e.g. `el.ComponentType(F64, (480, 3))`
-    (examples/rocket/main.py:91-98): kept in HBM as a window (dsl.Window), not in the register file."""
+    """(rows, width) of a component declared with a 2-D shape: `el.ComponentType(F64, (480, 3))` (examples/rocket/main.py:91-98)
+    is kept in HBM as a window (dsl.Window); a small one — `(3, 3)`, a filter covariance (examples/linalg/sim.py:33-36), up to
+    36 values — is a register matrix (dsl_mat.Mat).  The tracer decides by size (dsl._is_matrix_shape)."""
     c = Component.of(component)
     if c.ty is not None and len(c.ty.shape) == 2:
         return int(c.ty.shape[0]), int(c.ty.shape[1])
@@ -374,6 +375,9 @@ def _probe_value(component):
         return _dsl.leaf("tick")
     if _window_shape(component) is not None:
         rows, width = _window_shape(component)
+        if _dsl._is_matrix_shape((rows, width)):      # a small matrix (a 3 x 3 covariance): registers (dsl_mat.Mat), not a window
+            from . import dsl_mat
+            return dsl_mat.Mat([[_dsl.leaf(f"probe:{name}:{i}_{j}") for j in range(width)] for i in range(rows)])
         return _dsl.Window(name, 0, rows, width, _dsl.leaf(f"probe:{name}:head"), 0)
     v = _dsl.Vec([_dsl.leaf(f"probe:{name}:{k}") for k in range(w or 1)])
     return v if len(v) > 1 else v[0]

@@ -1,8 +1,12 @@
 """Test-side evaluator of a traced effector pipe (elodin_amd.dsl.TracedPipe) with numpy, vectorised over
 entities: the independent check of what elodin_amd/codegen.py generates.  TEST INFRASTRUCTURE."""
+import sys
+
 import numpy as np
 
 from scipy.special import erfc as _erfc
+
+sys.setrecursionlimit(max(sys.getrecursionlimit(), 20000))     # unrolled factorisations (dsl_mat) are deep, narrow DAGs
 from scipy.special import erfinv as _erfinv
 
 

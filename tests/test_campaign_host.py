@@ -53,6 +53,8 @@ def test_hook_metric_summary_uses_the_reference_percentile():
 def _score(ctx):
     """Shape of examples/apollo-lander/hooks/score.py:post_run, own code: reads result.json, returns scalars + verdict."""
     r = json.loads((Path(ctx.run_dir) / "result.json").read_text())
+    name = next(iter(ctx.params))                  # a run's parameters: a mapping AND attributes, like run_hook.py's namespace
+    assert getattr(ctx.params, name) == ctx.params[name] and dict(ctx.params.items())[name] == ctx.params[name]
     return {"landed": bool(r["landed"]), "soft_landing": bool(r["soft_landing"]), "valid": bool(r), "pass": bool(r["soft_landing"]),
             "touchdown_speed_mps": r["touchdown_speed"], "fuel_remaining_kg": r["fuel_remaining"],
             "downrange_miss_m": float("inf") if not r["landed"] else r["downrange_miss"], "seed_seen": ctx.seed}

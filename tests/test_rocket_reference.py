@@ -36,19 +36,19 @@ def test_window_component_api_guards():
     import pytest
     from elodin_amd import dsl
 
-    @dsl.system(buf=(4, 2), x=2)
+    @dsl.system(buf=dsl.window(4, 2), x=2)        # (a bare (4, 2) would be a register matrix: <= 36 values, dsl._is_matrix_shape)
     def whole(buf, x):
         return {"buf": buf}
     with pytest.raises(TypeError, match="push"):
         dsl.Program([whole], dsl.Pipe([]), []).trace()
 
-    @dsl.system(buf=(4, 2), x=3)
+    @dsl.system(buf=dsl.window(4, 2), x=3)
     def wrong_width(buf, x):
         return {"buf": buf.push(x)}
     with pytest.raises(ValueError, match="row has 2"):
         dsl.Program([wrong_width], dsl.Pipe([]), []).trace()
 
-    @dsl.system(buf=17)
+    @dsl.system(buf=65)
     def too_wide(buf):
         return {"buf": buf}
     with pytest.raises(ValueError, match="window"):
