@@ -326,8 +326,29 @@ class World:
         to = np.array([b for _, b in pairs], dtype=np.uint64)
         return (to, frm) if reverse else (frm, to)
 
+    def generated_sources(self, system, simulation_rate: float = 120.0, dtype: str = "float64") -> Dict[str, str]:
+        """The HIP sources World.build would generate for `system` (kernel name -> text), without touching a device: what a
+        user script compiles to.  Two scripts that build the same program produce the same text (tests compare a reference
+        script imported under elodin_amd.compat with its respelling this way).  Built-in effector ops generate nothing."""
+        plan = self.build(system, simulation_rate=simulation_rate, _dry=True)
+        from . import codegen, dsl as _dsl
+        out = {}
+        effs = plan["effectors"]
+        if isinstance(effs, _dsl.Effector):
+            effs = _dsl.pipe(effs)
+        if isinstance(effs, (_dsl.Pipe, _dsl.Program)):
+            cols = plan["columns"] or {}
+            widths = {k: (tuple(int(x) for x in np.shape(v)[1:]) if np.ndim(v) == 3 else int(np.atleast_2d(np.asarray(v)).shape[-1]))
+                      for k, v in cols.items() if v is not None}
+            out["step"] = codegen.generate_source(effs.trace(widths), dtype, plan["integrator"])
+        else:
+            for e in effs:
+                if isinstance(e, _dsl.EdgeFold):
+                    out["pair"] = codegen.generate_pair_source(e.trace())
+        return out
+
     def build(self, system: System, simulation_rate: float = 120.0, telemetry_rate: Optional[float] = None,
-              device: int = 0, backend: str = "hip") -> "Exec":
+              device: int = 0, backend: str = "hip", _dry: bool = False) -> "Exec":
         """World.build (world_builder.rs:1737-1780): validate rates, fix globals, bind the backend."""
         import os
         backend = os.environ.get("ELODIN_BACKEND", backend)    # same override as world_builder.rs:248
@@ -533,6 +554,9 @@ class World:
                     body_ids &= set(int(e) for e in v)
                 keep = np.array([int(a) in body_ids and int(b) in body_ids for a, b in zip(*edges)], dtype=bool)
                 edges = (edges[0][keep], edges[1][keep])
+        if _dry:       # generated_sources(): everything resolved, nothing bound
+            return dict(effectors=effs, columns=extra_columns, edges=edges, dt=dt,
+                        integrator=L.INTEGRATOR_NONE if getattr(system, "no_six_dof", False) else system.integrator.value)
         hip = HipExec(pos, body["world_vel"][0], body["inertia"][0], world_accel=body["world_accel"][0],
                       force=body["force"][0], entity_ids=ids, simulation_time_step=dt, time_step=system.time_step,
                       integrator=L.INTEGRATOR_NONE if getattr(system, "no_six_dof", False) else system.integrator.value,

@@ -1,0 +1,240 @@
+"""Run a reference script UNMODIFIED: `import elodin as el`, `import jax`, `from jax import numpy as jnp`, `jax.lax`,
+`jax.random`, `jax.scipy.linalg` resolve to this package's front-end.
+
+    import elodin_amd.compat as compat
+    compat.install()                 # before the script is imported
+    import sim                        # e.g. /root/reference/examples/ball/sim.py, untouched
+    exec = sim.world().build(sim.system())
+
+The reference's Python surface (libs/nox-py/python/elodin/__init__.py:160-557: decorators, queries, archetypes, spatial
+types) is `elodin_amd.frontend`; what a script additionally needs is `jax.numpy`.  A reference script uses it in two places
+with two meanings: at module level and while spawning, on concrete numbers (`jnp.array([0.0, 0.0, 6.0])` is data); inside
+`@el.map` / `@el.system` functions, on traced values.  The shim keeps that split: every `jnp.<fn>` call goes to the tracer
+(`elodin_amd.dsl.np`) when user code is being traced (dsl.TRACING) or an argument is a traced value, and to plain numpy
+otherwise; host arrays captured by traced code (module-level constants such as a filter's F matrix) enter the trace as
+constants (dsl._host).  Nothing here computes on the device or restates an algorithm — it is name resolution.
+
+What the shim is not: JAX.  `jax.jit`, `jax.grad`, `jax.vmap` over traced code, device arrays, pytrees are not provided;
+a script that uses them fails with AttributeError / NotImplementedError naming the missing piece.  `World.run(...)` (the
+reference's blocking entry point that also launches the editor) builds the executor and steps `max_ticks` ticks on the GPU
+when `max_ticks` is given; `compat.install(run="record")` makes it only remember its arguments (`world.compat_run`), which is
+what tests on a machine without a GPU use to look at the program a script builds.
+"""
+from __future__ import annotations
+
+import sys
+import types
+
+import numpy as _np
+
+from . import dsl as _dsl
+from . import dsl_mat as _mat
+from . import frontend as _fe
+
+_RUN_MODE = ["execute"]
+
+
+def _symbolic(x) -> bool:
+    if isinstance(x, (_dsl.Expr, _dsl.Vec, _dsl.Quaternion, _dsl.SpatialTransform, _dsl.SpatialMotion, _dsl.SpatialForce,
+                      _dsl.SpatialInertia, _dsl.Window)):
+        return True
+    if isinstance(x, (list, tuple)):
+        return any(_symbolic(v) for v in x)
+    if isinstance(x, dict):
+        return any(_symbolic(v) for v in x.values())
+    return False
+
+
+def _to_trace(x):
+    """Host data handed to a tracer function: arrays become constant vectors / matrices, scalars stay."""
+    if isinstance(x, _np.ndarray):
+        return _dsl._host(x) if x.ndim else float(x)
+    if isinstance(x, _np.generic):
+        return float(x)
+    return x
+
+
+class _Dispatch(types.ModuleType):
+    """A module whose functions exist twice: `traced` (elodin_amd.dsl.*) and `host` (numpy.*)."""
+
+    def __init__(self, name, traced, host, extra=None):
+        super().__init__(name)
+        self.__dict__["_traced"], self.__dict__["_host"] = traced, host
+        self.__dict__.update(extra or {})
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        traced, host = self.__dict__["_traced"], self.__dict__["_host"]
+        t = getattr(traced, name, None) if traced is not None else None
+        h = getattr(host, name, None) if host is not None else None
+        if t is None and h is None:
+            raise AttributeError(f"{self.__name__}.{name} is not provided by elodin_amd.compat")
+        if h is not None and not callable(h):
+            if isinstance(h, (int, float, type(None))):
+                return h                                 # constants: pi, inf, e, newaxis
+            raise AttributeError(f"{self.__name__}.{name} is not provided by elodin_amd.compat")   # sub-packages: fft, ma, ...
+        if isinstance(h, type) and t is None:
+            return h                                     # numpy types used as annotations / constructors
+
+        def call(*args, **kw):
+            tracing = _dsl.TRACING[0] > 0 or _symbolic(args) or _symbolic(kw)
+            if tracing and t is not None:
+                kw.pop("dtype", None) if name not in ("array", "zeros", "ones", "asarray", "arange", "eye", "full") else None
+                return t(*[_to_trace(a) for a in args], **{k: _to_trace(v) for k, v in kw.items()})
+            if h is None:
+                if t is None:
+                    raise AttributeError(f"{self.__name__}.{name}")
+                return t(*args, **kw)
+            return h(*args, **kw)
+        call.__name__ = name
+        return call
+
+
+def _host_array(x, dtype=None):
+    """jnp.array / jnp.asarray on concrete data under jax_enable_x64 (the reference's setting): Python floats are float64,
+    Python ints int64 — numpy's own rules."""
+    a = _np.asarray(x)
+    return a.astype(dtype) if dtype is not None else a
+
+
+class _HostNumpy:
+    """numpy with jax.numpy's float64 / functional-update defaults for the handful of constructors scripts call on data."""
+
+    def __getattr__(self, name):
+        return getattr(_np, name)
+
+    @staticmethod
+    def array(x, dtype=None): return _host_array(x, dtype)
+    @staticmethod
+    def asarray(x, dtype=None): return _host_array(x, dtype)
+    @staticmethod
+    def zeros(shape, dtype=None): return _np.zeros(shape, dtype=dtype or _np.float64)
+    @staticmethod
+    def ones(shape, dtype=None): return _np.ones(shape, dtype=dtype or _np.float64)
+    @staticmethod
+    def eye(n, m=None, dtype=None): return _np.eye(n, m, dtype=dtype or _np.float64)
+    @staticmethod
+    def identity(n, dtype=None): return _np.identity(n, dtype=dtype or _np.float64)
+    @staticmethod
+    def concat(parts, axis=0): return _np.concatenate(parts, axis=axis)
+
+
+class _TracedScipyLinalg:
+    """jax.scipy.linalg calls met in the reference's examples (examples/linalg/sim.py:343-345)."""
+
+    @staticmethod
+    def cholesky(a, lower=False): return _mat.cholesky(a, lower=lower)
+    @staticmethod
+    def solve(a, b, **kw): return _mat.solve(a, b)
+    @staticmethod
+    def inv(a): return _mat.inv(a)
+    @staticmethod
+    def det(a): return _mat.det(a)
+
+
+def _make_jax():
+    import scipy.linalg as _sla
+    jax = types.ModuleType("jax")
+    host = _HostNumpy()
+    jnp = _Dispatch("jax.numpy", _dsl.np, host)
+    la = _Dispatch("jax.numpy.linalg", _dsl.np.linalg, _np.linalg)
+    jnp.__dict__["linalg"] = la
+    for tname in ("float64", "float32", "int64", "int32", "uint64", "bool_", "ndarray"):
+        jnp.__dict__[tname] = getattr(_np, tname)
+    lax = _Dispatch("jax.lax", _dsl.lax, None)
+    rnd = _Dispatch("jax.random", _dsl.random, None, {"PRNGKey": _dsl.random.key})
+    jsl = _Dispatch("jax.scipy.linalg", _TracedScipyLinalg, _sla)
+    jscipy = types.ModuleType("jax.scipy")
+    jscipy.linalg = jsl
+    jax.numpy, jax.lax, jax.random, jax.scipy = jnp, lax, rnd, jscipy
+    jax.Array = _np.ndarray
+    jax.typing = types.SimpleNamespace(ArrayLike=_np.ndarray)
+    jax.config = types.SimpleNamespace(update=lambda *a, **k: None)
+
+    def _unsupported(what):
+        def f(*a, **k):
+            raise NotImplementedError(f"jax.{what} is not provided by elodin_amd.compat (the front-end traces per-entity code; "
+                                      "there is no JAX underneath)")
+        return f
+    jax.jit = lambda f=None, **k: (f if f is not None else (lambda g: g))      # a no-op: everything traced is compiled anyway
+    jax.grad, jax.vmap, jax.pmap = _unsupported("grad"), _unsupported("vmap"), _unsupported("pmap")
+    return {"jax": jax, "jax.numpy": jnp, "jax.numpy.linalg": la, "jax.lax": lax, "jax.random": rnd, "jax.scipy": jscipy,
+            "jax.scipy.linalg": jsl}
+
+
+class _Inert:
+    """Editor / recipe declarations (el.Panel, el.s10.PyRecipe ...): accepted and ignored."""
+
+    def __init__(self, *a, **k): pass
+    def __call__(self, *a, **k): return _Inert()
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Inert()
+
+
+def _make_elodin():
+    el = types.ModuleType("elodin")
+    el.__path__ = []
+    for name in dir(_fe):
+        if not name.startswith("_"):
+            setattr(el, name, getattr(_fe, name))
+    import typing
+    el.Annotated = typing.Annotated
+    el.skew = lambda v: (_mat.skew(_to_trace(v)) if (_dsl.TRACING[0] > 0 or _symbolic(v)) else
+                         _np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]]))
+
+    class World(_fe.World):
+        """el.World with the reference's entry points that have no meaning without its editor / database accepted:
+        `schematic(...)`, `recipe(...)` are ignored, `run(system, ...)` builds and steps (see the module docstring)."""
+
+        def schematic(self, *a, **k): return None
+        def recipe(self, *a, **k): return None
+        def glb(self, *a, **k): return None
+
+        def run(self, system, simulation_rate: float = 120.0, max_ticks=None, telemetry_rate=None, post_step=None, **ignored):
+            self.compat_run = dict(system=system, simulation_rate=simulation_rate, max_ticks=max_ticks, telemetry_rate=telemetry_rate,
+                                   post_step=post_step, ignored=ignored)
+            if _RUN_MODE[0] == "record":
+                return None
+            ex = self.build(system, simulation_rate=simulation_rate, telemetry_rate=telemetry_rate)
+            if post_step is not None:
+                raise NotImplementedError("World.run(post_step=...) is not provided by elodin_amd.compat: step the executor yourself")
+            if max_ticks:
+                ex.run(int(max_ticks))
+            self.compat_exec = ex
+            return ex
+    el.World = el.WorldBuilder = World
+    for name in ("Panel", "Mesh", "Material", "Shape", "Color", "Glb", "Scene", "Line3d", "BodyAxes", "VectorArrow", "s10",
+                 "StepContext", "Time"):
+        if not hasattr(el, name):
+            setattr(el, name, _Inert())
+    return el
+
+
+_INSTALLED = {}
+
+
+def install(run: str = "execute") -> None:
+    """Make `import elodin`, `import jax`, `from jax import numpy, lax, random` resolve to this package.  Refuses to shadow a
+    real JAX / elodin that is already imported."""
+    if run not in ("execute", "record"):
+        raise ValueError("run must be 'execute' or 'record'")
+    _RUN_MODE[0] = run
+    if _INSTALLED:
+        return
+    for name in ("jax", "elodin"):
+        if name in sys.modules and getattr(sys.modules[name], "__file__", None):
+            raise RuntimeError(f"a real `{name}` is already imported; elodin_amd.compat will not shadow it")
+    mods = _make_jax()
+    mods["elodin"] = _make_elodin()
+    sys.modules.update(mods)
+    _INSTALLED.update(mods)
+
+
+def uninstall() -> None:
+    for name, mod in list(_INSTALLED.items()):
+        if sys.modules.get(name) is mod:
+            del sys.modules[name]
+    _INSTALLED.clear()

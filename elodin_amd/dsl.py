@@ -27,6 +27,8 @@ from __future__ import annotations
 
 import inspect
 import math
+
+import numpy as _numpy          # host arrays met inside traced code (module-level constants of a user script); `np` below is _Np
 from typing import Callable, Dict, List, Optional, Sequence, Tuple, Union
 
 Number = Union[int, float]
@@ -50,15 +52,18 @@ class Expr:
         cls._interned[key] = self
         return self
 
+    # numpy must not broadcast a traced value into an object array: `ndarray * traced` falls through to the reflected method
+    __array_ufunc__ = None
+
     # ---- arithmetic -------------------------------------------------------------------------------------------
-    def __add__(self, o): return NotImplemented if isinstance(o, Vec) else _bin("add", self, o)
-    def __radd__(self, o): return _bin("add", o, self)
-    def __sub__(self, o): return NotImplemented if isinstance(o, Vec) else _bin("sub", self, o)
-    def __rsub__(self, o): return _bin("sub", o, self)
-    def __mul__(self, o): return NotImplemented if isinstance(o, Vec) else _bin("mul", self, o)
-    def __rmul__(self, o): return _bin("mul", o, self)
-    def __truediv__(self, o): return NotImplemented if isinstance(o, Vec) else _bin("div", self, o)
-    def __rtruediv__(self, o): return _bin("div", o, self)
+    def __add__(self, o): return NotImplemented if isinstance(o, Vec) else (_host(o) + self if _is_host_array(o) else _bin("add", self, o))
+    def __radd__(self, o): return _host(o) + self if _is_host_array(o) else _bin("add", o, self)
+    def __sub__(self, o): return NotImplemented if isinstance(o, Vec) else (-(_host(o) - self) if _is_host_array(o) else _bin("sub", self, o))
+    def __rsub__(self, o): return _host(o) - self if _is_host_array(o) else _bin("sub", o, self)
+    def __mul__(self, o): return NotImplemented if isinstance(o, Vec) else (_host(o) * self if _is_host_array(o) else _bin("mul", self, o))
+    def __rmul__(self, o): return _host(o) * self if _is_host_array(o) else _bin("mul", o, self)
+    def __truediv__(self, o): return NotImplemented if isinstance(o, Vec) else (self * (1.0 / _host(o)) if _is_host_array(o) else _bin("div", self, o))
+    def __rtruediv__(self, o): return _host(o) / self if _is_host_array(o) else _bin("div", o, self)
     def __neg__(self): return const(-self.value) if self.op == "const" else Expr("neg", (self,))
     def __pow__(self, k):
         if isinstance(k, int) and k >= 1:      # jnp integer_pow: repeated multiply
@@ -97,7 +102,44 @@ def _lift(x) -> Expr:
         return x
     if isinstance(x, (int, float)):
         return const(x)
+    if isinstance(x, (_numpy.generic, _numpy.ndarray)) and _numpy.ndim(x) == 0:
+        return const(float(x))
     raise TypeError(f"cannot use {type(x).__name__} in a traced effector")
+
+
+def _is_host_array(o) -> bool:
+    return isinstance(o, _numpy.ndarray) and o.ndim >= 1
+
+
+def _host(o):
+    """A host array met inside traced code (a module-level constant of a user script) as a traced constant: 1-D -> Vec,
+    2-D -> a matrix (dsl_mat.Mat)."""
+    if isinstance(o, _numpy.ndarray):
+        if o.ndim == 1:
+            return Vec([float(x) for x in o])
+        if o.ndim == 2:
+            from . import dsl_mat
+            return dsl_mat.Mat([[float(x) for x in r] for r in o])
+        if o.ndim == 0:
+            return const(float(o))
+        if o.ndim == 3:
+            from . import dsl_mat
+            return dsl_mat.Batch([_host(m) for m in o])
+        raise TypeError("arrays of more than three dimensions cannot enter traced code")
+    return o
+
+
+# > 0 while user code is being called on symbols (frontend decorators at decoration time, the tracers at build time): a
+# script-compatibility layer (elodin_amd/compat.py) then hands out traced values where plain numpy would do outside
+TRACING = [0]
+
+
+class _Tracing:
+    def __enter__(self): TRACING[0] += 1
+    def __exit__(self, *a): TRACING[0] -= 1
+
+
+tracing = _Tracing
 
 
 def _const_tree(e: "Expr") -> bool:
@@ -154,6 +196,8 @@ def _bin(op: str, a, b) -> Expr:
 class Vec:
     """Fixed-length vector of scalar nodes (jnp 1-D array of static shape)."""
 
+    __array_ufunc__ = None
+
     def __init__(self, elems: Sequence):
         self.e: Tuple[Expr, ...] = tuple(_lift(x) for x in elems)
 
@@ -163,6 +207,12 @@ class Vec:
         r = self.e[i]
         return Vec(r) if isinstance(i, slice) else r
     def _zip(self, o, f):
+        if _is_host_array(o):
+            if o.ndim == 2:           # vector (op) host matrix: numpy's row broadcast, done by the matrix
+                return NotImplemented
+            o = _host(o)
+        if isinstance(o, list) and o and isinstance(o[0], Vec):      # a matrix operand: let it broadcast this row vector
+            return NotImplemented
         if isinstance(o, Vec):
             if len(o) != len(self):
                 raise ValueError("shape mismatch")
@@ -337,7 +387,9 @@ class _Np:
     @staticmethod
     def transpose(x, axes=None): return x.T
     @staticmethod
-    def swapaxes(x, a, b): return x.T
+    def swapaxes(x, a, b):
+        x = _host(x)
+        return x.mT if hasattr(x, "mT") else x.T
     @staticmethod
     def trace(x):
         from . import dsl_mat
@@ -486,6 +538,7 @@ class _Np:
         """jax.numpy.linalg for per-entity matrices (elodin_amd/dsl_mat.py: every factorisation unrolled into the kernel)."""
         @staticmethod
         def norm(v, ord=None, axis=None):                 # jnp.linalg.norm, ord=None: 2-norm of a vector, Frobenius of a matrix
+            v = _host(v)
             if isinstance(v, Vec):
                 return _Np.sqrt(_Np.sum(v * v))
             from . import dsl_mat
@@ -1165,7 +1218,8 @@ class TracedPipe:
                     kwargs[name] = inertia
                 else:
                     kwargs[name] = self.table.symbols(name, eff.widths.get(name), 3)
-            out = eff.fn(**kwargs)
+            with tracing():
+                out = eff.fn(**kwargs)
             if not isinstance(out, SpatialForce):
                 raise TypeError(f"effector {eff.__name__} must return a dsl.SpatialForce")
             if out._q is None:
@@ -1273,7 +1327,8 @@ class TracedFold:
         acc = SpatialForce(torque=Vec([leaf(f"acc{k}") for k in range(3)]), linear=Vec([leaf(f"acc{k}") for k in range(3, 6)]))
         a = (_EdgeTransform(Vec([leaf("a" + c) for c in "xyz"])), _EdgeInertia(leaf("ma")))
         b = (_EdgeTransform(Vec([leaf("b" + c) for c in "xyz"])), _EdgeInertia(leaf("mb")))
-        out = fold.fn(acc, a[0], a[1], b[0], b[1])
+        with tracing():
+            out = fold.fn(acc, a[0], a[1], b[0], b[1])
         if not isinstance(out, SpatialForce):
             raise TypeError(f"edge_fold function {fold.__name__} must return a dsl.SpatialForce")
         if not all(e.is_const(0.0) for e in out._tb.e):
@@ -1316,7 +1371,8 @@ class TracedGraphFold:
         acc = sym("acc", w_out)
         args = [sym(f"a{i}", self.widths[n]) for i, n in enumerate(fold.left)]
         args += [sym(f"b{i}", self.widths[n]) for i, n in enumerate(fold.right)]
-        out = fold.fn(acc, *args)
+        with tracing():
+            out = fold.fn(acc, *args)
         out = out if isinstance(out, Vec) else Vec([out])
         if len(out) != w_out:
             raise ValueError(f"fold function returned {len(out)} values for component {fold.out} of width {w_out}")
@@ -1408,7 +1464,8 @@ class TracedSystem:
             else:
                 v = table.symbols(name, sys_.widths.get(name), 1)
                 kwargs[name] = v if len(v) > 1 else v[0]
-        out = sys_.fn(**kwargs)
+        with tracing():
+            out = sys_.fn(**kwargs)
         if not isinstance(out, dict):
             raise TypeError(f"system {self.name} must return a dict {{component: value}}")
         self.assign: List[Tuple[str, Expr]] = []      # (leaf name written, value)

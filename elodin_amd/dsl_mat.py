@@ -88,6 +88,8 @@ class Mat(list):
     """A static-shape matrix of scalar nodes: a list of `Vec` rows (so code written against lists of rows keeps working)
     with jax.numpy's array surface for 2-D values."""
 
+    __array_ufunc__ = None
+
     def __init__(self, rows: Sequence):
         rs = [r if isinstance(r, _d.Vec) else _d.Vec(list(r)) for r in rows]
         if not rs or any(len(r) != len(rs[0]) for r in rs):
@@ -149,6 +151,7 @@ class Mat(list):
 
     # ---- arithmetic ------------------------------------------------------------------------------------------------
     def _zip(self, o, f):
+        o = _d._host(o)
         if isinstance(o, Mat):
             if o.shape != self.shape:
                 raise ValueError(f"shape mismatch {self.shape} / {o.shape}")
@@ -180,6 +183,35 @@ class Mat(list):
         return matmul(self, o)
 
 
+class Batch(list):
+    """A stack of equal-shape matrices (a [b, r, c] array): what `jnp.linalg.cholesky` of a batch returns
+    (examples/linalg/sim.py:344-350).  Element-wise arithmetic, `@` and the last-two-axes transpose map over the stack."""
+    __array_ufunc__ = None
+
+    def __init__(self, mats):
+        super().__init__([as_mat(m) for m in mats])
+
+    def _zip(self, o, f):
+        o = _d._host(o)
+        if isinstance(o, Batch):
+            if len(o) != len(self):
+                raise ValueError("batch size mismatch")
+            return Batch([f(a, b) for a, b in zip(self, o)])
+        return Batch([f(a, o) for a in self])
+
+    def __add__(self, o): return self._zip(o, lambda a, b: a + b)
+    def __radd__(self, o): return self._zip(o, lambda a, b: b + a)
+    def __sub__(self, o): return self._zip(o, lambda a, b: a - b)
+    def __rsub__(self, o): return self._zip(o, lambda a, b: b - a)
+    def __mul__(self, o): return self._zip(o, lambda a, b: a * b)
+    def __rmul__(self, o): return self._zip(o, lambda a, b: b * a)
+    def __matmul__(self, o): return self._zip(o, lambda a, b: a @ b)
+    def __rmatmul__(self, o): return self._zip(o, lambda a, b: b @ a)
+
+    @property
+    def mT(self): return Batch([m.T for m in self])
+
+
 def _dot(a: Sequence, b: Sequence):
     """sum_k a_k b_k in index order, structural zeros skipped (a product with a constant 0 adds nothing to a finite sum: the
     reference's compiled code multiplies them out, which differs only for non-finite operands)."""
@@ -194,6 +226,7 @@ def _dot(a: Sequence, b: Sequence):
 
 def matmul(a, b):
     """`a @ b` for Mat / Vec operands (numpy's rules: vectors are promoted and the added axis dropped again)."""
+    a, b = _d._host(a), _d._host(b)
     if isinstance(a, Mat) and isinstance(b, Mat):
         if a.shape[1] != b.shape[0]:
             raise ValueError(f"matmul: {a.shape} @ {b.shape}")
@@ -217,6 +250,7 @@ def matmul(a, b):
 
 
 def as_mat(x) -> Mat:
+    x = _d._host(x)
     if isinstance(x, Mat):
         return x
     if isinstance(x, (list, tuple)) and x and isinstance(x[0], (_d.Vec, list, tuple)):
@@ -288,6 +322,12 @@ def trace(m) -> "_d.Expr":
 
 def fro_norm(m) -> "_d.Expr":
     acc = None
+    if isinstance(m, Batch):       # norm of the whole [b, r, c] array
+        for mat in m:
+            for r in mat:
+                for e in r.e:
+                    acc = e * e if acc is None else acc + e * e
+        return _d._un("sqrt", acc)
     for r in as_mat(m):
         for e in r.e:
             acc = e * e if acc is None else acc + e * e
@@ -379,6 +419,9 @@ def slogdet(a):
 
 def cholesky(a, lower: bool = True, upper: bool = False) -> Mat:
     """Lower-triangular L with L L^T = a (jnp.linalg.cholesky; jax.scipy.linalg.cholesky(a, lower=False) returns L^T)."""
+    a = _d._host(a)
+    if isinstance(a, Batch):
+        return Batch([cholesky(m, lower, upper) for m in a])
     a = as_mat(a)
     n = a.shape[0]
     L = [[_d.const(0.0)] * n for _ in range(n)]

@@ -117,8 +117,10 @@ def _width(component: Any) -> Optional[int]:
 
 # ---- spatial values: numpy-backed when spawning, symbolic inside a traced function -------------------------------------
 
+from . import dsl_mat as _dsl_mat  # noqa: E402
+
 _SYMBOLIC = (_dsl.Expr, _dsl.Vec, _dsl.Quaternion, _dsl.SpatialTransform, _dsl.SpatialMotion, _dsl.SpatialForce,
-             _dsl.SpatialInertia)
+             _dsl.SpatialInertia, _dsl_mat.Mat)
 
 
 def _symbolic(v) -> bool:
@@ -406,7 +408,8 @@ def system(func):
     def call(values: dict, indexed: set):
         args = [Query(a.components, [values[n] for n in a.names], indexed) if isinstance(a, _QueryType)
                 else GraphQuery(a.edge_component) for _, a in params]
-        return func(*args)
+        with _dsl.tracing():
+            return func(*args)
 
     unreadable = "force is a stage value of the integrator: readable by effectors inside six_dof(sys=...) only"
     indexed: set = set()
@@ -556,11 +559,13 @@ class World(_api.World):
     HISTORY_AUTO_LIMIT = 32 << 20        # bytes of component data per telemetry sample up to which history defaults to on
 
     def build(self, system, simulation_rate: float = 120.0, telemetry_rate: Optional[float] = None, device: int = 0,
-              backend: str = "hip", history: Optional[bool] = None):
+              backend: str = "hip", history: Optional[bool] = None, _dry: bool = False):
         """history=None: record telemetry samples for exec.history() unless one sample of this world exceeds
         HISTORY_AUTO_LIMIT (then a warning says so); True / False force it."""
         if isinstance(system, _dsl.Effector):
             raise TypeError("a system returning el.Force is a six_dof effector: build(el.six_dof(sys=...))")
+        if _dry:
+            return super().build(system, simulation_rate=simulation_rate, telemetry_rate=telemetry_rate, device=device, backend=backend, _dry=True)
         ex = super().build(system, simulation_rate=simulation_rate, telemetry_rate=telemetry_rate, device=device, backend=backend)
         if history is None:
             sample = sum(self.column(c)[0].nbytes for c in self._components)

@@ -41,14 +41,18 @@ def gravity(graph: el.GraphQuery[GravityEdge], query: el.Query[el.WorldPos, el.I
 BODIES = (("A", 0.8920281421, 0.9957939373), ("B", -0.6628498947, -1.6191613336), ("C", -0.2291782474, 0.6233673964))
 
 
-def build(builtin: bool = False, history: bool = True):
+def world_and_system(builtin: bool = False):
     w = el.World()
     a, b, c = (w.spawn(el.Body(world_pos=el.SpatialTransform(linear=numpy.array([x, 0.0, 0.0])),
                                world_vel=el.SpatialMotion(linear=numpy.array([0.0, vy, 0.0])),
                                inertia=el.SpatialInertia(1.0 / G)), name=name) for name, x, vy in BODIES)
     for x, y in ((a, b), (b, a), (a, c), (b, c), (c, a), (c, b)):   # spawn order = fold order
         w.spawn(GravityConstraint(x, y))
-    sys_ = builtin_api.six_dof(sys=builtin_api.gravity_newton(G)) if builtin else el.six_dof(sys=gravity)
+    return w, (builtin_api.six_dof(sys=builtin_api.gravity_newton(G)) if builtin else el.six_dof(sys=gravity))
+
+
+def build(builtin: bool = False, history: bool = True):
+    w, sys_ = world_and_system(builtin)
     return w.build(sys_, simulation_rate=120.0, history=history)
 
 
