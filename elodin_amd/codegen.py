@@ -77,6 +77,25 @@ _WINDOWS: Dict[int, tuple] = {}    # window slot -> (rows, width, head slot) of 
 # (8,192 rockets: 0.070 ms per tick against 0.088 element-major).
 WINDOW_SOA_MIN_ROWS = 32768
 _WINDOW_SOA = [False]                # layout of the program being emitted
+# Register columns of a program on the device: [n][w] (the reference's rows: a lane reads its w values at a stride of w
+# elements, so every load instruction of a wave touches w times the cache lines it uses) or ELEMENT-MAJOR [w][n] (a wave's
+# load of element j is 64 consecutive values: two full 128-byte lines per f32 instruction).  The generator owns this layout
+# (include/sixdof_hip.h: the object exports it, bit 29 of its column widths); executors of COLUMN_SOA_MIN_ROWS rows or more
+# without entity-set joins / folds use the element-major one (exec.py transposes at upload / download).
+COLUMN_SOA_MIN_ROWS = 32768
+_COLUMN_SOA = [False]
+
+
+def _col_ptr(k: int, w: int, row: str, const: bool = True) -> str:
+    """`g` such that element j of this lane's row of program column k is `g[_col_idx(j)]`."""
+    ty = "const T*" if const else "T*"
+    cast = f"static_cast<{ty}>(P.model_cols[{k}])"
+    return f"{ty} g = {cast} + (size_t){row}" + ("" if _COLUMN_SOA[0] else f" * {w}") + ";"
+
+
+def _col_idx(j: int) -> str:
+    return f"(size_t){j} * P.n" if _COLUMN_SOA[0] else str(j)
+
 
 
 class _Emitter:
@@ -261,7 +280,7 @@ class _Emitter:
         # nodes the outputs need are emitted in the order the user's program created them (`Expr.seq`; arguments always
         # precede their users), which is the order a person would have written the code in: the same step then peaks at a
         # few matrices' worth of registers.  (Nodes inside loop bodies keep their own scopes and are emitted with their loop.)
-        need, stack = {}, [e for _, e in assign]
+        need, stack = {}, ([e for _, e in assign] if _EMIT_ORDER[0] == "program" else [])
         while stack:
             x = stack.pop()
             if id(x) in need or x.op in ("const", "leaf"):
@@ -310,6 +329,14 @@ def emit_apply(tp: dsl.TracedPipe) -> List[str]:
 # (Tried first: keeping every column in HBM and wrapping each system in loads / stores — the optimiser forwards the stored
 # values to the next system's loads and the live set stays where it was: 150+ spills with every flag set.)
 _MEMORY_COLUMNS = [False]
+# Order in which a block's nodes are emitted: "program" = the order the user's code created them (see _Emitter.block),
+# "demand" = depth-first from the outputs, each value right before its first use.  Program order is tried first; a
+# machine-generated DAG with no meaningful creation order (the fuzzer's random programs) can do better on demand.
+_EMIT_ORDER = ["program"]
+# Last resort: the tick body compiled as a real function (step_kernel.hpp SIXDOF_TICK_OUT_OF_LINE) — for programs whose
+# TEMPORARIES, not state, overflow the register file (a fuzz program of 200 inlined f64 libm calls: 43 values live in source
+# order, 650 registers after LLVM's allocation across its 600 basic blocks, whatever the flags).
+_TICK_OUT_OF_LINE = [False]
 
 
 def _col_slots(names) -> set:
@@ -334,6 +361,33 @@ def _cold_slots(tp, pipe_tp, pre, post, reg_cols) -> Dict[int, int]:
     return {k: w for k, w in reg_cols if k in touched and k not in hot}
 
 
+def _transient_slots(pipe_tp, pre, post, reg_cols, cold) -> Dict[int, int]:
+    """Program columns that every tick OVERWRITES before anything reads them (a wrench recomputed per tick, q-bar, the
+    geodetic altitude ...): {slot: width}.  Their value never crosses a tick boundary, so they need neither the launch-level
+    load nor a register across the loop's back edge; they are stored from inside the tick body on the LAST tick of the
+    launch.  (Kept in registers and stored after the loop, each would be a loop-carried value — initial or last written — and
+    occupy its register for the whole iteration.)  40 values on the Falcon 9 program."""
+    if os.environ.get("SIXDOF_NO_TRANSIENT_COLUMNS", "") == "1":
+        return {}
+    widths = dict(reg_cols)
+    seen, out = set(), {}
+    stages = [(s_.every, _col_slots(dsl._leaves_of([e for _, e in s_.assign])), s_.written) for s_ in pre]
+    if pipe_tp is not None:
+        stages.append((1, _col_slots(dsl._leaves_of(list(pipe_tp.outputs))), ()))
+    stages += [(s_.every, _col_slots(dsl._leaves_of([e for _, e in s_.assign])), s_.written) for s_ in post]
+    for every, reads, written in stages:
+        seen |= reads & set(widths)
+        by_slot: Dict[int, set] = {}
+        for t in written:
+            if t[0] == "c" and "_" in t and t[1:].split("_")[0].isdigit():
+                by_slot.setdefault(int(t[1:].split("_")[0]), set()).add(t)
+        for k, elems in by_slot.items():
+            if k in widths and k not in seen and k not in cold and every <= 1 and len(elems) == widths[k]:
+                out[k] = widths[k]
+            seen.add(k)
+    return out
+
+
 def _emit_systems(systems, cold: Optional[Dict[int, int]] = None) -> str:
     out = []
     em = _Emitter(_SYSTEM_LEAVES)
@@ -346,19 +400,19 @@ def _emit_systems(systems, cold: Optional[Dict[int, int]] = None) -> str:
             cond = f"tick % {s.every}ull == {s.phase}ull" + (f" || tick == {s.also_at}ull" if s.also_at is not None else "")
             w_slots = sorted(_col_slots(written) & set(cold))
             r_slots = sorted((_col_slots(dsl._leaves_of([e for _, e in s.assign])) | set(w_slots)) & set(cold))
-            ld = "".join(f"            if (c_act) {{ const T* g = static_cast<const T*>(P.model_cols[{k}]) + (size_t)c_row * {cold[k]}; "
-                         + " ".join(f"r.c{k}[{j}] = g[{j}];" for j in range(cold[k])) + " }\n" for k in r_slots)
-            st = "".join(f"\n            if (c_act) {{ T* g = static_cast<T*>(P.model_cols[{k}]) + (size_t)c_row * {cold[k]}; "
-                         + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(cold[k])) + " }" for k in w_slots)
+            ld = "".join(f"            if (c_act) {{ {_col_ptr(k, cold[k], 'c_row')} "
+                         + " ".join(f"r.c{k}[{j}] = g[{_col_idx(j)}];" for j in range(cold[k])) + " }\n" for k in r_slots)
+            st = "".join(f"\n            if (c_act) {{ {_col_ptr(k, cold[k], 'c_row', False)} "
+                         + " ".join(f"g[{_col_idx(j)}] = r.c{k}[{j}];" for j in range(cold[k])) + " }" for k in w_slots)
             out.append(f"        if ({cond}) {{  // {s.name}\n{ld}{body}{st}\n        }}")
         else:
             body = "\n".join(em.block(assign, "        ", written))
             w_slots = sorted(_col_slots(written) & set(cold))
             r_slots = sorted((_col_slots(dsl._leaves_of([e for _, e in s.assign])) | set(w_slots)) & set(cold))
-            ld = "".join(f"        if (c_act) {{ const T* g = static_cast<const T*>(P.model_cols[{k}]) + (size_t)c_row * {cold[k]}; "
-                         + " ".join(f"r.c{k}[{j}] = g[{j}];" for j in range(cold[k])) + " }\n" for k in r_slots)
-            st = "".join(f"\n        if (c_act) {{ T* g = static_cast<T*>(P.model_cols[{k}]) + (size_t)c_row * {cold[k]}; "
-                         + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(cold[k])) + " }" for k in w_slots)
+            ld = "".join(f"        if (c_act) {{ {_col_ptr(k, cold[k], 'c_row')} "
+                         + " ".join(f"r.c{k}[{j}] = g[{_col_idx(j)}];" for j in range(cold[k])) + " }\n" for k in r_slots)
+            st = "".join(f"\n        if (c_act) {{ {_col_ptr(k, cold[k], 'c_row', False)} "
+                         + " ".join(f"g[{_col_idx(j)}] = r.c{k}[{j}];" for j in range(cold[k])) + " }" for k in w_slots)
             out.append(f"        // {s.name}\n{ld}{body}{st}")
     return "\n".join(out)
 
@@ -545,30 +599,37 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
         written = sorted(_slots_of(pre + post) & {int(t[1:].split("_")[0]) for s_ in pre + post for t in s_.written if t[0] == "c"}) \
             if used is not None else list(tp.written_slots)
         cold = _cold_slots(tp, pipe_tp, pre, post, reg_cols)
+        transient = _transient_slots(pipe_tp, pre, post, reg_cols, cold) if used is None else {}
         vol = "volatile " if _MEMORY_COLUMNS[0] else ""
         regs = "\n".join(f"        {vol}T c{k}[{w}];" + ("   // cold: lives in its HBM column between cadence blocks" if k in cold else "") for k, w in reg_cols)
         loads = "\n".join(
-            f"            {{ const T* g = static_cast<const T*>(P.model_cols[{k}]) + (size_t)row * {w}; "
-            + " ".join(f"r.c{k}[{j}] = g[{j}];" for j in range(w)) + " }" for k, w in reg_cols if k not in cold)
+            f"            {{ {_col_ptr(k, w, 'row')} "
+            + " ".join(f"r.c{k}[{j}] = g[{_col_idx(j)}];" for j in range(w)) + " }" for k, w in reg_cols if k not in cold and k not in transient)
         # element by element, not a loop: a loop the optimiser does not unroll (-O1, the low-register-pressure fallback build)
         # indexes the array dynamically, which pins the whole register file image in scratch memory
         zero = " ".join(" ".join(f"r.c{k}[{j}] = T(0);" for j in range(w)) for k, w in reg_cols)
         stores = "\n".join(
-            f"        {{ T* g = static_cast<T*>(P.model_cols[{k}]) + (size_t)row * {cols[k][1]}; "
-            + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(cols[k][1])) + " }" for k in written if k not in cold)
+            f"        {{ {_col_ptr(k, cols[k][1], 'row', False)} "
+            + " ".join(f"g[{_col_idx(j)}] = r.c{k}[{j}];" for j in range(cols[k][1])) + " }" for k in written if k not in cold and k not in transient)
+        transient_stores = ""
+        if transient:
+            transient_stores = ("\n        if (tick == P.tick0 + P.n_ticks && c_act) {   // last tick of the launch: the per-tick (transient) columns\n"
+                                + "".join(f"            {{ {_col_ptr(k, w, 'c_row', False)} " + " ".join(f"g[{_col_idx(j)}] = r.c{k}[{j}];" for j in range(w)) + " }\n"
+                                          for k, w in sorted(transient.items()))
+                                + "        }")
         records = "\n".join(
             (f"        if (P.model_hist[{k}]) {{ T* g = static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row) * {w}; "
-             f"const T* g0 = static_cast<const T*>(P.model_cols[{k}]) + (size_t)row * {w}; "
-             + " ".join(f"g[{j}] = g0[{j}];" for j in range(w)) + " }") if k in cold else
+             f"const T* g0 = static_cast<const T*>(P.model_cols[{k}]) + (size_t)row" + ("" if _COLUMN_SOA[0] else f" * {w}") + "; "
+             + " ".join(f"g[{j}] = g0[{_col_idx(j)}];" for j in range(w)) + " }") if k in cold else
             (f"        if (P.model_hist[{k}]) {{ T* g = static_cast<T*>(P.model_hist[{k}]) + (slot * P.n + row) * {w}; "
              + " ".join(f"g[{j}] = r.c{k}[{j}];" for j in range(w)) + " }") for k, w in reg_cols)
-        cold_setup = ("        const uint32_t c_row = blockIdx.x * kWave + threadIdx.x;\n        const bool c_act = c_row < P.n;\n" if cold else "")
+        cold_setup = ("        const uint32_t c_row = blockIdx.x * kWave + threadIdx.x;\n        const bool c_act = c_row < P.n;\n" if (cold or transient) else "")
         if pipe_tp is not None:
             a_slots = sorted(_col_slots(dsl._leaves_of(list(pipe_tp.outputs))) & set(cold))
             if a_slots:      # memory-resident columns the effector stage reads (`r` is the kernel's own register image)
                 apply_loads = (cold_setup + "        auto& rw = const_cast<R&>(r);\n" + "".join(
-                    f"        if (c_act) {{ const T* g = static_cast<const T*>(P.model_cols[{k}]) + (size_t)c_row * {cold[k]}; "
-                    + " ".join(f"rw.c{k}[{j}] = g[{j}];" for j in range(cold[k])) + " }\n" for k in a_slots))
+                    f"        if (c_act) {{ {_col_ptr(k, cold[k], 'c_row')} "
+                    + " ".join(f"rw.c{k}[{j}] = g[{_col_idx(j)}];" for j in range(cold[k])) + " }\n" for k in a_slots))
         if _WINDOWS:
             # one lane = one entity, a workgroup is one wave (step_kernel.hpp).  Element e of this lane's window sits at
             # W[e * w_n]: w_n = n for the element-major layout of large executors, 1 (a compile-time constant, so the addresses
@@ -613,7 +674,7 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
     __device__ static __forceinline__ void post(const StepParams& P, uint64_t tick, Regs<T>& r, Quat<T>& q, Vec3<T>& p,
                                                 Spatial<T>& v, Vec3<T>& I, T& mass, const Spatial<T>& accel) {{
         (void)P; (void)tick; (void)accel;
-{win_setup}{cold_setup}{_emit_systems(post, cold)}
+{win_setup}{cold_setup}{_emit_systems(post, cold)}{transient_stores}
     }}'''
     wt = pipe_tp.world_torque if pipe_tp is not None else False
     bt = pipe_tp.body_torque if pipe_tp is not None else False
@@ -695,11 +756,15 @@ __global__ __launch_bounds__(64) void fold{j}_commit(const StepParams P) {{
 '''
 
 
-def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, window_soa: bool = False) -> str:
+def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, window_soa: bool = False,
+                    column_soa: bool = False) -> str:
     """tp: dsl.TracedPipe (effectors only) or dsl.TracedProgram (pre | six_dof(effectors) | post).
     fast_math: f32 only — hardware transcendentals / reciprocal division in the generated user code (see _PRELUDE).
     window_soa: window columns are element-major on the device (executors of WINDOW_SOA_MIN_ROWS entities or more)."""
     _WINDOW_SOA[0] = bool(window_soa)
+    _COLUMN_SOA[0] = bool(column_soa)
+    if column_soa and isinstance(tp, dsl.TracedProgram) and tp.fold_stages:
+        raise ValueError("element-major program columns are not available for programs with stand-alone folds")
     if fast_math and dtype != "float32":
         raise ValueError("fast_math applies to float32 programs only")
     _TABLES.clear()
@@ -717,7 +782,8 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
         names_ = [c for c, _ in tp.columns]
         for wname, (wslot, wrows, wwidth) in tp.windows.items():
             _WINDOWS[wslot] = (wrows, wwidth, names_.index(wname + "#head"))
-        col_widths = "{" + ", ".join(f"{w}u" + ((" | 0x80000000u" + (" | 0x40000000u" if window_soa else "")) if k in _WINDOWS else "")
+        col_widths = "{" + ", ".join(f"{w}u" + ((" | 0x80000000u" + (" | 0x40000000u" if window_soa else "")) if k in _WINDOWS else
+                                                 (" | 0x20000000u" if column_soa else ""))
                                       for k, (_, w) in enumerate(tp.columns)) + "}"
     names = ", ".join(e.__name__ for e in pipe_tp.effectors)
     fast = "#define SIXDOF_FAST_MATH 1\n" if fast_math else ""
@@ -787,7 +853,7 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
                   + "\n".join(calls) + "\n    }\n")
     tables = _emit_tables()
     return f'''// generated by elodin_amd/codegen.py — do not edit.  Effectors: {names}
-{stage_comment}{fast}#include "step_kernel.hpp"
+{stage_comment}{fast}{"#define SIXDOF_TICK_OUT_OF_LINE" + chr(10) if _TICK_OUT_OF_LINE[0] else ""}#include "step_kernel.hpp"
 
 namespace sixdof {{
 
@@ -977,19 +1043,35 @@ def _headers_digest() -> str:
     return h.hexdigest()
 
 
-def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_math: bool = False, window_soa: bool = False) -> Path:
+def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_math: bool = False, window_soa: bool = False,
+          column_soa: bool = False) -> Path:
     """Generate + compile (cached by content hash).  Returns the .so path.  A program that no flag set builds without VGPR
     spills is generated again with its columns memory-resident (_MEMORY_COLUMNS) before giving up."""
     try:
-        return _compile(generate_source(tp, dtype, integrator, fast_math, window_soa), "pipe")
+        return _compile(generate_source(tp, dtype, integrator, fast_math, window_soa, column_soa), "pipe")
     except SpillError:
-        if not isinstance(tp, dsl.TracedProgram) or os.environ.get(ALLOW_SPILLS_ENV, "") == "1":
+        if os.environ.get(ALLOW_SPILLS_ENV, "") == "1":
             raise
+    _EMIT_ORDER[0] = "demand"
+    try:
+        return _compile(generate_source(tp, dtype, integrator, fast_math, window_soa, column_soa), "pipe")
+    except SpillError:
+        if not isinstance(tp, dsl.TracedProgram):
+            raise
+    finally:
+        _EMIT_ORDER[0] = "program"
     _MEMORY_COLUMNS[0] = True
     try:
-        return _compile(generate_source(tp, dtype, integrator, fast_math, window_soa), "pipe")
+        return _compile(generate_source(tp, dtype, integrator, fast_math, window_soa, column_soa), "pipe")
+    except SpillError:
+        pass
     finally:
         _MEMORY_COLUMNS[0] = False
+    _TICK_OUT_OF_LINE[0] = True
+    try:
+        return _compile(generate_source(tp, dtype, integrator, fast_math, window_soa, column_soa), "pipe")
+    finally:
+        _TICK_OUT_OF_LINE[0] = False
 
 
 # Generated programs are one long straight-line tick body inside the kernel's tick loop.  Left alone, LLVM's MachineLICM

@@ -792,7 +792,7 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
         if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "step: component column of the generated program is not bound");
         const unsigned expect = k < h->custom_model_width.size() ? h->custom_model_width[k] : 0u;
         const bool window = (expect >> 31) != 0;
-        const size_t want = expect & 0x3fffffffu;     // bit 30: the object was built for the element-major window layout
+        const size_t want = expect & 0x1fffffffu;     // bit 30: built for the element-major window layout; bit 29: element-major register columns
         if (c->prim != h->state_prim() || c->width < 1 || (!window && c->width > 64) || (want && c->width != want))
             return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH,
                            "step: program columns must be of the state dtype and as wide as the generated code expects "
@@ -801,6 +801,9 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
             int rc = resolve_join(h, c);
             if (rc != SIXDOF_OK) return rc;
             if (c->compact) {
+                if ((expect >> 29) & 1u)      // the gather / scatter kernels move [n,w] rows
+                    return h->fail(SIXDOF_ERR_UNSUPPORTED, "step: a program built for element-major columns needs every column on "
+                                                           "the executor's own entity set (no entity-set join)");
                 hipError_t e = launch_gather_rows(c->compact, c->dev, c->d_rows, static_cast<uint32_t>(h->joined_ids.size()),
                                                   static_cast<uint32_t>(c->width), c->elem, h->stream);
                 if (e != hipSuccess) return h->hip_fail(e, "gather_rows");

@@ -247,7 +247,14 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     // because contraction is per source expression (kernels.hpp: #pragma clang fp contract(on)).
     // `check` (first tick of the first launch after an upload only, StepParams::accel_in_check) reads the incoming
     // world_accel row for stage 0; also compile-time, so no other tick carries the branch or the load.
+#ifdef SIXDOF_TICK_OUT_OF_LINE
+    // last-resort build of a generated program (codegen.py): the tick body as a real function.  Its captures (the whole
+    // register image) are then reached through the closure in the lane's private memory and the body gets a register budget
+    // of its own — what LLVM did by itself in round 2 whenever a body was instantiated more than once and too big to inline.
+    auto one_tick = [&](auto early_tag, auto check_tag, uint32_t tick) __attribute__((noinline)) {
+#else
     auto one_tick = [&](auto early_tag, auto check_tag, uint32_t tick) {
+#endif
         constexpr bool early = decltype(early_tag)::value;
         // hand-written pipes: compile-time.  Generated programs: decided at run time (a wave-uniform branch around one
         // load), so that their kernel has exactly ONE call site of the tick body — a second copy of a 40,000-instruction

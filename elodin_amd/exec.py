@@ -10,6 +10,8 @@ import ctypes as C
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
+import os
+
 import numpy as np
 
 from . import _lib as L
@@ -75,6 +77,8 @@ class HipExec:
         self._aux = {}
         self._windows = {}
         self._window_soa = False
+        self._column_soa = False
+        self._soa = {}            # program column name -> the element-major staging array bound to the C ABI
         d = L.Desc()
         d.struct_size = C.sizeof(L.Desc)
         d.device_ordinal = device
@@ -132,7 +136,14 @@ class HipExec:
                     for name in self._windows:       # the ring's head (physical index of the oldest row): starts at 0
                         columns.setdefault(name + "#head", np.zeros((np.shape(columns[name])[0], 1)) if name in columns else None)
                 self._window_soa = bool(self._windows) and self.world_pos.shape[0] >= codegen.WINDOW_SOA_MIN_ROWS
-                so = codegen.build(custom, self.dtype.name, integrator, fast_math=fast_math, window_soa=self._window_soa)
+                # register columns of a large program executor: element-major on the device (codegen.COLUMN_SOA_MIN_ROWS); the
+                # host-facing arrays (self._aux) stay in the reference's [n, w] rows, upload / download transpose
+                soa_env = os.environ.get("SIXDOF_COLUMN_SOA")
+                self._column_soa = (isinstance(effectors, _dsl.Program) and not getattr(custom, "fold_stages", None)
+                                    and not self._column_ids and (soa_env == "1" or (soa_env != "0" and
+                                                                  self.world_pos.shape[0] >= codegen.COLUMN_SOA_MIN_ROWS)))
+                so = codegen.build(custom, self.dtype.name, integrator, fast_math=fast_math, window_soa=self._window_soa,
+                                   column_soa=self._column_soa)
                 for name, width in custom.columns:
                     if columns is None or columns.get(name) is None:
                         raise KeyError(f"effector reads component {name!r} which was not provided")
@@ -140,7 +151,11 @@ class HipExec:
                     if name in self._windows and self._window_soa:
                         arr = np.ascontiguousarray(arr.T).reshape(arr.shape)   # large executors: element-major [rows*width][n] (codegen.py)
                     self._aux[name] = arr
-                    cols.append((name, arr))
+                    if self._column_soa and name not in self._windows and width > 1:
+                        self._soa[name] = np.ascontiguousarray(arr.T).reshape(arr.shape)    # what the device holds
+                        cols.append((name, self._soa[name]))
+                    else:
+                        cols.append((name, arr))
                 effectors = ()
             pair_so = None
             effectors = list(effectors)
@@ -214,6 +229,9 @@ class HipExec:
 
     # -- reference-shaped surface -------------------------------------------------------------------
     def upload(self):
+        for name, dev in self._soa.items():      # [n, w] rows -> [w][n]
+            a = self._aux[name]
+            dev.reshape(a.shape[1], a.shape[0])[...] = a.T
         rc = self._lib.sixdof_upload(self._h)
         if rc != L.OK:
             _raise(self._h, rc, "sixdof_upload")
@@ -241,6 +259,9 @@ class HipExec:
             rc = self._lib.sixdof_download_column(self._h, L.component_id(name))
             if rc != L.OK:
                 _raise(self._h, rc, "sixdof_download_column")
+        for name, dev in self._soa.items():      # [w][n] -> [n, w] rows
+            a = self._aux[name]
+            a[...] = dev.reshape(a.shape[1], a.shape[0]).T
         return self
 
     def component(self, name: str) -> np.ndarray:

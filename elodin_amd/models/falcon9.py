@@ -1089,9 +1089,11 @@ def prebuild() -> list:
     out = []
     cols = initial_columns(default_param_row()[None, :])
     widths = {k: v.shape[1] for k, v in cols.items()}
-    for dtype, origin, fast in (("float32", pad_ecef(), True), ("float32", pad_ecef(), False), ("float64", None, False),
-                                ("float64", pad_ecef(), False)):
-        out.append(codegen.build(build_program(origin=origin).trace(widths), dtype, 1, fast_math=fast))
+    for dtype, origin, fast, soa in (("float32", pad_ecef(), True, False), ("float32", pad_ecef(), False, False), ("float64", None, False, False),
+                                     ("float64", pad_ecef(), False, False),
+                                     # campaign-size executors (>= codegen.COLUMN_SOA_MIN_ROWS rollouts): element-major columns
+                                     ("float32", pad_ecef(), True, True), ("float64", pad_ecef(), False, True)):
+        out.append(codegen.build(build_program(origin=origin).trace(widths), dtype, 1, fast_math=fast, column_soa=soa))
     return out
 
 

@@ -26,7 +26,7 @@ def main(n=4096, dtype="f32"):
     res = ex.result
     print(f"{n} rollouts x {f9.ASCENT_TICKS} ticks ({dtype}): build {t1 - t0:.2f} s, flight {t2 - t1:.2f} s "
           f"= {n * f9.ASCENT_TICKS / (t2 - t1):.3e} rollout-steps/s")
-    nominal = f9.AscentExec(f9.default_param_row()[None, :], dtype=np.float64, local_origin=False)
+    nominal = f9.AscentExec(f9.default_param_row()[None, :], dtype=np.float32 if dtype == "f32" else np.float64)
     nominal.run(f9.ASCENT_TICKS)
     print("calibrated defaults:", {k: round(float(v), 2) for k, v in zip(f9.METRIC_NAMES, nominal.result[0])},
           "(recorded CRS-12: Max-Q T+64 s, MECO T+147 s)")

@@ -189,16 +189,31 @@ def test_open_loop_vertical_burn_vs_1d_oracle():
 
 @pytest.fixture(scope="module")
 def nominal():
-    ex = f9.AscentExec(f9.default_param_row()[None, :], dtype=np.float64, local_origin=False)
+    # f32 (pad-relative coordinates): the assertions below are physical ranges, and the f64 flight of this very row is
+    # pinned tick for tick on the reference-flown ascent (tests/test_gpu_falcon9_closed_loop.py)
+    ex = f9.AscentExec(f9.default_param_row()[None, :], dtype=np.float32)
     ex.run(f9.ASCENT_TICKS)
     return ex
+
+
+@pytest.fixture(scope="module")
+def f64_plan_flight():
+    """ONE f64 flight (pad-relative coordinates) of 32,768 rows of spec.toml's plan — an f64 flight costs the same wall time
+    for 1 or 65,536 rollouts (one wave per SIMD), and the f64 program is the slow scratch-image build — shared by the
+    f32-vs-f64 tests below."""
+    params = f9.sample_params(32768)
+    ex = f9.AscentExec(params, dtype=np.float64, local_origin=True)
+    ex.run(f9.ASCENT_TICKS)
+    res = ex.result.copy()
+    ex.close()
+    return params, res
 
 
 def test_nominal_ascent_follows_the_recorded_crs12_timeline(nominal):
     """data/crs12/events.json: Max-Q at T+64 s, MECO at T+147 s; test_aero.py:102-118 puts the recorded ascent Max-Q at
     18-26 kPa; WHITEPAPER / test_propulsion.py:245: ~3.6 g near MECO; test_ladder.py:150: MECO-class state ~61 km, 1656 m/s.
-    The calibrated defaults (main.py:53-100) were fitted with the FSW following the recorded profile; the parametric
-    program flown here lands within seconds of it."""
+    The calibrated defaults (main.py:53-100) were fitted with the flight software following the recorded profile — which is
+    what flies here."""
     m = dict(zip(f9.METRIC_NAMES, nominal.result[0]))
     print("nominal ascent:", {k: round(v, 2) for k, v in m.items()})
     assert abs(m["t_max_qbar_s"] - 64.0) < 8.0 and 18_000.0 < m["max_qbar_pa"] < 26_000.0
@@ -209,27 +224,30 @@ def test_nominal_ascent_follows_the_recorded_crs12_timeline(nominal):
     assert nominal.column("fsw_state")[0, 0] == f9.PHASE_FLIP and nominal.column("thrust_total")[0, 0] == 0.0   # MECO + 3 s: the ascent software hands over
 
 
-def test_pad_relative_coordinates_fly_the_same_ascent(nominal):
-    """Storing world_pos relative to the pad (what the f32 campaign needs) is the same flight in f64."""
-    ex = f9.AscentExec(f9.default_param_row()[None, :], dtype=np.float64, local_origin=True)
-    ex.run(f9.ASCENT_TICKS)
-    assert np.allclose(ex.result, nominal.result, rtol=1e-6)
-    assert np.linalg.norm(ex.ecef - nominal.ecef) < 1e-3 * 1.0 + 1e-8 * np.linalg.norm(nominal.ecef)
-    assert parity.field_rel_err(ex.column("world_vel"), nominal.column("world_vel")) < 1e-6
+def test_pad_relative_coordinates_fly_the_same_ascent():
+    """Storing world_pos relative to the pad (what the f32 campaign needs) is the same flight in f64: 40 s from the pad,
+    through liftoff, the pitch kick and into the gravity turn."""
+    a = f9.AscentExec(f9.default_param_row()[None, :], dtype=np.float64, local_origin=False)
+    b = f9.AscentExec(f9.default_param_row()[None, :], dtype=np.float64, local_origin=True)
+    a.run(40_000)
+    b.run(40_000)
+    assert a.column("fsw_state")[0, 0] == b.column("fsw_state")[0, 0] == f9.PHASE_GRAVITY_TURN
+    assert np.linalg.norm(a.ecef - b.ecef) < 1e-3 * 1.0 + 1e-8 * np.linalg.norm(a.ecef)
+    assert parity.field_rel_err(b.column("world_vel"), a.column("world_vel")) < 1e-6
+    assert np.allclose(a.result[:, :3], b.result[:, :3], rtol=1e-6)
 
 
 @pytest.mark.parametrize("fast_math", [False, True])
-def test_f32_campaign_matches_f64_on_the_spec_plan(fast_math):
+def test_f32_campaign_matches_f64_on_the_spec_plan(fast_math, f64_plan_flight):
     """BASELINE config 5 runs f32 (the reference's six_dof is f64-only: parity unpinned).  Tolerance, stated:
     MECO / Max-Q observables of every rollout within 1 % of the f64 flight of the same plan row; MECO time within
     1.5 s; the TIME of Max-Q only within 15 s (q-bar is flat to 1 % for ~30 s inside the throttle bucket, so its argmax is
     ill-conditioned in any precision: over 1,024 plan rows the worst case seen is 10 s while Max-Q itself agrees to 0.2 %)."""
-    params = f9.sample_params(256)
-    f64 = f9.AscentExec(params, dtype=np.float64, local_origin=True)
+    params, a = f64_plan_flight
+    params, a = params[:256], a[:256]
     f32 = f9.AscentExec(params, dtype=np.float32, fast_math=fast_math)    # True = what campaigns run (hardware sin / cos / exp / rcp)
-    f64.run(f9.ASCENT_TICKS)
     f32.run(f9.ASCENT_TICKS)
-    a, b = f64.result, f32.result
+    b = f32.result
     names = f9.METRIC_NAMES
     assert np.all(a[:, names.index("meco_t_s")] > 100.0), "every sampled rollout reaches MECO"
     for k, name in enumerate(names):
@@ -243,20 +261,16 @@ def test_f32_campaign_matches_f64_on_the_spec_plan(fast_math):
     assert spread.max() - spread.min() > 5_000.0          # the plan actually disperses the flight
 
 
-def test_config5_full_size_32768_rollouts_f32_vs_f64_over_the_whole_ascent():
+def test_config5_full_size_32768_rollouts_f32_vs_f64_over_the_whole_ascent(f64_plan_flight):
     """BASELINE configs[4] at its stated size: 32,768 rollouts of spec.toml's plan (LHS, seed 20170814), f32 with hardware
     transcendentals (what the campaign runs) against the f64 flight of the same rows, T+180 s each.  Bound, stated (the
     reference has no f32 six_dof): every rollout reaches MECO in both; MECO / Max-Q observables within 1 %, MECO time
     within 1.5 s, the time of Max-Q within 15 s (flat q-bar inside the throttle bucket: an ill-conditioned argmax)."""
-    params = f9.sample_params(32768)
+    params, a = f64_plan_flight
     f32 = f9.AscentExec(params, dtype=np.float32, fast_math=True)
     f32.run(f9.ASCENT_TICKS)
     b = f32.result.copy()
     f32.close()
-    f64 = f9.AscentExec(params, dtype=np.float64, local_origin=True)
-    f64.run(f9.ASCENT_TICKS)
-    a = f64.result.copy()
-    f64.close()
     names = f9.METRIC_NAMES
     assert np.all(a[:, names.index("meco_t_s")] > 100.0) and np.all(b[:, names.index("meco_t_s")] > 100.0)
     worst = {}
@@ -270,7 +284,7 @@ def test_config5_full_size_32768_rollouts_f32_vs_f64_over_the_whole_ascent():
     print("config 5 at 32,768 rollouts, f32 vs f64 worst per metric:", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
-@pytest.mark.parametrize("start_tick", [0, 30_000, 100_000])
+@pytest.mark.parametrize("start_tick", [0, 20_000])
 def test_generated_kernel_vs_numpy_stepper_on_the_same_program(start_tick):
     """The traced program evaluated tick by tick with numpy (tests/dsl_numpy.program_tick: systems -> semi-implicit
     six_dof -> systems) against the fused kernel, 200 ticks from three points of the flight, 1e-9."""
@@ -348,8 +362,8 @@ def test_component_columns_of_a_program_are_recorded_in_the_history_ring():
     """sixdof_set_history with a generated program: besides the four Body outputs every component column of the program
     is recorded each tick from inside the fused launch; reading the ring back equals stepping one tick at a time."""
     params = f9.sample_params(6)
-    a = f9.AscentExec(params, dtype=np.float64, local_origin=False, ticks_per_launch=50)
-    b = f9.AscentExec(params, dtype=np.float64, local_origin=False, ticks_per_launch=1)
+    a = f9.AscentExec(params, dtype=np.float32, ticks_per_launch=50)      # bit equality between launch shapes: any dtype shows it
+    b = f9.AscentExec(params, dtype=np.float32, ticks_per_launch=1)
     a.run(3_000)
     b.run(3_000)
     a.hip.enable_history(128)

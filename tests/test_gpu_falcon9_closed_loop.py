@@ -30,10 +30,11 @@ def _getter(ex, i):
 
 @pytest.mark.parametrize("ticks_per_launch", [1000, 1])
 def test_generated_kernel_flies_the_reference_ascents_f64(ticks_per_launch):
-    """All fixture rows as ONE executor (one lane each).  K = 1 (every tick its own launch) flies the first 12 s only."""
+    """All fixture rows as ONE executor (one lane each).  K = 1 (every tick its own launch) flies the first 3 s only
+    (navigator initialisation, ignition, liftoff, the radar altimeter: the f64 program is the slow scratch-image build)."""
     flights = [cu.FLIGHTS[r] for r in ROWS]
     ex = _exec(flights, np.float64, ticks_per_launch)
-    horizon = 12_000 if ticks_per_launch == 1 else max(fl["ticks"] for fl in flights)
+    horizon = 3_000 if ticks_per_launch == 1 else max(fl["ticks"] for fl in flights)
     # every tick any row has something to check on: checkpoints, and the tick before each phase transition
     stops = sorted({c["tick"] for fl in flights for c in fl["checkpoints"] if c["tick"] <= horizon}
                    | {t - 1 for fl in flights for t in fl["transitions"].values() if t - 1 <= horizon})
@@ -60,7 +61,7 @@ def test_generated_kernel_flies_the_reference_ascents_f64(ticks_per_launch):
     top = sorted(worst.items(), key=lambda kv: -kv[1][0])[:12]
     print(f"f64 K={ticks_per_launch}: {len(flights)} flights, {n_cp} checkpoints, {n_tr} transitions on their tick; worst of {len(worst)} quantities:",
           ", ".join(f"{k} {e:.1e} (row {r} tick {t}; abs, scale, part {d})" for k, (e, r, t, d) in top))
-    assert n_cp >= (60 if ticks_per_launch > 1 else 30) and n_tr >= (4 * len(flights) if ticks_per_launch > 1 else len(flights))
+    assert n_cp >= (60 if ticks_per_launch > 1 else 35) and n_tr >= (4 * len(flights) if ticks_per_launch > 1 else len(flights))
     assert max(v[0] for v in worst.values()) < 1e-9, top
 
 
