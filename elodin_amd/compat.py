@@ -148,8 +148,11 @@ def _make_jax():
     jscipy = types.ModuleType("jax.scipy")
     jscipy.linalg = jsl
     jax.numpy, jax.lax, jax.random, jax.scipy = jnp, lax, rnd, jscipy
+    jax.__path__ = []                                   # a package: `from jax.typing import ArrayLike`
     jax.Array = _np.ndarray
-    jax.typing = types.SimpleNamespace(ArrayLike=_np.ndarray)
+    jtyping = types.ModuleType("jax.typing")
+    jtyping.ArrayLike = _np.ndarray
+    jax.typing = jtyping
     jax.config = types.SimpleNamespace(update=lambda *a, **k: None)
 
     def _unsupported(what):
@@ -160,7 +163,7 @@ def _make_jax():
     jax.jit = lambda f=None, **k: (f if f is not None else (lambda g: g))      # a no-op: everything traced is compiled anyway
     jax.grad, jax.vmap, jax.pmap = _unsupported("grad"), _unsupported("vmap"), _unsupported("pmap")
     return {"jax": jax, "jax.numpy": jnp, "jax.numpy.linalg": la, "jax.lax": lax, "jax.random": rnd, "jax.scipy": jscipy,
-            "jax.scipy.linalg": jsl}
+            "jax.scipy.linalg": jsl, "jax.typing": jtyping}
 
 
 class _Inert:
@@ -227,6 +230,13 @@ def install(run: str = "execute") -> None:
     for name in ("jax", "elodin"):
         if name in sys.modules and getattr(sys.modules[name], "__file__", None):
             raise RuntimeError(f"a real `{name}` is already imported; elodin_amd.compat will not shadow it")
+    import typing
+    if not hasattr(typing, "Self"):          # the reference targets Python >= 3.11 (examples/drone/config.py:65 `ty.Self`)
+        try:
+            import typing_extensions
+            typing.Self = typing_extensions.Self
+        except ImportError:
+            pass
     mods = _make_jax()
     mods["elodin"] = _make_elodin()
     sys.modules.update(mods)

@@ -395,9 +395,49 @@ def _annotations(func):
     return params, hints.get("return", sig.return_annotation)
 
 
+class _Deferred:
+    """A decorated function whose decoration-time call on symbols failed (its body reads something that does not exist yet:
+    examples/drone reads `Config.GLOBAL`, set by main.py after the modules with the @el.map functions were imported).  The
+    reference traces at build time, so such scripts work there; here the function is lowered on first USE instead — when it
+    is piped, handed to six_dof or built."""
+
+    def __init__(self, func, error):
+        self.func, self.error, self._made = func, error, None
+        self.__name__ = getattr(func, "__name__", "system")
+
+    def resolve(self):
+        if self._made is None:
+            self._made = _system_now(self.func)
+        return self._made
+
+    def __or__(self, other): return self.resolve() | _resolved(other)
+    def __ror__(self, other): return _resolved(other) | self.resolve()
+    def pipe(self, other): return self | other
+
+
+def _resolved(x):
+    """x with every deferred system inside it lowered."""
+    if isinstance(x, _Deferred):
+        return x.resolve()
+    if isinstance(x, _dsl.Stages):
+        return _dsl.Stages([_resolved(i) for i in x.items])
+    if isinstance(x, (list, tuple)):
+        return type(x)(_resolved(i) for i in x)
+    return x
+
+
 def system(func):
     """@el.system (__init__.py:160-185): parameters annotated el.Query[...] / el.GraphQuery[...]; returns the query that
-    holds the written components."""
+    holds the written components.  Lowered now (one call on symbols); if that call fails, on first use (_Deferred)."""
+    try:
+        return _system_now(func)
+    except TypeError:
+        raise                      # a misuse the decorator reports (bad annotations, reading `force` outside six_dof ...)
+    except Exception as e:  # noqa: BLE001
+        return _Deferred(func, e)
+
+
+def _system_now(func):
     params, _ret = _annotations(func)
     for pname, ann in params:
         if not isinstance(ann, (_QueryType, _GraphQueryType)):
@@ -527,6 +567,7 @@ for _cls in (_dsl.System, _dsl.Stages, _dsl.Effector, _dsl.Pipe, _dsl.GraphFold,
 def six_dof(time_step: Optional[float] = None, sys=None, integrator: Integrator = Integrator.Rk4):
     """elodin.six_dof (lib.rs:106-127): `sys` is what @el.map / @el.system made of functions returning el.Force —
     effectors piped with `|`, optionally closed by one edge_fold system."""
+    sys = _resolved(sys)
     if isinstance(sys, _dsl.Stages):                 # `gravity | drag` of two effector-kind systems
         sys = sys.items
     if isinstance(sys, (list, tuple)):
@@ -562,6 +603,7 @@ class World(_api.World):
               backend: str = "hip", history: Optional[bool] = None, _dry: bool = False):
         """history=None: record telemetry samples for exec.history() unless one sample of this world exceeds
         HISTORY_AUTO_LIMIT (then a warning says so); True / False force it."""
+        system = _resolved(system)
         if isinstance(system, _dsl.Effector):
             raise TypeError("a system returning el.Force is a six_dof effector: build(el.six_dof(sys=...))")
         if _dry:
