@@ -52,6 +52,36 @@ class Quaternion:
     def vector(self) -> np.ndarray:
         return self.arr
 
+    # host-side algebra (spawn-time data: a tilted motor axis, an initial attitude) — the traced twin is dsl.Quaternion
+    __array_ufunc__ = None                                     # `q @ ndarray` / `ndarray * q` must not broadcast over the object
+
+    def inverse(self) -> "Quaternion":                         # quaternion.rs:152-155: conj / |q|^2
+        x, y, z, w = self.arr
+        return Quaternion(np.array([-x, -y, -z, w]) / float(np.dot(self.arr, self.arr)))
+
+    def normalize(self) -> "Quaternion":                       # quaternion.rs:147-149
+        return Quaternion(self.arr / np.sqrt(np.dot(self.arr, self.arr)))
+
+    def __mul__(self, o):                                      # Hamilton product, quaternion.rs:268-281
+        if not isinstance(o, Quaternion):
+            return NotImplemented
+        l, r = self.arr, o.arr
+        return Quaternion([l[3] * r[0] + l[0] * r[3] + l[1] * r[2] - l[2] * r[1],
+                           l[3] * r[1] - l[0] * r[2] + l[1] * r[3] + l[2] * r[0],
+                           l[3] * r[2] + l[0] * r[1] - l[1] * r[0] + l[2] * r[3],
+                           l[3] * r[3] - l[0] * r[0] - l[1] * r[1] - l[2] * r[2]])
+
+    def __matmul__(self, v):                                   # q (x) (v, 0) (x) q^-1, quaternion.rs:283-305
+        if hasattr(v, "arr") and not isinstance(v, Quaternion):            # a spatial value: both halves
+            a = v.arr
+            return type(v)(arr=np.concatenate([self @ a[:3], self @ a[3:]]))
+        if not isinstance(v, np.ndarray) and not isinstance(v, (list, tuple)):
+            return NotImplemented
+        v = np.asarray(v, dtype=np.float64).reshape(3)
+        u = self.arr[:3]
+        t = np.cross(u, v) * (2.0 / float(np.dot(self.arr, self.arr)))
+        return v + t * self.arr[3] + np.cross(u, t)
+
 
 class SpatialTransform:
     def __init__(self, arr=None, angular: Optional[Quaternion] = None, linear=None):
@@ -368,12 +398,22 @@ class World:
             names = dict.fromkeys(system.left + system.right + (system.out,))
             return GraphFoldExec(system, {n: self.column(n) for n in names}, edges, device=device)
         program_stages = None
+        substeps = 1
         if isinstance(system, _dsl.System):
             system = _dsl.Stages([system])
         if isinstance(system, _dsl.Stages):      # pre | six_dof(effectors) | post  -> one generated program
             six = [k for k, it in enumerate(system.items) if isinstance(it, System)]
             if len(six) > 1:
-                raise ValueError("a system pipe can contain at most one six_dof(...)")
+                # `pre | (six_dof | post) x k` with the SAME six_dof and post objects repeated (examples/drone/sim.py:173-208
+                # `inner_loop`): k integrator sub-steps per tick = k executor ticks per world tick (dsl.Program.substeps)
+                seg = system.items[six[0]:six[1]]
+                k = len(six)
+                tail = system.items[six[0]:]
+                if len(tail) != k * len(seg) or any(a is not b for j in range(k) for a, b in zip(seg, tail[j * len(seg):(j + 1) * len(seg)])):
+                    raise ValueError("a system pipe with several six_dof(...) stages must repeat one `six_dof | post` segment")
+                substeps = k
+                system = _dsl.Stages(system.items[:six[0]] + seg)
+                six = six[:1]
             if not six:     # `w.build(sys)` with per-entity systems only (test_all.py:86-114): no integration stage
                 program_stages = (system.items, [])
                 system = System(None, Effectors(), Integrator.Rk4)
@@ -381,6 +421,21 @@ class World:
             else:
                 program_stages = (system.items[:six[0]], system.items[six[0] + 1:])
                 system = system.items[six[0]]
+                if substeps > 1:      # the systems in front run on the first sub-step of every tick; all see the world tick
+                    import copy
+                    def at_rate(s_, every):
+                        c = copy.copy(s_)
+                        c.every, c.phase, c.tick_substeps = every, 1 % every, substeps
+                        return c
+                    program_stages = ([at_rate(s_, substeps) for s_ in program_stages[0]], [at_rate(s_, 1) for s_ in program_stages[1]])
+                extra = list(getattr(system, "stage_systems", []) or [])
+                if extra:             # maps among the force effectors (frontend.six_dof): every step, behind the systems in front
+                    import copy
+                    def stepwise(s_):
+                        c = copy.copy(s_)
+                        c.tick_substeps = substeps
+                        return c
+                    program_stages = (program_stages[0] + [stepwise(s_) for s_ in extra], program_stages[1])
             for it in program_stages[0] + program_stages[1]:
                 if not isinstance(it, (_dsl.System, _dsl.GraphFold)):
                     raise TypeError("systems piped around six_dof must be elodin_amd.dsl systems (or stand-alone edge folds)")
@@ -502,7 +557,7 @@ class World:
                                                       "are not Bodies while six_dof is in the pipe")
                         side_systems.append(s_)
                         side_entities.update(int(e) for e in stray)
-            effs = _dsl.Program(program_stages[0], eff_pipe, program_stages[1])
+            effs = _dsl.Program(program_stages[0], eff_pipe, program_stages[1], substeps=substeps)
             extra_columns = {}
             for name, w_ in effs.trace(widths, partial, fold_edges=fold_rows).columns:
                 if name == "has:world_pos":                      # which rows are real Bodies (the others are stand-ins)
@@ -555,15 +610,17 @@ class World:
                 keep = np.array([int(a) in body_ids and int(b) in body_ids for a, b in zip(*edges)], dtype=bool)
                 edges = (edges[0][keep], edges[1][keep])
         if _dry:       # generated_sources(): everything resolved, nothing bound
-            return dict(effectors=effs, columns=extra_columns, edges=edges, dt=dt,
+            return dict(effectors=effs, columns=extra_columns, edges=edges, dt=dt, time_step=system.time_step,
+                        substeps=substeps if program_stages is not None else 1, body=dict(world_pos=pos, **{k: v[0] for k, v in body.items()}),
                         integrator=L.INTEGRATOR_NONE if getattr(system, "no_six_dof", False) else system.integrator.value)
         hip = HipExec(pos, body["world_vel"][0], body["inertia"][0], world_accel=body["world_accel"][0],
                       force=body["force"][0], entity_ids=ids, simulation_time_step=dt, time_step=system.time_step,
                       integrator=L.INTEGRATOR_NONE if getattr(system, "no_six_dof", False) else system.integrator.value,
                       effectors=effs, edges=edges,
-                      ticks_per_launch=ticks_per_telemetry, device=device,
+                      ticks_per_launch=ticks_per_telemetry * (substeps if program_stages is not None else 1), device=device,
                       column_entity_ids=None if same else column_ids, columns=extra_columns)
         ex = Exec(hip, self, ticks_per_telemetry, dt)
+        ex._substeps = substeps if program_stages is not None else 1
         ex._partial = self_partial
         ex._body_rows = body_rows if program_stages is not None else None
         if program_stages is not None and side_systems:
@@ -658,7 +715,7 @@ class Exec:
             done += step
 
     def _advance(self, ticks: int) -> None:
-        self._last = self._hip.run(ticks)
+        self._last = self._hip.run(ticks * getattr(self, "_substeps", 1))      # k integrator sub-steps per world tick
         side = getattr(self, "_side", None)        # plain-component entities beside the Bodies: same number of ticks
         if side is not None:
             side.run(ticks)
@@ -681,7 +738,7 @@ class Exec:
 
     @property
     def tick(self) -> int:
-        return self._hip.tick
+        return self._hip.tick // getattr(self, "_substeps", 1)
 
     def column_array(self, name: str) -> np.ndarray:
         out = self._main_column_array(name)

@@ -1047,6 +1047,8 @@ def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_
           column_soa: bool = False) -> Path:
     """Generate + compile (cached by content hash).  Returns the .so path.  A program that no flag set builds without VGPR
     spills is generated again with its columns memory-resident (_MEMORY_COLUMNS) before giving up."""
+    if getattr(tp, "frozen_source", None) is not None:      # dsl.FrozenProgram: the text exists, only the compiler is run
+        return _compile(tp.frozen_source, "pipe")
     try:
         return _compile(generate_source(tp, dtype, integrator, fast_math, window_soa, column_soa), "pipe")
     except SpillError:

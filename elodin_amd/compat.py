@@ -219,13 +219,20 @@ def _make_elodin():
 _INSTALLED = {}
 
 
-def install(run: str = "execute") -> None:
+def install(run: str = "execute", inert=()) -> None:
     """Make `import elodin`, `import jax`, `from jax import numpy, lax, random` resolve to this package.  Refuses to shadow a
-    real JAX / elodin that is already imported."""
+    real JAX / elodin that is already imported.  `inert` names modules a script imports for branches that are not taken here
+    (examples/drone/main.py:4 imports polars for its --telemetry export): absent ones become empty modules."""
     if run not in ("execute", "record"):
         raise ValueError("run must be 'execute' or 'record'")
     _RUN_MODE[0] = run
-    if _INSTALLED:
+    for name in inert:
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except ImportError:
+                _INSTALLED[name] = sys.modules[name] = types.ModuleType(name)
+    if "elodin" in _INSTALLED:
         return
     for name in ("jax", "elodin"):
         if name in sys.modules and getattr(sys.modules[name], "__file__", None):

@@ -134,7 +134,14 @@ class Mat(list):
         cols = list(range(c))[ci] if isinstance(ci, slice) else [range(c)[int(ci)]]
         return rows, cols
 
+    dtype = _d._numpy.float64
+
+    def astype(self, dtype):
+        return Mat([r.astype(dtype) for r in self])
+
     def __getitem__(self, idx):
+        if isinstance(idx, _d.Expr):        # a TRACED row index (a flight plan's `points[time.astype(int)]`): clamped select chain
+            return _d._dynamic_index([list.__getitem__(self, k) for k in range(len(self))], idx)
         if isinstance(idx, int):
             return list.__getitem__(self, idx)
         if isinstance(idx, slice):
@@ -152,10 +159,19 @@ class Mat(list):
     # ---- arithmetic ------------------------------------------------------------------------------------------------
     def _zip(self, o, f):
         o = _d._host(o)
-        if isinstance(o, Mat):
-            if o.shape != self.shape:
-                raise ValueError(f"shape mismatch {self.shape} / {o.shape}")
+        if isinstance(o, Mat) and o.shape == self.shape:
             return Mat([[f(a, b) for a, b in zip(ra.e, rb.e)] for ra, rb in zip(self, o)])
+        if isinstance(o, Mat) and o.shape != self.shape:      # numpy broadcasting of a column / row matrix
+            (r, c), (ro, co) = self.shape, o.shape
+            if co == 1 and ro == r:
+                return Mat([[f(a, rb.e[0]) for a in ra.e] for ra, rb in zip(self, o)])
+            if c == 1 and ro == r:
+                return Mat([[f(ra.e[0], b) for b in rb.e] for ra, rb in zip(self, o)])
+            if ro == 1 and co == c:
+                return Mat([[f(a, b) for a, b in zip(ra.e, o[0].e)] for ra in self])
+            if r == 1 and co == c:
+                return Mat([[f(a, b) for a, b in zip(self[0].e, rb.e)] for rb in o])
+            raise ValueError(f"shape mismatch {self.shape} / {o.shape}")
         if isinstance(o, _d.Vec):      # broadcasting a row vector over the rows, like numpy
             if len(o) != self.shape[1]:
                 raise ValueError("shape mismatch")

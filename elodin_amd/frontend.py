@@ -292,6 +292,10 @@ class _GraphQueryType:
         self.edge_component = name + _api.World.REV_SUFFIX if (len(meta) > 1 and meta[1] is RevEdge) else name
 
 
+class _Misuse(Exception):
+    """A misuse of the decorator surface reported with the reference's own message (never deferred, see _Deferred)."""
+
+
 class Query:
     """The values of one query inside a system being traced: one symbol (or symbolic spatial value) per component, the
     entity axis implicit — every entity of the query's join is one lane of the generated kernel."""
@@ -322,7 +326,7 @@ class Query:
 
     def __getitem__(self, index: int):
         if len(self.values) > 1:
-            raise Exception("Cannot index into a query with multiple inputs")
+            raise _Misuse("Cannot index into a query with multiple inputs")
         if index != 0:
             raise IndexError("only q[0] — the value of a one-entity component such as el.Seed — is available: the entity "
                              "axis of a query is the kernel's lane axis")
@@ -395,6 +399,38 @@ def _annotations(func):
     return params, hints.get("return", sig.return_annotation)
 
 
+def _typed(component, v):
+    """A user component annotated with a spatial type (`Annotated[el.SpatialForce, el.Component("body_thrust")]`,
+    `Annotated[el.Quaternion, el.Component("attitude_target")]`, examples/drone): its column is the flat vector, the function
+    sees the typed value (spatial.rs layouts: [torque, force], [angular, linear], [x, y, z, w], [q, p])."""
+    name = Component.name(component)
+    if name in _BODY + ("force", "world_accel", "tick") or not isinstance(v, _dsl.Vec) or type(v) is not _dsl.Vec:
+        return v
+    o = _origin(component)
+    if o is SpatialForce and len(v) == 6:
+        return _dsl.SpatialForce(torque=v[:3], linear=v[3:])
+    if o is SpatialMotion and len(v) == 6:
+        return _dsl.SpatialMotion(v[:3], v[3:])
+    if o is Quaternion and len(v) == 4:
+        return _dsl.Quaternion(v)
+    if o is SpatialTransform and len(v) == 7:
+        return _dsl.SpatialTransform(_dsl.Quaternion(v[:4]), v[4:])
+    return v
+
+
+def _untyped(v):
+    """The flat column value of what a system returned for a plain component (the inverse of _typed)."""
+    if isinstance(v, _dsl.SpatialForce):
+        return _dsl.np.concatenate([v.torque(), v.force()])
+    if isinstance(v, _dsl.SpatialMotion):
+        return _dsl.np.concatenate([v.angular(), v.linear()])
+    if isinstance(v, _dsl.Quaternion):
+        return v.vector()
+    if isinstance(v, _dsl.SpatialTransform):
+        return _dsl.np.concatenate([v.angular().vector(), v.linear()])
+    return v
+
+
 class _Deferred:
     """A decorated function whose decoration-time call on symbols failed (its body reads something that does not exist yet:
     examples/drone reads `Config.GLOBAL`, set by main.py after the modules with the @el.map functions were imported).  The
@@ -431,7 +467,7 @@ def system(func):
     holds the written components.  Lowered now (one call on symbols); if that call fails, on first use (_Deferred)."""
     try:
         return _system_now(func)
-    except TypeError:
+    except (TypeError, IndexError, _Misuse):
         raise                      # a misuse the decorator reports (bad annotations, reading `force` outside six_dof ...)
     except Exception as e:  # noqa: BLE001
         return _Deferred(func, e)
@@ -446,7 +482,7 @@ def _system_now(func):
     by_name = {Component.name(c): c for c in q_components}
 
     def call(values: dict, indexed: set):
-        args = [Query(a.components, [values[n] for n in a.names], indexed) if isinstance(a, _QueryType)
+        args = [Query(a.components, [_typed(c, values[n]) for c, n in zip(a.components, a.names)], indexed) if isinstance(a, _QueryType)
                 else GraphQuery(a.edge_component) for _, a in params]
         with _dsl.tracing():
             return func(*args)
@@ -478,9 +514,10 @@ def _system_now(func):
 
     def system_fn(**cols):
         out = call(cols, set())
-        return dict(zip(out.names, out.values))
+        return {n: (v if n in _BODY else _untyped(v)) for n, v in zip(out.names, out.values)}
     s = _dsl.System(system_fn, widths, 1, tuple(sorted(indexed)))
     s.params, s.__name__ = list(by_name), name
+    s.aliases = False            # component names are exact here: a user component may be called `accel`, `pos`, `vel`
     return s
 
 
@@ -570,13 +607,24 @@ def six_dof(time_step: Optional[float] = None, sys=None, integrator: Integrator 
     sys = _resolved(sys)
     if isinstance(sys, _dsl.Stages):                 # `gravity | drag` of two effector-kind systems
         sys = sys.items
+    plain = []
     if isinstance(sys, (list, tuple)):
+        # maps that write plain components piped among the force effectors (examples/drone/sim.py:193 `gravity | drag |
+        # motor_thrust_response | body_thrust | apply_body_forces`): with the semi-implicit integrator the pipe is evaluated
+        # once per step, so they run in front of the force evaluation in pipe order (nothing they read is a force)
+        plain = [s for s in sys if isinstance(s, _dsl.System)]
+        sys = [s for s in sys if not isinstance(s, _dsl.System)]
+        if plain and integrator != Integrator.SemiImplicit:
+            raise NotImplementedError("maps writing plain components inside six_dof(sys=...) are supported with the "
+                                      "semi-implicit integrator only (RK4 would evaluate them once per stage)")
         folds = [s for s in sys if isinstance(s, _dsl.EdgeFold)]
         effs = [s for s in sys if not isinstance(s, _dsl.EdgeFold)]
         if folds and effs:
             raise TypeError("a user edge_fold cannot be piped with generated effectors: fold it in its own six_dof(sys=...)")
         sys = folds[0] if folds else _dsl.pipe(*effs)
-    return _api.six_dof(time_step, sys, integrator)
+    out = _api.six_dof(time_step, sys, integrator)
+    out.stage_systems = plain
+    return out
 
 
 System = (_dsl.System, _dsl.Stages, _dsl.Effector, _dsl.Pipe, _dsl.EdgeFold, _dsl.GraphFold, _api.System)   # `-> el.System` annotations / isinstance

@@ -173,7 +173,8 @@ def _run_systems(systems, pos, vel, inertia, comps, table, tick, accel=None):
         if s.every > 1 and tick % s.every != s.phase and tick != s.also_at:
             continue
         lv = _leaf_arrays(pos, vel, inertia, comps, table, tick, accel)
-        vals = _eval([e for _, e in s.assign], lv, pos.shape[0])
+        vals = [np.array(v, copy=True) for v in _eval([e for _, e in s.assign], lv, pos.shape[0])]   # copies: an output that IS a
+        # leaf (a delay line shifting its rows) would otherwise be a view of the column about to be overwritten
         for (target, _), val in zip(s.assign, vals):     # all outputs computed before any is written
             if target == "mass":
                 inertia[:, 6] = val
@@ -219,15 +220,16 @@ def _run_fold_stage(fs, pos, vel, inertia, comps):
         comps[fs.scratch_name][row] = acc
 
 
-def program_tick(tp, pos, vel, accel, inertia, comps, tick, dt_g, integrator):
-    """One tick of a dsl.TracedProgram with numpy (in place on copies); `tick` = count after this tick."""
+def program_tick(tp, pos, vel, accel, inertia, comps, tick, dt_g, integrator, dt=None):
+    """One tick of a dsl.TracedProgram with numpy (in place on copies); `tick` = count after this tick.  `dt`: the
+    six_dof(time_step=) override (rk4.rs:93-100,129 / semi_implicit.rs) when it differs from the world's step."""
     from tests import np_sixdof
     _run_systems(tp.pre, pos, vel, inertia, comps, tp.table, tick, accel if getattr(tp, "pre_reads_accel", False) else None)
 
     def eff(xs, vs):
         lv = _leaf_arrays(xs, vs, inertia, comps, tp.table, tick)
         return _world_wrench(np.stack(_eval(tp.pipe.outputs, lv, xs.shape[0]), axis=1), xs)
-    pos2, vel2, acc2, F = np_sixdof.tick(pos, vel, accel, inertia, eff, dt_g, integrator=integrator)
+    pos2, vel2, acc2, F = np_sixdof.tick(pos, vel, accel, inertia, eff, dt_g, dt=dt, integrator=integrator)
     pos[:], vel[:], accel[:] = pos2, vel2, acc2
     _run_systems(tp.post, pos, vel, inertia, comps, tp.table, tick, accel)
     return F

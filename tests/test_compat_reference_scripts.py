@@ -8,6 +8,10 @@ read from /root/reference and never copied:
                                examples/three_body.py (GPU: the three-body golden CSV)
   examples/linalg/sim.py       traced and stepped 100 ticks on the CPU walker: every component lands on the rows of the
                                reference's CI baseline scripts/ci/baseline/linalg (1e-9; the reference's own CI accepts 1e-4)
+  examples/drone/main.py       the closed-loop quadcopter (cascaded attitude / rate PIDs, motor + sensor models, Mahony-style
+                               estimator; 300 Hz simulation under a 100 Hz telemetry tick = three semi-implicit sub-steps per
+                               tick): traced and stepped 100 ticks on the CPU walker against scripts/ci/baseline/drone-csv
+                               (GPU: tests/test_gpu_drone.py runs the same generated kernel from a frozen fixture)
 """
 import importlib.util
 import json
@@ -98,6 +102,74 @@ def test_linalg_script_unmodified_lands_on_the_reference_baseline(compat):
             assert np.all(comps[name][others] == 0.0), name
     print("examples/linalg/sim.py unmodified vs its CI baseline, worst per component:", {k: f"{v:.1e}" for k, v in worst.items()})
     assert len(worst) == 11 and max(worst.values()) < 1e-9, worst
+
+
+# What a drone component is compared against: its own largest baseline value in the row, but not less than 1e-3 rad/s (rad) for
+# the angular quantities, which start at 1e-11 on the first ticks.
+DRONE_FLOORS = {"ang_vel_setpoint": 1e-3, "body_ang_vel": 1e-3, "gyro": 1e-3, "rate_pid_state": 1e-3, "gyro_lpf_delay": 1e-3,
+                "torque": 1e-3, "euler_rate_target": 1e-3, "angle_desired": 1e-3, "attitude_estimate_error": 1e-3}
+
+
+# Through tick 6 every component agrees to 1e-17; on ticks 7-9 the attitude error is an angle of ~4e-6 rad taken through
+# arccos of a quaternion component 1e-12 below 1 (examples/drone/control.py), where one ulp of the argument is 1e-10 rad of the
+# result: ang_vel_setpoint differs by 1.1e-10 rad/s there, the rate PID's derivative term carries it to 6e-9 of its state, and
+# the closed loop damps it again (6.6e-12 rad/s by tick 100).  Those five columns are held to 5e-7 of their scale, everything
+# else to 2e-9; the reference's own CI accepts 1e-4 on this baseline.
+DRONE_RATE_CHAIN = ("ang_vel_setpoint", "body_ang_vel", "rate_pid_state", "gyro", "gyro_lpf_delay")
+
+
+def drone_verdict(worst, rate_chain=5e-7, rest=2e-9):
+    assert len(worst) >= 27, sorted(worst)
+    bad = {k: v for k, v in worst.items() if not v < (rate_chain if k in DRONE_RATE_CHAIN else rest)}
+    assert not bad, bad
+
+
+def drone_errors(gold, row, cur, worst):
+    for name, rows in gold["rows"].items():
+        if name not in cur:
+            continue
+        ref, got = np.asarray(rows[row], dtype=np.float64).reshape(-1), np.asarray(cur[name], dtype=np.float64).reshape(-1)
+        scale = max(float(np.max(np.abs(ref))), DRONE_FLOORS.get(name, 1e-9))
+        worst[name] = max(worst.get(name, 0.0), float(np.max(np.abs(got - ref))) / scale)
+
+
+def test_drone_script_unmodified_lands_on_the_reference_baseline(compat):
+    from tests import dsl_numpy
+    compat.install(run="record", inert=("polars",))
+    sys.path.insert(0, str(REF / "examples" / "drone"))
+    limit = sys.getrecursionlimit()
+    sys.setrecursionlimit(20000)
+    try:
+        ref = _load(REF / "examples" / "drone" / "main.py", "ref_drone_main")           # runs world.run(...) at import: recorded
+        run = ref.world.compat_run
+        assert run["simulation_rate"] == 300.0 and run["telemetry_rate"] == 100.0
+        plan = ref.world.build(run["system"], simulation_rate=run["simulation_rate"], telemetry_rate=run["telemetry_rate"], _dry=True)
+        tp = plan["effectors"].trace()
+        # the reference's schedule: control on the first of three sub-steps, plant + sensors on every one
+        assert plan["substeps"] == 3 and plan["integrator"] == 1 and abs(plan["time_step"] * 900.0 - 1.0) < 1e-12
+        sched = {s.name: (s.every, s.phase) for s in list(tp.pre) + list(tp.post)}
+        assert all(sched[k] == (3, 1) for k in ("attitude_flight_plan", "update_target_attitude", "attitude_control", "rate_control",
+                                                 "motor_input_to_pwm"))
+        assert all(sched[k] == (1, 0) for k in ("drag", "motor_thrust_response", "body_thrust", "gyro", "accel", "mag"))
+        gold = json.loads((ROOT / "tests" / "golden" / "drone.json").read_text())
+        body, cols = plan["body"], plan["columns"]
+        n = body["world_pos"].shape[0]
+        pos, vel, acc, inertia = (np.array(body[k], dtype=np.float64).copy() for k in ("world_pos", "world_vel", "world_accel", "inertia"))
+        comps = {name: np.array(cols[name], dtype=np.float64).reshape(n, -1).copy() for name, _ in tp.columns}
+        worst, sub = {}, 0
+        for tick in range(1, 101):
+            for _ in range(plan["substeps"]):
+                sub += 1
+                dsl_numpy.program_tick(tp, pos, vel, acc, inertia, comps, sub, plan["dt"], plan["integrator"], dt=plan["time_step"])
+            if tick in gold["tick"]:
+                cur = {k: v[0] for k, v in comps.items()}
+                cur.update(world_pos=pos[0], world_vel=vel[0], world_accel=acc[0])
+                drone_errors(gold, gold["tick"].index(tick), cur, worst)
+    finally:
+        sys.setrecursionlimit(limit)
+    print("examples/drone/main.py unmodified vs its CI baseline, worst per component:",
+          {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])})
+    drone_verdict(worst)
 
 
 def test_shim_keeps_data_and_traced_code_apart(compat):

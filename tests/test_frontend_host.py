@@ -126,8 +126,14 @@ def test_what_decorated_functions_lower_to():
     assert [type(i).__name__ for i in stages.items] == ["System", "System", "System", "System"]
     pipe = stages.items[2].effectors.trace()
     assert [e.value for e in pipe.linear.e[:2]] == [1.0, 0.0] and pipe.columns == []
-    with pytest.raises(TypeError):
-        gravity | foo                                    # a non-force system inside the effector pipe
+    # a map writing a plain component piped among the force effectors (examples/drone/sim.py:193): a stage list that six_dof
+    # splits — with the semi-implicit integrator (one evaluation of the pipe per step) the map runs in front of the forces
+    mixed = gravity | foo | constant_force
+    assert isinstance(mixed, dsl.Stages) and [type(i).__name__ for i in mixed.items] == ["Effector", "System", "Effector"]
+    six = el.six_dof(1 / 120.0, mixed, integrator=el.Integrator.SemiImplicit)
+    assert six.stage_systems == [foo] and len(six.effectors.effectors) == 2
+    with pytest.raises(NotImplementedError, match="semi-implicit"):
+        el.six_dof(1 / 120.0, mixed)
     with pytest.raises(TypeError):
         el.World().build(gravity)
     with pytest.raises(TypeError):
