@@ -109,7 +109,12 @@ class _Spatial6:
 
 
 class SpatialMotion(_Spatial6):
-    def __init__(self, arr=None, angular=None, linear=None):
+    """el.SpatialMotion(angular=None, linear=None) (libs/nox-py/src/spatial.rs:121-133), positional too: `SpatialMotion(w, v)`
+    (examples/cube-sat/main.py:541).  One six-element argument is taken as the whole [angular, linear] array."""
+
+    def __init__(self, angular=None, linear=None, arr=None):
+        if arr is None and linear is None and angular is not None and np.size(angular) == 6:
+            arr, angular = angular, None
         super().__init__(arr, angular, linear)
 
     def angular(self): return self.arr[:3]
@@ -294,11 +299,15 @@ class World:
     def entity_len(self) -> int:
         return int(self._lib.sixdof_world_entity_len(self._w))
 
-    def spawn(self, archetypes, name: Optional[str] = None) -> EntityId:
+    def spawn(self, archetypes, name: Optional[str] = None, id: Optional[str] = None) -> EntityId:   # noqa: A002 (the reference's keyword)
+        """WorldBuilder.spawn(spawnable, name=None, id=None) (world_builder.rs:268-310); `id` is the entity's snake_case name in
+        the database (the prefix of its CSV columns), kept in `entity_ids_by_name`."""
         eid = EntityId(self._lib.sixdof_world_spawn(self._w))
         self.insert(eid, archetypes)
         if name is not None:
             self._names[int(eid)] = name
+        if id is not None:
+            self.__dict__.setdefault("entity_ids_by_name", {})[id] = int(eid)
         return eid
 
     def insert(self, eid: EntityId, archetypes) -> None:
@@ -401,6 +410,8 @@ class World:
         substeps = 1
         if isinstance(system, _dsl.System):
             system = _dsl.Stages([system])
+        if isinstance(system, System) and getattr(system, "stage_systems", None):
+            system = _dsl.Stages([system])       # six_dof(sys=...) alone, with maps / folds among its effectors: a program too
         if isinstance(system, _dsl.Stages):      # pre | six_dof(effectors) | post  -> one generated program
             six = [k for k, it in enumerate(system.items) if isinstance(it, System)]
             if len(six) > 1:
@@ -477,6 +488,12 @@ class World:
             if not isinstance(system.effectors, _dsl.Pipe) and system.effectors.ops:
                 raise TypeError("inside a generated program the six_dof effectors must be dsl effectors")
             widths = {name: int(self.column(name)[0].shape[1]) for name in self._components}
+            # a fold returning el.Force (frontend._lower_fold): its result column and the mark of the rows it is folded onto
+            hidden = {}
+            for it in program_stages[0] + program_stages[1]:
+                if isinstance(it, _dsl.GraphFold) and getattr(it, "hidden_force", None):
+                    hidden[it.hidden_force[0]], hidden[it.hidden_force[1]] = ("value", it), ("mark", it)
+                    widths[it.hidden_force[0]], widths[it.hidden_force[1]] = 6, 1
             # the executor's row set: the Body join (ascending id unless the Body columns already coincide, query.rs:673,702)
             row_ids = ids
             for v in column_ids.values():
@@ -499,7 +516,8 @@ class World:
                 fold_pairs = {}
                 for it in folds:
                     frm, to = self.edge_pairs(it.edge_component)
-                    keep = [k for k in range(len(frm)) if carries(frm[k], it.left + (it.out,)) and carries(to[k], it.right)]
+                    out_names = () if it.out in hidden else (it.out,)
+                    keep = [k for k in range(len(frm)) if carries(frm[k], it.left + out_names) and carries(to[k], it.right)]
                     fold_pairs[it.edge_component] = ([int(frm[k]) for k in keep], [int(to[k]) for k in keep])
                 extra = sorted({e for f_, t_ in fold_pairs.values() for e in f_ + t_} - body_set)
                 if extra and synthesized_body is None:
@@ -523,7 +541,7 @@ class World:
                 where_row = {int(e): k for k, e in enumerate(row_ids)}
                 fold_rows = {name: ([where_row[a] for a in f_], [where_row[b] for b in t_]) for name, (f_, t_) in fold_pairs.items()}
             probe = _dsl.Program(program_stages[0], eff_pipe, program_stages[1]).trace(widths, fold_edges=fold_rows)
-            partial = [n for n, _ in probe.columns if "#fold" not in n and not n.endswith("#head")
+            partial = [n for n, _ in probe.columns if "#fold" not in n and not n.endswith("#head") and n not in hidden
                        and not np.all(np.isin(row_ids, self.column(n)[1]))]
             if body_rows is not None:
                 partial.append("world_pos")
@@ -564,6 +582,14 @@ class World:
                     mask = np.zeros((len(row_ids), 1))
                     mask[body_rows] = 1.0
                     extra_columns[name] = mask
+                    column_ids[name] = row_ids
+                    continue
+                if name in hidden:
+                    kind, it = hidden[name]
+                    col = np.zeros((len(row_ids), w_))
+                    if kind == "mark":
+                        col[sorted(set(fold_rows[it.edge_component][0]))] = 1.0
+                    extra_columns[name] = col
                     column_ids[name] = row_ids
                     continue
                 if name.startswith("has:") or "#fold" in name or name.endswith("#head"):   # presence columns / fold scratch rows /
@@ -610,7 +636,8 @@ class World:
                 keep = np.array([int(a) in body_ids and int(b) in body_ids for a, b in zip(*edges)], dtype=bool)
                 edges = (edges[0][keep], edges[1][keep])
         if _dry:       # generated_sources(): everything resolved, nothing bound
-            return dict(effectors=effs, columns=extra_columns, edges=edges, dt=dt, time_step=system.time_step,
+            return dict(effectors=effs, columns=extra_columns, edges=edges, dt=dt, time_step=system.time_step, row_ids=np.asarray(ids).copy(),
+                        names=dict(getattr(self, "entity_ids_by_name", {})),
                         substeps=substeps if program_stages is not None else 1, body=dict(world_pos=pos, **{k: v[0] for k, v in body.items()}),
                         integrator=L.INTEGRATOR_NONE if getattr(system, "no_six_dof", False) else system.integrator.value)
         hip = HipExec(pos, body["world_vel"][0], body["inertia"][0], world_accel=body["world_accel"][0],

@@ -1049,31 +1049,35 @@ def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_
     spills is generated again with its columns memory-resident (_MEMORY_COLUMNS) before giving up."""
     if getattr(tp, "frozen_source", None) is not None:      # dsl.FrozenProgram: the text exists, only the compiler is run
         return _compile(tp.frozen_source, "pipe")
+    variants = VARIANTS if isinstance(tp, dsl.TracedProgram) else VARIANTS[:2]
+    for k, variant in enumerate(variants):
+        try:
+            so = _compile(generate_variant(tp, variant, dtype, integrator, fast_math, window_soa, column_soa), "pipe")
+            last_variant[0] = variant
+            return so
+        except SpillError:
+            if os.environ.get(ALLOW_SPILLS_ENV, "") == "1" or k == len(variants) - 1:
+                raise
+
+
+# What build() tries, in order, until a build has no VGPR spills: the tick body emitted in the user's program order; in demand
+# order (each value right before its first use); with the columns in a memory image instead of registers (_MEMORY_COLUMNS);
+# with the tick body out of line (SIXDOF_TICK_OUT_OF_LINE).
+VARIANTS = ("program", "demand", "memory", "out_of_line")
+last_variant = ["program"]      # the variant the last build() settled on (fixture generators record it)
+
+
+def generate_variant(tp, variant: str, dtype: str = "float64", integrator: int = 0, fast_math: bool = False, window_soa: bool = False,
+                     column_soa: bool = False) -> str:
+    if variant not in VARIANTS:
+        raise ValueError(f"variant must be one of {VARIANTS}")
+    _EMIT_ORDER[0] = "demand" if variant == "demand" else "program"
+    _MEMORY_COLUMNS[0] = variant == "memory"
+    _TICK_OUT_OF_LINE[0] = variant == "out_of_line"
     try:
-        return _compile(generate_source(tp, dtype, integrator, fast_math, window_soa, column_soa), "pipe")
-    except SpillError:
-        if os.environ.get(ALLOW_SPILLS_ENV, "") == "1":
-            raise
-    _EMIT_ORDER[0] = "demand"
-    try:
-        return _compile(generate_source(tp, dtype, integrator, fast_math, window_soa, column_soa), "pipe")
-    except SpillError:
-        if not isinstance(tp, dsl.TracedProgram):
-            raise
+        return generate_source(tp, dtype, integrator, fast_math, window_soa, column_soa)
     finally:
-        _EMIT_ORDER[0] = "program"
-    _MEMORY_COLUMNS[0] = True
-    try:
-        return _compile(generate_source(tp, dtype, integrator, fast_math, window_soa, column_soa), "pipe")
-    except SpillError:
-        pass
-    finally:
-        _MEMORY_COLUMNS[0] = False
-    _TICK_OUT_OF_LINE[0] = True
-    try:
-        return _compile(generate_source(tp, dtype, integrator, fast_math, window_soa, column_soa), "pipe")
-    finally:
-        _TICK_OUT_OF_LINE[0] = False
+        _EMIT_ORDER[0], _MEMORY_COLUMNS[0], _TICK_OUT_OF_LINE[0] = "program", False, False
 
 
 # Generated programs are one long straight-line tick body inside the kernel's tick loop.  Left alone, LLVM's MachineLICM

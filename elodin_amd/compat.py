@@ -209,6 +209,29 @@ def _make_elodin():
             self.compat_exec = ex
             return ex
     el.World = el.WorldBuilder = World
+
+    def _get_cache_dir():                      # lib.rs:130-142: ProjectDirs("systems", "elodin", "elodin-cli").cache_dir()
+        import os
+        return os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "elodin-cli")
+    el._get_cache_dir = _get_cache_dir
+    native = types.ModuleType("elodin.elodin")      # the reference's extension module: same names (`from elodin.elodin import Quaternion`)
+    native.__dict__.update({k: v for k, v in el.__dict__.items() if not k.startswith("__")})
+    el.elodin = native
+    egm = types.ModuleType("elodin.egm08")
+
+    class EGM08:
+        """elodin.egm08.EGM08 (python/elodin/egm08.py:17-216) as a declaration: the reference downloads its degree-2190 coefficient
+        tables on first use (egm08.py:27-41) and evaluates the spherical-harmonic series with jax scans.  Neither the tables nor
+        a network exist here, so a script that constructs the model imports; evaluating the field is refused."""
+
+        def __init__(self, max_degree, cache_directory=""):
+            self.max_degree, self.cache_directory = max_degree, cache_directory
+
+        def compute_field(self, x, y, z, mass):
+            raise NotImplementedError("elodin.egm08.EGM08.compute_field is not provided by elodin_amd.compat: the EGM2008 coefficient "
+                                      "tables (C_normal.npy / S_normal.npy) are fetched from the network by the reference")
+    egm.EGM08 = EGM08
+    el.egm08 = egm
     for name in ("Panel", "Mesh", "Material", "Shape", "Color", "Glb", "Scene", "Line3d", "BodyAxes", "VectorArrow", "s10",
                  "StepContext", "Time"):
         if not hasattr(el, name):
@@ -246,6 +269,7 @@ def install(run: str = "execute", inert=()) -> None:
             pass
     mods = _make_jax()
     mods["elodin"] = _make_elodin()
+    mods["elodin.elodin"], mods["elodin.egm08"] = mods["elodin"].elodin, mods["elodin"].egm08
     sys.modules.update(mods)
     _INSTALLED.update(mods)
 

@@ -52,6 +52,15 @@ class Expr:
         cls._interned[key] = self
         return self
 
+    @classmethod
+    def fresh(cls) -> None:
+        """Start of a top-level trace: forget the hash-consing table and restart the creation counter.  A program's nodes are
+        then its own — the text generated for it (emission follows `seq`) does not depend on what else the process traced
+        before, so equal programs give equal sources and the JIT cache hits whatever the order.  Nodes of earlier traces
+        stay valid; they are just no longer shared."""
+        cls._interned = {}
+        cls._count[0] = 0
+
     # numpy must not broadcast a traced value into an object array: `ndarray * traced` falls through to the reflected method
     __array_ufunc__ = None
 
@@ -99,6 +108,8 @@ class Expr:
         return _un("trunc", self) if "int" in name else self
     dtype = _numpy.float64
     shape = ()
+    def all(self, axis=None): return self           # a 0-d comparison: `(x < fov).all()`
+    def any(self, axis=None): return self
 
     def __bool__(self):
         raise TypeError("traced values have no truth value; use dsl.np.where / logical_and")
@@ -396,8 +407,10 @@ class _Np:
     def array(x, dtype=None):
         """jnp.array of a flat sequence -> Vec; of a sequence of rows -> a matrix (dsl_mat.Mat)."""
         from . import dsl_mat
-        if isinstance(x, (Vec, dsl_mat.Mat)):
+        if isinstance(x, (Vec, dsl_mat.Mat, Expr)):
             return x
+        if isinstance(x, (int, float, bool)):        # a 0-d array: `np.array(0.0)` as a fold's initial value
+            return _lift(float(x))
         x = list(x)
         if x and isinstance(x[0], (list, tuple, Vec)):
             return dsl_mat.Mat(x)
@@ -758,6 +771,13 @@ class _Lax:
         return _tree_select(pred, on_true, on_false)
 
     @staticmethod
+    def convert_element_type(x, dtype):
+        """lax.convert_element_type: to an integer type truncates toward zero (values stay in the executor's float type)."""
+        name = getattr(dtype, "__name__", str(dtype))
+        f = (lambda e: _un("trunc", _lift(e))) if "int" in name else (lambda e: e)
+        return Vec([f(e) for e in x.e]) if isinstance(x, Vec) else f(x)
+
+    @staticmethod
     def branch_cond(pred, true_fun, false_fun, *operands):
         """`cond` with a REAL branch in the kernel (not in jax.lax): `true_fun(*operands)` is evaluated only by waves with a
         lane whose `pred` holds, instead of by every lane on every tick with the result selected away.  For rare, expensive
@@ -931,9 +951,14 @@ class _Random:
 
     @staticmethod
     def key(seed) -> _Key:
+        """threefry_seed on an int64 seed: words (seed >>> 32, seed & 0xffffffff) of its two's complement — a negative seed
+        (examples/cube-sat/main.py:173 seeds with a truncated ECEF coordinate) has the high word 0xffffffff."""
         seed = _lift(seed)
         hi = _un("floor", seed / 4294967296.0)
-        return _Key(hi, seed - hi * 4294967296.0)
+        lo = seed - hi * 4294967296.0
+        if seed.op == "const":
+            return _Key(float(int(hi.value) & 0xFFFFFFFF) if hi.op == "const" else hi, lo)
+        return _Key(hi - _un("floor", hi / 4294967296.0) * 4294967296.0, lo)
 
     @staticmethod
     def _threefry(key: _Key, c0, c1):
@@ -1340,6 +1365,7 @@ class TracedPipe:
         pos, vel, inertia = _body_symbols(stage=True)
         force = SpatialForce()                          # clear_forces: the pipe starts from zero (six_dof.rs:148-150)
         force._q = pos.angular()
+        self.leaves_upto = []
         for eff in self.effectors:
             kwargs = {}
             for name in eff.params:
@@ -1372,6 +1398,8 @@ class TracedPipe:
                 kept._q = out._q
                 out = kept
             force = out
+            if getattr(eff, "pipe_index", None) is not None:      # what the force depends on up to here (TracedProgram's order check)
+                self.leaves_upto.append((eff.pipe_index, _leaves_of(list(force._tw.e) + list(force._f.e) + list(force._tb.e))))
         self.torque_world, self.torque_body, self.linear = force._tw, force._tb, force.force()
         # outputs: world torque (3), force (3), body-frame torque (3)
         self.outputs: List[Expr] = list(self.torque_world.e) + list(self.linear.e) + list(self.torque_body.e)
@@ -1389,7 +1417,7 @@ def pipe(*effectors: Effector) -> "Pipe":
     flat: List[Effector] = []
     for e in effectors:
         flat.extend(e.effectors if isinstance(e, Pipe) else [e])
-    if any(isinstance(e, (System, Stages)) for e in flat):
+    if any(isinstance(e, (System, Stages, GraphFold)) for e in flat):
         # `gravity | drag | motor_response | apply_forces` (examples/drone/sim.py:193): force effectors piped with maps that
         # write plain components.  Kept as a flat stage list; six_dof(sys=...) splits it (frontend.six_dof)
         items = []
@@ -1414,6 +1442,7 @@ class Pipe:
 
     def trace(self, widths: Optional[Dict[str, int]] = None) -> TracedPipe:
         if self._traced is None:
+            Expr.fresh()
             self._traced = TracedPipe(self.effectors, widths=widths)
         return self._traced
 
@@ -1451,6 +1480,7 @@ class EdgeFold:
 
     def trace(self) -> "TracedFold":
         if self._traced is None:
+            Expr.fresh()
             self._traced = TracedFold(self)
         return self._traced
 
@@ -1495,6 +1525,7 @@ class GraphFold:
             raise TypeError("fold function must take (acc, *left components, *right components)")
 
     def trace(self, widths: Dict[str, int]) -> "TracedGraphFold":
+        Expr.fresh()
         return TracedGraphFold(self, widths)
 
 
@@ -1718,6 +1749,7 @@ class Program:
         Monte-Carlo batch of graph worlds); `fold_edges` then describe replica 0 only (rows < stride) and every replica folds
         over the same template, shifted by its base row — one baked CSR for the whole batch."""
         if self._traced is None:
+            Expr.fresh()
             self._traced = TracedProgram(self, widths, partial, fold_edges, fold_replicas)
         return self._traced
 
@@ -1809,6 +1841,16 @@ class TracedProgram:
         self.post = [trace_item(s, True) for s in prog.post]
         self.fold_stages = [s for s in self.pre + self.post if isinstance(s, TracedFoldStage)]
         self.writes_inertia = any(s.writes_inertia for s in self.pre + self.post)
+        # maps / folds that stood among the force effectors inside six_dof(sys=...) run in front of the force evaluation
+        # (frontend.six_dof).  That is the reference's order unless an effector reads what a system BEHIND it in the pipe writes
+        # (it would see the old value there, the new one here)
+        for s, ts in zip(prog.pre, self.pre):
+            j = getattr(s, "pipe_index", None)
+            for i, leaves in self.pipe.leaves_upto if j is not None else ():
+                clash = set(ts.written) & leaves if j > i else None
+                if clash:
+                    cols = sorted({self.table.cols[int(t[1:].split("_")[0])][0] for t in clash if t[0] == "c"})
+                    raise NotImplementedError(f"six_dof(sys=...): {ts.name} writes {cols}, which a force effector in front of it reads")
         # world_accel read in front of six_dof = the previous tick's; a system BEHIND a post fold runs in a launch of its own
         # and finds this tick's there, loaded the same way
         seen_fold = False

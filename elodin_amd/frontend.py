@@ -359,6 +359,7 @@ class GraphQuery:
     def edge_fold(self, left_query: Query, right_query: Query, return_type, init_value, fold_fn) -> _Fold:
         f = _Fold(self.edge_component, left_query.names, right_query.names, Component.name(return_type), init_value, fold_fn)
         f.out_type = return_type
+        f.types = {n: c for q in (left_query, right_query) for n, c in zip(q.names, q.components)}
         return f
 
 
@@ -499,18 +500,35 @@ def _system_now(func):
     widths = {n: (_window_shape(c) or w) for n, c in {**by_name, **{Component.name(c): c for c in probe.components}}.items()
               if (w := _width(c)) is not None and n not in _BODY + ("force", "tick", "world_accel")}
 
-    if out_names == ["force"]:                       # `-> el.Force`: an effector of six_dof (six_dof.rs:161-203 `sys`)
-        def effector_fn(**cols):             # the pipe tracer hands every plain column over as a Vec; shape-() ones are scalars
-            cols = {n: (v[0] if isinstance(v, _dsl.Vec) and type(v) is _dsl.Vec and len(v) == 1 else v) for n, v in cols.items()}
-            return call(cols, set()).values[0]
-        eff = _dsl.Effector(effector_fn, widths)
-        eff.params, eff.__name__ = list(by_name), name
-        return eff
-    if "force" in by_name:
-        raise TypeError(f"system {name}: {unreadable}")
-    if "force" in out_names or "world_accel" in out_names:
+    if "world_accel" in out_names:
         raise TypeError(f"system {name}: force / world_accel are produced inside six_dof — return el.Force alone and pass "
                         "the system as six_dof(sys=...)")
+    if "force" in out_names:                         # `-> el.Force`: an effector of six_dof (six_dof.rs:161-203 `sys`)
+        k_force = out_names.index("force")
+        def effector_fn(**cols):             # the pipe tracer hands every plain column over as a Vec; shape-() ones are scalars
+            cols = {n: (v[0] if isinstance(v, _dsl.Vec) and type(v) is _dsl.Vec and len(v) == 1 else v) for n, v in cols.items()}
+            return call(cols, set()).values[k_force]
+        eff = _dsl.Effector(effector_fn, widths)
+        eff.params, eff.__name__ = list(by_name), name
+        if len(out_names) == 1:
+            return eff
+        # `-> tuple[el.Force, Radius]` (examples/cube-sat/main.py:516-527): the force is the effector; the plain components are a
+        # map of their own over the same query, which may not look at the force (a stage value, gone when the step is over)
+        plain_names = [n for n in out_names if n != "force"]
+        def plain_fn(**cols):
+            cols = dict(cols)
+            cols["force"] = _probe_value(by_name["force"]) if "force" in by_name else None
+            out = call(cols, set())
+            vals = {n: (v if n in _BODY else _untyped(v)) for n, v in zip(out.names, out.values) if n != "force"}
+            flat = [e for v in vals.values() for e in (v.e if isinstance(v, _dsl.Vec) else [_dsl._lift(v)]) if isinstance(e, _dsl.Expr)]
+            if any(l.startswith("acc") and l[3:].isdigit() for l in _dsl._leaves_of(flat)):
+                raise TypeError(f"system {name}: {unreadable}")
+            return vals
+        s2 = _dsl.System(plain_fn, widths, 1, tuple(sorted(indexed)))
+        s2.params, s2.__name__, s2.aliases = [n for n in by_name if n != "force"], name + "_components", False
+        return _dsl.Stages([eff, s2])
+    if "force" in by_name:
+        raise TypeError(f"system {name}: {unreadable}")
 
     def system_fn(**cols):
         out = call(cols, set())
@@ -521,11 +539,23 @@ def _system_now(func):
     return s
 
 
+def _fold_init(v) -> list:
+    """The fold's initial value as numbers: arrays, 0-d arrays written while tracing (`np.array(0.0)`), spatial zeros."""
+    if hasattr(v, "arr"):                      # api.SpatialForce() / SpatialMotion(): [angular, linear]
+        return [float(x) for x in _np.asarray(v.arr, dtype=_np.float64).reshape(-1)]
+    v = _untyped(v)
+    if isinstance(v, _dsl.Expr):
+        v = _dsl.Vec([v])
+    if isinstance(v, _dsl.Vec):
+        if not all(_dsl._lift(e).is_const() for e in v.e):
+            raise TypeError("an edge_fold's initial value must be constant")
+        return [float(_dsl._lift(e).value) for e in v.e]
+    return [float(x) for x in _np.atleast_1d(_np.asarray(v, dtype=_np.float64)).reshape(-1)]
+
+
 def _lower_fold(fold: _Fold, name: str):
     body_pair = ["world_pos", "inertia"]
-    if fold.out == "force":
-        if fold.left != body_pair or fold.right != body_pair:
-            raise TypeError("an edge_fold returning el.Force folds over Query[el.WorldPos, el.Inertia] on both sides")
+    if fold.out == "force" and fold.left == body_pair and fold.right == body_pair:
         init = fold.init.arr if hasattr(fold.init, "arr") else None
         if init is None or _np.any(init != 0.0):
             raise ValueError("an edge_fold returning el.Force starts from el.SpatialForce() (zero)")
@@ -534,22 +564,50 @@ def _lower_fold(fold: _Fold, name: str):
                            fold.edge_component)
         ef.__name__ = name
         return ef
-    init = [float(v) for v in _np.atleast_1d(_np.asarray(fold.init, dtype=_np.float64)).reshape(-1)]
+    init = _fold_init(fold.init)
     fn, n_args = fold.fn, 1 + len(fold.left) + len(fold.right)
+    types = getattr(fold, "types", {})
 
-    def spatial(name, v):      # Body components reach the fold function as the reference's spatial types
-        if name == "world_pos":
+    def spatial(cname, v):      # Body components and spatially typed user components reach the fold function as the reference's types
+        if cname == "world_pos":
             return _dsl.SpatialTransform(_dsl.Quaternion(_dsl.Vec(v.e[:4])), _dsl.Vec(v.e[4:]))
-        if name == "world_vel":
+        if cname == "world_vel":
             return _dsl.SpatialMotion(_dsl.Vec(v.e[:3]), _dsl.Vec(v.e[3:]))
-        if name == "inertia":
+        if cname == "inertia":
             return _dsl.SpatialInertia(_dsl.Vec(v.e[:3]), v.e[6])
-        return v
+        if cname == "force":
+            return _dsl.SpatialForce(torque=_dsl.Vec(v.e[:3]), linear=_dsl.Vec(v.e[3:]))
+        return _typed(types[cname], v) if cname in types else v
 
     def fixed_arity(*args):
-        names = (None,) + tuple(fold.left) + tuple(fold.right)
-        return fn(*[spatial(n, a) for n, a in zip(names, args)])
+        names = (fold.out,) + tuple(fold.left) + tuple(fold.right)
+        typed = [spatial(n, a) for n, a in zip(names, args)]
+        if fold.out != "force" and fold.out_type is not None:
+            typed[0] = _typed(fold.out_type, args[0])
+        return _untyped(fn(*typed))
     fixed_arity.__signature__ = inspect.Signature([inspect.Parameter(f"a{k}", inspect.Parameter.POSITIONAL_ONLY) for k in range(n_args)])
+    if fold.out == "force":
+        # `-> el.Query[el.Force]` folded over other components (examples/cube-sat/main.py:492-504: the satellite's force is the sum
+        # of its wheels' torques).  Force is a stage value of the integrator, a fold reads other entities' rows: the fold runs as
+        # a stand-alone fold into a hidden column in front of the force evaluation, and an effector puts that value in the
+        # place of the force on the rows that have out-edges (the others keep theirs) — World.build makes the two columns
+        hidden, flag = f"fold_force:{name}", f"fold_src:{name}"
+        gf = _dsl.GraphFold(fixed_arity, fold.edge_component, fold.left, fold.right, hidden, init)
+        gf.__name__, gf.hidden_force = name, (hidden, flag)
+
+        def put(**cols):
+            force, h, src = cols["force"], cols[hidden], cols[flag]
+            m = (src[0] if isinstance(src, _dsl.Vec) else src) > 0.5
+            pick = lambda a, b: _dsl.Vec([_dsl.Expr("select", (m, _dsl._lift(x), _dsl._lift(y))) for x, y in zip(a.e, b.e)])
+            zero = _dsl.Vec([0.0, 0.0, 0.0])
+            out = _dsl.SpatialForce(linear=pick(_dsl.Vec(h.e[3:]), force._f), _tw=pick(_dsl.Vec(h.e[:3]), force._tw), _tb=pick(zero, force._tb))
+            out._q = force._q
+            return out
+        eff = _dsl.Effector(put, {hidden: 6, flag: 1})
+        eff.params, eff.__name__ = ["force", hidden, flag], name + "_put"
+        if fold.then:
+            raise NotImplementedError("edge_fold(...).map(...) on a fold returning el.Force")
+        return _dsl.Stages([gf, eff])
     gf = _dsl.GraphFold(fixed_arity, fold.edge_component, fold.left, fold.right, fold.out, init)
     gf.__name__ = name
     if not fold.then:
@@ -609,11 +667,24 @@ def six_dof(time_step: Optional[float] = None, sys=None, integrator: Integrator 
         sys = sys.items
     plain = []
     if isinstance(sys, (list, tuple)):
-        # maps that write plain components piped among the force effectors (examples/drone/sim.py:193 `gravity | drag |
-        # motor_thrust_response | body_thrust | apply_body_forces`): with the semi-implicit integrator the pipe is evaluated
-        # once per step, so they run in front of the force evaluation in pipe order (nothing they read is a force)
-        plain = [s for s in sys if isinstance(s, _dsl.System)]
-        sys = [s for s in sys if not isinstance(s, _dsl.System)]
+        # maps and folds that write plain components piped among the force effectors (examples/drone/sim.py:193 `gravity | drag |
+        # motor_thrust_response | body_thrust | apply_body_forces`; examples/cube-sat/main.py:699-710 runs its whole flight
+        # software inside six_dof): with the semi-implicit integrator the pipe is evaluated once per step on the state the
+        # step starts from, so they run in front of the force evaluation in pipe order (nothing they read is a force).  What
+        # that reordering must not change — a force effector reading a component that a LATER plain system writes — is checked
+        # when the program is traced (dsl.TracedProgram, `pipe_index`)
+        flat = []
+        def walk(items):
+            for it in items:
+                walk(it.items) if isinstance(it, _dsl.Stages) else flat.append(it)
+        walk(sys)
+        import copy
+        for k, it in enumerate(flat):
+            if getattr(it, "pipe_index", None) is not None:      # the same system object piped twice: each place its own index
+                flat[k] = it = copy.copy(it)
+            it.pipe_index = k
+        plain = [s for s in flat if isinstance(s, (_dsl.System, _dsl.GraphFold))]
+        sys = [s for s in flat if not isinstance(s, (_dsl.System, _dsl.GraphFold))]
         if plain and integrator != Integrator.SemiImplicit:
             raise NotImplementedError("maps writing plain components inside six_dof(sys=...) are supported with the "
                                       "semi-implicit integrator only (RK4 would evaluate them once per stage)")

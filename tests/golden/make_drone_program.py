@@ -34,8 +34,10 @@ spec.loader.exec_module(main)
 run = main.world.compat_run
 plan = main.world.build(run["system"], simulation_rate=run["simulation_rate"], telemetry_rate=run["telemetry_rate"], _dry=True)
 tp = plan["effectors"].trace()
+codegen.build(tp, "float64", plan["integrator"])            # settles on the first variant that fits a wave's registers
 doc = {
-    "source": codegen.generate_source(tp, "float64", plan["integrator"]),
+    "variant": codegen.last_variant[0],
+    "source": codegen.generate_variant(tp, codegen.last_variant[0], "float64", plan["integrator"]),
     "columns": [[n, w] for n, w in tp.columns], "mats": {k: list(v) for k, v in tp.table.mats.items()},
     "substeps": plan["substeps"], "integrator": plan["integrator"], "simulation_time_step": plan["dt"], "time_step": plan["time_step"],
     "simulation_rate": run["simulation_rate"], "telemetry_rate": run["telemetry_rate"],
@@ -45,4 +47,4 @@ doc = {
 }
 out = ROOT / "tests" / "golden" / "drone_program.json"
 out.write_text(json.dumps(doc))
-print(out, out.stat().st_size, "bytes;", len(doc["columns"]), "columns,", doc["source"].count("\n"), "source lines, substeps", doc["substeps"])
+print(out, out.stat().st_size, "bytes; variant", doc["variant"] + ";", len(doc["columns"]), "columns,", doc["source"].count("\n"), "source lines, substeps", doc["substeps"])

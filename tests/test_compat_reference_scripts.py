@@ -12,6 +12,10 @@ read from /root/reference and never copied:
                                estimator; 300 Hz simulation under a 100 Hz telemetry tick = three semi-implicit sub-steps per
                                tick): traced and stepped 100 ticks on the CPU walker against scripts/ci/baseline/drone-csv
                                (GPU: tests/test_gpu_drone.py runs the same generated kernel from a frozen fixture)
+  examples/cube-sat/main.py    the attitude-controlled satellite (MEKF with pseudo-inverses, reaction wheels, sun sensors; eleven
+                               entities, four edge folds, everything inside six_dof(sys=..., SemiImplicit)): traced and stepped
+                               100 ticks against scripts/ci/baseline/cube-sat-csv with the attitude loop closed and the orbit
+                               translation taken from the baseline (its EGM08 gravity tables are a download: tests/cube_sat_util.py)
 """
 import importlib.util
 import json
@@ -125,7 +129,7 @@ def test_drone_script_unmodified_lands_on_the_reference_baseline(compat):
         assert all(sched[k] == (1, 0) for k in ("drag", "motor_thrust_response", "body_thrust", "gyro", "accel", "mag"))
         from elodin_amd import codegen
         frozen = json.loads((ROOT / "tests" / "golden" / "drone_program.json").read_text())      # what tests/test_gpu_drone.py runs
-        assert codegen.generate_source(tp, "float64", plan["integrator"]) == frozen["source"], "re-run tests/golden/make_drone_program.py"
+        assert codegen.generate_variant(tp, frozen["variant"], "float64", plan["integrator"]) == frozen["source"], "re-run tests/golden/make_drone_program.py"
         assert [list(c) for c in tp.columns] == frozen["columns"] and frozen["substeps"] == 3
         gold = json.loads((ROOT / "tests" / "golden" / "drone.json").read_text())
         body, cols = plan["body"], plan["columns"]
@@ -146,6 +150,52 @@ def test_drone_script_unmodified_lands_on_the_reference_baseline(compat):
     print("examples/drone/main.py unmodified vs its CI baseline, worst per component:",
           {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])})
     drone_verdict(worst)
+
+
+def load_cube_sat(compat):
+    """examples/cube-sat/main.py imported unmodified; the one thing replaced is the evaluation of its EGM08 field (compat refuses
+    it: the coefficient tables are a download), by a zero field — see tests/cube_sat_util.py for what that leaves pinned."""
+    from elodin_amd import dsl
+    compat.install(run="record")
+    egm = sys.modules["elodin.egm08"].EGM08
+    refused = egm.compute_field
+    egm.compute_field = lambda self, x, y, z, mass: dsl.np.array([x * 0.0, y * 0.0, z * 0.0])
+    try:
+        ref = _load(REF / "examples" / "cube-sat" / "main.py", "ref_cube_sat_main")     # runs w.run(...) at import: recorded
+        run = ref.w.compat_run
+        assert run["simulation_rate"] == 120.0 and run["max_ticks"] == 144000
+        plan = ref.w.build(run["system"], simulation_rate=run["simulation_rate"], _dry=True)
+    finally:
+        egm.compute_field = refused
+    row_ids = [int(e) for e in plan["row_ids"]]
+    row_of = {name: row_ids.index(e) for name, e in plan["names"].items() if e in row_ids}
+    row_of["earth"] = next(k for k in range(len(row_ids)) if plan["columns"]["has:world_pos"][k, 0] > 0.5 and k != row_of["ore_sat"])
+    return ref, plan, row_of
+
+
+def test_cube_sat_script_unmodified_closes_its_attitude_loop_on_the_reference_baseline(compat):
+    from tests import cube_sat_util as U, dsl_numpy
+    ref, plan, row_of = load_cube_sat(compat)
+    tp = plan["effectors"].trace()
+    assert plan["integrator"] == 1 and plan["substeps"] == 1 and len(row_of) == 11 and dict(tp.columns)["P"] == 36
+    assert [s.name for s in tp.fold_stages] == ["sun_sensor", "sun_sensor_value", "actuator_allocator", "rw_effector"]
+    from elodin_amd import codegen
+    frozen = json.loads((ROOT / "tests" / "golden" / "cube_sat_program.json").read_text())       # what tests/test_gpu_cube_sat.py runs
+    assert codegen.generate_variant(tp, frozen["variant"], "float64", plan["integrator"]) == frozen["source"], "re-run tests/golden/make_cube_sat_program.py"
+    g = U.gold()
+    body, cols = plan["body"], plan["columns"]
+    n = len(plan["row_ids"])
+    pos, vel, acc, inertia = (np.array(body[k], dtype=np.float64).copy() for k in ("world_pos", "world_vel", "world_accel", "inertia"))
+    comps = {name: (np.array(cols[name], dtype=np.float64).reshape(n, -1).copy() if name in cols else np.zeros((n, w)))
+             for name, w in tp.columns}                                          # fold scratch rows start at zero
+    worst = {}
+    for tick in range(1, 101):
+        U.put_translation(g, tick, pos, vel, row_of["ore_sat"])
+        force = dsl_numpy.program_tick(tp, pos, vel, acc, inertia, comps, tick, plan["dt"], plan["integrator"], dt=plan["time_step"])
+        U.errors(g, tick, row_of, dict(world_pos=pos, world_vel=vel, world_accel=acc, force=force, inertia=inertia), comps.get, worst)
+    print("examples/cube-sat/main.py unmodified vs its CI baseline (attitude loop closed), worst per column:",
+          {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:12]}, f"... {len(worst)} columns")
+    U.verdict(worst)
 
 
 def test_shim_keeps_data_and_traced_code_apart(compat):
