@@ -1151,6 +1151,10 @@ def _compile(src: str, stem: str) -> Path:
     meta = JIT_DIR / f"{stem}_{digest}.json"
     global last_resources
     if so.exists():
+        try:
+            os.utime(so)          # last use: lets a cache be pruned by age
+        except OSError:
+            pass
         last_resources = json.loads(meta.read_text()) if meta.exists() else {}
         if last_resources.get("vgpr_spills", 0) > 0:    # only an opted-in build can be here: say so on every use
             if not allow_spills:

@@ -91,9 +91,6 @@ class HipExec:
         d.ticks_per_launch = ticks_per_launch
         d.flags = L.FLAG_USE_GRAPH if use_graph else 0
         self._h = C.c_void_p()
-        rc = lib.sixdof_create(C.byref(d), C.byref(self._h))
-        if rc != L.OK:
-            _raise(None, rc, "sixdof_create")
         try:
             cols = [("world_pos", self.world_pos), ("world_vel", self.world_vel), ("world_accel", self.world_accel),
                     ("force", self.force), ("inertia", self.inertia)]
@@ -180,6 +177,11 @@ class HipExec:
                     self._aux[name] = arr
                     cols.append((name, arr))
                     ops[k].aux_component_id = L.component_id(name)
+            # user code is traced and compiled above, before the device is touched: a program that cannot be built fails
+            # without a context, and a machine without a GPU can fill the JIT cache (elodin_amd/_jit) for one that has it
+            rc = lib.sixdof_create(C.byref(d), C.byref(self._h))
+            if rc != L.OK:
+                _raise(None, rc, "sixdof_create")
             self._bind(cols)
             rc = lib.sixdof_set_effectors(self._h, ops, len(effectors))
             if rc != L.OK:
