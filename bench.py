@@ -336,8 +336,15 @@ def campaign_bench(which, rank, world, local_rank, comm_device, barrier, capi_co
         run = lambda: model.run_campaign(table, per_gpu * world, ticks, device=local_rank, comm_device=comm_device, comm=capi_comm)
         ok = lambda res: float((res[:, 3] > 0.0).mean())   # reached MECO
         desc = f"Falcon 9 ascent Monte-Carlo, {per_gpu} rollouts per GPU x {ticks} ticks, semi-implicit f32 (BASELINE configs[4])"
-    if which == "falcon9":      # executor construction compiles / loads the generated program: keep it out of the timing
-        model.AscentExec(model.default_param_row()[None, :], dtype=np.float32, device=local_rank, fast_math=True).close()
+    warmup = 0
+    if which == "falcon9":
+        # one untimed launch of the executor the campaign will build (same row count -> same generated object and device
+        # layout): hipcc / the cached object, the code-object load and, on a freshly booted box, ~6 s of paging the toolchain
+        # and libraries in happen here once per process — a second process measured 0.15 s for the same construction
+        w = model.AscentExec(np.tile(model.default_param_row(), (per_gpu, 1)), dtype=np.float32, device=local_rank, fast_math=True)
+        w.hip.invoke_batch(1000)
+        w.close()
+        warmup = 1
     barrier()
     t0 = time.perf_counter()
     res = run()
@@ -347,11 +354,12 @@ def campaign_bench(which, rank, world, local_rank, comm_device, barrier, capi_co
         elapsed = shard.max_over_ranks(elapsed, device=comm_device)
     n_runs = per_gpu * world
     return {"metric": "rollout-steps/s (whole campaign)", "value": round(n_runs * ticks / elapsed, 1), "unit": "rollout-steps/s",
-            "n_gpus": world, "steps": ticks, "warmup": 0, "ms_per_step": round(elapsed / ticks * 1e3, 6),
+            "n_gpus": world, "steps": ticks, "warmup": warmup, "ms_per_step": round(elapsed / ticks * 1e3, 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic (sampled plan)",
             "config": {"workload": desc, "rollouts": n_runs, "parallelism": f"run-id shards x{world}; broadcast plan + gather results",
                        "collectives": "C ABI (sixdof_campaign_broadcast / _gather over RCCL)" if capi_comm is not None else "torch.distributed"},
-            "campaign_seconds": round(elapsed, 4), "success_fraction": round(ok(res), 4) if rank == 0 else None}
+            "campaign_seconds": round(elapsed, 4), "success_fraction": round(ok(res), 4) if rank == 0 else None,
+            "phases": {k: round(v, 4) for k, v in getattr(model, "last_campaign_phases", {}).items()}}
 
 
 def cpu_quota():

@@ -1097,6 +1097,9 @@ def prebuild() -> list:
     return out
 
 
+last_campaign_phases: Dict[str, float] = {}      # wall seconds of the last run_campaign on this rank, by phase
+
+
 def run_campaign(plan_table: Optional[np.ndarray], n_runs: int, n_ticks: int = ASCENT_TICKS, *, dtype=np.float32,
                  ticks_per_launch: int = 1000, device: int = 0, comm_device="cpu", make_exec=None,
                  fast_math: Optional[bool] = None, comm=None) -> np.ndarray:
@@ -1112,6 +1115,9 @@ def run_campaign(plan_table: Optional[np.ndarray], n_runs: int, n_ticks: int = A
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         rank = dist.get_rank() if world > 1 else 0
         table = shard.broadcast_table(plan_table, (n_runs, len(PARAM_NAMES)), device=comm_device)
+    import time
+    t = [time.perf_counter()]
+    mark = lambda: t.append(time.perf_counter())
     lo, hi = shard.shard_range(n_runs, world, rank)
     if make_exec is None:
         fast = (np.dtype(dtype) == np.float32) if fast_math is None else bool(fast_math)   # hardware transcendentals in f32:
@@ -1119,8 +1125,13 @@ def run_campaign(plan_table: Optional[np.ndarray], n_runs: int, n_ticks: int = A
         make_exec = lambda block, first_row: AscentExec(block, dtype=dtype, ticks_per_launch=ticks_per_launch, device=device,
                                                          fast_math=fast)
     ex = make_exec(table[lo:hi], lo)
+    mark()
     ex.run(n_ticks)
+    mark()
     local = np.ascontiguousarray(ex.result)
     if hasattr(ex, "close"):
         ex.close()
-    return comm.gather_rows(local, n_runs) if comm is not None else shard.gather_rows(local, n_runs, device=comm_device)
+    out = comm.gather_rows(local, n_runs) if comm is not None else shard.gather_rows(local, n_runs, device=comm_device)
+    mark()
+    last_campaign_phases.update(build_and_upload_s=t[1] - t[0], flight_and_download_s=t[2] - t[1], gather_s=t[3] - t[2])
+    return out
