@@ -447,6 +447,32 @@ def test_fast_math_functions_over_their_domains():
     assert excess.max() <= 0.0, (np.unravel_index(np.argmax(excess), excess.shape), excess.max())
 
 
+def test_fast_math_normal_samples_are_the_reference_draws_to_single_precision():
+    """fast_math programs run erfinv in single precision (codegen._FAST_ERFINV: Giles' polynomial on a double-formed 1 - u^2):
+    12,288 normal samples of a float32 fast-math program against the same draws in double (numpy walk of the trace: threefry
+    bits -> uniform -> scipy erfinv), same bound as the other replaced functions; the plain float32 program draws the
+    double samples, rounded."""
+    @dsl.system
+    def draw(s, z):
+        key = dsl.random.fold_in(dsl.random.key(20170814), s)
+        return {"z": dsl.random.normal(key, shape=(3,)) * 2.0}
+    n = 4096
+    seeds = np.arange(n, dtype=np.float64)[:, None] * 7.0 + 3.0
+    w = workloads.independent_bodies(n)
+    tp = dsl.Program([draw], dsl.Pipe([]), []).trace({"s": 1, "z": 3})
+    comps = {"s": seeds.copy(), "z": np.zeros((n, 3))}
+    dsl_numpy.program_tick_systems_only(tp, w["world_pos"].copy(), w["world_vel"].copy(), np.zeros((n, 6)), w["inertia"].copy(), comps, 1)
+    want = comps["z"]
+    assert 3.5 < np.abs(want).max() / 2.0 < 5.4 and abs(want.std() / 2.0 - 1.0) < 0.02
+    for fast, bound in ((True, lambda v: 2e-6 + 4e-6 * np.abs(v)), (False, lambda v: 1e-7 + 1.2e-7 * np.abs(v))):
+        hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=np.float32, integrator=L.INTEGRATOR_NONE,
+                         effectors=dsl.Program([draw], dsl.Pipe([]), []), columns={"s": seeds, "z": np.zeros((n, 3))}, fast_math=fast)
+        hip.run(1)
+        got = np.asarray(hip._aux["z"], dtype=np.float64)
+        excess = np.abs(got - want) - bound(want)
+        assert excess.max() <= 0.0, (fast, np.unravel_index(np.argmax(excess), excess.shape), excess.max())
+
+
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-13), (np.float32, 3e-6)])
 def test_interp_over_a_long_evenly_spaced_table_is_exactly_searchsorted(dtype, tol):
     """Long evenly spaced tables are indexed by division (then corrected against the stored breakpoints) instead of
