@@ -285,6 +285,7 @@ class World:
         self._lib = L.lib()
         self._w = C.c_void_p(self._lib.sixdof_world_create())
         self._names: Dict[int, str] = {0: "Globals"}
+        self.entity_ids_by_name: Dict[str, int] = {}      # spawn(..., id="ore_sat"): the entity's database name -> its id
         self._edges: Dict[str, List[tuple]] = {}
         self._components: List[str] = []
 
@@ -307,7 +308,7 @@ class World:
         if name is not None:
             self._names[int(eid)] = name
         if id is not None:
-            self.__dict__.setdefault("entity_ids_by_name", {})[id] = int(eid)
+            self.entity_ids_by_name[id] = int(eid)
         return eid
 
     def insert(self, eid: EntityId, archetypes) -> None:
@@ -637,7 +638,7 @@ class World:
                 edges = (edges[0][keep], edges[1][keep])
         if _dry:       # generated_sources(): everything resolved, nothing bound
             return dict(effectors=effs, columns=extra_columns, edges=edges, dt=dt, time_step=system.time_step, row_ids=np.asarray(ids).copy(),
-                        names=dict(getattr(self, "entity_ids_by_name", {})),
+                        names=dict(self.entity_ids_by_name),
                         substeps=substeps if program_stages is not None else 1, body=dict(world_pos=pos, **{k: v[0] for k, v in body.items()}),
                         integrator=L.INTEGRATOR_NONE if getattr(system, "no_six_dof", False) else system.integrator.value)
         hip = HipExec(pos, body["world_vel"][0], body["inertia"][0], world_accel=body["world_accel"][0],
