@@ -474,6 +474,13 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Dry run of the N > 1 code path on a box with ONE GPU (SIXDOF_BENCH_SHARED_GPU=1 under torch.distributed.run): every
+    # rank uses device 0 and the process group is gloo (RCCL refuses two ranks on one device).  The timed window is the same
+    # code as on N GPUs — barrier, device synchronize, t0, K steps, stream synchronize, t1, ... MAX over ranks; the value
+    # means nothing as a scaling point (the ranks time-share one GPU) and the line says so.
+    shared_gpu = os.environ.get("SIXDOF_BENCH_SHARED_GPU", "") == "1"
+    if shared_gpu:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = "WORLD_SIZE" in os.environ and "RANK" in os.environ   # launched by torch.distributed.run
 
@@ -484,27 +491,31 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    rank_device = "cpu" if shared_gpu else torch.device("cuda", local_rank)      # where the ranks' scalars are reduced
 
     def barrier():
         if distributed:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier() if shared_gpu else dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     if args.campaign:
-        comm = torch.device("cuda", local_rank) if distributed else "cpu"
+        comm = rank_device if distributed else "cpu"
         capi = None
         if args.capi_comm:
             from elodin_amd import shard
             box = [shard.CapiComm.unique_id() if (rank == 0 and world > 1) else None]
             if distributed:
-                dist.broadcast_object_list(box, src=0, device=torch.device("cuda", local_rank))
+                dist.broadcast_object_list(box, src=0, device=rank_device)
             capi = shard.CapiComm(box[0], world, rank, local_rank)
         line = campaign_bench(args.campaign, rank, world, local_rank, comm, barrier, capi)
         if capi is not None:
             capi.close()
         if distributed:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier() if shared_gpu else dist.barrier(device_ids=[local_rank])
             dist.destroy_process_group()
         if rank == 0:
             print(json.dumps(line), flush=True)
@@ -540,8 +551,8 @@ def main():
     elapsed, elapsed_incl = t1 - t0, t2 - t0
     if distributed:
         from elodin_amd import shard
-        elapsed = shard.max_over_ranks(elapsed, device=torch.device("cuda", local_rank))        # MAX over ranks
-        elapsed_incl = shard.max_over_ranks(elapsed_incl, device=torch.device("cuda", local_rank))
+        elapsed = shard.max_over_ranks(elapsed, device=rank_device)        # MAX over ranks
+        elapsed_incl = shard.max_over_ranks(elapsed_incl, device=rank_device)
 
     value = n * world * args.steps / elapsed
     out = {
@@ -554,7 +565,7 @@ def main():
                    "entities_per_gpu": n, "ticks_per_launch": K, "dt": 0.008333333,
                    "graph_replay": bool(tm.launches and tm.graph_launches == tm.launches),
                    "graph_launches": tm.graph_launches, "launches": tm.launches,
-                   "parallelism": f"entity shards x{world}, no collective",
+                   "parallelism": f"entity shards x{world}, no collective" + (" — DRY RUN: all ranks share GPU 0 (gloo group), not a scaling point" if shared_gpu else ""),
                    "sync": "every N: barrier, device synchronize, t0, K steps, hipStreamSynchronize of the launch stream (inside "
                            "sixdof_step), t1, device synchronize, barrier, t2; value = MAX over ranks of t1 - t0",
                    "excluded": "the final D2H download of the columns (amortised over the config's 10,000 ticks; 13 MB = "
@@ -650,7 +661,7 @@ def main():
         if world == 1:
             extra("cpu_baseline", cpu_baseline, w, eff)
     if distributed:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier() if shared_gpu else dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
