@@ -20,6 +20,8 @@ What is restated here, with citations, because it is not Python:
 Output: tests/golden/apollo_reference_runs.json — per rollout the plan row, the result record, the post_step tick it was
 emitted on, and the lander's components at batch ends every 3,000 ticks.
 """
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
 import csv
 import importlib
 import json

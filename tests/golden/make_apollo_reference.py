@@ -3,6 +3,8 @@
 reference example shares between its sim and its guidance controller, produced by the reference's OWN code
 (examples/apollo-lander/reference.py build_reference(), stdlib-only) from its vendored telemetry CSVs.
 Values are written with repr() so they round-trip exactly.  Build container only."""
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
 import importlib.util
 import sys
 from pathlib import Path

@@ -5,6 +5,8 @@ scripts/ci/baseline/cube-sat-csv/*.csv: ticks 0..100 of all 11 entities, verbati
 tests/golden/cube_sat.csv (make_golden.py) holds the satellite's Body columns of the same run for the integrator pin; this
 file is the whole world, for the closed attitude loop (tests/test_compat_reference_scripts.py).
 Run in the build container:  python tests/golden/make_cube_sat_golden.py"""
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
 import csv
 import json
 from pathlib import Path

@@ -5,6 +5,8 @@ place of its EGM08 evaluation (tests/cube_sat_util.py says why and what that lea
 it — 11 rows (satellite, Earth, three wheels, six sun sensors), four edge folds as links of one launch chain — and written to
 tests/golden/cube_sat_program.json: the generated HIP source (this repo's compiler output), its column table, the spawned
 columns and the entity -> row map.   python tests/golden/make_cube_sat_program.py"""
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
 import json
 import sys
 from pathlib import Path

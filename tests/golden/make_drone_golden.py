@@ -2,6 +2,8 @@
 """Golden rows of the reference's drone example (examples/drone) from its CI baseline scripts/ci/baseline/drone-csv/*.csv:
 the 35 recorded rows (ticks 0, 3, 6, ..., 99, 100 — the example commits telemetry every third tick) of every component of the
 `drone` entity, verbatim (f64 repr kept).  Run in the build container:  python tests/golden/make_drone_golden.py"""
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
 import csv
 import json
 from pathlib import Path

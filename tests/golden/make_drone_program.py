@@ -8,6 +8,8 @@ and what the GPU test needs is written to tests/golden/drone_program.json: the H
 program (this repo's compiler output, not reference code), its column table and the spawned initial columns.
 tests/test_gpu_drone.py compiles that source on the GPU box, runs 100 ticks and compares with the reference's CI baseline
 (tests/golden/drone.json <- scripts/ci/baseline/drone-csv).   python tests/golden/make_drone_program.py"""
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
 import importlib.util
 import json
 import sys

@@ -29,6 +29,8 @@ own plan (spec.toml, LHS, seed 20170814) as the reference's sampler (`elodin.mon
 after cutoff).  Output: tests/golden/falcon9_closed_loop.json — per row the parameter context, the tick of every phase
 transition, liftoff / MECO observables, and the full component state + the flight software's navigator at checkpoints.
 """
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
 import importlib
 import json
 import math

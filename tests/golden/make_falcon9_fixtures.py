@@ -19,6 +19,8 @@ delegated to the pinned C oracle) the reference's modules import and run UNMODIF
 What this does NOT cover: the flight software (a Rust process, controller/src/main.rs — not executable here; the model's
 restatement of its ascent phases stays unpinned), sensors, leg contact beyond "inactive during ascent".
 """
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
 import json
 import math
 import sys

@@ -3,6 +3,8 @@
 it at start-up (controller/src/profile.rs), computed by the PRODUCT's restatement (models/falcon9.resample_profile) from the
 reference's data file examples/falcon9/data/crs12/stage1_raw.json (the file ELODIN_F9_PROFILE names, main.py:193-199).
 Build container only.  tests/test_falcon9_fsw_oracle.py checks the table against the C oracle's own resampling."""
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
 import json
 import sys
 from pathlib import Path

@@ -11,6 +11,8 @@ verbatim so no precision is lost.
 Run in the build container only (the GPU box has no /root/reference):
     python tests/golden/make_golden.py [/root/reference]
 """
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
 import csv
 import sys
 from pathlib import Path

@@ -2,6 +2,8 @@
 """Golden rows of the reference's linalg example (examples/linalg/sim.py) from its CI baseline
 scripts/ci/baseline/linalg/*.csv: ticks 0..100 of every component of its six entities (verbatim re-pack, f64 repr kept).
 Run in the build container:  python tests/golden/make_linalg_golden.py"""
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
 import csv
 import json
 from pathlib import Path

@@ -2,6 +2,8 @@
 """Generate golden Monte-Carlo plans by running the REFERENCE's own sampler
 (libs/nox-py/python/elodin/monte_carlo/sample.py is stdlib-only Python, importable here) on a
 few specs.  Outputs tests/golden/plans/<name>.toml + <name>.plan.csv.  Build container only."""
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
 import importlib.util
 import shutil
 import sys

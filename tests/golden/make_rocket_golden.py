@@ -4,6 +4,8 @@ six_dof(RK4) with three effectors, a PID loop through a 480 x 3 sample window) f
 scripts/ci/baseline/rocket-csv/*.csv: ticks 0..100 of every component column.  The window column is kept as its final
 row set only (every row of it is a v_rel_accel sample that the v_rel_accel column already holds tick by tick).
 Run in the build container:  python tests/golden/make_rocket_golden.py"""
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
 import csv
 import json
 from pathlib import Path

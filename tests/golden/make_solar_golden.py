@@ -4,6 +4,8 @@ examples/n-body/planets_truth.csv (JPL-derived daily ephemeris, AU and AU/day) a
 over the first 840 days (the reference's accuracy report runs 20,000 one-hour ticks = 833 days).  Masses are the
 example's BODY_META (examples/n-body/sim.py:57-67).  Run in the build container (needs /root/reference):
     python tests/golden/make_solar_golden.py"""
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
 import csv
 import json
 from pathlib import Path

@@ -2,6 +2,8 @@
 """Golden rows of the reference's StableHLO coverage example (examples/stablehlo/sim.py) from its CI baseline
 scripts/ci/baseline/stablehlo/*.csv: ticks 0..100 of the seven float-valued component columns (the int64 bitwise column is
 outside this tracer's scope).  Run in the build container:  python tests/golden/make_stablehlo_golden.py"""
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
 import csv
 import json
 from pathlib import Path

@@ -23,6 +23,9 @@ the GPU box as anything but a dormant file (the generators need /root/reference)
 """
 from __future__ import annotations
 
+import sys as _sys
+_sys.dont_write_bytecode = True      # the reference checkout is read-only: no __pycache__ next to what is imported from it
+
 import sys
 import types
 
