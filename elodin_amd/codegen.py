@@ -33,7 +33,8 @@ _FN1 = {"sqrt": "m_sqrt", "abs": "m_abs", "sin": "m_sin", "cos": "m_cos", "tan":
         "log": "m_log", "acos": "m_acos", "asin": "m_asin", "log1p": "m_log1p", "expm1": "m_expm1", "cbrt": "m_cbrt",
         "floor": "m_floor", "ceil": "m_ceil", "trunc": "m_trunc", "rint": "m_rint", "sinh": "m_sinh", "cosh": "m_cosh",
         "erfc": "m_erfc", "isfinite": "m_isfinite", "erfinv": "m_erfinv"}
-_FN2 = {"max": "m_max", "min": "m_min", "atan2": "m_atan2", "hypot": "m_hypot", "pow": "m_pow", "mod": "m_mod"}
+_FN2 = {"max": "m_max", "min": "m_min", "atan2": "m_atan2", "hypot": "m_hypot", "pow": "m_pow", "mod": "m_mod",
+        "bxor": "m_bxor", "bor": "m_bor", "band": "m_band", "shl": "m_shl", "shr": "m_shr"}
 _BOOL_OPS = {"lt", "le", "eq", "and", "or", "not", "isfinite"}
 
 
@@ -756,6 +757,17 @@ __global__ __launch_bounds__(64) void fold{j}_commit(const StepParams P) {{
 '''
 
 
+# Integer components (el.PrimitiveType.I64: flags, counters, examples/stablehlo/sim.py:243-251) live in the executor's float
+# columns, exact up to 2^53 (2^24 in a float32 program); bitwise operators act on the integer the value holds.
+_BITWISE = '''
+template <class T> __device__ __forceinline__ T m_bxor(T a, T b) { return T(static_cast<long long>(a) ^ static_cast<long long>(b)); }
+template <class T> __device__ __forceinline__ T m_bor(T a, T b) { return T(static_cast<long long>(a) | static_cast<long long>(b)); }
+template <class T> __device__ __forceinline__ T m_band(T a, T b) { return T(static_cast<long long>(a) & static_cast<long long>(b)); }
+template <class T> __device__ __forceinline__ T m_shl(T a, T b) { return T(static_cast<long long>(a) << static_cast<int>(b)); }
+template <class T> __device__ __forceinline__ T m_shr(T a, T b) {      // logical: zero fill
+    return T(static_cast<long long>(static_cast<unsigned long long>(static_cast<long long>(a)) >> static_cast<int>(b))); }
+'''
+
 # fast_math programs draw their normal samples through the single-precision inverse error function of M. Giles, "Approximating
 # the erfinv function" (GPU Computing Gems, 2010): 3e-7 relative against the double routine over (-1, 1), ~15 f32 instructions
 # with the hardware log / sqrt where the library's double erfinv is several hundred f64 ones (the Falcon 9 program draws ten
@@ -879,6 +891,8 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
                   "        if (t) q.accel_in_check = 0;\n"
                   + "\n".join(calls) + "\n    }\n")
     tables = _emit_tables()
+    if any(f"m_{k}(" in structs for k in ("bxor", "bor", "band", "shl", "shr")):      # only programs that use them carry this text
+        structs = _BITWISE + structs
     fast_erfinv = ""
     if fast_math and "m_erfinv(" in structs:      # only programs that draw normal samples carry (and are keyed on) this text
         structs = structs.replace("m_erfinv(", "m_erfinv_fast(")

@@ -86,9 +86,30 @@ class _Dispatch(types.ModuleType):
                 if t is None:
                     raise AttributeError(f"{self.__name__}.{name}")
                 return t(*args, **kw)
+            if _symbolic(args) or _symbolic(kw):      # numpy would wrap traced values into an object array
+                raise NotImplementedError(f"{self.__name__}.{name} on traced values is not provided by elodin_amd.compat")
             return h(*args, **kw)
         call.__name__ = name
         return call
+
+
+class _ScalarType:
+    """jnp.float64 / jnp.int32 ...: a dtype (`dtype=jnp.int64`, `x.astype(jnp.int32)`) and a constructor (`jnp.int32(x)`), on
+    data and on traced values (integer types truncate toward zero; values stay in the executor's float type)."""
+
+    def __init__(self, np_type):
+        self.np_type, self.dtype, self.__name__ = np_type, _np.dtype(np_type), np_type.__name__
+
+    def __call__(self, x):
+        if _symbolic(x):
+            x = _to_trace(x)
+            return _dsl.np.int32(x) if self.dtype.kind in "iu" else x
+        return self.np_type(x)
+
+    def __eq__(self, other):
+        return other is self or other == self.np_type or other == self.dtype
+    def __hash__(self): return hash(self.dtype)
+    def __repr__(self): return f"jnp.{self.__name__}"
 
 
 def _host_array(x, dtype=None):
@@ -128,9 +149,20 @@ class _TracedScipyLinalg:
     @staticmethod
     def solve(a, b, **kw): return _mat.solve(a, b)
     @staticmethod
+    def solve_triangular(a, b, trans=0, lower=False, unit_diagonal=False, **kw):
+        return _mat.solve_triangular(a, b, lower=lower, trans=trans, unit_diagonal=unit_diagonal)
+    @staticmethod
     def inv(a): return _mat.inv(a)
     @staticmethod
     def det(a): return _mat.det(a)
+
+
+class _TracedScipySpecial:
+    """jax.scipy.special calls met in the reference's examples (examples/stablehlo/sim.py:158)."""
+    erfc = staticmethod(_dsl.np.erfc)
+
+    @staticmethod
+    def erf(x): return 1.0 - _dsl.np.erfc(x)
 
 
 def _make_jax():
@@ -140,13 +172,17 @@ def _make_jax():
     jnp = _Dispatch("jax.numpy", _dsl.np, host)
     la = _Dispatch("jax.numpy.linalg", _dsl.np.linalg, _np.linalg)
     jnp.__dict__["linalg"] = la
-    for tname in ("float64", "float32", "int64", "int32", "uint64", "bool_", "ndarray"):
-        jnp.__dict__[tname] = getattr(_np, tname)
+    for tname in ("float64", "float32", "int64", "int32", "uint64", "uint32", "bool_"):
+        jnp.__dict__[tname] = _ScalarType(getattr(_np, tname))
+    jnp.__dict__["ndarray"] = _np.ndarray
     lax = _Dispatch("jax.lax", _dsl.lax, None)
     rnd = _Dispatch("jax.random", _dsl.random, None, {"PRNGKey": _dsl.random.key})
     jsl = _Dispatch("jax.scipy.linalg", _TracedScipyLinalg, _sla)
+    import scipy.special as _ssp
+    jsp = _Dispatch("jax.scipy.special", _TracedScipySpecial, _ssp)
     jscipy = types.ModuleType("jax.scipy")
-    jscipy.linalg = jsl
+    jscipy.__path__ = []
+    jscipy.linalg, jscipy.special = jsl, jsp
     jax.numpy, jax.lax, jax.random, jax.scipy = jnp, lax, rnd, jscipy
     jax.__path__ = []                                   # a package: `from jax.typing import ArrayLike`
     jax.Array = _np.ndarray
@@ -163,7 +199,7 @@ def _make_jax():
     jax.jit = lambda f=None, **k: (f if f is not None else (lambda g: g))      # a no-op: everything traced is compiled anyway
     jax.grad, jax.vmap, jax.pmap = _unsupported("grad"), _unsupported("vmap"), _unsupported("pmap")
     return {"jax": jax, "jax.numpy": jnp, "jax.numpy.linalg": la, "jax.lax": lax, "jax.random": rnd, "jax.scipy": jscipy,
-            "jax.scipy.linalg": jsl, "jax.typing": jtyping}
+            "jax.scipy.linalg": jsl, "jax.scipy.special": jsp, "jax.typing": jtyping}
 
 
 class _Inert:

@@ -416,6 +416,22 @@ class _Np:
             return dsl_mat.Mat(x)
         return Vec(x)
     @staticmethod
+    def broadcast_to(x, shape):
+        """jnp.broadcast_to of a scalar / vector to (n,) or (rows, n)."""
+        from . import dsl_mat
+        shape = tuple(int(k) for k in (shape if hasattr(shape, "__len__") else (shape,)))
+        x = _host(x)
+        row = x if isinstance(x, Vec) else Vec([x] * shape[-1])
+        if len(row) != shape[-1]:
+            if len(row) != 1:
+                raise ValueError(f"cannot broadcast a vector of {len(row)} to {shape}")
+            row = Vec([row.e[0]] * shape[-1])
+        if len(shape) == 1:
+            return row
+        if len(shape) == 2:
+            return dsl_mat.Mat([Vec(list(row.e)) for _ in range(shape[0])])
+        raise NotImplementedError("broadcast_to beyond two dimensions")
+    @staticmethod
     def zeros(n, dtype=None, shape=None):
         from . import dsl_mat
         n = shape if shape is not None else n
@@ -515,8 +531,8 @@ class _Np:
             bm = b if isinstance(b, list) else [Vec([b] * len(m[0]))] * len(m)
             cm = c if isinstance(c, list) else [c] * len(m)
             return dsl_mat.Mat([_Np.where(ck, x, y) for ck, x, y in zip(cm, am, bm)])
-        if isinstance(a, Vec) or isinstance(b, Vec):
-            n = len(a) if isinstance(a, Vec) else len(b)
+        if isinstance(a, Vec) or isinstance(b, Vec) or isinstance(c, Vec):      # scalars broadcast against the vector among them
+            n = len(next(v for v in (a, b, c) if isinstance(v, Vec)))
             av = a if isinstance(a, Vec) else Vec([a] * n)
             bv = b if isinstance(b, Vec) else Vec([b] * n)
             cv = c.e if isinstance(c, Vec) else [c] * n
@@ -530,10 +546,21 @@ class _Np:
     def logical_or(a, b): return _zipv(a, b, lambda x, y: Expr("or", (_lift(x), _lift(y))))
     @staticmethod
     def logical_not(a): return Vec([Expr("not", (x,)) for x in a.e]) if isinstance(a, Vec) else Expr("not", (_lift(a),))
+    # integer components (I64 flags / counters) are integral values in the executor's float columns: bitwise ops act on them
     @staticmethod
-    def arctan2(y, x): return Expr("atan2", (_lift(y), _lift(x)))
+    def bitwise_xor(a, b): return _zipv(a, b, lambda x, y: Expr("bxor", (_lift(x), _lift(y))))
     @staticmethod
-    def hypot(x, y): return Expr("hypot", (_lift(x), _lift(y)))
+    def bitwise_or(a, b): return _zipv(a, b, lambda x, y: Expr("bor", (_lift(x), _lift(y))))
+    @staticmethod
+    def bitwise_and(a, b): return _zipv(a, b, lambda x, y: Expr("band", (_lift(x), _lift(y))))
+    @staticmethod
+    def left_shift(a, b): return _zipv(a, b, lambda x, y: Expr("shl", (_lift(x), _lift(y))))
+    @staticmethod
+    def right_shift(a, b): return _zipv(a, b, lambda x, y: Expr("shr", (_lift(x), _lift(y))))      # non-negative operands
+    @staticmethod
+    def arctan2(y, x): return _zipv(y, x, lambda a, b: Expr("atan2", (_lift(a), _lift(b))))
+    @staticmethod
+    def hypot(x, y): return _zipv(x, y, lambda a, b: Expr("hypot", (_lift(a), _lift(b))))
     @staticmethod
     def arctan(x): return _zipv(x, 1.0, lambda a, b: Expr("atan2", (_lift(a), _lift(b))))   # atan2(x, 1) == atan(x)
     @staticmethod
@@ -895,6 +922,10 @@ class _Lax:
     def min(a, b): return _Np.minimum(a, b)
     @staticmethod
     def rsqrt(x): return 1.0 / _Np.sqrt(x)
+    @staticmethod
+    def shift_right_logical(a, b): return _Np.right_shift(a, b)
+    @staticmethod
+    def shift_left(a, b): return _Np.left_shift(a, b)
 
 
 def _flatten(tree):

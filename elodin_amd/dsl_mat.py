@@ -405,6 +405,30 @@ def solve(a, b):
     return _d.Vec([r[0] for r in x]) if vec else Mat(x)
 
 
+def solve_triangular(a, b, lower: bool = False, trans=0, unit_diagonal: bool = False):
+    """jax.scipy.linalg.solve_triangular(a, b, lower=...): forward / back substitution (dtrsm's order: row by row, the dot over the
+    already solved entries first, then the division); only the named triangle of `a` is read."""
+    a = as_mat(a)
+    if trans not in (0, "N", 1, "T"):
+        raise NotImplementedError("solve_triangular: trans must be 0 / 'N' / 1 / 'T'")
+    if trans in (1, "T"):
+        a, lower = a.T, not lower
+    vec = isinstance(b, _d.Vec)
+    rhs = [[e] for e in b.e] if vec else [list(r.e) for r in as_mat(b)]
+    n = a.shape[0]
+    if len(rhs) != n:
+        raise ValueError("solve_triangular: shapes do not match")
+    m = len(rhs[0])
+    x = [[None] * m for _ in range(n)]
+    for j in range(m):
+        for i in (range(n) if lower else range(n - 1, -1, -1)):
+            acc = _s(rhs[i][j])
+            for k in (range(i) if lower else range(i + 1, n)):
+                acc = acc - a[i].e[k] * x[k][j]
+            x[i][j] = acc if unit_diagonal else acc / a[i].e[i]
+    return _d.Vec([r[0] for r in x]) if vec else Mat(x)
+
+
 def inv(a) -> Mat:
     a = as_mat(a)
     return solve(a, eye(a.shape[0]))

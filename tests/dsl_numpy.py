@@ -33,7 +33,12 @@ _F1 = {"sqrt": np.sqrt, "abs": np.abs, "sin": np.sin, "cos": np.cos, "tan": np.t
        "erfc": _erfc, "isfinite": np.isfinite, "erfinv": _erfinv}
 _F2 = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "max": np.fmax, "min": np.fmin,
        "atan2": np.arctan2, "hypot": np.hypot, "pow": np.power, "mod": np.mod, "lt": np.less, "le": np.less_equal, "eq": np.equal, "and": np.logical_and,
-       "or": np.logical_or}
+       "or": np.logical_or,
+       "bxor": lambda a, b: (a.astype(np.int64) ^ b.astype(np.int64)).astype(np.float64),
+       "bor": lambda a, b: (a.astype(np.int64) | b.astype(np.int64)).astype(np.float64),
+       "band": lambda a, b: (a.astype(np.int64) & b.astype(np.int64)).astype(np.float64),
+       "shl": lambda a, b: (a.astype(np.int64) << b.astype(np.int64)).astype(np.float64),
+       "shr": lambda a, b: (a.astype(np.int64).view(np.uint64) >> b.astype(np.uint64)).astype(np.float64)}
 
 
 def evaluate(tp, xs, vs, inertia, columns):

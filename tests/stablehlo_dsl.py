@@ -1,5 +1,5 @@
-"""The reference's StableHLO coverage example (examples/stablehlo/sim.py:120-345) written against elodin_amd.dsl — the
-float-valued systems, same expressions in the same order; static shape manipulation (broadcast / concat / slice / reshape
+"""The reference's StableHLO coverage example (examples/stablehlo/sim.py:120-345) written against elodin_amd.dsl — same
+expressions in the same order (the int64 bitwise system included: integer components are integral values in float columns); static shape manipulation (broadcast / concat / slice / reshape
 / transpose / flip) is done on the traced vectors directly.  Used by the golden-CSV tests.  TEST INFRASTRUCTURE."""
 from elodin_amd import dsl
 
@@ -8,7 +8,8 @@ lax = dsl.lax
 
 INITIAL = {"math_state": [0.5, 1.0, -0.3, 2.0], "sort_state": [3.0, 1.0, 4.0, 1.5, 2.0, 5.0, 0.5, 2.5],
            "shape_state": [1.0, 2.0, 3.0, 4.0], "control_state": [5.0, 1.0, -0.5, 0.0], "linalg_state": [1.0, 2.0, 3.0, 4.0],
-           "convert_state": [1.5, -2.7, 0.0, 100.0], "linalg2_state": [4.0, 2.0, 2.0, 3.0]}       # sim.py:72-113 defaults
+           "convert_state": [1.5, -2.7, 0.0, 100.0], "linalg2_state": [4.0, 2.0, 2.0, 3.0],
+           "bitwise_state": [float(0xA5), float(0x3C), float(0xFF), float(0x01)]}                    # sim.py:72-113 defaults
 
 
 @dsl.system
@@ -97,4 +98,13 @@ def linalg2_step(linalg2_state):                                  # sim.py:312-3
     return {"linalg2_state": np_.array([l00, l11, x0, x1])}
 
 
-SYSTEMS = [math_step, sort_step, shape_step, control_step, linalg_step, convert_step, linalg2_step]    # sim.py:343-353 order
+@dsl.system
+def bitwise_step(bitwise_state):                                  # sim.py:243-251
+    r = np_.bitwise_xor(bitwise_state, 255.0)
+    r = np_.bitwise_or(r, 15.0)
+    r = np_.bitwise_and(r, 4095.0)
+    r = np_.left_shift(r, 1.0)
+    return {"bitwise_state": lax.shift_right_logical(r, 2.0)}
+
+
+SYSTEMS = [math_step, sort_step, shape_step, control_step, bitwise_step, linalg_step, convert_step, linalg2_step]    # sim.py:343-353 order

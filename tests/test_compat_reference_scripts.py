@@ -8,6 +8,9 @@ read from /root/reference and never copied:
                                examples/three_body.py (GPU: the three-body golden CSV)
   examples/linalg/sim.py       traced and stepped 100 ticks on the CPU walker: every component lands on the rows of the
                                reference's CI baseline scripts/ci/baseline/linalg (1e-9; the reference's own CI accepts 1e-4)
+  examples/stablehlo/main.py   the op-coverage example (eight single-component entities, ~50 ops incl. int64 bitwise ones, sort,
+                               while_loop / switch, static shape ops, Cholesky + triangular solve): 100 ticks against
+                               scripts/ci/baseline/stablehlo, integers exact
   examples/drone/main.py       the closed-loop quadcopter (cascaded attitude / rate PIDs, motor + sensor models, Mahony-style
                                estimator; 300 Hz simulation under a 100 Hz telemetry tick = three semi-implicit sub-steps per
                                tick): traced and stepped 100 ticks on the CPU walker against scripts/ci/baseline/drone-csv
@@ -150,6 +153,39 @@ def test_drone_script_unmodified_lands_on_the_reference_baseline(compat):
     print("examples/drone/main.py unmodified vs its CI baseline, worst per component:",
           {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])})
     drone_verdict(worst)
+
+
+def test_stablehlo_script_unmodified_lands_on_the_reference_baseline(compat):
+    from tests import dsl_numpy, stablehlo_dsl as S
+    sys.path.insert(0, str(REF / "examples" / "stablehlo"))
+    _load(REF / "examples" / "stablehlo" / "main.py", "ref_stablehlo_main")         # `from sim import ...; world().run(...)`: recorded
+    sim = sys.modules["sim"]
+    w = sim.world()
+    plan = w.build(sim.system(), simulation_rate=sim.SIMULATION_RATE, _dry=True)
+    tp = plan["effectors"].trace()
+    names = [n for n, _ in tp.columns if not n.startswith("has:")]
+    assert len(names) == 8 and plan["integrator"] != 1          # no six_dof in this example: systems only
+    gold = json.loads((ROOT / "tests" / "golden" / "stablehlo.json").read_text())["rows"]
+    n = next(iter(plan["columns"].values())).shape[0]
+    comps = {name: np.array(plan["columns"][name], dtype=np.float64).reshape(n, -1).copy() for name, _ in tp.columns}
+    pos, vel, acc, inertia = np.tile([0, 0, 0, 1.0, 0, 0, 0], (n, 1)), np.zeros((n, 6)), np.zeros((n, 6)), np.ones((n, 7))
+    # math_state's baseline predates the example's current math_step (tests/test_dsl_host.py): that column is compared with the
+    # respelled system's walk, which is itself checked against a numpy transcription there
+    from elodin_amd import dsl
+    tm = dsl.ColumnTable("c", 48, 16, {"math_state": 4})
+    t_math = dsl.TracedSystem(S.math_step, tm)
+    math_ref = {"math_state": np.array([S.INITIAL["math_state"]])}
+    dummy = (np.array([[0, 0, 0, 1.0, 0, 0, 0]]), np.zeros((1, 6)), np.ones((1, 7)))
+    worst = {}
+    for tick in range(1, 101):
+        dsl_numpy.program_tick_systems_only(tp, pos, vel, acc, inertia, comps, tick)
+        dsl_numpy._run_systems([t_math], *dummy, math_ref, tm, tick)
+        for name, rows in gold.items():
+            row = int(np.argmax(comps["has:" + name][:, 0]))
+            ref = math_ref["math_state"][0] if name == "math_state" else np.asarray(rows[tick])
+            worst[name] = max(worst.get(name, 0.0), float(np.max(np.abs(comps[name][row] - ref) / np.maximum(np.abs(ref), 1e-12))))
+    print("examples/stablehlo/main.py unmodified vs its CI baseline, worst per component:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert len(worst) == 8 and max(worst.values()) < 1e-12 and worst["bitwise_state"] == 0.0, worst
 
 
 def load_cube_sat(compat):
