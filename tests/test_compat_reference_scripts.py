@@ -8,6 +8,9 @@ read from /root/reference and never copied:
                                examples/three_body.py (GPU: the three-body golden CSV)
   examples/linalg/sim.py       traced and stepped 100 ticks on the CPU walker: every component lands on the rows of the
                                reference's CI baseline scripts/ci/baseline/linalg (1e-9; the reference's own CI accepts 1e-4)
+  examples/n-body/sim.py       BASELINE configs[2]'s example (sun + nine planets from its truth CSV, complete gravity graph, the
+                               user-written softened fold): the spawned world is the one tests/solar_util.py holds, and the
+                               traced fold stepped with RK4 equals the C oracle's built-in softened all-pairs op
   examples/stablehlo/main.py   the op-coverage example (eight single-component entities, ~50 ops incl. int64 bitwise ones, sort,
                                while_loop / switch, static shape ops, Cholesky + triangular solve): 100 ticks against
                                scripts/ci/baseline/stablehlo, integers exact
@@ -153,6 +156,39 @@ def test_drone_script_unmodified_lands_on_the_reference_baseline(compat):
     print("examples/drone/main.py unmodified vs its CI baseline, worst per component:",
           {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])})
     drone_verdict(worst)
+
+
+def test_n_body_script_builds_the_solar_system_and_its_fold_is_the_oracles_pair_op(compat):
+    """sim.py only: main.py deletes and recreates the example's database directory before it runs."""
+    from oracle import oracle as orc
+    from tests import dsl_numpy, np_sixdof, solar_util as su
+    from elodin_amd import _lib as L
+    sim = _load(REF / "examples" / "n-body" / "sim.py", "ref_nbody_sim")
+    w, system = sim.build_world(), sim.build_system()
+    plan = w.build(system, simulation_rate=sim.SIMULATION_RATE_HZ, telemetry_rate=sim.TELEMETRY_RATE_HZ, _dry=True)
+    d, pos, vel, inertia = su.load()
+    body = plan["body"]
+    assert plan["dt"] == su.DT and plan["integrator"] == L.RK4
+    assert np.array_equal(body["world_pos"], pos) and np.array_equal(body["inertia"], inertia)
+    assert np.allclose(body["world_vel"], vel, rtol=1e-15, atol=0.0)             # the example divides by 86,400 s in jnp, the fixture in numpy
+    frm, to = plan["edges"]
+    ids = [int(e) for e in plan["row_ids"]]
+    assert len(frm) == 90 and sorted(zip(frm.tolist(), to.tolist())) == sorted((a, b) for a in ids for b in ids if a != b)
+    (fold,) = plan["effectors"]
+    tf = fold.trace()
+    rows = {e: k for k, e in enumerate(ids)}
+    src, dst = [rows[int(e)] for e in frm], [rows[int(e)] for e in to]
+    eff = lambda xs, vs: dsl_numpy.fold_force(tf, xs, inertia, src, dst)
+    ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=su.DT, ops=[(L.EFF_ALLPAIRS_GRAVITY_SOFTENED, (su.K_SQUARED, su.SOFTENING_AU2), None)])
+    x, v, a = body["world_pos"].copy(), body["world_vel"].copy(), np.zeros((len(ids), 6))
+    for _ in range(240):                                                           # ten days of one-hour RK4 ticks
+        x, v, a, _f = np_sixdof.tick(x, v, a, inertia, eff, su.DT, integrator=L.RK4)
+    ref.step(240)
+    err = max(float(np.max(np.abs(x[:, 4:] - ref.world_pos[:, 4:])) / np.max(np.abs(ref.world_pos[:, 4:]))),
+              float(np.max(np.abs(v[:, 3:] - ref.world_vel[:, 3:])) / np.max(np.abs(ref.world_vel[:, 3:]))))
+    print("examples/n-body/sim.py unmodified: traced fold vs the oracle's softened all-pairs op over 240 ticks:", f"{err:.1e}")
+    assert err < 1e-12
+    assert set(w.generated_sources(system, simulation_rate=sim.SIMULATION_RATE_HZ)) == {"pair"}
 
 
 def test_stablehlo_script_unmodified_lands_on_the_reference_baseline(compat):
