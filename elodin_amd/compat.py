@@ -112,11 +112,23 @@ class _ScalarType:
     def __repr__(self): return f"jnp.{self.__name__}"
 
 
+class _HostArray(_np.ndarray):
+    """What jnp.array / jnp.asarray give on concrete data: a numpy array that can also be indexed by a TRACED value —
+    `T_B[i]` with `T_B` a module-level table and `i` computed inside a decorated function (examples/falcon9/atmosphere.py:64)
+    is a gather from a constant table, which the tracer spells as a select chain."""
+
+    def __getitem__(self, idx):
+        if _symbolic(idx) or (isinstance(idx, tuple) and any(_symbolic(k) for k in idx)):
+            return _dsl._host(_np.asarray(self))[idx]
+        return super().__getitem__(idx)
+
+
 def _host_array(x, dtype=None):
     """jnp.array / jnp.asarray on concrete data under jax_enable_x64 (the reference's setting): Python floats are float64,
     Python ints int64 — numpy's own rules."""
     a = _np.asarray(x)
-    return a.astype(dtype) if dtype is not None else a
+    a = a.astype(dtype) if dtype is not None else a
+    return a.view(_HostArray) if a.ndim else a
 
 
 class _HostNumpy:
@@ -197,7 +209,28 @@ def _make_jax():
                                       "there is no JAX underneath)")
         return f
     jax.jit = lambda f=None, **k: (f if f is not None else (lambda g: g))      # a no-op: everything traced is compiled anyway
-    jax.grad, jax.vmap, jax.pmap = _unsupported("grad"), _unsupported("vmap"), _unsupported("pmap")
+    jax.grad, jax.pmap = _unsupported("grad"), _unsupported("pmap")
+
+    def vmap(f, in_axes=0, out_axes=0):
+        """jax.vmap over the leading axis of small static arrays inside per-entity code (four landing legs, examples/falcon9/sim.py:794):
+        unrolled — f per slice, results stacked.  in_axes: 0 or None per argument."""
+        if out_axes != 0:
+            raise NotImplementedError("jax.vmap(out_axes != 0) is not provided by elodin_amd.compat")
+
+        def mapped(*args):
+            axes = in_axes if isinstance(in_axes, (tuple, list)) else (in_axes,) * len(args)
+            if any(a not in (0, None) for a in axes):
+                raise NotImplementedError("jax.vmap: in_axes must be 0 or None")
+            n = {len(a) for a, ax in zip(args, axes) if ax == 0}
+            if len(n) != 1:
+                raise ValueError("jax.vmap: mapped arguments differ in length")
+            outs = [f(*[(a[i] if ax == 0 else a) for a, ax in zip(args, axes)]) for i in range(n.pop())]
+            stack = lambda items: (jnp.stack(items) if _symbolic(items) else _np.stack([_np.asarray(x) for x in items]))
+            if isinstance(outs[0], tuple):
+                return tuple(stack([o[k] for o in outs]) for k in range(len(outs[0])))
+            return stack(outs)
+        return mapped
+    jax.vmap = vmap
     return {"jax": jax, "jax.numpy": jnp, "jax.numpy.linalg": la, "jax.lax": lax, "jax.random": rnd, "jax.scipy": jscipy,
             "jax.scipy.linalg": jsl, "jax.scipy.special": jsp, "jax.typing": jtyping}
 

@@ -108,6 +108,11 @@ class Expr:
         return _un("trunc", self) if "int" in name else self
     dtype = _numpy.float64
     shape = ()
+    def __getitem__(self, k):
+        """A component of shape (1,) is held as its one value: `mdot[0]` (examples/falcon9/sim.py:445) is that value."""
+        if k in (0, -1, Ellipsis, ()) or k == slice(None):
+            return self
+        raise IndexError("a scalar traced value has one element")
     def all(self, axis=None): return self           # a 0-d comparison: `(x < fov).all()`
     def any(self, axis=None): return self
 
@@ -257,11 +262,9 @@ class Vec:
         return Vec(r) if isinstance(i, slice) else r
     def _zip(self, o, f):
         if _is_host_array(o):
-            if o.ndim == 2:           # vector (op) host matrix: numpy's row broadcast, done by the matrix
-                return NotImplemented
             o = _host(o)
-        if isinstance(o, list) and o and isinstance(o[0], Vec):      # a matrix operand: let it broadcast this row vector
-            return NotImplemented
+        if isinstance(o, list) and o and isinstance(o[0], Vec):      # a matrix operand: numpy's row broadcast, done by the matrix
+            return o._zip(self, lambda m, v: f(v, m))
         if isinstance(o, Vec):
             if len(o) != len(self):
                 raise ValueError("shape mismatch")
@@ -510,7 +513,13 @@ class _Np:
         from . import dsl_mat
         return dsl_mat.matmul(a, b)
     @staticmethod
-    def cross(a: Vec, b: Vec):
+    def cross(a, b):
+        a, b = _host(a), _host(b)
+        am, bm = (isinstance(x, list) and x and isinstance(x[0], Vec) for x in (a, b))
+        if am or bm:                        # [n, 3] x [n, 3] (or x [3]): row by row, like jnp.cross over the last axis
+            from . import dsl_mat
+            n = len(a) if am else len(b)
+            return dsl_mat.Mat([_Np.cross(a[i] if am else a, b[i] if bm else b) for i in range(n)])
         return Vec([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]])
     @staticmethod
     def maximum(a, b): return _zipv(a, b, lambda x, y: Expr("max", (_lift(x), _lift(y))))
@@ -536,6 +545,10 @@ class _Np:
             av = a if isinstance(a, Vec) else Vec([a] * n)
             bv = b if isinstance(b, Vec) else Vec([b] * n)
             cv = c.e if isinstance(c, Vec) else [c] * n
+            if len(cv) == 1 and n > 1:        # a [rows, 1] condition against [rows, n] values, row by row
+                cv = list(cv) * n
+            if not (len(cv) == len(av) == len(bv)):
+                raise ValueError("where: shape mismatch")
             return Vec([Expr("select", (_lift(k), x, y)) for k, x, y in zip(cv, av.e, bv.e)])
         return Expr("select", (_lift(c), _lift(a), _lift(b)))
     @staticmethod
@@ -599,10 +612,11 @@ class _Np:
     @staticmethod
     def stack(parts, axis=0):
         """jnp.stack of scalars -> a vector; of vectors -> a matrix as a list of rows (usable with matvec / outer results)."""
-        parts = list(parts)
+        parts = [_host(p_) for p_ in parts]
         if parts and isinstance(parts[0], Vec):
             from . import dsl_mat
-            return dsl_mat.Mat(parts)
+            m = dsl_mat.Mat(parts)
+            return m.T if axis in (1, -1) else m
         return Vec(parts)
     @staticmethod
     def zeros_like(x): return Vec([0.0] * len(x)) if isinstance(x, Vec) else const(0.0)
@@ -626,7 +640,7 @@ class _Np:
     def searchsorted(a, v, side="left"):
         """jnp.searchsorted over a CONSTANT sorted table: the count of entries below (side='left') / not above (side='right') v."""
         v = _lift(v)
-        table = [float(t) for t in a]
+        table = [float(t.value) if isinstance(t, Expr) and t.op == "const" else float(t) for t in a]
         hits = [(_Np.where(v > t, 1.0, 0.0) if side == "left" else _Np.where(v >= t, 1.0, 0.0)) for t in table]
         return _Np.sum(Vec(hits)) if hits else const(0.0)
     @staticmethod

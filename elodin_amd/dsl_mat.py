@@ -186,6 +186,15 @@ class Mat(list):
     def __rmul__(self, o): return self._zip(o, lambda a, b: b * a)
     def __truediv__(self, o): return self._zip(o, lambda a, b: a / b)
     def __neg__(self): return Mat([[-a for a in r.e] for r in self])
+    def __lt__(self, o): return self._zip(o, lambda a, b: a < b)
+    def __le__(self, o): return self._zip(o, lambda a, b: a <= b)
+    def __gt__(self, o): return self._zip(o, lambda a, b: a > b)
+    def __ge__(self, o): return self._zip(o, lambda a, b: a >= b)
+    def __and__(self, o): return self._zip(o, lambda a, b: a & b)
+    def __or__(self, o): return self._zip(o, lambda a, b: a | b)
+    def __invert__(self): return Mat([[~a for a in r.e] for r in self])
+    def __rtruediv__(self, o): return self._zip(o, lambda a, b: b / a)
+    def __pow__(self, k): return Mat([[a ** k for a in r.e] for r in self])
     def __iadd__(self, o): return self.__add__(o)          # list.__iadd__ would extend the row list
     def __imul__(self, o): return self.__mul__(o)
 

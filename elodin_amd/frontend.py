@@ -698,7 +698,16 @@ def six_dof(time_step: Optional[float] = None, sys=None, integrator: Integrator 
     return out
 
 
-System = (_dsl.System, _dsl.Stages, _dsl.Effector, _dsl.Pipe, _dsl.EdgeFold, _dsl.GraphFold, _api.System)   # `-> el.System` annotations / isinstance
+_SYSTEM_KINDS = (_dsl.System, _dsl.Stages, _dsl.Effector, _dsl.Pipe, _dsl.EdgeFold, _dsl.GraphFold, _api.System, _Deferred)
+
+
+class _SystemMeta(type):
+    def __instancecheck__(cls, x): return isinstance(x, _SYSTEM_KINDS)
+
+
+class System(metaclass=_SystemMeta):
+    """el.System: the type of everything the decorators and `|` produce — for `-> el.System` / `el.System | None` annotations
+    (examples/falcon9/sim.py:1476) and isinstance checks."""
 
 
 # ---- world --------------------------------------------------------------------------------------------------------------

@@ -11,6 +11,11 @@ read from /root/reference and never copied:
   examples/n-body/sim.py       BASELINE configs[2]'s example (sun + nine planets from its truth CSV, complete gravity graph, the
                                user-written softened fold): the spawned world is the one tests/solar_util.py holds, and the
                                traced fold stepped with RK4 equals the C oracle's built-in softened all-pairs op
+  examples/falcon9/sim.py      BASELINE configs[4]'s example: the whole powered plant of `build_powered` (engines with their ignition
+                               state machine, valves, TVC, grid fins, RCS allocation, tanks, US-76 atmosphere, aero tables, WGS84
+                               frames, pad clamp, leg contact, sensors; 23 systems, 62 components) driven the way the reference's
+                               own tests drive it, against the trajectories the reference's own functions flew
+                               (tests/golden/falcon9_plant.json): 43 columns, three windows
   examples/stablehlo/main.py   the op-coverage example (eight single-component entities, ~50 ops incl. int64 bitwise ones, sort,
                                while_loop / switch, static shape ops, Cholesky + triangular solve): 100 ticks against
                                scripts/ci/baseline/stablehlo, integers exact
@@ -191,6 +196,36 @@ def test_n_body_script_builds_the_solar_system_and_its_fold_is_the_oracles_pair_
     assert set(w.generated_sources(system, simulation_rate=sim.SIMULATION_RATE_HZ)) == {"pair"}
 
 
+@pytest.mark.parametrize("case", ["pad", "maxq", "coast"])
+def test_falcon9_plant_script_unmodified_follows_the_reference_flown_windows(compat, case):
+    from tests import dsl_numpy, falcon9_plant_util as pu, falcon9_unmodified_util as fu
+    limit = sys.getrecursionlimit()
+    sys.setrecursionlimit(50000)
+    try:
+        plan, tp, a = fu.build(case)
+        assert plan["integrator"] == 1 and len(tp.columns) == 62
+        assert [s.name for s in tp.pre][:3] == ["commands", "attitude_control", "valve_dynamics"] and "imu_model" in [s.name for s in tp.post]
+        if case == "maxq":
+            from elodin_amd import codegen
+            frozen = json.loads((ROOT / "tests" / "golden" / "falcon9_plant_program.json").read_text())     # what tests/test_gpu_falcon9_unmodified.py runs
+            assert codegen.generate_variant(tp, frozen["variant"], "float64", plan["integrator"]) == frozen["source"], \
+                "re-run tests/golden/make_falcon9_plant_program.py"
+        pos, vel, acc, inertia = a["world_pos"], a["world_vel"], a["world_accel"], a["inertia"]
+        comps = {name: a[name] for name, _ in tp.columns}
+        worst = {}
+        for tick in range(1, 1001):
+            force = dsl_numpy.program_tick(tp, pos, vel, acc, inertia, comps, tick, plan["dt"], plan["integrator"], dt=plan["time_step"])
+            if tick in (1, 2, 10, 500, 1000):
+                body = {"world_pos": pos, "world_vel": vel, "world_accel": acc, "inertia": inertia, "force": force}
+                for k, e in pu.compare(case, tick, lambda name: body[name] if name in body else comps[name]).items():
+                    worst[k] = max(worst.get(k, 0.0), e)
+    finally:
+        sys.setrecursionlimit(limit)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    print(f"examples/falcon9/sim.py unmodified, window {case}: worst of {len(worst)} columns over 1,000 ticks:", ", ".join(f"{k} {e:.1e}" for k, e in top))
+    assert len(worst) == 43 and max(worst.values()) < 1e-11, top
+
+
 def test_stablehlo_script_unmodified_lands_on_the_reference_baseline(compat):
     from tests import dsl_numpy, stablehlo_dsl as S
     sys.path.insert(0, str(REF / "examples" / "stablehlo"))
@@ -284,7 +319,13 @@ def test_shim_keeps_data_and_traced_code_apart(compat):
         assert isinstance(jnp.array([1.0, 2.0]), dsl.Vec) and isinstance(jnp.eye(3), list)
     assert isinstance(lax.cond(x > 0.0, lambda _: x, lambda _: -x, operand=None), dsl.Expr)
     assert isinstance(random.normal(random.key(dsl.leaf("seed")), shape=(3,)), dsl.Vec)
-    with pytest.raises(NotImplementedError, match="vmap"):
-        jax.vmap(lambda v: v)
+    with pytest.raises(NotImplementedError, match="grad"):
+        jax.grad(lambda v: v)
+    stacked = jax.vmap(lambda row: row * x)(jnp.array([[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]]))       # unrolled over the leading axis
+    assert isinstance(stacked, list) and len(stacked) == 3 and isinstance(stacked[0], dsl.Vec) and len(stacked[0]) == 2
+    table = jnp.asarray(np.array([10.0, 20.0, 30.0]))
+    assert isinstance(table[x], dsl.Expr) and table[1] == 20.0                  # a traced index into a host table: a select chain
+    with pytest.raises(NotImplementedError, match="traced values"):
+        jnp.unwrap(jnp.array([1.0, 2.0]) * x)          # numpy functions without a traced counterpart refuse traced values
     with pytest.raises(AttributeError, match="not provided"):
         jnp.fft
