@@ -258,6 +258,8 @@ class Vec:
             raise IndexError(i)
         if isinstance(i, Expr):             # a TRACED index into a vector: a select chain, clamped like jax's gather
             return _dynamic_index([x for x in self.e], i)
+        if isinstance(i, (list, _numpy.ndarray)):      # a constant index list: `torque[AXIS_OF_THRUSTER]` (examples/apollo-lander/sim.py:451)
+            return Vec([self.e[int(k)] for k in _numpy.asarray(i).reshape(-1)])
         r = self.e[i]
         return Vec(r) if isinstance(i, slice) else r
     def _zip(self, o, f):

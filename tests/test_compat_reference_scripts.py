@@ -16,6 +16,9 @@ read from /root/reference and never copied:
                                frames, pad clamp, leg contact, sensors; 23 systems, 62 components) driven the way the reference's
                                own tests drive it, against the trajectories the reference's own functions flew
                                (tests/golden/falcon9_plant.json): 43 columns, three windows
+  examples/apollo-lander/sim.py  BASELINE configs[3]'s example: `build(params)` traces and generates (its closed loop needs the
+                               example's controller process behind main.py's post_step; the campaign kernel of this repo is
+                               pinned on reference-flown descents separately, tests/test_apollo_reference_fixtures.py)
   examples/stablehlo/main.py   the op-coverage example (eight single-component entities, ~50 ops incl. int64 bitwise ones, sort,
                                while_loop / switch, static shape ops, Cholesky + triangular solve): 100 ticks against
                                scripts/ci/baseline/stablehlo, integers exact
@@ -194,6 +197,21 @@ def test_n_body_script_builds_the_solar_system_and_its_fold_is_the_oracles_pair_
     print("examples/n-body/sim.py unmodified: traced fold vs the oracle's softened all-pairs op over 240 ticks:", f"{err:.1e}")
     assert err < 1e-12
     assert set(w.generated_sources(system, simulation_rate=sim.SIMULATION_RATE_HZ)) == {"pair"}
+
+
+def test_apollo_lander_script_builds_and_generates(compat):
+    import elodin as el
+    sys.path.insert(0, str(REF / "examples" / "apollo-lander"))
+    sim = _load(REF / "examples" / "apollo-lander" / "sim.py", "ref_apollo_sim")
+    world, system = sim.build(el.monte_carlo.params(sim.PARAMS))             # main.py:88-90
+    plan = world.build(system, simulation_rate=sim.SIMULATION_RATE_HZ, telemetry_rate=sim.TELEMETRY_RATE_HZ, _dry=True)
+    tp = plan["effectors"].trace()
+    assert plan["integrator"] == 1 and abs(plan["dt"] - 1.0 / 120.0) < 1e-9
+    assert [e.__name__ for e in plan["effectors"].effectors.effectors] == ["lunar_gravity", "apply_main_thrust", "apply_rcs_torque"]
+    assert [s.name for s in tp.pre] == ["truth_playback", "engine_response", "attitude_control", "mass_props", "thrust_visualization"]
+    assert [s.name for s in tp.post] == ["ground_contact", "derive_telemetry"] and len(tp.columns) == 22
+    src = world.generated_sources(system, simulation_rate=sim.SIMULATION_RATE_HZ)["step"]
+    assert "apply_rcs_torque" in src and "ground_contact" in src
 
 
 @pytest.mark.parametrize("case", ["pad", "maxq", "coast"])
