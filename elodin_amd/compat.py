@@ -264,6 +264,7 @@ def _make_elodin():
         def schematic(self, *a, **k): return None
         def recipe(self, *a, **k): return None
         def glb(self, *a, **k): return None
+        def sensor_camera(self, *a, **k): return None      # a rendered camera of the editor (examples/sensor-camera)
 
         def run(self, system, simulation_rate: float = 120.0, max_ticks=None, telemetry_rate=None, post_step=None, **ignored):
             self.compat_run = dict(system=system, simulation_rate=simulation_rate, max_ticks=max_ticks, telemetry_rate=telemetry_rate,

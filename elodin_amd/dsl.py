@@ -113,6 +113,11 @@ class Expr:
         if k in (0, -1, Ellipsis, ()) or k == slice(None):
             return self
         raise IndexError("a scalar traced value has one element")
+    def reshape(self, *shape):                        # `jnp.asarray(x[0]).reshape(())` (examples/falcon9/sim.py:1288): still the one value
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        if tuple(shape) in ((), (1,), (-1,)):
+            return self if tuple(shape) == () else Vec([self])
+        raise ValueError(f"cannot reshape a scalar traced value to {tuple(shape)}")
     def all(self, axis=None): return self           # a 0-d comparison: `(x < fov).all()`
     def any(self, axis=None): return self
 
