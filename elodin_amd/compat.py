@@ -349,3 +349,25 @@ def uninstall() -> None:
         if sys.modules.get(name) is mod:
             del sys.modules[name]
     _INSTALLED.clear()
+
+
+def main(argv=None) -> None:
+    """`python -m elodin_amd.compat script.py [args...]`: run a reference sim script on this backend as it is."""
+    import argparse
+    import os
+    import runpy
+    ap = argparse.ArgumentParser(prog="python -m elodin_amd.compat",
+                                 description="Run an elodin sim script unmodified: `import elodin`, `jax`, `jax.numpy` ... resolve to "
+                                             "elodin_amd's front end; world.run / world.build compile for and step on the GPU.")
+    ap.add_argument("script")
+    ap.add_argument("args", nargs=argparse.REMAINDER)
+    ap.add_argument("--record", action="store_true", help="world.run(...) only records its arguments (no GPU needed)")
+    ns = ap.parse_args(argv)
+    install(run="record" if ns.record else "execute")
+    sys.argv = [ns.script, *ns.args]
+    sys.path.insert(0, os.path.dirname(os.path.abspath(ns.script)))
+    runpy.run_path(ns.script, run_name="__main__")
+
+
+if __name__ == "__main__":
+    main()
