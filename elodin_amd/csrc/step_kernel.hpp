@@ -109,19 +109,22 @@ __device__ __forceinline__ void slab_out_tail(const T* l, T* __restrict__ g, uin
 // first tick reads the incoming world_accel row for stage 0.  A kernel of its own so that the everyday kernels carry
 // neither the branch nor a third copy of the tick body (measured: +0.25 us per one-tick launch at 65,536 bodies when it
 // lived in the same kernel, profiles/r02_step_taint_check_ab.txt).  Generated programs (kHasModel) keep it in their one kernel.
-template <class T, int INTEGRATOR, class PIPE, int POL, bool CHECK = false>
+// ROWS: entities per wave.  64 = one per lane.  32 = half-filled waves, twice as many of them (lanes 32..63 idle): at sizes
+// where a full-width launch is one wave per SIMD the two waves a SIMD then holds overlap each other's load -> math -> store
+// chain (profiles/r03_step_half_waves_ab.txt).
+template <class T, int INTEGRATOR, class PIPE, int POL, bool CHECK = false, int ROWS = kWave>
 __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) {
     // pos | vel | inertia on the way in (20 elems/entity); pos | vel | accel | force on the way out (25)
-    __shared__ __attribute__((aligned(16))) T lds[kWave * 25];
+    __shared__ __attribute__((aligned(16))) T lds[ROWS * 25];
     T* const l_pos = lds;
-    T* const l_vel = lds + kWave * 7;
-    T* const l_c = lds + kWave * 13;  // inertia (in) / accel (out)
-    T* const l_force = lds + kWave * 19;
+    T* const l_vel = lds + ROWS * 7;
+    T* const l_c = lds + ROWS * 13;  // inertia (in) / accel (out)
+    T* const l_force = lds + ROWS * 19;
 
-    const uint32_t row0 = blockIdx.x * kWave;
-    const uint32_t rows = min((uint32_t)kWave, P.n - row0);
+    const uint32_t row0 = blockIdx.x * ROWS;
+    const uint32_t rows = min((uint32_t)ROWS, P.n - row0);
     const uint32_t t = threadIdx.x;
-    const bool full = rows == kWave;  // wave-uniform
+    const bool full = rows == ROWS;  // wave-uniform
 
     T* const g_pos = static_cast<T*>(P.pos) + (size_t)row0 * 7;
     T* const g_vel = static_cast<T*>(P.vel) + (size_t)row0 * 6;
@@ -130,9 +133,9 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     const T* const g_inertia = static_cast<const T*>(P.inertia) + (size_t)row0 * 7;
 
     if (full) {
-        slab_dma_in<kWave * 7 * sizeof(T), POL>(reinterpret_cast<const char*>(g_pos), reinterpret_cast<char*>(l_pos), t);
-        slab_dma_in<kWave * 6 * sizeof(T), POL>(reinterpret_cast<const char*>(g_vel), reinterpret_cast<char*>(l_vel), t);
-        slab_dma_in<kWave * 7 * sizeof(T), POL>(reinterpret_cast<const char*>(g_inertia), reinterpret_cast<char*>(l_c), t);
+        slab_dma_in<ROWS * 7 * sizeof(T), POL>(reinterpret_cast<const char*>(g_pos), reinterpret_cast<char*>(l_pos), t);
+        slab_dma_in<ROWS * 6 * sizeof(T), POL>(reinterpret_cast<const char*>(g_vel), reinterpret_cast<char*>(l_vel), t);
+        slab_dma_in<ROWS * 7 * sizeof(T), POL>(reinterpret_cast<const char*>(g_inertia), reinterpret_cast<char*>(l_c), t);
     } else {
         slab_in_tail(g_pos, l_pos, rows * 7, t);
         slab_in_tail(g_vel, l_vel, rows * 6, t);
@@ -217,11 +220,11 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
         }
     };
     auto flush7 = [&](const T* l, T* o, auto pol) {
-        if (full) slab_out<kWave * 7 * sizeof(T), decltype(pol)::value>(reinterpret_cast<const char*>(l), reinterpret_cast<char*>(o), t);
+        if (full) slab_out<ROWS * 7 * sizeof(T), decltype(pol)::value>(reinterpret_cast<const char*>(l), reinterpret_cast<char*>(o), t);
         else slab_out_tail(l, o, rows * 7, t);
     };
     auto flush6 = [&](const T* l, T* o, auto pol) {
-        if (full) slab_out<kWave * 6 * sizeof(T), decltype(pol)::value>(reinterpret_cast<const char*>(l), reinterpret_cast<char*>(o), t);
+        if (full) slab_out<ROWS * 6 * sizeof(T), decltype(pol)::value>(reinterpret_cast<const char*>(l), reinterpret_cast<char*>(o), t);
         else slab_out_tail(l, o, rows * 6, t);
     };
     constexpr std::integral_constant<int, POL> kLive{};   // cache policy of the live columns
@@ -452,6 +455,14 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
 
 template <class T, class PIPE, int POL>
 inline void launch_i(const StepParams& p, int integrator, dim3 grid, hipStream_t s) {
+#ifdef SIXDOF_AB_BUILD
+    if constexpr (!PIPE::kHasModel) {
+        if ((p.streaming & 512u) && integrator == kRk4 && !p.accel_in_check) {      // A/B: half-filled waves (ROWS = 32)
+            hipLaunchKernelGGL((sixdof_step_kernel<T, kRk4, PIPE, POL, false, 32>), dim3((p.n + 31) / 32), dim3(kWave), 0, s, p);
+            return;
+        }
+    }
+#endif
     if (integrator == kRk4) {
         if constexpr (!PIPE::kHasModel) {
             if (p.accel_in_check) {   // one launch per upload: a single cache policy is plenty
