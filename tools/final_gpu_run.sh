@@ -1,8 +1,9 @@
 #!/bin/bash
-# The round's closing GPU run (through gpurun from the repo root):  gpurun --timeout 2400 -- 'bash tools/final_gpu_run.sh r03'
-# bench lines (the driver's command, the default run, a 2-rank dry run sharing the one GPU), the whole GPU suite, the rocprofv3
-# collections; outputs under gpurun_out/final_<tag>/ — copy what is to be judged into profiles/.  Also lists which JIT objects
-# the run used and packs the ones it had to compile, so the build container can keep elodin_amd/_jit exact.
+# The round's closing GPU run (through gpurun from the repo root):  gpurun --timeout 2400 -- 'bash tools/final_gpu_run.sh r03 [quick]'
+# bench lines (the driver's command, the default run, a 2-rank dry run sharing the one GPU, both campaigns), the whole GPU suite,
+# the rocprofv3 collections (skipped with `quick`); outputs under gpurun_out/final_<tag>/ — copy what is to be judged into
+# profiles/.  Also lists which JIT objects the run used and packs the ones it had to compile, so the build container can keep
+# elodin_amd/_jit exact.
 TAG=${1:-r03}
 cd $GRAFT_REPO_ROOT; O=gpurun_out/final_$TAG; mkdir -p $O
 touch /tmp/jit_marker; sleep 1
@@ -10,7 +11,7 @@ find elodin_amd/_jit -name '*.so' | sort > /tmp/jit_before.txt
 python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/bench_steps20.err
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 SIXDOF_BENCH_SHARED_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
-    bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_2rank_shared_gpu.json 2> $O/bench_2rank.err
+    bench.py --gpus 2 --steps 20 --warmup 5 2> $O/bench_2rank.err | grep '^{' > $O/bench_2rank_shared_gpu.json
 python bench.py --campaign falcon9 > $O/campaign_falcon9.json 2> $O/campaign.err
 python bench.py --campaign apollo > $O/campaign_apollo.json 2>> $O/campaign.err
 timeout 1300 python -m pytest tests -m gpu -q --durations=15 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
@@ -18,7 +19,9 @@ find elodin_amd/_jit -name '*.so' -newer /tmp/jit_marker | sort > $O/jit_used.tx
 find elodin_amd/_jit -name '*.so' | sort > /tmp/jit_after.txt
 comm -13 /tmp/jit_before.txt /tmp/jit_after.txt | sed 's/\.so$//' | while read f; do ls $f.so $f.json $f.hip 2>/dev/null; done > /tmp/jit_new.txt
 tar czf $O/jit_new.tgz -T /tmp/jit_new.txt; wc -l < /tmp/jit_new.txt > $O/jit_new_count.txt
-bash profiles/collect.sh $TAG > $O/collect.log 2>&1
-bash profiles/collect_compute.sh $TAG > $O/collect_compute.log 2>&1
-python profiles/summarize_compute.py gpurun_out/prof_compute_$TAG > $O/summarize_compute.log 2>&1
-cat $O/bench_steps20.json | cut -c1-400; cat $O/bench_2rank_shared_gpu.json | cut -c1-700; tail -3 $O/bench_2rank.err; cat $O/campaign_falcon9.json | cut -c1-900; tail -25 $O/pytest.log; cat $O/jit_new_count.txt
+if [ "${2:-}" != "quick" ]; then
+  bash profiles/collect.sh $TAG > $O/collect.log 2>&1
+  bash profiles/collect_compute.sh $TAG > $O/collect_compute.log 2>&1
+  python profiles/summarize_compute.py gpurun_out/prof_compute_$TAG > $O/summarize_compute.log 2>&1
+fi
+cut -c1-400 $O/bench_steps20.json; tail -25 $O/pytest.log; cat $O/jit_new_count.txt
