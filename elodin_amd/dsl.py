@@ -1813,12 +1813,14 @@ class FrozenProgram(Program):
     (tests/golden/make_drone_program.py).  HipExec compiles and binds it like a program it traced itself."""
 
     def __init__(self, source: str, columns: Sequence[Tuple[str, int]], mats: Optional[Dict[str, Tuple[int, int]]] = None,
-                 substeps: int = 1):
+                 substeps: int = 1, column_soa: bool = False):
+        """column_soa: the text was generated with element-major program columns (codegen.generate_source(column_soa=True));
+        the executor lays the columns out the way the text expects, whatever its row count."""
         super().__init__([], Pipe([]), [], substeps=substeps)
         import types
         table = types.SimpleNamespace(mats={k: tuple(v) for k, v in (mats or {}).items()}, windows={})
         self._traced = types.SimpleNamespace(frozen_source=source, columns=[(str(n), int(w)) for n, w in columns], windows={},
-                                             table=table, fold_stages=[], pre=[], post=[])
+                                             table=table, fold_stages=[], pre=[], post=[], column_soa=bool(column_soa))
 
     def trace(self, *a, **k):
         return self._traced

@@ -139,6 +139,8 @@ class HipExec:
                 self._column_soa = (isinstance(effectors, _dsl.Program) and not getattr(custom, "fold_stages", None)
                                     and not self._column_ids and (soa_env == "1" or (soa_env != "0" and
                                                                   self.world_pos.shape[0] >= codegen.COLUMN_SOA_MIN_ROWS)))
+                if getattr(custom, "frozen_source", None) is not None:      # a frozen text was generated for ONE device layout
+                    self._column_soa, self._window_soa = bool(custom.column_soa), False
                 so = codegen.build(custom, self.dtype.name, integrator, fast_math=fast_math, window_soa=self._window_soa,
                                    column_soa=self._column_soa)
                 for name, width in custom.columns:

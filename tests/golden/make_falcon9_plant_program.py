@@ -28,6 +28,9 @@ doc = {
     "case": CASE, "variant": codegen.last_variant[0],
     "source": codegen.generate_variant(tp, codegen.last_variant[0], "float64", plan["integrator"]),
     "columns": [[n, w] for n, w in tp.columns], "mats": {k: list(v) for k, v in tp.table.mats.items()},
+    # the campaign-style build of the same program (float32, hardware transcendentals): register-resident, for the throughput
+    # measurement of tools/falcon9_unmodified_throughput.py
+    "source_f32_fast": codegen.generate_variant(tp, "program", "float32", plan["integrator"], fast_math=True),
     "integrator": plan["integrator"], "simulation_time_step": plan["dt"],
     "initial": {k: v.tolist() for k, v in a.items()},
 }
