@@ -14,7 +14,7 @@ import hashlib
 import os
 import subprocess
 from pathlib import Path
-from typing import Optional, Dict, List, Sequence
+from typing import Optional, Dict, List, Sequence, Tuple
 
 from . import dsl
 
@@ -155,6 +155,7 @@ class _Emitter:
         lines: List[str] = []
         before = set(self.names)
         outer = {"parent": None, "names": self.names, "lines": lines, "vars": {}, "varset": frozenset(), "indent": indent}
+        guards: Dict[int, tuple] = {}      # id(select) -> (guarded arm index, member node ids, selects of the group): _plan_guards
 
         def rhs_of(e: dsl.Expr, a: List[str]) -> str:
             if e.op == "div":
@@ -239,8 +240,9 @@ class _Emitter:
                         return s_["vars"][e.name]
                     s_ = s_["parent"]
                 return _leaf_ref(e.name, self.leaves)
-            # a node that does not depend on this loop's carried values belongs to the enclosing scope
-            while sc["parent"] is not None and not (self._deps(e) & sc["varset"]):
+            # a node that does not depend on this loop's carried values (or, in a guarded region, is not one of its members)
+            # belongs to the enclosing scope
+            while sc["parent"] is not None and not ((self._deps(e) & sc["varset"]) or id(e) in sc.get("members", ())):
                 sc = sc["parent"]
             s_ = sc
             while s_ is not None:                      # visible in this scope or any enclosing one
@@ -257,6 +259,31 @@ class _Emitter:
                 sc["names"][id(e)] = name
                 self._deps(e)
                 return name
+            if e.op == "select" and id(e) in guards:
+                # GUARDED SELECT (opt-in, _GUARD_SELECTS): `where(c, expensive, cheap)` whose expensive arm nobody else needs —
+                # a sensor's noise draw behind its sample-time test, as a script written for JAX spells a cadence.  The arm's
+                # nodes are emitted inside `if (any lane of the wave wants them)`; the value is the same select.
+                arm, members, group = guards[id(e)]
+                cast = lambda x, scope: (f"T({ref(x, scope)})" if x.op != "const" and self._is_wide(x) else ref(x, scope))
+                c_ref = ref(e.args[0], sc)
+                want = c_ref if arm == 1 else f"!({c_ref})"
+                others = [cast(g.args[3 - arm], sc) for g in group]          # the cheap sides, outside
+                inner = {"parent": sc, "names": {}, "lines": [], "vars": {}, "varset": frozenset(), "indent": sc["indent"] + "    ",
+                         "members": members}
+                mine = [cast(g.args[arm], inner) for g in group]             # the expensive sides: their nodes land in `inner`
+                names = []
+                for g, other in zip(group, others):
+                    names.append(f"t{self.n}")
+                    self.n += 1
+                    sc["names"][id(g)] = names[-1]
+                    self._deps(g)
+                    sc["lines"].append(f"{sc['indent']}T {names[-1]} = {other};")
+                sc["lines"].append(f"{sc['indent']}if (__any({want})) {{")
+                sc["lines"].extend(inner["lines"])
+                for nm, m in zip(names, mine):
+                    sc["lines"].append(f"{inner['indent']}{nm} = ({want}) ? {m} : {nm};")
+                sc["lines"].append(f"{sc['indent']}}}")
+                return sc["names"][id(e)]
             wide = self._is_wide(e)
             a = []
             for x in e.args:
@@ -281,7 +308,7 @@ class _Emitter:
         # nodes the outputs need are emitted in the order the user's program created them (`Expr.seq`; arguments always
         # precede their users), which is the order a person would have written the code in: the same step then peaks at a
         # few matrices' worth of registers.  (Nodes inside loop bodies keep their own scopes and are emitted with their loop.)
-        need, stack = {}, ([e for _, e in assign] if _EMIT_ORDER[0] == "program" else [])
+        need, stack = {}, ([e for _, e in assign] if (_EMIT_ORDER[0] == "program" or _GUARD_SELECTS[0]) else [])
         while stack:
             x = stack.pop()
             if id(x) in need or x.op in ("const", "leaf"):
@@ -291,8 +318,12 @@ class _Emitter:
                 continue
             need[id(x)] = x
             stack.extend(x.args)
-        for x in sorted(need.values(), key=lambda n_: n_.seq):
-            ref(x)
+        if _GUARD_SELECTS[0]:
+            guards.update(_plan_guards(need, [e for _, e in assign], set(self.names)))
+        guarded = set().union(*[g[1] for g in guards.values()]) if guards else set()
+        for x in (sorted(need.values(), key=lambda n_: n_.seq) if _EMIT_ORDER[0] == "program" else ()):
+            if id(x) not in guarded:
+                ref(x)
         outs = []
         for lv, e in assign:
             o = f"o{self.n}"
@@ -310,6 +341,99 @@ class _Emitter:
             if (scoped and k not in before) or (wr and dk & wr):
                 del self.names[k]
         return lines
+
+
+# Opt-in (codegen.generate_source(..., guard_selects=True) / SIXDOF_GUARD_SELECTS=1): see _Emitter.block, "GUARDED SELECT".
+_GUARD_SELECTS = [False]
+_GUARD_MIN_COST = 40
+_NODE_COST = {"threefry": 90, "erfinv": 120, "sin": 12, "cos": 12, "tan": 20, "exp": 10, "log": 10, "pow": 25, "atan2": 27, "asin": 20,
+              "acos": 20, "hypot": 12, "div": 4, "sqrt": 4, "interp": 30, "cbrt": 20, "sinh": 20, "cosh": 20, "erfc": 40, "log1p": 15,
+              "expm1": 15, "mod": 8}
+
+
+def _plan_guards(need: Dict[int, "dsl.Expr"], roots: Sequence["dsl.Expr"], available: set) -> Dict[int, tuple]:
+    """Which selects of a block get a guarded arm: id(select) -> (arm index, member ids, [the selects of its group in creation order]).
+
+    Selects with the SAME condition and the same guarded side form one group (`imu = where(due, fresh, held)` per axis: the three
+    draws share their key derivation) and get one branch.  A group's MEMBERS are the nodes every use of which lies inside the
+    group's arms (found in reverse creation order: a node joins once all its users have); the group is guarded when their summed
+    cost is worth a branch.  Never members: nodes an earlier block already emitted (`available`), block outputs, loops, window
+    loads.  A select whose condition or other arm needs a value computed inside the group stays a plain select."""
+    users: Dict[int, list] = {}
+    for n in need.values():
+        if n.op in ("while_out", "while"):      # loop bodies reach nodes this walk does not see: no guards in such a block
+            return {}
+        for a in n.args:
+            users.setdefault(id(a), []).append(n)
+    root_ids = {id(r) for r in roots}
+    by_seq = sorted(need.values(), key=lambda n_: -n_.seq)
+    groups: Dict[tuple, list] = {}
+    for s_ in need.values():
+        if s_.op != "select" or s_.args[0].op == "const":      # a constant condition: the compiler folds it
+            continue
+        for arm in (1, 2):
+            a = s_.args[arm]
+            if a.op in ("const", "leaf") or id(a) not in need or id(a) in available or id(a) in root_ids or a is s_.args[0] \
+                    or a is s_.args[3 - arm] or any(u is not s_ for u in users.get(id(a), [])):
+                continue
+            groups.setdefault((id(s_.args[0]), arm), []).append(s_)
+
+    def reaches(start, blocked):
+        seen, stack = set(), [start]
+        while stack:
+            x = stack.pop()
+            if id(x) in blocked:
+                return True
+            if id(x) in seen or x.op in ("const", "leaf"):
+                continue
+            seen.add(id(x))
+            stack.extend(x.args)
+        return False
+
+    def plan(sels, arm):
+        """(cost, arm, members, sels) of one candidate region, or None when it cannot be one."""
+        sel_ids = {id(s_) for s_ in sels}
+        members = {id(s_.args[arm]) for s_ in sels}
+        cost = sum(_NODE_COST.get(s_.args[arm].op, 1) for s_ in sels)
+        top = max(s_.args[arm].seq for s_ in sels)
+        if any(s_.args[arm].op in ("while", "while_out", "wload") for s_ in sels):
+            return None
+        for x in by_seq:
+            if x.seq >= top or id(x) in members or id(x) in available or id(x) in root_ids or id(x) in sel_ids:
+                continue
+            us = users.get(id(x), [])
+            if us and all(id(u) in members for u in us):
+                if x.op in ("while", "while_out", "wload"):
+                    return None
+                members.add(id(x))
+                cost += _NODE_COST.get(x.op, 1)
+        if cost < _GUARD_MIN_COST:
+            return None
+        # nothing the region needs from outside (conditions, cheap sides) may be computed inside it, and no arm may need the
+        # value of another select of the region
+        blocked = members | sel_ids
+        for s_ in sels:
+            if reaches(s_.args[0], blocked) or reaches(s_.args[3 - arm], blocked) or reaches(s_.args[arm], sel_ids - {id(s_)}):
+                return None
+        return (cost, arm, members, sels)
+
+    plans = []
+    for (cond_id, arm), sels in groups.items():
+        sels = sorted(sels, key=lambda n_: n_.seq)
+        p_ = plan(sels, arm)
+        if p_ is not None:
+            plans.append(p_)
+        elif len(sels) > 1:
+            plans.extend(q for q in (plan([s_], arm) for s_ in sels) if q is not None)
+    out: Dict[int, tuple] = {}
+    taken: set = set()
+    for cost, arm, members, sels in sorted(plans, key=lambda p_: -p_[0]):      # costliest first; a node belongs to one region
+        if members & taken or any(id(s_) in taken for s_ in sels):
+            continue
+        for s_ in sels:
+            out[id(s_)] = (arm, members, sels)
+        taken |= members | {id(s_) for s_ in sels}
+    return out
 
 
 def emit_block(assign, leaves: Dict[str, str], indent: str = "        ") -> List[str]:
@@ -796,10 +920,13 @@ __device__ __forceinline__ double m_erfinv_fast(double u) {
 
 
 def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, window_soa: bool = False,
-                    column_soa: bool = False) -> str:
+                    column_soa: bool = False, guard_selects: Optional[bool] = None) -> str:
     """tp: dsl.TracedPipe (effectors only) or dsl.TracedProgram (pre | six_dof(effectors) | post).
     fast_math: f32 only — hardware transcendentals / reciprocal division in the generated user code (see _PRELUDE).
-    window_soa: window columns are element-major on the device (executors of WINDOW_SOA_MIN_ROWS entities or more)."""
+    window_soa: window columns are element-major on the device (executors of WINDOW_SOA_MIN_ROWS entities or more).
+    guard_selects: expensive `where` arms nobody else needs are computed behind a wave-level branch (_Emitter.block);
+    None = the SIXDOF_GUARD_SELECTS environment switch (off unless "1")."""
+    _GUARD_SELECTS[0] = (os.environ.get("SIXDOF_GUARD_SELECTS", "") == "1") if guard_selects is None else bool(guard_selects)
     _WINDOW_SOA[0] = bool(window_soa)
     _COLUMN_SOA[0] = bool(column_soa)
     if column_soa and isinstance(tp, dsl.TracedProgram) and tp.fold_stages:

@@ -75,3 +75,13 @@ def compare(case, tick, get, floors=None):
             e = max(e, float(np.max(np.abs(g - w))) / scale)
         errs[name] = e
     return errs
+
+
+def load_program_fixture():
+    """tests/golden/falcon9_plant_program.json with its generated sources inflated (make_falcon9_plant_program.py stores them deflated)."""
+    import base64
+    import zlib
+    doc = json.loads((Path(__file__).parent / "golden" / "falcon9_plant_program.json").read_text())
+    for k in doc.get("packed", ()):
+        doc[k] = zlib.decompress(base64.b64decode(doc[k])).decode()
+    return doc

@@ -225,9 +225,12 @@ def test_falcon9_plant_script_unmodified_follows_the_reference_flown_windows(com
         assert [s.name for s in tp.pre][:3] == ["commands", "attitude_control", "valve_dynamics"] and "imu_model" in [s.name for s in tp.post]
         if case == "maxq":
             from elodin_amd import codegen
-            frozen = json.loads((ROOT / "tests" / "golden" / "falcon9_plant_program.json").read_text())     # what tests/test_gpu_falcon9_unmodified.py runs
+            frozen = pu.load_program_fixture()     # what tests/test_gpu_falcon9_unmodified.py runs
             assert codegen.generate_variant(tp, frozen["variant"], "float64", plan["integrator"]) == frozen["source"], \
                 "re-run tests/golden/make_falcon9_plant_program.py"
+            guarded = codegen.generate_source(tp, "float32", plan["integrator"], fast_math=True, guard_selects=True)
+            assert guarded == frozen["source_f32_fast_guarded"] and guarded.count("if (__any(") == 8
+            assert codegen.generate_source(tp, "float32", plan["integrator"], fast_math=True) == frozen["source_f32_fast"]      # the switch is off by default
         pos, vel, acc, inertia = a["world_pos"], a["world_vel"], a["world_accel"], a["inertia"]
         comps = {name: a[name] for name, _ in tp.columns}
         worst = {}

@@ -136,6 +136,22 @@ def test_random_programs_f64(seed):
     assert np.abs(want["c"]).max() > 0.0 and not np.array_equal(want["x"], cols["x"])
 
 
+@pytest.mark.parametrize("seed", [0, 3, 5])
+def test_random_programs_with_guarded_selects_f64(seed, monkeypatch):
+    """The same random programs generated with guarded selects (codegen: expensive `where` arms behind a wave-level branch, with
+    _GUARD_MIN_COST lowered so that these small DAGs qualify): a select guarded or not is the same select."""
+    from elodin_amd import codegen
+    monkeypatch.setenv("SIXDOF_GUARD_SELECTS", "1")
+    monkeypatch.setattr(codegen, "_GUARD_MIN_COST", 6)
+    prog, cols = make_program(seed), columns(seed, 2048)
+    src = codegen.generate_source(prog.trace({k: v.shape[1] for k, v in cols.items()}), "float64", 2)
+    assert "if (__any(" in src, "no select of this program qualified: the test would prove nothing"
+    got, want = run_both(make_program(seed), cols, 2, np.float64)
+    for k in ("a", "b", "c", "x"):
+        err = np.abs(got[k] - want[k]) / np.maximum(np.abs(want[k]), 1.0)
+        assert (err < 1e-10).mean() > 0.9995 and np.median(err) < 1e-14, (seed, k, float(err.max()))
+
+
 def test_random_program_f32():
     prog, cols = make_program(101, depth=3), columns(101, 2048)
     got, want = run_both(prog, cols, 1, np.float32)
