@@ -404,3 +404,33 @@ def test_concurrent_builds_of_one_program_share_the_cache_safely():
     assert all(rc == 0 for _, _, rc in outs), outs
     assert len({o.strip() for o, _, _ in outs}) == 1 and outs[0][0].split()[1] == "0"
     assert not list(codegen.JIT_DIR.glob("*.tmp*"))
+
+
+def test_guarded_selects_wrap_only_what_the_expensive_arm_alone_needs():
+    """codegen guard_selects: `where(due, fresh, held)` with an expensive `fresh` becomes `T x = held; if (__any(due)) {...}`.
+    Nodes another use needs stay outside; selects on the same condition share one branch; constant conditions, loops and the
+    default (switch off) are untouched."""
+    from elodin_amd import codegen
+
+    @dsl.system
+    def sensor(a, b, c):
+        due = a[0] > 0.5
+        shared = np_.sin(a[1])                                   # also read by `c`: must stay outside the branch
+        key = dsl.random.fold_in(dsl.random.key(7), a[2])        # needed by both draws and by nothing else: inside
+        n = dsl.random.normal(key, shape=(2,))
+        fresh0, fresh1 = b[0] + n[0] * shared, b[1] + n[1] * np_.cos(a[1])
+        return {"b": np_.array([np_.where(due, fresh0, b[0]), np_.where(due, fresh1, b[1])]),
+                "c": np_.array([shared, np_.where(a[0] * 0.0 + 1.0 > 2.0, np_.tan(a[1]), 0.0)])}
+    tp = dsl.Program([sensor], dsl.Pipe([]), []).trace({"a": 3, "b": 2, "c": 2})
+    plain = codegen.generate_source(tp, "float64", 2)
+    src = codegen.generate_source(tp, "float64", 2, guard_selects=True)
+    assert "__any(" not in plain and plain == codegen.generate_source(tp, "float64", 2, guard_selects=False)
+    body = src[src.index("// sensor"):]
+    assert body.count("if (__any(") == 1                          # one branch for the two selects that test `due`
+    guard = body[body.index("if (__any("):]
+    inside = guard[:guard.index("\n        }")]
+    assert inside.count("m_threefry(") >= 3 and inside.count("m_erfinv(") == 2 and "m_cos(" in inside
+    assert "m_sin(" not in inside and "m_sin(" in body[:body.index("if (__any(")]            # the shared node: outside, before
+    assert inside.count(" ? ") == 2 and "m_tan(" not in inside                                   # cheap arm (tan: cost below the bar) plain
+    # evaluation is unchanged by construction (the numpy walk has no notion of the switch); the GPU side is
+    # tests/test_gpu_fuzz.py::test_random_programs_with_guarded_selects_f64 and tests/test_gpu_falcon9_unmodified.py
