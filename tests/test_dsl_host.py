@@ -434,3 +434,42 @@ def test_guarded_selects_wrap_only_what_the_expensive_arm_alone_needs():
     assert inside.count(" ? ") == 2 and "m_tan(" not in inside                                   # cheap arm (tan: cost below the bar) plain
     # evaluation is unchanged by construction (the numpy walk has no notion of the switch); the GPU side is
     # tests/test_gpu_fuzz.py::test_random_programs_with_guarded_selects_f64 and tests/test_gpu_falcon9_unmodified.py
+
+
+def test_array_surface_added_for_the_unmodified_scripts_matches_numpy():
+    """What the reference's falcon9 / cube-sat / stablehlo / apollo scripts needed beyond round 2's surface, each against numpy on
+    random data: row-wise cross products and column-condition `where` over matrices, vector-against-matrix broadcasting, stack
+    along axis 1, constant fancy indexing, traced gathers from host tables, triangular solves, integer bitwise ops, broadcast_to."""
+    import scipy.linalg as sla
+    from elodin_amd import dsl_mat
+    rng = np.random.default_rng(12)
+    A, B, v, cnd = rng.normal(size=(4, 3)), rng.normal(size=(4, 3)), rng.normal(size=3), rng.normal(size=4)
+
+    def mats(xp, a_flat, b_flat, vv, cc):
+        a, b = a_flat.reshape(4, 3), b_flat.reshape(4, 3)
+        crossed = xp.cross(a - vv, b)                               # [4, 3] - [3] broadcasts; cross row by row
+        picked = xp.where(cc[:, None] <= 0.0, a, xp.zeros_like(a))  # a [4, 1] condition against [4, 3] values
+        stacked = xp.stack([a[0], b[0]], axis=1)                    # [3, 2]
+        return crossed.flatten(), xp.sum(picked, axis=0), stacked.flatten(), vv - a[1], a[2][np.array([2, 0, 0, 1])]
+    c_, p_, s_, d_, f_ = dsl_numpy.trace_eval(mats, A.reshape(-1), B.reshape(-1), v, cnd)
+    assert np.allclose(c_, np.cross(A - v, B).reshape(-1), rtol=1e-14) and np.allclose(p_, np.where(cnd[:, None] <= 0, A, 0).sum(axis=0))
+    assert np.allclose(s_, np.stack([A[0], B[0]], axis=1).reshape(-1)) and np.allclose(d_, v - A[1]) and np.allclose(f_, A[2][[2, 0, 0, 1]])
+
+    L_ = np.tril(rng.normal(size=(4, 4))) + 3.0 * np.eye(4)
+    rhs = rng.normal(size=4)
+    for lower, trans in ((True, 0), (False, 0), (True, 1)):
+        M = L_ if lower else L_.T
+        got = dsl_numpy.trace_eval(lambda xp, m, r: dsl_mat.solve_triangular(m.reshape(4, 4), r, lower=lower, trans=trans), M.reshape(-1), rhs)
+        assert np.allclose(got, sla.solve_triangular(M, rhs, lower=lower, trans=trans), rtol=1e-13), (lower, trans)
+
+    ints = np.array([0xA5, 0x3C, 0xFF, 0x01], dtype=np.int64)
+    def bits(xp, x):
+        r = xp.bitwise_and(xp.bitwise_or(xp.bitwise_xor(x, 255.0), 15.0), 4095.0)
+        return dsl.lax.shift_right_logical(xp.left_shift(r, 3.0), 2.0)
+    assert np.array_equal(dsl_numpy.trace_eval(bits, ints.astype(float)), ((((ints ^ 0xFF) | 0x0F) & 0xFFF) << 3) >> 2)
+
+    table = np.array([10.0, 20.0, 30.0, 40.0])
+    def gather(xp, i):
+        return dsl._host(table)[i[0]], xp.sum(xp.broadcast_to(i, (3, 2)), axis=0)
+    g, bsum = dsl_numpy.trace_eval(gather, np.array([2.0, 5.0]))
+    assert g == 30.0 and np.allclose(bsum, [6.0, 15.0])
