@@ -14,7 +14,7 @@ import hashlib
 import os
 import subprocess
 from pathlib import Path
-from typing import Optional, Dict, List, Sequence, Tuple
+from typing import Optional, Dict, List, Sequence
 
 from . import dsl
 

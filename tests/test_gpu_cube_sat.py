@@ -9,7 +9,6 @@ tests/golden/cube_sat_program.json), compiled on this box.  tests/cube_sat_util.
 EGM08 gravity tables are a download, so the orbit translation comes from the baseline row by row while the attitude loop runs
 closed — and tests/test_compat_reference_scripts.py checks in the build container that the script still generates this text."""
 import json
-from pathlib import Path
 
 import numpy as np
 import pytest

@@ -7,7 +7,6 @@ fins + RCS active, wind) against every checkpoint of the trajectory the referenc
 (tests/golden/falcon9_plant.json), 1e-9 on 43 columns — the same fixtures and bound as for this repo's own model of the vehicle
 (tests/test_gpu_falcon9_plant.py).  tests/test_compat_reference_scripts.py checks in the build container that the script still
 generates this text and walks all three windows on the CPU."""
-import json
 from pathlib import Path
 
 import numpy as np

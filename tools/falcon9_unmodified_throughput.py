@@ -6,7 +6,6 @@ built the way the campaign builds its programs: float32, hardware transcendental
 `guarded`: the text generated with guarded selects (codegen._Emitter.block: expensive `where` arms behind a wave-level branch).
 Every rollout flies the same window (identical spawn state), so the result is also compared with the float64 trajectory the
 reference's own functions flew (tests/golden/falcon9_plant.json) at the f32 tolerances of tests/falcon9_plant_util.py."""
-import json
 import sys
 import time
 from pathlib import Path
