@@ -1,6 +1,7 @@
 """Every example script of the reference checkout, imported UNMODIFIED under elodin_amd.compat in a process of its own (build
 container only): which ones import, and — where the script calls `world.run(...)` at import — resolve to a program through
-World.build.  A regression list, not a parity test: the examples with reference-held data are pinned one by one in
+World.build; for seven of the traced ones the generated kernel is also compiled for gfx950 and must be register-resident.  A
+regression list, not a parity test: the examples with reference-held data are pinned one by one in
 tests/test_compat_reference_scripts.py.  The ones that cannot run here say why."""
 import os
 import subprocess
@@ -30,6 +31,10 @@ if worlds:
     run = worlds[0].compat_run
     plan = worlds[0].build(run["system"], simulation_rate=run["simulation_rate"], telemetry_rate=run["telemetry_rate"], _dry=True)
     eff = plan["effectors"]
+    if len(sys.argv) > 3 and hasattr(eff, "trace"):      # also generate + compile the program for gfx950 (hipcc cross-compiles)
+        from elodin_amd import codegen
+        codegen.build(eff.trace(), "float64", plan["integrator"])
+        print("scratch", codegen.last_resources.get("scratch_bytes_per_lane"), "variant", codegen.last_variant[0])
     print("TRACED", len(eff.trace().columns) if hasattr(eff, "trace") else 0)
 else:
     print("IMPORTED")
@@ -57,14 +62,22 @@ EXPECTED = {
 }
 
 
+# traced examples whose generated kernel is also compiled here (seconds each; linalg / drone / cube-sat / falcon9 have tests of their own)
+COMPILED = ("apollo-lander/main.py", "crazyflie-edu/main.py", "logstream/main.py", "rc-jet/main.py", "sensor-camera/main.py",
+            "stablehlo/main.py", "video-stream/main.py")
+
+
 @pytest.mark.parametrize("script", sorted(EXPECTED))
 def test_example_script_under_compat(script, tmp_path):
     want = EXPECTED[script]
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-    r = subprocess.run([sys.executable, "-c", ONE, str(REF / script), str(ROOT)], capture_output=True, text=True, timeout=600, cwd=tmp_path, env=env)
+    extra = ["build"] if script in COMPILED else []
+    r = subprocess.run([sys.executable, "-c", ONE, str(REF / script), str(ROOT), *extra], capture_output=True, text=True, timeout=900, cwd=tmp_path, env=env)
     last = (r.stdout.strip().splitlines() or [""])[-1]
     if want == "traced":
         assert r.returncode == 0 and last.startswith("TRACED"), (r.stdout[-300:], r.stderr[-600:])
+        if script in COMPILED:      # register-resident on gfx950: no scratch, first variant
+            assert "scratch 0 variant program" in r.stdout, r.stdout[-300:]
     elif want == "imported":
         assert r.returncode == 0 and last.startswith(("IMPORTED", "TRACED")), (r.stdout[-300:], r.stderr[-600:])
     else:
