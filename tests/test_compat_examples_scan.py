@@ -87,3 +87,14 @@ def test_example_script_under_compat(script, tmp_path):
 def test_the_list_covers_every_example_with_a_script():
     have = {f"{d.name}/{f}" for d in REF.iterdir() if d.is_dir() for f in ("main.py",) if (d / f).exists()}
     assert have - set(EXPECTED) == {"n-body/main.py"}, have - set(EXPECTED)
+
+
+def test_command_line_runner_in_record_mode(tmp_path):
+    """`python -m elodin_amd.compat --record script.py`: the runner itself, without a GPU (world.run only records)."""
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=str(ROOT))
+    r = subprocess.run([sys.executable, "-m", "elodin_amd.compat", "--record", str(REF / "three-body" / "main.py")],
+                       capture_output=True, text=True, timeout=300, cwd=tmp_path, env=env)
+    assert r.returncode == 0, r.stderr[-800:]
+    r = subprocess.run([sys.executable, "-m", "elodin_amd.compat", str(REF / "three-body" / "no_such_script.py")],
+                       capture_output=True, text=True, timeout=300, cwd=tmp_path, env=env)
+    assert r.returncode != 0 and "no_such_script" in r.stderr
