@@ -13,8 +13,11 @@
  * (tests/golden/make_falcon9_closed_loop.py: the reference's OWN plant + sensor systems stepped by this flight software)
  * pin the product's generated kernel against something that is not the product's tracer.
  *
- * Parity of this restatement itself: the Rust source has no tests and no vectors, so it is pinned by reading
- * only — every function cites the lines it follows.  libm calls are the ones Rust's f64 methods lower to on Linux.
+ * Parity of this restatement itself: PARITY UNPINNED by reference-held vectors — the Rust source has no tests and no vectors
+ *  and cannot be built here, so the state machine and the navigator are pinned by reading only (every function cites
+ * the lines it follows).  What of it can be checked against reference code run here is (tests/test_falcon9_fsw_oracle.py): the
+ * WGS84 helpers against the answers of the example's frames.py, the profile resampling against reference.py's interpolation.
+ * libm calls are the ones Rust's f64 methods lower to on Linux.
  */
 #include <math.h>
 #include <stdlib.h>
