@@ -54,6 +54,9 @@ def _to_trace(x):
     return x
 
 
+_MISSING = object()      # "attribute absent" sentinel: None is a legitimate value (newaxis)
+
+
 class _Dispatch(types.ModuleType):
     """A module whose functions exist twice: `traced` (elodin_amd.dsl.*) and `host` (numpy.*)."""
 
@@ -66,8 +69,12 @@ class _Dispatch(types.ModuleType):
         if name.startswith("__"):
             raise AttributeError(name)
         traced, host = self.__dict__["_traced"], self.__dict__["_host"]
-        t = getattr(traced, name, None) if traced is not None else None
-        h = getattr(host, name, None) if host is not None else None
+        if name == "newaxis":
+            return None                                  # numpy's / jnp's newaxis IS None
+        t = getattr(traced, name, _MISSING) if traced is not None else _MISSING
+        h = getattr(host, name, _MISSING) if host is not None else _MISSING
+        t = None if t is _MISSING else t
+        h = None if h is _MISSING else h
         if t is None and h is None:
             raise AttributeError(f"{self.__name__}.{name} is not provided by elodin_amd.compat")
         if h is not None and not callable(h):
@@ -81,7 +88,13 @@ class _Dispatch(types.ModuleType):
             tracing = _dsl.TRACING[0] > 0 or _symbolic(args) or _symbolic(kw)
             if tracing and t is not None:
                 kw.pop("dtype", None) if name not in ("array", "zeros", "ones", "asarray", "arange", "eye", "full") else None
-                return t(*[_to_trace(a) for a in args], **{k: _to_trace(v) for k, v in kw.items()})
+                try:
+                    return t(*[_to_trace(a) for a in args], **{k: _to_trace(v) for k, v in kw.items()})
+                except TypeError as err:
+                    if "unexpected keyword" in str(err):      # say which keyword of which function, not the tracer's internals
+                        raise NotImplementedError(f"{self.__name__}.{name}({', '.join(kw)}=...) on traced values: {err} "
+                                                  f"— not provided by elodin_amd.compat") from err
+                    raise
             if h is None:
                 if t is None:
                     raise AttributeError(f"{self.__name__}.{name}")

@@ -110,7 +110,10 @@ class Expr:
     shape = ()
     def __getitem__(self, k):
         """A component of shape (1,) is held as its one value: `mdot[0]` (examples/falcon9/sim.py:445) is that value."""
-        if k in (0, -1, Ellipsis, ()) or k == slice(None):
+        if isinstance(k, Expr):          # a traced index into the one element: jax clamps it, there is nothing else to read
+            return self                  # (tested before the membership check below: `expr in tuple` would call bool() on a traced ==)
+        if any(k is v for v in (Ellipsis,)) or (isinstance(k, tuple) and k == ()) or (isinstance(k, int) and k in (0, -1)) \
+                or (isinstance(k, slice) and k == slice(None)):
             return self
         raise IndexError("a scalar traced value has one element")
     def reshape(self, *shape):                        # `jnp.asarray(x[0]).reshape(())` (examples/falcon9/sim.py:1288): still the one value
@@ -143,9 +146,38 @@ def _lift(x) -> Expr:
     raise TypeError(f"cannot use {type(x).__name__} in a traced effector")
 
 
+def _nonneg(e: "Expr", depth: int = 0) -> bool:
+    """Provably >= 0 from the expression's shape alone (a clipped / counted / floored index): such an index needs no
+    negative-index normalisation, and the gather keeps the select chain it always had."""
+    if depth > 16:
+        return False
+    if e.op == "const":
+        return e.value >= 0.0
+    if e.op == "leaf":
+        return e.name in ("tick", "dt", "dt_g")                     # the tick counter (u64) and the time steps
+    if e.op in ("lt", "le", "eq", "ne", "and", "or", "not", "abs"):
+        return True                                                   # comparisons are 0 / 1
+    if e.op == "max":
+        return any(_nonneg(a, depth + 1) for a in e.args)
+    if e.op in ("add", "mul", "min"):
+        return all(_nonneg(a, depth + 1) for a in e.args)
+    if e.op in ("floor", "trunc", "ceil", "rint", "sqrt"):
+        return _nonneg(e.args[0], depth + 1)
+    if e.op == "select":
+        return _nonneg(e.args[1], depth + 1) and _nonneg(e.args[2], depth + 1)
+    return False
+
+
+def _normalise_index(idx: "Expr", n: int) -> "Expr":
+    """jax's treatment of a dynamic index: a negative one counts from the end (idx + n) before anything clamps or drops it."""
+    return idx if _nonneg(idx) else Expr("select", (idx < 0.0, idx + float(n), idx))
+
+
 def _dynamic_index(items, idx: "Expr"):
-    """items[idx] for a traced idx (jax clamps out-of-range gathers): selects on idx == k over scalars, vectors or rows."""
+    """items[idx] for a traced idx: selects on idx == k over scalars, vectors or rows.  Like jax's gather the index is
+    normalised first (a negative idx counts from the end: x[-1] is the last element) and THEN clamped into [0, n)."""
     n = len(items)
+    idx = _normalise_index(idx, n)
     out = items[n - 1]
     for k in range(n - 2, -1, -1):
         cond = idx < (k + 0.5)           # idx <= k (integral values): rows above the last match fall through, clamping both ends
@@ -325,8 +357,8 @@ class Vec:
 
 class _VecAt:
     """`v.at[i].set(x)` / `.add(x)` of jax for a static index or slice — or a TRACED index (`result.at[idx].set(1)`,
-    examples/linalg/sim.py:371-372): every element becomes a select on `idx == k`, indices wrapping like jax's negative ones do not
-    (an index outside [0, n) leaves the vector unchanged, jax's default scatter mode drops it)."""
+    examples/linalg/sim.py:371-372): every element becomes a select on `idx == k` after jax's normalisation of a negative index
+    (idx + n); an index still outside [0, n) leaves the vector unchanged (jax's default scatter mode drops it)."""
 
     def __init__(self, v): self.v = v
     def __getitem__(self, idx): return _VecAtIdx(self.v, idx)
@@ -339,7 +371,8 @@ class _VecAtIdx:
         e = list(self.v.e)
         if isinstance(self.idx, (Expr,)):
             val = _lift(value)
-            return Vec([Expr("select", (Expr("eq", (self.idx, const(float(k)))), combine(x, val), x)) for k, x in enumerate(e)])
+            idx = _normalise_index(self.idx, len(e))     # x.at[-1] is the last element, like jax
+            return Vec([Expr("select", (Expr("eq", (idx, const(float(k)))), combine(x, val), x)) for k, x in enumerate(e)])
         ks = list(range(len(e)))[self.idx] if isinstance(self.idx, slice) else [range(len(e))[int(self.idx)]]
         vals = list(value.e) if isinstance(value, Vec) else [_lift(value)] * len(ks)
         if len(vals) != len(ks):

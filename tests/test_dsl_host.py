@@ -473,3 +473,38 @@ def test_array_surface_added_for_the_unmodified_scripts_matches_numpy():
         return dsl._host(table)[i[0]], xp.sum(xp.broadcast_to(i, (3, 2)), axis=0)
     g, bsum = dsl_numpy.trace_eval(gather, np.array([2.0, 5.0]))
     assert g == 30.0 and np.allclose(bsum, [6.0, 15.0])
+
+
+def test_traced_negative_indices_follow_jax_and_scalar_getitem_takes_traced_keys():
+    """jax normalises a dynamic negative index before clamping (x[i] with i = -1 reads the LAST element, x.at[-1].set() updates
+    it); a traced key into a one-element value must not trip the membership test (`expr in tuple` would call bool())."""
+    v = np.array([10.0, 20.0, 30.0, 40.0])
+
+    def gather(xp, x, i):
+        return x[i[0]], x[i[1]], x[i[2]], x[i[3]]
+    assert dsl_numpy.trace_eval(gather, v, np.array([-1.0, -4.0, 2.0, 9.0])) == (40.0, 10.0, 30.0, 40.0)
+    assert dsl_numpy.trace_eval(gather, v, np.array([-9.0, -2.0, 0.0, 3.0])) == (10.0, 30.0, 10.0, 40.0)    # below -n clamps to 0
+
+    def scatter(xp, x, i):
+        return x.at[i[0]].set(-1.0), x.at[i[1]].add(5.0), x.at[i[2]].set(7.0)
+    a, b, c = dsl_numpy.trace_eval(scatter, v, np.array([-1.0, -3.0, 11.0]))
+    assert np.array_equal(a, [10, 20, 30, -1]) and np.array_equal(b, [10, 25, 30, 40]) and np.array_equal(c, v)   # out of range: dropped
+    s, k = dsl.leaf("s"), dsl.leaf("k")
+    assert s[k] is s and s[0] is s and s[-1] is s and s[...] is s and s[()] is s
+    with pytest.raises(IndexError):
+        s[1]
+
+
+def test_compat_dispatch_probes_with_a_sentinel_and_names_unsupported_keywords():
+    from elodin_amd import compat
+    compat.install(run="record")
+    try:
+        import jax.numpy as jnp
+        assert jnp.newaxis is None and jnp.pi == np.pi
+        with pytest.raises(AttributeError):
+            jnp.fft
+        x = dsl.Vec([dsl.leaf("a"), dsl.leaf("b")])
+        with pytest.raises(NotImplementedError, match="jax.numpy.clip"):
+            jnp.clip(x, 0.0, 1.0, out=None)
+    finally:
+        compat.uninstall()
