@@ -70,6 +70,7 @@ def _leaf_ref(name: str, table: Dict[str, str]) -> str:
 
 
 _TABLES: Dict[tuple, str] = {}    # (xp, fp) -> C++ symbol stem, filled while emitting one translation unit
+_GATHERS: Dict[str, str] = {}     # dsl gather-table key -> C++ symbol of its __device__ const array, same lifetime
 _WINDOWS: Dict[int, tuple] = {}    # window slot -> (rows, width, head slot) of the program being emitted (dsl.Window)
 # Device layout of a window column by executor size, fixed when the program is built (HipExec knows its row count; the object
 # says which one it was built for, bit 30 of sixdof_custom_column_widths): from this many entities on it is ELEMENT-major, [rows*width][n] — a wave reads 512 contiguous bytes per element (65,536 rockets:
@@ -178,6 +179,10 @@ class _Emitter:
                 if uniform:   # evenly spaced long table: index by division instead of bisecting through memory
                     return f"m_interp_uniform<T, {len(xs)}>({a[0]}, {stem}_x, {stem}_f, T({1.0 / step!r}))"
                 return f"m_interp<T, {len(xs)}>({a[0]}, {stem}_x, {stem}_f)"
+            if e.op == "gather":    # constant table in device memory (dsl.gather): jax's index normalisation + clamp in m_gather
+                key, col, n, w = e.value
+                stem = _GATHERS.setdefault(key, f"gtab{len(_GATHERS)}")
+                return f"m_gather<T>({stem}, {a[0]}, {n}, {w}, {col})"
             if e.op == "wload":     # logical row a[1] of the ring whose oldest row sits at physical row a[0]
                 slot, rows, width, j, _ = e.value
                 return f"W{slot}[(size_t)(((static_cast<int>({a[0]}) + static_cast<int>({a[1]})) % {rows}) * {width} + {j}) * w_n]"
@@ -627,6 +632,15 @@ SIXDOF_M2(m_pow, pow, m_fast_pow) SIXDOF_M2(m_hypot, hypot, m_fast_hypot)
 #else
 SIXDOF_M2(m_pow, pow, powf) SIXDOF_M2(m_hypot, hypot, hypotf)
 #endif
+// table[idx, col] for a constant table in device memory (dsl.gather): a negative index counts from the end, then the index
+// is clamped into [0, n) — jax's gather; a NaN index converts to 0.
+template <class T>
+__device__ __forceinline__ T m_gather(const double* __restrict__ tab, T idx, int n, int stride, int col) {
+    int i = static_cast<int>(idx);
+    i = i < 0 ? i + n : i;
+    i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    return T(tab[(size_t)i * stride + col]);
+}
 // jnp.interp over a constant table: i = clip(searchsorted(xp, x, 'right'), 1, N-1); fp[i-1] + (x-xp[i-1])/dx * df,
 // clamped to the end values outside the table.
 template <class T, int N>
@@ -671,6 +685,9 @@ __device__ __forceinline__ T m_interp_uniform(T x, const double (&xp)[N], const 
 
 def _emit_tables() -> str:
     out = []
+    for key, stem in _GATHERS.items():      # row-major [rows, cols], doubles whatever the program's dtype (read through m_gather)
+        t = dsl._GATHER_TABLES[key]
+        out.append(f"__device__ const double {stem}[{t.size}] = {{{', '.join(repr(float(v)) for v in t.reshape(-1))}}};")
     for (xs, fs), stem in _TABLES.items():
         out.append(f"__device__ const double {stem}_x[{len(xs)}] = {{{', '.join(repr(v) for v in xs)}}};")
         out.append(f"__device__ const double {stem}_f[{len(fs)}] = {{{', '.join(repr(v) for v in fs)}}};")
@@ -934,6 +951,7 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
     if fast_math and dtype != "float32":
         raise ValueError("fast_math applies to float32 programs only")
     _TABLES.clear()
+    _GATHERS.clear()
     T = {"float64": "double", "float32": "float"}[dtype]
     integ = {0: "kRk4", 1: "kSemiImplicit", 2: "kNone"}[integrator]
     is_prog = isinstance(tp, dsl.TracedProgram)
@@ -1082,6 +1100,7 @@ def _fold_is_additive(tf: "dsl.TracedFold") -> bool:
 def generate_pair_source(tf: "dsl.TracedFold") -> str:
     """A user-written edge_fold function as the PAIR functor of csrc/pair_kernel.hpp (f64, both integrators)."""
     _TABLES.clear()
+    _GATHERS.clear()
     body = "\n".join(emit_block([(f"acc[{k}]", e) for k, e in enumerate(tf.outputs)], _PAIR_LEAVES))
     tables = _emit_tables()
     additive = _fold_is_additive(tf)
@@ -1132,6 +1151,7 @@ def generate_graph_fold_source(tf: "dsl.TracedGraphFold") -> str:
     (CSR by source, spawn order) into a scratch row; a second kernel moves the rows into the output component, so every
     fold sees the component values from before the system ran."""
     _TABLES.clear()
+    _GATHERS.clear()
     f = tf.fold
     leaves = {f"acc_{k}": f"acc[{k}]" for k in range(tf.widths[f.out])}
     loads_a, loads_b = [], []

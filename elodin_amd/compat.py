@@ -132,6 +132,10 @@ class _HostArray(_np.ndarray):
 
     def __getitem__(self, idx):
         if _symbolic(idx) or (isinstance(idx, tuple) and any(_symbolic(k) for k in idx)):
+            # a long table (examples/monte-carlo/sim.py:84-97: 262,144 rows) is a gather from device memory, a short one a
+            # select chain in registers
+            if self.ndim <= 2 and self.shape[0] >= _dsl.GATHER_MIN_ROWS and (not isinstance(idx, tuple) or not _symbolic(idx[1:])):
+                return _dsl.HostTable(_np.asarray(self))[idx]
             return _dsl._host(_np.asarray(self))[idx]
         return super().__getitem__(idx)
 
@@ -259,6 +263,109 @@ class _Inert:
         return _Inert()
 
 
+class StepContext:
+    """el.StepContext (elodin.pyi:25-170) over an executor's host columns: what pre_step / post_step callbacks read and write.
+    The reference's callbacks talk to the database the world commits to; here the committed state IS the executor's host
+    columns (refreshed after every batch), and a write lands in them and is uploaded before the next batch runs
+    (copy_db_to_world, impeller2_server.rs:607-640)."""
+
+    def __init__(self, ex, world, dt: float, start_timestamp: int = 0):
+        self._ex, self._world, self._dt, self._t0 = ex, world, dt, int(start_timestamp or 0)
+        self._tick = 0
+        self._dirty = False
+        names = dict(world._names)
+        self._entity = {}
+        for eid, name in names.items():
+            self._entity[name] = eid
+            self._entity[_snake(name)] = eid
+        self._entity.update(world.entity_ids_by_name)
+
+    @property
+    def tick(self) -> int: return int(self._tick)
+
+    @property
+    def timestamp(self) -> int:                          # microseconds since the epoch: start + tick * time step
+        return self._t0 + int(round(self._tick * self._dt * 1e6))
+
+    def _locate(self, pair_name: str):
+        entity, _, comp = pair_name.rpartition(".")
+        if not entity or entity not in self._entity:
+            raise RuntimeError(f"component {pair_name!r} does not exist: no entity named {entity!r}")
+        eid = self._entity[entity]
+        cache = self._ex.__dict__.setdefault("_ctx_row_of", {})      # component -> {entity id: row}; entity sets never change
+        try:
+            col = self._ex.column_array(comp)
+            if comp not in cache:
+                cache[comp] = {int(e): k for k, e in enumerate(self._ex.column_ids(comp))}
+        except KeyError:
+            raise RuntimeError(f"component {pair_name!r} does not exist") from None
+        row = cache[comp].get(int(eid))
+        if row is None:
+            raise RuntimeError(f"component {pair_name!r} does not exist: entity {entity!r} does not carry {comp!r}")
+        return comp, col, row
+
+    def read_component(self, pair_name: str, timestamp=None):
+        _, col, row = self._locate(pair_name)
+        return _np.array(col[row], dtype=_np.float64)
+
+    def write_component(self, pair_name: str, data, timestamp=None) -> None:
+        comp, col, row = self._locate(pair_name)
+        data = _np.asarray(data, dtype=_np.float64).reshape(-1)
+        if data.size != col.shape[1]:
+            raise ValueError(f"component {pair_name!r}: {data.size} values for a component of {col.shape[1]}")
+        target = self._ex._main_column_array(comp)       # the executor's own host array (a view the upload reads)
+        if target.shape != col.shape or getattr(self._ex, "_body_rows", None) is not None or comp in getattr(self._ex, "_partial", {}):
+            raise NotImplementedError(f"StepContext.write_component({pair_name!r}): writes into a joined / partial column are not provided")
+        target[row] = data
+        self._dirty = True
+
+    def component_batch_operation(self, reads=(), writes=None, **kw):
+        out = {name: self.read_component(name) for name in (reads or ())}
+        for name, data in (writes or {}).items():
+            self.write_component(name, data)
+        return out
+
+    def truncate(self): raise NotImplementedError("StepContext.truncate is not provided by elodin_amd.compat (no database to rewind)")
+    def read_msg(self, *a, **k): raise NotImplementedError("StepContext.read_msg is not provided by elodin_amd.compat (no message log)")
+    def stop_recipes(self): return None
+
+
+def _snake(name: str) -> str:
+    out = []
+    for ch in str(name).strip():
+        out.append("_" if ch in " -" else ch.lower())
+    return "".join(out)
+
+
+def run_stepwise(ex, world, simulation_rate, telemetry_rate, max_ticks, pre_step, post_step, is_canceled=None, start_timestamp=None):
+    """The reference's server loop (impeller2_server.rs:553-678) around an executor: batches of ticks_per_telemetry ticks,
+    pre_step(first tick of the batch) -> columns the callback wrote go to the device -> the batch -> commit (host columns
+    refreshed) -> post_step(LAST tick of the batch)."""
+    tpt = max(1, int(round(simulation_rate / telemetry_rate))) if telemetry_rate else 1
+    ctx = StepContext(ex, world, 1.0 / float(simulation_rate), start_timestamp)
+    hip = ex._hip
+    tick = ex.tick
+    limit = int(max_ticks) if max_ticks else None
+    while limit is None or tick < limit:
+        if is_canceled is not None and is_canceled():
+            break
+        batch = tpt if limit is None else max(1, min(tpt, limit - tick))
+        ctx._tick = tick
+        if pre_step is not None:
+            pre_step(tick, ctx)
+        if ctx._dirty:
+            hip.upload()
+            ctx._dirty = False
+        ex.run(batch)
+        tick = ex.tick
+        ctx._tick = tick - 1                     # end_tick: the world now reflects the last tick of the batch
+        if post_step is not None:
+            post_step(tick - 1, ctx)
+    if ctx._dirty:
+        hip.upload()
+    return ctx
+
+
 def _make_elodin():
     el = types.ModuleType("elodin")
     el.__path__ = []
@@ -279,17 +386,32 @@ def _make_elodin():
         def glb(self, *a, **k): return None
         def sensor_camera(self, *a, **k): return None      # a rendered camera of the editor (examples/sensor-camera)
 
-        def run(self, system, simulation_rate: float = 120.0, max_ticks=None, telemetry_rate=None, post_step=None, **ignored):
+        def run(self, system, simulation_rate: float = 120.0, generate_real_time: bool = False, telemetry_rate=None,
+                default_playback_speed: float = 1.0, max_ticks=None, optimize: bool = False, is_canceled=None, pre_step=None,
+                post_step=None, db_path=None, interactive: bool = True, start_timestamp=None, log_level=None,
+                backend: str = "cranelift"):
+            """World.run with the reference's signature, in the reference's positional order (elodin/__init__.py:673-690).
+            Editor / database arguments (generate_real_time, default_playback_speed, db_path, interactive, log_level, optimize,
+            backend) have nothing to act on here and are recorded only.  `pre_step(tick, ctx)` / `post_step(end_tick, ctx)` run
+            on the server loop's cadence (impeller2_server.rs:553-678): per batch of ticks_per_telemetry ticks — pre_step with the
+            batch's first tick, the world's columns refreshed from what the callbacks wrote, the batch, the commit, post_step
+            with the batch's LAST tick — through a StepContext over the executor's host columns."""
             self.compat_run = dict(system=system, simulation_rate=simulation_rate, max_ticks=max_ticks, telemetry_rate=telemetry_rate,
-                                   post_step=post_step, ignored=ignored)
+                                   pre_step=pre_step, post_step=post_step, is_canceled=is_canceled, start_timestamp=start_timestamp,
+                                   ignored=dict(generate_real_time=generate_real_time, default_playback_speed=default_playback_speed,
+                                                optimize=optimize, db_path=db_path, interactive=interactive, log_level=log_level,
+                                                backend=backend))
             if _RUN_MODE[0] == "record":
                 return None
             ex = self.build(system, simulation_rate=simulation_rate, telemetry_rate=telemetry_rate)
-            if post_step is not None:
-                raise NotImplementedError("World.run(post_step=...) is not provided by elodin_amd.compat: step the executor yourself")
-            if max_ticks:
-                ex.run(int(max_ticks))
             self.compat_exec = ex
+            if pre_step is None and post_step is None and is_canceled is None:
+                if max_ticks:
+                    ex.run(int(max_ticks))
+                return ex
+            if not max_ticks and is_canceled is None:
+                raise ValueError("World.run with step callbacks needs max_ticks or is_canceled here (there is no editor to stop the loop)")
+            run_stepwise(ex, self, simulation_rate, telemetry_rate, max_ticks, pre_step, post_step, is_canceled, start_timestamp)
             return ex
     el.World = el.WorldBuilder = World
 

@@ -132,7 +132,19 @@ class Expr:
         return self.op == "const" and (v is None or self.value == v)
 
 
+# Campaign vectorisation (elodin_amd/vectorize.py): a sim script bakes a Monte-Carlo parameter into its traced code as a plain
+# Python float (`mass = float(params.get("mass"))`, examples/monte-carlo/sim.py:72-75).  While a campaign's program is traced the
+# parameters hold SENTINEL values; a constant that equals one is that parameter and becomes a per-run column `mc:<name>` of the
+# executor (one row per run) instead of a literal.
+PARAM_SENTINELS: Dict[float, str] = {}
+_ACTIVE_TABLE: List[Optional["ColumnTable"]] = [None]      # the column table of the system / pipe being traced
+
+
 def const(v: Number) -> Expr:
+    if PARAM_SENTINELS and _ACTIVE_TABLE[0] is not None:
+        name = PARAM_SENTINELS.get(float(v))
+        if name is not None:
+            return _ACTIVE_TABLE[0].symbols("mc:" + name, 1, 1)[0]
     return Expr("const", (), float(v))
 
 
@@ -185,6 +197,76 @@ def _dynamic_index(items, idx: "Expr"):
     return out
 
 
+# ---- constant tables in device memory: a traced gather --------------------------------------------------------------------
+# `table[idx, 0]` with `table` a host array of thousands of rows and `idx` computed per entity (examples/monte-carlo/sim.py:84-97:
+# a 262,144-row drag table; an EGM-style coefficient table is the same thing) cannot be a select chain.  The table becomes a
+# `__device__ const` array of the generated translation unit — in HBM once, shared by every entity — and the read a per-lane
+# global load.  jax's gather semantics: a negative index counts from the end, then the index is clamped into [0, rows).
+GATHER_MIN_ROWS = 33                        # shorter tables stay select chains (registers, no memory access)
+_GATHER_TABLES: Dict[str, "_numpy.ndarray"] = {}      # content key -> [rows, cols] float64
+
+
+def _gather_key(table) -> str:
+    import hashlib
+    t = _numpy.ascontiguousarray(table, dtype=_numpy.float64)
+    t = t.reshape(t.shape[0], -1)
+    key = "g" + hashlib.sha256(t.tobytes() + repr(t.shape).encode()).hexdigest()[:16]
+    _GATHER_TABLES.setdefault(key, t)
+    return key
+
+
+def gather(table, row, col: int = 0) -> "Expr":
+    """table[row, col] for a traced `row` (integral values) over a constant host table [rows] or [rows, cols]."""
+    key = _gather_key(table)
+    t = _GATHER_TABLES[key]
+    n, w = t.shape
+    col = int(col) + (w if int(col) < 0 else 0)
+    if not 0 <= col < w:
+        raise IndexError(f"column {col} of a table with {w} columns")
+    row = _lift(row)
+    if row.op == "const":
+        i = int(row.value)
+        i = i + n if i < 0 else i
+        return const(float(t[min(max(i, 0), n - 1), col]))
+    return Expr("gather", (row,), (key, col, n, w))
+
+
+class HostTable:
+    """A constant host array indexable by traced rows: `tab[i]`, `tab[i, c]`, `tab[rows_vec, c]` (each element a gather)."""
+
+    def __init__(self, array):
+        self.array = _numpy.ascontiguousarray(array, dtype=_numpy.float64)
+        if self.array.ndim not in (1, 2):
+            raise TypeError("a gather table has one or two dimensions")
+        self.shape = self.array.shape
+
+    def __len__(self): return self.shape[0]
+
+    def __getitem__(self, idx):
+        row, col = (idx if isinstance(idx, tuple) else (idx, None))
+        if isinstance(idx, tuple) and len(idx) != 2:
+            raise IndexError("a gather table is indexed [row] or [row, column]")
+        two_d = self.array.ndim == 2
+        if two_d and col is None:                      # a whole row of a 2-D table
+            cols = list(range(self.shape[1]))
+        elif two_d and isinstance(col, slice):
+            cols = list(range(self.shape[1]))[col]
+        elif two_d:
+            cols = int(col)
+        else:
+            if col is not None:
+                raise IndexError("too many indices for a 1-D table")
+            cols = 0
+        rows = row.e if isinstance(row, Vec) else ([_lift(x) for x in row] if isinstance(row, (list, tuple)) else None)
+
+        def one(r):
+            return Vec([gather(self.array, r, c) for c in cols]) if isinstance(cols, list) else gather(self.array, r, cols)
+        if rows is None:
+            return one(row)
+        out = [one(r) for r in rows]
+        return out if isinstance(cols, list) else Vec(out)
+
+
 def _is_host_array(o) -> bool:
     return isinstance(o, _numpy.ndarray) and o.ndim >= 1
 
@@ -213,8 +295,14 @@ TRACING = [0]
 
 
 class _Tracing:
-    def __enter__(self): TRACING[0] += 1
-    def __exit__(self, *a): TRACING[0] -= 1
+    """`with tracing(table):` — user code is being called on symbols; `table` (when given) is where columns it implies live."""
+    def __init__(self, table=None): self.table, self.saved = table, None
+    def __enter__(self):
+        TRACING[0] += 1
+        self.saved, _ACTIVE_TABLE[0] = _ACTIVE_TABLE[0], (self.table if self.table is not None else _ACTIVE_TABLE[0])
+    def __exit__(self, *a):
+        TRACING[0] -= 1
+        _ACTIVE_TABLE[0] = self.saved
 
 
 tracing = _Tracing
@@ -1464,7 +1552,7 @@ class TracedPipe:
                     kwargs[name] = inertia
                 else:
                     kwargs[name] = self.table.symbols(name, eff.widths.get(name), 3)
-            with tracing():
+            with tracing(self.table if self.table.prefix == "c" else None):      # a program's table holds `mc:` parameter columns too
                 out = eff.fn(**kwargs)
             if not isinstance(out, SpatialForce):
                 raise TypeError(f"effector {eff.__name__} must return a dsl.SpatialForce")
@@ -1731,7 +1819,7 @@ class TracedSystem:
             else:
                 v = table.symbols(name, sys_.widths.get(name), 1)
                 kwargs[name] = v if len(v) > 1 else v[0]
-        with tracing():
+        with tracing(table):
             out = sys_.fn(**kwargs)
         if not isinstance(out, dict):
             raise TypeError(f"system {self.name} must return a dict {{component: value}}")

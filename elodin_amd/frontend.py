@@ -44,6 +44,7 @@ from ._lib import BackendError  # noqa: F401
 
 np, lax, random = _dsl.np, _dsl.lax, _dsl.random
 Array = _np.ndarray          # stands where the reference's annotations say jax.Array
+table = _dsl.HostTable       # `jnp.asarray(big_host_array)` of a reference script: a constant table traced code gathers rows from
 
 
 # ---- component metadata (elodin.pyi:165-183,424-443) ---------------------------------------------------------------

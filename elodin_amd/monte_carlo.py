@@ -320,11 +320,18 @@ def port(name: str, default: Optional[int] = None) -> int:
     return default
 
 
+_active_result = [None]      # vectorize.Campaign: the record of the run whose callback is executing (all runs share the process)
+
+
 def result(**kwargs) -> None:
-    """Write the run's scalars to <run_dir>/result.json, where the campaign's post_run hook reads them."""
+    """Write the run's scalars to <run_dir>/result.json, where the campaign's post_run hook reads them.  Inside a vectorised
+    campaign (all runs in one process, elodin_amd/vectorize.py) they land in that run's record instead."""
     import json
     from pathlib import Path
     if not kwargs:
+        return
+    if _active_result[0] is not None:
+        _active_result[0].update({k: _jsonable(v) for k, v in kwargs.items()})
         return
     run_dir = params(None).run_dir
     if run_dir is None:

@@ -1,0 +1,211 @@
+"""A Monte-Carlo campaign of a reference sim script as ONE executor: rows = runs.
+
+The reference flies a campaign as one OS process per run (libs/monte-carlo/src/lib.rs:2083 `run_one`): each process calls
+the script's `build(params)` with its own parameter values, which the script bakes into the traced code as Python floats
+(`mass = float(params.get("mass", 1.5))`, examples/monte-carlo/sim.py:72-75) and into the spawned components
+(`el.C(Velocity, jnp.array([wind]))`).  On a GPU the runs are rows of one world:
+
+* the program is traced ONCE, with every parameter holding a distinctive sentinel value; a constant that equals a sentinel is
+  that parameter and becomes a per-run column `mc:<name>` (elodin_amd.dsl.PARAM_SENTINELS).  Tracing twice with two sentinel
+  sets and comparing the generated sources proves that no parameter reached the code in a form the tracer could not see
+  (host arithmetic on a parameter before the traced function — `k = 2.0 * mass` outside it — would differ between the two
+  and is refused: such a script needs one program per run);
+* the spawned components are read from `build(params_i)` run on the host for every run (its traced function is never
+  called), entity e of run i becoming row i * E + e;
+* `post_step(tick, ctx)` callbacks — how the reference's scripts exchange with their controllers — are called per run with a
+  StepContext that sees that run's entities under their own names, on the server loop's cadence (compat.run_stepwise);
+  `el.monte_carlo.result(...)` lands in the run's result record instead of <run_dir>/result.json.
+
+Used by tests/test_gpu_monte_carlo_example.py and bench.py's `monte_carlo_example` leg on examples/monte-carlo.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, List, Mapping, Optional, Sequence
+
+import numpy as np
+
+from . import api as _api
+from . import dsl as _dsl
+from . import monte_carlo as _mc
+
+
+def _sentinels(names: Sequence[str], spec: Optional[_mc.ParamsSpec], variant: int) -> Dict[str, float]:
+    """One distinctive value per parameter inside its declared [min, max]: irrational-looking fractions no literal of a
+    script will equal, different for the two variants."""
+    out = {}
+    for k, name in enumerate(names):
+        p = spec.params.get(name) if spec is not None else None
+        lo = float(p.min) if p is not None and p.min is not None else 0.5
+        hi = float(p.max) if p is not None and p.max is not None else 1.5
+        frac = ((k + 1) * 0.6180339887498949 + (0.2718281828459045 if variant else 0.1414213562373095)) % 1.0
+        out[name] = lo + (hi - lo) * (0.05 + 0.9 * frac)
+    if len(set(out.values())) != len(out):
+        raise RuntimeError("sentinel values collide")
+    return out
+
+
+class _sentinel_scope:
+    def __init__(self, values: Mapping[str, float]): self.map = {float(v): k for k, v in values.items()}
+    def __enter__(self):
+        self.saved = dict(_dsl.PARAM_SENTINELS)
+        _dsl.PARAM_SENTINELS.clear()
+        _dsl.PARAM_SENTINELS.update(self.map)
+    def __exit__(self, *a):
+        _dsl.PARAM_SENTINELS.clear()
+        _dsl.PARAM_SENTINELS.update(self.saved)
+
+
+def _entities(world: _api.World) -> Dict[int, Dict[str, np.ndarray]]:
+    """{entity id: {component: row}} of a spawned world, ids ascending."""
+    out: Dict[int, Dict[str, np.ndarray]] = {}
+    for cname in world._components:
+        rows, ids = world.column(cname)
+        for row, eid in zip(rows, ids):
+            out.setdefault(int(eid), {})[cname] = row
+    return dict(sorted(out.items()))
+
+
+def plan_of(param_rows: Sequence[Mapping[str, float]]) -> _mc.Plan:
+    """A plan from explicit parameter rows (run ids / seeds numbered like sample.py:149 does: run_%07d, seed = index)."""
+    names = sorted({k for r in param_rows for k in r})
+    return _mc.Plan(headers=["run_id", "seed"] + [f"param.{n}" for n in names],
+                    rows=[{f"param.{n}": r[n] for n in names if n in r} for r in param_rows],
+                    run_ids=[f"run_{i:07d}" for i in range(len(param_rows))], seeds=np.arange(len(param_rows), dtype=np.uint64))
+
+
+class Campaign:
+    """`build(params) -> (world, system)` of a sim script over the rows of a plan, as one executor.
+
+    plan: monte_carlo.Plan; spec: the script's el.monte_carlo.params_spec (defaults / bounds); world_cls: the World class the
+    script used (elodin_amd.frontend.World, or compat's el.World)."""
+
+    def __init__(self, build: Callable, plan: _mc.Plan, spec: Optional[_mc.ParamsSpec] = None, *, simulation_rate: float = 120.0,
+                 telemetry_rate: Optional[float] = None, device: int = 0, world_cls=None, dry: bool = False):
+        self.plan, self.spec = plan, spec
+        self.names = list(plan.param_names)
+        defaults = {k: p.default for k, p in spec.params.items()} if spec is not None else {}
+        self.table = plan.table(self.names, defaults)
+        self.n_runs = len(plan)
+        self.simulation_rate, self.telemetry_rate = float(simulation_rate), telemetry_rate
+        if self.n_runs == 0:
+            raise ValueError("an empty plan")
+
+        def built(values, ctx=None):
+            w, system = build(_mc.Params({**defaults, **values}, ctx))
+            return w, system
+
+        # -- the program: traced under two sentinel sets, the sources must agree ------------------------------------------
+        sources = []
+        for variant in (0, 1):
+            sent = _sentinels(self.names, spec, variant)
+            w, system = built(sent)
+            for eid in _entities(w):
+                w.insert(_api.EntityId(eid), [_api.C("mc:" + n, [sent[n]]) for n in self.names])
+            with _sentinel_scope(sent):
+                sources.append(w.generated_sources(system, simulation_rate=simulation_rate))
+            if variant == 0:
+                self._system, self._sent = system, sent
+        if sources[0] != sources[1]:
+            raise NotImplementedError(
+                "this script's code depends on a Monte-Carlo parameter in a way the tracer cannot see (host arithmetic on the "
+                "parameter before the traced function): the campaign cannot share one program — build one executor per run")
+        self.sources = sources[0]
+
+        # -- the world: every run's spawned entities, run-major ------------------------------------------------------------
+        from . import frontend as _fe
+        self.world = (world_cls or _fe.World)()
+        self.entity_names: List[Dict[str, int]] = []          # per run: the script's entity name -> entity id in the big world
+        self.entities_per_run = None
+        for i in range(self.n_runs):
+            values = {n: float(self.table[i, k]) for k, n in enumerate(self.names)}
+            w, _ = built(values, plan.context(i))
+            ents = _entities(w)
+            if self.entities_per_run is None:
+                self.entities_per_run = len(ents)
+            elif len(ents) != self.entities_per_run:
+                raise NotImplementedError("runs of one campaign spawn different numbers of entities")
+            local_to_big, names = {}, {}
+            for eid, comps in ents.items():
+                arch = [_api.C(c, row) for c, row in comps.items()] + [_api.C("mc:" + n, [values[n]]) for n in self.names]
+                big = self.world.spawn(arch, name=f"{plan.run_ids[i]}.{w._names.get(eid, eid)}")
+                local_to_big[eid] = int(big)
+                if eid in w._names:
+                    names[w._names[eid]] = int(big)
+            for nm, eid in w.entity_ids_by_name.items():
+                names[nm] = local_to_big[eid]
+            for comp, pairs in w._edges.items():
+                for a, b in pairs:
+                    self.world.insert(_api.EntityId(local_to_big[a]), [_api.GravityEdge(local_to_big[a], local_to_big[b], comp)])
+            self.entity_names.append(names)
+        self.exec = None
+        if not dry:
+            with _sentinel_scope(self._sent):
+                kw = {"history": False} if "history" in self.world.build.__code__.co_varnames else {}
+                self.exec = self.world.build(self._system, simulation_rate=simulation_rate, telemetry_rate=telemetry_rate,
+                                             device=device, **kw)
+        self.results: List[Dict[str, Any]] = [dict() for _ in range(self.n_runs)]
+
+    # ---------------------------------------------------------------------------------------------------------------------
+    def run(self, max_ticks: int, post_step: Optional[Callable] = None, pre_step: Optional[Callable] = None) -> "Campaign":
+        """The server loop over all runs in lock-step.  Callbacks are the script's own, called once per run and batch with that
+        run's StepContext (a write is uploaded before the next batch).  Without callbacks: one launch sequence, no host work."""
+        ex = self.exec
+        if post_step is None and pre_step is None:
+            ex.run(int(max_ticks))
+            return self
+        from . import compat as _compat
+        tpt = max(1, int(round(self.simulation_rate / self.telemetry_rate))) if self.telemetry_rate else 1
+        ctxs = []
+        for i in range(self.n_runs):
+            c = _compat.StepContext(ex, self.world, 1.0 / self.simulation_rate)
+            c._entity = dict(self.entity_names[i])
+            c._entity.update({_compat._snake(k): v for k, v in self.entity_names[i].items()})
+            c.run_index, c.run_id = i, self.plan.run_ids[i]          # beyond the reference's StepContext: which run this is
+            ctxs.append(c)
+        tick, limit = ex.tick, int(max_ticks)
+        saved = _mc._active_result[0]
+        try:
+            while tick < limit:
+                batch = max(1, min(tpt, limit - tick))
+                if pre_step is not None:
+                    for i, c in enumerate(ctxs):
+                        c._tick = tick
+                        _mc._active_result[0] = self.results[i]
+                        pre_step(tick, c)
+                if any(c._dirty for c in ctxs):
+                    ex._hip.upload()
+                    for c in ctxs:
+                        c._dirty = False
+                ex.run(batch)
+                tick = ex.tick
+                if post_step is not None:
+                    for i, c in enumerate(ctxs):
+                        c._tick = tick - 1
+                        _mc._active_result[0] = self.results[i]
+                        post_step(tick - 1, c)
+            if any(c._dirty for c in ctxs):
+                ex._hip.upload()
+        finally:
+            _mc._active_result[0] = saved
+        return self
+
+    def traced(self):
+        """(TracedProgram, {column: initial rows}, dt) of the campaign's program without a device: what a CPU walk of the
+        trace needs (tests/dsl_numpy.py)."""
+        with _sentinel_scope(self._sent):
+            plan = self.world.build(self._system, simulation_rate=self.simulation_rate, telemetry_rate=self.telemetry_rate, _dry=True)
+            tp = plan["effectors"].trace()
+        return tp, {n: np.asarray(plan["columns"][n], dtype=np.float64) for n, _ in tp.columns}, plan["dt"]
+
+    def column(self, component: str) -> np.ndarray:
+        """[n_runs * entities carrying it, w] rows of a component, run-major."""
+        return np.asarray(self.exec.column_array(component))
+
+    def result_table(self, names: Sequence[str]) -> np.ndarray:
+        """The runs' `el.monte_carlo.result(...)` records as [n_runs, len(names)] (NaN where a run reported nothing)."""
+        out = np.full((self.n_runs, len(names)), np.nan)
+        for i, rec in enumerate(self.results):
+            for k, n in enumerate(names):
+                if n in rec:
+                    out[i, k] = float(rec[n])
+        return out

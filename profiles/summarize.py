@@ -67,6 +67,15 @@ for grid, c in sorted(pmc.items()):
         traffic[str(grid)] = {"fetch_size_kib_raw": f, "write_size_kib": w, "read_bytes": rd, "write_bytes": wr,
                               "hbm_bytes_per_launch": rd + wr, "correction": "FETCH_SIZE x2 (gfx950), KiB units"}
         lines.append(f"| {grid} | {f:.1f} | {rd:.0f} | {w:.1f} | {wr:.0f} | {rd+wr:.0f} | {384*grid} |")
+# stamp: the collection is valid for THESE kernel sources (bench.py reports traffic: null once they change)
+import hashlib
+import os
+from pathlib import Path
+root = Path(__file__).resolve().parent.parent
+h = hashlib.sha256()
+for name in ("step_kernel.hpp", "effectors.hpp", "spatial.hpp", "kernels.hpp", "sixdof_kernels.hip"):      # = bench.STEP_KERNEL_SOURCES
+    h.update((root / "elodin_amd" / "csrc" / name).read_bytes())
+traffic["_stamp"] = {"step_kernel_hash": h.hexdigest()[:16], "tag": tag, "commit": os.environ.get("SIXDOF_COMMIT", "unknown (no .git on the GPU box)")}
 open(f"{out}/summary_{tag}.md", "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(f"{out}/pmc_traffic.json", "w"), indent=1)
 print("\n".join(lines))

@@ -134,6 +134,12 @@ def _eval(exprs, leaves, n):
             r = np.where(ev(e.args[0]), ev(e.args[1]), ev(e.args[2]))
         elif e.op == "interp":
             r = np.interp(ev(e.args[0]), np.array(e.value[0]), np.array(e.value[1]))
+        elif e.op == "gather":      # constant table in device memory: negative rows count from the end, then clamp (jax's gather)
+            from elodin_amd import dsl as _dsl
+            key, col, rows, _w = e.value
+            i = np.nan_to_num(np.broadcast_to(ev(e.args[0]), (n,)), nan=0.0).astype(np.int64)
+            i = np.clip(np.where(i < 0, i + rows, i), 0, rows - 1)
+            r = _dsl._GATHER_TABLES[key][i, col]
         elif e.op == "threefry":
             r = _threefry(*[np.broadcast_to(ev(a), (n,)) for a in e.args])[e.value]
         elif e.op == "wload":

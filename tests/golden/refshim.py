@@ -99,11 +99,19 @@ class _JnpModule(types.ModuleType):
         call.__name__ = name
         return call
 
+    @staticmethod
+    def _dtype(x, dtype):
+        # data that already IS an integer numpy array keeps its type, like jax (`jnp.asarray(np.linspace(..., dtype=np.int32))`,
+        # examples/monte-carlo/sim.py:65: row indices); everything else is float64 (jax_enable_x64, Python lists of numbers)
+        if dtype is None and isinstance(x, (np.ndarray, np.generic)) and np.asarray(x).dtype.kind in "iub":
+            return np.asarray(x).dtype
+        return np.float64 if dtype is None else dtype
+
     def array(self, x, dtype=None):
-        return np.array(x, dtype=np.float64 if dtype is None else dtype).view(JArray)
+        return np.array(x, dtype=self._dtype(x, dtype)).view(JArray)
 
     def asarray(self, x, dtype=None):
-        return np.asarray(x, dtype=np.float64 if dtype is None else dtype).view(JArray)
+        return np.asarray(x, dtype=self._dtype(x, dtype)).view(JArray)
 
     def zeros(self, shape, dtype=None):
         return np.zeros(shape, dtype=np.float64 if dtype is None else dtype).view(JArray)

@@ -58,7 +58,8 @@ EXPECTED = {
     "voyager/main.py": "spiceypy",                    # third-party ephemeris library, not in this image
     "db-client/main.py": "elodin.db",                 # a database client, no simulation
     "betaflight-sitl/main.py": "betaflight_SITL.elf",  # needs the Betaflight SITL binary (the script says so and exits)
-    "monte-carlo/main.py": "Expr",                    # gathers from a large lookup table by traced row indices (not built: select chains only)
+    "monte-carlo/main.py": "traced",                  # its 262,144-row lookup table is a gather from device memory (dsl.gather); the
+                                                      # campaign itself runs as one executor: tests/test_monte_carlo_example.py
 }
 
 

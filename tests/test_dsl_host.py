@@ -508,3 +508,25 @@ def test_compat_dispatch_probes_with_a_sentinel_and_names_unsupported_keywords()
             jnp.clip(x, 0.0, 1.0, out=None)
     finally:
         compat.uninstall()
+
+
+def test_gather_from_a_constant_device_table_follows_jax_and_generates_a_load():
+    """dsl.gather / HostTable: `table[idx, 0]`, `table[rows_vec, 0]` with traced rows over a table too long for a select chain
+    (examples/monte-carlo/sim.py:84-97).  jax's gather: negative rows count from the end, then clamp."""
+    rng = np.random.default_rng(3)
+    table = rng.normal(size=(500, 2))
+    tab = dsl.HostTable(table)
+
+    def lookups(xp, i):
+        rows = (dsl._host(np.arange(3.0) * 7.0) + i[0]) % 500.0
+        return tab[i[0], 0], tab[i[1], 1], tab[i[2], 0], tab[i[3], 1], xp.sum(tab[rows, 0]), tab[i[0]]
+    a, b, c, d, e, row = dsl_numpy.trace_eval(lookups, np.array([17.0, -1.0, 900.0, -900.0]))
+    assert (a, b, c, d) == (table[17, 0], table[-1, 1], table[499, 0], table[0, 1])
+    assert e == table[[17, 24, 31], 0].sum() and np.array_equal(row, table[17])
+    assert dsl.gather(table, 3, 1).is_const(table[3, 1])            # a constant row folds
+
+    @dsl.system(x=1, y=1)
+    def look(x, y):
+        return {"y": tab[dsl.np.clip(dsl.np.abs(x * 10.0).astype(int), 0, 499), 0] + y * 0.0}
+    src = codegen.generate_source(dsl.Program([look], dsl.pipe(), []).trace({"x": 1, "y": 1}), "float64", 2)
+    assert "m_gather<T>(gtab0," in src and "__device__ const double gtab0[1000]" in src
