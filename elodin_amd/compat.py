@@ -91,6 +91,10 @@ class _Dispatch(types.ModuleType):
                 try:
                     return t(*[_to_trace(a) for a in args], **{k: _to_trace(v) for k, v in kw.items()})
                 except TypeError as err:
+                    if h is not None and not (_symbolic(args) or _symbolic(kw)):
+                        # concrete data only, in a shape the tracer has no value for (a 4-D coefficient grid assembled inside a
+                        # decorated function, examples/rocket/main.py:236-252): plain numpy — it is a constant of the program
+                        return h(*args, **kw)
                     if "unexpected keyword" in str(err):      # say which keyword of which function, not the tracer's internals
                         raise NotImplementedError(f"{self.__name__}.{name}({', '.join(kw)}=...) on traced values: {err} "
                                                   f"— not provided by elodin_amd.compat") from err
@@ -186,6 +190,14 @@ class _TracedScipyLinalg:
     def det(a): return _mat.det(a)
 
 
+class _TracedScipyNdimage:
+    """jax.scipy.ndimage.map_coordinates over a constant grid at traced coordinates (examples/rocket/main.py:9,368)."""
+
+    @staticmethod
+    def map_coordinates(input, coordinates, order, mode="constant", cval=0.0):      # noqa: A002  (jax's argument name)
+        return _dsl.map_coordinates(_np.asarray(input), coordinates, order, mode=mode, cval=cval)
+
+
 class _TracedScipySpecial:
     """jax.scipy.special calls met in the reference's examples (examples/stablehlo/sim.py:158)."""
     erfc = staticmethod(_dsl.np.erfc)
@@ -209,9 +221,11 @@ def _make_jax():
     jsl = _Dispatch("jax.scipy.linalg", _TracedScipyLinalg, _sla)
     import scipy.special as _ssp
     jsp = _Dispatch("jax.scipy.special", _TracedScipySpecial, _ssp)
+    import scipy.ndimage as _snd
+    jnd = _Dispatch("jax.scipy.ndimage", _TracedScipyNdimage, _snd)
     jscipy = types.ModuleType("jax.scipy")
     jscipy.__path__ = []
-    jscipy.linalg, jscipy.special = jsl, jsp
+    jscipy.linalg, jscipy.special, jscipy.ndimage = jsl, jsp, jnd
     jax.numpy, jax.lax, jax.random, jax.scipy = jnp, lax, rnd, jscipy
     jax.__path__ = []                                   # a package: `from jax.typing import ArrayLike`
     jax.Array = _np.ndarray
@@ -249,7 +263,7 @@ def _make_jax():
         return mapped
     jax.vmap = vmap
     return {"jax": jax, "jax.numpy": jnp, "jax.numpy.linalg": la, "jax.lax": lax, "jax.random": rnd, "jax.scipy": jscipy,
-            "jax.scipy.linalg": jsl, "jax.scipy.special": jsp, "jax.typing": jtyping}
+            "jax.scipy.linalg": jsl, "jax.scipy.special": jsp, "jax.scipy.ndimage": jnd, "jax.typing": jtyping}
 
 
 class _Inert:
@@ -459,7 +473,11 @@ def install(run: str = "execute", inert=()) -> None:
             try:
                 __import__(name)
             except ImportError:
-                _INSTALLED[name] = sys.modules[name] = types.ModuleType(name)
+                if name == "polars":         # not an empty stand-in: the pandas-backed subset (compat_polars)
+                    from . import compat_polars
+                    _INSTALLED[name] = sys.modules[name] = compat_polars.module()
+                else:
+                    _INSTALLED[name] = sys.modules[name] = types.ModuleType(name)
     if "elodin" in _INSTALLED:
         return
     for name in ("jax", "elodin"):
@@ -473,6 +491,12 @@ def install(run: str = "execute", inert=()) -> None:
         except ImportError:
             pass
     mods = _make_jax()
+    if "polars" not in sys.modules:      # host-side table preparation of example scripts: a pandas-backed subset when polars is absent
+        try:
+            __import__("polars")
+        except ImportError:
+            from . import compat_polars
+            mods["polars"] = compat_polars.module()
     mods["elodin"] = _make_elodin()
     mods["elodin.elodin"], mods["elodin.egm08"] = mods["elodin"].elodin, mods["elodin"].egm08
     sys.modules.update(mods)

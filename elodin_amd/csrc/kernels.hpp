@@ -16,7 +16,7 @@
 namespace sixdof {
 
 constexpr int kMaxOps = 4;       // per-entity effector ops fused into the step kernel
-constexpr int kMaxModelCols = 64; // component columns a generated program keeps in registers
+constexpr int kMaxModelCols = 128; // component columns of a generated program (kernarg: 2 pointers each; 128 keep StepParams at 2.4 KB of the 4 KB limit)
 constexpr int kBlock = 256;      // threads per workgroup = entities per workgroup (4 waves of 64)
 
 // One effector op as the kernel sees it (sixdof_effector_op with the aux column resolved).

@@ -267,6 +267,60 @@ class HostTable:
         return out if isinstance(cols, list) else Vec(out)
 
 
+def map_coordinates(grid, coordinates, order: int = 1, mode: str = "constant", cval: float = 0.0):
+    """jax.scipy.ndimage.map_coordinates(input, coordinates, order, mode, cval) for a CONSTANT n-d `grid` and one traced
+    coordinate per axis (examples/rocket/main.py:368: a 3 x 5 x 4 aerodynamic table interpolated at (Mach, fin deflection,
+    angle of attack)).  order 0 (nearest sample) or 1 (multilinear); modes "nearest" (indices clamped to the grid) and
+    "constant" (samples outside it read `cval`).  Same arithmetic, in the same order, as jax's _map_coordinates: per axis
+    lower = floor(c), weights (1 - (c - lower), c - lower); contributions grid[corner] * (w0 * w1 * ...) summed over
+    itertools.product of the per-axis (index, weight) pairs, first axis slowest.  Corner values come from the flattened grid
+    by a traced linear index: a select chain for small grids, a gather from device memory for larger ones."""
+    import itertools
+    g = _numpy.ascontiguousarray(grid, dtype=_numpy.float64)
+    coords = list(coordinates.e) if isinstance(coordinates, Vec) else list(coordinates)
+    if len(coords) != g.ndim:
+        raise ValueError("coordinates must be a sequence of length input.ndim")
+    if order not in (0, 1):
+        raise NotImplementedError("map_coordinates: order must be 0 or 1")
+    if mode not in ("nearest", "constant"):
+        raise NotImplementedError(f"map_coordinates: mode {mode!r} is not provided (nearest, constant)")
+    flat = g.reshape(-1)
+    strides = [int(_numpy.prod(g.shape[a + 1:])) for a in range(g.ndim)]
+    per_axis = []
+    for c, size in zip(coords, g.shape):
+        c = _lift(c)
+        if order == 0:
+            items = [(_un("rint", c), const(1.0))]        # round half to even, like jnp.round
+        else:
+            lower = _un("floor", c)
+            upper_weight = c - lower
+            items = [(lower, 1.0 - upper_weight), (lower + 1.0, upper_weight)]
+        fixed = []
+        for index, weight in items:
+            inside = (index > -0.5) & (index < size - 0.5) if mode == "constant" else None
+            fixed.append((_Np.clip(index, 0.0, float(size - 1)), weight, inside))
+        per_axis.append(fixed)
+    table = HostTable(flat) if flat.size >= GATHER_MIN_ROWS else Vec([float(v) for v in flat])
+    total = None
+    for items in itertools.product(*per_axis):
+        lin = None
+        for (index, _, _), stride in zip(items, strides):
+            term = index * float(stride)
+            lin = term if lin is None else lin + term
+        value = table[lin]
+        if mode == "constant":
+            ok = None
+            for _, _, inside in items:
+                ok = inside if ok is None else (ok & inside)
+            value = _Np.where(ok, value, float(cval))
+        weight = None
+        for _, w, _ in items:
+            weight = w if weight is None else weight * w
+        contribution = value * weight
+        total = contribution if total is None else total + contribution
+    return total
+
+
 def _is_host_array(o) -> bool:
     return isinstance(o, _numpy.ndarray) and o.ndim >= 1
 
@@ -1998,10 +2052,13 @@ class TracedFoldStage:
         self.every, self.phase, self.also_at, self.reads_accel, self.writes_inertia = 1, 0, None, False, False
 
 
+MAX_PROGRAM_COLUMNS = 128      # = csrc/kernels.hpp kMaxModelCols (two kernarg pointers per column)
+
+
 class TracedProgram:
     def __init__(self, prog: Program, widths: Optional[Dict[str, int]] = None, partial: Sequence[str] = (), fold_edges=None,
                  fold_replicas: Optional[Tuple[int, int]] = None):
-        self.table = ColumnTable("c", 64, _MAT_MAX_ELEMS, widths)
+        self.table = ColumnTable("c", MAX_PROGRAM_COLUMNS, _MAT_MAX_ELEMS, widths)
         self.partial = tuple(partial)
         fold_edges = fold_edges or {}
         n_folds = [0]

@@ -286,7 +286,7 @@ int sixdof_bind_world(sixdof_handle* h, sixdof_world* w);
  * builds it with hipcc for gfx950 and hands the shared object to this call.  `aux_component_ids` name the bound
  * per-entity columns the generated code uses, in the order it indexes them: first the read-only effector
  * columns (row width 1..3, <= 4), then — for whole programs `pre | six_dof(effectors) | post` — the component
- * columns its systems read AND write (row width 1..64 — a small matrix component is its row-major flattening —, <= 64 columns; fetch them back with sixdof_download_column).
+ * columns its systems read AND write (row width 1..64 — a small matrix component is its row-major flattening —, <= 128 columns; fetch them back with sixdof_download_column).
  * A WINDOW column (a wide component such as the rocket example's 480 x 3 sample buffer, examples/rocket/main.py:91-98)
  * is bound like any other ([n, rows*width] elements) but stays in HBM, in the layout the generated object was built for: entity-major
  * (the reference's rows; small executors) or ELEMENT-major — buffer[e * n + entity] for e < rows*width, so that lane-adjacent

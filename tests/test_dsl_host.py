@@ -530,3 +530,63 @@ def test_gather_from_a_constant_device_table_follows_jax_and_generates_a_load():
         return {"y": tab[dsl.np.clip(dsl.np.abs(x * 10.0).astype(int), 0, 499), 0] + y * 0.0}
     src = codegen.generate_source(dsl.Program([look], dsl.pipe(), []).trace({"x": 1, "y": 1}), "float64", 2)
     assert "m_gather<T>(gtab0," in src and "__device__ const double gtab0[1000]" in src
+
+
+def test_map_coordinates_follows_jax_on_constant_grids():
+    """dsl.map_coordinates (jax.scipy.ndimage.map_coordinates, examples/rocket/main.py:368) against a numpy restatement of
+    jax's _map_coordinates — bit for bit, both modes, orders 0 and 1 — and against scipy where the two libraries agree
+    (mode="nearest"); a grid of 33+ samples is read from device memory (dsl.gather), a smaller one through selects."""
+    import itertools
+    from scipy import ndimage
+
+    def jax_mc(g, c, order, mode, cval):
+        per = []
+        for x, size in zip(c, g.shape):
+            if order == 0:
+                items = [(np.round(x), 1.0)]
+            else:
+                lo = np.floor(x)
+                uw = x - lo
+                items = [(lo, 1 - uw), (lo + 1, uw)]
+            per.append([(int(np.clip(i, 0, size - 1)), ((0 <= i) & (i < size)) if mode == "constant" else True, w) for i, w in items])
+        out = 0.0
+        for items in itertools.product(*per):
+            idxs, valids, ws = zip(*items)
+            w = ws[0]
+            for k in ws[1:]:
+                w = w * k
+            out = out + (g[idxs] if all(valids) else cval) * w
+        return out
+    rng = np.random.default_rng(5)
+    for shape in ((3, 5, 4), (3, 4), (40,)):
+        g = rng.normal(size=shape)
+        for _ in range(12):
+            c = np.array([rng.uniform(-1.5, s + 0.5) for s in shape])
+            for order in (0, 1):
+                for mode in ("nearest", "constant"):
+                    got = dsl_numpy.trace_eval(lambda xp, cc: dsl.map_coordinates(g, [cc[k] for k in range(len(shape))], order, mode=mode, cval=0.25),
+                                               np.concatenate([c, [0.0]]))
+                    assert got == jax_mc(g, c, order, mode, 0.25), (shape, order, mode, c)
+                    if mode == "nearest":
+                        assert abs(got - ndimage.map_coordinates(g, c.reshape(-1, 1), order=order, mode=mode)[0]) < 1e-14
+    with pytest.raises(NotImplementedError):
+        dsl.map_coordinates(np.zeros((2, 2)), [dsl.leaf("a"), dsl.leaf("b")], 3)
+
+
+def test_polars_subset_over_pandas_builds_the_rocket_examples_grid():
+    """elodin_amd/compat_polars.py: the calls examples/rocket/main.py:150-262 makes, checked on a table of the same shape."""
+    from elodin_amd import compat_polars
+    pl = compat_polars.module()
+    mach, delta, alpha = [0.1, 0.5], [-20.0, 0.0, 20.0], [0.0, 5.0]
+    rows = [(m, d, a) for m in mach for d in delta for a in alpha]
+    df = pl.from_dict({"Mach": [r[0] for r in rows], "Alphac": [r[2] for r in rows], "Delta": [r[1] for r in rows],
+                       "CA": [100 * r[0] + r[1] + 0.1 * r[2] for r in rows], "CZ": [float(k) for k in range(len(rows))]})
+    coefs = ["CA", "CZ"]
+    grid = np.array([[sub2.group_by(["Alphac"], maintain_order=True).agg(pl.col(coefs).min()).select(pl.col(coefs)).to_numpy()
+                      for _, sub2 in sub.group_by(["Delta"], maintain_order=True)] for _, sub in df.group_by(["Mach"], maintain_order=True)])
+    assert grid.shape == (2, 3, 2, 2)
+    assert grid[1, 2, 1, 0] == 100 * 0.5 + 20.0 + 0.5 and grid[0, 1, 1, 1] == 3.0
+    s = df["Delta"]
+    assert (s.min(), s.max(), len(s.unique())) == (-20.0, 20.0, 3)
+    with pytest.raises(AttributeError):
+        pl.scan_csv

@@ -1,5 +1,6 @@
 """Randomly generated programs through the tracer + code generator + hipcc + the fused step kernel, against the numpy
-interpreter evaluating the SAME traced DAG (tests/dsl_numpy.py).  The generator is seeded, so the set of programs is
+interpreter evaluating the SAME traced DAG (tests/dsl_numpy.py) AND against an independent plain-numpy twin of each program
+drawn from the same seed (tests/fuzz_gen.py: pins the tracer itself, tests/test_fuzz_twin.py shows it catches seeded tracer bugs).  The generator is seeded, so the set of programs is
 fixed; it mixes every scalar op family the front-end offers, vector helpers, selects, cadenced systems and writes that
 invalidate shared sub-expressions — the combinations a hand-written test would not think of."""
 import numpy as np
@@ -14,97 +15,7 @@ pytestmark = pytest.mark.gpu
 np_ = dsl.np
 
 
-class Gen:
-    """Random expressions whose values stay O(1) (every partial function is fed through a guard), so the comparison
-    measures the generated code and not the conditioning of the expression."""
-
-    def __init__(self, seed):
-        self.rng = np.random.default_rng(seed)
-
-    def pick(self, xs):
-        return xs[int(self.rng.integers(len(xs)))]
-
-    def const(self):
-        return float(np.round(self.rng.uniform(-2.0, 2.0), 3))
-
-    def scalar(self, leaves, depth):
-        r = self.rng
-        if depth == 0 or r.random() < 0.12:
-            return self.pick(leaves) if r.random() < 0.8 else dsl.const(self.const())
-        s = lambda: self.scalar(leaves, depth - 1)
-        kind = self.pick(["bin", "bin", "un", "un", "sel", "vec", "pow", "cmpmix", "lax"])
-        if kind == "bin":
-            a, b = s(), s()
-            return self.pick([lambda: a + b, lambda: a - b, lambda: a * b, lambda: a / (np_.abs(b) + 0.5),
-                              lambda: np_.maximum(a, b), lambda: np_.minimum(a, b), lambda: np_.hypot(a, b),
-                              lambda: np_.arctan2(a, b + 2.5 * np_.sign(b) + 0.1), lambda: a * self.const() + b,
-                              lambda: np_.remainder(a, np_.abs(b) + 0.7)])()
-        if kind == "un":
-            a = s()
-            return self.pick([lambda: np_.sin(a), lambda: np_.cos(a), lambda: np_.tanh(a), lambda: np_.sqrt(np_.abs(a) + 0.1),
-                              lambda: np_.exp(np_.clip(a, -3.0, 2.0)), lambda: np_.log(np_.abs(a) + 0.5), lambda: np_.abs(a) - 0.3,
-                              lambda: np_.arccos(np_.clip(a, -0.95, 0.95)), lambda: np_.arcsin(np_.clip(a * 0.5, -0.95, 0.95)),
-                              lambda: np_.arctan(a), lambda: np_.tan(np_.clip(a, -1.2, 1.2)), lambda: np_.log1p(np_.abs(a)),
-                              lambda: np_.expm1(np_.clip(a, -2.0, 1.0)), lambda: np_.cbrt(np_.abs(a) + 0.2), lambda: np_.sinh(np_.clip(a, -2.0, 2.0)),
-                              lambda: np_.cosh(np_.clip(a, -2.0, 2.0)), lambda: np_.erfc(a), lambda: -a, lambda: np_.sign(a) * 0.5 + a,
-                              lambda: np_.clip(a, -0.7, 0.9), lambda: a ** 2, lambda: a ** 3])()
-        if kind == "sel":
-            c = self.cond(leaves, depth - 1)
-            return np_.where(c, s(), s())
-        if kind == "lax":
-            c, a, b = self.cond(leaves, depth - 1), s(), s()
-            return self.pick([lambda: dsl.lax.cond(c, lambda _: a * 2.0, lambda _: b - 1.0, operand=None),
-                              lambda: dsl.lax.select(c, a, b),
-                              lambda: dsl.lax.switch(np_.floor(np_.clip(a, 0.0, 2.9)), [lambda: a, lambda: b, lambda: a * b]),
-                              lambda: dsl.lax.fori_loop(0, 3, lambda i, v: v * 0.5 + np_.sin(v + float(i)), a)])()
-        if kind == "pow":
-            return np_.power(np_.abs(s()) + 0.5, self.pick([-2.0, -1.5, -0.5, 0.5, 1.5, 2.0, 3.0, self.const()]))
-        if kind == "cmpmix":       # staircase functions of an exactly representable argument
-            leaf = self.pick(leaves)
-            return self.pick([np_.floor, np_.ceil, np_.trunc, np_.rint])(leaf * 4.0) * 0.25 + s()
-        u, v = self.vec3(leaves, depth - 1), self.vec3(leaves, depth - 1)
-        return self.pick([lambda: np_.dot(u, v), lambda: np_.linalg.norm(u), lambda: np_.cross(u, v)[int(self.rng.integers(3))],
-                          lambda: np_.sum(u * v + u), lambda: np_.max(u) - np_.min(v), lambda: np_.sort(u)[1],
-                          lambda: np_.interp(np_.clip(u[0], -1.0, 1.0), [-1.0, -0.2, 0.3, 1.0], [0.5, -1.0, 2.0, 0.25])])()
-
-    def vec3(self, leaves, depth):
-        return dsl.Vec([self.scalar(leaves, depth) for _ in range(3)])
-
-    def cond(self, leaves, depth):
-        a, b = self.scalar(leaves, depth), self.scalar(leaves, depth)
-        c = self.pick([lambda: a > b, lambda: a < b + 0.25, lambda: a >= -b])()
-        if self.rng.random() < 0.3:
-            d = self.scalar(leaves, depth) > 0.1
-            c = self.pick([np_.logical_and, np_.logical_or])(c, d) if self.rng.random() < 0.7 else np_.logical_not(c)
-        return c
-
-
-def make_program(seed, depth=4):
-    g = Gen(seed)
-
-    @dsl.system(x=8, y=8, a=16)
-    def sys_a(x, y, a):
-        leaves = list(x.e) + list(y.e)
-        return {"a": dsl.Vec([g.scalar(leaves, depth) for _ in range(16)])}
-
-    @dsl.system(x=8, a=16, b=16)
-    def sys_b(x, a, b, tick):
-        leaves = list(x.e) + list(a.e) + [np_.sin(tick * 0.37)]
-        out = dsl.Vec([g.scalar(leaves, depth) for _ in range(16)])
-        return {"b": out, "x": x * 0.5 + dsl.Vec([np_.tanh(e) for e in out.e[:8]])}     # x rewritten: later reads must see it
-
-    @dsl.system(every=2, x=8, a=16, b=16, c=8)
-    def sys_c(x, a, b, c):
-        leaves = list(x.e) + list(a.e[:4]) + list(b.e[:4]) + list(c.e[:2])
-        return {"c": dsl.Vec([g.scalar(leaves, depth - 1) for _ in range(8)])}
-    return dsl.Program([sys_a, sys_b], dsl.Pipe([]), [sys_c])
-
-
-def columns(seed, n):
-    rng = np.random.default_rng(1000 + seed)
-    quant = lambda a: np.round(a * 64.0) / 64.0           # exactly representable in f32 too
-    return {"x": quant(rng.uniform(-1.5, 1.5, (n, 8))), "y": quant(rng.uniform(-1.5, 1.5, (n, 8))),
-            "a": np.zeros((n, 16)), "b": np.zeros((n, 16)), "c": np.zeros((n, 8))}
+from tests.fuzz_gen import Gen, columns, make_program, twin_run  # noqa: E402,F401
 
 
 def run_both(prog, cols, ticks, dtype):
@@ -122,6 +33,15 @@ def run_both(prog, cols, ticks, dtype):
     return {k: np.asarray(hip._aux[k], dtype=np.float64) for k in cols}, want
 
 
+def check_against_the_twin(got, seed, cols, ticks, depth=4, tol=1e-10, frac=0.9995):
+    """The generated kernel against the INDEPENDENT numpy evaluation of the same random program (tests/fuzz_gen.twin_run: no
+    tracer involved) — what pins elodin_amd/dsl.py itself; the walker comparison next to it pins the code generator."""
+    twin = twin_run(seed, cols, ticks, depth)
+    for k in ("a", "b", "c", "x"):
+        err = np.abs(got[k] - twin[k]) / np.maximum(np.abs(twin[k]), 1.0)
+        assert (err < tol).mean() > frac, ("twin", seed, k, float(err.max()), float((err >= tol).mean()))
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_programs_f64(seed):
     prog, cols = make_program(seed), columns(seed, 2048)
@@ -134,6 +54,7 @@ def test_random_programs_f64(seed):
         assert (err < 1e-10).mean() > 0.9995, (seed, k, float(err.max()), float((err >= 1e-10).mean()))
         assert np.median(err) < 1e-14, (seed, k)
     assert np.abs(want["c"]).max() > 0.0 and not np.array_equal(want["x"], cols["x"])
+    check_against_the_twin(got, seed, cols, 2)
 
 
 @pytest.mark.parametrize("seed", [0, 3, 5])
@@ -158,6 +79,7 @@ def test_random_program_f32():
     for k in ("a", "b", "x"):
         err = np.abs(got[k] - want[k]) / np.maximum(np.abs(want[k]), 1.0)
         assert (err < 2e-3).mean() > 0.995 and np.median(err) < 5e-6, (k, float(err.max()), float(np.median(err)))
+    check_against_the_twin(got, 101, cols, 1, depth=3, tol=2e-3, frac=0.995)
 
 
 @pytest.mark.parametrize("seed", range(3))
