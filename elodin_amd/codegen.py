@@ -746,13 +746,13 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
         regs = "\n".join(f"        {vol}T c{k}[{w}];" + ("   // cold: lives in its HBM column between cadence blocks" if k in cold else "") for k, w in reg_cols)
         loads = "\n".join(
             f"            {{ {_col_ptr(k, w, 'row')} "
-            + " ".join(f"r.c{k}[{j}] = g[{_col_idx(j)}];" for j in range(w)) + " }" for k, w in reg_cols if k not in cold and k not in transient)
+            + " ".join(f"r.c{k}[{j}] = col_ld<POL>(g + {_col_idx(j)});" for j in range(w)) + " }" for k, w in reg_cols if k not in cold and k not in transient)
         # element by element, not a loop: a loop the optimiser does not unroll (-O1, the low-register-pressure fallback build)
         # indexes the array dynamically, which pins the whole register file image in scratch memory
         zero = " ".join(" ".join(f"r.c{k}[{j}] = T(0);" for j in range(w)) for k, w in reg_cols)
         stores = "\n".join(
             f"        {{ {_col_ptr(k, cols[k][1], 'row', False)} "
-            + " ".join(f"g[{_col_idx(j)}] = r.c{k}[{j}];" for j in range(cols[k][1])) + " }" for k in written if k not in cold and k not in transient)
+            + " ".join(f"col_st<POL>(g + {_col_idx(j)}, r.c{k}[{j}]);" for j in range(cols[k][1])) + " }" for k in written if k not in cold and k not in transient)
         transient_stores = ""
         if transient:
             transient_stores = ("\n        if (tick == P.tick0 + P.n_ticks && c_act) {   // last tick of the launch: the per-tick (transient) columns\n"
@@ -791,14 +791,14 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
     struct Regs {{
 {regs}
     }};
-    template <class T>
+    template <class T, int POL>
     __device__ static __forceinline__ void load(const StepParams& P, uint32_t row, bool active, Regs<T>& r) {{
         {zero}
         if (active) {{
 {loads}
         }}
     }}
-    template <class T>
+    template <class T, int POL>
     __device__ static __forceinline__ void store(const StepParams& P, uint32_t row, const Regs<T>& r) {{
 {stores}
     }}

@@ -312,7 +312,17 @@ class StepContext:
             if comp not in cache:
                 cache[comp] = {int(e): k for k, e in enumerate(self._ex.column_ids(comp))}
         except KeyError:
-            raise RuntimeError(f"component {pair_name!r} does not exist") from None
+            # a component no system reads or writes (examples/monte-carlo's `target`) is not bound to the executor: it keeps the
+            # value it was spawned with, which the world still holds
+            static = self._ex.__dict__.setdefault("_ctx_static", {})
+            if comp not in static:
+                try:
+                    rows, ids = self._world.column(comp)
+                except KeyError:
+                    raise RuntimeError(f"component {pair_name!r} does not exist") from None
+                static[comp] = rows
+                cache[comp] = {int(e): k for k, e in enumerate(ids)}
+            col = static[comp]
         row = cache[comp].get(int(eid))
         if row is None:
             raise RuntimeError(f"component {pair_name!r} does not exist: entity {entity!r} does not carry {comp!r}")
@@ -327,6 +337,9 @@ class StepContext:
         data = _np.asarray(data, dtype=_np.float64).reshape(-1)
         if data.size != col.shape[1]:
             raise ValueError(f"component {pair_name!r}: {data.size} values for a component of {col.shape[1]}")
+        if comp in self._ex.__dict__.get("_ctx_static", {}):      # nothing on the device reads it: the host copy is the component
+            col[row] = data
+            return
         target = self._ex._main_column_array(comp)       # the executor's own host array (a view the upload reads)
         if target.shape != col.shape or getattr(self._ex, "_body_rows", None) is not None or comp in getattr(self._ex, "_partial", {}):
             raise NotImplementedError(f"StepContext.write_component({pair_name!r}): writes into a joined / partial column are not provided")

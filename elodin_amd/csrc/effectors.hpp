@@ -77,9 +77,9 @@ struct NoModel {
     static constexpr bool kPreReadsAccel = false;   // a system in front of six_dof reads world_accel (the previous tick's)
     template <class T>
     struct Regs {};
-    template <class T>
+    template <class T, int POL>
     __device__ static __forceinline__ void load(const StepParams&, uint32_t, bool, Regs<T>&) {}
-    template <class T>
+    template <class T, int POL>
     __device__ static __forceinline__ void store(const StepParams&, uint32_t, const Regs<T>&) {}
     template <class T>
     __device__ static __forceinline__ void record(const StepParams&, size_t, uint32_t, const Regs<T>&) {}

@@ -762,7 +762,10 @@ int fill_step_params(sixdof_handle* h, StepParams* P) {
     // (inputs are re-read next tick: keep them cacheable while the 256 MiB Infinity Cache can hold them; outputs are
     // written once per tick: never worth a line).  SIXDOF_STREAMING=<code> overrides it for A/B runs (tools/step_ab.py).
     const char* force_nt = std::getenv("SIXDOF_STREAMING");
-    const size_t state_bytes = static_cast<size_t>(h->desc.n_entities) * 32 * h->elem_size();
+    size_t row_elems = 32;      // the Body columns: pos 7 + vel 6 + accel 6 + force 6 + inertia 7
+    for (size_t k = 0; k < h->custom_model.size(); k++)      // + the component columns of a generated program (Falcon 9: 201 values)
+        if (const Column* c = h->col(h->custom_model[k])) row_elems += c->width;
+    const size_t state_bytes = static_cast<size_t>(h->desc.n_entities) * row_elems * h->elem_size();
     // NOT the write-through (`sc1`) store policy, although it measured 7 % faster between 48 and 192 MiB of state: the next
     // launch can read STALE rows after it (262,144 bodies: ~10 % of the rows differ from the fused run, differently every
     // run — tools/debug_midsize_determinism.py, profiles/r02_sc1_store_policy_is_unsafe.txt).  It is compiled into the A/B

@@ -103,6 +103,20 @@ __device__ __forceinline__ void slab_out_tail(const T* l, T* __restrict__ g, uin
     for (uint32_t e = lane; e < count; e += kWave) g[e] = l[e];
 }
 
+// One element of a generated program's component column, per lane, under the launch's cache policy: at one tick per launch
+// every column byte is touched once per tick — non-temporal accesses keep a stream of 1.7 KB per rollout from evicting what
+// little is re-read (A/B: profiles/r04_falcon9_k1_policy_ab.txt).
+template <int POL, class T>
+__device__ __forceinline__ T col_ld(const T* p) {
+    if constexpr (pol_ld(POL) == 1) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <int POL, class T>
+__device__ __forceinline__ void col_st(T* p, T v) {
+    if constexpr (pol_st(POL) == 1) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 // ---- the kernel --------------------------------------------------------------------------------------
 
 // CHECK: the instantiation a launch with StepParams::accel_in_check uses (first RK4 launch after an upload, once): its
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     // each lane reads / writes its own rows straight from global memory: for programs with dozens of narrow columns that
     // beats staging their slabs through LDS (profiles/r02_generated_io_ab.txt: Falcon 9 at one tick per launch, 1M
     // rollouts: 287 us per-lane vs 360 us with LDS-DMA slabs, double-buffered) — everything is in flight at once
-    if constexpr (PIPE::kHasModel) PIPE::load(P, row0 + t, active, regs);
+    if constexpr (PIPE::kHasModel) PIPE::template load<T, POL>(P, row0 + t, active, regs);
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA data has landed
     __syncthreads();
@@ -431,7 +445,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     }
     if constexpr (PIPE::kHasModel) {
         if (active) {
-            PIPE::store(P, row0 + t, regs);
+            PIPE::template store<T, POL>(P, row0 + t, regs);
             if constexpr (PIPE::kWritesInertia) {   // a system returned el.Inertia: the column is an output
                 T* gi = static_cast<T*>(const_cast<void*>(P.inertia)) + (size_t)(row0 + t) * 7;
                 gi[0] = I_diag.x; gi[1] = I_diag.y; gi[2] = I_diag.z; gi[6] = mass;

@@ -60,6 +60,8 @@ class Expr:
         stay valid; they are just no longer shared."""
         cls._interned = {}
         cls._count[0] = 0
+        _Lax._loop_ids[0] = 0      # loop-carried leaves are named after a counter: it restarts too, or the second trace of the
+        #                            same program in one process would name them differently (and miss the JIT cache)
 
     # numpy must not broadcast a traced value into an object array: `ndarray * traced` falls through to the reflected method
     __array_ufunc__ = None

@@ -200,3 +200,14 @@ def test_rcs_allocation_and_fin_mixing():
         assert np.all(np.abs(np.delete(torque, axis)) < 1e-9 * max(1.0, abs(torque[axis])))
     force, _ = f9.fin_wrench(np, f9.fin_mix(np, np.array([0.0, 0.0, 0.2])), 2.0, 30_000.0, 20.0)
     assert np.all(np.abs(force) < 1e-9)
+
+
+def test_tracing_the_campaign_program_twice_in_one_process_gives_one_text():
+    """bench.py builds the campaign executor twice in one process (an untimed warm-up, then the campaign): the second trace must
+    generate the SAME source — loop-carried leaves are named after a counter that restarts with every top-level trace — or it
+    misses the JIT cache and the timed campaign pays a 19 s hipcc run (measured on the GPU box in round 4: 6.3 s of 7.6)."""
+    from elodin_amd import codegen
+    cols = f9.initial_columns(f9.default_param_row()[None, :], origin=f9.pad_ecef())
+    widths = {k: v.shape[1] for k, v in cols.items() if k not in ("world_pos", "world_vel", "inertia")}
+    texts = [codegen.generate_source(f9.build_program(origin=f9.pad_ecef()).trace(widths), "float32", 1, fast_math=True) for _ in range(2)]
+    assert texts[0] == texts[1] and "for (int it_" in texts[0]        # it does hold loops (branch_cond)
