@@ -382,6 +382,46 @@ def falcon9_leg(device):
 CAMPAIGN_TOTALS = {"apollo": 8192, "falcon9": 32768}      # BASELINE configs[3] / configs[4]: rollouts of the WHOLE campaign
 
 
+def monte_carlo_example_leg(device):
+    """The reference's own Monte-Carlo example (examples/monte-carlo: sim.py's point-mass plant gathering its drag coefficient
+    from a lookup table, main.py's post_step control law, spec.toml's 100-run LHS plan = its plan.csv; grid size 4,096 as
+    monte_carlo_scaling_sweep.py sweeps it) as ONE executor (elodin_amd/vectorize.py; examples/monte_carlo_sitl.py generates byte
+    for byte the program of the unmodified script).  (a) the script's post_step called per run and tick on the host, the way
+    main.py runs; (b) the same law as a system on the device, at the plan's size and at a count that fills the chip."""
+    os.environ["ELODIN_MONTE_CARLO_GRID_SIZE"], os.environ["ELODIN_MONTE_CARLO_PROBE_ROWS"] = "4096", "0"
+    from examples import monte_carlo_sitl as ex
+    from elodin_amd import monte_carlo as mc
+    from elodin_amd import vectorize
+    plan = mc.materialize(ex.SPEC)
+    t0 = time.perf_counter()
+    c = vectorize.Campaign(ex.build, plan, ex.PARAMS, simulation_rate=ex.SIMULATION_RATE_HZ, device=device)
+    build_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    c.run(ex.DEFAULT_MAX_TICKS, post_step=ex.post_step)
+    host_s = time.perf_counter() - t0
+    res = c.result_table(["final_position", "target", "error"])
+    out = {"plan": "spec.toml: 100 runs, LHS seed 42 (parameter values = the example's plan.csv)", "grid_size": 4096, "ticks": ex.DEFAULT_MAX_TICKS,
+           "build_seconds": round(build_s, 3),
+           "host_post_step": {"runs": len(plan), "seconds": round(host_s, 4), "rollout_steps_per_s": round(len(plan) * ex.DEFAULT_MAX_TICKS / host_s, 1),
+                              "what": "main.py's post_step per run and tick through StepContext (read x3, write x1), columns committed every tick",
+                              "captured_fraction": round(float(np.mean(res[:, 2] < 8.5)), 3), "mean_error_m": round(float(res[:, 2].mean()), 4)}}
+    c.exec._hip.close()
+    for runs in (100, 65536):
+        spec = {"monte_carlo": dict(ex.SPEC["monte_carlo"], n_samples=runs)}
+        t0 = time.perf_counter()
+        d = vectorize.Campaign(ex.build_closed_loop, mc.materialize(spec), ex.PARAMS, simulation_rate=ex.SIMULATION_RATE_HZ, device=device)
+        b = time.perf_counter() - t0
+        d.exec._hip.set_ticks_per_launch(ex.DEFAULT_MAX_TICKS)
+        d.exec._hip.invoke_batch(ex.DEFAULT_MAX_TICKS)                      # untimed: code-object load
+        tm = d.exec._hip.invoke_batch(ex.DEFAULT_MAX_TICKS)
+        d.exec._hip.download()
+        err = np.abs(d.column("target")[:, 0] - d.column("position")[:, 0]) if "target" in d.exec._hip._aux else None
+        out[f"device_controller_{runs}"] = {"runs": runs, "build_seconds_incl_host_spawn": round(b, 3), "device_ms_per_360_ticks": round(tm.kernel_device_ms, 4),
+                                            "rollout_steps_per_s": round(runs * ex.DEFAULT_MAX_TICKS / (tm.kernel_device_ms * 1e-3), 1)}
+        d.exec._hip.close()
+    return out
+
+
 def campaign_bench(which, rank, world, local_rank, comm_device, barrier, capi_comm=None, scaling="strong"):
     """One whole campaign over the ranks.  `strong` = BASELINE's rollout count as it is stated (8,192 Apollo descents /
     32,768 Falcon 9 ascents IN TOTAL) split over the ranks in run-id order; `weak` = that count PER GPU.  Rank 0 samples the
@@ -744,6 +784,7 @@ def main():
         extra("sparse_edges_hubs", sparse_edges_leg, local_rank, 8)
         extra("telemetry_commit", telemetry_leg, local_rank, n)
         extra("history_stream", history_stream_leg, local_rank, n)
+        extra("monte_carlo_example", monte_carlo_example_leg, local_rank)
         extra("apollo_mc", apollo_leg, local_rank)
         extra("falcon9_mc", falcon9_leg, local_rank)
     tc = out.get("telemetry_commit", {}).get("k1x48", {}) if isinstance(out.get("telemetry_commit"), dict) else {}

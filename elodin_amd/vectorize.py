@@ -95,10 +95,12 @@ class Campaign:
             return w, system
 
         # -- the program: traced under two sentinel sets, the sources must agree ------------------------------------------
-        sources = []
+        sources, sentinels, worlds = [], [], []
         for variant in (0, 1):
             sent = _sentinels(self.names, spec, variant)
+            sentinels.append(sent)
             w, system = built(sent)
+            worlds.append((w, _entities(w)))
             for eid in _entities(w):
                 w.insert(_api.EntityId(eid), [_api.C("mc:" + n, [sent[n]]) for n in self.names])
             with _sentinel_scope(sent):
@@ -110,23 +112,33 @@ class Campaign:
                 "this script's code depends on a Monte-Carlo parameter in a way the tracer cannot see (host arithmetic on the "
                 "parameter before the traced function): the campaign cannot share one program — build one executor per run")
         self.sources = sources[0]
+        self._sentinel_worlds = worlds
 
         # -- the world: every run's spawned entities, run-major ------------------------------------------------------------
+        # A spawned value that is the same under both sentinel sets is a constant of the script; one that equals a sentinel
+        # under both is that parameter (`el.C(Velocity, jnp.array([wind]))`): such worlds are laid out from the plan table
+        # directly.  Any other dependence on the parameters (host arithmetic before the spawn) needs build(params_i) per run.
         from . import frontend as _fe
         self.world = (world_cls or _fe.World)()
         self.entity_names: List[Dict[str, int]] = []          # per run: the script's entity name -> entity id in the big world
-        self.entities_per_run = None
+        ents_a, ents_b = self._sentinel_worlds
+        template = self._spawn_template(ents_a, ents_b, sentinels)
+        self.per_run_builds = template is None
+        self.entities_per_run = len(ents_a[1])
+        w0 = ents_a[0]
         for i in range(self.n_runs):
             values = {n: float(self.table[i, k]) for k, n in enumerate(self.names)}
-            w, _ = built(values, plan.context(i))
-            ents = _entities(w)
-            if self.entities_per_run is None:
-                self.entities_per_run = len(ents)
-            elif len(ents) != self.entities_per_run:
-                raise NotImplementedError("runs of one campaign spawn different numbers of entities")
+            if template is None:
+                w, _ = built(values, plan.context(i))
+                ents = _entities(w)
+                if len(ents) != self.entities_per_run:
+                    raise NotImplementedError("runs of one campaign spawn different numbers of entities")
+            else:
+                w, ents = w0, {eid: {c: (row if src is None else self._fill(row, src, values)) for c, (row, src) in comps.items()}
+                               for eid, comps in template.items()}
             local_to_big, names = {}, {}
             for eid, comps in ents.items():
-                arch = [_api.C(c, row) for c, row in comps.items()] + [_api.C("mc:" + n, [values[n]]) for n in self.names]
+                arch = [_api.C(c, row) for c, row in comps.items() if not c.startswith("mc:")] + [_api.C("mc:" + n, [values[n]]) for n in self.names]
                 big = self.world.spawn(arch, name=f"{plan.run_ids[i]}.{w._names.get(eid, eid)}")
                 local_to_big[eid] = int(big)
                 if eid in w._names:
@@ -144,6 +156,46 @@ class Campaign:
                 self.exec = self.world.build(self._system, simulation_rate=simulation_rate, telemetry_rate=telemetry_rate,
                                              device=device, **kw)
         self.results: List[Dict[str, Any]] = [dict() for _ in range(self.n_runs)]
+
+    @staticmethod
+    def _spawn_template(a, b, sentinels):
+        """{entity: {component: (row, None | [parameter name or None per element])}} when every spawned element is a constant
+        or exactly one of the parameters; None when a run's spawn cannot be derived from the plan row that simply."""
+        (wa, ea), (wb, eb) = a, b
+        if list(ea) != list(eb) or wa._names != wb._names or wa._edges != wb._edges:
+            return None
+        inv_a = {v: k for k, v in sentinels[0].items()}
+        inv_b = {v: k for k, v in sentinels[1].items()}
+        out = {}
+        for eid in ea:
+            if set(ea[eid]) != set(eb[eid]):
+                return None
+            out[eid] = {}
+            for c, ra in ea[eid].items():
+                rb = eb[eid][c]
+                if ra.shape != rb.shape:
+                    return None
+                if np.array_equal(ra, rb):
+                    out[eid][c] = (ra, None)
+                    continue
+                src = []
+                for x, y in zip(ra.reshape(-1), rb.reshape(-1)):
+                    if x == y:
+                        src.append(None)
+                    elif inv_a.get(float(x)) is not None and inv_a.get(float(x)) == inv_b.get(float(y)):
+                        src.append(inv_a[float(x)])
+                    else:
+                        return None
+                out[eid][c] = (ra, src)
+        return out
+
+    @staticmethod
+    def _fill(row, src, values):
+        out = np.array(row, dtype=np.float64).reshape(-1)
+        for k, name in enumerate(src):
+            if name is not None:
+                out[k] = values[name]
+        return out.reshape(row.shape)
 
     # ---------------------------------------------------------------------------------------------------------------------
     def run(self, max_ticks: int, post_step: Optional[Callable] = None, pre_step: Optional[Callable] = None) -> "Campaign":

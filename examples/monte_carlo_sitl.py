@@ -86,11 +86,24 @@ def post_step(tick: int, ctx) -> None:                                          
         el.monte_carlo.result(final_position=position, target=target, error=abs(target - position))
 
 
+@el.map
+def pd_controller(pos: Position, vel: Velocity, target: Target) -> Command:
+    """main.py's control law (:98, external controller switched off) as a system piped behind the plant: the same campaign
+    without a host callback per run and tick — `campaign.run(ticks)` is then launches only."""
+    return jnp.clip((target - pos) * 1.2 - vel * 0.35, -20.0, 20.0)
+
+
 SPEC = {"monte_carlo": {"n_samples": 100, "seed": 42, "method": "lhs",                                   # spec.toml
                         "variables": {"mass": {"dist": "uniform", "min": 1.0, "max": 2.0},
                                       "target_x": {"dist": "uniform", "min": 20.0, "max": 40.0},
                                       "thrust_gain": {"dist": "uniform", "min": 0.8, "max": 1.2},
                                       "wind": {"dist": "normal", "mean": 0.0, "std": 0.5}}}}
+
+
+def build_closed_loop(params):
+    """build(params) with the control law on the device: plant | pd_controller."""
+    world, plant = build(params)
+    return world, plant | pd_controller
 
 
 def main(runs=100):

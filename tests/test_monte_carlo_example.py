@@ -97,3 +97,25 @@ def test_a_parameter_that_reaches_the_code_through_host_arithmetic_is_refused():
         return world, plant
     with pytest.raises(NotImplementedError, match="host arithmetic"):
         vectorize.Campaign(build, vectorize.plan_of([{"mass": 1.0}, {"mass": 2.0}]), ex.PARAMS, dry=True)
+
+
+def test_spawned_worlds_come_from_the_plan_table_or_from_one_build_per_run():
+    """A spawned element that IS a parameter is filled from the plan row; one derived from a parameter on the host makes the
+    campaign call build(params_i) for every run — same world either way."""
+    import elodin_amd.frontend as el
+    ex = example(0)
+    rows = [{"mass": 1.0 + 0.1 * k, "target_x": 20.0 + k, "thrust_gain": 1.0, "wind": 0.1 * k - 0.2} for k in range(5)]
+    direct = vectorize.Campaign(ex.build, vectorize.plan_of(rows), ex.PARAMS, dry=True)
+    assert not direct.per_run_builds
+
+    def build_derived(params):
+        world, plant = ex.build(params)
+        world.spawn([el.C(ex.Target, np.array([2.0 * float(params.get("target_x", 30.0))]))], name="beacon")     # host arithmetic on a parameter
+        return world, plant
+    derived = vectorize.Campaign(build_derived, vectorize.plan_of(rows), ex.PARAMS, dry=True)
+    assert derived.per_run_builds and derived.entities_per_run == 2
+    t = derived.world.column("target")[0][:, 0]
+    assert np.array_equal(t[0::2], [r["target_x"] for r in rows]) and np.array_equal(t[1::2], [2.0 * r["target_x"] for r in rows])
+    assert np.array_equal(direct.world.column("velocity")[0][:, 0], [r["wind"] for r in rows])
+    assert np.array_equal(direct.world.column("mc:mass")[0][:, 0], [r["mass"] for r in rows])
+    assert direct.entity_names[3] == {"vehicle": 4} and derived.entity_names[2] == {"vehicle": 5, "beacon": 6}
