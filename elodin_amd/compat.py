@@ -195,7 +195,7 @@ class _TracedScipyNdimage:
 
     @staticmethod
     def map_coordinates(input, coordinates, order, mode="constant", cval=0.0):      # noqa: A002  (jax's argument name)
-        return _dsl.map_coordinates(_np.asarray(input), coordinates, order, mode=mode, cval=cval)
+        return _dsl.map_coordinates(input, coordinates, order, mode=mode, cval=cval)
 
 
 class _TracedScipySpecial:

@@ -278,7 +278,18 @@ def map_coordinates(grid, coordinates, order: int = 1, mode: str = "constant", c
     itertools.product of the per-axis (index, weight) pairs, first axis slowest.  Corner values come from the flattened grid
     by a traced linear index: a select chain for small grids, a gather from device memory for larger ones."""
     import itertools
-    g = _numpy.ascontiguousarray(grid, dtype=_numpy.float64)
+
+    def concrete(x):      # the grid may arrive as the tracer's own constant containers (compat hands host arrays over that way)
+        if isinstance(x, Expr):
+            if x.op != "const":
+                raise NotImplementedError("map_coordinates: the sampled grid must be a constant")
+            return x.value
+        if isinstance(x, Vec):
+            return [concrete(e) for e in x.e]
+        if isinstance(x, (list, tuple)) or type(x).__name__ in ("Mat", "Batch"):
+            return [concrete(e) for e in x]
+        return x
+    g = _numpy.ascontiguousarray(concrete(grid), dtype=_numpy.float64)
     coords = list(coordinates.e) if isinstance(coordinates, Vec) else list(coordinates)
     if len(coords) != g.ndim:
         raise ValueError("coordinates must be a sequence of length input.ndim")
@@ -764,6 +775,16 @@ class _Np:
     def power(x, y): return _zipv(x, y, lambda a, b: Expr("pow", (_lift(a), _lift(b))))
     @staticmethod
     def concatenate(parts, axis=0):
+        parts = list(parts)
+        if parts and isinstance(parts[0], WindowSlice) and axis == 0:
+            # `jnp.concatenate((buffer[1:], row.reshape(1, w)))` (examples/rocket/main.py:449): drop the oldest row, append one = push
+            w = parts[0]
+            rest = [r for p_ in parts[1:] for r in (list(p_) if isinstance(p_, list) else [p_])]
+            if w.start == 1 and w.stop == w.window.rows and len(rest) == 1 and isinstance(rest[0], Vec):
+                return w.window.push(rest[0])
+            raise NotImplementedError("concatenate over window rows: only `concatenate((window[1:], one_row))` (a push) is provided")
+        if any(isinstance(p_, LazyRows) for p_ in parts) and axis == 0:
+            return LazyRows([q for p_ in parts for q in (p_.parts if isinstance(p_, LazyRows) else [list(p_)])])
         parts = [_host(p_) for p_ in parts]
         if parts and isinstance(parts[0], list) and parts[0] and isinstance(parts[0][0], Vec):     # matrices
             from . import dsl_mat
@@ -1070,6 +1091,19 @@ class _Lax:
             if isinstance(x, tuple):          # a tuple of scanned operands, like jax pytrees
                 return tuple(at(v, i) for v in x)
             return x[i]                        # list of per-step rows
+        if isinstance(xs, WindowSlice):
+            # a REAL loop over the window's rows in the kernel; the last step's output rides along in the carry, the first is
+            # the loop's first iteration written out (emitted only if something reads it): LazyRows
+            if len(xs) == 0:
+                return init, LazyRows([])
+            carry1, y_first = f(init, xs.window[xs.start])
+            yf, y_rebuild = _flatten(y_first)
+
+            def step(c, row):
+                nc, y = f(c[0], row)
+                return (nc, y), None
+            last_carry, y_last = xs.window.scan(step, (init, y_rebuild([const(0.0)] * len(yf))), start=xs.start, stop=xs.stop)
+            return last_carry, LazyRows.of_scan(y_first, y_last, len(xs))
         L = int(length) if xs is None else n_steps(xs)
         if length is not None and xs is not None and int(length) != L:
             raise ValueError("scan: length disagrees with the leading axis of xs")
@@ -1453,11 +1487,19 @@ class Window:
         return Vec([Expr("wload", (self.head, idx), (self.slot, self.rows, self.width, j, self.version)) for j in range(self.width)])
 
     def __getitem__(self, i):
+        if isinstance(i, slice):              # `buffer[1:]`, `signal[2:]`, `signal[0:1]` of a reference script: rows, not yet read
+            start, stop, step = i.indices(self.rows)
+            if step != 1:
+                raise TypeError("window[a:b:c]: only unit steps")
+            return WindowSlice(self, start, max(start, stop))
         if not isinstance(i, int):
             raise TypeError("window[i] takes a Python int (use .row(index) for a traced index, .scan(...) for a loop)")
         if not -self.rows <= i < self.rows:
             raise IndexError(i)
         return self.row(float(i % self.rows))
+
+    @property
+    def shape(self): return (self.rows, self.width)
 
     def push(self, row) -> "WindowPush":
         row = row if isinstance(row, Vec) else Vec([row])
@@ -1492,6 +1534,75 @@ class WindowPush:
 
     def __init__(self, window: Window, row: "Vec"):
         self.window, self.row = window, row
+
+
+class WindowSlice:
+    """`window[a:b]`: rows a..b-1 of a window, not read yet.  What a reference script does with it decides what is generated:
+    `concatenate((buffer[1:], row))` is a push (Window.push); `lax.scan(f, init, signal[2:])` a loop over those rows in the
+    kernel (Window.scan) whose stacked outputs stay lazy (LazyRows); indexing reads rows."""
+
+    def __init__(self, window: Window, start: int, stop: int):
+        self.window, self.start, self.stop = window, int(start), int(stop)
+
+    def __len__(self): return self.stop - self.start
+
+    @property
+    def shape(self): return (len(self), self.window.width)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            a, b, step = i.indices(len(self))
+            if step != 1:
+                raise TypeError("window[a:b][c:d:e]: only unit steps")
+            return WindowSlice(self.window, self.start + a, self.start + max(a, b))
+        if not -len(self) <= i < len(self):
+            raise IndexError(i)
+        return self.window[self.start + (i % len(self))]
+
+
+class LazyRows:
+    """The stacked per-step outputs of a scan over a window (478 rows of the rocket example's filtered signal,
+    examples/rocket/main.py:187-195), of which a script uses the ends: a sequence of `parts` — explicit rows, or (first row,
+    last row, count) of a scan's outputs.  `rows[-1]`, `rows[0]`, `rows[0:1]`, `rows[-1:]`, len, and concatenation are what exist;
+    anything in the middle of a scan's outputs was never computed and says so."""
+
+    def __init__(self, parts): self.parts = [p for p in parts if (p[2] if isinstance(p, tuple) else len(p)) > 0]
+
+    @staticmethod
+    def of_scan(first, last, count): return LazyRows([(first, last, int(count))])
+
+    def __len__(self): return sum(p[2] if isinstance(p, tuple) else len(p) for p in self.parts)
+
+    def _at(self, i):
+        n = len(self)
+        if not -n <= i < n:
+            raise IndexError(i)
+        i %= n
+        for p in self.parts:
+            m = p[2] if isinstance(p, tuple) else len(p)
+            if i < m:
+                if not isinstance(p, tuple):
+                    return p[i]
+                if i == 0:
+                    return p[0]
+                if i == m - 1:
+                    return p[1]
+                raise NotImplementedError("only the first and the last output of a scan over a window are available")
+            i -= m
+        raise IndexError(i)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            a, b, step = i.indices(len(self))
+            if step != 1:
+                raise TypeError("only unit steps")
+            if (a, b) == (0, len(self)):
+                return self
+            return LazyRows([[self._at(k) for k in range(a, b)]]) if b - a <= 2 else self._middle(a, b)
+        return self._at(i)
+
+    def _middle(self, a, b):
+        raise NotImplementedError("a slice of more than two rows out of a scan's stacked outputs is not provided")
 
 
 # A component declared with a 2-D shape is a MATRIX held in registers (dsl_mat.Mat: a 3 x 3 / 6 x 6 filter covariance,
@@ -1990,13 +2101,15 @@ class FrozenProgram(Program):
     (tests/golden/make_drone_program.py).  HipExec compiles and binds it like a program it traced itself."""
 
     def __init__(self, source: str, columns: Sequence[Tuple[str, int]], mats: Optional[Dict[str, Tuple[int, int]]] = None,
-                 substeps: int = 1, column_soa: bool = False):
+                 substeps: int = 1, column_soa: bool = False, windows: Optional[Dict[str, Tuple[int, int, int]]] = None):
         """column_soa: the text was generated with element-major program columns (codegen.generate_source(column_soa=True));
         the executor lays the columns out the way the text expects, whatever its row count."""
         super().__init__([], Pipe([]), [], substeps=substeps)
         import types
         table = types.SimpleNamespace(mats={k: tuple(v) for k, v in (mats or {}).items()}, windows={})
-        self._traced = types.SimpleNamespace(frozen_source=source, columns=[(str(n), int(w)) for n, w in columns], windows={},
+        # windows: name -> (slot, rows, width) of the wide components the text keeps in HBM as rings (entity-major layout)
+        self._traced = types.SimpleNamespace(frozen_source=source, columns=[(str(n), int(w)) for n, w in columns],
+                                             windows={str(k): tuple(int(x) for x in v) for k, v in (windows or {}).items()},
                                              table=table, fold_stages=[], pre=[], post=[], column_soa=bool(column_soa))
 
     def trace(self, *a, **k):

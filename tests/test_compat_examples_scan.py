@@ -54,9 +54,8 @@ EXPECTED = {
     "cube-sat-pysim/main.py": "NotImplementedError",  # same
     "falcon9/main.py": "at most 64 component columns",  # the full mission adds truth-ghost / display-scoring components to the plant's 62;
                                                         # the plant itself (sim.build_powered) is pinned in test_compat_reference_scripts.py
-    "rocket/main.py": "window[i] takes a Python int",  # its polars table preparation (compat_polars) and map_coordinates trace now; what stops it
-                                                       # is the sample window spelled `concatenate((buffer[1:], row))` + `lax.scan` over the whole
-                                                       # window with stacked outputs (main.py:187-195,449) — tests/rocket_dsl.py spells those push / scan
+    "rocket/main.py": "traced",                       # polars subset (compat_polars), map_coordinates, the sample window spelled concatenate /
+                                                      # lax.scan: pinned on its rocket-csv baseline in test_compat_reference_scripts.py
     "voyager/main.py": "spiceypy",                    # third-party ephemeris library, not in this image
     "db-client/main.py": "elodin.db",                 # a database client, no simulation
     "betaflight-sitl/main.py": "betaflight_SITL.elf",  # needs the Betaflight SITL binary (the script says so and exits)

@@ -350,3 +350,38 @@ def test_shim_keeps_data_and_traced_code_apart(compat):
         jnp.unwrap(jnp.array([1.0, 2.0]) * x)          # numpy functions without a traced counterpart refuse traced values
     with pytest.raises(AttributeError, match="not provided"):
         jnp.fft
+
+
+def test_rocket_script_unmodified_lands_on_the_reference_baseline(compat):
+    """examples/rocket/main.py as it is: its polars table preparation (elodin_amd/compat_polars.py over pandas), `map_coordinates`
+    over the aero grid, the 480 x 3 sample window spelled `concatenate((buffer[1:], row))` (recognised as a push) and
+    `lax.scan` over `signal[2:]` with stacked outputs of which only `[-1]` is read (a loop in the kernel, dsl.LazyRows) — 100
+    ticks free-running on the CPU walker against scripts/ci/baseline/rocket-csv, all 24 columns + the final window."""
+    from elodin_amd import _lib as L
+    from tests import dsl_numpy, rocket_util as U
+    sys.path.insert(0, str(REF / "examples" / "rocket"))
+    main = _load(REF / "examples" / "rocket" / "main.py", "ref_rocket_main")
+    world = next(v for v in vars(main).values() if hasattr(v, "compat_run"))
+    run = world.compat_run
+    plan = world.build(run["system"], simulation_rate=run["simulation_rate"], telemetry_rate=run["telemetry_rate"], _dry=True)
+    tp = plan["effectors"].trace()
+    assert tp.windows == {"v_rel_accel_buffer": (tp.windows["v_rel_accel_buffer"][0], 480, 3)} and tp.pre_reads_accel
+    assert plan["integrator"] == L.RK4 and abs(plan["dt"] - U.GOLDEN["simulation_time_step"]) < 1e-15
+    from elodin_amd import codegen
+    frozen = json.loads((ROOT / "tests" / "golden" / "rocket_program.json").read_text())      # what tests/test_gpu_rocket.py runs on the GPU box
+    assert codegen.generate_variant(tp, frozen["variant"], "float64", plan["integrator"]) == frozen["source"], "re-run tests/golden/make_rocket_program.py"
+    body = plan["body"]
+    pos, vel, inertia = (np.array(body[k], dtype=np.float64).reshape(1, -1).copy() for k in ("world_pos", "world_vel", "inertia"))
+    comps = {name: np.array(plan["columns"][name], dtype=np.float64).reshape(1, -1).copy() for name, _ in tp.columns if not name.endswith("#head")}
+    comps["v_rel_accel_buffer#head"] = np.zeros((1, 1))
+    acc, worst = np.zeros((1, 6)), {}
+    for tick in range(1, 101):
+        F = dsl_numpy.program_tick(tp, pos, vel, acc, inertia, comps, tick, plan["dt"], L.RK4)
+        got = {k: v[0] for k, v in comps.items()}
+        got.update(world_pos=pos[0], world_vel=vel[0], world_accel=acc[0], force=F[0], inertia=inertia[0])
+        U.check_row(tick, got, worst)
+    print("examples/rocket/main.py unmodified vs its CI baseline, CPU walker:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
+    U.assert_all_columns(worst)
+    window = dsl_numpy.window_rows(comps, "v_rel_accel_buffer", 480, 3)[0].ravel()
+    want = np.array(U.GOLDEN["v_rel_accel_buffer_final"])
+    assert np.abs(window - want).max() < 1e-9 * np.abs(want).max()

@@ -63,3 +63,37 @@ def test_rocket_window_in_both_device_layouts():
         U.assert_all_columns(worst)
     want = np.array(U.GOLDEN["v_rel_accel_buffer_final"])
     assert np.abs(hip.component("v_rel_accel_buffer")[n - 1].ravel() - want).max() < 1e-9 * np.abs(want).max()
+
+
+def test_unmodified_rocket_script_through_its_frozen_kernel():
+    """examples/rocket/main.py imported UNMODIFIED under elodin_amd.compat in the build container (polars subset, map_coordinates,
+    the window spelled concatenate / lax.scan): the kernel text the code generator emitted for it there
+    (tests/golden/make_rocket_program.py -> rocket_program.json; tests/test_compat_reference_scripts.py checks the script still
+    generates it and walks it on the CPU), compiled here, every golden row at one tick per launch and the end state fused."""
+    import json
+    from pathlib import Path
+    from elodin_amd import dsl
+    doc = json.loads((Path(__file__).parent / "golden" / "rocket_program.json").read_text())
+    for k, n in ((1, 1), (20, 70)):
+        prog = dsl.FrozenProgram(doc["source"], doc["columns"], doc["mats"], windows=doc["windows"])
+        rep = lambda a: np.repeat(np.asarray(a, dtype=np.float64).reshape(1, -1), n, axis=0)
+        body = doc["body"]
+        cols = {name: rep(v) for name, v in doc["initial"].items()}
+        for name, (_, rows, width) in doc["windows"].items():
+            cols[name] = cols[name].reshape(n, rows, width)
+        hip = ea.HipExec(rep(body["world_pos"]), rep(body["world_vel"]), rep(body["inertia"]), world_accel=rep(body["world_accel"]),
+                         simulation_time_step=doc["simulation_time_step"], time_step=doc["time_step"], integrator=doc["integrator"],
+                         effectors=prog, columns=cols, ticks_per_launch=k)
+        worst = {}
+        if k == 1:
+            for tick in range(1, 101):
+                hip.run(1)
+                U.check_row(tick, _row(hip), worst)
+        else:
+            hip.run(100)
+            for row in (0, n - 1):
+                U.check_row(100, _row(hip, row), worst)
+        print(f"examples/rocket/main.py unmodified, frozen kernel, {k} tick(s) per launch:", {a: f"{b:.1e}" for a, b in sorted(worst.items(), key=lambda kv: -kv[1])[:4]})
+        U.assert_all_columns(worst)
+        want = np.array(U.GOLDEN["v_rel_accel_buffer_final"])
+        assert np.abs(hip.component("v_rel_accel_buffer")[n - 1].ravel() - want).max() < 1e-9 * np.abs(want).max()
