@@ -385,3 +385,86 @@ def test_rocket_script_unmodified_lands_on_the_reference_baseline(compat):
     window = dsl_numpy.window_rows(comps, "v_rel_accel_buffer", 480, 3)[0].ravel()
     want = np.array(U.GOLDEN["v_rel_accel_buffer_final"])
     assert np.abs(window - want).max() < 1e-9 * np.abs(want).max()
+
+
+def test_falcon9_full_mission_script_unmodified_flies_the_closed_loop_ascent_window(compat):
+    """examples/falcon9/main.py — the FULL mission world (plant + sensors + truth ghost + display scoring: 65 component columns,
+    more than the 64 a program could hold before round 4), unmodified.  Its program is stepped on the CPU walker with main.py's
+    OWN post_step bridging to the flight software on the server loop's cadence (only the UDP socket is replaced, by
+    oracle/falcon9_fsw.c — exactly how tests/golden/make_falcon9_closed_loop.py flew the reference's plant), from the pad through
+    navigator initialisation, the ignition command and liftoff: every component the fixture holds at its checkpoints up to
+    tick 3,000 of flight 0 (the calibrated defaults), and the flight software's own state."""
+    from elodin_amd import _lib as L
+    from oracle import falcon9_fsw as fsw_mod
+    from tests import dsl_numpy, falcon9_closed_loop_util as cu
+    if "0" not in cu.FLIGHTS:
+        pytest.skip("closed-loop fixture not generated")
+    flight = cu.FLIGHTS["0"]
+    ex_dir = REF / "examples" / "falcon9"
+    sys.path.insert(0, str(ex_dir))
+    main = _load(ex_dir / "main.py", "ref_falcon9_main")
+    world = main.world
+    run = world.compat_run
+    assert run["post_step"] is main.post_step and run["simulation_rate"] == 1000.0
+    plan = world.build(run["system"], simulation_rate=run["simulation_rate"], telemetry_rate=run["telemetry_rate"], _dry=True)
+    tp = plan["effectors"].trace()
+    assert len(tp.columns) == 65 and plan["integrator"] == L.SEMI_IMPLICIT
+    booster = next(e for e, nm in world._names.items() if nm == "booster")
+
+    def row_of(name, width):          # the booster's row of a component (the executor's rows are the Body join = the booster)
+        try:
+            rows, ids = world.column(name)
+        except KeyError:
+            return np.zeros((1, width))
+        hit = np.nonzero(ids == booster)[0]
+        return rows[hit[:1]].astype(np.float64).reshape(1, -1) if len(hit) else np.zeros((1, width))
+    comps = {name: (np.array([[1.0 if booster in world.column(name[4:])[1] else 0.0]]) if name.startswith("has:") else row_of(name, w))
+             for name, w in tp.columns}
+    pos, vel, inertia = (row_of(k, w) for k, w in (("world_pos", 7), ("world_vel", 6), ("inertia", 7)))
+    acc = np.zeros((1, 6))
+    body = {"world_pos": pos, "world_vel": vel, "world_accel": acc, "inertia": inertia}
+    fsw = fsw_mod.Fsw(fsw_mod.read_raw_profile(ex_dir / "data" / "crs12" / "stage1_raw.json"))
+
+    class OracleBridge:                     # main.py:221-243 minus the socket
+        def exchange(self, state):
+            return fsw.step(np.asarray(state, dtype=np.float64))
+    main.bridge = OracleBridge()
+
+    class Ctx:                              # el.StepContext.component_batch_operation over the walker's arrays
+        def component_batch_operation(self, reads=None, writes=None):
+            if writes:
+                for name, v in writes.items():
+                    k = name.split(".", 1)[1]
+                    (body[k] if k in body else comps[k])[0] = np.asarray(v, dtype=np.float64).reshape(-1)
+                return None
+            out = {}
+            for name in reads:
+                k = name.split(".", 1)[1]
+                src = body[k] if k in body else (comps[k] if k in comps else row_of(k, 1))
+                out[name] = np.array(src[0], dtype=np.float64).reshape(-1)
+            return out
+    ctx = Ctx()
+    cps = {c["tick"]: c for c in flight["checkpoints"] if c["tick"] <= 3000}
+    worst, seen, fsw_worst = {}, 0, 0.0
+    for tick in range(1, 3001):
+        F = dsl_numpy.program_tick(tp, pos, vel, acc, inertia, comps, tick, plan["dt"], L.SEMI_IMPLICIT)
+        main.post_step(tick - 1, ctx)       # the server loop's call after the tick (ticks_per_telemetry = 1)
+        if tick in cps:
+            cp = dict(cps[tick], state={k: v for k, v in cps[tick]["state"].items() if k != "fsw"})
+            cp["state"]["fsw"] = {}
+            state = dict(body, force=F)
+            for k, e in cu.compare(flight, cp, lambda name: state[name] if name in state else comps[name]).items():
+                worst[k] = max(worst.get(k, 0.0), e)
+            pk = fsw.peek()
+            for k, want in cps[tick]["state"]["fsw"].items():
+                if k in pk and k in cu.FSW_MAP:
+                    got, want = np.asarray(pk[k], dtype=np.float64).reshape(-1), np.asarray(want, dtype=np.float64).reshape(-1)
+                    fl = cu.FLOORS.get(k, 1e-300)
+                    fsw_worst = max(fsw_worst, float(np.max(np.abs(got - want))) / max(float(np.max(np.abs(want))), fl if not isinstance(fl, tuple) else fl[0]))
+            seen += 1
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    print(f"examples/falcon9/main.py unmodified, closed loop on the CPU walker: worst of {len(worst)} quantities at {seen} checkpoints:",
+          ", ".join(f"{k} {e:.1e}" for k, e in top), f"; flight software state {fsw_worst:.1e}")
+    assert seen >= 8 and len(worst) >= 45
+    assert max(worst.values()) < 1e-9 and fsw_worst < 1e-9, (top, fsw_worst)
+    assert float(comps["lifted"][0, 0]) == 1.0 and fsw.peek()["phase"] == 1.0      # off the pad, vertical rise

@@ -72,7 +72,16 @@ def test_two_gloo_ranks_fly_both_campaigns_with_the_hip_executors_on_one_gpu():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    a2, f2 = q.get(timeout=600)
+    import queue
+    import time
+    deadline = time.time() + 600
+    while True:                      # a rank that dies (no GPU, a failed assertion) must fail the test now, not after the timeout
+        try:
+            a2, f2 = q.get(timeout=2)
+            break
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead and time.time() < deadline, f"rank processes exited with {dead}"
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
