@@ -15,7 +15,7 @@ LIB_PATH = Path(os.environ["SIXDOF_LIBRARY"]) if os.environ.get("SIXDOF_LIBRARY"
 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_COMPONENT_NOT_FOUND, ERR_VALUE_SIZE_MISMATCH = -1, -2, -3
-ERR_BACKEND, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ENTITY_MISMATCH = -4, -5, -6, -7
+ERR_BACKEND, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ENTITY_MISMATCH, ERR_TIME_TRAVEL = -4, -5, -6, -7, -8
 
 RK4, SEMI_IMPLICIT, INTEGRATOR_NONE = 0, 1, 2
 F64, F32 = 0, 1
@@ -131,6 +131,22 @@ SYMBOLS = {
     "sixdof_download_column": (C.c_int, [_H, C.c_uint64]),
     "sixdof_tick_slots": (C.c_int, [_H, C.POINTER(Slot), C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Slot),
                                     C.c_size_t, C.POINTER(C.c_size_t)]),
+    # the commit path's hand-off (csrc/telemetry_sink.cpp)
+    "sixdof_pair_id": (C.c_uint64, [C.c_char_p, C.c_char_p]),
+    "sixdof_sink_create": (C.c_void_p, []),
+    "sixdof_sink_destroy": (None, [C.c_void_p]),
+    "sixdof_sink_last_error": (C.c_char_p, [C.c_void_p]),
+    "sixdof_sink_register": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_char_p]),
+    "sixdof_sink_push": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p, C.c_uint32]),
+    "sixdof_sink_sample_count": (C.c_uint64, [C.c_void_p, C.c_uint64]),
+    "sixdof_sink_pairs": (C.c_size_t, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]),
+    "sixdof_sink_latest": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_int64), C.c_void_p, C.c_uint32]),
+    "sixdof_sink_at": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_uint32]),
+    "sixdof_sink_series": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.POINTER(C.c_uint8)),
+                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "sixdof_sink_truncate": (None, [C.c_void_p]),
+    "sixdof_sink_commit_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint32, C.c_uint32, C.c_int64]),
+    "sixdof_sink_copy_to_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]),
 }
 
 _lib = None

@@ -283,23 +283,40 @@ class StepContext:
     columns (refreshed after every batch), and a write lands in them and is uploaded before the next batch runs
     (copy_db_to_world, impeller2_server.rs:607-640)."""
 
-    def __init__(self, ex, world, dt: float, start_timestamp: int = 0):
+    def __init__(self, ex, world, dt: float, start_timestamp: int = 0, sink=None):
+        """sink: an elodin_amd.telemetry.Sink attached to `ex` — reads then come from the pairs' time series (with the
+        reference's timestamp semantics) and writes are pushes into them, brought into the world by copy_db_to_world before
+        the next batch; without one (a vectorised campaign: thousands of contexts) reads and writes go to the executor's
+        host columns directly."""
         self._ex, self._world, self._dt, self._t0 = ex, world, dt, int(start_timestamp or 0)
         self._tick = 0
         self._dirty = False
+        self._sink = sink
+        self._now = None                                 # the loop sets the batch-end timestamp for post_step
         names = dict(world._names)
         self._entity = {}
         for eid, name in names.items():
             self._entity[name] = eid
             self._entity[_snake(name)] = eid
         self._entity.update(world.entity_ids_by_name)
+        self._canon = dict(names)
+        self._canon.update({eid: nm for nm, eid in world.entity_ids_by_name.items()})
 
     @property
     def tick(self) -> int: return int(self._tick)
 
     @property
     def timestamp(self) -> int:                          # microseconds since the epoch: start + tick * time step
-        return self._t0 + int(round(self._tick * self._dt * 1e6))
+        return self._now if self._now is not None else self._t0 + int(round(self._tick * self._dt * 1e6))
+
+    def _pair(self, pair_name: str) -> str:
+        """The name the sink knows the pair under: the entity as spawned (`name=` or `id=`), any accepted spelling."""
+        entity, _, comp = pair_name.rpartition(".")
+        eid = self._entity.get(entity)
+        if eid is None:
+            raise RuntimeError(f"component {pair_name!r} does not exist: no entity named {entity!r}")
+        canon = self._canon.get(eid, entity)
+        return f"{canon}.{comp}"
 
     def _locate(self, pair_name: str):
         entity, _, comp = pair_name.rpartition(".")
@@ -329,10 +346,16 @@ class StepContext:
         return comp, col, row
 
     def read_component(self, pair_name: str, timestamp=None):
+        if self._sink is not None:
+            name = self._pair(pair_name)
+            return (self._sink.latest(name) if timestamp is None else self._sink.at(name, int(timestamp)))[1]
         _, col, row = self._locate(pair_name)
         return _np.array(col[row], dtype=_np.float64)
 
     def write_component(self, pair_name: str, data, timestamp=None) -> None:
+        if self._sink is not None:       # a push into the pair's series (TimeTravel if older than its last sample); the world sees
+            self._sink.push(self._pair(pair_name), data, self.timestamp if timestamp is None else int(timestamp))     # it at the next copy_db_to_world
+            return
         comp, col, row = self._locate(pair_name)
         data = _np.asarray(data, dtype=_np.float64).reshape(-1)
         if data.size != col.shape[1]:
@@ -352,7 +375,10 @@ class StepContext:
             self.write_component(name, data)
         return out
 
-    def truncate(self): raise NotImplementedError("StepContext.truncate is not provided by elodin_amd.compat (no database to rewind)")
+    def truncate(self):
+        if self._sink is None:
+            raise NotImplementedError("StepContext.truncate needs the commit sink (World.run attaches one)")
+        self._sink.truncate()
     def read_msg(self, *a, **k): raise NotImplementedError("StepContext.read_msg is not provided by elodin_amd.compat (no message log)")
     def stop_recipes(self): return None
 
@@ -365,31 +391,38 @@ def _snake(name: str) -> str:
 
 
 def run_stepwise(ex, world, simulation_rate, telemetry_rate, max_ticks, pre_step, post_step, is_canceled=None, start_timestamp=None):
-    """The reference's server loop (impeller2_server.rs:553-678) around an executor: batches of ticks_per_telemetry ticks,
-    pre_step(first tick of the batch) -> columns the callback wrote go to the device -> the batch -> commit (host columns
-    refreshed) -> post_step(LAST tick of the batch)."""
+    """The reference's server loop (impeller2_server.rs:553-678) around an executor, with its hand-off (elodin_amd.telemetry.Sink
+    = the pairs' time series): per batch of ticks_per_telemetry ticks
+        pre_step(first tick of the batch) -> copy_db_to_world (what callbacks wrote reaches the device) -> the batch ->
+        commit_world_head at the batch's END timestamp -> post_step(LAST tick of the batch)."""
+    from . import telemetry
+    from . import frontend as _fe2
     tpt = max(1, int(round(simulation_rate / telemetry_rate))) if telemetry_rate else 1
-    ctx = StepContext(ex, world, 1.0 / float(simulation_rate), start_timestamp)
-    hip = ex._hip
+    dt = 1.0 / float(simulation_rate)
+    t0 = int(start_timestamp or 0)
+    stamp = lambda k: t0 + int(round(k * dt * 1e6))
+    external = tuple(n for n, md in _fe2.COMPONENT_METADATA.items() if str(md.get("external_control", "")).lower() == "true")
+    sink = telemetry.Sink.attach(ex, world, t0, external=external)
+    ctx = StepContext(ex, world, dt, t0, sink=sink)
     tick = ex.tick
     limit = int(max_ticks) if max_ticks else None
     while limit is None or tick < limit:
         if is_canceled is not None and is_canceled():
             break
         batch = tpt if limit is None else max(1, min(tpt, limit - tick))
-        ctx._tick = tick
+        ctx._tick, ctx._now = tick, None
         if pre_step is not None:
             pre_step(tick, ctx)
-        if ctx._dirty:
-            hip.upload()
-            ctx._dirty = False
+        sink.copy_to_world()
         ex.run(batch)
         tick = ex.tick
-        ctx._tick = tick - 1                     # end_tick: the world now reflects the last tick of the batch
+        end_tick = tick - 1                      # the world now reflects the last tick of the batch
+        sink.commit(stamp(end_tick))
+        ctx._tick, ctx._now = end_tick, stamp(end_tick)
         if post_step is not None:
-            post_step(tick - 1, ctx)
-    if ctx._dirty:
-        hip.upload()
+            post_step(end_tick, ctx)
+    sink.copy_to_world()
+    ex.compat_sink = sink
     return ctx
 
 

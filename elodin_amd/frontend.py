@@ -77,9 +77,14 @@ ComponentType.SpatialPosF64 = ComponentType(PrimitiveType.F64, (7,))
 ComponentType.SpatialMotionF64 = ComponentType(PrimitiveType.F64, (6,))
 
 
+COMPONENT_METADATA: dict = {}      # component name -> the metadata it was declared with (the commit path reads `external_control`)
+
+
 class Component:
     def __init__(self, name: str, ty: Optional[ComponentType] = None, asset: bool = False, metadata: Optional[dict] = None):
         self.name_, self.ty, self.asset, self.metadata = name, ty, asset, dict(metadata or {})
+        if self.metadata:
+            COMPONENT_METADATA.setdefault(name, {}).update(self.metadata)
 
     @staticmethod
     def of(component: Any) -> "Component":

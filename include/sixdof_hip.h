@@ -55,7 +55,8 @@ typedef enum sixdof_status {
     SIXDOF_ERR_BACKEND = -4,              /* Error::CraneliftBackend(String) analogue: HIP runtime failure */
     SIXDOF_ERR_NO_DEVICE = -5,
     SIXDOF_ERR_UNSUPPORTED = -6,
-    SIXDOF_ERR_ENTITY_MISMATCH = -7       /* Body columns do not share one entity-id vector */
+    SIXDOF_ERR_ENTITY_MISMATCH = -7,      /* Body columns do not share one entity-id vector */
+    SIXDOF_ERR_TIME_TRAVEL = -8           /* elodin-db Error::TimeTravel: a sample older than the pair's last one */
 } sixdof_status;
 
 /* integrator/mod.rs:7-10 */
@@ -278,6 +279,37 @@ void sixdof_world_advance_tick(sixdof_world* w, uint64_t n);
 /* Bind every 1-D f64/f32 component column of the world to the backend handle (CraneliftExec::new walks
  * world.column_by_id the same way, cranelift_exec.rs:101-106).  Follow with sixdof_upload. */
 int sixdof_bind_world(sixdof_handle* h, sixdof_world* w);
+
+/* ---- the commit path's hand-off: per (entity, component) pair one time series ------------------------------------------
+ * What commit_world_head_for_world (libs/nox-py/src/impeller2_server.rs:398-438) writes after every batch and
+ * copy_db_to_world (:320-364) reads back before the next: PairId = ComponentId::from_pair(entity, component)
+ * (impeller2/src/types.rs:54-59), a series = an index of i64 microsecond timestamps + the samples' bytes
+ * (libs/db/src/time_series.rs:201-230: a push older than the last timestamp is SIXDOF_ERR_TIME_TRAVEL).  The database
+ * behind it (files, subscriptions, wire protocol) is out of scope; pure host code, needs no GPU. */
+typedef struct sixdof_sink sixdof_sink;
+uint64_t sixdof_pair_id(const char* entity, const char* component);               /* ComponentId::from_pair */
+sixdof_sink* sixdof_sink_create(void);
+void sixdof_sink_destroy(sixdof_sink* s);
+const char* sixdof_sink_last_error(const sixdof_sink* s);
+int sixdof_sink_register(sixdof_sink* s, uint64_t pair_id, uint32_t elem_bytes, const char* name);
+int sixdof_sink_push(sixdof_sink* s, uint64_t pair_id, int64_t timestamp_us, const void* buf, uint32_t bytes);   /* TimeSeries::push_buf */
+uint64_t sixdof_sink_sample_count(const sixdof_sink* s, uint64_t pair_id);
+size_t sixdof_sink_pairs(const sixdof_sink* s, uint64_t* ids, size_t cap);        /* ascending PairId */
+int sixdof_sink_latest(const sixdof_sink* s, uint64_t pair_id, int64_t* timestamp_us, void* out, uint32_t bytes);
+/* the sample with the greatest timestamp <= timestamp_us (past the last write: the latest; before the first:
+ * SIXDOF_ERR_COMPONENT_NOT_FOUND) — StepContext.read_component(timestamp=), elodin.pyi:63-88 */
+int sixdof_sink_at(const sixdof_sink* s, uint64_t pair_id, int64_t timestamp_us, int64_t* found_us, void* out, uint32_t bytes);
+/* the two append logs of a pair, as the database would persist them (valid until the next push) */
+int sixdof_sink_series(const sixdof_sink* s, uint64_t pair_id, const int64_t** timestamps, const uint8_t** data, uint64_t* n,
+                       uint32_t* elem_bytes);
+void sixdof_sink_truncate(sixdof_sink* s);
+/* commit_world_head for one column: row i of `rows` ([n_rows, row_bytes], e.g. a bound host column after sixdof_download /
+ * sixdof_download_wait) -> the series of pair_ids[i] (0 or unregistered: skipped, like an entity without metadata). */
+int sixdof_sink_commit_rows(sixdof_sink* s, const uint64_t* pair_ids, const void* rows, uint32_t n_rows, uint32_t row_bytes,
+                            int64_t timestamp_us);
+/* copy_db_to_world for one column: latest samples -> rows; *changed = 1 when a byte differed (follow with sixdof_upload). */
+int sixdof_sink_copy_to_rows(const sixdof_sink* s, const uint64_t* pair_ids, void* rows, uint32_t n_rows, uint32_t row_bytes,
+                             int* changed);
 
 /* ---- effector front-end: run-time generated pipes -------------------------------------------------------------
  * The reference JIT-compiles whatever effector graph the user wrote (cranelift_compile.rs:13-162).  The analogue

@@ -52,8 +52,8 @@ EXPECTED = {
     "video-stream/main.py": "traced",
     "cube-sat/main.py": "NotImplementedError",        # EGM08 gravity tables are a download (tests/cube_sat_util.py flies it with them replaced)
     "cube-sat-pysim/main.py": "NotImplementedError",  # same
-    "falcon9/main.py": "at most 64 component columns",  # the full mission adds truth-ghost / display-scoring components to the plant's 62;
-                                                        # the plant itself (sim.build_powered) is pinned in test_compat_reference_scripts.py
+    "falcon9/main.py": "traced",                      # the full mission world: 65 component columns (the limit is 128 since round 4); its ascent
+                                                      # window is flown closed-loop on the reference's fixture in test_compat_reference_scripts.py
     "rocket/main.py": "traced",                       # polars subset (compat_polars), map_coordinates, the sample window spelled concatenate /
                                                       # lax.scan: pinned on its rocket-csv baseline in test_compat_reference_scripts.py
     "voyager/main.py": "spiceypy",                    # third-party ephemeris library, not in this image

@@ -64,7 +64,10 @@ def compat():
         c.uninstall()
         sys.path[:] = path
         for name in set(sys.modules) - before:       # the scripts imported meanwhile hold references to the shim modules
-            del sys.modules[name]
+            f = getattr(sys.modules[name], "__file__", None) or ""
+            if "site-packages" in f or "dist-packages" in f or "/lib/python3" in f:
+                continue                             # real libraries first imported during the test (pandas under compat_polars)
+            del sys.modules[name]                    # stay imported: purging and re-importing them leaves two copies of their classes
 
 
 def test_ball_script_generates_the_same_kernel_as_its_respelling(compat):
@@ -83,7 +86,7 @@ def test_ball_script_generates_the_same_kernel_as_its_respelling(compat):
 def test_three_body_script_generates_the_same_pair_kernel_and_world(compat):
     ref = _load(REF / "examples" / "three-body" / "main.py", "ref_three_body")       # runs w.run(...) at import: recorded
     run = ref.w.compat_run
-    assert run["simulation_rate"] == 120.0 and run["ignored"] == {"generate_real_time": True}
+    assert run["simulation_rate"] == 120.0 and run["ignored"]["generate_real_time"] is True      # editor-only arguments are recorded, not acted on
     ours = _load(ROOT / "examples" / "three_body.py", "our_three_body")
     w2, sys2 = ours.world_and_system()
     a = ref.w.generated_sources(run["system"], simulation_rate=run["simulation_rate"])

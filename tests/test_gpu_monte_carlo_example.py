@@ -72,5 +72,12 @@ def test_unmodified_style_world_run_with_step_callbacks():
         mc._active_result[0] = saved
     assert pre_ticks[:3] == [(0, 0), (1, 1), (2, 2)] and len(pre_ticks) == doc["max_ticks"]
     assert abs(rec["final_position"] - run["result"]["final_position"]) < 1e-11 and abs(rec["error"] - run["result"]["error"]) < 1e-11
+    # the run went through the commit path's hand-off (elodin_amd.telemetry.Sink): one sample of every pair per tick + the spawned
+    # state, stamped start + tick / 120 Hz; `command` is an external control (its component says so): only the callback's writes
+    sink = w2.compat_exec.compat_sink
+    ts, pos = sink.series("vehicle.position")
+    assert len(ts) == doc["max_ticks"] + 1 and ts[0] == 0 and ts[-1] == int(round((doc["max_ticks"] - 1) / 120.0 * 1e6))
+    assert abs(pos[-1, 0] - run["result"]["final_position"]) < 1e-11
+    assert sink.sample_count("vehicle.command") == doc["max_ticks"] + 1 and sink.sample_count("vehicle.target") == doc["max_ticks"] + 1
     with pytest.raises(ValueError, match="max_ticks"):
         w2.run(system, ex.SIMULATION_RATE_HZ, post_step=ex.post_step)
