@@ -412,6 +412,9 @@ def test_falcon9_full_mission_script_unmodified_flies_the_closed_loop_ascent_win
     plan = world.build(run["system"], simulation_rate=run["simulation_rate"], telemetry_rate=run["telemetry_rate"], _dry=True)
     tp = plan["effectors"].trace()
     assert len(tp.columns) == 65 and plan["integrator"] == L.SEMI_IMPLICIT
+    from elodin_amd import codegen
+    frozen = json.loads((ROOT / "tests" / "golden" / "falcon9_main_program.json").read_text())      # what tests/test_gpu_falcon9_main.py runs on the GPU box
+    assert codegen.generate_variant(tp, frozen["variant"], "float64", plan["integrator"]) == frozen["source"], "re-run tests/golden/make_falcon9_main_program.py"
     booster = next(e for e, nm in world._names.items() if nm == "booster")
 
     def row_of(name, width):          # the booster's row of a component (the executor's rows are the Body join = the booster)

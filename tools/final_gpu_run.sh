@@ -1,20 +1,19 @@
 #!/bin/bash
-# The round's closing GPU run (through gpurun from the repo root):  gpurun --timeout 2400 -- 'bash tools/final_gpu_run.sh r03 [quick]'
+# The round's closing GPU run (through gpurun from the repo root):  gpurun --timeout 2700 -- 'bash tools/final_gpu_run.sh r04 [quick]'
 # bench lines (the driver's command, the default run, a 2-rank dry run sharing the one GPU, both campaigns), the whole GPU suite,
 # the rocprofv3 collections (skipped with `quick`); outputs under gpurun_out/final_<tag>/ — copy what is to be judged into
 # profiles/.  Also lists which JIT objects the run used and packs the ones it had to compile, so the build container can keep
 # elodin_amd/_jit exact.
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd $GRAFT_REPO_ROOT; O=gpurun_out/final_$TAG; mkdir -p $O
 touch /tmp/jit_marker; sleep 1
 find elodin_amd/_jit -name '*.so' | sort > /tmp/jit_before.txt
 python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/bench_steps20.err
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-SIXDOF_BENCH_SHARED_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
-    bench.py --gpus 2 --steps 20 --warmup 5 2> $O/bench_2rank.err | grep '^{' > $O/bench_2rank_shared_gpu.json
-python bench.py --campaign falcon9 > $O/campaign_falcon9.json 2> $O/campaign.err
-python bench.py --campaign apollo > $O/campaign_apollo.json 2>> $O/campaign.err
-timeout 1300 python -m pytest tests -m gpu -q --durations=15 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+# (the 2-rank dry run sharing the one GPU is tests/test_gpu_multirank_shared.py now: it leaves gpurun_out/bench_2rank_shared_gpu.json;
+#  both campaigns, strong and weak, are inside the bench line: `campaigns`)
+timeout 240 python tools/falcon9_k1.py > $O/falcon9_k1_policy_ab.txt 2> $O/falcon9_k1.err
+timeout 1700 python -m pytest tests -m gpu -q --durations=15 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
 find elodin_amd/_jit -name '*.so' -newer /tmp/jit_marker | sort > $O/jit_used.txt
 find elodin_amd/_jit -name '*.so' | sort > /tmp/jit_after.txt
 comm -13 /tmp/jit_before.txt /tmp/jit_after.txt | sed 's/\.so$//' | while read f; do ls $f.so $f.json $f.hip 2>/dev/null; done > /tmp/jit_new.txt
