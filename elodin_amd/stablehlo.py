@@ -1,0 +1,821 @@
+"""StableHLO text -> this package's scalar DAG (SURVEY §8 f1 in its literal form): the MLIR module the reference dumps before its
+JIT (`ELODIN_CRANELIFT_DEBUG_DIR/stablehlo.mlir`, libs/nox-py/src/cranelift_compile.rs:47-68), or the text of any
+`jax.jit(f).lower(...).as_text()`, ingested as PER-ENTITY code: `@main`'s tensor arguments are an entity's components, its
+results the components it writes, every tensor a small static array whose elements become nodes of elodin_amd.dsl — and from
+there the same code generator, the same fused kernel.
+
+What is read: the textual form the reference's own parser reads (libs/cranelift-mlir/src/parser.rs) for the op set its
+ARCHITECTURE.md lists, minus what only a whole-world (entity-batched) tick needs: element-wise arithmetic / transcendentals /
+comparisons / bit operations, constant, iota, convert, select, clamp, broadcast_in_dim, reshape, transpose, slice, concatenate,
+reverse, dot_general (batching + contracting dims), reduce (`applies` form and reducer regions), while, case, func.call,
+dynamic_slice, dynamic_update_slice, gather (the index-clamping general form), sort (1-D, comparator LT / GT), cholesky,
+triangular_solve, chlo.{erf_inv, square, acos, asin, sinh, cosh, erfc, ...}.  Integer tensors are integral values in the
+executor's float type (exact up to 2^53 in f64), like everywhere in the tracer.  Not read: scatter, convolution,
+reduce_window, select_and_scatter, rng, custom_call (LAPACK FFI), batch_norm — an unsupported op says which.
+
+Pinned on the known answers of the reference's own op tests (libs/cranelift-mlir/tests/ops.rs: inline modules with expected
+outputs -> tests/golden/stablehlo_ops.json, tests/test_stablehlo_ingest.py on the CPU walker, tests/test_gpu_stablehlo.py on
+the generated kernel).
+"""
+from __future__ import annotations
+
+import itertools
+import re
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import dsl as _dsl
+from .dsl import Expr
+
+_np = _dsl.np
+
+
+# ---- types and values ---------------------------------------------------------------------------------------------------------
+
+class TensorType:
+    def __init__(self, shape: Tuple[int, ...], dtype: str):
+        self.shape, self.dtype = tuple(int(s) for s in shape), dtype
+
+    @property
+    def size(self) -> int: return int(np.prod(self.shape)) if self.shape else 1
+    def __repr__(self): return f"tensor<{'x'.join(map(str, self.shape + (self.dtype,)))}>"
+
+
+def parse_type(text: str) -> TensorType:
+    m = re.fullmatch(r"\s*tensor<([^>]*)>\s*", text)
+    if not m:
+        raise ValueError(f"not a ranked tensor type: {text!r}")
+    parts = m.group(1).split("x")
+    return TensorType(tuple(int(p) for p in parts[:-1]), parts[-1].strip())
+
+
+class Sym:
+    """A tensor of scalar nodes: an object ndarray of dsl.Expr (booleans for i1) + its element type."""
+
+    def __init__(self, arr, dtype: str):
+        self.a = arr if isinstance(arr, np.ndarray) and arr.dtype == object else _obj(arr)
+        self.dtype = dtype
+
+    @property
+    def shape(self): return self.a.shape
+    def is_int(self): return self.dtype[0] in "iu" and self.dtype != "i1"
+    def is_bool(self): return self.dtype == "i1"
+
+
+def _obj(values) -> np.ndarray:
+    v = np.asarray(values, dtype=object) if not isinstance(values, np.ndarray) else values
+    out = np.empty(v.shape, dtype=object)
+    for idx in np.ndindex(v.shape):
+        x = v[idx]
+        out[idx] = x if isinstance(x, Expr) else _dsl.const(float(x))
+    if v.shape == ():
+        x = v[()] if isinstance(values, np.ndarray) else values
+        out = np.empty((), dtype=object)
+        out[()] = x if isinstance(x, Expr) else _dsl.const(float(x))
+    return out
+
+
+def _emap(f: Callable, *arrs) -> np.ndarray:
+    arrs = np.broadcast_arrays(*[a for a in arrs])
+    out = np.empty(arrs[0].shape, dtype=object)
+    for idx in np.ndindex(arrs[0].shape):
+        out[idx] = f(*[a[idx] for a in arrs])
+    if arrs[0].shape == ():
+        out[()] = f(*[a[()] for a in arrs])
+    return out
+
+
+# ---- parsing --------------------------------------------------------------------------------------------------------------------
+
+class Op:
+    def __init__(self, results, name, text, regions=None, region_args=None):
+        self.results, self.name, self.text = results, name, text
+        self.regions: List[List["Op"]] = regions or []
+        self.region_args: List[List[Tuple[str, TensorType]]] = region_args or []
+
+
+class Func:
+    def __init__(self, name, args, result_types, body):
+        self.name, self.args, self.result_types, self.body = name, args, result_types, body
+
+
+_HEAD = re.compile(r"^(?:(%[\w#.]+(?::\d+)?(?:\s*,\s*%[\w#.]+)*)\s*=\s*)?(\"?[\w.]+\"?)(.*)$", re.S)
+
+
+def _split_top(text: str, sep: str = ",") -> List[str]:
+    parts, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "([{<":
+            depth += 1
+        elif ch in ")]}>":
+            depth -= 1
+        if ch == sep and depth == 0:
+            parts.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        parts.append(cur)
+    return [p.strip() for p in parts]
+
+
+def _typed_args(text: str) -> List[Tuple[str, TensorType]]:
+    out = []
+    for p in _split_top(text):
+        if not p:
+            continue
+        name, _, ty = p.partition(":")
+        ty = re.sub(r"\s*\{.*\}\s*$", "", ty.strip())          # argument attributes
+        out.append((name.strip(), parse_type(ty)))
+    return out
+
+
+class _Lines:
+    def __init__(self, text):
+        raw = [ln.strip() for ln in text.splitlines()]
+        raw = [ln for ln in raw if ln and not ln.startswith("//")]
+        # logical lines: a statement (or a function header) may wrap — while its parentheses / brackets are open, or it ends
+        # in `,` / `:` — but a line that OPENS a region (`({`, `{`) is complete
+        self.lines, cur = [], ""
+        for ln in raw:
+            cur = (cur + " " + ln) if cur else ln
+            open_ = cur.count("(") - cur.count(")") + cur.count("[") - cur.count("]")
+            if cur.endswith(("({", "{")) or cur.startswith("^bb") or (open_ <= 0 and not cur.endswith((",", ":"))):
+                self.lines.append(cur)
+                cur = ""
+        if cur:
+            self.lines.append(cur)
+        self.i = 0
+
+    def peek(self): return self.lines[self.i] if self.i < len(self.lines) else None
+    def next(self):
+        ln = self.lines[self.i]
+        self.i += 1
+        return ln
+
+
+def _parse_block(L: _Lines) -> Tuple[List[Op], str]:
+    """Ops until a line that closes the block; returns (ops, the closing line)."""
+    ops: List[Op] = []
+    while True:
+        ln = L.next()
+        if ln.startswith("}"):
+            return ops, ln
+        if ln.startswith("^bb"):                              # block header inside a generic region: handled by the caller
+            ops.append(Op([], "^bb", ln))
+            continue
+        while L.peek() is not None and L.peek()[0] in "(:-" and not ln.rstrip().endswith("({"):      # a signature on its own line
+            ln = ln + " " + L.next()
+        m = _HEAD.match(ln)
+        if not m:
+            raise ValueError(f"cannot parse statement: {ln!r}")
+        res, name, rest = m.group(1), m.group(2).strip('"'), m.group(3)
+        results = []
+        if res:
+            for r in _split_top(res):
+                base, _, count = r.partition(":")
+                results += [f"{base}#{k}" for k in range(int(count))] if count else [base]
+                if count:
+                    results.insert(len(results) - int(count), base)      # %0:2 also answers to %0 (= #0)
+        op = Op(results, name, rest.strip())
+        text = rest
+        # regions
+        if name == "stablehlo.while":
+            while L.peek() is not None and re.match(r"^(\}\s*)?(cond|do)\s*\{", L.peek()):
+                L.next()
+                body, closing = _parse_block(L)
+                op.regions.append(body)
+                while re.match(r"^\}\s*do\s*\{", closing):
+                    body, closing = _parse_block(L)
+                    op.regions.append(body)
+        elif text.rstrip().endswith("({"):
+            while True:
+                body, closing = _parse_block(L)
+                args = []
+                if body and body[0].name == "^bb":
+                    hdr = body.pop(0).text
+                    args = _typed_args(hdr[hdr.index("(") + 1: hdr.rindex(")")])
+                op.regions.append(body)
+                op.region_args.append(args)
+                if re.match(r"^\}\s*,\s*\{", closing):
+                    continue
+                op.text = text + " " + closing
+                break
+        elif L.peek() is not None and L.peek().startswith("reducer("):
+            hdr = L.next()
+            args = _typed_args(hdr[hdr.index("(") + 1: hdr.rindex(")")])
+            body, _ = _parse_block(L)
+            op.regions.append(body)
+            op.region_args.append(args)
+        ops.append(op)
+
+
+def parse_module(text: str) -> Dict[str, Func]:
+    L = _Lines(text)
+    funcs: Dict[str, Func] = {}
+    while L.peek() is not None:
+        ln = L.next()
+        m = re.match(r"^func\.func\s+(?:public\s+|private\s+)?@([\w.$-]+)\(", ln)
+        if not m or not ln.endswith("{"):
+            continue
+        depth, k0 = 0, m.end() - 1
+        for k in range(k0, len(ln)):                       # the balanced argument list
+            depth += ln[k] == "("
+            depth -= ln[k] == ")"
+            if depth == 0:
+                break
+        args_text, tail = ln[k0 + 1:k], ln[k + 1:-1].strip()
+        tail = re.sub(r"attributes\s*\{.*\}\s*$", "", tail).strip()
+        res = tail[2:].strip() if tail.startswith("->") else ""
+        if res.startswith("("):
+            res = res[1:res.rindex(")")]
+        rtypes = [parse_type(re.sub(r"\s*\{.*\}\s*$", "", r)) for r in _split_top(res)] if res else []
+        body, _ = _parse_block(L)
+        funcs[m.group(1)] = Func(m.group(1), _typed_args(args_text), rtypes, body)
+    if "main" not in funcs:
+        raise ValueError("module has no @main")
+    return funcs
+
+
+# ---- evaluation ---------------------------------------------------------------------------------------------------------------
+
+_UNARY = {"negate": lambda x: -x, "sqrt": _np.sqrt, "rsqrt": lambda x: 1.0 / _np.sqrt(x), "exponential": _np.exp, "log": _np.log,
+          "sine": _np.sin, "cosine": _np.cos, "tan": _np.tan, "tanh": _np.tanh, "abs": _np.abs, "sign": _np.sign, "floor": _np.floor,
+          "ceil": _np.ceil, "log_plus_one": _np.log1p, "exponential_minus_one": _np.expm1, "cbrt": _np.cbrt,
+          "round_nearest_even": _np.rint, "atan": _np.arctan}
+_CHLO = {"erf_inv": lambda x: Expr("erfinv", (_dsl._lift(x),)), "square": lambda x: x * x, "acos": _np.arccos, "asin": _np.arcsin,
+         "sinh": _np.sinh, "cosh": _np.cosh, "erfc": _np.erfc, "atan": _np.arctan, "tan": _np.tan, "erf": lambda x: 1.0 - _np.erfc(x)}
+_CMP = {"EQ": lambda a, b: _np.equal(a, b), "NE": lambda a, b: _np.logical_not(_np.equal(a, b)), "LT": lambda a, b: a < b,
+        "LE": lambda a, b: a <= b, "GT": lambda a, b: a > b, "GE": lambda a, b: a >= b}
+
+
+def _trunc_div(a, b):
+    return _np.trunc(a / b)
+
+
+def _rem(a, b):                                    # stablehlo.remainder: the sign of the DIVIDEND (C's fmod / %)
+    return a - _np.trunc(a / b) * b
+
+
+class _Eval:
+    def __init__(self, funcs: Dict[str, Func]):
+        self.funcs = funcs
+
+    # -- plumbing --
+    def call(self, fn: Func, args: Sequence[Sym]) -> List[Sym]:
+        env = {name: a for (name, _), a in zip(fn.args, args)}
+        return self.block(fn.body, env)
+
+    def block(self, ops: List[Op], env: Dict[str, Sym]) -> List[Sym]:
+        env = dict(env)
+        for op in ops:
+            if op.name in ("return", "stablehlo.return", "func.return"):
+                names = _split_top(op.text.split(":")[0]) if op.text.strip() else []
+                return [env[n] for n in names]
+            outs = self.op(op, env)
+            if len(op.results) == 1:
+                env[op.results[0]] = outs[0]
+            else:
+                plain = [r for r in op.results if "#" in r]
+                for r, o in zip(plain, outs):
+                    env[r] = o
+                if plain:
+                    env[plain[0].split("#")[0]] = outs[0]
+        return []
+
+    def _operands(self, text: str, env) -> List[Sym]:
+        return [env[n] for n in re.findall(r"%[\w#.]+", text)]
+
+    @staticmethod
+    def _result_types(text: str) -> List[TensorType]:
+        sig = text[text.rindex(":") + 1:] if ":" in text else ""
+        # the type signature is what follows the LAST top-level colon
+        depth, cut = 0, None
+        for k, ch in enumerate(text):
+            if ch in "([{<":
+                depth += 1
+            elif ch in ")]}>":
+                depth -= 1
+            elif ch == ":" and depth == 0:
+                cut = k
+        sig = text[cut + 1:].strip() if cut is not None else ""
+        if cut is None and "->" in text:                       # custom_call: `{attributes} -> (types)` without a colon
+            sig = "->" + text.rsplit("->", 1)[1]
+        if "->" in sig:
+            sig = sig.split("->")[-1].strip()
+        if sig.startswith("("):
+            sig = sig[1:-1]
+        return [parse_type(t) for t in _split_top(sig) if t.startswith("tensor<")]
+
+    @staticmethod
+    def _ints(text: str, key: str) -> List[int]:
+        m = re.search(re.escape(key) + r"\s*=\s*(?:array<i64(?::\s*([^>]*))?>|\[([^\]]*)\])", text)
+        if not m:
+            return []
+        body = m.group(1) if m.group(1) is not None else (m.group(2) or "")
+        return [int(x) for x in body.replace(" ", "").split(",") if x]
+
+    # -- ops --
+    def op(self, op: Op, env) -> List[Sym]:
+        name, text = op.name, op.text
+        short = name.split(".", 1)[1] if "." in name else name
+        if name in ("call", "func.call"):
+            m = re.match(r"\s*@([\w.$-]+)\((.*?)\)\s*:", text)
+            return self.call(self.funcs[m.group(1)], [env[n] for n in re.findall(r"%[\w#.]+", m.group(2))])
+        rts = self._result_types(text)
+        rt = rts[0] if rts else None
+        if short == "constant":
+            return [self._constant(text, rt)]
+        if short == "iota":
+            dim = int(re.search(r"dim\s*=\s*(\d+)", text).group(1))
+            idx = np.indices(rt.shape)[dim] if rt.shape else np.zeros(())
+            return [Sym(_obj(idx.astype(float)), rt.dtype)]
+        args_text = text
+        for r in (op.regions and [""] or []):
+            pass
+        head = text.split(":")[0] if name.startswith("chlo") or short in _UNARY else text
+        if short == "while":
+            return self._while(op, text, env)
+        xs = self._operands(self._operand_text(text), env)
+        if name.startswith("chlo."):
+            return [Sym(_emap(_CHLO[short], xs[0].a), rt.dtype)]
+        if short in _UNARY:
+            x = xs[0]
+            if short == "abs" and x.is_int():
+                return [Sym(_emap(_np.abs, x.a), x.dtype)]
+            return [Sym(_emap(_UNARY[short], x.a), x.dtype)]
+        if short == "not":
+            x = xs[0]
+            if x.is_bool():
+                return [Sym(_emap(_np.logical_not, x.a), "i1")]
+            bits = int(re.sub(r"\D", "", x.dtype) or 64)
+            return [Sym(_emap(lambda v: (2.0 ** bits - 1.0) - v if x.dtype[0] == "u" else -v - 1.0, x.a), x.dtype)]
+        if short == "is_finite":
+            return [Sym(_emap(lambda v: Expr("isfinite", (_dsl._lift(v),)), xs[0].a), "i1")]
+        if short in ("add", "subtract", "multiply", "divide", "maximum", "minimum", "power", "atan2", "remainder", "and", "or", "xor",
+                     "shift_left", "shift_right_logical", "shift_right_arithmetic"):
+            a, b = xs[0], xs[1]
+            return [Sym(_emap(self._binary(short, a), a.a, b.a), a.dtype)]
+        if short == "compare":
+            d = re.search(r"\b(EQ|NE|LT|LE|GT|GE)\b", text).group(1)
+            return [Sym(_emap(_CMP[d], xs[0].a, xs[1].a), "i1")]
+        if short == "select":
+            c, a, b = xs
+            return [Sym(_emap(lambda cc, x, y: _np.where(cc, x, y), np.broadcast_to(c.a, a.a.shape), a.a, b.a), a.dtype)]
+        if short == "clamp":
+            lo, x, hi = xs
+            return [Sym(_emap(lambda l, v, h: _np.minimum(_np.maximum(v, l), h), np.broadcast_to(lo.a, x.a.shape), x.a, np.broadcast_to(hi.a, x.a.shape)), x.dtype)]
+        if short == "convert":
+            return [self._convert(xs[0], rt.dtype)]
+        if short == "broadcast_in_dim":
+            dims = self._ints(text, "dims") or self._ints(text, "broadcast_dimensions")
+            x = xs[0]
+            shape = [1] * len(rt.shape)
+            for src, dst in enumerate(dims):
+                shape[dst] = x.shape[src]
+            return [Sym(np.broadcast_to(x.a.reshape(shape), rt.shape).copy(), x.dtype)]
+        if short == "reshape":
+            return [Sym(xs[0].a.reshape(rt.shape), xs[0].dtype)]
+        if short == "transpose":
+            perm = self._ints(text, "dims") or self._ints(text, "permutation")
+            return [Sym(np.transpose(xs[0].a, perm).copy(), xs[0].dtype)]
+        if short == "reverse":
+            dims = self._ints(text, "dims") or self._ints(text, "dimensions")
+            return [Sym(np.flip(xs[0].a, axis=tuple(dims)).copy(), xs[0].dtype)]
+        if short == "slice":
+            m = re.search(r"\[([^\]]*)\]\s*:", text)
+            sl = []
+            for part in m.group(1).split(","):
+                p = [int(v) for v in part.strip().split(":")]
+                sl.append(slice(p[0], p[1], p[2] if len(p) > 2 else 1))
+            return [Sym(xs[0].a[tuple(sl)].copy(), xs[0].dtype)]
+        if short == "concatenate":
+            dim = int(re.search(r"dim(?:ension)?\s*=\s*(\d+)", text).group(1))
+            return [Sym(np.concatenate([x.a for x in xs], axis=dim), xs[0].dtype)]
+        if short == "dot_general":
+            return [self._dot_general(xs[0], xs[1], text, rt)]
+        if short == "reduce":
+            return self._reduce(op, xs, text, rts, env)
+        if short == "while":
+            return self._while(op, text, env)
+        if short == "case":
+            return self._case(op, xs[0], env)
+        if short == "dynamic_slice":
+            sizes = self._ints(text, "sizes") or self._ints(text, "slice_sizes")
+            return [self._dynamic_slice(xs[0], xs[1:], sizes)]
+        if short == "dynamic_update_slice":
+            return [self._dynamic_update_slice(xs[0], xs[1], xs[2:])]
+        if short == "gather":
+            return [self._gather(xs[0], xs[1], text, rt)]
+        if short == "sort":
+            return [self._sort(op, xs[0], text)]
+        if short == "cholesky":
+            from . import dsl_mat
+            lower = "lower = true" in text
+            rows = [_dsl.Vec(list(r)) for r in xs[0].a]
+            Lm = dsl_mat.cholesky(dsl_mat.Mat(rows), lower=lower)
+            return [Sym(np.array([[e for e in r.e] for r in Lm], dtype=object), xs[0].dtype)]
+        if short == "custom_call":
+            return self._custom_call(text, xs, rts)
+        if short == "triangular_solve":
+            from . import dsl_mat
+            if "left_side = true" not in text:
+                raise NotImplementedError("stablehlo.triangular_solve: left_side = false")
+            lower, unit = "lower = true" in text, "unit_diagonal = true" in text
+            trans = 1 if re.search(r"transpose_a\s*=\s*#stablehlo<transpose\s+(TRANSPOSE|ADJOINT)>", text) else 0
+            A = dsl_mat.Mat([_dsl.Vec(list(r)) for r in xs[0].a])
+            B = xs[1].a
+            cols = []
+            for j in range(B.shape[1]):
+                cols.append(dsl_mat.solve_triangular(A, _dsl.Vec(list(B[:, j])), lower=lower, trans=trans, unit_diagonal=unit))
+            return [Sym(np.array([[cols[j].e[i] for j in range(B.shape[1])] for i in range(B.shape[0])], dtype=object), xs[1].dtype)]
+        if short == "map":
+            region = self._region_fn(op, 0, env)
+            out = np.empty(xs[0].shape, dtype=object)
+            for idx in (np.ndindex(xs[0].shape) if xs[0].shape else [()]):
+                out[idx] = region(*[Sym(_obj_scalar(x.a[idx]), x.dtype) for x in xs])[0].a[()]
+            return [Sym(out, rt.dtype)]
+        raise NotImplementedError(f"StableHLO op {name} is not provided by elodin_amd.stablehlo")
+
+    @staticmethod
+    def _operand_text(text: str) -> str:
+        """The part of a statement that names its operands: everything before the type signature / attribute dictionary."""
+        depth, cut = 0, len(text)
+        for k, ch in enumerate(text):
+            if ch in "([<":
+                depth += 1
+            elif ch in ")]>":
+                depth -= 1
+            elif ch == "{" and depth == 0:
+                cut = min(cut, k)
+                break
+            elif ch == ":" and depth == 0:
+                cut = k
+                break
+        return text[:cut]
+
+    def _binary(self, short, a: Sym):
+        if short == "add":
+            return lambda x, y: x + y
+        if short == "subtract":
+            return lambda x, y: x - y
+        if short == "multiply":
+            return (lambda x, y: _np.logical_and(x, y)) if a.is_bool() else (lambda x, y: x * y)
+        if short == "divide":
+            return _trunc_div if a.is_int() else (lambda x, y: x / y)
+        if short == "maximum":
+            return (lambda x, y: _np.logical_or(x, y)) if a.is_bool() else _np.maximum
+        if short == "minimum":
+            return (lambda x, y: _np.logical_and(x, y)) if a.is_bool() else _np.minimum
+        if short == "power":
+            return _np.power
+        if short == "atan2":
+            return _np.arctan2
+        if short == "remainder":
+            return _rem
+        if short in ("and", "or", "xor"):
+            if a.is_bool():
+                return {"and": _np.logical_and, "or": _np.logical_or,
+                        "xor": lambda x, y: _np.logical_and(_np.logical_or(x, y), _np.logical_not(_np.logical_and(x, y)))}[short]
+            return {"and": _np.bitwise_and, "or": _np.bitwise_or, "xor": _np.bitwise_xor}[short]
+        bits = float(int(re.sub(r"\D", "", a.dtype) or 64))
+        if short == "shift_left":        # a shift by the width or more gives 0 (StableHLO), and the result wraps to the width
+            return lambda x, y: _np.where(y >= bits, 0.0, _np.remainder(_np.left_shift(x, _np.minimum(y, bits - 1.0)), 2.0 ** bits)
+                                          if a.dtype[0] == "u" else _np.left_shift(x, _np.minimum(y, bits - 1.0)))
+        if short == "shift_right_logical":
+            return lambda x, y: _np.where(y >= bits, 0.0, _np.right_shift(x, _np.minimum(y, bits - 1.0)))
+        if short == "shift_right_arithmetic":
+            return lambda x, y: _np.floor(x / _np.power(2.0, _np.minimum(y, bits - 1.0)))
+        raise NotImplementedError(short)
+
+    @staticmethod
+    def _constant(text: str, rt: TensorType) -> Sym:
+        m = re.search(r"dense<(.*)>\s*:", text, re.S)
+        body = m.group(1).strip()
+        if body.startswith('"0x'):
+            raise NotImplementedError("hex-encoded dense constants")
+        body = body.replace("true", "1").replace("false", "0")
+        vals = [float(int(v, 16)) if v.lower().startswith(("0x", "-0x")) else float(v) for v in re.findall(r"-?(?:0x[0-9a-fA-F]+|[\d.]+(?:[eE][-+]?\d+)?|inf|nan)", body)]
+        arr = np.full(rt.shape, vals[0]) if len(vals) == 1 else np.array(vals, dtype=np.float64).reshape(rt.shape)
+        if rt.dtype == "i1":
+            out = np.empty(rt.shape, dtype=object)
+            for idx in np.ndindex(rt.shape):
+                out[idx] = _dsl.const(arr[idx]) > 0.5
+            if rt.shape == ():
+                out[()] = _dsl.const(float(arr)) > 0.5
+            return Sym(out, "i1")
+        return Sym(_obj(arr), rt.dtype)
+
+    @staticmethod
+    def _convert(x: Sym, to: str) -> Sym:
+        if x.is_bool():
+            return x if to == "i1" else Sym(_emap(lambda c: _np.where(c, 1.0, 0.0), x.a), to)
+        if to == "i1":
+            return Sym(_emap(lambda v: _np.logical_not(_np.equal(v, 0.0)), x.a), "i1")
+        if to[0] in "iu" and not x.is_int():
+            return Sym(_emap(_np.trunc, x.a), to)
+        return Sym(x.a, to)
+
+    def _dot_general(self, a: Sym, b: Sym, text: str, rt: TensorType) -> Sym:
+        def pair(key):
+            m = re.search(key + r"\s*=\s*\[([^\]]*)\]\s*x\s*\[([^\]]*)\]", text)
+            if not m:
+                return [], []
+            f = lambda s: [int(v) for v in s.replace(" ", "").split(",") if v]
+            return f(m.group(1)), f(m.group(2))
+        ba, bb = pair("batching_dims")
+        ca, cb = pair("contracting_dims")
+        fa = [d for d in range(a.a.ndim) if d not in ba + ca]
+        fb = [d for d in range(b.a.ndim) if d not in bb + cb]
+        out = np.empty(rt.shape, dtype=object)
+        for idx in (np.ndindex(rt.shape) if rt.shape else [()]):
+            bi, ai, bj = idx[:len(ba)], idx[len(ba):len(ba) + len(fa)], idx[len(ba) + len(fa):]
+            acc = None
+            for k in itertools.product(*[range(a.shape[d]) for d in ca]):
+                ia, ib = [0] * a.a.ndim, [0] * b.a.ndim
+                for d, v in zip(ba, bi):
+                    ia[d] = v
+                for d, v in zip(bb, bi):
+                    ib[d] = v
+                for d, v in zip(fa, ai):
+                    ia[d] = v
+                for d, v in zip(fb, bj):
+                    ib[d] = v
+                for d, v in zip(ca, k):
+                    ia[d] = v
+                for d, v in zip(cb, k):
+                    ib[d] = v
+                term = a.a[tuple(ia)] * b.a[tuple(ib)]
+                acc = term if acc is None else acc + term
+            out[idx] = acc if acc is not None else _dsl.const(0.0)
+        return Sym(out, a.dtype)
+
+    def _region_fn(self, op: Op, k: int, env):
+        ops, args = op.regions[k], op.region_args[k] if k < len(op.region_args) else []
+        def f(*vals):
+            e = dict(env)
+            for (name, ty), v in zip(args, vals):
+                e[name] = v if isinstance(v, Sym) else Sym(_obj(v), ty.dtype)
+            return self.block(ops, e)
+        return f
+
+    def _reduce(self, op: Op, xs, text, rts, env) -> List[Sym]:
+        dims = self._ints(text, "dimensions")
+        n = len(xs) // 2
+        operands, inits = xs[:n], xs[n:]
+        m = re.search(r"applies\s+([\w.]+)", text)
+        if m:
+            short = m.group(1).split(".", 1)[1]
+            fn = self._binary(short, operands[0])
+            combine = lambda acc, vals: [fn(acc[0], vals[0])]
+        else:
+            region = self._region_fn(op, 0, env)
+            def combine(acc, vals):
+                outs = region(*[Sym(_obj_scalar(v), o.dtype) for v, o in zip(acc, operands)], *[Sym(_obj_scalar(v), o.dtype) for v, o in zip(vals, operands)])
+                return [o.a[()] for o in outs]
+        keep = [d for d in range(operands[0].a.ndim) if d not in dims]
+        out_shape = tuple(operands[0].shape[d] for d in keep)
+        outs = [np.empty(out_shape, dtype=object) for _ in operands]
+        for idx in (np.ndindex(out_shape) if out_shape else [()]):
+            acc = [i.a[()] for i in inits]
+            for k in itertools.product(*[range(operands[0].shape[d]) for d in dims]):
+                full = [0] * operands[0].a.ndim
+                for d, v in zip(keep, idx):
+                    full[d] = v
+                for d, v in zip(dims, k):
+                    full[d] = v
+                acc = combine(acc, [o.a[tuple(full)] for o in operands])
+            for o, v in zip(outs, acc):
+                o[idx] = v
+        return [Sym(o, x.dtype) for o, x in zip(outs, operands)]
+
+    def _while(self, op: Op, text: str, env) -> List[Sym]:
+        m = re.match(r"\s*\((.*?)\)\s*:", text, re.S)
+        binds = [p.split("=") for p in _split_top(m.group(1))]
+        names = [b[0].strip() for b in binds]
+        inits = [env[b[1].strip()] for b in binds]
+        shapes, dtypes = [x.shape for x in inits], [x.dtype for x in inits]
+        flat = [v for x in inits for v in x.a.reshape(-1)]
+        # i1 values cannot be carried as floats and back without a comparison: carry 0 / 1
+        flat = [(_np.where(v, 1.0, 0.0) if dt == "i1" else v) for x, dt in zip(inits, dtypes) for v in x.a.reshape(-1)]
+
+        def rebuild(vals):
+            out, k = {}, 0
+            for nm, shp, dt in zip(names, shapes, dtypes):
+                size = int(np.prod(shp)) if shp else 1
+                arr = np.empty(shp, dtype=object)
+                chunk = vals[k:k + size]
+                chunk = [(c > 0.5) for c in chunk] if dt == "i1" else chunk
+                if shp == ():
+                    arr[()] = chunk[0]
+                else:
+                    arr.reshape(-1)[:] = chunk
+                out[nm] = Sym(arr, dt)
+                k += size
+            return out
+
+        def cond(c):
+            e = dict(env)
+            e.update(rebuild(list(c.e) if isinstance(c, _dsl.Vec) else [c]))
+            return self.block(op.regions[0], e)[0].a[()]
+
+        def body(c):
+            e = dict(env)
+            e.update(rebuild(list(c.e) if isinstance(c, _dsl.Vec) else [c]))
+            outs = self.block(op.regions[1], e)
+            vals = [(_np.where(v, 1.0, 0.0) if o.dtype == "i1" else v) for o in outs for v in o.a.reshape(-1)]
+            return _dsl.Vec(vals)
+        res = _dsl.lax.while_loop(cond, body, _dsl.Vec(flat))
+        final = rebuild(list(res.e))
+        return [final[nm] for nm in names]
+
+    def _case(self, op: Op, index: Sym, env) -> List[Sym]:
+        branches = [self.block(r, env) for r in op.regions]
+        n = len(branches)
+        idx = index.a[()]
+        idx = _np.where(_np.logical_or(idx < 0.0, idx > float(n - 1)), float(n - 1), idx)      # out of range: the last branch
+        outs = []
+        for k in range(len(branches[0])):
+            pick = branches[n - 1][k].a
+            for j in range(n - 2, -1, -1):
+                pick = _emap(lambda cur, alt, j=j: _np.where(_np.equal(idx, float(j)), alt, cur), pick, branches[j][k].a)
+            outs.append(Sym(pick, branches[0][k].dtype))
+        return outs
+
+    @staticmethod
+    def _pick(cands: List[np.ndarray], idx) -> np.ndarray:
+        """cands[idx] element-wise for a traced (already clamped) idx."""
+        if len(cands) == 1:
+            return cands[0]
+        out = cands[-1]
+        for k in range(len(cands) - 2, -1, -1):
+            out = _emap(lambda cur, alt, k=k: _np.where(idx < (k + 0.5), alt, cur), out, cands[k])
+        return out
+
+    def _dynamic_slice(self, x: Sym, starts: List[Sym], sizes: List[int]) -> Sym:
+        cur = x.a
+        for d, (s, size) in enumerate(zip(starts, sizes)):
+            hi = cur.shape[d] - size
+            idx = _np.clip(s.a[()], 0.0, float(hi))                     # StableHLO clamps the start so the slice fits
+            cands = [np.take(cur, range(k, k + size), axis=d) for k in range(hi + 1)]
+            cur = self._pick(cands, idx)
+        return Sym(cur, x.dtype)
+
+    def _dynamic_update_slice(self, x: Sym, upd: Sym, starts: List[Sym]) -> Sym:
+        idxs = [_np.clip(s.a[()], 0.0, float(x.shape[d] - upd.shape[d])) for d, s in enumerate(starts)]
+        out = np.empty(x.shape, dtype=object)
+        for pos in (np.ndindex(x.shape) if x.shape else [()]):
+            val = x.a[pos]
+            # the update element that lands on `pos`, if any: pos - start in [0, upd.shape)
+            for off in (np.ndindex(upd.shape) if upd.shape else [()]):
+                start = [p - o for p, o in zip(pos, off)]
+                if any(s_ < 0 or s_ > x.shape[d] - upd.shape[d] for d, s_ in enumerate(start)):
+                    continue
+                hit = None
+                for d, s_ in enumerate(start):
+                    c = _np.equal(idxs[d], float(s_))
+                    hit = c if hit is None else _np.logical_and(hit, c)
+                val = upd.a[off] if hit is None else _np.where(hit, upd.a[off], val)
+            out[pos] = val
+        return Sym(out, x.dtype)
+
+    def _gather(self, operand: Sym, indices: Sym, text: str, rt: TensorType) -> Sym:
+        g = lambda key: self._ints(text, key)
+        offset_dims, collapsed, start_map = g("offset_dims"), g("collapsed_slice_dims"), g("start_index_map")
+        op_batch, idx_batch = g("operand_batching_dims"), g("start_indices_batching_dims")
+        ivd = int(re.search(r"index_vector_dim\s*=\s*(\d+)", text).group(1))
+        slice_sizes = g("slice_sizes")
+        batch_dims = [d for d in range(len(rt.shape)) if d not in offset_dims]
+        kept_operand_dims = [d for d in range(operand.a.ndim) if d not in collapsed and d not in op_batch]
+        out = np.empty(rt.shape, dtype=object)
+        for pos in (np.ndindex(rt.shape) if rt.shape else [()]):
+            bidx = [pos[d] for d in batch_dims]
+            # the start vector of this batch position
+            sel = list(bidx)
+            if ivd < indices.a.ndim:
+                sel.insert(ivd, slice(None))
+                vec = list(np.atleast_1d(indices.a[tuple(sel)]))
+            else:
+                vec = [indices.a[tuple(sel)]]
+            full = [None] * operand.a.ndim                           # per operand dim: a static int or a traced index
+            for k, d in enumerate(start_map):
+                full[d] = _np.clip(vec[k], 0.0, float(operand.shape[d] - slice_sizes[d]))
+            for ob, ib in zip(op_batch, idx_batch):
+                pos_in_idx = [d for d in range(indices.a.ndim) if d != ivd]
+                full[ob] = bidx[pos_in_idx.index(ib)]
+            for k, d in enumerate(kept_operand_dims):
+                off = pos[offset_dims[k]]
+                full[d] = off if full[d] is None else full[d] + float(off)
+            for d in range(operand.a.ndim):
+                if full[d] is None:
+                    full[d] = 0
+            cur = operand.a
+            for d in range(operand.a.ndim):                           # peel one dimension at a time
+                ix = full[d]
+                if isinstance(ix, (int, np.integer)):
+                    cur = cur[int(ix)]
+                elif isinstance(ix, Expr) and ix.op == "const":
+                    cur = cur[int(ix.value)]
+                else:
+                    cands = [np.asarray(cur[k], dtype=object) if cur.ndim > 1 else _scalar(cur[k]) for k in range(cur.shape[0])]
+                    cur = self._pick(cands, ix)
+            out[pos] = cur[()] if isinstance(cur, np.ndarray) else cur
+        return Sym(out, operand.dtype)
+
+    def _custom_call(self, text: str, xs: List[Sym], rts) -> List[Sym]:
+        """The LAPACK FFI calls jax.numpy.linalg lowers to on CPU, for the factorisations elodin_amd.dsl_mat unrolls: dpotrf
+        (Cholesky; the other triangle is zero) and dtrsm (triangular solve, left side)."""
+        from . import dsl_mat
+        target = re.search(r"@([\w.]+)", text).group(1)
+        attr = lambda key, default=None: (lambda m: int(m.group(1)) if m else default)(re.search(key + r"\s*=\s*(\d+)\s*:\s*ui8", text))
+        if target == "lapack_dpotrf_ffi" and xs[0].a.ndim == 2:
+            lower = attr("uplo", 76) == 76
+            n = xs[0].shape[0]
+            Lm = dsl_mat.cholesky(dsl_mat.Mat([_dsl.Vec(list(r)) for r in xs[0].a]), lower=lower)
+            out = _obj(np.zeros((n, n)))                    # the reference's dpotrf hands back the factor alone: other triangle zero
+            for i in range(n):                              # (libs/cranelift-mlir/tests/ops.rs test_lapack_cholesky_3x3)
+                for j in range(n):
+                    if (j <= i) if lower else (j >= i):
+                        out[i, j] = Lm[i].e[j]
+            return [Sym(out, xs[0].dtype), Sym(_obj(np.zeros(())), "i32")][:max(1, len(rts))]
+        if target == "lapack_dtrsm_ffi" and xs[0].a.ndim == 2 and attr("side", 76) == 76:
+            lower, unit, trans = attr("uplo", 76) == 76, attr("diag", 78) == 85, 0 if attr("trans_x", 78) == 78 else 1
+            A, B = dsl_mat.Mat([_dsl.Vec(list(r)) for r in xs[0].a]), xs[1].a
+            cols = [dsl_mat.solve_triangular(A, _dsl.Vec(list(B[:, j])), lower=lower, trans=trans, unit_diagonal=unit) for j in range(B.shape[1])]
+            return [Sym(np.array([[cols[j].e[i] for j in range(B.shape[1])] for i in range(B.shape[0])], dtype=object), xs[1].dtype)]
+        raise NotImplementedError(f"stablehlo.custom_call @{target} is not provided by elodin_amd.stablehlo")
+
+    def _sort(self, op: Op, x: Sym, text: str) -> Sym:
+        if x.a.ndim != 1:
+            raise NotImplementedError("stablehlo.sort: one-dimensional operands only")
+        body = " ".join(o.text for o in op.regions[0])
+        descending = bool(re.search(r"\bGT\b|\bGE\b", body))
+        v = _np.sort(_dsl.Vec(list(x.a)))
+        elems = list(v.e)[::-1] if descending else list(v.e)
+        return Sym(np.array(elems, dtype=object), x.dtype)
+
+
+def _scalar(v) -> np.ndarray:
+    a = np.empty((), dtype=object)
+    a[()] = v
+    return a
+
+
+def _obj_scalar(v) -> np.ndarray:
+    return _scalar(v if isinstance(v, Expr) else _dsl.const(float(v)))
+
+
+# ---- the front-end entry points ----------------------------------------------------------------------------------------------
+
+def trace(text: str, inputs: Sequence) -> List[Sym]:
+    """Evaluate @main on symbolic inputs (one per argument: a Sym, a dsl.Vec / Expr, or nested lists of those / numbers)."""
+    funcs = parse_module(text)
+    main = funcs["main"]
+    if len(inputs) != len(main.args):
+        raise ValueError(f"@main takes {len(main.args)} arguments, {len(inputs)} given")
+    args = []
+    for (name, ty), v in zip(main.args, inputs):
+        if isinstance(v, Sym):
+            args.append(v)
+            continue
+        elems = list(v.e) if isinstance(v, _dsl.Vec) else ([v] if isinstance(v, Expr) else list(np.asarray(v, dtype=object).reshape(-1)))
+        if len(elems) != ty.size:
+            raise ValueError(f"argument {name}: {ty} has {ty.size} elements, {len(elems)} given")
+        arr = np.empty(ty.shape, dtype=object)
+        if ty.shape == ():
+            arr[()] = elems[0]
+        else:
+            arr.reshape(-1)[:] = elems
+        if ty.dtype == "i1":
+            arr = _emap(lambda e: e > 0.5, arr)
+        args.append(Sym(arr, ty.dtype))
+    return _Eval(funcs).call(main, args)
+
+
+def system(text: str, inputs: Sequence[str], outputs: Sequence[str], name: str = "stablehlo_main", every: int = 1) -> "_dsl.System":
+    """@main as a per-entity system: argument k reads component inputs[k] (its tensor flattened row-major), result k is written
+    to component outputs[k].  Booleans are written as 0 / 1."""
+    funcs = parse_module(text)
+    main = funcs["main"]
+    if len(inputs) != len(main.args) or len(outputs) != len(main.result_types):
+        raise ValueError("one component name per @main argument and per result")
+    widths = {n: ty.size for n, (_, ty) in zip(inputs, main.args)}
+    widths.update({n: ty.size for n, ty in zip(outputs, main.result_types)})
+    params = list(dict.fromkeys(list(inputs) + [o for o in outputs]))
+
+    def fn(**cols):
+        syms = []
+        for cname in inputs:
+            v = cols[cname]
+            syms.append(v if isinstance(v, _dsl.Vec) else _dsl.Vec([v]))
+        outs = trace(text, syms)
+        res = {}
+        for cname, o in zip(outputs, outs):
+            vals = [(_np.where(e, 1.0, 0.0) if o.dtype == "i1" else e) for e in o.a.reshape(-1)]
+            res[cname] = _dsl.Vec(vals)
+        return res
+    fn.__name__ = name
+    import inspect
+    fn.__signature__ = inspect.Signature([inspect.Parameter(p, inspect.Parameter.KEYWORD_ONLY) for p in params])
+    return _dsl.system(fn, every=every, **widths)

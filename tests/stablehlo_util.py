@@ -1,0 +1,47 @@
+"""Shared by the CPU and GPU StableHLO-ingestion tests: the reference's op-test known answers (tests/golden/stablehlo_ops.json <-
+libs/cranelift-mlir/tests/ops.rs, make_stablehlo_ops_golden.py) as per-entity systems.  TEST INFRASTRUCTURE."""
+import json
+from pathlib import Path
+
+import numpy as np
+
+from elodin_amd import dsl
+from elodin_amd import stablehlo as sh
+
+DOC = json.loads((Path(__file__).parent / "golden" / "stablehlo_ops.json").read_text())
+CASES = DOC["cases"]
+# ops elodin_amd.stablehlo refuses by name (its docstring lists them) and the one case beyond f64's integers
+UNSUPPORTED = {"test_lapack_dgetrf_2x2": "lapack_dgetrf", "test_lapack_svd_2x2": "lapack_dgesdd", "test_solve_3x3_vector_rhs": "lapack_dgetrf",
+               "test_scatter_i32_index_mem": "scatter", "test_roll_scatter_broadcast_reduce_mem": "scatter", "test_lapack_gesv_2x2": "lapack_dgesv",
+               "test_real_dynamic_slice_mem": "real_dynamic_slice", "test_reduce_window_sum_mem": "reduce_window",
+               "test_select_and_scatter_mem": "select_and_scatter"}
+BEYOND_F64_INTEGERS = {"test_ui64_large_constant"}          # 2^64 - 1 is not an integral double
+
+
+def build(case, prefix=""):
+    """(system, {input column: [w] values}, {output column: (width, {index: expected})}) of one case."""
+    main = sh.parse_module(case["mlir"])["main"]
+    ins = [f"{prefix}in{k}" for k in range(len(main.args))]
+    outs = [f"{prefix}out{k}" for k in range(len(main.result_types))]
+    system = sh.system(case["mlir"], ins, outs, name=case["name"])
+    values = {}
+    for nm, inp, (_, ty) in zip(ins, case["inputs"], main.args):
+        v = np.array(inp["values"], dtype=np.float64)
+        assert v.size == ty.size, (case["name"], nm, v.size, ty)
+        values[nm] = v
+    expect = {nm: (ty.size, {}) for nm, ty in zip(outs, main.result_types)}
+    for k, e in case["expected"].items():
+        expect[f"{prefix}out{k}"][1].update({int(j): float(v) for j, v in e["values"].items()})
+    return system, values, expect
+
+
+def check(case_name, got_row, width, expected, tol):
+    assert len(got_row) == width
+    for j, want in expected.items():
+        g = float(got_row[j])
+        if want != want:
+            assert g != g, (case_name, j, g)
+        elif abs(want) == float("inf"):
+            assert g == want, (case_name, j, g, want)
+        else:
+            assert abs(g - want) <= tol * max(1.0, abs(want)), (case_name, j, g, want)

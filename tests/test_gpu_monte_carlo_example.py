@@ -63,13 +63,13 @@ def test_unmodified_style_world_run_with_step_callbacks():
         w2.spawn([vectorize._api.C(c_, row) for c_, row in comps.items()], name=world._names[eid])
     pre_ticks = []
     rec = {}
-    saved = mc._active_result[0]
-    mc._active_result[0] = rec
+    saved, mode = mc._active_result[0], compat._RUN_MODE[0]
+    mc._active_result[0], compat._RUN_MODE[0] = rec, "execute"          # (another test may have left the shim in record mode)
     try:
         w2.run(system, ex.SIMULATION_RATE_HZ, False, None, 1.0, doc["max_ticks"], pre_step=lambda t, ctx: pre_ticks.append((t, ctx.tick)),
                post_step=ex.post_step, interactive=False)
     finally:
-        mc._active_result[0] = saved
+        mc._active_result[0], compat._RUN_MODE[0] = saved, mode
     assert pre_ticks[:3] == [(0, 0), (1, 1), (2, 2)] and len(pre_ticks) == doc["max_ticks"]
     assert abs(rec["final_position"] - run["result"]["final_position"]) < 1e-11 and abs(rec["error"] - run["result"]["error"]) < 1e-11
     # the run went through the commit path's hand-off (elodin_amd.telemetry.Sink): one sample of every pair per tick + the spawned
