@@ -287,7 +287,9 @@ def telemetry_leg(device, n):
     mb = n * 8 * (7 + 6 + 6 + 6) / 1e6
     out = {"entities": n, "column_MB_per_batch": round(mb, 2)}
     for label, tpl, k, batches in (("fused8", 8, 8, 200), ("k1x48", 1, 48, 100)):
-        ex, w, eff = make_exec(n, 0, device, tpl, False)
+        ex, w, eff = make_exec(n, 0, device, tpl, tpl == 1)      # single-tick batches replay a captured chain, like the headline
+        if tpl == 1:
+            ex.prepare(k)
         ex.invoke_batch(k)
         ex.download(mask)
         t0 = time.perf_counter()
@@ -295,8 +297,9 @@ def telemetry_leg(device, n):
             ex.invoke_batch(k)
             ex.download(mask)
         sync_s = time.perf_counter() - t0
-        ex.run_streaming(8, k)
-        stream_s = ex.run_streaming(batches, k)
+        gflag = L.FLAG_USE_GRAPH if tpl == 1 else 0            # run_streaming sets the handle's flags: keep the replay on
+        ex.run_streaming(8, k, flags=gflag)
+        stream_s = ex.run_streaming(batches, k, flags=gflag)
         ex.close()
         out[label] = {"ticks_per_batch": k, "ticks_per_launch": tpl, "batches": batches,
                       "sync_ms_per_batch": round(sync_s / batches * 1e3, 4),
