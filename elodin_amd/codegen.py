@@ -1236,7 +1236,7 @@ def _headers_digest() -> str:
 
 
 def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_math: bool = False, window_soa: bool = False,
-          column_soa: bool = False) -> Path:
+          column_soa: bool = False, guard_selects: Optional[bool] = None) -> Path:
     """Generate + compile (cached by content hash).  Returns the .so path.  A program that no flag set builds without VGPR
     spills is generated again with its columns memory-resident (_MEMORY_COLUMNS) before giving up."""
     if getattr(tp, "frozen_source", None) is not None:      # dsl.FrozenProgram: the text exists, only the compiler is run
@@ -1244,7 +1244,7 @@ def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_
     variants = VARIANTS if isinstance(tp, dsl.TracedProgram) else VARIANTS[:2]
     for k, variant in enumerate(variants):
         try:
-            so = _compile(generate_variant(tp, variant, dtype, integrator, fast_math, window_soa, column_soa), "pipe")
+            so = _compile(generate_variant(tp, variant, dtype, integrator, fast_math, window_soa, column_soa, guard_selects), "pipe")
             last_variant[0] = variant
             return so
         except SpillError:
@@ -1260,14 +1260,14 @@ last_variant = ["program"]      # the variant the last build() settled on (fixtu
 
 
 def generate_variant(tp, variant: str, dtype: str = "float64", integrator: int = 0, fast_math: bool = False, window_soa: bool = False,
-                     column_soa: bool = False) -> str:
+                     column_soa: bool = False, guard_selects: Optional[bool] = None) -> str:
     if variant not in VARIANTS:
         raise ValueError(f"variant must be one of {VARIANTS}")
     _EMIT_ORDER[0] = "demand" if variant == "demand" else "program"
     _MEMORY_COLUMNS[0] = variant == "memory"
     _TICK_OUT_OF_LINE[0] = variant == "out_of_line"
     try:
-        return generate_source(tp, dtype, integrator, fast_math, window_soa, column_soa)
+        return generate_source(tp, dtype, integrator, fast_math, window_soa, column_soa, guard_selects)
     finally:
         _EMIT_ORDER[0], _MEMORY_COLUMNS[0], _TICK_OUT_OF_LINE[0] = "program", False, False
 

@@ -54,7 +54,7 @@ class HipExec:
                  integrator: int = L.RK4, dtype=np.float64, effectors: Sequence[Effector] = (),
                  edges=None, ticks_per_launch: int = 1, use_graph: bool = False, device: int = 0,
                  tick: int = 0, column_entity_ids=None, columns=None, fast_math: bool = False, graph_edges=None,
-                 graph_replicas=None):
+                 graph_replicas=None, guard_selects: Optional[bool] = None):
         lib = L.lib()
         self._lib = lib
         self.dtype = np.dtype(dtype)
@@ -142,7 +142,7 @@ class HipExec:
                 if getattr(custom, "frozen_source", None) is not None:      # a frozen text was generated for ONE device layout
                     self._column_soa, self._window_soa = bool(custom.column_soa), False
                 so = codegen.build(custom, self.dtype.name, integrator, fast_math=fast_math, window_soa=self._window_soa,
-                                   column_soa=self._column_soa)
+                                   column_soa=self._column_soa, guard_selects=guard_selects)
                 for name, width in custom.columns:
                     if columns is None or columns.get(name) is None:
                         raise KeyError(f"effector reads component {name!r} which was not provided")

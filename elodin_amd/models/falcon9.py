@@ -1057,9 +1057,13 @@ class AscentExec:
         self.program = build_program(origin=self.origin if local else None, fsw=fsw, scripted=scripted)
         cols = initial_columns(params, origin=self.origin) if columns is None else dict(columns)
         body = {k: cols.pop(k) for k in ("world_pos", "world_vel", "inertia")}
+        # campaign builds (fast math) put the expensive arm of a `where` nobody else needs behind a wave-level branch
+        # (codegen guarded selects: the GPS fix's noise draws on one tick in forty ...): same values, -2.7 % per tick
+        # (profiles/r04_falcon9_guard_ab.txt); the precise builds keep plain selects unless SIXDOF_GUARD_SELECTS says otherwise
         self.hip = HipExec(body["world_pos"], body["world_vel"], body["inertia"], integrator=L.SEMI_IMPLICIT, dtype=dtype,
                            simulation_time_step=SIM_TIME_STEP, effectors=self.program, columns=cols,
-                           ticks_per_launch=ticks_per_launch, device=device, fast_math=fast_math)
+                           ticks_per_launch=ticks_per_launch, device=device, fast_math=fast_math,
+                           guard_selects=True if fast_math else None)
 
     def run(self, ticks: int):
         return self.hip.run(ticks)
@@ -1093,7 +1097,8 @@ def prebuild() -> list:
                                      ("float64", pad_ecef(), False, False),
                                      # campaign-size executors (>= codegen.COLUMN_SOA_MIN_ROWS rollouts): element-major columns
                                      ("float32", pad_ecef(), True, True), ("float64", pad_ecef(), False, True)):
-        out.append(codegen.build(build_program(origin=origin).trace(widths), dtype, 1, fast_math=fast, column_soa=soa))
+        out.append(codegen.build(build_program(origin=origin).trace(widths), dtype, 1, fast_math=fast, column_soa=soa,
+                                 guard_selects=True if fast else None))
     return out
 
 
