@@ -250,8 +250,8 @@ _CMP = {"EQ": lambda a, b: _np.equal(a, b), "NE": lambda a, b: _np.logical_not(_
         "LE": lambda a, b: a <= b, "GT": lambda a, b: a > b, "GE": lambda a, b: a >= b}
 
 
-def _trunc_div(a, b):
-    return _np.trunc(a / b)
+def _trunc_div(a, b):                              # integer division: toward zero; by zero -> 0 like the reference's lowering
+    return _np.where(_np.equal(b, 0.0), 0.0, _np.trunc(a / _np.where(_np.equal(b, 0.0), 1.0, b)))      # (ops.rs test_div_i64_mem)
 
 
 def _rem(a, b):                                    # stablehlo.remainder: the sign of the DIVIDEND (C's fmod / %)

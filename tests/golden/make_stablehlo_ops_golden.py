@@ -116,6 +116,41 @@ for t in tests:
                        expected={str(k): {"type": e["type"], "values": {str(j): v for j, v in e["values"].items()}} for k, e in exp.items()}))
     except Exception as e:
         bad.append((name, f"{type(e).__name__}: {e}"[:100]))
+# ---- tests written through ops.rs's own helper functions: the helper's module template + the call's literal arguments -------
+TEMPLATES = {          # helper -> (result reader, module text with {n} / {op}, number of inputs, element type)
+    "mem_binop_test": ("f64", "module @module {{\n  func.func public @main(%arg0: tensor<{n}xf64>, %arg1: tensor<{n}xf64>) -> tensor<{n}xf64> {{\n"
+                              "    %0 = stablehlo.{op} %arg0, %arg1 : tensor<{n}xf64>\n    return %0 : tensor<{n}xf64>\n  }}\n}}", 2, "f64"),
+    "mem_unop_test": ("f64", "module @module {{\n  func.func public @main(%arg0: tensor<{n}xf64>) -> tensor<{n}xf64> {{\n"
+                             "    %0 = stablehlo.{op} %arg0 : tensor<{n}xf64>\n    return %0 : tensor<{n}xf64>\n  }}\n}}", 1, "f64"),
+    "i64_binop_mem_test": ("i64", "module @module {{\n  func.func public @main(%arg0: tensor<{n}xi64>, %arg1: tensor<{n}xi64>) -> tensor<{n}xi64> {{\n"
+                                  "    %0 = stablehlo.{op} %arg0, %arg1 : tensor<{n}xi64>\n    return %0 : tensor<{n}xi64>\n  }}\n}}", 2, "i64"),
+    "chlo_unop_test": ("f64", "module @module {{\n  func.func public @main(%arg0: tensor<{n}xf64>) -> tensor<{n}xf64> {{\n"
+                              "    %0 = chlo.{op} %arg0 : tensor<{n}xf64> -> tensor<{n}xf64>\n    return %0 : tensor<{n}xf64>\n  }}\n}}", 1, "f64"),
+}
+TEMPLATES["chlo_unop_mem_test"] = TEMPLATES["chlo_unop_test"]
+for helper, (_, template, _, _) in TEMPLATES.items():      # the templates above must be the helpers' own (ops.rs may move on)
+    body = re.search(r"fn %s\(.*?\n}\n" % helper, src, re.S).group(0)
+    want = re.search(r'r#"(.*?)"#', body, re.S).group(1)
+    assert want == template, helper
+by_helper = 0
+for t in re.split(r'\n#\[test\]\n', src)[1:]:
+    m = re.match(r'fn (test_\w+)\(\) \{\s*(\w+)\(\s*"(\w+)",\s*(.*?)\s*,?\s*\);\s*\}', t, re.S)
+    if not m or m.group(2) not in TEMPLATES or any(c["name"] == m.group(1) for c in ok):
+        continue
+    reader, template, n_in, ety = TEMPLATES[m.group(2)]
+    try:
+        lists = [rust_list(x) for x in re.findall(r"&\[(.*?)\]", m.group(4), re.S)]
+        if len(lists) != n_in + 1:
+            raise ValueError("arguments")
+        n = len(lists[0])
+        ok.append(dict(name=m.group(1), mlir="\n" + template.format(n=n, op=m.group(3)).replace("{{", "{").replace("}}", "}") + "\n",
+                       inputs=[{"type": ety, "values": v} for v in lists[:n_in]], output_bytes=[n * 8],
+                       expected={"0": {"type": reader, "values": {str(j): v for j, v in enumerate(lists[n_in])}}}))
+        bad[:] = [b for b in bad if b[0] != m.group(1)]
+        by_helper += 1
+    except Exception as e:      # noqa: BLE001
+        pass
+print(by_helper, "cases through helper templates")
 print(len(ok), "cases extracted;", len(bad), "tests left out")
 OUT.write_text(json.dumps({"source": "libs/cranelift-mlir/tests/ops.rs (inline modules + asserted outputs)", "cases": ok,
                            "left_out": [{"name": n, "why": w} for n, w in bad]}))
