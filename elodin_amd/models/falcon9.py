@@ -625,29 +625,55 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
                         propellant_rp1, params):
         """sim.py:372-430: ignition gating (TEA-TEB charge + feed + igniter valves), three-regime spool, thrust with
         ambient back-pressure, mass flow."""
-        cmd_c = xp.clip(engine_cmd, 0.0, 1.0)
-        cmd_on = cmd_c >= THROTTLE_MIN * 0.5
         feed_open = (valve_state[VALVE_MAIN_LOX] > 0.5) & (valve_state[VALVE_MAIN_RP1] > 0.5)
         teateb_open = valve_state[VALVE_TEATEB] > 0.5
         prop_ok = (propellant_lox > 0.0) & (propellant_rp1 > 0.0)
-        lighting = cmd_on & (engine_armed < 0.5) & (teateb_charges >= 1.0) & feed_open & teateb_open & prop_ok
-        charges_next = teateb_charges - xp.where(lighting, xp.ones(N_ENGINES), xp.zeros(N_ENGINES))
-        armed_next = xp.where(cmd_on & ((engine_armed > 0.5) | lighting), xp.ones(N_ENGINES), xp.zeros(N_ENGINES))
-        burn_ok = (armed_next > 0.5) & feed_open & prop_ok
-        target = xp.where(burn_ok, xp.maximum(cmd_c, THROTTLE_MIN), xp.zeros(N_ENGINES))
-        running = engine_spool > 0.5 * THROTTLE_MIN
-        tau = xp.where(target > engine_spool,
-                       xp.where(running, xp.ones(N_ENGINES) * ENGINE_THROTTLE_TAU_S, xp.ones(N_ENGINES) * ENGINE_SPINUP_TAU_S),
-                       xp.ones(N_ENGINES) * ENGINE_SHUTDOWN_TAU_S)
-        spool_next = dsl.Vec([actuator_step(xp, s, t, dt, ta, lo=0.0, hi=1.0) for s, t, ta in zip(engine_spool, target, tau)])
         _, _, alt = ecef_to_geodetic(xp, ecef(pos))
         p_amb = pressure(xp, xp.maximum(alt, 0.0))
-        lit = spool_next > 1e-3
         thrust_scale, isp_scale = params[P["thrust_scale"]], params[P["isp_scale"]]
-        thrust_per = xp.where(lit, engine_thrust_per_engine(xp, spool_next, p_amb) * thrust_scale, xp.zeros(N_ENGINES))
-        mdot = cluster_mdot(xp, xp.where(lit, xp.ones(N_ENGINES), xp.zeros(N_ENGINES)), spool_next) * (thrust_scale / isp_scale)
+
+        def step(cmd, spool, armed, charges):
+            """The reference's per-engine update over m engines (vectors of length m); returns the new engine state and the
+            cluster's thrust / mass flow summed over them."""
+            m = len(cmd)
+            ones, zeros = xp.ones(m), xp.zeros(m)
+            cmd_c = xp.clip(cmd, 0.0, 1.0)
+            cmd_on = cmd_c >= THROTTLE_MIN * 0.5
+            lighting = cmd_on & (armed < 0.5) & (charges >= 1.0) & feed_open & teateb_open & prop_ok
+            charges_next = charges - xp.where(lighting, ones, zeros)
+            armed_next = xp.where(cmd_on & ((armed > 0.5) | lighting), ones, zeros)
+            burn_ok = (armed_next > 0.5) & feed_open & prop_ok
+            target = xp.where(burn_ok, xp.maximum(cmd_c, THROTTLE_MIN), zeros)
+            running = spool > 0.5 * THROTTLE_MIN
+            tau = xp.where(target > spool, xp.where(running, ones * ENGINE_THROTTLE_TAU_S, ones * ENGINE_SPINUP_TAU_S),
+                           ones * ENGINE_SHUTDOWN_TAU_S)
+            spool_next = dsl.Vec([actuator_step(xp, s_, t_, dt, ta, lo=0.0, hi=1.0) for s_, t_, ta in zip(spool, target, tau)])
+            lit = spool_next > 1e-3
+            thrust_per = xp.where(lit, engine_thrust_per_engine(xp, spool_next, p_amb) * thrust_scale, zeros)
+            mdot = cluster_mdot(xp, xp.where(lit, ones, zeros), spool_next) * (thrust_scale / isp_scale)
+            return spool_next, armed_next, charges_next, thrust_per, mdot
+
+        def all_nine(cmd, spool, armed, charges):
+            s_, a_, c_, thrust_per, mdot = step(cmd, spool, armed, charges)
+            return s_, a_, c_, xp.sum(thrust_per), xp.sum(mdot)
+
+        def one_for_all(cmd, spool, armed, charges):
+            # nine engines in the same state under the same command take the same step: engine 0's, nine times over — the same
+            # arithmetic on the same numbers (the sums add nine equal terms in the same order), so not an approximation
+            s_, a_, c_, thrust_per, mdot = step(cmd[:1], spool[:1], armed[:1], charges[:1])
+            rep = lambda v: dsl.Vec([v[0]] * N_ENGINES)
+            return rep(s_), rep(a_), rep(c_), xp.sum(rep(thrust_per)), xp.sum(rep(mdot))
+        differ = None
+        for v in (engine_cmd, engine_spool, engine_armed, teateb_charges):
+            for k in range(1, N_ENGINES):
+                d = ~xp.equal(v[k], v[0])
+                differ = d if differ is None else (differ | d)
+        # most of an ascent the cluster runs as one (ignition staggers it, an engine-out scenario splits it): then a wave takes
+        # the cheap side only — 822 -> ~170 issue slots of a ~3,000-slot tick (tools/rollout_split_model.py's cost table)
+        spool_next, armed_next, charges_next, thrust_total, mdot_total = dsl.lax.branch_cond(
+            differ, all_nine, one_for_all, engine_cmd, engine_spool, engine_armed, teateb_charges)
         return {"engine_spool": spool_next, "engine_armed": armed_next, "teateb_charges": charges_next,
-                "thrust_total": xp.sum(thrust_per), "mdot_total": xp.sum(mdot)}
+                "thrust_total": thrust_total, "mdot_total": mdot_total}
 
     @dsl.system
     def mass_props(mdot_total, propellant_lox, propellant_rp1, thrust_total, upper_mass):
