@@ -602,13 +602,27 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
     @dsl.system
     def rcs_dynamics(rcs_levels, rcs_torque_cmd, cg_station, nitrogen_kg):
         """sim.py:560-576: allocate the requested torque to the eight cold-gas thrusters, valve dynamics, meter N2."""
-        have_gas = nitrogen_kg > 0.0
-        cmd_levels = xp.where(have_gas, allocate_torque(xp, rcs_torque_cmd, cg_station), xp.zeros(N_RCS))
-        levels_next = actuator_step(xp, rcs_levels, cmd_levels, dt, RCS_VALVE_TAU_S, lo=0.0, hi=1.0)
-        force, torque = rcs_wrench(xp, levels_next, cg_station)
-        thrust_sum = xp.sum(levels_next) * RCS_THRUST_PER_THRUSTER_N
-        n2_next = xp.maximum(nitrogen_kg - thrust_sum / (N2_ISP_S * G0) * dt, 0.0)
-        return {"rcs_levels": levels_next, "rcs_wrench": xp.concatenate([force, torque]), "nitrogen_kg": n2_next}
+        def active(levels, torque_cmd, cg, n2):
+            have_gas = n2 > 0.0
+            cmd_levels = xp.where(have_gas, allocate_torque(xp, torque_cmd, cg), xp.zeros(N_RCS))
+            levels_next = actuator_step(xp, levels, cmd_levels, dt, RCS_VALVE_TAU_S, lo=0.0, hi=1.0)
+            force, torque = rcs_wrench(xp, levels_next, cg)
+            thrust_sum = xp.sum(levels_next) * RCS_THRUST_PER_THRUSTER_N
+            n2_next = xp.maximum(n2 - thrust_sum / (N2_ISP_S * G0) * dt, 0.0)
+            return levels_next, xp.concatenate([force, torque]), n2_next
+
+        def quiescent(levels, torque_cmd, cg, n2):
+            # closed valves and no torque request: the allocation is zero (|cmd| > 2 % of the authority fails), the valves stay
+            # where they are, the wrench is zero and no gas flows — what `active` computes for these inputs, in 3 instructions
+            return levels, xp.zeros(6), xp.maximum(n2, 0.0)
+        busy = None
+        for v in list(rcs_levels) + list(rcs_torque_cmd):
+            b = ~xp.equal(v, 0.0)
+            busy = b if busy is None else (busy | b)
+        # the cold-gas system is idle for the whole powered ascent (it flies the coast and the flip): a wave whose rollouts all
+        # have it idle skips the allocation / valve / wrench arithmetic (~280 issue slots of a tick)
+        levels_next, wrench, n2_next = dsl.lax.branch_cond(busy, active, quiescent, rcs_levels, rcs_torque_cmd, cg_station, nitrogen_kg)
+        return {"rcs_levels": levels_next, "rcs_wrench": wrench, "nitrogen_kg": n2_next}
 
     @dsl.system
     def wind_model(pos, wind_ned):
@@ -632,15 +646,16 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
         p_amb = pressure(xp, xp.maximum(alt, 0.0))
         thrust_scale, isp_scale = params[P["thrust_scale"]], params[P["isp_scale"]]
 
-        def step(cmd, spool, armed, charges):
-            """The reference's per-engine update over m engines (vectors of length m); returns the new engine state and the
-            cluster's thrust / mass flow summed over them."""
+        def step(cmd, spool, armed, charged):
+            """The reference's per-engine update over m engines (vectors of length m; `charged` = 1 where the engine still holds a
+            TEA-TEB charge, the only way the charge COUNT enters): new spool / armed state, 1 where an engine lights on this
+            tick, per-engine thrust and mass flow."""
             m = len(cmd)
             ones, zeros = xp.ones(m), xp.zeros(m)
             cmd_c = xp.clip(cmd, 0.0, 1.0)
             cmd_on = cmd_c >= THROTTLE_MIN * 0.5
-            lighting = cmd_on & (armed < 0.5) & (charges >= 1.0) & feed_open & teateb_open & prop_ok
-            charges_next = charges - xp.where(lighting, ones, zeros)
+            lighting = cmd_on & (armed < 0.5) & (charged > 0.5) & feed_open & teateb_open & prop_ok
+            lit_now = xp.where(lighting, ones, zeros)
             armed_next = xp.where(cmd_on & ((armed > 0.5) | lighting), ones, zeros)
             burn_ok = (armed_next > 0.5) & feed_open & prop_ok
             target = xp.where(burn_ok, xp.maximum(cmd_c, THROTTLE_MIN), zeros)
@@ -651,28 +666,31 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
             lit = spool_next > 1e-3
             thrust_per = xp.where(lit, engine_thrust_per_engine(xp, spool_next, p_amb) * thrust_scale, zeros)
             mdot = cluster_mdot(xp, xp.where(lit, ones, zeros), spool_next) * (thrust_scale / isp_scale)
-            return spool_next, armed_next, charges_next, thrust_per, mdot
+            return spool_next, armed_next, lit_now, thrust_per, mdot
 
-        def all_nine(cmd, spool, armed, charges):
-            s_, a_, c_, thrust_per, mdot = step(cmd, spool, armed, charges)
-            return s_, a_, c_, xp.sum(thrust_per), xp.sum(mdot)
+        def all_nine(cmd, spool, armed, charged):
+            s_, a_, l_, thrust_per, mdot = step(cmd, spool, armed, charged)
+            return s_, a_, l_, xp.sum(thrust_per), xp.sum(mdot)
 
-        def one_for_all(cmd, spool, armed, charges):
+        def one_for_all(cmd, spool, armed, charged):
             # nine engines in the same state under the same command take the same step: engine 0's, nine times over — the same
             # arithmetic on the same numbers (the sums add nine equal terms in the same order), so not an approximation
-            s_, a_, c_, thrust_per, mdot = step(cmd[:1], spool[:1], armed[:1], charges[:1])
+            s_, a_, l_, thrust_per, mdot = step(cmd[:1], spool[:1], armed[:1], charged[:1])
             rep = lambda v: dsl.Vec([v[0]] * N_ENGINES)
-            return rep(s_), rep(a_), rep(c_), xp.sum(rep(thrust_per)), xp.sum(rep(mdot))
+            return rep(s_), rep(a_), rep(l_), xp.sum(rep(thrust_per)), xp.sum(rep(mdot))
+        # what an engine's TEA-TEB charges can still do: light it, if it is not burning.  (The counts differ by design — three
+        # engines carry relight charges — and so does "has a charge left" once the cluster has lit; an armed engine ignores both.)
+        charged = xp.where((teateb_charges >= 1.0) & (engine_armed < 0.5), xp.ones(N_ENGINES), xp.zeros(N_ENGINES))
         differ = None
-        for v in (engine_cmd, engine_spool, engine_armed, teateb_charges):
+        for v in (engine_cmd, engine_spool, engine_armed, charged):
             for k in range(1, N_ENGINES):
                 d = ~xp.equal(v[k], v[0])
                 differ = d if differ is None else (differ | d)
-        # most of an ascent the cluster runs as one (ignition staggers it, an engine-out scenario splits it): then a wave takes
-        # the cheap side only — 822 -> ~170 issue slots of a ~3,000-slot tick (tools/rollout_split_model.py's cost table)
-        spool_next, armed_next, charges_next, thrust_total, mdot_total = dsl.lax.branch_cond(
-            differ, all_nine, one_for_all, engine_cmd, engine_spool, engine_armed, teateb_charges)
-        return {"engine_spool": spool_next, "engine_armed": armed_next, "teateb_charges": charges_next,
+        # most of an ascent the cluster runs as one (an engine-out scenario, or a relight of three, splits it): then a wave
+        # takes the cheap side only — 822 -> ~170 issue slots of a ~3,000-slot tick (tools/rollout_split_model.py's cost table)
+        spool_next, armed_next, lit_now, thrust_total, mdot_total = dsl.lax.branch_cond(
+            differ, all_nine, one_for_all, engine_cmd, engine_spool, engine_armed, charged)
+        return {"engine_spool": spool_next, "engine_armed": armed_next, "teateb_charges": teateb_charges - lit_now,
                 "thrust_total": thrust_total, "mdot_total": mdot_total}
 
     @dsl.system
