@@ -223,9 +223,36 @@ def ecef_to_geodetic(xp, r):                                               # fra
     return lat, lon, alt
 
 
-def ned_basis(xp, lat, lon):                                               # frames.py:74-84: rows north, east, down
-    sl, cl, so, co = xp.sin(lat), xp.cos(lat), xp.sin(lon), xp.cos(lon)
+def geodetic_sincos(xp, r):
+    """ecef_to_geodetic without a single angle: the same Bowring recurrence (frames.py:43-66, 4 fixed iterations) carried
+    on tan(beta) — tan(lat) = (z + e'^2 b sin^3 beta) / (p - e^2 a cos^3 beta), tan(beta) = (1 - f) tan(lat), sin / cos of an
+    angle in (-pi/2, pi/2) from its tangent by 1 / sqrt(1 + t^2) — returning (sin lat, cos lat, sin lon, cos lon, alt), which
+    is all the plant ever asks of a latitude or a longitude.  Algebraically the reference's function (identical in exact
+    arithmetic for p > 0, i.e. off the polar axis); ~75 instructions where the ten arctan / tan / sin / cos round trips of
+    the angle form are ~400.  The f32 campaign builds use it (build_program(algebraic_geodesy=True)); the f64 parity builds
+    keep the reference's angle arithmetic operation for operation."""
+    x, y, z = r[0], r[1], r[2]
+    p = xp.hypot(x, y)
+    k = 1.0 - WGS84_F
+    t = z / (k * p)
+    for _ in range(4):
+        cb = 1.0 / xp.sqrt(1.0 + t * t)
+        sb = t * cb
+        num = z + WGS84_EP2 * WGS84_B_M * sb ** 3
+        den = p - WGS84_E2 * WGS84_A_M * cb ** 3
+        t = k * num / den
+    h = xp.hypot(num, den)
+    sl, cl = num / h, den / h
+    alt = p * cl + z * sl - WGS84_A_M * xp.sqrt(1.0 - WGS84_E2 * sl ** 2)
+    return sl, cl, y / p, x / p, alt
+
+
+def ned_rows(xp, sl, cl, so, co):                                          # frames.py:74-84 from the sines and cosines
     return (xp.array([-sl * co, -sl * so, cl]), xp.array([-so, co, 0.0]), xp.array([-cl * co, -cl * so, -sl]))
+
+
+def ned_basis(xp, lat, lon):                                               # frames.py:74-84: rows north, east, down
+    return ned_rows(xp, xp.sin(lat), xp.cos(lat), xp.sin(lon), xp.cos(lon))
 
 
 def gravity_accel(xp, r):                                                  # frames.py:92-95
@@ -541,7 +568,8 @@ def upright_attitude() -> np.ndarray:                                      # sim
 
 # ---- the plant, as dsl systems (one function per reference system) ---------------------------------------------------------
 
-def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, scripted=None) -> dsl.Program:
+def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, scripted=None,
+                  algebraic_geodesy: bool = False) -> dsl.Program:
     """`propulsion_systems | six_dof(gravity_and_frame_forces | apply_body_wrenches) | pad_clamp | telemetry | fsw`
     (sim.py:1433-1530) for the ascent.
 
@@ -551,6 +579,8 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
     attitude_setpoint, ctrl_enable, fin_cmd, fsw_phase — replaces the flight software by an open-loop script
     (test_propulsion.py:113-135 `_script`) for the reference's open-loop known-answer tests and for the plant
     trajectories tests/golden/make_falcon9_fixtures.py records from the reference's own systems.
+    `algebraic_geodesy`: ECEF -> geodetic by geodetic_sincos (the same recurrence without the angle round trips) — the f32
+    campaign builds; off, every conversion is the reference's ecef_to_geodetic operation for operation.
     Run the returned program with the semi-implicit integrator at 1 kHz (build_powered's default, sim.py:1476).
     """
     xp = dsl.np
@@ -560,6 +590,12 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
 
     def ecef(pos):                      # stored coordinates -> ECEF
         return pos.linear() + xp.array(org)
+
+    def geodetic(r):                    # (sin lat, cos lat, sin lon, cos lon, altitude) of an ECEF point
+        if algebraic_geodesy:
+            return geodetic_sincos(xp, r)
+        lat, lon, alt = ecef_to_geodetic(xp, r)
+        return xp.sin(lat), xp.cos(lat), xp.sin(lon), xp.cos(lon), alt
 
     @dsl.system
     def attitude_control(pos, vel, inertia, attitude_setpoint, ctrl_enable, thrust_total, cg_station, fsw_phase):
@@ -628,8 +664,8 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
     def wind_model(pos, wind_ned):
         """sim.py:579-611 without the gust process (gust_sigma = 0 in every shipped spec; the gust draws from jax.random):
         steady NED wind with the near-surface shear factor, rotated into ECEF."""
-        lat, lon, alt = ecef_to_geodetic(xp, ecef(pos))
-        north, east, down = ned_basis(xp, lat, lon)
+        sl, cl, so, co, alt = geodetic(ecef(pos))
+        north, east, down = ned_rows(xp, sl, cl, so, co)
         shear = xp.clip(1.0 + 0.15 * (500.0 - xp.minimum(alt, 500.0)) / 500.0, 1.0, 1.15)
         w = wind_ned * shear
         return {"wind_ecef": north * w[0] + east * w[1] + down * w[2]}
@@ -642,7 +678,7 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
         feed_open = (valve_state[VALVE_MAIN_LOX] > 0.5) & (valve_state[VALVE_MAIN_RP1] > 0.5)
         teateb_open = valve_state[VALVE_TEATEB] > 0.5
         prop_ok = (propellant_lox > 0.0) & (propellant_rp1 > 0.0)
-        _, _, alt = ecef_to_geodetic(xp, ecef(pos))
+        alt = geodetic(ecef(pos))[4]
         p_amb = pressure(xp, xp.maximum(alt, 0.0))
         thrust_scale, isp_scale = params[P["thrust_scale"]], params[P["isp_scale"]]
 
@@ -729,7 +765,7 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
     @dsl.system
     def aero_dynamics(pos, vel, wind_ecef, thrust_total, fin_state, cg_station, params):
         """sim.py:614-660: air data, body aero wrench with plume dominance, grid-fin wrench."""
-        _, _, alt = ecef_to_geodetic(xp, ecef(pos))
+        alt = geodetic(ecef(pos))[4]
         alt = xp.maximum(alt, 0.0)
         rho = density(xp, alt)
         a_sound = speed_of_sound(xp, alt)
@@ -773,7 +809,7 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
 
     @dsl.system
     def derive_geodetic_telemetry(pos, vel):                                # sim.py:1128-1137
-        _, _, alt = ecef_to_geodetic(xp, ecef(pos))
+        alt = geodetic(ecef(pos))[4]
         return {"altitude_geodetic": alt, "ground_speed": xp.linalg.norm(vel.linear())}
 
     @dsl.system
@@ -787,8 +823,7 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
         f_body = (engine_wrench[:3] + aero_wrench[:3]) / inertia.mass()     # fin / rcs forces are zero during the ascent
         a_sensed = xp.linalg.norm(f_body)
         r = ecef(pos)
-        lat, lon, _ = ecef_to_geodetic(xp, r)
-        up = -ned_basis(xp, lat, lon)[2]
+        up = -ned_rows(xp, *geodetic(r)[:4])[2]
         v = vel.linear()
         fpa = xp.rad2deg(xp.arcsin(xp.clip(xp.dot(v, up) / xp.maximum(ground_speed, 1e-9), -1.0, 1.0)))
         downrange = xp.linalg.norm(r - xp.array(tuple(float(a) for a in pad_ecef())))
@@ -841,8 +876,8 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
         t = radar_timer + dt
         fired = t >= RADAR_DT_S
         t = xp.where(fired, t - RADAR_DT_S, t)
-        lat, lon, alt = ecef_to_geodetic(xp, ecef(pos))
-        up = xp.array([xp.cos(lat) * xp.cos(lon), xp.cos(lat) * xp.sin(lon), xp.sin(lat)])
+        sl, cl, so, co, alt = geodetic(ecef(pos))
+        up = xp.array([cl * co, cl * so, sl])
         bore_world = quat_rotate(xp, pos.angular().vector(), xp.array([-1.0, 0.0, 0.0]))
         cos_tilt = xp.dot(bore_world, -up)
         slant = alt / xp.maximum(cos_tilt, 1e-3)
@@ -862,8 +897,8 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
     prof_t, prof_speed, prof_alt, prof_vspeed = ascent_profile()
 
     def up_and_ned(r_ecef):
-        lat, lon, alt = ecef_to_geodetic(xp, r_ecef)
-        north, east, down = ned_basis(xp, lat, lon)
+        sl, cl, so, co, alt = geodetic(r_ecef)
+        north, east, down = ned_rows(xp, sl, cl, so, co)
         return -down, north, east, alt
 
     def normalize(v):                                                       # math.rs:41-48
@@ -1098,7 +1133,10 @@ class AscentExec:
         # f32 state cannot hold ECEF metres (0.5 m ulp): integrate pad-relative coordinates instead
         local = (dtype == np.float32) if local_origin is None else bool(local_origin)
         self.origin = pad_ecef() if local else np.zeros(3)
-        self.program = build_program(origin=self.origin if local else None, fsw=fsw, scripted=scripted)
+        # the f32 campaign build converts ECEF -> geodetic without angles (geodetic_sincos: the same recurrence, a fifth of
+        # the instructions); an f64 executor flies the reference's arithmetic operation for operation
+        self.program = build_program(origin=self.origin if local else None, fsw=fsw, scripted=scripted,
+                                     algebraic_geodesy=bool(fast_math))
         cols = initial_columns(params, origin=self.origin) if columns is None else dict(columns)
         body = {k: cols.pop(k) for k in ("world_pos", "world_vel", "inertia")}
         # campaign builds (fast math) put the expensive arm of a `where` nobody else needs behind a wave-level branch
@@ -1141,7 +1179,7 @@ def prebuild() -> list:
                                      ("float64", pad_ecef(), False, False),
                                      # campaign-size executors (>= codegen.COLUMN_SOA_MIN_ROWS rollouts): element-major columns
                                      ("float32", pad_ecef(), True, True), ("float64", pad_ecef(), False, True)):
-        out.append(codegen.build(build_program(origin=origin).trace(widths), dtype, 1, fast_math=fast, column_soa=soa,
+        out.append(codegen.build(build_program(origin=origin, algebraic_geodesy=fast).trace(widths), dtype, 1, fast_math=fast, column_soa=soa,
                                  guard_selects=True if fast else None))
     return out
 

@@ -58,6 +58,21 @@ def test_geodetic_roundtrip():
                 assert abs(h - alt) < 1e-6
 
 
+def test_angle_free_geodetic_conversion_is_the_same_function():
+    """geodetic_sincos (the f32 campaign builds' conversion) against ecef_to_geodetic over the test_frames.py:45-53 grid and
+    along an ascent: sines / cosines to 1e-13, altitude to 1e-8 m — the recurrence is the reference's, carried on tangents."""
+    pts = [f9.geodetic_to_ecef(np, math.radians(la), math.radians(lo), h)
+           for la in (-75.0, -28.0, 0.0, 28.60839, 45.0, 89.0) for lo in (-170.0, -80.60433, 0.0, 91.0)
+           for h in (0.0, 3.0, 8_700.0, 118_000.0, 200_000.0)]
+    for k, r in enumerate(pts):
+        lat, lon, h = f9.ecef_to_geodetic(np, r)
+        got = both(f9.geodetic_sincos, r) if k == 47 else f9.geodetic_sincos(np, r)
+        assert np.allclose(got[:4], [math.sin(lat), math.cos(lat), math.sin(lon), math.cos(lon)], rtol=0, atol=1e-13)
+        assert abs(got[4] - h) < 1e-8
+    n, e, d = f9.ned_rows(np, *f9.geodetic_sincos(np, pts[47])[:4])
+    assert all(np.allclose(a, b, atol=1e-13) for a, b in zip((n, e, d), f9.ned_basis(np, *f9.ecef_to_geodetic(np, pts[47])[:2])))
+
+
 def test_ned_basis_and_ellipsoid_normal():
     """test_frames.py:56-66."""
     n, e, d = both(f9.ned_basis, PAD_LAT, PAD_LON)
