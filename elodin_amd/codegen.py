@@ -553,7 +553,7 @@ _PRELUDE = '''// SIXDOF_FAST_MATH (f32 programs, opt-in): hardware transcendenta
 template <class T> __device__ __forceinline__ T m_div(T a, T b) { return a / b; }
 #ifdef SIXDOF_FAST_MATH
 __device__ __forceinline__ float m_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }   // v_rcp_f32, 1 ulp
-__device__ __forceinline__ float m_sqrt(float x) { return __fsqrt_rn(x); }
+__device__ __forceinline__ float m_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }               // v_sqrt_f32, 1 ulp
 __device__ __forceinline__ double m_sqrt(double x) { return fast_sqrt(x); }
 #else
 template <class T> __device__ __forceinline__ T m_sqrt(T x) { return fast_sqrt(x); }
@@ -627,7 +627,7 @@ SIXDOF_M2(m_atan2, atan2, atan2f)
 #endif
 #ifdef SIXDOF_FAST_MATH
 __device__ __forceinline__ float m_fast_pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }   // x > 0 (x = 0 -> 0 for y > 0)
-__device__ __forceinline__ float m_fast_hypot(float x, float y) { return __fsqrt_rn(x * x + y * y); }
+__device__ __forceinline__ float m_fast_hypot(float x, float y) { return __builtin_amdgcn_sqrtf(x * x + y * y); }
 SIXDOF_M2(m_pow, pow, m_fast_pow) SIXDOF_M2(m_hypot, hypot, m_fast_hypot)
 #else
 SIXDOF_M2(m_pow, pow, powf) SIXDOF_M2(m_hypot, hypot, hypotf)
@@ -645,22 +645,30 @@ __device__ __forceinline__ T m_gather(const double* __restrict__ tab, T idx, int
 // clamped to the end values outside the table.
 template <class T, int N>
 __device__ __forceinline__ T m_interp(T x, const double (&xp)[N], const double (&fp)[N]) {
-    int c = 0;
+    if constexpr (N == 1) return T(fp[0]);
+    T x0, f0, x1, f1;
     if constexpr (N <= 32) {
+        // short tables: the bracketing breakpoints by a chain of selects over compile-time constants (tables sharing their
+        // breakpoints and their x share the compares) — no per-lane table load, which a lone wave has nothing to hide behind.
+        // Same interval as the count below for an ascending xp: the last k in [1, N-2] with xp[k] <= x, else 0.
+        x0 = T(xp[0]); f0 = T(fp[0]); x1 = T(xp[1]); f1 = T(fp[1]);
 #pragma unroll
-        for (int k = 0; k < N; k++) c += (T(xp[k]) <= x) ? 1 : 0;
+        for (int k = 1; k < N - 1; k++) {
+            const bool at = T(xp[k]) <= x;
+            x0 = at ? T(xp[k]) : x0; f0 = at ? T(fp[k]) : f0;
+            x1 = at ? T(xp[k + 1]) : x1; f1 = at ? T(fp[k + 1]) : f1;
+        }
     } else {   // long tables: bisect (searchsorted side='right')
         int lo = 0, hi = N;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if (x < T(xp[mid])) hi = mid; else lo = mid + 1;
         }
-        c = lo;
+        const int i = lo < 1 ? 1 : (lo > N - 1 ? N - 1 : lo);
+        x0 = T(xp[i - 1]); f0 = T(fp[i - 1]); x1 = T(xp[i]); f1 = T(fp[i]);
     }
-    const int i = c < 1 ? 1 : (c > N - 1 ? N - 1 : c);
-    const T x0 = T(xp[i - 1]), f0 = T(fp[i - 1]);
-    const T dx = T(xp[i]) - x0, df = T(fp[i]) - f0;
-    T f = dx == T(0) ? f0 : f0 + ((x - x0) / dx) * df;
+    const T dx = x1 - x0, df = f1 - f0;
+    T f = dx == T(0) ? f0 : f0 + m_div(x - x0, dx) * df;
     f = x < T(xp[0]) ? T(fp[0]) : f;
     return x > T(xp[N - 1]) ? T(fp[N - 1]) : f;
 }
@@ -676,7 +684,7 @@ __device__ __forceinline__ T m_interp_uniform(T x, const double (&xp)[N], const 
     c = (c < N - 1 && T(xp[c]) <= x) ? c + 1 : c;
     const T x0 = T(xp[c - 1]), f0 = T(fp[c - 1]);
     const T dx = T(xp[c]) - x0, df = T(fp[c]) - f0;
-    T f = dx == T(0) ? f0 : f0 + ((x - x0) / dx) * df;
+    T f = dx == T(0) ? f0 : f0 + m_div(x - x0, dx) * df;
     f = x < T(xp[0]) ? T(fp[0]) : f;
     return x > T(xp[N - 1]) ? T(fp[N - 1]) : f;
 }

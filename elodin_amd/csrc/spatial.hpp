@@ -83,7 +83,11 @@ __device__ __forceinline__ double recip(double x) {
     r = fma(fma(-x, r, 1.0), r, r);
     return e == e ? r : (r0 == 0.0 ? r0 : __builtin_nan(""));
 }
+#ifdef SIXDOF_FAST_MATH   // generated f32 programs that opt in (codegen.py): the hardware's 1-ulp v_rcp / v_rsq / v_sqrt alone
+__device__ __forceinline__ float recip(float x) { return x == 0.0f ? __builtin_nanf("") : __builtin_amdgcn_rcpf(x); }
+#else
 __device__ __forceinline__ float recip(float x) { return x == 0.0f ? __builtin_nanf("") : 1.0f / x; }
+#endif
 // 1/sqrt(x) for finite x > 0: hardware v_rsq_f64 seed plus one cubic correction (y0 (1 + e/2 + 3e^2/8), e = 1 - x y0^2):
 // full f64 accuracy in 5 instructions, without the 0 / inf / denormal special-casing of the library rsqrt (4 more
 // instructions and a v_cmp_class per call).  Arguments here are squared norms of quaternions (~1) and softened pair
@@ -94,9 +98,14 @@ __device__ __forceinline__ double rsqrt_pos(double x) {
     return fma(y0 * e, fma(e, 0.375, 0.5), y0);
 }
 __device__ __forceinline__ double fast_rsqrt(double x) { return rsqrt_pos(x); }
-__device__ __forceinline__ float fast_rsqrt(float x) { return rsqrtf(x); }
 __device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
+#ifdef SIXDOF_FAST_MATH
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }   // 1 instruction (rsqrtf: 5, sqrtf: 15)
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+__device__ __forceinline__ float fast_rsqrt(float x) { return rsqrtf(x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
+#endif
 
 // q * v for a UNIT quaternion:  v + 2w(u x v) + 2 u x (u x v)        (reference: quaternion.rs:283-305)
 template <class T>
