@@ -157,6 +157,7 @@ class _Emitter:
         before = set(self.names)
         outer = {"parent": None, "names": self.names, "lines": lines, "vars": {}, "varset": frozenset(), "indent": indent}
         guards: Dict[int, tuple] = {}      # id(select) -> (guarded arm index, member node ids, selects of the group): _plan_guards
+        fused: Dict[int, int] = {}         # id(add / sub) -> which argument is the product folded into it (_FUSE_FMA)
 
         def rhs_of(e: dsl.Expr, a: List[str]) -> str:
             if e.op == "div":
@@ -290,6 +291,21 @@ class _Emitter:
                 sc["lines"].append(f"{sc['indent']}}}")
                 return sc["names"][id(e)]
             wide = self._is_wide(e)
+            if id(e) in fused:
+                # FUSED MULTIPLY-ADD (fast-math builds, _FUSE_FMA): a product whose only use is this sum never becomes a value of
+                # its own.  Decided here, per node, so every copy of the tick body the compiler makes rounds the same way (the
+                # compiler's own "fast" contraction fuses whatever lands in one basic block: kernels.hpp).
+                k = fused[id(e)]
+                arg = lambda x: (f"T({ref(x, sc)})" if x.op != "const" and self._is_wide(x) else ref(x, sc))
+                p_, q_, o_ = arg(e.args[k].args[0]), arg(e.args[k].args[1]), arg(e.args[1 - k])
+                name = f"t{self.n}"
+                self.n += 1
+                sc["names"][id(e)] = name
+                self._deps(e)
+                rhs = (f"m_fma({p_}, {q_}, {o_})" if e.op == "add" else
+                       (f"m_fma({p_}, {q_}, -{o_})" if k == 0 else f"m_fma(-{p_}, {q_}, {o_})"))
+                sc["lines"].append(f"{sc['indent']}const T {name} = {rhs};")
+                return name
             a = []
             for x in e.args:
                 if wide:        # double island: literals as doubles, state-typed operands cast in
@@ -313,7 +329,7 @@ class _Emitter:
         # nodes the outputs need are emitted in the order the user's program created them (`Expr.seq`; arguments always
         # precede their users), which is the order a person would have written the code in: the same step then peaks at a
         # few matrices' worth of registers.  (Nodes inside loop bodies keep their own scopes and are emitted with their loop.)
-        need, stack = {}, ([e for _, e in assign] if (_EMIT_ORDER[0] == "program" or _GUARD_SELECTS[0]) else [])
+        need, stack = {}, ([e for _, e in assign] if (_EMIT_ORDER[0] == "program" or _GUARD_SELECTS[0] or _FUSE_FMA[0]) else [])
         while stack:
             x = stack.pop()
             if id(x) in need or x.op in ("const", "leaf"):
@@ -326,8 +342,24 @@ class _Emitter:
         if _GUARD_SELECTS[0]:
             guards.update(_plan_guards(need, [e for _, e in assign], set(self.names)))
         guarded = set().union(*[g[1] for g in guards.values()]) if guards else set()
+        folded = set()
+        if _FUSE_FMA[0]:
+            n_users: Dict[int, int] = {}
+            for n_ in need.values():
+                for a_ in n_.args:
+                    n_users[id(a_)] = n_users.get(id(a_), 0) + 1
+            root_ids = {id(e) for _, e in assign}
+            for n_ in sorted(need.values(), key=lambda v: v.seq):
+                if n_.op in ("add", "sub") and not self._is_wide(n_):
+                    for k in (1, 0):
+                        m = n_.args[k]
+                        if (m.op == "mul" and n_users.get(id(m)) == 1 and id(m) in need and id(m) not in root_ids and id(m) not in folded
+                                and id(m) not in self.names and not self._is_wide(m)):
+                            fused[id(n_)] = k
+                            folded.add(id(m))
+                            break
         for x in (sorted(need.values(), key=lambda n_: n_.seq) if _EMIT_ORDER[0] == "program" else ()):
-            if id(x) not in guarded:
+            if id(x) not in guarded and id(x) not in folded:
                 ref(x)
         outs = []
         for lv, e in assign:
@@ -350,6 +382,9 @@ class _Emitter:
 
 # Opt-in (codegen.generate_source(..., guard_selects=True) / SIXDOF_GUARD_SELECTS=1): see _Emitter.block, "GUARDED SELECT".
 _GUARD_SELECTS = [False]
+# Fast-math builds fold single-use products into the sums that consume them (see _Emitter.block, "FUSED MULTIPLY-ADD");
+# SIXDOF_FUSE_FMA=0 keeps them apart (A/B).  Exact builds never fuse: a reference evaluates every node to a rounded value.
+_FUSE_FMA = [False]
 _GUARD_MIN_COST = 40
 _NODE_COST = {"threefry": 90, "erfinv": 120, "sin": 12, "cos": 12, "tan": 20, "exp": 10, "log": 10, "pow": 25, "atan2": 27, "asin": 20,
               "acos": 20, "hypot": 12, "div": 4, "sqrt": 4, "interp": 30, "cbrt": 20, "sinh": 20, "cosh": 20, "erfc": 40, "log1p": 15,
@@ -522,19 +557,31 @@ def _emit_systems(systems, cold: Optional[Dict[int, int]] = None) -> str:
     out = []
     em = _Emitter(_SYSTEM_LEAVES)
     cold = cold or {}
+    cadence = lambda s: f"tick % {s.every}ull == {s.phase}ull" + (f" || tick == {s.also_at}ull" if s.also_at is not None else "")
+    reads_of = lambda s: sorted((_col_slots(dsl._leaves_of([e for _, e in s.assign])) | _col_slots([t for t, _ in s.assign])) & set(cold))
+    # Cold columns are loaded AHEAD of the blocks that use them: one batch per cadence at the top of the function, so the
+    # round trip (a lone wave per SIMD has nothing to hide it behind) overlaps the every-tick systems in between, and blocks
+    # that share a cadence share one trip.  Every block still stores what it wrote on exit; a later block of the same tick
+    # reads the registers, not memory, so it sees those writes.
+    ahead: Dict[str, list] = {}
+    for s in systems:
+        if s.every > 1 and reads_of(s):
+            ahead.setdefault(cadence(s), [[], set()])
+            ahead[cadence(s)][0].append(s.name)
+            ahead[cadence(s)][1].update(reads_of(s))
+    for cond, (names, slots) in ahead.items():
+        ld = "".join(f"            if (c_act) {{ {_col_ptr(k, cold[k], 'c_row')} "
+                     + " ".join(f"r.c{k}[{j}] = g[{_col_idx(j)}];" for j in range(cold[k])) + " }\n" for k in sorted(slots))
+        out.append(f"        if ({cond}) {{  // cold columns of {', '.join(names)}\n{ld}        }}")
     for s in systems:
         assign = [(_leaf_ref(t, _SYSTEM_LEAVES), e) for t, e in s.assign]
         written = [t for t, _ in s.assign]
         if s.every > 1:     # wave-uniform cadence branch: its temporaries stay inside
             body = "\n".join(em.block(assign, "            ", written, scoped=True))
-            cond = f"tick % {s.every}ull == {s.phase}ull" + (f" || tick == {s.also_at}ull" if s.also_at is not None else "")
             w_slots = sorted(_col_slots(written) & set(cold))
-            r_slots = sorted((_col_slots(dsl._leaves_of([e for _, e in s.assign])) | set(w_slots)) & set(cold))
-            ld = "".join(f"            if (c_act) {{ {_col_ptr(k, cold[k], 'c_row')} "
-                         + " ".join(f"r.c{k}[{j}] = g[{_col_idx(j)}];" for j in range(cold[k])) + " }\n" for k in r_slots)
             st = "".join(f"\n            if (c_act) {{ {_col_ptr(k, cold[k], 'c_row', False)} "
                          + " ".join(f"g[{_col_idx(j)}] = r.c{k}[{j}];" for j in range(cold[k])) + " }" for k in w_slots)
-            out.append(f"        if ({cond}) {{  // {s.name}\n{ld}{body}{st}\n        }}")
+            out.append(f"        if ({cadence(s)}) {{  // {s.name}\n{body}{st}\n        }}")
         else:
             body = "\n".join(em.block(assign, "        ", written))
             w_slots = sorted(_col_slots(written) & set(cold))
@@ -551,6 +598,8 @@ _PRELUDE = '''// SIXDOF_FAST_MATH (f32 programs, opt-in): hardware transcendenta
 // v_sqrt, ~1e-6 relative) instead of the correctly rounded library calls — sinf+cosf alone are ~240 instructions, and a
 // tick of the Falcon 9 program makes 32 of them.  f64 programs and the default f32 mode keep the library functions.
 template <class T> __device__ __forceinline__ T m_div(T a, T b) { return a / b; }
+__device__ __forceinline__ float m_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double m_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 #ifdef SIXDOF_FAST_MATH
 __device__ __forceinline__ float m_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }   // v_rcp_f32, 1 ulp
 __device__ __forceinline__ float m_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }               // v_sqrt_f32, 1 ulp
@@ -680,10 +729,20 @@ __device__ __forceinline__ T m_interp_uniform(T x, const double (&xp)[N], const 
     k = k > T(0) ? (k < T(N) ? k : T(N)) : T(0);                      // also absorbs NaN and values far off the table
     int c = static_cast<int>(k) + 1;                                  // ~ number of breakpoints <= x
     c = c < 1 ? 1 : (c > N - 1 ? N - 1 : c);
-    c = (c > 1 && x < T(xp[c - 1])) ? c - 1 : c;
-    c = (c < N - 1 && T(xp[c]) <= x) ? c + 1 : c;
-    const T x0 = T(xp[c - 1]), f0 = T(fp[c - 1]);
-    const T dx = T(xp[c]) - x0, df = T(fp[c]) - f0;
+    // the correction moves c by one at most, so the four breakpoints around it are all it can ask for: ONE round trip to
+    // the table (8 independent loads) instead of three dependent ones.  (Indices clamped; a clamped entry is never selected.)
+    T xs[4], fs[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = c - 2 + j;
+        const int ic = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
+        xs[j] = T(xp[ic]); fs[j] = T(fp[ic]);
+    }
+    const bool down = c > 1 && x < xs[1];                             // c -> c - 1
+    const bool up = !down && c < N - 1 && xs[2] <= x;                 // c -> c + 1 (xp[c] <= x cannot hold after a step down)
+    const T x0 = down ? xs[0] : (up ? xs[2] : xs[1]), f0 = down ? fs[0] : (up ? fs[2] : fs[1]);
+    const T x1 = down ? xs[1] : (up ? xs[3] : xs[2]), f1 = down ? fs[1] : (up ? fs[3] : fs[2]);
+    const T dx = x1 - x0, df = f1 - f0;
     T f = dx == T(0) ? f0 : f0 + m_div(x - x0, dx) * df;
     f = x < T(xp[0]) ? T(fp[0]) : f;
     return x > T(xp[N - 1]) ? T(fp[N - 1]) : f;
@@ -952,6 +1011,7 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
     guard_selects: expensive `where` arms nobody else needs are computed behind a wave-level branch (_Emitter.block);
     None = the SIXDOF_GUARD_SELECTS environment switch (off unless "1")."""
     _GUARD_SELECTS[0] = (os.environ.get("SIXDOF_GUARD_SELECTS", "") == "1") if guard_selects is None else bool(guard_selects)
+    _FUSE_FMA[0] = bool(fast_math) and os.environ.get("SIXDOF_FUSE_FMA", "1") != "0"
     _WINDOW_SOA[0] = bool(window_soa)
     _COLUMN_SOA[0] = bool(column_soa)
     if column_soa and isinstance(tp, dsl.TracedProgram) and tp.fold_stages:
@@ -1107,6 +1167,7 @@ def _fold_is_additive(tf: "dsl.TracedFold") -> bool:
 
 def generate_pair_source(tf: "dsl.TracedFold") -> str:
     """A user-written edge_fold function as the PAIR functor of csrc/pair_kernel.hpp (f64, both integrators)."""
+    _GUARD_SELECTS[0], _FUSE_FMA[0] = False, False      # switches of generate_source: exact arithmetic here
     _TABLES.clear()
     _GATHERS.clear()
     body = "\n".join(emit_block([(f"acc[{k}]", e) for k, e in enumerate(tf.outputs)], _PAIR_LEAVES))
@@ -1158,6 +1219,7 @@ def generate_graph_fold_source(tf: "dsl.TracedGraphFold") -> str:
     """A stand-alone GraphQuery.edge_fold over arbitrary components: one lane per source entity folds its out-edges
     (CSR by source, spawn order) into a scratch row; a second kernel moves the rows into the output component, so every
     fold sees the component values from before the system ran."""
+    _GUARD_SELECTS[0], _FUSE_FMA[0] = False, False      # switches of generate_source: exact arithmetic here
     _TABLES.clear()
     _GATHERS.clear()
     f = tf.fold

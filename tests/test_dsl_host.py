@@ -1,5 +1,7 @@
 """Effector front-end, CPU side: tracing, code generation (hipcc cross-compiles here) and the numpy
 stepper that serves as oracle for user-written effectors."""
+import os
+
 import numpy as np
 import pytest
 
@@ -590,3 +592,27 @@ def test_polars_subset_over_pandas_builds_the_rocket_examples_grid():
     assert (s.min(), s.max(), len(s.unique())) == (-20.0, 20.0, 3)
     with pytest.raises(AttributeError):
         pl.scan_csv
+
+
+def test_fast_math_builds_fold_single_use_products_into_their_sums():
+    """codegen._FUSE_FMA: in a fast-math program `a * b + c`, `a * b - c` and `c - a * b` become one m_fma each when the product
+    has no other use; a product used twice, a block output and every exact build stay apart."""
+    import re
+
+    @dsl.system(x=3, y=5)
+    def sums(x, y):
+        a, b, c = x[0], x[1], x[2]
+        shared = a * c
+        return {"y": dsl.np.array([a * b + c, b * c * 2.0 - a, c - b * b, shared + b, shared - a])}
+    tp = dsl.Program([sums], dsl.pipe(), []).trace({"x": 3, "y": 5})
+    fast = codegen.generate_source(tp, "float32", 2, fast_math=True)
+    body = fast[fast.index("// sums"):]
+    fmas = re.findall(r"= (m_fma\([^;]*\));", body)
+    assert len(fmas) == 3 and sum("-" in f for f in fmas) == 2, fmas
+    assert len(re.findall(r"= r\.c0\[0\] \* r\.c0\[2\];", body)) == 1          # the shared product is a value of its own
+    os.environ["SIXDOF_FUSE_FMA"] = "0"
+    try:
+        assert "= m_fma(" not in codegen.generate_source(tp, "float32", 2, fast_math=True)
+    finally:
+        del os.environ["SIXDOF_FUSE_FMA"]
+    assert "= m_fma(" not in codegen.generate_source(tp, "float32", 2) and "= m_fma(" not in codegen.generate_source(tp, "float64", 2)

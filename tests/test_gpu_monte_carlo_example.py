@@ -68,6 +68,8 @@ def test_unmodified_style_world_run_with_step_callbacks():
     try:
         w2.run(system, ex.SIMULATION_RATE_HZ, False, None, 1.0, doc["max_ticks"], pre_step=lambda t, ctx: pre_ticks.append((t, ctx.tick)),
                post_step=ex.post_step, interactive=False)
+        with pytest.raises(ValueError, match="max_ticks"):      # no editor to stop the loop: callbacks need a tick budget
+            w2.run(system, ex.SIMULATION_RATE_HZ, post_step=ex.post_step)
     finally:
         mc._active_result[0], compat._RUN_MODE[0] = saved, mode
     assert pre_ticks[:3] == [(0, 0), (1, 1), (2, 2)] and len(pre_ticks) == doc["max_ticks"]
@@ -79,5 +81,3 @@ def test_unmodified_style_world_run_with_step_callbacks():
     assert len(ts) == doc["max_ticks"] + 1 and ts[0] == 0 and ts[-1] == int(round((doc["max_ticks"] - 1) / 120.0 * 1e6))
     assert abs(pos[-1, 0] - run["result"]["final_position"]) < 1e-11
     assert sink.sample_count("vehicle.command") == doc["max_ticks"] + 1 and sink.sample_count("vehicle.target") == doc["max_ticks"] + 1
-    with pytest.raises(ValueError, match="max_ticks"):
-        w2.run(system, ex.SIMULATION_RATE_HZ, post_step=ex.post_step)
