@@ -68,6 +68,7 @@ def test_unmodified_style_world_run_with_step_callbacks():
     try:
         w2.run(system, ex.SIMULATION_RATE_HZ, False, None, 1.0, doc["max_ticks"], pre_step=lambda t, ctx: pre_ticks.append((t, ctx.tick)),
                post_step=ex.post_step, interactive=False)
+        sink = w2.compat_exec.compat_sink
         with pytest.raises(ValueError, match="max_ticks"):      # no editor to stop the loop: callbacks need a tick budget
             w2.run(system, ex.SIMULATION_RATE_HZ, post_step=ex.post_step)
     finally:
@@ -76,7 +77,6 @@ def test_unmodified_style_world_run_with_step_callbacks():
     assert abs(rec["final_position"] - run["result"]["final_position"]) < 1e-11 and abs(rec["error"] - run["result"]["error"]) < 1e-11
     # the run went through the commit path's hand-off (elodin_amd.telemetry.Sink): one sample of every pair per tick + the spawned
     # state, stamped start + tick / 120 Hz; `command` is an external control (its component says so): only the callback's writes
-    sink = w2.compat_exec.compat_sink
     ts, pos = sink.series("vehicle.position")
     assert len(ts) == doc["max_ticks"] + 1 and ts[0] == 0 and ts[-1] == int(round((doc["max_ticks"] - 1) / 120.0 * 1e6))
     assert abs(pos[-1, 0] - run["result"]["final_position"]) < 1e-11
