@@ -49,6 +49,10 @@ __device__ __forceinline__ Q qmul(Q l, Q r) {
             l.w * r.k + l.i * r.j - l.j * r.i + l.k * r.w, l.w * r.w - l.i * r.i - l.j * r.j - l.k * r.k};
 }
 
+__device__ __forceinline__ double pitch_deg(Q q) {
+    return acos(clampd(1.0 - 2.0 * (q.i * q.i + q.j * q.j), -1.0, 1.0)) * (180.0 / kPi);
+}
+
 }  // namespace
 
 // tick_refs row: ref_alt, ref_rate, |ref_pitch|, ref_hspeed, ref_downrange, ref_hdecel, reserved, reserved
@@ -99,8 +103,16 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
     double mass = 0.0, inv_m = 0.0;
     Spatial<double> A = {{0, 0, 0}, {0, 0, 0}}, Fw = {{0, 0, 0}, {0, 0, 0}};
 
+    // tick % ticks_per_telemetry and (tick - 1) % guidance_period as wrapping counters: a run-time 64-bit modulo is ~100
+    // scalar instructions, a third of a tick's issue slots
+    uint32_t tel_phase = (uint32_t)((P.tick0 + 1) % P.ticks_per_telemetry);
+    uint32_t gd_phase = (uint32_t)(P.tick0 % P.guidance_period);
     for (uint32_t k = 0; k < P.n_ticks; k++) {
         const uint64_t tick = P.tick0 + k + 1;
+        const bool exchange = tel_phase == 0 || tick == P.max_ticks;
+        const bool guidance_due = gd_phase == 0;
+        tel_phase = tel_phase + 1 == P.ticks_per_telemetry ? 0 : tel_phase + 1;
+        gd_phase = gd_phase + 1 == P.guidance_period ? 0 : gd_phase + 1;
         const double* ref = P.tick_refs + (size_t)k * 8;  // wave-uniform
         const bool is_landed = landed > 0.5;
         // engine_response (sim.py:334-343)
@@ -171,24 +183,26 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
             }
             landed = now ? 1.0 : 0.0;
         }
-        // derive_telemetry (sim.py:433-444): pitch = acos(body_up.z); body_up.z = 1 - 2(qi^2 + qj^2)
-        pitch = acos(clampd(1.0 - 2.0 * (q.i * q.i + q.j * q.j), -1.0, 1.0)) * (180.0 / kPi);
         const double altitude = p.z, vertical_speed = v.z;
 
         // ---- post_step (main.py:166-283), once per telemetry batch (impeller2_server.rs:553-678): the server loop runs
         // ticks_per_telemetry ticks, then calls post_step(end_tick) with end_tick = ticks completed - 1 — that is the
         // `tick` main.py sees (its t_s, its `tick % guidance_period_ticks`, its `tick >= max_ticks - 1`).  The last batch
         // of a run is cut short at max_ticks.  Wave-uniform condition.
-        if (!(tick % P.ticks_per_telemetry == 0 || tick == P.max_ticks)) continue;
+        if (!exchange) continue;
         const uint64_t end_tick = tick - 1;
         const bool landed_now = landed > 0.5;
+        // derive_telemetry (sim.py:433-444): pitch = acos(body_up.z); body_up.z = 1 - 2(qi^2 + qj^2).  A pure function of this
+        // tick's attitude that only the exchange below (and the final store) reads: evaluated where it is read — the f64 acos
+        // is a quarter of a tick's instructions, and two ticks in three have no exchange.
+        pitch = pitch_deg(q);
         {
             const double da = altitude - ref[0], dp = pitch - ref[2];
             e_alt = fma(da, da, e_alt);
             e_pitch = fma(dp, dp, e_pitch);
             e_n += 1.0;
         }
-        if (end_tick % P.guidance_period == 0 && !landed_now) {  // end_tick is wave-uniform; landed is per lane
+        if (guidance_due && !landed_now) {  // end_tick % guidance_period == 0: wave-uniform; landed is per lane
             // controller/src/main.rs:188-262
             const double h_speed = sqrt(v.x * v.x + v.y * v.y);
             const double m_now = dry_mass + prop + rcs_prop;
@@ -282,6 +296,7 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
         }
     }
     if (P.n_ticks == 0) return;
+    pitch = pitch_deg(q);          // the column holds the last tick's value
     gpos[0] = q.i; gpos[1] = q.j; gpos[2] = q.k; gpos[3] = q.w; gpos[4] = p.x; gpos[5] = p.y; gpos[6] = p.z;
     gvel[0] = om.x; gvel[1] = om.y; gvel[2] = om.z; gvel[3] = v.x; gvel[4] = v.y; gvel[5] = v.z;
     double* ga = P.accel + (size_t)i * 6;
