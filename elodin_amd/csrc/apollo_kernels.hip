@@ -105,6 +105,7 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
 
     // tick % ticks_per_telemetry and (tick - 1) % guidance_period as wrapping counters: a run-time 64-bit modulo is ~100
     // scalar instructions, a third of a tick's issue slots
+    if (P.n_ticks != 0) q = normalized(q);     // user-supplied initial attitudes need not be unit; q * v is scale-invariant
     uint32_t tel_phase = (uint32_t)((P.tick0 + 1) % P.ticks_per_telemetry);
     uint32_t gd_phase = (uint32_t)(P.tick0 % P.guidance_period);
     for (uint32_t k = 0; k < P.n_ticks; k++) {
@@ -122,9 +123,9 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
             throttle = (prop > 0.0 && !is_landed) ? actual : 0.0;
             thrust = throttle * DPS_MAX_THRUST_N * thrust_scale;
         }
-        // attitude_control (sim.py:368-378).  q is unit after the first integration; normalise so the
-        // conjugate is the inverse for user-supplied initial attitudes too.
-        const Q qn = normalized(q);
+        // attitude_control (sim.py:368-378).  q is unit here (normalised before the loop, and by every integration), so the
+        // conjugate is the inverse.
+        const Q qn = q;
         {
             const Q qc = {-qn.i, -qn.j, -qn.k, qn.w};
             const Q err = qmul(qc, setpoint);
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(64) void apollo_rollout_kernel(const ApolloParams P
             const double sc = mass * inv_total_mass;
             I_diag = is_landed ? V3{1.0e9, 1.0e9, 1.0e9} : V3{base_I.x * sc, base_I.y * sc, base_I.z * sc};
             // one divide per tick: 1/m, and 1/I = (1/I_base) * (m_total / m)
-            inv_m = 1.0 / mass;
+            inv_m = recip(mass);      // v_rcp_f64 + two Newton steps (spatial.hpp): 5 instructions against an IEEE divide's 11
             const double inv_sc = total_mass * inv_m;
             inv_I = is_landed ? V3{1.0e-9, 1.0e-9, 1.0e-9}
                               : V3{inv_base_I.x * inv_sc, inv_base_I.y * inv_sc, inv_base_I.z * inv_sc};
