@@ -553,10 +553,24 @@ def _transient_slots(pipe_tp, pre, post, reg_cols, cold) -> Dict[int, int]:
     return out
 
 
-def _emit_systems(systems, cold: Optional[Dict[int, int]] = None) -> str:
+def _store_only_slots(pipe_tp, pre, post, transient) -> Dict[int, int]:
+    """Transient columns NOTHING in the program reads (telemetry a script derives for the database: a geodetic altitude, an
+    inlet pressure): {slot: width}.  Their value is only ever looked at through the column — after the launch, or by the
+    history ring — so they are evaluated on the ticks that store them (the last tick of a launch, every tick while the column
+    is being recorded) instead of on all of them.  SIXDOF_NO_STORE_ONLY_COLUMNS=1 switches the analysis off."""
+    if os.environ.get("SIXDOF_NO_STORE_ONLY_COLUMNS", "") == "1":
+        return {}
+    read = _col_slots(dsl._leaves_of(list(pipe_tp.outputs))) if pipe_tp is not None else set()
+    for s_ in pre + post:
+        read |= _col_slots(dsl._leaves_of([e for _, e in s_.assign]))
+    return {k: w for k, w in transient.items() if k not in read}
+
+
+def _emit_systems(systems, cold: Optional[Dict[int, int]] = None, store_only: Optional[Dict[int, int]] = None) -> str:
     out = []
     em = _Emitter(_SYSTEM_LEAVES)
     cold = cold or {}
+    store_only = store_only or {}
     cadence = lambda s: f"tick % {s.every}ull == {s.phase}ull" + (f" || tick == {s.also_at}ull" if s.also_at is not None else "")
     reads_of = lambda s: sorted((_col_slots(dsl._leaves_of([e for _, e in s.assign])) | _col_slots([t for t, _ in s.assign])) & set(cold))
     # Cold columns are loaded AHEAD of the blocks that use them: one batch per cadence at the top of the function, so the
@@ -583,7 +597,20 @@ def _emit_systems(systems, cold: Optional[Dict[int, int]] = None) -> str:
                          + " ".join(f"g[{_col_idx(j)}] = r.c{k}[{j}];" for j in range(cold[k])) + " }" for k in w_slots)
             out.append(f"        if ({cadence(s)}) {{  // {s.name}\n{body}{st}\n        }}")
         else:
-            body = "\n".join(em.block(assign, "        ", written))
+            late = [(t, e) for t, e in s.assign if _col_slots([t]) & set(store_only)]
+            lazy = ""
+            if late:
+                # store-only columns (_store_only_slots): in front of the rest of the block (they read what the block has not
+                # written yet), inside the condition under which somebody will look at the column
+                # (P.hist_ring: the history ring is on for this launch — one kernarg word the kernel holds anyway; testing the
+                # columns' own P.model_hist pointers costs a scalar load and its wait per block and tick)
+                lazy = (f"        if (tick == P.tick0 + P.n_ticks || P.hist_ring != 0u) {{"
+                        f"  // store-only columns of {s.name}\n"
+                        + "\n".join(em.block([(_leaf_ref(t, _SYSTEM_LEAVES), e) for t, e in late], "            ", [t for t, _ in late], scoped=True))
+                        + "\n        }\n")
+                assign = [(_leaf_ref(t, _SYSTEM_LEAVES), e) for t, e in s.assign if not (_col_slots([t]) & set(store_only))]
+                written = [t for t, _ in s.assign if not (_col_slots([t]) & set(store_only))]
+            body = lazy + "\n".join(em.block(assign, "        ", written))
             w_slots = sorted(_col_slots(written) & set(cold))
             r_slots = sorted((_col_slots(dsl._leaves_of([e for _, e in s.assign])) | set(w_slots)) & set(cold))
             ld = "".join(f"        if (c_act) {{ {_col_ptr(k, cold[k], 'c_row')} "
@@ -809,6 +836,7 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
             if used is not None else list(tp.written_slots)
         cold = _cold_slots(tp, pipe_tp, pre, post, reg_cols)
         transient = _transient_slots(pipe_tp, pre, post, reg_cols, cold) if used is None else {}
+        store_only = _store_only_slots(pipe_tp, pre, post, transient)
         vol = "volatile " if _MEMORY_COLUMNS[0] else ""
         regs = "\n".join(f"        {vol}T c{k}[{w}];" + ("   // cold: lives in its HBM column between cadence blocks" if k in cold else "") for k, w in reg_cols)
         loads = "\n".join(
@@ -877,13 +905,13 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
     __device__ static __forceinline__ void pre(const StepParams& P, uint64_t tick, Regs<T>& r, Quat<T>& q, Vec3<T>& p,
                                                Spatial<T>& v, Vec3<T>& I, T& mass, const Spatial<T>& accel) {{
         (void)P; (void)tick; (void)accel;
-{win_setup}{cold_setup}{_emit_systems(pre, cold)}
+{win_setup}{cold_setup}{_emit_systems(pre, cold, store_only)}
     }}
     template <class T>
     __device__ static __forceinline__ void post(const StepParams& P, uint64_t tick, Regs<T>& r, Quat<T>& q, Vec3<T>& p,
                                                 Spatial<T>& v, Vec3<T>& I, T& mass, const Spatial<T>& accel) {{
         (void)P; (void)tick; (void)accel;
-{win_setup}{cold_setup}{_emit_systems(post, cold)}{transient_stores}
+{win_setup}{cold_setup}{_emit_systems(post, cold, store_only)}{transient_stores}
     }}'''
     wt = pipe_tp.world_torque if pipe_tp is not None else False
     bt = pipe_tp.body_torque if pipe_tp is not None else False

@@ -11,6 +11,7 @@ from dataclasses import dataclass
 from typing import Optional, Sequence
 
 import os
+from pathlib import Path
 
 import numpy as np
 
@@ -124,7 +125,14 @@ class HipExec:
                     for fs in custom.fold_stages:       # scratch rows: a fold reads the values from before it ran
                         columns.setdefault(fs.scratch_name, np.zeros((self.world_pos.shape[0], fs.out[2])))
                 else:
-                    custom = effectors.trace(widths)
+                    # executors built again and again from ONE program object (a campaign service: one per block of runs)
+                    # trace it and generate its source once per column layout; the objects themselves are cached on disk
+                    memo = effectors.__dict__.setdefault("_exec_memo", {}) if hasattr(effectors, "__dict__") else {}
+                    wkey = (tuple(sorted((k, v) for k, v in widths.items())),
+                            tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("SIXDOF_"))))
+                    custom = memo.get(("trace", wkey))
+                    if custom is None:
+                        custom = memo[("trace", wkey)] = effectors.trace(widths)
                 if isinstance(effectors, _dsl.Program):
                     self._program_columns = [n for n, _ in custom.columns]
                     self._windows = {name: (rows, width) for name, (_, rows, width) in custom.windows.items()}
@@ -141,8 +149,15 @@ class HipExec:
                                                                   self.world_pos.shape[0] >= codegen.COLUMN_SOA_MIN_ROWS)))
                 if getattr(custom, "frozen_source", None) is not None:      # a frozen text was generated for ONE device layout
                     self._column_soa, self._window_soa = bool(custom.column_soa), False
-                so = codegen.build(custom, self.dtype.name, integrator, fast_math=fast_math, window_soa=self._window_soa,
-                                   column_soa=self._column_soa, guard_selects=guard_selects)
+                memo = effectors.__dict__.get("_exec_memo") if hasattr(effectors, "__dict__") else None
+                bkey = ("build", id(custom), self.dtype.name, integrator, bool(fast_math), self._window_soa, self._column_soa, guard_selects,
+                        tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("SIXDOF_"))))
+                so = memo.get(bkey) if memo is not None else None
+                if so is None or not Path(so).exists():
+                    so = codegen.build(custom, self.dtype.name, integrator, fast_math=fast_math, window_soa=self._window_soa,
+                                       column_soa=self._column_soa, guard_selects=guard_selects)
+                    if memo is not None:
+                        memo[bkey] = so
                 for name, width in custom.columns:
                     if columns is None or columns.get(name) is None:
                         raise KeyError(f"effector reads component {name!r} which was not provided")

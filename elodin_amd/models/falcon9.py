@@ -813,18 +813,21 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
         return {"altitude_geodetic": alt, "ground_speed": xp.linalg.norm(vel.linear())}
 
     @dsl.system
-    def ascent_metrics_latch(ascent_metrics, qbar, engine_wrench, aero_wrench, inertia, tick, fsw_phase, fsw_state,
-                             altitude_geodetic, ground_speed, pos, vel):
+    def ascent_metrics_latch(ascent_metrics, qbar, engine_wrench, aero_wrench, inertia, tick, fsw_phase, fsw_state, pos, vel):
         """Campaign observables the reference's hooks derive from DB telemetry afterwards (hooks/score.py): Max-Q, peak
-        sensed acceleration, and the state at MECO, latched in the loop."""
+        sensed acceleration, and the state at MECO, latched in the loop.  Altitude and ground speed are derive_geodetic_
+        telemetry's expressions on the same state (nothing moves the vehicle in between), spelled again here so that the
+        COLUMNS have no reader: codegen then evaluates them where they are stored, and these uses sit behind `at_meco`."""
         t_s = tick * dt
         m = ascent_metrics
         new_q = qbar > m[0]
         f_body = (engine_wrench[:3] + aero_wrench[:3]) / inertia.mass()     # fin / rcs forces are zero during the ascent
         a_sensed = xp.linalg.norm(f_body)
         r = ecef(pos)
-        up = -ned_rows(xp, *geodetic(r)[:4])[2]
+        sl, cl, so, co, altitude_geodetic = geodetic(r)
+        up = -ned_rows(xp, sl, cl, so, co)[2]
         v = vel.linear()
+        ground_speed = xp.linalg.norm(v)
         fpa = xp.rad2deg(xp.arcsin(xp.clip(xp.dot(v, up) / xp.maximum(ground_speed, 1e-9), -1.0, 1.0)))
         downrange = xp.linalg.norm(r - xp.array(tuple(float(a) for a in pad_ecef())))
         at_meco = (fsw_state[3] > 0.5) & (m[3] <= 0.0)          # cutoff commanded, not latched yet
@@ -876,21 +879,31 @@ def build_program(origin: Optional[Sequence[float]] = None, fsw: bool = True, sc
         t = radar_timer + dt
         fired = t >= RADAR_DT_S
         t = xp.where(fired, t - RADAR_DT_S, t)
-        sl, cl, so, co, alt = geodetic(ecef(pos))
-        up = xp.array([cl * co, cl * so, sl])
-        bore_world = quat_rotate(xp, pos.angular().vector(), xp.array([-1.0, 0.0, 0.0]))
-        cos_tilt = xp.dot(bore_world, -up)
-        slant = alt / xp.maximum(cos_tilt, 1e-3)
         n = radar_count + xp.where(fired, 1.0, 0.0)
-        valid = (cos_tilt > RADAR_FOV_COS) & (slant <= RADAR_MAX_RANGE_M) & (alt > 0.0)
-        # a valid return draws its noise on the ticks the altimeter fires inside its gates (the first seconds of an ascent)
-        rng_new = dsl.lax.branch_cond(fired & valid, lambda n_, s_: s_ + noise(n_, 5, 0, RADAR_SIGMA_M),
-                                      lambda n_, s_: xp.where(fired, -1.0, radar_range), n, slant)
+
+        def ping(n_, held, p_, q_):
+            # the boresight geometry (and, inside the gates, the noise draw) on the ticks the altimeter fires: 1 in 25
+            sl, cl, so, co, alt = geodetic(p_ + xp.array(org))
+            up = xp.array([cl * co, cl * so, sl])
+            bore_world = quat_rotate(xp, q_, xp.array([-1.0, 0.0, 0.0]))
+            cos_tilt = xp.dot(bore_world, -up)
+            slant = alt / xp.maximum(cos_tilt, 1e-3)
+            valid = (cos_tilt > RADAR_FOV_COS) & (slant <= RADAR_MAX_RANGE_M) & (alt > 0.0)
+            return xp.where(valid, slant + noise(n_, 5, 0, RADAR_SIGMA_M), -1.0)
+        rng_new = dsl.lax.branch_cond(fired, ping, lambda n_, held, p_, q_: held, n, radar_range, pos.linear(), pos.angular().vector())
         return {"radar_timer": t, "radar_range": rng_new, "radar_count": n}
 
     @dsl.system(every=GUIDANCE_PERIOD_TICKS, phase=1)
-    def pressure_transducers(sensor_tick, tank_pressure_lox, tank_pressure_rp1, inlet_pressure_lox, inlet_pressure_rp1):
-        truth = xp.array([tank_pressure_lox, tank_pressure_rp1, inlet_pressure_lox, inlet_pressure_rp1])   # sim.py:1099-1109
+    def pressure_transducers(sensor_tick, tank_pressure_lox, tank_pressure_rp1, propellant_lox, propellant_rp1, mdot_total,
+                             axial_specific_force, cg_station):
+        # sim.py:1099-1109.  The inlet pressures are tank_dynamics' expressions on the values it left in the columns (same
+        # numbers), evaluated on the sampling ticks: the inlet_pressure_* columns themselves then have no reader
+        mdot_lox, mdot_rp1 = split_mdot(mdot_total)
+        inlet_lox = inlet_pressure(xp, tank_pressure_lox, propellant_lox, RHO_LOX, LOX_TANK_BOTTOM_M, cg_station,
+                                   axial_specific_force, mdot_lox)
+        inlet_rp1 = inlet_pressure(xp, tank_pressure_rp1, propellant_rp1, RHO_RP1, RP1_TANK_BOTTOM_M, cg_station,
+                                   axial_specific_force, mdot_rp1)
+        truth = xp.array([tank_pressure_lox, tank_pressure_rp1, inlet_lox, inlet_rp1])
         return {"pressure_meas": truth + noise(sensor_tick, 6, 4, PRESSURE_SIGMA_PA)}
 
     # ---- the flight software (controller/src/main.rs), one exchange per 10 ticks ---------------------------------------------
@@ -1120,6 +1133,9 @@ def sample_params(n: int, seed: int = SPEC_SEED) -> np.ndarray:
 ASCENT_TICKS = 180_000            # 180 s of flight at 1 kHz: every rollout of spec.toml's ranges reaches MECO by then (latest ~T+170 s)
 
 
+_PROGRAMS: Dict[tuple, "dsl.Program"] = {}
+
+
 class AscentExec:
     """One block of ascent rollouts on one GPU: rows = rollouts, the closed loop runs as a generated program
     (sixdof_set_custom_pipe) with `ticks_per_launch` ticks per launch and all state in registers in between."""
@@ -1135,8 +1151,14 @@ class AscentExec:
         self.origin = pad_ecef() if local else np.zeros(3)
         # the f32 campaign build converts ECEF -> geodetic without angles (geodetic_sincos: the same recurrence, a fifth of
         # the instructions); an f64 executor flies the reference's arithmetic operation for operation
-        self.program = build_program(origin=self.origin if local else None, fsw=fsw, scripted=scripted,
-                                     algebraic_geodesy=bool(fast_math))
+        key = (tuple(float(v) for v in self.origin) if local else None, bool(fsw), bool(fast_math))
+        if scripted is None and key in _PROGRAMS:      # one program object per configuration: HipExec keeps its trace and object
+            self.program = _PROGRAMS[key]
+        else:
+            self.program = build_program(origin=self.origin if local else None, fsw=fsw, scripted=scripted,
+                                         algebraic_geodesy=bool(fast_math))
+            if scripted is None:
+                _PROGRAMS[key] = self.program
         cols = initial_columns(params, origin=self.origin) if columns is None else dict(columns)
         body = {k: cols.pop(k) for k in ("world_pos", "world_vel", "inertia")}
         # campaign builds (fast math) put the expensive arm of a `where` nobody else needs behind a wave-level branch

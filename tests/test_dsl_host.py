@@ -422,7 +422,7 @@ def test_guarded_selects_wrap_only_what_the_expensive_arm_alone_needs():
         n = dsl.random.normal(key, shape=(2,))
         fresh0, fresh1 = b[0] + n[0] * shared, b[1] + n[1] * np_.cos(a[1])
         return {"b": np_.array([np_.where(due, fresh0, b[0]), np_.where(due, fresh1, b[1])]),
-                "c": np_.array([shared, np_.where(a[0] * 0.0 + 1.0 > 2.0, np_.tan(a[1]), 0.0)])}
+                "c": np_.array([shared + c[0], np_.where(a[0] * 0.0 + 1.0 > 2.0, np_.tan(a[1]), 0.0)])}   # (c carried: computed every tick)
     tp = dsl.Program([sensor], dsl.Pipe([]), []).trace({"a": 3, "b": 2, "c": 2})
     plain = codegen.generate_source(tp, "float64", 2)
     src = codegen.generate_source(tp, "float64", 2, guard_selects=True)
@@ -616,3 +616,30 @@ def test_fast_math_builds_fold_single_use_products_into_their_sums():
     finally:
         del os.environ["SIXDOF_FUSE_FMA"]
     assert "= m_fma(" not in codegen.generate_source(tp, "float32", 2) and "= m_fma(" not in codegen.generate_source(tp, "float64", 2)
+
+
+def test_columns_nobody_reads_are_evaluated_where_they_are_stored():
+    """codegen._store_only_slots: a per-tick (transient) column no system and no effector reads — telemetry derived for the
+    database — is computed on the last tick of a launch or while the history ring records it, not on every tick; a column with
+    a reader, and a loop-carried one, are computed every tick as before."""
+    @dsl.system(x=1, seen=1, unseen=2, acc=1)
+    def derive(x, acc):
+        return {"seen": x * 2.0, "unseen": dsl.np.array([dsl.np.sin(x[0]), x[0] * x[0]]), "acc": acc + x}
+
+    @dsl.system(seen=1, out=1)
+    def use(seen):
+        return {"out": seen + 1.0}
+    tp = dsl.Program([derive, use], dsl.pipe(), []).trace({"x": 1, "seen": 1, "unseen": 2, "acc": 1, "out": 1})
+    src = codegen.generate_source(tp, "float64", 2)
+    names = [c for c, _ in tp.columns]
+    k = names.index("unseen")
+    assert "if (tick == P.tick0 + P.n_ticks || P.hist_ring != 0u) {  // store-only columns of derive" in src
+    lazy = src[src.index("// store-only columns of derive"):]
+    lazy = lazy[:lazy.index("\n        }")]
+    assert "m_sin(" in lazy and f"r.c{k}[1] =" in lazy and f"r.c{names.index('seen')}[0]" not in lazy
+    assert src.count("m_sin(") == 1                                   # (the prelude defines it by macro) the one use, inside the block
+    os.environ["SIXDOF_NO_STORE_ONLY_COLUMNS"] = "1"
+    try:
+        assert "store-only" not in codegen.generate_source(tp, "float64", 2)
+    finally:
+        del os.environ["SIXDOF_NO_STORE_ONLY_COLUMNS"]

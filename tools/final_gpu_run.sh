@@ -22,5 +22,6 @@ if [ "${2:-}" != "quick" ]; then
   bash profiles/collect.sh $TAG > $O/collect.log 2>&1
   bash profiles/collect_compute.sh $TAG > $O/collect_compute.log 2>&1
   python profiles/summarize_compute.py gpurun_out/prof_compute_$TAG > $O/summarize_compute.log 2>&1
+  bash profiles/collect_falcon9_mix.sh $TAG > $O/falcon9_instruction_mix.md 2> $O/falcon9_mix.err
 fi
 cut -c1-400 $O/bench_steps20.json; tail -25 $O/pytest.log; cat $O/jit_new_count.txt
