@@ -80,7 +80,9 @@ def test_unmodified_script_generates_the_program_of_the_respelling(probe_rows):
     for name in ("position", "velocity", "target", "mc:mass", "mc:thrust_gain"):
         assert np.array_equal(mine.world.column(name)[0], theirs.world.column(name)[0]), name
     src = next(iter(mine.sources.values()))
-    assert src.count("m_gather<T>(gtab0") == 1 + probe_rows                  # the drag coefficient + every probe row: loads, not select chains
+    # the drag coefficient + every probe row: loads, not select chains — once in the tick, and once more where the
+    # specific_force column (which nothing reads) is evaluated for storing
+    assert src.count("m_gather<T>(gtab0") == 2 * (1 + probe_rows) and src.count("// store-only columns of") == 1
 
 
 def test_a_parameter_that_reaches_the_code_through_host_arithmetic_is_refused():
