@@ -640,3 +640,42 @@ def test_random_streams_match_numpy_evaluation_and_differ_per_entity():
         dsl_numpy._run_systems(tp.pre, pos, vel, inertia, comps, tp.table, tick)
         assert hip32._aux["sample"].dtype == np.float32
         assert np.allclose(hip32._aux["sample"], comps["sample"], rtol=3e-7, atol=1e-7), tick
+
+
+def test_fast_math_bits_do_not_depend_on_the_launch_shape_and_a_program_object_is_built_once():
+    """A fast-math program (products folded into their sums by the generator, hardware sqrt / rcp, a store-only column) gives
+    the SAME bits with 1, 5 and 12 ticks per launch — fusion is decided per DAG node, not by what the compiler finds in one
+    basic block — and the history ring sees the store-only column on every tick.  The three executors come from ONE program
+    object: traced once, built once (HipExec keeps both on the object)."""
+    @dsl.system
+    def plant(x, y, derived):
+        a, b, c = x[0], x[1], x[2]
+        s = a * b + c
+        t = c - b * b * 0.25
+        u = np_.sqrt(np_.abs(s * t) + 1.0) / (np_.abs(a) + 0.5)
+        return {"x": np_.array([a * 0.999 + u * 1e-3, b - a * 1e-3, c + np_.where(u > 1.2, s, t) * 1e-3]),
+                "y": np_.array([s, t, u]) + y * 0.5,
+                "derived": np_.array([np_.sin(a) * u, s - t])}                 # nobody reads `derived`: evaluated where stored
+    prog = dsl.Program([plant], dsl.Pipe([]), [])
+    n = 4096
+    rng = np.random.default_rng(11)
+    x0 = rng.uniform(-2.0, 2.0, (n, 3))
+    w = workloads.independent_bodies(n)
+    runs = []
+    for k in (1, 5, 12):
+        hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=np.float32, integrator=L.INTEGRATOR_NONE, effectors=prog,
+                         columns={"x": x0, "y": np.zeros((n, 3)), "derived": np.zeros((n, 2))}, fast_math=True, ticks_per_launch=k)
+        if k == 12:
+            hip.enable_history(60)
+        hip.run(60)
+        runs.append({c: np.array(hip._aux[c]) for c in ("x", "y", "derived")})
+        if k == 12:
+            hist = hip.history("derived", 1, 60)
+        hip.close()
+    for r in runs[1:]:
+        for c in ("x", "y", "derived"):
+            assert np.array_equal(r[c], runs[0][c]), c
+    assert np.isfinite(runs[0]["y"]).all() and np.abs(runs[0]["derived"]).max() > 0.0
+    assert np.array_equal(hist[-1], runs[0]["derived"]) and not np.array_equal(hist[0], hist[-1])      # recorded on every tick
+    memo = prog._exec_memo
+    assert sum(1 for key in memo if key[0] == "trace") == 1 and sum(1 for key in memo if key[0] == "build") == 1
