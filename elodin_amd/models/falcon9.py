@@ -1229,8 +1229,9 @@ def run_campaign(plan_table: Optional[np.ndarray], n_runs: int, n_ticks: int = A
     mark = lambda: t.append(time.perf_counter())
     lo, hi = shard.shard_range(n_runs, world, rank)
     if make_exec is None:
-        fast = (np.dtype(dtype) == np.float32) if fast_math is None else bool(fast_math)   # hardware transcendentals in f32:
-        # 1.4x faster, and its deviation from the f64 flight is indistinguishable from plain f32's (tools/falcon9_fastmath.py)
+        fast = (np.dtype(dtype) == np.float32) if fast_math is None else bool(fast_math)   # the fast-math f32 build: 4.2x
+        # faster than plain f32 (3.8 vs 15.8 us per tick), and its deviation from the f64 flight is plain f32's to two digits
+        # in every campaign metric (tools/falcon9_fastmath.py, profiles/r04_falcon9_fastmath.txt)
         make_exec = lambda block, first_row: AscentExec(block, dtype=dtype, ticks_per_launch=ticks_per_launch, device=device,
                                                          fast_math=fast)
     ex = make_exec(table[lo:hi], lo)
