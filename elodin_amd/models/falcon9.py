@@ -223,19 +223,26 @@ def ecef_to_geodetic(xp, r):                                               # fra
     return lat, lon, alt
 
 
-def geodetic_sincos(xp, r):
-    """ecef_to_geodetic without a single angle: the same Bowring recurrence (frames.py:43-66, 4 fixed iterations) carried
-    on tan(beta) — tan(lat) = (z + e'^2 b sin^3 beta) / (p - e^2 a cos^3 beta), tan(beta) = (1 - f) tan(lat), sin / cos of an
-    angle in (-pi/2, pi/2) from its tangent by 1 / sqrt(1 + t^2) — returning (sin lat, cos lat, sin lon, cos lon, alt), which
-    is all the plant ever asks of a latitude or a longitude.  Algebraically the reference's function (identical in exact
-    arithmetic for p > 0, i.e. off the polar axis); ~75 instructions where the ten arctan / tan / sin / cos round trips of
-    the angle form are ~400.  The f32 campaign builds use it (build_program(algebraic_geodesy=True)); the f64 parity builds
-    keep the reference's angle arithmetic operation for operation."""
+GEODETIC_SINCOS_PASSES = 2
+
+
+def geodetic_sincos(xp, r, passes: int = GEODETIC_SINCOS_PASSES):
+    """ecef_to_geodetic without a single angle: the same Bowring recurrence (frames.py:43-66) carried on tan(beta) —
+    tan(lat) = (z + e'^2 b sin^3 beta) / (p - e^2 a cos^3 beta), tan(beta) = (1 - f) tan(lat), sin / cos of an angle in
+    (-pi/2, pi/2) from its tangent by 1 / sqrt(1 + t^2) — returning (sin lat, cos lat, sin lon, cos lon, alt), which is all
+    the plant ever asks of a latitude or a longitude.  Algebraically the reference's function (identical in exact arithmetic
+    for p > 0, i.e. off the polar axis); ~50 instructions where the ten arctan / tan / sin / cos round trips of the angle
+    form are ~400.  The reference makes 4 fixed passes; this makes `passes` = 2: the recurrence converges quadratically from
+    Bowring's starting value, and from -100 m to 400 km altitude at every latitude the second pass already leaves sin lat
+    within 2.2e-16 and the altitude within the 3e-9 m cancellation noise of the 4-pass value in FLOAT64 (in float32 two passes
+    are as close to four as three are) — tests/test_falcon9_host.py.  The f32 campaign builds use it
+    (build_program(algebraic_geodesy=True)); the f64 parity builds keep the reference's angle arithmetic operation for
+    operation, four passes included."""
     x, y, z = r[0], r[1], r[2]
     p = xp.hypot(x, y)
     k = 1.0 - WGS84_F
     t = z / (k * p)
-    for _ in range(4):
+    for _ in range(passes):
         cb = 1.0 / xp.sqrt(1.0 + t * t)
         sb = t * cb
         num = z + WGS84_EP2 * WGS84_B_M * sb ** 3
