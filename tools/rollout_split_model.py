@@ -70,7 +70,7 @@ def weighted(roots, scale=1.0):
 
 def program():
     cols = f9.initial_columns(f9.default_param_row()[None, :])
-    return f9.build_program(origin=f9.pad_ecef()).trace({k: v.shape[1] for k, v in cols.items()})
+    return f9.build_program(origin=f9.pad_ecef(), algebraic_geodesy=True).trace({k: v.shape[1] for k, v in cols.items()})
 
 
 # ---- 1 + 2: systems as tasks -----------------------------------------------------------------------------------------------
