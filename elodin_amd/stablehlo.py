@@ -9,9 +9,11 @@ ARCHITECTURE.md lists, minus what only a whole-world (entity-batched) tick needs
 comparisons / bit operations, constant, iota, convert, select, clamp, broadcast_in_dim, reshape, transpose, slice, concatenate,
 reverse, dot_general (batching + contracting dims), reduce (`applies` form and reducer regions), while, case, func.call,
 dynamic_slice, dynamic_update_slice, gather (the index-clamping general form), sort (1-D, comparator LT / GT), cholesky,
-triangular_solve, chlo.{erf_inv, square, acos, asin, sinh, cosh, erfc, ...}.  Integer tensors are integral values in the
-executor's float type (exact up to 2^53 in f64), like everywhere in the tracer.  Not read: scatter, convolution,
-reduce_window, select_and_scatter, rng, custom_call (LAPACK FFI), batch_norm — an unsupported op says which.
+triangular_solve, scatter (one operand, no batching dims: `x.at[i].set / .add`), real_dynamic_slice, reduce_window,
+select_and_scatter, the LAPACK FFI custom calls jax.numpy.linalg lowers to on CPU (dpotrf, dtrsm, dgetrf with LAPACK's pivots
+and row order, dgesv, dgesdd), chlo.{erf_inv, square, acos, asin, sinh, cosh, erfc, ...}.  Integer tensors are integral
+values in the executor's float type (exact up to 2^53 in f64), like everywhere in the tracer.  Not read: convolution, rng,
+batch_norm, the remaining LAPACK calls (geqrf, syevd, ...) — an unsupported op says which.
 
 Pinned on the known answers of the reference's own op tests (libs/cranelift-mlir/tests/ops.rs: inline modules with expected
 outputs -> tests/golden/stablehlo_ops.json, tests/test_stablehlo_ingest.py on the CPU walker, tests/test_gpu_stablehlo.py on
@@ -141,6 +143,8 @@ class _Lines:
         for ln in raw:
             cur = (cur + " " + ln) if cur else ln
             open_ = cur.count("(") - cur.count(")") + cur.count("[") - cur.count("]")
+            if cur.count("<{") > cur.count("}>"):          # inside a generic op's property dictionary `<{ ... }>`: not a region
+                continue
             if cur.endswith(("({", "{")) or cur.startswith("^bb") or (open_ <= 0 and not cur.endswith((",", ":"))):
                 self.lines.append(cur)
                 cur = ""
@@ -430,6 +434,14 @@ class _Eval:
             for j in range(B.shape[1]):
                 cols.append(dsl_mat.solve_triangular(A, _dsl.Vec(list(B[:, j])), lower=lower, trans=trans, unit_diagonal=unit))
             return [Sym(np.array([[cols[j].e[i] for j in range(B.shape[1])] for i in range(B.shape[0])], dtype=object), xs[1].dtype)]
+        if short == "scatter":
+            return self._scatter(op, xs, text, env)
+        if short == "real_dynamic_slice":
+            return [self._real_dynamic_slice(xs[0], xs[1], xs[3], rt)]
+        if short == "reduce_window":
+            return self._reduce_window(op, xs, text, rts, env)
+        if short == "select_and_scatter":
+            return [self._select_and_scatter(op, xs, text, env)]
         if short == "map":
             region = self._region_fn(op, 0, env)
             out = np.empty(xs[0].shape, dtype=object)
@@ -723,6 +735,199 @@ class _Eval:
             out[pos] = cur[()] if isinstance(cur, np.ndarray) else cur
         return Sym(out, operand.dtype)
 
+    @staticmethod
+    def _window_attr(text: str, key: str, rank: int, default: int) -> List[int]:
+        """window_dimensions / window_strides / ... in either spelling: `array<i64: 2, 2>` or `dense<[2, 2]> : tensor<2xi64>` (a
+        splat `dense<1>` repeats)."""
+        m = re.search(re.escape(key) + r"\s*=\s*(?:array<i64(?::\s*([^>]*))?>|dense<\[?([^\]>]*)\]?>)", text)
+        if not m:
+            return [default] * rank
+        body = m.group(1) if m.group(1) is not None else (m.group(2) or "")
+        vals = [int(x) for x in body.replace(" ", "").split(",") if x]
+        return vals * rank if len(vals) == 1 and rank > 1 else (vals or [default] * rank)
+
+    @staticmethod
+    def _padding_attr(text: str, rank: int) -> List[Tuple[int, int]]:
+        m = re.search(r"padding\s*=\s*dense<([^>]*)>", text)
+        if not m:
+            return [(0, 0)] * rank
+        vals = [int(x) for x in re.findall(r"-?\d+", m.group(1))]
+        if len(vals) == 1:
+            return [(vals[0], vals[0])] * rank
+        return [(vals[2 * d], vals[2 * d + 1]) for d in range(rank)]
+
+    def _scatter(self, op: Op, xs: List[Sym], text: str, env) -> List[Sym]:
+        """stablehlo.scatter, one operand: every update element lands on operand[start + window offset] through the update
+        region — with traced start indices as a select per (operand position, update element) that can meet; an update whose
+        window leaves the operand is skipped (scatter does not clamp).  `x.at[i].set(v)` / `.add(v)` lower to this."""
+        if len(xs) != 3:
+            raise NotImplementedError("stablehlo.scatter with several operands")
+        operand, indices, updates = xs
+        g = lambda key: self._ints(text, key)
+        uwd, iwd, sdod = g("update_window_dims"), g("inserted_window_dims"), g("scatter_dims_to_operand_dims")
+        ob, ib = g("input_batching_dims"), g("scatter_indices_batching_dims")
+        if ob or ib:
+            raise NotImplementedError("stablehlo.scatter with batching dimensions")
+        m = re.search(r"index_vector_dim\s*=\s*(\d+)", text)
+        ivd = int(m.group(1)) if m else (indices.a.ndim - 1 if indices.a.ndim else 0)
+        region = self._region_fn(op, 0, env)
+        scatter_dims = [d for d in range(updates.a.ndim) if d not in uwd]           # update dims that walk the index batch
+        window_operand_dims = [d for d in range(operand.a.ndim) if d not in iwd]    # operand dims the update window spans
+        out = operand.a.copy()
+        for upos in (np.ndindex(updates.shape) if updates.shape else [()]):
+            batch = [upos[d] for d in scatter_dims]
+            sel = list(batch)
+            if ivd < indices.a.ndim:
+                sel.insert(ivd, slice(None))
+                vec = list(np.atleast_1d(indices.a[tuple(sel)]))
+            else:
+                vec = [indices.a[tuple(sel)] if sel else indices.a[()]]
+            start = [None] * operand.a.ndim
+            for k, d in enumerate(sdod):
+                start[d] = vec[k]
+            offs = [0] * operand.a.ndim
+            for k, d in enumerate(window_operand_dims):
+                offs[d] = upos[uwd[k]]
+            upd = updates.a[upos]
+            for pos in (np.ndindex(operand.shape) if operand.shape else [()]):
+                hit, possible = None, True
+                for d in range(operand.a.ndim):
+                    want = pos[d] - offs[d]                    # the start index that would put this update element on `pos`
+                    if start[d] is None:
+                        possible = possible and want == 0
+                        continue
+                    window = max((upos[uwd[k]] for k, dd in enumerate(window_operand_dims) if dd == d), default=0)
+                    size = (updates.shape[uwd[window_operand_dims.index(d)]] if d in window_operand_dims else 1)
+                    if want < 0 or want > operand.shape[d] - size:    # the whole window would not fit: such an update is skipped
+                        possible = False
+                        break
+                    c = _np.equal(start[d], float(want))
+                    hit = c if hit is None else _np.logical_and(hit, c)
+                if not possible:
+                    continue
+                new = region(Sym(_obj_scalar(out[pos]), operand.dtype), Sym(_obj_scalar(upd), updates.dtype))[0].a[()]
+                out[pos] = new if hit is None else _np.where(hit, new, out[pos])
+        return [Sym(out, operand.dtype)]
+
+    def _real_dynamic_slice(self, x: Sym, start: Sym, strides: Sym, rt: TensorType) -> Sym:
+        """operand[start + i * stride] for the STATIC result shape (start / limit / strides are tensors; the limit only
+        restates the shape)."""
+        out = np.empty(rt.shape, dtype=object)
+        for pos in (np.ndindex(rt.shape) if rt.shape else [()]):
+            cur = x.a
+            for d in range(x.a.ndim):
+                ix = start.a.reshape(-1)[d] + float(pos[d]) * strides.a.reshape(-1)[d]
+                if isinstance(ix, Expr) and ix.op == "const":
+                    cur = cur[int(ix.value)]
+                elif not isinstance(ix, Expr):
+                    cur = cur[int(ix)]
+                else:
+                    cands = [np.asarray(cur[k], dtype=object) if cur.ndim > 1 else _scalar(cur[k]) for k in range(cur.shape[0])]
+                    cur = self._pick(cands, _np.clip(ix, 0.0, float(len(cands) - 1)))
+            out[pos] = cur[()] if isinstance(cur, np.ndarray) else cur
+        return Sym(out, x.dtype)
+
+    def _windows(self, shape, text: str):
+        """(output shape, for each output position the list of (operand position or None for padding / dilation holes))."""
+        rank = len(shape)
+        wd = self._window_attr(text, "window_dimensions", rank, 1)
+        ws = self._window_attr(text, "window_strides", rank, 1)
+        bd = self._window_attr(text, "base_dilations", rank, 1)
+        wdil = self._window_attr(text, "window_dilations", rank, 1)
+        pad = self._padding_attr(text, rank)
+        dilated = [(n - 1) * b + 1 if n > 0 else 0 for n, b in zip(shape, bd)]
+        padded = [n + lo + hi for n, (lo, hi) in zip(dilated, pad)]
+        span = [(w - 1) * dl + 1 for w, dl in zip(wd, wdil)]
+        out_shape = tuple(max((p - sp) // st + 1, 0) if p >= sp else 0 for p, sp, st in zip(padded, span, ws))
+
+        def elems(opos):
+            res = []
+            for w in itertools.product(*[range(k) for k in wd]):
+                src = []
+                for d in range(rank):
+                    q = opos[d] * ws[d] + w[d] * wdil[d] - pad[d][0]          # position in the dilated operand
+                    if q < 0 or q >= dilated[d] or q % bd[d] != 0:
+                        src = None
+                        break
+                    src.append(q // bd[d])
+                res.append(tuple(src) if src is not None else None)
+            return res
+        return out_shape, elems
+
+    def _reduce_window(self, op: Op, xs: List[Sym], text: str, rts, env) -> List[Sym]:
+        n = len(xs) // 2
+        operands, inits = xs[:n], xs[n:]
+        region = self._region_fn(op, 0, env)
+        out_shape, elems = self._windows(operands[0].shape, text)
+        outs = [np.empty(out_shape, dtype=object) for _ in operands]
+        for opos in (np.ndindex(out_shape) if out_shape else [()]):
+            acc = [i.a[()] for i in inits]
+            for src in elems(opos):
+                vals = [i.a[()] for i in inits] if src is None else [o.a[src] for o in operands]      # padding reads the init value
+                res = region(*[Sym(_obj_scalar(v), o.dtype) for v, o in zip(acc, operands)], *[Sym(_obj_scalar(v), o.dtype) for v, o in zip(vals, operands)])
+                acc = [r.a[()] for r in res]
+            for o, v in zip(outs, acc):
+                o[opos] = v
+        return [Sym(o, x.dtype) for o, x in zip(outs, operands)]
+
+    def _select_and_scatter(self, op: Op, xs: List[Sym], text: str, env) -> Sym:
+        """Per window of `operand`: the element the select region keeps (the running choice survives while select(choice,
+        candidate) holds) receives that window's `source` value through the scatter region; everything starts at `init`."""
+        operand, source, init = xs
+        select, scatter = self._region_fn(op, 0, env), self._region_fn(op, 1, env)
+        out_shape, elems = self._windows(operand.shape, text)
+        if tuple(out_shape) != tuple(source.shape):
+            raise ValueError(f"select_and_scatter: {len(out_shape)}-d windows give {out_shape}, source is {source.shape}")
+        out = np.empty(operand.shape, dtype=object)
+        for pos in (np.ndindex(operand.shape) if operand.shape else [()]):
+            out[pos] = init.a[()]
+        for wpos in (np.ndindex(out_shape) if out_shape else [()]):
+            cand = [e for e in elems(wpos) if e is not None]
+            if not cand:
+                continue
+            cur = operand.a[cand[0]]
+            chosen = [True]                                   # per candidate: is it the selected element (Python bool or traced)
+            for e in cand[1:]:
+                keep = select(Sym(_obj_scalar(cur), operand.dtype), Sym(_obj_scalar(operand.a[e]), operand.dtype))[0].a[()]
+                chosen = [(_np.logical_and(c, keep) if c is not True else keep) for c in chosen] + [_np.logical_not(keep)]
+                cur = _np.where(keep, cur, operand.a[e])
+            for e, c in zip(cand, chosen):
+                new = scatter(Sym(_obj_scalar(out[e]), operand.dtype), Sym(_obj_scalar(source.a[wpos]), source.dtype))[0].a[()]
+                out[e] = new if c is True else _np.where(c, new, out[e])
+        return Sym(out, operand.dtype)
+
+    @staticmethod
+    def _getrf(a: np.ndarray):
+        """dgetrf on an object matrix: (LU in LAPACK's layout, ipiv 1-based, info) — per column the FIRST entry of largest
+        magnitude on or below the diagonal is swapped up (one swap, as LAPACK leaves the rows), multipliers stored below the
+        diagonal; pivot choice and swap are selects.  info = 1-based index of the first exactly-zero pivot, else 0."""
+        n = a.shape[0]
+        u = [[a[i, j] for j in range(n)] for i in range(n)]
+        ipiv, info = [], _dsl.const(0.0)
+        for k in range(n):
+            p, best = _dsl.const(float(k)), _np.abs(u[k][k])
+            for i in range(k + 1, n):
+                better = _np.abs(u[i][k]) > best
+                p, best = _np.where(better, float(i), p), _np.where(better, _np.abs(u[i][k]), best)
+            ipiv.append(p + 1.0)
+            old_k = list(u[k])
+            for j in range(n):                                     # row k <- row p
+                v = old_k[j]
+                for i in range(k + 1, n):
+                    v = _np.where(_np.equal(p, float(i)), u[i][j], v)
+                u[k][j] = v
+            for i in range(k + 1, n):                              # row p <- old row k
+                hit = _np.equal(p, float(i))
+                for j in range(n):
+                    u[i][j] = _np.where(hit, old_k[j], u[i][j])
+            info = _np.where(_np.logical_and(_np.equal(info, 0.0), _np.equal(u[k][k], 0.0)), float(k + 1), info)
+            for i in range(k + 1, n):
+                f = u[i][k] / u[k][k]
+                u[i][k] = f
+                for j in range(k + 1, n):
+                    u[i][j] = u[i][j] - f * u[k][j]
+        return np.array(u, dtype=object), np.array(ipiv, dtype=object), _scalar(info)
+
     def _custom_call(self, text: str, xs: List[Sym], rts) -> List[Sym]:
         """The LAPACK FFI calls jax.numpy.linalg lowers to on CPU, for the factorisations elodin_amd.dsl_mat unrolls: dpotrf
         (Cholesky; the other triangle is zero) and dtrsm (triangular solve, left side)."""
@@ -744,6 +949,21 @@ class _Eval:
             A, B = dsl_mat.Mat([_dsl.Vec(list(r)) for r in xs[0].a]), xs[1].a
             cols = [dsl_mat.solve_triangular(A, _dsl.Vec(list(B[:, j])), lower=lower, trans=trans, unit_diagonal=unit) for j in range(B.shape[1])]
             return [Sym(np.array([[cols[j].e[i] for j in range(B.shape[1])] for i in range(B.shape[0])], dtype=object), xs[1].dtype)]
+        if target == "lapack_dgetrf_ffi" and xs[0].a.ndim == 2 and xs[0].shape[0] == xs[0].shape[1]:
+            lu, ipiv, info = self._getrf(xs[0].a)
+            return [Sym(lu, xs[0].dtype), Sym(ipiv, "i32"), Sym(info, "i32")][:max(1, len(rts))]
+        if target == "lapack_dgesv_ffi" and xs[0].a.ndim == 2 and xs[1].a.ndim == 2:
+            # the solution of A X = B by the pivoted elimination above + substitution (dsl_mat.solve: same pivots, same sums)
+            X = dsl_mat.solve(dsl_mat.Mat([_dsl.Vec(list(r)) for r in xs[0].a]), dsl_mat.Mat([_dsl.Vec(list(r)) for r in xs[1].a]))
+            _, _, info = self._getrf(xs[0].a)
+            return [Sym(np.array([[e for e in r.e] for r in X], dtype=object), xs[1].dtype), Sym(info, "i32")][:max(1, len(rts))]
+        if target == "lapack_dgesdd_ffi" and xs[0].a.ndim == 2:
+            # (A as LAPACK leaves it: unspecified for jobz = 'A', handed back unchanged; s descending; U; V^T; info = 0) by one-sided
+            # Jacobi (dsl_mat.svd).  Singular vectors are determined up to a sign per pair, so U / V^T may differ from LAPACK's by it.
+            u, sv, vh = dsl_mat.svd(dsl_mat.Mat([_dsl.Vec(list(r)) for r in xs[0].a]))
+            mat = lambda m: np.array([[e for e in r.e] for r in m], dtype=object)
+            return [Sym(xs[0].a.copy(), xs[0].dtype), Sym(np.array(list(sv.e), dtype=object), xs[0].dtype), Sym(mat(u), xs[0].dtype),
+                    Sym(mat(vh), xs[0].dtype), Sym(_obj(np.zeros(())), "i32")][:max(1, len(rts))]
         raise NotImplementedError(f"stablehlo.custom_call @{target} is not provided by elodin_amd.stablehlo")
 
     def _sort(self, op: Op, x: Sym, text: str) -> Sym:
