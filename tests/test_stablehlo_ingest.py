@@ -48,7 +48,7 @@ def test_the_fixture_covers_the_front_ends_op_set():
     assert len(U.CASES) >= 100 and len(U.CASES) - len(U.UNSUPPORTED) - len(U.BEYOND_F64_INTEGERS) >= 90
     for op in ("add", "dot_general", "reduce", "while", "case", "gather", "dynamic_slice", "dynamic_update_slice", "broadcast_in_dim", "transpose",
                "concatenate", "slice", "compare", "select", "convert", "iota", "sort", "cholesky", "triangular_solve", "custom_call", "erf_inv",
-               "shift_right_logical", "remainder", "clamp", "reverse", "map"):
+               "shift_right_logical", "remainder", "clamp", "reverse", "map", "scatter", "real_dynamic_slice", "reduce_window", "select_and_scatter"):
         assert op in ops, op
 
 
@@ -81,5 +81,102 @@ module @m {
     assert [str(t) for t in funcs["two"].result_types] == ["tensor<2xf64>", "tensor<f64>"] and len(funcs["two"].args) == 2
     out = dsl_numpy.trace_eval(lambda xp, a, b: sh.trace(text, [a, b])[0].a[()], np.array([2.0, 3.0]), 4.0)
     assert out == (2 * 4) * 2 + (3 * 4) * 3 + (8 + 12)
-    with pytest.raises(NotImplementedError, match="scatter"):
-        sh.trace(text.replace("stablehlo.add %0, %r#1", "stablehlo.scatter %0, %r#1"), [dsl.Vec([dsl.leaf("a"), dsl.leaf("b")]), dsl.leaf("c")])
+    with pytest.raises(NotImplementedError, match="convolution"):          # an op the front end does not read says so by name
+        sh.trace(text.replace("stablehlo.add %0, %r#1", "stablehlo.convolution %0, %r#1"), [dsl.Vec([dsl.leaf("a"), dsl.leaf("b")]), dsl.leaf("c")])
+
+
+def test_scatter_with_a_traced_row_index_windowed_updates_and_an_add_region():
+    """What `x.at[i].add(row)` lowers to, with the row index an INPUT (the reference's own scatter tests use constants): a 3-wide
+    window added into row i of a 4 x 3 operand; an index that does not fit is skipped (scatter does not clamp); negative too."""
+    text = """
+module @m {
+  func.func public @main(%arg0: tensor<4x3xf64>, %arg1: tensor<1xi32>, %arg2: tensor<3xf64>) -> tensor<4x3xf64> {
+    %0 = "stablehlo.scatter"(%arg0, %arg1, %arg2) <{
+      indices_are_sorted = true,
+      scatter_dimension_numbers = #stablehlo.scatter<update_window_dims = [0], inserted_window_dims = [0], scatter_dims_to_operand_dims = [0]>,
+      unique_indices = true
+    }> ({
+    ^bb0(%a: tensor<f64>, %b: tensor<f64>):
+      %s = stablehlo.add %a, %b : tensor<f64>
+      stablehlo.return %s : tensor<f64>
+    }) : (tensor<4x3xf64>, tensor<1xi32>, tensor<3xf64>) -> tensor<4x3xf64>
+    return %0 : tensor<4x3xf64>
+  }
+}
+"""
+    x = np.arange(12.0).reshape(4, 3)
+    row = np.array([100.0, 200.0, 300.0])
+    for i in (0, 2, 3, 4, -1):
+        got = dsl_numpy.trace_eval(lambda xp, a, k, r: dsl.Vec(list(sh.trace(text, [a, k, r])[0].a.reshape(-1))), x.reshape(-1), np.array([float(i)]), row)
+        want = x.copy()
+        if 0 <= i < 4:
+            want[i] += row
+        assert np.array_equal(np.asarray(got).reshape(4, 3), want), i
+
+
+def test_reduce_window_with_padding_strides_and_a_max_region_and_select_and_scatter_in_two_dimensions():
+    """A 2 x 2 / stride 2 max pool over a padded 3 x 3 input (padding reads the init value), and the select_and_scatter that
+    routes one value per window back to the window's maximum — against numpy."""
+    pool = """
+module @m {
+  func.func public @main(%arg0: tensor<3x3xf64>, %arg1: tensor<f64>) -> tensor<2x2xf64> {
+    %0 = "stablehlo.reduce_window"(%arg0, %arg1) ({
+    ^bb0(%a: tensor<f64>, %b: tensor<f64>):
+      %1 = stablehlo.maximum %a, %b : tensor<f64>
+      stablehlo.return %1 : tensor<f64>
+    }) {window_dimensions = array<i64: 2, 2>, window_strides = array<i64: 2, 2>, padding = dense<[[0, 1], [0, 1]]> : tensor<2x2xi64>} : (tensor<3x3xf64>, tensor<f64>) -> tensor<2x2xf64>
+    return %0 : tensor<2x2xf64>
+  }
+}
+"""
+    x = np.array([[1.0, 7.0, 2.0], [3.0, 4.0, 9.0], [8.0, 5.0, 6.0]])
+    got = dsl_numpy.trace_eval(lambda xp, a, i: dsl.Vec(list(sh.trace(pool, [a, i])[0].a.reshape(-1))), x.reshape(-1), -1e9)
+    padded = np.full((4, 4), -1e9)
+    padded[:3, :3] = x
+    want = np.array([[padded[2 * i:2 * i + 2, 2 * j:2 * j + 2].max() for j in range(2)] for i in range(2)])
+    assert np.array_equal(np.asarray(got).reshape(2, 2), want)
+    route = """
+module @m {
+  func.func public @main(%arg0: tensor<4x4xf64>, %arg1: tensor<2x2xf64>, %arg2: tensor<f64>) -> tensor<4x4xf64> {
+    %0 = "stablehlo.select_and_scatter"(%arg0, %arg1, %arg2) ({
+    ^bb0(%a: tensor<f64>, %b: tensor<f64>):
+      %1 = stablehlo.compare GE, %a, %b, FLOAT : (tensor<f64>, tensor<f64>) -> tensor<i1>
+      stablehlo.return %1 : tensor<i1>
+    }, {
+    ^bb0(%x: tensor<f64>, %y: tensor<f64>):
+      %1 = stablehlo.add %x, %y : tensor<f64>
+      stablehlo.return %1 : tensor<f64>
+    }) {window_dimensions = dense<[2, 2]> : tensor<2xi64>, window_strides = dense<[2, 2]> : tensor<2xi64>, padding = dense<0> : tensor<2x2xi64>} : (tensor<4x4xf64>, tensor<2x2xf64>, tensor<f64>) -> tensor<4x4xf64>
+    return %0 : tensor<4x4xf64>
+  }
+}
+"""
+    rng = np.random.default_rng(5)
+    op, src = rng.permutation(16).astype(float).reshape(4, 4), np.array([[10.0, 20.0], [30.0, 40.0]])
+    got = dsl_numpy.trace_eval(lambda xp, a, b, i: dsl.Vec(list(sh.trace(route, [a, b, i])[0].a.reshape(-1))), op.reshape(-1), src.reshape(-1), 0.5)
+    want = np.full((4, 4), 0.5)
+    for i in range(2):
+        for j in range(2):
+            blk = op[2 * i:2 * i + 2, 2 * j:2 * j + 2]
+            r, c = np.unravel_index(np.argmax(blk), (2, 2))
+            want[2 * i + r, 2 * j + c] += src[i, j]
+    assert np.array_equal(np.asarray(got).reshape(4, 4), want)
+
+
+def test_dgetrf_keeps_lapacks_pivots_and_row_order():
+    """lapack_dgetrf_ffi on a 4 x 4 matrix that needs a swap in every column: LU and ipiv equal scipy.linalg.lu_factor (LAPACK's
+    own dgetrf) — the factor in LAPACK's row order, not merely a valid factorisation."""
+    from scipy.linalg import lu_factor
+    text = """
+module @m {
+  func.func public @main(%arg0: tensor<4x4xf64>) -> (tensor<4x4xf64>, tensor<4xi32>, tensor<i32>) {
+    %0:3 = stablehlo.custom_call @lapack_dgetrf_ffi(%arg0) {backend_config = "", mhlo.backend_config = {}} -> (tensor<4x4xf64>, tensor<4xi32>, tensor<i32>)
+    return %0#0, %0#1, %0#2 : tensor<4x4xf64>, tensor<4xi32>, tensor<i32>
+  }
+}
+"""
+    a = np.array([[1.0, 2.0, 3.0, 4.0], [2.0, -1.0, 0.5, 7.0], [9.0, 1.0, 2.0, -3.0], [4.0, 8.0, -6.0, 1.0]])
+    out = dsl_numpy.trace_eval(lambda xp, m: dsl.Vec([v for r in sh.trace(text, [m]) for v in r.a.reshape(-1)]), a.reshape(-1))
+    out = np.asarray(out)
+    lu, piv = lu_factor(a)
+    assert np.allclose(out[:16].reshape(4, 4), lu, rtol=0, atol=1e-13) and np.array_equal(out[16:20], piv + 1.0) and out[20] == 0.0
