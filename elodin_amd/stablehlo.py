@@ -13,7 +13,8 @@ triangular_solve, scatter (one operand, no batching dims: `x.at[i].set / .add`),
 select_and_scatter, the LAPACK FFI custom calls jax.numpy.linalg lowers to on CPU (dpotrf, dtrsm, dgetrf with LAPACK's pivots
 and row order, dgesv, dgesdd), chlo.{erf_inv, square, acos, asin, sinh, cosh, erfc, ...}.  Integer tensors are integral
 values in the executor's float type (exact up to 2^53 in f64), like everywhere in the tracer.  Not read: convolution, rng,
-batch_norm, the remaining LAPACK calls (geqrf, syevd, ...) — an unsupported op says which.
+batch_norm, the remaining LAPACK calls (gees, geev, ...) — an unsupported op says which.  (dgeqrf / dorgqr — `jnp.linalg.qr` — and
+dsyevd — `eigh` — are read too; the reference's op tests hold no answers for them: pinned on LAPACK itself through scipy.)
 
 Pinned on the known answers of the reference's own op tests (libs/cranelift-mlir/tests/ops.rs: inline modules with expected
 outputs -> tests/golden/stablehlo_ops.json, tests/test_stablehlo_ingest.py on the CPU walker, tests/test_gpu_stablehlo.py on
@@ -928,6 +929,57 @@ class _Eval:
                     u[i][j] = u[i][j] - f * u[k][j]
         return np.array(u, dtype=object), np.array(ipiv, dtype=object), _scalar(info)
 
+    @staticmethod
+    def _geqrf(a: np.ndarray):
+        """dgeqrf (unblocked dgeqr2 + dlarfg): R on and above the diagonal, the Householder vectors (v[0] = 1 implied) below it,
+        tau per reflector — H = I - tau v v^T, beta = -sign(alpha) |x|, tau = (beta - alpha) / beta, v = x / (alpha - beta); a
+        column that is already zero below the diagonal gets tau = 0."""
+        m, n = a.shape
+        r = [[a[i, j] for j in range(n)] for i in range(m)]
+        taus = []
+        for k in range(min(m, n)):
+            alpha = r[k][k]
+            xnorm2 = None
+            for i in range(k + 1, m):
+                xnorm2 = r[i][k] * r[i][k] if xnorm2 is None else xnorm2 + r[i][k] * r[i][k]
+            if xnorm2 is None:                                   # last row: H = I
+                taus.append(_dsl.const(0.0))
+                continue
+            trivial = _np.equal(xnorm2, 0.0)
+            beta = -_np.where(alpha >= 0.0, 1.0, -1.0) * _np.sqrt(alpha * alpha + xnorm2)
+            safe_beta = _np.where(trivial, 1.0, beta)
+            tau = _np.where(trivial, 0.0, (safe_beta - alpha) / safe_beta)
+            scale = 1.0 / _np.where(trivial, 1.0, alpha - safe_beta)
+            v = [_dsl.const(1.0)] + [r[i][k] * scale for i in range(k + 1, m)]
+            r[k][k] = _np.where(trivial, alpha, beta)
+            for i in range(k + 1, m):
+                r[i][k] = _np.where(trivial, r[i][k], v[i - k])
+            for j in range(k + 1, n):                            # apply H to the trailing columns: c -= tau v (v . c)
+                dot = r[k][j]
+                for i in range(k + 1, m):
+                    dot = dot + v[i - k] * r[i][j]
+                for i in range(k, m):
+                    r[i][j] = r[i][j] - tau * v[i - k] * dot
+            taus.append(tau)
+        return np.array(r, dtype=object), np.array(taus, dtype=object)
+
+    @staticmethod
+    def _orgqr(a: np.ndarray, tau: np.ndarray) -> np.ndarray:
+        """dorgqr: the first n columns of Q = H_1 H_2 ... H_k from dgeqrf's reflectors (applied to the identity, last first)."""
+        m, n = a.shape
+        k = tau.shape[0]
+        q = [[_dsl.const(1.0 if i == j else 0.0) for j in range(n)] for i in range(m)]
+        for kk in range(k - 1, -1, -1):
+            v = [_dsl.const(1.0)] + [a[i, kk] for i in range(kk + 1, m)]
+            for j in range(n):
+                dot = None
+                for i in range(kk, m):
+                    t = v[i - kk] * q[i][j]
+                    dot = t if dot is None else dot + t
+                for i in range(kk, m):
+                    q[i][j] = q[i][j] - tau[kk] * v[i - kk] * dot
+        return np.array(q, dtype=object)
+
     def _custom_call(self, text: str, xs: List[Sym], rts) -> List[Sym]:
         """The LAPACK FFI calls jax.numpy.linalg lowers to on CPU, for the factorisations elodin_amd.dsl_mat unrolls: dpotrf
         (Cholesky; the other triangle is zero) and dtrsm (triangular solve, left side)."""
@@ -964,6 +1016,20 @@ class _Eval:
             mat = lambda m: np.array([[e for e in r.e] for r in m], dtype=object)
             return [Sym(xs[0].a.copy(), xs[0].dtype), Sym(np.array(list(sv.e), dtype=object), xs[0].dtype), Sym(mat(u), xs[0].dtype),
                     Sym(mat(vh), xs[0].dtype), Sym(_obj(np.zeros(())), "i32")][:max(1, len(rts))]
+        if target == "lapack_dgeqrf_ffi" and xs[0].a.ndim == 2:
+            qr_, tau = self._geqrf(xs[0].a)
+            return [Sym(qr_, xs[0].dtype), Sym(tau, xs[0].dtype), Sym(_obj(np.zeros(())), "i32")][:max(1, len(rts))]
+        if target == "lapack_dorgqr_ffi" and xs[0].a.ndim == 2:
+            return [Sym(self._orgqr(xs[0].a, xs[1].a), xs[0].dtype), Sym(_obj(np.zeros(())), "i32")][:max(1, len(rts))]
+        if target == "lapack_dsyevd_ffi" and xs[0].a.ndim == 2:
+            # (eigenvectors as columns, eigenvalues ascending, info = 0) of the symmetric matrix whose `uplo` triangle is given, by
+            # cyclic Jacobi (dsl_mat.eigh); an eigenvector is determined up to its sign, so columns may differ from LAPACK's by it
+            lower = attr("uplo", 76) == 76
+            n = xs[0].shape[0]
+            sym = [[xs[0].a[max(i, j), min(i, j)] if lower else xs[0].a[min(i, j), max(i, j)] for j in range(n)] for i in range(n)]
+            w, v = dsl_mat.eigh(dsl_mat.Mat([_dsl.Vec(r) for r in sym]))
+            return [Sym(np.array([[e for e in r.e] for r in v], dtype=object), xs[0].dtype), Sym(np.array(list(w.e), dtype=object), xs[0].dtype),
+                    Sym(_obj(np.zeros(())), "i32")][:max(1, len(rts))]
         raise NotImplementedError(f"stablehlo.custom_call @{target} is not provided by elodin_amd.stablehlo")
 
     def _sort(self, op: Op, x: Sym, text: str) -> Sym:

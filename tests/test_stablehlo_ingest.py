@@ -180,3 +180,39 @@ module @m {
     out = np.asarray(out)
     lu, piv = lu_factor(a)
     assert np.allclose(out[:16].reshape(4, 4), lu, rtol=0, atol=1e-13) and np.array_equal(out[16:20], piv + 1.0) and out[20] == 0.0
+
+
+def test_qr_and_eigh_custom_calls_against_lapack_itself():
+    """What jnp.linalg.qr (dgeqrf + dorgqr) and jnp.linalg.eigh (dsyevd) lower to on CPU.  The reference's op tests hold no
+    answers for these three: dgeqrf's packed output and tau are compared with scipy's binding of LAPACK's own routine
+    (same reflectors, not merely a valid factorisation), Q R = A, and the eigen-decomposition by its defining properties."""
+    from scipy.linalg import lapack
+    qr_text = """
+module @m {
+  func.func public @main(%arg0: tensor<4x3xf64>) -> (tensor<4x3xf64>, tensor<3xf64>, tensor<4x3xf64>) {
+    %0:2 = stablehlo.custom_call @lapack_dgeqrf_ffi(%arg0) {mhlo.backend_config = {}} -> (tensor<4x3xf64>, tensor<3xf64>)
+    %1 = stablehlo.custom_call @lapack_dorgqr_ffi(%0#0, %0#1) {mhlo.backend_config = {}} -> (tensor<4x3xf64>)
+    return %0#0, %0#1, %1 : tensor<4x3xf64>, tensor<3xf64>, tensor<4x3xf64>
+  }
+}
+"""
+    a = np.array([[2.0, -1.0, 0.5], [1.0, 3.0, -2.0], [0.0, 4.0, 1.0], [-3.0, 0.5, 2.5]])
+    out = np.asarray(dsl_numpy.trace_eval(lambda xp, m: dsl.Vec([v for r in sh.trace(qr_text, [m]) for v in r.a.reshape(-1)]), a.reshape(-1)))
+    packed, tau, q = out[:12].reshape(4, 3), out[12:15], out[15:].reshape(4, 3)
+    want_packed, want_tau, _, info = lapack.dgeqrf(a)
+    assert info == 0 and np.allclose(packed, want_packed, rtol=0, atol=1e-13) and np.allclose(tau, want_tau, rtol=0, atol=1e-13)
+    assert np.allclose(q @ np.triu(packed)[:3], a, atol=1e-13) and np.allclose(q.T @ q, np.eye(3), atol=1e-13)
+    eigh_text = """
+module @m {
+  func.func public @main(%arg0: tensor<3x3xf64>) -> (tensor<3x3xf64>, tensor<3xf64>, tensor<i32>) {
+    %0:3 = stablehlo.custom_call @lapack_dsyevd_ffi(%arg0) {mhlo.backend_config = {mode = 86 : ui8, uplo = 76 : ui8}} -> (tensor<3x3xf64>, tensor<3xf64>, tensor<i32>)
+    return %0#0, %0#1, %0#2 : tensor<3x3xf64>, tensor<3xf64>, tensor<i32>
+  }
+}
+"""
+    s_ = np.array([[4.0, 99.0, 99.0], [1.0, 3.0, 99.0], [-2.0, 0.5, 5.0]])          # uplo = L: the upper triangle is not read
+    out = np.asarray(dsl_numpy.trace_eval(lambda xp, m: dsl.Vec([v for r in sh.trace(eigh_text, [m]) for v in r.a.reshape(-1)]), s_.reshape(-1)))
+    vecs, vals = out[:9].reshape(3, 3), out[9:12]
+    full = np.tril(s_) + np.tril(s_, -1).T
+    assert np.allclose(vals, np.linalg.eigvalsh(full), atol=1e-12) and np.all(np.diff(vals) > 0) and out[12] == 0.0
+    assert np.allclose(full @ vecs, vecs * vals, atol=1e-12) and np.allclose(vecs.T @ vecs, np.eye(3), atol=1e-12)
