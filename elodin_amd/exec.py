@@ -55,7 +55,7 @@ class HipExec:
                  integrator: int = L.RK4, dtype=np.float64, effectors: Sequence[Effector] = (),
                  edges=None, ticks_per_launch: int = 1, use_graph: bool = False, device: int = 0,
                  tick: int = 0, column_entity_ids=None, columns=None, fast_math: bool = False, graph_edges=None,
-                 graph_replicas=None, guard_selects: Optional[bool] = None):
+                 graph_replicas=None, guard_selects: Optional[bool] = None, reuse_trace: bool = False):
         lib = L.lib()
         self._lib = lib
         self.dtype = np.dtype(dtype)
@@ -127,12 +127,19 @@ class HipExec:
                 else:
                     # executors built again and again from ONE program object (a campaign service: one per block of runs)
                     # trace it and generate its source once per column layout; the objects themselves are cached on disk
-                    memo = effectors.__dict__.setdefault("_exec_memo", {}) if hasattr(effectors, "__dict__") else {}
+                    # — OPT-IN (`reuse_trace=True`): the memo returns the FIRST trace, so the caller promises that neither the
+                    # program's systems nor any Python value its functions close over (gains, host tables, parameter
+                    # sentinels) changes between the executors.  Without the promise every executor traces again; the object
+                    # is still found in the on-disk cache by the digest of the generated source.
+                    memo = (effectors.__dict__.setdefault("_exec_memo", {}) if reuse_trace and hasattr(effectors, "__dict__") else None)
                     wkey = (tuple(sorted((k, v) for k, v in widths.items())),
-                            tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("SIXDOF_"))))
-                    custom = memo.get(("trace", wkey))
+                            tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("SIXDOF_"))),
+                            tuple(sorted((str(k), repr(v)) for k, v in getattr(_dsl, "PARAM_SENTINELS", {}).items())))
+                    custom = memo.get(("trace", wkey)) if memo is not None else None
                     if custom is None:
-                        custom = memo[("trace", wkey)] = effectors.trace(widths)
+                        custom = effectors.trace(widths)
+                        if memo is not None:
+                            memo[("trace", wkey)] = custom
                 if isinstance(effectors, _dsl.Program):
                     self._program_columns = [n for n, _ in custom.columns]
                     self._windows = {name: (rows, width) for name, (_, rows, width) in custom.windows.items()}
@@ -149,7 +156,7 @@ class HipExec:
                                                                   self.world_pos.shape[0] >= codegen.COLUMN_SOA_MIN_ROWS)))
                 if getattr(custom, "frozen_source", None) is not None:      # a frozen text was generated for ONE device layout
                     self._column_soa, self._window_soa = bool(custom.column_soa), False
-                memo = effectors.__dict__.get("_exec_memo") if hasattr(effectors, "__dict__") else None
+                memo = effectors.__dict__.get("_exec_memo") if reuse_trace and hasattr(effectors, "__dict__") else None
                 bkey = ("build", id(custom), self.dtype.name, integrator, bool(fast_math), self._window_soa, self._column_soa, guard_selects,
                         tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("SIXDOF_"))))
                 so = memo.get(bkey) if memo is not None else None

@@ -1174,7 +1174,8 @@ class AscentExec:
         self.hip = HipExec(body["world_pos"], body["world_vel"], body["inertia"], integrator=L.SEMI_IMPLICIT, dtype=dtype,
                            simulation_time_step=SIM_TIME_STEP, effectors=self.program, columns=cols,
                            ticks_per_launch=ticks_per_launch, device=device, fast_math=fast_math,
-                           guard_selects=True if fast_math else None)
+                           guard_selects=True if fast_math else None,
+                           reuse_trace=scripted is None)     # _PROGRAMS' objects are built here from fixed code: nothing a trace reads changes
 
     def run(self, ticks: int):
         return self.hip.run(ticks)

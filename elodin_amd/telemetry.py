@@ -167,6 +167,15 @@ class Sink:
             if rc != L.OK:
                 self._fail(rc, "sixdof_sink_commit_rows")
 
+    def _real_host_array(self, name: str):
+        """The array the executor uploads from for `name` (None: the column is assembled on read)."""
+        hip = self._ex._hip
+        if name in ("world_pos", "world_vel", "world_accel", "force", "inertia"):
+            return getattr(hip, name, None)
+        if name in getattr(hip, "_windows", {}) or name in getattr(self._ex, "_partial", {}):
+            return None
+        return hip._aux.get(name)
+
     def copy_to_world(self) -> bool:
         """copy_db_to_world: the latest sample of every pair overwrites its row of the executor's host columns; uploads when a
         byte changed.  Returns whether anything did."""
@@ -175,11 +184,25 @@ class Sink:
             if target is None:
                 continue
             host = self._ex._main_column_array(target)
-            if host.shape[0] != len(pids) or host.dtype != np.float64 or not host.flags.c_contiguous:
-                continue                         # joined / partial / f32 columns: not written back (callbacks cannot write them either)
+            real = self._real_host_array(target)
+            direct = (real is not None and host.shape[0] == len(pids) and host.dtype == np.float64 and host.flags.c_contiguous
+                      and np.shares_memory(host, real))
+            # what the executor hands out may be a COPY (stand-in rows filtered out by fancy indexing, a reshaped window, a
+            # densified partial column, an f32 column): the latest samples go into an f64 staging copy, and a change is
+            # scattered into the real host array where that is possible and REFUSED where it is not — never dropped
+            stage = host if direct else np.ascontiguousarray(np.asarray(host, dtype=np.float64).reshape(len(pids), -1))
             changed = C.c_int()
-            self._lib.sixdof_sink_copy_to_rows(self._s, pids.ctypes.data_as(C.POINTER(C.c_uint64)), host.ctypes.data, len(pids),
-                                               host.shape[1] * 8, C.byref(changed))
+            self._lib.sixdof_sink_copy_to_rows(self._s, pids.ctypes.data_as(C.POINTER(C.c_uint64)), stage.ctypes.data, len(pids),
+                                               stage.shape[1] * 8, C.byref(changed))
+            if changed.value and not direct:
+                rows = getattr(self._ex, "_body_rows", None)
+                if real is not None and rows is not None and real.dtype == np.float64 and real[rows].shape == stage.shape:
+                    real[rows] = stage                      # Body column of an executor with stand-in rows: scatter through the row map
+                else:
+                    raise NotImplementedError(
+                        f"a write to component {target!r} reached the telemetry sink, but its column cannot be written back to the "
+                        "executor (a window, a component on fewer entities than the row set, or a float32 column): same refusal as "
+                        "StepContext.write_component on the direct path")
             dirty = dirty or bool(changed.value)
         if dirty:
             self._ex._hip.upload()

@@ -113,6 +113,23 @@ class Campaign:
                 "parameter before the traced function): the campaign cannot share one program — build one executor per run")
         self.sources = sources[0]
         self._sentinel_worlds = worlds
+        # Two mid-range sentinels cannot see host CONTROL FLOW or truncation on a parameter (`if wind > 0:`, `int(p)`,
+        # `range(int(p))`, a table row picked by a parameter): both take the same path and generate the same text.  So the
+        # same comparison is repeated at both ends of every parameter's range and on real rows of the plan (each value nudged
+        # by a relative 1e-12-scale irrational so no literal of the script equals it): a script whose host code branches on a
+        # parameter generates different text somewhere along the way and is refused like host arithmetic is.
+        self._probe_values = self._probes(self.names, spec, self.table)
+        for values in self._probe_values:
+            w, system = built(values)
+            for eid in _entities(w):
+                w.insert(_api.EntityId(eid), [_api.C("mc:" + n, [values[n]]) for n in self.names])
+            with _sentinel_scope(values):
+                probe_src = w.generated_sources(system, simulation_rate=simulation_rate)
+            if probe_src != self.sources:
+                raise NotImplementedError(
+                    "this script's host code takes a different path for different values of a Monte-Carlo parameter (a Python `if`, "
+                    "`int()`, `round()`, `range()` or a table lookup on the parameter): the traced program differs between runs, so "
+                    f"the campaign cannot share one program — build one executor per run (probe values: {values})")
 
         # -- the world: every run's spawned entities, run-major ------------------------------------------------------------
         # A spawned value that is the same under both sentinel sets is a constant of the script; one that equals a sentinel
@@ -123,6 +140,17 @@ class Campaign:
         self.entity_names: List[Dict[str, int]] = []          # per run: the script's entity name -> entity id in the big world
         ents_a, ents_b = self._sentinel_worlds
         template = self._spawn_template(ents_a, ents_b, sentinels)
+        if template is not None:      # the same probes for the spawned values: a spawn that branches on a parameter needs build(params_i)
+            for values in self._probe_values:
+                w, _ = built(values)
+                ents = _entities(w)
+                if list(ents) != list(template) or any(
+                        set(ents[eid]) != set(comps) or any(not np.array_equal(np.asarray(ents[eid][c], dtype=np.float64),
+                                                            np.asarray(row if src is None else self._fill(row, src, values), dtype=np.float64))
+                                                            for c, (row, src) in comps.items())
+                        for eid, comps in template.items()):
+                    template = None
+                    break
         self.per_run_builds = template is None
         self.entities_per_run = len(ents_a[1])
         w0 = ents_a[0]
@@ -156,6 +184,35 @@ class Campaign:
                 self.exec = self.world.build(self._system, simulation_rate=simulation_rate, telemetry_rate=telemetry_rate,
                                              device=device, **kw)
         self.results: List[Dict[str, Any]] = [dict() for _ in range(self.n_runs)]
+
+    @staticmethod
+    def _probes(names, spec, table, max_rows: int = 6):
+        """Parameter value sets at which the program is traced again: both ends of every range (the spec's bounds, else the plan
+        table's extremes) and up to `max_rows` real plan rows spread over the plan, every value nudged to be distinctive."""
+        def nudge(v, k, salt):
+            eps = (1.0 + ((k + 1) * 0.6180339887498949 + salt) % 1.0) * 1e-12
+            return float(v) + (abs(float(v)) if v else 1.0) * eps
+        out = []
+        if not names:
+            return out
+        lo_hi = []
+        for k, name in enumerate(names):
+            p = spec.params.get(name) if spec is not None else None
+            col = table[:, k]
+            lo = float(p.min) if p is not None and p.min is not None else float(np.min(col))
+            hi = float(p.max) if p is not None and p.max is not None else float(np.max(col))
+            lo_hi.append((lo, hi))
+        if any(lo != hi for lo, hi in lo_hi):
+            out.append({n: nudge(lo, k, 0.31) for k, (n, (lo, _)) in enumerate(zip(names, lo_hi))})
+            out.append({n: nudge(hi, k, 0.73) - 2e-12 * (abs(hi) if hi else 1.0) * 2 for k, (n, (_, hi)) in enumerate(zip(names, lo_hi))})
+        rows = sorted(set(int(round(x)) for x in np.linspace(0, len(table) - 1, min(max_rows, len(table)))))
+        for j, i in enumerate(rows):
+            out.append({n: nudge(table[i, k], k, 0.11 * (j + 1)) for k, n in enumerate(names)})
+        good = []
+        for values in out:      # distinct values per set (the sentinel map is keyed on them)
+            if len(set(values.values())) == len(values):
+                good.append(values)
+        return good
 
     @staticmethod
     def _spawn_template(a, b, sentinels):

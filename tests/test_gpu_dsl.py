@@ -664,7 +664,8 @@ def test_fast_math_bits_do_not_depend_on_the_launch_shape_and_a_program_object_i
     runs = []
     for k in (1, 5, 12):
         hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=np.float32, integrator=L.INTEGRATOR_NONE, effectors=prog,
-                         columns={"x": x0, "y": np.zeros((n, 3)), "derived": np.zeros((n, 2))}, fast_math=True, ticks_per_launch=k)
+                         columns={"x": x0, "y": np.zeros((n, 3)), "derived": np.zeros((n, 2))}, fast_math=True, ticks_per_launch=k,
+                         reuse_trace=True)
         if k == 12:
             hip.enable_history(60)
         hip.run(60)

@@ -121,3 +121,52 @@ def test_spawned_worlds_come_from_the_plan_table_or_from_one_build_per_run():
     assert np.array_equal(direct.world.column("velocity")[0][:, 0], [r["wind"] for r in rows])
     assert np.array_equal(direct.world.column("mc:mass")[0][:, 0], [r["mass"] for r in rows])
     assert direct.entity_names[3] == {"vehicle": 4} and derived.entity_names[2] == {"vehicle": 5, "beacon": 6}
+
+
+def test_host_control_flow_on_a_parameter_is_refused_even_when_both_sentinels_take_the_same_branch():
+    """two mid-range sentinels take the same side of `if wind > 0:` / give the same `int(p)`, so comparing their two
+    traces proves nothing; the campaign also traces at both ends of every parameter's range and on real plan rows."""
+    import elodin_amd.frontend as el
+    ex = example(0)
+
+    def build_branch(params):
+        world, _ = ex.build(params)
+        wind = float(params.get("wind", 0.0))                     # PARAMS: wind in [-1, 1] — the sentinels sit on one side of 0.9
+
+        @el.map
+        def plant(pos: ex.Position, vel: ex.Velocity) -> ex.Position:
+            return pos + vel * (0.5 if wind > 0.9 else 0.25)      # a Python branch on a parameter: per-run code
+        return world, plant
+    rows = [{"mass": 1.5, "target_x": 30.0, "thrust_gain": 1.0, "wind": w} for w in (-0.5, 0.2, 0.95)]
+    with pytest.raises(NotImplementedError, match="different path"):
+        vectorize.Campaign(build_branch, vectorize.plan_of(rows), ex.PARAMS, dry=True)
+
+    def build_int(params):
+        world, _ = ex.build(params)
+        n = int(float(params.get("target_x", 30.0)) / 10.0)       # truncation on the host: 2 / 3 / 4 copies of a term
+
+        @el.map
+        def plant(pos: ex.Position, vel: ex.Velocity) -> ex.Position:
+            out = pos
+            for _ in range(n):
+                out = out + vel * 0.125
+            return out
+        return world, plant
+    rows = [{"mass": 1.5, "target_x": t, "thrust_gain": 1.0, "wind": 0.1} for t in (21.0, 30.0, 44.0)]
+    with pytest.raises(NotImplementedError, match="cannot share one program"):
+        vectorize.Campaign(build_int, vectorize.plan_of(rows), ex.PARAMS, dry=True)
+
+
+def test_a_spawn_that_branches_on_a_parameter_falls_back_to_one_build_per_run():
+    import elodin_amd.frontend as el
+    ex = example(0)
+
+    def build(params):
+        world, plant = ex.build(params)
+        side = 1.0 if float(params.get("wind", 0.0)) > 0.9 else -1.0        # constant under both sentinels, not over the plan
+        world.spawn([el.C(ex.Target, np.array([side]))], name="marker")
+        return world, plant
+    rows = [{"mass": 1.5, "target_x": 30.0, "thrust_gain": 1.0, "wind": w} for w in (-0.5, 0.2, 0.95)]
+    c = vectorize.Campaign(build, vectorize.plan_of(rows), ex.PARAMS, dry=True)
+    assert c.per_run_builds
+    assert np.array_equal(c.world.column("target")[0][1::2, 0], [-1.0, -1.0, 1.0])

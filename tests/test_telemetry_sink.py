@@ -110,3 +110,29 @@ def test_server_loop_commits_at_batch_end_and_brings_callback_writes_back(monkey
     assert sink.sample_count("vehicle.world_pos") == 6 and sink.latest("vehicle.world_pos")[1][4] == 4.0
     with pytest.raises(RuntimeError):
         sink.latest(f"{int(b)}.position")                                              # the unnamed entity has no pairs
+
+
+def test_copy_to_world_reaches_the_real_host_array_or_refuses():
+    """the column an executor hands out may be a fancy-indexed COPY (stand-in rows of plain entities filtered out of a
+    Body column) — a sample pushed into the sink must land in the array the executor uploads from, and a column that cannot be
+    written back (float32 here) must refuse instead of dropping the write."""
+    from elodin_amd import api
+    world = api.World()
+    world.spawn([api.C("gain", [1.0])], name="a")
+    world.spawn([api.C("gain", [2.0])], name="b")
+    real = np.zeros((3, 7))                                                       # row 1 is a stand-in the world does not know
+    real[:, 4] = [1.0, -1.0, 2.0]
+    gain32 = np.array([[1.0], [2.0]], dtype=np.float32)
+    ex = _FakeExec({"world_pos": real, "gain": gain32}, {"world_pos": np.array([1, 2], dtype=np.uint64), "gain": np.array([1, 2], dtype=np.uint64)})
+    ex._body_rows = np.array([0, 2])
+    ex._hip.world_pos = real
+    ex._main_column_array = lambda name: real[ex._body_rows] if name == "world_pos" else ex.cols[name]
+    ex.column_array = ex._main_column_array
+    sink = telemetry.Sink().attach(ex, world, 0)
+    assert sink.copy_to_world() is False and ex.uploads == 0                       # nothing newer than what was committed
+    sink.push("b.world_pos", np.array([0, 0, 0, 1, 7.5, 0, 0.0]), 10)
+    assert sink.copy_to_world() is True and ex.uploads == 1
+    assert real[2, 4] == 7.5 and real[1, 4] == -1.0 and real[0, 4] == 1.0        # scattered through the row map, stand-in untouched
+    sink.push("a.gain", np.array([5.0]), 20)
+    with pytest.raises(NotImplementedError, match="cannot be written back"):
+        sink.copy_to_world()
