@@ -34,13 +34,16 @@ _FN1 = {"sqrt": "m_sqrt", "abs": "m_abs", "sin": "m_sin", "cos": "m_cos", "tan":
         "floor": "m_floor", "ceil": "m_ceil", "trunc": "m_trunc", "rint": "m_rint", "sinh": "m_sinh", "cosh": "m_cosh",
         "erfc": "m_erfc", "isfinite": "m_isfinite", "erfinv": "m_erfinv"}
 _FN2 = {"max": "m_max", "min": "m_min", "atan2": "m_atan2", "hypot": "m_hypot", "pow": "m_pow", "mod": "m_mod",
-        "bxor": "m_bxor", "bor": "m_bor", "band": "m_band", "shl": "m_shl", "shr": "m_shr"}
+        "bxor": "m_bxor", "bor": "m_bor", "band": "m_band", "shl": "m_shl", "shr": "m_shr", "bits2f": "m_bits2f"}
+_FN1.update({"bits2f32": "m_bits2f32", "f32bits": "m_f32bits"})
 _BOOL_OPS = {"lt", "le", "eq", "and", "or", "not", "isfinite"}
 
 
 def _literal(v: float) -> str:
-    if v != v or v in (float("inf"), float("-inf")):
-        raise ValueError("non-finite constant in generated code")
+    if v != v:            # a StableHLO module may carry them: `dense<0x7FF8000000000000>` (jnp.linalg.solve's failure value), the
+        return "T(__builtin_nan(\"\"))"      # -inf init of a max reduction the front end could not fold away
+    if v in (float("inf"), float("-inf")):
+        return "T(__builtin_inf())" if v > 0 else "T(-__builtin_inf())"
     return f"T({v!r})"
 
 
@@ -189,6 +192,8 @@ class _Emitter:
                 return f"W{slot}[(size_t)(((static_cast<int>({a[0]}) + static_cast<int>({a[1]})) % {rows}) * {width} + {j}) * w_n]"
             if e.op == "threefry":
                 return f"m_threefry({a[0]}, {a[1]}, {a[2]}, {a[3]}, {int(e.value)})"
+            if e.op == "fbits":     # one 32-bit word of a double's bit pattern (stablehlo.bitcast_convert f64 -> ui64): 1 = high
+                return f"m_fbits({a[0]}, {int(e.value)})"
             if e.op == "lt":
                 return f"{a[0]} < {a[1]}"
             if e.op == "le":
@@ -1002,6 +1007,14 @@ template <class T> __device__ __forceinline__ T m_band(T a, T b) { return T(stat
 template <class T> __device__ __forceinline__ T m_shl(T a, T b) { return T(static_cast<long long>(a) << static_cast<int>(b)); }
 template <class T> __device__ __forceinline__ T m_shr(T a, T b) {      // logical: zero fill
     return T(static_cast<long long>(static_cast<unsigned long long>(static_cast<long long>(a)) >> static_cast<int>(b))); }
+// bit casts between integer words held as integral doubles and floating-point values (stablehlo.bitcast_convert): a ui64 is two
+// uint32 words (elodin_amd/stablehlo.py U64), so every bit pattern is exact; double programs only
+__device__ __forceinline__ double m_bits2f(double hi, double lo) {
+    return __hiloint2double(static_cast<int>(static_cast<uint32_t>(hi)), static_cast<int>(static_cast<uint32_t>(lo))); }
+__device__ __forceinline__ double m_fbits(double x, int high) {
+    return static_cast<double>(static_cast<uint32_t>(high ? __double2hiint(x) : __double2loint(x))); }
+__device__ __forceinline__ double m_bits2f32(double w) { return static_cast<double>(__uint_as_float(static_cast<uint32_t>(w))); }
+__device__ __forceinline__ double m_f32bits(double x) { return static_cast<double>(__float_as_uint(static_cast<float>(x))); }
 '''
 
 # fast_math programs draw their normal samples through the single-precision inverse error function of M. Giles, "Approximating
@@ -1132,7 +1145,7 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
                   "        if (t) q.accel_in_check = 0;\n"
                   + "\n".join(calls) + "\n    }\n")
     tables = _emit_tables()
-    if any(f"m_{k}(" in structs for k in ("bxor", "bor", "band", "shl", "shr")):      # only programs that use them carry this text
+    if any(f"m_{k}(" in structs for k in ("bxor", "bor", "band", "shl", "shr", "bits2f", "fbits", "bits2f32", "f32bits")):      # only programs that use them carry this text
         structs = _BITWISE + structs
     fast_erfinv = ""
     if fast_math and "m_erfinv(" in structs:      # only programs that draw normal samples carry (and are keyed on) this text

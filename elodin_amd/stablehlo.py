@@ -54,11 +54,17 @@ def parse_type(text: str) -> TensorType:
 
 
 class Sym:
-    """A tensor of scalar nodes: an object ndarray of dsl.Expr (booleans for i1) + its element type."""
+    """A tensor of scalar nodes: an object ndarray of dsl.Expr (booleans for i1; U64 word pairs for ui64) + its element type.
 
-    def __init__(self, arr, dtype: str):
-        self.a = arr if isinstance(arr, np.ndarray) and arr.dtype == object else _obj(arr)
+    In entity-parallel ("lane") evaluation a Sym also says how its STORED array relates to the tensor's true shape `tshape`:
+    along `eaxis` (the entity axis, true size N) and along every axis of `uni` (broadcast axes: all entries equal) the stored size
+    is 1."""
+
+    def __init__(self, arr, dtype: str, eaxis: Optional[int] = None, uni=frozenset(), tshape: Optional[Tuple[int, ...]] = None):
+        self.a = arr if isinstance(arr, np.ndarray) and arr.dtype == object else _obj(arr, dtype)
         self.dtype = dtype
+        self.eaxis, self.uni = eaxis, frozenset(uni)
+        self.tshape = tuple(tshape) if tshape is not None else tuple(self.a.shape)
 
     @property
     def shape(self): return self.a.shape
@@ -66,16 +72,19 @@ class Sym:
     def is_bool(self): return self.dtype == "i1"
 
 
-def _obj(values) -> np.ndarray:
+def _obj(values, dtype: str = "f64") -> np.ndarray:
     v = np.asarray(values, dtype=object) if not isinstance(values, np.ndarray) else values
+    if dtype == "ui64":
+        lift = lambda x: x if isinstance(x, U64) else (U64.from_float(x) if isinstance(x, Expr) else U64.from_int(int(x)))
+    else:
+        lift = lambda x: x if isinstance(x, Expr) else _dsl.const(float(x))
     out = np.empty(v.shape, dtype=object)
     for idx in np.ndindex(v.shape):
-        x = v[idx]
-        out[idx] = x if isinstance(x, Expr) else _dsl.const(float(x))
+        out[idx] = lift(v[idx])
     if v.shape == ():
         x = v[()] if isinstance(values, np.ndarray) else values
         out = np.empty((), dtype=object)
-        out[()] = x if isinstance(x, Expr) else _dsl.const(float(x))
+        out[()] = lift(x)
     return out
 
 
@@ -87,6 +96,258 @@ def _emap(f: Callable, *arrs) -> np.ndarray:
     if arrs[0].shape == ():
         out[()] = f(*[a[()] for a in arrs])
     return out
+
+
+# ---- integer semantics -----------------------------------------------------------------------------------------------------------
+# Integer tensors are integral values in float nodes (exact to 2^53 in a float64 program).  What the reference's lowering does
+# with them it does in machine integers, so: results of add / subtract / multiply / negate / shift_left / convert WRAP to the
+# declared width for every type of 32 bits or fewer (mod 2^bits, two's complement for signed types; a 32 x 32 product is formed
+# from 16-bit halves so no intermediate leaves the exact range); `ui64` elements are TWO uint32 words (U64 below) and every
+# operation on them is exact — jax.random builds its 52 random mantissa bits that way, (hi << 32 | lo) >> 12 | 0x3FF0..., then
+# bitcast_convert (libs/cranelift-mlir/tests/test_uniform_pipeline.rs); `i64` stays one node: exact while |value| < 2^53 (ticks,
+# counters, indices, seeds), no wrap at 2^63 — the one documented gap.
+
+_TWO32 = 4294967296.0
+_INV32 = 1.0 / _TWO32
+
+
+def _bits(dtype: str) -> int:
+    return int(re.sub(r"\D", "", dtype) or 64)
+
+
+_CONST_FN1 = {"neg": lambda x: -x, "floor": np.floor, "ceil": np.ceil, "trunc": np.trunc, "abs": abs, "rint": np.rint, "not": lambda x: not x,
+              "sqrt": lambda x: float(np.sqrt(x))}
+_CONST_FN2 = {"add": lambda a, b: a + b, "sub": lambda a, b: a - b, "mul": lambda a, b: a * b, "div": lambda a, b: a / b if b else None,
+              "max": max, "min": min, "lt": lambda a, b: a < b, "le": lambda a, b: a <= b, "eq": lambda a, b: a == b,
+              "and": lambda a, b: bool(a) and bool(b), "or": lambda a, b: bool(a) or bool(b),
+              "mod": lambda a, b: float(np.mod(a, b)) if b else None,
+              "bxor": lambda a, b: float(int(a) ^ int(b)), "bor": lambda a, b: float(int(a) | int(b)), "band": lambda a, b: float(int(a) & int(b)),
+              "shl": lambda a, b: float(int(a) << int(b)), "shr": lambda a, b: float((int(a) & 0xFFFFFFFFFFFFFFFF) >> int(b))}
+_const_memo: Dict[int, tuple] = {}      # id(Expr) -> (Expr kept alive, value | None)
+
+
+def _try_const(e):
+    """The Python value (float / bool) of a node that depends on no leaf, else None.  Iterative, memoised per node."""
+    if not isinstance(e, Expr):
+        return e if isinstance(e, (bool, int, float)) else None
+    hit = _const_memo.get(id(e))
+    if hit is not None:
+        return hit[1]
+    stack = [e]
+    while stack:
+        x = stack[-1]
+        if id(x) in _const_memo:
+            stack.pop()
+            continue
+        if x.op == "const":
+            _const_memo[id(x)] = (x, x.value)
+            stack.pop()
+            continue
+        if x.op not in _CONST_FN1 and x.op not in _CONST_FN2 and x.op != "select":
+            _const_memo[id(x)] = (x, None)
+            stack.pop()
+            continue
+        todo = [a for a in x.args if id(a) not in _const_memo]
+        if todo:
+            stack.extend(todo)
+            continue
+        vals = [_const_memo[id(a)][1] for a in x.args]
+        stack.pop()
+        if x.op == "select":
+            v = None if vals[0] is None else (vals[1] if vals[0] else vals[2])
+        elif any(v is None for v in vals):
+            v = None
+        else:
+            try:
+                v = _CONST_FN1[x.op](*vals) if x.op in _CONST_FN1 else _CONST_FN2[x.op](*vals)
+                v = bool(v) if isinstance(v, (bool, np.bool_)) else (None if v is None else float(v))
+            except (ValueError, OverflowError, ZeroDivisionError):
+                v = None
+        _const_memo[id(x)] = (x, v)
+    return _const_memo[id(e)][1]
+
+
+def _fold(e):
+    """A float node replaced by its constant when it has one (keeps unrolled loop counters and their index arithmetic out of the DAG)."""
+    if isinstance(e, Expr) and e.op != "const":
+        v = _try_const(e)
+        if v is not None and not isinstance(v, bool):
+            return _dsl.const(v)
+    return e
+
+
+def _floor_mod(x, m: float):
+    """x mod m for an integral x and a power of two m (exact: the reciprocal of m is exact, the product below |x|)."""
+    return _fold(x - _np.floor(x * (1.0 / m)) * m)
+
+
+def _wrap(x, dtype: str):
+    """An integral value folded into the range of an integer type of 32 bits or fewer (two's complement)."""
+    if dtype[0] not in "iu" or dtype == "i1":
+        return x
+    bits = _bits(dtype)
+    if bits >= 64:
+        return x
+    m = float(2 ** bits)
+    if dtype[0] == "u":
+        return _floor_mod(x, m)
+    return _fold(_floor_mod(x + m / 2, m) - m / 2)
+
+
+def _mul_lo32(a, b):
+    """Low 32 bits of the product of two values in [0, 2^32): 16-bit halves, every intermediate below 2^49."""
+    a1 = _np.floor(a * (1.0 / 65536.0))
+    a0 = a - a1 * 65536.0
+    t = _floor_mod(a1 * b, _TWO32)
+    return _floor_mod(t * 65536.0 + a0 * b, _TWO32)
+
+
+def _shl32(x, k, bits: int = 32):
+    """(x << k) mod 2^bits for x in [0, 2^bits), 0 <= k < bits: the bits that would leave the word are masked off FIRST, so the
+    shifted value never exceeds the exact range of the float carrier."""
+    kc = _try_const(k)
+    if kc is not None:
+        kc = int(kc)
+        return x if kc == 0 else _fold(_np.left_shift(_np.bitwise_and(x, float((1 << (bits - kc)) - 1)), float(kc)))
+    mask = _np.left_shift(1.0, float(bits) - k) - 1.0
+    return _np.left_shift(_np.bitwise_and(x, mask), k)
+
+
+def _where(c, a, b):
+    """Element select that folds a constant condition and reaches into ui64 elements."""
+    k = _try_const(c)
+    if k is not None:
+        return a if k else b
+    if isinstance(a, U64) or isinstance(b, U64):
+        a, b = U64.of(a), U64.of(b)
+        return U64(_np.where(c, a.hi, b.hi), _np.where(c, a.lo, b.lo))
+    if a is b:
+        return a
+    return _np.where(c, a, b)
+
+
+class NotEntityParallel(NotImplementedError):
+    """A whole-world module moves data between entities in a way one-lane-per-entity evaluation cannot follow."""
+
+
+class _KindsChanged(Exception):
+    pass
+
+
+class U64:
+    """One ui64 element: two uint32 words, each an integral float node."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo = _fold(_dsl._lift(hi)), _fold(_dsl._lift(lo))
+
+    @staticmethod
+    def of(v) -> "U64":
+        return v if isinstance(v, U64) else U64.from_float(v)
+
+    @staticmethod
+    def from_int(v: int) -> "U64":
+        v &= 0xFFFFFFFFFFFFFFFF
+        return U64(float(v >> 32), float(v & 0xFFFFFFFF))
+
+    @staticmethod
+    def from_float(x) -> "U64":
+        """An integral float (possibly negative: two's complement) as words."""
+        x = _dsl._lift(x)
+        k = _try_const(x)
+        if k is not None:
+            return U64.from_int(int(k))
+        hi = _np.floor(x * _INV32)
+        return U64(_floor_mod(hi, _TWO32), x - hi * _TWO32)
+
+    def to_float(self):
+        return _fold(self.hi * _TWO32 + self.lo)
+
+    # element-wise operations -------------------------------------------------------------------------------------------------
+    def bitwise(self, o: "U64", op) -> "U64": return U64(op(self.hi, o.hi), op(self.lo, o.lo))
+    def invert(self) -> "U64": return U64(4294967295.0 - self.hi, 4294967295.0 - self.lo)
+
+    def add(self, o: "U64") -> "U64":
+        lo = self.lo + o.lo
+        carry = _np.floor(lo * _INV32)
+        return U64(_floor_mod(self.hi + o.hi + carry, _TWO32), lo - carry * _TWO32)
+
+    def sub(self, o: "U64") -> "U64":
+        lo = self.lo - o.lo
+        borrow = _np.floor(lo * _INV32)                        # 0 or -1
+        return U64(_floor_mod(self.hi - o.hi + borrow, _TWO32), lo - borrow * _TWO32)
+
+    def mul(self, o: "U64") -> "U64":
+        a1, b1 = _np.floor(self.lo * (1.0 / 65536.0)), _np.floor(o.lo * (1.0 / 65536.0))
+        a0, b0 = self.lo - a1 * 65536.0, o.lo - b1 * 65536.0
+        p0, p1, p2 = a0 * b0, a1 * b0 + a0 * b1, a1 * b1           # < 2^32, < 2^33, < 2^32
+        p1h = _np.floor(p1 * (1.0 / 65536.0))
+        lo = p0 + (p1 - p1h * 65536.0) * 65536.0                    # < 2^33
+        carry = _np.floor(lo * _INV32)
+        hi = p2 + p1h + carry + _mul_lo32(self.hi, o.lo) + _mul_lo32(self.lo, o.hi)
+        return U64(_floor_mod(hi, _TWO32), lo - carry * _TWO32)
+
+    def shl(self, s) -> "U64":
+        k = _try_const(s)
+        if k is not None:
+            k = int(k)
+            if k >= 64:
+                return U64(0.0, 0.0)
+            if k == 0:
+                return self
+            if k >= 32:
+                return U64(_shl32(self.lo, float(k - 32)), 0.0)
+            return U64(_shl32(self.hi, float(k)) + _np.right_shift(self.lo, float(32 - k)),
+                       _shl32(self.lo, float(k)))
+        big = _dsl._lift(s) >= 32.0
+        sb, ss = _np.clip(s - 32.0, 0.0, 31.0), _np.clip(s, 0.0, 31.0)
+        hi_small = _shl32(self.hi, ss) + _np.where(_np.equal(ss, 0.0), 0.0, _np.right_shift(self.lo, 32.0 - ss))
+        out = U64(_np.where(big, _shl32(self.lo, sb), hi_small),
+                  _np.where(big, 0.0, _shl32(self.lo, ss)))
+        return _where(_dsl._lift(s) >= 64.0, U64(0.0, 0.0), out)
+
+    def shr(self, s) -> "U64":
+        k = _try_const(s)
+        if k is not None:
+            k = int(k)
+            if k >= 64:
+                return U64(0.0, 0.0)
+            if k == 0:
+                return self
+            if k >= 32:
+                return U64(0.0, _np.right_shift(self.hi, float(k - 32)))
+            return U64(_np.right_shift(self.hi, float(k)),
+                       _np.right_shift(self.lo, float(k)) + _shl32(self.hi, float(32 - k)))
+        big = _dsl._lift(s) >= 32.0
+        sb, ss = _np.clip(s - 32.0, 0.0, 31.0), _np.clip(s, 0.0, 31.0)
+        lo_small = _np.right_shift(self.lo, ss) + _np.where(_np.equal(ss, 0.0), 0.0, _shl32(self.hi, 32.0 - ss))
+        out = U64(_np.where(big, 0.0, _np.right_shift(self.hi, ss)), _np.where(big, _np.right_shift(self.hi, sb), lo_small))
+        return _where(_dsl._lift(s) >= 64.0, U64(0.0, 0.0), out)
+
+    def compare(self, o: "U64", d: str):
+        eq = _np.logical_and(_np.equal(self.hi, o.hi), _np.equal(self.lo, o.lo))
+        lt = _np.logical_or(self.hi < o.hi, _np.logical_and(_np.equal(self.hi, o.hi), self.lo < o.lo))
+        return {"EQ": eq, "NE": _np.logical_not(eq), "LT": lt, "LE": _np.logical_or(lt, eq),
+                "GT": _np.logical_not(_np.logical_or(lt, eq)), "GE": _np.logical_not(lt)}[d]
+
+
+def _u64_binary(short: str):
+    if short in ("and", "or", "xor"):
+        f = {"and": _np.bitwise_and, "or": _np.bitwise_or, "xor": _np.bitwise_xor}[short]
+        return lambda x, y: U64.of(x).bitwise(U64.of(y), f)
+    if short == "add":
+        return lambda x, y: U64.of(x).add(U64.of(y))
+    if short == "subtract":
+        return lambda x, y: U64.of(x).sub(U64.of(y))
+    if short == "multiply":
+        return lambda x, y: U64.of(x).mul(U64.of(y))
+    if short == "shift_left":
+        return lambda x, y: U64.of(x).shl(U64.of(y).lo if isinstance(y, U64) else y)      # amounts of 2^32 and beyond do not occur
+    if short == "shift_right_logical":
+        return lambda x, y: U64.of(x).shr(U64.of(y).lo if isinstance(y, U64) else y)
+    if short in ("maximum", "minimum"):
+        return lambda x, y: _where(U64.of(x).compare(U64.of(y), "LT" if short == "minimum" else "GT"), U64.of(x), U64.of(y))
+    raise NotImplementedError(f"stablehlo.{short} on ui64 tensors")
 
 
 # ---- parsing --------------------------------------------------------------------------------------------------------------------
@@ -260,7 +521,8 @@ def _trunc_div(a, b):                              # integer division: toward ze
 
 
 def _rem(a, b):                                    # stablehlo.remainder: the sign of the DIVIDEND (C's fmod / %)
-    return a - _np.trunc(a / b) * b
+    r = _np.remainder(_np.abs(a), _np.abs(b))      # both non-negative: the floor-mod node IS fmod (exact, whatever the ratio)
+    return _np.where(_dsl._lift(a) < 0.0, -r, r)
 
 
 class _Eval:
@@ -335,7 +597,7 @@ class _Eval:
         if short == "iota":
             dim = int(re.search(r"dim\s*=\s*(\d+)", text).group(1))
             idx = np.indices(rt.shape)[dim] if rt.shape else np.zeros(())
-            return [Sym(_obj(idx.astype(float)), rt.dtype)]
+            return [Sym(_obj(idx.astype(float), rt.dtype), rt.dtype)]
         args_text = text
         for r in (op.regions and [""] or []):
             pass
@@ -347,15 +609,27 @@ class _Eval:
             return [Sym(_emap(_CHLO[short], xs[0].a), rt.dtype)]
         if short in _UNARY:
             x = xs[0]
+            if x.dtype == "ui64":
+                if short != "negate":
+                    raise NotImplementedError(f"stablehlo.{short} on ui64 tensors")
+                return [Sym(_emap(lambda v: U64(0.0, 0.0).sub(v), x.a), x.dtype)]
             if short == "abs" and x.is_int():
                 return [Sym(_emap(_np.abs, x.a), x.dtype)]
+            if short == "negate" and x.is_int():
+                return [Sym(_emap(lambda v: _wrap(-v, x.dtype), x.a), x.dtype)]
             return [Sym(_emap(_UNARY[short], x.a), x.dtype)]
         if short == "not":
             x = xs[0]
             if x.is_bool():
                 return [Sym(_emap(_np.logical_not, x.a), "i1")]
-            bits = int(re.sub(r"\D", "", x.dtype) or 64)
+            if x.dtype == "ui64":
+                return [Sym(_emap(lambda v: v.invert(), x.a), x.dtype)]
+            bits = _bits(x.dtype)
             return [Sym(_emap(lambda v: (2.0 ** bits - 1.0) - v if x.dtype[0] == "u" else -v - 1.0, x.a), x.dtype)]
+        if short == "bitcast_convert":
+            return [self._bitcast(xs[0], rt)]
+        if short in ("popcnt", "count_leading_zeros"):
+            raise NotImplementedError(f"StableHLO op {name} is not provided by elodin_amd.stablehlo")
         if short == "is_finite":
             return [Sym(_emap(lambda v: Expr("isfinite", (_dsl._lift(v),)), xs[0].a), "i1")]
         if short in ("add", "subtract", "multiply", "divide", "maximum", "minimum", "power", "atan2", "remainder", "and", "or", "xor",
@@ -364,13 +638,17 @@ class _Eval:
             return [Sym(_emap(self._binary(short, a), a.a, b.a), a.dtype)]
         if short == "compare":
             d = re.search(r"\b(EQ|NE|LT|LE|GT|GE)\b", text).group(1)
+            if xs[0].dtype == "ui64":
+                return [Sym(_emap(lambda x, y: U64.of(x).compare(U64.of(y), d), xs[0].a, xs[1].a), "i1")]
             return [Sym(_emap(_CMP[d], xs[0].a, xs[1].a), "i1")]
         if short == "select":
             c, a, b = xs
-            return [Sym(_emap(lambda cc, x, y: _np.where(cc, x, y), np.broadcast_to(c.a, a.a.shape), a.a, b.a), a.dtype)]
+            return [Sym(_emap(_where, c.a, a.a, b.a), a.dtype)]
         if short == "clamp":
             lo, x, hi = xs
-            return [Sym(_emap(lambda l, v, h: _np.minimum(_np.maximum(v, l), h), np.broadcast_to(lo.a, x.a.shape), x.a, np.broadcast_to(hi.a, x.a.shape)), x.dtype)]
+            if x.dtype == "ui64":
+                raise NotImplementedError("stablehlo.clamp on ui64 tensors")
+            return [Sym(_emap(lambda l, v, h: _np.minimum(_np.maximum(v, l), h), lo.a, x.a, hi.a), x.dtype)]
         if short == "convert":
             return [self._convert(xs[0], rt.dtype)]
         if short == "broadcast_in_dim":
@@ -469,6 +747,33 @@ class _Eval:
         return text[:cut]
 
     def _binary(self, short, a: Sym):
+        """The element function of a binary op on tensors of `a`'s type, integer results wrapped to the type's width."""
+        if a.dtype == "ui64":
+            return _u64_binary(short)
+        f = self._binary_raw(short, a)
+        if not a.is_int() or _bits(a.dtype) >= 64:
+            return f
+        dt, bits = a.dtype, _bits(a.dtype)
+        uns = "ui" + str(bits)
+        if short in ("add", "subtract"):
+            return lambda x, y: _wrap(f(x, y), dt)
+        if short == "multiply":
+            if bits < 32:
+                return lambda x, y: _wrap(f(x, y), dt)
+            def mul(x, y):
+                for p, q in ((x, y), (y, x)):
+                    k = _try_const(p)
+                    if k is not None and abs(k) < 1048576.0:              # a small constant factor: the product stays exact
+                        return _wrap(f(x, y), dt)
+                return _wrap(_mul_lo32(_wrap(x, uns), _wrap(y, uns)), dt)
+            return mul
+        if short == "shift_left":
+            return lambda x, y: _where(_dsl._lift(y) >= float(bits), _dsl.const(0.0), _wrap(_shl32(_wrap(x, uns), _np.clip(y, 0.0, float(bits - 1)), bits), dt))
+        if short == "shift_right_logical":
+            return lambda x, y: _where(_dsl._lift(y) >= float(bits), _dsl.const(0.0), _wrap(_np.right_shift(_wrap(x, uns), _np.clip(y, 0.0, float(bits - 1))), dt))
+        return f
+
+    def _binary_raw(self, short, a: Sym):
         if short == "add":
             return lambda x, y: x + y
         if short == "subtract":
@@ -477,10 +782,12 @@ class _Eval:
             return (lambda x, y: _np.logical_and(x, y)) if a.is_bool() else (lambda x, y: x * y)
         if short == "divide":
             return _trunc_div if a.is_int() else (lambda x, y: x / y)
-        if short == "maximum":
-            return (lambda x, y: _np.logical_or(x, y)) if a.is_bool() else _np.maximum
+        if short == "maximum":      # max(-inf, x) = x: the init of jnp.max / argmax / a padded max reduce_window never reaches the kernel
+            return (lambda x, y: _np.logical_or(x, y)) if a.is_bool() else (
+                lambda x, y: y if _try_const(x) == float("-inf") else (x if _try_const(y) == float("-inf") else _np.maximum(x, y)))
         if short == "minimum":
-            return (lambda x, y: _np.logical_and(x, y)) if a.is_bool() else _np.minimum
+            return (lambda x, y: _np.logical_and(x, y)) if a.is_bool() else (
+                lambda x, y: y if _try_const(x) == float("inf") else (x if _try_const(y) == float("inf") else _np.minimum(x, y)))
         if short == "power":
             return _np.power
         if short == "atan2":
@@ -502,33 +809,106 @@ class _Eval:
             return lambda x, y: _np.floor(x / _np.power(2.0, _np.minimum(y, bits - 1.0)))
         raise NotImplementedError(short)
 
+    _NP_OF = {"f64": np.float64, "f32": np.float32, "f16": np.float16, "i64": np.int64, "i32": np.int32, "i16": np.int16, "i8": np.int8,
+              "ui64": np.uint64, "ui32": np.uint32, "ui16": np.uint16, "ui8": np.uint8, "i1": np.uint8}
+
     @staticmethod
-    def _constant(text: str, rt: TensorType) -> Sym:
+    def _hex_float(word: str, dtype: str) -> float:
+        """A bare hex literal of a FLOAT type is the value's bit pattern (MLIR prints inf, nan and some finite values that way; the
+        reference decodes it with f64::from_bits, libs/cranelift-mlir/src/parser.rs:740-744)."""
+        import struct
+        bits = int(word, 16)
+        if dtype == "f64":
+            return struct.unpack("<d", struct.pack("<Q", bits & 0xFFFFFFFFFFFFFFFF))[0]
+        if dtype == "f32":
+            return float(struct.unpack("<f", struct.pack("<I", bits & 0xFFFFFFFF))[0])
+        if dtype == "f16":
+            return float(np.array([bits & 0xFFFF], dtype=np.uint16).view(np.float16)[0])
+        if dtype == "bf16":
+            return float(struct.unpack("<f", struct.pack("<I", (bits & 0xFFFF) << 16))[0])
+        raise NotImplementedError(f"hex literal of element type {dtype}")
+
+    @classmethod
+    def _constant(cls, text: str, rt: TensorType) -> Sym:
         m = re.search(r"dense<(.*)>\s*:", text, re.S)
         body = m.group(1).strip()
-        if body.startswith('"0x'):
-            raise NotImplementedError("hex-encoded dense constants")
-        body = body.replace("true", "1").replace("false", "0")
-        vals = [float(int(v, 16)) if v.lower().startswith(("0x", "-0x")) else float(v) for v in re.findall(r"-?(?:0x[0-9a-fA-F]+|[\d.]+(?:[eE][-+]?\d+)?|inf|nan)", body)]
-        arr = np.full(rt.shape, vals[0]) if len(vals) == 1 else np.array(vals, dtype=np.float64).reshape(rt.shape)
+        is_float = rt.dtype[0] in "fb"
+        if body.startswith('"0x'):                 # the raw little-endian bytes of the whole tensor (how large constants are printed)
+            raw = bytes.fromhex(body.strip('"')[2:])
+            if rt.dtype == "bf16":
+                vals = [cls._hex_float(raw[k + 1:k + 2].hex() + raw[k:k + 1].hex(), "bf16") for k in range(0, len(raw), 2)]
+            else:
+                vals = np.frombuffer(raw, dtype=np.dtype(cls._NP_OF[rt.dtype]).newbyteorder("<")).tolist()
+            if len(vals) == 1 and rt.size > 1:
+                vals = vals * rt.size
+        else:
+            body = body.replace("true", "1").replace("false", "0")
+            words = re.findall(r"-?(?:0x[0-9a-fA-F]+|[\d.]+(?:[eE][-+]?\d+)?|inf|nan)", body)
+            vals = []
+            for w in words:
+                if w.lower().startswith(("0x", "-0x")):
+                    vals.append(cls._hex_float(w, rt.dtype) if is_float else int(w, 16))
+                elif is_float or any(c in w for c in ".eEn"):
+                    vals.append(float(w))
+                else:
+                    vals.append(int(w))                      # integer literals stay Python ints: ui64 keeps all 64 bits
+        if rt.dtype[0] in "iu" and rt.dtype not in ("i1", "ui64"):
+            bits = _bits(rt.dtype)
+            fold = (lambda v: v % (1 << bits)) if rt.dtype[0] == "u" else (lambda v: (v + (1 << (bits - 1))) % (1 << bits) - (1 << (bits - 1)))
+            vals = [fold(int(v)) for v in vals]              # `dense<-1> : tensor<ui32>` is 0xFFFFFFFF
+        flat = np.empty(rt.size, dtype=object)
+        flat[:] = (list(vals) * rt.size) if len(vals) == 1 else list(vals)
+        arr = flat.reshape(rt.shape)
         if rt.dtype == "i1":
             out = np.empty(rt.shape, dtype=object)
-            for idx in np.ndindex(rt.shape):
-                out[idx] = _dsl.const(arr[idx]) > 0.5
-            if rt.shape == ():
-                out[()] = _dsl.const(float(arr)) > 0.5
+            for idx in (np.ndindex(rt.shape) if rt.shape else [()]):
+                out[idx] = _dsl.const(float(arr[idx])) > 0.5
             return Sym(out, "i1")
-        return Sym(_obj(arr), rt.dtype)
+        return Sym(_obj(arr, rt.dtype), rt.dtype)
 
     @staticmethod
     def _convert(x: Sym, to: str) -> Sym:
         if x.is_bool():
-            return x if to == "i1" else Sym(_emap(lambda c: _np.where(c, 1.0, 0.0), x.a), to)
+            if to == "i1":
+                return x
+            if to == "ui64":
+                return Sym(_emap(lambda c: U64(0.0, _np.where(c, 1.0, 0.0)), x.a), to)
+            return Sym(_emap(lambda c: _np.where(c, 1.0, 0.0), x.a), to)
+        if x.dtype == "ui64":
+            if to == "ui64":
+                return x
+            if to == "i1":
+                return Sym(_emap(lambda v: _np.logical_not(_np.logical_and(_np.equal(v.hi, 0.0), _np.equal(v.lo, 0.0))), x.a), "i1")
+            if to[0] in "iu" and _bits(to) <= 32:            # truncation keeps the low word
+                return Sym(_emap(lambda v: _wrap(v.lo, to), x.a), to)
+            return Sym(_emap(lambda v: v.to_float(), x.a), to)        # i64 / floats: hi * 2^32 + lo (rounded beyond 2^53)
         if to == "i1":
             return Sym(_emap(lambda v: _np.logical_not(_np.equal(v, 0.0)), x.a), "i1")
-        if to[0] in "iu" and not x.is_int():
-            return Sym(_emap(_np.trunc, x.a), to)
+        if to == "ui64":
+            src = x.a if x.is_int() else _emap(_np.trunc, x.a)
+            return Sym(_emap(U64.from_float, src), to)
+        if to[0] in "iu":
+            src = x.a if x.is_int() else _emap(_np.trunc, x.a)
+            return Sym(_emap(lambda v: _wrap(v, to), src), to)
         return Sym(x.a, to)
+
+    @staticmethod
+    def _bitcast(x: Sym, rt: TensorType) -> Sym:
+        """stablehlo.bitcast_convert between equal-width types (how jax.random turns mantissa bits into a float)."""
+        frm, to = x.dtype, rt.dtype
+        if frm == to:
+            return x
+        if frm == "ui64" and to == "f64":
+            return Sym(_emap(lambda v: Expr("bits2f", (v.hi, v.lo)), x.a), to)
+        if frm == "f64" and to == "ui64":
+            return Sym(_emap(lambda v: U64(Expr("fbits", (_dsl._lift(v),), 1), Expr("fbits", (_dsl._lift(v),), 0)), x.a), to)
+        if frm in ("ui32", "i32") and to == "f32":
+            return Sym(_emap(lambda v: Expr("bits2f32", (_wrap(v, "ui32"),)), x.a), to)
+        if frm == "f32" and to in ("ui32", "i32"):
+            return Sym(_emap(lambda v: _wrap(Expr("f32bits", (_dsl._lift(v),)), to), x.a), to)
+        if frm[0] in "iu" and to[0] in "iu" and _bits(frm) == _bits(to) and _bits(to) <= 32:      # a reinterpretation of sign
+            return Sym(_emap(lambda v: _wrap(v, to), x.a), to)
+        raise NotImplementedError(f"stablehlo.bitcast_convert {frm} -> {to}")
 
     def _dot_general(self, a: Sym, b: Sym, text: str, rt: TensorType) -> Sym:
         def pair(key):
@@ -603,29 +983,61 @@ class _Eval:
                 o[idx] = v
         return [Sym(o, x.dtype) for o, x in zip(outs, operands)]
 
+    UNROLL_MAX_TRIPS = 64          # a while whose trip count is known while tracing is unrolled up to this many iterations ...
+    UNROLL_MAX_NODES = 200_000     # ... as long as the unrolled body stays below this many new nodes
+
+    @staticmethod
+    def _flatten_elems(x: Sym) -> list:
+        """The float nodes that carry a tensor across a loop boundary: i1 as 0 / 1, ui64 as its two words."""
+        out = []
+        for v in x.a.reshape(-1):
+            if x.dtype == "i1":
+                out.append(_np.where(v, 1.0, 0.0))
+            elif isinstance(v, U64):
+                out += [v.hi, v.lo]
+            else:
+                out.append(v)
+        return out
+
     def _while(self, op: Op, text: str, env) -> List[Sym]:
         m = re.match(r"\s*\((.*?)\)\s*:", text, re.S)
         binds = [p.split("=") for p in _split_top(m.group(1))]
         names = [b[0].strip() for b in binds]
         inits = [env[b[1].strip()] for b in binds]
+
+        # -- static trip count: the reference's edge_fold is `lax.scan` over a source's out-edges, i.e. a while whose counter
+        #    starts at a constant and is compared with a constant (libs/cranelift-mlir/tests/test_while_dyn_slice.rs); unrolled,
+        #    its dynamic_slice / dynamic_update_slice by the counter are plain static slices
+        state, trips, start_nodes = list(inits), 0, Expr._count[0]
+        while trips <= self.UNROLL_MAX_TRIPS and Expr._count[0] - start_nodes <= self.UNROLL_MAX_NODES:
+            e = dict(env)
+            e.update(zip(names, state))
+            c = _try_const(self.block(op.regions[0], e)[0].a[()])
+            if c is None:
+                break                      # data-dependent condition: a real loop (from the ORIGINAL state: nothing unrolled is kept)
+            if not c:
+                return state
+            outs = self.block(op.regions[1], e)
+            state = [self._relabel(o, s_) for o, s_ in zip(outs, state)]
+            trips += 1
+
         shapes, dtypes = [x.shape for x in inits], [x.dtype for x in inits]
-        flat = [v for x in inits for v in x.a.reshape(-1)]
-        # i1 values cannot be carried as floats and back without a comparison: carry 0 / 1
-        flat = [(_np.where(v, 1.0, 0.0) if dt == "i1" else v) for x, dt in zip(inits, dtypes) for v in x.a.reshape(-1)]
+        kinds = [(x.eaxis, x.uni, x.tshape) for x in inits]
+        flat = [v for x in inits for v in self._flatten_elems(x)]
 
         def rebuild(vals):
             out, k = {}, 0
-            for nm, shp, dt in zip(names, shapes, dtypes):
+            for nm, shp, dt, (ea, un, ts) in zip(names, shapes, dtypes, kinds):
                 size = int(np.prod(shp)) if shp else 1
-                arr = np.empty(shp, dtype=object)
-                chunk = vals[k:k + size]
-                chunk = [(c > 0.5) for c in chunk] if dt == "i1" else chunk
-                if shp == ():
-                    arr[()] = chunk[0]
-                else:
-                    arr.reshape(-1)[:] = chunk
-                out[nm] = Sym(arr, dt)
-                k += size
+                arr = np.empty(size, dtype=object)
+                for j in range(size):
+                    if dt == "ui64":
+                        arr[j] = U64(vals[k], vals[k + 1])
+                        k += 2
+                    else:
+                        arr[j] = (vals[k] > 0.5) if dt == "i1" else vals[k]
+                        k += 1
+                out[nm] = Sym(arr.reshape(shp), dt, ea, un, ts)
             return out
 
         def cond(c):
@@ -637,46 +1049,86 @@ class _Eval:
             e = dict(env)
             e.update(rebuild(list(c.e) if isinstance(c, _dsl.Vec) else [c]))
             outs = self.block(op.regions[1], e)
-            vals = [(_np.where(v, 1.0, 0.0) if o.dtype == "i1" else v) for o in outs for v in o.a.reshape(-1)]
-            return _dsl.Vec(vals)
-        res = _dsl.lax.while_loop(cond, body, _dsl.Vec(flat))
+            for k, (o, shp) in enumerate(zip(outs, shapes)):
+                if o.shape != shp:
+                    raise NotEntityParallel(f"a value carried by stablehlo.while changes its stored shape {shp} -> {o.shape}")
+                if o.eaxis is not None and kinds[k][0] is None:
+                    kinds[k] = (o.eaxis, kinds[k][1] - {o.eaxis}, kinds[k][2])      # a broadcast init that the body makes per-entity
+                    raise _KindsChanged()
+                if not (kinds[k][1] <= o.uni | ({o.eaxis} if o.eaxis is not None else set())) and kinds[k][1] - o.uni:
+                    kinds[k] = (kinds[k][0], kinds[k][1] & o.uni, kinds[k][2])
+                    raise _KindsChanged()
+            return _dsl.Vec([v for o in outs for v in self._flatten_elems(o)])
+        for _ in range(4):
+            try:
+                res = _dsl.lax.while_loop(cond, body, _dsl.Vec(flat))
+                break
+            except _KindsChanged:
+                continue
+        else:
+            raise NotEntityParallel("the carried values of a stablehlo.while do not settle on an entity layout")
         final = rebuild(list(res.e))
         return [final[nm] for nm in names]
+
+    @staticmethod
+    def _relabel(o: Sym, like: Sym) -> Sym:
+        return o
 
     def _case(self, op: Op, index: Sym, env) -> List[Sym]:
         branches = [self.block(r, env) for r in op.regions]
         n = len(branches)
         idx = index.a[()]
+        if isinstance(idx, U64):
+            idx = idx.to_float()
+        k = _try_const(idx)
+        if k is not None:
+            k = int(k)
+            return branches[k if 0 <= k < n else n - 1]
         idx = _np.where(_np.logical_or(idx < 0.0, idx > float(n - 1)), float(n - 1), idx)      # out of range: the last branch
         outs = []
         for k in range(len(branches[0])):
-            pick = branches[n - 1][k].a
+            syms = [branches[j][k] for j in range(n)]
+            syms = self._agree(syms, "stablehlo.case")
+            pick = syms[n - 1].a
             for j in range(n - 2, -1, -1):
-                pick = _emap(lambda cur, alt, j=j: _np.where(_np.equal(idx, float(j)), alt, cur), pick, branches[j][k].a)
-            outs.append(Sym(pick, branches[0][k].dtype))
+                pick = _emap(lambda cur, alt, j=j: _where(_np.equal(idx, float(j)), alt, cur), pick, syms[j].a)
+            outs.append(Sym(pick, syms[0].dtype, syms[0].eaxis, syms[0].uni, syms[0].tshape))
         return outs
+
+    def _agree(self, syms: List[Sym], what: str) -> List[Sym]:
+        """Results of alternative regions brought to one entity layout."""
+        return syms
 
     @staticmethod
     def _pick(cands: List[np.ndarray], idx) -> np.ndarray:
         """cands[idx] element-wise for a traced (already clamped) idx."""
         if len(cands) == 1:
             return cands[0]
+        k = _try_const(idx)
+        if k is not None:
+            return cands[int(min(max(k, 0), len(cands) - 1))]
         out = cands[-1]
         for k in range(len(cands) - 2, -1, -1):
-            out = _emap(lambda cur, alt, k=k: _np.where(idx < (k + 0.5), alt, cur), out, cands[k])
+            out = _emap(lambda cur, alt, k=k: _where(idx < (k + 0.5), alt, cur), out, cands[k])
         return out
+
+    @staticmethod
+    def _index(s: Sym):
+        """A rank-0 index operand as one float node."""
+        v = s.a.reshape(-1)[0]
+        return v.to_float() if isinstance(v, U64) else v
 
     def _dynamic_slice(self, x: Sym, starts: List[Sym], sizes: List[int]) -> Sym:
         cur = x.a
         for d, (s, size) in enumerate(zip(starts, sizes)):
             hi = cur.shape[d] - size
-            idx = _np.clip(s.a[()], 0.0, float(hi))                     # StableHLO clamps the start so the slice fits
+            idx = _fold(_np.clip(self._index(s), 0.0, float(hi)))        # StableHLO clamps the start so the slice fits
             cands = [np.take(cur, range(k, k + size), axis=d) for k in range(hi + 1)]
             cur = self._pick(cands, idx)
         return Sym(cur, x.dtype)
 
     def _dynamic_update_slice(self, x: Sym, upd: Sym, starts: List[Sym]) -> Sym:
-        idxs = [_np.clip(s.a[()], 0.0, float(x.shape[d] - upd.shape[d])) for d, s in enumerate(starts)]
+        idxs = [_fold(_np.clip(self._index(s), 0.0, float(x.shape[d] - upd.shape[d]))) for d, s in enumerate(starts)]
         out = np.empty(x.shape, dtype=object)
         for pos in (np.ndindex(x.shape) if x.shape else [()]):
             val = x.a[pos]
@@ -689,7 +1141,7 @@ class _Eval:
                 for d, s_ in enumerate(start):
                     c = _np.equal(idxs[d], float(s_))
                     hit = c if hit is None else _np.logical_and(hit, c)
-                val = upd.a[off] if hit is None else _np.where(hit, upd.a[off], val)
+                val = upd.a[off] if hit is None else _where(hit, upd.a[off], val)
             out[pos] = val
         return Sym(out, x.dtype)
 
@@ -712,14 +1164,15 @@ class _Eval:
             else:
                 vec = [indices.a[tuple(sel)]]
             full = [None] * operand.a.ndim                           # per operand dim: a static int or a traced index
+            vec = [(v.to_float() if isinstance(v, U64) else v) for v in vec]
             for k, d in enumerate(start_map):
-                full[d] = _np.clip(vec[k], 0.0, float(operand.shape[d] - slice_sizes[d]))
+                full[d] = _fold(_np.clip(vec[k], 0.0, float(operand.shape[d] - slice_sizes[d])))
             for ob, ib in zip(op_batch, idx_batch):
                 pos_in_idx = [d for d in range(indices.a.ndim) if d != ivd]
                 full[ob] = bidx[pos_in_idx.index(ib)]
             for k, d in enumerate(kept_operand_dims):
                 off = pos[offset_dims[k]]
-                full[d] = off if full[d] is None else full[d] + float(off)
+                full[d] = off if full[d] is None else _fold(full[d] + float(off))
             for d in range(operand.a.ndim):
                 if full[d] is None:
                     full[d] = 0
@@ -1054,6 +1507,11 @@ def _obj_scalar(v) -> np.ndarray:
 
 # ---- the front-end entry points ----------------------------------------------------------------------------------------------
 
+def _column_values(o: Sym) -> list:
+    """A result tensor as the float values a component column holds: i1 as 0 / 1, ui64 as hi * 2^32 + lo (exact to 2^53)."""
+    return [(_np.where(e, 1.0, 0.0) if o.dtype == "i1" else (e.to_float() if isinstance(e, U64) else e)) for e in o.a.reshape(-1)]
+
+
 def trace(text: str, inputs: Sequence) -> List[Sym]:
     """Evaluate @main on symbolic inputs (one per argument: a Sym, a dsl.Vec / Expr, or nested lists of those / numbers)."""
     funcs = parse_module(text)
@@ -1075,6 +1533,8 @@ def trace(text: str, inputs: Sequence) -> List[Sym]:
             arr.reshape(-1)[:] = elems
         if ty.dtype == "i1":
             arr = _emap(lambda e: e > 0.5, arr)
+        elif ty.dtype == "ui64":
+            arr = _emap(U64.of, arr)
         args.append(Sym(arr, ty.dtype))
     return _Eval(funcs).call(main, args)
 
@@ -1098,8 +1558,7 @@ def system(text: str, inputs: Sequence[str], outputs: Sequence[str], name: str =
         outs = trace(text, syms)
         res = {}
         for cname, o in zip(outputs, outs):
-            vals = [(_np.where(e, 1.0, 0.0) if o.dtype == "i1" else e) for e in o.a.reshape(-1)]
-            res[cname] = _dsl.Vec(vals)
+            res[cname] = _dsl.Vec(_column_values(o))
         return res
     fn.__name__ = name
     import inspect

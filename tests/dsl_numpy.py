@@ -30,7 +30,9 @@ def _threefry(k0, k1, c0, c1):
 _F1 = {"sqrt": np.sqrt, "abs": np.abs, "sin": np.sin, "cos": np.cos, "tan": np.tan, "exp": np.exp, "log": np.log,
        "acos": np.arccos, "asin": np.arcsin, "neg": np.negative, "not": np.logical_not, "log1p": np.log1p, "expm1": np.expm1,
        "cbrt": np.cbrt, "floor": np.floor, "ceil": np.ceil, "trunc": np.trunc, "rint": np.rint, "sinh": np.sinh, "cosh": np.cosh,
-       "erfc": _erfc, "isfinite": np.isfinite, "erfinv": _erfinv}
+       "erfc": _erfc, "isfinite": np.isfinite, "erfinv": _erfinv,
+       "bits2f32": lambda w: np.asarray(w, dtype=np.float64).astype(np.uint32).view(np.float32).astype(np.float64),
+       "f32bits": lambda x: np.asarray(x, dtype=np.float64).astype(np.float32).view(np.uint32).astype(np.float64)}
 _F2 = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "max": np.fmax, "min": np.fmin,
        "atan2": np.arctan2, "hypot": np.hypot, "pow": np.power, "mod": np.mod, "lt": np.less, "le": np.less_equal, "eq": np.equal, "and": np.logical_and,
        "or": np.logical_or,
@@ -38,7 +40,9 @@ _F2 = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, 
        "bor": lambda a, b: (a.astype(np.int64) | b.astype(np.int64)).astype(np.float64),
        "band": lambda a, b: (a.astype(np.int64) & b.astype(np.int64)).astype(np.float64),
        "shl": lambda a, b: (a.astype(np.int64) << b.astype(np.int64)).astype(np.float64),
-       "shr": lambda a, b: (a.astype(np.int64).view(np.uint64) >> b.astype(np.uint64)).astype(np.float64)}
+       "shr": lambda a, b: (a.astype(np.int64).view(np.uint64) >> b.astype(np.uint64)).astype(np.float64),
+       "bits2f": lambda hi, lo: ((np.asarray(hi, dtype=np.float64).astype(np.uint64) << np.uint64(32))
+                                 | np.asarray(lo, dtype=np.float64).astype(np.uint64)).view(np.float64)}
 
 
 def evaluate(tp, xs, vs, inertia, columns):
@@ -142,6 +146,9 @@ def _eval(exprs, leaves, n):
             r = _dsl._GATHER_TABLES[key][i, col]
         elif e.op == "threefry":
             r = _threefry(*[np.broadcast_to(ev(a), (n,)) for a in e.args])[e.value]
+        elif e.op == "fbits":
+            words = np.ascontiguousarray(np.broadcast_to(ev(e.args[0]), (n,)), dtype=np.float64).view(np.uint64)
+            r = ((words >> np.uint64(32)) if e.value else (words & np.uint64(0xFFFFFFFF))).astype(np.float64)
         elif e.op == "wload":
             slot, rows, width, j, _ = e.value
             head = np.broadcast_to(ev(e.args[0]), (n,)).astype(int)

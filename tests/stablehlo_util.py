@@ -10,9 +10,14 @@ from elodin_amd import stablehlo as sh
 
 DOC = json.loads((Path(__file__).parent / "golden" / "stablehlo_ops.json").read_text())
 CASES = DOC["cases"]
+# the pieces of a dumped WORLD tick (libs/cranelift-mlir/tests/test_gather_3body.rs ... test_uniform_pipeline.rs): same layout, the
+# expected values as full lists (make_stablehlo_world_golden.py)
+WORLD_DOC = json.loads((Path(__file__).parent / "golden" / "stablehlo_world_fragments.json").read_text())
+WORLD_CASES = [dict(c, expected={k: {"type": e["type"], "values": {str(j): v for j, v in enumerate(e["values"])}} for k, e in c["expected"].items()})
+               for c in WORLD_DOC["cases"]]
 # ops elodin_amd.stablehlo refuses by name (its docstring lists them) and the one case beyond f64's integers
 UNSUPPORTED = {}          # (round 4, late: dgetrf / dgesv / dgesdd, scatter, real_dynamic_slice, reduce_window, select_and_scatter were the last)
-BEYOND_F64_INTEGERS = {"test_ui64_large_constant"}          # 2^64 - 1 is not an integral double
+BEYOND_F64_INTEGERS = set()          # round 5: ui64 elements are two uint32 words (stablehlo.U64) — 1 + (2^64 - 1) wraps to 0 exactly
 
 
 def build(case, prefix=""):

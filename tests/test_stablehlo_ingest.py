@@ -39,6 +39,19 @@ def test_reference_op_test_known_answers_on_the_cpu_walker(case):
         assert np.array_equal(comps[nm][0], comps[nm][1], equal_nan=True)
 
 
+@pytest.mark.parametrize("case", U.WORLD_CASES, ids=[c["name"] for c in U.WORLD_CASES])
+def test_reference_world_fragment_known_answers_on_the_cpu_walker(case):
+    """The entity-batched pieces of a dumped world tick and jax.random's integer pipeline (u32 wrap-around, ui64 as two words,
+    bitcast to f64), libs/cranelift-mlir/tests/test_{gather_3body,dynamic_ops_3body,while_dyn_slice,closed_call,threefry,
+    threefry_e2e,uniform_pipeline}.rs.  Integer results are compared EXACTLY."""
+    system, values, expect = U.build(case)
+    comps = walk(system, values, expect)
+    for nm, (w, exp) in expect.items():
+        integer = case["expected"].get(nm[len("out"):], {"type": "f64"})["type"] != "f64"
+        U.check(case["name"], comps[nm][0], w, exp, 0.0 if integer else max(case["tol"], 1e-15))
+        assert np.array_equal(comps[nm][0], comps[nm][1], equal_nan=True)
+
+
 def test_the_fixture_covers_the_front_ends_op_set():
     import re
     ops = set()
