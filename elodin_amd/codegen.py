@@ -334,7 +334,7 @@ class _Emitter:
         # nodes the outputs need are emitted in the order the user's program created them (`Expr.seq`; arguments always
         # precede their users), which is the order a person would have written the code in: the same step then peaks at a
         # few matrices' worth of registers.  (Nodes inside loop bodies keep their own scopes and are emitted with their loop.)
-        need, stack = {}, ([e for _, e in assign] if (_EMIT_ORDER[0] == "program" or _GUARD_SELECTS[0] or _FUSE_FMA[0]) else [])
+        need, stack = {}, ([e for _, e in assign] if (_EMIT_ORDER[0] in ("program", "pressure") or _GUARD_SELECTS[0] or _FUSE_FMA[0]) else [])
         while stack:
             x = stack.pop()
             if id(x) in need or x.op in ("const", "leaf"):
@@ -363,7 +363,11 @@ class _Emitter:
                             fused[id(n_)] = k
                             folded.add(id(m))
                             break
-        for x in (sorted(need.values(), key=lambda n_: n_.seq) if _EMIT_ORDER[0] == "program" else ()):
+        if _EMIT_ORDER[0] == "pressure":
+            ordered = _pressure_order(need, [e for _, e in assign])
+        else:
+            ordered = sorted(need.values(), key=lambda n_: n_.seq) if _EMIT_ORDER[0] == "program" else ()
+        for x in ordered:
             if id(x) not in guarded and id(x) not in folded:
                 ref(x)
         outs = []
@@ -383,6 +387,66 @@ class _Emitter:
             if (scoped and k not in before) or (wr and dk & wr):
                 del self.names[k]
         return lines
+
+
+def _pressure_order(need: Dict[int, "dsl.Expr"], roots: Sequence["dsl.Expr"]) -> List["dsl.Expr"]:
+    """REGISTER-PRESSURE ORDER.  Greedy list scheduling of a block's nodes: among the nodes whose arguments exist, the one that
+    ends the most live ranges comes next (the last user of an argument frees its register); ties go to the node the DEMAND order
+    (depth-first from the outputs) would reach first, so nothing that ends no range is started before something needs it.
+    What it is for: a whole-world tick (elodin_amd/stablehlo.py, one lane = one world) is four RK4 stages whose stage vectors
+    are combined by left-associated sums written after the last stage.  In creation order every stage velocity is live from its
+    stage to the end (peak 200 live values for the three-body world, 225 spilled registers); on demand the velocity sum forms
+    stage by stage but all four stage accelerations wait for theirs (135 / 10 spills); here each partial sum is formed the moment
+    its operands exist (115)."""
+    def deps(x):
+        src = x.args[0].args if x.op == "while_out" else x.args
+        return [a for a in src if id(a) in need]
+    users: Dict[int, int] = {}
+    consumers: Dict[int, list] = {}
+    pending: Dict[int, int] = {}
+    for i, x in need.items():
+        d = {id(a) for a in deps(x)}
+        pending[i] = len(d)
+        for a in d:
+            users[a] = users.get(a, 0) + 1
+            consumers.setdefault(a, []).append(i)
+    for r in roots:
+        if id(r) in need:
+            users[id(r)] = users.get(id(r), 0) + 1                      # a block output stays live to the end
+    # demand positions (iterative depth-first post-order from the outputs)
+    pos, seen = {}, set()
+    for r in roots:
+        stack = [(r, 0)]
+        while stack:
+            n_, k = stack.pop()
+            if id(n_) in seen or id(n_) not in need:
+                continue
+            d = deps(n_)
+            if k < len(d):
+                stack.append((n_, k + 1))
+                stack.append((d[k], 0))
+            else:
+                seen.add(id(n_))
+                pos[id(n_)] = len(pos)
+    for i in need:
+        pos.setdefault(i, len(pos))
+
+    def score(i):
+        return sum(1 for a in {id(a) for a in deps(need[i])} if users[a] == 1)
+    ready = {i for i, p_ in pending.items() if p_ == 0}
+    order: List["dsl.Expr"] = []
+    while ready:
+        best = max(ready, key=lambda i: (score(i), -pos[i]))
+        ready.discard(best)
+        x = need[best]
+        order.append(x)
+        for a in {id(a) for a in deps(x)}:
+            users[a] -= 1
+        for c in consumers.get(best, ()):
+            pending[c] -= 1
+            if pending[c] == 0:
+                ready.add(c)
+    return order
 
 
 # Opt-in (codegen.generate_source(..., guard_selects=True) / SIXDOF_GUARD_SELECTS=1): see _Emitter.block, "GUARDED SELECT".
@@ -1350,6 +1414,10 @@ def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_
           column_soa: bool = False, guard_selects: Optional[bool] = None) -> Path:
     """Generate + compile (cached by content hash).  Returns the .so path.  A program that no flag set builds without VGPR
     spills is generated again with its columns memory-resident (_MEMORY_COLUMNS) before giving up."""
+    if getattr(tp, "prebuilt_so", None) is not None:        # dsl.FrozenProgram(prebuilt_so=...): the object exists (stablehlo CLI)
+        if not Path(tp.prebuilt_so).exists():
+            raise FileNotFoundError(tp.prebuilt_so)
+        return Path(tp.prebuilt_so)
     if getattr(tp, "frozen_source", None) is not None:      # dsl.FrozenProgram: the text exists, only the compiler is run
         return _compile(tp.frozen_source, "pipe")
     variants = VARIANTS if isinstance(tp, dsl.TracedProgram) else VARIANTS[:2]
@@ -1364,9 +1432,10 @@ def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_
 
 
 # What build() tries, in order, until a build has no VGPR spills: the tick body emitted in the user's program order; in demand
-# order (each value right before its first use); with the columns in a memory image instead of registers (_MEMORY_COLUMNS);
+# order (each value right before its first use); in register-pressure order (_pressure_order: the node that ends the most live
+# ranges next); with the columns in a memory image instead of registers (_MEMORY_COLUMNS);
 # with the tick body out of line (SIXDOF_TICK_OUT_OF_LINE).
-VARIANTS = ("program", "demand", "memory", "out_of_line")
+VARIANTS = ("program", "demand", "pressure", "memory", "out_of_line")
 last_variant = ["program"]      # the variant the last build() settled on (fixture generators record it)
 
 
@@ -1374,7 +1443,7 @@ def generate_variant(tp, variant: str, dtype: str = "float64", integrator: int =
                      column_soa: bool = False, guard_selects: Optional[bool] = None) -> str:
     if variant not in VARIANTS:
         raise ValueError(f"variant must be one of {VARIANTS}")
-    _EMIT_ORDER[0] = "demand" if variant == "demand" else "program"
+    _EMIT_ORDER[0] = variant if variant in ("demand", "pressure") else "program"
     _MEMORY_COLUMNS[0] = variant == "memory"
     _TICK_OUT_OF_LINE[0] = variant == "out_of_line"
     try:

@@ -2100,15 +2100,18 @@ class FrozenProgram(Program):
     imported where the reference checkout is: its kernel source is committed as a fixture and run where the GPU is
     (tests/golden/make_drone_program.py).  HipExec compiles and binds it like a program it traced itself."""
 
-    def __init__(self, source: str, columns: Sequence[Tuple[str, int]], mats: Optional[Dict[str, Tuple[int, int]]] = None,
-                 substeps: int = 1, column_soa: bool = False, windows: Optional[Dict[str, Tuple[int, int, int]]] = None):
+    def __init__(self, source: Optional[str], columns: Sequence[Tuple[str, int]], mats: Optional[Dict[str, Tuple[int, int]]] = None,
+                 substeps: int = 1, column_soa: bool = False, windows: Optional[Dict[str, Tuple[int, int, int]]] = None,
+                 prebuilt_so: Optional[str] = None):
         """column_soa: the text was generated with element-major program columns (codegen.generate_source(column_soa=True));
-        the executor lays the columns out the way the text expects, whatever its row count."""
+        the executor lays the columns out the way the text expects, whatever its row count.
+        prebuilt_so: the shared object itself already exists (`python -m elodin_amd.stablehlo ... -o pipe.so`): nothing is
+        generated or compiled, the executor installs it with sixdof_set_custom_pipe as a host without Python would."""
         super().__init__([], Pipe([]), [], substeps=substeps)
         import types
         table = types.SimpleNamespace(mats={k: tuple(v) for k, v in (mats or {}).items()}, windows={})
         # windows: name -> (slot, rows, width) of the wide components the text keeps in HBM as rings (entity-major layout)
-        self._traced = types.SimpleNamespace(frozen_source=source, columns=[(str(n), int(w)) for n, w in columns],
+        self._traced = types.SimpleNamespace(frozen_source=source, prebuilt_so=prebuilt_so, columns=[(str(n), int(w)) for n, w in columns],
                                              windows={str(k): tuple(int(x) for x in v) for k, v in (windows or {}).items()},
                                              table=table, fold_stages=[], pre=[], post=[], column_soa=bool(column_soa))
 

@@ -154,7 +154,7 @@ class HipExec:
                 self._column_soa = (isinstance(effectors, _dsl.Program) and not getattr(custom, "fold_stages", None)
                                     and not self._column_ids and (soa_env == "1" or (soa_env != "0" and
                                                                   self.world_pos.shape[0] >= codegen.COLUMN_SOA_MIN_ROWS)))
-                if getattr(custom, "frozen_source", None) is not None:      # a frozen text was generated for ONE device layout
+                if getattr(custom, "frozen_source", None) is not None or getattr(custom, "prebuilt_so", None) is not None:      # generated for ONE device layout
                     self._column_soa, self._window_soa = bool(custom.column_soa), False
                 memo = effectors.__dict__.get("_exec_memo") if reuse_trace and hasattr(effectors, "__dict__") else None
                 bkey = ("build", id(custom), self.dtype.name, integrator, bool(fast_math), self._window_soa, self._column_soa, guard_selects,

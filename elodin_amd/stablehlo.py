@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import itertools
 import re
+from pathlib import Path
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -528,6 +529,9 @@ def _rem(a, b):                                    # stablehlo.remainder: the si
 class _Eval:
     def __init__(self, funcs: Dict[str, Func]):
         self.funcs = funcs
+        self._rt_override: Optional[List[TensorType]] = None      # lane mode: the STORED result types of the next _op call
+        self._ints_override: Dict[str, List[int]] = {}            # lane mode: attribute lists with the entity axis at size 1
+        self._slice_override = None
 
     # -- plumbing --
     def call(self, fn: Func, args: Sequence[Sym]) -> List[Sym]:
@@ -575,8 +579,9 @@ class _Eval:
             sig = sig[1:-1]
         return [parse_type(t) for t in _split_top(sig) if t.startswith("tensor<")]
 
-    @staticmethod
-    def _ints(text: str, key: str) -> List[int]:
+    def _ints(self, text: str, key: str) -> List[int]:
+        if key in self._ints_override:
+            return list(self._ints_override[key])
         m = re.search(re.escape(key) + r"\s*=\s*(?:array<i64(?::\s*([^>]*))?>|\[([^\]]*)\])", text)
         if not m:
             return []
@@ -585,12 +590,17 @@ class _Eval:
 
     # -- ops --
     def op(self, op: Op, env) -> List[Sym]:
+        return self._op(op, env)
+
+    def _op(self, op: Op, env) -> List[Sym]:
         name, text = op.name, op.text
         short = name.split(".", 1)[1] if "." in name else name
         if name in ("call", "func.call"):
             m = re.match(r"\s*@([\w.$-]+)\((.*?)\)\s*:", text)
             return self.call(self.funcs[m.group(1)], [env[n] for n in re.findall(r"%[\w#.]+", m.group(2))])
         rts = self._result_types(text)
+        if self._rt_override is not None:
+            rts, self._rt_override = self._rt_override, None
         rt = rts[0] if rts else None
         if short == "constant":
             return [self._constant(text, rt)]
@@ -667,11 +677,7 @@ class _Eval:
             dims = self._ints(text, "dims") or self._ints(text, "dimensions")
             return [Sym(np.flip(xs[0].a, axis=tuple(dims)).copy(), xs[0].dtype)]
         if short == "slice":
-            m = re.search(r"\[([^\]]*)\]\s*:", text)
-            sl = []
-            for part in m.group(1).split(","):
-                p = [int(v) for v in part.strip().split(":")]
-                sl.append(slice(p[0], p[1], p[2] if len(p) > 2 else 1))
+            sl = [slice(*t) for t in (self._slice_override or self._slice_ranges(text))]
             return [Sym(xs[0].a[tuple(sl)].copy(), xs[0].dtype)]
         if short == "concatenate":
             dim = int(re.search(r"dim(?:ension)?\s*=\s*(\d+)", text).group(1))
@@ -728,6 +734,15 @@ class _Eval:
                 out[idx] = region(*[Sym(_obj_scalar(x.a[idx]), x.dtype) for x in xs])[0].a[()]
             return [Sym(out, rt.dtype)]
         raise NotImplementedError(f"StableHLO op {name} is not provided by elodin_amd.stablehlo")
+
+    @staticmethod
+    def _slice_ranges(text: str) -> List[Tuple[int, int, int]]:
+        m = re.search(r"\[([^\]]*)\]\s*:", text)
+        out = []
+        for part in m.group(1).split(","):
+            p = [int(v) for v in part.strip().split(":")]
+            out.append((p[0], p[1], p[2] if len(p) > 2 else 1))
+        return out
 
     @staticmethod
     def _operand_text(text: str) -> str:
@@ -1049,15 +1064,17 @@ class _Eval:
             e = dict(env)
             e.update(rebuild(list(c.e) if isinstance(c, _dsl.Vec) else [c]))
             outs = self.block(op.regions[1], e)
+            changed = False
             for k, (o, shp) in enumerate(zip(outs, shapes)):
                 if o.shape != shp:
                     raise NotEntityParallel(f"a value carried by stablehlo.while changes its stored shape {shp} -> {o.shape}")
-                if o.eaxis is not None and kinds[k][0] is None:
-                    kinds[k] = (o.eaxis, kinds[k][1] - {o.eaxis}, kinds[k][2])      # a broadcast init that the body makes per-entity
-                    raise _KindsChanged()
-                if not (kinds[k][1] <= o.uni | ({o.eaxis} if o.eaxis is not None else set())) and kinds[k][1] - o.uni:
-                    kinds[k] = (kinds[k][0], kinds[k][1] & o.uni, kinds[k][2])
-                    raise _KindsChanged()
+                ea, un, ts = kinds[k]
+                ea2 = ea if ea is not None else o.eaxis            # a broadcast init that the body makes per-entity
+                un2 = frozenset(d for d in (un & o.uni) if d != ea2)
+                if (ea2, un2) != (ea, un):
+                    kinds[k], changed = (ea2, un2, ts), True
+            if changed:
+                raise _KindsChanged()
             return _dsl.Vec([v for o in outs for v in self._flatten_elems(o)])
         for _ in range(4):
             try:
@@ -1495,6 +1512,378 @@ class _Eval:
         return Sym(np.array(elems, dtype=object), x.dtype)
 
 
+class _LaneEval(_Eval):
+    """ENTITY-PARALLEL evaluation of a whole-world module: the world's `[N, w]` columns arrive with their entity axis marked
+    (Sym.eaxis) and stored at size 1 — one lane's row — and every statement is carried out on that one row, which is exact as long
+    as the statement treats the entity axis as a pure batch axis (what `jax.vmap` over a query produces:
+    libs/nox-py/python/elodin/__init__.py:212-253).  Every rule below derives where the entity axis of a result lies from where it
+    lies in the operands, and REFUSES (NotEntityParallel) a statement that would move data between entities: a constant-index
+    gather over the entity axis (an edge_fold's targets), a slice / reduce / contraction / concatenation along it.  A world whose
+    tick is refused can still run with one lane per WHOLE world (world_system(mode="world"))."""
+
+    CAP = 1 << 16              # elements a lazily-broadcast (uniform) tensor may take when a statement needs it in full
+
+    def __init__(self, funcs, n_entities: int):
+        super().__init__(funcs)
+        self.N = int(n_entities)
+
+    # -- helpers --
+    @staticmethod
+    def _kind(x: Sym, d: int) -> str:
+        return "E" if x.eaxis == d else ("U" if d in x.uni else "F")
+
+    def _mat(self, x: Sym, axes=None) -> Sym:
+        """`x` with its lazily-broadcast axes (all of them, or those in `axes`) stored in full."""
+        axes = set(x.uni) if axes is None else (set(x.uni) & set(axes))
+        if not axes:
+            return x
+        shape = list(x.a.shape)
+        for d in axes:
+            shape[d] = x.tshape[d]
+        if int(np.prod(shape)) > self.CAP:
+            raise NotEntityParallel(f"a broadcast tensor {x.tshape} is consumed element by element along a broadcast axis")
+        return Sym(np.broadcast_to(x.a, shape).copy(), x.dtype, x.eaxis, frozenset(x.uni) - axes, x.tshape)
+
+    @staticmethod
+    def _stored(tshape, eaxis, uni) -> Tuple[int, ...]:
+        return tuple(1 if (d == eaxis or d in uni) else s for d, s in enumerate(tshape))
+
+    def _annot(self, out: Sym, tshape, eaxis, uni) -> Sym:
+        uni = frozenset(d for d in uni if tshape[d] > 1 and d != eaxis)
+        want = self._stored(tshape, eaxis, uni)
+        if tuple(out.a.shape) != want:
+            raise NotEntityParallel(f"internal: stored shape {out.a.shape} of a {tuple(tshape)} tensor (entity axis {eaxis}, broadcast axes {sorted(uni)})")
+        out.tshape, out.eaxis, out.uni = tuple(tshape), eaxis, uni
+        return out
+
+    def _join(self, xs: List[Sym], what: str, skip: Sequence[int] = ()):
+        """Per axis of equally ranked operands: the common layout.  -> (operands, eaxis, uni)"""
+        rank = len(xs[0].tshape)
+        eaxis, uni, xs = None, set(), list(xs)
+        for d in range(rank):
+            if d in skip:
+                continue
+            kinds = [self._kind(x, d) for x in xs]
+            if "E" in kinds:
+                for x, k in zip(xs, kinds):
+                    if k == "F" and x.tshape[d] > 1:
+                        raise NotEntityParallel(f"{what}: a per-entity tensor meets one that differs along the entity axis without being a column of the world")
+                eaxis = d
+            elif "U" in kinds and "F" in kinds:
+                if all(x.tshape[d] == 1 for x, k in zip(xs, kinds) if k == "F"):
+                    uni.add(d)                         # size-1 operands broadcast like anywhere else
+            elif "U" in kinds:
+                uni.add(d)
+        return xs, eaxis, uni
+
+    # -- the statement dispatcher --
+    _EW = {"add", "subtract", "multiply", "divide", "maximum", "minimum", "power", "atan2", "remainder", "and", "or", "xor", "shift_left",
+           "shift_right_logical", "shift_right_arithmetic", "compare", "select", "clamp", "convert", "bitcast_convert", "not", "is_finite"} | set(_UNARY)
+    _BATCHED_LEADING = {"cholesky", "triangular_solve", "custom_call"}
+
+    def op(self, op: Op, env) -> List[Sym]:
+        name, text = op.name, op.text
+        short = name.split(".", 1)[1] if "." in name else name
+        if name in ("call", "func.call") or short == "while":
+            return self._op(op, env)
+        rts = self._result_types(text)
+        if short == "constant":
+            return [self._lane_constant(text, rts[0])]
+        if short == "iota":
+            if rts[0].size > self.CAP:
+                raise NotEntityParallel(f"stablehlo.iota of {rts[0]}: an index over the entities")
+            return self._op(op, env)
+        xs = self._operands(self._operand_text(text), env)
+        if not any(x.eaxis is not None or x.uni for x in xs):
+            if rts and max(t.size for t in rts) > self.CAP and short not in ("broadcast_in_dim",):
+                raise NotEntityParallel(f"{name}: a {rts[0]} tensor that is not a column of the world")
+            if short != "broadcast_in_dim":
+                return self._op(op, env)
+        h = getattr(self, "_lane_" + short, None)
+        if name.startswith("chlo.") or short in self._EW:
+            h = self._lane_elementwise
+        if short in self._BATCHED_LEADING:
+            h = self._lane_batched_leading
+        if h is None:
+            raise NotEntityParallel(f"StableHLO op {name} on per-entity tensors is not provided by the entity-parallel front end")
+        outs = h(op, xs, rts, env)
+        return outs if isinstance(outs, list) else [outs]
+
+    def _lane_constant(self, text: str, rt: TensorType) -> Sym:
+        body = re.search(r"dense<(.*)>\s*:", text, re.S).group(1)
+        splat = "[" not in body and not body.strip().startswith('"0x')
+        lazy = {d for d, s_ in enumerate(rt.shape) if s_ == self.N and s_ > 1} if splat else set()
+        if not lazy:
+            if rt.size > self.CAP:
+                raise NotEntityParallel(f"a constant {rt}: per-entity data baked into the module")
+            return self._constant(text, rt)
+        out = self._constant(text, TensorType(self._stored(rt.shape, None, lazy), rt.dtype))
+        return self._annot(out, rt.shape, None, lazy)
+
+    def _lane_elementwise(self, op, xs, rts, env):
+        ranked = [x for x in xs if len(x.tshape) == len(rts[0].shape)] if rts[0].shape else []
+        eaxis, uni = None, set()
+        if ranked:
+            _, eaxis, uni = self._join(ranked, op.name)
+        outs = self._op(op, env)
+        return [self._annot(o, rt.shape, eaxis, uni) for o, rt in zip(outs, rts)]
+
+    def _lane_broadcast_in_dim(self, op, xs, rts, env):
+        x, rt = xs[0], rts[0]
+        dims = self._ints(op.text, "dims") or self._ints(op.text, "broadcast_dimensions")
+        src_of = {dst: src for src, dst in enumerate(dims)}
+        stored, eaxis, uni = [], None, set()
+        for r, size in enumerate(rt.shape):
+            k = src_of.get(r)
+            kd = self._kind(x, k) if k is not None else None
+            if kd == "E":
+                eaxis = r
+                stored.append(1)
+            elif kd == "U" or ((k is None or x.tshape[k] != size) and size == self.N and size > 1):
+                uni.add(r)                                  # a new (or stretched) axis as long as the entity axis stays a broadcast
+                stored.append(1)
+            else:
+                stored.append(size)
+        shape_in = [1] * len(rt.shape)
+        for src, dst in enumerate(dims):
+            shape_in[dst] = x.a.shape[src]
+        arr = np.broadcast_to(x.a.reshape(shape_in), stored).copy()
+        return self._annot(Sym(arr, x.dtype), rt.shape, eaxis, uni)
+
+    @staticmethod
+    def _reshape_groups(a: Sequence[int], b: Sequence[int]):
+        """Axis groups of a reshape a -> b: [(axes of a, axes of b)] with equal products (size-1 axes ride along)."""
+        groups, i, j = [], 0, 0
+        while i < len(a) or j < len(b):
+            gi, gj, pa, pb = [], [], 1, 1
+            if i < len(a):
+                gi.append(i); pa *= a[i]; i += 1
+            if j < len(b):
+                gj.append(j); pb *= b[j]; j += 1
+            while pa != pb:
+                if pa < pb and i < len(a):
+                    gi.append(i); pa *= a[i]; i += 1
+                elif j < len(b):
+                    gj.append(j); pb *= b[j]; j += 1
+                else:
+                    raise ValueError("reshape sizes do not match")
+            groups.append((gi, gj))
+        return groups
+
+    def _lane_reshape(self, op, xs, rts, env):
+        x, rt = xs[0], rts[0]
+        special = ({x.eaxis} if x.eaxis is not None else set()) | set(x.uni)
+        mapping = {}
+        for gi, gj in self._reshape_groups(x.tshape, rt.shape):
+            mine = [d for d in gi if d in special]
+            if not mine:
+                continue
+            big_i = [d for d in gi if x.tshape[d] > 1]
+            big_j = [d for d in gj if rt.shape[d] > 1]
+            if len(big_i) == 1 and len(big_j) == 1:
+                mapping[big_i[0]] = big_j[0]
+            else:
+                bad = [d for d in mine if d == x.eaxis]
+                if bad:
+                    raise NotEntityParallel("stablehlo.reshape merges the entity axis with another axis")
+                x = self._mat(x, mine)
+        eaxis = mapping.get(x.eaxis) if x.eaxis is not None else None
+        uni = {mapping[d] for d in x.uni if d in mapping}
+        arr = x.a.reshape(self._stored(rt.shape, eaxis, uni))
+        return self._annot(Sym(arr, x.dtype), rt.shape, eaxis, uni)
+
+    def _lane_transpose(self, op, xs, rts, env):
+        x = xs[0]
+        perm = self._ints(op.text, "dims") or self._ints(op.text, "permutation")
+        inv = {src: dst for dst, src in enumerate(perm)}
+        return self._annot(Sym(np.transpose(x.a, perm).copy(), x.dtype), rts[0].shape,
+                           inv.get(x.eaxis) if x.eaxis is not None else None, {inv[d] for d in x.uni})
+
+    def _lane_reverse(self, op, xs, rts, env):
+        x = xs[0]
+        dims = self._ints(op.text, "dims") or self._ints(op.text, "dimensions")
+        if x.eaxis in dims:
+            raise NotEntityParallel("stablehlo.reverse along the entity axis")
+        x = self._mat(x, dims)
+        return self._annot(Sym(np.flip(x.a, axis=tuple(dims)).copy(), x.dtype), rts[0].shape, x.eaxis, x.uni)
+
+    def _lane_slice(self, op, xs, rts, env):
+        x = xs[0]
+        ranges, sl, uni = self._slice_ranges(op.text), [], set()
+        for d, (lo, hi, st) in enumerate(ranges):
+            k = self._kind(x, d)
+            if k == "E":
+                if (lo, hi, st) != (0, x.tshape[d], 1):
+                    raise NotEntityParallel("stablehlo.slice takes some entities' rows out of a column")
+                sl.append(slice(0, 1))
+            elif k == "U":
+                sl.append(slice(0, 1))
+                uni.add(d)
+            else:
+                sl.append(slice(lo, hi, st))
+        return self._annot(Sym(x.a[tuple(sl)].copy(), x.dtype), rts[0].shape, x.eaxis, uni)
+
+    def _lane_concatenate(self, op, xs, rts, env):
+        dim = int(re.search(r"dim(?:ension)?\s*=\s*(\d+)", op.text).group(1))
+        if any(x.eaxis == dim for x in xs):
+            raise NotEntityParallel("stablehlo.concatenate along the entity axis (entity sets joined into one column)")
+        xs = [self._mat(x, [dim]) for x in xs]
+        xs, eaxis, uni = self._join(xs, "stablehlo.concatenate", skip=[dim])
+        full = [d for d in range(len(rts[0].shape)) if d != dim and d != eaxis and d not in uni]
+        xs = [self._mat(x, full) for x in xs]
+        return self._annot(Sym(np.concatenate([x.a for x in xs], axis=dim), xs[0].dtype), rts[0].shape, eaxis, uni)
+
+    def _lane_dot_general(self, op, xs, rts, env):
+        a, b = xs
+        def pair(key):
+            m = re.search(key + r"\s*=\s*\[([^\]]*)\]\s*x\s*\[([^\]]*)\]", op.text)
+            f = lambda s_: [int(v) for v in s_.replace(" ", "").split(",") if v]
+            return (f(m.group(1)), f(m.group(2))) if m else ([], [])
+        (ba, bb), (ca, cb) = pair("batching_dims"), pair("contracting_dims")
+        if a.eaxis in ca or b.eaxis in cb:
+            raise NotEntityParallel("stablehlo.dot_general contracts over the entity axis")
+        a, b = self._mat(a, ca), self._mat(b, cb)
+        kinds = []
+        for da, db in zip(ba, bb):
+            ka, kb = self._kind(a, da), self._kind(b, db)
+            if "E" in (ka, kb):
+                if "F" in (ka, kb) and max(a.tshape[da], b.tshape[db]) > 1:
+                    raise NotEntityParallel("stablehlo.dot_general batches a per-entity tensor against per-entity data that is not a column")
+                kinds.append("E")
+            elif ka == kb == "U":
+                kinds.append("U")
+            else:
+                a, b = self._mat(a, [da]), self._mat(b, [db])
+                kinds.append("F")
+        fa = [d for d in range(len(a.tshape)) if d not in ba + ca]
+        fb = [d for d in range(len(b.tshape)) if d not in bb + cb]
+        kinds += [self._kind(a, d) for d in fa] + [self._kind(b, d) for d in fb]
+        es = [r for r, k in enumerate(kinds) if k == "E"]
+        if len(es) > 1:
+            raise NotEntityParallel("stablehlo.dot_general forms an entity-by-entity product")
+        eaxis, uni = (es[0] if es else None), {r for r, k in enumerate(kinds) if k == "U"}
+        rt = rts[0]
+        out = self._dot_general(a, b, op.text, TensorType(self._stored(rt.shape, eaxis, uni), rt.dtype))
+        return self._annot(out, rt.shape, eaxis, uni)
+
+    def _lane_reduce(self, op, xs, rts, env):
+        dims = self._ints(op.text, "dimensions")
+        n = len(xs) // 2
+        if any(x.eaxis in dims for x in xs[:n]):
+            raise NotEntityParallel("stablehlo.reduce over the entity axis (a sum over the world)")
+        for k in range(n):
+            xs[k] = self._mat(xs[k], dims)
+        ranked, eaxis, uni = self._join(xs[:n], "stablehlo.reduce", skip=dims)
+        keep = [d for d in range(len(xs[0].tshape)) if d not in dims]
+        full = [d for d in keep if d != eaxis and d not in uni]
+        xs[:n] = [self._mat(x, full) for x in xs[:n]]
+        outs = self._reduce(op, xs, op.text, rts, env)
+        pos = {d: r for r, d in enumerate(keep)}
+        return [self._annot(o, rt.shape, pos.get(eaxis) if eaxis is not None else None, {pos[d] for d in uni}) for o, rt in zip(outs, rts)]
+
+    def _lane_dynamic_slice(self, op, xs, rts, env):
+        x, starts = xs[0], xs[1:]
+        sizes = self._ints(op.text, "sizes") or self._ints(op.text, "slice_sizes")
+        sizes2, uni = list(sizes), set()
+        for d in range(len(x.tshape)):
+            k = self._kind(x, d)
+            if k == "E":
+                if sizes[d] != x.tshape[d]:
+                    raise NotEntityParallel("stablehlo.dynamic_slice takes some entities' rows out of a column")
+                sizes2[d] = 1
+            elif k == "U":
+                sizes2[d] = 1
+                uni.add(d)
+        if any(s_.eaxis is not None for s_ in starts):
+            raise NotEntityParallel("stablehlo.dynamic_slice with a per-entity start index")
+        out = self._dynamic_slice(x, starts, sizes2)
+        return self._annot(out, rts[0].shape, x.eaxis, uni)
+
+    def _lane_dynamic_update_slice(self, op, xs, rts, env):
+        x, upd, starts = xs[0], xs[1], xs[2:]
+        eaxis, uni = None, set()
+        for d in range(len(x.tshape)):
+            kx, ku = self._kind(x, d), self._kind(upd, d)
+            if "E" in (kx, ku):
+                if upd.tshape[d] != x.tshape[d] or ("F" in (kx, ku) and x.tshape[d] > 1):
+                    raise NotEntityParallel("stablehlo.dynamic_update_slice writes some entities' rows of a column (a partial query's update_var)")
+                eaxis = d
+            elif kx == ku == "U" and upd.tshape[d] == x.tshape[d]:
+                uni.add(d)
+            else:
+                x, upd = self._mat(x, [d]), self._mat(upd, [d])
+        out = self._dynamic_update_slice(x, upd, starts)
+        return self._annot(out, rts[0].shape, eaxis, uni)
+
+    def _lane_gather(self, op, xs, rts, env):
+        operand, indices = xs
+        g = lambda key: _Eval._ints(self, op.text, key)
+        offset_dims, collapsed, start_map = g("offset_dims"), g("collapsed_slice_dims"), g("start_index_map")
+        op_batch, idx_batch = g("operand_batching_dims"), g("start_indices_batching_dims")
+        ivd = int(re.search(r"index_vector_dim\s*=\s*(\d+)", op.text).group(1))
+        slice_sizes = g("slice_sizes")
+        rt = rts[0]
+        batch_dims = [d for d in range(len(rt.shape)) if d not in offset_dims]
+        idx_dims = [d for d in range(len(indices.tshape)) if d != ivd]
+        kept = [d for d in range(len(operand.tshape)) if d not in collapsed and d not in op_batch]
+        indices = self._mat(indices)
+        operand = self._mat(operand)
+        eaxis = None
+        oe, ie = operand.eaxis, indices.eaxis
+        if ie is not None and ie == ivd:
+            raise NotEntityParallel("stablehlo.gather whose index vector runs over the entities")
+        if oe is not None:
+            if oe in op_batch:                                  # vmap of an indexed read: both sides batched over the entities
+                if ie is None or idx_batch[op_batch.index(oe)] != ie:
+                    raise NotEntityParallel("stablehlo.gather batches the entity axis of its operand against non-entity indices")
+                eaxis = batch_dims[idx_dims.index(ie)]
+            elif oe in kept and slice_sizes[oe] == operand.tshape[oe] and oe not in start_map and ie is None:
+                eaxis = offset_dims[kept.index(oe)]             # whole columns picked by a shared index: the entity axis rides along
+                slice_sizes = list(slice_sizes)
+                slice_sizes[oe] = 1
+            else:
+                raise NotEntityParallel("stablehlo.gather reads other entities' rows of a per-entity tensor (a join or an edge_fold's targets): "
+                                        "the tick exchanges data between entities")
+        elif ie is not None:                                     # a per-entity index into a table every entity shares
+            eaxis = batch_dims[idx_dims.index(ie)]
+        self._ints_override = {"slice_sizes": list(slice_sizes)}
+        try:
+            out = self._gather(operand, indices, op.text, TensorType(self._stored(rt.shape, eaxis, ()), rt.dtype))
+        finally:
+            self._ints_override = {}
+        return self._annot(out, rt.shape, eaxis, ())
+
+    def _lane_batched_leading(self, op, xs, rts, env):
+        """cholesky / triangular_solve / the LAPACK calls on `[N, ...]` operands: the entity axis is their leading batch axis."""
+        ranked = [x for x in xs if x.tshape]
+        if any(x.eaxis not in (0, None) for x in ranked) or not all(x.eaxis == 0 or x.tshape[0] != self.N for x in ranked):
+            raise NotEntityParallel(f"{op.name}: the entity axis is not the leading batch axis of every operand")
+        names = re.findall(r"%[\w#.]+", self._operand_text(op.text))
+        env2 = dict(env)
+        for nm, x in zip(names, xs):
+            x = self._mat(x)
+            env2[nm] = Sym(x.a.reshape(x.a.shape[1:]), x.dtype) if x.eaxis == 0 else x
+        self._rt_override = [TensorType(rt.shape[1:], rt.dtype) if (rt.shape and rt.shape[0] == self.N) else rt for rt in rts]
+        outs = self._op(op, env2)
+        res = []
+        for o, rt in zip(outs, rts):
+            if rt.shape and rt.shape[0] == self.N:
+                res.append(self._annot(Sym(o.a.reshape((1,) + o.a.shape), o.dtype), rt.shape, 0, ()))
+            else:
+                res.append(o)
+        return res
+
+    def _agree(self, syms: List[Sym], what: str) -> List[Sym]:
+        if not syms[0].tshape:
+            return syms
+        syms, eaxis, uni = self._join(syms, what)
+        full = [d for d in range(len(syms[0].tshape)) if d != eaxis and d not in uni]
+        syms = [self._mat(x, full) for x in syms]
+        for x in syms:
+            x.eaxis, x.uni = eaxis, frozenset(uni)
+        return syms
+
+
 def _scalar(v) -> np.ndarray:
     a = np.empty((), dtype=object)
     a[()] = v
@@ -1564,3 +1953,212 @@ def system(text: str, inputs: Sequence[str], outputs: Sequence[str], name: str =
     import inspect
     fn.__signature__ = inspect.Signature([inspect.Parameter(p, inspect.Parameter.KEYWORD_ONLY) for p in params])
     return _dsl.system(fn, every=every, **widths)
+
+
+# ---- whole-world ticks (what the reference hands a backend: libs/nox-py/src/cranelift_compile.rs:47-68) ----------------------------
+
+class Slot:
+    """One argument / result of a world tick's @main: ExecSlotMetadata (libs/nox-py/src/exec.rs:17-22) plus a readable name."""
+
+    def __init__(self, component, shape: Sequence[int], entity_axis_elided: bool, component_id: Optional[int] = None):
+        self.component, self.shape, self.elided = str(component), tuple(int(s) for s in shape), bool(entity_axis_elided)
+        self.component_id = component_id
+
+    @property
+    def column(self) -> str:
+        return "hlo_" + re.sub(r"\W", "_", self.component)
+
+    @staticmethod
+    def of(x) -> "Slot":
+        if isinstance(x, Slot):
+            return x
+        if isinstance(x, dict):
+            cid = x.get("component_id")
+            return Slot(x.get("component", x.get("name", f"c{cid}")), x.get("shape", []), x.get("entity_axis_elided", False), cid)
+        return Slot(*x)
+
+
+def slots_from_metadata(doc: dict):
+    """(argument slots, result slots) from a JSON document: either the reference's ExecMetadata as serde writes it —
+    {"arg_ids": [...], "ret_ids": [...], "arg_slots": [{"component_id", "shape", "entity_axis_elided"}]}, optionally with
+    "names": {"<id>": "world_pos"} — or the plain {"inputs": [{"component", "shape", "entity_axis_elided"}], "outputs": [...]}."""
+    if "arg_slots" in doc:
+        names = {int(k): v for k, v in doc.get("names", {}).items()}
+        args = [Slot(names.get(int(s_["component_id"]), f"c{s_['component_id']}"), s_["shape"], s_["entity_axis_elided"], int(s_["component_id"]))
+                for s_ in doc["arg_slots"]]
+        seen, uniq = set(), []
+        for a in args:                                    # CraneliftExec::new keeps the first slot of a repeated id (cranelift_exec.rs:66-72)
+            if a.component_id not in seen:
+                seen.add(a.component_id)
+                uniq.append(a)
+        by_id = {a.component_id: a for a in uniq}
+        rets = [by_id.get(int(i)) or Slot(names.get(int(i), f"c{i}"), [], False, int(i)) for i in doc.get("ret_ids", [])]
+        return uniq, rets
+    ins = [Slot.of(x) for x in doc["inputs"]]
+    outs = [Slot.of(x) for x in doc["outputs"]] if "outputs" in doc else list(ins)
+    return ins, outs
+
+
+def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = None, mode: str = "auto", name: str = "world_tick",
+                 every: int = 1):
+    """A whole-world StableHLO tick (entity-batched `[N, w]` arguments) as ONE system of the generated kernel.  -> (system, manifest)
+
+    slots / out_slots: per @main argument / result a Slot (or (component, shape, entity_axis_elided), or ExecSlotMetadata dicts);
+    results default to the arguments' slots in order.  mode:
+      "lane"  — one lane per ENTITY: the entity axis of every batched slot becomes the executor's row axis, singleton slots
+                (entity axis elided: Globals) are replicated per row; statements that move data between entities are refused;
+      "world" — one lane per WORLD: every slot is flattened into one row of a column, the executor's rows are independent worlds
+                (a Monte-Carlo of small worlds — edge folds, joins and everything else are just index arithmetic inside a lane);
+      "auto"  — "lane" when the tick is entity-parallel, else "world".
+    The manifest says which it became and lists the program's columns in binding order."""
+    funcs = parse_module(text)
+    main = funcs["main"]
+    ins = [Slot.of(x) for x in slots]
+    outs = [Slot.of(x) for x in out_slots] if out_slots is not None else list(ins)
+    if len(ins) != len(main.args) or len(outs) != len(main.result_types):
+        raise ValueError(f"@main has {len(main.args)} arguments / {len(main.result_types)} results; {len(ins)} / {len(outs)} slots given")
+    for s_, (_, ty) in zip(ins, main.args):
+        if tuple(s_.shape) != tuple(ty.shape):
+            raise ValueError(f"slot {s_.component}: shape {s_.shape} but @main takes {ty}")
+    for k, (s_, ty) in enumerate(zip(outs, main.result_types)):
+        if not s_.shape and ty.shape:
+            outs[k] = Slot(s_.component, ty.shape, False, s_.component_id)       # a result-only component: shape from the module
+        elif tuple(outs[k].shape) != tuple(ty.shape):
+            raise ValueError(f"result slot {s_.component}: shape {s_.shape} but @main returns {ty}")
+    counts = {s_.shape[0] for s_ in ins + outs if not s_.elided and s_.shape}
+    n_entities = counts.pop() if len(counts) == 1 else None
+
+    def build(lane: bool):
+        def width(s_: Slot) -> int:
+            shp = s_.shape[1:] if (lane and not s_.elided) else s_.shape
+            return int(np.prod(shp)) if shp else 1
+        widths = {}
+        for s_ in ins + outs:
+            if widths.setdefault(s_.column, width(s_)) != width(s_):
+                raise ValueError(f"component {s_.component} appears with two shapes")
+        too_wide = [c for c, w in widths.items() if w > _dsl._MAT_MAX_ELEMS]
+        if too_wide:
+            raise NotImplementedError(f"columns {too_wide} are wider than {_dsl._MAT_MAX_ELEMS} values: this world is too large for one lane per world")
+        params = list(dict.fromkeys([s_.column for s_ in ins] + [s_.column for s_ in outs]))
+
+        def fn(**cols):
+            args = []
+            for s_, (_, ty) in zip(ins, main.args):
+                v = cols[s_.column]
+                elems = list(v.e) if isinstance(v, _dsl.Vec) else [v]
+                batched = lane and not s_.elided
+                stored = ((1,) + tuple(ty.shape[1:])) if batched else tuple(ty.shape)
+                arr = np.empty(len(elems), dtype=object)
+                arr[:] = elems
+                arr = arr.reshape(stored)
+                if ty.dtype == "i1":
+                    arr = _emap(lambda e: e > 0.5, arr)
+                elif ty.dtype == "ui64":
+                    arr = _emap(U64.of, arr)
+                args.append(Sym(arr, ty.dtype, 0 if batched else None, (), ty.shape))
+            ev = _LaneEval(funcs, n_entities) if lane else _Eval(funcs)
+            res = {}
+            for s_, o in zip(outs, ev.call(main, args)):
+                if lane:
+                    o = ev._mat(o, [d for d in o.uni if d != 0] if not s_.elided else None)
+                    if s_.elided and o.eaxis is not None:
+                        raise NotEntityParallel(f"the singleton component {s_.component} would become per-entity")
+                    if not s_.elided and o.eaxis not in (0, None):
+                        raise NotEntityParallel(f"result {s_.component}: the entity axis is not its leading axis")
+                    if not s_.elided and o.eaxis is None and 0 not in o.uni and o.tshape and o.tshape[0] > 1:
+                        raise NotEntityParallel(f"result {s_.component} is per-entity data that does not come from a column of the world")
+                res[s_.column] = _dsl.Vec(_column_values(o))
+            return res
+        fn.__name__ = name
+        import inspect
+        fn.__signature__ = inspect.Signature([inspect.Parameter(p, inspect.Parameter.KEYWORD_ONLY) for p in params])
+        system_ = _dsl.system(fn, every=every, **widths)
+        manifest = {"mode": "lane" if lane else "world", "rows": "entities" if lane else "worlds",
+                    "entities_per_world": n_entities,
+                    "columns": [{"column": c, "width": widths[c],
+                                 "component": next(s_.component for s_ in ins + outs if s_.column == c),
+                                 "component_id": next(s_.component_id for s_ in ins + outs if s_.column == c),
+                                 "shape": list(next(s_.shape for s_ in ins + outs if s_.column == c)),
+                                 "entity_axis_elided": next(s_.elided for s_ in ins + outs if s_.column == c),
+                                 "argument": next((k for k, s_ in enumerate(ins) if s_.column == c), None),
+                                 "result": next((k for k, s_ in enumerate(outs) if s_.column == c), None)} for c in params]}
+        return system_, manifest, widths
+
+    if mode not in ("auto", "lane", "world"):
+        raise ValueError("mode must be 'auto', 'lane' or 'world'")
+    if mode in ("auto", "lane"):
+        try:
+            if n_entities is None:
+                raise NotEntityParallel("the batched slots do not share one entity count (components on different entity sets)")
+            system_, manifest, widths = build(True)
+            _dsl.Program([system_], _dsl.Pipe([]), []).trace(widths)      # refusals surface while tracing: find out now
+            return system_, manifest
+        except NotEntityParallel as e:
+            if mode == "lane":
+                raise
+            reason = str(e)
+    system_, manifest, _ = build(False)
+    if mode == "auto":
+        manifest["lane_refused"] = reason
+    return system_, manifest
+
+
+def compile_world(text: str, slots_doc: dict, out: Optional[str] = None, mode: str = "auto", dtype: str = "float64", fast_math: bool = False):
+    """The build-time step a host (`WorldExec::Hip`, INTEGRATION.md §3) runs once per world: module text + slot metadata -> the
+    shared object `sixdof_set_custom_pipe` installs, and the manifest of its columns.  -> (path of the .so, manifest)"""
+    import json
+    import shutil
+    import time
+    from . import codegen
+    t0 = time.perf_counter()
+    ins, outs = slots_from_metadata(slots_doc)
+    system_, manifest = world_system(text, ins, outs, mode=mode)
+    widths = {c["column"]: c["width"] for c in manifest["columns"]}
+    tp = _dsl.Program([system_], _dsl.Pipe([]), []).trace(widths)
+    t1 = time.perf_counter()
+    rows = int(slots_doc.get("rows", 0))
+    soa = bool(rows >= codegen.COLUMN_SOA_MIN_ROWS)
+    so = codegen.build(tp, dtype, 2, fast_math=fast_math, column_soa=soa)          # 2 = SIXDOF_INTEGRATOR_NONE: the module IS the tick
+    t2 = time.perf_counter()
+    order = [n for n, _ in tp.columns]
+    manifest["columns"] = sorted(manifest["columns"], key=lambda c: order.index(c["column"]))     # = the aux_component_ids order
+    manifest.update({"integrator": "none", "dtype": dtype, "column_layout": "element-major" if soa else "rows",
+                     "build": {"trace_ms": round((t1 - t0) * 1e3, 1), "compile_ms": round((t2 - t1) * 1e3, 1),
+                               "resources": dict(codegen.last_resources)}})
+    if out:
+        shutil.copyfile(so, out)
+        Path(str(out) + ".json").write_text(json.dumps(manifest, indent=1))
+        so = Path(out)
+    return so, manifest
+
+
+def load_world(so_path: str):
+    """What compile_world / the CLI wrote, as a program an executor can bind: (dsl.FrozenProgram, manifest).  Nothing is traced,
+    generated or compiled — the object is installed as it is (sixdof_set_custom_pipe)."""
+    import json
+    manifest = json.loads(Path(str(so_path) + ".json").read_text())
+    prog = _dsl.FrozenProgram(None, [(c["column"], c["width"]) for c in manifest["columns"]],
+                              column_soa=manifest.get("column_layout") == "element-major", prebuilt_so=str(so_path))
+    return prog, manifest
+
+
+def _main(argv=None) -> int:
+    """python -m elodin_amd.stablehlo module.mlir --slots slots.json -o pipe.so [--mode auto|lane|world] [--dtype float64|float32]"""
+    import argparse
+    import json
+    ap = argparse.ArgumentParser(prog="python -m elodin_amd.stablehlo", description=_main.__doc__)
+    ap.add_argument("module", help="StableHLO text (ELODIN_CRANELIFT_DEBUG_DIR/stablehlo.mlir, libs/nox-py/src/cranelift_compile.rs:58-60)")
+    ap.add_argument("--slots", required=True, help="ExecMetadata JSON (libs/nox-py/src/exec.rs:17-29) or {inputs, outputs}")
+    ap.add_argument("-o", "--out", required=True, help="shared object to write (its manifest goes to <out>.json)")
+    ap.add_argument("--mode", default="auto", choices=("auto", "lane", "world"))
+    ap.add_argument("--dtype", default="float64", choices=("float64", "float32"))
+    ap.add_argument("--fast-math", action="store_true")
+    a = ap.parse_args(argv)
+    so, manifest = compile_world(Path(a.module).read_text(), json.loads(Path(a.slots).read_text()), a.out, a.mode, a.dtype, a.fast_math)
+    print(json.dumps({"object": str(so), "mode": manifest["mode"], "rows": manifest["rows"], "columns": [c["column"] for c in manifest["columns"]],
+                      "build": manifest["build"], **({"lane_refused": manifest["lane_refused"]} if "lane_refused" in manifest else {})}))
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(_main())

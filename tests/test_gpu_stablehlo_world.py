@@ -1,0 +1,148 @@
+"""WHOLE-WORLD StableHLO ticks through the generated gfx950 kernel: the reference's world-fragment known answers,
+the assembled three-body world module against G1's 100 ticks (one lane = one world, a Monte-Carlo of worlds), BASELINE configs[1]
+as an entity-batched module with one lane per entity against the hand-written step kernel, and the build-time CLI's object
+installed as it is.  CPU twins: tests/test_stablehlo_ingest.py, tests/test_stablehlo_world.py."""
+import json
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import elodin_amd as ea
+from elodin_amd import _lib as L
+from elodin_amd import dsl, workloads
+from elodin_amd import stablehlo as sh
+from oracle import oracle as orc
+from tests import stablehlo_util as U
+from tests import stablehlo_world_util as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _exec(program, columns, n, **kw):
+    w = workloads.independent_bodies(n)
+    return ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=L.INTEGRATOR_NONE, effectors=program, columns=columns, **kw)
+
+
+def test_reference_world_fragment_known_answers_through_the_generated_kernel():
+    """libs/cranelift-mlir/tests/test_{gather_3body,dynamic_ops_3body,while_dyn_slice,closed_call,threefry,threefry_e2e,
+    uniform_pipeline}.rs: all 22 cases as systems of ONE generated kernel; integer results exact (u32 wrap-around, ui64 words)."""
+    systems, columns, expects = [], {}, []
+    n = 70
+    for k, case in enumerate(U.WORLD_CASES):
+        system, values, expect = U.build(case, prefix=f"k{k}_")
+        systems.append(system)
+        for nm, v in values.items():
+            columns[nm] = np.tile(v.reshape(1, -1), (n, 1))
+        for nm, (w, _) in expect.items():
+            columns[nm] = np.zeros((n, w))
+        expects.append((case, expect))
+    assert len(columns) <= dsl.MAX_PROGRAM_COLUMNS
+    hip = _exec(dsl.Program(systems, dsl.Pipe([]), []), columns, n)
+    hip.run(1)
+    for case, expect in expects:
+        for nm, (width, exp) in expect.items():
+            got = np.asarray(hip._aux[nm], dtype=np.float64)
+            out_k = nm.split("_out")[1]
+            integer = case["expected"].get(out_k, {"type": "f64"})["type"] != "f64"
+            U.check(case["name"], got[0], width, exp, 0.0 if integer else max(case["tol"], 1e-15))
+            assert np.array_equal(got, np.repeat(got[:1], n, axis=0), equal_nan=True), (case["name"], nm)
+    print(f"{len(expects)} world-fragment known answers of the reference through one generated kernel")
+    hip.close()
+
+
+def test_three_body_whole_world_module_reproduces_g1_on_the_gpu():
+    """The assembled whole-world tick (7 in / 7 out, main + inner + closed_call + norm; gather + transpose + while + dynamic_slice +
+    call) with one lane per WORLD: lane 0 flies the reference's golden initial state for its 100 recorded ticks (<= 1e-9, vector-
+    scaled AND element-wise), the other lanes fly perturbed worlds and are compared with the C oracle world by world."""
+    system, manifest, widths, row, g = W.three_body("auto")
+    assert manifest["mode"] == "world"
+    n = 96
+    rng = np.random.default_rng(17)
+    cols = {c: np.tile(v[None, :], (n, 1)) for c, v in row.items()}
+    cols["hlo_world_pos"][1:, [4, 5, 11, 12, 18, 19]] += rng.uniform(-0.05, 0.05, (n - 1, 6))        # other worlds: other starts
+    cols["hlo_world_vel"][1:, [3, 4, 9, 10, 15, 16]] += rng.uniform(-0.05, 0.05, (n - 1, 6))
+    start = {k: v.copy() for k, v in cols.items()}
+    hip = _exec(dsl.Program([system], dsl.Pipe([]), []), cols, n)
+    worst = [0.0, 0.0]
+    for r in range(1, 101):
+        hip.run(1)
+        e = W.three_body_errors(hip._aux, g, r)
+        worst = [max(worst[0], e[0]), max(worst[1], e[1])]
+        assert hip._aux["hlo_tick"][0, 0] == r
+    print(f"three-body whole-world module, 100 ticks vs G1: {worst[0]:.2e} (vector-scaled), {worst[1]:.2e} (element-wise)")
+    assert worst[0] <= 1e-9 and worst[1] <= 1e-9, worst
+    dt = float(g["globals.simulation_time_step"][0, 0])
+    G = 6.6743e-11
+    src, dst = np.array([0, 1, 0, 1, 2, 2], dtype=np.uint32), np.array([1, 0, 2, 2, 0, 1], dtype=np.uint32)
+    bad = 0.0
+    for lane in (1, 7, 40, 95):
+        w = orc.OracleWorld(start["hlo_world_pos"][lane].reshape(3, 7), start["hlo_world_vel"][lane].reshape(3, 6),
+                            start["hlo_inertia"][lane].reshape(3, 7), simulation_time_step=dt,
+                            ops=[(orc.EFF_EDGE_GRAVITY_NEWTON, (G,), None)], edges=(src, dst))
+        w.step(100)
+        for c, ref in (("world_pos", w.world_pos), ("world_vel", w.world_vel), ("world_accel", w.world_accel), ("force", w.force)):
+            got = hip._aux["hlo_" + c][lane].reshape(ref.shape)
+            bad = max(bad, float(np.max(np.abs(got - ref) / np.maximum(np.max(np.abs(ref), axis=1, keepdims=True), 1e-300))))
+    print(f"Monte-Carlo of three-body worlds vs the oracle, 100 ticks: {bad:.2e}")
+    assert bad <= 1e-9
+    hip.close()
+
+
+@pytest.mark.parametrize("n", [1000, 65536])
+def test_independent_bodies_whole_world_module_one_lane_per_entity(n):
+    """BASELINE configs[1] as the reference would dump it ([n, 7] / [n, 6] tensors, vmapped arithmetic): the entity axis becomes
+    the executor's rows; 16 ticks against the hand-written step kernel on the same world (and the oracle on a sample)."""
+    text, slots, cols = W.independent_bodies(n)
+    system, manifest = sh.world_system(text, slots, mode="lane")
+    assert manifest["mode"] == "lane"
+    dt = orc.quantize_time_step(120.0)
+    columns = {"hlo_" + k: np.array(v) for k, v in cols.items()}
+    columns["hlo_tick"], columns["hlo_simulation_time_step"] = np.zeros((n, 1)), np.full((n, 1), dt)
+    hip = _exec(dsl.Program([system], dsl.Pipe([]), []), columns, n)
+    hip.run(16)
+    ref = ea.HipExec(cols["world_pos"], cols["world_vel"], cols["inertia"], simulation_time_step=dt,
+                     effectors=[ea.Effector(L.EFF_UNIFORM_GRAVITY, (0.0, 0.0, -9.81)), ea.Effector(L.EFF_BODY_TORQUE, (), "torque", cols["torque"])])
+    ref.run(16)
+    for c, r in (("world_pos", ref.world_pos), ("world_vel", ref.world_vel), ("world_accel", ref.world_accel), ("force", ref.force)):
+        got = hip._aux["hlo_" + c]
+        err = float(np.max(np.abs(got - r) / np.maximum(np.max(np.abs(r), axis=1, keepdims=True), 1e-300)))
+        assert err <= 1e-9, (c, err)
+    assert np.all(hip._aux["hlo_tick"] == 16)
+    k = min(n, 64)
+    w = orc.OracleWorld(cols["world_pos"][:k], cols["world_vel"][:k], cols["inertia"][:k], simulation_time_step=dt,
+                        ops=[(orc.EFF_UNIFORM_GRAVITY, (0.0, 0.0, -9.81), None), (orc.EFF_BODY_TORQUE, (), cols["torque"][:k])])
+    w.step(16)
+    assert np.max(np.abs(hip._aux["hlo_world_pos"][:k] - w.world_pos) / np.maximum(np.abs(w.world_pos), 1e-9)) <= 1e-9
+    hip.close()
+    ref.close()
+
+
+def test_the_build_time_cli_object_is_installed_as_it_is(tmp_path):
+    """`python -m elodin_amd.stablehlo module.mlir --slots slots.json -o pipe.so` (what a Rust WorldExec::Hip runs
+    once per world) -> the object + manifest; a fresh executor binds the manifest's columns and installs the object without
+    tracing or compiling anything."""
+    from tests.golden import hlo_world_builder as hb
+    text, slots = hb.three_body_world()
+    (tmp_path / "tick.mlir").write_text(text)
+    names = {str(L.component_id(c)): c for c, _, _ in slots}
+    meta = {"arg_ids": [L.component_id(c) for c, _, _ in slots], "ret_ids": [L.component_id(c) for c, _, _ in slots], "names": names,
+            "arg_slots": [{"component_id": L.component_id(c), "shape": s, "entity_axis_elided": e} for c, s, e in slots]}      # ExecMetadata, exec.rs:17-29
+    (tmp_path / "slots.json").write_text(json.dumps(meta))
+    out = tmp_path / "pipe.so"
+    res = subprocess.run([sys.executable, "-m", "elodin_amd.stablehlo", str(tmp_path / "tick.mlir"), "--slots", str(tmp_path / "slots.json"), "-o", str(out)],
+                         capture_output=True, text=True, cwd=str(L.PKG.parent))
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["mode"] == "world" and out.exists()
+    program, manifest = sh.load_world(out)
+    assert [c["component_id"] for c in manifest["columns"]] == [L.component_id(c["component"]) for c in manifest["columns"]]
+    _, _, _, row, g = W.three_body("world")
+    n = 64
+    hip = _exec(program, {c: np.tile(v[None, :], (n, 1)) for c, v in row.items()}, n)
+    hip.run(100)
+    worst = W.three_body_errors(hip._aux, g, 100)
+    print("CLI-built object, tick 100 vs G1:", worst, "build:", manifest["build"])
+    assert max(worst) <= 1e-9
+    hip.close()

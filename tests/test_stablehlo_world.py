@@ -1,0 +1,166 @@
+"""WHOLE-WORLD StableHLO ticks (what libs/nox-py/src/cranelift_compile.rs:47-68 hands a backend) through elodin_amd/stablehlo.py on
+the CPU: parse -> world_system (one lane per world, or one lane per entity) -> the numpy walk of the traced program.
+tests/test_gpu_stablehlo_world.py runs the same programs through the generated gfx950 kernel."""
+import json
+
+import numpy as np
+import pytest
+
+from elodin_amd import dsl
+from elodin_amd import stablehlo as sh
+from oracle import oracle as orc
+from tests import dsl_numpy
+from tests import stablehlo_world_util as W
+from tests.golden import hlo_world_builder as hb
+
+
+def walk(system, widths, comps, ticks, check=None):
+    tp = dsl.Program([system], dsl.Pipe([]), []).trace(widths)
+    n = next(iter(comps.values())).shape[0]
+    for nm, w in tp.columns:
+        comps.setdefault(nm, np.zeros((n, w)))
+    pos, vel, acc, inertia = np.tile([0, 0, 0, 1.0, 0, 0, 0], (n, 1)), np.zeros((n, 6)), np.zeros((n, 6)), np.ones((n, 7))
+    for r in range(1, ticks + 1):
+        dsl_numpy.program_tick_systems_only(tp, pos, vel, acc, inertia, comps, r)
+        if check:
+            check(r)
+    return tp
+
+
+def test_three_body_world_module_has_the_structure_of_the_reference_dump():
+    """libs/cranelift-mlir/tests/three_body_e2e.rs:16-50: 7 inputs, 7 outputs, main + inner + closed_call + norm, and a while whose
+    body holds a dynamic_slice and a call."""
+    text, slots = hb.three_body_world()
+    funcs = sh.parse_module(text)
+    assert sorted(funcs) == ["closed_call", "inner", "main", "norm"]
+    assert len(funcs["main"].args) == 7 and len(funcs["main"].result_types) == 7 and len(slots) == 7
+    whiles = [o for o in funcs["inner"].body if o.name == "stablehlo.while"]
+    assert len(whiles) == 4                                                       # one edge_fold per RK4 stage
+    for w in whiles:
+        body = [o.name for o in w.regions[1]]
+        assert "stablehlo.dynamic_slice" in body and "call" in body
+    assert text.count('"stablehlo.gather"') == 4 * 4 * 3 and "stablehlo.transpose" in text
+
+
+def test_three_body_world_tick_reproduces_the_reference_golden_100_ticks():
+    """G1 (scripts/ci/baseline/three-body-csv) through the WHOLE-WORLD module, one lane = one world: bit for bit on the CPU walker
+    (the module keeps the reference's operation order; numpy does not contract)."""
+    system, manifest, widths, row, g = W.three_body("auto")
+    assert manifest["mode"] == "world" and "edge_fold" in manifest["lane_refused"] or "other entities" in manifest["lane_refused"]
+    comps = {c: np.tile(v[None, :], (2, 1)) for c, v in row.items()}
+    worst = [0.0, 0.0]
+
+    def check(r):
+        assert comps["hlo_tick"][0, 0] == r == int(g["globals.tick"][r, 0])
+        e = W.three_body_errors(comps, g, r)
+        worst[0], worst[1] = max(worst[0], e[0]), max(worst[1], e[1])
+    walk(system, widths, comps, 100, check)
+    assert worst == [0.0, 0.0], worst
+    assert np.array_equal(comps["hlo_world_pos"][0], comps["hlo_world_pos"][1])
+
+
+def test_independent_bodies_world_tick_is_entity_parallel_and_matches_the_oracle():
+    """BASELINE configs[1] spelled as a whole-world module ([n, w] tensors, vmapped arithmetic): ingested with one lane per ENTITY
+    (the [n, 7] world_pos argument becomes a 7-wide column) and equal to the C oracle's RK4 over 16 ticks."""
+    n = 12
+    text, slots, cols = W.independent_bodies(n)
+    system, manifest = sh.world_system(text, slots, mode="lane")
+    assert manifest["mode"] == "lane" and manifest["rows"] == "entities" and manifest["entities_per_world"] == n
+    widths = {c["column"]: c["width"] for c in manifest["columns"]}
+    assert widths["hlo_world_pos"] == 7 and widths["hlo_torque"] == 3 and widths["hlo_tick"] == 1
+    dt = orc.quantize_time_step(120.0)
+    comps = {"hlo_" + k: np.array(v) for k, v in cols.items()}
+    comps["hlo_tick"], comps["hlo_simulation_time_step"] = np.zeros((n, 1)), np.full((n, 1), dt)
+    walk(system, widths, comps, 16)
+    w = orc.OracleWorld(cols["world_pos"], cols["world_vel"], cols["inertia"], simulation_time_step=dt,
+                        ops=[(orc.EFF_UNIFORM_GRAVITY, (0.0, 0.0, -9.81), None), (orc.EFF_BODY_TORQUE, (), cols["torque"])])
+    w.step(16)
+    for c, ref in (("world_pos", w.world_pos), ("world_vel", w.world_vel), ("world_accel", w.world_accel), ("force", w.force)):
+        assert np.max(np.abs(comps["hlo_" + c] - ref) / np.maximum(np.abs(ref), 1e-9)) < 1e-12, c
+    assert np.all(comps["hlo_tick"] == 16)
+
+
+def test_a_world_of_65536_bodies_traces_as_fast_as_a_world_of_twelve():
+    """One lane per entity never materialises an [N, w] tensor: BASELINE's 65,536-body world costs what twelve bodies cost to trace,
+    and generates the same program text."""
+    import time
+    from elodin_amd import codegen
+    srcs = []
+    for n in (12, 65536):
+        text, slots = hb.independent_bodies_world(n)
+        t0 = time.perf_counter()
+        system, manifest = sh.world_system(text, slots, mode="lane")
+        widths = {c["column"]: c["width"] for c in manifest["columns"]}
+        dsl.Expr.fresh()
+        tp = dsl.Program([system], dsl.Pipe([]), []).trace(widths)
+        assert time.perf_counter() - t0 < 30.0
+        srcs.append(codegen.generate_source(tp, "float64", 2))
+    assert srcs[0] == srcs[1]
+
+
+def test_what_the_entity_parallel_front_end_refuses_it_refuses_by_reason():
+    text, slots = hb.three_body_world()
+    with pytest.raises(sh.NotEntityParallel, match="other entities' rows"):
+        sh.world_system(text, slots, mode="lane")
+    reduce_world = """
+module @module {
+  func.func public @main(%arg0: tensor<4x3xf64>) -> tensor<4x3xf64> {
+    %c = stablehlo.constant dense<0.0> : tensor<f64>
+    %0 = stablehlo.reduce(%arg0 init: %c) applies stablehlo.add across dimensions = [0] : (tensor<4x3xf64>, tensor<f64>) -> tensor<3xf64>
+    %1 = stablehlo.broadcast_in_dim %0, dims = [1] : (tensor<3xf64>) -> tensor<4x3xf64>
+    %2 = stablehlo.subtract %arg0, %1 : tensor<4x3xf64>
+    return %2 : tensor<4x3xf64>
+  }
+}"""
+    with pytest.raises(sh.NotEntityParallel, match="sum over the world"):
+        sh.world_system(reduce_world, [("x", [4, 3], False)], mode="lane")
+    system, manifest = sh.world_system(reduce_world, [("x", [4, 3], False)], mode="auto")      # ... and still runs, one lane per world
+    assert manifest["mode"] == "world" and manifest["columns"][0]["width"] == 12
+    comps = {"hlo_x": np.arange(24.0).reshape(2, 12)}
+    walk(system, {"hlo_x": 12}, comps, 1)
+    x = np.arange(24.0).reshape(2, 4, 3)
+    assert np.array_equal(comps["hlo_x"].reshape(2, 4, 3), x - x.sum(axis=1, keepdims=True))
+
+
+def test_entity_parallel_rules_follow_the_entity_axis_through_shape_ops():
+    """vmap's usual spellings: transposes, reshapes that keep the entity axis whole, a dot_general batched over it, a per-entity
+    index into a shared table, broadcasts of world-wide scalars — against numpy on a random world."""
+    text = """
+module @module {
+  func.func public @main(%arg0: tensor<5x2x3xf64>, %arg1: tensor<5x3xf64>, %arg2: tensor<f64>, %arg3: tensor<5xi64>) -> (tensor<5x2xf64>, tensor<5x3xf64>) {
+    %0 = stablehlo.dot_general %arg0, %arg1, batching_dims = [0] x [0], contracting_dims = [2] x [1] : (tensor<5x2x3xf64>, tensor<5x3xf64>) -> tensor<5x2xf64>
+    %1 = stablehlo.broadcast_in_dim %arg2, dims = [] : (tensor<f64>) -> tensor<5x2xf64>
+    %2 = stablehlo.multiply %0, %1 : tensor<5x2xf64>
+    %3 = stablehlo.transpose %arg1, dims = [1, 0] : (tensor<5x3xf64>) -> tensor<3x5xf64>
+    %4 = stablehlo.reshape %3 : (tensor<3x5xf64>) -> tensor<3x1x5xf64>
+    %5 = stablehlo.reverse %4, dims = [0] : tensor<3x1x5xf64>
+    %6 = stablehlo.reshape %5 : (tensor<3x1x5xf64>) -> tensor<3x5xf64>
+    %7 = stablehlo.transpose %6, dims = [1, 0] : (tensor<3x5xf64>) -> tensor<5x3xf64>
+    %cst = stablehlo.constant dense<[[1.0, 2.0, 3.0], [10.0, 20.0, 30.0], [100.0, 200.0, 300.0], [-1.0, -2.0, -3.0]]> : tensor<4x3xf64>
+    %8 = stablehlo.reshape %arg3 : (tensor<5xi64>) -> tensor<5x1xi64>
+    %9 = "stablehlo.gather"(%cst, %8) <{dimension_numbers = #stablehlo.gather<offset_dims = [1], collapsed_slice_dims = [0], start_index_map = [0], index_vector_dim = 1>, indices_are_sorted = false, slice_sizes = array<i64: 1, 3>}> : (tensor<4x3xf64>, tensor<5x1xi64>) -> tensor<5x3xf64>
+    %10 = stablehlo.add %7, %9 : tensor<5x3xf64>
+    return %2, %10 : tensor<5x2xf64>, tensor<5x3xf64>
+  }
+}"""
+    slots = [("m", [5, 2, 3], False), ("v", [5, 3], False), ("k", [], True), ("row", [5], False)]
+    outs = [("mv", [5, 2], False), ("w", [5, 3], False)]
+    system, manifest = sh.world_system(text, slots, outs, mode="lane")
+    widths = {c["column"]: c["width"] for c in manifest["columns"]}
+    assert widths == {"hlo_m": 6, "hlo_v": 3, "hlo_k": 1, "hlo_row": 1, "hlo_mv": 2, "hlo_w": 3}
+    rng = np.random.default_rng(3)
+    m, v, row = rng.normal(size=(5, 2, 3)), rng.normal(size=(5, 3)), np.array([0, 3, 1, 2, 9])       # 9: clamped to the last row
+    comps = {"hlo_m": m.reshape(5, 6), "hlo_v": v.copy(), "hlo_k": np.full((5, 1), 2.5), "hlo_row": row[:, None].astype(float)}
+    walk(system, widths, comps, 1)
+    table = np.array([[1.0, 2, 3], [10, 20, 30], [100, 200, 300], [-1, -2, -3]])
+    assert np.allclose(comps["hlo_mv"], np.einsum("nij,nj->ni", m, v) * 2.5, rtol=1e-15, atol=0)
+    assert np.array_equal(comps["hlo_w"], v[:, ::-1] + table[np.minimum(row, 3)])
+
+
+def test_slots_from_the_references_exec_metadata_json():
+    doc = {"arg_ids": [7, 3, 7], "ret_ids": [3, 7], "names": {"3": "tick", "7": "world_pos"},
+           "arg_slots": [{"component_id": 7, "shape": [3, 7], "entity_axis_elided": False}, {"component_id": 3, "shape": [], "entity_axis_elided": True},
+                         {"component_id": 7, "shape": [3, 7], "entity_axis_elided": False}]}
+    ins, outs = sh.slots_from_metadata(json.loads(json.dumps(doc)))
+    assert [(s.component, s.shape, s.elided, s.component_id) for s in ins] == [("world_pos", (3, 7), False, 7), ("tick", (), True, 3)]
+    assert [s.component for s in outs] == ["tick", "world_pos"] and ins[0].column == "hlo_world_pos"
