@@ -509,7 +509,7 @@ def parse_module(text: str) -> Dict[str, Func]:
 
 _UNARY = {"negate": lambda x: -x, "sqrt": _np.sqrt, "rsqrt": lambda x: 1.0 / _np.sqrt(x), "exponential": _np.exp, "log": _np.log,
           "sine": _np.sin, "cosine": _np.cos, "tan": _np.tan, "tanh": _np.tanh, "abs": _np.abs, "sign": _np.sign, "floor": _np.floor,
-          "ceil": _np.ceil, "log_plus_one": _np.log1p, "exponential_minus_one": _np.expm1, "cbrt": _np.cbrt,
+          "ceil": _np.ceil, "log_plus_one": _np.log1p, "exponential_minus_one": _np.expm1, "expm1": _np.expm1, "cbrt": _np.cbrt,
           "round_nearest_even": _np.rint, "atan": _np.arctan}
 _CHLO = {"erf_inv": lambda x: Expr("erfinv", (_dsl._lift(x),)), "square": lambda x: x * x, "acos": _np.arccos, "asin": _np.arcsin,
          "sinh": _np.sinh, "cosh": _np.cosh, "erfc": _np.erfc, "atan": _np.arctan, "tan": _np.tan, "erf": lambda x: 1.0 - _np.erfc(x)}
@@ -727,6 +727,16 @@ class _Eval:
             return self._reduce_window(op, xs, text, rts, env)
         if short == "select_and_scatter":
             return [self._select_and_scatter(op, xs, text, env)]
+        if short == "pad":
+            return [self._pad(xs[0], xs[1], text, rt)]
+        if short == "batch_norm_inference":      # (x - mean) / sqrt(variance + epsilon) * scale + offset along feature_index
+            x, scale, offset, mean, var = xs
+            eps = float(re.search(r"epsilon\s*=\s*([-+0-9.eE]+)", text).group(1))
+            feat = int(re.search(r"feature_index\s*=\s*(\d+)", text).group(1))
+            shp = [1] * x.a.ndim
+            shp[feat] = x.shape[feat]
+            b = lambda v: v.a.reshape(shp)
+            return [Sym(_emap(lambda xv, s_, o, m_, v_: (xv - m_) / _np.sqrt(v_ + eps) * s_ + o, x.a, b(scale), b(offset), b(mean), b(var)), x.dtype)]
         if short == "map":
             region = self._region_fn(op, 0, env)
             out = np.empty(xs[0].shape, dtype=object)
@@ -1205,6 +1215,25 @@ class _Eval:
                     cur = self._pick(cands, ix)
             out[pos] = cur[()] if isinstance(cur, np.ndarray) else cur
         return Sym(out, operand.dtype)
+
+    def _pad(self, x: Sym, value: Sym, text: str, rt: TensorType) -> Sym:
+        """stablehlo.pad: edge padding low / high (negative = crop) and interior padding with one value (jnp.pad, shifted windows)."""
+        g = lambda key: self._ints(text, key)
+        low, high = g("low") or g("edge_padding_low"), g("high") or g("edge_padding_high")
+        interior = g("interior") or g("interior_padding") or [0] * x.a.ndim
+        out = np.empty(rt.shape, dtype=object)
+        pv = value.a.reshape(-1)[0]
+        for pos in (np.ndindex(rt.shape) if rt.shape else [()]):
+            src, inside = [], True
+            for d, p_ in enumerate(pos):
+                q = p_ - low[d]
+                step = interior[d] + 1
+                if q < 0 or q % step or q // step >= x.shape[d]:
+                    inside = False
+                    break
+                src.append(q // step)
+            out[pos] = x.a[tuple(src)] if inside else pv
+        return Sym(out, x.dtype)
 
     @staticmethod
     def _window_attr(text: str, key: str, rank: int, default: int) -> List[int]:

@@ -229,3 +229,22 @@ module @m {
     full = np.tril(s_) + np.tril(s_, -1).T
     assert np.allclose(vals, np.linalg.eigvalsh(full), atol=1e-12) and np.all(np.diff(vals) > 0) and out[12] == 0.0
     assert np.allclose(full @ vecs, vecs * vals, atol=1e-12) and np.allclose(vecs.T @ vecs, np.eye(3), atol=1e-12)
+
+
+def test_pad_edge_interior_and_negative_padding_against_numpy():
+    """stablehlo.pad (the reference's parser reads it, libs/cranelift-mlir/src/parser.rs; its op tests hold no case): jnp.pad's
+    edge padding, lax.pad's interior padding and a negative (cropping) edge, against numpy."""
+    text = """
+module @m {
+  func.func public @main(%arg0: tensor<2x3xf64>, %arg1: tensor<f64>) -> tensor<4x6xf64> {
+    %0 = stablehlo.pad %arg0, %arg1, low = [1, -1], high = [1, 2], interior = [0, 1] : (tensor<2x3xf64>, tensor<f64>) -> tensor<4x6xf64>
+    return %0 : tensor<4x6xf64>
+  }
+}
+"""
+    x = np.arange(1.0, 7.0).reshape(2, 3)
+    got = dsl_numpy.trace_eval(lambda xp, a, v: dsl.Vec(list(sh.trace(text, [a, v])[0].a.reshape(-1))), x.reshape(-1), -7.0)
+    want = np.full((2, 5), -7.0)
+    want[:, ::2] = x                                                   # interior padding: x0 . x1 . x2
+    want = np.pad(want[:, 1:], ((1, 1), (0, 2)), constant_values=-7.0)  # low -1 crops the first column, high 2 appends two
+    assert np.array_equal(np.asarray(got).reshape(4, 6), want)
