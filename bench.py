@@ -39,6 +39,28 @@ ENTITIES = 65536
 BYTES_PER_ENTITY_STEP_F64 = 360 + 24
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 PMC_FILE = ROOT / "profiles" / "pmc_traffic.json"  # written by profiles/collect.sh from separate --pmc passes
+PMC_VALU_FILE = ROOT / "profiles" / "pmc_valu.json"   # profiles/collect_compute.sh + summarize_compute.py --json: VALU per wave and tick
+VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4      # 1,024 SIMDs x 2.4 GHz / 4 clocks per 64-wide VALU instruction (MI355X_MICROARCH.md)
+
+
+def valu_roofline(key, rollouts, ticks, seconds):
+    """The roofline that bounds a campaign kernel (BASELINE configs[3] / [4]): VALU ISSUE.  One lane flies one rollout with its
+    state in registers, so a tick is `valu_per_wave_per_tick` vector instructions per wave (measured: SQ_INSTS_VALU / SQ_WAVES /
+    ticks in its own rocprofv3 --pmc pass, committed as profiles/pmc_valu.json + profiles/r05_compute_kernels_pmc.md) and the chip
+    issues at most one per SIMD every 4 clocks.  achieved = that count x waves x ticks / the seconds measured HERE."""
+    waves = (int(rollouts) + 63) // 64
+    out = {"bound": "valu issue", "unit": "wave-instructions/s", "peak": VALU_PEAK_WAVE_INSTR_PER_S, "waves": waves, "simds": 1024,
+           "simds_occupied": min(waves, 1024), "achieved": None, "frac": None}
+    try:
+        k = json.loads(PMC_VALU_FILE.read_text())["kernels"][key]
+        per_tick = float(k["valu_per_wave_per_tick"])
+        out.update({"valu_per_wave_per_tick": per_tick, "achieved": round(per_tick * waves * ticks / seconds, 1),
+                    "frac": round(per_tick * waves * ticks / seconds / VALU_PEAK_WAVE_INSTR_PER_S, 4),
+                    "frac_of_occupied_simds": round(per_tick * waves * ticks / seconds / (VALU_PEAK_WAVE_INSTR_PER_S * min(waves, 1024) / 1024), 4),
+                    "counted_at": {"grid": k["grid"], "waves": k["waves"], "file": "profiles/pmc_valu.json"}})
+    except Exception as e:  # noqa: BLE001
+        out["note"] = f"no VALU count on file for {key!r} ({type(e).__name__}): run profiles/collect_compute.sh"
+    return out
 
 
 def make_exec(n, first_row, device, ticks_per_launch, use_graph):
@@ -246,6 +268,8 @@ def apollo_leg(device):
     dt = time.perf_counter() - t0
     ex.close()
     out = {"rollouts": 8192, "steps": 10000, "seconds": round(dt, 5), "rollout_steps_per_s": round(8192 * 10000 / dt, 1),
+           "roofline": valu_roofline("apollo", 8192, 10000, dt),
+           "parity": "plant pinned on the reference's Python (sim.py under refshim); guidance law a restatement of the Rust sidecar: unpinned",
            "launches": tm.launches, "integrator": "semi-implicit", "guidance": "in-kernel, on the reference cadence: post_step once per 3-tick telemetry batch, exchange when end_tick % 5 == 0 (every 15 ticks)"}
     # time per tick against the number of rollouts on ONE GPU: each rollout is a serial chain of ticks (one lane), so below
     # one wave per SIMD (65,536 rollouts) the tick time is the latency of one wave's tick whatever the count — this curve IS
@@ -372,7 +396,10 @@ def falcon9_leg(device):
           "prediction": "t(32768 rollouts) / t(4096 rollouts): what sharding BASELINE's 32,768 rollouts over 8 GPUs can gain at best — "
                         "one lane flies one rollout, 32,768 rollouts are 512 waves on 1,024 SIMDs, so the tick time is one wave's "
                         "latency from 64 rollouts up to 65,536; weak scaling (32,768 per GPU) is what this path scales as"}
-    return {"rollouts": n, "steps": steps, "roofline_hbm_k1": hbm, "rollouts_vs_time": vs, "seconds": round(dt, 4), "rollout_steps_per_s": round(n * steps / dt, 1),
+    return {"rollouts": n, "steps": steps, "roofline": valu_roofline("falcon9", n, steps, dt),
+            "parity": "plant + helpers pinned on the reference's Python modules; flight software a restatement of the Rust sidecar (oracle/falcon9_fsw.c): "
+                      "unpinned; this f32 fast-math build is compared with the f64 flight of the same plan rows (campaign metrics <= 1 %), pinned on nothing bit-wise",
+            "roofline_hbm_k1": hbm, "rollouts_vs_time": vs, "seconds": round(dt, 4), "rollout_steps_per_s": round(n * steps / dt, 1),
             "dtype": "f32", "math": "hardware transcendentals in the generated user code (codegen fast_math)",
             "launches": tm.launches, "integrator": "semi-implicit @ 1 kHz", "guidance": "in-kernel, 100 Hz",
             "bound": "valu (state stays in registers for 1000 ticks per launch)",
@@ -434,7 +461,9 @@ def campaign_bench(which, rank, world, local_rank, comm_device, barrier, capi_co
     from elodin_amd import shard
     total = CAMPAIGN_TOTALS[which] * (world if scaling == "weak" else 1)
     lo, hi = shard.shard_range(total, world, rank)
-    how = f"{CAMPAIGN_TOTALS[which]} rollouts per GPU (weak)" if scaling == "weak" else f"{total} rollouts in total, split over {world} GPU(s) (strong, as BASELINE states it)"
+    how = (f"{CAMPAIGN_TOTALS[which]} rollouts per GPU (weak)" if scaling == "weak" else
+           f"{total} rollouts in total, split over {world} GPU(s) (strong, as BASELINE states it; predicted 8-GPU speed-up 1.0x: a tick is ONE wave's "
+           "latency whatever the rollout count below one wave per SIMD — what scales is the number of rollouts, see the weak line)")
     if which == "apollo":
         from elodin_amd.models import apollo as model
         dtype = "f64"
@@ -475,6 +504,9 @@ def campaign_bench(which, rank, world, local_rank, comm_device, barrier, capi_co
                        "parallelism": f"run-id shards x{world}; broadcast plan + gather results",
                        "collectives": "C ABI (sixdof_campaign_broadcast / _gather over RCCL)" if capi_comm is not None else "torch.distributed"},
             "campaign_seconds": round(elapsed, 4), "success_fraction": round(ok(res), 4) if rank == 0 else None,
+            "roofline": valu_roofline(which, hi - lo, ticks, max(getattr(model, "last_campaign_phases", {}).get("flight_and_download_s", elapsed), 1e-9)),
+            "parity": ("plant pinned on the reference's Python; guidance restatement unpinned" if which == "apollo" else
+                       "plant pinned on the reference's Python; flight-software restatement unpinned; f32 fast-math build bounded against the f64 flight, not pinned bit-wise"),
             "phases": {k: round(v, 4) for k, v in getattr(model, "last_campaign_phases", {}).items()}}
 
 
@@ -553,18 +585,22 @@ def parity_figure(device, rows=4096, ticks=16):
     hip.run(ticks)
     ref = orc.OracleWorld(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ,
                           ops=[(e.kind, tuple(e.p), e.aux) for e in eff]).step(ticks)
-    worst = {}
+    worst, worst_elem = {}, {}
     for f in ("world_pos", "world_vel", "world_accel", "force"):
         g, r = getattr(hip, f), getattr(ref, f)
-        e = 0.0
+        e, ee = 0.0, 0.0
         for sl in ((slice(0, 4), slice(4, 7)) if f == "world_pos" else (slice(0, 3), slice(3, 6))):
             scale = np.maximum(np.max(np.abs(r[:, sl]), axis=1, keepdims=True), 1e-300)
             e = max(e, float(np.max(np.abs(g[:, sl] - r[:, sl]) / scale)))
-        worst[f] = e
+            # SURVEY §8(d)'s own form: |s_i - s_i^ref| / max(|s_i^ref|, floor), floor = 1e-12 x the field vector's scale
+            ee = max(ee, float(np.max(np.abs(g[:, sl] - r[:, sl]) / np.maximum(np.abs(r[:, sl]), 1e-12 * scale))))
+        worst[f], worst_elem[f] = e, ee
     # integer surface: the gather rows the C ABI resolved for the joined entity ids (identity here) — bit-exact or wrong
     ids_equal = bool(np.array_equal(hip.join_rows("world_pos"), np.arange(rows, dtype=np.uint32)))
     hip.close()
-    return {"max_rel_err": max(worst.values()), "by_column": worst, "ticks": ticks, "rows": rows, "tolerance": 1e-9,
+    return {"max_rel_err": max(worst.values()), "by_column": worst, "max_rel_err_elementwise": max(worst_elem.values()),
+            "by_column_elementwise": worst_elem, "elementwise_floor": "1e-12 x the largest component of the field vector",
+            "ticks": ticks, "rows": rows, "tolerance": 1e-9,
             "entity_rows_bit_exact": ids_equal,
             "vs": "oracle/sixdof_oracle.c (reference operation order, no FMA; bit-exact on the reference's three-body / ball golden CSVs)"}
 

@@ -23,3 +23,27 @@ for (name, grid), c in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("SQ_WAV
     print(f"| `{name[:90]}` | {grid} | {m['SQ_WAVES']:.0f} | {m['SQ_INSTS_VALU'] / m['SQ_WAVES']:.0f} | "
           f"{m['SQ_ACTIVE_INST_ANY'] / wc:.1%} / {m['SQ_ACTIVE_INST_VALU'] / wc:.1%} | {m['SQ_WAIT_INST_ANY'] / wc:.1%} | "
           f"{m['SQ_WAIT_ANY'] / wc:.1%} | {sum(d) / len(d):.1f} |")
+
+
+# ---- the VALU-issue roofline's inputs for bench.py (configs 3 / 4 / 5): instructions per wave and TICK, from the counters above ----
+# python profiles/summarize_compute.py <dir> --json profiles/pmc_valu.json
+if "--json" in sys.argv:
+    import json
+    TICKS = 1000                                     # tools/prof_compute_kernels.py TICKS_PER_LAUNCH (campaign kernels); the n-body tick is one sweep
+    doc = {"source": "profiles/collect_compute.sh -> rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU ... (its own pass, no trace domains)",
+           "peak": {"simds": 1024, "clock_hz": 2.4e9, "clocks_per_wave_instruction": 4, "wave_instructions_per_s": 1024 * 2.4e9 / 4,
+                    "what": "one VALU instruction of a 64-wide wave occupies its SIMD's 16 lanes for 4 clocks (MI355X_MICROARCH.md)"}, "kernels": {}}
+    for (name, grid), c in agg.items():
+        m = {k: sum(v) / len(v) for k, v in c.items()}
+        key = ("falcon9" if ("sixdof_step_kernel<float" in name and "PipeCustom" in name) else "apollo" if "apollo_rollout" in name else
+               "nbody_allpairs" if "allpairs_kernel" in name else None)
+        if key is None:
+            continue
+        ticks = TICKS if key in ("falcon9", "apollo") else 1
+        d = dur.get(name, [0.0])
+        doc["kernels"][key] = {"kernel": name[:120], "grid": grid, "waves": round(m["SQ_WAVES"]), "ticks_per_launch": ticks,
+                               "valu_per_wave_per_tick": round(m["SQ_INSTS_VALU"] / m["SQ_WAVES"] / ticks, 2),
+                               "issuing_fraction_of_wave_cycles": round(m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"], 4),
+                               "profiled_us_per_launch": round(sum(d) / len(d), 2)}
+    path = sys.argv[sys.argv.index("--json") + 1]
+    open(path, "w").write(json.dumps(doc, indent=1))

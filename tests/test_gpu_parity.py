@@ -424,37 +424,44 @@ def test_config2_full_baseline_horizon_10000_ticks():
     import os
     hip, ref, w = _pair(65536, 10000, ticks_per_launch=100)
     th = len(os.sched_getaffinity(0))
-    worst = 0.0
+    worst, worst_elem = 0.0, 0.0
     for cp in (2500, 5000, 10000):
         hip.run(cp - hip.tick)
         ref.step(cp - ref.tick, threads=th)
         worst = max(worst, max(parity.state_errors(hip, ref).values()))
-    print("config2 10,000 ticks worst rel err", worst)
+        worst_elem = max(worst_elem, max(parity.state_errors_elementwise(hip, ref).values()))
+    print("config2 10,000 ticks worst rel err", worst, "element-wise (SURVEY 8d, floor 1e-12 x field scale)", worst_elem)
     assert worst < parity.F64_RTOL
+    # element by element a component is measured on ITS OWN size: after 10,000 ticks a quaternion element that is 1e-4 of its
+    # vector carries the vector's absolute error, i.e. 1e4 x the vector-scaled figure — the bound asserted is that ratio's
+    assert worst_elem < 1e-5, worst_elem
     assert hip.tick == ref.tick == 10000
 
 
 def test_nbody_config3_full_size_vs_oracle_over_many_ticks():
     """BASELINE configs[2] at its stated size: 16,384 bodies, all-pairs softened gravity, RK4, dt = 3600 s,
-    against the sequential-fold oracle (its all-pairs fold spread over the host cores) at ticks 1, 10 and 25 — about a
-    second of oracle time per tick on the GPU box's 16-CPU quota.  SIXDOF_LONG_TESTS=1 runs the full 100-tick horizon
-    (run on MI355X in round 2: passes the 1e-9 bar; 102 s, nearly all of it the oracle)."""
+    against the sequential-fold oracle (its all-pairs fold spread over the host cores) at ticks 1, 10, 50 and 100 — the FULL stated
+    horizon, about a second of oracle time per tick on the GPU box's 16-CPU quota (~100 s, nearly all of it the oracle;
+    SIXDOF_SHORT_TESTS=1 stops at tick 25)."""
     import os
-    checkpoints = (1, 10, 50, 100) if os.environ.get("SIXDOF_LONG_TESTS") == "1" else (1, 10, 25)
+    checkpoints = (1, 10, 25) if os.environ.get("SIXDOF_SHORT_TESTS") == "1" else (1, 10, 50, 100)      # the stated horizon by default (VERDICT r04 4b)
     n = 16384
     pos, vel, inertia = _plummer(n, seed=16384)
     op = (K_SQ, EPS_AU2)
     hip = ea.HipExec(pos, vel, inertia, simulation_time_step=3600.0, effectors=[ea.Effector(L.EFF_ALLPAIRS_GRAVITY_SOFTENED, op)])
     ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=3600.0, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, op, None)])
     th = len(os.sched_getaffinity(0))
-    worst = {}
+    worst, worst_elem = {}, {}
     for cp in checkpoints:
         hip.run(cp - hip.tick)
         ref.step(cp - ref.tick, threads=th)
         for k, e in parity.state_errors(hip, ref).items():
             worst[k] = max(worst.get(k, 0.0), e)
-    print(f"n-body 16,384 x {checkpoints[-1]} ticks worst rel err", worst)
+        for k, e in parity.state_errors_elementwise(hip, ref).items():
+            worst_elem[k] = max(worst_elem.get(k, 0.0), e)
+    print(f"n-body 16,384 x {checkpoints[-1]} ticks worst rel err", worst, "element-wise", worst_elem)
     assert max(worst.values()) < parity.F64_RTOL, worst
+    assert max(worst_elem.values()) < 1e-5, worst_elem
 
 
 def test_nbody_config3_full_size_vs_oracle_and_momentum():
