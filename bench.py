@@ -126,6 +126,30 @@ def roofline_from(avg_launch_ms, n, launches, how):
             "entities": n, "ticks_per_launch": 1, "launches_timed": int(launches), "timing": how}
 
 
+_stream_cache = {}
+
+
+def measured_stream_GBps(device=0):
+    """What this box's HBM actually streams: a 1 GiB device-to-device copy (read + write = 2 GiB of traffic), best of 5, HIP events.
+    MI355X_MICROARCH.md measures 6.29 TB/s for a float4 copy against the 8 TB/s spec the `frac` above is priced on."""
+    if device not in _stream_cache:
+        import torch
+        a = torch.empty(1 << 28, dtype=torch.float32, device=f"cuda:{device}")
+        b = torch.empty_like(a)
+        b.copy_(a)
+        best = 1e30
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            b.copy_(a)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        _stream_cache[device] = 2 * a.numel() * 4 / (best * 1e-3) / 1e9
+        del a, b
+    return _stream_cache[device]
+
+
 def kernel_roofline(ex, n, steps, warmup):
     """Average duration of one launch of the step kernel at ticks_per_launch = 1: `steps` launches enqueued back
     to back on the handle's stream between ONE HIP event pair (so inter-kernel gaps count against us)."""
@@ -409,6 +433,163 @@ def falcon9_leg(device):
             "meco_alt_km": [round(float(res[:, 4].min()) / 1e3, 2), round(float(res[:, 4].max()) / 1e3, 2)]}
 
 
+def build_times_leg(device):
+    """`build_time_ms` (the reference gates it in CI: scripts/ci/baseline/three-body-csv/profile-metrics.json 249 ms,
+    tolerances.json; libs/nox-py/src/profile.rs:14-59): per generated program the COLD build on this host — trace + generate + every
+    hipcc run, into an empty cache directory — and the cached one (what every later executor of the same program pays)."""
+    import shutil
+    import tempfile
+    from elodin_amd import codegen, dsl
+    from elodin_amd import stablehlo as sh
+    saved = codegen.JIT_DIR
+    out = {"unit": "ms", "compiler": "hipcc --offload-arch=gfx950, one cache-policy instantiation per object, flag sets of a large program compiled concurrently"}
+
+    def timed(name, make):
+        """make() -> a callable that builds (trace + generate + compile) and returns the object's path."""
+        tmp = Path(tempfile.mkdtemp(prefix="jit_cold_"))
+        try:
+            codegen.JIT_DIR = tmp
+            n0 = codegen.build_stats["hipcc_invocations"]
+            t0 = time.perf_counter()
+            make()()
+            cold = time.perf_counter() - t0
+            inv = codegen.build_stats["hipcc_invocations"] - n0
+            t0 = time.perf_counter()
+            make()()
+            cached = time.perf_counter() - t0
+            out[name] = {"cold_ms": round(cold * 1e3, 1), "cached_ms": round(cached * 1e3, 1), "hipcc_invocations": int(inv),
+                         "resources": {k: codegen.last_resources.get(k) for k in ("vgprs", "agprs", "scratch_bytes_per_lane", "flags")}}
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            codegen.JIT_DIR = saved
+            shutil.rmtree(tmp, ignore_errors=True)
+
+    def example(mod_name):
+        def make():
+            import importlib
+            mod = importlib.import_module("examples." + mod_name)
+            w, sys_ = (mod.world(), mod.system()) if mod_name == "ball" else mod.world_and_system()
+            def build():
+                dsl.Expr.fresh()
+                srcs = w.generated_sources(sys_, simulation_rate=120.0)
+                codegen._ONLY_POLICY[0] = 1
+                try:
+                    return [codegen._compile(src, kind) for kind, src in srcs.items()]
+                finally:
+                    codegen._ONLY_POLICY[0] = None
+            return build
+        return make
+    timed("three_body_fold", example("three_body"))
+    timed("ball_program", example("ball"))
+
+    def falcon9():
+        from elodin_amd.models import falcon9 as f9
+        cols = f9.initial_columns(f9.default_param_row()[None, :])
+        widths = {k: v.shape[1] for k, v in cols.items()}
+        def build():
+            dsl.Expr.fresh()
+            tp = f9.build_program(origin=f9.pad_ecef(), algebraic_geodesy=True).trace(widths)
+            return codegen.build(tp, "float32", 1, fast_math=True, column_soa=True, guard_selects=True, policy=1)
+        return build
+    timed("falcon9_f32_campaign", falcon9)
+
+    def world_module():
+        sys.path.insert(0, str(ROOT))
+        from tests.golden import hlo_world_builder as hb
+        text, slots = hb.three_body_world()
+        doc = {"inputs": [{"component": c, "shape": s_, "entity_axis_elided": e} for c, s_, e in slots], "rows": 4096}
+        return lambda: sh.compile_world(text, doc)[0]
+    timed("three_body_world_module", world_module)
+    out["apollo"] = {"cold_ms": 0.0, "cached_ms": 0.0, "hipcc_invocations": 0,
+                     "note": "the Apollo rollout kernel is hand-written and compiled ahead of time into libsixdof_hip.so (csrc/apollo_kernels.hip): nothing is built per program"}
+    return out
+
+
+def world_module_leg(device):
+    """f1 in its literal form: the reference's WHOLE-WORLD StableHLO tick (what cranelift_compile.rs:47-68 hands a backend) through
+    the generated kernel.  (a) the three-body world module (edge_fold while + gathers), one lane per WORLD: a Monte-Carlo of
+    worlds; (b) BASELINE configs[1] spelled as an entity-batched module ([65536, 7] tensors), one lane per ENTITY, next to the
+    hand-written step kernel on the same world."""
+    import elodin_amd as ea
+    from elodin_amd import _lib as L
+    from elodin_amd import dsl, workloads
+    from elodin_amd import stablehlo as sh
+    sys.path.insert(0, str(ROOT))
+    from tests.golden import hlo_world_builder as hb
+    out = {}
+    text, slots = hb.three_body_world()
+    system, manifest = sh.world_system(text, slots, mode="auto")
+    widths = {c["column"]: c["width"] for c in manifest["columns"]}
+    g_pos = np.array([0, 0, 0, 1, 0.8920281421, 0, 0, 0, 0, 0, 1, -0.6628498947, 0, 0, 0, 0, 0, 1, -0.2291782474, 0, 0.0])
+    g_vel = np.array([0, 0, 0, 0, 0.9957939373, 0, 0, 0, 0, 0, -1.6191613336, 0, 0, 0, 0, 0, 0.6233673964, 0.0])
+    m = 1.0 / 6.6743e-11
+    g_in = np.tile([m, m, m, 0, 0, 0, m], 3)
+    for worlds in (4096, 65536):
+        w = workloads.independent_bodies(worlds)
+        cols = {"hlo_tick": np.zeros((worlds, 1)), "hlo_simulation_time_step": np.full((worlds, 1), 0.008333333),
+                "hlo_world_pos": np.tile(g_pos, (worlds, 1)), "hlo_world_vel": np.tile(g_vel, (worlds, 1)),
+                "hlo_world_accel": np.zeros((worlds, 18)), "hlo_force": np.zeros((worlds, 18)), "hlo_inertia": np.tile(g_in, (worlds, 1))}
+        ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=L.INTEGRATOR_NONE, effectors=dsl.Program([system], dsl.Pipe([]), []),
+                        columns=cols, ticks_per_launch=100, device=device)
+        ex.invoke_batch(100)
+        tm = ex.invoke_batch(1000)
+        ex.close()
+        out[f"three_body_worlds_{worlds}"] = {"mode": manifest["mode"], "worlds": worlds, "ticks": 1000, "us_per_tick": round(tm.kernel_device_ms, 3),
+                                             "world_steps_per_s": round(worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
+                                             "body_steps_per_s": round(3 * worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1)}
+    n = 65536
+    text, slots = hb.independent_bodies_world(n)
+    system, manifest = sh.world_system(text, slots, mode="lane")
+    w = workloads.independent_bodies(n)
+    cols = {"hlo_tick": np.zeros((n, 1)), "hlo_simulation_time_step": np.full((n, 1), workloads.DT_120HZ), "hlo_world_pos": w["world_pos"].copy(),
+            "hlo_world_vel": w["world_vel"].copy(), "hlo_world_accel": np.zeros((n, 6)), "hlo_force": np.zeros((n, 6)), "hlo_inertia": w["inertia"].copy(),
+            "hlo_torque": w["body_torque"].copy()}
+    ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=L.INTEGRATOR_NONE, effectors=dsl.Program([system], dsl.Pipe([]), []),
+                    columns=cols, device=device)
+    ex.invoke_batch(64)
+    tm = ex.invoke_batch(1024)
+    us = tm.kernel_device_ms / 1024 * 1e3
+    ex.set_ticks_per_launch(64)
+    ex.invoke_batch(64)
+    tf = ex.invoke_batch(64 * 32)
+    ex.close()
+    bytes_per = 8 * (1 + 1 + 7 + 6 + 6 + 6 + 7 + 3) + 8 * (1 + 1 + 7 + 6 + 6 + 6 + 7 + 3)       # every slot read and written back (the module returns all eight)
+    out["independent_bodies_65536_lane_mode"] = {
+        "mode": manifest["mode"], "entities": n, "us_per_tick_k1": round(us, 3), "entity_steps_per_s_k1": round(n / us * 1e6, 1),
+        "bytes_per_entity_tick": bytes_per, "algorithmic_GBps": round(bytes_per * n / us / 1e3, 1), "frac_of_hbm_peak": round(bytes_per * n / us / 1e3 / HBM_PEAK_GBPS, 4),
+        "entity_steps_per_s_k64": round(n * 64 * 32 / (tf.kernel_device_ms * 1e-3), 1),
+        "what": "the whole tick is the module's (integrator NONE); globals are replicated per row, so a tick moves 592 B per entity where the hand-written kernel moves 384"}
+    return out
+
+
+def rccl_attestation(torch, dist, world, local_rank, shared_gpu):
+    """What the process group actually is: backend, world size as the group reports it, and per rank the device it computes on
+    (index + PCI bus id), gathered over the group itself.  Distinct bus ids are asserted unless the dry-run switch is set."""
+    props = torch.cuda.get_device_properties(local_rank)
+    try:
+        bus = torch.cuda.get_device_properties(local_rank).pci_bus_id
+        bus = f"{getattr(props, 'pci_domain_id', 0):04x}:{bus:02x}:{getattr(props, 'pci_device_id', 0):02x}"
+    except Exception:  # noqa: BLE001
+        bus = os.environ.get("HIP_VISIBLE_DEVICES", "") + f"#{local_rank}"
+    mine = {"rank": int(os.environ.get("RANK", "0")), "device_index": int(local_rank), "pci_bus_id": bus, "name": props.name,
+            "uuid": str(getattr(props, "uuid", ""))}
+    if dist is None:
+        return {"backend": None, "world_size": 1, "ranks": [mine]}
+    box = [None] * world
+    dist.all_gather_object(box, mine)
+    ids = [(r["pci_bus_id"], r["uuid"]) for r in box]
+    distinct = len(set(ids)) == len(ids)
+    if not distinct and not shared_gpu:
+        raise SystemExit(f"bench.py --gpus {world}: ranks share a device {ids} (set SIXDOF_BENCH_SHARED_GPU=1 for a one-GPU dry run)")
+    ver = None
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        pass
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver, "distinct_devices": distinct, "ranks": box}
+
+
 CAMPAIGN_TOTALS = {"apollo": 8192, "falcon9": 32768}      # BASELINE configs[3] / configs[4]: rollouts of the WHOLE campaign
 
 
@@ -652,6 +833,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     rank_device = "cpu" if shared_gpu else torch.device("cuda", local_rank)      # where the ranks' scalars are reduced
+    attest = rccl_attestation(torch, dist if distributed else None, world, local_rank, shared_gpu)
 
     def barrier():
         if distributed:
@@ -729,7 +911,11 @@ def main():
         "window_incl_device_sync_and_barrier": {"value": round(n * world * args.steps / elapsed_incl, 1), "unit": "entity-steps/s",
                                                 "ms_per_step": round(elapsed_incl / args.steps * 1e3, 6)},
         "device_ms_per_step": round(tm.kernel_device_ms / args.steps, 6),
+        "rccl": attest,      # what the group says it is: backend, dist.get_world_size(), every rank's device (asserted distinct)
     }
+    if world > 1:
+        out["n1_reference_value"] = {"what": "the N = 1 point of the same command on this box's rank 0 alone is `value / n_gpus` under weak scaling with "
+                                             "no collective; compare with BENCH_rNN.json's `value`", "value_per_gpu": round(value / world, 1)}
 
     if rank == 0:
         if K == 1:  # the timed region itself: HIP events bracket exactly the `steps` launches
@@ -748,6 +934,14 @@ def main():
             ss = roofline_from(st.kernel_device_ms / max(1, st.launches), n, st.launches,
                                "HIP events around a 4,096-launch batch on the launch stream / launches")
             out["roofline"]["steady_state"] = {k: ss[k] for k in ("achieved", "frac", "frac_360B", "avg_launch_us", "launches_timed", "timing")}
+        if not args.no_extras:
+            try:
+                bw = measured_stream_GBps(local_rank)
+                out["roofline"]["measured_stream_GBps"] = round(bw, 1)
+                out["roofline"]["frac_of_measured_stream"] = round(out["roofline"]["achieved"] / bw, 4)
+                out["roofline"]["measured_stream_how"] = "1 GiB device-to-device copy (2 GiB of traffic), best of 5, on this GPU in this run"
+            except Exception as e:  # noqa: BLE001
+                out["roofline"]["measured_stream_GBps"] = f"{type(e).__name__}: {e}"[:120]
         if not args.no_extras and world == 1:
             # fused batch: the reference's ticks_per_telemetry semantics, state held in VGPRs
             ex.set_ticks_per_launch(64)
@@ -826,11 +1020,18 @@ def main():
         extra("monte_carlo_example", monte_carlo_example_leg, local_rank)
         extra("apollo_mc", apollo_leg, local_rank)
         extra("falcon9_mc", falcon9_leg, local_rank)
+        extra("world_module", world_module_leg, local_rank)
+        extra("build", build_times_leg, local_rank)
     tc = out.get("telemetry_commit", {}).get("k1x48", {}) if isinstance(out.get("telemetry_commit"), dict) else {}
     if tc.get("entity_steps_per_s_streaming"):
         # the metric includes the commit of the output columns to the host.  `value` is the step alone (columns
         # resident in HBM); this is the same K = 1 stepping with the four output columns committed to page-locked host columns
         # every 48 ticks, the copy overlapping the next batch (PCIe-bound: 13.1 MB per commit)
+        # SURVEY 8(d)'s metric as it is defined (commit included), both ways a host can write invoke_batch
+        out["incl_commit"] = {"unit": "entity-steps/s", "streaming": tc["entity_steps_per_s_streaming"], "blocking": tc.get("entity_steps_per_s_sync"),
+                              "streaming_is": "sixdof_step + sixdof_download_async: the D2H of batch k overlaps batch k + 1 (what INTEGRATION.md §2 shows)",
+                              "blocking_is": "sixdof_step, then a blocking sixdof_download per batch (jax_exec.rs:150-178's shape)",
+                              "batch": "48 single-tick launches, 13.1 MB of output columns per commit: PCIe-bound"}
         out["value_incl_commit"] = {"value": tc["entity_steps_per_s_streaming"], "unit": "entity-steps/s",
                                     "what": "K = 1 launches, output columns committed to the host every 48 ticks (async D2H overlapped with the next batch); "
                                             "blocking step-then-download: " + str(tc.get("entity_steps_per_s_sync"))}

@@ -363,6 +363,8 @@ class _Emitter:
                             fused[id(n_)] = k
                             folded.add(id(m))
                             break
+        if _ESTIMATE[0] is not None and _EMIT_ORDER[0] != "pressure" and need:
+            _pressure_order(need, [e for _, e in assign])          # for its estimates only
         if _EMIT_ORDER[0] == "pressure":
             ordered = _pressure_order(need, [e for _, e in assign])
         else:
@@ -430,6 +432,11 @@ def _pressure_order(need: Dict[int, "dsl.Expr"], roots: Sequence["dsl.Expr"]) ->
                 pos[id(n_)] = len(pos)
     for i in need:
         pos.setdefault(i, len(pos))
+    if _ESTIMATE[0] is not None:       # build(): how many values each emission order keeps live at its worst in this block
+        by_seq = sorted(need.values(), key=lambda n_: n_.seq)
+        by_pos = sorted(need.values(), key=lambda n_: pos[id(n_)])
+        for name_, order_ in (("program", by_seq), ("demand", by_pos)):
+            _ESTIMATE[0][name_] = max(_ESTIMATE[0].get(name_, 0), _peak_live(order_, deps, dict(users)))
 
     def score(i):
         return sum(1 for a in {id(a) for a in deps(need[i])} if users[a] == 1)
@@ -446,7 +453,33 @@ def _pressure_order(need: Dict[int, "dsl.Expr"], roots: Sequence["dsl.Expr"]) ->
             pending[c] -= 1
             if pending[c] == 0:
                 ready.add(c)
+    if _ESTIMATE[0] is not None:
+        users2: Dict[int, int] = {}
+        for i, x in need.items():
+            for a in {id(a) for a in deps(x)}:
+                users2[a] = users2.get(a, 0) + 1
+        for r in roots:
+            if id(r) in need:
+                users2[id(r)] = users2.get(id(r), 0) + 1
+        _ESTIMATE[0]["pressure"] = max(_ESTIMATE[0].get("pressure", 0), _peak_live(order, deps, users2))
     return order
+
+
+_ESTIMATE: List[Optional[Dict[str, int]]] = [None]
+
+
+def _peak_live(order, deps, users: Dict[int, int]) -> int:
+    """Largest number of simultaneously live node values when a block's nodes are emitted in `order` (users: remaining-use counts,
+    consumed here)."""
+    live = peak = 0
+    for x in order:
+        live += 1
+        peak = max(peak, live)
+        for a in {id(a) for a in deps(x)}:
+            users[a] -= 1
+            if users[a] == 0:
+                live -= 1
+    return peak
 
 
 # Opt-in (codegen.generate_source(..., guard_selects=True) / SIXDOF_GUARD_SELECTS=1): see _Emitter.block, "GUARDED SELECT".
@@ -1144,10 +1177,19 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
                                       for k, (_, w) in enumerate(tp.columns)) + "}"
     names = ", ".join(e.__name__ for e in pipe_tp.effectors)
     fast = "#define SIXDOF_FAST_MATH 1\n" if fast_math else ""
-    launch_k = lambda pipe, ig, params: (
-        f"    if (({params}.streaming & 255u) == kPolNt) hipLaunchKernelGGL((sixdof_step_kernel<{T}, {ig}, {pipe}, kPolNt>), grid, dim3(kWave), 0, s, {params});\n"
-        f"    else if (({params}.streaming & 255u) == kPolNtStores || ({params}.streaming & 255u) == kPolSc1Stores) hipLaunchKernelGGL((sixdof_step_kernel<{T}, {ig}, {pipe}, kPolNtStores>), grid, dim3(kWave), 0, s, {params});\n"
-        f"    else hipLaunchKernelGGL((sixdof_step_kernel<{T}, {ig}, {pipe}, kPolPlain>), grid, dim3(kWave), 0, s, {params});\n")
+    only = _ONLY_POLICY[0]
+    if only is None:
+        launch_k = lambda pipe, ig, params: (
+            f"    if (({params}.streaming & 255u) == kPolNt) hipLaunchKernelGGL((sixdof_step_kernel<{T}, {ig}, {pipe}, kPolNt>), grid, dim3(kWave), 0, s, {params});\n"
+            f"    else if (({params}.streaming & 255u) == kPolNtStores || ({params}.streaming & 255u) == kPolSc1Stores) hipLaunchKernelGGL((sixdof_step_kernel<{T}, {ig}, {pipe}, kPolNtStores>), grid, dim3(kWave), 0, s, {params});\n"
+            f"    else hipLaunchKernelGGL((sixdof_step_kernel<{T}, {ig}, {pipe}, kPolPlain>), grid, dim3(kWave), 0, s, {params});\n")
+    else:
+        # ONE cache-policy instantiation (build(policy=...)): the executor's size class is known when its program is built, a
+        # policy only changes cache hints (never values), and each instantiation of the step kernel costs a third of the device
+        # compile — so an object built for an executor carries the one it will be launched with
+        pname = {0: "kPolPlain", 1: "kPolNtStores", 9: "kPolNt"}[only]
+        launch_k = lambda pipe, ig, params: (
+            f"    hipLaunchKernelGGL((sixdof_step_kernel<{T}, {ig}, {pipe}, {pname}>), grid, dim3(kWave), 0, s, {params});   // built for this executor's cache policy only\n")
     staged = is_prog and bool(tp.fold_stages)
     if not staged:
         structs = _emit_pipe_struct("PipeCustom", tp if is_prog else None, pipe_tp, tp.pre if is_prog else [], tp.post if is_prog else [],
@@ -1410,10 +1452,30 @@ def _headers_digest() -> str:
     return h.hexdigest()
 
 
+_ONLY_POLICY: List[Optional[int]] = [None]      # build(policy=...): the one cache policy the object is generated for (None: all three)
+
+
+def policy_for(n_rows: int, row_elems: int, elem_bytes: int) -> Optional[int]:
+    """The cache policy csrc/sixdof_capi.cpp fill_step_params picks for an executor of this size (plain loads + nt stores up to
+    768 MiB of state, nt both ways beyond), or None when an environment override may pick another at run time (A/B tooling)."""
+    if os.environ.get("SIXDOF_STREAMING") is not None or os.environ.get("SIXDOF_ALL_POLICIES", "") == "1":
+        return None
+    return 1 if int(n_rows) * int(row_elems) * int(elem_bytes) <= (768 << 20) else 9
+
+
 def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_math: bool = False, window_soa: bool = False,
-          column_soa: bool = False, guard_selects: Optional[bool] = None) -> Path:
+          column_soa: bool = False, guard_selects: Optional[bool] = None, policy: Optional[int] = None) -> Path:
     """Generate + compile (cached by content hash).  Returns the .so path.  A program that no flag set builds without VGPR
-    spills is generated again with its columns memory-resident (_MEMORY_COLUMNS) before giving up."""
+    spills is generated again with its columns memory-resident (_MEMORY_COLUMNS) before giving up.
+    policy: instantiate the step kernel for this cache policy only (policy_for); None = all three, selectable at launch."""
+    _ONLY_POLICY[0] = policy if policy in (0, 1, 9) else None
+    try:
+        return _build(tp, dtype, integrator, fast_math, window_soa, column_soa, guard_selects)
+    finally:
+        _ONLY_POLICY[0] = None
+
+
+def _build(tp, dtype, integrator, fast_math, window_soa, column_soa, guard_selects) -> Path:
     if getattr(tp, "prebuilt_so", None) is not None:        # dsl.FrozenProgram(prebuilt_so=...): the object exists (stablehlo CLI)
         if not Path(tp.prebuilt_so).exists():
             raise FileNotFoundError(tp.prebuilt_so)
@@ -1421,9 +1483,29 @@ def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_
     if getattr(tp, "frozen_source", None) is not None:      # dsl.FrozenProgram: the text exists, only the compiler is run
         return _compile(tp.frozen_source, "pipe")
     variants = VARIANTS if isinstance(tp, dsl.TracedProgram) else VARIANTS[:2]
+    first_src = None
+    if isinstance(tp, dsl.TracedProgram) and not tp.fold_stages:
+        # a tick that keeps more values live than a wave has registers (a whole-world module: every stage vector of its RK4 waits
+        # for the final sum) would fail the first variants one hipcc run after another: estimate each emission order's peak of live
+        # values from the DAG and, only when creation order is over budget, try the orders from the leanest up
+        _ESTIMATE[0] = {}
+        try:
+            first_src = generate_variant(tp, variants[0], dtype, integrator, fast_math, window_soa, column_soa, guard_selects)
+            est = dict(_ESTIMATE[0])
+        finally:
+            _ESTIMATE[0] = None
+        regs_per_value = 2 if dtype == "float64" else 1
+        held = sum(int(w_) for _, w_ in tp.columns)
+        if est and (est.get("program", 0) + held) * regs_per_value > PRESSURE_BUDGET_REGS:
+            lean = sorted([v for v in ("program", "demand", "pressure") if v in est], key=lambda v: (est[v], VARIANTS.index(v)))
+            variants = tuple(lean) + tuple(v for v in variants if v not in lean)
+            first_src = None
+        last_estimate.clear()
+        last_estimate.update(est)
     for k, variant in enumerate(variants):
         try:
-            so = _compile(generate_variant(tp, variant, dtype, integrator, fast_math, window_soa, column_soa, guard_selects), "pipe")
+            src_k = first_src if (k == 0 and first_src is not None) else generate_variant(tp, variant, dtype, integrator, fast_math, window_soa, column_soa, guard_selects)
+            so = _compile(src_k, "pipe")
             last_variant[0] = variant
             return so
         except SpillError:
@@ -1436,6 +1518,8 @@ def build(tp: dsl.TracedPipe, dtype: str = "float64", integrator: int = 0, fast_
 # ranges next); with the columns in a memory image instead of registers (_MEMORY_COLUMNS);
 # with the tick body out of line (SIXDOF_TICK_OUT_OF_LINE).
 VARIANTS = ("program", "demand", "pressure", "memory", "out_of_line")
+PRESSURE_BUDGET_REGS = 440       # (estimated live values + column values) x registers per value above which build() reorders its variants
+last_estimate: Dict[str, int] = {}      # peak live values per emission order of the last build (diagnostics, bench.py)
 last_variant = ["program"]      # the variant the last build() settled on (fixture generators record it)
 
 
@@ -1467,6 +1551,8 @@ _RETRY_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills"]
 # live set (-O1: no unrolling / less hoisting); the fuzz program that miscomputed when spilling is exact at -O1.
 _ATTEMPTS = (("-O3", _BASE_FLAGS), ("-O3", _BASE_FLAGS + _RETRY_FLAGS), ("-O1", []))
 _CACHE_TAG = "rp2"           # bump when the flag policy changes: cached objects are keyed on it
+SPECULATIVE_MIN_SOURCE = 120_000      # characters of generated source from which the flag sets of _ATTEMPTS are compiled concurrently
+build_stats: Dict[str, float] = {"hipcc_invocations": 0, "cache_hits": 0}      # since import (bench.py reports them per program)
 ALLOW_SPILLS_ENV = "SIXDOF_ALLOW_SPILLS"   # "1": accept a build that still spills VGPRs (known-unsafe on gfx950, see above)
 last_resources: Dict[str, int] = {}
 
@@ -1528,6 +1614,7 @@ def _compile(src: str, stem: str) -> Path:
     meta = JIT_DIR / f"{stem}_{digest}.json"
     global last_resources
     if so.exists():
+        build_stats["cache_hits"] += 1
         try:
             os.utime(so)          # last use: lets a cache be pruned by age
         except OSError:
@@ -1551,28 +1638,58 @@ def _compile(src: str, stem: str) -> Path:
         temps.append(name)
         return name
 
-    def run(opt, flags, out):
-        cmd = [HIPCC, "--offload-arch=gfx950", opt, "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-               "-Rpass-analysis=kernel-resource-usage", *flags, *(ilp if opt != "-O1" else []), *extra, f"-I{CSRC}", str(hip), "-o", out]
-        res = subprocess.run(cmd, capture_output=True, text=True)
-        if res.returncode != 0:
-            raise RuntimeError(f"hipcc failed for generated code {hip}:\n{res.stderr[-4000:]}")
-        return dict(_resources(res.stderr), flags=" ".join([opt, *flags, *(ilp if opt != "-O1" else [])]))
+    def command(opt, flags, out):
+        return [HIPCC, "--offload-arch=gfx950", opt, "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+                "-Rpass-analysis=kernel-resource-usage", *flags, *(ilp if opt != "-O1" else []), *extra, f"-I{CSRC}", str(hip), "-o", out]
+
+    def verdict(opt, flags, returncode, stderr):
+        if returncode != 0:
+            raise RuntimeError(f"hipcc failed for generated code {hip}:\n{stderr[-4000:]}")
+        used = dict(_resources(stderr), flags=" ".join([opt, *flags, *(ilp if opt != "-O1" else [])]))
+        if used["vgpr_spills"] and not used.get("scratch_bytes_per_lane", 1):
+            used["vgpr_spills"] = 0      # spill slots that never reached memory (parked in AGPRs / eliminated): no scratch, no spill
+        return used
     try:
         if not hip.exists():
             t = temp(".hip.tmp")
             Path(t).write_text(src)
             os.replace(t, hip)
         best, best_obj = None, None
-        for opt, flags in _ATTEMPTS:
-            obj = temp(".so.tmp")
-            used = run(opt, flags, obj)
-            if used["vgpr_spills"] and not used.get("scratch_bytes_per_lane", 1):
-                used["vgpr_spills"] = 0      # spill slots that never reached memory (parked in AGPRs / eliminated): no scratch, no spill
-            if best is None or used["vgpr_spills"] < best["vgpr_spills"]:
-                best, best_obj = used, obj
-            if used["vgpr_spills"] == 0:
-                break
+        # A LARGE program (the Falcon 9 tick: ~6 s per hipcc run, and its first flag set spills) starts every flag set AT ONCE and
+        # keeps the first spill-free one in priority order, stopping the rest: a cold build costs the slowest attempt, not their sum
+        # (19 -> ~7 s).  Small programs pass on the first set nearly always: they try one at a time as before.
+        speculative = len(src) > SPECULATIVE_MIN_SOURCE and os.environ.get("SIXDOF_SERIAL_BUILD", "") != "1"
+        procs = []
+        try:
+            if speculative:
+                for opt, flags in _ATTEMPTS:
+                    obj = temp(".so.tmp")
+                    procs.append((opt, flags, obj, subprocess.Popen(command(opt, flags, obj), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                                                      start_new_session=True)))       # its own process group: hipcc's children stop with it
+                    build_stats["hipcc_invocations"] += 1
+            for k, (opt, flags) in enumerate(_ATTEMPTS):
+                if speculative:
+                    _, _, obj, pr = procs[k]
+                    _, err = pr.communicate()
+                    used = verdict(opt, flags, pr.returncode, err)
+                else:
+                    obj = temp(".so.tmp")
+                    res = subprocess.run(command(opt, flags, obj), capture_output=True, text=True)
+                    build_stats["hipcc_invocations"] += 1
+                    used = verdict(opt, flags, res.returncode, res.stderr)
+                if best is None or used["vgpr_spills"] < best["vgpr_spills"]:
+                    best, best_obj = used, obj
+                if used["vgpr_spills"] == 0:
+                    break
+        finally:
+            for _, _, _, pr in procs:
+                if pr.poll() is None:
+                    import signal
+                    try:
+                        os.killpg(pr.pid, signal.SIGKILL)      # exactly the group started above
+                    except OSError:
+                        pr.kill()
+                    pr.communicate()
         if best["vgpr_spills"] > 0:
             if not allow_spills:
                 mt = temp(".json.tmp")

@@ -158,11 +158,14 @@ class HipExec:
                     self._column_soa, self._window_soa = bool(custom.column_soa), False
                 memo = effectors.__dict__.get("_exec_memo") if reuse_trace and hasattr(effectors, "__dict__") else None
                 bkey = ("build", id(custom), self.dtype.name, integrator, bool(fast_math), self._window_soa, self._column_soa, guard_selects,
+                        self.world_pos.shape[0] * self.dtype.itemsize * (32 + sum(int(w_) for _, w_ in custom.columns)) <= (768 << 20),
                         tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("SIXDOF_"))))
                 so = memo.get(bkey) if memo is not None else None
                 if so is None or not Path(so).exists():
+                    row_elems = 32 + sum(int(w_) for _, w_ in custom.columns)       # what fill_step_params counts (csrc/sixdof_capi.cpp)
                     so = codegen.build(custom, self.dtype.name, integrator, fast_math=fast_math, window_soa=self._window_soa,
-                                       column_soa=self._column_soa, guard_selects=guard_selects)
+                                       column_soa=self._column_soa, guard_selects=guard_selects,
+                                       policy=codegen.policy_for(self.world_pos.shape[0], row_elems, self.dtype.itemsize))
                     if memo is not None:
                         memo[bkey] = so
                 for name, width in custom.columns:
