@@ -129,6 +129,7 @@ SYMBOLS = {
     "sixdof_history_stream": (C.c_int, [_H, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]),
     "sixdof_set_model_apollo": (C.c_int, [_H, C.c_void_p]),
     "sixdof_download_column": (C.c_int, [_H, C.c_uint64]),
+    "sixdof_upload_column": (C.c_int, [_H, C.c_uint64]),
     "sixdof_tick_slots": (C.c_int, [_H, C.POINTER(Slot), C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Slot),
                                     C.c_size_t, C.POINTER(C.c_size_t)]),
     # the commit path's hand-off (csrc/telemetry_sink.cpp)

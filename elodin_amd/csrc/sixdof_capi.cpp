@@ -1224,6 +1224,25 @@ int sixdof_download_column(sixdof_handle* h, uint64_t component_id) {
     return SIXDOF_OK;
 }
 
+// H2D of ONE bound column: an external write to a component (StepContext.write_component, copy_db_to_world's per-component copy,
+// impeller2_server.rs:320-362) reaches the device without re-uploading — and so clobbering — the columns the host never downloaded.
+int sixdof_upload_column(sixdof_handle* h, uint64_t component_id) {
+    if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
+    Column* c = h->col(component_id);
+    if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "upload_column: unknown component");
+    if (!h->resident) return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "upload_column: nothing is resident yet (sixdof_upload first)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (c->bytes) HIP_TRY(h, hipMemcpyAsync(c->dev, c->host, c->bytes, hipMemcpyHostToDevice, h->stream));
+    if (c->joined && c->compact) {
+        hipError_t e = launch_gather_rows(c->compact, c->dev, c->d_rows, static_cast<uint32_t>(h->joined_ids.size()),
+                                          static_cast<uint32_t>(c->width), c->elem, h->stream);
+        if (e != hipSuccess) return h->hip_fail(e, "gather_rows");
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (component_id == h->id_accel) h->accel_is_host_data = true;
+    return SIXDOF_OK;
+}
+
 // Launches per replayed chain.  A long chain amortises the gap between two replays (4,096 launches: 4.96 -> 4.83 us each with
 // 128-launch chains) but starts later (100 launches as one chain: 8 % slower than 32 + 32 + 32 + 4), so a batch OPENS with a
 // 32-launch chain and, when at least four fit, continues with 128-launch ones (profiles/r02_graph_len_ab.txt).  SIXDOF_GRAPH_LONG=<n> overrides the

@@ -293,6 +293,26 @@ class HipExec:
             a[...] = dev.reshape(a.shape[1], a.shape[0]).T
         return self
 
+    def download_column(self, name: str) -> np.ndarray:
+        """D2H of ONE bound column (a Body column or a program component): what StepContext.read_component costs."""
+        rc = self._lib.sixdof_download_column(self._h, L.component_id(name))
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_download_column")
+        if name in self._soa:
+            a = self._aux[name]
+            a[...] = self._soa[name].reshape(a.shape[1], a.shape[0]).T
+        return getattr(self, name) if name in ("world_pos", "world_vel", "world_accel", "force", "inertia") else self._aux[name]
+
+    def upload_column(self, name: str) -> None:
+        """H2D of ONE bound column from its host array (StepContext.write_component; copy_db_to_world's per-component copy): the
+        other columns — which the host may never have downloaded — are left alone."""
+        if name in self._soa:
+            a = self._aux[name]
+            self._soa[name].reshape(a.shape[1], a.shape[0])[...] = a.T
+        rc = self._lib.sixdof_upload_column(self._h, L.component_id(name))
+        if rc != L.OK:
+            _raise(self._h, rc, "sixdof_upload_column")
+
     def component(self, name: str) -> np.ndarray:
         """A generated program's component column as the reference lays it out.  Plain columns: the [n, w] host array
         itself.  Window components (dsl.Window) are kept as a ring on the device: un-rotated here to [n, rows, w], oldest

@@ -368,6 +368,10 @@ struct sixdof_apollo_tables; /* include/sixdof_apollo.h */
 int sixdof_set_model_apollo(sixdof_handle* h, const struct sixdof_apollo_tables* tables);
 /* D2H of any bound column by id (model columns are not covered by the sixdof_download mask). */
 int sixdof_download_column(sixdof_handle* h, uint64_t component_id);
+/* H2D of ONE bound column from its host buffer: how an external write to a component (StepContext.write_component,
+ * libs/nox-py/src/step_context.rs; copy_db_to_world's per-component copy, impeller2_server.rs:320-362) reaches the device between
+ * batches without re-uploading the columns the host never downloaded.  Needs a prior sixdof_upload. */
+int sixdof_upload_column(sixdof_handle* h, uint64_t component_id);
 
 /* ---- campaign collectives: Monte-Carlo rollouts sharded over the GPUs of one node ---------------------------------------
  * The reference runs one OS process per rollout with nothing exchanged between them (libs/monte-carlo/src/lib.rs:2083): the

@@ -245,6 +245,29 @@ int f9fsw_load_profile(f9fsw* f, const double* time, const double* velocity, con
     f->prof_vspeed = vspeed;
     return 0;
 }
+/* The resampled table itself (what f9fsw_profile_table returns, shipped as elodin_amd/data/falcon9_crs12_profile.csv and checked
+ * bit for bit against f9fsw_load_profile's own resampling in tests/test_falcon9_fsw_oracle.py): for a host that has the table but
+ * not the reference's raw data file (the GPU box). */
+int f9fsw_load_table(f9fsw* f, const double* time, const double* speed, const double* alt_m, const double* vspeed, size_t n) {
+    if (!f || !time || !speed || !alt_m || !vspeed || n == 0) return -1;
+    double* c[4];
+    const double* src[4] = {time, speed, alt_m, vspeed};
+    for (int k = 0; k < 4; k++) {
+        c[k] = (double*)malloc(n * sizeof(double));
+        if (!c[k]) return -1;
+        memcpy(c[k], src[k], n * sizeof(double));
+    }
+    free(f->prof_time);
+    free(f->prof_speed);
+    free(f->prof_alt);
+    free(f->prof_vspeed);
+    f->n_prof = n;
+    f->prof_time = c[0];
+    f->prof_speed = c[1];
+    f->prof_alt = c[2];
+    f->prof_vspeed = c[3];
+    return 0;
+}
 size_t f9fsw_profile_table(const f9fsw* f, double* time, double* speed, double* alt_m, double* vspeed, size_t cap) {
     if (!f) return 0;
     for (size_t i = 0; i < f->n_prof && i < cap; i++) {

@@ -16,6 +16,7 @@ f9fsw* f9fsw_new(void);
 void f9fsw_free(f9fsw*);
 /* the recorded profile the FSW flies (ELODIN_F9_PROFILE, data/<mission>/stage1_raw.json: time s, velocity m/s, altitude km) */
 int f9fsw_load_profile(f9fsw*, const double* time, const double* velocity, const double* altitude_km, size_t n_raw);
+int f9fsw_load_table(f9fsw*, const double* time, const double* speed, const double* alt_m, const double* vspeed, size_t n);   /* the resampled table as it is */
 size_t f9fsw_profile_table(const f9fsw*, double* time, double* speed, double* alt_m, double* vspeed, size_t cap);
 /* one exchange: 49-double sensor packet in, 27-double command packet out; 0, F9FSW_BEYOND_ASCENT or -1 */
 int f9fsw_step(f9fsw*, const double* state49, double* cmd27);

@@ -26,6 +26,8 @@ def _lib():
         L.f9fsw_free.restype = None
         L.f9fsw_load_profile.argtypes = [C.c_void_p, dp, dp, dp, C.c_size_t]
         L.f9fsw_load_profile.restype = C.c_int
+        L.f9fsw_load_table.argtypes = [C.c_void_p, dp, dp, dp, dp, C.c_size_t]
+        L.f9fsw_load_table.restype = C.c_int
         L.f9fsw_profile_table.argtypes = [C.c_void_p, dp, dp, dp, dp, C.c_size_t]
         L.f9fsw_profile_table.restype = C.c_size_t
         L.f9fsw_step.argtypes = [C.c_void_p, dp, dp]
@@ -55,10 +57,16 @@ def read_raw_profile(path) -> tuple:
 class Fsw:
     """One flight-software process: `cmd = fsw.step(state)` per exchange."""
 
-    def __init__(self, profile=None):
+    def __init__(self, profile=None, table=None):
+        """profile: the raw (time, velocity, altitude_km) columns, resampled like profile.rs does; table: the resampled
+        (time, speed, alt_m, vspeed) columns themselves (elodin_amd.models.falcon9.ascent_profile(): bit-equal to the former)."""
         self._L = _lib()
         self._h = C.c_void_p(self._L.f9fsw_new())
         self.beyond_ascent = False
+        if table is not None:
+            cols = [np.ascontiguousarray(x, dtype=np.float64) for x in table]
+            if self._L.f9fsw_load_table(self._h, *[_p(c) for c in cols], cols[0].size) != 0:
+                raise ValueError("f9fsw_load_table failed")
         if profile is not None:
             t, v, a = (np.ascontiguousarray(x, dtype=np.float64) for x in profile)
             if self._L.f9fsw_load_profile(self._h, _p(t), _p(v), _p(a), t.size) != 0:

@@ -109,6 +109,12 @@ doc = {
     "body": {k: v.tolist() for k, v in body0.items()},
     "initial": {k: v.tolist() for k, v in initial.items()},
     "writes": writes,                  # {tick after which post_step wrote: {component: values}} — the flight software's answers
+    # what main.py's post_step packs besides the sensor reads: its own module-level constants, recorded as data for the live bridge
+    # (tests/falcon9_bridge.py) that flies this loop on the GPU box
+    "exchange": {"period_ticks": int(main.guidance_period_ticks), "sim_time_step": float(main.SIM_TIME_STEP),
+                 "guidance_values": [float(v) for v in main.guidance_values], "fin_wn": float(main.fin_wn),
+                 "divert_speed_cap": float(main.divert_speed_cap), "steer_tilt_cap": float(main.steer_tilt_cap), "upper_kg": float(main.upper_kg),
+                 "state_floats": int(main.STATE_FLOATS), "reads": list(main.READS)},
     "final": {"lifted": float(comps["lifted"][0, 0]), "fsw_phase": float(fsw.peek()["phase"])},
 }
 out = ROOT / "tests" / "golden" / "falcon9_main_program.json"

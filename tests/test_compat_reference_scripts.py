@@ -450,11 +450,33 @@ def test_falcon9_full_mission_script_unmodified_flies_the_closed_loop_ascent_win
                 out[name] = np.array(src[0], dtype=np.float64).reshape(-1)
             return out
     ctx = Ctx()
+    # the LIVE bridge the GPU box flies this loop with (tests/falcon9_bridge.py: the packet layout restated as data, the script's
+    # constants from the fixture) runs beside main.py's own post_step, on the same reads, with its own flight-software instance:
+    # it must write exactly what main.py writes, tick for tick — that is what pins it on the reference's code
+    from tests import falcon9_bridge
+    assert frozen["exchange"]["reads"] == list(main.READS) and frozen["exchange"]["period_ticks"] == main.guidance_period_ticks
+    twin_writes = {}
+
+    class TwinCtx:
+        def component_batch_operation(self, reads=None, writes=None):
+            if writes:
+                twin_writes.clear()
+                twin_writes.update({k: np.array(v, dtype=np.float64).reshape(-1) for k, v in writes.items()})
+                return None
+            return ctx.component_batch_operation(reads=reads)
+    twin = falcon9_bridge.Exchange(frozen["exchange"], fsw_mod.Fsw(table=__import__("elodin_amd.models.falcon9", fromlist=["x"]).ascent_profile()))
+    twin_ctx, twin_checked = TwinCtx(), 0
     cps = {c["tick"]: c for c in flight["checkpoints"] if c["tick"] <= 1000}
     worst, seen, fsw_worst = {}, 0, 0.0
     for tick in range(1, 1001):
         F = dsl_numpy.program_tick(tp, pos, vel, acc, inertia, comps, tick, plan["dt"], L.SEMI_IMPLICIT)
+        twin_writes.clear()
+        twin.post_step(tick - 1, twin_ctx)  # reads only (its writes are captured, not applied)
         main.post_step(tick - 1, ctx)       # the server loop's call after the tick (ticks_per_telemetry = 1)
+        for name, v in twin_writes.items():
+            k = name.split(".", 1)[1]
+            assert np.array_equal((body[k] if k in body else comps[k])[0], v), (tick, name)
+            twin_checked += 1
         if tick in cps:
             cp = dict(cps[tick], state={k: v for k, v in cps[tick]["state"].items() if k != "fsw"})
             cp["state"]["fsw"] = {}
@@ -474,3 +496,4 @@ def test_falcon9_full_mission_script_unmodified_flies_the_closed_loop_ascent_win
     assert seen >= 7 and len(worst) >= 45
     assert max(worst.values()) < 1e-9 and fsw_worst < 1e-9, (top, fsw_worst)
     assert float(comps["lifted"][0, 0]) == 1.0 and fsw.peek()["phase"] == 1.0      # off the pad, vertical rise
+    assert twin.exchanges == 100 and twin_checked == 700                            # 100 exchanges x 7 written components, all identical

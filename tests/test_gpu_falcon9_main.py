@@ -1,12 +1,14 @@
 """examples/falcon9/main.py — the reference's FULL mission script, 65 component columns — through its generated gfx950 kernel,
-closed loop from the pad through liftoff, against the ascent the reference's own code flew (tests/golden/falcon9_closed_loop.json).
+closed loop from the pad through liftoff with a LIVE flight software, against the ascent the reference's own code flew
+(tests/golden/falcon9_closed_loop.json).
 
-The script, its post_step and the flight-software oracle live where the reference checkout is; what runs here is the kernel
-THIS repo's code generator emitted for the unmodified script there, with the flight software's answers replayed from the
-command stream recorded there (tests/golden/make_falcon9_main_program.py: main.py's own post_step + oracle/falcon9_fsw.c around
-the CPU walk of the same program — the loop tests/test_compat_reference_scripts.py pins to 4e-15).  Plant, sensors and every
-other system are computed on the GPU tick by tick; after each tick the recorded writes of that tick are applied and uploaded,
-like copy_db_to_world does before the next batch."""
+The script lives where the reference checkout is; what runs here is the kernel THIS repo's code generator emitted for the unmodified
+script there (frozen in tests/golden/falcon9_main_program.json) and, around it, the server loop's exchange (impeller2_server.rs:
+553-678): after every tick `post_step` — tests/falcon9_bridge.py, pinned write for write on main.py's own post_step in the build
+container — reads the sensor components from the device (sixdof_download_column), packs the controller's state packet, steps the
+flight software (oracle/falcon9_fsw.c, the restatement of the Rust sidecar: parity unpinned) and uploads the commands
+before the next tick.  Nothing is replayed: a plant that drifted would be answered with different commands.  The recorded command
+stream of the CPU walk stays in the fixture and is compared with what the live loop commanded."""
 import json
 from pathlib import Path
 
@@ -32,15 +34,43 @@ def test_full_mission_script_kernel_flies_the_reference_ascent_through_liftoff()
     hip = ea.HipExec(rep(body["world_pos"]), rep(body["world_vel"]), rep(body["inertia"]), world_accel=rep(body["world_accel"]),
                      simulation_time_step=doc["simulation_time_step"], integrator=doc["integrator"], effectors=prog,
                      columns={k: rep(v) for k, v in doc["initial"].items()}, ticks_per_launch=1)
+    from elodin_amd import _lib as L
+    from elodin_amd.models import falcon9 as f9
+    from oracle import falcon9_fsw as fsw_mod
+    from tests import falcon9_bridge
+    body_names = ("world_pos", "world_vel", "world_accel", "force", "inertia")
+
+    class Ctx:                                   # el.StepContext.component_batch_operation over the executor's device columns
+        def __init__(self):
+            self.downloads = self.uploads = 0
+
+        def component_batch_operation(self, reads=None, writes=None):
+            if writes:
+                for name, v in writes.items():
+                    k = name.split(".", 1)[1]
+                    (getattr(hip, k) if k in body_names else hip._aux[k])[:] = np.asarray(v, dtype=np.float64).reshape(1, -1)
+                    hip.upload_column(k)         # ONLY the written component (copy_db_to_world, impeller2_server.rs:320-362): the plant's
+                    self.uploads += 1            # state lives on the device and the host's copy of it is stale
+                return None
+            out = {}
+            for name in reads:
+                k = name.split(".", 1)[1]
+                out[name] = np.array(hip.download_column(k)[0], dtype=np.float64).reshape(-1)
+                self.downloads += 1
+            return out
+    ctx = Ctx()
+    live = falcon9_bridge.Exchange(doc["exchange"], fsw_mod.Fsw(table=f9.ascent_profile()))
+    commanded = {}
     cps = {c["tick"]: c for c in flight["checkpoints"] if c["tick"] <= doc["ticks"]}
     worst, seen = {}, 0
     for tick in range(1, doc["ticks"] + 1):
-        hip.run(1)
-        w = doc["writes"].get(str(tick))
-        if w:                                                         # post_step's writes after this tick (the FSW's commands)
-            for comp, v in w.items():
-                (getattr(hip, comp) if comp in ("world_pos", "world_vel") else hip._aux[comp])[:] = np.asarray(v)
-            hip.upload()
+        hip.invoke_batch(1)                      # the tick; nothing is downloaded unless the exchange or a checkpoint asks
+        before = ctx.uploads
+        live.post_step(tick - 1, ctx)            # the server loop's call after the tick (ticks_per_telemetry = 1)
+        if ctx.uploads != before:
+            commanded[str(tick)] = {k: np.array(hip._aux[k][0]).tolist() for k in doc["writes"][str(tick)]} if str(tick) in doc["writes"] else None
+        if tick in cps:
+            hip.download()
         if tick in cps:
             cp = dict(cps[tick], state={k: v for k, v in cps[tick]["state"].items() if k != "fsw"})
             cp["state"]["fsw"] = {}
@@ -54,7 +84,13 @@ def test_full_mission_script_kernel_flies_the_reference_ascent_through_liftoff()
                 assert np.array_equal(full, np.repeat(full[:1], n, axis=0)), name
             seen += 1
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
-    print(f"examples/falcon9/main.py unmodified, generated kernel, closed loop (FSW replayed): worst of {len(worst)} quantities at {seen} "
+    # what the live loop commanded is what main.py's own post_step commanded on the CPU walk of the same program: same exchange
+    # ticks, and the commands equal to within the plant's own agreement
+    assert sorted(commanded, key=int) == sorted(doc["writes"], key=int) and live.exchanges == 100 and ctx.uploads == 700
+    cmd_dev = max(float(np.max(np.abs(np.asarray(commanded[t][k]) - np.asarray(v)))) for t, w in doc["writes"].items() for k, v in w.items())
+    print(f"live exchange: {live.exchanges} exchanges, {ctx.downloads} column downloads, {ctx.uploads} uploads; commands vs the recorded stream: max |d| {cmd_dev:.1e}")
+    assert cmd_dev < 1e-9
+    print(f"examples/falcon9/main.py unmodified, generated kernel, closed loop (LIVE flight software): worst of {len(worst)} quantities at {seen} "
           f"checkpoints:", ", ".join(f"{k} {e:.1e}" for k, e in top))
     assert seen >= 7 and len(worst) >= 45 and max(worst.values()) < 1e-9, top
     assert float(hip._aux["lifted"][0, 0]) == doc["final"]["lifted"] == 1.0

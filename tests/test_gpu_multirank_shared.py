@@ -105,7 +105,13 @@ def test_the_drivers_multi_rank_command_prints_config_2_and_both_campaigns_stron
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["entities_per_gpu"] == 65536 and line["value"] > 0
     assert "DRY RUN" in line["config"]["parallelism"]
+    # the line attests what the process group IS: backend, the group's own world size, every rank's device
+    att = line["rccl"]
+    assert att["backend"] == "gloo" and att["world_size"] == 2 and [r["rank"] for r in att["ranks"]] == [0, 1]
+    assert all(r["device_index"] == 0 and r["pci_bus_id"] for r in att["ranks"]) and att["distinct_devices"] is False      # one GPU, said so
+    assert abs(line["n1_reference_value"]["value_per_gpu"] * 2 - line["value"]) < 1.0
     camp = line["campaigns"]
+    assert all("valu issue" == camp[w_][s_]["roofline"]["bound"] and "unpinned" in camp[w_][s_]["parity"] for w_ in camp for s_ in camp[w_])
     for which, total in (("apollo", 8192), ("falcon9", 32768)):
         s, w = camp[which]["strong"], camp[which]["weak"]
         assert "error" not in s and "error" not in w, (s, w)
