@@ -1,24 +1,37 @@
 """StableHLO text -> this package's scalar DAG (SURVEY §8 f1 in its literal form): the MLIR module the reference dumps before its
 JIT (`ELODIN_CRANELIFT_DEBUG_DIR/stablehlo.mlir`, libs/nox-py/src/cranelift_compile.rs:47-68), or the text of any
-`jax.jit(f).lower(...).as_text()`, ingested as PER-ENTITY code: `@main`'s tensor arguments are an entity's components, its
-results the components it writes, every tensor a small static array whose elements become nodes of elodin_amd.dsl — and from
-there the same code generator, the same fused kernel.
+`jax.jit(f).lower(...).as_text()`, read by the textual form the reference's own parser reads (libs/cranelift-mlir/src/parser.rs) and
+turned into code of the SAME generated kernel the tracer feeds (elodin_amd.dsl -> codegen.py).  Three ways in:
 
-What is read: the textual form the reference's own parser reads (libs/cranelift-mlir/src/parser.rs) for the op set its
-ARCHITECTURE.md lists, minus what only a whole-world (entity-batched) tick needs: element-wise arithmetic / transcendentals /
-comparisons / bit operations, constant, iota, convert, select, clamp, broadcast_in_dim, reshape, transpose, slice, concatenate,
-reverse, dot_general (batching + contracting dims), reduce (`applies` form and reducer regions), while, case, func.call,
-dynamic_slice, dynamic_update_slice, gather (the index-clamping general form), sort (1-D, comparator LT / GT), cholesky,
-triangular_solve, scatter (one operand, no batching dims: `x.at[i].set / .add`), real_dynamic_slice, reduce_window,
-select_and_scatter, the LAPACK FFI custom calls jax.numpy.linalg lowers to on CPU (dpotrf, dtrsm, dgetrf with LAPACK's pivots
-and row order, dgesv, dgesdd), chlo.{erf_inv, square, acos, asin, sinh, cosh, erfc, ...}.  Integer tensors are integral
-values in the executor's float type (exact up to 2^53 in f64), like everywhere in the tracer.  Not read: convolution, rng,
-batch_norm, the remaining LAPACK calls (gees, geev, ...) — an unsupported op says which.  (dgeqrf / dorgqr — `jnp.linalg.qr` — and
-dsyevd — `eigh` — are read too; the reference's op tests hold no answers for them: pinned on LAPACK itself through scipy.)
+* `system(text, inputs, outputs)` — a PER-ENTITY function: `@main`'s tensor arguments are one entity's components, every tensor a
+  small static array whose elements become nodes.
+* `world_system(text, slots, mode=...)` / `compile_world` / `python -m elodin_amd.stablehlo tick.mlir --slots slots.json -o pipe.so` —
+  a WHOLE-WORLD tick, what the reference actually hands a backend: `@main` over entity-batched `[N, w]` columns.  mode "lane": the
+  entity axis becomes the executor's rows (_LaneEval follows it through every statement and refuses whatever moves data between
+  entities; no `[N, ...]` tensor is ever materialised, 65,536 bodies trace like twelve); mode "world": the whole world in one lane,
+  rows = independent worlds (edge folds, joins, reductions over the world are index arithmetic inside a lane); "auto" tries the
+  former and falls back to the latter, recording why.  INTEGRATION.md §2b has the host side.
+* `load_world(pipe.so)` — the CLI's object + manifest back as a program an executor installs as it is.
 
-Pinned on the known answers of the reference's own op tests (libs/cranelift-mlir/tests/ops.rs: inline modules with expected
-outputs -> tests/golden/stablehlo_ops.json, tests/test_stablehlo_ingest.py on the CPU walker, tests/test_gpu_stablehlo.py on
-the generated kernel).
+What is read: element-wise arithmetic / transcendentals / comparisons / bit operations, constant (decimal, hex bit patterns of floats,
+hex byte blobs), iota, convert, bitcast_convert, select, clamp, broadcast_in_dim, reshape, transpose, slice, concatenate, reverse,
+pad, dot_general (batching + contracting dims), reduce (`applies` form and reducer regions), while (unrolled when its trip count is
+known while tracing, else a real loop), case, func.call, dynamic_slice, dynamic_update_slice, gather (the index-clamping general form),
+sort (1-D), cholesky, triangular_solve, scatter, real_dynamic_slice, reduce_window, select_and_scatter, batch_norm_inference, map, the
+LAPACK FFI custom calls jax.numpy.linalg lowers to on CPU (dpotrf, dtrsm, dgetrf with LAPACK's pivots and row order, dgesv, dgesdd,
+dgeqrf / dorgqr, dsyevd), chlo.{erf_inv, square, acos, asin, sinh, cosh, erfc, ...}.  INTEGERS have the machine's semantics: results of
+add / subtract / multiply / negate / shifts / convert wrap to the declared width for types of 32 bits or fewer, `ui64` is exact as two
+uint32 words (U64) — jax.random's threefry rounds and its bits -> mantissa -> bitcast construction run bit for bit — and `i64` is one
+node, exact below 2^53 (ticks, counters, indices, seeds; no wrap at 2^63).  Not read: convolution, fft, rng, the remaining LAPACK calls
+— an unsupported op says which.
+
+Pinned on the reference's own tests: libs/cranelift-mlir/tests/ops.rs (198 inline modules with asserted outputs ->
+tests/golden/stablehlo_ops.json; the 22 not extracted are listed there with the reason), the world-tick fragments of
+test_gather_3body / test_dynamic_ops_3body / test_while_dyn_slice / test_closed_call / test_threefry / test_threefry_e2e /
+test_uniform_pipeline.rs (-> tests/golden/stablehlo_world_fragments.json, 22 cases, integers compared exactly), and G1's 100
+three-body ticks through an assembled whole-world module (tests/golden/hlo_world_builder.py) — CPU walker:
+tests/test_stablehlo_ingest.py, tests/test_stablehlo_world.py; generated kernel: tests/test_gpu_stablehlo.py,
+tests/test_gpu_stablehlo_world.py.
 """
 from __future__ import annotations
 

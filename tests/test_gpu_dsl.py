@@ -680,3 +680,31 @@ def test_fast_math_bits_do_not_depend_on_the_launch_shape_and_a_program_object_i
     assert np.array_equal(hist[-1], runs[0]["derived"]) and not np.array_equal(hist[0], hist[-1])      # recorded on every tick
     memo = prog._exec_memo
     assert sum(1 for key in memo if key[0] == "trace") == 1 and sum(1 for key in memo if key[0] == "build") == 1
+
+
+def test_a_program_object_is_traced_again_unless_the_caller_promises_it_did_not_change():
+    """the trace memo is opt-in.  A system that closes over a Python gain is re-traced by every executor, so changing
+    the gain between two executors changes what the second computes; with reuse_trace=True the FIRST trace is kept (the promise)."""
+    gain = [2.0]
+
+    @dsl.system
+    def scale(x):
+        return {"x": x * gain[0]}
+    prog = dsl.Program([scale], dsl.Pipe([]), [])
+    n = 64
+    w = workloads.independent_bodies(n)
+    x0 = np.arange(n, dtype=np.float64).reshape(n, 1) + 1.0
+
+    def run(**kw):
+        hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=L.INTEGRATOR_NONE, effectors=prog, columns={"x": x0}, **kw)
+        hip.run(1)
+        out = np.array(hip._aux["x"])
+        hip.close()
+        return out
+    assert np.array_equal(run(), 2.0 * x0)
+    gain[0] = 3.0
+    assert np.array_equal(run(), 3.0 * x0) and "_exec_memo" not in prog.__dict__       # traced again: the new gain
+    assert np.array_equal(run(reuse_trace=True), 3.0 * x0)
+    gain[0] = 5.0
+    assert np.array_equal(run(reuse_trace=True), 3.0 * x0)                              # the promise: the first kept trace
+    assert np.array_equal(run(), 5.0 * x0)

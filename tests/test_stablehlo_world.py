@@ -164,3 +164,52 @@ def test_slots_from_the_references_exec_metadata_json():
     ins, outs = sh.slots_from_metadata(json.loads(json.dumps(doc)))
     assert [(s.component, s.shape, s.elided, s.component_id) for s in ins] == [("world_pos", (3, 7), False, 7), ("tick", (), True, 3)]
     assert [s.component for s in outs] == ["tick", "world_pos"] and ins[0].column == "hlo_world_pos"
+
+
+def test_lane_mode_and_world_mode_agree_on_an_entity_parallel_tick():
+    """Differential: the SAME whole-world module (four independent bodies: small enough for one lane per world) ingested both ways —
+    one lane per entity, and the whole world in one lane (the plain evaluator, no entity-axis reasoning at all) — gives the same
+    columns bit for bit on the CPU walker."""
+    n = 4
+    text, slots, cols = W.independent_bodies(n, seed=11)
+    dt = orc.quantize_time_step(120.0)
+    lane_sys, lane_m = sh.world_system(text, slots, mode="lane")
+    world_sys, world_m = sh.world_system(text, slots, mode="world")
+    assert lane_m["mode"] == "lane" and world_m["mode"] == "world"
+    lw = {c["column"]: c["width"] for c in lane_m["columns"]}
+    ww = {c["column"]: c["width"] for c in world_m["columns"]}
+    assert ww["hlo_world_pos"] == 7 * n and lw["hlo_world_pos"] == 7
+    lane = {"hlo_" + k: np.array(v) for k, v in cols.items()}
+    lane["hlo_tick"], lane["hlo_simulation_time_step"] = np.zeros((n, 1)), np.full((n, 1), dt)
+    world = {"hlo_" + k: np.tile(np.array(v).reshape(1, -1), (2, 1)) for k, v in cols.items()}
+    world["hlo_tick"], world["hlo_simulation_time_step"] = np.zeros((2, 1)), np.full((2, 1), dt)
+    walk(lane_sys, lw, lane, 8)
+    walk(world_sys, ww, world, 8)
+    for c in ("world_pos", "world_vel", "world_accel", "force"):
+        assert np.array_equal(lane["hlo_" + c].reshape(-1), world["hlo_" + c][0]), c
+    assert lane["hlo_tick"][0, 0] == world["hlo_tick"][0, 0] == 8
+
+
+def test_batched_cholesky_and_triangular_solve_ride_the_entity_axis():
+    """`jnp.linalg.cholesky` / `solve_triangular` vmapped over the entities: [N, 3, 3] operands whose leading axis is the entity
+    axis (the reference's test_cholesky_batched_mem only asserts a reconstruction; here: numpy per entity)."""
+    text = """
+module @module {
+  func.func public @main(%arg0: tensor<5x3x3xf64>, %arg1: tensor<5x3x1xf64>) -> (tensor<5x3x3xf64>, tensor<5x3x1xf64>) {
+    %0 = stablehlo.cholesky %arg0, lower = true : tensor<5x3x3xf64>
+    %1 = "stablehlo.triangular_solve"(%0, %arg1) <{left_side = true, lower = true, transpose_a = #stablehlo<transpose NO_TRANSPOSE>, unit_diagonal = false}> : (tensor<5x3x3xf64>, tensor<5x3x1xf64>) -> tensor<5x3x1xf64>
+    return %0, %1 : tensor<5x3x3xf64>, tensor<5x3x1xf64>
+  }
+}"""
+    system, manifest = sh.world_system(text, [("a", [5, 3, 3], False), ("b", [5, 3, 1], False)], [("l", [5, 3, 3], False), ("y", [5, 3, 1], False)], mode="lane")
+    widths = {c["column"]: c["width"] for c in manifest["columns"]}
+    rng = np.random.default_rng(9)
+    m = rng.normal(size=(5, 3, 3))
+    a = m @ np.transpose(m, (0, 2, 1)) + 3.0 * np.eye(3)
+    b = rng.normal(size=(5, 3, 1))
+    comps = {"hlo_a": a.reshape(5, 9), "hlo_b": b.reshape(5, 3)}
+    walk(system, widths, comps, 1)
+    L_ = np.linalg.cholesky(a)
+    got_l = comps["hlo_l"].reshape(5, 3, 3)
+    assert np.allclose(np.tril(got_l), L_, rtol=1e-13, atol=1e-15)
+    assert np.allclose(comps["hlo_y"].reshape(5, 3, 1), np.linalg.solve(L_, b), rtol=1e-12, atol=1e-14)
