@@ -1550,7 +1550,7 @@ _RETRY_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills"]
 # Builds are tried in this order and the FIRST without VGPR spills is kept.  The last resort trades speed for a smaller
 # live set (-O1: no unrolling / less hoisting); the fuzz program that miscomputed when spilling is exact at -O1.
 _ATTEMPTS = (("-O3", _BASE_FLAGS), ("-O3", _BASE_FLAGS + _RETRY_FLAGS), ("-O1", []))
-_CACHE_TAG = "rp2"           # bump when the flag policy changes: cached objects are keyed on it
+_CACHE_TAG = "rp3"           # bump when the flag policy changes: cached objects are keyed on it
 SPECULATIVE_MIN_SOURCE = 120_000      # characters of generated source from which the flag sets of _ATTEMPTS are compiled concurrently
 build_stats: Dict[str, float] = {"hipcc_invocations": 0, "cache_hits": 0}      # since import (bench.py reports them per program)
 ALLOW_SPILLS_ENV = "SIXDOF_ALLOW_SPILLS"   # "1": accept a build that still spills VGPRs (known-unsafe on gfx950, see above)
@@ -1608,6 +1608,13 @@ def _compile(src: str, stem: str) -> Path:
     # 15 % fewer AGPR moves in the Falcon 9 tick (flight 0.765 -> 0.737 s; "max-ilp": 0.745).  Exact builds keep the
     # default scheduler they were validated under.
     ilp = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"] if "#define SIXDOF_FAST_MATH" in src and os.environ.get("SIXDOF_ILP_SCHED", "1") != "0" else []
+    # ... and WITHOUT LLVM's SLP vectoriser.  On gfx950 it pairs isomorphic f32 operations into v_pk_{add,mul,fma}_f32 (441 packed
+    # instructions in the Falcon 9 tick, 700 fewer static VALU), and a packed instruction does take ONE issue slot of a lone wave
+    # (tools/ubench/pk_f32.hip, profiles/r05_ubench_pk_f32.txt) — but the register pairs it needs are assembled and taken apart by
+    # moves, and the flight is FASTER the less is packed: 3.763 us per tick (default) > 3.690 / 3.673 / 3.653 (slp-threshold 4 / 12 /
+    # 32) > 3.622 with the vectoriser off (profiles/r05_falcon9_pk_ab.txt; three interleaved passes, +-0.002).  SIXDOF_SLP=1 keeps it.
+    if ilp and os.environ.get("SIXDOF_SLP", "0") != "1":
+        ilp = ilp + ["-fno-slp-vectorize"]
     digest = hashlib.sha1((src + _headers_digest() + " ".join(extra + ilp) + _CACHE_TAG + _hipcc_version()).encode()).hexdigest()[:16]
     JIT_DIR.mkdir(exist_ok=True)
     so = JIT_DIR / f"{stem}_{digest}.so"
@@ -1621,7 +1628,7 @@ def _compile(src: str, stem: str) -> Path:
             pass
         last_resources = json.loads(meta.read_text()) if meta.exists() else {}
         if last_resources.get("vgpr_spills", 0) > 0:    # only an opted-in build can be here: say so on every use
-            if not allow_spills:
+            if not allow_spills and not (os.environ.get(ALLOW_SPILLS_ENV, "") == "checked" and last_resources.get("spills_checked")):
                 raise SpillError(_spill_message(so.name, last_resources) + f" (cached object built under {ALLOW_SPILLS_ENV}=1; "
                                  "set it again to use it)")
             warnings.warn(_spill_message(so.name, last_resources), RuntimeWarning, stacklevel=3)
@@ -1677,9 +1684,12 @@ def _compile(src: str, stem: str) -> Path:
                     res = subprocess.run(command(opt, flags, obj), capture_output=True, text=True)
                     build_stats["hipcc_invocations"] += 1
                     used = verdict(opt, flags, res.returncode, res.stderr)
-                if best is None or used["vgpr_spills"] < best["vgpr_spills"]:
+                # fewest VGPR spills first, then least scratch: a build without VGPR spills may still keep something in scratch
+                # memory (SGPR spill carriers), and a later flag set that needs none is the better object
+                cost = lambda u: (u["vgpr_spills"], u.get("scratch_bytes_per_lane", 0))
+                if best is None or cost(used) < cost(best):
                     best, best_obj = used, obj
-                if used["vgpr_spills"] == 0:
+                if cost(used) == (0, 0):
                     break
         finally:
             for _, _, _, pr in procs:
@@ -1690,6 +1700,14 @@ def _compile(src: str, stem: str) -> Path:
                     except OSError:
                         pr.kill()
                     pr.communicate()
+        if best["vgpr_spills"] > 0 and os.environ.get(ALLOW_SPILLS_ENV, "") == "checked":
+            # opt-in middle ground: accept the spilling object only when every spill slot (scratch and SGPR-in-lane) is provably
+            # written on every path before it is read (elodin_amd/isa_check.py)
+            from . import isa_check
+            dirty = [f for _, lines in isa_check.kernels(isa_check.disassemble(Path(best_obj))).items() for f in isa_check.analyse(lines)[0]]
+            if not dirty:
+                best = dict(best, spills_checked="every spill slot written before read on every path (isa_check)")
+                allow_spills = True
         if best["vgpr_spills"] > 0:
             if not allow_spills:
                 mt = temp(".json.tmp")

@@ -107,6 +107,11 @@ class HipExec:
                 widths = {k: (tuple(int(x) for x in np.shape(v)[1:]) if np.ndim(v) == 3 else int(np.atleast_2d(np.asarray(v)).shape[-1]))
                           for k, v in (columns or {}).items()}
                 fold_rows = None
+                # A Pipe / Program keeps its first trace (`_traced`).  An executor starts from a FRESH one unless the caller promises
+                # (reuse_trace=True) that nothing a trace reads has changed since: the program's systems, and every Python value their
+                # functions close over (gains, host tables, parameter sentinels).  A frozen program has no functions to trace again.
+                if not reuse_trace and not isinstance(effectors, _dsl.FrozenProgram) and getattr(effectors, "_traced", None) is not None:
+                    effectors._traced = None
                 if isinstance(effectors, _dsl.Program) and effectors.folds:
                     # stand-alone folds inside the program: their edges as row pairs of this executor (spawn order)
                     if self._column_ids:

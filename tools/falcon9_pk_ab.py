@@ -14,7 +14,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
 
-FLAGS = ["", "-mllvm -slp-threshold=4", "-mllvm -slp-threshold=12", "-mllvm -slp-threshold=32", "-fno-slp-vectorize", "-mllvm -slp-threshold=-4"]
+FLAGS = ["", "-fslp-vectorize", "-fslp-vectorize -mllvm -slp-threshold=12", "-fslp-vectorize -mllvm -slp-threshold=32"]      # "" = the product's build: vectoriser off
 REPEATS = 3          # whole passes over FLAGS, interleaved: box drift and clock settling hit every variant alike
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
@@ -56,7 +56,7 @@ def main():
             ex.close()
     for fl in FLAGS:
         res, mix = info[fl]
-        print(f"{fl or '(default: SLP on)':34s} {min(times[fl]):26.3f} {' '.join(f'{t:.3f}' for t in times[fl]):>30s} {mix.get('valu', 0):11d} {mix.get('pk_f32', 0):7d} "
+        print(f"{fl or '(product: SLP off)':34s} {min(times[fl]):26.3f} {' '.join(f'{t:.3f}' for t in times[fl]):>30s} {mix.get('valu', 0):11d} {mix.get('pk_f32', 0):7d} "
               f"{mix.get('scalar_f32', 0):10d} {mix.get('moves', 0):6d}  vgprs {res.get('vgprs')} agprs {res.get('agprs')} scratch {res.get('scratch_bytes_per_lane')}")
 
 
