@@ -2109,7 +2109,12 @@ def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = Non
                         raise NotEntityParallel(f"result {s_.component}: the entity axis is not its leading axis")
                     if not s_.elided and o.eaxis is None and 0 not in o.uni and o.tshape and o.tshape[0] > 1:
                         raise NotEntityParallel(f"result {s_.component} is per-entity data that does not come from a column of the world")
-                res[s_.column] = _dsl.Vec(_column_values(o))
+                vals = _column_values(o)
+                src = cols.get(s_.column)
+                src = (list(src.e) if isinstance(src, _dsl.Vec) else [src]) if src is not None else None
+                if src is not None and len(src) == len(vals) and all(a is b for a, b in zip(src, vals)):
+                    continue                          # the tick hands the column back untouched (inertia, a parameter column): no store
+                res[s_.column] = _dsl.Vec(vals)
             return res
         fn.__name__ = name
         import inspect
