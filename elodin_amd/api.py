@@ -407,6 +407,11 @@ class World:
             edges = self.edge_pairs(system.edge_component)
             names = dict.fromkeys(system.left + system.right + (system.out,))
             return GraphFoldExec(system, {n: self.column(n) for n in names}, edges, device=device)
+        # one build = one trace: whatever trace the system's effector pipe kept from an earlier build is dropped here (its functions
+        # may close over values that changed since), everything below shares the fresh one and hands it to the executor as it is
+        eff0 = getattr(system, "effectors", None)
+        if isinstance(eff0, (_dsl.Pipe, _dsl.Program)) and not isinstance(eff0, _dsl.FrozenProgram) and getattr(eff0, "_traced", None) is not None:
+            eff0._traced = None
         program_stages = None
         substeps = 1
         if isinstance(system, _dsl.System):
@@ -646,7 +651,8 @@ class World:
                       integrator=L.INTEGRATOR_NONE if getattr(system, "no_six_dof", False) else system.integrator.value,
                       effectors=effs, edges=edges,
                       ticks_per_launch=ticks_per_telemetry * (substeps if program_stages is not None else 1), device=device,
-                      column_entity_ids=None if same else column_ids, columns=extra_columns)
+                      column_entity_ids=None if same else column_ids, columns=extra_columns,
+                      reuse_trace=True)      # traced above, in THIS build, with the presence masks and fold rows the executor cannot know
         ex = Exec(hip, self, ticks_per_telemetry, dt)
         ex._substeps = substeps if program_stages is not None else 1
         ex._partial = self_partial

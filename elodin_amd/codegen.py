@@ -466,6 +466,7 @@ def _pressure_order(need: Dict[int, "dsl.Expr"], roots: Sequence["dsl.Expr"]) ->
 
 
 _ESTIMATE: List[Optional[Dict[str, int]]] = [None]
+_EXPECT_SCRATCH = [False]      # the variant being compiled keeps state in private memory by design ("memory")
 
 
 def _peak_live(order, deps, users: Dict[int, int]) -> int:
@@ -1505,7 +1506,11 @@ def _build(tp, dtype, integrator, fast_math, window_soa, column_soa, guard_selec
     for k, variant in enumerate(variants):
         try:
             src_k = first_src if (k == 0 and first_src is not None) else generate_variant(tp, variant, dtype, integrator, fast_math, window_soa, column_soa, guard_selects)
-            so = _compile(src_k, "pipe")
+            _EXPECT_SCRATCH[0] = variant == "memory"
+            try:
+                so = _compile(src_k, "pipe")
+            finally:
+                _EXPECT_SCRATCH[0] = False
             last_variant[0] = variant
             return so
         except SpillError:
@@ -1678,15 +1683,20 @@ def _compile(src: str, stem: str) -> Path:
                 if speculative:
                     _, _, obj, pr = procs[k]
                     _, err = pr.communicate()
-                    used = verdict(opt, flags, pr.returncode, err)
+                    rc_k, err_k = pr.returncode, err
                 else:
                     obj = temp(".so.tmp")
                     res = subprocess.run(command(opt, flags, obj), capture_output=True, text=True)
                     build_stats["hipcc_invocations"] += 1
-                    used = verdict(opt, flags, res.returncode, res.stderr)
+                    rc_k, err_k = res.returncode, res.stderr
+                if rc_k != 0 and best is not None and best["vgpr_spills"] == 0:
+                    continue          # this flag set does not even compile (an -O1 backend assertion): an acceptable object already exists
+                used = verdict(opt, flags, rc_k, err_k)
                 # fewest VGPR spills first, then least scratch: a build without VGPR spills may still keep something in scratch
                 # memory (SGPR spill carriers), and a later flag set that needs none is the better object
-                cost = lambda u: (u["vgpr_spills"], u.get("scratch_bytes_per_lane", 0))
+                # (the memory-image variant keeps its columns in scratch on purpose: there only the spill count decides)
+                by_design = _EXPECT_SCRATCH[0] or "        volatile T c" in src          # (a frozen text of that variant says so itself)
+                cost = lambda u: (u["vgpr_spills"], 0 if by_design else u.get("scratch_bytes_per_lane", 0))
                 if best is None or cost(used) < cost(best):
                     best, best_obj = used, obj
                 if cost(used) == (0, 0):

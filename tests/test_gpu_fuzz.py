@@ -19,9 +19,11 @@ from tests.fuzz_gen import Gen, columns, make_program, twin_run  # noqa: E402,F4
 
 
 def run_both(prog, cols, ticks, dtype):
+    # reuse_trace=True everywhere in this file: a fuzz program's functions DRAW their expressions from a seeded generator while they
+    # are traced, so a second trace of the same object is another program — the first one is the program under test
     n = len(cols["x"])
     w = workloads.independent_bodies(n)
-    hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=dtype, integrator=L.INTEGRATOR_NONE, effectors=prog,
+    hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=dtype, integrator=L.INTEGRATOR_NONE, effectors=prog, reuse_trace=True,
                      columns={k: v.copy() for k, v in cols.items()})
     hip.run(ticks)
     tp = prog.trace({k: v.shape[1] for k, v in cols.items()})
@@ -103,7 +105,7 @@ def test_random_effector_pipes_through_the_integrator(seed):
     kcol = np.random.default_rng(seed).uniform(-1.0, 1.0, (n, 3))
     prog = dsl.Program([], first | second, [])
     hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=dt, integrator=L.SEMI_IMPLICIT,
-                     effectors=prog, columns={"k": kcol})
+                     effectors=prog, reuse_trace=True, columns={"k": kcol})
     hip.run(5)
     tp = prog.trace({"k": 3})
     pos, vel, inertia = (np.array(w[k], dtype=np.float64) for k in ("world_pos", "world_vel", "inertia"))
@@ -160,7 +162,7 @@ def test_random_program_f32_fast_math():
     prog, cols = make_program(202, depth=3), columns(202, 2048)
     n = len(cols["x"])
     w = workloads.independent_bodies(n)
-    hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=np.float32, integrator=L.INTEGRATOR_NONE, effectors=prog,
+    hip = el.HipExec(w["world_pos"], w["world_vel"], w["inertia"], dtype=np.float32, integrator=L.INTEGRATOR_NONE, effectors=prog, reuse_trace=True,
                      columns={k: v.copy() for k, v in cols.items()}, fast_math=True)
     hip.run(1)
     _, want = run_both(prog, cols, 1, np.float32)
