@@ -153,6 +153,42 @@ class Fn:
                   f"({a.ty}, {', '.join(s.ty for s in starts)}) -> {r.ty}")
         return r
 
+
+    def _cmp(self, direction, a: V, b: V, kind="FLOAT") -> V:
+        r = self._new(a.shape, "i1")
+        self.emit(f"{r.name} = stablehlo.compare  {direction}, {a.name}, {b.name},  {kind} : ({a.ty}, {b.ty}) -> {r.ty}")
+        return r
+
+    def select(self, c: V, a: V, b: V) -> V:
+        r = self._new(a.shape, a.dtype)
+        self.emit(f"{r.name} = stablehlo.select {c.name}, {a.name}, {b.name} : {c.ty}, {r.ty}")
+        return r
+
+    def maximum(self, a, b): return self._bin("maximum", a, b)
+    def bit_and(self, a, b): return self._bin("and", a, b)
+    def bit_or(self, a, b): return self._bin("or", a, b)
+    def shl(self, a, b): return self._bin("shift_left", a, b)
+    def shr(self, a, b): return self._bin("shift_right_logical", a, b)
+
+    def bitcast(self, a: V, dtype: str) -> V:
+        r = self._new(a.shape, dtype)
+        self.emit(f"{r.name} = stablehlo.bitcast_convert {a.name} : ({a.ty}) -> {r.ty}")
+        return r
+
+    def iota(self, shape, dim, dtype) -> V:
+        r = self._new(shape, dtype)
+        self.emit(f"{r.name} = stablehlo.iota dim = {dim} : {r.ty}")
+        return r
+
+    def erf_inv(self, a: V) -> V:
+        r = self._new(a.shape, a.dtype)
+        self.emit(f"{r.name} = chlo.erf_inv {a.name} : {a.ty} -> {r.ty}")
+        return r
+
+    def raw_function(self, text: str):
+        """A function given as text (the reconstructed jax.random functions of make_stablehlo_world_golden.py)."""
+        self._raw = text
+
     def call(self, fn: "Fn", args: Sequence[V]) -> List[V]:
         outs = [V(None, v.shape, v.dtype) for v in fn.results]
         base = f"%{self.n}"
@@ -394,6 +430,92 @@ def independent_bodies_world(n: int):
     slots = [("tick", [], True), ("simulation_time_step", [], True), ("world_pos", [n, 7], False), ("world_vel", [n, 6], False),
              ("world_accel", [n, 6], False), ("force", [n, 6], False), ("inertia", [n, 7], False), ("torque", [n, 3], False)]
     return module([main, inner]), slots
+
+
+class RawFn:
+    """A private function whose text exists already; `results` is what call() needs to type its outputs."""
+    def __init__(self, name: str, text: str, results: Sequence[V]):
+        self.name, self._text, self.results = name, text, list(results)
+
+    def text(self) -> str: return self._text
+
+
+def ball_world():
+    """examples/ball as ONE tick of its singleton world (one entity: every column has its entity axis elided, system.rs:12-23):
+    increment_sim_tick | sample_wind | bounce | six_dof(gravity | apply_drag), RK4 — examples/ball/sim.py:56-125.  sample_wind is
+    `random.normal(random.key(seed), (3,))`: jax.random's threefry2x32 + mantissa construction + erf_inv, the functions reconstructed
+    in tests/golden/make_stablehlo_world_golden.py and pinned there on the reference's known answers.
+    -> (module text, slots): @main(tick, seed, wind, world_pos, world_vel, force, inertia, world_accel, simulation_time_step) -> the same
+    nine (the argument list of libs/cranelift-mlir/tests/test_uniform_pipeline.rs:86-99)."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("_mk_world_golden_parts", Path(__file__).with_name("hlo_random_parts.py"))
+    parts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(parts)
+    u3 = V(None, (3,), "ui32")
+    threefry = RawFn("threefry2x32", parts.THREEFRY, [u3, u3])
+    closed = RawFn("closed_call", parts.closed_call_fn(False), [])
+    inner = Fn("inner", [((), "i64"), ((), "i64"), ((3,), "f64"), ((7,), "f64"), ((6,), "f64"), ((6,), "f64"), ((7,), "f64"), ((6,), "f64"), ((), "f64")])
+    tick, seed, _wind_in, pos_in, vel_in, _force_in, inertia_in, accel_in, dt = inner.args
+    f = inner
+    tick1 = f.add(tick, f.const(1, (), "i64"))
+    # ---- sample_wind: random.normal(random.key(seed), (3,)) ----------------------------------------------------------------------
+    k0 = f.convert(f.shr(seed, f.const(32, (), "i64")), "ui32")                                  # threefry_seed: the two halves of the int64 seed
+    k1 = f.convert(f.bit_and(seed, f.const(4294967295, (), "i64")), "ui32")
+    ctr = f.iota((3,), 0, "ui64")                                                                 # partitionable counters (0, i)
+    c_hi = f.convert(f.shr(ctr, f.splat(32, (3,), "ui64")), "ui32")
+    c_lo = f.convert(f.bit_and(ctr, f.splat(4294967295, (3,), "ui64")), "ui32")
+    b_hi, b_lo = f.call(threefry, [k0, k1, c_hi, c_lo])
+    bits = f.bit_or(f.shl(f.convert(b_hi, "ui64"), f.splat(32, (3,), "ui64")), f.convert(b_lo, "ui64"))
+    mant = f.bit_or(f.shr(bits, f.splat(12, (3,), "ui64")), f.splat(4607182418800017408, (3,), "ui64"))      # | bits of 1.0
+    u01 = f.sub(f.bitcast(mant, "f64"), f.splat(1.0, (3,)))
+    lo = f.splat(-0.99999999999999989, (3,))                                                     # nextafter(-1, inf)
+    u = f.maximum(lo, f.add(f.mul(u01, f.splat(2.0, (3,))), lo))
+    wind = f.mul(f.splat(1.4142135623730951, (3,)), f.erf_inv(u))
+    # ---- batch1 -> batched (query.rs:627-631) for the vmapped arithmetic ----------------------------------------------------------
+    pos0, vel_b, inertia, accel_b = (f.reshape(x, (1,) + x.shape) for x in (pos_in, vel_in, inertia_in, accel_in))
+    windb = f.reshape(wind, (1, 3))
+    # ---- bounce (sim.py:65-73): lax.cond on max(p.z, v.z) < 0 -> select under vmap ----------------------------------------------
+    pz, vz = col(f, pos0, 6), col(f, vel_b, 5)
+    hit = f._cmp("LT", f.maximum(pz, vz), f.splat(0.0, (1,)))
+    refl = f.mul(f.mul(f.slice(vel_b, [(0, 1), (3, 6)]), f.bcast(f.const([1.0, 1.0, -1.0], (3,)), (1, 3), [1])), f.splat(0.85, (1, 3)))
+    bounced = f.concat([f.splat(0.0, (1, 3)), refl], 1)                                          # el.SpatialMotion(linear=...): angular = 0
+    vel0 = f.select(f.bcast(hit, (1, 6), [0]), bounced, vel_b)
+    n = 1
+
+    def pipe(xs: V, vs: V):
+        mass = col(f, inertia, 6)
+        zero = f.splat(0.0, (n,))
+        grav = [f.add(zero, zero) for _ in range(3)] + [f.add(zero, f.mul(f.splat(g_, (n,)), mass)) for g_ in (0.0, 0.0, -9.81)]     # gravity: f + SpatialForce(linear = g * m)
+        fl = [f.sub(col(f, windb, k), col(f, vs, 3 + k)) for k in range(3)]                     # apply_drag (sim.py:96-116)
+        V_ = f.sqrt(f.add(f.add(f.mul(fl[0], fl[0]), f.mul(fl[1], fl[1])), f.mul(fl[2], fl[2])))
+        drag = f.mul(f.splat(0.5, (n,)), f.mul(f.mul(f.splat(0.5 * 1.225, (n,)), f.mul(V_, V_)), f.splat(2 * 3.1415 * 0.2 ** 2, (n,))))
+        cols = [f.splat(0.0, (n,)) for _ in range(3)] + [f.add(grav[3 + k], f.mul(drag, f.div(fl[k], V_))) for k in range(3)]       # torque zeroed: SpatialForce(linear=...)
+        force = stack_cols(f, cols)
+        return force, calc_accel(f, force, inertia, xs)
+    V4, A4, prev_a, F_last = [], [], accel_b, None
+    for c_ in (0.0, 0.5, 0.5, 1.0):
+        h = f.mul(dt, f.const(c_))
+        xs = transform_add_motion(f, pos0, scaled(f, h, vel0))
+        vs = f.add(vel0, stack_cols(f, scaled(f, h, prev_a)))
+        F_last, a_ = pipe(xs, vs)
+        V4.append(vs)
+        A4.append(a_)
+        prev_a = a_
+    g = f.mul(dt, f.const(1.0 / 6.0))
+
+    def combine(K):
+        two = f.splat(2.0, K[0].shape)
+        return f.add(f.add(f.add(K[0], f.mul(two, K[1])), f.mul(two, K[2])), K[3])
+    pos1 = transform_add_motion(f, pos0, scaled(f, g, combine(V4)))
+    vel1 = f.add(vel0, stack_cols(f, scaled(f, g, combine(A4))))
+    sq = lambda x: f.reshape(x, x.shape[1:])
+    inner.ret(tick1, seed, wind, sq(pos1), sq(vel1), sq(F_last), inertia_in, sq(A4[3]), dt)
+    main = Fn("main", [(a.shape, a.dtype) for a in inner.args], public=True)
+    main.ret(*main.call(inner, main.args))
+    slots = [("tick", [], True), ("seed", [], True), ("wind", [3], True), ("world_pos", [7], True), ("world_vel", [6], True), ("force", [6], True),
+             ("inertia", [7], True), ("world_accel", [6], True), ("simulation_time_step", [], True)]
+    return module([main, inner, threefry, closed]), slots
 
 
 if __name__ == "__main__":

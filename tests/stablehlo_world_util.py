@@ -45,3 +45,23 @@ def independent_bodies(n, seed=5):
             "inertia": np.concatenate([rng.uniform(0.5, 2.0, (n, 3)), np.zeros((n, 3)), rng.uniform(1.0, 5.0, (n, 1))], axis=1),
             "torque": rng.uniform(-0.1, 0.1, (n, 3))}
     return text, slots, cols
+
+
+def ball(mode="auto"):
+    """examples/ball's singleton world as a whole-world module -> (system, manifest, widths, {column: initial row}, golden)"""
+    text, slots = hb.ball_world()
+    system, manifest = sh.world_system(text, slots, mode=mode, name="ball_world")
+    widths = {c["column"]: c["width"] for c in manifest["columns"]}
+    g = gu.load("ball")
+    row = {"hlo_tick": np.zeros(1), "hlo_seed": np.array([float(g["ball.seed"][0, 0])]), "hlo_wind": g["ball.wind"][0].copy(),
+           "hlo_simulation_time_step": np.array([g["globals.simulation_time_step"][0, 0]])}
+    for c, _ in BODY:
+        row["hlo_" + c] = g[f"ball.{c}"][0].copy()
+    return system, manifest, widths, row, g
+
+
+def ball_errors(columns, g, r, lane=0):
+    worst = 0.0
+    for c in ("world_pos", "world_vel", "world_accel", "force", "wind"):
+        worst = max(worst, gu.rel_err(np.asarray(columns["hlo_" + c][lane], dtype=np.float64), g[f"ball.{c}"][r]))
+    return worst

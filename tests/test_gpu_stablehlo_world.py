@@ -146,3 +146,21 @@ def test_the_build_time_cli_object_is_installed_as_it_is(tmp_path):
     print("CLI-built object, tick 100 vs G1:", worst, "build:", manifest["build"])
     assert max(worst) <= 1e-9
     hip.close()
+
+
+def test_ball_whole_world_module_with_jax_random_reproduces_g2_on_the_gpu():
+    """examples/ball's singleton world as the reference would dump it, jax.random's threefry in u32 arithmetic included (sample_wind runs
+    every tick): 100 ticks of G2 — wind, position, velocity, acceleration, force — through the generated kernel, <= 1e-9."""
+    system, manifest, widths, row, g = W.ball("auto")
+    assert manifest["mode"] == "world"
+    n = 70
+    hip = _exec(dsl.Program([system], dsl.Pipe([]), []), {c: np.tile(v[None, :], (n, 1)) for c, v in row.items()}, n)
+    worst = 0.0
+    for r in range(1, 101):
+        hip.run(1)
+        worst = max(worst, W.ball_errors(hip._aux, g, r))
+        assert hip._aux["hlo_tick"][0, 0] == r
+    print(f"ball whole-world module (jax.random in the tick), 100 ticks vs G2: {worst:.2e}")
+    assert worst <= 1e-9
+    assert np.array_equal(hip._aux["hlo_world_pos"], np.repeat(hip._aux["hlo_world_pos"][:1], n, axis=0))
+    hip.close()

@@ -237,3 +237,23 @@ def test_random_entity_parallel_modules_lane_mode_equals_world_mode(seed):
         got, want = lane["hlo_" + name].reshape(-1), world["hlo_" + name][0]
         assert got.shape == want.shape and np.array_equal(got, want, equal_nan=True), (seed, name, shape)
         assert np.isfinite(want).all()
+
+
+def test_ball_world_tick_with_jax_random_reproduces_the_reference_golden_100_ticks():
+    """G2 (scripts/ci/baseline/ball-csv) through the ball's WHOLE-WORLD module: `sample_wind` draws the wind from the seed with jax.random
+    as jax lowers it (threefry2x32 in u32 arithmetic, 64 random bits -> mantissa -> bitcast -> erf_inv) inside the tick, `bounce` is a
+    vmapped lax.cond, six_dof(gravity | apply_drag) the RK4 — 9 inputs, 9 outputs, main + inner + threefry2x32 + closed_call, the shape
+    test_threefry.rs / test_uniform_pipeline.rs:86-112 describe.  Wind, position, velocity, acceleration and force of all 100 recorded
+    ticks on the CPU walker."""
+    system, manifest, widths, row, g = W.ball("auto")
+    assert manifest["mode"] == "world" and "entity count" in manifest["lane_refused"]       # a singleton world: nothing is batched
+    comps = {c: np.tile(v[None, :], (2, 1)) for c, v in row.items()}
+    worst = [0.0]
+
+    def check(r):
+        assert comps["hlo_tick"][0, 0] == r == int(g["globals.tick"][r, 0]) and comps["hlo_seed"][0, 0] == g["ball.seed"][r, 0]
+        worst[0] = max(worst[0], W.ball_errors(comps, g, r))
+    walk(system, widths, comps, 100, check)
+    print("ball whole-world module vs G2, 100 ticks:", worst[0])
+    assert worst[0] < 1e-12
+    assert np.allclose(comps["hlo_wind"][0], [-0.2058421394796434, -0.7847657764467411, 1.8160866726679836], rtol=1e-13)   # test_uniform_pipeline.rs:152-156
