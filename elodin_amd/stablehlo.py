@@ -2189,18 +2189,96 @@ def load_world(so_path: str):
     return prog, manifest
 
 
+_NP_DTYPE = {"f64": "float64", "f32": "float32", "i64": "int64", "i32": "int32", "ui64": "uint64", "ui32": "uint32", "i1": "bool", "ui8": "uint8", "i8": "int8"}
+
+
+def checkpoint(debug_dir: str, mode: str = "auto", device: int = 0, rtol: float = 1e-9) -> dict:
+    """The reference's first-tick parity harness (libs/cranelift-mlir/tests/checkpoint_test.rs; producer cranelift_compile.rs:70-153,
+    cranelift_exec.rs:199-267), with this backend in Cranelift's place.  `ELODIN_CRANELIFT_DEBUG_DIR=<dir>` makes a reference run dump
+    `stablehlo.mlir`, `input_<i>.bin` (the raw column bytes of @main's arguments) and `xla_output_<i>.bin` / `cranelift_output_<i>.bin`
+    (the first tick's results).  This function compiles that module for gfx950, runs ONE tick on the same inputs, writes
+    `hip_output_<i>.bin` next to them and compares: integers bit for bit, floats to `rtol` of each output's largest magnitude.
+    -> {"mode", "outputs": [{"index", "max_rel_err" | "equal", "against"}], "ok"}"""
+    import json
+    d = Path(debug_dir)
+    text = (d / "stablehlo.mlir").read_text()
+    main = parse_module(text)["main"]
+    ins = []
+    for k, (_, ty) in enumerate(main.args):
+        raw = np.fromfile(d / f"input_{k}.bin", dtype=_NP_DTYPE[ty.dtype])
+        if raw.size != ty.size:
+            raise ValueError(f"input_{k}.bin holds {raw.size} elements, @main's argument {k} is {ty}")
+        ins.append(raw.reshape(ty.shape))
+    meta = json.loads((d / "slots.json").read_text()) if (d / "slots.json").exists() else None
+    if meta is not None:
+        arg_slots, ret_slots = slots_from_metadata(meta)
+    else:       # no ExecMetadata beside the dump: the modal leading size of the rank >= 2 arguments is taken for the entity count
+        lead = [ty.shape[0] for _, ty in main.args if len(ty.shape) >= 2]
+        n = max(set(lead), key=lead.count) if lead else None
+        arg_slots = [Slot(f"arg{k}", ty.shape, not (len(ty.shape) >= 2 and ty.shape[0] == n)) for k, (_, ty) in enumerate(main.args)]
+        ret_slots = [Slot(f"ret{k}", ty.shape, not (len(ty.shape) >= 2 and ty.shape[0] == n)) for k, ty in enumerate(main.result_types)]
+    system_, manifest = world_system(text, arg_slots, ret_slots, mode=mode)
+    lane = manifest["mode"] == "lane"
+    rows = manifest["entities_per_world"] if lane else 1
+    cols = {}
+    for s_, a in zip(arg_slots, ins):
+        v = np.asarray(a, dtype=np.float64)
+        cols[s_.column] = v.reshape(rows, -1) if (lane and not s_.elided) else np.tile(v.reshape(1, -1), (rows, 1))
+    for s_ in ret_slots:
+        w = next(c["width"] for c in manifest["columns"] if c["column"] == s_.column)
+        cols.setdefault(s_.column, np.zeros((rows, w)))
+    from . import _lib as L
+    from .exec import HipExec
+    ident = np.tile([0, 0, 0, 1.0, 0, 0, 0], (rows, 1))
+    hip = HipExec(ident, np.zeros((rows, 6)), np.ones((rows, 7)), integrator=L.INTEGRATOR_NONE, effectors=_dsl.Program([system_], _dsl.Pipe([]), []),
+                  columns=cols, device=device)
+    try:
+        hip.run(1)
+        report = {"mode": manifest["mode"], "outputs": [], "ok": True}
+        for k, (s_, ty) in enumerate(zip(ret_slots, main.result_types)):
+            got = np.asarray(hip._aux[s_.column], dtype=np.float64)
+            got = (got.reshape(ty.shape) if (lane and not s_.elided) else got[0].reshape(ty.shape))
+            np.ascontiguousarray(got.astype(_NP_DTYPE[ty.dtype])).tofile(d / f"hip_output_{k}.bin")
+            for ref_name in ("xla_output", "cranelift_output"):
+                f_ = d / f"{ref_name}_{k}.bin"
+                if not f_.exists():
+                    continue
+                want = np.fromfile(f_, dtype=_NP_DTYPE[ty.dtype]).reshape(ty.shape)
+                if ty.dtype[0] in "iu":
+                    rec = {"index": k, "against": ref_name, "equal": bool(np.array_equal(got.astype(want.dtype), want))}
+                    report["ok"] &= rec["equal"]
+                else:
+                    scale = max(float(np.max(np.abs(want))) if want.size else 0.0, 1e-300)
+                    err = float(np.max(np.abs(got - want)) / scale) if want.size else 0.0
+                    rec = {"index": k, "against": ref_name, "max_rel_err": err}
+                    report["ok"] &= bool(err <= rtol or not np.isfinite(want).all())
+                report["outputs"].append(rec)
+    finally:
+        hip.close()
+    (d / "hip_checkpoint.json").write_text(json.dumps(report, indent=1))
+    return report
+
+
 def _main(argv=None) -> int:
     """python -m elodin_amd.stablehlo module.mlir --slots slots.json -o pipe.so [--mode auto|lane|world] [--dtype float64|float32]"""
     import argparse
     import json
     ap = argparse.ArgumentParser(prog="python -m elodin_amd.stablehlo", description=_main.__doc__)
-    ap.add_argument("module", help="StableHLO text (ELODIN_CRANELIFT_DEBUG_DIR/stablehlo.mlir, libs/nox-py/src/cranelift_compile.rs:58-60)")
-    ap.add_argument("--slots", required=True, help="ExecMetadata JSON (libs/nox-py/src/exec.rs:17-29) or {inputs, outputs}")
-    ap.add_argument("-o", "--out", required=True, help="shared object to write (its manifest goes to <out>.json)")
+    ap.add_argument("module", nargs="?", help="StableHLO text (ELODIN_CRANELIFT_DEBUG_DIR/stablehlo.mlir, libs/nox-py/src/cranelift_compile.rs:58-60)")
+    ap.add_argument("--slots", help="ExecMetadata JSON (libs/nox-py/src/exec.rs:17-29) or {inputs, outputs}")
+    ap.add_argument("-o", "--out", help="shared object to write (its manifest goes to <out>.json)")
+    ap.add_argument("--checkpoint", metavar="DIR", help="a reference debug dump (ELODIN_CRANELIFT_DEBUG_DIR): run its first tick on the GPU and compare "
+                                                        "with xla_output_<i>.bin / cranelift_output_<i>.bin (needs a GPU)")
     ap.add_argument("--mode", default="auto", choices=("auto", "lane", "world"))
     ap.add_argument("--dtype", default="float64", choices=("float64", "float32"))
     ap.add_argument("--fast-math", action="store_true")
     a = ap.parse_args(argv)
+    if a.checkpoint:
+        rep = checkpoint(a.checkpoint, a.mode)
+        print(json.dumps(rep))
+        return 0 if rep["ok"] else 1
+    if not (a.module and a.slots and a.out):
+        ap.error("module, --slots and -o are required (or --checkpoint DIR)")
     so, manifest = compile_world(Path(a.module).read_text(), json.loads(Path(a.slots).read_text()), a.out, a.mode, a.dtype, a.fast_math)
     print(json.dumps({"object": str(so), "mode": manifest["mode"], "rows": manifest["rows"], "columns": [c["column"] for c in manifest["columns"]],
                       "build": manifest["build"], **({"lane_refused": manifest["lane_refused"]} if "lane_refused" in manifest else {})}))

@@ -164,3 +164,31 @@ def test_ball_whole_world_module_with_jax_random_reproduces_g2_on_the_gpu():
     assert worst <= 1e-9
     assert np.array_equal(hip._aux["hlo_world_pos"], np.repeat(hip._aux["hlo_world_pos"][:1], n, axis=0))
     hip.close()
+
+
+def test_the_references_first_tick_checkpoint_harness_with_this_backend_in_cranelifts_place(tmp_path):
+    """libs/cranelift-mlir/tests/checkpoint_test.rs's layout: a debug directory holding stablehlo.mlir, input_<i>.bin and
+    xla_output_<i>.bin (here written from the golden CSV: G1's row 0 as the inputs, row 1 as the outputs XLA produced).
+    `python -m elodin_amd.stablehlo --checkpoint DIR` compiles the module, runs the first tick on the GPU, writes hip_output_<i>.bin
+    and compares."""
+    from tests.golden import hlo_world_builder as hb
+    text, slots = hb.three_body_world()
+    (tmp_path / "stablehlo.mlir").write_text(text)
+    _, _, _, row, g = W.three_body("world")
+    order = [c for c, _, _ in slots]
+    for k, c in enumerate(order):
+        np.asarray(row["hlo_" + c], dtype=np.int64 if c == "tick" else np.float64).tofile(tmp_path / f"input_{k}.bin")
+    want = {"tick": np.array([1], dtype=np.int64), "simulation_time_step": np.asarray(row["hlo_simulation_time_step"]),
+            "inertia": np.asarray(row["hlo_inertia"])}
+    for c, _ in W.BODY[:4]:
+        want[c] = np.concatenate([g[f"{e}.{c}"][1] for e in "abc"])
+    for k, c in enumerate(order):
+        np.asarray(want[c]).tofile(tmp_path / f"xla_output_{k}.bin")
+    res = subprocess.run([sys.executable, "-m", "elodin_amd.stablehlo", "--checkpoint", str(tmp_path)], capture_output=True, text=True, cwd=str(L.PKG.parent))
+    assert res.returncode == 0, (res.stdout[-500:], res.stderr[-1500:])
+    rep = json.loads(res.stdout.strip().splitlines()[-1])
+    assert rep["ok"] and rep["mode"] == "world" and len(rep["outputs"]) == 7
+    assert rep["outputs"][0] == {"index": 0, "against": "xla_output", "equal": True}
+    assert max(o.get("max_rel_err", 0.0) for o in rep["outputs"]) <= 1e-12
+    assert np.array_equal(np.fromfile(tmp_path / "hip_output_0.bin", dtype=np.int64), [1])
+    assert (tmp_path / "hip_checkpoint.json").exists()
