@@ -204,22 +204,7 @@ extern "C" {
 
 uint32_t sixdof_abi_version(void) { return SIXDOF_ABI_VERSION; }
 
-uint64_t sixdof_component_id(const char* name) {
-    uint64_t h = 0xcbf29ce484222325ull;
-    if (name)
-        for (const unsigned char* p = reinterpret_cast<const unsigned char*>(name); *p; ++p) {
-            h ^= static_cast<uint64_t>(*p);
-            h *= 0x100000001b3ull;
-        }
-    return h & ~(1ull << 63);
-}
-
-double sixdof_quantize_time_step(double rate_hz) {
-    if (!(rate_hz > 0.0)) return std::nan("");
-    const long double ns = nearbyintl(static_cast<long double>(1.0 / rate_hz) * 1.0e9L);
-    const uint64_t total = static_cast<uint64_t>(ns);
-    return static_cast<double>(total / 1000000000ull) + static_cast<double>(total % 1000000000ull) / 1.0e9;
-}
+// sixdof_component_id / sixdof_quantize_time_step: pure host code, in world.cpp (so the host layer links without HIP: `make asan`)
 
 int sixdof_device_count(void) {
     int n = 0;

@@ -34,6 +34,25 @@ static size_t prim_size(int prim) { return prim == SIXDOF_PRIM_F32 ? 4 : 8; }
 
 extern "C" {
 
+// ComponentId::new: FNV-1a-64 & !(1 << 63) (impeller2/src/types.rs:39-44, const-fnv1a-hash)
+uint64_t sixdof_component_id(const char* name) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    if (name)
+        for (const unsigned char* p = reinterpret_cast<const unsigned char*>(name); *p; ++p) {
+            h ^= static_cast<uint64_t>(*p);
+            h *= 0x100000001b3ull;
+        }
+    return h & ~(1ull << 63);
+}
+
+// Duration::from_secs_f64(1/rate).as_secs_f64(): ns-quantised (world_builder.rs:221, world.rs:185-191)
+double sixdof_quantize_time_step(double rate_hz) {
+    if (!(rate_hz > 0.0)) return std::nan("");
+    const long double ns = nearbyintl(static_cast<long double>(1.0 / rate_hz) * 1.0e9L);
+    const uint64_t total = static_cast<uint64_t>(ns);
+    return static_cast<double>(total / 1000000000ull) + static_cast<double>(total % 1000000000ull) / 1.0e9;
+}
+
 sixdof_world* sixdof_world_create(void) {
     auto* w = new sixdof_world();
     // add_globals (world.rs:174-183): SystemGlobals::new(sim_time_step) on entity 0; DEFAULT_TIME_STEP = 1/120 s in ns
