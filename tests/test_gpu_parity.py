@@ -667,3 +667,22 @@ def test_unsafe_cache_policy_is_not_selectable_in_the_product_library():
         del os.environ["SIXDOF_STREAMING"]
     for f in parity.FIELDS:
         assert np.array_equal(getattr(one, f), getattr(fused, f)), f
+
+
+@pytest.mark.parametrize("n,k", [(1000, 1), (65536, 1), (4099, 16)])
+def test_results_do_not_depend_on_which_lane_or_workgroup_an_entity_lands_in(n, k):
+    """SURVEY §5 (race detection): the same world with its rows PERMUTED — every entity in another lane, wave and workgroup, ragged
+    tails elsewhere — gives the same rows, permuted, bit for bit (RK4, gravity + body torque; 1 and 16 ticks per launch).  An order
+    dependence (a lane reading a neighbour's LDS row, a tail lane touching a real row) would show here."""
+    w = workloads.independent_bodies(n)
+    eff = workloads.gravity_torque_effectors(w["body_torque"])
+    a = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ, effectors=eff, ticks_per_launch=k)
+    a.run(32)
+    perm = np.random.default_rng(n + k).permutation(n)
+    effp = workloads.gravity_torque_effectors(w["body_torque"][perm])
+    b = ea.HipExec(w["world_pos"][perm], w["world_vel"][perm], w["inertia"][perm], simulation_time_step=workloads.DT_120HZ, effectors=effp, ticks_per_launch=k)
+    b.run(32)
+    for f in parity.FIELDS:
+        assert np.array_equal(getattr(a, f)[perm], getattr(b, f)), f
+    a.close()
+    b.close()
