@@ -2212,11 +2212,16 @@ def checkpoint(debug_dir: str, mode: str = "auto", device: int = 0, rtol: float 
     meta = json.loads((d / "slots.json").read_text()) if (d / "slots.json").exists() else None
     if meta is not None:
         arg_slots, ret_slots = slots_from_metadata(meta)
-    else:       # no ExecMetadata beside the dump: the modal leading size of the rank >= 2 arguments is taken for the entity count
+    else:       # no ExecMetadata beside the dump: the modal leading size of the rank >= 2 arguments is taken for the entity count,
+        #             and checkpoint.json (cranelift_exec.rs:211-243) says which result is which argument's component
         lead = [ty.shape[0] for _, ty in main.args if len(ty.shape) >= 2]
         n = max(set(lead), key=lead.count) if lead else None
-        arg_slots = [Slot(f"arg{k}", ty.shape, not (len(ty.shape) >= 2 and ty.shape[0] == n)) for k, (_, ty) in enumerate(main.args)]
-        ret_slots = [Slot(f"ret{k}", ty.shape, not (len(ty.shape) >= 2 and ty.shape[0] == n)) for k, ty in enumerate(main.result_types)]
+        ck = json.loads((d / "checkpoint.json").read_text()) if (d / "checkpoint.json").exists() else {}
+        in_ids = {int(e["index"]): int(e["component_id"]) for e in ck.get("inputs", [])}
+        out_ids = {int(e["index"]): int(e["component_id"]) for e in ck.get("outputs", [])} if len(ck.get("outputs", [])) == len(main.result_types) else {}
+        name = lambda ids, k, stem: f"c{ids[k]}" if k in ids else f"{stem}{k}"
+        arg_slots = [Slot(name(in_ids, k, "arg"), ty.shape, not (len(ty.shape) >= 2 and ty.shape[0] == n)) for k, (_, ty) in enumerate(main.args)]
+        ret_slots = [Slot(name(out_ids, k, "ret"), ty.shape, not (len(ty.shape) >= 2 and ty.shape[0] == n)) for k, ty in enumerate(main.result_types)]
     system_, manifest = world_system(text, arg_slots, ret_slots, mode=mode)
     lane = manifest["mode"] == "lane"
     rows = manifest["entities_per_world"] if lane else 1

@@ -184,6 +184,8 @@ def test_the_references_first_tick_checkpoint_harness_with_this_backend_in_crane
         want[c] = np.concatenate([g[f"{e}.{c}"][1] for e in "abc"])
     for k, c in enumerate(order):
         np.asarray(want[c]).tofile(tmp_path / f"xla_output_{k}.bin")
+    ids = [{"index": k, "component_id": L.component_id(c), "byte_size": int(np.asarray(want[c]).nbytes)} for k, c in enumerate(order)]
+    (tmp_path / "checkpoint.json").write_text(json.dumps({"inputs": ids, "outputs": ids, "num_output_slots": len(ids)}))      # cranelift_exec.rs:211-243
     res = subprocess.run([sys.executable, "-m", "elodin_amd.stablehlo", "--checkpoint", str(tmp_path)], capture_output=True, text=True, cwd=str(L.PKG.parent))
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-1500:])
     rep = json.loads(res.stdout.strip().splitlines()[-1])
