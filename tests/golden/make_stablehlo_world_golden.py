@@ -4,7 +4,7 @@
 Build container only (/root/reference):   python tests/golden/make_stablehlo_world_golden.py
 
 libs/cranelift-mlir/tests/{test_gather_3body, test_dynamic_ops_3body, test_while_dyn_slice, test_closed_call, test_threefry,
-test_threefry_e2e, test_uniform_pipeline}.rs hold the pieces a dumped world tick is made of (constant-index row gathers, the
+test_threefry_e2e, test_uniform_pipeline, test_sret_large}.rs hold the pieces a dumped world tick is made of (constant-index row gathers, the
 `edge_fold` while with dynamic_slice / dynamic_update_slice by the loop counter, the transposes and broadcasts around it, jax.random's
 threefry rounds and its bits -> uniform float construction), each as an inline MLIR module with inputs and asserted outputs.  Their
 expectations are computed by Rust expressions, so each case is transcribed here BY HAND: the module text is read from the
@@ -99,6 +99,14 @@ bits = ((((hi << 32) | lo) >> 12) | 0x3FF0000000000000)
 case("test_uniform_float_construction", f + ":33-76", inline_module(f, "test_uniform_float_construction"),
      [("u32", [hi]), ("u32", [lo])], {0: ("f64", [struct.unpack("<d", struct.pack("<Q", bits))[0] - 1.0])}, tol=1e-15)
 
+# ---- test_sret_large.rs: calls returning large / several tensors (how @inner and @closed_call return) -----------------------------------
+f = "test_sret_large.rs"
+a18 = list(range(1, 19))
+case("test_sret_call_3x6_return", f + ":5-28", inline_module(f, "test_sret_call_3x6_return"),
+     [("f64", a18), ("f64", [10 * v for v in a18])], {0: ("f64", [11 * v for v in a18])})                     # :20-27
+case("test_sret_call_multi_return", f + ":31-53", inline_module(f, "test_sret_call_multi_return"),
+     [("f64", a18)], {0: ("f64", [2 * v for v in a18]), 1: ("i64", [42])})                                   # :46-52
+
 # ---- the three tests whose modules are LFS pointers: reconstructed in jax's spelling, pinned on the reference's asserted outputs ----
 pointer = (T / "closed_call_test.mlir").read_text()
 assert pointer.startswith("version https://git-lfs.github.com/spec/v1"), "closed_call_test.mlir has content now: read it instead"
@@ -172,7 +180,7 @@ case("test_full_prng_pipeline_seed_zero__wind", f + ":79-176", "module @module {
      [("i64", [0])], {0: ("f64", [-0.2058421394796434, -0.7847657764467411, 1.8160866726679836])}, tol=1e-12, reconstructed=True)   # :152-156
 
 doc = {"source": "libs/cranelift-mlir/tests/{test_gather_3body,test_dynamic_ops_3body,test_while_dyn_slice,test_closed_call,test_threefry,"
-                 "test_threefry_e2e,test_uniform_pipeline}.rs (inline modules + asserted outputs; see make_stablehlo_world_golden.py)",
+                 "test_threefry_e2e,test_uniform_pipeline,test_sret_large}.rs (inline modules + asserted outputs; see make_stablehlo_world_golden.py)",
        "not_known_answers": {"test_threefry.rs::test_threefry_round": "parses the LFS-pointer ball module and checks that @closed_call exists: no output asserted",
                              "test_threefry.rs::test_inner_prng": "compiles the LFS-pointer ball module and checks that @inner / @main exist: no output asserted"},
        "cases": cases}

@@ -27,7 +27,7 @@ def _exec(program, columns, n, **kw):
 
 def test_reference_world_fragment_known_answers_through_the_generated_kernel():
     """libs/cranelift-mlir/tests/test_{gather_3body,dynamic_ops_3body,while_dyn_slice,closed_call,threefry,threefry_e2e,
-    uniform_pipeline}.rs: all 22 cases as systems of ONE generated kernel; integer results exact (u32 wrap-around, ui64 words)."""
+    uniform_pipeline}.rs: all 24 cases as systems of ONE generated kernel; integer results exact (u32 wrap-around, ui64 words)."""
     systems, columns, expects = [], {}, []
     n = 70
     for k, case in enumerate(U.WORLD_CASES):

@@ -245,6 +245,9 @@ def test_ball_world_tick_with_jax_random_reproduces_the_reference_golden_100_tic
     vmapped lax.cond, six_dof(gravity | apply_drag) the RK4 — 9 inputs, 9 outputs, main + inner + threefry2x32 + closed_call, the shape
     test_threefry.rs / test_uniform_pipeline.rs:86-112 describe.  Wind, position, velocity, acceleration and force of all 100 recorded
     ticks on the CPU walker."""
+    text, _slots = hb.ball_world()
+    funcs = sh.parse_module(text)           # libs/cranelift-mlir/tests/e2e.rs:13-24 (9 params, 9 results), test_threefry.rs:8-42 (@closed_call, @inner)
+    assert len(funcs["main"].args) == 9 and len(funcs["main"].result_types) == 9 and {"inner", "closed_call", "threefry2x32"} <= set(funcs)
     system, manifest, widths, row, g = W.ball("auto")
     assert manifest["mode"] == "world" and "entity count" in manifest["lane_refused"]       # a singleton world: nothing is batched
     comps = {c: np.tile(v[None, :], (2, 1)) for c, v in row.items()}
