@@ -519,7 +519,7 @@ def world_module_leg(device):
     from tests.golden import hlo_world_builder as hb
     out = {}
     text, slots = hb.three_body_world()
-    system, manifest = sh.world_system(text, slots, mode="auto")
+    system, manifest = sh.world_system(text, slots, mode="world")
     widths = {c["column"]: c["width"] for c in manifest["columns"]}
     g_pos = np.array([0, 0, 0, 1, 0.8920281421, 0, 0, 0, 0, 0, 1, -0.6628498947, 0, 0, 0, 0, 0, 1, -0.2291782474, 0, 0.0])
     g_vel = np.array([0, 0, 0, 0, 0.9957939373, 0, 0, 0, 0, 0, -1.6191613336, 0, 0, 0, 0, 0, 0.6233673964, 0.0])
@@ -538,6 +538,30 @@ def world_module_leg(device):
         out[f"three_body_worlds_{worlds}"] = {"mode": manifest["mode"], "worlds": worlds, "ticks": 1000, "us_per_tick": round(tm.kernel_device_ms, 3),
                                              "world_steps_per_s": round(worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
                                              "body_steps_per_s": round(3 * worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1)}
+    # the same module with one lane per ENTITY (mode "auto"): a world = 4 consecutive rows, the fold's targets read from the other
+    # lanes of the world (lane_read = ds_bpermute) — the layout IS the ECS column layout, [worlds * 4, 7] rows of world_pos
+    lsys, lman = sh.world_system(text, slots, mode="auto")
+    S = lman.get("rows_per_world", 3)
+    for worlds in (16384, 262144):
+        rows = S * worlds
+        w = workloads.independent_bodies(rows)
+        def lay(vals, width, fill):
+            a = np.tile(np.asarray(fill, dtype=np.float64), (rows, 1))
+            for i in range(3):
+                a[i::S] = vals[i * width:(i + 1) * width]
+            return a
+        cols = {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), 0.008333333),
+                "hlo_world_pos": lay(g_pos, 7, [0, 0, 0, 1.0, 0, 0, 0]), "hlo_world_vel": lay(g_vel, 6, np.zeros(6)), "hlo_inertia": lay(g_in, 7, np.ones(7)),
+                "hlo_world_accel": np.zeros((rows, 6)), "hlo_force": np.zeros((rows, 6))}
+        ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=L.INTEGRATOR_NONE, effectors=dsl.Program([lsys], dsl.Pipe([]), []),
+                        columns=cols, ticks_per_launch=100, device=device)
+        ex.invoke_batch(100)
+        tm = ex.invoke_batch(1000)
+        ex.close()
+        out[f"three_body_worlds_{worlds}_lane_mode"] = {"mode": lman["mode"], "rows_per_world": S, "worlds": worlds, "rows": rows, "ticks": 1000,
+                                                       "us_per_tick": round(tm.kernel_device_ms, 3),
+                                                       "world_steps_per_s": round(worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
+                                                       "body_steps_per_s": round(3 * worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1)}
     n = 65536
     text, slots = hb.independent_bodies_world(n)
     system, manifest = sh.world_system(text, slots, mode="lane")

@@ -192,6 +192,17 @@ class _Emitter:
                 return f"W{slot}[(size_t)(((static_cast<int>({a[0]}) + static_cast<int>({a[1]})) % {rows}) * {width} + {j}) * w_n]"
             if e.op == "threefry":
                 return f"m_threefry({a[0]}, {a[1]}, {a[2]}, {a[3]}, {int(e.value)})"
+            if e.op == "lane_read":     # the value another entity of THIS lane's world holds (whole-world StableHLO ticks: a join / an
+                # edge_fold's targets).  A world is `stride` consecutive rows, stride a power of two <= 16 dividing the 64-lane wave,
+                # so the exchange never leaves the wavefront: one ds_bpermute per 32-bit half.  The source entity per entity index
+                # is a compile-time table packed four bits each into one 64-bit constant.
+                stride, table = e.value
+                if len(set(table)) == 1:
+                    src = f"static_cast<int>((threadIdx.x & ~{stride - 1}u) + {table[0]}u)"
+                else:
+                    packed = sum((int(j) & 15) << (4 * i) for i, j in enumerate(table))
+                    src = (f"static_cast<int>((threadIdx.x & ~{stride - 1}u) + static_cast<unsigned>(({packed}ull >> ((threadIdx.x & {stride - 1}u) * 4u)) & 15ull))")
+                return f"__shfl({a[0]}, {src}, 64)"
             if e.op == "fbits":     # one 32-bit word of a double's bit pattern (stablehlo.bitcast_convert f64 -> ui64): 1 = high
                 return f"m_fbits({a[0]}, {int(e.value)})"
             if e.op == "lt":
@@ -489,7 +500,7 @@ _GUARD_SELECTS = [False]
 # SIXDOF_FUSE_FMA=0 keeps them apart (A/B).  Exact builds never fuse: a reference evaluates every node to a rounded value.
 _FUSE_FMA = [False]
 _GUARD_MIN_COST = 40
-_NODE_COST = {"threefry": 90, "erfinv": 120, "sin": 12, "cos": 12, "tan": 20, "exp": 10, "log": 10, "pow": 25, "atan2": 27, "asin": 20,
+_NODE_COST = {"lane_read": 8, "threefry": 90, "erfinv": 120, "sin": 12, "cos": 12, "tan": 20, "exp": 10, "log": 10, "pow": 25, "atan2": 27, "asin": 20,
               "acos": 20, "hypot": 12, "div": 4, "sqrt": 4, "interp": 30, "cbrt": 20, "sinh": 20, "cosh": 20, "erfc": 40, "log1p": 15,
               "expm1": 15, "mod": 8}
 

@@ -1565,9 +1565,89 @@ class _LaneEval(_Eval):
 
     CAP = 1 << 16              # elements a lazily-broadcast (uniform) tensor may take when a statement needs it in full
 
-    def __init__(self, funcs, n_entities: int):
+    def __init__(self, funcs, n_entities: int, stride: Optional[int] = None):
+        """stride: rows per world when the executor lays worlds out as `stride` consecutive rows (a power of two <= 16, >= N): lets a
+        constant-index gather ALONG the entity axis (a join, an edge_fold's targets) become an exchange inside the wavefront —
+        lane i of a world reads what lane j of the same world holds (dsl op `lane_read`, one ds_bpermute per 32-bit half).  None:
+        such gathers are refused."""
         super().__init__(funcs)
         self.N = int(n_entities)
+        self.S = int(stride) if stride else None
+        self.exchanges = 0            # lane_read nodes made: the manifest says whether the row layout matters
+
+    # -- the exchange inside a world --
+    def _lane_read(self, v, table: Tuple[int, ...]):
+        """What entity table[i] of this lane's world holds of `v`, seen from entity i."""
+        if isinstance(v, U64):
+            return U64(self._lane_read(v.hi, table), self._lane_read(v.lo, table))
+        v = _dsl._lift(v)
+        if _try_const(v) is not None or all(j == i for i, j in enumerate(table)):
+            return v
+        if v.op == "lane_read":                      # a read of a read: entity i <- t2[i] <- t1[t2[i]]
+            _, t1 = v.value
+            return self._lane_read(v.args[0], tuple(t1[j] for j in table))
+        self.exchanges += 1
+        return Expr("lane_read", (v,), (self.S, tuple(int(j) for j in table)))
+
+    def _exchange_gather(self, operand: Sym, indices: Sym, oe: int, ivd: int, rt: TensorType) -> Sym:
+        """operand[..., j_b, ...] for constant j_b along the entity axis: every lane gets entity j_b's slice of its own world."""
+        if self.S is None:
+            raise NotEntityParallel("stablehlo.gather reads other entities' rows of a per-entity tensor (a join or an edge_fold's targets): "
+                                    "the tick exchanges data between entities")
+        operand = self._mat(operand)
+        base = np.squeeze(operand.a, axis=oe)                      # one lane's slice, the entity axis gone
+        if operand.dtype == "i1":
+            base = _emap(lambda c: _np.where(c, 1.0, 0.0), base)
+        idx = self._mat(indices).a
+        batch_shape = tuple(d for k, d in enumerate(idx.shape) if k != ivd) if ivd < idx.ndim else idx.shape
+        flat = np.moveaxis(idx, ivd, -1).reshape(-1) if ivd < idx.ndim else idx.reshape(-1)
+        rows = []
+        for v in flat:
+            j = _try_const(v.to_float() if isinstance(v, U64) else v)
+            if j is None:
+                raise NotEntityParallel("stablehlo.gather along the entity axis with a traced (per-tick) index")
+            j = int(min(max(j, 0), self.N - 1))                    # gather clamps
+            rows.append(_emap(lambda e, j=j: self._lane_read(e, (j,) * self.S), base))
+        out = np.stack(rows, axis=0).reshape(batch_shape + base.shape) if rows else np.empty(rt.shape, dtype=object)
+        if operand.dtype == "i1":
+            out = _emap(lambda e: _dsl._lift(e) > 0.5, out)
+        if tuple(out.shape) != tuple(rt.shape):
+            raise NotEntityParallel(f"stablehlo.gather along the entity axis: result layout {out.shape} is not the module's {rt.shape}")
+        return self._annot(Sym(out, operand.dtype), rt.shape, None, ())
+
+    def _merge_rows(self, full: np.ndarray, dim: int):
+        """An [..., N, ...] tensor whose row s along `dim` holds, element by element, `lane_read(v, entity j_s)` of ONE node v (or one
+        constant): it is the per-entity tensor whose lane i reads entity j_i — the rows folded back onto the entity axis.  -> the
+        stored [..., 1, ...] array, or None when some element is not of that form."""
+        moved = np.moveaxis(full, dim, 0)
+        out = np.empty((1,) + moved.shape[1:], dtype=object)
+        pad = tuple(range(self.N, self.S))
+
+        def merge(col):
+            if all(isinstance(c, U64) for c in col):
+                hi, lo = merge([c.hi for c in col]), merge([c.lo for c in col])
+                return None if hi is None or lo is None else U64(hi, lo)
+            if any(not isinstance(c, Expr) for c in col):
+                return None
+            k0 = _try_const(col[0])
+            if k0 is not None and not isinstance(k0, bool) and all(_try_const(c) == k0 for c in col):
+                return col[0]
+            base, table = None, []
+            for c in col:
+                if c.op != "lane_read" or len(set(c.value[1])) != 1:
+                    return None
+                if base is None:
+                    base = c.args[0]
+                elif c.args[0] is not base:
+                    return None
+                table.append(c.value[1][0])
+            return self._lane_read(base, tuple(table) + pad)
+        for pos in (np.ndindex(moved.shape[1:]) if moved.ndim > 1 else [()]):
+            m = merge([moved[(s_,) + pos] for s_ in range(self.N)])
+            if m is None:
+                return None
+            out[(0,) + pos] = m
+        return np.moveaxis(out, 0, dim)
 
     # -- helpers --
     @staticmethod
@@ -1639,7 +1719,7 @@ class _LaneEval(_Eval):
         if not any(x.eaxis is not None or x.uni for x in xs):
             if rts and max(t.size for t in rts) > self.CAP and short not in ("broadcast_in_dim",):
                 raise NotEntityParallel(f"{name}: a {rts[0]} tensor that is not a column of the world")
-            if short != "broadcast_in_dim":
+            if short != "broadcast_in_dim" and not (short == "concatenate" and self.S):      # (a stack of exchange reads may fold back onto the entity axis)
                 return self._op(op, env)
         h = getattr(self, "_lane_" + short, None)
         if name.startswith("chlo.") or short in self._EW:
@@ -1769,6 +1849,13 @@ class _LaneEval(_Eval):
         dim = int(re.search(r"dim(?:ension)?\s*=\s*(\d+)", op.text).group(1))
         if any(x.eaxis == dim for x in xs):
             raise NotEntityParallel("stablehlo.concatenate along the entity axis (entity sets joined into one column)")
+        if self.S and all(x.eaxis is None for x in xs) and rts[0].shape[dim] == self.N and self.N > 1 and xs[0].dtype != "i1":
+            # per-source rows gathered from other entities, stacked back along the source axis (graph.rs:187-235): if every row is
+            # an exchange read of one value, the stack IS a per-entity tensor again (lane i reads entity j_i)
+            full = np.concatenate([self._mat(x).a for x in xs], axis=dim)
+            merged = self._merge_rows(full, dim)
+            if merged is not None:
+                return self._annot(Sym(merged, xs[0].dtype), rts[0].shape, dim, ())
         xs = [self._mat(x, [dim]) for x in xs]
         xs, eaxis, uni = self._join(xs, "stablehlo.concatenate", skip=[dim])
         full = [d for d in range(len(rts[0].shape)) if d != dim and d != eaxis and d not in uni]
@@ -1883,6 +1970,10 @@ class _LaneEval(_Eval):
                 eaxis = offset_dims[kept.index(oe)]             # whole columns picked by a shared index: the entity axis rides along
                 slice_sizes = list(slice_sizes)
                 slice_sizes[oe] = 1
+            elif oe in collapsed and start_map == [oe] and ie is None and all(slice_sizes[d] == operand.tshape[d] for d in kept):
+                if offset_dims != list(range(len(rt.shape) - len(offset_dims), len(rt.shape))):
+                    raise NotEntityParallel("stablehlo.gather along the entity axis whose offset dimensions are not the trailing ones")
+                return self._exchange_gather(operand, indices, oe, ivd, rt)
             else:
                 raise NotEntityParallel("stablehlo.gather reads other entities' rows of a per-entity tensor (a join or an edge_fold's targets): "
                                         "the tick exchanges data between entities")
@@ -2069,6 +2160,10 @@ def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = Non
             raise ValueError(f"result slot {s_.component}: shape {s_.shape} but @main returns {ty}")
     counts = {s_.shape[0] for s_ in ins + outs if not s_.elided and s_.shape}
     n_entities = counts.pop() if len(counts) == 1 else None
+    stride = None
+    if n_entities and 1 < n_entities <= 16:
+        stride = 1 << (n_entities - 1).bit_length()          # rows per world should the tick exchange data between its entities
+    used = {"exchanges": 0}
 
     def build(lane: bool):
         def width(s_: Slot) -> int:
@@ -2098,7 +2193,7 @@ def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = Non
                 elif ty.dtype == "ui64":
                     arr = _emap(U64.of, arr)
                 args.append(Sym(arr, ty.dtype, 0 if batched else None, (), ty.shape))
-            ev = _LaneEval(funcs, n_entities) if lane else _Eval(funcs)
+            ev = _LaneEval(funcs, n_entities, stride) if lane else _Eval(funcs)
             res = {}
             for s_, o in zip(outs, ev.call(main, args)):
                 if lane:
@@ -2115,6 +2210,7 @@ def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = Non
                 if src is not None and len(src) == len(vals) and all(a is b for a, b in zip(src, vals)):
                     continue                          # the tick hands the column back untouched (inertia, a parameter column): no store
                 res[s_.column] = _dsl.Vec(vals)
+            used["exchanges"] = getattr(ev, "exchanges", 0)
             return res
         fn.__name__ = name
         import inspect
@@ -2139,6 +2235,12 @@ def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = Non
                 raise NotEntityParallel("the batched slots do not share one entity count (components on different entity sets)")
             system_, manifest, widths = build(True)
             _dsl.Program([system_], _dsl.Pipe([]), []).trace(widths)      # refusals surface while tracing: find out now
+            if used["exchanges"]:
+                # the tick reads other entities of the same world (joins, an edge_fold's targets): a world must be `stride`
+                # consecutive rows of the executor — its N entities, then stride - N rows of padding — so that it never straddles a
+                # wavefront and the reads are lane exchanges (dsl op lane_read)
+                manifest["rows_per_world"] = stride
+                manifest["exchange_reads"] = used["exchanges"]
             return system_, manifest
         except NotEntityParallel as e:
             if mode == "lane":
@@ -2224,11 +2326,16 @@ def checkpoint(debug_dir: str, mode: str = "auto", device: int = 0, rtol: float 
         ret_slots = [Slot(name(out_ids, k, "ret"), ty.shape, not (len(ty.shape) >= 2 and ty.shape[0] == n)) for k, ty in enumerate(main.result_types)]
     system_, manifest = world_system(text, arg_slots, ret_slots, mode=mode)
     lane = manifest["mode"] == "lane"
-    rows = manifest["entities_per_world"] if lane else 1
+    n_ent = manifest["entities_per_world"] if lane else 1
+    rows = manifest.get("rows_per_world", n_ent) if lane else 1
     cols = {}
     for s_, a in zip(arg_slots, ins):
         v = np.asarray(a, dtype=np.float64)
-        cols[s_.column] = v.reshape(rows, -1) if (lane and not s_.elided) else np.tile(v.reshape(1, -1), (rows, 1))
+        if lane and not s_.elided:
+            cols[s_.column] = np.zeros((rows, v.size // n_ent))
+            cols[s_.column][:n_ent] = v.reshape(n_ent, -1)           # the world's entities, then padding rows
+        else:
+            cols[s_.column] = np.tile(v.reshape(1, -1), (rows, 1))
     for s_ in ret_slots:
         w = next(c["width"] for c in manifest["columns"] if c["column"] == s_.column)
         cols.setdefault(s_.column, np.zeros((rows, w)))
@@ -2242,7 +2349,7 @@ def checkpoint(debug_dir: str, mode: str = "auto", device: int = 0, rtol: float 
         report = {"mode": manifest["mode"], "outputs": [], "ok": True}
         for k, (s_, ty) in enumerate(zip(ret_slots, main.result_types)):
             got = np.asarray(hip._aux[s_.column], dtype=np.float64)
-            got = (got.reshape(ty.shape) if (lane and not s_.elided) else got[0].reshape(ty.shape))
+            got = (got[:n_ent].reshape(ty.shape) if (lane and not s_.elided) else got[0].reshape(ty.shape))
             np.ascontiguousarray(got.astype(_NP_DTYPE[ty.dtype])).tofile(d / f"hip_output_{k}.bin")
             for ref_name in ("xla_output", "cranelift_output"):
                 f_ = d / f"{ref_name}_{k}.bin"

@@ -146,6 +146,12 @@ def _eval(exprs, leaves, n):
             r = _dsl._GATHER_TABLES[key][i, col]
         elif e.op == "threefry":
             r = _threefry(*[np.broadcast_to(ev(a), (n,)) for a in e.args])[e.value]
+        elif e.op == "lane_read":      # the value entity table[i] of the row's world holds (worlds = `stride` consecutive rows)
+            stride, table = e.value
+            v = np.array(np.broadcast_to(ev(e.args[0]), (n,)))
+            rows = np.arange(n)
+            src = (rows // stride) * stride + np.asarray(table)[rows % stride]
+            r = v[np.minimum(src, n - 1)]
         elif e.op == "fbits":
             words = np.ascontiguousarray(np.broadcast_to(ev(e.args[0]), (n,)), dtype=np.float64).view(np.uint64)
             r = ((words >> np.uint64(32)) if e.value else (words & np.uint64(0xFFFFFFFF))).astype(np.float64)

@@ -314,35 +314,49 @@ def scaled(f: Fn, h: V, x: V) -> List[V]:
 G = 6.6743e-11
 
 
-def three_body_world():
-    """examples/three-body as ONE entity-batched tick: increment_sim_tick | six_dof(gravity), RK4.  -> (module text, slots)
+def edge_fold_world(n: int, targets: dict, fold: str, params: Sequence[float]):
+    """A world of n bodies whose forces come from ONE edge_fold over (WorldPos, Inertia) as ONE entity-batched tick:
+    increment_sim_tick | six_dof(fold), RK4.  targets: source row -> target rows in spawn order (every source the same count e, so
+    graph.rs:187-235 makes one bucket); fold: "newton" (examples/three-body/main.py:64-71, params = (G,)) or "softened"
+    (examples/n-body/sim.py:349-361, params = (K, eps)).  -> (module text, slots)
     slots: the seven (component, shape, entity_axis_elided) of @main's arguments = its results, in the module's order."""
-    n, e = 3, 2                                            # three bodies, two out-edges per source (main.py:80-87)
+    e = len(targets[0])
+    assert sorted(targets) == list(range(n)) and all(len(t) == e for t in targets.values())
     # ---- @norm: jnp.linalg.norm over the last axis, vmapped over the sources -------------------------------------------------------
     norm = Fn("norm", [((n, 3), "f64")])
     sq = norm.mul(norm.args[0], norm.args[0])
     norm.ret(norm.sqrt(norm.reduce_sum(sq, [1])))
-    # ---- @closed_call: the fold body gravity_fn (main.py:64-71) for all sources at once: (force, a_pos, a_inertia, b_pos, b_inertia) ---
+    # ---- @closed_call: the fold body for all sources at once: (force, a_pos, a_inertia, b_pos, b_inertia) --------------------------
     cc = Fn("closed_call", [((n, 6), "f64"), ((n, 7), "f64"), ((n, 7), "f64"), ((n, 7), "f64"), ((n, 7), "f64")])
     force, a_pos, a_in, b_pos, b_in = cc.args
-    r = cc.sub(cc.slice(a_pos, [(0, n), (4, 7)]), cc.slice(b_pos, [(0, n), (4, 7)]))
-    m, M = col(cc, a_in, 6), col(cc, b_in, 6)
-    (nr,) = cc.call(norm, [r])
-    gmm = cc.mul(cc.mul(cc.splat(G, (n,)), M), m)                                  # G * M * m
-    num = cc.mul(cc.bcast(gmm, (n, 3), [0]), r)                                    # ... * r
-    den = cc.mul(cc.mul(nr, nr), nr)                                               # norm * norm * norm
-    fvec = cc.div(num, cc.bcast(den, (n, 3), [0]))
-    lin = cc.sub(cc.slice(force, [(0, n), (3, 6)]), fvec)                          # el.Force(linear = force.force() - f): torque = 0
-    cc.ret(cc.concat([cc.splat(0.0, (n, 3)), lin], 1))
+    ma, mb = col(cc, a_in, 6), col(cc, b_in, 6)
+    if fold == "newton":
+        r = cc.sub(cc.slice(a_pos, [(0, n), (4, 7)]), cc.slice(b_pos, [(0, n), (4, 7)]))
+        (nr,) = cc.call(norm, [r])
+        gmm = cc.mul(cc.mul(cc.splat(params[0], (n,)), mb), ma)                          # G * M * m
+        num = cc.mul(cc.bcast(gmm, (n, 3), [0]), r)                                     # ... * r
+        den = cc.mul(cc.mul(nr, nr), nr)                                                # norm * norm * norm
+        fvec = cc.div(num, cc.bcast(den, (n, 3), [0]))
+        lin = cc.sub(cc.slice(force, [(0, n), (3, 6)]), fvec)                           # el.Force(linear = force.force() - f): torque = 0
+        cc.ret(cc.concat([cc.splat(0.0, (n, 3)), lin], 1))
+    else:
+        r = cc.sub(cc.slice(b_pos, [(0, n), (4, 7)]), cc.slice(a_pos, [(0, n), (4, 7)]))
+        d2 = cc.add(cc.reduce_sum(cc.mul(r, r), [1]), cc.splat(params[1], (n,)))       # jnp.dot(r, r) + SOFTENING
+        inv = cc.div(cc.splat(1.0, (n,)), cc.sqrt(d2))                                  # jnp.reciprocal(jnp.sqrt(.))
+        inv3 = cc.mul(cc.mul(inv, inv), inv)
+        sc = cc.mul(cc.mul(cc.mul(cc.splat(params[0], (n,)), ma), mb), inv3)            # K * m_a * m_b * inv_dist3
+        tq = cc.add(cc.slice(force, [(0, n), (0, 3)]), cc.splat(0.0, (n, 3)))           # acc + SpatialForce(linear = ...): torque + 0
+        lin = cc.add(cc.slice(force, [(0, n), (3, 6)]), cc.mul(cc.bcast(sc, (n, 3), [0]), r))
+        cc.ret(cc.concat([tq, lin], 1))
+        norm = None
     # ---- @inner: the whole tick ----------------------------------------------------------------------------------------------------
     inner = Fn("inner", [((), "i64"), ((), "f64"), ((n, 7), "f64"), ((n, 6), "f64"), ((n, 6), "f64"), ((n, 6), "f64"), ((n, 7), "f64")])
     tick, dt, pos0, vel0, accel_in, _force_in, inertia = inner.args
     f = inner
     tick1 = f.add(tick, f.const(1, (), "i64"))                                     # increment_sim_tick, globals.rs:40-44
-    targets = {0: [1, 2], 1: [0, 2], 2: [0, 1]}                                    # source row -> target rows in spawn order (main.py:80-87)
 
     def pipe(xs: V):
-        """clear_forces | gravity | calc_accel on the stage transforms xs (six_dof.rs:176)."""
+        """clear_forces | fold | calc_accel on the stage transforms xs (six_dof.rs:176)."""
         zero_force = f.splat(0.0, (n, 6))                                          # clear_forces + the fold's init value el.Force()
         # graph.rs:187-235: per source its row and its targets' rows by constant-index gathers, concatenated over the sources
         frm_p = f.concat([f.gather_rows(xs, [s]) for s in range(n)], 0)
@@ -387,7 +401,18 @@ def three_body_world():
     main.ret(*main.call(inner, main.args))
     slots = [("tick", [], True), ("simulation_time_step", [], True), ("world_pos", [n, 7], False), ("world_vel", [n, 6], False),
              ("world_accel", [n, 6], False), ("force", [n, 6], False), ("inertia", [n, 7], False)]
-    return module([main, inner, cc, norm]), slots
+    return module([main, inner, cc] + ([norm] if norm is not None else [])), slots
+
+
+def three_body_world():
+    """examples/three-body as ONE entity-batched tick: three bodies, two out-edges per source in spawn order (main.py:80-87)."""
+    return edge_fold_world(3, {0: [1, 2], 1: [0, 2], 2: [0, 1]}, "newton", (G,))
+
+
+def nbody_world(n: int, k: float, eps: float):
+    """examples/n-body as ONE entity-batched tick: n bodies, the complete gravity graph in spawn order (sim.py:330-338: for every
+    source its targets in ascending order), the softened fold of sim.py:349-361."""
+    return edge_fold_world(n, {s: [t for t in range(n) if t != s] for s in range(n)}, "softened", (k, eps))
 
 
 def independent_bodies_world(n: int):

@@ -65,3 +65,22 @@ def ball_errors(columns, g, r, lane=0):
     for c in ("world_pos", "world_vel", "world_accel", "force", "wind"):
         worst = max(worst, gu.rel_err(np.asarray(columns["hlo_" + c][lane], dtype=np.float64), g[f"ball.{c}"][r]))
     return worst
+
+
+def strided_world_columns(g, names, stride, worlds, extra_fill=None):
+    """Columns of `worlds` copies of a golden world laid out one lane per entity: a world = `stride` consecutive rows, its entities first,
+    padding rows (identity pose, unit inertia) behind them."""
+    n = len(names)
+    rows = stride * worlds
+    comps = {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), g["globals.simulation_time_step"][0, 0])}
+    for c, w in BODY:
+        a = np.zeros((rows, w))
+        if c == "world_pos":
+            a[:, 3] = 1.0
+        if c == "inertia":
+            a[:] = 1.0
+        for wd in range(worlds):
+            for i, e in enumerate(names):
+                a[wd * stride + i] = g[f"{e}.{c}"][0]
+        comps["hlo_" + c] = a
+    return comps

@@ -56,7 +56,7 @@ def test_three_body_whole_world_module_reproduces_g1_on_the_gpu():
     """The assembled whole-world tick (7 in / 7 out, main + inner + closed_call + norm; gather + transpose + while + dynamic_slice +
     call) with one lane per WORLD: lane 0 flies the reference's golden initial state for its 100 recorded ticks (<= 1e-9, vector-
     scaled AND element-wise), the other lanes fly perturbed worlds and are compared with the C oracle world by world."""
-    system, manifest, widths, row, g = W.three_body("auto")
+    system, manifest, widths, row, g = W.three_body("world")
     assert manifest["mode"] == "world"
     n = 96
     rng = np.random.default_rng(17)
@@ -131,7 +131,7 @@ def test_the_build_time_cli_object_is_installed_as_it_is(tmp_path):
             "arg_slots": [{"component_id": L.component_id(c), "shape": s, "entity_axis_elided": e} for c, s, e in slots]}      # ExecMetadata, exec.rs:17-29
     (tmp_path / "slots.json").write_text(json.dumps(meta))
     out = tmp_path / "pipe.so"
-    res = subprocess.run([sys.executable, "-m", "elodin_amd.stablehlo", str(tmp_path / "tick.mlir"), "--slots", str(tmp_path / "slots.json"), "-o", str(out)],
+    res = subprocess.run([sys.executable, "-m", "elodin_amd.stablehlo", str(tmp_path / "tick.mlir"), "--slots", str(tmp_path / "slots.json"), "-o", str(out), "--mode", "world"],
                          capture_output=True, text=True, cwd=str(L.PKG.parent))
     assert res.returncode == 0, res.stderr[-2000:]
     line = json.loads(res.stdout.strip().splitlines()[-1])
@@ -189,8 +189,85 @@ def test_the_references_first_tick_checkpoint_harness_with_this_backend_in_crane
     res = subprocess.run([sys.executable, "-m", "elodin_amd.stablehlo", "--checkpoint", str(tmp_path)], capture_output=True, text=True, cwd=str(L.PKG.parent))
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-1500:])
     rep = json.loads(res.stdout.strip().splitlines()[-1])
-    assert rep["ok"] and rep["mode"] == "world" and len(rep["outputs"]) == 7
+    assert rep["ok"] and rep["mode"] == "lane" and len(rep["outputs"]) == 7          # auto: one lane per entity, the fold's reads inside the wavefront
     assert rep["outputs"][0] == {"index": 0, "against": "xla_output", "equal": True}
     assert max(o.get("max_rel_err", 0.0) for o in rep["outputs"]) <= 1e-12
     assert np.array_equal(np.fromfile(tmp_path / "hip_output_0.bin", dtype=np.int64), [1])
     assert (tmp_path / "hip_checkpoint.json").exists()
+
+
+def test_three_body_world_one_lane_per_entity_exchange_inside_the_wavefront_on_the_gpu(tmp_path):
+    """mode "auto" on the three-body module: one lane per ENTITY, a world = 4 consecutive rows, the edge_fold's target rows read from
+    the other lanes of the world with ds_bpermute (`lane_read`).  4,096 worlds: world 0 flies G1's initial state (bit for bit over its
+    100 ticks), the others perturbed states checked against the C oracle; the CLI's default object (auto) is what runs."""
+    from tests.golden import hlo_world_builder as hb
+    text, slots = hb.three_body_world()
+    (tmp_path / "tick.mlir").write_text(text)
+    (tmp_path / "slots.json").write_text(json.dumps({"inputs": [{"component": c, "shape": s_, "entity_axis_elided": e} for c, s_, e in slots], "rows": 16384}))
+    res = subprocess.run([sys.executable, "-m", "elodin_amd.stablehlo", str(tmp_path / "tick.mlir"), "--slots", str(tmp_path / "slots.json"), "-o", str(tmp_path / "pipe.so")],
+                         capture_output=True, text=True, cwd=str(L.PKG.parent))
+    assert res.returncode == 0, res.stderr[-2000:]
+    program, manifest = sh.load_world(tmp_path / "pipe.so")
+    assert (manifest["mode"], manifest["rows_per_world"], manifest["entities_per_world"]) == ("lane", 4, 3)
+    g = W.gu.load("three_body")
+    S, worlds = 4, 4096
+    cols = W.strided_world_columns(g, "abc", S, worlds)
+    rng = np.random.default_rng(23)
+    body_rows = np.array([w_ * S + i for w_ in range(1, worlds) for i in range(3)])
+    cols["hlo_world_pos"][body_rows, 4:6] += rng.uniform(-0.05, 0.05, (len(body_rows), 2))
+    cols["hlo_world_vel"][body_rows, 3:5] += rng.uniform(-0.05, 0.05, (len(body_rows), 2))
+    start = {k: v.copy() for k, v in cols.items()}
+    hip = _exec(program, cols, S * worlds)
+    for r in range(1, 101):
+        hip.run(1)
+        for c, w in W.BODY[:4]:
+            for i, e in enumerate("abc"):
+                assert np.array_equal(hip._aux["hlo_" + c][i], g[f"{e}.{c}"][r]), (r, c, e)
+    dt = float(g["globals.simulation_time_step"][0, 0])
+    src, dst = np.array([0, 1, 0, 1, 2, 2], dtype=np.uint32), np.array([1, 0, 2, 2, 0, 1], dtype=np.uint32)
+    worst = 0.0
+    for wd in (1, 17, 2048, 4095):
+        sl = slice(wd * S, wd * S + 3)
+        w = orc.OracleWorld(start["hlo_world_pos"][sl], start["hlo_world_vel"][sl], start["hlo_inertia"][sl], simulation_time_step=dt,
+                            ops=[(orc.EFF_EDGE_GRAVITY_NEWTON, (6.6743e-11,), None)], edges=(src, dst))
+        w.step(100)
+        for c, ref in (("world_pos", w.world_pos), ("world_vel", w.world_vel), ("world_accel", w.world_accel), ("force", w.force)):
+            worst = max(worst, float(np.max(np.abs(hip._aux["hlo_" + c][sl] - ref) / np.maximum(np.max(np.abs(ref), axis=1, keepdims=True), 1e-300))))
+    print(f"three-body worlds, one lane per entity (lane_read): G1 bit for bit; perturbed worlds vs the oracle {worst:.2e}")
+    assert worst <= 1e-9
+    hip.close()
+
+
+def test_ten_body_solar_system_world_in_lane_mode_on_the_gpu():
+    """examples/n-body's 10-body world (90 edges, softened fold): one lane per entity, a world = 16 rows, every fold target an exchange
+    read; 1,024 worlds x 240 hourly ticks against the C oracle's sequential fold."""
+    from tests import solar_util as su
+    from tests.golden import hlo_world_builder as hb
+    d, pos, vel, inertia = su.load()
+    n = pos.shape[0]
+    text, slots = hb.nbody_world(n, su.K_SQUARED, su.SOFTENING_AU2)
+    system, manifest = sh.world_system(text, slots, mode="auto")
+    assert (manifest["mode"], manifest["rows_per_world"]) == ("lane", 16)
+    S, worlds = 16, 1024
+    rows = S * worlds
+
+    def lay(a, fill):
+        out = np.tile(np.asarray(fill, dtype=np.float64), (rows, 1))
+        for w_ in range(worlds):
+            out[w_ * S:w_ * S + n] = a
+        return out
+    cols = {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), su.DT), "hlo_world_pos": lay(pos, [0, 0, 0, 1.0, 0, 0, 0]),
+            "hlo_world_vel": lay(vel, np.zeros(6)), "hlo_inertia": lay(inertia, np.ones(7)), "hlo_world_accel": np.zeros((rows, 6)), "hlo_force": np.zeros((rows, 6))}
+    hip = _exec(dsl.Program([system], dsl.Pipe([]), []), cols, rows, ticks_per_launch=24)
+    hip.run(240)
+    w = orc.OracleWorld(pos, vel, inertia, simulation_time_step=su.DT, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, (su.K_SQUARED, su.SOFTENING_AU2), None)])
+    w.step(240)
+    worst = 0.0
+    for c, ref in (("world_pos", w.world_pos), ("world_vel", w.world_vel), ("world_accel", w.world_accel), ("force", w.force)):
+        for w_ in (0, 511, 1023):
+            got = hip._aux["hlo_" + c][w_ * S:w_ * S + n]
+            worst = max(worst, float(np.max(np.abs(got - ref) / np.maximum(np.max(np.abs(ref), axis=1, keepdims=True), 1e-300))))
+        assert np.array_equal(hip._aux["hlo_" + c][:n], hip._aux["hlo_" + c][1023 * S:1023 * S + n])          # identical worlds, identical rows
+    print(f"10-body solar system, 1,024 worlds x 240 ticks, lane mode vs the oracle: {worst:.2e}")
+    assert worst <= 1e-9
+    hip.close()

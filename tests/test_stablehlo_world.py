@@ -45,8 +45,8 @@ def test_three_body_world_module_has_the_structure_of_the_reference_dump():
 def test_three_body_world_tick_reproduces_the_reference_golden_100_ticks():
     """G1 (scripts/ci/baseline/three-body-csv) through the WHOLE-WORLD module, one lane = one world: bit for bit on the CPU walker
     (the module keeps the reference's operation order; numpy does not contract)."""
-    system, manifest, widths, row, g = W.three_body("auto")
-    assert manifest["mode"] == "world" and "edge_fold" in manifest["lane_refused"] or "other entities" in manifest["lane_refused"]
+    system, manifest, widths, row, g = W.three_body("world")
+    assert manifest["mode"] == "world" and manifest["rows"] == "worlds"
     comps = {c: np.tile(v[None, :], (2, 1)) for c, v in row.items()}
     worst = [0.0, 0.0]
 
@@ -57,6 +57,64 @@ def test_three_body_world_tick_reproduces_the_reference_golden_100_ticks():
     walk(system, widths, comps, 100, check)
     assert worst == [0.0, 0.0], worst
     assert np.array_equal(comps["hlo_world_pos"][0], comps["hlo_world_pos"][1])
+
+
+def test_three_body_world_tick_one_lane_per_entity_with_the_exchange_inside_the_wavefront():
+    """The same module with one lane per ENTITY (mode "auto" picks it): the edge_fold's constant-index row gathers along the entity axis
+    become reads of the other lanes of the world (dsl op `lane_read` = one ds_bpermute per 32-bit half), the per-source stack of
+    those rows folds back onto the entity axis, and a world is `rows_per_world` = 4 consecutive rows (3 bodies + 1 padding row).
+    G1's 100 ticks, three worlds side by side, bit for bit on the CPU walker; the kernel text is less than half the world-per-lane one."""
+    from elodin_amd import codegen
+    text, slots = hb.three_body_world()
+    system, manifest = sh.world_system(text, slots, mode="auto")
+    assert (manifest["mode"], manifest["rows_per_world"], manifest["entities_per_world"]) == ("lane", 4, 3) and manifest["exchange_reads"] > 0
+    widths = {c["column"]: c["width"] for c in manifest["columns"]}
+    assert widths["hlo_world_pos"] == 7
+    g = W.gu.load("three_body")
+    S, worlds = 4, 3
+    comps = W.strided_world_columns(g, "abc", S, worlds)
+    tp_box = []
+
+    def check(r):
+        for c, w in W.BODY[:4]:
+            for wd in range(worlds):
+                for i, e in enumerate("abc"):
+                    assert np.array_equal(comps["hlo_" + c][wd * S + i], g[f"{e}.{c}"][r]), (r, c, wd, e)
+    tp = walk(system, widths, comps, 100, check)
+    src = codegen.generate_source(tp, "float64", 2)
+    assert 0 < src.count("__shfl(") <= 64 and len(src) < 100_000
+
+
+def test_ten_body_solar_system_world_tick_in_lane_mode_equals_the_oracle():
+    """examples/n-body's world (sun + nine planets, the complete gravity graph: 90 edges, the softened fold of sim.py:349-361) as a
+    whole-world module: too large for one lane per world (70-wide world_pos), ingested with one lane per entity, a world = 16
+    consecutive rows, every fold target read from another lane of the wavefront.  48 hourly ticks equal to the C oracle's
+    sequential fold, bit for bit, for two worlds side by side."""
+    from tests import solar_util as su
+    d, pos, vel, inertia = su.load()
+    n = pos.shape[0]
+    text, slots = hb.nbody_world(n, su.K_SQUARED, su.SOFTENING_AU2)
+    with pytest.raises(NotImplementedError, match="wider than"):
+        sh.world_system(text, slots, mode="world")
+    system, manifest = sh.world_system(text, slots, mode="auto")
+    assert (manifest["mode"], manifest["rows_per_world"], manifest["entities_per_world"]) == ("lane", 16, 10)
+    widths = {c["column"]: c["width"] for c in manifest["columns"]}
+    S, worlds = 16, 2
+    rows = S * worlds
+
+    def lay(a, fill):
+        out = np.tile(np.asarray(fill, dtype=np.float64), (rows, 1))
+        for w_ in range(worlds):
+            out[w_ * S:w_ * S + n] = a
+        return out
+    comps = {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), su.DT), "hlo_world_pos": lay(pos, [0, 0, 0, 1.0, 0, 0, 0]),
+             "hlo_world_vel": lay(vel, np.zeros(6)), "hlo_inertia": lay(inertia, np.ones(7)), "hlo_world_accel": np.zeros((rows, 6)), "hlo_force": np.zeros((rows, 6))}
+    walk(system, widths, comps, 48)
+    w = orc.OracleWorld(pos, vel, inertia, simulation_time_step=su.DT, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, (su.K_SQUARED, su.SOFTENING_AU2), None)])
+    w.step(48)
+    for c, ref in (("world_pos", w.world_pos), ("world_vel", w.world_vel), ("world_accel", w.world_accel), ("force", w.force)):
+        for w_ in range(worlds):
+            assert np.array_equal(comps["hlo_" + c][w_ * S:w_ * S + n], ref), (c, w_)
 
 
 def test_independent_bodies_world_tick_is_entity_parallel_and_matches_the_oracle():
@@ -99,9 +157,6 @@ def test_a_world_of_65536_bodies_traces_as_fast_as_a_world_of_twelve():
 
 
 def test_what_the_entity_parallel_front_end_refuses_it_refuses_by_reason():
-    text, slots = hb.three_body_world()
-    with pytest.raises(sh.NotEntityParallel, match="other entities' rows"):
-        sh.world_system(text, slots, mode="lane")
     reduce_world = """
 module @module {
   func.func public @main(%arg0: tensor<4x3xf64>) -> tensor<4x3xf64> {
