@@ -7,8 +7,10 @@ turned into code of the SAME generated kernel the tracer feeds (elodin_amd.dsl -
   small static array whose elements become nodes.
 * `world_system(text, slots, mode=...)` / `compile_world` / `python -m elodin_amd.stablehlo tick.mlir --slots slots.json -o pipe.so` —
   a WHOLE-WORLD tick, what the reference actually hands a backend: `@main` over entity-batched `[N, w]` columns.  mode "lane": the
-  entity axis becomes the executor's rows (_LaneEval follows it through every statement and refuses whatever moves data between
-  entities; no `[N, ...]` tensor is ever materialised, 65,536 bodies trace like twelve); mode "world": the whole world in one lane,
+  entity axis becomes the executor's rows (_LaneEval follows it through every statement; no `[N, ...]` tensor is ever materialised,
+  65,536 bodies trace like twelve; constant-index gathers ALONG the entity axis — joins, an edge_fold's targets — become reads of the
+  other lanes of the world's wavefront, dsl op `lane_read`, with a world laid out as `rows_per_world` consecutive rows; what no lane
+  exchange covers is refused by reason); mode "world": the whole world in one lane,
   rows = independent worlds (edge folds, joins, reductions over the world are index arithmetic inside a lane); "auto" tries the
   former and falls back to the latter, recording why.  INTEGRATION.md §2b has the host side.
 * `load_world(pipe.so)` — the CLI's object + manifest back as a program an executor installs as it is.
@@ -28,8 +30,8 @@ node, exact below 2^53 (ticks, counters, indices, seeds; no wrap at 2^63).  Not 
 Pinned on the reference's own tests: libs/cranelift-mlir/tests/ops.rs (198 inline modules with asserted outputs ->
 tests/golden/stablehlo_ops.json; the 22 not extracted are listed there with the reason), the world-tick fragments of
 test_gather_3body / test_dynamic_ops_3body / test_while_dyn_slice / test_closed_call / test_threefry / test_threefry_e2e /
-test_uniform_pipeline.rs (-> tests/golden/stablehlo_world_fragments.json, 22 cases, integers compared exactly), and G1's 100
-three-body ticks through an assembled whole-world module (tests/golden/hlo_world_builder.py) — CPU walker:
+test_uniform_pipeline / test_sret_large.rs (-> tests/golden/stablehlo_world_fragments.json, 24 cases, integers compared exactly), and G1's 100
+three-body ticks and G2's 100 ball ticks through assembled whole-world modules (tests/golden/hlo_world_builder.py) — CPU walker:
 tests/test_stablehlo_ingest.py, tests/test_stablehlo_world.py; generated kernel: tests/test_gpu_stablehlo.py,
 tests/test_gpu_stablehlo_world.py.
 """
