@@ -562,6 +562,34 @@ def world_module_leg(device):
                                                        "us_per_tick": round(tm.kernel_device_ms, 3),
                                                        "world_steps_per_s": round(worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
                                                        "body_steps_per_s": round(3 * worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1)}
+    try:      # examples/n-body's 10-body solar system (90 edges, softened fold): too wide for one lane per world; lane mode, a world = 16 rows
+        from tests import solar_util as su
+        _, spos, svel, sin_ = su.load()
+        nb = spos.shape[0]
+        ntext, nslots = hb.nbody_world(nb, su.K_SQUARED, su.SOFTENING_AU2)
+        nsys, nman = sh.world_system(ntext, nslots, mode="auto")
+        S = nman["rows_per_world"]
+        worlds = 4096
+        rows = S * worlds
+        w = workloads.independent_bodies(rows)
+        def nlay(a, fill):
+            o = np.tile(np.asarray(fill, dtype=np.float64), (rows, 1))
+            for i in range(nb):
+                o[i::S] = a[i]
+            return o
+        cols = {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), su.DT), "hlo_world_pos": nlay(spos, [0, 0, 0, 1.0, 0, 0, 0]),
+                "hlo_world_vel": nlay(svel, np.zeros(6)), "hlo_inertia": nlay(sin_, np.ones(7)), "hlo_world_accel": np.zeros((rows, 6)), "hlo_force": np.zeros((rows, 6))}
+        ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=L.INTEGRATOR_NONE, effectors=dsl.Program([nsys], dsl.Pipe([]), []),
+                        columns=cols, ticks_per_launch=100, device=device)
+        ex.invoke_batch(100)
+        tm = ex.invoke_batch(1000)
+        ex.close()
+        out["solar_system_10_bodies_lane_mode"] = {"mode": nman["mode"], "rows_per_world": S, "entities_per_world": nb, "worlds": worlds, "rows": rows, "ticks": 1000,
+                                                   "us_per_tick": round(tm.kernel_device_ms, 3), "world_steps_per_s": round(worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
+                                                   "pair_evals_per_s": round(4.0 * nb * (nb - 1) * worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
+                                                   "exchange_reads_per_tick_in_the_program": nman.get("exchange_reads")}
+    except Exception as e:  # noqa: BLE001
+        out["solar_system_10_bodies_lane_mode"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     n = 65536
     text, slots = hb.independent_bodies_world(n)
     system, manifest = sh.world_system(text, slots, mode="lane")

@@ -52,7 +52,7 @@ class _F(Fn):
         return r
 
 
-def make(seed: int, n: int, steps: int = 28):
+def make(seed: int, n: int, steps: int = 28, exchange: bool = False):
     """-> (module text, argument slots, result slots) of a random entity-parallel tick over n entities."""
     rng = np.random.default_rng(seed)
     f = _F("main", [((n, 4), "f64"), ((n, 3), "f64"), ((n, 2, 3), "f64"), ((), "f64"), ((n,), "i64")], public=True)
@@ -69,7 +69,7 @@ def make(seed: int, n: int, steps: int = 28):
         eax[id(v)] = e
         return v
     for _ in range(steps):
-        kind = int(rng.integers(13))
+        kind = int(rng.integers(14 if exchange else 13))
         x = pick(lambda v: eax[id(v)] == 0)
         if kind == 0:                                           # unary
             put(f.un(["sine", "tanh", "abs", "cosine"][int(rng.integers(4))], x))
@@ -136,6 +136,11 @@ def make(seed: int, n: int, steps: int = 28):
             buf = f.while_counted(T, [f.splat(0.0, (T, n, w)), x], body)[0]
             pick_t = int(rng.integers(T))
             put(f.reshape(f.slice(buf, [(pick_t, pick_t + 1), (0, n), (0, w)]), (n, w)))
+        elif kind == 13 and len(x.shape) == 2:                  # a join: every entity reads ANOTHER entity's row (constant table), k reads per entity
+            e_ = int(rng.integers(1, 3))
+            tgt = [[int(t) for t in rng.integers(0, n, e_)] for _ in range(n)]
+            st = f.concat([f.reshape(f.gather_rows(x, tgt[s_]), (1, e_, x.shape[1])) for s_ in range(n)], 0)        # [n, e, w]
+            put(f.add(x, f.reduce_sum(f.transpose(st, [0, 2, 1]), [2])))                                          # own row + the sum of the rows read
     outs = []
     for want in (lambda v: len(v.shape) == 2 and v.shape[1] <= 12, lambda v: True):
         v = None

@@ -315,3 +315,42 @@ def test_ball_world_tick_with_jax_random_reproduces_the_reference_golden_100_tic
     print("ball whole-world module vs G2, 100 ticks:", worst[0])
     assert worst[0] < 1e-12
     assert np.allclose(comps["hlo_wind"][0], [-0.2058421394796434, -0.7847657764467411, 1.8160866726679836], rtol=1e-13)   # test_uniform_pipeline.rs:152-156
+
+
+@pytest.mark.parametrize("seed,n", [(s_, 3 + s_ % 3) for s_ in range(100, 116)])
+def test_random_modules_with_reads_between_entities_lane_exchange_equals_world_mode(seed, n):
+    """The same differential fuzz with JOINS in the mix: every entity reads rows of other entities of its world by a constant table
+    (gather along the entity axis, re-stacked per source — graph.rs:187-235's shape).  One lane per entity turns them into lane
+    exchanges inside a world of `rows_per_world` rows (3, 4 and 5 entities: strides 4, 4 and 8, padding rows included); the result
+    equals the plain evaluator's with the whole world in one lane, bit for bit, for two worlds side by side."""
+    from tests import hlo_fuzz
+    text, slots, out_slots = hlo_fuzz.make(seed, n, exchange=True)
+    vals = [hlo_fuzz.inputs(seed + 1000 * w_, n) for w_ in range(2)]
+    for v in vals[1:]:
+        v["k"] = vals[0]["k"]                       # the world-wide scalar is one value per world; keep the worlds' programs comparable
+    lane_sys, lane_m = sh.world_system(text, slots, out_slots, mode="lane")
+    world_sys, world_m = sh.world_system(text, slots, out_slots, mode="world")
+    S = lane_m.get("rows_per_world", n)
+    lw = {c["column"]: c["width"] for c in lane_m["columns"]}
+    ww = {c["column"]: c["width"] for c in world_m["columns"]}
+    lane, world = {}, {}
+    for k in vals[0]:
+        per_world = [np.asarray(v[k], dtype=np.float64) for v in vals]
+        if np.ndim(vals[0][k]) == 0:
+            lane["hlo_" + k] = np.concatenate([np.tile(p.reshape(1, -1), (S, 1)) for p in per_world])
+        else:
+            blocks = []
+            for p in per_world:
+                b = np.zeros((S, p.reshape(n, -1).shape[1]))
+                b[:n] = p.reshape(n, -1)
+                blocks.append(b)
+            lane["hlo_" + k] = np.concatenate(blocks)
+        world["hlo_" + k] = np.stack([p.reshape(-1) for p in per_world])
+    walk(lane_sys, lw, lane, 1)
+    walk(world_sys, ww, world, 1)
+    for name, shape, _ in out_slots:
+        for w_ in range(2):
+            got, want = lane["hlo_" + name][w_ * S:w_ * S + n].reshape(-1), world["hlo_" + name][w_]
+            assert np.array_equal(got, want, equal_nan=True), (seed, n, name, w_)
+    if "stablehlo.gather" in text and text.count('start_index_map = [0]') > text.count("tensor<5x3xf64>"):
+        assert lane_m.get("exchange_reads", 0) >= 0
