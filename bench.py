@@ -442,23 +442,37 @@ def build_times_leg(device):
     from elodin_amd import codegen, dsl
     from elodin_amd import stablehlo as sh
     saved = codegen.JIT_DIR
-    out = {"unit": "ms", "compiler": "hipcc --offload-arch=gfx950, one cache-policy instantiation per object, flag sets of a large program compiled concurrently"}
+    out = {"unit": "ms", "compiler": "hipcc --offload-arch=gfx950, one cache-policy instantiation per object, flag sets of a large program compiled concurrently, "
+                           "the kernel headers precompiled once per flag set (device + host PCH, codegen._Hipcc) and hipcc's own plan replayed with -include-pch"}
 
     def timed(name, make):
         """make() -> a callable that builds (trace + generate + compile) and returns the object's path."""
         tmp = Path(tempfile.mkdtemp(prefix="jit_cold_"))
         try:
             codegen.JIT_DIR = tmp
-            n0 = codegen.build_stats["hipcc_invocations"]
+            first = None
+            for attempt in range(2):
+                n0, p0 = codegen.build_stats["hipcc_invocations"], codegen.build_stats.get("pch_builds", 0)
+                build = make()                # (constructing the world / importing the example is not part of a build)
+                t0 = time.perf_counter()
+                build()
+                cold = time.perf_counter() - t0
+                inv = codegen.build_stats["hipcc_invocations"] - n0
+                if codegen.build_stats.get("pch_builds", 0) == p0:
+                    break
+                # this build also compiled the precompiled preamble of its flag set (once per install and header state, shared by
+                # every later program): reported on its own, and the program is built cold again with the preamble in place
+                first = cold
+                shutil.rmtree(tmp, ignore_errors=True)
+                tmp.mkdir()
+            build = make()
             t0 = time.perf_counter()
-            make()()
-            cold = time.perf_counter() - t0
-            inv = codegen.build_stats["hipcc_invocations"] - n0
-            t0 = time.perf_counter()
-            make()()
+            build()
             cached = time.perf_counter() - t0
             out[name] = {"cold_ms": round(cold * 1e3, 1), "cached_ms": round(cached * 1e3, 1), "hipcc_invocations": int(inv),
                          "resources": {k: codegen.last_resources.get(k) for k in ("vgprs", "agprs", "scratch_bytes_per_lane", "flags")}}
+            if first is not None:
+                out[name]["first_build_incl_precompiled_preamble_ms"] = round(first * 1e3, 1)
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
         finally:
@@ -472,9 +486,9 @@ def build_times_leg(device):
             w, sys_ = (mod.world(), mod.system()) if mod_name == "ball" else mod.world_and_system()
             def build():
                 dsl.Expr.fresh()
-                srcs = w.generated_sources(sys_, simulation_rate=120.0)
-                codegen._ONLY_POLICY[0] = 1
+                codegen._ONLY_POLICY[0] = 1          # as exec.HipExec builds it: the one cache policy its row count selects
                 try:
+                    srcs = w.generated_sources(sys_, simulation_rate=120.0)
                     return [codegen._compile(src, kind) for kind, src in srcs.items()]
                 finally:
                     codegen._ONLY_POLICY[0] = None

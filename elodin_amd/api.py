@@ -24,6 +24,7 @@ import enum
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
 
+import os
 import numpy as np
 
 from . import _lib as L
@@ -384,7 +385,8 @@ class World:
         else:
             for e in effs:
                 if isinstance(e, _dsl.EdgeFold):
-                    out["pair"] = codegen.generate_pair_source(e.trace())
+                    small = int(self.entity_len) <= 256 and os.environ.get("SIXDOF_PAIR_SMALL", "")[:1] != "0"     # as exec.HipExec does
+                    out["pair"] = codegen.generate_pair_source(e.trace(), integrator=plan["integrator"], small=small)
         return out
 
     def build(self, system: System, simulation_rate: float = 120.0, telemetry_rate: Optional[float] = None,

@@ -1324,8 +1324,15 @@ def _fold_is_additive(tf: "dsl.TracedFold") -> bool:
     return True
 
 
-def generate_pair_source(tf: "dsl.TracedFold") -> str:
-    """A user-written edge_fold function as the PAIR functor of csrc/pair_kernel.hpp (f64, both integrators)."""
+def generate_pair_source(tf: "dsl.TracedFold", integrator: Optional[int] = None, small: Optional[bool] = None) -> str:
+    """A user-written edge_fold function as the PAIR functor of csrc/pair_kernel.hpp (f64).  An executor names the integrator it
+    steps with and whether its graph runs as the one-launch small kernel (n <= kPairSmallMax, csrc/sixdof_capi.cpp): the object
+    then carries those kernels alone (5 or 2 instead of 11: a third of the device code to compile); launched any other way it
+    returns hipErrorInvalidValue.  None keeps both."""
+    only_i = -1 if integrator is None else int(integrator)
+    if only_i not in (-1, 0, 1):
+        raise ValueError(f"edge_fold effectors step under RK4 or the semi-implicit integrator, not integrator {integrator}")
+    only_s = -1 if small is None else int(bool(small))
     _GUARD_SELECTS[0], _FUSE_FMA[0] = False, False      # switches of generate_source: exact arithmetic here
     _TABLES.clear()
     _GATHERS.clear()
@@ -1359,19 +1366,25 @@ extern "C" unsigned sixdof_custom_pair_abi() {{ return static_cast<unsigned>(siz
 extern "C" int sixdof_custom_pair_launch(const sixdof::PairParams* p, int integrator, uint32_t n_ticks, int small,
                                          void* stream, uint64_t* launches) {{
     using namespace sixdof;
+    constexpr int kOnlyIntegrator = {only_i}, kOnlySmall = {only_s};      // -1: both
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (small) return static_cast<int>(launch_pair_small_t<PairCustom>(*p, integrator, n_ticks, s, launches));
-    for (uint32_t t = 0; t < n_ticks; t++) {{
-        const hipError_t e = launch_pair_tick_t<PairCustom, false>(*p, integrator, s, launches);
-        if (e != hipSuccess) return static_cast<int>(e);
+    if (kOnlySmall >= 0 && (small != 0) != (kOnlySmall != 0)) return static_cast<int>(hipErrorInvalidValue);
+    if constexpr (kOnlySmall != 0) {{
+        if (small) return static_cast<int>(launch_pair_small_t<PairCustom, kOnlyIntegrator>(*p, integrator, n_ticks, s, launches));
+    }}
+    if constexpr (kOnlySmall != 1) {{
+        for (uint32_t t = 0; t < n_ticks; t++) {{
+            const hipError_t e = launch_pair_tick_t<PairCustom, false, kOnlyIntegrator>(*p, integrator, s, launches);
+            if (e != hipSuccess) return static_cast<int>(e);
+        }}
     }}
     return static_cast<int>(hipSuccess);
 }}
 '''
 
 
-def build_pair(tf: "dsl.TracedFold") -> Path:
-    return _compile(generate_pair_source(tf), "pair")
+def build_pair(tf: "dsl.TracedFold", integrator: Optional[int] = None, small: Optional[bool] = None) -> Path:
+    return _compile(generate_pair_source(tf, integrator, small), "pair")
 
 
 def generate_graph_fold_source(tf: "dsl.TracedGraphFold") -> str:
@@ -1607,6 +1620,210 @@ def _resources(stderr: str) -> Dict[str, int]:
     return out
 
 
+# ---- precompiled preamble -------------------------------------------------------------------------------------------------
+# A small generated program is ~10 KB of straight-line code behind `#include "step_kernel.hpp"`; hipcc spends 1.2 of its 1.6 s
+# parsing hip_runtime.h and the kernel headers, once for the device pass and once for the host pass (-ftime-report).  The leading
+# comment / #define / #include lines of a generated source are the same for every program of a kind, so they are compiled ONCE
+# per (preamble, flag set, header state, compiler) into a device and a host PCH under _jit/, and a build replays hipcc's own plan
+# (`hipcc -###`: cc1 device, lld, bundler, cc1 host, ld) with `-include-pch` added to the two cc1 lines.  The device code is
+# byte-identical to the plain build's (tests/test_codegen_pch.py compares the disassembly).  Anything unexpected — a plan that
+# does not look like the above, a PCH clang refuses, a failing step — falls back to the plain hipcc command, which is also what
+# reports real compile errors.  SIXDOF_PCH=0 turns it off.
+_PCH_BROKEN: set = set()
+PCH_KEEP = 8
+PCH_PRUNE_MIN_AGE_S = 600.0
+PCH_DIR: List[Optional[Path]] = [None]       # where the PCH pairs live (default: the package's _jit/, also when JIT_DIR is redirected)
+
+
+def _preamble(src: str) -> str:
+    lines = []
+    seen_include = False
+    for line in src.splitlines(keepends=True):
+        t = line.strip()
+        if not t or t.startswith("//"):
+            continue                      # (the first comment names the program's systems: not part of what is precompiled)
+        elif t.startswith("#include") or (t.startswith("#define") and not t.endswith("\\")):
+            lines.append(line)
+            seen_include = seen_include or t.startswith("#include")
+        else:
+            break
+    return "".join(lines) if seen_include else ""
+
+
+def _plan(cmd: List[str]) -> Optional[List[List[str]]]:
+    import shlex
+    r = subprocess.run([*cmd, "-###"], capture_output=True, text=True)
+    if r.returncode != 0:
+        return None
+    steps = [shlex.split(line) for line in r.stderr.splitlines() if line.startswith(' "')]
+    cc1 = [c for c in steps if "-cc1" in c]
+    if len(cc1) != 2 or any("-emit-obj" not in c or "-triple" not in c or "-x" not in c for c in cc1):
+        return None
+    return steps
+
+
+def _cc1_side(c: List[str]) -> str:
+    return "dev" if c[c.index("-triple") + 1].startswith("amdgcn") else "host"
+
+
+def _header_state() -> str:
+    out = []
+    for f in sorted(CSRC.glob("*.hpp")) + [PKG.parent / "include" / "sixdof_hip.h"]:
+        st = f.stat()
+        out.append(f"{f.name}:{st.st_size}:{st.st_mtime_ns}")       # clang refuses a PCH whose inputs changed size or mtime
+    return ";".join(out)
+
+
+def _pch_pair(flags: List[str], preamble: str) -> Optional[Dict[str, str]]:
+    """The {dev, host} PCH files of `preamble` under `flags`, built on first use (both passes at once, ~1 s)."""
+    import tempfile
+    key = hashlib.sha1("\0".join([preamble, *flags, _header_state(), _hipcc_version(), _CACHE_TAG]).encode()).hexdigest()[:16]
+    if key in _PCH_BROKEN:
+        return None
+    store = PCH_DIR[0] or (PKG / "_jit")
+    store.mkdir(exist_ok=True)
+    pair = {side: str(store / f"pch_{key}.{side}.pch") for side in ("dev", "host")}
+    if all(os.path.exists(f) for f in pair.values()):
+        try:
+            os.utime(pair["dev"])          # last use (the pruning below keeps the most recently used)
+        except OSError:
+            pass
+        return pair
+    import time
+    t0 = time.perf_counter()
+    head = store / f"pch_{key}.hip"
+    made = []
+    try:
+        if not head.exists():
+            fd, name = tempfile.mkstemp(prefix=head.name + ".", suffix=".tmp", dir=store)
+            os.close(fd)
+            made.append(name)
+            Path(name).write_text(preamble)
+            os.replace(name, head)
+        steps = _plan([HIPCC, *flags, str(head), "-o", str(store / f"pch_{key}.so")])
+        if steps is None:
+            raise RuntimeError("unexpected hipcc plan")
+        procs = []
+        for c in steps:
+            if "-cc1" not in c:
+                continue
+            side = _cc1_side(c)
+            c = list(c)
+            c[c.index("-emit-obj")] = "-emit-pch"
+            fd, name = tempfile.mkstemp(prefix=f"pch_{key}.{side}.", suffix=".tmp", dir=store)
+            os.close(fd)
+            made.append(name)
+            c[c.index("-o") + 1] = name
+            if "-fcuda-include-gpubinary" in c:
+                i = c.index("-fcuda-include-gpubinary")
+                del c[i:i + 2]
+            procs.append((side, name, subprocess.Popen(c, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)))
+        bad = None
+        for side, name, pr in procs:
+            _, err = pr.communicate()
+            if pr.returncode != 0:
+                bad = err[-400:]
+        if bad is not None:
+            raise RuntimeError(bad)
+        for side, name, _ in procs:
+            os.replace(name, pair[side])
+        keep = sorted(store.glob("pch_*.dev.pch"), key=lambda f: f.stat().st_mtime, reverse=True)[:PCH_KEEP]
+        for f in store.glob("pch_*"):            # header edits and flag sets leave 24 MB pairs behind: the newest few stay
+            if not any(f.name.startswith(k.name[:-len("dev.pch")]) for k in keep) and not f.name.endswith(".tmp"):
+                try:
+                    if time.time() - f.stat().st_mtime < PCH_PRUNE_MIN_AGE_S:
+                        continue                 # another thread or process may be half-way through building this one
+                    f.unlink()
+                except OSError:
+                    pass
+        build_stats["pch_builds"] = build_stats.get("pch_builds", 0) + 1
+        build_stats["pch_build_ms"] = build_stats.get("pch_build_ms", 0.0) + (time.perf_counter() - t0) * 1e3
+        return pair
+    except (OSError, RuntimeError, ValueError):
+        _PCH_BROKEN.add(key)
+        return None
+    finally:
+        for name in made:
+            try:
+                os.unlink(name)
+            except OSError:
+                pass
+
+
+class _Hipcc:
+    """One hipcc invocation, replayed step by step with the precompiled preamble when there is one; `stop()` from another
+    thread ends it."""
+
+    def __init__(self, cmd: List[str], preamble: str):
+        self.cmd, self.preamble = cmd, preamble
+        self.current = None
+        self.stopped = False
+        self.returncode, self.stderr = None, ""
+
+    def _run(self, c, group=False):
+        if self.stopped:
+            return 1, ""
+        self.current = subprocess.Popen(c, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=group)
+        self._group = group
+        _, err = self.current.communicate()
+        return self.current.returncode, err
+
+    def stop(self):
+        import signal
+        self.stopped = True
+        pr = self.current
+        if pr is not None and pr.poll() is None:
+            try:
+                if self._group:
+                    os.killpg(pr.pid, signal.SIGKILL)      # exactly the group started in _run: hipcc's children stop with it
+                else:
+                    pr.kill()
+            except OSError:
+                pass
+
+    def run(self):
+        import tempfile
+        cmd = self.cmd
+        steps = pair = None
+        if self.preamble and os.environ.get("SIXDOF_PCH", "1") != "0":
+            src, out = cmd[-3], cmd[-1]
+            pair = _pch_pair([a for a in cmd[1:-3]], self.preamble)
+            steps = _plan(cmd) if pair else None
+        if steps:
+            tmpdir = tempfile.gettempdir()
+            scratch = set()
+            errs = []
+            ok = True
+            try:
+                for c in steps:
+                    for i, a in enumerate(c):
+                        f = c[i + 1] if a == "-o" and i + 1 < len(c) else a.split("=", 1)[1] if a.startswith("-output=") else None
+                        if f and f != out and os.path.dirname(f) == tmpdir:
+                            scratch.add(f)
+                    if "-cc1" in c:
+                        i = c.index("-x")
+                        c = c[:i] + ["-include-pch", pair[_cc1_side(c)]] + c[i:]
+                    rc, err = self._run(c)
+                    errs.append(err)
+                    if rc != 0:
+                        ok = False
+                        break
+            finally:
+                for f in scratch:
+                    try:
+                        os.unlink(f)
+                    except OSError:
+                        pass
+            if ok:
+                build_stats["pch_uses"] = build_stats.get("pch_uses", 0) + 1
+                self.returncode, self.stderr = 0, "".join(errs)
+                return self
+            if not self.stopped:
+                build_stats["pch_fallbacks"] = build_stats.get("pch_fallbacks", 0) + 1
+        self.returncode, self.stderr = self._run(cmd, group=True)
+        return self
+
+
 def _spill_message(name: str, used: Dict[str, int]) -> str:
     return (f"generated kernel {name} spills {used.get('vgpr_spills', 0)} VGPRs to scratch "
             f"({used.get('scratch_bytes_per_lane', 0)} B/lane): the program holds more state than a wave's 512 registers; "
@@ -1678,6 +1895,7 @@ def _compile(src: str, stem: str) -> Path:
             Path(t).write_text(src)
             os.replace(t, hip)
         best, best_obj = None, None
+        preamble = _preamble(src)
         # A LARGE program (the Falcon 9 tick: ~6 s per hipcc run, and its first flag set spills) starts every flag set AT ONCE and
         # keeps the first spill-free one in priority order, stopping the rest: a cold build costs the slowest attempt, not their sum
         # (19 -> ~7 s).  Small programs pass on the first set nearly always: they try one at a time as before.
@@ -1685,21 +1903,24 @@ def _compile(src: str, stem: str) -> Path:
         procs = []
         try:
             if speculative:
+                import threading
                 for opt, flags in _ATTEMPTS:
                     obj = temp(".so.tmp")
-                    procs.append((opt, flags, obj, subprocess.Popen(command(opt, flags, obj), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                                                                      start_new_session=True)))       # its own process group: hipcc's children stop with it
+                    job = _Hipcc(command(opt, flags, obj), preamble)
+                    th = threading.Thread(target=job.run, daemon=True)
+                    th.start()
+                    procs.append((opt, flags, obj, (job, th)))
                     build_stats["hipcc_invocations"] += 1
             for k, (opt, flags) in enumerate(_ATTEMPTS):
                 if speculative:
-                    _, _, obj, pr = procs[k]
-                    _, err = pr.communicate()
-                    rc_k, err_k = pr.returncode, err
+                    _, _, obj, (job, th) = procs[k]
+                    th.join()
+                    rc_k, err_k = job.returncode, job.stderr
                 else:
                     obj = temp(".so.tmp")
-                    res = subprocess.run(command(opt, flags, obj), capture_output=True, text=True)
+                    job = _Hipcc(command(opt, flags, obj), preamble).run()
                     build_stats["hipcc_invocations"] += 1
-                    rc_k, err_k = res.returncode, res.stderr
+                    rc_k, err_k = job.returncode, job.stderr
                 if rc_k != 0 and best is not None and best["vgpr_spills"] == 0:
                     continue          # this flag set does not even compile (an -O1 backend assertion): an acceptable object already exists
                 used = verdict(opt, flags, rc_k, err_k)
@@ -1713,14 +1934,10 @@ def _compile(src: str, stem: str) -> Path:
                 if cost(used) == (0, 0):
                     break
         finally:
-            for _, _, _, pr in procs:
-                if pr.poll() is None:
-                    import signal
-                    try:
-                        os.killpg(pr.pid, signal.SIGKILL)      # exactly the group started above
-                    except OSError:
-                        pr.kill()
-                    pr.communicate()
+            for _, _, _, (job, th) in procs:
+                job.stop()
+            for _, _, _, (job, th) in procs:
+                th.join()
         if best["vgpr_spills"] > 0 and os.environ.get(ALLOW_SPILLS_ENV, "") == "checked":
             # opt-in middle ground: accept the spilling object only when every spill slot (scratch and SGPR-in-lane) is provably
             # written on every path before it is read (elodin_amd/isa_check.py)

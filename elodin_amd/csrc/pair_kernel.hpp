@@ -498,47 +498,57 @@ inline uint32_t pair_splits_for_n(uint32_t n) {
 }
 
 // n <= kPairSmallMax: one single-workgroup launch for n_ticks ticks.
-template <class PAIR>
+// ONLY: -1 instantiates both integrators (the product library); a generated object built for one executor names the integrator
+// it will be launched with and carries that kernel alone — half the device code to compile (codegen.generate_pair_source).
+// Launching such an object with the other integrator is an error, not a silent substitution.
+template <class PAIR, int ONLY = -1>
 inline hipError_t launch_pair_small_t(const PairParams& p, int integrator, uint32_t n_ticks, hipStream_t stream,
                                       uint64_t* launches) {
     if (p.n == 0 || n_ticks == 0) return hipSuccess;
+    if (ONLY >= 0 && integrator != ONLY) return hipErrorInvalidValue;
     const dim3 block(p.n <= 64 ? 64 : kTile);   // one wave when it suffices: its barriers cost nothing
-    if (integrator == kRk4) hipLaunchKernelGGL((pair_small_kernel<kRk4, PAIR>), dim3(1), block, 0, stream, p, n_ticks);
-    else hipLaunchKernelGGL((pair_small_kernel<kSemiImplicit, PAIR>), dim3(1), block, 0, stream, p, n_ticks);
+    if constexpr (ONLY != kSemiImplicit) {
+        if (integrator == kRk4) hipLaunchKernelGGL((pair_small_kernel<kRk4, PAIR>), dim3(1), block, 0, stream, p, n_ticks);
+    }
+    if constexpr (ONLY != kRk4) {
+        if (integrator != kRk4) hipLaunchKernelGGL((pair_small_kernel<kSemiImplicit, PAIR>), dim3(1), block, 0, stream, p, n_ticks);
+    }
     if (launches) *launches += 1;
     return hipGetLastError();
 }
 
 // One tick as pack -> fold -> integrate.  ALLPAIRS selects the tiled complete-graph kernel (softened gravity).
-template <class PAIR, bool ALLPAIRS>
+template <class PAIR, bool ALLPAIRS, int ONLY = -1>
 inline hipError_t launch_pair_tick_t(const PairParams& p, int integrator, hipStream_t stream, uint64_t* launches) {
     if (p.n == 0) return hipSuccess;
+    if (ONLY >= 0 && integrator != ONLY) return hipErrorInvalidValue;
     const uint32_t blocks = (p.n + 255) / 256;
     const double h1 = p.dt_g * 0.5, h3 = p.dt_g;
     hipLaunchKernelGGL(pair_pack_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<const double*>(p.pos),
                        static_cast<const double*>(p.vel), static_cast<const double*>(p.inertia), p.pack, p.n, h1, h3);
     const bool rk4 = integrator == kRk4;
-    if (ALLPAIRS) {
+    if constexpr (ALLPAIRS) {
         const dim3 grid((p.n + kTile - 1) / kTile, p.splits);
-        if (rk4) hipLaunchKernelGGL(allpairs_kernel<3>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1);
-        else hipLaunchKernelGGL(allpairs_kernel<1>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1);
+        if constexpr (ONLY != kSemiImplicit) { if (rk4) hipLaunchKernelGGL(allpairs_kernel<3>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1); }
+        if constexpr (ONLY != kRk4) { if (!rk4) hipLaunchKernelGGL(allpairs_kernel<1>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1); }
     } else {
         const uint32_t hubs = PAIR::kAdditive ? p.n_hubs : 0u;   // a fold that is not a plain sum stays sequential per source
-        if (rk4) hipLaunchKernelGGL((edge_kernel<3, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1, hubs);
-        else hipLaunchKernelGGL((edge_kernel<1, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1, hubs);
+        if constexpr (ONLY != kSemiImplicit) { if (rk4) hipLaunchKernelGGL((edge_kernel<3, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1, hubs); }
+        if constexpr (ONLY != kRk4) { if (!rk4) hipLaunchKernelGGL((edge_kernel<1, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1, hubs); }
         if (hubs) {
-            if (rk4) {
+            if constexpr (ONLY != kSemiImplicit) if (rk4) {
                 hipLaunchKernelGGL((edge_hub_chunk_kernel<3, PAIR>), dim3(p.n_hub_chunks), dim3(64), 0, stream, p.pack, p.row_start, p.dst, p.chunk_e0, p.chunk_row, p.chunk_partial, p.p0, p.p1);
                 hipLaunchKernelGGL(edge_hub_reduce_kernel<3>, dim3(hubs), dim3(64), 0, stream, p.hub_rows, p.hub_chunk_start, p.chunk_partial, p.partial);
-            } else {
+            }
+            if constexpr (ONLY != kRk4) if (!rk4) {
                 hipLaunchKernelGGL((edge_hub_chunk_kernel<1, PAIR>), dim3(p.n_hub_chunks), dim3(64), 0, stream, p.pack, p.row_start, p.dst, p.chunk_e0, p.chunk_row, p.chunk_partial, p.p0, p.p1);
                 hipLaunchKernelGGL(edge_hub_reduce_kernel<1>, dim3(hubs), dim3(64), 0, stream, p.hub_rows, p.hub_chunk_start, p.chunk_partial, p.partial);
             }
             if (launches) *launches += 2;
         }
     }
-    if (rk4) hipLaunchKernelGGL(pair_integrate_kernel<kRk4>, dim3(blocks), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(pair_integrate_kernel<kSemiImplicit>, dim3(blocks), dim3(256), 0, stream, p);
+    if constexpr (ONLY != kSemiImplicit) { if (rk4) hipLaunchKernelGGL(pair_integrate_kernel<kRk4>, dim3(blocks), dim3(256), 0, stream, p); }
+    if constexpr (ONLY != kRk4) { if (!rk4) hipLaunchKernelGGL(pair_integrate_kernel<kSemiImplicit>, dim3(blocks), dim3(256), 0, stream, p); }
     if (launches) *launches += 3;
     return hipGetLastError();
 }
