@@ -2212,7 +2212,17 @@ def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = Non
                 if src is not None and len(src) == len(vals) and all(a is b for a, b in zip(src, vals)):
                     continue                          # the tick hands the column back untouched (inertia, a parameter column): no store
                 res[s_.column] = _dsl.Vec(vals)
-            used["exchanges"] = getattr(ev, "exchanges", 0)
+            # the reads the kernel executes: lane_read nodes the stored results reach (the evaluator builds many more that fold away —
+            # rows gathered one source at a time and merged back, carried tensors a loop never uses)
+            seen, live, todo = set(), 0, [e for v in res.values() for e in v.e if isinstance(e, Expr)]
+            while todo:
+                x = todo.pop()
+                if id(x) in seen:
+                    continue
+                seen.add(id(x))
+                live += x.op == "lane_read"
+                todo.extend(a for a in x.args if isinstance(a, Expr))
+            used["exchanges"] = live
             return res
         fn.__name__ = name
         import inspect
