@@ -1635,6 +1635,24 @@ PCH_PRUNE_MIN_AGE_S = 600.0
 PCH_DIR: List[Optional[Path]] = [None]       # where the PCH pairs live (default: the package's _jit/, also when JIT_DIR is redirected)
 
 
+def lane_stride(tp) -> int:
+    """The largest `rows_per_world` among the program's lane_read nodes (1 when it has none): an executor of this program must
+    hold a whole number of such worlds, or the last partial one would read lanes that do not exist."""
+    stride, seen, todo = 1, set(), []
+    for ts in list(getattr(tp, "pre", None) or []) + list(getattr(tp, "post", None) or []):
+        for item in getattr(ts, "assign", None) or []:
+            todo.extend(x for x in (item if isinstance(item, (tuple, list)) else [item]) if isinstance(x, dsl.Expr))
+    while todo:
+        x = todo.pop()
+        if id(x) in seen:
+            continue
+        seen.add(id(x))
+        if x.op == "lane_read":
+            stride = max(stride, int(x.value[0]))
+        todo.extend(a for a in x.args if isinstance(a, dsl.Expr))
+    return stride
+
+
 def _preamble(src: str) -> str:
     lines = []
     seen_include = False

@@ -145,6 +145,11 @@ class HipExec:
                         custom = effectors.trace(widths)
                         if memo is not None:
                             memo[("trace", wkey)] = custom
+                rows_multiple = int(getattr(custom, "rows_multiple", 0) or codegen.lane_stride(custom))
+                if rows_multiple > 1 and self.world_pos.shape[0] % rows_multiple:
+                    raise ValueError(f"this program exchanges data between the entities of a world laid out as {rows_multiple} consecutive rows "
+                                     f"(a whole-world StableHLO tick in lane mode, manifest 'rows_per_world'): the executor's {self.world_pos.shape[0]} "
+                                     f"rows are not a whole number of worlds")
                 if isinstance(effectors, _dsl.Program):
                     self._program_columns = [n for n, _ in custom.columns]
                     self._windows = {name: (rows, width) for name, (_, rows, width) in custom.windows.items()}

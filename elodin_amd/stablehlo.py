@@ -2300,6 +2300,7 @@ def load_world(so_path: str):
     manifest = json.loads(Path(str(so_path) + ".json").read_text())
     prog = _dsl.FrozenProgram(None, [(c["column"], c["width"]) for c in manifest["columns"]],
                               column_soa=manifest.get("column_layout") == "element-major", prebuilt_so=str(so_path))
+    prog._traced.rows_multiple = int(manifest.get("rows_per_world", 1))      # exec.HipExec refuses a row count that splits a world
     return prog, manifest
 
 

@@ -85,6 +85,28 @@ def test_three_body_world_tick_one_lane_per_entity_with_the_exchange_inside_the_
     assert 0 < src.count("__shfl(") <= 64 and len(src) < 100_000
 
 
+def test_an_executor_whose_rows_split_a_world_is_refused_before_the_device_is_touched():
+    """Lane mode with exchange lays a world out as `rows_per_world` consecutive rows; a row count that is not a whole number of
+    worlds would let the last one read lanes that do not exist.  HipExec checks it on the traced program (and on a prebuilt
+    object through the manifest), before any device call — so this runs without a GPU."""
+    import elodin_amd.exec as ea
+    from elodin_amd import _lib as L, codegen, dsl
+    text, slots = hb.three_body_world()
+    system, manifest = sh.world_system(text, slots, mode="lane")
+    assert manifest["exchange_reads"] == 20
+    widths = {c["column"]: c["width"] for c in manifest["columns"]}
+    assert codegen.lane_stride(dsl.Program([system], dsl.Pipe([]), []).trace(widths)) == 4
+    rows = 6
+    cols = {c: np.zeros((rows, w)) for c, w in widths.items()}
+    body = (np.tile([0, 0, 0, 1.0, 0, 0, 0], (rows, 1)), np.zeros((rows, 6)), np.ones((rows, 7)))
+    with pytest.raises(ValueError, match="not a whole number of worlds"):
+        ea.HipExec(*body, integrator=L.INTEGRATOR_NONE, effectors=dsl.Program([system], dsl.Pipe([]), []), columns=cols)
+    frozen = dsl.FrozenProgram(None, list(widths.items()), prebuilt_so="/nonexistent/pipe.so")
+    frozen._traced.rows_multiple = manifest["rows_per_world"]
+    with pytest.raises(ValueError, match="not a whole number of worlds"):
+        ea.HipExec(*body, integrator=L.INTEGRATOR_NONE, effectors=frozen, columns=cols)
+
+
 def test_ten_body_solar_system_world_tick_in_lane_mode_equals_the_oracle():
     """examples/n-body's world (sun + nine planets, the complete gravity graph: 90 edges, the softened fold of sim.py:349-361) as a
     whole-world module: too large for one lane per world (70-wide world_pos), ingested with one lane per entity, a world = 16
