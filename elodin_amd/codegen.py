@@ -1979,8 +1979,11 @@ def _compile(src: str, stem: str) -> Path:
         last_resources = best
         return so
     finally:
+        import glob
         for t in temps:
-            try:
-                os.unlink(t)
-            except OSError:
-                pass
+            # (+ what a stopped attempt's linker left half-written next to its output: ld.lld writes `<out>.tmpXXXXXX`, then renames)
+            for f in [t, *glob.glob(glob.escape(t) + ".tmp*")]:
+                try:
+                    os.unlink(f)
+                except OSError:
+                    pass
