@@ -1624,7 +1624,7 @@ def _resources(stderr: str) -> Dict[str, int]:
 # A small generated program is ~10 KB of straight-line code behind `#include "step_kernel.hpp"`; hipcc spends 1.2 of its 1.6 s
 # parsing hip_runtime.h and the kernel headers, once for the device pass and once for the host pass (-ftime-report).  The leading
 # comment / #define / #include lines of a generated source are the same for every program of a kind, so they are compiled ONCE
-# per (preamble, flag set, header state, compiler) into a device and a host PCH under _jit/, and a build replays hipcc's own plan
+# per (preamble, flag set, header state, compiler) into a device and a host PCH (in a per-user temporary directory), and a build replays hipcc's own plan
 # (`hipcc -###`: cc1 device, lld, bundler, cc1 host, ld) with `-include-pch` added to the two cc1 lines.  The device code is
 # byte-identical to the plain build's (tests/test_codegen_pch.py compares the disassembly).  Anything unexpected — a plan that
 # does not look like the above, a PCH clang refuses, a failing step — falls back to the plain hipcc command, which is also what
@@ -1632,7 +1632,7 @@ def _resources(stderr: str) -> Dict[str, int]:
 _PCH_BROKEN: set = set()
 PCH_KEEP = 8
 PCH_PRUNE_MIN_AGE_S = 600.0
-PCH_DIR: List[Optional[Path]] = [None]       # where the PCH pairs live (default: the package's _jit/, also when JIT_DIR is redirected)
+PCH_DIR: List[Optional[Path]] = [None]       # where the PCH pairs live (None: _pch_store()'s default)
 
 
 def lane_stride(tp) -> int:
@@ -1692,14 +1692,32 @@ def _header_state() -> str:
     return ";".join(out)
 
 
+def _pch_store() -> Optional[Path]:
+    """Where the PCH pairs live: PCH_DIR[0], else $SIXDOF_PCH_DIR, else a per-user directory under the system's temporary directory —
+    NOT the package's _jit/: a pair is 24 MB and valid only for this machine's header files (clang checks their size and mtime), so
+    it must not travel with the tree the way the built objects do.  The directory is private (0700) and must belong to this user."""
+    import tempfile
+    store = PCH_DIR[0] or (Path(os.environ["SIXDOF_PCH_DIR"]) if os.environ.get("SIXDOF_PCH_DIR") else
+                           Path(tempfile.gettempdir()) / f"elodin_amd_pch_{os.getuid()}")
+    try:
+        store.mkdir(mode=0o700, parents=True, exist_ok=True)
+        st = store.stat()
+        if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            return None           # somebody else's (or writable by others): compile without it
+    except OSError:
+        return None
+    return store
+
+
 def _pch_pair(flags: List[str], preamble: str) -> Optional[Dict[str, str]]:
     """The {dev, host} PCH files of `preamble` under `flags`, built on first use (both passes at once, ~1 s)."""
     import tempfile
     key = hashlib.sha1("\0".join([preamble, *flags, _header_state(), _hipcc_version(), _CACHE_TAG]).encode()).hexdigest()[:16]
     if key in _PCH_BROKEN:
         return None
-    store = PCH_DIR[0] or (PKG / "_jit")
-    store.mkdir(exist_ok=True)
+    store = _pch_store()
+    if store is None:
+        return None
     pair = {side: str(store / f"pch_{key}.{side}.pch") for side in ("dev", "host")}
     if all(os.path.exists(f) for f in pair.values()):
         try:
