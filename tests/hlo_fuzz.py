@@ -64,6 +64,8 @@ def make(seed: int, n: int, steps: int = 28, exchange: bool = False):
         cand = [v for v in pool if pred(v)]
         return cand[int(rng.integers(len(cand)))] if cand else None
 
+    joins = []
+
     def put(v, e=0):
         pool.append(v)
         eax[id(v)] = e
@@ -140,7 +142,11 @@ def make(seed: int, n: int, steps: int = 28, exchange: bool = False):
             e_ = int(rng.integers(1, 3))
             tgt = [[int(t) for t in rng.integers(0, n, e_)] for _ in range(n)]
             st = f.concat([f.reshape(f.gather_rows(x, tgt[s_]), (1, e_, x.shape[1])) for s_ in range(n)], 0)        # [n, e, w]
-            put(f.add(x, f.reduce_sum(f.transpose(st, [0, 2, 1]), [2])))                                          # own row + the sum of the rows read
+            joins.append(put(f.add(x, f.reduce_sum(f.transpose(st, [0, 2, 1]), [2]))))                            # own row + the sum of the rows read
+    if exchange and not joins:                                  # at least one join whose result is returned (below): the exchange is LIVE
+        tgt = [[(s_ + 1) % n, int(rng.integers(0, n))] for s_ in range(n)]
+        st = f.concat([f.reshape(f.gather_rows(a, tgt[s_]), (1, 2, 4)) for s_ in range(n)], 0)
+        joins.append(put(f.add(a, f.reduce_sum(f.transpose(st, [0, 2, 1]), [2]))))
     outs = []
     for want in (lambda v: len(v.shape) == 2 and v.shape[1] <= 12, lambda v: True):
         v = None
@@ -149,6 +155,8 @@ def make(seed: int, n: int, steps: int = 28, exchange: bool = False):
                 v = cand
                 break
         outs.append(v if v is not None else a)
+    if joins and all(joins[-1] is not o for o in outs):
+        outs.append(joins[-1])
     f.ret(*outs)
     slots = [("a", [n, 4], False), ("b", [n, 3], False), ("c", [n, 2, 3], False), ("k", [], True), ("idx", [n], False)]
     out_slots = [(f"out{j}", list(o.shape), False) for j, o in enumerate(outs)]

@@ -271,3 +271,53 @@ def test_ten_body_solar_system_world_in_lane_mode_on_the_gpu():
     print(f"10-body solar system, 1,024 worlds x 240 ticks, lane mode vs the oracle: {worst:.2e}")
     assert worst <= 1e-9
     hip.close()
+
+
+@pytest.mark.parametrize("seed,n", [(s_, 3 + s_ % 3) for s_ in (101, 102, 104, 106, 107, 108, 110, 113)])
+def test_random_modules_with_reads_between_entities_through_the_generated_kernel(seed, n):
+    """tests/hlo_fuzz.py's modules with JOINS (constant-table gathers along the entity axis, re-stacked per source) in lane mode on the
+    GPU: `lane_read` with per-entity source tables as one ds_bpermute per 32-bit half, worlds of 4 and 8 rows at every position of a
+    wavefront, the last wavefront only partly filled.  Against the numpy walker of the same traced program: 1e-12 of each result's
+    scale (the device's libm differs from numpy's in the last place), NaNs in the same places."""
+    from tests import hlo_fuzz
+    from tests.test_stablehlo_world import walk
+    text, slots, out_slots = hlo_fuzz.make(seed, n, exchange=True)
+    system, manifest = sh.world_system(text, slots, out_slots, mode="lane")
+    S = manifest.get("rows_per_world", n)
+    assert manifest["exchange_reads"] > 0 and S in (4, 8)
+    worlds = 24 if S == 4 else 12                        # 96 rows: one full wavefront + half of a second
+    vals = [hlo_fuzz.inputs(seed + 1000 * w_, n) for w_ in range(worlds)]
+    widths = {c["column"]: c["width"] for c in manifest["columns"]}
+    cols = {}
+    for k in vals[0]:
+        per_world = [np.asarray(v[k], dtype=np.float64) for v in vals]
+        if np.ndim(vals[0][k]) == 0:
+            cols["hlo_" + k] = np.concatenate([np.tile(p.reshape(1, -1), (S, 1)) for p in per_world])
+        else:
+            blocks = []
+            for p in per_world:
+                b = np.zeros((S, p.reshape(n, -1).shape[1]))
+                b[:n] = p.reshape(n, -1)
+                blocks.append(b)
+            cols["hlo_" + k] = np.concatenate(blocks)
+    rows = S * worlds
+    for c, w in widths.items():
+        cols.setdefault(c, np.zeros((rows, w)))
+    host = {k: v.copy() for k, v in cols.items()}
+    walk(system, widths, host, 1)
+    hip = _exec(dsl.Program([system], dsl.Pipe([]), []), cols, rows)
+    hip.run(1)
+    worst = 0.0
+    for name, shape, _ in out_slots:
+        c = "hlo_" + name
+        got, want = np.asarray(hip._aux[c], dtype=np.float64), host[c]
+        for w_ in range(worlds):
+            g, e = got[w_ * S:w_ * S + n], want[w_ * S:w_ * S + n]
+            assert np.array_equal(np.isnan(g), np.isnan(e)), (seed, name, w_)
+            fin = np.isfinite(e)
+            assert np.array_equal(g[~fin & ~np.isnan(e)], e[~fin & ~np.isnan(e)]), (seed, name, w_)
+            if fin.any():
+                worst = max(worst, float(np.max(np.abs(g[fin] - e[fin])) / max(1.0, float(np.max(np.abs(e[fin]))))))
+    print(f"seed {seed}: n {n}, rows_per_world {S}, {manifest['exchange_reads']} exchange reads, worst {worst:.2e}")
+    assert worst <= 1e-12
+    hip.close()

@@ -374,5 +374,4 @@ def test_random_modules_with_reads_between_entities_lane_exchange_equals_world_m
         for w_ in range(2):
             got, want = lane["hlo_" + name][w_ * S:w_ * S + n].reshape(-1), world["hlo_" + name][w_]
             assert np.array_equal(got, want, equal_nan=True), (seed, n, name, w_)
-    if "stablehlo.gather" in text and text.count('start_index_map = [0]') > text.count("tensor<5x3xf64>"):
-        assert lane_m.get("exchange_reads", 0) >= 0
+    assert lane_m["exchange_reads"] > 0 and S == (4 if n <= 4 else 8)      # every module returns a join's result: the exchange is live
