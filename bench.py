@@ -40,10 +40,11 @@ BYTES_PER_ENTITY_STEP_F64 = 360 + 24
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 PMC_FILE = ROOT / "profiles" / "pmc_traffic.json"  # written by profiles/collect.sh from separate --pmc passes
 PMC_VALU_FILE = ROOT / "profiles" / "pmc_valu.json"   # profiles/collect_compute.sh + summarize_compute.py --json: VALU per wave and tick
+WORLD_VALU_FILE = ROOT / "profiles" / "pmc_valu_world.json"   # profiles/collect_world.sh: the same count for the whole-world StableHLO ticks
 VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4      # 1,024 SIMDs x 2.4 GHz / 4 clocks per 64-wide VALU instruction (MI355X_MICROARCH.md)
 
 
-def valu_roofline(key, rollouts, ticks, seconds):
+def valu_roofline(key, rollouts, ticks, seconds, file=None):
     """The roofline that bounds a campaign kernel (BASELINE configs[3] / [4]): VALU ISSUE.  One lane flies one rollout with its
     state in registers, so a tick is `valu_per_wave_per_tick` vector instructions per wave (measured: SQ_INSTS_VALU / SQ_WAVES /
     ticks in its own rocprofv3 --pmc pass, committed as profiles/pmc_valu.json + profiles/r05_compute_kernels_pmc.md) and the chip
@@ -52,14 +53,15 @@ def valu_roofline(key, rollouts, ticks, seconds):
     out = {"bound": "valu issue", "unit": "wave-instructions/s", "peak": VALU_PEAK_WAVE_INSTR_PER_S, "waves": waves, "simds": 1024,
            "simds_occupied": min(waves, 1024), "achieved": None, "frac": None}
     try:
-        k = json.loads(PMC_VALU_FILE.read_text())["kernels"][key]
+        src = Path(file) if file else PMC_VALU_FILE
+        k = json.loads(src.read_text())["kernels"][key]
         per_tick = float(k["valu_per_wave_per_tick"])
         out.update({"valu_per_wave_per_tick": per_tick, "achieved": round(per_tick * waves * ticks / seconds, 1),
                     "frac": round(per_tick * waves * ticks / seconds / VALU_PEAK_WAVE_INSTR_PER_S, 4),
                     "frac_of_occupied_simds": round(per_tick * waves * ticks / seconds / (VALU_PEAK_WAVE_INSTR_PER_S * min(waves, 1024) / 1024), 4),
-                    "counted_at": {"grid": k["grid"], "waves": k["waves"], "file": "profiles/pmc_valu.json"}})
+                    "counted_at": {"grid": k["grid"], "waves": k["waves"], "file": "profiles/" + src.name}})
     except Exception as e:  # noqa: BLE001
-        out["note"] = f"no VALU count on file for {key!r} ({type(e).__name__}): run profiles/collect_compute.sh"
+        out["note"] = f"no VALU count on file for {key!r} ({type(e).__name__}): run profiles/collect_compute.sh / collect_world.sh"
     return out
 
 
@@ -551,7 +553,8 @@ def world_module_leg(device):
         ex.close()
         out[f"three_body_worlds_{worlds}"] = {"mode": manifest["mode"], "worlds": worlds, "ticks": 1000, "us_per_tick": round(tm.kernel_device_ms, 3),
                                              "world_steps_per_s": round(worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
-                                             "body_steps_per_s": round(3 * worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1)}
+                                             "body_steps_per_s": round(3 * worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
+                                             "roofline": valu_roofline("three_body_world_mode", worlds, 1000, tm.kernel_device_ms * 1e-3, WORLD_VALU_FILE)}
     # the same module with one lane per ENTITY (mode "auto"): a world = 4 consecutive rows, the fold's targets read from the other
     # lanes of the world (lane_read = ds_bpermute) — the layout IS the ECS column layout, [worlds * 4, 7] rows of world_pos
     lsys, lman = sh.world_system(text, slots, mode="auto")
@@ -575,7 +578,8 @@ def world_module_leg(device):
         out[f"three_body_worlds_{worlds}_lane_mode"] = {"mode": lman["mode"], "rows_per_world": S, "worlds": worlds, "rows": rows, "ticks": 1000,
                                                        "us_per_tick": round(tm.kernel_device_ms, 3),
                                                        "world_steps_per_s": round(worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
-                                                       "body_steps_per_s": round(3 * worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1)}
+                                                       "body_steps_per_s": round(3 * worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
+                                                       "roofline": valu_roofline("three_body_lane_mode", rows, 1000, tm.kernel_device_ms * 1e-3, WORLD_VALU_FILE)}
     try:      # examples/n-body's 10-body solar system (90 edges, softened fold): too wide for one lane per world; lane mode, a world = 16 rows
         from tests import solar_util as su
         _, spos, svel, sin_ = su.load()
@@ -601,7 +605,8 @@ def world_module_leg(device):
         out["solar_system_10_bodies_lane_mode"] = {"mode": nman["mode"], "rows_per_world": S, "entities_per_world": nb, "worlds": worlds, "rows": rows, "ticks": 1000,
                                                    "us_per_tick": round(tm.kernel_device_ms, 3), "world_steps_per_s": round(worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
                                                    "pair_evals_per_s": round(4.0 * nb * (nb - 1) * worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
-                                                   "exchange_reads_per_tick_in_the_program": nman.get("exchange_reads")}
+                                                   "exchange_reads_per_tick_in_the_program": nman.get("exchange_reads"),
+                                                   "roofline": valu_roofline("solar_system_10_bodies_lane_mode", rows, 1000, tm.kernel_device_ms * 1e-3, WORLD_VALU_FILE)}
     except Exception as e:  # noqa: BLE001
         out["solar_system_10_bodies_lane_mode"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     n = 65536
