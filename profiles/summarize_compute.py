@@ -22,7 +22,7 @@ print("|---|---|---|---|---|---|---|---|")
 for (name, grid), c in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("SQ_WAVE_CYCLES", [0]))):
     m = {k: sum(v) / len(v) for k, v in c.items()}
     wc = m["SQ_WAVE_CYCLES"]
-    d = dur.get(name, [0.0])
+    d = dur_grid.get((name, grid)) or dur.get(name, [0.0])
     print(f"| `{name[:90]}` | {grid} | {m['SQ_WAVES']:.0f} | {m['SQ_INSTS_VALU'] / m['SQ_WAVES']:.0f} | "
           f"{m['SQ_ACTIVE_INST_ANY'] / wc:.1%} / {m['SQ_ACTIVE_INST_VALU'] / wc:.1%} | {m['SQ_WAIT_INST_ANY'] / wc:.1%} | "
           f"{m['SQ_WAIT_ANY'] / wc:.1%} | {sum(d) / len(d):.1f} |")
