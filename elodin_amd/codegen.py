@@ -74,6 +74,7 @@ def _leaf_ref(name: str, table: Dict[str, str]) -> str:
 
 _TABLES: Dict[tuple, str] = {}    # (xp, fp) -> C++ symbol stem, filled while emitting one translation unit
 _GATHERS: Dict[str, str] = {}     # dsl gather-table key -> C++ symbol of its __device__ const array, same lifetime
+_LANE_TABLES: Dict[tuple, str] = {}    # (stride, source entity per entity index) of a lane_read in a world of 32 / 64 rows -> symbol, same lifetime
 _WINDOWS: Dict[int, tuple] = {}    # window slot -> (rows, width, head slot) of the program being emitted (dsl.Window)
 # Device layout of a window column by executor size, fixed when the program is built (HipExec knows its row count; the object
 # says which one it was built for, bit 30 of sixdof_custom_column_widths): from this many entities on it is ELEMENT-major, [rows*width][n] — a wave reads 512 contiguous bytes per element (65,536 rockets:
@@ -193,12 +194,15 @@ class _Emitter:
             if e.op == "threefry":
                 return f"m_threefry({a[0]}, {a[1]}, {a[2]}, {a[3]}, {int(e.value)})"
             if e.op == "lane_read":     # the value another entity of THIS lane's world holds (whole-world StableHLO ticks: a join / an
-                # edge_fold's targets).  A world is `stride` consecutive rows, stride a power of two <= 16 dividing the 64-lane wave,
+                # edge_fold's targets).  A world is `stride` consecutive rows, stride a power of two <= 64 dividing the 64-lane wave,
                 # so the exchange never leaves the wavefront: one ds_bpermute per 32-bit half.  The source entity per entity index
                 # is a compile-time table packed four bits each into one 64-bit constant.
                 stride, table = e.value
                 if len(set(table)) == 1:
                     src = f"static_cast<int>((threadIdx.x & ~{stride - 1}u) + {table[0]}u)"
+                elif stride > 16:       # worlds of 32 or 64 rows: a byte per entity in constant memory (one cached load per read)
+                    stem = _LANE_TABLES.setdefault((int(stride), tuple(int(j) for j in table)), f"ltab{len(_LANE_TABLES)}")
+                    src = f"static_cast<int>((threadIdx.x & ~{stride - 1}u) + {stem}[threadIdx.x & {stride - 1}u])"
                 else:
                     packed = sum((int(j) & 15) << (4 * i) for i, j in enumerate(table))
                     src = (f"static_cast<int>((threadIdx.x & ~{stride - 1}u) + static_cast<unsigned>(({packed}ull >> ((threadIdx.x & {stride - 1}u) * 4u)) & 15ull))")
@@ -896,6 +900,8 @@ def _emit_tables() -> str:
     for key, stem in _GATHERS.items():      # row-major [rows, cols], doubles whatever the program's dtype (read through m_gather)
         t = dsl._GATHER_TABLES[key]
         out.append(f"__device__ const double {stem}[{t.size}] = {{{', '.join(repr(float(v)) for v in t.reshape(-1))}}};")
+    for (stride, table), stem in _LANE_TABLES.items():
+        out.append(f"__device__ const unsigned char {stem}[{stride}] = {{{', '.join(str(j) for j in table)}}};")
     for (xs, fs), stem in _TABLES.items():
         out.append(f"__device__ const double {stem}_x[{len(xs)}] = {{{', '.join(repr(v) for v in xs)}}};")
         out.append(f"__device__ const double {stem}_f[{len(fs)}] = {{{', '.join(repr(v) for v in fs)}}};")
@@ -1170,6 +1176,7 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
         raise ValueError("fast_math applies to float32 programs only")
     _TABLES.clear()
     _GATHERS.clear()
+    _LANE_TABLES.clear()
     T = {"float64": "double", "float32": "float"}[dtype]
     integ = {0: "kRk4", 1: "kSemiImplicit", 2: "kNone"}[integrator]
     is_prog = isinstance(tp, dsl.TracedProgram)
@@ -1336,6 +1343,7 @@ def generate_pair_source(tf: "dsl.TracedFold", integrator: Optional[int] = None,
     _GUARD_SELECTS[0], _FUSE_FMA[0] = False, False      # switches of generate_source: exact arithmetic here
     _TABLES.clear()
     _GATHERS.clear()
+    _LANE_TABLES.clear()
     body = "\n".join(emit_block([(f"acc[{k}]", e) for k, e in enumerate(tf.outputs)], _PAIR_LEAVES))
     tables = _emit_tables()
     additive = _fold_is_additive(tf)
@@ -1394,6 +1402,7 @@ def generate_graph_fold_source(tf: "dsl.TracedGraphFold") -> str:
     _GUARD_SELECTS[0], _FUSE_FMA[0] = False, False      # switches of generate_source: exact arithmetic here
     _TABLES.clear()
     _GATHERS.clear()
+    _LANE_TABLES.clear()
     f = tf.fold
     leaves = {f"acc_{k}": f"acc[{k}]" for k in range(tf.widths[f.out])}
     loads_a, loads_b = [], []

@@ -1568,7 +1568,7 @@ class _LaneEval(_Eval):
     CAP = 1 << 16              # elements a lazily-broadcast (uniform) tensor may take when a statement needs it in full
 
     def __init__(self, funcs, n_entities: int, stride: Optional[int] = None):
-        """stride: rows per world when the executor lays worlds out as `stride` consecutive rows (a power of two <= 16, >= N): lets a
+        """stride: rows per world when the executor lays worlds out as `stride` consecutive rows (a power of two <= 64, >= N): lets a
         constant-index gather ALONG the entity axis (a join, an edge_fold's targets) become an exchange inside the wavefront —
         lane i of a world reads what lane j of the same world holds (dsl op `lane_read`, one ds_bpermute per 32-bit half).  None:
         such gathers are refused."""
@@ -2163,8 +2163,8 @@ def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = Non
     counts = {s_.shape[0] for s_ in ins + outs if not s_.elided and s_.shape}
     n_entities = counts.pop() if len(counts) == 1 else None
     stride = None
-    if n_entities and 1 < n_entities <= 16:
-        stride = 1 << (n_entities - 1).bit_length()          # rows per world should the tick exchange data between its entities
+    if n_entities and 1 < n_entities <= 64:
+        stride = 1 << (n_entities - 1).bit_length()          # rows per world should the tick exchange data between its entities (<= one wavefront)
     used = {"exchanges": 0}
 
     def build(lane: bool):

@@ -321,3 +321,40 @@ def test_random_modules_with_reads_between_entities_through_the_generated_kernel
     print(f"seed {seed}: n {n}, rows_per_world {S}, {manifest['exchange_reads']} exchange reads, worst {worst:.2e}")
     assert worst <= 1e-12
     hip.close()
+
+
+@pytest.mark.parametrize("n,stride", [(20, 32), (35, 64)])
+def test_worlds_of_32_and_64_rows_in_lane_mode_on_the_gpu(n, stride):
+    """Lane exchange up to a whole wavefront per world: 20 bodies in 32 rows and 35 bodies in 64 rows (the complete gravity graph,
+    380 / 1,190 edges), source tables as bytes in constant memory.  129 worlds (the last wavefront partly filled for 32 rows) x 48
+    ticks against the C oracle's sequential fold."""
+    from tests.golden import hlo_world_builder as hb
+    from tests.test_stablehlo_world import _random_cluster
+    K, EPS, DT = 2.9591220828e-4, 1e-6, 0.5
+    pos, vel, inertia = _random_cluster(n)
+    text, slots = hb.nbody_world(n, K, EPS)
+    system, manifest = sh.world_system(text, slots, mode="auto")
+    assert (manifest["mode"], manifest["rows_per_world"]) == ("lane", stride)
+    worlds = 129
+    rows = stride * worlds
+
+    def lay(a, fill):
+        out = np.tile(np.asarray(fill, dtype=np.float64), (rows, 1))
+        for w_ in range(worlds):
+            out[w_ * stride:w_ * stride + n] = a
+        return out
+    cols = {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), DT), "hlo_world_pos": lay(pos, [0, 0, 0, 1.0, 0, 0, 0]),
+            "hlo_world_vel": lay(vel, np.zeros(6)), "hlo_inertia": lay(inertia, np.ones(7)), "hlo_world_accel": np.zeros((rows, 6)), "hlo_force": np.zeros((rows, 6))}
+    hip = _exec(dsl.Program([system], dsl.Pipe([]), []), cols, rows, ticks_per_launch=12)
+    tm = hip.run(48)
+    w = orc.OracleWorld(pos, vel, inertia, simulation_time_step=DT, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, (K, EPS), None)])
+    w.step(48)
+    worst = 0.0
+    for c, ref in (("world_pos", w.world_pos), ("world_vel", w.world_vel), ("world_accel", w.world_accel), ("force", w.force)):
+        for w_ in (0, 64, 128):
+            got = hip._aux["hlo_" + c][w_ * stride:w_ * stride + n]
+            worst = max(worst, float(np.max(np.abs(got - ref) / np.maximum(np.max(np.abs(ref), axis=1, keepdims=True), 1e-300))))
+        assert np.array_equal(hip._aux["hlo_" + c][:n], hip._aux["hlo_" + c][128 * stride:128 * stride + n])
+    print(f"{n}-body world, rows_per_world {stride}, 129 worlds x 48 ticks vs the oracle: {worst:.2e}; {tm.kernel_device_ms / 48 * 1e3:.1f} us per tick")
+    assert worst <= 1e-9
+    hip.close()

@@ -139,6 +139,49 @@ def test_ten_body_solar_system_world_tick_in_lane_mode_equals_the_oracle():
             assert np.array_equal(comps["hlo_" + c][w_ * S:w_ * S + n], ref), (c, w_)
 
 
+def _random_cluster(n):
+    rng = np.random.default_rng(n)
+    pos = np.concatenate([np.tile([0, 0, 0, 1.0], (n, 1)), rng.normal(size=(n, 3)) * 3], axis=1)
+    vel = np.concatenate([np.zeros((n, 3)), rng.normal(size=(n, 3)) * 1e-3], axis=1)
+    m = rng.uniform(1e-6, 1e-3, n)
+    inertia = np.concatenate([np.tile(m[:, None], (1, 3)), np.zeros((n, 3)), m[:, None]], axis=1)
+    return pos, vel, inertia
+
+
+@pytest.mark.parametrize("n,stride", [(20, 32), (35, 64)])
+def test_worlds_of_up_to_a_whole_wavefront_in_lane_mode(n, stride):
+    """The exchange stays inside the wavefront up to 64 rows per world: 20 bodies -> 32 rows, 35 bodies (the largest n-body world the
+    reference's example is sized for) -> 64 rows, the complete gravity graph (380 / 1,190 edges).  Above 16 rows the per-entity source
+    tables are bytes in constant memory instead of 4-bit fields of one literal.  Equal to the C oracle's sequential fold, bit for bit,
+    two worlds side by side."""
+    from elodin_amd import codegen
+    K, EPS, DT = 2.9591220828e-4, 1e-6, 0.5
+    pos, vel, inertia = _random_cluster(n)
+    text, slots = hb.nbody_world(n, K, EPS)
+    system, manifest = sh.world_system(text, slots, mode="auto")
+    assert (manifest["mode"], manifest["rows_per_world"], manifest["exchange_reads"]) == ("lane", stride, 10 * (n - 1))     # 3 x 3 stage positions + the mass
+    widths = {c["column"]: c["width"] for c in manifest["columns"]}
+    worlds = 2
+    rows = stride * worlds
+
+    def lay(a, fill):
+        out = np.tile(np.asarray(fill, dtype=np.float64), (rows, 1))
+        for w_ in range(worlds):
+            out[w_ * stride:w_ * stride + n] = a
+        return out
+    comps = {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), DT), "hlo_world_pos": lay(pos, [0, 0, 0, 1.0, 0, 0, 0]),
+             "hlo_world_vel": lay(vel, np.zeros(6)), "hlo_inertia": lay(inertia, np.ones(7)), "hlo_world_accel": np.zeros((rows, 6)), "hlo_force": np.zeros((rows, 6))}
+    tp = walk(system, widths, comps, 4)
+    w = orc.OracleWorld(pos, vel, inertia, simulation_time_step=DT, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, (K, EPS), None)])
+    w.step(4)
+    for c, ref in (("world_pos", w.world_pos), ("world_vel", w.world_vel), ("world_accel", w.world_accel), ("force", w.force)):
+        for w_ in range(worlds):
+            assert np.array_equal(comps["hlo_" + c][w_ * stride:w_ * stride + n], ref), (c, w_)
+    src = codegen.generate_source(tp, "float64", 2)
+    assert f"__device__ const unsigned char ltab0[{stride}]" in src and src.count("__shfl(") == 14 * (n - 1)
+    assert codegen.lane_stride(tp) == stride
+
+
 def test_independent_bodies_world_tick_is_entity_parallel_and_matches_the_oracle():
     """BASELINE configs[1] spelled as a whole-world module ([n, w] tensors, vmapped arithmetic): ingested with one lane per ENTITY
     (the [n, 7] world_pos argument becomes a 7-wide column) and equal to the C oracle's RK4 over 16 ticks."""
