@@ -207,6 +207,13 @@ class _Emitter:
                     packed = sum((int(j) & 15) << (4 * i) for i, j in enumerate(table))
                     src = (f"static_cast<int>((threadIdx.x & ~{stride - 1}u) + static_cast<unsigned>(({packed}ull >> ((threadIdx.x & {stride - 1}u) * 4u)) & 15ull))")
                 return f"__shfl({a[0]}, {src}, 64)"
+            if e.op == "lane_read_dyn":     # the same exchange with the source table picked by a traced index (a scan's counter over the
+                # edge slot: stablehlo.py _LaneEval._pick): slot-major bytes in constant memory
+                stride, tables = e.value
+                flat = tuple(int(j) for t in tables for j in t)
+                stem = _LANE_TABLES.setdefault((int(stride), flat), f"ltab{len(_LANE_TABLES)}")
+                return (f"__shfl({a[0]}, static_cast<int>((threadIdx.x & ~{stride - 1}u) + {stem}[static_cast<int>({a[1]}) * {stride} + "
+                        f"static_cast<int>(threadIdx.x & {stride - 1}u)]), 64)")
             if e.op == "fbits":     # one 32-bit word of a double's bit pattern (stablehlo.bitcast_convert f64 -> ui64): 1 = high
                 return f"m_fbits({a[0]}, {int(e.value)})"
             if e.op == "lt":
@@ -247,7 +254,9 @@ class _Emitter:
             for nm, t_ in zip(names, tmp):
                 inner["lines"].append(f"{inner['indent']}{cvars[nm]} = {t_};")
             if counted is not None:   # static trip count, no early exit: let the compiler overlap the loads of several rows
-                sc["lines"].append(f"{sc['indent']}#pragma unroll 8")
+                # (counted[2], optional: the unroll factor — 1 for a loop that was kept a loop BECAUSE its unrolled form is too large,
+                # stablehlo.py _Eval.ROLL)
+                sc["lines"].append(f"{sc['indent']}#pragma unroll {int(counted[2]) if len(counted) > 2 else 8}")
                 sc["lines"].append(f"{sc['indent']}for (int it_{self.n} = {counted[0]}; it_{self.n} < {counted[1]}; it_{self.n}++) {{")
             else:
                 sc["lines"].append(f"{sc['indent']}for (int it_{self.n} = 0; it_{self.n} < {max_iter}; it_{self.n}++) {{")
@@ -504,7 +513,7 @@ _GUARD_SELECTS = [False]
 # SIXDOF_FUSE_FMA=0 keeps them apart (A/B).  Exact builds never fuse: a reference evaluates every node to a rounded value.
 _FUSE_FMA = [False]
 _GUARD_MIN_COST = 40
-_NODE_COST = {"lane_read": 8, "threefry": 90, "erfinv": 120, "sin": 12, "cos": 12, "tan": 20, "exp": 10, "log": 10, "pow": 25, "atan2": 27, "asin": 20,
+_NODE_COST = {"lane_read": 8, "lane_read_dyn": 10, "threefry": 90, "erfinv": 120, "sin": 12, "cos": 12, "tan": 20, "exp": 10, "log": 10, "pow": 25, "atan2": 27, "asin": 20,
               "acos": 20, "hypot": 12, "div": 4, "sqrt": 4, "interp": 30, "cbrt": 20, "sinh": 20, "cosh": 20, "erfc": 40, "log1p": 15,
               "expm1": 15, "mod": 8}
 
@@ -901,7 +910,7 @@ def _emit_tables() -> str:
         t = dsl._GATHER_TABLES[key]
         out.append(f"__device__ const double {stem}[{t.size}] = {{{', '.join(repr(float(v)) for v in t.reshape(-1))}}};")
     for (stride, table), stem in _LANE_TABLES.items():
-        out.append(f"__device__ const unsigned char {stem}[{stride}] = {{{', '.join(str(j) for j in table)}}};")
+        out.append(f"__device__ const unsigned char {stem}[{len(table)}] = {{{', '.join(str(j) for j in table)}}};")
     for (xs, fs), stem in _TABLES.items():
         out.append(f"__device__ const double {stem}_x[{len(xs)}] = {{{', '.join(repr(v) for v in xs)}}};")
         out.append(f"__device__ const double {stem}_f[{len(fs)}] = {{{', '.join(repr(v) for v in fs)}}};")
@@ -1656,9 +1665,11 @@ def lane_stride(tp) -> int:
         if id(x) in seen:
             continue
         seen.add(id(x))
-        if x.op == "lane_read":
+        if x.op in ("lane_read", "lane_read_dyn"):
             stride = max(stride, int(x.value[0]))
         todo.extend(a for a in x.args if isinstance(a, dsl.Expr))
+        if x.op == "while":
+            todo.extend([x.value[1], *x.value[2]])
     return stride
 
 

@@ -1128,7 +1128,7 @@ class _Lax:
     _loop_ids = [0]
 
     @staticmethod
-    def while_loop(cond_fun, body_fun, init_val, max_iter: int = 1_000_000, counted: Optional[Tuple[int, int]] = None):
+    def while_loop(cond_fun, body_fun, init_val, max_iter: int = 1_000_000, counted: Optional[Tuple[int, ...]] = None):
         """jax.lax.while_loop with a data-dependent trip count (e.g. examples/stablehlo/sim.py:223, or a flight
         computer propagating a ballistic arc until it meets the ground): becomes a real loop in the generated kernel,
         lanes leave it independently.  `init_val`: a scalar, a Vec, or a tuple / list of those.  `max_iter` bounds the
@@ -1142,8 +1142,9 @@ class _Lax:
         body, _ = _flatten(body_fun(carried))
         if len(body) != len(flat):
             raise TypeError("while_loop body must return the structure of init_val")
-        # counted=(start, stop): the first carried value is a counter start, start+1, ... and the condition is `counter < stop`
-        # (Window.scan) — the code generator may then emit a plain counted loop it can unroll and software-pipeline
+        # counted=(start, stop[, unroll]): the loop runs exactly stop - start times and the condition agrees (Window.scan's counter; a
+        # statically counted stablehlo.while) — the code generator emits a plain counted loop it can unroll (by 8, or `unroll`) and
+        # software-pipeline
         node = Expr("while", tuple(_lift(x) for x in flat),
                     (names, cond, tuple(_lift(b) for b in body), int(max_iter)) + ((tuple(counted),) if counted else ()))
         return rebuild([Expr("while_out", (node,), j) for j in range(len(flat))])

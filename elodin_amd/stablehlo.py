@@ -1025,6 +1025,13 @@ class _Eval:
 
     UNROLL_MAX_TRIPS = 64          # a while whose trip count is known while tracing is unrolled up to this many iterations ...
     UNROLL_MAX_NODES = 200_000     # ... as long as the unrolled body stays below this many new nodes
+    # ... unless the evaluator can keep it a COUNTED loop at no cost (_LaneEval: an edge_fold's scan over the edge slot whose targets are
+    # exchange reads — the slot's source table is indexed by the counter, op lane_read_dyn) and the unrolled form is large: a world of 20
+    # or 35 bodies unrolls to 9,100 / 13,000 instructions per tick, more than the 64 KB instruction cache holds (58 / 40 us per tick,
+    # fetch-bound); as four 19- / 34-trip loops it is ~700 instructions
+    ROLL = False
+    ROLL_MIN_TRIPS = 12
+    ROLL_MIN_NODES = 300
 
     @staticmethod
     def _flatten_elems(x: Sym) -> list:
@@ -1048,7 +1055,8 @@ class _Eval:
         # -- static trip count: the reference's edge_fold is `lax.scan` over a source's out-edges, i.e. a while whose counter
         #    starts at a constant and is compared with a constant (libs/cranelift-mlir/tests/test_while_dyn_slice.rs); unrolled,
         #    its dynamic_slice / dynamic_update_slice by the counter are plain static slices
-        state, trips, start_nodes = list(inits), 0, Expr._count[0]
+        state, trips, start_nodes, static_trips = list(inits), 0, Expr._count[0], None
+        saved = self._loop_counters()
         while trips <= self.UNROLL_MAX_TRIPS and Expr._count[0] - start_nodes <= self.UNROLL_MAX_NODES:
             e = dict(env)
             e.update(zip(names, state))
@@ -1056,18 +1064,62 @@ class _Eval:
             if c is None:
                 break                      # data-dependent condition: a real loop (from the ORIGINAL state: nothing unrolled is kept)
             if not c:
-                return state
+                static_trips = trips
+                break
             outs = self.block(op.regions[1], e)
             state = [self._relabel(o, s_) for o, s_ in zip(outs, state)]
             trips += 1
+        if static_trips is not None:
+            if not (self.ROLL and static_trips >= self.ROLL_MIN_TRIPS and self._unrolled_size(state, inits, self.ROLL_MIN_NODES) >= self.ROLL_MIN_NODES):
+                return state
+            unrolled = self._loop_counters()
+            self._loop_counters(saved)     # the unrolled nodes are dropped: what they counted is not part of the program
+            try:
+                return self._while_loop(op, env, names, inits, static_trips, saved)
+            except NotEntityParallel:      # a carried value the loop form cannot hold (its layout changes inside the body): unrolled it is
+                self._loop_counters(unrolled)
+                return state
+        return self._while_loop(op, env, names, inits, None, saved)
+
+    def _while_loop(self, op: Op, env, names, inits, static_trips, saved) -> List[Sym]:
+        """The while as a loop of the generated kernel: data-dependent (static_trips None), or counted."""
 
         shapes, dtypes = [x.shape for x in inits], [x.dtype for x in inits]
         kinds = [(x.eaxis, x.uni, x.tshape) for x in inits]
-        flat = [v for x in inits for v in self._flatten_elems(x)]
+
+        # carried values the body hands back untouched (a scan's per-source rows, the stacked target rows it slices by the counter) are
+        # not loop state: inside the loop they are the outer nodes themselves, so a dynamic_slice of them sees what they are made of
+        invariant = [False] * len(inits)
+        try:
+            probe_in = [[_dsl.leaf(f"__probe{k}_{j}") for j in range(len(self._flatten_elems(x)))] for k, x in enumerate(inits)]
+            pe, pk = dict(env), 0
+            for nm, x, leaves_ in zip(names, inits, probe_in):
+                size = int(np.prod(x.shape)) if x.shape else 1
+                arr = np.empty(size, dtype=object)
+                step = 2 if x.dtype == "ui64" else 1
+                for j in range(size):
+                    arr[j] = U64(leaves_[2 * j], leaves_[2 * j + 1]) if step == 2 else ((leaves_[j] > 0.5) if x.dtype == "i1" else leaves_[j])
+                pe[nm] = Sym(arr.reshape(x.shape), x.dtype, x.eaxis, x.uni, x.tshape)
+            probe_out = self.block(op.regions[1], pe)
+            for k, (o, x) in enumerate(zip(probe_out, inits)):
+                if x.dtype == "i1" or o.shape != x.shape:
+                    continue
+                got = self._flatten_elems(o)
+                invariant[k] = len(got) == len(probe_in[k]) and all(a is b for a, b in zip(got, probe_in[k]))
+        except (NotEntityParallel, _KindsChanged, NotImplementedError, TypeError, ValueError, KeyError):
+            invariant = [False] * len(inits)
+        self._loop_counters(saved)
+        variant = [k for k in range(len(inits)) if not invariant[k]]
+        if not variant:
+            return list(inits)
+        flat = [v for k in variant for v in self._flatten_elems(inits[k])]
 
         def rebuild(vals):
             out, k = {}, 0
-            for nm, shp, dt, (ea, un, ts) in zip(names, shapes, dtypes, kinds):
+            for idx_, (nm, shp, dt, (ea, un, ts)) in enumerate(zip(names, shapes, dtypes, kinds)):
+                if invariant[idx_]:
+                    out[nm] = inits[idx_]
+                    continue
                 size = int(np.prod(shp)) if shp else 1
                 arr = np.empty(size, dtype=object)
                 for j in range(size):
@@ -1091,6 +1143,8 @@ class _Eval:
             outs = self.block(op.regions[1], e)
             changed = False
             for k, (o, shp) in enumerate(zip(outs, shapes)):
+                if invariant[k]:
+                    continue
                 if o.shape != shp:
                     raise NotEntityParallel(f"a value carried by stablehlo.while changes its stored shape {shp} -> {o.shape}")
                 ea, un, ts = kinds[k]
@@ -1100,10 +1154,11 @@ class _Eval:
                     kinds[k], changed = (ea2, un2, ts), True
             if changed:
                 raise _KindsChanged()
-            return _dsl.Vec([v for o in outs for v in self._flatten_elems(o)])
+            return _dsl.Vec([v for k in variant for v in self._flatten_elems(outs[k])])
+        counted = (0, int(static_trips), 1) if static_trips is not None else None         # (, 1): do not unroll it again
         for _ in range(4):
             try:
-                res = _dsl.lax.while_loop(cond, body, _dsl.Vec(flat))
+                res = _dsl.lax.while_loop(cond, body, _dsl.Vec(flat), **({"counted": counted, "max_iter": counted[1] + 1} if counted else {}))
                 break
             except _KindsChanged:
                 continue
@@ -1111,6 +1166,23 @@ class _Eval:
             raise NotEntityParallel("the carried values of a stablehlo.while do not settle on an entity layout")
         final = rebuild(list(res.e))
         return [final[nm] for nm in names]
+
+    def _unrolled_size(self, state: List[Sym], inits: List[Sym], enough: int) -> int:
+        """Nodes the unrolled loop adds between its initial values and its results (counted by reachability, not by creation: nodes
+        are hash-consed, a second loop over the same values creates none); stops counting at `enough`."""
+        stop = {id(v) for x in inits for v in self._flatten_elems(x) if isinstance(v, Expr)}
+        seen, todo = set(), [v for x in state for v in self._flatten_elems(x) if isinstance(v, Expr)]
+        while todo and len(seen) < enough:
+            x = todo.pop()
+            if id(x) in seen or id(x) in stop or x.op in ("const", "leaf"):
+                continue
+            seen.add(id(x))
+            todo.extend(a for a in x.args if isinstance(a, Expr))
+        return len(seen)
+
+    def _loop_counters(self, restore=None):
+        """Bookkeeping a discarded trial evaluation of a loop body must not leave behind (the lane evaluator's exchange count)."""
+        return None
 
     @staticmethod
     def _relabel(o: Sym, like: Sym) -> Sym:
@@ -1578,6 +1650,55 @@ class _LaneEval(_Eval):
         self.exchanges = 0            # lane_read nodes made: the manifest says whether the row layout matters
 
     # -- the exchange inside a world --
+    ROLL = True
+
+    def _loop_counters(self, restore=None):
+        if restore is not None:
+            self.exchanges = restore
+        return self.exchanges
+
+    def _pick(self, cands: List[np.ndarray], idx) -> np.ndarray:
+        """cands[idx] for a traced idx (dynamic_slice by a loop counter).  Element by element: candidates that are exchange reads of ONE
+        value — a scan over the edge slot slicing the stacked target rows — become one read whose source table is indexed by `idx`
+        (lane_read_dyn); anything else is the plain chain of selects."""
+        if len(cands) == 1 or self.S is None or _try_const(idx) is not None:
+            return _Eval._pick(cands, idx)
+        out = np.empty(cands[0].shape, dtype=object)
+        for pos in (np.ndindex(cands[0].shape) if cands[0].shape else [()]):
+            col = [c[pos] for c in cands]
+            m = self._pick_reads(col, idx)
+            if m is None:
+                m = col[-1]
+                for k in range(len(col) - 2, -1, -1):
+                    m = _where(idx < (k + 0.5), col[k], m)
+            out[pos] = m
+        return out
+
+    def _pick_reads(self, col, idx):
+        if all(c is col[0] for c in col):
+            return col[0]
+        if all(isinstance(c, U64) for c in col):
+            hi, lo = self._pick_reads([c.hi for c in col], idx), self._pick_reads([c.lo for c in col], idx)
+            return None if hi is None or lo is None else U64(hi, lo)
+        if any(not isinstance(c, Expr) for c in col):
+            return None
+        k0 = _try_const(col[0])
+        if k0 is not None and not isinstance(k0, bool) and all(_try_const(c) == k0 for c in col):
+            return col[0]
+        ident = tuple(range(self.S))
+        base, tables = None, []
+        for c in col:
+            b, t = (c.args[0], tuple(c.value[1])) if c.op == "lane_read" else (c, ident)
+            if base is None:
+                base = b
+            elif b is not base:
+                return None
+            tables.append(t)
+        if all(t == tables[0] for t in tables):
+            return col[0]
+        self.exchanges += 1
+        return Expr("lane_read_dyn", (base, _dsl._lift(idx)), (self.S, tuple(tables)))
+
     def _lane_read(self, v, table: Tuple[int, ...]):
         """What entity table[i] of this lane's world holds of `v`, seen from entity i."""
         if isinstance(v, U64):
@@ -2220,8 +2341,10 @@ def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = Non
                 if id(x) in seen:
                     continue
                 seen.add(id(x))
-                live += x.op == "lane_read"
+                live += x.op in ("lane_read", "lane_read_dyn")
                 todo.extend(a for a in x.args if isinstance(a, Expr))
+                if x.op == "while":                  # ... and what its condition and body read
+                    todo.extend([x.value[1], *x.value[2]])
             used["exchanges"] = live
             return res
         fn.__name__ = name

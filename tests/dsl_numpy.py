@@ -152,6 +152,13 @@ def _eval(exprs, leaves, n):
             rows = np.arange(n)
             src = (rows // stride) * stride + np.asarray(table)[rows % stride]
             r = v[np.minimum(src, n - 1)]
+        elif e.op == "lane_read_dyn":  # ... with the table picked by a traced index (row by row)
+            stride, tables = e.value
+            v = np.array(np.broadcast_to(ev(e.args[0]), (n,)))
+            k = np.clip(np.broadcast_to(ev(e.args[1]), (n,)).astype(int), 0, len(tables) - 1)
+            rows = np.arange(n)
+            src = (rows // stride) * stride + np.asarray(tables)[k, rows % stride]
+            r = v[np.minimum(src, n - 1)]
         elif e.op == "fbits":
             words = np.ascontiguousarray(np.broadcast_to(ev(e.args[0]), (n,)), dtype=np.float64).view(np.uint64)
             r = ((words >> np.uint64(32)) if e.value else (words & np.uint64(0xFFFFFFFF))).astype(np.float64)

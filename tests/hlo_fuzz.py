@@ -71,7 +71,7 @@ def make(seed: int, n: int, steps: int = 28, exchange: bool = False):
         eax[id(v)] = e
         return v
     for _ in range(steps):
-        kind = int(rng.integers(14 if exchange else 13))
+        kind = int(rng.integers(15 if exchange else 13))
         x = pick(lambda v: eax[id(v)] == 0)
         if kind == 0:                                           # unary
             put(f.un(["sine", "tanh", "abs", "cosine"][int(rng.integers(4))], x))
@@ -143,6 +143,18 @@ def make(seed: int, n: int, steps: int = 28, exchange: bool = False):
             tgt = [[int(t) for t in rng.integers(0, n, e_)] for _ in range(n)]
             st = f.concat([f.reshape(f.gather_rows(x, tgt[s_]), (1, e_, x.shape[1])) for s_ in range(n)], 0)        # [n, e, w]
             joins.append(put(f.add(x, f.reduce_sum(f.transpose(st, [0, 2, 1]), [2]))))                            # own row + the sum of the rows read
+        elif kind == 14 and len(x.shape) == 2:                  # an edge_fold's shape: a scan over the edge slot of the stacked target rows (graph.rs:187-235)
+            e_, w = int(rng.integers(2, 4)), x.shape[1]
+            tgt = [[int(t) for t in rng.integers(0, n, e_)] for _ in range(n)]
+            st = f.concat([f.reshape(f.gather_rows(x, tgt[s_]), (1, e_, w)) for s_ in range(n)], 0)             # [n, e, w]
+            st_t = f.transpose(st, [1, 0, 2])                                                                  # the scanned axis first
+
+            def body(fb, i, carried):
+                acc, src = carried
+                z = fb.const(0, (), "i64")
+                row = fb.reshape(fb.dynamic_slice(src, [i, z, z], (1, n, w)), (n, w))
+                return [fb.add(fb.mul(acc, fb.splat(0.5, acc.shape)), row), src]
+            joins.append(put(f.while_counted(e_, [x, st_t], body)[0]))
     if exchange and not joins:                                  # at least one join whose result is returned (below): the exchange is LIVE
         tgt = [[(s_ + 1) % n, int(rng.integers(0, n))] for s_ in range(n)]
         st = f.concat([f.reshape(f.gather_rows(a, tgt[s_]), (1, 2, 4)) for s_ in range(n)], 0)

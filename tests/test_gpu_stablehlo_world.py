@@ -273,18 +273,27 @@ def test_ten_body_solar_system_world_in_lane_mode_on_the_gpu():
     hip.close()
 
 
-@pytest.mark.parametrize("seed,n", [(s_, 3 + s_ % 3) for s_ in (101, 102, 104, 106, 107, 108, 110, 113)])
-def test_random_modules_with_reads_between_entities_through_the_generated_kernel(seed, n):
+@pytest.mark.parametrize("seed,n,rolled", [(s_, 3 + s_ % 3, False) for s_ in (101, 102, 104, 106, 107, 108, 110, 113)] +
+                         [(s_, 3 + s_ % 3, True) for s_ in (100, 103, 104, 105, 107, 114, 115)])
+def test_random_modules_with_reads_between_entities_through_the_generated_kernel(seed, n, rolled, monkeypatch):
     """tests/hlo_fuzz.py's modules with JOINS (constant-table gathers along the entity axis, re-stacked per source) in lane mode on the
     GPU: `lane_read` with per-entity source tables as one ds_bpermute per 32-bit half, worlds of 4 and 8 rows at every position of a
     wavefront, the last wavefront only partly filled.  Against the numpy walker of the same traced program: 1e-12 of each result's
     scale (the device's libm differs from numpy's in the last place), NaNs in the same places."""
     from tests import hlo_fuzz
     from tests.test_stablehlo_world import walk
+    if rolled:      # every counted while of two trips or more stays a loop: carried values the body hands back untouched leave the loop
+        # state, an edge_fold-shaped scan reads its slot's targets through a table indexed by the counter (lane_read_dyn)
+        monkeypatch.setattr(sh._LaneEval, "ROLL_MIN_TRIPS", 2)
+        monkeypatch.setattr(sh._LaneEval, "ROLL_MIN_NODES", 1)
     text, slots, out_slots = hlo_fuzz.make(seed, n, exchange=True)
     system, manifest = sh.world_system(text, slots, out_slots, mode="lane")
     S = manifest.get("rows_per_world", n)
     assert manifest["exchange_reads"] > 0 and S in (4, 8)
+    if rolled:
+        from elodin_amd import codegen
+        src = codegen.generate_source(dsl.Program([system], dsl.Pipe([]), []).trace({c["column"]: c["width"] for c in manifest["columns"]}), "float64", 2)
+        assert "#pragma unroll 1" in src and f") * {S} + static_cast<int>(threadIdx.x" in src
     worlds = 24 if S == 4 else 12                        # 96 rows: one full wavefront + half of a second
     vals = [hlo_fuzz.inputs(seed + 1000 * w_, n) for w_ in range(worlds)]
     widths = {c["column"]: c["width"] for c in manifest["columns"]}
@@ -318,7 +327,7 @@ def test_random_modules_with_reads_between_entities_through_the_generated_kernel
             assert np.array_equal(g[~fin & ~np.isnan(e)], e[~fin & ~np.isnan(e)]), (seed, name, w_)
             if fin.any():
                 worst = max(worst, float(np.max(np.abs(g[fin] - e[fin])) / max(1.0, float(np.max(np.abs(e[fin]))))))
-    print(f"seed {seed}: n {n}, rows_per_world {S}, {manifest['exchange_reads']} exchange reads, worst {worst:.2e}")
+    print(f"seed {seed}{' (loops kept)' if rolled else ''}: n {n}, rows_per_world {S}, {manifest['exchange_reads']} exchange reads, worst {worst:.2e}")
     assert worst <= 1e-12
     hip.close()
 

@@ -152,14 +152,17 @@ def _random_cluster(n):
 def test_worlds_of_up_to_a_whole_wavefront_in_lane_mode(n, stride):
     """The exchange stays inside the wavefront up to 64 rows per world: 20 bodies -> 32 rows, 35 bodies (the largest n-body world the
     reference's example is sized for) -> 64 rows, the complete gravity graph (380 / 1,190 edges).  Above 16 rows the per-entity source
-    tables are bytes in constant memory instead of 4-bit fields of one literal.  Equal to the C oracle's sequential fold, bit for bit,
-    two worlds side by side."""
+    tables are bytes in constant memory instead of 4-bit fields of one literal, and a scan this long is kept a loop (the carried
+    values its body hands back untouched are not loop state; the slot's target rows become reads indexed by the counter).  Equal to
+    the C oracle's sequential fold, bit for bit, two worlds side by side."""
     from elodin_amd import codegen
     K, EPS, DT = 2.9591220828e-4, 1e-6, 0.5
     pos, vel, inertia = _random_cluster(n)
     text, slots = hb.nbody_world(n, K, EPS)
     system, manifest = sh.world_system(text, slots, mode="auto")
-    assert (manifest["mode"], manifest["rows_per_world"], manifest["exchange_reads"]) == ("lane", stride, 10 * (n - 1))     # 3 x 3 stage positions + the mass
+    # the four 19- / 34-trip scans over the edge slot stay COUNTED LOOPS (unrolled they are 9,100 / 13,000 instructions per tick, more
+    # than the instruction cache holds): per loop four reads — x, y, z, mass — whose source table is indexed by the counter
+    assert (manifest["mode"], manifest["rows_per_world"], manifest["exchange_reads"]) == ("lane", stride, 16)
     widths = {c["column"]: c["width"] for c in manifest["columns"]}
     worlds = 2
     rows = stride * worlds
@@ -178,7 +181,8 @@ def test_worlds_of_up_to_a_whole_wavefront_in_lane_mode(n, stride):
         for w_ in range(worlds):
             assert np.array_equal(comps["hlo_" + c][w_ * stride:w_ * stride + n], ref), (c, w_)
     src = codegen.generate_source(tp, "float64", 2)
-    assert f"__device__ const unsigned char ltab0[{stride}]" in src and src.count("__shfl(") == 14 * (n - 1)
+    assert f"__device__ const unsigned char ltab0[{stride * (n - 1)}]" in src and src.count("__shfl(") <= 20
+    assert src.count("#pragma unroll 1\n") >= 4 and src.count("#pragma unroll 1\n") == src.count(f"< {n - 1}; it_")
     assert codegen.lane_stride(tp) == stride
 
 
@@ -335,8 +339,19 @@ module @module {
     assert np.allclose(comps["hlo_y"].reshape(5, 3, 1), np.linalg.solve(L_, b), rtol=1e-12, atol=1e-14)
 
 
+@pytest.fixture
+def rolled_loops(request, monkeypatch):
+    """roll=True: every statically counted while of two trips or more stays a counted loop in lane mode (the thresholds that keep
+    short loops unrolled are lowered), so the random modules exercise loop-invariant carried values and counter-indexed exchange reads."""
+    if request.param:
+        monkeypatch.setattr(sh._LaneEval, "ROLL_MIN_TRIPS", 2)
+        monkeypatch.setattr(sh._LaneEval, "ROLL_MIN_NODES", 1)
+    return request.param
+
+
+@pytest.mark.parametrize("rolled_loops", [False, True], indirect=True, ids=["unrolled", "rolled"])
 @pytest.mark.parametrize("seed", range(24))
-def test_random_entity_parallel_modules_lane_mode_equals_world_mode(seed):
+def test_random_entity_parallel_modules_lane_mode_equals_world_mode(seed, rolled_loops):
     """Differential fuzz of the entity-axis rules: a seeded random module of vmap-style statements (element-wise ops with broadcast
     scalars, slices / concatenations / reshapes / transposes that keep the entity axis whole, reductions and batched contractions over
     the other axes, selects, counted whiles, per-entity gathers from a shared table, iota ramps) evaluated with one lane per entity
@@ -382,8 +397,9 @@ def test_ball_world_tick_with_jax_random_reproduces_the_reference_golden_100_tic
     assert np.allclose(comps["hlo_wind"][0], [-0.2058421394796434, -0.7847657764467411, 1.8160866726679836], rtol=1e-13)   # test_uniform_pipeline.rs:152-156
 
 
+@pytest.mark.parametrize("rolled_loops", [False, True], indirect=True, ids=["unrolled", "rolled"])
 @pytest.mark.parametrize("seed,n", [(s_, 3 + s_ % 3) for s_ in range(100, 116)])
-def test_random_modules_with_reads_between_entities_lane_exchange_equals_world_mode(seed, n):
+def test_random_modules_with_reads_between_entities_lane_exchange_equals_world_mode(seed, n, rolled_loops):
     """The same differential fuzz with JOINS in the mix: every entity reads rows of other entities of its world by a constant table
     (gather along the entity axis, re-stacked per source — graph.rs:187-235's shape).  One lane per entity turns them into lane
     exchanges inside a world of `rows_per_world` rows (3, 4 and 5 entities: strides 4, 4 and 8, padding rows included); the result
