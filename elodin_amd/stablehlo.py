@@ -38,6 +38,7 @@ tests/test_gpu_stablehlo_world.py.
 from __future__ import annotations
 
 import itertools
+import os
 import re
 from pathlib import Path
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -1032,6 +1033,7 @@ class _Eval:
     ROLL = False
     ROLL_MIN_TRIPS = 12
     ROLL_MIN_NODES = 300
+    ROLL_UNROLL = 1
 
     @staticmethod
     def _flatten_elems(x: Sym) -> list:
@@ -1155,7 +1157,9 @@ class _Eval:
             if changed:
                 raise _KindsChanged()
             return _dsl.Vec([v for k in variant for v in self._flatten_elems(outs[k])])
-        counted = (0, int(static_trips), 1) if static_trips is not None else None         # (, 1): do not unroll it again
+        # (, ROLL_UNROLL = 1): not unrolled again — measured on the 20-body world, unroll 1 / 2 / 4 / 8 = 30.9 / 32.1 / 29.7 / 32.1 us per
+        # tick (one wave per SIMD: the tick is ~13,000 issued instructions either way), and 4 / 8 spill the 35-body world
+        counted = (0, int(static_trips), int(self.ROLL_UNROLL)) if static_trips is not None else None
         for _ in range(4):
             try:
                 res = _dsl.lax.while_loop(cond, body, _dsl.Vec(flat), **({"counted": counted, "max_iter": counted[1] + 1} if counted else {}))
