@@ -1194,6 +1194,7 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
     pipe_tp = tp.pipe if is_prog else tp
     n_aux = 0 if is_prog else len(tp.columns)
     n_model = len(tp.columns) if is_prog else 0
+    rows_multiple = lane_stride(tp) if is_prog else 1
     _WINDOWS.clear()
     col_widths = "{0u}"
     if is_prog:
@@ -1304,6 +1305,10 @@ extern "C" void sixdof_custom_column_widths(unsigned* out) {{
     static const unsigned w[] = {col_widths};
     for (unsigned k = 0; k < {n_model}u; k++) out[k] = w[k];
 }}
+
+// rows per world when the program exchanges data between the entities of a world inside the wavefront (whole-world StableHLO ticks in
+// lane mode, ops lane_read / lane_read_dyn; 1 otherwise): sixdof_set_custom_pipe refuses an executor whose row count would split a world
+extern "C" unsigned sixdof_custom_rows_multiple() {{ return {rows_multiple}u; }}
 
 extern "C" int sixdof_custom_launch(const sixdof::StepParams* p, int integrator, int dtype, void* stream) {{
     using namespace sixdof;

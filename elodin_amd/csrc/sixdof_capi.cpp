@@ -1043,6 +1043,15 @@ int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t
         return h->fail(SIXDOF_ERR_BACKEND, "set_custom_pipe: not a generated pipe for this library build (StepParams layout differs)");
     }
     auto col_widths = reinterpret_cast<void (*)(unsigned*)>(dlsym(dl, "sixdof_custom_column_widths"));
+    // a program that exchanges data between the entities of a world inside the wavefront (a whole-world StableHLO tick with one lane
+    // per entity: elodin_amd/stablehlo.py, manifest "rows_per_world") lays a world out as that many consecutive rows
+    auto rows_multiple = reinterpret_cast<unsigned (*)()>(dlsym(dl, "sixdof_custom_rows_multiple"));
+    if (rows_multiple && rows_multiple() > 1 && h->desc.n_entities % rows_multiple() != 0) {
+        const unsigned m = rows_multiple();
+        dlclose(dl);
+        return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "set_custom_pipe: the program lays a world out as " + std::to_string(m) +
+                       " consecutive rows; " + std::to_string(h->desc.n_entities) + " rows are not a whole number of worlds");
+    }
     const unsigned lay = layout();
     const size_t k_aux = lay & 0xff, k_model = (lay >> 8) & 0xff;
     if (k_aux > static_cast<size_t>(kMaxOps) || k_model > static_cast<size_t>(kMaxModelCols) || k_aux + k_model != n_aux) {

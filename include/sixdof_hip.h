@@ -328,7 +328,10 @@ int sixdof_sink_copy_to_rows(const sixdof_sink* s, const uint64_t* pair_ids, voi
  * with another width.  A program may hold stand-alone folds between its systems (graph.rs:239-361): the generated launch
  * entry then issues a chain of kernels per tick (systems | fold | systems | six_dof | ...) over the same columns; the fold's
  * scratch rows are one more program column `<out>#fold<k>`.  Replaces the built-in op list (sixdof_set_effectors) for the
- * per-entity path. */
+ * per-entity path.  An object built from a whole-world StableHLO tick with one lane per entity (cranelift_compile.rs:47-68's module,
+ * `python -m elodin_amd.stablehlo`, manifest "rows_per_world") exchanges data between the entities of a world inside the
+ * wavefront and exports the rows a world occupies; a handle whose n_entities is not a multiple of it is refused with
+ * SIXDOF_ERR_INVALID_ARGUMENT. */
 int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t* aux_component_ids, size_t n_aux);
 /* Same idea for GraphQuery.edge_fold (graph.rs:177-282) with a user-written fold function over
  * (acc: Force, a: (WorldPos, Inertia), b: (WorldPos, Inertia)): the generated object instantiates the pair kernels

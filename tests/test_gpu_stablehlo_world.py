@@ -236,6 +236,11 @@ def test_three_body_world_one_lane_per_entity_exchange_inside_the_wavefront_on_t
     print(f"three-body worlds, one lane per entity (lane_read): G1 bit for bit; perturbed worlds vs the oracle {worst:.2e}")
     assert worst <= 1e-9
     hip.close()
+    # a host without Python reads "rows_per_world" from the manifest; should it get the row count wrong, the C ABI itself refuses:
+    # the object exports the rows a world occupies and sixdof_set_custom_pipe checks the handle against it
+    program._traced.rows_multiple = 0                                    # (switch off the Python-side check of the same thing)
+    with pytest.raises(ValueError, match="lays a world out as 4 consecutive rows; 6 rows are not a whole number of worlds"):
+        _exec(program, {k: v[:6].copy() for k, v in start.items()}, 6)
 
 
 def test_ten_body_solar_system_world_in_lane_mode_on_the_gpu():
