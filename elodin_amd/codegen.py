@@ -1194,7 +1194,11 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
     pipe_tp = tp.pipe if is_prog else tp
     n_aux = 0 if is_prog else len(tp.columns)
     n_model = len(tp.columns) if is_prog else 0
+    # rows per world when the program exchanges data between the entities of a world inside the wavefront (whole-world StableHLO ticks
+    # in lane mode, ops lane_read / lane_read_dyn): sixdof_set_custom_pipe refuses an executor whose row count would split a world
     rows_multiple = lane_stride(tp) if is_prog else 1
+    rows_export = (f"// a world of this program is {rows_multiple} consecutive rows (its entities exchange data inside the wavefront)\n"
+                   f'extern "C" unsigned sixdof_custom_rows_multiple() {{ return {rows_multiple}u; }}\n\n') if rows_multiple > 1 else ""
     _WINDOWS.clear()
     col_widths = "{0u}"
     if is_prog:
@@ -1306,11 +1310,7 @@ extern "C" void sixdof_custom_column_widths(unsigned* out) {{
     for (unsigned k = 0; k < {n_model}u; k++) out[k] = w[k];
 }}
 
-// rows per world when the program exchanges data between the entities of a world inside the wavefront (whole-world StableHLO ticks in
-// lane mode, ops lane_read / lane_read_dyn; 1 otherwise): sixdof_set_custom_pipe refuses an executor whose row count would split a world
-extern "C" unsigned sixdof_custom_rows_multiple() {{ return {rows_multiple}u; }}
-
-extern "C" int sixdof_custom_launch(const sixdof::StepParams* p, int integrator, int dtype, void* stream) {{
+{rows_export}extern "C" int sixdof_custom_launch(const sixdof::StepParams* p, int integrator, int dtype, void* stream) {{
     using namespace sixdof;
     if (integrator != {integrator} || dtype != {0 if dtype == "float64" else 1}) return static_cast<int>(hipErrorInvalidValue);
     if (p->n == 0) return static_cast<int>(hipSuccess);
