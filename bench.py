@@ -638,7 +638,8 @@ def world_module_leg(device):
                                               "us_per_tick": round(tm.kernel_device_ms * 2, 3), "world_steps_per_s": round(worlds * 500 / (tm.kernel_device_ms * 1e-3), 1),
                                               "pair_evals_per_s": round(4.0 * nb * (nb - 1) * worlds * 500 / (tm.kernel_device_ms * 1e-3), 1),
                                               "exchange_reads_per_tick_in_the_program": cman.get("exchange_reads"),
-                                              "loops": "four 34-trip counted loops (lane_read_dyn), not unrolled"}
+                                              "loops": "four 34-trip counted loops (lane_read_dyn), not unrolled",
+                                              "roofline": valu_roofline("cluster_35_bodies_lane_mode", rows, 500, tm.kernel_device_ms * 1e-3, WORLD_VALU_FILE)}
     except Exception as e:  # noqa: BLE001
         out["cluster_35_bodies_lane_mode"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     n = 65536

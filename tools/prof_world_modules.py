@@ -74,6 +74,20 @@ def nlay(a, fill):
 run(nsys, {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), su.DT), "hlo_world_pos": nlay(spos, [0, 0, 0, 1.0, 0, 0, 0]),
            "hlo_world_vel": nlay(svel, np.zeros(6)), "hlo_inertia": nlay(sin_, np.ones(7)), "hlo_world_accel": np.zeros((rows, 6)),
            "hlo_force": np.zeros((rows, 6))}, rows, "solar_system_10_bodies_lane_mode")
+nb = 35                                                            # a 35-body cluster: a world = one wavefront, four 34-trip counted loops
+rng = np.random.default_rng(nb)
+cpos = np.concatenate([np.tile([0, 0, 0, 1.0], (nb, 1)), rng.normal(size=(nb, 3)) * 3], axis=1)
+cvel = np.concatenate([np.zeros((nb, 3)), rng.normal(size=(nb, 3)) * 1e-3], axis=1)
+cm = rng.uniform(1e-6, 1e-3, nb)
+cin = np.concatenate([np.tile(cm[:, None], (1, 3)), np.zeros((nb, 3)), cm[:, None]], axis=1)
+ctext, cslots = hb.nbody_world(nb, 2.9591220828e-4, 1e-6)
+csys, cman = sh.world_system(ctext, cslots, mode="auto")
+S = cman["rows_per_world"]
+rows = S * 256                                                     # 16,384 rows
+spos, svel, sin_ = cpos, cvel, cin
+run(csys, {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), 0.5), "hlo_world_pos": nlay(spos, [0, 0, 0, 1.0, 0, 0, 0]),
+           "hlo_world_vel": nlay(svel, np.zeros(6)), "hlo_inertia": nlay(sin_, np.ones(7)), "hlo_world_accel": np.zeros((rows, 6)),
+           "hlo_force": np.zeros((rows, 6))}, rows, "cluster_35_bodies_lane_mode")
 out = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / "world_keys.json"
 out.write_text(json.dumps({"ticks_per_launch": TICKS_PER_LAUNCH, "grids": keys}))
 print("done", keys)
