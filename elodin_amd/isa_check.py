@@ -12,7 +12,6 @@ tools/spill_repro/run.py (profiles/r05_spill_repro.md) and, opt-in, by codegen.p
 build only when this check is clean."""
 import re
 import subprocess
-import sys
 import tempfile
 from pathlib import Path
 

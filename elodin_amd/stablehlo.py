@@ -38,7 +38,6 @@ tests/test_gpu_stablehlo_world.py.
 from __future__ import annotations
 
 import itertools
-import os
 import re
 from pathlib import Path
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
