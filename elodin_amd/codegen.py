@@ -1725,10 +1725,11 @@ def _pch_store() -> Optional[Path]:
     store = PCH_DIR[0] or (Path(os.environ["SIXDOF_PCH_DIR"]) if os.environ.get("SIXDOF_PCH_DIR") else
                            Path(tempfile.gettempdir()) / f"elodin_amd_pch_{os.getuid()}")
     try:
+        import stat
         store.mkdir(mode=0o700, parents=True, exist_ok=True)
-        st = store.stat()
-        if st.st_uid != os.getuid() or (st.st_mode & 0o022):
-            return None           # somebody else's (or writable by others): compile without it
+        st = os.lstat(store)
+        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            return None           # a link, somebody else's, or writable by others: compile without it
     except OSError:
         return None
     return store
