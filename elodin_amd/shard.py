@@ -14,13 +14,18 @@ from typing import Tuple
 import numpy as np
 
 
-def shard_range(total_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
-    """Contiguous block [lo, hi) of rank `rank`; blocks differ by at most one row."""
+def shard_range(total_rows: int, world_size: int, rank: int, unit: int = 1) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of rank `rank`; blocks differ by at most one unit.  `unit`: rows that must stay on one rank — 1 for
+    independent bodies / rollouts; the `rows_per_world` of a whole-world StableHLO tick in lane mode (elodin_amd/stablehlo.py), whose
+    entities exchange data inside the wavefront: a Monte-Carlo of such worlds shards by WORLD.  (A C host calls sixdof_shard_range on
+    total_rows / unit and multiplies.)"""
     if not (0 <= rank < world_size):
         raise ValueError("rank out of range")
-    base, extra = divmod(total_rows, world_size)
+    if unit < 1 or total_rows % unit:
+        raise ValueError(f"{total_rows} rows are not a whole number of {unit}-row units")
+    base, extra = divmod(total_rows // unit, world_size)
     lo = rank * base + min(rank, extra)
-    return lo, lo + base + (1 if rank < extra else 0)
+    return lo * unit, (lo + base + (1 if rank < extra else 0)) * unit
 
 
 def run_id(idx: int) -> str:
@@ -56,8 +61,8 @@ def broadcast_table(table: np.ndarray | None, shape, dtype=np.float64, src: int 
     return t.cpu().numpy()
 
 
-def gather_rows(local_rows: np.ndarray, total_rows: int, device="cpu") -> np.ndarray:
-    """All-gather per-rollout result rows back into run-id order (shards are contiguous blocks)."""
+def gather_rows(local_rows: np.ndarray, total_rows: int, device="cpu", unit: int = 1) -> np.ndarray:
+    """All-gather per-rollout result rows back into run-id order (shards are contiguous blocks; `unit` as in shard_range)."""
     import torch
     dist = _dist()
     local_rows = np.ascontiguousarray(local_rows)
@@ -65,7 +70,7 @@ def gather_rows(local_rows: np.ndarray, total_rows: int, device="cpu") -> np.nda
         return local_rows
     world = dist.get_world_size()
     width = local_rows.shape[1]
-    sizes = [shard_range(total_rows, world, r) for r in range(world)]
+    sizes = [shard_range(total_rows, world, r, unit) for r in range(world)]
     pad = max(hi - lo for lo, hi in sizes)
     buf = torch.zeros((pad, width), dtype=getattr(torch, local_rows.dtype.name), device=device)
     buf[: local_rows.shape[0]] = torch.from_numpy(local_rows)

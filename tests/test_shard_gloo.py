@@ -192,3 +192,72 @@ def test_falcon9_campaign_two_ranks_equals_one():
     assert res2.shape == (5, 8) and np.array_equal(res1, res2)         # run-id order, bit-identical (3 + 2 rows)
     assert np.array_equal(res2[:, 7], params[:, 0])                    # every rank flew ITS rows of rank 0's table
     assert np.all(res2[:, 0] > 1.0e5) and np.all(res2[:, 4] == 1.0)     # 0.25 s after ignition: engines spooling up, VerticalRise
+
+
+# ---- a Monte-Carlo of WHOLE-WORLD ticks (three-body worlds, one lane per entity: a world = 4 consecutive rows that exchange data
+#      inside the wavefront) shards by world: shard_range(..., unit=rows_per_world).  Stepped by the numpy walker of the traced program.
+WORLDS = 9
+
+
+def _world_columns(lo_world, hi_world, S):
+    from tests import stablehlo_world_util as W
+    g = W.gu.load("three_body")
+    cols = W.strided_world_columns(g, "abc", S, WORLDS)
+    rng = np.random.default_rng(5)
+    body_rows = np.array([w_ * S + i for w_ in range(WORLDS) for i in range(3)])
+    cols["hlo_world_pos"][body_rows, 4:6] += rng.uniform(-0.05, 0.05, (len(body_rows), 2))       # every world its own state
+    return {k: v[lo_world * S:hi_world * S].copy() for k, v in cols.items()}
+
+
+def _world_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from elodin_amd import stablehlo as sh
+        from tests.golden import hlo_world_builder as hb
+        from tests.test_stablehlo_world import walk
+        text, slots = hb.three_body_world()
+        system, manifest = sh.world_system(text, slots, mode="auto")
+        S = manifest["rows_per_world"]
+        lo, hi = shard.shard_range(WORLDS * S, world, rank, unit=S)
+        assert lo % S == 0 and hi % S == 0
+        cols = _world_columns(lo // S, hi // S, S)
+        walk(system, {c["column"]: c["width"] for c in manifest["columns"]}, cols, 10)
+        gathered = shard.gather_rows(np.concatenate([cols["hlo_world_pos"], cols["hlo_world_vel"]], axis=1), WORLDS * S, unit=S)
+        if rank == 0:
+            q.put((gathered, (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shards_of_whole_world_ticks_are_whole_worlds():
+    assert [shard.shard_range(36, 2, r, unit=4) for r in range(2)] == [(0, 20), (20, 36)]            # 9 worlds: 5 + 4
+    assert [shard.shard_range(64 * 3, 8, r, unit=64) for r in range(8)] == [(0, 64), (64, 128), (128, 192)] + [(192, 192)] * 5
+    with pytest.raises(ValueError, match="whole number"):
+        shard.shard_range(38, 2, 0, unit=4)
+
+
+def test_two_rank_gloo_monte_carlo_of_three_body_worlds_in_lane_mode_matches_single_process():
+    from elodin_amd import stablehlo as sh
+    from tests.golden import hlo_world_builder as hb
+    from tests.test_stablehlo_world import walk
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gathered, rank0 = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    text, slots = hb.three_body_world()
+    system, manifest = sh.world_system(text, slots, mode="auto")
+    S = manifest["rows_per_world"]
+    assert rank0 == (0, 5 * S)
+    cols = _world_columns(0, WORLDS, S)
+    walk(system, {c["column"]: c["width"] for c in manifest["columns"]}, cols, 10)
+    want = np.concatenate([cols["hlo_world_pos"], cols["hlo_world_vel"]], axis=1)
+    body = np.array([w_ * S + i for w_ in range(WORLDS) for i in range(3)])
+    assert np.isfinite(want[body]).all() and np.array_equal(gathered[body], want[body])      # not a bit differs (padding rows hold nothing)
+    assert np.array_equal(gathered, want, equal_nan=True)
