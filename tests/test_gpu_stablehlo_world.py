@@ -372,3 +372,44 @@ def test_worlds_of_32_and_64_rows_in_lane_mode_on_the_gpu(n, stride):
     print(f"{n}-body world, rows_per_world {stride}, 129 worlds x 48 ticks vs the oracle: {worst:.2e}; {tm.kernel_device_ms / 48 * 1e3:.1f} us per tick")
     assert worst <= 1e-9
     hip.close()
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_whole_world_ticks_build_in_float32_too(fast):
+    """`--dtype float32 [--fast-math]` of the CLI: the 10-body solar system in lane mode (exchange reads of floats: one ds_bpermute
+    each) and the three-body world with one lane per world, 48 / 100 ticks against the f64 oracle / G1 at single-precision accuracy."""
+    from tests import solar_util as su
+    from tests.golden import hlo_world_builder as hb
+    d, pos, vel, inertia = su.load()
+    n = pos.shape[0]
+    text, slots = hb.nbody_world(n, su.K_SQUARED, su.SOFTENING_AU2)
+    system, manifest = sh.world_system(text, slots, mode="auto")
+    S, worlds = manifest["rows_per_world"], 256
+    rows = S * worlds
+
+    def lay(a, fill):
+        out = np.tile(np.asarray(fill, dtype=np.float64), (rows, 1))
+        for w_ in range(worlds):
+            out[w_ * S:w_ * S + n] = a
+        return out
+    cols = {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), su.DT), "hlo_world_pos": lay(pos, [0, 0, 0, 1.0, 0, 0, 0]),
+            "hlo_world_vel": lay(vel, np.zeros(6)), "hlo_inertia": lay(inertia, np.ones(7)), "hlo_world_accel": np.zeros((rows, 6)), "hlo_force": np.zeros((rows, 6))}
+    hip = _exec(dsl.Program([system], dsl.Pipe([]), []), cols, rows, ticks_per_launch=12, dtype=np.float32, fast_math=fast)
+    hip.run(48)
+    w = orc.OracleWorld(pos, vel, inertia, simulation_time_step=su.DT, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, (su.K_SQUARED, su.SOFTENING_AU2), None)])
+    w.step(48)
+    worst = 0.0
+    for c, ref in (("world_pos", w.world_pos), ("world_vel", w.world_vel)):
+        for w_ in (0, 255):
+            got = np.asarray(hip._aux["hlo_" + c][w_ * S:w_ * S + n], dtype=np.float64)
+            worst = max(worst, float(np.max(np.abs(got - ref) / np.maximum(np.max(np.abs(ref), axis=1, keepdims=True), 1e-300))))
+    hip.close()
+    row = W.three_body("world")[3]
+    g = W.three_body("world")[4]
+    wsys, wman = sh.world_system(*hb.three_body_world(), mode="world")
+    hip = _exec(dsl.Program([wsys], dsl.Pipe([]), []), {c: np.tile(v[None, :], (64, 1)) for c, v in row.items()}, 64, dtype=np.float32, fast_math=fast)
+    hip.run(100)
+    e3 = max(W.three_body_errors({k: np.asarray(v, dtype=np.float64) for k, v in hip._aux.items()}, g, 100))
+    hip.close()
+    print(f"float32{' fast-math' if fast else ''}: 10-body lane mode, 48 ticks vs the f64 oracle {worst:.2e}; three-body world, 100 ticks vs G1 {e3:.2e}")
+    assert worst <= 2e-5 and e3 <= 2e-4
