@@ -24,8 +24,9 @@ LAPACK FFI custom calls jax.numpy.linalg lowers to on CPU (dpotrf, dtrsm, dgetrf
 dgeqrf / dorgqr, dsyevd), chlo.{erf_inv, square, acos, asin, sinh, cosh, erfc, ...}.  INTEGERS have the machine's semantics: results of
 add / subtract / multiply / negate / shifts / convert wrap to the declared width for types of 32 bits or fewer, `ui64` is exact as two
 uint32 words (U64) — jax.random's threefry rounds and its bits -> mantissa -> bitcast construction run bit for bit — and `i64` is one
-node, exact below 2^53 (ticks, counters, indices, seeds; no wrap at 2^63).  Not read: convolution, fft, rng, the remaining LAPACK calls
-— an unsupported op says which.
+node, exact below 2^53 (ticks, counters, indices, seeds; no wrap at 2^63).  `convolution` (N-D, strides, padding, dilations; one feature /
+batch group) is unrolled into multiply-adds and `rng` is the reference's deterministic fill.  Not read: fft (complex tensors), grouped
+convolutions, the remaining LAPACK calls — an unsupported op says which.
 
 Pinned on the reference's own tests: libs/cranelift-mlir/tests/ops.rs (198 inline modules with asserted outputs ->
 tests/golden/stablehlo_ops.json; the 22 not extracted are listed there with the reason), the world-tick fragments of
@@ -752,6 +753,20 @@ class _Eval:
             shp[feat] = x.shape[feat]
             b = lambda v: v.a.reshape(shp)
             return [Sym(_emap(lambda xv, s_, o, m_, v_: (xv - m_) / _np.sqrt(v_ + eps) * s_ + o, x.a, b(scale), b(offset), b(mean), b(var)), x.dtype)]
+        if short == "convolution":
+            return [self._convolution(xs[0], xs[1], text, rt)]
+        if short == "rng":
+            # the reference's stablehlo.rng is a DETERMINISTIC fill, not a generator (libs/cranelift-mlir/src/tensor_rt.rs:2103-2140,
+            # ARCHITECTURE.md:916; jax.random lowers to threefry instead, which is read bit for bit): UNIFORM = n values linearly spaced
+            # from a to b inclusive (0.5 of the way for n = 1), NORMAL = the midpoints (i + 0.5) / n of the same span.  Same values here.
+            a, b = _dsl._lift(xs[0].a.reshape(-1)[0]), _dsl._lift(xs[1].a.reshape(-1)[0])
+            normal = re.search(r"rng_distribution\s+NORMAL", text) is not None
+            n = rt.size
+            ts = [((i + 0.5) / n if normal else (i / (n - 1) if n > 1 else 0.5)) for i in range(n)]
+            out = np.empty(n, dtype=object)
+            for i, t in enumerate(ts):
+                out[i] = a + t * (b - a)
+            return [Sym(out.reshape(rt.shape), rt.dtype)]
         if short == "map":
             region = self._region_fn(op, 0, env)
             out = np.empty(xs[0].shape, dtype=object)
@@ -759,6 +774,82 @@ class _Eval:
                 out[idx] = region(*[Sym(_obj_scalar(x.a[idx]), x.dtype) for x in xs])[0].a[()]
             return [Sym(out, rt.dtype)]
         raise NotImplementedError(f"StableHLO op {name} is not provided by elodin_amd.stablehlo")
+
+    def _convolution(self, lhs: Sym, rhs: Sym, text: str, rt: TensorType) -> Sym:
+        """stablehlo.convolution over static shapes, unrolled into multiply-adds: N spatial dimensions, window strides, padding, lhs /
+        rhs dilation, any dimension_numbers `#stablehlo.conv<[b, 0, f]x[0, i, o]->[b, 0, f]>`; feature_group_count = batch_group_count
+        = 1.  A cross-correlation (the kernel is not flipped); a window position that falls into the padding or between the dilated
+        input samples contributes nothing.  (libs/cranelift-mlir/ARCHITECTURE.md:910; the reference's own known answer for it,
+        ops.rs:4211-4230, is #[ignore]d there — it passes here.)"""
+        # generic form: dimension_numbers = #stablehlo.conv<[b, 0, f]x[0, i, o]->[b, 0, f]>, window_strides = array<i64: 1>, padding = dense<...>;
+        # pretty form (what jax dumps): dim_numbers = [b, 0, f]x[0, i, o]->[b, 0, f], window = {stride = [1], pad = [[0, 0]], lhs_dilate = [1], ...}
+        m = re.search(r"(?:#stablehlo\.conv<\s*(?:raw\s*)?|dim_numbers\s*=\s*)\[([^\]]*)\]\s*x\s*\[([^\]]*)\]\s*->\s*\[([^\]]*)\]", text)
+        if not m:
+            raise NotImplementedError("stablehlo.convolution without [...]x[...]->[...] dimension numbers")
+        ld, kd, od = ([t.strip() for t in g.split(",")] for g in m.groups())
+        ns = len(ld) - 2
+        for key in ("feature_group_count", "batch_group_count"):
+            g = re.search(key + r"\s*=\s*(\d+)", text)
+            if g and int(g.group(1)) != 1:
+                raise NotImplementedError(f"stablehlo.convolution with {key} = {g.group(1)}")
+        if re.search(r"window_reversal\s*=\s*(?:array<i1:[^>]*true|dense<[^>]*true)", text):
+            raise NotImplementedError("stablehlo.convolution with window_reversal")
+        win = re.search(r"window\s*=\s*\{(.*?)\}\s*(?:\{|:)", text, re.S)
+        if win:
+            def wlist(key, default):
+                g = re.search(key + r"\s*=\s*\[([^\]]*)\]", win.group(1))
+                return [int(v) for v in g.group(1).split(",")] if g and g.group(1).strip() else [default] * ns
+            stride, ldil, rdil = wlist("stride", 1), wlist("lhs_dilate", 1), wlist("rhs_dilate", 1)
+            g = re.search(r"pad\s*=\s*\[((?:\s*\[[^\]]*\]\s*,?)*)\]", win.group(1))
+            vals = [int(v) for v in re.findall(r"-?\d+", g.group(1))] if g else []
+            pad = [(vals[2 * d], vals[2 * d + 1]) for d in range(ns)] if vals else [(0, 0)] * ns
+            if re.search(r"reverse\s*=\s*\[[^\]]*true", win.group(1)):
+                raise NotImplementedError("stablehlo.convolution with window reversal")
+        else:
+            stride = self._window_attr(text, "window_strides", ns, 1)
+            ldil = self._window_attr(text, "lhs_dilation", ns, 1)
+            rdil = self._window_attr(text, "rhs_dilation", ns, 1)
+            pad = self._padding_attr(text, ns)
+        sp = [str(k) for k in range(ns)]
+        lb, lf, ls = ld.index("b"), ld.index("f"), [ld.index(k) for k in sp]
+        ki, ko, ks = kd.index("i"), kd.index("o"), [kd.index(k) for k in sp]
+        ob, of, os_ = od.index("b"), od.index("f"), [od.index(k) for k in sp]
+        B, Cin, Cout = lhs.shape[lb], lhs.shape[lf], rhs.shape[ko]
+        if rhs.shape[ki] != Cin:
+            raise ValueError("stablehlo.convolution: the kernel's input-feature size differs from the operand's")
+        in_sz = [lhs.shape[a] for a in ls]
+        k_sz = [rhs.shape[a] for a in ks]
+        out_sz = [rt.shape[a] for a in os_]
+        out = np.empty(rt.shape, dtype=object)
+        for b in range(B):
+            for o in range(Cout):
+                for opos in (np.ndindex(*out_sz) if ns else [()]):
+                    acc = None
+                    for kpos in (np.ndindex(*k_sz) if ns else [()]):
+                        src, ok = [], True
+                        for d in range(ns):      # position in the dilated + padded input -> the input sample it is, if any
+                            p = opos[d] * stride[d] + kpos[d] * rdil[d] - pad[d][0]
+                            if p < 0 or p % ldil[d] or p // ldil[d] >= in_sz[d]:
+                                ok = False
+                                break
+                            src.append(p // ldil[d])
+                        if not ok:
+                            continue
+                        for c in range(Cin):
+                            li = [0] * lhs.a.ndim
+                            li[lb], li[lf] = b, c
+                            ri = [0] * rhs.a.ndim
+                            ri[ki], ri[ko] = c, o
+                            for d in range(ns):
+                                li[ls[d]], ri[ks[d]] = src[d], kpos[d]
+                            term = _dsl._lift(lhs.a[tuple(li)]) * _dsl._lift(rhs.a[tuple(ri)])
+                            acc = term if acc is None else acc + term
+                    oi = [0] * len(rt.shape)
+                    oi[ob], oi[of] = b, o
+                    for d in range(ns):
+                        oi[os_[d]] = opos[d]
+                    out[tuple(oi)] = acc if acc is not None else _dsl._lift(0.0)
+        return Sym(out, lhs.dtype)
 
     @staticmethod
     def _slice_ranges(text: str) -> List[Tuple[int, int, int]]:

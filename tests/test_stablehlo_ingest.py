@@ -248,3 +248,80 @@ module @m {
     want[:, ::2] = x                                                   # interior padding: x0 . x1 . x2
     want = np.pad(want[:, 1:], ((1, 1), (0, 2)), constant_values=-7.0)  # low -1 crops the first column, high 2 appends two
     assert np.array_equal(np.asarray(got).reshape(4, 6), want)
+
+
+def _conv_reference(x, k, stride, pad, ldil, rdil):
+    """stablehlo.convolution for [b, 0, 1, f] x [0, 1, i, o] -> [b, 0, 1, f] with plain loops (the spec's definition)."""
+    B, H, W, C = x.shape
+    xd = np.zeros((B, (H - 1) * ldil[0] + 1, (W - 1) * ldil[1] + 1, C))
+    xd[:, ::ldil[0], ::ldil[1]] = x
+    xp = np.pad(xd, ((0, 0), pad[0], pad[1], (0, 0)))
+    KH, KW, _, O = k.shape
+    eh, ew = (KH - 1) * rdil[0] + 1, (KW - 1) * rdil[1] + 1
+    oh, ow = (xp.shape[1] - eh) // stride[0] + 1, (xp.shape[2] - ew) // stride[1] + 1
+    out = np.zeros((B, oh, ow, O))
+    for b in range(B):
+        for i in range(oh):
+            for j in range(ow):
+                for o in range(O):
+                    acc = 0.0
+                    for a in range(KH):
+                        for c in range(KW):
+                            for f in range(C):
+                                acc += xp[b, i * stride[0] + a * rdil[0], j * stride[1] + c * rdil[1], f] * k[a, c, f, o]
+                    out[b, i, j, o] = acc
+    return out
+
+
+def test_convolution_the_references_own_ignored_case_and_a_strided_padded_dilated_one():
+    """stablehlo.convolution (libs/cranelift-mlir/ARCHITECTURE.md:910 lists it as supported; the reference's one known answer for it,
+    ops.rs:4211-4230, is #[ignore]d there: "runtime indexing needs further debugging").  That case — [1, 2, 3, 4] with the kernel
+    [1, 1] -> [3, 5, 7] — and a 2-D one with strides, asymmetric padding, lhs and rhs dilation and a channel-last layout against
+    plain loops over the spec's definition."""
+    text = """
+module @module {
+  func.func public @main(%arg0: tensor<1x4x1xf64>, %arg1: tensor<2x1x1xf64>) -> tensor<1x3x1xf64> {
+    %0 = "stablehlo.convolution"(%arg0, %arg1) {window_strides = array<i64: 1>, padding = dense<[[0, 0]]> : tensor<1x2xi64>, lhs_dilation = array<i64: 1>, rhs_dilation = array<i64: 1>, dimension_numbers = #stablehlo.conv<[b, 0, f]x[0, i, o]->[b, 0, f]>, batch_group_count = 1 : i64, feature_group_count = 1 : i64} : (tensor<1x4x1xf64>, tensor<2x1x1xf64>) -> tensor<1x3x1xf64>
+    return %0 : tensor<1x3x1xf64>
+  }
+}
+"""
+    got = dsl_numpy.trace_eval(lambda xp, a, k: dsl.Vec(list(sh.trace(text, [a, k])[0].a.reshape(-1))), np.array([1.0, 2.0, 3.0, 4.0]), np.array([1.0, 1.0]))
+    assert np.array_equal(np.asarray(got), [3.0, 5.0, 7.0])
+    rng = np.random.default_rng(12)
+    x, k = rng.normal(size=(2, 4, 5, 3)), rng.normal(size=(2, 3, 3, 2))
+    stride, pad, ldil, rdil = (2, 1), ((1, 0), (2, 1)), (1, 2), (2, 1)
+    want = _conv_reference(x, k, stride, pad, ldil, rdil)
+    text2 = f"""
+module @module {{
+  func.func public @main(%arg0: tensor<2x4x5x3xf64>, %arg1: tensor<2x3x3x2xf64>) -> tensor<{'x'.join(str(d) for d in want.shape)}xf64> {{
+    %0 = stablehlo.convolution(%arg0, %arg1) dim_numbers = [b, 0, 1, f]x[0, 1, i, o]->[b, 0, 1, f], window = {{stride = [2, 1], pad = [[1, 0], [2, 1]], lhs_dilate = [1, 2], rhs_dilate = [2, 1]}} {{batch_group_count = 1 : i64, feature_group_count = 1 : i64}} : (tensor<2x4x5x3xf64>, tensor<2x3x3x2xf64>) -> tensor<{'x'.join(str(d) for d in want.shape)}xf64>
+    return %0 : tensor<{'x'.join(str(d) for d in want.shape)}xf64>
+  }}
+}}
+"""
+    got = dsl_numpy.trace_eval(lambda xp, a, kk: dsl.Vec(list(sh.trace(text2, [a, kk])[0].a.reshape(-1))), x.reshape(-1), k.reshape(-1))
+    assert np.allclose(np.asarray(got).reshape(want.shape), want, rtol=1e-13, atol=1e-13)
+    with pytest.raises(NotImplementedError, match="feature_group_count"):
+        sh.trace(text.replace("feature_group_count = 1", "feature_group_count = 2"), [dsl.Vec([dsl.leaf(f"a{i}") for i in range(4)]), dsl.Vec([dsl.leaf("k0"), dsl.leaf("k1")])])
+
+
+def test_rng_is_the_references_deterministic_fill():
+    """stablehlo.rng in the reference is not a generator but a deterministic fill (libs/cranelift-mlir/src/tensor_rt.rs:2103-2140:
+    UNIFORM = n values linearly spaced from a to b inclusive, NORMAL = the span's midpoints (i + 0.5) / n; ARCHITECTURE.md:916).  A
+    module that carries the op gets the same values here; ops.rs:4414-4431 (`test_rng_uniform_mem`) asserts the range only."""
+    def module(dist, n):
+        return f"""
+module @module {{
+  func.func public @main(%arg0: tensor<f64>, %arg1: tensor<f64>) -> tensor<{n}xf64> {{
+    %0 = "stablehlo.rng"(%arg0, %arg1) {{rng_distribution = #stablehlo<rng_distribution {dist}>}} : (tensor<f64>, tensor<f64>) -> tensor<{n}xf64>
+    return %0 : tensor<{n}xf64>
+  }}
+}}
+"""
+    run = lambda text, a, b: np.asarray(dsl_numpy.trace_eval(lambda xp, x, y: dsl.Vec(list(sh.trace(text, [x, y])[0].a.reshape(-1))), a, b))
+    got = run(module("UNIFORM", 4), 0.0, 1.0)
+    assert np.array_equal(got, [0.0, 1.0 / 3.0, 2.0 / 3.0, 1.0]) and np.all((got >= 0.0) & (got <= 1.0))        # the reference's own assertion
+    assert np.array_equal(run(module("UNIFORM", 5), -2.0, 6.0), [-2.0 + (i / 4.0) * 8.0 for i in range(5)])
+    assert np.array_equal(run(module("UNIFORM", 1), 3.0, 5.0), [4.0])
+    assert np.array_equal(run(module("NORMAL", 4), 0.0, 2.0), [0.0 + ((i + 0.5) / 4.0) * 2.0 for i in range(4)])
