@@ -950,7 +950,7 @@ def _slots_of(systems, extra_exprs=()) -> set:
     return {int(n[1:].split("_")[0]) for n in names if n[0] == "c" and "_" in n and n[1:].split("_")[0].isdigit()}
 
 
-def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pre_reads_accel: bool, n_aux: int) -> str:
+def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pre_reads_accel: bool, n_aux: int, body_dead: bool = False) -> str:
     """One PIPE struct of csrc/step_kernel.hpp: effector stage from `pipe_tp` (None: no effectors), `pre` / `post` hooks from
     traced systems.  `used`: the program column slots this struct keeps in registers (None: all of tp.columns)."""
     body = "\n".join(emit_apply(pipe_tp)) if pipe_tp is not None else ""
@@ -1010,7 +1010,7 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
         model = f'''
     static constexpr bool kHasModel = true;
     static constexpr bool kWritesInertia = {"true" if writes_inertia else "false"};
-    static constexpr bool kPreReadsAccel = {"true" if pre_reads_accel else "false"};
+    static constexpr bool kPreReadsAccel = {"true" if pre_reads_accel else "false"};{chr(10) + "    static constexpr bool kBodyDead = true;      // no system touches a Body column: the kernel leaves the Body slabs alone" if body_dead else ""}
     template <class T>
     struct Regs {{
 {regs}
@@ -1224,9 +1224,19 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
         launch_k = lambda pipe, ig, params: (
             f"    hipLaunchKernelGGL((sixdof_step_kernel<{T}, {ig}, {pipe}, {pname}>), grid, dim3(kWave), 0, s, {params});   // built for this executor's cache policy only\n")
     staged = is_prog and bool(tp.fold_stages)
+    body_dead = False
+    if is_prog and not staged and integrator == 2 and getattr(tp, "body_free", False):
+        # the program says no system touches a Body column (a whole-world StableHLO tick, stablehlo.world_system): hold it to that —
+        # column slots, window pushes, `tick` and the loop / probe leaves aside, nothing may be read, and only columns written
+        systems_ = tp.pre + tp.post
+        touched = {n for n in dsl._leaves_of([e for s_ in systems_ for _, e in s_.assign]) if n in _LEAF_CPP or n.startswith("aux") or n in ("aax", "aay", "aaz", "alx", "aly", "alz")}
+        wrote = {t for s_ in systems_ for t in s_.written if not (t[0] == "c" or t.startswith("wst"))}
+        if touched or wrote or any(s_.writes_inertia or s_.reads_accel for s_ in systems_):
+            raise ValueError(f"a program declared free of Body state reads {sorted(touched)} / writes {sorted(wrote)}")
+        body_dead = True
     if not staged:
         structs = _emit_pipe_struct("PipeCustom", tp if is_prog else None, pipe_tp, tp.pre if is_prog else [], tp.post if is_prog else [],
-                                    None, tp.pre_reads_accel if is_prog else False, n_aux)
+                                    None, tp.pre_reads_accel if is_prog else False, n_aux, body_dead)
         launch = launch_k("PipeCustom", integ, "(*p)")
         stage_comment = ""
     else:

@@ -75,6 +75,10 @@ struct NoModel {
     static constexpr bool kHasModel = false;
     static constexpr bool kWritesInertia = false;
     static constexpr bool kPreReadsAccel = false;   // a system in front of six_dof reads world_accel (the previous tick's)
+    // a generated program WITHOUT six_dof whose systems touch no Body column (a whole-world StableHLO tick: every component of the
+    // world, world_pos included, is a program column; the executor's Body columns are stand-ins): the kernel then neither loads nor
+    // stores the Body slabs — 456 B per entity and tick at one tick per launch
+    static constexpr bool kBodyDead = false;
     template <class T>
     struct Regs {};
     template <class T, int POL>

@@ -146,14 +146,18 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     T* const g_force = static_cast<T*>(P.force) + (size_t)row0 * 6;
     const T* const g_inertia = static_cast<const T*>(P.inertia) + (size_t)row0 * 7;
 
-    if (full) {
-        slab_dma_in<ROWS * 7 * sizeof(T), POL>(reinterpret_cast<const char*>(g_pos), reinterpret_cast<char*>(l_pos), t);
-        slab_dma_in<ROWS * 6 * sizeof(T), POL>(reinterpret_cast<const char*>(g_vel), reinterpret_cast<char*>(l_vel), t);
-        slab_dma_in<ROWS * 7 * sizeof(T), POL>(reinterpret_cast<const char*>(g_inertia), reinterpret_cast<char*>(l_c), t);
-    } else {
-        slab_in_tail(g_pos, l_pos, rows * 7, t);
-        slab_in_tail(g_vel, l_vel, rows * 6, t);
-        slab_in_tail(g_inertia, l_c, rows * 7, t);
+    // systems only and none of them touches a Body column (NoModel::kBodyDead): the Body slabs stay where they are
+    constexpr bool kDead = INTEGRATOR == kNone && PIPE::kBodyDead;
+    if constexpr (!kDead) {
+        if (full) {
+            slab_dma_in<ROWS * 7 * sizeof(T), POL>(reinterpret_cast<const char*>(g_pos), reinterpret_cast<char*>(l_pos), t);
+            slab_dma_in<ROWS * 6 * sizeof(T), POL>(reinterpret_cast<const char*>(g_vel), reinterpret_cast<char*>(l_vel), t);
+            slab_dma_in<ROWS * 7 * sizeof(T), POL>(reinterpret_cast<const char*>(g_inertia), reinterpret_cast<char*>(l_c), t);
+        } else {
+            slab_in_tail(g_pos, l_pos, rows * 7, t);
+            slab_in_tail(g_vel, l_vel, rows * 6, t);
+            slab_in_tail(g_inertia, l_c, rows * 7, t);
+        }
     }
 
     // per-entity effector columns: 24-byte rows, read once per launch straight from global
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
     Vec3<T> p0 = {T(0), T(0), T(0)}, inv_I = {T(1), T(1), T(1)}, I_diag = {T(1), T(1), T(1)};
     Spatial<T> v0 = zero6, A_out = zero6, F_out = zero6;
     T mass = T(1), inv_m = T(1);
-    if (active) {
+    if (active && !kDead) {
         const T* r = l_pos + t * 7;
         q0 = Quat<T>{r[0], r[1], r[2], r[3]};
         p0 = Vec3<T>{r[4], r[5], r[6]};
@@ -411,17 +415,19 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             // telemetry: this tick's world_pos / world_vel / world_accel / force rows -> ring slot, in the
             // reference's row layout, write-once (non-temporal); the stores drain under the next tick's math
             if constexpr (INTEGRATOR != kNone) F_out = world_wrench<PIPE>(b.q, F);
-            stage_pos(q0, p0);
-            stage6(l_vel, v0);
-            stage6(l_c, A_out);
-            stage6(l_force, F_out);
-            __syncthreads();
             const size_t slot = (size_t)((P.hist_slot0 + tick) % P.hist_ring);
-            const size_t r7 = (slot * P.n + row0) * 7, r6 = (slot * P.n + row0) * 6;
-            flush7(l_pos, static_cast<T*>(P.hist_pos) + r7, kRing);
-            flush6(l_vel, static_cast<T*>(P.hist_vel) + r6, kRing);
-            flush6(l_c, static_cast<T*>(P.hist_accel) + r6, kRing);
-            flush6(l_force, static_cast<T*>(P.hist_force) + r6, kRing);
+            if constexpr (!kDead) {      // (a program without Body state records its component columns only)
+                stage_pos(q0, p0);
+                stage6(l_vel, v0);
+                stage6(l_c, A_out);
+                stage6(l_force, F_out);
+                __syncthreads();
+                const size_t r7 = (slot * P.n + row0) * 7, r6 = (slot * P.n + row0) * 6;
+                flush7(l_pos, static_cast<T*>(P.hist_pos) + r7, kRing);
+                flush6(l_vel, static_cast<T*>(P.hist_vel) + r6, kRing);
+                flush6(l_c, static_cast<T*>(P.hist_accel) + r6, kRing);
+                flush6(l_force, static_cast<T*>(P.hist_force) + r6, kRing);
+            }
             if constexpr (PIPE::kHasModel)
                 if (active) PIPE::record(P, slot, row0 + t, regs);   // component columns of a generated program
             __syncthreads();
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(kWave) void sixdof_step_kernel(const StepParams P) 
             }
         }
     }
-    if (flushed) return;
+    if (flushed || kDead) return;
     if constexpr (INTEGRATOR != kNone) F_out = world_wrench<PIPE>(b.q, F);  // wrench of the last stage evaluated, world frame
     stage_pos(q0, p0);
     stage6(l_vel, v0);

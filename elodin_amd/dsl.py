@@ -1943,6 +1943,7 @@ class TracedSystem:
     def __init__(self, sys_: System, table: ColumnTable, partial: Sequence[str] = (), after_six_dof: bool = False):
         self.name, self.every, self.phase, self.also_at = sys_.__name__, sys_.every, sys_.phase, sys_.also_at
         self.reads_accel = False
+        self.body_free = bool(getattr(sys_, "body_free", False))     # the system declares it touches no Body column (checked by codegen)
         pos, vel, inertia = _body_symbols()
         kwargs = {}
 
@@ -2191,6 +2192,10 @@ class TracedProgram:
         self.pipe = TracedPipe(prog.effectors.effectors, table=self.table, partial=self.partial)
         self.post = [trace_item(s, True) for s in prog.post]
         self.fold_stages = [s for s in self.pre + self.post if isinstance(s, TracedFoldStage)]
+        # every system declares itself free of Body state and nothing else is in the pipe: a systems-only executor of this program
+        # may leave the Body slabs alone (NoModel::kBodyDead, csrc/effectors.hpp)
+        self.body_free = (bool(self.pre + self.post) and not self.fold_stages and not prog.effectors.effectors
+                          and all(getattr(s, "body_free", False) for s in self.pre + self.post))
         self.writes_inertia = any(s.writes_inertia for s in self.pre + self.post)
         # maps / folds that stood among the force effectors inside six_dof(sys=...) run in front of the force evaluation
         # (frontend.six_dof).  That is the reference's order unless an effector reads what a system BEHIND it in the pipe writes

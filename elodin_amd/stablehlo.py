@@ -2445,6 +2445,7 @@ def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = Non
         import inspect
         fn.__signature__ = inspect.Signature([inspect.Parameter(p, inspect.Parameter.KEYWORD_ONLY) for p in params])
         system_ = _dsl.system(fn, every=every, **widths)
+        system_.body_free = True          # every slot of the world is a column of the program: no Body column is read or written
         manifest = {"mode": "lane" if lane else "world", "rows": "entities" if lane else "worlds",
                     "entities_per_world": n_entities,
                     "columns": [{"column": c, "width": widths[c],

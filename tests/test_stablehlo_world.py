@@ -107,6 +107,29 @@ def test_an_executor_whose_rows_split_a_world_is_refused_before_the_device_is_to
         ea.HipExec(*body, integrator=L.INTEGRATOR_NONE, effectors=frozen, columns=cols)
 
 
+def test_a_whole_world_program_leaves_the_body_slabs_alone():
+    """Every slot of a whole-world tick is a column of the program; the executor's Body columns are stand-ins.  The program says so
+    (`body_free`), the generator checks it and the kernel then neither loads nor stores the Body slabs (NoModel::kBodyDead) — 456 B
+    per entity and tick at one tick per launch.  A systems-only program written against the API keeps the pass-through it had."""
+    from elodin_amd import codegen
+    text, slots = hb.three_body_world()
+    system, manifest = sh.world_system(text, slots, mode="lane")
+    tp = dsl.Program([system], dsl.Pipe([]), []).trace({c["column"]: c["width"] for c in manifest["columns"]})
+    assert tp.body_free and "static constexpr bool kBodyDead = true;" in codegen.generate_source(tp, "float64", 2)
+
+    @dsl.system(x=2)
+    def plain(x):
+        return {"x": x * 2.0}
+    assert "kBodyDead" not in codegen.generate_source(dsl.Program([plain], dsl.Pipe([]), []).trace({"x": 2}), "float64", 2)
+
+    @dsl.system(x=2)
+    def liar(x, pos):
+        return {"x": x + pos.linear()[0]}
+    liar.body_free = True
+    with pytest.raises(ValueError, match="declared free of Body state reads"):
+        codegen.generate_source(dsl.Program([liar], dsl.Pipe([]), []).trace({"x": 2}), "float64", 2)
+
+
 def test_ten_body_solar_system_world_tick_in_lane_mode_equals_the_oracle():
     """examples/n-body's world (sun + nine planets, the complete gravity graph: 90 edges, the softened fold of sim.py:349-361) as a
     whole-world module: too large for one lane per world (70-wide world_pos), ingested with one lane per entity, a world = 16
