@@ -1234,6 +1234,15 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
         if touched or wrote or any(s_.writes_inertia or s_.reads_accel for s_ in systems_):
             raise ValueError(f"a program declared free of Body state reads {sorted(touched)} / writes {sorted(wrote)}")
         body_dead = True
+    # bit 17 of the layout word: a one-kernel program whose code never looks at the absolute tick (no `tick` leaf, every system on
+    # every tick, no windows) — its launches are identical whatever StepParams::tick0 says, so batches of them may replay from a
+    # captured hipGraph like the hand-written kernel's (csrc/sixdof_capi.cpp graph_eligible)
+    tick_free = False
+    if is_prog and not staged and not tp.windows:
+        systems_ = tp.pre + tp.post
+        exprs_ = [e for s_ in systems_ for _, e in s_.assign] + (list(pipe_tp.outputs) if pipe_tp is not None else [])
+        tick_free = ("tick" not in dsl._leaves_of(exprs_) and all(s_.every == 1 and s_.also_at is None for s_ in systems_))
+    tick_free_bit = " | (1u << 17)" if tick_free else ""
     if not staged:
         structs = _emit_pipe_struct("PipeCustom", tp if is_prog else None, pipe_tp, tp.pre if is_prog else [], tp.post if is_prog else [],
                                     None, tp.pre_reads_accel if is_prog else False, n_aux, body_dead)
@@ -1312,7 +1321,7 @@ namespace sixdof {{
 }}  // namespace sixdof
 
 extern "C" unsigned sixdof_custom_abi() {{ return static_cast<unsigned>(sizeof(sixdof::StepParams)); }}
-extern "C" unsigned sixdof_custom_layout() {{ return {n_aux}u | ({n_model}u << 8) | ({1 if (is_prog and tp.writes_inertia) else 0}u << 16); }}
+extern "C" unsigned sixdof_custom_layout() {{ return {n_aux}u | ({n_model}u << 8) | ({1 if (is_prog and tp.writes_inertia) else 0}u << 16){tick_free_bit}; }}
 // row width of every program column, in slot order (bit 31: window column, kept in HBM; bit 30: built for the element-major
 // layout) — checked against the bound columns
 extern "C" void sixdof_custom_column_widths(unsigned* out) {{

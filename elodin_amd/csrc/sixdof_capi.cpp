@@ -105,6 +105,7 @@ struct sixdof_handle {
     CustomPairLaunchFn pair_launch = nullptr;
     std::vector<uint64_t> custom_aux;      // read-only [n,1..3] columns of a generated effector pipe
     std::vector<uint64_t> custom_model;    // read/write [n,1..16] component columns of a generated program
+    bool custom_tick_free = false;          // the generated program never looks at the absolute tick (layout bit 17): replayable
     // telemetry ring
     uint32_t hist_ring = 0;
     uint64_t hist_first_tick = 0;   // first tick (1-based count) recorded since the ring was enabled
@@ -1063,6 +1064,7 @@ int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t
     h->custom_launch = launch;
     h->custom_aux.assign(aux_ids, aux_ids + k_aux);
     h->custom_model.assign(aux_ids + k_aux, aux_ids + k_aux + k_model);
+    h->custom_tick_free = ((lay >> 17) & 1u) != 0;
     // row widths the generated code was built for (bit 31: a window column — memory-resident, any width, not recorded)
     h->custom_model_width.assign(k_model, 0u);
     if (col_widths && k_model) col_widths(h->custom_model_width.data());
@@ -1246,7 +1248,7 @@ static const uint32_t kGraphLong = [] { const char* e = std::getenv("SIXDOF_GRAP
 
 bool graph_eligible(const sixdof_handle* h) {
     return (h->desc.flags & SIXDOF_FLAG_USE_GRAPH) && !(h->desc.flags & SIXDOF_FLAG_TIME_EACH_LAUNCH) && !h->hist_ring &&
-           h->custom_model.empty() && h->model == 0 && !h->has_pair_op();
+           (h->custom_model.empty() || h->custom_tick_free) && h->model == 0 && !h->has_pair_op();
 }
 
 constexpr uint32_t kGraphMinLen = 4;   // shorter chains are launched eagerly (a replay costs ~10-16 us of host time)

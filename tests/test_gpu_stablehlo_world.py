@@ -413,3 +413,41 @@ def test_whole_world_ticks_build_in_float32_too(fast):
     hip.close()
     print(f"float32{' fast-math' if fast else ''}: 10-body lane mode, 48 ticks vs the f64 oracle {worst:.2e}; three-body world, 100 ticks vs G1 {e3:.2e}")
     assert worst <= 2e-5 and e3 <= 2e-4
+
+
+def test_a_program_that_never_looks_at_the_tick_replays_from_captured_graphs():
+    """Batches of identical one-tick launches of the hand-written kernel replay from captured hipGraphs (SIXDOF_FLAG_USE_GRAPH).  A
+    generated program qualifies when its code never looks at the absolute tick (layout bit 17: no `tick` leaf, no cadence, no
+    window) — a whole-world StableHLO tick carries its own tick COLUMN.  configs[1] as a whole-world module: 96 launches, all
+    replayed, the same bits as eager launches; a program that reads the kernel's tick stays eager."""
+    from tests.golden import hlo_world_builder as hb
+    n = 4096
+    text, slots = hb.independent_bodies_world(n)
+    system, manifest = sh.world_system(text, slots, mode="lane")
+    w = workloads.independent_bodies(n)
+
+    def run(use_graph):
+        cols = {"hlo_tick": np.zeros((n, 1)), "hlo_simulation_time_step": np.full((n, 1), workloads.DT_120HZ), "hlo_world_pos": w["world_pos"].copy(),
+                "hlo_world_vel": w["world_vel"].copy(), "hlo_world_accel": np.zeros((n, 6)), "hlo_force": np.zeros((n, 6)), "hlo_inertia": w["inertia"].copy(),
+                "hlo_torque": w["body_torque"].copy()}
+        hip = _exec(dsl.Program([system], dsl.Pipe([]), []), cols, n, use_graph=use_graph)
+        t = hip.invoke_batch(96)
+        hip.download()
+        out = {k: np.array(v) for k, v in hip._aux.items()}
+        hip.close()
+        return t, out
+    tg, og = run(True)
+    te, oe = run(False)
+    assert tg.graph_launches == 96 and te.graph_launches == 0 and tg.launches == te.launches == 96
+    for k in oe:
+        assert np.array_equal(og[k], oe[k]), k
+    assert np.all(og["hlo_tick"] == 96)
+
+    @dsl.system(x=1)
+    def counts(x, tick):
+        return {"x": x + tick}
+    hip = _exec(dsl.Program([counts], dsl.Pipe([]), []), {"x": np.zeros((n, 1))}, n, use_graph=True)
+    t = hip.invoke_batch(96)
+    hip.download()
+    assert t.graph_launches == 0 and np.all(hip._aux["x"] == 96 * 97 / 2)
+    hip.close()
