@@ -24,8 +24,8 @@ LAPACK FFI custom calls jax.numpy.linalg lowers to on CPU (dpotrf, dtrsm, dgetrf
 dgeqrf / dorgqr, dsyevd), chlo.{erf_inv, square, acos, asin, sinh, cosh, erfc, ...}.  INTEGERS have the machine's semantics: results of
 add / subtract / multiply / negate / shifts / convert wrap to the declared width for types of 32 bits or fewer, `ui64` is exact as two
 uint32 words (U64) — jax.random's threefry rounds and its bits -> mantissa -> bitcast construction run bit for bit — and `i64` is one
-node, exact below 2^53 (ticks, counters, indices, seeds; no wrap at 2^63).  `convolution` (N-D, strides, padding, dilations; one feature /
-batch group) is unrolled into multiply-adds and `rng` is the reference's deterministic fill.  Not read: fft (complex tensors), grouped
+node, exact below 2^53 (ticks, counters, indices, seeds; no wrap at 2^63).  `convolution` (N-D, strides, padding, dilations, feature
+groups) is unrolled into multiply-adds and `rng` is the reference's deterministic fill.  Not read: fft (complex tensors), batch-grouped
 convolutions, the remaining LAPACK calls — an unsupported op says which.
 
 Pinned on the reference's own tests: libs/cranelift-mlir/tests/ops.rs (198 inline modules with asserted outputs ->
@@ -777,8 +777,7 @@ class _Eval:
 
     def _convolution(self, lhs: Sym, rhs: Sym, text: str, rt: TensorType) -> Sym:
         """stablehlo.convolution over static shapes, unrolled into multiply-adds: N spatial dimensions, window strides, padding, lhs /
-        rhs dilation, any dimension_numbers `#stablehlo.conv<[b, 0, f]x[0, i, o]->[b, 0, f]>`; feature_group_count = batch_group_count
-        = 1.  A cross-correlation (the kernel is not flipped); a window position that falls into the padding or between the dilated
+        rhs dilation, feature groups, any dimension_numbers `#stablehlo.conv<[b, 0, f]x[0, i, o]->[b, 0, f]>`; batch_group_count = 1.  A cross-correlation (the kernel is not flipped); a window position that falls into the padding or between the dilated
         input samples contributes nothing.  (libs/cranelift-mlir/ARCHITECTURE.md:910; the reference's own known answer for it,
         ops.rs:4211-4230, is #[ignore]d there — it passes here.)"""
         # generic form: dimension_numbers = #stablehlo.conv<[b, 0, f]x[0, i, o]->[b, 0, f]>, window_strides = array<i64: 1>, padding = dense<...>;
@@ -788,10 +787,11 @@ class _Eval:
             raise NotImplementedError("stablehlo.convolution without [...]x[...]->[...] dimension numbers")
         ld, kd, od = ([t.strip() for t in g.split(",")] for g in m.groups())
         ns = len(ld) - 2
-        for key in ("feature_group_count", "batch_group_count"):
-            g = re.search(key + r"\s*=\s*(\d+)", text)
-            if g and int(g.group(1)) != 1:
-                raise NotImplementedError(f"stablehlo.convolution with {key} = {g.group(1)}")
+        g = re.search(r"batch_group_count\s*=\s*(\d+)", text)
+        if g and int(g.group(1)) != 1:
+            raise NotImplementedError(f"stablehlo.convolution with batch_group_count = {g.group(1)}")
+        g = re.search(r"feature_group_count\s*=\s*(\d+)", text)
+        groups = int(g.group(1)) if g else 1
         if re.search(r"window_reversal\s*=\s*(?:array<i1:[^>]*true|dense<[^>]*true)", text):
             raise NotImplementedError("stablehlo.convolution with window_reversal")
         win = re.search(r"window\s*=\s*\{(.*?)\}\s*(?:\{|:)", text, re.S)
@@ -815,8 +815,9 @@ class _Eval:
         ki, ko, ks = kd.index("i"), kd.index("o"), [kd.index(k) for k in sp]
         ob, of, os_ = od.index("b"), od.index("f"), [od.index(k) for k in sp]
         B, Cin, Cout = lhs.shape[lb], lhs.shape[lf], rhs.shape[ko]
-        if rhs.shape[ki] != Cin:
-            raise ValueError("stablehlo.convolution: the kernel's input-feature size differs from the operand's")
+        if rhs.shape[ki] * groups != Cin or Cout % groups:
+            raise ValueError("stablehlo.convolution: the kernel's input-feature size times feature_group_count differs from the operand's")
+        cin_g, cout_g = Cin // groups, Cout // groups        # feature groups (depthwise: groups = Cin): output feature o reads group o // cout_g
         in_sz = [lhs.shape[a] for a in ls]
         k_sz = [rhs.shape[a] for a in ks]
         out_sz = [rt.shape[a] for a in os_]
@@ -835,9 +836,9 @@ class _Eval:
                             src.append(p // ldil[d])
                         if not ok:
                             continue
-                        for c in range(Cin):
+                        for c in range(cin_g):
                             li = [0] * lhs.a.ndim
-                            li[lb], li[lf] = b, c
+                            li[lb], li[lf] = b, (o // cout_g) * cin_g + c
                             ri = [0] * rhs.a.ndim
                             ri[ki], ri[ko] = c, o
                             for d in range(ns):

@@ -302,8 +302,21 @@ module @module {{
 """
     got = dsl_numpy.trace_eval(lambda xp, a, kk: dsl.Vec(list(sh.trace(text2, [a, kk])[0].a.reshape(-1))), x.reshape(-1), k.reshape(-1))
     assert np.allclose(np.asarray(got).reshape(want.shape), want, rtol=1e-13, atol=1e-13)
-    with pytest.raises(NotImplementedError, match="feature_group_count"):
-        sh.trace(text.replace("feature_group_count = 1", "feature_group_count = 2"), [dsl.Vec([dsl.leaf(f"a{i}") for i in range(4)]), dsl.Vec([dsl.leaf("k0"), dsl.leaf("k1")])])
+    with pytest.raises(NotImplementedError, match="batch_group_count"):
+        sh.trace(text.replace("batch_group_count = 1", "batch_group_count = 2"), [dsl.Vec([dsl.leaf(f"a{i}") for i in range(4)]), dsl.Vec([dsl.leaf("k0"), dsl.leaf("k1")])])
+    # a depthwise convolution (feature_group_count = the number of channels): every channel with its own 3-tap kernel
+    xd, kd = rng.normal(size=(1, 6, 2)), rng.normal(size=(3, 1, 2))
+    text3 = """
+module @module {
+  func.func public @main(%arg0: tensor<1x6x2xf64>, %arg1: tensor<3x1x2xf64>) -> tensor<1x4x2xf64> {
+    %0 = stablehlo.convolution(%arg0, %arg1) dim_numbers = [b, 0, f]x[0, i, o]->[b, 0, f], window = {} {batch_group_count = 1 : i64, feature_group_count = 2 : i64} : (tensor<1x6x2xf64>, tensor<3x1x2xf64>) -> tensor<1x4x2xf64>
+    return %0 : tensor<1x4x2xf64>
+  }
+}
+"""
+    got = np.asarray(dsl_numpy.trace_eval(lambda xp, a, kk: dsl.Vec(list(sh.trace(text3, [a, kk])[0].a.reshape(-1))), xd.reshape(-1), kd.reshape(-1))).reshape(1, 4, 2)
+    want = np.stack([np.correlate(xd[0, :, c], kd[:, 0, c], mode="valid") for c in range(2)], axis=1)[None]
+    assert np.allclose(got, want, rtol=1e-13, atol=1e-13)
 
 
 def test_rng_is_the_references_deterministic_fill():
