@@ -619,27 +619,30 @@ def world_module_leg(device):
         ctext, cslots = hb.nbody_world(nb, 2.9591220828e-4, 1e-6)
         csys, cman = sh.world_system(ctext, cslots, mode="auto")
         S = cman["rows_per_world"]
-        worlds = 1024
-        rows = S * worlds
-        w = workloads.independent_bodies(rows)
-        def clay(a, fill):
-            o = np.tile(np.asarray(fill, dtype=np.float64), (rows, 1))
-            for i in range(nb):
-                o[i::S] = a[i]
-            return o
-        cols = {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), 0.5), "hlo_world_pos": clay(cpos, [0, 0, 0, 1.0, 0, 0, 0]),
-                "hlo_world_vel": clay(cvel, np.zeros(6)), "hlo_inertia": clay(cin, np.ones(7)), "hlo_world_accel": np.zeros((rows, 6)), "hlo_force": np.zeros((rows, 6))}
-        ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=L.INTEGRATOR_NONE, effectors=dsl.Program([csys], dsl.Pipe([]), []),
-                        columns=cols, ticks_per_launch=50, device=device)
-        ex.invoke_batch(50)
-        tm = ex.invoke_batch(500)
-        ex.close()
-        out["cluster_35_bodies_lane_mode"] = {"mode": cman["mode"], "rows_per_world": S, "entities_per_world": nb, "worlds": worlds, "rows": rows, "ticks": 500,
-                                              "us_per_tick": round(tm.kernel_device_ms * 2, 3), "world_steps_per_s": round(worlds * 500 / (tm.kernel_device_ms * 1e-3), 1),
-                                              "pair_evals_per_s": round(4.0 * nb * (nb - 1) * worlds * 500 / (tm.kernel_device_ms * 1e-3), 1),
-                                              "exchange_reads_per_tick_in_the_program": cman.get("exchange_reads"),
-                                              "loops": "four 34-trip counted loops (lane_read_dyn), not unrolled",
-                                              "roofline": valu_roofline("cluster_35_bodies_lane_mode", rows, 500, tm.kernel_device_ms * 1e-3, WORLD_VALU_FILE)}
+
+        def cluster(worlds):
+            rows = S * worlds
+            w = workloads.independent_bodies(rows)
+            def clay(a, fill):
+                o = np.tile(np.asarray(fill, dtype=np.float64), (rows, 1))
+                for i in range(nb):
+                    o[i::S] = a[i]
+                return o
+            cols = {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), 0.5), "hlo_world_pos": clay(cpos, [0, 0, 0, 1.0, 0, 0, 0]),
+                    "hlo_world_vel": clay(cvel, np.zeros(6)), "hlo_inertia": clay(cin, np.ones(7)), "hlo_world_accel": np.zeros((rows, 6)), "hlo_force": np.zeros((rows, 6))}
+            ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=L.INTEGRATOR_NONE, effectors=dsl.Program([csys], dsl.Pipe([]), []),
+                            columns=cols, ticks_per_launch=50, device=device)
+            ex.invoke_batch(50)
+            tm = ex.invoke_batch(500)
+            ex.close()
+            return {"mode": cman["mode"], "rows_per_world": S, "entities_per_world": nb, "worlds": worlds, "rows": rows, "ticks": 500,
+                    "us_per_tick": round(tm.kernel_device_ms * 2, 3), "world_steps_per_s": round(worlds * 500 / (tm.kernel_device_ms * 1e-3), 1),
+                    "pair_evals_per_s": round(4.0 * nb * (nb - 1) * worlds * 500 / (tm.kernel_device_ms * 1e-3), 1),
+                    "exchange_reads_per_tick_in_the_program": cman.get("exchange_reads"),
+                    "loops": "four 34-trip counted loops (lane_read_dyn), not unrolled",
+                    "roofline": valu_roofline("cluster_35_bodies_lane_mode", rows, 500, tm.kernel_device_ms * 1e-3, WORLD_VALU_FILE)}
+        out["cluster_35_bodies_lane_mode"] = cluster(1024)              # one wave per SIMD
+        out["cluster_35_bodies_lane_mode_4096_worlds"] = cluster(4096)  # four (254 registers: two resident at a time hide each other's trip-opening latency)
     except Exception as e:  # noqa: BLE001
         out["cluster_35_bodies_lane_mode"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     n = 65536
