@@ -12,12 +12,12 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # telemetry_commit is left out of the traced run: its launches share the device with D2H copies and would blur the
 # per-kernel averages of the timed region
-CMD="python $R/bench.py --steps 2048 --warmup 128 --no-cpu-baseline --no-campaigns --skip-legs telemetry_commit,history_stream,monte_carlo_example,world_module,build"
+CMD="python $R/bench.py --steps 2048 --warmup 128 --no-cpu-baseline --extras --extras-out $OUT/bench_extras_trace.json --skip-legs telemetry_commit,history_stream,monte_carlo_example,world_module,build"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.err
 # PMC passes: only the timed region's kernel (1 tick per launch), no graph replay (counters are attributed per
 # dispatch), fewer steps; once at the bench size and once at 4,194,304 bodies (the roofline_hbm leg's size)
 for SIZE in 65536 4194304; do
-  CMDP="python $R/bench.py --entities $SIZE --steps 32 --warmup 4 --no-cpu-baseline --no-extras --no-graph"
+  CMDP="python $R/bench.py --entities $SIZE --steps 32 --warmup 4 --no-cpu-baseline --no-graph"
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$SIZE -o bench -- $CMDP > $OUT/bench_fetch_$SIZE.json 2> $OUT/fetch_$SIZE.err
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$SIZE -o bench -- $CMDP > $OUT/bench_write_$SIZE.json 2> $OUT/write_$SIZE.err
 done

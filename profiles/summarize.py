@@ -26,7 +26,7 @@ for r in rows(f"{out}/trace/**/*kernel_trace.csv"):
     stats[(r["Kernel_Name"], grid)].append(dur)
 
 lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
-         "Command: `python bench.py --steps 2048 --warmup 128 --no-cpu-baseline --no-campaigns --skip-legs telemetry_commit,history_stream,monte_carlo_example` (profiles/collect.sh).",
+         "Command: `python bench.py --steps 2048 --warmup 128 --no-cpu-baseline --extras --skip-legs telemetry_commit,history_stream,monte_carlo_example,world_module,build` (profiles/collect.sh).",
          "Durations in microseconds; `grid` = total work-items (= entities for the step kernel). The 65536-entity",
          "step kernel appears with ticks_per_launch = 1 (timed region + warmup), = 64 (`fused`) and = 64 with the",
          "telemetry ring (`recording`): rows are split by duration.  PipeStatic<2, 3> = gravity | body_torque;",

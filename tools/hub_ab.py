@@ -3,7 +3,7 @@ edges each) with 0 / 1 / 8 / 64 all-to-everyone hubs, with the hub path and with
 Each case in its own process (the knob is read when the edges are set)."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CHILD = "import sys, json; sys.path.insert(0, %r); import bench; print(json.dumps(bench.sparse_edges_leg(0, int(sys.argv[1]))))" % ROOT
+CHILD = "import sys, json; sys.path.insert(0, %r); from tools import bench_legs as bench; print(json.dumps(bench.sparse_edges_leg(0, int(sys.argv[1]))))" % ROOT
 for hubs in (0, 1, 8, 64):
     row = []
     for no in ("0", "1"):
