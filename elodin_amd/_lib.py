@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ["SIXDOF_LIBRARY"]) if os.environ.get("SIXDOF_LIBRARY"
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_COMPONENT_NOT_FOUND, ERR_VALUE_SIZE_MISMATCH = -1, -2, -3
 ERR_BACKEND, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ENTITY_MISMATCH, ERR_TIME_TRAVEL = -4, -5, -6, -7, -8
+ERR_OUT_OF_MEMORY, ERR_INTERNAL = -9, -10      # the exception barrier of the C ABI (csrc/abi_guard.hpp)
 
 RK4, SEMI_IMPLICIT, INTEGRATOR_NONE = 0, 1, 2
 F64, F32 = 0, 1

@@ -6,10 +6,34 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "../../include/sixdof_hip.h"
+
+// Allocation-failure injection: the program's own operator new throws std::bad_alloc on the k-th allocation from now
+// (g_fail_in = k >= 0), like a host that has run out of memory.  Nothing may unwind out of an entry point (the callers are
+// `extern "C"` frames of another language, csrc/abi_guard.hpp): the call returns SIXDOF_ERR_OUT_OF_MEMORY with a message.
+static long g_fail_in = -1, g_thrown = 0;
+void* operator new(std::size_t n) {
+    if (g_fail_in >= 0 && g_fail_in-- == 0) {
+        g_thrown++;
+        throw std::bad_alloc();
+    }
+    if (void* p = std::malloc(n ? n : 1)) return p;
+    throw std::bad_alloc();
+}
+void* operator new[](std::size_t n) { return operator new(n); }
+void* operator new(std::size_t n, const std::nothrow_t&) noexcept {
+    if (g_fail_in >= 0 && g_fail_in-- == 0) return nullptr;
+    return std::malloc(n ? n : 1);
+}
+void operator delete(void* p) noexcept { std::free(p); }
+void operator delete[](void* p) noexcept { std::free(p); }
+void operator delete(void* p, std::size_t) noexcept { std::free(p); }
+void operator delete[](void* p, std::size_t) noexcept { std::free(p); }
 
 #define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "asan_host_test: CHECK failed at line %d: %s\n", __LINE__, #c); return 1; } } while (0)
 
@@ -96,6 +120,91 @@ int main() {
     sixdof_sink_truncate(s);
     CHECK(sixdof_sink_sample_count(s, pids[0]) == 0 && sixdof_sink_push(s, pids[0], 1, out, 56) == SIXDOF_OK);
     sixdof_sink_destroy(s);
+    // ---- the exception barrier: every allocation of every allocating entry point fails once ----
+    {
+        long oom = 0, fine = 0;
+        const double row[7] = {0, 0, 0, 1, 1, 2, 3};
+        for (long k = 0; k < 24; k++) {              // sixdof_world_create: new world + two global columns
+            g_fail_in = k;
+            sixdof_world* x = sixdof_world_create();
+            g_fail_in = -1;
+            if (!x) { oom++; continue; }
+            CHECK(sixdof_world_entity_len(x) == 1 && sixdof_world_components(x, nullptr, 0) == 2);
+            sixdof_world_destroy(x);
+            fine++;
+        }
+        CHECK(oom > 0 && fine > 0);
+        sixdof_world* x = sixdof_world_create();
+        CHECK(x);
+        const uint64_t e1 = sixdof_world_spawn(x);
+        long first_ok = -1;
+        for (long k = 0; k < 24 && first_ok < 0; k++) {      // a NEW component: name string, map node, row buffer, id vector
+            const size_t before = sixdof_world_components(x, nullptr, 0);
+            g_fail_in = k;
+            const int rc = sixdof_world_insert(x, e1, "world_pos", SIXDOF_PRIM_F64, d7, 1, row, sizeof(row));
+            g_fail_in = -1;
+            if (rc == SIXDOF_OK) { first_ok = k; break; }
+            CHECK(rc == SIXDOF_ERR_OUT_OF_MEMORY && std::strstr(sixdof_world_last_error(x), "out of memory"));
+            CHECK(sixdof_world_components(x, nullptr, 0) == before);               // no half-made column stays behind
+        }
+        CHECK(first_ok > 0);                                                       // it did fail a few times first
+        sixdof_column cc;
+        CHECK(sixdof_world_column(x, sixdof_component_id("world_pos"), &cc) == SIXDOF_OK && cc.n_rows == 1 && cc.entity_ids[0] == e1);
+        for (int i = 0; i < 200; i++) {                                             // growth of an EXISTING column under failures
+            const uint64_t e = sixdof_world_spawn(x);
+            g_fail_in = i % 3;
+            int rc = sixdof_world_insert(x, e, "world_pos", SIXDOF_PRIM_F64, d7, 1, row, sizeof(row));
+            g_fail_in = -1;
+            CHECK(rc == SIXDOF_OK || rc == SIXDOF_ERR_OUT_OF_MEMORY);
+            if (rc != SIXDOF_OK) CHECK(sixdof_world_insert(x, e, "world_pos", SIXDOF_PRIM_F64, d7, 1, row, sizeof(row)) == SIXDOF_OK);
+        }
+        CHECK(sixdof_world_column(x, sixdof_component_id("world_pos"), &cc) == SIXDOF_OK && cc.n_rows == 201);      // rows and ids in step
+        g_fail_in = 0;
+        CHECK(sixdof_world_set_rates(x, -1.0, 0.0) != SIXDOF_OK);                  // the error text itself cannot be allocated: still a status
+        g_fail_in = -1;
+        sixdof_world_destroy(x);
+
+        g_fail_in = 0;
+        CHECK(sixdof_sink_create() == nullptr);                                     // nothrow new: a null sink, not an exception
+        g_fail_in = -1;
+        sixdof_sink* z = sixdof_sink_create();
+        CHECK(z);
+        const uint64_t pid = sixdof_pair_id("a_rather_long_entity_name_that_needs_the_heap", "world_pos");
+        g_fail_in = 0;
+        CHECK(sixdof_pair_id("a_rather_long_entity_name_that_needs_the_heap", "world_pos") == 0);        // no status to return: the neutral value
+        g_fail_in = -1;
+        long reg_ok = -1;
+        for (long k = 0; k < 16 && reg_ok < 0; k++) {
+            g_fail_in = k;
+            const int rc = sixdof_sink_register(z, pid, 56, "a_rather_long_entity_name_that_needs_the_heap.world_pos");
+            g_fail_in = -1;
+            if (rc == SIXDOF_OK) { reg_ok = k; break; }
+            CHECK(rc == SIXDOF_ERR_OUT_OF_MEMORY && std::strstr(sixdof_sink_last_error(z), "out of memory"));
+            CHECK(sixdof_sink_pairs(z, nullptr, 0) == 0);
+        }
+        CHECK(reg_ok > 0);
+        long pushed = 0;
+        for (int t = 0; t < 300; t++) {
+            g_fail_in = t % 4 == 0 ? 0 : -1;
+            const int rc = sixdof_sink_push(z, pid, 1000 * (t + 1), row, 56);
+            g_fail_in = -1;
+            CHECK(rc == SIXDOF_OK || rc == SIXDOF_ERR_OUT_OF_MEMORY);
+            pushed += rc == SIXDOF_OK;
+            CHECK(sixdof_sink_sample_count(z, pid) == static_cast<uint64_t>(pushed));      // index and data never out of step
+        }
+        CHECK(pushed > 200 && pushed <= 300);
+        const int64_t* tv = nullptr;
+        const uint8_t* dv = nullptr;
+        uint64_t nn = 0;
+        uint32_t ebb = 0;
+        CHECK(sixdof_sink_series(z, pid, &tv, &dv, &nn, &ebb) == SIXDOF_OK && nn == static_cast<uint64_t>(pushed));
+        double lastrow[7];
+        std::memcpy(lastrow, dv + (nn - 1) * 56, 56);
+        CHECK(lastrow[6] == 3.0);
+        sixdof_sink_destroy(z);
+        CHECK(g_thrown > 20);
+        std::printf("asan_host_test: exception barrier: %ld injected allocation failures came back as statuses\n", g_thrown);
+    }
     std::printf("asan_host_test: ok\n");
     return 0;
 }

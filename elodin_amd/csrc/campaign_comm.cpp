@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/sixdof_hip.h"
+#include "abi_guard.hpp"
 
 namespace {
 
@@ -99,6 +100,8 @@ struct sixdof_comm {
     }
 };
 
+static std::string* err_of(const sixdof_comm* c) { return c ? &const_cast<sixdof_comm*>(c)->error : &g_comm_error; }
+
 extern "C" {
 
 void sixdof_shard_range(uint64_t n_rows, int world, int rank, uint64_t* lo, uint64_t* hi) {
@@ -112,7 +115,7 @@ void sixdof_shard_range(uint64_t n_rows, int world, int rank, uint64_t* lo, uint
     if (hi) *hi = l + base + (r < extra ? 1 : 0);
 }
 
-int sixdof_comm_unique_id(uint8_t id[SIXDOF_COMM_ID_BYTES]) {
+int sixdof_comm_unique_id(uint8_t id[SIXDOF_COMM_ID_BYTES]) try {
     if (!id) return SIXDOF_ERR_INVALID_ARGUMENT;
     Rccl& r = rccl();
     if (!r.error.empty()) {
@@ -128,9 +131,9 @@ int sixdof_comm_unique_id(uint8_t id[SIXDOF_COMM_ID_BYTES]) {
     static_assert(sizeof(u) == SIXDOF_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
     std::memcpy(id, &u, sizeof(u));
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(&g_comm_error)
 
-int sixdof_comm_init(sixdof_comm** out, const uint8_t id[SIXDOF_COMM_ID_BYTES], int world, int rank, int device_ordinal) {
+int sixdof_comm_init(sixdof_comm** out, const uint8_t id[SIXDOF_COMM_ID_BYTES], int world, int rank, int device_ordinal) try {
     if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id)) return SIXDOF_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     auto* c = new sixdof_comm();
@@ -180,20 +183,20 @@ int sixdof_comm_init(sixdof_comm** out, const uint8_t id[SIXDOF_COMM_ID_BYTES], 
     }
     *out = c;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(&g_comm_error)
 
-void sixdof_comm_destroy(sixdof_comm* c) {
+void sixdof_comm_destroy(sixdof_comm* c) try {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->comm) rccl().comm_destroy(c->comm);
     if (c->d_buf) hipFree(c->d_buf);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
-}
+} SIXDOF_ABI_CATCH_VALUE(err_of(c), )
 
 const char* sixdof_comm_last_error(const sixdof_comm* c) { return c ? c->error.c_str() : g_comm_error.c_str(); }
 
-int sixdof_campaign_broadcast(sixdof_comm* c, void* table, uint64_t n_bytes, int root) {
+int sixdof_campaign_broadcast(sixdof_comm* c, void* table, uint64_t n_bytes, int root) try {
     if (!c || (!table && n_bytes) || root < 0 || root >= c->world) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (c->comm == nullptr || n_bytes == 0) return SIXDOF_OK;   // single rank without a communicator: nothing to move
     hipError_t e = hipSetDevice(c->device);
@@ -208,10 +211,10 @@ int sixdof_campaign_broadcast(sixdof_comm* c, void* table, uint64_t n_bytes, int
         return c->hip(e, "hipMemcpyAsync (D2H)");
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip(e, "hipStreamSynchronize");
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(c))
 
 int sixdof_campaign_gather(sixdof_comm* c, const double* local_rows, uint64_t n_local, uint64_t width, double* all_rows,
-                           uint64_t n_total) {
+                           uint64_t n_total) try {
     if (!c || !all_rows || (!local_rows && n_local)) return SIXDOF_ERR_INVALID_ARGUMENT;
     uint64_t lo = 0, hi = 0;
     sixdof_shard_range(n_total, c->world, c->rank, &lo, &hi);
@@ -248,6 +251,6 @@ int sixdof_campaign_gather(sixdof_comm* c, const double* local_rows, uint64_t n_
             std::memcpy(all_rows + l * width, host.data() + static_cast<size_t>(r) * pad_rows * width, (h - l) * width * sizeof(double));
     }
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(c))
 
 }  // extern "C"

@@ -27,6 +27,7 @@
 #include "../../include/sixdof_hip.h"
 #include "../../include/sixdof_apollo.h"
 #include "kernels.hpp"
+#include "abi_guard.hpp"
 
 using namespace sixdof;
 
@@ -165,6 +166,9 @@ struct sixdof_handle {
     }
 };
 
+// where the exception barrier (abi_guard.hpp) leaves its message: the handle's error, or the creation error without a handle
+std::string* err_of(const sixdof_handle* h) { return h ? &const_cast<sixdof_handle*>(h)->err : &g_create_error; }
+
 #define HIP_TRY(h, call)                                      \
     do {                                                      \
         hipError_t e_ = (call);                               \
@@ -207,17 +211,17 @@ uint32_t sixdof_abi_version(void) { return SIXDOF_ABI_VERSION; }
 
 // sixdof_component_id / sixdof_quantize_time_step: pure host code, in world.cpp (so the host layer links without HIP: `make asan`)
 
-int sixdof_device_count(void) {
+int sixdof_device_count(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
-}
+} SIXDOF_ABI_CATCH(&g_create_error)
 
 const char* sixdof_last_error(const sixdof_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 void sixdof_destroy(sixdof_handle* h);
 
-int sixdof_create(const sixdof_desc* d, sixdof_handle** out) {
+int sixdof_create(const sixdof_desc* d, sixdof_handle** out) try {
     if (!d || !out) {
         g_create_error = "sixdof_create: null argument";
         return SIXDOF_ERR_INVALID_ARGUMENT;
@@ -271,9 +275,9 @@ int sixdof_create(const sixdof_desc* d, sixdof_handle** out) {
     }
     *out = h;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(&g_create_error)
 
-void sixdof_destroy(sixdof_handle* h) {
+void sixdof_destroy(sixdof_handle* h) try {
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
@@ -306,9 +310,9 @@ void sixdof_destroy(sixdof_handle* h) {
     if (h->evp1) hipEventDestroy(h->evp1);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
-}
+} SIXDOF_ABI_CATCH_VALUE(err_of(h), )
 
-int sixdof_bind_columns(sixdof_handle* h, const sixdof_column* cols, size_t n_cols) {
+int sixdof_bind_columns(sixdof_handle* h, const sixdof_column* cols, size_t n_cols) try {
     if (!h || (!cols && n_cols)) return SIXDOF_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     h->drop_graph();
@@ -385,9 +389,9 @@ int sixdof_bind_columns(sixdof_handle* h, const sixdof_column* cols, size_t n_co
     h->bound = true;
     h->resident = false;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_bind_world(sixdof_handle* h, sixdof_world* w) {
+int sixdof_bind_world(sixdof_handle* h, sixdof_world* w) try {
     if (!h || !w) return SIXDOF_ERR_INVALID_ARGUMENT;
     std::vector<uint64_t> ids(sixdof_world_components(w, nullptr, 0));
     sixdof_world_components(w, ids.data(), ids.size());
@@ -402,9 +406,9 @@ int sixdof_bind_world(sixdof_handle* h, sixdof_world* w) {
     h->desc.simulation_time_step = sixdof_world_time_step(w);
     h->tick = sixdof_world_tick(w);
     return sixdof_bind_columns(h, cols.data(), cols.size());
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_set_effectors(sixdof_handle* h, const sixdof_effector_op* ops, size_t n_ops) {
+int sixdof_set_effectors(sixdof_handle* h, const sixdof_effector_op* ops, size_t n_ops) try {
     if (!h || (!ops && n_ops)) return SIXDOF_ERR_INVALID_ARGUMENT;
     size_t n_entity_ops = 0, n_pair = 0;
     for (size_t i = 0; i < n_ops; i++) {
@@ -425,9 +429,9 @@ int sixdof_set_effectors(sixdof_handle* h, const sixdof_effector_op* ops, size_t
     h->ops.assign(ops, ops + n_ops);
     h->drop_graph();
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_set_edges(sixdof_handle* h, const uint64_t* from_ids, const uint64_t* to_ids, size_t n_edges) {
+int sixdof_set_edges(sixdof_handle* h, const uint64_t* from_ids, const uint64_t* to_ids, size_t n_edges) try {
     if (!h || ((!from_ids || !to_ids) && n_edges)) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "set_edges: bind Body columns first");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -491,9 +495,9 @@ int sixdof_set_edges(sixdof_handle* h, const uint64_t* from_ids, const uint64_t*
     h->csr_dst.swap(cdst);
     h->drop_graph();
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_get_join_rows(const sixdof_handle* h, uint64_t component_id, uint32_t* rows, size_t cap, size_t* n_out) {
+int sixdof_get_join_rows(const sixdof_handle* h, uint64_t component_id, uint32_t* rows, size_t cap, size_t* n_out) try {
     if (!h || !n_out) return SIXDOF_ERR_INVALID_ARGUMENT;
     const Column* c = h->col(component_id);
     if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "get_join_rows: unknown component");
@@ -504,20 +508,20 @@ int sixdof_get_join_rows(const sixdof_handle* h, uint64_t component_id, uint32_t
     if (!c->joined) return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "get_join_rows: column is not part of the join yet");
     for (size_t j = 0; j < m; j++) rows[j] = c->rows.empty() ? static_cast<uint32_t>(j) : c->rows[j];
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_get_edge_rows(const sixdof_handle* h, uint32_t* src_rows, uint32_t* dst_rows, size_t cap, size_t* n_out) {
+int sixdof_get_edge_rows(const sixdof_handle* h, uint32_t* src_rows, uint32_t* dst_rows, size_t cap, size_t* n_out) try {
     if (!h || !n_out) return SIXDOF_ERR_INVALID_ARGUMENT;
     *n_out = h->edge_src.size();
     if (cap < h->edge_src.size()) return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, "get_edge_rows: buffer too small");
     if (src_rows) std::memcpy(src_rows, h->edge_src.data(), h->edge_src.size() * sizeof(uint32_t));
     if (dst_rows) std::memcpy(dst_rows, h->edge_dst.data(), h->edge_dst.size() * sizeof(uint32_t));
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
 int prepare_graph(sixdof_handle* h);
 
-int sixdof_upload(sixdof_handle* h) {
+int sixdof_upload(sixdof_handle* h) try {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "upload: no columns bound");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -536,7 +540,7 @@ int sixdof_upload(sixdof_handle* h) {
     h->resident = true;
     h->accel_is_host_data = true;
     return prepare_graph(h);   // SIXDOF_FLAG_USE_GRAPH: capture now, not inside the first long step call
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
 // joined rows -> their places in the full column (before any D2H of that column)
 static int scatter_back(sixdof_handle* h, Column* c) {
@@ -548,7 +552,7 @@ static int scatter_back(sixdof_handle* h, Column* c) {
     return SIXDOF_OK;
 }
 
-int sixdof_download(sixdof_handle* h, uint32_t mask) {
+int sixdof_download(sixdof_handle* h, uint32_t mask) try {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "download: no columns bound");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -569,9 +573,9 @@ int sixdof_download(sixdof_handle* h, uint32_t mask) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->last.d2h_download_ms = now_ms() - t_dn;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_download_async(sixdof_handle* h, uint32_t mask) {
+int sixdof_download_async(sixdof_handle* h, uint32_t mask) try {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "download_async: no columns bound");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -610,9 +614,9 @@ int sixdof_download_async(sixdof_handle* h, uint32_t mask) {
     HIP_TRY(h, hipEventRecord(h->ev_copied, h->copy_stream));
     h->copy_pending = true;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_download_wait(sixdof_handle* h) {
+int sixdof_download_wait(sixdof_handle* h) try {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->copy_pending) return SIXDOF_OK;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -620,9 +624,9 @@ int sixdof_download_wait(sixdof_handle* h) {
     HIP_TRY(h, hipEventSynchronize(h->ev_copied));
     h->last.d2h_download_ms = now_ms() - t0;     // the part of the copy the host actually waited for
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_sync(sixdof_handle* h) {
+int sixdof_sync(sixdof_handle* h) try {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -636,37 +640,37 @@ int sixdof_sync(sixdof_handle* h) {
     for (void* p : h->pinned_user) (void)hipHostUnregister(p);
     h->pinned_user.clear();
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_get_tick(const sixdof_handle* h, uint64_t* tick) {
+int sixdof_get_tick(const sixdof_handle* h, uint64_t* tick) try {
     if (!h || !tick) return SIXDOF_ERR_INVALID_ARGUMENT;
     *tick = h->tick;
     return SIXDOF_OK;
-}
-int sixdof_set_tick(sixdof_handle* h, uint64_t tick) {
+} SIXDOF_ABI_CATCH(err_of(h))
+int sixdof_set_tick(sixdof_handle* h, uint64_t tick) try {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     h->tick = tick;
     h->hist_first_tick = tick + 1;
     return SIXDOF_OK;
-}
-int sixdof_set_ticks_per_launch(sixdof_handle* h, uint32_t k) {
+} SIXDOF_ABI_CATCH(err_of(h))
+int sixdof_set_ticks_per_launch(sixdof_handle* h, uint32_t k) try {
     if (!h || k == 0) return SIXDOF_ERR_INVALID_ARGUMENT;
     h->desc.ticks_per_launch = k;
     h->drop_graph();
     return h->resident ? prepare_graph(h) : SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_set_flags(sixdof_handle* h, uint32_t flags) {
+int sixdof_set_flags(sixdof_handle* h, uint32_t flags) try {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     h->desc.flags = flags;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-void* sixdof_device_column(sixdof_handle* h, uint64_t component_id) {
+void* sixdof_device_column(sixdof_handle* h, uint64_t component_id) try {
     if (!h) return nullptr;
     Column* c = h->col(component_id);
     return c ? (c->live ? c->live : c->dev) : nullptr;
-}
+} SIXDOF_ABI_CATCH_VALUE(err_of(h), nullptr)
 void* sixdof_stream(sixdof_handle* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
 
 }  // extern "C"
@@ -984,7 +988,7 @@ int step_apollo(sixdof_handle* h, uint64_t n_ticks, uint64_t* launches) {
 
 extern "C" {
 
-int sixdof_set_model_apollo(sixdof_handle* h, const sixdof_apollo_tables* t) {
+int sixdof_set_model_apollo(sixdof_handle* h, const sixdof_apollo_tables* t) try {
     if (!h || !t || t->n < 2 || !t->time_s || !t->altitude_m || !t->descent_rate_mps || !t->pitch_deg ||
         !t->horizontal_speed_mps || !t->downrange_m)
         return SIXDOF_ERR_INVALID_ARGUMENT;
@@ -1001,15 +1005,15 @@ int sixdof_set_model_apollo(sixdof_handle* h, const sixdof_apollo_tables* t) {
     h->ap_max_ticks = t->max_ticks;
     h->model = 1;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_last_timings(const sixdof_handle* h, sixdof_timings* out) {
+int sixdof_last_timings(const sixdof_handle* h, sixdof_timings* out) try {
     if (!h || !out) return SIXDOF_ERR_INVALID_ARGUMENT;
     *out = h->last;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_count_nonfinite(sixdof_handle* h, uint64_t* count, uint8_t* row_flags) {
+int sixdof_count_nonfinite(sixdof_handle* h, uint64_t* count, uint8_t* row_flags) try {
     if (!h || !count) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "count_nonfinite: no columns bound");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1030,9 +1034,9 @@ int sixdof_count_nonfinite(sixdof_handle* h, uint64_t* count, uint8_t* row_flags
     if (e != hipSuccess) return h->hip_fail(e, "count_nonfinite");
     *count = host_count;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t* aux_ids, size_t n_aux) {
+int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t* aux_ids, size_t n_aux) try {
     if (!h || !so_path || (!aux_ids && n_aux)) return SIXDOF_ERR_INVALID_ARGUMENT;
     void* dl = dlopen(so_path, RTLD_NOW | RTLD_LOCAL);
     if (!dl) return h->fail(SIXDOF_ERR_BACKEND, std::string("set_custom_pipe: dlopen failed: ") + dlerror());
@@ -1071,9 +1075,9 @@ int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t
     h->ops.clear();
     h->drop_graph();
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_set_custom_pair(sixdof_handle* h, const char* so_path) {
+int sixdof_set_custom_pair(sixdof_handle* h, const char* so_path) try {
     if (!h || !so_path) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (h->custom_launch) return h->fail(SIXDOF_ERR_UNSUPPORTED, "set_custom_pair: a generated per-entity pipe is installed; pair folds combine with built-in ops only");
     void* dl = dlopen(so_path, RTLD_NOW | RTLD_LOCAL);
@@ -1093,9 +1097,9 @@ int sixdof_set_custom_pair(sixdof_handle* h, const char* so_path) {
     h->ops.push_back(op);
     h->drop_graph();
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_set_history(sixdof_handle* h, uint32_t ring_ticks) {
+int sixdof_set_history(sixdof_handle* h, uint32_t ring_ticks) try {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "set_history: bind Body columns first");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1137,9 +1141,9 @@ int sixdof_set_history(sixdof_handle* h, uint32_t ring_ticks) {
     h->hist_ring = ring_ticks;
     h->hist_first_tick = h->tick + 1;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_history_read(sixdof_handle* h, uint64_t component_id, uint64_t tick, void* host_dst) {
+int sixdof_history_read(sixdof_handle* h, uint64_t component_id, uint64_t tick, void* host_dst) try {
     if (!h || !host_dst) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->hist_ring) return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "history_read: no history ring (sixdof_set_history)");
     int k = -1;
@@ -1166,9 +1170,9 @@ int sixdof_history_read(sixdof_handle* h, uint64_t component_id, uint64_t tick, 
     if (block) HIP_TRY(h, hipMemcpyAsync(host_dst, static_cast<const char*>(ring_base) + slot * block, block, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_history_stream(sixdof_handle* h, uint64_t first_tick, uint64_t n_ticks, void* const host_dst[4]) {
+int sixdof_history_stream(sixdof_handle* h, uint64_t first_tick, uint64_t n_ticks, void* const host_dst[4]) try {
     if (!h || !host_dst) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->hist_ring) return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "history_stream: no history ring (sixdof_set_history)");
     if (n_ticks == 0) return SIXDOF_OK;
@@ -1206,9 +1210,9 @@ int sixdof_history_stream(sixdof_handle* h, uint64_t first_tick, uint64_t n_tick
     h->stream_lo = first_tick;
     h->stream_hi = last;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_download_column(sixdof_handle* h, uint64_t component_id) {
+int sixdof_download_column(sixdof_handle* h, uint64_t component_id) try {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     Column* c = h->col(component_id);
     if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "download_column: unknown component");
@@ -1218,11 +1222,11 @@ int sixdof_download_column(sixdof_handle* h, uint64_t component_id) {
     if (c->bytes) HIP_TRY(h, hipMemcpyAsync(c->host, c->dev, c->bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
 // H2D of ONE bound column: an external write to a component (StepContext.write_component, copy_db_to_world's per-component copy,
 // impeller2_server.rs:320-362) reaches the device without re-uploading — and so clobbering — the columns the host never downloaded.
-int sixdof_upload_column(sixdof_handle* h, uint64_t component_id) {
+int sixdof_upload_column(sixdof_handle* h, uint64_t component_id) try {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     Column* c = h->col(component_id);
     if (!c) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "upload_column: unknown component");
@@ -1237,7 +1241,7 @@ int sixdof_upload_column(sixdof_handle* h, uint64_t component_id) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (component_id == h->id_accel) h->accel_is_host_data = true;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
 // Launches per replayed chain.  A long chain amortises the gap between two replays (4,096 launches: 4.96 -> 4.83 us each with
 // 128-launch chains) but starts later (100 launches as one chain: 8 % slower than 32 + 32 + 32 + 4), so a batch OPENS with a
@@ -1323,7 +1327,7 @@ int prepare_graph(sixdof_handle* h) {
     return rc;
 }
 
-int sixdof_prepare_step(sixdof_handle* h, uint64_t n_ticks) {
+int sixdof_prepare_step(sixdof_handle* h, uint64_t n_ticks) try {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->bound || !h->resident) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "prepare_step: upload the columns first");
     if (!graph_eligible(h)) return SIXDOF_OK;
@@ -1354,9 +1358,9 @@ int sixdof_prepare_step(sixdof_handle* h, uint64_t n_ticks) {
     if (h->accel_is_host_data && h->desc.integrator == SIXDOF_INTEGRATOR_RK4 && full > 0 && (rc = prepare(full - 1)) != SIXDOF_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
+int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) try {
     if (!h) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!h->bound) return h->fail(SIXDOF_ERR_COMPONENT_NOT_FOUND, "step: no columns bound");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1579,16 +1583,16 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) {
         }
     }
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
 // ---- TickFn-compatible shim (cranelift_exec.rs:11,129-195) -----------------------------------------------------
 
 static thread_local sixdof_handle* g_tick_handle = nullptr;
 
-int sixdof_tick_bind(sixdof_handle* h) {
+int sixdof_tick_bind(sixdof_handle* h) try {
     g_tick_handle = h;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
 static void tick_slot_ids(const sixdof_handle* h, std::vector<uint64_t>* in, std::vector<uint64_t>* out) {
     // inputs: first-use order of `increment_sim_tick | six_dof(sys)` (system.rs:172-200); then effector columns
@@ -1609,7 +1613,7 @@ static uint64_t slot_bytes(const sixdof_handle* h, uint64_t id) {
 }
 
 int sixdof_tick_slots(const sixdof_handle* h, sixdof_slot* inputs, size_t in_cap, size_t* n_in, sixdof_slot* outputs,
-                      size_t out_cap, size_t* n_out) {
+                      size_t out_cap, size_t* n_out) try {
     if (!h || !n_in || !n_out) return SIXDOF_ERR_INVALID_ARGUMENT;
     std::vector<uint64_t> in, out;
     tick_slot_ids(h, &in, &out);
@@ -1620,9 +1624,9 @@ int sixdof_tick_slots(const sixdof_handle* h, sixdof_slot* inputs, size_t in_cap
     for (size_t i = 0; inputs && i < in.size(); i++) inputs[i] = {in[i], slot_bytes(h, in[i])};
     for (size_t i = 0; outputs && i < out.size(); i++) outputs[i] = {out[i], slot_bytes(h, out[i])};
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(h))
 
-void sixdof_tick(const uint8_t* const* inputs, uint8_t* const* outputs) {
+void sixdof_tick(const uint8_t* const* inputs, uint8_t* const* outputs) try {
     sixdof_handle* h = g_tick_handle;
     if (!h || !h->bound || !inputs || !outputs) return;  // TickFn cannot fail (cranelift_exec.rs:163-165)
     if (hipSetDevice(h->device) != hipSuccess) return;
@@ -1654,6 +1658,6 @@ void sixdof_tick(const uint8_t* const* inputs, uint8_t* const* outputs) {
         }
     }
     hipStreamSynchronize(h->stream);
-}
+} SIXDOF_ABI_CATCH_VALUE(err_of(g_tick_handle), )      // TickFn returns nothing: the message is on the bound handle
 
 }  // extern "C"

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/sixdof_hip.h"
+#include "abi_guard.hpp"
 
 struct Series {
     std::string name;
@@ -35,6 +36,8 @@ struct sixdof_sink {
     uint64_t commits = 0;
 };
 
+static std::string* err_of(const sixdof_sink* s) { return s ? &const_cast<sixdof_sink*>(s)->err : nullptr; }
+
 static int fail(sixdof_sink* s, int code, const std::string& msg) {
     if (s) s->err = msg;
     return code;
@@ -42,17 +45,17 @@ static int fail(sixdof_sink* s, int code, const std::string& msg) {
 
 extern "C" {
 
-uint64_t sixdof_pair_id(const char* entity, const char* component) {
+uint64_t sixdof_pair_id(const char* entity, const char* component) try {
     // ComponentId::from_pair: the component id of "entity.component" (types.rs:54-59)
     const std::string joined = std::string(entity ? entity : "") + "." + (component ? component : "");
     return sixdof_component_id(joined.c_str());
-}
+} SIXDOF_ABI_CATCH_VALUE(nullptr, 0)
 
-sixdof_sink* sixdof_sink_create(void) { return new sixdof_sink(); }
+sixdof_sink* sixdof_sink_create(void) { return new (std::nothrow) sixdof_sink(); }
 void sixdof_sink_destroy(sixdof_sink* s) { delete s; }
 const char* sixdof_sink_last_error(const sixdof_sink* s) { return s ? s->err.c_str() : "null sink"; }
 
-int sixdof_sink_register(sixdof_sink* s, uint64_t pair_id, uint32_t elem_bytes, const char* name) {
+int sixdof_sink_register(sixdof_sink* s, uint64_t pair_id, uint32_t elem_bytes, const char* name) try {
     if (!s || elem_bytes == 0) return fail(s, SIXDOF_ERR_INVALID_ARGUMENT, "sink_register: null sink or empty element");
     auto it = s->series.find(pair_id);
     if (it != s->series.end()) {
@@ -60,13 +63,14 @@ int sixdof_sink_register(sixdof_sink* s, uint64_t pair_id, uint32_t elem_bytes, 
             return fail(s, SIXDOF_ERR_VALUE_SIZE_MISMATCH, "sink_register: pair " + it->second.name + " exists with another element size");
         return SIXDOF_OK;
     }
-    Series& t = s->series[pair_id];
-    t.name = name ? name : "";
-    t.elem_bytes = elem_bytes;
+    Series fresh;                                   // filled before it enters the map: a failed allocation leaves no half-made pair
+    fresh.name = name ? name : "";
+    fresh.elem_bytes = elem_bytes;
+    s->series.emplace(pair_id, std::move(fresh));
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(s))
 
-int sixdof_sink_push(sixdof_sink* s, uint64_t pair_id, int64_t timestamp_us, const void* buf, uint32_t bytes) {
+int sixdof_sink_push(sixdof_sink* s, uint64_t pair_id, int64_t timestamp_us, const void* buf, uint32_t bytes) try {
     if (!s || !buf) return fail(s, SIXDOF_ERR_INVALID_ARGUMENT, "sink_push: null argument");
     auto it = s->series.find(pair_id);
     if (it == s->series.end()) return fail(s, SIXDOF_ERR_COMPONENT_NOT_FOUND, "sink_push: pair is not registered");
@@ -75,18 +79,19 @@ int sixdof_sink_push(sixdof_sink* s, uint64_t pair_id, int64_t timestamp_us, con
     if (!t.index.empty() && t.index.back() > timestamp_us)      // time_series.rs:206-222
         return fail(s, SIXDOF_ERR_TIME_TRAVEL, "sink_push: " + t.name + ": time travel (timestamp older than the last sample)");
     const uint8_t* b = static_cast<const uint8_t*>(buf);
+    t.index.reserve(t.index.size() + 1);            // whatever can throw throws before a byte changes: a failed push leaves the series as it was
     t.data.insert(t.data.end(), b, b + bytes);      // data first, index last (consistent reads, :224-228)
     t.index.push_back(timestamp_us);
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(s))
 
-uint64_t sixdof_sink_sample_count(const sixdof_sink* s, uint64_t pair_id) {
+uint64_t sixdof_sink_sample_count(const sixdof_sink* s, uint64_t pair_id) try {
     if (!s) return 0;
     auto it = s->series.find(pair_id);
     return it == s->series.end() ? 0 : it->second.index.size();
-}
+} SIXDOF_ABI_CATCH_VALUE(err_of(s), 0)
 
-size_t sixdof_sink_pairs(const sixdof_sink* s, uint64_t* ids, size_t cap) {
+size_t sixdof_sink_pairs(const sixdof_sink* s, uint64_t* ids, size_t cap) try {
     if (!s) return 0;
     size_t n = 0;
     for (const auto& kv : s->series) {
@@ -94,9 +99,9 @@ size_t sixdof_sink_pairs(const sixdof_sink* s, uint64_t* ids, size_t cap) {
         n++;
     }
     return n;
-}
+} SIXDOF_ABI_CATCH_VALUE(err_of(s), 0)
 
-int sixdof_sink_latest(const sixdof_sink* s, uint64_t pair_id, int64_t* timestamp_us, void* out, uint32_t bytes) {
+int sixdof_sink_latest(const sixdof_sink* s, uint64_t pair_id, int64_t* timestamp_us, void* out, uint32_t bytes) try {
     if (!s) return SIXDOF_ERR_INVALID_ARGUMENT;
     auto it = s->series.find(pair_id);
     if (it == s->series.end() || it->second.index.empty()) return SIXDOF_ERR_COMPONENT_NOT_FOUND;
@@ -106,9 +111,9 @@ int sixdof_sink_latest(const sixdof_sink* s, uint64_t pair_id, int64_t* timestam
     if (timestamp_us) *timestamp_us = t.index[k];
     if (out) std::memcpy(out, t.data.data() + k * t.elem_bytes, t.elem_bytes);
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(s))
 
-int sixdof_sink_at(const sixdof_sink* s, uint64_t pair_id, int64_t timestamp_us, int64_t* found_us, void* out, uint32_t bytes) {
+int sixdof_sink_at(const sixdof_sink* s, uint64_t pair_id, int64_t timestamp_us, int64_t* found_us, void* out, uint32_t bytes) try {
     if (!s) return SIXDOF_ERR_INVALID_ARGUMENT;
     auto it = s->series.find(pair_id);
     if (it == s->series.end() || it->second.index.empty()) return SIXDOF_ERR_COMPONENT_NOT_FOUND;
@@ -121,10 +126,10 @@ int sixdof_sink_at(const sixdof_sink* s, uint64_t pair_id, int64_t timestamp_us,
     if (found_us) *found_us = t.index[k];
     if (out) std::memcpy(out, t.data.data() + k * t.elem_bytes, t.elem_bytes);
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(s))
 
 int sixdof_sink_series(const sixdof_sink* s, uint64_t pair_id, const int64_t** timestamps, const uint8_t** data, uint64_t* n,
-                       uint32_t* elem_bytes) {
+                       uint32_t* elem_bytes) try {
     if (!s) return SIXDOF_ERR_INVALID_ARGUMENT;
     auto it = s->series.find(pair_id);
     if (it == s->series.end()) return SIXDOF_ERR_COMPONENT_NOT_FOUND;
@@ -134,18 +139,18 @@ int sixdof_sink_series(const sixdof_sink* s, uint64_t pair_id, const int64_t** t
     if (n) *n = t.index.size();
     if (elem_bytes) *elem_bytes = t.elem_bytes;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(s))
 
-void sixdof_sink_truncate(sixdof_sink* s) {      // TimeSeries::truncate: samples go, the schema stays
+void sixdof_sink_truncate(sixdof_sink* s) try {      // TimeSeries::truncate: samples go, the schema stays
     if (!s) return;
     for (auto& kv : s->series) {
         kv.second.index.clear();
         kv.second.data.clear();
     }
-}
+} SIXDOF_ABI_CATCH_VALUE(err_of(s), )
 
 int sixdof_sink_commit_rows(sixdof_sink* s, const uint64_t* pair_ids, const void* rows, uint32_t n_rows, uint32_t row_bytes,
-                            int64_t timestamp_us) {
+                            int64_t timestamp_us) try {
     // commit_world_head_for_world for ONE column: row i -> the series of pair_ids[i]; pair id 0 = that entity has no name
     // in the metadata (the reference skips it, :418-420); an unregistered pair is skipped too (:432-434)
     if (!s || !pair_ids || (!rows && n_rows)) return fail(s, SIXDOF_ERR_INVALID_ARGUMENT, "sink_commit_rows: null argument");
@@ -159,10 +164,10 @@ int sixdof_sink_commit_rows(sixdof_sink* s, const uint64_t* pair_ids, const void
     }
     s->commits++;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(s))
 
 int sixdof_sink_copy_to_rows(const sixdof_sink* s, const uint64_t* pair_ids, void* rows, uint32_t n_rows, uint32_t row_bytes,
-                             int* changed) {
+                             int* changed) try {
     // copy_db_to_world for ONE column: the latest sample of every pair overwrites its row; *changed = some byte differed
     // (the reference marks the component dirty then, :353-361)
     if (!s || !pair_ids || (!rows && n_rows)) return SIXDOF_ERR_INVALID_ARGUMENT;
@@ -182,6 +187,6 @@ int sixdof_sink_copy_to_rows(const sixdof_sink* s, const uint64_t* pair_ids, voi
     }
     if (changed) *changed = diff;
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(s))
 
 }  // extern "C"

@@ -6,10 +6,12 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/sixdof_hip.h"
+#include "abi_guard.hpp"
 
 struct WorldColumn {
     std::string name;
@@ -31,6 +33,7 @@ struct sixdof_world {
 };
 
 static size_t prim_size(int prim) { return prim == SIXDOF_PRIM_F32 ? 4 : 8; }
+static std::string* err_of(const sixdof_world* w) { return w ? &const_cast<sixdof_world*>(w)->err : nullptr; }
 
 extern "C" {
 
@@ -53,16 +56,17 @@ double sixdof_quantize_time_step(double rate_hz) {
     return static_cast<double>(total / 1000000000ull) + static_cast<double>(total % 1000000000ull) / 1.0e9;
 }
 
-sixdof_world* sixdof_world_create(void) {
-    auto* w = new sixdof_world();
+sixdof_world* sixdof_world_create(void) try {
+    std::unique_ptr<sixdof_world> owner(new sixdof_world());      // released only once the globals are in
+    sixdof_world* w = owner.get();
     // add_globals (world.rs:174-183): SystemGlobals::new(sim_time_step) on entity 0; DEFAULT_TIME_STEP = 1/120 s in ns
     const uint64_t globals = w->entity_len++;
     const uint64_t tick0 = 0;
     w->sim_time_step = static_cast<double>(1000000000ull / 120) / 1.0e9;
-    sixdof_world_insert(w, globals, "tick", SIXDOF_PRIM_U64, nullptr, 0, &tick0, 8);
-    sixdof_world_insert(w, globals, "simulation_time_step", SIXDOF_PRIM_F64, nullptr, 0, &w->sim_time_step, 8);
-    return w;
-}
+    if (sixdof_world_insert(w, globals, "tick", SIXDOF_PRIM_U64, nullptr, 0, &tick0, 8) != SIXDOF_OK) return nullptr;
+    if (sixdof_world_insert(w, globals, "simulation_time_step", SIXDOF_PRIM_F64, nullptr, 0, &w->sim_time_step, 8) != SIXDOF_OK) return nullptr;
+    return owner.release();
+} SIXDOF_ABI_CATCH_VALUE(nullptr, nullptr)
 
 void sixdof_world_destroy(sixdof_world* w) { delete w; }
 
@@ -73,7 +77,7 @@ uint64_t sixdof_world_spawn(sixdof_world* w) { return w ? w->entity_len++ : 0; }
 uint64_t sixdof_world_entity_len(const sixdof_world* w) { return w ? w->entity_len : 0; }
 
 int sixdof_world_insert(sixdof_world* w, uint64_t entity, const char* component, int prim, const uint64_t* dims,
-                        uint32_t ndim, const void* row, size_t n_bytes) {
+                        uint32_t ndim, const void* row, size_t n_bytes) try {
     if (!w || !component || (!row && n_bytes) || ndim > 2 || (ndim && !dims)) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (entity >= w->entity_len) {
         w->err = "insert: unknown entity";
@@ -87,7 +91,8 @@ int sixdof_world_insert(sixdof_world* w, uint64_t entity, const char* component,
     }
     const uint64_t id = sixdof_component_id(component);
     auto it = w->host.find(id);
-    if (it == w->host.end()) {
+    const bool fresh = it == w->host.end();
+    if (fresh) {
         WorldColumn c;
         c.name = component;
         c.prim = prim;
@@ -101,12 +106,18 @@ int sixdof_world_insert(sixdof_world* w, uint64_t entity, const char* component,
     }
     WorldColumn& c = it->second;
     const uint8_t* p = static_cast<const uint8_t*>(row);
-    c.buffer.insert(c.buffer.end(), p, p + n_bytes);
+    try {       // whatever can throw throws before a byte changes: a failed insert leaves the world as it was
+        c.entity_ids.reserve(c.entity_ids.size() + 1);
+        c.buffer.insert(c.buffer.end(), p, p + n_bytes);
+    } catch (...) {
+        if (fresh) w->host.erase(it);
+        throw;      // -> SIXDOF_ERR_OUT_OF_MEMORY at the barrier below
+    }
     c.entity_ids.push_back(entity);
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(w))
 
-int sixdof_world_column(sixdof_world* w, uint64_t component_id, sixdof_column* out) {
+int sixdof_world_column(sixdof_world* w, uint64_t component_id, sixdof_column* out) try {
     if (!w || !out) return SIXDOF_ERR_INVALID_ARGUMENT;
     auto it = w->host.find(component_id);
     if (it == w->host.end()) {
@@ -123,9 +134,9 @@ int sixdof_world_column(sixdof_world* w, uint64_t component_id, sixdof_column* o
     out->entity_ids = c.entity_ids.data();
     out->host_ptr = c.buffer.data();
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(w))
 
-size_t sixdof_world_components(const sixdof_world* w, uint64_t* ids, size_t cap) {
+size_t sixdof_world_components(const sixdof_world* w, uint64_t* ids, size_t cap) try {
     if (!w) return 0;
     size_t k = 0;
     for (auto& kv : w->host) {     // ascending ComponentId, like the reference's BTreeMap
@@ -133,10 +144,10 @@ size_t sixdof_world_components(const sixdof_world* w, uint64_t* ids, size_t cap)
         k++;
     }
     return k;
-}
+} SIXDOF_ABI_CATCH_VALUE(err_of(w), 0)
 
 // validate_rates + set_globals (world_builder.rs:211-243, world.rs:185-191)
-int sixdof_world_set_rates(sixdof_world* w, double simulation_rate_hz, double telemetry_rate_hz) {
+int sixdof_world_set_rates(sixdof_world* w, double simulation_rate_hz, double telemetry_rate_hz) try {
     if (!w) return SIXDOF_ERR_INVALID_ARGUMENT;
     if (!(simulation_rate_hz > 0.0)) {
         w->err = "simulation_rate must be > 0 Hz, got " + std::to_string(simulation_rate_hz);
@@ -158,18 +169,18 @@ int sixdof_world_set_rates(sixdof_world* w, double simulation_rate_hz, double te
     auto it = w->host.find(sixdof_component_id("simulation_time_step"));
     if (it != w->host.end() && it->second.buffer.size() >= 8) std::memcpy(it->second.buffer.data(), &w->sim_time_step, 8);
     return SIXDOF_OK;
-}
+} SIXDOF_ABI_CATCH(err_of(w))
 
 double sixdof_world_time_step(const sixdof_world* w) { return w ? w->sim_time_step : 0.0; }
 uint64_t sixdof_world_ticks_per_telemetry(const sixdof_world* w) { return w ? w->ticks_per_telemetry : 1; }
 uint64_t sixdof_world_tick(const sixdof_world* w) { return w ? w->tick : 0; }
 
 // advance_tick (world.rs:276-278) + the globals `tick` column the compiled tick increments (globals.rs:42-44)
-void sixdof_world_advance_tick(sixdof_world* w, uint64_t n) {
+void sixdof_world_advance_tick(sixdof_world* w, uint64_t n) try {
     if (!w) return;
     w->tick += n;
     auto it = w->host.find(sixdof_component_id("tick"));
     if (it != w->host.end() && it->second.buffer.size() >= 8) std::memcpy(it->second.buffer.data(), &w->tick, 8);
-}
+} SIXDOF_ABI_CATCH_VALUE(err_of(w), )
 
 }  // extern "C"

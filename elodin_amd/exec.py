@@ -25,6 +25,8 @@ def _raise(h, rc: int, what: str):
         raise KeyError(f"{what}: {msg}")           # Error::ComponentNotFound -> ValueError-class in PyO3
     if rc in (L.ERR_VALUE_SIZE_MISMATCH, L.ERR_INVALID_ARGUMENT, L.ERR_ENTITY_MISMATCH, L.ERR_UNSUPPORTED):
         raise ValueError(f"{what}: {msg}")
+    if rc == L.ERR_OUT_OF_MEMORY:
+        raise MemoryError(f"{what}: {msg}")
     raise L.BackendError(f"{what}: {msg} (status {rc})")
 
 

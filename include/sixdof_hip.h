@@ -56,7 +56,11 @@ typedef enum sixdof_status {
     SIXDOF_ERR_NO_DEVICE = -5,
     SIXDOF_ERR_UNSUPPORTED = -6,
     SIXDOF_ERR_ENTITY_MISMATCH = -7,      /* Body columns do not share one entity-id vector */
-    SIXDOF_ERR_TIME_TRAVEL = -8           /* elodin-db Error::TimeTravel: a sample older than the pair's last one */
+    SIXDOF_ERR_TIME_TRAVEL = -8,          /* elodin-db Error::TimeTravel: a sample older than the pair's last one */
+    /* The exception barrier (csrc/abi_guard.hpp): a C++ exception never unwinds into the caller's frames (Rust `extern "C"`,
+     * cranelift_exec.rs:11,163-165).  Every allocating entry point catches, leaves the text in *_last_error and returns: */
+    SIXDOF_ERR_OUT_OF_MEMORY = -9,        /* std::bad_alloc / std::length_error: a host allocation failed (absurd row count?) */
+    SIXDOF_ERR_INTERNAL = -10             /* any other exception: Error::Unknown / PyErr analogue (error.rs:12-51) */
 } sixdof_status;
 
 /* integrator/mod.rs:7-10 */
