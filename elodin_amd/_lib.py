@@ -91,6 +91,9 @@ SYMBOLS = {
     "sixdof_comm_destroy": (None, [C.c_void_p]),
     "sixdof_comm_last_error": (C.c_char_p, [C.c_void_p]),
     "sixdof_shard_range": (None, [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "sixdof_gather_block_rows": (C.c_uint64, [C.c_uint64, C.c_int]),
+    "sixdof_gather_pack": (C.c_int, [C.POINTER(C.c_double), C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "sixdof_gather_unpack": (C.c_int, [C.POINTER(C.c_double), C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     "sixdof_campaign_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
     "sixdof_campaign_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_uint64, C.c_uint64, C.POINTER(C.c_double), C.c_uint64]),
     "sixdof_step": (C.c_int, [_H, C.c_uint64, C.POINTER(Timings)]),

@@ -115,6 +115,36 @@ void sixdof_shard_range(uint64_t n_rows, int world, int rank, uint64_t* lo, uint
     if (hi) *hi = l + base + (r < extra ? 1 : 0);
 }
 
+// ---- the gather's packing, free of any transport: what sixdof_campaign_gather does around its ONE ncclAllGather, and what a
+// host with another transport (torch.distributed over gloo in the CPU tests, elodin_amd/shard.py) calls around its own ----
+uint64_t sixdof_gather_block_rows(uint64_t n_total, int world) {
+    const uint64_t w = static_cast<uint64_t>(world < 1 ? 1 : world);
+    return (n_total + w - 1) / w;      // the largest shard: blocks differ by at most one row
+}
+
+int sixdof_gather_pack(const double* local_rows, uint64_t n_local, uint64_t width, uint64_t n_total, int world, int rank, double* block) {
+    if (world < 1 || rank < 0 || rank >= world || (!local_rows && n_local * width) || (!block && n_total * width)) return SIXDOF_ERR_INVALID_ARGUMENT;
+    uint64_t lo = 0, hi = 0;
+    sixdof_shard_range(n_total, world, rank, &lo, &hi);
+    if (hi - lo != n_local) return SIXDOF_ERR_VALUE_SIZE_MISMATCH;
+    const uint64_t pad_rows = sixdof_gather_block_rows(n_total, world);
+    if (n_local * width) std::memcpy(block, local_rows, n_local * width * sizeof(double));
+    if ((pad_rows - n_local) * width) std::memset(block + n_local * width, 0, (pad_rows - n_local) * width * sizeof(double));
+    return SIXDOF_OK;
+}
+
+int sixdof_gather_unpack(const double* blocks, uint64_t width, uint64_t n_total, int world, double* all_rows) {
+    if (world < 1 || ((!blocks || !all_rows) && n_total * width)) return SIXDOF_ERR_INVALID_ARGUMENT;
+    const uint64_t pad_rows = sixdof_gather_block_rows(n_total, world);
+    for (int r = 0; r < world; r++) {   // drop the padding: rank r's rows go to [lo_r, hi_r) in run-id order
+        uint64_t l = 0, h = 0;
+        sixdof_shard_range(n_total, world, r, &l, &h);
+        if ((h - l) * width)
+            std::memcpy(all_rows + l * width, blocks + static_cast<uint64_t>(r) * pad_rows * width, (h - l) * width * sizeof(double));
+    }
+    return SIXDOF_OK;
+}
+
 int sixdof_comm_unique_id(uint8_t id[SIXDOF_COMM_ID_BYTES]) try {
     if (!id) return SIXDOF_ERR_INVALID_ARGUMENT;
     Rccl& r = rccl();
@@ -224,8 +254,9 @@ int sixdof_campaign_gather(sixdof_comm* c, const double* local_rows, uint64_t n_
         if (n_local * width) std::memcpy(all_rows, local_rows, n_local * width * sizeof(double));
         return SIXDOF_OK;
     }
-    // equal, padded blocks so ONE ncclAllGather moves everything; blocks differ by at most one row
-    const uint64_t pad_rows = (n_total + static_cast<uint64_t>(c->world) - 1) / static_cast<uint64_t>(c->world);
+    // equal, padded blocks so ONE ncclAllGather moves everything (sixdof_gather_pack / _unpack: the same packing a host
+    // with another transport uses, unit-tested on the CPU for uneven blocks)
+    const uint64_t pad_rows = sixdof_gather_block_rows(n_total, c->world);
     const size_t block = static_cast<size_t>(pad_rows * width) * sizeof(double);
     if (block == 0) return SIXDOF_OK;
     hipError_t e = hipSetDevice(c->device);
@@ -234,23 +265,17 @@ int sixdof_campaign_gather(sixdof_comm* c, const double* local_rows, uint64_t n_
     if (rc != SIXDOF_OK) return rc;
     char* send = static_cast<char*>(c->d_buf);
     char* recv = send + block;
-    if ((e = hipMemsetAsync(send, 0, block, c->stream)) != hipSuccess) return c->hip(e, "hipMemsetAsync");
-    if (n_local * width &&
-        (e = hipMemcpyAsync(send, local_rows, n_local * width * sizeof(double), hipMemcpyHostToDevice, c->stream)) != hipSuccess)
-        return c->hip(e, "hipMemcpyAsync (H2D)");
+    std::vector<double> host(static_cast<size_t>(pad_rows * width) * static_cast<size_t>(c->world));
+    if ((rc = sixdof_gather_pack(local_rows, n_local, width, n_total, c->world, c->rank, host.data())) != SIXDOF_OK)
+        return c->fail(rc, "campaign_gather: sixdof_gather_pack refused the block");
+    if ((e = hipMemcpyAsync(send, host.data(), block, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return c->hip(e, "hipMemcpyAsync (H2D)");
     const int nrc = rccl().all_gather(send, recv, pad_rows * width, kNcclFloat64, c->comm, c->stream);
     if (nrc != kNcclSuccess) return c->nccl(nrc, "ncclAllGather");
-    std::vector<double> host(static_cast<size_t>(pad_rows * width) * static_cast<size_t>(c->world));
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip(e, "hipStreamSynchronize");      // `host` was the H2D source
     if ((e = hipMemcpyAsync(host.data(), recv, block * static_cast<size_t>(c->world), hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
         return c->hip(e, "hipMemcpyAsync (D2H)");
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return c->hip(e, "hipStreamSynchronize");
-    for (int r = 0; r < c->world; r++) {   // drop the padding: rank r's rows go to [lo_r, hi_r) in run-id order
-        uint64_t l = 0, h = 0;
-        sixdof_shard_range(n_total, c->world, r, &l, &h);
-        if (h > l)
-            std::memcpy(all_rows + l * width, host.data() + static_cast<size_t>(r) * pad_rows * width, (h - l) * width * sizeof(double));
-    }
-    return SIXDOF_OK;
+    return sixdof_gather_unpack(host.data(), width, n_total, c->world, all_rows);
 } SIXDOF_ABI_CATCH(err_of(c))
 
 }  // extern "C"

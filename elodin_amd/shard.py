@@ -68,15 +68,48 @@ def gather_rows(local_rows: np.ndarray, total_rows: int, device="cpu", unit: int
     local_rows = np.ascontiguousarray(local_rows)
     if not (dist.is_available() and dist.is_initialized()):
         return local_rows
-    world = dist.get_world_size()
-    width = local_rows.shape[1]
-    sizes = [shard_range(total_rows, world, r, unit) for r in range(world)]
-    pad = max(hi - lo for lo, hi in sizes)
-    buf = torch.zeros((pad, width), dtype=getattr(torch, local_rows.dtype.name), device=device)
-    buf[: local_rows.shape[0]] = torch.from_numpy(local_rows)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
-    return np.concatenate([o.cpu().numpy()[: hi - lo] for o, (lo, hi) in zip(out, sizes)], axis=0)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if unit < 1 or total_rows % unit or local_rows.shape[0] % unit:
+        raise ValueError(f"{total_rows} rows are not a whole number of {unit}-row units")
+    # the packing is the C ABI's (sixdof_gather_pack / _unpack: equal zero-padded blocks, what sixdof_campaign_gather runs around
+    # its ncclAllGather); only the transport is torch's.  A `unit` of rows travels as one wider row; f64 on the wire (exact for f32).
+    dtype, width = local_rows.dtype, local_rows.shape[1] * unit
+    local = np.ascontiguousarray(local_rows, dtype=np.float64).reshape(local_rows.shape[0] // unit, width)
+    pad = pack_block(local, total_rows // unit, world, rank)
+    buf = torch.from_numpy(pad).to(device)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    rows = unpack_blocks(torch.stack(parts).cpu().numpy(), width, total_rows // unit, world)
+    return rows.reshape(total_rows, width // unit).astype(dtype, copy=False)
+
+
+def pack_block(local_rows: np.ndarray, total_rows: int, world: int, rank: int) -> np.ndarray:
+    """Rank `rank`'s zero-padded block of the gather ([ceil(total_rows / world), width] f64) through sixdof_gather_pack."""
+    import ctypes as C
+    from . import _lib as L
+    lib, dp = L.lib(), C.POINTER(C.c_double)
+    local = np.ascontiguousarray(local_rows, dtype=np.float64)
+    width = local.shape[1]
+    block = np.empty((int(lib.sixdof_gather_block_rows(int(total_rows), int(world))), width), dtype=np.float64)
+    rc = lib.sixdof_gather_pack(local.ctypes.data_as(dp), local.shape[0], width, int(total_rows), int(world), int(rank), block.ctypes.data_as(dp))
+    if rc == L.ERR_VALUE_SIZE_MISMATCH:
+        raise ValueError(f"gather: {local.shape[0]} rows are not rank {rank}'s block of {total_rows} rows over {world} ranks (shard_range)")
+    if rc != L.OK:
+        raise ValueError(f"sixdof_gather_pack: status {rc}")
+    return block
+
+
+def unpack_blocks(blocks: np.ndarray, width: int, total_rows: int, world: int) -> np.ndarray:
+    """The `world` padded blocks in rank order -> [total_rows, width] in run-id order through sixdof_gather_unpack."""
+    import ctypes as C
+    from . import _lib as L
+    dp = C.POINTER(C.c_double)
+    blocks = np.ascontiguousarray(blocks, dtype=np.float64)
+    out = np.empty((int(total_rows), int(width)), dtype=np.float64)
+    rc = L.lib().sixdof_gather_unpack(blocks.ctypes.data_as(dp), int(width), int(total_rows), int(world), out.ctypes.data_as(dp))
+    if rc != L.OK:
+        raise ValueError(f"sixdof_gather_unpack: status {rc}")
+    return out
 
 
 class CapiComm:

@@ -396,6 +396,12 @@ void sixdof_comm_destroy(sixdof_comm* c);
 const char* sixdof_comm_last_error(const sixdof_comm* c);                          /* c may be NULL: last init error */
 /* Rank r's contiguous block [lo, hi) of n_rows run ids (blocks differ by at most one row). */
 void sixdof_shard_range(uint64_t n_rows, int world, int rank, uint64_t* lo, uint64_t* hi);
+/* The gather's packing without a transport (pure host code): equal blocks of sixdof_gather_block_rows(n_total, world) =
+ * ceil(n_total / world) rows, rank r's rows first and zeros after; `blocks` = the `world` blocks in rank order.  What
+ * sixdof_campaign_gather runs around its one ncclAllGather, and what a host with its own transport runs around its. */
+uint64_t sixdof_gather_block_rows(uint64_t n_total, int world);
+int sixdof_gather_pack(const double* local_rows, uint64_t n_local, uint64_t width, uint64_t n_total, int world, int rank, double* block);
+int sixdof_gather_unpack(const double* blocks, uint64_t width, uint64_t n_total, int world, double* all_rows);
 /* `root`'s host buffer of n_bytes (the plan table [n_runs, n_params] f64, a reference profile ...) -> every rank's. */
 int sixdof_campaign_broadcast(sixdof_comm* c, void* table, uint64_t n_bytes, int root);
 /* Every rank contributes its block's result rows [n_local, width] f64 (n_local = its sixdof_shard_range of n_total);
