@@ -109,3 +109,68 @@ def test_two_ranks_over_rccl_broadcast_and_gather_in_run_id_order(tmp_path):
         got = np.load(str(tmp_path / ("out%d.npy" % r)))
         assert np.array_equal(got[: n * 17].reshape(n, 17), table)
         assert np.array_equal(got[n * 17:].reshape(n, 12), want_rows)
+
+
+def _shared_device_rank(rank, world, id_path, out_path):
+    """Like _rank_main, but every rank opens its communicator on device 0; the outcome (rows or the refusal text) is written down."""
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    try:
+        if rank == 0:
+            cid = shard.CapiComm.unique_id()
+            with open(id_path + ".tmp", "wb") as f:
+                f.write(cid)
+            os.replace(id_path + ".tmp", id_path)
+        else:
+            import time
+            while not os.path.exists(id_path):
+                time.sleep(0.01)
+            cid = open(id_path, "rb").read()
+        c = shard.CapiComm(cid, world, rank, 0)
+        n, width = 101, 12                                       # 101 rows over 2 ranks: blocks of 51 and 50, one padded row on the wire
+        table = np.arange(n * 17, dtype=np.float64).reshape(n, 17) if rank == 0 else None
+        got = c.broadcast_table(table, (n, 17))
+        lo, hi = shard.shard_range(n, world, rank)
+        allrows = c.gather_rows(got[lo:hi, :width] * 2.0 + rank, n)
+        np.save(out_path % rank, np.concatenate([got.ravel(), allrows.ravel()]))
+        c.close()
+    except L.BackendError as e:
+        open((out_path % rank) + ".refused", "w").write(str(e))
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_device_over_rccl_or_the_recorded_refusal(tmp_path):
+    """A gpurun box has ONE GPU.  RCCL with two ranks on it either works — then the uneven 101-row broadcast + gather is checked
+    exactly like the two-GPU test — or refuses the duplicate device at ncclCommInitRank (NCCL's "Duplicate GPU detected"); the
+    refusal must come back through the C ABI as a status with RCCL's text, not as a hang or a crash, and is written to
+    gpurun_out/rccl_two_ranks_one_gpu.txt.  (Uneven-block padding itself is covered on the CPU: tests/test_gather_packing.py.)"""
+    if L.lib().sixdof_device_count() < 1:
+        pytest.skip("needs a GPU")
+    world = 2
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_shared_device_rank, args=(r, world, str(tmp_path / "id"), str(tmp_path / "out%d.npy"))) for r in range(world)]
+    for p in procs:
+        p.start()
+    hung = False
+    for p in procs:
+        p.join(90)
+        if p.is_alive():
+            hung = True
+            p.terminate()
+            p.join(10)
+    refusals = [(tmp_path / ("out%d.npy.refused" % r)).read_text() for r in range(world) if (tmp_path / ("out%d.npy.refused" % r)).exists()]
+    from pathlib import Path
+    log = Path(__file__).resolve().parent.parent / "gpurun_out"
+    log.mkdir(exist_ok=True)
+    if refusals:
+        (log / "rccl_two_ranks_one_gpu.txt").write_text("refused (as expected of two ranks on one device):\n" + "\n".join(refusals) + "\n")
+        assert all("ncclCommInitRank" in t or "comm_init" in t for t in refusals), refusals
+        return
+    assert not hung, "two ranks on one device neither finished nor were refused within 90 s"
+    n = 101
+    table = np.arange(n * 17, dtype=np.float64).reshape(n, 17)
+    want_rows = np.concatenate([table[slice(*shard.shard_range(n, world, r)), :12] * 2.0 + r for r in range(world)])
+    for r in range(world):
+        got = np.load(str(tmp_path / ("out%d.npy" % r)))
+        assert np.array_equal(got[: n * 17].reshape(n, 17), table)
+        assert np.array_equal(got[n * 17:].reshape(n, 12), want_rows)
+    (log / "rccl_two_ranks_one_gpu.txt").write_text("two RCCL ranks on one device ran: uneven 101-row broadcast + gather bit-identical\n")
