@@ -1549,6 +1549,10 @@ def _build(tp, dtype, integrator, fast_math, window_soa, column_soa, guard_selec
         return Path(tp.prebuilt_so)
     if getattr(tp, "frozen_source", None) is not None:      # dsl.FrozenProgram: the text exists, only the compiler is run
         return _compile(tp.frozen_source, "pipe")
+    if dtype == "float32" and getattr(tp, "float32_refused", None):
+        # a whole-world StableHLO system whose integer tensors (PRNG words, bit casts, shifts) are carried as integral floats:
+        # exact in double programs only (stablehlo.float32_hazards) — refused rather than silently rounded at 2^24
+        raise NotImplementedError("this program cannot be built with dtype float32: " + "; ".join(tp.float32_refused[:4]))
     variants = VARIANTS if isinstance(tp, dsl.TracedProgram) else VARIANTS[:2]
     first_src = None
     if isinstance(tp, dsl.TracedProgram) and not tp.fold_stages:
@@ -2023,10 +2027,12 @@ def _compile(src: str, stem: str) -> Path:
             # opt-in middle ground: accept the spilling object only when every spill slot (scratch and SGPR-in-lane) is provably
             # written on every path before it is read (elodin_amd/isa_check.py)
             from . import isa_check
-            dirty = [f for _, lines in isa_check.kernels(isa_check.disassemble(Path(best_obj))).items() for f in isa_check.analyse(lines)[0]]
-            if not dirty:
-                best = dict(best, spills_checked="every spill slot written before read on every path (isa_check)")
+            clean, why, _ = isa_check.check_object(Path(best_obj), int(best["vgpr_spills"]))      # fails closed: no proof = dirty
+            if clean:
+                best = dict(best, spills_checked=why + " (isa_check)")
                 allow_spills = True
+            else:
+                best = dict(best, spills_check_failed=why)
         if best["vgpr_spills"] > 0:
             if not allow_spills:
                 mt = temp(".json.tmp")

@@ -1944,6 +1944,7 @@ class TracedSystem:
         self.name, self.every, self.phase, self.also_at = sys_.__name__, sys_.every, sys_.phase, sys_.also_at
         self.reads_accel = False
         self.body_free = bool(getattr(sys_, "body_free", False))     # the system declares it touches no Body column (checked by codegen)
+        self.float32_refused = list(getattr(sys_, "float32_refused", ()) or ())     # stablehlo.float32_hazards: integer work exact in f64 only
         pos, vel, inertia = _body_symbols()
         kwargs = {}
 
@@ -2196,6 +2197,7 @@ class TracedProgram:
         # may leave the Body slabs alone (NoModel::kBodyDead, csrc/effectors.hpp)
         self.body_free = (bool(self.pre + self.post) and not self.fold_stages and not prog.effectors.effectors
                           and all(getattr(s, "body_free", False) for s in self.pre + self.post))
+        self.float32_refused = [r for s in self.pre + self.post for r in getattr(s, "float32_refused", ())]
         self.writes_inertia = any(s.writes_inertia for s in self.pre + self.post)
         # maps / folds that stood among the force effectors inside six_dof(sys=...) run in front of the force evaluation
         # (frontend.six_dof).  That is the reference's order unless an effector reads what a system BEHIND it in the pipe writes

@@ -2303,7 +2303,9 @@ def system(text: str, inputs: Sequence[str], outputs: Sequence[str], name: str =
     fn.__name__ = name
     import inspect
     fn.__signature__ = inspect.Signature([inspect.Parameter(p, inspect.Parameter.KEYWORD_ONLY) for p in params])
-    return _dsl.system(fn, every=every, **widths)
+    out = _dsl.system(fn, every=every, **widths)
+    out.float32_refused = float32_hazards(funcs)      # a float32 build of a program holding this system is refused (codegen._build)
+    return out
 
 
 # ---- whole-world ticks (what the reference hands a backend: libs/nox-py/src/cranelift_compile.rs:47-68) ----------------------------
@@ -2382,6 +2384,10 @@ def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = Non
     if n_entities and 1 < n_entities <= 64:
         stride = 1 << (n_entities - 1).bit_length()          # rows per world should the tick exchange data between its entities (<= one wavefront)
     used = {"exchanges": 0}
+    hazards = float32_hazards(funcs)
+    # integer components of the world (a tick counter) live in columns of the program's element type: in a float32 build they are
+    # exact below 2^24 = 16,777,216 — said in the manifest, not refused (38 hours of 120 Hz ticks)
+    int_cols = sorted({s_.column for s_, (_, ty) in zip(ins, main.args) if ty.dtype[0] in "iu" and ty.dtype != "i1" and _bits(ty.dtype) >= 32})
 
     def build(lane: bool):
         def width(s_: Slot) -> int:
@@ -2447,7 +2453,10 @@ def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = Non
         fn.__signature__ = inspect.Signature([inspect.Parameter(p, inspect.Parameter.KEYWORD_ONLY) for p in params])
         system_ = _dsl.system(fn, every=every, **widths)
         system_.body_free = True          # every slot of the world is a column of the program: no Body column is read or written
+        system_.float32_refused = hazards     # dsl / codegen refuse a float32 build of a program that holds this system
         manifest = {"mode": "lane" if lane else "world", "rows": "entities" if lane else "worlds",
+                    **({"float32_refused": hazards} if hazards else {}),
+                    **({"float32_integer_columns": int_cols} if int_cols else {}),
                     "entities_per_world": n_entities,
                     "columns": [{"column": c, "width": widths[c],
                                  "component": next(s_.component for s_ in ins + outs if s_.column == c),
@@ -2483,6 +2492,54 @@ def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = Non
     return system_, manifest
 
 
+_F32_BIT_OPS = ("bitcast_convert", "shift_left", "shift_right_logical", "shift_right_arithmetic", "popcnt", "count_leading_zeros",
+                "rng_bit_generator")
+_F32_EXACT = float(1 << 24)      # integers above 2^24 are not all representable in an f32 lane
+
+
+def float32_hazards(funcs: Dict[str, Func]) -> List[str]:
+    """Why a module must not be built with dtype float32, or [] when it may.  The evaluator carries every integer tensor as an
+    integral FLOAT of the program's element type (i32 / ui32 PRNG words, ui64 as two 32-bit halves, bitcasts, shifts, _mul_lo32):
+    exact in f64, where 2^53 covers 32-bit words and their partial products — in an f32 program anything at or above 2^24 rounds,
+    and the float <-> bits nodes (m_bits2f / m_fbits) exist for doubles only.  So an f32 build is refused for a module that
+    (a) reinterprets, shifts or counts bits, (b) combines integers with and / or / xor, (c) multiplies 32-bit-or-wider integers, or
+    (d) holds an integer constant of 2^24 or more; integer COLUMNS of @main (a tick counter) are reported by world_system in the
+    manifest (`float32_integer_columns`: exact below 16,777,216), small loop counters and gather indices pass."""
+    why: List[str] = []
+
+    def is_wide_int(ty: TensorType) -> bool:
+        return ty.dtype[0] in "iu" and ty.dtype != "i1" and _bits(ty.dtype) >= 32
+
+    def walk(ops: List[Op], where: str):
+        for op in ops:
+            short = op.name.strip('"').split(".")[-1]
+            try:
+                rts = _Eval._result_types(op.text)
+            except Exception:  # noqa: BLE001 - an op this scan cannot type is typed (or refused) by the evaluator itself
+                rts = []
+            ints = [t for t in rts if is_wide_int(t)]
+            if short in _F32_BIT_OPS:
+                why.append(f"@{where}: stablehlo.{short} works on bit patterns")
+            elif short in ("and", "or", "xor", "not") and ints:
+                why.append(f"@{where}: stablehlo.{short} on {ints[0]}")
+            elif short == "multiply" and ints:
+                why.append(f"@{where}: integer multiply on {ints[0]} (products pass 2^24)")
+            elif short == "constant" and ints:
+                try:
+                    vals = np.asarray(_Eval._constant(op.text, rts[0]).a, dtype=object).ravel()
+                    big = [v for v in vals if not isinstance(v, U64) and abs(float(_try_const(v) if _try_const(v) is not None else 0.0)) >= _F32_EXACT]
+                    if big or any(isinstance(v, U64) for v in vals):
+                        why.append(f"@{where}: integer constant of 2^24 or more ({rts[0]})")
+                except Exception:  # noqa: BLE001
+                    why.append(f"@{where}: integer constant {rts[0]} could not be bounded")
+            for region in op.regions:
+                walk(region, where)
+
+    for name, fn in funcs.items():
+        walk(fn.body, name)
+    return list(dict.fromkeys(why))
+
+
 def compile_world(text: str, slots_doc: dict, out: Optional[str] = None, mode: str = "auto", dtype: str = "float64", fast_math: bool = False):
     """The build-time step a host (`WorldExec::Hip`, INTEGRATION.md §3) runs once per world: module text + slot metadata -> the
     shared object `sixdof_set_custom_pipe` installs, and the manifest of its columns.  -> (path of the .so, manifest)"""
@@ -2493,6 +2550,9 @@ def compile_world(text: str, slots_doc: dict, out: Optional[str] = None, mode: s
     t0 = time.perf_counter()
     ins, outs = slots_from_metadata(slots_doc)
     system_, manifest = world_system(text, ins, outs, mode=mode)
+    if dtype == "float32" and manifest.get("float32_refused"):
+        raise NotImplementedError("this module cannot be built with dtype float32 (integer tensors are carried as floats: exact in f64 only): "
+                                  + "; ".join(manifest["float32_refused"][:4]))
     widths = {c["column"]: c["width"] for c in manifest["columns"]}
     tp = _dsl.Program([system_], _dsl.Pipe([]), []).trace(widths)
     t1 = time.perf_counter()

@@ -66,7 +66,7 @@ def _check(stdout, n_gpus, steps, warmup):
     assert abs(doc["roofline"]["frac"] - doc["roofline"]["achieved"] / doc["roofline"]["peak"]) < 1e-3
     # value = units all ranks processed / the (max over ranks) time; ms_per_step is that time per step
     assert doc["value"] == pytest.approx(doc["config"]["entities_per_gpu"] * n_gpus / (doc["ms_per_step"] * 1e-3), rel=1e-3)
-    assert set(doc["parity"]) >= {"max_rel_err", "elementwise_state", "tolerance", "entity_rows_bit_exact"}
+    assert set(doc["parity"]) >= {"max_rel_err", "max_rel_err_elementwise", "tolerance", "entity_rows_bit_exact"}
     return doc
 
 
@@ -104,7 +104,7 @@ def test_fit_line_drops_detail_before_it_outgrows_the_driver():
     fat = {f: 1.2345678e-15 for f in ("world_pos", "world_vel", "world_accel", "force")}
     out = bench.compose_line(args, 8, 65536, 1, 1.4e-4, 3.0e-4, tm,
                              roofline=bench.roofline_from(6e-3, 65536, 20, "x" * 3000),
-                             parity={"max_rel_err": 2e-15, "by_column": fat, "elementwise_state": 1e-12, "elementwise_by_column": fat,
+                             parity={"max_rel_err": 2e-15, "by_column": fat, "max_rel_err_elementwise": 1e-12, "by_column_elementwise": fat,
                                      "tolerance": 1e-9, "entity_rows_bit_exact": True},
                              rccl={"backend": "nccl", "world_size": 8, "devices": ["0000:%02x:00" % i for i in range(8)]},
                              campaigns={"apollo": {"strong": 1.0}})
@@ -129,7 +129,7 @@ def test_real_sized_lines_fit_with_margin():
     roof["traffic"], roof["traffic_source"] = 25401234.0, "profiles/pmc_traffic.json (rocprofv3 --pmc passes; valid for step-kernel sources 0123456789abcdef)"
     roof["long_batch"] = {"launches": 4096, "avg_launch_us": 5.59, "frac": 0.5627}
     out = bench.compose_line(args, 8, 65536, 1, 1.4e-4, 3.0e-4, tm, roofline=roof,
-                             parity={"max_rel_err": 2.062e-15, "by_column": fat, "elementwise_state": 1.098e-12, "elementwise_by_column": fat,
+                             parity={"max_rel_err": 2.062e-15, "by_column": fat, "max_rel_err_elementwise": 1.098e-12, "by_column_elementwise": fat,
                                      "tolerance": 1e-9, "entity_rows_bit_exact": True, "rows": 4096, "ticks": 16,
                                      "vs": "oracle/sixdof_oracle.c (bit-exact on the reference's golden CSVs)"},
                              cpu={"value": 3934129.8, "unit": "entity-steps/s", "cores": 1, "kind": "port", "sample": "s" * 180,

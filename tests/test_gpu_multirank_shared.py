@@ -109,7 +109,7 @@ def test_the_drivers_multi_rank_command_prints_config_2_and_both_campaigns_stron
     att = line["rccl"]
     assert att["backend"] == "gloo" and att["world_size"] == 2 and len(att["devices"]) == 2 and att["distinct_devices"] is False      # one GPU, said so
     assert abs(line["n1_reference_value"] * 2 - line["value"]) < 1.0
-    assert line["parity"]["max_rel_err"] < 1e-9 and line["parity"]["elementwise_state"] < 1e-9 and line["parity"]["entity_rows_bit_exact"] is True
+    assert line["parity"]["max_rel_err"] < 1e-9 and line["parity"]["max_rel_err_elementwise"] < 1e-9 and line["parity"]["entity_rows_bit_exact"] is True
     camp = line["campaigns"]                                 # BASELINE configs[3] / [4] over the same two ranks: rollout-steps/s, strong and weak
     for which, total in (("apollo", 8192), ("falcon9", 32768)):
         assert camp["totals"][which] == total

@@ -457,3 +457,31 @@ def test_random_modules_with_reads_between_entities_lane_exchange_equals_world_m
             got, want = lane["hlo_" + name][w_ * S:w_ * S + n].reshape(-1), world["hlo_" + name][w_]
             assert np.array_equal(got, want, equal_nan=True), (seed, n, name, w_)
     assert lane_m["exchange_reads"] > 0 and S == (4 if n <= 4 else 8)      # every module returns a join's result: the exchange is live
+
+
+def test_float32_builds_are_refused_for_modules_that_work_on_integer_bit_patterns():
+    """integer tensors travel as integral floats of the program's element type — exact in f64 (2^53), not in f32
+    (2^24).  A module that reinterprets / shifts / masks bits, multiplies wide integers or holds a constant >= 2^24 (jax.random's
+    threefry, libs/cranelift-mlir/tests/test_threefry.rs) must refuse `dtype float32`; the float-only worlds (three-body, n-body,
+    independent bodies: gather indices and loop counters are small) must not, and an integer COLUMN is named in the manifest."""
+    from elodin_amd import codegen
+    from tests import stablehlo_util as U
+    prng = [c for c in U.WORLD_CASES if "threefry" in c["name"] or "uniform" in c["name"]]
+    assert prng, "the fixture should hold the reference's PRNG cases"
+    for case in prng:
+        why = sh.float32_hazards(sh.parse_module(case["mlir"]))
+        assert why, case["name"]
+        assert any(w_ in " ".join(why) for w_ in ("bit patterns", "2^24", "stablehlo.xor", "stablehlo.or", "stablehlo.and", "multiply")), why
+    text, slots = hb.nbody_world(10, 2.9591220828e-4, 1e-6)
+    assert sh.float32_hazards(sh.parse_module(text)) == []
+    system, manifest = sh.world_system(text, slots, mode="auto")
+    assert "float32_refused" not in manifest and system.float32_refused == []
+    assert manifest["float32_integer_columns"] == ["hlo_tick"]          # exact below 2^24 ticks in a float32 build: said, not refused
+    # a hazardous system reaches codegen.build(..., "float32") only to be refused there (the executor path), and compile_world refuses too
+    case = prng[0]
+    system, values, expect = U.build(case)
+    widths = {k: len(np.atleast_1d(v)) for k, v in values.items()}
+    tp = dsl.Program([system], dsl.Pipe([]), []).trace({**widths, **{k: w for k, (w, _) in expect.items()}})
+    assert tp.float32_refused
+    with pytest.raises(NotImplementedError, match="float32"):
+        codegen.build(tp, "float32", 2)
