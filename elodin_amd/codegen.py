@@ -243,6 +243,18 @@ class _Emitter:
                 sc["lines"].append(f"{sc['indent']}T {cvars[nm]} = {init};")
             inner = {"parent": sc, "names": {}, "lines": [], "vars": cvars, "varset": frozenset(names), "indent": sc["indent"] + "    "}
             if counted is None:
+                # a data-dependent loop leaves per lane (`if (!(c)) break`): an exchange that depends on its carried values would run
+                # with some lanes of the world gone.  (One that does not depend on them is hoisted out of the loop by ref().)
+                seen_, stack_ = set(), [cond, *body]
+                while stack_:
+                    x_ = stack_.pop()
+                    if id(x_) in seen_ or x_.op in ("const", "leaf"):
+                        continue
+                    seen_.add(id(x_))
+                    if x_.op in _WAVE_WIDE and (self._deps(x_) & frozenset(names)):
+                        raise NotImplementedError("a lane exchange (lane_read) inside a data-dependent while loop depends on the loop's carried "
+                                                  "values: lanes that have left the loop would be read; only statically counted loops may exchange")
+                    stack_.extend(x_.args)
                 c = ref(cond, inner)
                 inner["lines"].append(f"{inner['indent']}if (!({c})) break;")
             new = [ref(b, inner) for b in body]
@@ -518,6 +530,14 @@ _NODE_COST = {"lane_read": 8, "lane_read_dyn": 10, "threefry": 90, "erfinv": 120
               "expm1": 15, "mod": 8}
 
 
+# Never inside a guarded arm.  Loops and window loads own scopes of their own.  lane_read / lane_read_dyn are wave-wide exchanges
+# (__shfl -> ds_bpermute): EVERY lane of the world must execute them, or the lanes that do read the registers of lanes whose EXEC
+# bit is off — zero or stale values, i.e. silently wrong joins and edge folds.  They stay outside: a would-be member
+# that is an exchange is simply not a member (it and everything it needs is emitted before the branch, unconditionally).
+_NEVER_GUARDED = ("while", "while_out", "wload")
+_WAVE_WIDE = ("lane_read", "lane_read_dyn")
+
+
 def _plan_guards(need: Dict[int, "dsl.Expr"], roots: Sequence["dsl.Expr"], available: set) -> Dict[int, tuple]:
     """Which selects of a block get a guarded arm: id(select) -> (arm index, member ids, [the selects of its group in creation order]).
 
@@ -563,15 +583,17 @@ def _plan_guards(need: Dict[int, "dsl.Expr"], roots: Sequence["dsl.Expr"], avail
         members = {id(s_.args[arm]) for s_ in sels}
         cost = sum(_NODE_COST.get(s_.args[arm].op, 1) for s_ in sels)
         top = max(s_.args[arm].seq for s_ in sels)
-        if any(s_.args[arm].op in ("while", "while_out", "wload") for s_ in sels):
+        if any(s_.args[arm].op in _NEVER_GUARDED + _WAVE_WIDE for s_ in sels):
             return None
         for x in by_seq:
             if x.seq >= top or id(x) in members or id(x) in available or id(x) in root_ids or id(x) in sel_ids:
                 continue
             us = users.get(id(x), [])
             if us and all(id(u) in members for u in us):
-                if x.op in ("while", "while_out", "wload"):
+                if x.op in _NEVER_GUARDED:
                     return None
+                if x.op in _WAVE_WIDE:
+                    continue        # computed outside the branch by every lane (so is everything only it needs: its users are not all members)
                 members.add(id(x))
                 cost += _NODE_COST.get(x.op, 1)
         if cost < _GUARD_MIN_COST:
@@ -1380,6 +1402,10 @@ def generate_pair_source(tf: "dsl.TracedFold", integrator: Optional[int] = None,
     body = "\n".join(emit_block([(f"acc[{k}]", e) for k, e in enumerate(tf.outputs)], _PAIR_LEAVES))
     tables = _emit_tables()
     additive = _fold_is_additive(tf)
+    # an object built for ONE of the two launch shapes says so, and the library follows the object rather than re-deriving the choice
+    # from the row count and the environment at step time (only specialised objects carry the export: other texts are unchanged)
+    only_export = (f'extern "C" int sixdof_custom_pair_only_small() {{ return {only_s}; }}      // 1: the one-launch small-graph kernel only, 0: the three-kernel tick only\n'
+                   if only_s >= 0 else "")
     return f'''// generated by elodin_amd/codegen.py — do not edit.  edge_fold function: {tf.fold.__name__}
 #include "pair_kernel.hpp"
 
@@ -1403,7 +1429,7 @@ struct PairCustom {{
 }}  // namespace sixdof
 
 extern "C" unsigned sixdof_custom_pair_abi() {{ return static_cast<unsigned>(sizeof(sixdof::PairParams)); }}
-
+{only_export}
 extern "C" int sixdof_custom_pair_launch(const sixdof::PairParams* p, int integrator, uint32_t n_ticks, int small,
                                          void* stream, uint64_t* launches) {{
     using namespace sixdof;
@@ -1841,25 +1867,30 @@ class _Hipcc:
 
     def __init__(self, cmd: List[str], preamble: str):
         self.cmd, self.preamble = cmd, preamble
+        import threading
         self.current = None
+        self._group = False
         self.stopped = False
+        self._lock = threading.Lock()          # start-of-process and stop() exclude each other: no process is started once stopped
         self.returncode, self.stderr = None, ""
 
     def _run(self, c, group=False):
-        if self.stopped:
-            return 1, ""
-        self.current = subprocess.Popen(c, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=group)
-        self._group = group
+        with self._lock:
+            if self.stopped:                   # (checked under the lock: a stop() that came first wins, one that comes later finds `current`)
+                return 1, ""
+            self._group = group
+            self.current = subprocess.Popen(c, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=group)
         _, err = self.current.communicate()
         return self.current.returncode, err
 
     def stop(self):
         import signal
-        self.stopped = True
-        pr = self.current
+        with self._lock:
+            self.stopped = True
+            pr, group = self.current, self._group
         if pr is not None and pr.poll() is None:
             try:
-                if self._group:
+                if group:
                     os.killpg(pr.pid, signal.SIGKILL)      # exactly the group started in _run: hipcc's children stop with it
                 else:
                     pr.kill()
@@ -2013,10 +2044,14 @@ def _compile(src: str, stem: str) -> Path:
                 # memory (SGPR spill carriers), and a later flag set that needs none is the better object
                 # (the memory-image variant keeps its columns in scratch on purpose: there only the spill count decides)
                 by_design = _EXPECT_SCRATCH[0] or "        volatile T c" in src          # (a frozen text of that variant says so itself)
-                cost = lambda u: (u["vgpr_spills"], 0 if by_design else u.get("scratch_bytes_per_lane", 0))
+                # ... compared between attempts at the SAME optimisation level only: legitimate scratch (a program's private arrays)
+                # must not let the -O1 object — a slower kernel — displace a spill-free -O3 one
+                level = lambda u: 1 if u["flags"].startswith("-O1") else 0
+                cost = lambda u: (u["vgpr_spills"], level(u), 0 if by_design else u.get("scratch_bytes_per_lane", 0))
                 if best is None or cost(used) < cost(best):
                     best, best_obj = used, obj
-                if cost(used) == (0, 0):
+                # done: no spills and either no scratch at all or no later flag set at this level that could need less
+                if used["vgpr_spills"] == 0 and (cost(used)[2] == 0 or not any(o == opt for o, _ in _ATTEMPTS[k + 1:])):
                     break
         finally:
             for _, _, _, (job, th) in procs:

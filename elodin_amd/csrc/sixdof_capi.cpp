@@ -107,6 +107,8 @@ struct sixdof_handle {
     std::vector<uint64_t> custom_aux;      // read-only [n,1..3] columns of a generated effector pipe
     std::vector<uint64_t> custom_model;    // read/write [n,1..16] component columns of a generated program
     bool custom_tick_free = false;          // the generated program never looks at the absolute tick (layout bit 17): replayable
+    int pair_only_small = -1;               // what the installed pair object was generated for (-1: both launch shapes)
+    unsigned custom_rows_multiple = 1;      // rows a world of the generated program occupies (lane mode): the joined row count must be a multiple
     // telemetry ring
     uint32_t hist_ring = 0;
     uint64_t hist_first_tick = 0;   // first tick (1-based count) recorded since the ring was enabled
@@ -379,6 +381,10 @@ int sixdof_bind_columns(sixdof_handle* h, const sixdof_column* cols, size_t n_co
     }
     h->identity_join = identical;
     if (h->desc.n_entities == 0) h->desc.n_entities = h->joined_ids.size();
+    // a generated program installed BEFORE the join was sized (n_entities == 0 then: its whole-worlds check passed on nothing)
+    if (h->custom_rows_multiple > 1 && h->desc.n_entities % h->custom_rows_multiple != 0)
+        return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "bind_columns: the installed program lays a world out as " + std::to_string(h->custom_rows_multiple) +
+                       " consecutive rows; the joined " + std::to_string(h->desc.n_entities) + " rows are not a whole number of worlds");
     if (h->joined_ids.size() != h->desc.n_entities)
         return h->fail(SIXDOF_ERR_VALUE_SIZE_MISMATCH, "bind_columns: n_entities does not match the joined Body entity set");
     for (auto& kv : h->cols) h->free_join(kv.second);
@@ -1066,6 +1072,7 @@ int sixdof_set_custom_pipe(sixdof_handle* h, const char* so_path, const uint64_t
     if (h->custom_dl) dlclose(h->custom_dl);
     h->custom_dl = dl;
     h->custom_launch = launch;
+    h->custom_rows_multiple = rows_multiple ? rows_multiple() : 1;      // checked again when the join is (re)sized: sixdof_bind_columns
     h->custom_aux.assign(aux_ids, aux_ids + k_aux);
     h->custom_model.assign(aux_ids + k_aux, aux_ids + k_aux + k_model);
     h->custom_tick_free = ((lay >> 17) & 1u) != 0;
@@ -1091,6 +1098,9 @@ int sixdof_set_custom_pair(sixdof_handle* h, const char* so_path) try {
     if (h->pair_dl) dlclose(h->pair_dl);
     h->pair_dl = dl;
     h->pair_launch = launch;
+    // an object generated for one launch shape only (codegen.build_pair(small=...)) says which: step follows the object
+    auto only_small = reinterpret_cast<int (*)()>(dlsym(dl, "sixdof_custom_pair_only_small"));
+    h->pair_only_small = only_small ? only_small() : -1;
     while (!h->ops.empty() && SIXDOF_EFF_IS_PAIR(h->ops.back().kind)) h->ops.pop_back();
     sixdof_effector_op op{};
     op.kind = SIXDOF_EFF_EDGE_CUSTOM;
@@ -1403,7 +1413,10 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) try {
         const char* no_small = std::getenv("SIXDOF_PAIR_SMALL");   // "0": force the three-kernel path (tests)
         if (P.pair_kind == SIXDOF_EFF_EDGE_CUSTOM) {
             if (!h->pair_launch) return h->fail(SIXDOF_ERR_BACKEND, "step: custom pair op without sixdof_set_custom_pair");
-            const bool small = P.n <= kPairSmallMax && !(no_small && no_small[0] == '0');
+            const bool small = h->pair_only_small >= 0 ? h->pair_only_small == 1 : (P.n <= kPairSmallMax && !(no_small && no_small[0] == '0'));
+            if (small && P.n > kPairSmallMax)
+                return h->fail(SIXDOF_ERR_INVALID_ARGUMENT, "step: the pair object was generated for the one-launch small-graph kernel (<= " +
+                               std::to_string(kPairSmallMax) + " rows) but the joined graph has " + std::to_string(P.n) + " rows");
             const uint32_t K = h->hist_ring ? 1u : (small ? h->desc.ticks_per_launch : 1u << 20);
             for (uint64_t done = 0; done < n_ticks;) {
                 const uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(K, n_ticks - done));

@@ -77,6 +77,16 @@ class HipExec:
                            else np.ascontiguousarray(entity_ids, dtype=np.uint64))
         self._column_ids = {k: np.ascontiguousarray(v, dtype=np.uint64) for k, v in (column_entity_ids or {}).items()}
         n = self.world_pos.shape[0] if not self._column_ids else 0   # 0 = let the library size the join
+        # rows the device really steps: with per-column id vectors six_dof runs on the INTERSECTION of the Body columns' entity
+        # sets (csrc/sixdof_capi.cpp sixdof_bind_columns, query.rs:136-208) — every build-time choice below that depends on the
+        # row count (one-launch pair kernel, cache policy, column layout, whole worlds per executor) uses this, not world_pos's
+        self._n_rows = self.world_pos.shape[0]
+        if self._column_ids:
+            joined = None
+            for name in ("world_pos", "world_vel", "world_accel", "force", "inertia"):
+                ids = self._column_ids.get(name, self.entity_ids)
+                joined = set(ids.tolist()) if joined is None else joined & set(ids.tolist())
+            self._n_rows = len(joined)
         self._aux = {}
         self._windows = {}
         self._window_soa = False
@@ -148,9 +158,9 @@ class HipExec:
                         if memo is not None:
                             memo[("trace", wkey)] = custom
                 rows_multiple = int(getattr(custom, "rows_multiple", 0) or codegen.lane_stride(custom))
-                if rows_multiple > 1 and self.world_pos.shape[0] % rows_multiple:
+                if rows_multiple > 1 and self._n_rows % rows_multiple:
                     raise ValueError(f"this program exchanges data between the entities of a world laid out as {rows_multiple} consecutive rows "
-                                     f"(a whole-world StableHLO tick in lane mode, manifest 'rows_per_world'): the executor's {self.world_pos.shape[0]} "
+                                     f"(a whole-world StableHLO tick in lane mode, manifest 'rows_per_world'): the executor's {self._n_rows} "
                                      f"rows are not a whole number of worlds")
                 if isinstance(effectors, _dsl.Program):
                     self._program_columns = [n for n, _ in custom.columns]
@@ -159,25 +169,25 @@ class HipExec:
                     columns = dict(columns or {})
                     for name in self._windows:       # the ring's head (physical index of the oldest row): starts at 0
                         columns.setdefault(name + "#head", np.zeros((np.shape(columns[name])[0], 1)) if name in columns else None)
-                self._window_soa = bool(self._windows) and self.world_pos.shape[0] >= codegen.WINDOW_SOA_MIN_ROWS
+                self._window_soa = bool(self._windows) and self._n_rows >= codegen.WINDOW_SOA_MIN_ROWS
                 # register columns of a large program executor: element-major on the device (codegen.COLUMN_SOA_MIN_ROWS); the
                 # host-facing arrays (self._aux) stay in the reference's [n, w] rows, upload / download transpose
                 soa_env = os.environ.get("SIXDOF_COLUMN_SOA")
                 self._column_soa = (isinstance(effectors, _dsl.Program) and not getattr(custom, "fold_stages", None)
                                     and not self._column_ids and (soa_env == "1" or (soa_env != "0" and
-                                                                  self.world_pos.shape[0] >= codegen.COLUMN_SOA_MIN_ROWS)))
+                                                                  self._n_rows >= codegen.COLUMN_SOA_MIN_ROWS)))
                 if getattr(custom, "frozen_source", None) is not None or getattr(custom, "prebuilt_so", None) is not None:      # generated for ONE device layout
                     self._column_soa, self._window_soa = bool(custom.column_soa), False
                 memo = effectors.__dict__.get("_exec_memo") if reuse_trace and hasattr(effectors, "__dict__") else None
                 bkey = ("build", id(custom), self.dtype.name, integrator, bool(fast_math), self._window_soa, self._column_soa, guard_selects,
-                        self.world_pos.shape[0] * self.dtype.itemsize * (32 + sum(int(w_) for _, w_ in custom.columns)) <= (768 << 20),
+                        self._n_rows * self.dtype.itemsize * (32 + sum(int(w_) for _, w_ in custom.columns)) <= (768 << 20),
                         tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("SIXDOF_"))))
                 so = memo.get(bkey) if memo is not None else None
                 if so is None or not Path(so).exists():
                     row_elems = 32 + sum(int(w_) for _, w_ in custom.columns)       # what fill_step_params counts (csrc/sixdof_capi.cpp)
                     so = codegen.build(custom, self.dtype.name, integrator, fast_math=fast_math, window_soa=self._window_soa,
                                        column_soa=self._column_soa, guard_selects=guard_selects,
-                                       policy=codegen.policy_for(self.world_pos.shape[0], row_elems, self.dtype.itemsize))
+                                       policy=codegen.policy_for(self._n_rows, row_elems, self.dtype.itemsize))
                     if memo is not None:
                         memo[bkey] = so
                 for name, width in custom.columns:
@@ -205,7 +215,7 @@ class HipExec:
                 # the object is built for THIS executor: its integrator, and the one-launch small-graph kernel or the three-kernel
                 # tick — the same rule csrc/sixdof_capi.cpp applies at step time (kPairSmallMax = 256; SIXDOF_PAIR_SMALL=0 forces
                 # the three-kernel path)
-                pair_small = self.world_pos.shape[0] <= 256 and os.environ.get("SIXDOF_PAIR_SMALL", "")[:1] != "0"
+                pair_small = self._n_rows <= 256 and os.environ.get("SIXDOF_PAIR_SMALL", "")[:1] != "0"
                 pair_so = codegen.build_pair(effectors.pop().trace(), integrator=integrator, small=pair_small)
             if any(isinstance(e, _dsl.EdgeFold) for e in effectors):
                 raise ValueError("an edge_fold effector must be last in the pipe")

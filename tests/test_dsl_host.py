@@ -643,3 +643,39 @@ def test_columns_nobody_reads_are_evaluated_where_they_are_stored():
         assert "store-only" not in codegen.generate_source(tp, "float64", 2)
     finally:
         del os.environ["SIXDOF_NO_STORE_ONLY_COLUMNS"]
+
+
+def test_lane_exchanges_never_land_in_a_guarded_arm_or_a_divergent_loop():
+    """lane_read / lane_read_dyn are __shfl exchanges every lane of the world must execute.  With guard_selects on, an
+    exchange that only an expensive select arm needs is still emitted BEFORE the branch, unconditionally (with what only it needs);
+    the rest of the arm stays guarded.  A data-dependent while loop whose body exchanges a carried value is refused."""
+    from elodin_amd import codegen
+    from elodin_amd.dsl import Expr
+
+    @dsl.system
+    def world(a, b):
+        due = a[0] > 0.5
+        mine = np_.sin(a[1]) * 3.0                                        # needed only by the exchange: outside with it
+        other = Expr("lane_read", (dsl._lift(mine),), (4, (1, 2, 3, 0)))    # what the next entity of this 4-row world holds
+        key = dsl.random.fold_in(dsl.random.key(7), a[2])
+        fresh = b[0] + dsl.random.normal(key, shape=(1,))[0] * other      # expensive arm: threefry + erfinv, and the exchange's value
+        return {"b": np_.array([np_.where(due, fresh, b[0])])}
+    tp = dsl.Program([world], dsl.Pipe([]), []).trace({"a": 3, "b": 1})
+    src = codegen.generate_source(tp, "float64", 2, guard_selects=True)
+    body = src[src.index("// world"):]
+    assert body.count("if (__any(") == 1 and body.count("__shfl(") == 1
+    before, guard = body[:body.index("if (__any(")], body[body.index("if (__any("):]
+    inside = guard[:guard.index("\n        }")]
+    assert "__shfl(" in before and "m_sin(" in before and "__shfl(" not in inside           # the exchange and its operand: every lane
+    assert "m_threefry(" in inside and "m_erfinv(" in inside                                    # the draw itself stays guarded
+
+    @dsl.system
+    def bad(a, b):
+        def cond(s):
+            return s[0] < a[0]
+        def step(s):
+            return (s[0] + Expr("lane_read", (dsl._lift(s[0]),), (4, (1, 2, 3, 0))) + 1.0,)
+        return {"b": np_.array([dsl.lax.while_loop(cond, step, (b[0],))[0]])}
+    tp2 = dsl.Program([bad], dsl.Pipe([]), []).trace({"a": 1, "b": 1})
+    with pytest.raises(NotImplementedError, match="lane exchange"):
+        codegen.generate_source(tp2, "float64", 2)
