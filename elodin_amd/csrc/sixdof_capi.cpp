@@ -107,6 +107,9 @@ struct sixdof_handle {
     std::vector<uint64_t> custom_aux;      // read-only [n,1..3] columns of a generated effector pipe
     std::vector<uint64_t> custom_model;    // read/write [n,1..16] component columns of a generated program
     bool custom_tick_free = false;          // the generated program never looks at the absolute tick (layout bit 17): replayable
+    std::vector<hipStream_t> split_streams;  // side streams of a replay graph split into row-block chains (SIXDOF_GRAPH_SPLIT)
+    std::vector<hipEvent_t> split_joins;
+    hipEvent_t split_fork = nullptr;
     int pair_only_small = -1;               // what the installed pair object was generated for (-1: both launch shapes)
     unsigned custom_rows_multiple = 1;      // rows a world of the generated program occupies (lane mode): the joined row count must be a multiple
     // telemetry ring
@@ -293,6 +296,9 @@ void sixdof_destroy(sixdof_handle* h) try {
     }
     for (void* p : h->pinned_user) (void)hipHostUnregister(p);
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
+    for (auto st : h->split_streams) hipStreamDestroy(st);
+    for (auto ev : h->split_joins) hipEventDestroy(ev);
+    if (h->split_fork) hipEventDestroy(h->split_fork);
     if (h->ev_snap) hipEventDestroy(h->ev_snap);
     if (h->ev_copied) hipEventDestroy(h->ev_copied);
     if (h->d_csr_start) hipFree(h->d_csr_start);
@@ -1287,6 +1293,31 @@ uint64_t step_signature(const sixdof_handle* h, StepParams P, uint32_t K) {
     return sig;
 }
 
+// Row blocks a replayed chain is split into (ensure_graph): SIXDOF_GRAPH_SPLIT=<S>, default 1.  Hand-written pipes only (a
+// generated program's columns have widths of their own), no recording, and at least 4,096 rows per block.
+static const uint32_t kGraphSplit = [] { const char* e = std::getenv("SIXDOF_GRAPH_SPLIT"); const int v = e ? std::atoi(e) : 1; return static_cast<uint32_t>(v < 1 ? 1 : (v > 16 ? 16 : v)); }();
+
+uint32_t graph_split_for(const sixdof_handle* h, const StepParams& P) {
+    if (kGraphSplit <= 1 || h->custom_launch || P.hist_ring || P.n < kGraphSplit * 4096u) return 1;
+    return kGraphSplit;
+}
+
+// The argument block of rows [row0, row0 + rows) of a launch: every column pointer moved to the block's first row.
+StepParams row_block(const sixdof_handle* h, const StepParams& P, uint32_t row0, uint32_t rows) {
+    StepParams Q = P;
+    const size_t es = h->elem_size();
+    auto at = [&](const void* p, size_t width) { return p ? static_cast<const char*>(p) + static_cast<size_t>(row0) * width * es : nullptr; };
+    Q.pos = const_cast<char*>(at(P.pos, 7));
+    Q.vel = const_cast<char*>(at(P.vel, 6));
+    Q.accel = const_cast<char*>(at(P.accel, 6));
+    Q.force = const_cast<char*>(at(P.force, 6));
+    Q.inertia = at(P.inertia, 7);
+    for (uint32_t k = 0; k < P.n_ops && k < static_cast<uint32_t>(kMaxOps); k++)
+        Q.ops[k].aux = at(P.ops[k].aux, P.ops[k].aux_width ? P.ops[k].aux_width : 3);
+    Q.n = rows;
+    return Q;
+}
+
 // An executable graph of `len` identical launches of the step kernel (cached per chain length; all cached graphs share
 // one signature and are dropped together when it changes).
 int ensure_graph(sixdof_handle* h, const StepParams& P, uint32_t K, uint32_t len, hipGraphExec_t* out) {
@@ -1305,9 +1336,41 @@ int ensure_graph(sixdof_handle* h, const StepParams& P, uint32_t K, uint32_t len
         }
     }
     hipGraph_t g = nullptr;
+    const uint32_t S = graph_split_for(h, P);
+    if (S > 1) {      // the side streams and the fork / join events exist before the capture starts
+        while (h->split_streams.size() < S - 1) {
+            hipStream_t s = nullptr;
+            HIP_TRY(h, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            h->split_streams.push_back(s);
+            hipEvent_t e = nullptr;
+            HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->split_joins.push_back(e);
+        }
+        if (!h->split_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->split_fork, hipEventDisableTiming));
+    }
     HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     hipError_t le = hipSuccess;
-    for (uint32_t i = 0; i < len && le == hipSuccess; i++) le = launch_any(h, P);
+    if (S <= 1) {
+        for (uint32_t i = 0; i < len && le == hipSuccess; i++) le = launch_any(h, P);
+    } else {
+        // ROW-BLOCK CHAINS.  Rows are independent and a launch of this path exchanges nothing, so tick k + 1 of a row block
+        // depends on tick k of THAT block only: the replayed graph is S parallel chains of `len` launches, one per contiguous
+        // row block, forked from and joined back into the handle's stream once per replay.  Same kernel, same rows per wave,
+        // same arithmetic -> the same bits; what changes is that one block's end-of-kernel write-back and dispatch gap overlap
+        // another block's loads and math (profiles/r06_k1_floor.md).
+        const uint32_t block = ((P.n + S - 1) / S + 255u) & ~255u;      // whole 256-row groups: every wave shape divides it
+        le = hipEventRecord(h->split_fork, h->stream);
+        for (uint32_t s = 0; s < S && le == hipSuccess; s++) {
+            const uint32_t row0 = s * block;
+            if (row0 >= P.n) break;
+            hipStream_t st = s == 0 ? h->stream : h->split_streams[s - 1];
+            if (s > 0) le = hipStreamWaitEvent(st, h->split_fork, 0);
+            const StepParams Ps = row_block(h, P, row0, std::min(block, P.n - row0));
+            for (uint32_t i = 0; i < len && le == hipSuccess; i++) le = launch_step(Ps, h->desc.integrator, h->desc.dtype, st);
+            if (s > 0 && le == hipSuccess) le = hipEventRecord(h->split_joins[s - 1], st);
+            if (s > 0 && le == hipSuccess) le = hipStreamWaitEvent(h->stream, h->split_joins[s - 1], 0);
+        }
+    }
     hipError_t ce = hipStreamEndCapture(h->stream, &g);
     if (le != hipSuccess) return h->hip_fail(le, "launch_step (capture)");
     if (ce != hipSuccess) return h->hip_fail(ce, "hipStreamEndCapture");

@@ -31,7 +31,8 @@ def test_every_allocating_entry_point_is_behind_the_exception_barrier():
     no allocator and the three pure-arithmetic functions.  A new entry point that forgets the barrier fails here."""
     import re
     sig = re.compile(r"^(const char\*|void\*?|int|uint64_t|uint32_t|size_t|double|sixdof_\w+\*) (sixdof_\w+)\(")
-    pure = {"sixdof_component_id", "sixdof_quantize_time_step", "sixdof_shard_range"}      # integer / float arithmetic only
+    pure = {"sixdof_component_id", "sixdof_quantize_time_step", "sixdof_shard_range",               # integer / float arithmetic only
+            "sixdof_gather_block_rows", "sixdof_gather_pack", "sixdof_gather_unpack"}                    # ... and memcpy into caller buffers
     guarded, bare = [], []
     for name in ("sixdof_capi.cpp", "world.cpp", "telemetry_sink.cpp", "campaign_comm.cpp"):
         lines = (CSRC / name).read_text().split("\n")
