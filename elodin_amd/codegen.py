@@ -1439,11 +1439,9 @@ extern "C" int sixdof_custom_pair_launch(const sixdof::PairParams* p, int integr
     if constexpr (kOnlySmall != 0) {{
         if (small) return static_cast<int>(launch_pair_small_t<PairCustom, kOnlyIntegrator>(*p, integrator, n_ticks, s, launches));
     }}
-    if constexpr (kOnlySmall != 1) {{
-        for (uint32_t t = 0; t < n_ticks; t++) {{
-            const hipError_t e = launch_pair_tick_t<PairCustom, false, kOnlyIntegrator>(*p, integrator, s, launches);
-            if (e != hipSuccess) return static_cast<int>(e);
-        }}
+    if constexpr (kOnlySmall != 1) {{      // one pack launch (unless p->packed), then fold + integrate per tick
+        const hipError_t e = launch_pair_ticks_t<PairCustom, false, kOnlyIntegrator>(*p, integrator, n_ticks, p->packed != 0, s, launches);
+        if (e != hipSuccess) return static_cast<int>(e);
     }}
     return static_cast<int>(hipSuccess);
 }}

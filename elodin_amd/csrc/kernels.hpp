@@ -103,10 +103,15 @@ struct PairParams {
     double p0, p1;        // G | K, eps
     uint32_t n_ops;       // per-entity ops applied BEFORE the pair op (pipe order); they survive only on
     DevOp ops[kMaxOps];   // rows that are not edge sources (edge_fold replaces Force on source rows)
+    // 1: `pack` already holds the rows of the current state (the previous tick's integrate kernel wrote them, and nothing has
+    // touched pos / vel / inertia since): the batch starts without a pack launch.  Set by the caller inside ONE step call only —
+    // between calls a host may write the columns (upload, sixdof_device_column), so every call packs once.
+    uint32_t packed;
 };
 // Picks the number of source splits for n targets so the all-pairs grid fills 256 CUs.
 uint32_t pair_splits_for(uint32_t n);
-hipError_t launch_pair_tick(const PairParams& p, int integrator, hipStream_t stream, uint64_t* launches);
+// n_ticks ticks: one pack launch (unless p.packed), then fold + integrate per tick (the integrate kernel writes the next pack rows).
+hipError_t launch_pair_ticks(const PairParams& p, int integrator, uint32_t n_ticks, hipStream_t stream, uint64_t* launches);
 // n <= kPairSmallMax: pack, fold and integrate n_ticks ticks in one single-workgroup launch (bit-identical results).
 constexpr uint32_t kPairSmallMax = 256;
 constexpr uint32_t kHubDegree = 32;    // a source with this many out-edges or more is a hub

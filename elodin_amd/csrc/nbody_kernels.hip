@@ -12,10 +12,11 @@ hipError_t launch_pair_small(const PairParams& p, int integrator, uint32_t n_tic
     return launch_pair_small_t<PairSoftened>(p, integrator, n_ticks, stream, launches);
 }
 
-hipError_t launch_pair_tick(const PairParams& p, int integrator, hipStream_t stream, uint64_t* launches) {
-    if (p.pair_kind == SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED) return launch_pair_tick_t<PairSoftened, true>(p, integrator, stream, launches);
-    if (p.pair_kind == SIXDOF_EFF_EDGE_GRAVITY_NEWTON) return launch_pair_tick_t<PairNewton, false>(p, integrator, stream, launches);
-    return launch_pair_tick_t<PairSoftened, false>(p, integrator, stream, launches);
+hipError_t launch_pair_ticks(const PairParams& p, int integrator, uint32_t n_ticks, hipStream_t stream, uint64_t* launches) {
+    const bool packed = p.packed != 0;
+    if (p.pair_kind == SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED) return launch_pair_ticks_t<PairSoftened, true>(p, integrator, n_ticks, packed, stream, launches);
+    if (p.pair_kind == SIXDOF_EFF_EDGE_GRAVITY_NEWTON) return launch_pair_ticks_t<PairNewton, false>(p, integrator, n_ticks, packed, stream, launches);
+    return launch_pair_ticks_t<PairSoftened, false>(p, integrator, n_ticks, packed, stream, launches);
 }
 
 }  // namespace sixdof

@@ -14,12 +14,15 @@
 // velocity only (rk4.rs:95-121: x_s = x0 (+) c*dt*v0), and gravity reads positions and masses only,
 // so all stage forces of a tick are known from (x0, v0) before any acceleration is: F(c=0),
 // F(c=1/2) (shared by stages 1 and 2, bit-identical) and F(c=1).  One tick is therefore
-//   1. pair_pack_kernel      per source: p(c=0), p(c=1/2), p(c=1), mass -> pack[n,10]
+//   1. pair_pack_kernel      per source: p(c=0), p(c=1/2), p(c=1), mass -> pack[n,10]   (FIRST tick of a batch only)
 //   2. allpairs_kernel       LDS-tiled all-pairs: every (target, source) pair is visited ONCE and
 //      / edge_kernel         accumulates the three stage forces together (3 independent FMA chains)
 //   3. pair_integrate_kernel per entity: reduce the source splits in fixed order, calc_accel on each
-//                            stage, RK4 combination, write pos / vel / accel / force.
-// instead of four dependent all-pairs sweeps.  Bound: f64 vector ALU (about 21 instructions per pair
+//                            stage, RK4 combination, write pos / vel / accel / force — and the NEXT tick's pack row
+//                            from the state it has just formed, so a batch of ticks is pack + 2 launches per tick.
+// instead of four dependent all-pairs sweeps.  Kernels 1 and 3 use the step kernel's memory plan (step_kernel.hpp):
+// single-wave workgroups own 64 consecutive rows, whole slabs move HBM <-> LDS 16 B per lane (LDS-DMA on the way in), a lane
+// reads / writes its own row in LDS — no 56- / 48-byte-strided global access is left on the path.  Bound: f64 vector ALU (about 21 instructions per pair
 // evaluation, of which one v_rsq_f64 + refinement); bytes are negligible.  MFMA is not used: gfx950's
 // f64 MFMA rate equals its f64 vector rate, and the |ri|^2+|rj|^2-2 ri.rj form a dense tile would
 // need cancels catastrophically for close pairs, breaking the 1e-9 parity bar.
@@ -31,6 +34,7 @@
 #include "effectors.hpp"
 #include "kernels.hpp"
 #include "spatial.hpp"
+#include "step_kernel.hpp"      // slab_dma_in / slab_out / the ragged-tail movers
 
 namespace sixdof {
 
@@ -70,21 +74,49 @@ struct PairSoftened {   // examples/n-body/sim.py:356-361: acc + SpatialForce(li
 };
 
 // ---- 1. pack ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pair_pack_kernel(const double* __restrict__ pos, const double* __restrict__ vel,
-                                                        const double* __restrict__ inertia, double* __restrict__ pack,
-                                                        uint32_t n, double h1, double h3) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const double* x = pos + (size_t)j * 7 + 4;
-    const double* v = vel + (size_t)j * 6 + 3;
-    double* o = pack + (size_t)j * kPackWidth;
+// One pack row from a body's position, linear velocity and mass — the one expression every path shares (this kernel, the
+// integrate kernel's next-tick rows, the one-launch small-graph kernel), so they agree bit for bit.
+__device__ __forceinline__ void pack_row(double* o, const double (&x)[3], const double (&v)[3], double mass, double h1, double h3) {
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         o[c] = x[c];
         o[3 + c] = x[c] + h1 * v[c];  // linear half of SpatialTransform + SpatialMotion (spatial.rs:546)
         o[6 + c] = x[c] + h3 * v[c];
     }
-    o[9] = inertia[(size_t)j * 7 + 6];
+    o[9] = mass;
+}
+
+// Single-wave workgroups, 64 rows each: pos / vel slabs by LDS-DMA, the pack rows leave as one 5,120-byte slab.  (The mass is
+// one double of a 56-byte inertia row: read per lane — a slab would move seven times the bytes for it.)
+__global__ __launch_bounds__(kWave) void pair_pack_kernel(const double* __restrict__ pos, const double* __restrict__ vel,
+                                                          const double* __restrict__ inertia, double* __restrict__ pack,
+                                                          uint32_t n, double h1, double h3) {
+    __shared__ __attribute__((aligned(16))) double lds[kWave * (7 + 6)];
+    double* const l_pos = lds;
+    double* const l_vel = lds + kWave * 7;
+    const uint32_t row0 = blockIdx.x * kWave, t = threadIdx.x;
+    const uint32_t rows = min((uint32_t)kWave, n - row0);
+    const bool full = rows == kWave, active = t < rows;
+    if (full) {
+        slab_dma_in<kWave * 7 * 8, kPolPlain>(reinterpret_cast<const char*>(pos + (size_t)row0 * 7), reinterpret_cast<char*>(l_pos), t);
+        slab_dma_in<kWave * 6 * 8, kPolPlain>(reinterpret_cast<const char*>(vel + (size_t)row0 * 6), reinterpret_cast<char*>(l_vel), t);
+    } else {
+        slab_in_tail(pos + (size_t)row0 * 7, l_pos, rows * 7, t);
+        slab_in_tail(vel + (size_t)row0 * 6, l_vel, rows * 6, t);
+    }
+    const double mass = active ? inertia[(size_t)(row0 + t) * 7 + 6] : 0.0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    double x[3] = {0, 0, 0}, v[3] = {0, 0, 0};
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { x[c] = l_pos[t * 7 + 4 + c]; v[c] = l_vel[t * 6 + 3 + c]; }
+    }
+    __syncthreads();      // the input slabs are consumed: the same LDS stages the pack rows (10 <= 13 doubles per row)
+    if (active) pack_row(lds + t * kPackWidth, x, v, mass, h1, h3);
+    __syncthreads();
+    if (full) slab_out<kWave * kPackWidth * 8, kPolPlain>(reinterpret_cast<const char*>(lds), reinterpret_cast<char*>(pack + (size_t)row0 * kPackWidth), t);
+    else slab_out_tail(lds, pack + (size_t)row0 * kPackWidth, rows * kPackWidth, t);
 }
 
 // ---- 2a. all-pairs, softened (examples/n-body/sim.py:344-369) -------------------------------------------
@@ -379,39 +411,138 @@ __device__ __forceinline__ void store_entity(const PairParams& P, uint32_t i, co
     fo[0] = Fw.ang.x; fo[1] = Fw.ang.y; fo[2] = Fw.ang.z; fo[3] = Fw.lin.x; fo[4] = Fw.lin.y; fo[5] = Fw.lin.z;
 }
 
-template <int INTEGRATOR>
-__global__ __launch_bounds__(256) void pair_integrate_kernel(const PairParams P) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
-    EntityState e;
+// The per-entity ops' view of PairParams and this row's effector columns (24-byte rows, read per lane like the step kernel).
+__device__ __forceinline__ void load_ops(const PairParams& P, uint32_t i, bool active, StepParams& SP, Vec3<double> (&aux)[kMaxOps]) {
+    SP.n_ops = P.n_ops;
+    SP.vel_independent = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxOps; k++) SP.ops[k] = P.ops[k];
+#pragma unroll
+    for (int k = 0; k < kMaxOps; k++) {
+        aux[k] = Vec3<double>{0, 0, 0};
+        if (active && k < (int)P.n_ops && P.ops[k].aux != nullptr) {
+            const double* a = static_cast<const double*>(P.ops[k].aux) + (size_t)i * 3;
+            aux[k] = Vec3<double>{a[0], a[1], a[2]};
+        }
+    }
+}
+
+// Single-wave workgroups, 64 rows each (the step kernel's memory plan): pos / vel / inertia / world_accel — and, for edge
+// lists, the fold's [64, 18] partial rows — come in as slabs by LDS-DMA; pos / vel / accel / force and the NEXT tick's pack rows
+// leave as slabs.  The arithmetic is load_entity / pair_integrate_entity / pack_row, i.e. exactly the one-launch small-graph
+// kernel's: the two paths stay bit-identical (tests/test_gpu_parity.py::test_small_graph_single_launch_path_is_bit_identical).
+// (1.0 / x stays an IEEE divide here — four per entity and launch — because recip() may differ from it in the last bit.)
+template <int INTEGRATOR, bool PACK_NEXT>
+__global__ __launch_bounds__(kWave) void pair_integrate_kernel(const PairParams P) {
+    // in: pos 7 | vel 6 | inertia 7 | accel 6 | partial 18 = 44 doubles per row; out: pos 7 | vel 6 | accel 6 | force 6 | pack 10 = 35
+    __shared__ __attribute__((aligned(16))) double lds[kWave * 44];
+    double* const l_pos = lds;
+    double* const l_vel = lds + kWave * 7;
+    double* const l_in = lds + kWave * 13;
+    double* const l_acc = lds + kWave * 20;
+    double* const l_part = lds + kWave * 26;
+    const uint32_t row0 = blockIdx.x * kWave, t = threadIdx.x, i = row0 + t;
+    const uint32_t rows = min((uint32_t)kWave, P.n - row0);
+    const bool full = rows == kWave, active = t < rows;
+    double* const g_pos = static_cast<double*>(P.pos) + (size_t)row0 * 7;
+    double* const g_vel = static_cast<double*>(P.vel) + (size_t)row0 * 6;
+    double* const g_acc = static_cast<double*>(P.accel) + (size_t)row0 * 6;
+    double* const g_force = static_cast<double*>(P.force) + (size_t)row0 * 6;
+    const double* const g_in = static_cast<const double*>(P.inertia) + (size_t)row0 * 7;
+    const bool edge_partial = P.partial_width != kPartialForce;      // wave-uniform
+    const double* const g_part = P.partial + (size_t)row0 * kPartialWidth;
+    if (full) {
+        slab_dma_in<kWave * 7 * 8, kPolPlain>(reinterpret_cast<const char*>(g_pos), reinterpret_cast<char*>(l_pos), t);
+        slab_dma_in<kWave * 6 * 8, kPolPlain>(reinterpret_cast<const char*>(g_vel), reinterpret_cast<char*>(l_vel), t);
+        slab_dma_in<kWave * 7 * 8, kPolPlain>(reinterpret_cast<const char*>(g_in), reinterpret_cast<char*>(l_in), t);
+        slab_dma_in<kWave * 6 * 8, kPolPlain>(reinterpret_cast<const char*>(g_acc), reinterpret_cast<char*>(l_acc), t);
+        if (edge_partial) slab_dma_in<kWave * kPartialWidth * 8, kPolNt>(reinterpret_cast<const char*>(g_part), reinterpret_cast<char*>(l_part), t);
+    } else {
+        slab_in_tail(g_pos, l_pos, rows * 7, t);
+        slab_in_tail(g_vel, l_vel, rows * 6, t);
+        slab_in_tail(g_in, l_in, rows * 7, t);
+        slab_in_tail(g_acc, l_acc, rows * 6, t);
+        if (edge_partial) slab_in_tail(g_part, l_part, rows * kPartialWidth, t);
+    }
     StepParams SP;
     Vec3<double> aux[kMaxOps];
-    load_entity(P, i, e, SP, aux);
-    const bool is_source = P.pair_kind == SIXDOF_EFF_ALLPAIRS_GRAVITY_SOFTENED
-                               ? (P.n > 1)
-                               : (P.row_start[i + 1] > P.row_start[i]);
+    load_ops(P, i, active, SP, aux);
     constexpr int NS = INTEGRATOR == kRk4 ? 3 : 1;
     double pf[3][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
-    if (P.partial_width == kPartialForce) {
-        for (uint32_t s = 0; s < P.splits; s++) {  // fixed order: deterministic
-            const double* part = P.partial + ((size_t)s * P.n + i) * kPartialForce;
+    bool is_source = false;
+    if (active) {
+        if (!edge_partial) {      // all-pairs: `splits` partial sums of 72 bytes each, added in fixed order (deterministic)
+            is_source = P.n > 1;
+            for (uint32_t sp = 0; sp < P.splits; sp++) {
+                const double* part = P.partial + ((size_t)sp * P.n + i) * kPartialForce;
+#pragma unroll
+                for (int st = 0; st < NS; st++)
+                    for (int c = 0; c < 3; c++) pf[st][3 + c] += part[3 * st + c];
+            }
+        } else {
+            is_source = P.row_start[i + 1] > P.row_start[i];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA data has landed
+    __syncthreads();
+    EntityState e;
+    Spatial<double> A = {{0, 0, 0}, {0, 0, 0}}, Fw = {{0, 0, 0}, {0, 0, 0}};
+    if (active) {
+        const double* pos = l_pos + t * 7;
+        const double* vel = l_vel + t * 6;
+        const double* in = l_in + t * 7;
+        e.q0 = {pos[0], pos[1], pos[2], pos[3]};
+        e.p0 = {pos[4], pos[5], pos[6]};
+        e.v0 = {{vel[0], vel[1], vel[2]}, {vel[3], vel[4], vel[5]}};
+        e.I = {in[0], in[1], in[2]};
+        e.inv_I = {1.0 / in[0], 1.0 / in[1], 1.0 / in[2]};
+        e.mass = in[6];
+        e.inv_m = 1.0 / in[6];
+        const double* ac = l_acc + t * 6;
+        A = Spatial<double>{{ac[0], ac[1], ac[2]}, {ac[3], ac[4], ac[5]}};
+        if (edge_partial) {
+            const double* part = l_part + t * kPartialWidth;
 #pragma unroll
             for (int st = 0; st < NS; st++)
-                for (int c = 0; c < 3; c++) pf[st][3 + c] += part[3 * st + c];
+                for (int c = 0; c < 6; c++) pf[st][c] = part[6 * st + c];
         }
+    }
+    __syncthreads();  // every lane has consumed the input slabs; LDS is the output staging area from here on
+    if (active) pair_integrate_entity<INTEGRATOR>(P, SP, aux, pf, is_source, e, A, Fw);
+    double* const o_pos = lds;
+    double* const o_vel = lds + kWave * 7;
+    double* const o_acc = lds + kWave * 13;
+    double* const o_force = lds + kWave * 19;
+    double* const o_pack = lds + kWave * 25;
+    if (active) {
+        double* r = o_pos + t * 7;
+        r[0] = e.q0.i; r[1] = e.q0.j; r[2] = e.q0.k; r[3] = e.q0.w; r[4] = e.p0.x; r[5] = e.p0.y; r[6] = e.p0.z;
+        double* v = o_vel + t * 6;
+        v[0] = e.v0.ang.x; v[1] = e.v0.ang.y; v[2] = e.v0.ang.z; v[3] = e.v0.lin.x; v[4] = e.v0.lin.y; v[5] = e.v0.lin.z;
+        double* a = o_acc + t * 6;
+        a[0] = A.ang.x; a[1] = A.ang.y; a[2] = A.ang.z; a[3] = A.lin.x; a[4] = A.lin.y; a[5] = A.lin.z;
+        double* f = o_force + t * 6;
+        f[0] = Fw.ang.x; f[1] = Fw.ang.y; f[2] = Fw.ang.z; f[3] = Fw.lin.x; f[4] = Fw.lin.y; f[5] = Fw.lin.z;
+        if constexpr (PACK_NEXT) {
+            const double x[3] = {e.p0.x, e.p0.y, e.p0.z}, vl[3] = {e.v0.lin.x, e.v0.lin.y, e.v0.lin.z};
+            pack_row(o_pack + t * kPackWidth, x, vl, e.mass, P.dt_g * 0.5, P.dt_g);
+        }
+    }
+    __syncthreads();
+    double* const g_pack = P.pack + (size_t)row0 * kPackWidth;
+    if (full) {
+        slab_out<kWave * 7 * 8, kPolPlain>(reinterpret_cast<const char*>(o_pos), reinterpret_cast<char*>(g_pos), t);
+        slab_out<kWave * 6 * 8, kPolPlain>(reinterpret_cast<const char*>(o_vel), reinterpret_cast<char*>(g_vel), t);
+        slab_out<kWave * 6 * 8, kPolPlain>(reinterpret_cast<const char*>(o_acc), reinterpret_cast<char*>(g_acc), t);
+        slab_out<kWave * 6 * 8, kPolNtStores>(reinterpret_cast<const char*>(o_force), reinterpret_cast<char*>(g_force), t);   // written, never read back
+        if constexpr (PACK_NEXT) slab_out<kWave * kPackWidth * 8, kPolPlain>(reinterpret_cast<const char*>(o_pack), reinterpret_cast<char*>(g_pack), t);
     } else {
-        const double* part = P.partial + (size_t)i * kPartialWidth;   // edge lists: one split
-#pragma unroll
-        for (int st = 0; st < NS; st++)
-            for (int c = 0; c < 6; c++) pf[st][c] = part[6 * st + c];
+        slab_out_tail(o_pos, g_pos, rows * 7, t);
+        slab_out_tail(o_vel, g_vel, rows * 6, t);
+        slab_out_tail(o_acc, g_acc, rows * 6, t);
+        slab_out_tail(o_force, g_force, rows * 6, t);
+        if constexpr (PACK_NEXT) slab_out_tail(o_pack, g_pack, rows * kPackWidth, t);
     }
-    Spatial<double> A, Fw;
-    {
-        const double* ac = static_cast<const double*>(P.accel) + (size_t)i * 6;
-        A = Spatial<double>{{ac[0], ac[1], ac[2]}, {ac[3], ac[4], ac[5]}};
-    }
-    pair_integrate_entity<INTEGRATOR>(P, SP, aux, pf, is_source, e, A, Fw);
-    store_entity(P, i, e, A, Fw);
 }
 
 // ---- small graphs: the whole tick (and n_ticks of them) in ONE single-workgroup launch --------------------------
@@ -448,15 +579,8 @@ __global__ __launch_bounds__(kTile) void pair_small_kernel(const PairParams P, u
     }
     for (uint32_t t = 0; t < n_ticks; t++) {
         if (active) {
-            double* o = pack + i * kPackWidth;
             const double x[3] = {e.p0.x, e.p0.y, e.p0.z}, v[3] = {e.v0.lin.x, e.v0.lin.y, e.v0.lin.z};
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                o[c] = x[c];
-                o[3 + c] = x[c] + h1 * v[c];
-                o[6 + c] = x[c] + h3 * v[c];
-            }
-            o[9] = e.mass;
+            pack_row(pack + i * kPackWidth, x, v, e.mass, h1, h3);
         }
         __syncthreads();
         double pf[3][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
@@ -517,40 +641,55 @@ inline hipError_t launch_pair_small_t(const PairParams& p, int integrator, uint3
     return hipGetLastError();
 }
 
-// One tick as pack -> fold -> integrate.  ALLPAIRS selects the tiled complete-graph kernel (softened gravity).
+// A batch of ticks: pack once (unless the caller says `pack` already holds the rows of the current state: `packed`), then per
+// tick fold -> integrate, the integrate kernel writing the next tick's pack rows.  ALLPAIRS selects the tiled complete-graph
+// kernel (softened gravity).  `last_packs`: the final tick also leaves its pack rows (so a following batch may skip the pack).
+template <class PAIR, bool ALLPAIRS, int ONLY = -1>
+inline hipError_t launch_pair_ticks_t(const PairParams& p, int integrator, uint32_t n_ticks, bool packed, hipStream_t stream, uint64_t* launches) {
+    if (p.n == 0 || n_ticks == 0) return hipSuccess;
+    if (ONLY >= 0 && integrator != ONLY) return hipErrorInvalidValue;
+    const uint32_t blocks = (p.n + 255) / 256, waves = (p.n + kWave - 1) / kWave;
+    const double h1 = p.dt_g * 0.5, h3 = p.dt_g;
+    if (!packed) {
+        hipLaunchKernelGGL(pair_pack_kernel, dim3(waves), dim3(kWave), 0, stream, static_cast<const double*>(p.pos),
+                           static_cast<const double*>(p.vel), static_cast<const double*>(p.inertia), p.pack, p.n, h1, h3);
+        if (launches) *launches += 1;
+    }
+    const bool rk4 = integrator == kRk4;
+    for (uint32_t t = 0; t < n_ticks; t++) {
+        if constexpr (ALLPAIRS) {
+            const dim3 grid((p.n + kTile - 1) / kTile, p.splits);
+            if constexpr (ONLY != kSemiImplicit) { if (rk4) hipLaunchKernelGGL(allpairs_kernel<3>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1); }
+            if constexpr (ONLY != kRk4) { if (!rk4) hipLaunchKernelGGL(allpairs_kernel<1>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1); }
+        } else {
+            const uint32_t hubs = PAIR::kAdditive ? p.n_hubs : 0u;   // a fold that is not a plain sum stays sequential per source
+            if constexpr (ONLY != kSemiImplicit) { if (rk4) hipLaunchKernelGGL((edge_kernel<3, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1, hubs); }
+            if constexpr (ONLY != kRk4) { if (!rk4) hipLaunchKernelGGL((edge_kernel<1, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1, hubs); }
+            if (hubs) {
+                if constexpr (ONLY != kSemiImplicit) if (rk4) {
+                    hipLaunchKernelGGL((edge_hub_chunk_kernel<3, PAIR>), dim3(p.n_hub_chunks), dim3(64), 0, stream, p.pack, p.row_start, p.dst, p.chunk_e0, p.chunk_row, p.chunk_partial, p.p0, p.p1);
+                    hipLaunchKernelGGL(edge_hub_reduce_kernel<3>, dim3(hubs), dim3(64), 0, stream, p.hub_rows, p.hub_chunk_start, p.chunk_partial, p.partial);
+                }
+                if constexpr (ONLY != kRk4) if (!rk4) {
+                    hipLaunchKernelGGL((edge_hub_chunk_kernel<1, PAIR>), dim3(p.n_hub_chunks), dim3(64), 0, stream, p.pack, p.row_start, p.dst, p.chunk_e0, p.chunk_row, p.chunk_partial, p.p0, p.p1);
+                    hipLaunchKernelGGL(edge_hub_reduce_kernel<1>, dim3(hubs), dim3(64), 0, stream, p.hub_rows, p.hub_chunk_start, p.chunk_partial, p.partial);
+                }
+                if (launches) *launches += 2;
+            }
+        }
+        // every tick writes the next tick's pack rows (5 KB per wave beside the 12.5 KB of state it writes anyway): the last tick's
+        // are what lets the NEXT batch skip its pack launch when nothing touched the state in between
+        if constexpr (ONLY != kSemiImplicit) { if (rk4) hipLaunchKernelGGL((pair_integrate_kernel<kRk4, true>), dim3(waves), dim3(kWave), 0, stream, p); }
+        if constexpr (ONLY != kRk4) { if (!rk4) hipLaunchKernelGGL((pair_integrate_kernel<kSemiImplicit, true>), dim3(waves), dim3(kWave), 0, stream, p); }
+        if (launches) *launches += 2;
+    }
+    return hipGetLastError();
+}
+
+// One tick on its own (pack -> fold -> integrate).
 template <class PAIR, bool ALLPAIRS, int ONLY = -1>
 inline hipError_t launch_pair_tick_t(const PairParams& p, int integrator, hipStream_t stream, uint64_t* launches) {
-    if (p.n == 0) return hipSuccess;
-    if (ONLY >= 0 && integrator != ONLY) return hipErrorInvalidValue;
-    const uint32_t blocks = (p.n + 255) / 256;
-    const double h1 = p.dt_g * 0.5, h3 = p.dt_g;
-    hipLaunchKernelGGL(pair_pack_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<const double*>(p.pos),
-                       static_cast<const double*>(p.vel), static_cast<const double*>(p.inertia), p.pack, p.n, h1, h3);
-    const bool rk4 = integrator == kRk4;
-    if constexpr (ALLPAIRS) {
-        const dim3 grid((p.n + kTile - 1) / kTile, p.splits);
-        if constexpr (ONLY != kSemiImplicit) { if (rk4) hipLaunchKernelGGL(allpairs_kernel<3>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1); }
-        if constexpr (ONLY != kRk4) { if (!rk4) hipLaunchKernelGGL(allpairs_kernel<1>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1); }
-    } else {
-        const uint32_t hubs = PAIR::kAdditive ? p.n_hubs : 0u;   // a fold that is not a plain sum stays sequential per source
-        if constexpr (ONLY != kSemiImplicit) { if (rk4) hipLaunchKernelGGL((edge_kernel<3, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1, hubs); }
-        if constexpr (ONLY != kRk4) { if (!rk4) hipLaunchKernelGGL((edge_kernel<1, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1, hubs); }
-        if (hubs) {
-            if constexpr (ONLY != kSemiImplicit) if (rk4) {
-                hipLaunchKernelGGL((edge_hub_chunk_kernel<3, PAIR>), dim3(p.n_hub_chunks), dim3(64), 0, stream, p.pack, p.row_start, p.dst, p.chunk_e0, p.chunk_row, p.chunk_partial, p.p0, p.p1);
-                hipLaunchKernelGGL(edge_hub_reduce_kernel<3>, dim3(hubs), dim3(64), 0, stream, p.hub_rows, p.hub_chunk_start, p.chunk_partial, p.partial);
-            }
-            if constexpr (ONLY != kRk4) if (!rk4) {
-                hipLaunchKernelGGL((edge_hub_chunk_kernel<1, PAIR>), dim3(p.n_hub_chunks), dim3(64), 0, stream, p.pack, p.row_start, p.dst, p.chunk_e0, p.chunk_row, p.chunk_partial, p.p0, p.p1);
-                hipLaunchKernelGGL(edge_hub_reduce_kernel<1>, dim3(hubs), dim3(64), 0, stream, p.hub_rows, p.hub_chunk_start, p.chunk_partial, p.partial);
-            }
-            if (launches) *launches += 2;
-        }
-    }
-    if constexpr (ONLY != kSemiImplicit) { if (rk4) hipLaunchKernelGGL(pair_integrate_kernel<kRk4>, dim3(blocks), dim3(256), 0, stream, p); }
-    if constexpr (ONLY != kRk4) { if (!rk4) hipLaunchKernelGGL(pair_integrate_kernel<kSemiImplicit>, dim3(blocks), dim3(256), 0, stream, p); }
-    if (launches) *launches += 3;
-    return hipGetLastError();
+    return launch_pair_ticks_t<PAIR, ALLPAIRS, ONLY>(p, integrator, 1, false, stream, launches);
 }
 
 }  // namespace sixdof

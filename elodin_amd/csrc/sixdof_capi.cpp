@@ -1486,6 +1486,7 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) try {
                 hipError_t e = static_cast<hipError_t>(h->pair_launch(&P, h->desc.integrator, k, small ? 1 : 0, h->stream, &launches));
                 if (e != hipSuccess) return h->hip_fail(e, "custom pair launch");
                 done += k;
+                P.packed = 1;      // the integrate kernel left the next tick's pack rows (this call only: PairParams::packed)
                 if (int src = snapshot_tick_to_ring(h, h->tick + done); src != SIXDOF_OK) return src;
             }
         } else if (P.n <= kPairSmallMax && !(no_small && no_small[0] == '0')) {   // small graphs: ticks_per_launch ticks per launch
@@ -1498,10 +1499,16 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) try {
                 if (int src = snapshot_tick_to_ring(h, h->tick + done); src != SIXDOF_OK) return src;
             }
         } else {
-            for (uint64_t t = 0; t < n_ticks; t++) {
-                hipError_t e = launch_pair_tick(P, h->desc.integrator, h->stream, &launches);
-                if (e != hipSuccess) return h->hip_fail(e, "launch_pair_tick");
-                if (int src = snapshot_tick_to_ring(h, h->tick + t + 1); src != SIXDOF_OK) return src;
+            // a batch is ONE pack launch, then fold + integrate per tick (the integrate kernel writes the next tick's pack rows);
+            // with a telemetry ring the batch is cut at every tick for the snapshot, the pack rows carry over all the same
+            const uint32_t K = h->hist_ring ? 1u : 1u << 20;
+            for (uint64_t done = 0; done < n_ticks;) {
+                const uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(K, n_ticks - done));
+                hipError_t e = launch_pair_ticks(P, h->desc.integrator, k, h->stream, &launches);
+                if (e != hipSuccess) return h->hip_fail(e, "launch_pair_ticks");
+                done += k;
+                P.packed = 1;
+                if (int src = snapshot_tick_to_ring(h, h->tick + done); src != SIXDOF_OK) return src;
             }
         }
     } else {

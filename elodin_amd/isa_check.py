@@ -37,15 +37,18 @@ def disassemble(so: Path, strict: bool = True) -> str:
     with tempfile.TemporaryDirectory() as t:
         subprocess.run(["cp", str(so), f"{t}/k.so"], check=True)
         ex = subprocess.run([OBJDUMP, "--offloading", "k.so"], cwd=t, capture_output=True, text=True)
-        dev = list(Path(t).glob("k.so.0.hipv4*"))
+        dev = sorted(Path(t).glob("k.so.*.hipv4*"))      # one bundle per translation unit of the library
         if not dev:
             if strict and b"\x7fELF" == Path(t, "k.so").read_bytes()[:4] and Path(t, "k.so").read_bytes()[18:20] != (224).to_bytes(2, "little"):
                 raise IsaCheckError(f"{so}: no offload bundle could be extracted (llvm-objdump --offloading rc {ex.returncode}: {ex.stderr.strip()[:200]})")
             dev = [Path(t) / "k.so"]                      # e_machine 224 = EM_AMDGPU: a bare code object
-        r = subprocess.run([OBJDUMP, "-d", "--symbolize-operands", "--no-show-raw-insn", str(dev[0])], capture_output=True, text=True)
-        if strict and (r.returncode != 0 or "elf64-amdgpu" not in r.stdout[:400]):
-            raise IsaCheckError(f"{so}: llvm-objdump -d rc {r.returncode}, not an amdgpu disassembly: {r.stderr.strip()[:200]}")
-        return r.stdout
+        out = []
+        for d in dev:
+            r = subprocess.run([OBJDUMP, "-d", "--symbolize-operands", "--no-show-raw-insn", str(d)], capture_output=True, text=True)
+            if strict and (r.returncode != 0 or "elf64-amdgpu" not in r.stdout[:400]):
+                raise IsaCheckError(f"{so}: llvm-objdump -d rc {r.returncode}, not an amdgpu disassembly: {r.stderr.strip()[:200]}")
+            out.append(r.stdout)
+        return "\n".join(out)
 
 
 def check_object(so: Path, reported_vgpr_spills: int = 0):
