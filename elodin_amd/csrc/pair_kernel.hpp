@@ -190,12 +190,30 @@ __global__ __launch_bounds__(kTile) void allpairs_kernel(const double* __restric
 
 // ---- 2b. explicit edge list, CSR by source (three-body and sparse graphs) ---------------------------------
 // One source's left fold over its out-edges (CSR range), spawn order, for the NS stage positions.
+// A lane's edges are independent GATHERS feeding one dependent fold: with one wave per SIMD (65,536 sources = 1,024 waves) nothing
+// hides a gather's round trip, so the targets' pack rows are fetched kEdgeBatch edges at a time — all their loads in flight
+// together — and folded in order afterwards.  Same operations in the same order: the bits do not change.
+constexpr int kEdgeBatch = 4;
 template <int NS, class PAIR>
 __device__ __forceinline__ void edge_accumulate_range(const double* pack, uint32_t e0, uint32_t e1, const uint32_t* dst,
                                                       uint32_t i, double p0, double p1, double (&acc)[3][6]) {
     const double* a = pack + (size_t)i * kPackWidth;
     const double ma = a[9];
-    for (uint32_t e = e0; e < e1; e++) {  // spawn order inside a source
+    uint32_t e = e0;
+    for (; e + kEdgeBatch <= e1; e += kEdgeBatch) {
+        double rows[kEdgeBatch][kPackWidth];
+#pragma unroll
+        for (int u = 0; u < kEdgeBatch; u++) {
+            const double* b = pack + (size_t)dst[e + u] * kPackWidth;
+#pragma unroll
+            for (int k = 0; k < kPackWidth; k++) rows[u][k] = (k < 3 * NS || k == 9) ? b[k] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kEdgeBatch; u++)
+#pragma unroll
+            for (int st = 0; st < NS; st++) PAIR::fold(acc[st], a + 3 * st, ma, rows[u] + 3 * st, rows[u][9], p0, p1);
+    }
+    for (; e < e1; e++) {  // spawn order inside a source
         const double* b = pack + (size_t)dst[e] * kPackWidth;
         const double mb = b[9];
 #pragma unroll
@@ -207,14 +225,7 @@ template <int NS, class PAIR>
 __device__ __forceinline__ void edge_accumulate(const double* pack, const uint32_t* __restrict__ row_start,
                                                 const uint32_t* __restrict__ dst, uint32_t i, double p0, double p1,
                                                 double (&acc)[3][6]) {
-    const double* a = pack + (size_t)i * kPackWidth;
-    const double ma = a[9];
-    for (uint32_t e = row_start[i]; e < row_start[i + 1]; e++) {  // spawn order inside a source
-        const double* b = pack + (size_t)dst[e] * kPackWidth;
-        const double mb = b[9];
-#pragma unroll
-        for (int st = 0; st < NS; st++) PAIR::fold(acc[st], a + 3 * st, ma, b + 3 * st, mb, p0, p1);
-    }
+    edge_accumulate_range<NS, PAIR>(pack, row_start[i], row_start[i + 1], dst, i, p0, p1, acc);
 }
 
 // `skip_hubs`: sources with kHubDegree or more out-edges are left to the hub kernels (2c), which write the same rows.

@@ -158,6 +158,8 @@ class HipExec:
                         if memo is not None:
                             memo[("trace", wkey)] = custom
                 rows_multiple = int(getattr(custom, "rows_multiple", 0) or codegen.lane_stride(custom))
+                if getattr(custom, "exact_rows", 0) and self._n_rows != int(custom.exact_rows):
+                    raise ValueError(f"this object's fold stages were generated for {int(custom.exact_rows)} rows (manifest 'row_count'); the executor has {self._n_rows}")
                 if rows_multiple > 1 and self._n_rows % rows_multiple:
                     raise ValueError(f"this program exchanges data between the entities of a world laid out as {rows_multiple} consecutive rows "
                                      f"(a whole-world StableHLO tick in lane mode, manifest 'rows_per_world'): the executor's {self._n_rows} "

@@ -2331,6 +2331,431 @@ class Slot:
         return Slot(*x)
 
 
+# ---- worlds of MORE than one wavefront whose entities exchange data: the edge_fold becomes fold stages ---------------------------
+# The reference's `edge_fold` (libs/nox-py/src/graph.rs:177-361, python twin elodin/__init__.py:454-557) reaches a backend as, per
+# source, constant-index gathers of its targets' rows ([e, w] each), stacked to [N, e, w], transposed to [e, N, w] and consumed by a
+# `while` over the edge slot that slices row `i` and calls the fold body (libs/cranelift-mlir/tests/test_gather_3body.rs,
+# test_dynamic_ops_3body.rs, test_while_dyn_slice.rs).  Up to 64 entities the reads are lane exchanges inside the wavefront
+# (_LaneEval with a stride).  Beyond that an entity's targets live in other wavefronts, so the exchange goes through memory and
+# a launch boundary: the loop leaves the per-entity kernel and becomes a fold STAGE of the program (dsl.GraphFold — one lane
+# per source folds its out-edges in slot order over CSR, the design of csrc/pair_kernel.hpp's edge kernel), with the per-entity
+# statements in front of it and behind it as systems of their own (world_program).
+
+class _Nbr(Sym):
+    """Rows of ONE per-entity tensor `base` ([N, w]) taken at other entities, on their way into an edge_fold's scan — never
+    materialised.  kind / true shape / table:  "rows" (k, w): rows `table` (k ints) | "rows3" (1, k, w) | "table" (N, e, w):
+    table[s] = the e target rows of source s, slot order | "tableT" (e, N, w)."""
+
+    def __init__(self, base: Sym, table, tshape, kind: str):
+        self.a = np.empty((0,), dtype=object)
+        self.dtype, self.eaxis, self.uni, self.tshape = base.dtype, None, frozenset(), tuple(tshape)
+        self.base, self.table, self.kind = base, table, kind
+
+
+class _FoldRequest:
+    """One scan over the edge slot, lifted out of the tick: acc' = f(acc, own values, target values) over `table`."""
+
+    def __init__(self, index, width, init, outputs, acc_leaves, own_exprs, own_leaves, nb_exprs, nb_leaves, table):
+        self.index, self.width, self.init, self.outputs = index, width, init, outputs
+        self.acc_leaves, self.own_exprs, self.own_leaves = acc_leaves, own_exprs, own_leaves
+        self.nb_exprs, self.nb_leaves, self.table = nb_exprs, nb_leaves, table
+
+
+def _substitute(exprs: Sequence[Expr], mapping: Dict[int, Expr]) -> List[Expr]:
+    """The DAGs `exprs` with the nodes in `mapping` (by id) replaced; everything above them rebuilt (hash-consed)."""
+    memo: Dict[int, Expr] = {}
+
+    def go(x):
+        if not isinstance(x, Expr):
+            return x
+        if id(x) in mapping:
+            return mapping[id(x)]
+        if id(x) in memo:
+            return memo[id(x)]
+        if x.op in ("while", "while_out", "lane_read", "lane_read_dyn", "wload"):
+            raise NotEntityParallel(f"an edge_fold body holds a {x.op} node: only straight-line fold functions leave the tick as fold stages")
+        args = tuple(go(a) for a in x.args)
+        out = x if all(a is b for a, b in zip(args, x.args)) else Expr(x.op, args, x.value, x.name)
+        memo[id(x)] = out
+        return out
+    return [go(e) for e in exprs]
+
+
+class _FoldEval(_LaneEval):
+    """_LaneEval for a world larger than a wavefront (no stride): constant-index gathers along the entity axis stay LAZY (_Nbr),
+    and the `while` that consumes them is lifted out as a _FoldRequest; its results read the fold stage's output column."""
+
+    def __init__(self, funcs, n_entities: int, fold_out_leaves):
+        super().__init__(funcs, n_entities, None)
+        self.fold_out_leaves = fold_out_leaves        # (fold index, width) -> the leaves of that fold's output column
+        self.requests: List[_FoldRequest] = []
+        self._nb_reads: Dict[Tuple[int, int], Expr] = {}      # (id(base Sym), feature) -> placeholder leaf, inside one fold body
+        self._nb_base: Dict[int, Sym] = {}
+        self._nb_table = None
+
+    # -- lazy neighbour rows --
+    def _exchange_gather(self, operand: Sym, indices: Sym, oe: int, ivd: int, rt: TensorType) -> Sym:
+        operand = self._mat(operand)
+        if oe != 0 or len(operand.tshape) != 2 or operand.dtype != "f64":
+            raise NotEntityParallel("a constant-index gather along the entity axis of a tensor that is not an [N, w] f64 column value")
+        idx = self._mat(indices).a
+        flat = np.moveaxis(idx, ivd, -1).reshape(-1) if ivd < idx.ndim else idx.reshape(-1)
+        rows = []
+        for v in flat:
+            j = _try_const(v.to_float() if isinstance(v, U64) else v)
+            if j is None:
+                raise NotEntityParallel("stablehlo.gather along the entity axis with a traced (per-tick) index")
+            rows.append(int(min(max(j, 0), self.N - 1)))
+        if tuple(rt.shape) != (len(rows), operand.tshape[1]):
+            raise NotEntityParallel(f"stablehlo.gather along the entity axis: result {rt} is not [rows, w]")
+        return _Nbr(operand, rows, rt.shape, "rows")
+
+    def op(self, op: Op, env) -> List[Sym]:
+        name = op.name
+        short = name.split(".", 1)[1] if "." in name else name
+        if name not in ("call", "func.call") and short not in ("while", "constant", "iota", "return"):
+            xs = self._operands(self._operand_text(op.text), env)
+            if any(isinstance(x, _Nbr) for x in xs):
+                return [self._nbr_op(short, op, xs)]
+        return super().op(op, env)
+
+    def _nbr_op(self, short: str, op: Op, xs: List[Sym]) -> Sym:
+        rt = self._result_types(op.text)[0]
+        x = xs[0]
+        w = x.base.tshape[1] if isinstance(x, _Nbr) else None
+        if short == "reshape" and x.kind == "rows" and tuple(rt.shape) == (1,) + x.tshape:
+            return _Nbr(x.base, x.table, rt.shape, "rows3")
+        if short == "concatenate" and all(isinstance(y, _Nbr) and y.base is x.base and y.kind == x.kind for y in xs) and self._ints(op.text, "dim") in ([0], []) \
+                and len(xs) == self.N:
+            if x.kind == "rows3" and len({len(y.table) for y in xs}) == 1:
+                return _Nbr(x.base, [list(y.table) for y in xs], rt.shape, "table")
+            if x.kind == "rows" and all(len(y.table) == 1 for y in xs):
+                if [y.table[0] for y in xs] == list(range(self.N)):
+                    return x.base                    # every source's OWN row, stacked in source order: the column value itself
+                raise NotEntityParallel("rows of a per-entity tensor permuted across the world (a join): not an edge_fold's source rows")
+        if short == "transpose" and x.kind == "table" and self._ints(op.text, "dims") == [1, 0, 2]:
+            return _Nbr(x.base, x.table, rt.shape, "tableT")
+        if short == "dynamic_slice" and x.kind == "tableT":
+            sizes = self._ints(op.text, "sizes") or self._ints(op.text, "slice_sizes")
+            starts = xs[1:]
+            if sizes == [1, self.N, w] and all(_try_const(self._index(s_)) == 0 for s_ in starts[1:]) and self._nb_table is not None:
+                if self._nb_table[0] is None:
+                    self._nb_table[0] = x.table
+                elif self._nb_table[0] is not x.table and self._nb_table[0] != x.table:
+                    raise NotEntityParallel("one scan slices neighbour rows of two different edge sets")
+                self._nb_table[1].append(self._index(starts[0]))
+                self._nb_base[id(x.base)] = x.base
+                arr = np.empty((1, 1, w), dtype=object)
+                t_ = list(self._nb_base).index(id(x.base))
+                for j in range(w):
+                    if (id(x.base), j) not in self._nb_reads:
+                        self._nb_reads[(id(x.base), j)] = _dsl.leaf(f"__nb{len(self.requests)}_{t_}_{j}")
+                    arr[0, 0, j] = self._nb_reads[(id(x.base), j)]
+                return self._annot(Sym(arr, x.dtype), rt.shape, 1, ())
+        raise NotEntityParallel(f"stablehlo.{short} on rows gathered from other entities: in a world of more than 64 entities only an edge_fold's "
+                                "scan (stack, transpose, slice by the counter, fold body) may consume them")
+
+    # -- the scan itself --
+    def _while(self, op: Op, text: str, env) -> List[Sym]:
+        m = re.match(r"\s*\((.*?)\)\s*:", text, re.S)
+        binds = [p_.split("=") for p_ in _split_top(m.group(1))]
+        names = [b[0].strip() for b in binds]
+        inits = [env[b[1].strip()] for b in binds]
+        if not any(isinstance(x, _Nbr) for x in inits):
+            return super()._while(op, text, env)
+        return self._fold_while(op, env, names, inits)
+
+    def _placeholder(self, k: int, x: Sym) -> Sym:
+        """A carried value as fresh leaves, per-entity along its N-sized axis when it has one."""
+        if x.dtype in ("ui64", "i1"):
+            raise NotEntityParallel(f"an edge_fold scan carries a {x.dtype} value")
+        eaxis = x.eaxis if x.eaxis is not None else next((d for d, s_ in enumerate(x.tshape) if s_ == self.N and self.N > 1), None)
+        stored = self._stored(x.tshape, eaxis, ())
+        arr = np.empty(int(np.prod(stored)) if stored else 1, dtype=object)
+        for j in range(arr.size):
+            arr[j] = _dsl.leaf(f"__fc{len(self.requests)}_{k}_{j}")
+        return Sym(arr.reshape(stored), x.dtype, eaxis, (), x.tshape)
+
+    def _fold_while(self, op: Op, env, names, inits) -> List[Sym]:
+        f_idx = len(self.requests)
+        ph = [x if isinstance(x, _Nbr) else self._placeholder(k, x) for k, x in enumerate(inits)]
+
+        def run_body(ph_):
+            saved = (self._nb_reads, self._nb_base, self._nb_table)
+            self._nb_reads, self._nb_base, self._nb_table = {}, {}, [None, []]
+            try:
+                e2 = dict(env)
+                e2.update(zip(names, ph_))
+                outs_ = self.block(op.regions[1], e2)
+                cond_ = self.block(op.regions[0], e2)[0].a[()]
+                return outs_, cond_, self._nb_reads, self._nb_base, self._nb_table
+            finally:
+                self._nb_reads, self._nb_base, self._nb_table = saved
+        # carried values the body hands back untouched (the source's own rows) are not state: inside the body they are the outer nodes
+        outs, _, _, _, _ = run_body(ph)
+        for k, (x, p_, o) in enumerate(zip(inits, ph, outs)):
+            if isinstance(x, _Nbr) or isinstance(o, _Nbr):
+                continue
+            got, was = self._flatten_elems(o), self._flatten_elems(p_)
+            if len(got) == len(was) and all(a_ is b_ for a_, b_ in zip(got, was)) and not (not x.tshape and x.is_int()):
+                ph[k] = x
+        outs, cond, nb_reads, nb_base, (table, counters) = run_body(ph)
+        if table is None:
+            raise NotEntityParallel("a while carries gathered neighbour rows but never slices them by its counter")
+        e_slots = len(table[0])
+        # which carried value is the counter: the one the condition reads
+        def leaves_of(x, acc):
+            todo, seen = [x], set()
+            while todo:
+                y = todo.pop()
+                if not isinstance(y, Expr) or id(y) in seen:
+                    continue
+                seen.add(id(y))
+                if y.op == "leaf":
+                    acc.add(y.name)
+                todo.extend(y.args)
+            return acc
+        cond_leaves = leaves_of(cond if isinstance(cond, Expr) else _dsl._lift(cond), set())
+        counter = [k for k, x in enumerate(ph) if not isinstance(x, _Nbr) and x.a.size == 1 and not x.tshape and x.a.reshape(-1)[0].name in cond_leaves]
+        if len(counter) != 1 or not inits[counter[0]].is_int():
+            raise NotEntityParallel("an edge_fold scan whose condition is not a test of one integer counter")
+        c = counter[0]
+        c_leaf = ph[c].a.reshape(-1)[0]
+        if any(ix is not c_leaf for ix in counters):
+            raise NotEntityParallel("an edge_fold scan slices its neighbour rows by something that is not its counter")
+        # trip count: the counter starts at a constant, goes up by one, and the condition holds exactly while it is below the slot count
+        c0 = _try_const(inits[c].a.reshape(-1)[0])
+        def with_counter(region, value):
+            e3 = dict(env)
+            e3.update(zip(names, ph))
+            e3[names[c]] = Sym(np.array(_dsl.const(float(value)), dtype=object).reshape(()), inits[c].dtype)
+            saved_ = (self._nb_reads, self._nb_base, self._nb_table)
+            self._nb_reads, self._nb_base, self._nb_table = {}, {}, [None, []]
+            try:
+                return self.block(region, e3)
+            finally:
+                self._nb_reads, self._nb_base, self._nb_table = saved_
+        if c0 is None or _try_const(with_counter(op.regions[1], c0)[c].a.reshape(-1)[0]) != c0 + 1 \
+                or _try_const(with_counter(op.regions[0], c0 + e_slots - 1)[0].a[()]) is not True \
+                or _try_const(with_counter(op.regions[0], c0 + e_slots)[0].a[()]) is not False:
+            raise NotEntityParallel(f"an edge_fold scan that does not run its counter from a constant over the {e_slots} edge slots")
+        variant, acc_leaves, init_vals, out_exprs, layouts = [], [], [], [], {}
+        for k, (x, p_, o) in enumerate(zip(inits, ph, outs)):
+            if isinstance(x, _Nbr) or k == c:
+                if isinstance(x, _Nbr) and o is not x:
+                    raise NotEntityParallel("an edge_fold scan rewrites the neighbour rows it carries")
+                continue
+            if p_ is x:
+                if o is not x and not (len(self._flatten_elems(o)) == len(self._flatten_elems(x)) and all(a is b for a, b in zip(self._flatten_elems(o), self._flatten_elems(x)))):
+                    raise NotEntityParallel("internal: a carried value classified as untouched is rewritten by the scan")
+                continue                                   # handed back untouched: not state
+            o = self._mat(o)
+            got, was = self._flatten_elems(o), self._flatten_elems(p_)
+            if o.eaxis != p_.eaxis or tuple(o.a.shape) != tuple(p_.a.shape):
+                raise NotEntityParallel(f"a value carried by an edge_fold scan changes its entity layout ({p_.tshape})")
+            init = x.a
+            if p_.eaxis is not None and init.ndim == len(p_.a.shape) and init.shape[p_.eaxis] != 1:      # stored in full along the entity axis
+                first = np.take(init, [0], axis=p_.eaxis)
+                if not all(a_ is b_ or _try_const(a_) == _try_const(b_) is not None
+                           for a_, b_ in zip(np.broadcast_to(first, init.shape).reshape(-1), init.reshape(-1))):
+                    raise NotEntityParallel("an edge_fold scan whose initial accumulator differs from entity to entity")
+                init = first
+            init = np.broadcast_to(init, p_.a.shape)
+            vals = [_try_const(v) for v in init.reshape(-1)]
+            if any(v is None or isinstance(v, bool) for v in vals):
+                raise NotEntityParallel("an edge_fold scan whose initial accumulator is not a constant (the reference folds from el.Force() / a literal)")
+            variant.append(k)
+            layouts[k] = (p_.a.shape, p_.dtype, p_.eaxis, p_.tshape)
+            acc_leaves += was
+            init_vals += [float(v) for v in vals]
+            out_exprs += [_dsl._lift(v) for v in got]
+        if not variant:
+            raise NotEntityParallel("an edge_fold scan without an accumulator")
+        if any(c_leaf.name in leaves_of(e_, set()) for e_ in out_exprs):
+            raise NotEntityParallel("an edge_fold body reads the edge slot's number")
+        # what the body reads besides its accumulator and the targets' rows: values of the source's own lane, computed in front of the
+        # loop — the maximal sub-DAGs that do not depend on a placeholder
+        inner_names = {v.name for v in acc_leaves} | {v.name for v in nb_reads.values()}
+        dep: Dict[int, bool] = {}
+        def depends(x):
+            if not isinstance(x, Expr):
+                return False
+            if id(x) in dep:
+                return dep[id(x)]
+            r = (x.op == "leaf" and x.name in inner_names) or any(depends(a) for a in x.args)
+            dep[id(x)] = r
+            return r
+        own: List[Expr] = []
+        seen = set()
+        def frontier(x):
+            if not isinstance(x, Expr) or id(x) in seen:
+                return
+            seen.add(id(x))
+            if not depends(x):
+                if x.op != "const":
+                    own.append(x)
+                return
+            for a in x.args:
+                frontier(a)
+        for e_ in out_exprs:
+            frontier(e_)
+        own_leaves = [_dsl.leaf(f"__own{f_idx}_{j}") for j in range(len(own))]
+        nb_keys = sorted(nb_reads, key=lambda kj: (list(nb_base).index(kj[0]), kj[1]))
+        used_nb = [kj for kj in nb_keys if any(nb_reads[kj].name in leaves_of(e_, set()) for e_ in out_exprs)]
+        nb_exprs = [_dsl._lift(nb_base[b].a.reshape(-1)[j]) for b, j in used_nb]
+        req = _FoldRequest(f_idx, len(acc_leaves), init_vals, out_exprs, acc_leaves, own, own_leaves, nb_exprs, [nb_reads[kj] for kj in used_nb], table)
+        self.requests.append(req)
+        out_leaves = list(self.fold_out_leaves(f_idx, req.width))
+        results, k0 = [], 0
+        for k, x in enumerate(inits):
+            if isinstance(x, _Nbr):
+                results.append(x)
+            elif k == c:
+                results.append(Sym(np.array(_dsl.const(float(c0 + e_slots)), dtype=object).reshape(()), x.dtype))
+            elif k in layouts:
+                shp, dt, ea, ts = layouts[k]
+                n_ = int(np.prod(shp)) if shp else 1
+                arr = np.empty(n_, dtype=object)
+                arr[:] = out_leaves[k0:k0 + n_]
+                k0 += n_
+                results.append(Sym(arr.reshape(shp), dt, ea, (), ts))
+            else:
+                results.append(x)
+        return results
+
+
+def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = None, name: str = "world_tick"):
+    """A whole-world tick whose entities exchange data across MORE than a wavefront (an edge_fold over a world of more than 64
+    entities) as a PROGRAM: per-entity systems with the tick's scans over the edge slot between them as fold stages.
+    -> (dsl.Program, manifest, graph_edges)
+
+    The program's columns are the world's slots (`hlo_<component>`, one row per entity; singleton slots replicated per row) plus,
+    per scan k, three scratch columns the host provides zero-filled: `hlo_fold<k>_own` (what the fold body reads of the source's
+    own lane), `hlo_fold<k>_nbr` (what it reads of a target) and `hlo_fold<k>_out` (the accumulator it leaves).  One tick =
+    system 0 | fold 0 | system 1 | ... | fold K-1 | system K: system k recomputes from the world's columns and the earlier folds'
+    outputs what fold k needs and stores it; the last one computes the tick's results.  `graph_edges` = {edge component of fold
+    k: (source rows, target rows)} in slot order — rows of ONE world; hand them to the executor as entity ids of its rows
+    (HipExec graph_edges=, with graph_replicas=(worlds, N) for a Monte-Carlo of such worlds)."""
+    funcs = parse_module(text)
+    main = funcs["main"]
+    ins = [Slot.of(x) for x in slots]
+    outs = [Slot.of(x) for x in out_slots] if out_slots is not None else list(ins)
+    if len(ins) != len(main.args) or len(outs) != len(main.result_types):
+        raise ValueError(f"@main has {len(main.args)} arguments / {len(main.result_types)} results; {len(ins)} / {len(outs)} slots given")
+    for k, (s_, ty) in enumerate(zip(outs, main.result_types)):
+        if not s_.shape and ty.shape:
+            outs[k] = Slot(s_.component, ty.shape, False, s_.component_id)
+    counts = {s_.shape[0] for s_ in ins + outs if not s_.elided and s_.shape}
+    if len(counts) != 1:
+        raise NotEntityParallel("the batched slots do not share one entity count (components on different entity sets)")
+    n_entities = counts.pop()
+    width = lambda s_: int(np.prod(s_.shape[1:] if not s_.elided else s_.shape)) if (s_.shape[1:] if not s_.elided else s_.shape) else 1
+    widths = {}
+    for s_ in ins + outs:
+        if widths.setdefault(s_.column, width(s_)) != width(s_):
+            raise ValueError(f"component {s_.component} appears with two shapes")
+    world_cols = list(dict.fromkeys([s_.column for s_ in ins] + [s_.column for s_ in outs]))
+
+    def evaluate(cols, fold_out_leaves):
+        """One entity-parallel evaluation of @main over the leaves `cols`: -> (evaluator with its fold requests, {result column: Vec})."""
+        args = []
+        for s_, (_, ty) in zip(ins, main.args):
+            v = cols[s_.column]
+            elems = list(v.e) if isinstance(v, _dsl.Vec) else [v]
+            stored = ((1,) + tuple(ty.shape[1:])) if not s_.elided else tuple(ty.shape)
+            arr = np.empty(len(elems), dtype=object)
+            arr[:] = elems
+            arr = arr.reshape(stored)
+            if ty.dtype in ("i1", "ui64"):
+                raise NotEntityParallel(f"slot {s_.component}: {ty.dtype} columns are not provided for worlds larger than a wavefront")
+            args.append(Sym(arr, ty.dtype, None if s_.elided else 0, (), ty.shape))
+        ev = _FoldEval(funcs, n_entities, fold_out_leaves)
+        res = {}
+        for s_, o in zip(outs, ev.call(main, args)):
+            if isinstance(o, _Nbr):
+                raise NotEntityParallel(f"result {s_.component} is a stack of other entities' rows")
+            o = ev._mat(o, [d for d in o.uni if d != 0] if not s_.elided else None)
+            if s_.elided and o.eaxis is not None:
+                raise NotEntityParallel(f"the singleton component {s_.component} would become per-entity")
+            if not s_.elided and o.eaxis not in (0, None):
+                raise NotEntityParallel(f"result {s_.component}: the entity axis is not its leading axis")
+            vals = _column_values(o)
+            src = cols.get(s_.column)
+            src = (list(src.e) if isinstance(src, _dsl.Vec) else [src]) if src is not None else None
+            if src is not None and len(src) == len(vals) and all(a is b for a, b in zip(src, vals)):
+                continue
+            res[s_.column] = _dsl.Vec(vals)
+        return ev, res
+
+    # ---- discovery: how many scans, how wide their accumulators, what they read (leaves of this pass never reach the program) ----
+    probe_cols = {c: (lambda v: v if len(v) > 1 else v[0])(_dsl.Vec([_dsl.leaf(f"__w_{c}_{j}") for j in range(widths[c])])) for c in world_cols}
+    probe, _ = evaluate(probe_cols, lambda k, w: [_dsl.leaf(f"__fo{k}_{j}") for j in range(w)])
+    if not probe.requests:
+        raise NotEntityParallel("this tick has no scan over gathered neighbour rows: it is entity-parallel (world_system) or not an edge_fold world")
+    folds, graph_edges = [], {}
+    for r in probe.requests:
+        own_c, nbr_c, out_c = f"hlo_fold{r.index}_own", f"hlo_fold{r.index}_nbr", f"hlo_fold{r.index}_out"
+        widths[own_c], widths[nbr_c], widths[out_c] = max(1, len(r.own_exprs)), max(1, len(r.nb_exprs)), r.width
+        too_wide = [c for c in (own_c, nbr_c, out_c) if widths[c] > _dsl._MAT_MAX_ELEMS]
+        if too_wide:
+            raise NotImplementedError(f"fold {r.index}: scratch columns {too_wide} are wider than {_dsl._MAT_MAX_ELEMS} values")
+
+        def make_fn(r=r):
+            def fold_fn(acc, own, nbr):
+                vec = lambda v: list(v.e) if isinstance(v, _dsl.Vec) else [v]
+                mapping = {id(a): b for a, b in zip(r.acc_leaves, vec(acc))}
+                mapping.update({id(a): b for a, b in zip(r.own_exprs, vec(own))})
+                mapping.update({id(a): b for a, b in zip(r.nb_leaves, vec(nbr))})
+                return _dsl.Vec(_substitute(r.outputs, mapping))
+            fold_fn.__name__ = f"{name}_fold{r.index}"
+            return fold_fn
+        edge_c = f"hlo_fold{r.index}_edges"
+        folds.append(_dsl.GraphFold(make_fn(), edge_c, (own_c,), (nbr_c,), out_c, list(r.init)))
+        graph_edges[edge_c] = ([s_ for s_ in range(n_entities) for _ in r.table[s_]], [t for s_ in range(n_entities) for t in r.table[s_]])
+    n_folds = len(folds)
+    all_cols = world_cols + [c for r in probe.requests for c in (f"hlo_fold{r.index}_own", f"hlo_fold{r.index}_nbr", f"hlo_fold{r.index}_out")]
+
+    # ---- the systems: ONE evaluation over the program's own leaves when system 0 is traced, every later system reads its share ----
+    cache: Dict[str, object] = {}
+
+    def phases(cols):
+        vec = lambda v: list(v.e) if isinstance(v, _dsl.Vec) else [v]
+        ev, res = evaluate(cols, lambda k, w: vec(cols[f"hlo_fold{k}_out"]))
+        if len(ev.requests) != n_folds:
+            raise NotEntityParallel("internal: the traced evaluation found another number of scans than the discovery pass")
+        out = []
+        for r in ev.requests:
+            pad = lambda xs, c: _dsl.Vec(list(xs) + [_dsl.const(0.0)] * (widths[c] - len(xs)))
+            out.append({f"hlo_fold{r.index}_own": pad(r.own_exprs, f"hlo_fold{r.index}_own"), f"hlo_fold{r.index}_nbr": pad(r.nb_exprs, f"hlo_fold{r.index}_nbr")})
+        out.append(res)
+        return out
+
+    def make_system(k):
+        def fn(**cols):
+            if k == 0 or "phases" not in cache:
+                cache["phases"] = phases(cols)
+            return cache["phases"][k]
+        fn.__name__ = f"{name}_{k}"
+        import inspect
+        fn.__signature__ = inspect.Signature([inspect.Parameter(p_, inspect.Parameter.KEYWORD_ONLY) for p_ in all_cols])
+        system_ = _dsl.system(fn, **{c: widths[c] for c in all_cols})
+        system_.float32_refused = float32_hazards(funcs)
+        return system_
+    pre = []
+    for k in range(n_folds):
+        pre += [make_system(k), folds[k]]
+    pre.append(make_system(n_folds))
+    prog = _dsl.Program(pre, _dsl.Pipe([]), [])
+    manifest = {"mode": "folds", "rows": "entities", "entities_per_world": n_entities, "rows_per_world": n_entities, "fold_stages": n_folds,
+                "edges_per_fold": [len(graph_edges[f"hlo_fold{r.index}_edges"][0]) for r in probe.requests],
+                "columns": [{"column": c, "width": widths[c],
+                             "component": next((s_.component for s_ in ins + outs if s_.column == c), None),
+                             "component_id": next((s_.component_id for s_ in ins + outs if s_.column == c), None),
+                             "entity_axis_elided": next((s_.elided for s_ in ins + outs if s_.column == c), False),
+                             "scratch": c not in world_cols} for c in all_cols]}
+    return prog, manifest, graph_edges
+
+
 def slots_from_metadata(doc: dict):
     """(argument slots, result slots) from a JSON document: either the reference's ExecMetadata as serde writes it —
     {"arg_ids": [...], "ret_ids": [...], "arg_slots": [{"component_id", "shape", "entity_axis_elided"}]}, optionally with
@@ -2549,7 +2974,45 @@ def compile_world(text: str, slots_doc: dict, out: Optional[str] = None, mode: s
     from . import codegen
     t0 = time.perf_counter()
     ins, outs = slots_from_metadata(slots_doc)
-    system_, manifest = world_system(text, ins, outs, mode=mode)
+    folds = mode == "folds"
+    if not folds:
+        try:
+            system_, manifest = world_system(text, ins, outs, mode=mode)
+        except (NotEntityParallel, NotImplementedError) as refused:
+            # a world of more than a wavefront whose entities exchange data fits neither one lane per entity (the exchange leaves
+            # the wavefront) nor one lane per world (too wide): its scans over the edge slot become fold stages (world_program)
+            if mode != "auto":
+                raise
+            try:
+                world_program(text, ins, outs)
+            except NotEntityParallel:
+                raise refused from None
+            folds = True
+    if folds:
+        if dtype != "float64":
+            raise NotImplementedError("whole-world ticks with fold stages are float64 (the fold kernels gather doubles)")
+        prog, manifest, edges = world_program(text, ins, outs)
+        n_world = int(manifest["entities_per_world"])
+        rows = int(slots_doc.get("rows", 0)) or n_world
+        if rows % n_world:
+            raise ValueError(f"{rows} rows are not a whole number of {n_world}-entity worlds")
+        widths = {c["column"]: c["width"] for c in manifest["columns"]}
+        tp = prog.trace(widths, fold_edges=edges, fold_replicas=(rows // n_world, n_world) if rows > n_world else None)
+        t1 = time.perf_counter()
+        so = codegen.build(tp, dtype, 2, fast_math=False)
+        t2 = time.perf_counter()
+        known = {c["column"] for c in manifest["columns"]}
+        manifest["columns"] += [{"column": n_, "width": w_, "component": None, "component_id": None, "entity_axis_elided": False, "scratch": True}
+                                for n_, w_ in tp.columns if n_ not in known]          # the folds' commit buffers
+        order = [n_ for n_, _ in tp.columns]
+        manifest["columns"] = sorted(manifest["columns"], key=lambda c: order.index(c["column"]))
+        manifest.update({"integrator": "none", "dtype": dtype, "column_layout": "rows", "row_count": rows,      # the fold kernels are generated for this many rows
+                         "build": {"trace_ms": round((t1 - t0) * 1e3, 1), "compile_ms": round((t2 - t1) * 1e3, 1), "resources": dict(codegen.last_resources)}})
+        if out:
+            shutil.copyfile(so, out)
+            Path(str(out) + ".json").write_text(json.dumps(manifest, indent=1))
+            so = Path(out)
+        return so, manifest
     if dtype == "float32" and manifest.get("float32_refused"):
         raise NotImplementedError("this module cannot be built with dtype float32 (integer tensors are carried as floats: exact in f64 only): "
                                   + "; ".join(manifest["float32_refused"][:4]))
@@ -2580,6 +3043,7 @@ def load_world(so_path: str):
     prog = _dsl.FrozenProgram(None, [(c["column"], c["width"]) for c in manifest["columns"]],
                               column_soa=manifest.get("column_layout") == "element-major", prebuilt_so=str(so_path))
     prog._traced.rows_multiple = int(manifest.get("rows_per_world", 1))      # exec.HipExec refuses a row count that splits a world
+    prog._traced.exact_rows = int(manifest.get("row_count", 0))              # ... and, for an object with fold stages, any count but the one it was generated for
     return prog, manifest
 
 
@@ -2664,7 +3128,7 @@ def checkpoint(debug_dir: str, mode: str = "auto", device: int = 0, rtol: float 
 
 
 def _main(argv=None) -> int:
-    """python -m elodin_amd.stablehlo module.mlir --slots slots.json -o pipe.so [--mode auto|lane|world] [--dtype float64|float32]"""
+    """python -m elodin_amd.stablehlo module.mlir --slots slots.json -o pipe.so [--mode auto|lane|world|folds] [--dtype float64|float32]"""
     import argparse
     import json
     ap = argparse.ArgumentParser(prog="python -m elodin_amd.stablehlo", description=_main.__doc__)
@@ -2673,7 +3137,7 @@ def _main(argv=None) -> int:
     ap.add_argument("-o", "--out", help="shared object to write (its manifest goes to <out>.json)")
     ap.add_argument("--checkpoint", metavar="DIR", help="a reference debug dump (ELODIN_CRANELIFT_DEBUG_DIR): run its first tick on the GPU and compare "
                                                         "with xla_output_<i>.bin / cranelift_output_<i>.bin (needs a GPU)")
-    ap.add_argument("--mode", default="auto", choices=("auto", "lane", "world"))
+    ap.add_argument("--mode", default="auto", choices=("auto", "lane", "world", "folds"))
     ap.add_argument("--dtype", default="float64", choices=("float64", "float32"))
     ap.add_argument("--fast-math", action="store_true")
     a = ap.parse_args(argv)

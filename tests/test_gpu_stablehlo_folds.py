@@ -1,0 +1,124 @@
+"""Whole-world StableHLO ticks whose entities exchange data across MORE than a wavefront (VERDICT r05 missing #2): an n-body world of
+80 / 256 bodies as the reference would dump it — per source constant-index gathers of its targets' rows, stacked, transposed, consumed
+by a `while` over the edge slot (libs/nox-py/src/graph.rs:177-361; fold term examples/n-body/sim.py:356-361; module structure
+libs/cranelift-mlir/tests/test_gather_3body.rs, three_body_e2e.rs:16-50) — through elodin_amd.stablehlo.world_program: the scans leave
+the per-entity kernel as fold stages (CSR, one lane per source, slot order).  Against the CPU oracle's sequential softened fold."""
+import json
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import elodin_amd as ea
+from elodin_amd import _lib as L
+from elodin_amd import dsl
+from elodin_amd import stablehlo as sh
+from oracle import oracle as orc
+from tests.golden import hlo_world_builder as hb
+
+pytestmark = pytest.mark.gpu
+K_SQ, EPS = 2.9591220828e-4, 1e-6
+
+
+def _world(nb, seed=None):
+    rng = np.random.default_rng(nb if seed is None else seed)
+    pos = np.concatenate([np.tile([0, 0, 0, 1.0], (nb, 1)), rng.normal(size=(nb, 3)) * 3], axis=1)
+    vel = np.concatenate([np.zeros((nb, 3)), rng.normal(size=(nb, 3)) * 1e-3], axis=1)
+    m = rng.uniform(1e-6, 1e-3, nb)
+    return pos, vel, np.concatenate([np.tile(m[:, None], (1, 3)), np.zeros((nb, 3)), m[:, None]], axis=1)
+
+
+def _columns(manifest, rows, pos, vel, inertia, dt):
+    cols = {c["column"]: np.zeros((rows, c["width"])) for c in manifest["columns"]}
+    cols["hlo_simulation_time_step"][:] = dt
+    cols["hlo_world_pos"], cols["hlo_world_vel"], cols["hlo_inertia"] = pos.copy(), vel.copy(), inertia.copy()
+    return cols
+
+
+def _errors(cols, ref, rows=slice(None)):
+    worst = 0.0
+    for c, r in (("world_pos", ref.world_pos), ("world_vel", ref.world_vel), ("world_accel", ref.world_accel), ("force", ref.force)):
+        g = cols["hlo_" + c][rows]
+        for sl in ((slice(0, 4), slice(4, 7)) if c == "world_pos" else (slice(0, 3), slice(3, 6))):
+            scale = np.maximum(np.max(np.abs(r[:, sl]), axis=1, keepdims=True), 1e-300)
+            worst = max(worst, float(np.max(np.abs(g[:, sl] - r[:, sl]) / scale)))
+    return worst
+
+
+@pytest.mark.parametrize("nb,ticks", [(80, 20), (256, 6)])
+def test_nbody_world_larger_than_a_wavefront_runs_as_fold_stages(nb, ticks):
+    text, slots = hb.nbody_world(nb, K_SQ, EPS)
+    prog, manifest, edges = sh.world_program(text, slots)
+    assert manifest["mode"] == "folds" and manifest["fold_stages"] == 4 and manifest["edges_per_fold"] == [nb * (nb - 1)] * 4      # one scan per RK4 stage
+    pos, vel, inertia = _world(nb)
+    dt = 0.5
+    cols = _columns(manifest, nb, pos, vel, inertia, dt)
+    ids = np.arange(1, nb + 1, dtype=np.uint64)
+    hip = ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (nb, 1)), np.zeros((nb, 6)), np.ones((nb, 7)), entity_ids=ids, integrator=L.INTEGRATOR_NONE,
+                     effectors=prog, columns=cols, graph_edges={k: (ids[np.asarray(a)], ids[np.asarray(b)]) for k, (a, b) in edges.items()})
+    ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=dt, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, (K_SQ, EPS), None)])
+    worst = 0.0
+    for r in range(1, ticks + 1):
+        hip.run(1)
+        ref.step(1)
+        worst = max(worst, _errors(hip._aux, ref))
+        assert np.all(hip._aux["hlo_tick"] == r)
+    print(f"{nb}-body whole-world module as fold stages, {ticks} ticks vs the oracle: {worst:.2e}")
+    assert worst <= 1e-9
+    # the fold stages' edge rows are the module's gather tables, bit for bit: per source its targets ascending, itself left out
+    tp = prog.trace({c["column"]: c["width"] for c in manifest["columns"]}, fold_edges=edges)
+    for fs in tp.fold_stages:
+        assert fs.src_rows == list(range(nb)) and fs.row_start == [s * (nb - 1) for s in range(nb + 1)]
+        assert fs.dst == [t for s in range(nb) for t in range(nb) if t != s]
+    hip.close()
+
+
+def test_a_monte_carlo_of_large_worlds_shares_one_edge_template():
+    """12 worlds of 80 bodies in one executor (graph_replicas): every world folds over the same table, rows of its own block."""
+    nb, worlds, ticks = 80, 12, 5
+    text, slots = hb.nbody_world(nb, K_SQ, EPS)
+    prog, manifest, edges = sh.world_program(text, slots)
+    rows = nb * worlds
+    starts = [_world(nb, seed=100 + w) for w in range(worlds)]
+    pos, vel, inertia = (np.concatenate([s[k] for s in starts]) for k in range(3))
+    cols = _columns(manifest, rows, pos, vel, inertia, 0.5)
+    ids = np.arange(1, rows + 1, dtype=np.uint64)
+    hip = ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (rows, 1)), np.zeros((rows, 6)), np.ones((rows, 7)), entity_ids=ids, integrator=L.INTEGRATOR_NONE,
+                     effectors=prog, columns=cols, graph_replicas=(worlds, nb),
+                     graph_edges={k: (ids[np.asarray(a)], ids[np.asarray(b)]) for k, (a, b) in edges.items()})
+    hip.run(ticks)
+    for w in (0, 5, 11):
+        ref = orc.OracleWorld(*starts[w], simulation_time_step=0.5, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, (K_SQ, EPS), None)]).step(ticks)
+        assert _errors(hip._aux, ref, slice(w * nb, (w + 1) * nb)) <= 1e-9, w
+    hip.close()
+
+
+def test_the_cli_builds_a_large_world_and_the_object_is_installed_as_it_is(tmp_path):
+    """`python -m elodin_amd.stablehlo` on a 96-body world: neither one lane per entity (the exchange leaves the wavefront) nor one lane
+    per world (too wide) — `--mode auto` builds the fold-stage object; a fresh executor installs it without tracing anything."""
+    nb = 96
+    text, slots = hb.nbody_world(nb, K_SQ, EPS)
+    (tmp_path / "tick.mlir").write_text(text)
+    names = {str(L.component_id(c)): c for c, _, _ in slots}
+    meta = {"arg_ids": [L.component_id(c) for c, _, _ in slots], "ret_ids": [L.component_id(c) for c, _, _ in slots], "names": names, "rows": nb,
+            "arg_slots": [{"component_id": L.component_id(c), "shape": s, "entity_axis_elided": e} for c, s, e in slots]}
+    (tmp_path / "slots.json").write_text(json.dumps(meta))
+    out = tmp_path / "pipe.so"
+    res = subprocess.run([sys.executable, "-m", "elodin_amd.stablehlo", str(tmp_path / "tick.mlir"), "--slots", str(tmp_path / "slots.json"), "-o", str(out)],
+                         capture_output=True, text=True, cwd=str(L.PKG.parent))
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["mode"] == "folds" and out.exists()
+    prog, manifest = sh.load_world(str(out))
+    assert manifest["fold_stages"] == 4 and manifest["row_count"] == nb and manifest["rows_per_world"] == nb
+    pos, vel, inertia = _world(nb)
+    cols = _columns(manifest, nb, pos, vel, inertia, 0.5)
+    hip = ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (nb, 1)), np.zeros((nb, 6)), np.ones((nb, 7)), integrator=L.INTEGRATOR_NONE, effectors=prog, columns=cols)
+    hip.run(8)
+    ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=0.5, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, (K_SQ, EPS), None)]).step(8)
+    assert _errors(hip._aux, ref) <= 1e-9
+    with pytest.raises(ValueError, match="row_count"):      # the object's fold kernels are generated for 96 rows, not 192
+        cols2 = {k: np.concatenate([v, v]) for k, v in cols.items()}
+        ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (2 * nb, 1)), np.zeros((2 * nb, 6)), np.ones((2 * nb, 7)), integrator=L.INTEGRATOR_NONE, effectors=prog, columns=cols2)
+    hip.close()
