@@ -45,18 +45,22 @@ constexpr uint32_t kSmallEdgeCache = 2048;  // edges of a small graph (n <= 256)
 // fold(acc, pa, ma, pb, mb, p0, p1): pa / pb = the two bodies' positions at ONE stage, ma / mb their masses.
 // kAdditive: fold(acc, ...) = acc + g(a, b) component by component (or the constant 0), so partial
 // accumulators over disjoint edge subsets may be summed — what lets a hub's out-edges be folded by many lanes (2c).
+// Both built-in folds form 1/|r|^3 from ONE v_rsq_f64 + cubic correction (spatial.hpp rsqrt_pos: full f64 accuracy in 5
+// instructions) where the reference's text divides three components by norm^3 (three IEEE divides and a sqrt, ~80 dependent f64
+// instructions per stage and edge): with one wave per SIMD a sparse fold is a chain of dependent arithmetic, not of gathers
+// (profiles/r06_pair_kernels.md: batching the gathers changed nothing, this did).  Algebraically the same value, O(1e-16) per edge
+// against the divide-exact oracle — inside the 1e-9 bar like every other reciprocal of this backend.
 struct PairNewton {   // examples/three-body/main.py:61-70: r = a - b; f = G*M*m*r / |r|^3; Force(linear = acc.f - f)
     static constexpr bool kAdditive = true;
     __device__ static __forceinline__ void fold(double (&acc)[6], const double* pa, double ma, const double* pb,
                                                 double mb, double p0, double) {
         const double rx = pa[0] - pb[0], ry = pa[1] - pb[1], rz = pa[2] - pb[2];
-        const double nrm = sqrt(rx * rx + ry * ry + rz * rz);
-        const double gmm = p0 * mb * ma;
-        const double den = nrm * nrm * nrm;
+        const double inv = rsqrt_pos(rx * rx + ry * ry + rz * rz);   // coincident bodies: rsqrt(0) = inf, inf * 0 = NaN like the reference's 0 / 0
+        const double sc = (p0 * mb * ma) * (inv * inv * inv);
         acc[0] = 0.0; acc[1] = 0.0; acc[2] = 0.0;   // el.Force(linear=...) carries zero torque
-        acc[3] -= gmm * rx / den;
-        acc[4] -= gmm * ry / den;
-        acc[5] -= gmm * rz / den;
+        acc[3] -= sc * rx;
+        acc[4] -= sc * ry;
+        acc[5] -= sc * rz;
     }
 };
 struct PairSoftened {   // examples/n-body/sim.py:356-361: acc + SpatialForce(linear = K ma mb inv^3 r), r = b - a
@@ -64,8 +68,7 @@ struct PairSoftened {   // examples/n-body/sim.py:356-361: acc + SpatialForce(li
     __device__ static __forceinline__ void fold(double (&acc)[6], const double* pa, double ma, const double* pb,
                                                 double mb, double p0, double p1) {
         const double rx = pb[0] - pa[0], ry = pb[1] - pa[1], rz = pb[2] - pa[2];
-        const double d2 = (rx * rx + ry * ry + rz * rz) + p1;
-        const double inv = 1.0 / sqrt(d2);
+        const double inv = rsqrt_pos((rx * rx + ry * ry + rz * rz) + p1);
         const double sc = p0 * ma * mb * (inv * inv * inv);
         acc[3] += sc * rx;
         acc[4] += sc * ry;
