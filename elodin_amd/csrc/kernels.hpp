@@ -84,6 +84,7 @@ struct PairParams {
     uint32_t n;
     double dt_g, dt;
     double* pack;         // [n,10] scratch
+    double* pack_next;    // [n,10] the pack rows the one-launch sparse tick writes for the NEXT tick (pair_kernel.hpp 3b); nullptr: not provided
     double* partial;      // [splits,n,partial_width] scratch
     uint32_t splits;      // source-range splits of the all-pairs kernel (1 for edge lists)
     uint32_t partial_width;  // kPartialForce (all-pairs: 3 stages x force) or kPartialWidth (3 stages x [tau, f])

@@ -559,6 +559,103 @@ __global__ __launch_bounds__(kWave) void pair_integrate_kernel(const PairParams 
     }
 }
 
+// ---- 3b. sparse graphs without hubs: fold + integrate in ONE launch ------------------------------------------------------------
+// The edge fold reads only the PACK rows (of the source and of its targets); the integrate half reads the source's own state.
+// With the pack rows double-buffered — this tick reads `pack`, writes the next tick's rows to `pack_next` — nothing a wave reads
+// is written by another wave of the same launch, so the two halves need no launch boundary between them: a tick is one kernel,
+// the [n, 18] partial rows (144 B written and read back per entity and tick) never exist, and the state slabs' LDS-DMA is in
+// flight while the lane folds its edges.  Same device functions as the two-kernel path in the same order: identical bits.
+template <int INTEGRATOR, class PAIR>
+__global__ __launch_bounds__(kWave) void pair_tick_fused_kernel(const PairParams P) {
+    __shared__ __attribute__((aligned(16))) double lds[kWave * 35];      // in: pos 7 | vel 6 | inertia 7 | accel 6; out: + force 6 | pack 10
+    double* const l_pos = lds;
+    double* const l_vel = lds + kWave * 7;
+    double* const l_in = lds + kWave * 13;
+    double* const l_acc = lds + kWave * 20;
+    const uint32_t row0 = blockIdx.x * kWave, t = threadIdx.x, i = row0 + t;
+    const uint32_t rows = min((uint32_t)kWave, P.n - row0);
+    const bool full = rows == kWave, active = t < rows;
+    double* const g_pos = static_cast<double*>(P.pos) + (size_t)row0 * 7;
+    double* const g_vel = static_cast<double*>(P.vel) + (size_t)row0 * 6;
+    double* const g_acc = static_cast<double*>(P.accel) + (size_t)row0 * 6;
+    double* const g_force = static_cast<double*>(P.force) + (size_t)row0 * 6;
+    const double* const g_in = static_cast<const double*>(P.inertia) + (size_t)row0 * 7;
+    if (full) {
+        slab_dma_in<kWave * 7 * 8, kPolPlain>(reinterpret_cast<const char*>(g_pos), reinterpret_cast<char*>(l_pos), t);
+        slab_dma_in<kWave * 6 * 8, kPolPlain>(reinterpret_cast<const char*>(g_vel), reinterpret_cast<char*>(l_vel), t);
+        slab_dma_in<kWave * 7 * 8, kPolPlain>(reinterpret_cast<const char*>(g_in), reinterpret_cast<char*>(l_in), t);
+        slab_dma_in<kWave * 6 * 8, kPolPlain>(reinterpret_cast<const char*>(g_acc), reinterpret_cast<char*>(l_acc), t);
+    } else {
+        slab_in_tail(g_pos, l_pos, rows * 7, t);
+        slab_in_tail(g_vel, l_vel, rows * 6, t);
+        slab_in_tail(g_in, l_in, rows * 7, t);
+        slab_in_tail(g_acc, l_acc, rows * 6, t);
+    }
+    StepParams SP;
+    Vec3<double> aux[kMaxOps];
+    load_ops(P, i, active, SP, aux);
+    constexpr int NS = INTEGRATOR == kRk4 ? 3 : 1;
+    double pf[3][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
+    bool is_source = false;
+    if (active) {      // the fold, while the slabs land
+        const uint32_t e0 = P.row_start[i], e1 = P.row_start[i + 1];
+        is_source = e1 > e0;
+        edge_accumulate_range<NS, PAIR>(P.pack, e0, e1, P.dst, i, P.p0, P.p1, pf);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    EntityState e;
+    Spatial<double> A = {{0, 0, 0}, {0, 0, 0}}, Fw = {{0, 0, 0}, {0, 0, 0}};
+    if (active) {
+        const double* pos = l_pos + t * 7;
+        const double* vel = l_vel + t * 6;
+        const double* in = l_in + t * 7;
+        e.q0 = {pos[0], pos[1], pos[2], pos[3]};
+        e.p0 = {pos[4], pos[5], pos[6]};
+        e.v0 = {{vel[0], vel[1], vel[2]}, {vel[3], vel[4], vel[5]}};
+        e.I = {in[0], in[1], in[2]};
+        e.inv_I = {1.0 / in[0], 1.0 / in[1], 1.0 / in[2]};
+        e.mass = in[6];
+        e.inv_m = 1.0 / in[6];
+        const double* ac = l_acc + t * 6;
+        A = Spatial<double>{{ac[0], ac[1], ac[2]}, {ac[3], ac[4], ac[5]}};
+    }
+    __syncthreads();
+    if (active) pair_integrate_entity<INTEGRATOR>(P, SP, aux, pf, is_source, e, A, Fw);
+    double* const o_pos = lds;
+    double* const o_vel = lds + kWave * 7;
+    double* const o_acc = lds + kWave * 13;
+    double* const o_force = lds + kWave * 19;
+    double* const o_pack = lds + kWave * 25;
+    if (active) {
+        double* r = o_pos + t * 7;
+        r[0] = e.q0.i; r[1] = e.q0.j; r[2] = e.q0.k; r[3] = e.q0.w; r[4] = e.p0.x; r[5] = e.p0.y; r[6] = e.p0.z;
+        double* v = o_vel + t * 6;
+        v[0] = e.v0.ang.x; v[1] = e.v0.ang.y; v[2] = e.v0.ang.z; v[3] = e.v0.lin.x; v[4] = e.v0.lin.y; v[5] = e.v0.lin.z;
+        double* a = o_acc + t * 6;
+        a[0] = A.ang.x; a[1] = A.ang.y; a[2] = A.ang.z; a[3] = A.lin.x; a[4] = A.lin.y; a[5] = A.lin.z;
+        double* f = o_force + t * 6;
+        f[0] = Fw.ang.x; f[1] = Fw.ang.y; f[2] = Fw.ang.z; f[3] = Fw.lin.x; f[4] = Fw.lin.y; f[5] = Fw.lin.z;
+        const double x[3] = {e.p0.x, e.p0.y, e.p0.z}, vl[3] = {e.v0.lin.x, e.v0.lin.y, e.v0.lin.z};
+        pack_row(o_pack + t * kPackWidth, x, vl, e.mass, P.dt_g * 0.5, P.dt_g);
+    }
+    __syncthreads();
+    double* const g_pack = P.pack_next + (size_t)row0 * kPackWidth;
+    if (full) {
+        slab_out<kWave * 7 * 8, kPolPlain>(reinterpret_cast<const char*>(o_pos), reinterpret_cast<char*>(g_pos), t);
+        slab_out<kWave * 6 * 8, kPolPlain>(reinterpret_cast<const char*>(o_vel), reinterpret_cast<char*>(g_vel), t);
+        slab_out<kWave * 6 * 8, kPolPlain>(reinterpret_cast<const char*>(o_acc), reinterpret_cast<char*>(g_acc), t);
+        slab_out<kWave * 6 * 8, kPolNtStores>(reinterpret_cast<const char*>(o_force), reinterpret_cast<char*>(g_force), t);
+        slab_out<kWave * kPackWidth * 8, kPolPlain>(reinterpret_cast<const char*>(o_pack), reinterpret_cast<char*>(g_pack), t);
+    } else {
+        slab_out_tail(o_pos, g_pos, rows * 7, t);
+        slab_out_tail(o_vel, g_vel, rows * 6, t);
+        slab_out_tail(o_acc, g_acc, rows * 6, t);
+        slab_out_tail(o_force, g_force, rows * 6, t);
+        slab_out_tail(o_pack, g_pack, rows * kPackWidth, t);
+    }
+}
+
 // ---- small graphs: the whole tick (and n_ticks of them) in ONE single-workgroup launch --------------------------
 // Three-body / solar-system sized worlds (n <= 256) are launch-bound, not math-bound: pack, fold and integrate
 // run in one workgroup with the packed sources in LDS and the entity state in registers across ticks.  Same device
@@ -664,12 +761,28 @@ inline hipError_t launch_pair_ticks_t(const PairParams& p, int integrator, uint3
     if (ONLY >= 0 && integrator != ONLY) return hipErrorInvalidValue;
     const uint32_t blocks = (p.n + 255) / 256, waves = (p.n + kWave - 1) / kWave;
     const double h1 = p.dt_g * 0.5, h3 = p.dt_g;
-    if (!packed) {
+    const bool fused_path = !ALLPAIRS && (PAIR::kAdditive ? p.n_hubs : 0u) == 0 && p.pack_next != nullptr;      // (its buffers alternate: every batch packs)
+    if (!packed || fused_path) {
         hipLaunchKernelGGL(pair_pack_kernel, dim3(waves), dim3(kWave), 0, stream, static_cast<const double*>(p.pos),
                            static_cast<const double*>(p.vel), static_cast<const double*>(p.inertia), p.pack, p.n, h1, h3);
         if (launches) *launches += 1;
     }
     const bool rk4 = integrator == kRk4;
+    if constexpr (!ALLPAIRS) {
+        // no hub sources (or a fold that may not be regrouped: it never uses the hub kernels) and a second pack buffer: ONE launch per tick
+        if ((PAIR::kAdditive ? p.n_hubs : 0u) == 0 && p.pack_next != nullptr) {
+            PairParams q = p;
+            for (uint32_t t = 0; t < n_ticks; t++) {
+                if constexpr (ONLY != kSemiImplicit) { if (rk4) hipLaunchKernelGGL((pair_tick_fused_kernel<kRk4, PAIR>), dim3(waves), dim3(kWave), 0, stream, q); }
+                if constexpr (ONLY != kRk4) { if (!rk4) hipLaunchKernelGGL((pair_tick_fused_kernel<kSemiImplicit, PAIR>), dim3(waves), dim3(kWave), 0, stream, q); }
+                double* const cur = q.pack;      // the rows just written are the next tick's
+                q.pack = q.pack_next;
+                q.pack_next = cur;
+                if (launches) *launches += 1;
+            }
+            return hipGetLastError();
+        }
+    }
     for (uint32_t t = 0; t < n_ticks; t++) {
         if constexpr (ALLPAIRS) {
             const dim3 grid((p.n + kTile - 1) / kTile, p.splits);

@@ -842,7 +842,7 @@ int fill_pair_params(sixdof_handle* h, PairParams* P) {
     const size_t pwidth = allpairs ? kPartialForce : kPartialWidth;
     const size_t pack_bytes = align_up(sizeof(double) * kPackWidth * n, 256);
     const size_t partial_bytes = align_up(sizeof(double) * pwidth * n * splits, 256);
-    const size_t total = pack_bytes + partial_bytes;
+    const size_t total = pack_bytes + partial_bytes + (allpairs ? 0 : pack_bytes);      // edge lists: a second pack buffer (the one-launch tick ping-pongs)
     if (total > h->scratch_bytes) {
         if (h->d_scratch) hipFree(h->d_scratch), h->d_scratch = nullptr;
         HIP_TRY(h, hipMalloc(&h->d_scratch, total ? total : 256));
@@ -859,6 +859,7 @@ int fill_pair_params(sixdof_handle* h, PairParams* P) {
     P->dt = h->desc.has_time_step ? h->desc.time_step : h->desc.simulation_time_step;
     P->pack = reinterpret_cast<double*>(base);
     P->partial = reinterpret_cast<double*>(base + pack_bytes);
+    P->pack_next = allpairs ? nullptr : reinterpret_cast<double*>(base + pack_bytes + partial_bytes);
     P->splits = splits;
     P->partial_width = static_cast<uint32_t>(pwidth);
     P->pair_kind = pop.kind;

@@ -88,6 +88,15 @@ spos, svel, sin_ = cpos, cvel, cin
 run(csys, {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), 0.5), "hlo_world_pos": nlay(spos, [0, 0, 0, 1.0, 0, 0, 0]),
            "hlo_world_vel": nlay(svel, np.zeros(6)), "hlo_inertia": nlay(sin_, np.ones(7)), "hlo_world_accel": np.zeros((rows, 6)),
            "hlo_force": np.zeros((rows, 6))}, rows, "cluster_35_bodies_lane_mode")
+# BASELINE configs[1] as a whole-world module ([n, 7] / [n, 6] tensors, no edges), one lane per entity: the instruction count that
+# explains its K = 1 time against the hand-written kernel's (the module's arithmetic is the reference's, operation for operation)
+rows = 262144                                                      # a grid of its own
+itext, islots = hb.independent_bodies_world(rows)
+isys, iman = sh.world_system(itext, islots, mode="lane")
+iw = workloads.independent_bodies(rows)
+run(isys, {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), workloads.DT_120HZ), "hlo_world_pos": iw["world_pos"].copy(),
+           "hlo_world_vel": iw["world_vel"].copy(), "hlo_world_accel": np.zeros((rows, 6)), "hlo_force": np.zeros((rows, 6)), "hlo_inertia": iw["inertia"].copy(),
+           "hlo_torque": iw["body_torque"].copy()}, rows, "independent_bodies_lane_mode")
 out = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / "world_keys.json"
 out.write_text(json.dumps({"ticks_per_launch": TICKS_PER_LAUNCH, "grids": keys}))
 print("done", keys)
