@@ -122,3 +122,27 @@ def test_the_cli_builds_a_large_world_and_the_object_is_installed_as_it_is(tmp_p
         cols2 = {k: np.concatenate([v, v]) for k, v in cols.items()}
         ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (2 * nb, 1)), np.zeros((2 * nb, 6)), np.ones((2 * nb, 7)), integrator=L.INTEGRATOR_NONE, effectors=prog, columns=cols2)
     hip.close()
+
+
+def test_a_sparse_newton_fold_world_on_the_gpu():
+    """70 bodies, three out-edges each, the three-body example's Newton fold (a `norm` function of its own in the module)."""
+    nb = 70
+    targets = {s_: [(s_ + k) % nb for k in (1, 5, 11)] for s_ in range(nb)}
+    G = 6.6743e-11
+    text, slots = hb.edge_fold_world(nb, targets, "newton", (G,))
+    prog, manifest, edges = sh.world_program(text, slots)
+    rng = np.random.default_rng(3)
+    pos = np.concatenate([np.tile([0, 0, 0, 1.0], (nb, 1)), rng.normal(size=(nb, 3)) * 10], axis=1)
+    vel = np.concatenate([np.zeros((nb, 3)), rng.normal(size=(nb, 3))], axis=1)
+    m = rng.uniform(1e9, 1e10, nb)
+    inertia = np.concatenate([np.tile(m[:, None], (1, 3)), np.zeros((nb, 3)), m[:, None]], axis=1)
+    cols = _columns(manifest, nb, pos, vel, inertia, 0.01)
+    ids = np.arange(1, nb + 1, dtype=np.uint64)
+    hip = ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (nb, 1)), np.zeros((nb, 6)), np.ones((nb, 7)), entity_ids=ids, integrator=L.INTEGRATOR_NONE,
+                     effectors=prog, columns=cols, graph_edges={k: (ids[np.asarray(a)], ids[np.asarray(b)]) for k, (a, b) in edges.items()})
+    hip.run(50)
+    src = np.array([s_ for s_ in range(nb) for _ in targets[s_]], dtype=np.uint32)
+    dst = np.array([t for s_ in range(nb) for t in targets[s_]], dtype=np.uint32)
+    ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=0.01, ops=[(orc.EFF_EDGE_GRAVITY_NEWTON, (G,), None)], edges=(src, dst)).step(50)
+    assert _errors(hip._aux, ref) <= 1e-9
+    hip.close()

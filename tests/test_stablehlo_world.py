@@ -548,3 +548,36 @@ def test_world_program_refuses_what_is_not_an_edge_fold_scan():
         sh.compile_world(text, meta, mode="lane")
     with pytest.raises(NotImplementedError, match="float64"):
         sh.compile_world(text, meta, mode="folds", dtype="float32")
+
+
+def test_a_sparse_newton_fold_over_a_large_world_is_lifted_the_same_way():
+    """Another fold body (examples/three-body/main.py:64-71: Newton gravity through `jnp.linalg.norm`, a function of its own in the
+    module, replacing the force's torque by zero) over another graph (70 bodies, three out-edges each, not a complete graph): the edges
+    come out in slot order and the walker equals the oracle's edge fold bit for bit."""
+    nb = 70
+    targets = {s_: [(s_ + k) % nb for k in (1, 5, 11)] for s_ in range(nb)}
+    G = 6.6743e-11
+    text, slots = hb.edge_fold_world(nb, targets, "newton", (G,))
+    prog, manifest, edges = sh.world_program(text, slots)
+    assert manifest["edges_per_fold"] == [3 * nb] * 4
+    for frm, to in edges.values():
+        assert list(frm) == [s_ for s_ in range(nb) for _ in range(3)] and list(to) == [t for s_ in range(nb) for t in targets[s_]]
+    tp = prog.trace({c["column"]: c["width"] for c in manifest["columns"]}, fold_edges=edges)
+    rng = np.random.default_rng(3)
+    pos = np.concatenate([np.tile([0, 0, 0, 1.0], (nb, 1)), rng.normal(size=(nb, 3)) * 10], axis=1)
+    vel = np.concatenate([np.zeros((nb, 3)), rng.normal(size=(nb, 3))], axis=1)
+    m = rng.uniform(1e9, 1e10, nb)
+    inertia = np.concatenate([np.tile(m[:, None], (1, 3)), np.zeros((nb, 3)), m[:, None]], axis=1)
+    comps = {"hlo_tick": np.zeros((nb, 1)), "hlo_simulation_time_step": np.full((nb, 1), 0.01), "hlo_world_pos": pos.copy(), "hlo_world_vel": vel.copy(),
+             "hlo_world_accel": np.zeros((nb, 6)), "hlo_force": np.zeros((nb, 6)), "hlo_inertia": inertia.copy()}
+    for nm, w in tp.columns:
+        comps.setdefault(nm, np.zeros((nb, w)))
+    bp, bv, ba, bi = np.tile([0, 0, 0, 1.0, 0, 0, 0], (nb, 1)), np.zeros((nb, 6)), np.zeros((nb, 6)), np.ones((nb, 7))
+    src = np.array([s_ for s_ in range(nb) for _ in targets[s_]], dtype=np.uint32)
+    dst = np.array([t for s_ in range(nb) for t in targets[s_]], dtype=np.uint32)
+    ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=0.01, ops=[(orc.EFF_EDGE_GRAVITY_NEWTON, (G,), None)], edges=(src, dst))
+    for r in range(1, 4):
+        dsl_numpy.program_tick_systems_only(tp, bp, bv, ba, bi, comps, r)
+    ref.step(3)
+    for nm, arr in (("hlo_world_pos", ref.world_pos), ("hlo_world_vel", ref.world_vel), ("hlo_world_accel", ref.world_accel), ("hlo_force", ref.force)):
+        assert np.array_equal(comps[nm], arr), nm
