@@ -16,10 +16,12 @@
 // F(c=1/2) (shared by stages 1 and 2, bit-identical) and F(c=1).  One tick is therefore
 //   1. pair_pack_kernel      per source: p(c=0), p(c=1/2), p(c=1), mass -> pack[n,10]   (FIRST tick of a batch only)
 //   2. allpairs_kernel       LDS-tiled all-pairs: every (target, source) pair is visited ONCE and
-//      / edge_kernel         accumulates the three stage forces together (3 independent FMA chains)
+//                            accumulates the three stage forces together (3 independent FMA chains)
 //   3. pair_integrate_kernel per entity: reduce the source splits in fixed order, calc_accel on each
 //                            stage, RK4 combination, write pos / vel / accel / force — and the NEXT tick's pack row
-//                            from the state it has just formed, so a batch of ticks is pack + 2 launches per tick.
+//                            from the state it has just formed, so a batch of ticks is pack + 2 launches per tick;
+//   edge lists (CSR):        2 + 3 in ONE launch per tick (pair_tick_fused_kernel, 3b: the lane folds its out-edges while its
+//                            state slabs land; pack rows double-buffered), hub sources folded by whole waves in front of it (2c).
 // instead of four dependent all-pairs sweeps.  Kernels 1 and 3 use the step kernel's memory plan (step_kernel.hpp):
 // single-wave workgroups own 64 consecutive rows, whole slabs move HBM <-> LDS 16 B per lane (LDS-DMA on the way in), a lane
 // reads / writes its own row in LDS — no 56- / 48-byte-strided global access is left on the path.  Bound: f64 vector ALU (about 21 instructions per pair
@@ -231,23 +233,6 @@ __device__ __forceinline__ void edge_accumulate(const double* pack, const uint32
     edge_accumulate_range<NS, PAIR>(pack, row_start[i], row_start[i + 1], dst, i, p0, p1, acc);
 }
 
-// `skip_hubs`: sources with kHubDegree or more out-edges are left to the hub kernels (2c), which write the same rows.
-template <int NS, class PAIR>
-__global__ __launch_bounds__(256) void edge_kernel(const double* __restrict__ pack, double* __restrict__ partial,
-                                                   const uint32_t* __restrict__ row_start,
-                                                   const uint32_t* __restrict__ dst, uint32_t n, double p0, double p1,
-                                                   uint32_t skip_hubs) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (skip_hubs && row_start[i + 1] - row_start[i] >= kHubDegree) return;
-    double acc[3][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
-    edge_accumulate<NS, PAIR>(pack, row_start, dst, i, p0, p1, acc);
-    double* o = partial + (size_t)i * kPartialWidth;
-#pragma unroll
-    for (int st = 0; st < NS; st++)
-        for (int c = 0; c < 6; c++) o[6 * st + c] = acc[st][c];
-}
-
 // ---- 2c. hub sources ----------------------------------------------------------------------------------------
 // One lane per source serialises on a source's out-degree: a hub with 10^5 out-edges would hold its wave for 10^5
 // dependent gathers while every other lane idles.  The reference buckets sources by out-degree for the same reason
@@ -441,20 +426,19 @@ __device__ __forceinline__ void load_ops(const PairParams& P, uint32_t i, bool a
     }
 }
 
-// Single-wave workgroups, 64 rows each (the step kernel's memory plan): pos / vel / inertia / world_accel — and, for edge
-// lists, the fold's [64, 18] partial rows — come in as slabs by LDS-DMA; pos / vel / accel / force and the NEXT tick's pack rows
-// leave as slabs.  The arithmetic is load_entity / pair_integrate_entity / pack_row, i.e. exactly the one-launch small-graph
+// The integrate half of an ALL-PAIRS tick (edge lists fold and integrate in one launch: 3b).  Single-wave workgroups, 64 rows
+// each (the step kernel's memory plan): pos / vel / inertia / world_accel come in as slabs by LDS-DMA; pos / vel / accel / force
+// and the NEXT tick's pack rows leave as slabs; the `splits` partial force sums (72 B each) are added per lane in fixed order.  The arithmetic is load_entity / pair_integrate_entity / pack_row, i.e. exactly the one-launch small-graph
 // kernel's: the two paths stay bit-identical (tests/test_gpu_parity.py::test_small_graph_single_launch_path_is_bit_identical).
 // (1.0 / x stays an IEEE divide here — four per entity and launch — because recip() may differ from it in the last bit.)
 template <int INTEGRATOR, bool PACK_NEXT>
 __global__ __launch_bounds__(kWave) void pair_integrate_kernel(const PairParams P) {
-    // in: pos 7 | vel 6 | inertia 7 | accel 6 | partial 18 = 44 doubles per row; out: pos 7 | vel 6 | accel 6 | force 6 | pack 10 = 35
-    __shared__ __attribute__((aligned(16))) double lds[kWave * 44];
+    // in: pos 7 | vel 6 | inertia 7 | accel 6 = 26 doubles per row; out: pos 7 | vel 6 | accel 6 | force 6 | pack 10 = 35
+    __shared__ __attribute__((aligned(16))) double lds[kWave * 35];
     double* const l_pos = lds;
     double* const l_vel = lds + kWave * 7;
     double* const l_in = lds + kWave * 13;
     double* const l_acc = lds + kWave * 20;
-    double* const l_part = lds + kWave * 26;
     const uint32_t row0 = blockIdx.x * kWave, t = threadIdx.x, i = row0 + t;
     const uint32_t rows = min((uint32_t)kWave, P.n - row0);
     const bool full = rows == kWave, active = t < rows;
@@ -463,38 +447,29 @@ __global__ __launch_bounds__(kWave) void pair_integrate_kernel(const PairParams 
     double* const g_acc = static_cast<double*>(P.accel) + (size_t)row0 * 6;
     double* const g_force = static_cast<double*>(P.force) + (size_t)row0 * 6;
     const double* const g_in = static_cast<const double*>(P.inertia) + (size_t)row0 * 7;
-    const bool edge_partial = P.partial_width != kPartialForce;      // wave-uniform
-    const double* const g_part = P.partial + (size_t)row0 * kPartialWidth;
     if (full) {
         slab_dma_in<kWave * 7 * 8, kPolPlain>(reinterpret_cast<const char*>(g_pos), reinterpret_cast<char*>(l_pos), t);
         slab_dma_in<kWave * 6 * 8, kPolPlain>(reinterpret_cast<const char*>(g_vel), reinterpret_cast<char*>(l_vel), t);
         slab_dma_in<kWave * 7 * 8, kPolPlain>(reinterpret_cast<const char*>(g_in), reinterpret_cast<char*>(l_in), t);
         slab_dma_in<kWave * 6 * 8, kPolPlain>(reinterpret_cast<const char*>(g_acc), reinterpret_cast<char*>(l_acc), t);
-        if (edge_partial) slab_dma_in<kWave * kPartialWidth * 8, kPolNt>(reinterpret_cast<const char*>(g_part), reinterpret_cast<char*>(l_part), t);
     } else {
         slab_in_tail(g_pos, l_pos, rows * 7, t);
         slab_in_tail(g_vel, l_vel, rows * 6, t);
         slab_in_tail(g_in, l_in, rows * 7, t);
         slab_in_tail(g_acc, l_acc, rows * 6, t);
-        if (edge_partial) slab_in_tail(g_part, l_part, rows * kPartialWidth, t);
     }
     StepParams SP;
     Vec3<double> aux[kMaxOps];
     load_ops(P, i, active, SP, aux);
     constexpr int NS = INTEGRATOR == kRk4 ? 3 : 1;
     double pf[3][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
-    bool is_source = false;
-    if (active) {
-        if (!edge_partial) {      // all-pairs: `splits` partial sums of 72 bytes each, added in fixed order (deterministic)
-            is_source = P.n > 1;
-            for (uint32_t sp = 0; sp < P.splits; sp++) {
-                const double* part = P.partial + ((size_t)sp * P.n + i) * kPartialForce;
+    const bool is_source = active && P.n > 1;
+    if (active) {      // `splits` partial sums of 72 bytes each, added in fixed order (deterministic)
+        for (uint32_t sp = 0; sp < P.splits; sp++) {
+            const double* part = P.partial + ((size_t)sp * P.n + i) * kPartialForce;
 #pragma unroll
-                for (int st = 0; st < NS; st++)
-                    for (int c = 0; c < 3; c++) pf[st][3 + c] += part[3 * st + c];
-            }
-        } else {
-            is_source = P.row_start[i + 1] > P.row_start[i];
+            for (int st = 0; st < NS; st++)
+                for (int c = 0; c < 3; c++) pf[st][3 + c] += part[3 * st + c];
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA data has landed
@@ -514,12 +489,6 @@ __global__ __launch_bounds__(kWave) void pair_integrate_kernel(const PairParams 
         e.inv_m = 1.0 / in[6];
         const double* ac = l_acc + t * 6;
         A = Spatial<double>{{ac[0], ac[1], ac[2]}, {ac[3], ac[4], ac[5]}};
-        if (edge_partial) {
-            const double* part = l_part + t * kPartialWidth;
-#pragma unroll
-            for (int st = 0; st < NS; st++)
-                for (int c = 0; c < 6; c++) pf[st][c] = part[6 * st + c];
-        }
     }
     __syncthreads();  // every lane has consumed the input slabs; LDS is the output staging area from here on
     if (active) pair_integrate_entity<INTEGRATOR>(P, SP, aux, pf, is_source, e, A, Fw);
@@ -559,7 +528,7 @@ __global__ __launch_bounds__(kWave) void pair_integrate_kernel(const PairParams 
     }
 }
 
-// ---- 3b. sparse graphs without hubs: fold + integrate in ONE launch ------------------------------------------------------------
+// ---- 3b. edge lists: fold + integrate in ONE launch (hub sources' sums come from the two hub launches in front of it) -------------
 // The edge fold reads only the PACK rows (of the source and of its targets); the integrate half reads the source's own state.
 // With the pack rows double-buffered — this tick reads `pack`, writes the next tick's rows to `pack_next` — nothing a wave reads
 // is written by another wave of the same launch, so the two halves need no launch boundary between them: a tick is one kernel,
@@ -600,7 +569,15 @@ __global__ __launch_bounds__(kWave) void pair_tick_fused_kernel(const PairParams
     if (active) {      // the fold, while the slabs land
         const uint32_t e0 = P.row_start[i], e1 = P.row_start[i + 1];
         is_source = e1 > e0;
-        edge_accumulate_range<NS, PAIR>(P.pack, e0, e1, P.dst, i, P.p0, P.p1, pf);
+        if (PAIR::kAdditive && P.n_hubs && e1 - e0 >= kHubDegree) {
+            // a hub source: its edges were folded by whole waves in front of this launch (2c), the sums wait in its partial row
+            const double* part = P.partial + (size_t)i * kPartialWidth;
+#pragma unroll
+            for (int st = 0; st < NS; st++)
+                for (int c = 0; c < 6; c++) pf[st][c] = part[6 * st + c];
+        } else {
+            edge_accumulate_range<NS, PAIR>(P.pack, e0, e1, P.dst, i, P.p0, P.p1, pf);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -759,9 +736,9 @@ template <class PAIR, bool ALLPAIRS, int ONLY = -1>
 inline hipError_t launch_pair_ticks_t(const PairParams& p, int integrator, uint32_t n_ticks, bool packed, hipStream_t stream, uint64_t* launches) {
     if (p.n == 0 || n_ticks == 0) return hipSuccess;
     if (ONLY >= 0 && integrator != ONLY) return hipErrorInvalidValue;
-    const uint32_t blocks = (p.n + 255) / 256, waves = (p.n + kWave - 1) / kWave;
+    const uint32_t waves = (p.n + kWave - 1) / kWave;
     const double h1 = p.dt_g * 0.5, h3 = p.dt_g;
-    const bool fused_path = !ALLPAIRS && (PAIR::kAdditive ? p.n_hubs : 0u) == 0 && p.pack_next != nullptr;      // (its buffers alternate: every batch packs)
+    const bool fused_path = !ALLPAIRS && p.pack_next != nullptr;      // (its buffers alternate: every batch packs)
     if (!packed || fused_path) {
         hipLaunchKernelGGL(pair_pack_kernel, dim3(waves), dim3(kWave), 0, stream, static_cast<const double*>(p.pos),
                            static_cast<const double*>(p.vel), static_cast<const double*>(p.inertia), p.pack, p.n, h1, h3);
@@ -769,10 +746,22 @@ inline hipError_t launch_pair_ticks_t(const PairParams& p, int integrator, uint3
     }
     const bool rk4 = integrator == kRk4;
     if constexpr (!ALLPAIRS) {
-        // no hub sources (or a fold that may not be regrouped: it never uses the hub kernels) and a second pack buffer: ONE launch per tick
-        if ((PAIR::kAdditive ? p.n_hubs : 0u) == 0 && p.pack_next != nullptr) {
+        // with a second pack buffer: ONE launch per tick (+ the two hub launches in front of it when there are hub sources)
+        if (p.pack_next != nullptr) {
             PairParams q = p;
+            const uint32_t hubs = PAIR::kAdditive ? p.n_hubs : 0u;
             for (uint32_t t = 0; t < n_ticks; t++) {
+                if (hubs) {
+                    if constexpr (ONLY != kSemiImplicit) if (rk4) {
+                        hipLaunchKernelGGL((edge_hub_chunk_kernel<3, PAIR>), dim3(q.n_hub_chunks), dim3(64), 0, stream, q.pack, q.row_start, q.dst, q.chunk_e0, q.chunk_row, q.chunk_partial, q.p0, q.p1);
+                        hipLaunchKernelGGL(edge_hub_reduce_kernel<3>, dim3(hubs), dim3(64), 0, stream, q.hub_rows, q.hub_chunk_start, q.chunk_partial, q.partial);
+                    }
+                    if constexpr (ONLY != kRk4) if (!rk4) {
+                        hipLaunchKernelGGL((edge_hub_chunk_kernel<1, PAIR>), dim3(q.n_hub_chunks), dim3(64), 0, stream, q.pack, q.row_start, q.dst, q.chunk_e0, q.chunk_row, q.chunk_partial, q.p0, q.p1);
+                        hipLaunchKernelGGL(edge_hub_reduce_kernel<1>, dim3(hubs), dim3(64), 0, stream, q.hub_rows, q.hub_chunk_start, q.chunk_partial, q.partial);
+                    }
+                    if (launches) *launches += 2;
+                }
                 if constexpr (ONLY != kSemiImplicit) { if (rk4) hipLaunchKernelGGL((pair_tick_fused_kernel<kRk4, PAIR>), dim3(waves), dim3(kWave), 0, stream, q); }
                 if constexpr (ONLY != kRk4) { if (!rk4) hipLaunchKernelGGL((pair_tick_fused_kernel<kSemiImplicit, PAIR>), dim3(waves), dim3(kWave), 0, stream, q); }
                 double* const cur = q.pack;      // the rows just written are the next tick's
@@ -783,34 +772,19 @@ inline hipError_t launch_pair_ticks_t(const PairParams& p, int integrator, uint3
             return hipGetLastError();
         }
     }
-    for (uint32_t t = 0; t < n_ticks; t++) {
-        if constexpr (ALLPAIRS) {
+    if constexpr (ALLPAIRS) {
+        for (uint32_t t = 0; t < n_ticks; t++) {
             const dim3 grid((p.n + kTile - 1) / kTile, p.splits);
             if constexpr (ONLY != kSemiImplicit) { if (rk4) hipLaunchKernelGGL(allpairs_kernel<3>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1); }
             if constexpr (ONLY != kRk4) { if (!rk4) hipLaunchKernelGGL(allpairs_kernel<1>, grid, dim3(kTile), 0, stream, p.pack, p.partial, p.n, p.splits, p.p0, p.p1); }
-        } else {
-            const uint32_t hubs = PAIR::kAdditive ? p.n_hubs : 0u;   // a fold that is not a plain sum stays sequential per source
-            if constexpr (ONLY != kSemiImplicit) { if (rk4) hipLaunchKernelGGL((edge_kernel<3, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1, hubs); }
-            if constexpr (ONLY != kRk4) { if (!rk4) hipLaunchKernelGGL((edge_kernel<1, PAIR>), dim3(blocks), dim3(256), 0, stream, p.pack, p.partial, p.row_start, p.dst, p.n, p.p0, p.p1, hubs); }
-            if (hubs) {
-                if constexpr (ONLY != kSemiImplicit) if (rk4) {
-                    hipLaunchKernelGGL((edge_hub_chunk_kernel<3, PAIR>), dim3(p.n_hub_chunks), dim3(64), 0, stream, p.pack, p.row_start, p.dst, p.chunk_e0, p.chunk_row, p.chunk_partial, p.p0, p.p1);
-                    hipLaunchKernelGGL(edge_hub_reduce_kernel<3>, dim3(hubs), dim3(64), 0, stream, p.hub_rows, p.hub_chunk_start, p.chunk_partial, p.partial);
-                }
-                if constexpr (ONLY != kRk4) if (!rk4) {
-                    hipLaunchKernelGGL((edge_hub_chunk_kernel<1, PAIR>), dim3(p.n_hub_chunks), dim3(64), 0, stream, p.pack, p.row_start, p.dst, p.chunk_e0, p.chunk_row, p.chunk_partial, p.p0, p.p1);
-                    hipLaunchKernelGGL(edge_hub_reduce_kernel<1>, dim3(hubs), dim3(64), 0, stream, p.hub_rows, p.hub_chunk_start, p.chunk_partial, p.partial);
-                }
-                if (launches) *launches += 2;
-            }
+            // every tick writes the next tick's pack rows (5 KB per wave beside the 12.5 KB of state it writes anyway)
+            if constexpr (ONLY != kSemiImplicit) { if (rk4) hipLaunchKernelGGL((pair_integrate_kernel<kRk4, true>), dim3(waves), dim3(kWave), 0, stream, p); }
+            if constexpr (ONLY != kRk4) { if (!rk4) hipLaunchKernelGGL((pair_integrate_kernel<kSemiImplicit, true>), dim3(waves), dim3(kWave), 0, stream, p); }
+            if (launches) *launches += 2;
         }
-        // every tick writes the next tick's pack rows (5 KB per wave beside the 12.5 KB of state it writes anyway): the last tick's
-        // are what lets the NEXT batch skip its pack launch when nothing touched the state in between
-        if constexpr (ONLY != kSemiImplicit) { if (rk4) hipLaunchKernelGGL((pair_integrate_kernel<kRk4, true>), dim3(waves), dim3(kWave), 0, stream, p); }
-        if constexpr (ONLY != kRk4) { if (!rk4) hipLaunchKernelGGL((pair_integrate_kernel<kSemiImplicit, true>), dim3(waves), dim3(kWave), 0, stream, p); }
-        if (launches) *launches += 2;
+        return hipGetLastError();
     }
-    return hipGetLastError();
+    return hipErrorInvalidValue;      // an edge list without the second pack buffer (PairParams::pack_next): not a launch this library makes
 }
 
 // One tick on its own (pack -> fold -> integrate).

@@ -343,7 +343,7 @@ def test_hub_sources_are_folded_by_whole_waves_and_match_the_sequential_fold(kin
     hip.run(5); ref.step(5)
     errs = parity.state_errors(hip, ref)
     assert max(errs.values()) < parity.F64_RTOL, errs
-    assert hip.last_timings().launches == 1 + 5 * 4        # one pack for the batch, then per tick: lane fold, hub chunks, hub reduce, integrate (+ next pack rows)
+    assert hip.last_timings().launches == 1 + 5 * 3        # one pack for the batch, then per tick: hub chunks, hub reduce, the fused fold-and-integrate launch
 
 
 def test_edge_fold_replaces_force_only_on_source_rows():
