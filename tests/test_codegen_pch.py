@@ -118,10 +118,11 @@ def test_a_pair_object_built_for_one_executor_carries_only_its_kernels(jit_dirs)
     every = _kernel_names(codegen.build_pair(tf))
     small_rk4 = _kernel_names(codegen.build_pair(tf, integrator=0, small=True))
     tick_semi = _kernel_names(codegen.build_pair(tf, integrator=1, small=False))
-    assert len(every) == 11
+    assert len(every) == 9         # pack | small x2 | hub chunk x2 | hub reduce x2 | fused fold-and-integrate x2
     # (pair_pack_kernel is a plain __global__ of the header: always there)
     assert len(small_rk4) == 2 and any("pair_small_kernel" in k and "ILi0E" in k for k in small_rk4)
-    assert len(tick_semi) == 5 and not any("pair_small_kernel" in k for k in tick_semi), tick_semi
+    assert len(tick_semi) == 4 and not any("pair_small_kernel" in k for k in tick_semi), tick_semi
+    assert any("pair_tick_fused_kernel" in k for k in tick_semi)
     assert all("ILi1E" in k for k in tick_semi if "ILi" in k), tick_semi       # the semi-implicit stage count / integrator only
     assert set(small_rk4) <= set(every) and set(tick_semi) <= set(every)
     with pytest.raises(ValueError):
