@@ -195,30 +195,15 @@ __global__ __launch_bounds__(kTile) void allpairs_kernel(const double* __restric
 
 // ---- 2b. explicit edge list, CSR by source (three-body and sparse graphs) ---------------------------------
 // One source's left fold over its out-edges (CSR range), spawn order, for the NS stage positions.
-// A lane's edges are independent GATHERS feeding one dependent fold: with one wave per SIMD (65,536 sources = 1,024 waves) nothing
-// hides a gather's round trip, so the targets' pack rows are fetched kEdgeBatch edges at a time — all their loads in flight
-// together — and folded in order afterwards.  Same operations in the same order: the bits do not change.
-constexpr int kEdgeBatch = 4;
+// (Fetching the targets' pack rows several edges at a time, all their loads in flight together, was tried and measured: nothing —
+// 20.0 vs 19.5 us for the 1 M-edge fold; the fold is a chain of dependent arithmetic, not of gathers — and the row buffers cost a
+// large generated fold function its registers: profiles/r06_pair_kernels.md.)
 template <int NS, class PAIR>
 __device__ __forceinline__ void edge_accumulate_range(const double* pack, uint32_t e0, uint32_t e1, const uint32_t* dst,
                                                       uint32_t i, double p0, double p1, double (&acc)[3][6]) {
     const double* a = pack + (size_t)i * kPackWidth;
     const double ma = a[9];
-    uint32_t e = e0;
-    for (; e + kEdgeBatch <= e1; e += kEdgeBatch) {
-        double rows[kEdgeBatch][kPackWidth];
-#pragma unroll
-        for (int u = 0; u < kEdgeBatch; u++) {
-            const double* b = pack + (size_t)dst[e + u] * kPackWidth;
-#pragma unroll
-            for (int k = 0; k < kPackWidth; k++) rows[u][k] = (k < 3 * NS || k == 9) ? b[k] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < kEdgeBatch; u++)
-#pragma unroll
-            for (int st = 0; st < NS; st++) PAIR::fold(acc[st], a + 3 * st, ma, rows[u] + 3 * st, rows[u][9], p0, p1);
-    }
-    for (; e < e1; e++) {  // spawn order inside a source
+    for (uint32_t e = e0; e < e1; e++) {  // spawn order inside a source
         const double* b = pack + (size_t)dst[e] * kPackWidth;
         const double mb = b[9];
 #pragma unroll
