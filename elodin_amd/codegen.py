@@ -1418,6 +1418,7 @@ struct PairCustom {{
     // every component is acc_k +/- g_k(a, b) or the constant 0: partial folds over disjoint edge subsets may be summed, so hub
     // sources are folded by whole waves (pair_kernel.hpp 2c); anything else keeps the sequential fold per source
     static constexpr bool kAdditive = {"true" if additive else "false"};
+    static constexpr int kEdgeBatch = 1;      // a generated fold keeps the plain per-edge loop (pair_kernel.hpp edge_accumulate_range: registers)
     __device__ static __forceinline__ void fold(double (&acc)[6], const double* pa, double ma, const double* pb,
                                                 double mb, double, double) {{
         using T = double;

@@ -54,6 +54,7 @@ constexpr uint32_t kSmallEdgeCache = 2048;  // edges of a small graph (n <= 256)
 // against the divide-exact oracle — inside the 1e-9 bar like every other reciprocal of this backend.
 struct PairNewton {   // examples/three-body/main.py:61-70: r = a - b; f = G*M*m*r / |r|^3; Force(linear = acc.f - f)
     static constexpr bool kAdditive = true;
+    static constexpr int kEdgeBatch = 4;      // targets fetched per round trip (edge_accumulate_range)
     __device__ static __forceinline__ void fold(double (&acc)[6], const double* pa, double ma, const double* pb,
                                                 double mb, double p0, double) {
         const double rx = pa[0] - pb[0], ry = pa[1] - pb[1], rz = pa[2] - pb[2];
@@ -67,6 +68,7 @@ struct PairNewton {   // examples/three-body/main.py:61-70: r = a - b; f = G*M*m
 };
 struct PairSoftened {   // examples/n-body/sim.py:356-361: acc + SpatialForce(linear = K ma mb inv^3 r), r = b - a
     static constexpr bool kAdditive = true;
+    static constexpr int kEdgeBatch = 4;
     __device__ static __forceinline__ void fold(double (&acc)[6], const double* pa, double ma, const double* pb,
                                                 double mb, double p0, double p1) {
         const double rx = pb[0] - pa[0], ry = pb[1] - pa[1], rz = pb[2] - pa[2];
@@ -195,15 +197,35 @@ __global__ __launch_bounds__(kTile) void allpairs_kernel(const double* __restric
 
 // ---- 2b. explicit edge list, CSR by source (three-body and sparse graphs) ---------------------------------
 // One source's left fold over its out-edges (CSR range), spawn order, for the NS stage positions.
-// (Fetching the targets' pack rows several edges at a time, all their loads in flight together, was tried and measured: nothing —
-// 20.0 vs 19.5 us for the 1 M-edge fold; the fold is a chain of dependent arithmetic, not of gathers — and the row buffers cost a
-// large generated fold function its registers: profiles/r06_pair_kernels.md.)
+// A lane's edges are independent GATHERS feeding one dependent fold.  PAIR::kEdgeBatch > 1 fetches the targets' pack rows that
+// many edges at a time — all their loads in flight together — and folds them in order afterwards: same operations in the same
+// order, the bits do not change.  Measured (profiles/r06_pair_kernels.md): nothing for the stand-alone fold kernel of the
+// two-kernel tick (20.0 vs 19.5 us), 17.0 -> 13.0 us for the fused fold-and-integrate launch, where the fold sits on the wave's
+// critical path beside its slab loads.  The built-in folds take 4; a GENERATED fold function keeps the plain loop (kEdgeBatch = 1):
+// the row buffers cost registers a large function does not have (a fuzz-generated fold spilled 8 VGPRs with them and was refused).
 template <int NS, class PAIR>
 __device__ __forceinline__ void edge_accumulate_range(const double* pack, uint32_t e0, uint32_t e1, const uint32_t* dst,
                                                       uint32_t i, double p0, double p1, double (&acc)[3][6]) {
     const double* a = pack + (size_t)i * kPackWidth;
     const double ma = a[9];
-    for (uint32_t e = e0; e < e1; e++) {  // spawn order inside a source
+    uint32_t e = e0;
+    if constexpr (PAIR::kEdgeBatch > 1) {
+        constexpr int B = PAIR::kEdgeBatch;
+        for (; e + B <= e1; e += B) {
+            double rows[B][kPackWidth];
+#pragma unroll
+            for (int u = 0; u < B; u++) {
+                const double* b = pack + (size_t)dst[e + u] * kPackWidth;
+#pragma unroll
+                for (int k = 0; k < kPackWidth; k++) rows[u][k] = (k < 3 * NS || k == 9) ? b[k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < B; u++)
+#pragma unroll
+                for (int st = 0; st < NS; st++) PAIR::fold(acc[st], a + 3 * st, ma, rows[u] + 3 * st, rows[u][9], p0, p1);
+        }
+    }
+    for (; e < e1; e++) {  // spawn order inside a source
         const double* b = pack + (size_t)dst[e] * kPackWidth;
         const double mb = b[9];
 #pragma unroll
