@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Tick time of whole-world StableHLO ticks run as fold stages (stablehlo.world_program): n-body worlds of 80 and 256 bodies, one
+world and a Monte-Carlo of them.   python tools/fold_world_time.py   (needs a GPU)"""
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import numpy as np
+import elodin_amd as ea
+from elodin_amd import _lib as L
+from elodin_amd import stablehlo as sh
+from tests.golden import hlo_world_builder as hb
+
+out = {}
+for nb, worlds in ((80, 1), (80, 64), (256, 1), (256, 16)):
+    t0 = time.perf_counter()
+    text, slots = hb.nbody_world(nb, 2.9591220828e-4, 1e-6)
+    prog, manifest, edges = sh.world_program(text, slots)
+    rows = nb * worlds
+    rng = np.random.default_rng(nb)
+    pos = np.concatenate([np.tile([0, 0, 0, 1.0], (rows, 1)), rng.normal(size=(rows, 3)) * 3], axis=1)
+    vel = np.concatenate([np.zeros((rows, 3)), rng.normal(size=(rows, 3)) * 1e-3], axis=1)
+    m = rng.uniform(1e-6, 1e-3, rows)
+    inertia = np.concatenate([np.tile(m[:, None], (1, 3)), np.zeros((rows, 3)), m[:, None]], axis=1)
+    cols = {c["column"]: np.zeros((rows, c["width"])) for c in manifest["columns"]}
+    cols["hlo_simulation_time_step"][:] = 0.5
+    cols["hlo_world_pos"], cols["hlo_world_vel"], cols["hlo_inertia"] = pos, vel, inertia
+    ids = np.arange(1, rows + 1, dtype=np.uint64)
+    ex = ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (rows, 1)), np.zeros((rows, 6)), np.ones((rows, 7)), entity_ids=ids, integrator=L.INTEGRATOR_NONE,
+                    effectors=prog, columns=cols, graph_replicas=(worlds, nb) if worlds > 1 else None,
+                    graph_edges={k: (ids[np.asarray(a)], ids[np.asarray(b)]) for k, (a, b) in edges.items()})
+    build_s = time.perf_counter() - t0
+    ex.invoke_batch(5)
+    tm = ex.invoke_batch(50)
+    ex.close()
+    us = tm.kernel_device_ms / 50 * 1e3
+    out[f"{nb}_bodies_x_{worlds}_worlds"] = {"us_per_tick": round(us, 2), "launches_per_tick": int(tm.launches // 50), "pair_evals_per_s": round(4.0 * nb * (nb - 1) * worlds / us * 1e6, 1),
+                                              "build_seconds_incl_trace_and_hipcc_or_cache": round(build_s, 2)}
+print(json.dumps(out, indent=1))
