@@ -1108,6 +1108,20 @@ def _emit_fold_stage(fs: "dsl.TracedFoldStage") -> str:
     body = "\n".join(emit_block([(f"acc[{k}]", e) for k, e in enumerate(fs.traced.outputs)], leaves, indent="        "))
     init = ", ".join(f"T({v!r})" for v in f.init)
     nl = "\n"
+    # One lane per source folds its out-edges in order: a chain of dependent gathers, ~350 ns a trip with nothing to hide it behind
+    # (a 256-body complete graph: 255 trips, 4 folds per tick = 353 us: profiles/r06_fold_world_time_plain_loop.json).  So the targets'
+    # rows are fetched FOLD_BATCH edges at a time — all their loads in flight together — and folded in order afterwards: the same
+    # operations in the same order.  Only for narrow right-hand sides (the row buffers are registers).
+    batched = ""
+    if sum(wn for _, _, wn in fs.right) <= 16 and len(fs.dst) >= 4 * len(fs.src_rows):
+        B = 4
+        decl = "".join(f"        T rb{i}[{B}][{wn}];\n" for i, (_, _, wn) in enumerate(fs.right))
+        fetch = "".join(f"            {{ const T* g = {ptr(n, slot)} + (size_t)(base + fold{j}_dst[e + u]) * {wn};\n"
+                        f"#pragma unroll\n              for (int k = 0; k < {wn}; k++) rb{i}[u][k] = g[k]; }}\n" for i, (n, slot, wn) in enumerate(fs.right))
+        use = "".join(f"            const T* b{i} = rb{i}[u];\n" for i in range(len(fs.right)))
+        inner = "\n".join("    " + ln for ln in body.split("\n"))
+        batched = (f"    for (; e + {B} <= fold{j}_start[i + 1]; e += {B}) {{\n{decl}#pragma unroll\n        for (int u = 0; u < {B}; u++) {{\n{fetch}        }}\n"
+                   f"#pragma unroll\n        for (int u = 0; u < {B}; u++) {{\n{use}{inner}\n        }}\n    }}\n")
     n_src = len(fs.src_rows)
     count, stride = fs.replicas if fs.replicas else (1, 0)
     arr = lambda xs: ", ".join(str(int(x)) for x in xs) if xs else "0"
@@ -1124,7 +1138,8 @@ __global__ __launch_bounds__(64) void fold{j}_kernel(const StepParams P) {{
     if (row >= P.n) return;
 {nl.join(loads_a)}
     T acc[{w}] = {{{init}}};
-    for (uint32_t e = fold{j}_start[i]; e < fold{j}_start[i + 1]; e++) {{
+    uint32_t e = fold{j}_start[i];
+{batched}    for (; e < fold{j}_start[i + 1]; e++) {{
 {nl.join(loads_b)}
 {body}
     }}
