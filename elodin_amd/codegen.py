@@ -1111,10 +1111,12 @@ def _emit_fold_stage(fs: "dsl.TracedFoldStage") -> str:
     # One lane per source folds its out-edges in order: a chain of dependent gathers, ~350 ns a trip with nothing to hide it behind
     # (a 256-body complete graph: 255 trips, 4 folds per tick = 353 us: profiles/r06_fold_world_time_plain_loop.json).  So the targets'
     # rows are fetched FOLD_BATCH edges at a time — all their loads in flight together — and folded in order afterwards: the same
-    # operations in the same order.  Only for narrow right-hand sides (the row buffers are registers).
+    # operations in the same order.  Asked for by the fold (dsl.GraphFold.gather_batch: the scans stablehlo.world_program lifts out of a
+    # whole-world tick set it; folds written by hand keep the plain loop and their generated text), narrow right-hand sides only
+    # (the row buffers are registers).
     batched = ""
-    if sum(wn for _, _, wn in fs.right) <= 16 and len(fs.dst) >= 4 * len(fs.src_rows):
-        B = 4
+    B = int(getattr(f, "gather_batch", 1) or 1)
+    if B > 1 and sum(wn for _, _, wn in fs.right) <= 16:
         decl = "".join(f"        T rb{i}[{B}][{wn}];\n" for i, (_, _, wn) in enumerate(fs.right))
         fetch = "".join(f"            {{ const T* g = {ptr(n, slot)} + (size_t)(base + fold{j}_dst[e + u]) * {wn};\n"
                         f"#pragma unroll\n              for (int k = 0; k < {wn}; k++) rb{i}[u][k] = g[k]; }}\n" for i, (n, slot, wn) in enumerate(fs.right))
@@ -1138,8 +1140,7 @@ __global__ __launch_bounds__(64) void fold{j}_kernel(const StepParams P) {{
     if (row >= P.n) return;
 {nl.join(loads_a)}
     T acc[{w}] = {{{init}}};
-    uint32_t e = fold{j}_start[i];
-{batched}    for (; e < fold{j}_start[i + 1]; e++) {{
+{("    uint32_t e = fold" + str(j) + "_start[i];" + nl + batched + "    for (; e < fold" + str(j) + "_start[i + 1]; e++) {") if batched else ("    for (uint32_t e = fold" + str(j) + "_start[i]; e < fold" + str(j) + "_start[i + 1]; e++) {")}
 {nl.join(loads_b)}
 {body}
     }}

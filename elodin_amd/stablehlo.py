@@ -2711,6 +2711,7 @@ def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = No
             return fold_fn
         edge_c = f"hlo_fold{r.index}_edges"
         folds.append(_dsl.GraphFold(make_fn(), edge_c, (own_c,), (nbr_c,), out_c, list(r.init)))
+        folds[-1].gather_batch = 4 if len(r.table[0]) >= 4 else 1      # a long scan is a chain of dependent gathers: fetch four targets per round trip (codegen._emit_fold_stage)
         graph_edges[edge_c] = ([s_ for s_ in range(n_entities) for _ in r.table[s_]], [t for s_ in range(n_entities) for t in r.table[s_]])
     n_folds = len(folds)
     all_cols = world_cols + [c for r in probe.requests for c in (f"hlo_fold{r.index}_own", f"hlo_fold{r.index}_nbr", f"hlo_fold{r.index}_out")]
