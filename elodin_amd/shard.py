@@ -73,6 +73,8 @@ def gather_rows(local_rows: np.ndarray, total_rows: int, device="cpu", unit: int
         raise ValueError(f"{total_rows} rows are not a whole number of {unit}-row units")
     # the packing is the C ABI's (sixdof_gather_pack / _unpack: equal zero-padded blocks, what sixdof_campaign_gather runs around
     # its ncclAllGather); only the transport is torch's.  A `unit` of rows travels as one wider row; f64 on the wire (exact for f32).
+    if local_rows.dtype.kind in "iu" and local_rows.dtype.itemsize >= 8:
+        raise TypeError("gather_rows moves rows as float64: 64-bit integer rows would not survive beyond 2^53 (gather them as 32-bit halves)")
     dtype, width = local_rows.dtype, local_rows.shape[1] * unit
     local = np.ascontiguousarray(local_rows, dtype=np.float64).reshape(local_rows.shape[0] // unit, width)
     pad = pack_block(local, total_rows // unit, world, rank)
