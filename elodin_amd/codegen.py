@@ -1096,6 +1096,10 @@ def _emit_fold_stage(fs: "dsl.TracedFoldStage") -> str:
     body_ptr = {"world_pos": "P.pos", "world_vel": "P.vel", "inertia": "P.inertia"}
     ptr = lambda name, slot: f"static_cast<const T*>({body_ptr[name]})" if slot is None else f"static_cast<const T*>(P.model_cols[{slot}])"
     leaves = {f"acc_{k}": f"acc[{k}]" for k in range(w)}
+    complete = int(getattr(fs, "complete", 0) or 0)
+    # the target row of edge e: from the baked CSR, or — a complete graph — slot s of source i is row s + (s >= i)
+    dst_of = (lambda e_: f"({e_} + (({e_}) >= i ? 1u : 0u))") if complete else (lambda e_: f"fold{j}_dst[{e_}]")
+    e_lo, e_hi = ("0u", f"{complete - 1}u") if complete else (f"fold{j}_start[i]", f"fold{j}_start[i + 1]")
     loads_a, loads_b = [], []
     for i, (n, slot, wn) in enumerate(fs.left):
         for k in range(wn):
@@ -1104,7 +1108,7 @@ def _emit_fold_stage(fs: "dsl.TracedFoldStage") -> str:
     for i, (n, slot, wn) in enumerate(fs.right):
         for k in range(wn):
             leaves[f"b{i}_{k}"] = f"b{i}[{k}]"
-        loads_b.append(f"        const T* b{i} = {ptr(n, slot)} + (size_t)(base + fold{j}_dst[e]) * {wn};")
+        loads_b.append(f"        const T* b{i} = {ptr(n, slot)} + (size_t)(base + {dst_of('e')}) * {wn};")
     body = "\n".join(emit_block([(f"acc[{k}]", e) for k, e in enumerate(fs.traced.outputs)], leaves, indent="        "))
     init = ", ".join(f"T({v!r})" for v in f.init)
     nl = "\n"
@@ -1118,29 +1122,33 @@ def _emit_fold_stage(fs: "dsl.TracedFoldStage") -> str:
     B = int(getattr(f, "gather_batch", 1) or 1)
     if B > 1 and sum(wn for _, _, wn in fs.right) <= 16:
         decl = "".join(f"        T rb{i}[{B}][{wn}];\n" for i, (_, _, wn) in enumerate(fs.right))
-        fetch = "".join(f"            {{ const T* g = {ptr(n, slot)} + (size_t)(base + fold{j}_dst[e + u]) * {wn};\n"
+        fetch = "".join(f"            {{ const T* g = {ptr(n, slot)} + (size_t)(base + {dst_of('e + u')}) * {wn};\n"
                         f"#pragma unroll\n              for (int k = 0; k < {wn}; k++) rb{i}[u][k] = g[k]; }}\n" for i, (n, slot, wn) in enumerate(fs.right))
         use = "".join(f"            const T* b{i} = rb{i}[u];\n" for i in range(len(fs.right)))
         inner = "\n".join("    " + ln for ln in body.split("\n"))
-        batched = (f"    for (; e + {B} <= fold{j}_start[i + 1]; e += {B}) {{\n{decl}#pragma unroll\n        for (int u = 0; u < {B}; u++) {{\n{fetch}        }}\n"
+        batched = (f"    for (; e + {B} <= {e_hi}; e += {B}) {{\n{decl}#pragma unroll\n        for (int u = 0; u < {B}; u++) {{\n{fetch}        }}\n"
                    f"#pragma unroll\n        for (int u = 0; u < {B}; u++) {{\n{use}{inner}\n        }}\n    }}\n")
     n_src = len(fs.src_rows)
     count, stride = fs.replicas if fs.replicas else (1, 0)
     arr = lambda xs: ", ".join(str(int(x)) for x in xs) if xs else "0"
-    return f'''// ---- fold stage {j}: {fs.name} ({len(fs.dst)} edges, {n_src} sources{f", x {count} replicas of {stride} rows" if fs.replicas else ""}) ----
-__device__ const uint32_t fold{j}_src[{max(n_src, 1)}] = {{{arr(fs.src_rows)}}};
-__device__ const uint32_t fold{j}_start[{n_src + 1}] = {{{arr(fs.row_start)}}};
-__device__ const uint32_t fold{j}_dst[{max(len(fs.dst), 1)}] = {{{arr(fs.dst)}}};
+    tables = (f"// (the complete graph over the {complete} rows of a world: no tables — slot s of source i is row s + (s >= i))" if complete else
+              f"__device__ const uint32_t fold{j}_src[{max(n_src, 1)}] = {{{arr(fs.src_rows)}}};\n"
+              f"__device__ const uint32_t fold{j}_start[{n_src + 1}] = {{{arr(fs.row_start)}}};\n"
+              f"__device__ const uint32_t fold{j}_dst[{max(len(fs.dst), 1)}] = {{{arr(fs.dst)}}};")
+    src_of = (lambda i_: i_) if complete else (lambda i_: f"fold{j}_src[{i_}]")
+    n_edges = complete * (complete - 1) if complete else len(fs.dst)
+    return f'''// ---- fold stage {j}: {fs.name} ({n_edges} edges, {n_src} sources{f", x {count} replicas of {stride} rows" if fs.replicas else ""}) ----
+{tables}
 template <class T>
 __global__ __launch_bounds__(64) void fold{j}_kernel(const StepParams P) {{
     const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
     if (gi >= {n_src * count}u) return;
     const uint32_t i = gi % {max(n_src, 1)}u, base = (gi / {max(n_src, 1)}u) * {stride}u;   // source within the template, replica's first row
-    const uint32_t row = base + fold{j}_src[i];
+    const uint32_t row = base + {src_of("i")};
     if (row >= P.n) return;
 {nl.join(loads_a)}
     T acc[{w}] = {{{init}}};
-{("    uint32_t e = fold" + str(j) + "_start[i];" + nl + batched + "    for (; e < fold" + str(j) + "_start[i + 1]; e++) {") if batched else ("    for (uint32_t e = fold" + str(j) + "_start[i]; e < fold" + str(j) + "_start[i + 1]; e++) {")}
+{("    uint32_t e = " + e_lo + ";" + nl + batched + "    for (; e < " + e_hi + "; e++) {") if batched else ("    for (uint32_t e = " + e_lo + "; e < " + e_hi + "; e++) {")}
 {nl.join(loads_b)}
 {body}
     }}
@@ -1151,7 +1159,7 @@ template <class T>
 __global__ __launch_bounds__(64) void fold{j}_commit(const StepParams P) {{
     const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
     if (gi >= {n_src * count}u) return;
-    const uint32_t row = (gi / {max(n_src, 1)}u) * {stride}u + fold{j}_src[gi % {max(n_src, 1)}u];
+    const uint32_t row = (gi / {max(n_src, 1)}u) * {stride}u + {f"(gi % {max(n_src, 1)}u)" if complete else f"fold{j}_src[gi % {max(n_src, 1)}u]"};
     if (row >= P.n) return;
     const T* sc = static_cast<const T*>(P.model_cols[{fs.scratch_slot}]) + (size_t)row * {w};
     T* o = static_cast<T*>(P.model_cols[{fs.out[1]}]) + (size_t)row * {w};

@@ -2152,6 +2152,20 @@ class TracedFoldStage:
         self.scratch_slot = slot_of(self.scratch_name)
         if edges is None:
             raise ValueError(f"fold {self.name}: no edges given for edge component {fold.edge_component!r} (fold_edges)")
+        self.complete = 0
+        if len(edges) == 2 and isinstance(edges[0], str) and edges[0] == "complete":
+            # the COMPLETE graph over rows 0..n-1 of a world (every source folds every other row in ascending order — the spawn order
+            # of examples/n-body/sim.py:330-338): nothing is baked, the kernel forms the target of slot s as s + (s >= source), so
+            # the graph may have any number of edges
+            n_ = int(edges[1])
+            if self.replicas and n_ > self.replicas[1]:
+                raise ValueError(f"fold {self.name}: a complete graph of {n_} rows does not fit a replica of {self.replicas[1]} rows")
+            self.complete = n_
+            self.src_rows = list(range(n_))
+            self._n_edges = n_ * (n_ - 1)
+            self.written = [f"c{self.out[1]}_{k}" for k in range(self.out[2])] + [f"c{self.scratch_slot}_{k}" for k in range(self.out[2])]
+            self.every, self.phase, self.also_at, self.reads_accel, self.writes_inertia = 1, 0, None, False, False
+            return
         src = [int(x) for x in edges[0]]
         dst = [int(x) for x in edges[1]]
         if len(src) != len(dst):
@@ -2171,6 +2185,18 @@ class TracedFoldStage:
             self.row_start.append(len(self.dst))
         self.written = [f"c{self.out[1]}_{k}" for k in range(self.out[2])] + [f"c{self.scratch_slot}_{k}" for k in range(self.out[2])]
         self.every, self.phase, self.also_at, self.reads_accel, self.writes_inertia = 1, 0, None, False, False
+
+
+    # a complete graph's CSR, made on demand (the numpy walker of the tests reads it; the generated kernel does not)
+    def __getattr__(self, name):
+        if name in ("row_start", "dst") and self.__dict__.get("complete"):
+            n_ = self.complete
+            if n_ > 1024:
+                raise ValueError(f"fold {self.name}: the explicit edge list of a {n_}-row complete graph is not materialised")
+            self.__dict__["row_start"] = [s_ * (n_ - 1) for s_ in range(n_ + 1)]
+            self.__dict__["dst"] = [t for s_ in range(n_) for t in range(n_) if t != s_]
+            return self.__dict__[name]
+        raise AttributeError(name)
 
 
 MAX_PROGRAM_COLUMNS = 128      # = csrc/kernels.hpp kMaxModelCols (two kernarg pointers per column)

@@ -131,6 +131,9 @@ class HipExec:
                     row_of = {int(e): k for k, e in enumerate(self.entity_ids)}
                     fold_rows = {}
                     for name, (frm, to) in (graph_edges or {}).items():
+                        if isinstance(frm, str) and frm == "complete":      # the complete graph over a world's rows: nothing to resolve
+                            fold_rows[name] = (frm, int(to))
+                            continue
                         try:
                             fold_rows[name] = ([row_of[int(a)] for a in frm], [row_of[int(b)] for b in to])
                         except KeyError as e:

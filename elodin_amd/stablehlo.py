@@ -2712,7 +2712,12 @@ def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = No
         edge_c = f"hlo_fold{r.index}_edges"
         folds.append(_dsl.GraphFold(make_fn(), edge_c, (own_c,), (nbr_c,), out_c, list(r.init)))
         folds[-1].gather_batch = 4 if len(r.table[0]) >= 4 else 1      # a long scan is a chain of dependent gathers: fetch four targets per round trip (codegen._emit_fold_stage)
-        graph_edges[edge_c] = ([s_ for s_ in range(n_entities) for _ in r.table[s_]], [t for s_ in range(n_entities) for t in r.table[s_]])
+        if all(len(r.table[s_]) == n_entities - 1 and r.table[s_] == [t for t in range(n_entities) if t != s_] for s_ in range(n_entities)):
+            # every source folds every other entity in ascending order (examples/n-body/sim.py:330-338): the complete graph — said,
+            # not listed, so its n (n - 1) edges need not fit the 65,536 a fold stage bakes
+            graph_edges[edge_c] = ("complete", n_entities)
+        else:
+            graph_edges[edge_c] = ([s_ for s_ in range(n_entities) for _ in r.table[s_]], [t for s_ in range(n_entities) for t in r.table[s_]])
     n_folds = len(folds)
     all_cols = world_cols + [c for r in probe.requests for c in (f"hlo_fold{r.index}_own", f"hlo_fold{r.index}_nbr", f"hlo_fold{r.index}_out")]
 
@@ -2740,7 +2745,7 @@ def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = No
         import inspect
         fn.__signature__ = inspect.Signature([inspect.Parameter(p_, inspect.Parameter.KEYWORD_ONLY) for p_ in all_cols])
         system_ = _dsl.system(fn, **{c: widths[c] for c in all_cols})
-        system_.float32_refused = float32_hazards(funcs)
+        system_.float32_refused = ["a whole-world tick with fold stages is a float64 program (its fold kernels gather doubles)"]
         return system_
     pre = []
     for k in range(n_folds):
@@ -2748,13 +2753,20 @@ def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = No
     pre.append(make_system(n_folds))
     prog = _dsl.Program(pre, _dsl.Pipe([]), [])
     manifest = {"mode": "folds", "rows": "entities", "entities_per_world": n_entities, "rows_per_world": n_entities, "fold_stages": n_folds,
-                "edges_per_fold": [len(graph_edges[f"hlo_fold{r.index}_edges"][0]) for r in probe.requests],
+                "edges_per_fold": [sum(len(t_) for t_ in r.table) for r in probe.requests],
                 "columns": [{"column": c, "width": widths[c],
                              "component": next((s_.component for s_ in ins + outs if s_.column == c), None),
                              "component_id": next((s_.component_id for s_ in ins + outs if s_.column == c), None),
                              "entity_axis_elided": next((s_.elided for s_ in ins + outs if s_.column == c), False),
                              "scratch": c not in world_cols} for c in all_cols]}
     return prog, manifest, graph_edges
+
+
+def edges_as_entity_ids(graph_edges: dict, entity_ids) -> dict:
+    """world_program's edges (ROWS of one world) as what HipExec(graph_edges=) takes: entity ids of the executor's rows; the complete
+    graph's marker passes through."""
+    ids = np.asarray(entity_ids)
+    return {k: (v if isinstance(v[0], str) else (ids[np.asarray(v[0], dtype=np.int64)], ids[np.asarray(v[1], dtype=np.int64)])) for k, v in graph_edges.items()}
 
 
 def slots_from_metadata(doc: dict):

@@ -51,12 +51,13 @@ def test_nbody_world_larger_than_a_wavefront_runs_as_fold_stages(nb, ticks):
     text, slots = hb.nbody_world(nb, K_SQ, EPS)
     prog, manifest, edges = sh.world_program(text, slots)
     assert manifest["mode"] == "folds" and manifest["fold_stages"] == 4 and manifest["edges_per_fold"] == [nb * (nb - 1)] * 4      # one scan per RK4 stage
+    assert all(e == ("complete", nb) for e in edges.values())      # every source folds every other body in ascending order: said, not listed
     pos, vel, inertia = _world(nb)
     dt = 0.5
     cols = _columns(manifest, nb, pos, vel, inertia, dt)
     ids = np.arange(1, nb + 1, dtype=np.uint64)
     hip = ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (nb, 1)), np.zeros((nb, 6)), np.ones((nb, 7)), entity_ids=ids, integrator=L.INTEGRATOR_NONE,
-                     effectors=prog, columns=cols, graph_edges={k: (ids[np.asarray(a)], ids[np.asarray(b)]) for k, (a, b) in edges.items()})
+                     effectors=prog, columns=cols, graph_edges=sh.edges_as_entity_ids(edges, ids))
     ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=dt, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, (K_SQ, EPS), None)])
     worst = 0.0
     for r in range(1, ticks + 1):
@@ -86,7 +87,7 @@ def test_a_monte_carlo_of_large_worlds_shares_one_edge_template():
     ids = np.arange(1, rows + 1, dtype=np.uint64)
     hip = ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (rows, 1)), np.zeros((rows, 6)), np.ones((rows, 7)), entity_ids=ids, integrator=L.INTEGRATOR_NONE,
                      effectors=prog, columns=cols, graph_replicas=(worlds, nb),
-                     graph_edges={k: (ids[np.asarray(a)], ids[np.asarray(b)]) for k, (a, b) in edges.items()})
+                     graph_edges=sh.edges_as_entity_ids(edges, ids))
     hip.run(ticks)
     for w in (0, 5, 11):
         ref = orc.OracleWorld(*starts[w], simulation_time_step=0.5, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, (K_SQ, EPS), None)]).step(ticks)
@@ -139,7 +140,7 @@ def test_a_sparse_newton_fold_world_on_the_gpu():
     cols = _columns(manifest, nb, pos, vel, inertia, 0.01)
     ids = np.arange(1, nb + 1, dtype=np.uint64)
     hip = ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (nb, 1)), np.zeros((nb, 6)), np.ones((nb, 7)), entity_ids=ids, integrator=L.INTEGRATOR_NONE,
-                     effectors=prog, columns=cols, graph_edges={k: (ids[np.asarray(a)], ids[np.asarray(b)]) for k, (a, b) in edges.items()})
+                     effectors=prog, columns=cols, graph_edges=sh.edges_as_entity_ids(edges, ids))
     hip.run(50)
     src = np.array([s_ for s_ in range(nb) for _ in targets[s_]], dtype=np.uint32)
     dst = np.array([t for s_ in range(nb) for t in targets[s_]], dtype=np.uint32)

@@ -532,7 +532,9 @@ def test_a_world_larger_than_a_wavefront_becomes_systems_and_fold_stages_and_equ
     # the generated program compiles without spills (hipcc cross-compiles here), fold kernels and their baked CSR in the text
     from elodin_amd import codegen
     src = codegen.generate_source(tp, "float64", 2)
-    assert src.count("_kernel(const StepParams P)") >= 4 and "fold3_dst[6320]" in src and "fold3_commit" in src
+    # the fold kernels; a COMPLETE graph bakes no tables (slot s of source i is row s + (s >= i))
+    assert src.count("_kernel(const StepParams P)") >= 4 and "fold3_commit" in src and "fold3_dst" not in src and "e + u + ((e + u) >= i ? 1u : 0u)" in src
+    assert edges["hlo_fold0_edges"] == ("complete", nb) and all(fs.complete == nb for fs in tp.fold_stages)
 
 
 def test_world_program_refuses_what_is_not_an_edge_fold_scan():

@@ -31,7 +31,7 @@ for nb, worlds in ((80, 1), (80, 64), (256, 1), (256, 16)):
     ids = np.arange(1, rows + 1, dtype=np.uint64)
     ex = ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (rows, 1)), np.zeros((rows, 6)), np.ones((rows, 7)), entity_ids=ids, integrator=L.INTEGRATOR_NONE,
                     effectors=prog, columns=cols, graph_replicas=(worlds, nb) if worlds > 1 else None,
-                    graph_edges={k: (ids[np.asarray(a)], ids[np.asarray(b)]) for k, (a, b) in edges.items()})
+                    graph_edges=sh.edges_as_entity_ids(edges, ids))
     build_s = time.perf_counter() - t0
     ex.invoke_batch(5)
     tm = ex.invoke_batch(50)
