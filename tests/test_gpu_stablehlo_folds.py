@@ -46,7 +46,7 @@ def _errors(cols, ref, rows=slice(None)):
     return worst
 
 
-@pytest.mark.parametrize("nb,ticks", [(80, 20), (256, 6)])
+@pytest.mark.parametrize("nb,ticks", [(80, 20), (256, 6), (512, 2)])      # 512 bodies: 261,632 edges per scan — the complete graph is not listed
 def test_nbody_world_larger_than_a_wavefront_runs_as_fold_stages(nb, ticks):
     text, slots = hb.nbody_world(nb, K_SQ, EPS)
     prog, manifest, edges = sh.world_program(text, slots)
