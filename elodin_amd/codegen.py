@@ -1086,6 +1086,26 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
 '''
 
 
+def _graph_fold_kinds(outputs, w: int):
+    """Per component of a traced stand-alone fold: "sum" (acc_k + g, g + acc_k or acc_k - g with g free of the accumulator), "keep"
+    (acc_k itself) or "zero" (the constant 0) — or None when some component is none of these (such a fold cannot be regrouped)."""
+    acc = {f"acc_{k}" for k in range(w)}
+    free = lambda e: not (dsl._leaves_of([e]) & acc)
+    kinds = []
+    for k, e in enumerate(outputs):
+        own = lambda x: x.op == "leaf" and x.name == f"acc_{k}"
+        if e.op == "const" and e.value == 0.0:
+            kinds.append("zero")
+        elif own(e):
+            kinds.append("keep")
+        elif (e.op == "add" and ((own(e.args[0]) and free(e.args[1])) or (own(e.args[1]) and free(e.args[0])))) or \
+                (e.op == "sub" and own(e.args[0]) and free(e.args[1])):
+            kinds.append("sum")
+        else:
+            return None
+    return kinds
+
+
 def _emit_fold_stage(fs: "dsl.TracedFoldStage") -> str:
     """A stand-alone fold inside a program (dsl.TracedFoldStage): one lane per SOURCE folds its out-edges in spawn order into
     the scratch column, a second kernel commits scratch -> out on source rows (every fold reads the values from before it
@@ -1137,6 +1157,51 @@ def _emit_fold_stage(fs: "dsl.TracedFoldStage") -> str:
               f"__device__ const uint32_t fold{j}_dst[{max(len(fs.dst), 1)}] = {{{arr(fs.dst)}}};")
     src_of = (lambda i_: i_) if complete else (lambda i_: f"fold{j}_src[{i_}]")
     n_edges = complete * (complete - 1) if complete else len(fs.dst)
+    kinds = _graph_fold_kinds(fs.traced.outputs, w) if getattr(f, "wave_fold", False) else None
+    if kinds is not None:
+        # A WAVE per source (dsl.GraphFold.wave_fold: the long scans stablehlo.world_program lifts out of a whole-world tick ask for
+        # it).  One lane per source walks its N - 1 out-edges alone — 2,047 dependent trips at 2,048 bodies, 1.4 ms per tick — although the
+        # fold is a plain sum: every component is acc_k +- g_k(source, target), acc_k itself, or the constant 0.  So lane l folds edges
+        # l, l + 64, ... from zero in slot order, the 64 partial sums are added by a fixed shuffle tree and the initial value joins at
+        # the end: the same sum in another association (~1e-16 x sqrt(degree) relative, identical from run to run) — the trade the
+        # hub kernels of csrc/pair_kernel.hpp make.  world_program(..., wave_folds=False) keeps the sequential, bit-for-bit fold.
+        zero = ", ".join("T(0)" for _ in range(w))
+        fin = "\n".join({"sum": f"        if (lane == 0) sc[{k}] = T({f.init[k]!r}) + v{k};", "keep": f"        if (lane == 0) sc[{k}] = T({f.init[k]!r});",
+                         "zero": f"        if (lane == 0) sc[{k}] = ({e_hi} > {e_lo}) ? T(0) : T({f.init[k]!r});"}[kd] for k, kd in enumerate(kinds))
+        red = "\n".join(f"        T v{k} = acc[{k}];\n#pragma unroll\n        for (int off = 32; off >= 1; off >>= 1) v{k} += __shfl_down(v{k}, off, 64);"
+                        for k, kd in enumerate(kinds) if kd == "sum")
+        return f'''// ---- fold stage {j}: {fs.name} ({n_edges} edges, {n_src} sources{f", x {count} replicas of {stride} rows" if fs.replicas else ""}), one WAVE per source ----
+{tables}
+template <class T>
+__global__ __launch_bounds__(64) void fold{j}_kernel(const StepParams P) {{
+    const uint32_t gi = blockIdx.x, lane = threadIdx.x;
+    if (gi >= {n_src * count}u) return;
+    const uint32_t i = gi % {max(n_src, 1)}u, base = (gi / {max(n_src, 1)}u) * {stride}u;   // source within the template, replica's first row
+    const uint32_t row = base + {src_of("i")};
+    if (row >= P.n) return;
+{nl.join(loads_a)}
+    T acc[{w}] = {{{zero}}};
+    for (uint32_t e = {e_lo} + lane; e < {e_hi}; e += 64u) {{
+{nl.join(loads_b)}
+{body}
+    }}
+    T* sc = static_cast<T*>(P.model_cols[{fs.scratch_slot}]) + (size_t)row * {w};
+    {{
+{red}
+{fin}
+    }}
+}}
+template <class T>
+__global__ __launch_bounds__(64) void fold{j}_commit(const StepParams P) {{
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= {n_src * count}u) return;
+    const uint32_t row = (gi / {max(n_src, 1)}u) * {stride}u + {f"(gi % {max(n_src, 1)}u)" if complete else f"fold{j}_src[gi % {max(n_src, 1)}u]"};
+    if (row >= P.n) return;
+    const T* sc = static_cast<const T*>(P.model_cols[{fs.scratch_slot}]) + (size_t)row * {w};
+    T* o = static_cast<T*>(P.model_cols[{fs.out[1]}]) + (size_t)row * {w};
+    for (int k = 0; k < {w}; k++) o[k] = sc[k];
+}}
+'''
     return f'''// ---- fold stage {j}: {fs.name} ({n_edges} edges, {n_src} sources{f", x {count} replicas of {stride} rows" if fs.replicas else ""}) ----
 {tables}
 template <class T>
@@ -1328,8 +1393,10 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
                 fs = c[1]
                 parts.append(_emit_fold_stage(fs))
                 nb = (len(fs.src_rows) * (fs.replicas[0] if fs.replicas else 1) + 63) // 64
+                waves = (getattr(fs.traced.fold, "wave_fold", False) and _graph_fold_kinds(fs.traced.outputs, fs.out[2]) is not None)
+                nk = len(fs.src_rows) * (fs.replicas[0] if fs.replicas else 1) if waves else nb      # one wave per source, or one lane
                 if nb:
-                    calls.append(f"        hipLaunchKernelGGL(fold{fs.index}_kernel<{T}>, dim3({nb}), dim3(64), 0, s, q);\n"
+                    calls.append(f"        hipLaunchKernelGGL(fold{fs.index}_kernel<{T}>, dim3({nk}), dim3(64), 0, s, q);\n"
                                  f"        hipLaunchKernelGGL(fold{fs.index}_commit<{T}>, dim3({nb}), dim3(64), 0, s, q);")
                 continue
             _, pre, post, six = c

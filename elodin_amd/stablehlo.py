@@ -2624,7 +2624,7 @@ class _FoldEval(_LaneEval):
         return results
 
 
-def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = None, name: str = "world_tick"):
+def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = None, name: str = "world_tick", wave_folds: bool = True):
     """A whole-world tick whose entities exchange data across MORE than a wavefront (an edge_fold over a world of more than 64
     entities) as a PROGRAM: per-entity systems with the tick's scans over the edge slot between them as fold stages.
     -> (dsl.Program, manifest, graph_edges)
@@ -2712,6 +2712,10 @@ def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = No
         edge_c = f"hlo_fold{r.index}_edges"
         folds.append(_dsl.GraphFold(make_fn(), edge_c, (own_c,), (nbr_c,), out_c, list(r.init)))
         folds[-1].gather_batch = 4 if len(r.table[0]) >= 4 else 1      # a long scan is a chain of dependent gathers: fetch four targets per round trip (codegen._emit_fold_stage)
+        # ... and a scan of a wavefront's worth of edges or more, when it is a plain sum, is folded by a whole WAVE per source (partial
+        # sums per lane, a fixed shuffle tree: another association of the same sum, ~1e-16 x sqrt(degree)); wave_folds=False keeps
+        # the one-lane sequential fold, bit for bit the reference's order
+        folds[-1].wave_fold = bool(wave_folds) and len(r.table[0]) >= 64
         if all(len(r.table[s_]) == n_entities - 1 and r.table[s_] == [t for t in range(n_entities) if t != s_] for s_ in range(n_entities)):
             # every source folds every other entity in ascending order (examples/n-body/sim.py:330-338): the complete graph — said,
             # not listed, so its n (n - 1) edges need not fit the 65,536 a fold stage bakes

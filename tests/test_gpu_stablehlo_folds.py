@@ -65,8 +65,8 @@ def test_nbody_world_larger_than_a_wavefront_runs_as_fold_stages(nb, ticks):
         ref.step(1)
         worst = max(worst, _errors(hip._aux, ref))
         assert np.all(hip._aux["hlo_tick"] == r)
-    print(f"{nb}-body whole-world module as fold stages, {ticks} ticks vs the oracle: {worst:.2e}")
-    assert worst <= 1e-9
+    print(f"{nb}-body whole-world module as fold stages (a wave per source), {ticks} ticks vs the oracle: {worst:.2e}")
+    assert worst <= 1e-12            # the same sums in another association (lane partials + shuffle tree): rounding, nothing more
     # the fold stages' edge rows are the module's gather tables, bit for bit: per source its targets ascending, itself left out
     tp = prog.trace({c["column"]: c["width"] for c in manifest["columns"]}, fold_edges=edges)
     for fs in tp.fold_stages:
@@ -146,4 +146,22 @@ def test_a_sparse_newton_fold_world_on_the_gpu():
     dst = np.array([t for s_ in range(nb) for t in targets[s_]], dtype=np.uint32)
     ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=0.01, ops=[(orc.EFF_EDGE_GRAVITY_NEWTON, (G,), None)], edges=(src, dst)).step(50)
     assert _errors(hip._aux, ref) <= 1e-9
+    hip.close()
+
+
+def test_the_sequential_fold_is_bit_identical_to_the_oracle():
+    """world_program(wave_folds=False): one lane per source folds its out-edges in slot order — the reference's association, so the
+    GPU result equals the CPU oracle's sequential softened fold BIT FOR BIT (the default, a wave per source, differs in the last bits)."""
+    nb = 96
+    text, slots = hb.nbody_world(nb, K_SQ, EPS)
+    prog, manifest, edges = sh.world_program(text, slots, wave_folds=False)
+    pos, vel, inertia = _world(nb)
+    cols = _columns(manifest, nb, pos, vel, inertia, 0.5)
+    ids = np.arange(1, nb + 1, dtype=np.uint64)
+    hip = ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (nb, 1)), np.zeros((nb, 6)), np.ones((nb, 7)), entity_ids=ids, integrator=L.INTEGRATOR_NONE,
+                     effectors=prog, columns=cols, graph_edges=sh.edges_as_entity_ids(edges, ids))
+    hip.run(10)
+    ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=0.5, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, (K_SQ, EPS), None)]).step(10)
+    for c, r in (("world_pos", ref.world_pos), ("world_vel", ref.world_vel), ("world_accel", ref.world_accel), ("force", ref.force)):
+        assert np.array_equal(hip._aux["hlo_" + c], r), c
     hip.close()

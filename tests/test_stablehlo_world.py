@@ -532,9 +532,15 @@ def test_a_world_larger_than_a_wavefront_becomes_systems_and_fold_stages_and_equ
     # the generated program compiles without spills (hipcc cross-compiles here), fold kernels and their baked CSR in the text
     from elodin_amd import codegen
     src = codegen.generate_source(tp, "float64", 2)
-    # the fold kernels; a COMPLETE graph bakes no tables (slot s of source i is row s + (s >= i))
-    assert src.count("_kernel(const StepParams P)") >= 4 and "fold3_commit" in src and "fold3_dst" not in src and "e + u + ((e + u) >= i ? 1u : 0u)" in src
+    # the fold kernels; a COMPLETE graph bakes no tables (slot s of source i is row s + (s >= i)); a scan of 64 edges or more that is a
+    # plain sum is folded by a whole wave per source (lane partials + a fixed shuffle tree) ...
+    assert src.count("_kernel(const StepParams P)") >= 4 and "fold3_commit" in src and "fold3_dst" not in src
+    assert src.count("one WAVE per source") == 4 and "__shfl_down(v3, off, 64)" in src and codegen._graph_fold_kinds(tp.fold_stages[0].traced.outputs, 6) == ["keep"] * 3 + ["sum"] * 3
     assert edges["hlo_fold0_edges"] == ("complete", nb) and all(fs.complete == nb for fs in tp.fold_stages)
+    # ... unless the host asks for the sequential fold — one lane per source, targets fetched four at a time, the reference's order bit for bit
+    seq, m2, e2 = sh.world_program(text, slots, wave_folds=False)
+    src2 = codegen.generate_source(seq.trace({c["column"]: c["width"] for c in m2["columns"]}, fold_edges=e2), "float64", 2)
+    assert "one WAVE per source" not in src2 and "e + u + ((e + u) >= i ? 1u : 0u)" in src2
 
 
 def test_world_program_refuses_what_is_not_an_edge_fold_scan():

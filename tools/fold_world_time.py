@@ -15,10 +15,10 @@ from elodin_amd import stablehlo as sh
 from tests.golden import hlo_world_builder as hb
 
 out = {}
-for nb, worlds in ((80, 1), (80, 64), (256, 1), (256, 16)):
+for nb, worlds, wave in ((80, 1, True), (80, 64, True), (256, 1, True), (256, 16, True), (256, 1, False), (1024, 1, True)):
     t0 = time.perf_counter()
     text, slots = hb.nbody_world(nb, 2.9591220828e-4, 1e-6)
-    prog, manifest, edges = sh.world_program(text, slots)
+    prog, manifest, edges = sh.world_program(text, slots, wave_folds=wave)
     rows = nb * worlds
     rng = np.random.default_rng(nb)
     pos = np.concatenate([np.tile([0, 0, 0, 1.0], (rows, 1)), rng.normal(size=(rows, 3)) * 3], axis=1)
@@ -37,6 +37,6 @@ for nb, worlds in ((80, 1), (80, 64), (256, 1), (256, 16)):
     tm = ex.invoke_batch(50)
     ex.close()
     us = tm.kernel_device_ms / 50 * 1e3
-    out[f"{nb}_bodies_x_{worlds}_worlds"] = {"us_per_tick": round(us, 2), "launches_per_tick": int(tm.launches // 50), "pair_evals_per_s": round(4.0 * nb * (nb - 1) * worlds / us * 1e6, 1),
+    out[f"{nb}_bodies_x_{worlds}_worlds" + ("" if wave else "_sequential_fold")] = {"us_per_tick": round(us, 2), "launches_per_tick": int(tm.launches // 50), "pair_evals_per_s": round(4.0 * nb * (nb - 1) * worlds / us * 1e6, 1),
                                               "build_seconds_incl_trace_and_hipcc_or_cache": round(build_s, 2)}
 print(json.dumps(out, indent=1))
