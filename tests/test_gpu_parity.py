@@ -317,6 +317,41 @@ def test_edge_list_equals_allpairs():
     assert max(parity.state_errors(b, ref).values()) < parity.F64_RTOL
 
 
+@pytest.mark.parametrize("n,integrator", [(65536, L.RK4), (65536 + 37, L.SEMI_IMPLICIT)])
+def test_sparse_lattice_of_a_million_edges_in_one_launch_per_tick_vs_the_oracle(n, integrator):
+    """The sparse workload bench.py's side leg times (a ring lattice, 16 out-edges per body in spawn order: 1,048,576 directed
+    edges at 65,536 bodies) at its full size, through the fused fold-and-integrate launch (pair_kernel.hpp 3b: pack rows
+    double-buffered, ONE launch per tick), against the oracle's sequential edge fold; a row count that is not a whole number
+    of waves under the other integrator; every fifth body carries no out-edges and keeps its per-entity gravity instead."""
+    deg = 16
+    rng = np.random.default_rng(11)
+    pos = np.concatenate([np.tile([0, 0, 0, 1.0], (n, 1)), rng.normal(size=(n, 3)) * 1e3], axis=1)
+    vel = np.concatenate([np.zeros((n, 3)), rng.normal(size=(n, 3))], axis=1)
+    m = rng.uniform(1.0, 10.0, n)
+    inertia = np.concatenate([np.tile(m[:, None], (1, 3)), np.zeros((n, 3)), m[:, None]], axis=1)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    offs = np.array([k for k in range(-deg // 2, deg // 2 + 1) if k != 0][:deg])
+    src_rows = np.arange(n)[np.arange(n) % 5 != 0]                       # rows 0, 5, 10, ... are targets only
+    frm = np.repeat(ids[src_rows], deg)
+    to = ((np.repeat(src_rows, deg) + np.tile(offs, len(src_rows))) % n + 1).astype(np.uint64)
+    G = 6.6743e-11
+    eff = [ea.Effector(L.EFF_UNIFORM_GRAVITY, (0.0, 0.0, -9.81)), ea.Effector(L.EFF_EDGE_GRAVITY_NEWTON, (G,))]
+    hip = ea.HipExec(pos, vel, inertia, entity_ids=ids, simulation_time_step=0.01, integrator=integrator, effectors=eff, edges=(frm, to))
+    ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=0.01, integrator=integrator,
+                          ops=[(orc.EFF_UNIFORM_GRAVITY, (0.0, 0.0, -9.81), None), (orc.EFF_EDGE_GRAVITY_NEWTON, (G,), None)],
+                          edges=orc.resolve_edges(ids, frm, to))
+    worst = parity.Worst()
+    for cp in (1, 6, 12):
+        t = hip.run(cp - hip.tick)
+        ref.step(cp - ref.tick, threads=8)
+        worst.update(hip, ref, cp)
+    assert t.launches == 1 + 6                                       # the last batch: one pack, then one launch per tick
+    worst.check(f"sparse lattice {n} bodies x {len(frm)} edges, integrator {integrator}")
+    assert np.abs(hip.force[::5, 5] + 9.81 * m[::5]).max() < 1e-9 * 98.1    # target-only rows: the per-entity gravity survived
+    e_src, e_dst = hip.edge_rows()
+    assert np.array_equal(e_src, np.repeat(src_rows, deg).astype(np.uint32)) and np.array_equal(e_dst, (to - 1).astype(np.uint32))      # edge rows bit-exact, spawn order
+
+
 @pytest.mark.parametrize("kind,integrator", [("newton", L.RK4), ("softened", L.RK4), ("softened", L.SEMI_IMPLICIT)])
 def test_hub_sources_are_folded_by_whole_waves_and_match_the_sequential_fold(kind, integrator):
     """A graph with hubs (the reference buckets sources by out-degree, graph.rs:290-328): two sources with thousands of
