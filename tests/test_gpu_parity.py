@@ -318,9 +318,9 @@ def test_edge_list_equals_allpairs():
 
 
 @pytest.mark.parametrize("n,integrator", [(65536, L.RK4), (65536 + 37, L.SEMI_IMPLICIT)])
-def test_sparse_lattice_of_a_million_edges_in_one_launch_per_tick_vs_the_oracle(n, integrator):
-    """The sparse workload bench.py's side leg times (a ring lattice, 16 out-edges per body in spawn order: 1,048,576 directed
-    edges at 65,536 bodies) at its full size, through the fused fold-and-integrate launch (pair_kernel.hpp 3b: pack rows
+def test_sparse_lattice_at_bench_size_in_one_launch_per_tick_vs_the_oracle(n, integrator):
+    """The sparse workload bench.py's side leg times (a ring lattice, 16 out-edges per source in spawn order; here every fifth body
+    is a target only: 838,848 directed edges at 65,536 bodies) at its full size, through the fused fold-and-integrate launch (pair_kernel.hpp 3b: pack rows
     double-buffered, ONE launch per tick), against the oracle's sequential edge fold; a row count that is not a whole number
     of waves under the other integrator; every fifth body carries no out-edges and keeps its per-entity gravity instead."""
     deg = 16
