@@ -586,7 +586,7 @@ def world_module_leg(device):
         "bytes_per_entity_tick": bytes_per, "algorithmic_GBps": round(bytes_per * n / us / 1e3, 1), "frac_of_hbm_peak": round(bytes_per * n / us / 1e3 / HBM_PEAK_GBPS, 4),
         "graph_launches_k1": int(tm.graph_launches),
         "entity_steps_per_s_k64": round(n * 64 * 32 / (tf.kernel_device_ms * 1e-3), 1),
-        "what": "the whole tick is the module's (integrator NONE, the executor's Body slabs untouched); globals (tick, dt) are replicated per row and world_accel / force are read as well as written, so a tick moves more bytes per entity than the hand-written kernel's 384"}
+        "what": "the whole tick is the module's (integrator NONE, the executor's Body slabs untouched); `bytes_per_entity_tick` is the analytic bound (every slot read, changed slots written); by PMC the kernel moves 460 B (force is never loaded: profiles/r06_world_module_bytes_pmc.md) against the hand-written kernel's 386 — globals (tick, dt) replicated per row, the 0 * world_accel read kept; its time is instruction issue (1,744 VALU per wave and tick, the reference's arithmetic as written)"}
     return out
 
 
