@@ -2982,7 +2982,8 @@ def float32_hazards(funcs: Dict[str, Func]) -> List[str]:
     return list(dict.fromkeys(why))
 
 
-def compile_world(text: str, slots_doc: dict, out: Optional[str] = None, mode: str = "auto", dtype: str = "float64", fast_math: bool = False):
+def compile_world(text: str, slots_doc: dict, out: Optional[str] = None, mode: str = "auto", dtype: str = "float64", fast_math: bool = False,
+                  wave_folds: bool = True):
     """The build-time step a host (`WorldExec::Hip`, INTEGRATION.md §3) runs once per world: module text + slot metadata -> the
     shared object `sixdof_set_custom_pipe` installs, and the manifest of its columns.  -> (path of the .so, manifest)"""
     import json
@@ -3001,14 +3002,15 @@ def compile_world(text: str, slots_doc: dict, out: Optional[str] = None, mode: s
             if mode != "auto":
                 raise
             try:
-                world_program(text, ins, outs)
+                built = world_program(text, ins, outs, wave_folds=wave_folds)
             except NotEntityParallel:
                 raise refused from None
             folds = True
     if folds:
         if dtype != "float64":
             raise NotImplementedError("whole-world ticks with fold stages are float64 (the fold kernels gather doubles)")
-        prog, manifest, edges = world_program(text, ins, outs)
+        prog, manifest, edges = built if mode == "auto" else world_program(text, ins, outs, wave_folds=wave_folds)
+        manifest["folds"] = "a wave per source (lane partials + shuffle tree) for additive scans of 64 edges or more" if wave_folds else "sequential, one lane per source"
         n_world = int(manifest["entities_per_world"])
         rows = int(slots_doc.get("rows", 0)) or n_world
         if rows % n_world:
@@ -3157,6 +3159,8 @@ def _main(argv=None) -> int:
     ap.add_argument("--mode", default="auto", choices=("auto", "lane", "world", "folds"))
     ap.add_argument("--dtype", default="float64", choices=("float64", "float32"))
     ap.add_argument("--fast-math", action="store_true")
+    ap.add_argument("--sequential-folds", action="store_true", help="fold stages (--mode folds) with one lane per source in slot order: the reference's "
+                                                                     "association bit for bit, N - 1 dependent trips per scan (default: a wave per source for long additive scans)")
     a = ap.parse_args(argv)
     if a.checkpoint:
         rep = checkpoint(a.checkpoint, a.mode)
@@ -3164,7 +3168,8 @@ def _main(argv=None) -> int:
         return 0 if rep["ok"] else 1
     if not (a.module and a.slots and a.out):
         ap.error("module, --slots and -o are required (or --checkpoint DIR)")
-    so, manifest = compile_world(Path(a.module).read_text(), json.loads(Path(a.slots).read_text()), a.out, a.mode, a.dtype, a.fast_math)
+    so, manifest = compile_world(Path(a.module).read_text(), json.loads(Path(a.slots).read_text()), a.out, a.mode, a.dtype, a.fast_math,
+                                 wave_folds=not a.sequential_folds)
     print(json.dumps({"object": str(so), "mode": manifest["mode"], "rows": manifest["rows"], "columns": [c["column"] for c in manifest["columns"]],
                       "build": manifest["build"], **({"lane_refused": manifest["lane_refused"]} if "lane_refused" in manifest else {})}))
     return 0

@@ -589,3 +589,31 @@ def test_a_sparse_newton_fold_over_a_large_world_is_lifted_the_same_way():
     ref.step(3)
     for nm, arr in (("hlo_world_pos", ref.world_pos), ("hlo_world_vel", ref.world_vel), ("hlo_world_accel", ref.world_accel), ("hlo_force", ref.force)):
         assert np.array_equal(comps[nm], arr), nm
+
+
+def test_the_cli_builds_a_fold_stage_world_without_a_gpu(tmp_path):
+    """`python -m elodin_amd.stablehlo tick.mlir --slots slots.json -o pipe.so` on a 72-body n-body world (hipcc cross-compiles): --mode auto
+    falls through lane and world mode to fold stages; the manifest lists the scratch columns a host binds zero-filled and the row count the
+    object was generated for; --sequential-folds asks for the one-lane fold."""
+    import subprocess
+    import sys
+    from elodin_amd import _lib as L
+    nb = 72
+    text, slots = hb.nbody_world(nb, 2.9591220828e-4, 1e-6)
+    (tmp_path / "tick.mlir").write_text(text)
+    meta = {"arg_ids": [L.component_id(c) for c, _, _ in slots], "ret_ids": [L.component_id(c) for c, _, _ in slots], "names": {str(L.component_id(c)): c for c, _, _ in slots},
+            "rows": 3 * nb, "arg_slots": [{"component_id": L.component_id(c), "shape": s_, "entity_axis_elided": e_} for c, s_, e_ in slots]}
+    (tmp_path / "slots.json").write_text(json.dumps(meta))
+    for flags, said in (([], "a wave per source"), (["--sequential-folds"], "sequential")):
+        out = tmp_path / ("pipe" + ("_seq" if flags else "") + ".so")
+        res = subprocess.run([sys.executable, "-m", "elodin_amd.stablehlo", str(tmp_path / "tick.mlir"), "--slots", str(tmp_path / "slots.json"), "-o", str(out), *flags],
+                             capture_output=True, text=True, cwd=str(L.PKG.parent))
+        assert res.returncode == 0, res.stderr[-2000:]
+        line = json.loads(res.stdout.strip().splitlines()[-1])
+        assert line["mode"] == "folds" and out.exists()
+        prog, manifest = sh.load_world(str(out))
+        assert manifest["fold_stages"] == 4 and manifest["rows_per_world"] == nb and manifest["row_count"] == 3 * nb and said in manifest["folds"]
+        scratch = [c["column"] for c in manifest["columns"] if c.get("scratch")]
+        assert len(scratch) == 16 and "hlo_fold2_nbr" in scratch and "hlo_fold3_out#fold3" in scratch
+        assert prog._traced.exact_rows == 3 * nb and [n_ for n_, _ in prog._traced.columns] == [c["column"] for c in manifest["columns"]]
+        assert manifest["build"]["resources"]["vgpr_spills"] == 0
