@@ -1495,7 +1495,7 @@ def generate_pair_source(tf: "dsl.TracedFold", integrator: Optional[int] = None,
     additive = _fold_is_additive(tf)
     # an object built for ONE of the two launch shapes says so, and the library follows the object rather than re-deriving the choice
     # from the row count and the environment at step time (only specialised objects carry the export: other texts are unchanged)
-    only_export = (f'extern "C" int sixdof_custom_pair_only_small() {{ return {only_s}; }}      // 1: the one-launch small-graph kernel only, 0: the three-kernel tick only\n'
+    only_export = (f'extern "C" int sixdof_custom_pair_only_small() {{ return {only_s}; }}      // 1: the one-launch small-graph kernel only, 0: the multi-kernel tick only (pack, then fold + integrate)\n'
                    if only_s >= 0 else "")
     return f'''// generated by elodin_amd/codegen.py — do not edit.  edge_fold function: {tf.fold.__name__}
 #include "pair_kernel.hpp"

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(kWave) void pair_tick_fused_kernel(const PairParams
 // ---- small graphs: the whole tick (and n_ticks of them) in ONE single-workgroup launch --------------------------
 // Three-body / solar-system sized worlds (n <= 256) are launch-bound, not math-bound: pack, fold and integrate
 // run in one workgroup with the packed sources in LDS and the entity state in registers across ticks.  Same device
-// functions as the three-kernel path, so results are bit-identical to it.
+// functions as the multi-kernel path, so results are bit-identical to it.
 template <int INTEGRATOR, class PAIR>
 __global__ __launch_bounds__(kTile) void pair_small_kernel(const PairParams P, uint32_t n_ticks) {
     __shared__ __attribute__((aligned(16))) double pack[kTile * kPackWidth];
@@ -794,7 +794,7 @@ inline hipError_t launch_pair_ticks_t(const PairParams& p, int integrator, uint3
     return hipErrorInvalidValue;      // an edge list without the second pack buffer (PairParams::pack_next): not a launch this library makes
 }
 
-// One tick on its own (pack -> fold -> integrate).
+// One tick on its own (pack, then fold + integrate).
 template <class PAIR, bool ALLPAIRS, int ONLY = -1>
 inline hipError_t launch_pair_tick_t(const PairParams& p, int integrator, hipStream_t stream, uint64_t* launches) {
     return launch_pair_ticks_t<PAIR, ALLPAIRS, ONLY>(p, integrator, 1, false, stream, launches);

@@ -1474,7 +1474,7 @@ int sixdof_step(sixdof_handle* h, uint64_t n_ticks, sixdof_timings* tm) try {
         PairParams P;
         int rc = fill_pair_params(h, &P);
         if (rc != SIXDOF_OK) return rc;
-        const char* no_small = std::getenv("SIXDOF_PAIR_SMALL");   // "0": force the three-kernel path (tests)
+        const char* no_small = std::getenv("SIXDOF_PAIR_SMALL");   // "0": force the multi-kernel path (tests)
         if (P.pair_kind == SIXDOF_EFF_EDGE_CUSTOM) {
             if (!h->pair_launch) return h->fail(SIXDOF_ERR_BACKEND, "step: custom pair op without sixdof_set_custom_pair");
             const bool small = h->pair_only_small >= 0 ? h->pair_only_small == 1 : (P.n <= kPairSmallMax && !(no_small && no_small[0] == '0'));
