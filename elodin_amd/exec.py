@@ -218,8 +218,8 @@ class HipExec:
                 if edges is None:
                     raise ValueError("an edge_fold effector needs edges=(from_ids, to_ids)")
                 # the object is built for THIS executor: its integrator, and the one-launch small-graph kernel or the multi-kernel
-                # tick — the same rule csrc/sixdof_capi.cpp applies at step time (kPairSmallMax = 256; SIXDOF_PAIR_SMALL=0 forces
-                # path: pack once per batch, then the fused fold-and-integrate launch per tick)
+                # tick (pack once per batch, then the fused fold-and-integrate launch per tick) — the rule csrc/sixdof_capi.cpp applies
+                # at step time (kPairSmallMax = 256; SIXDOF_PAIR_SMALL=0 forces the multi-kernel path)
                 pair_small = self._n_rows <= 256 and os.environ.get("SIXDOF_PAIR_SMALL", "")[:1] != "0"
                 pair_so = codegen.build_pair(effectors.pop().trace(), integrator=integrator, small=pair_small)
             if any(isinstance(e, _dsl.EdgeFold) for e in effectors):
