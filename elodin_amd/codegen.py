@@ -1345,6 +1345,17 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
         if touched or wrote or any(s_.writes_inertia or s_.reads_accel for s_ in systems_):
             raise ValueError(f"a program declared free of Body state reads {sorted(touched)} / writes {sorted(wrote)}")
         body_dead = True
+    if staged and integrator == 2:
+        # the same for a chain of launches (a whole-world tick with fold stages, stablehlo.world_program): every system declares itself free
+        # of Body state, every fold reads and writes program columns only — then no link of the chain touches the Body slabs
+        systems_ = [s_ for s_ in tp.pre + tp.post if not isinstance(s_, dsl.TracedFoldStage)]
+        if systems_ and all(getattr(s_, "body_free", False) for s_ in systems_) and \
+                all(slot is not None for fs in tp.fold_stages for _, slot, _ in fs.left + fs.right + [fs.out]):
+            touched = {n for n in dsl._leaves_of([e for s_ in systems_ for _, e in s_.assign]) if n in _LEAF_CPP or n.startswith("aux") or n in ("aax", "aay", "aaz", "alx", "aly", "alz")}
+            wrote = {t for s_ in systems_ for t in s_.written if not (t[0] == "c" or t.startswith("wst"))}
+            if touched or wrote or any(s_.writes_inertia or s_.reads_accel for s_ in systems_):
+                raise ValueError(f"a program declared free of Body state reads {sorted(touched)} / writes {sorted(wrote)}")
+            body_dead = True
     # bit 17 of the layout word: a one-kernel program whose code never looks at the absolute tick (no `tick` leaf, every system on
     # every tick, no windows) — its launches are identical whatever StepParams::tick0 says, so batches of them may replay from a
     # captured hipGraph like the hand-written kernel's (csrc/sixdof_capi.cpp graph_eligible)
@@ -1404,7 +1415,7 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
             if i == last_seg:       # the link that records the tick into the history ring holds every column
                 used = set(range(len(tp.columns)))
             reads_accel = any(s_.reads_accel for s_ in pre)
-            parts.append(_emit_pipe_struct(f"PipeSeg{i}", tp, pipe_tp if six else None, pre, post, used, reads_accel, 0))
+            parts.append(_emit_pipe_struct(f"PipeSeg{i}", tp, pipe_tp if six else None, pre, post, used, reads_accel, 0, body_dead))
             ig = integ if six else "kNone"
             tweak = "" if i == last_seg else " qs.hist_ring = 0; qs.hist_pos = qs.hist_vel = qs.hist_accel = qs.hist_force = nullptr;"          # only the last link records the tick
             tweak += "" if six else " qs.accel_in_check = 0;"

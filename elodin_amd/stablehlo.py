@@ -2750,6 +2750,7 @@ def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = No
         fn.__signature__ = inspect.Signature([inspect.Parameter(p_, inspect.Parameter.KEYWORD_ONLY) for p_ in all_cols])
         system_ = _dsl.system(fn, **{c: widths[c] for c in all_cols})
         system_.float32_refused = ["a whole-world tick with fold stages is a float64 program (its fold kernels gather doubles)"]
+        system_.body_free = True          # every slot of the world is a column of the program: no link of the chain touches a Body column
         return system_
     pre = []
     for k in range(n_folds):
