@@ -1360,9 +1360,11 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
     # every tick, no windows) — its launches are identical whatever StepParams::tick0 says, so batches of them may replay from a
     # captured hipGraph like the hand-written kernel's (csrc/sixdof_capi.cpp graph_eligible)
     tick_free = False
-    if is_prog and not staged and not tp.windows:
-        systems_ = tp.pre + tp.post
-        exprs_ = [e for s_ in systems_ for _, e in s_.assign] + (list(pipe_tp.outputs) if pipe_tp is not None else [])
+    if is_prog and not tp.windows and (not staged or body_dead):      # (a whole-world tick run as a chain of launches — fold stages between
+        #                                                                  its systems — replays just the same: every link is captured)
+        systems_ = [s_ for s_ in tp.pre + tp.post if not isinstance(s_, dsl.TracedFoldStage)]
+        exprs_ = [e for s_ in systems_ for _, e in s_.assign] + (list(pipe_tp.outputs) if pipe_tp is not None else []) + \
+                 [e for fs in tp.fold_stages for e in fs.traced.outputs]
         tick_free = ("tick" not in dsl._leaves_of(exprs_) and all(s_.every == 1 and s_.also_at is None for s_ in systems_))
     tick_free_bit = " | (1u << 17)" if tick_free else ""
     if not staged:

@@ -165,3 +165,27 @@ def test_the_sequential_fold_is_bit_identical_to_the_oracle():
     for c, r in (("world_pos", ref.world_pos), ("world_vel", ref.world_vel), ("world_accel", ref.world_accel), ("force", ref.force)):
         assert np.array_equal(hip._aux["hlo_" + c], r), c
     hip.close()
+
+
+def test_a_fold_stage_world_replays_from_a_captured_graph_with_the_same_bits():
+    """The module carries its own tick column and no link of its chain looks at the absolute tick, so a batch of one-tick launches — 13
+    kernels each — replays from a captured hipGraph (layout bit 17) exactly like the hand-written kernel's: same bits as the eager chain."""
+    nb = 128
+    text, slots = hb.nbody_world(nb, K_SQ, EPS)
+    prog, manifest, edges = sh.world_program(text, slots)
+    pos, vel, inertia = _world(nb)
+    ids = np.arange(1, nb + 1, dtype=np.uint64)
+    out = {}
+    for graph in (False, True):
+        cols = _columns(manifest, nb, pos, vel, inertia, 0.5)
+        hip = ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (nb, 1)), np.zeros((nb, 6)), np.ones((nb, 7)), entity_ids=ids, integrator=L.INTEGRATOR_NONE,
+                         effectors=prog, columns=cols, graph_edges=sh.edges_as_entity_ids(edges, ids), use_graph=graph)
+        if graph:
+            hip.prepare(48)
+        t = hip.run(48)
+        assert (t.graph_launches == 48) == graph, (graph, t.graph_launches)
+        out[graph] = {c: hip._aux[c].copy() for c in ("hlo_world_pos", "hlo_world_vel", "hlo_world_accel", "hlo_force", "hlo_tick")}
+        hip.close()
+    for c in out[False]:
+        assert np.array_equal(out[False][c], out[True][c]), c
+    assert np.all(out[True]["hlo_tick"] == 48)

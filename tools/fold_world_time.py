@@ -35,8 +35,15 @@ for nb, worlds, wave in ((80, 1, True), (80, 64, True), (256, 1, True), (256, 16
     build_s = time.perf_counter() - t0
     ex.invoke_batch(5)
     tm = ex.invoke_batch(50)
-    ex.close()
     us = tm.kernel_device_ms / 50 * 1e3
-    out[f"{nb}_bodies_x_{worlds}_worlds" + ("" if wave else "_sequential_fold")] = {"us_per_tick": round(us, 2), "launches_per_tick": int(tm.launches // 50), "pair_evals_per_s": round(4.0 * nb * (nb - 1) * worlds / us * 1e6, 1),
+    # the module carries its own tick column, so the launches of a batch are identical: with SIXDOF_FLAG_USE_GRAPH the 13-launch chain
+    # of a tick replays from a captured graph like the hand-written kernel's
+    ex.set_flags(L.FLAG_USE_GRAPH)
+    ex.prepare(64)
+    ex.invoke_batch(64)
+    tg = ex.invoke_batch(64)
+    us_graph, graph_launches = tg.kernel_device_ms / 64 * 1e3, int(tg.graph_launches)
+    ex.close()
+    out[f"{nb}_bodies_x_{worlds}_worlds" + ("" if wave else "_sequential_fold")] = {"us_per_tick": round(us, 2), "us_per_tick_graph_replay": round(us_graph, 2), "graph_launches_of_64": graph_launches, "launches_per_tick": int(tm.launches // 50), "pair_evals_per_s": round(4.0 * nb * (nb - 1) * worlds / us * 1e6, 1),
                                               "build_seconds_incl_trace_and_hipcc_or_cache": round(build_s, 2)}
 print(json.dumps(out, indent=1))
