@@ -1157,6 +1157,10 @@ def _emit_fold_stage(fs: "dsl.TracedFoldStage") -> str:
               f"__device__ const uint32_t fold{j}_dst[{max(len(fs.dst), 1)}] = {{{arr(fs.dst)}}};")
     src_of = (lambda i_: i_) if complete else (lambda i_: f"fold{j}_src[{i_}]")
     n_edges = complete * (complete - 1) if complete else len(fs.dst)
+    # a fold whose output column is none of the columns it reads (dsl.GraphFold.direct_out: the scans of stablehlo.world_program) needs
+    # no scratch-then-commit: no lane can read what another has already replaced
+    direct = bool(getattr(f, "direct_out", False)) and fs.out[0] not in [n for n, _, _ in fs.left + fs.right]
+    out_slot = fs.out[1] if direct else fs.scratch_slot
     kinds = _graph_fold_kinds(fs.traced.outputs, w) if getattr(f, "wave_fold", False) else None
     if kinds is not None:
         # A WAVE per source (dsl.GraphFold.wave_fold: the long scans stablehlo.world_program lifts out of a whole-world tick ask for
@@ -1185,7 +1189,7 @@ __global__ __launch_bounds__(64) void fold{j}_kernel(const StepParams P) {{
 {nl.join(loads_b)}
 {body}
     }}
-    T* sc = static_cast<T*>(P.model_cols[{fs.scratch_slot}]) + (size_t)row * {w};
+    T* sc = static_cast<T*>(P.model_cols[{out_slot}]) + (size_t)row * {w};
     {{
 {red}
 {fin}
@@ -1217,7 +1221,7 @@ __global__ __launch_bounds__(64) void fold{j}_kernel(const StepParams P) {{
 {nl.join(loads_b)}
 {body}
     }}
-    T* sc = static_cast<T*>(P.model_cols[{fs.scratch_slot}]) + (size_t)row * {w};
+    T* sc = static_cast<T*>(P.model_cols[{out_slot}]) + (size_t)row * {w};
     for (int k = 0; k < {w}; k++) sc[k] = acc[k];
 }}
 template <class T>
@@ -1408,9 +1412,10 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
                 nb = (len(fs.src_rows) * (fs.replicas[0] if fs.replicas else 1) + 63) // 64
                 waves = (getattr(fs.traced.fold, "wave_fold", False) and _graph_fold_kinds(fs.traced.outputs, fs.out[2]) is not None)
                 nk = len(fs.src_rows) * (fs.replicas[0] if fs.replicas else 1) if waves else nb      # one wave per source, or one lane
+                direct = bool(getattr(fs.traced.fold, "direct_out", False)) and fs.out[0] not in [n_ for n_, _, _ in fs.left + fs.right]
                 if nb:
-                    calls.append(f"        hipLaunchKernelGGL(fold{fs.index}_kernel<{T}>, dim3({nk}), dim3(64), 0, s, q);\n"
-                                 f"        hipLaunchKernelGGL(fold{fs.index}_commit<{T}>, dim3({nb}), dim3(64), 0, s, q);")
+                    calls.append(f"        hipLaunchKernelGGL(fold{fs.index}_kernel<{T}>, dim3({nk}), dim3(64), 0, s, q);" +
+                                 ("" if direct else f"\n        hipLaunchKernelGGL(fold{fs.index}_commit<{T}>, dim3({nb}), dim3(64), 0, s, q);"))
                 continue
             _, pre, post, six = c
             used = _slots_of(pre + post, pipe_tp.outputs if six else ())

@@ -2716,6 +2716,7 @@ def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = No
         # sums per lane, a fixed shuffle tree: another association of the same sum, ~1e-16 x sqrt(degree)); wave_folds=False keeps
         # the one-lane sequential fold, bit for bit the reference's order
         folds[-1].wave_fold = bool(wave_folds) and len(r.table[0]) >= 64
+        folds[-1].direct_out = True      # the accumulator column is none of the columns the scan reads: no scratch-then-commit launch
         if all(len(r.table[s_]) == n_entities - 1 and r.table[s_] == [t for t in range(n_entities) if t != s_] for s_ in range(n_entities)):
             # every source folds every other entity in ascending order (examples/n-body/sim.py:330-338): the complete graph — said,
             # not listed, so its n (n - 1) edges need not fit the 65,536 a fold stage bakes
