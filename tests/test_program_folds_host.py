@@ -96,3 +96,34 @@ def test_fold_stage_csr_keeps_spawn_order_per_source():
     tp = dsl.Program([fold_test], dsl.pipe(), []).trace({"x": 1}, fold_edges={"e": ([2, 0, 2, 0, 2], [1, 2, 0, 1, 2])})
     fs = tp.fold_stages[0]
     assert fs.src_rows == [0, 2] and fs.row_start == [0, 2, 5] and fs.dst == [2, 1, 1, 0, 2]
+
+
+def test_only_plain_sums_are_folded_by_a_wave_per_source():
+    """dsl.GraphFold.wave_fold asks for the wave-per-source fold kernel (lane partials + a shuffle tree: another association of the
+    sum).  codegen grants it only when every component is acc_k +- g, acc_k itself or the constant 0 (_graph_fold_kinds); a fold that
+    is not a plain sum — a running maximum, a product, an accumulator that feeds its own update — keeps the sequential kernel."""
+    from elodin_amd import codegen
+    np_ = dsl.np
+
+    def program(fn, init):
+        @dsl.system(x=3)
+        def produce(x, y):
+            return {"y": np_.array([x[0] * 2.0, x[1] + x[2]])}
+        fold = dsl.GraphFold(fn, "e", ("y",), ("y",), "z", init)
+        fold.wave_fold = True
+        prog = dsl.Program([produce, fold], dsl.Pipe([]), [])
+        n = 6
+        edges = ([s_ for s_ in range(n) for _ in range(n - 1)], [t for s_ in range(n) for t in range(n) if t != s_])
+        tp = prog.trace({"x": 3, "y": 2, "z": 2}, fold_edges={"e": edges})
+        return tp, codegen.generate_source(tp, "float64", 2)
+
+    tp, src = program(lambda acc, a, b: np_.array([acc[0] + a[0] * b[1], acc[1] - b[0]]), [0.0, 1.5])
+    assert codegen._graph_fold_kinds(tp.fold_stages[0].traced.outputs, 2) == ["sum", "sum"]
+    assert "one WAVE per source" in src and "T(1.5) + v1" in src                       # the initial value joins after the tree
+    tp, src = program(lambda acc, a, b: np_.array([np_.maximum(acc[0], b[0]), acc[1] + b[1]]), [0.0, 0.0])
+    assert codegen._graph_fold_kinds(tp.fold_stages[0].traced.outputs, 2) is None      # a running maximum is not a sum
+    assert "one WAVE per source" not in src and "fold0_kernel" in src
+    tp, src = program(lambda acc, a, b: np_.array([acc[0] * b[0], acc[1]]), [1.0, 0.0])
+    assert codegen._graph_fold_kinds(tp.fold_stages[0].traced.outputs, 2) is None and "one WAVE per source" not in src
+    tp, src = program(lambda acc, a, b: np_.array([acc[0] + acc[1] * b[0], acc[1] + 1.0]), [0.0, 0.0])      # g depends on the accumulator
+    assert codegen._graph_fold_kinds(tp.fold_stages[0].traced.outputs, 2) is None and "one WAVE per source" not in src
