@@ -189,3 +189,68 @@ def test_a_fold_stage_world_replays_from_a_captured_graph_with_the_same_bits():
     for c in out[False]:
         assert np.array_equal(out[False][c], out[True][c]), c
     assert np.all(out[True]["hlo_tick"] == 48)
+
+
+def _mc_rank(rank, world, port, q, nb, worlds, ticks):
+    """One gloo rank of a Monte-Carlo of fold-stage worlds: its block of WHOLE worlds on cuda:0, the rows gathered in world order."""
+    import os
+    import torch.distributed as dist
+    from elodin_amd import shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        text, slots = hb.nbody_world(nb, K_SQ, EPS)
+        prog, manifest, edges = sh.world_program(text, slots)
+        lo, hi = shard.shard_range(nb * worlds, world, rank, unit=manifest["rows_per_world"])      # never splits a world
+        mine = range(lo // nb, hi // nb)
+        starts = [_world(nb, seed=100 + w_) for w_ in mine]
+        pos, vel, inertia = (np.concatenate([s_[k] for s_ in starts]) for k in range(3))
+        rows = hi - lo
+        cols = _columns(manifest, rows, pos, vel, inertia, 0.5)
+        ids = np.arange(1, rows + 1, dtype=np.uint64)
+        hip = ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (rows, 1)), np.zeros((rows, 6)), np.ones((rows, 7)), entity_ids=ids, integrator=L.INTEGRATOR_NONE,
+                         effectors=prog, columns=cols, graph_replicas=(len(mine), nb), graph_edges=sh.edges_as_entity_ids(edges, ids))
+        hip.run(ticks)
+        local = np.concatenate([hip._aux["hlo_world_pos"], hip._aux["hlo_world_vel"]], axis=1)
+        hip.close()
+        allrows = shard.gather_rows(local, nb * worlds, unit=nb)
+        if rank == 0:
+            q.put(allrows)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_monte_carlo_of_large_worlds_shards_by_world_over_two_ranks():
+    """Five 80-body worlds over two gloo ranks sharing cuda:0 (3 + 2 worlds: blocks of whole worlds, shard_range(unit=rows_per_world)),
+    each rank stepping its block with the HIP fold-stage program, the rows gathered through the C packing (unit = a world): equal to the
+    five worlds stepped one by one against the oracle."""
+    import queue
+    import socket
+    import time
+    import torch.multiprocessing as mp
+    nb, worlds, ticks = 80, 5, 4
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mc_rank, args=(r, 2, port, q, nb, worlds, ticks)) for r in range(2)]
+    for p in procs:
+        p.start()
+    deadline = time.time() + 300
+    while True:
+        try:
+            got = q.get(timeout=2)
+            break
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead and time.time() < deadline, f"rank processes exited with {dead}"
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got.shape == (nb * worlds, 13)
+    for w_ in range(worlds):
+        ref = orc.OracleWorld(*_world(nb, seed=100 + w_), simulation_time_step=0.5, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, (K_SQ, EPS), None)]).step(ticks)
+        blk = got[w_ * nb:(w_ + 1) * nb]
+        assert np.max(np.abs(blk[:, 4:7] - ref.world_pos[:, 4:7]) / np.maximum(np.max(np.abs(ref.world_pos[:, 4:7]), axis=1, keepdims=True), 1e-300)) <= 1e-12, w_
+        assert np.max(np.abs(blk[:, 10:13] - ref.world_vel[:, 3:6]) / np.maximum(np.max(np.abs(ref.world_vel[:, 3:6]), axis=1, keepdims=True), 1e-300)) <= 1e-12, w_
