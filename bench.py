@@ -15,7 +15,8 @@ Rank 0's LAST stdout line is ONE compact JSON object (< 4 KB, gated by tests/tes
 duration from HIP events around the timed region), `parity` (max |dState| vs the oracle on a 4,096-row world, outside the
 timed region — the second half of BASELINE.json's metric) and `cpu_baseline` (the CPU oracle on the host cores, one thread,
 bounded sample, N = 1 only); at N > 1 also `rccl` (what the process group is) and `campaigns` (BASELINE configs[3] / [4] as
-whole Monte-Carlo campaigns over the same ranks, four numbers).  What the reference's own profile prints is as small
+whole Monte-Carlo campaigns over the same ranks, four numbers — run LAST and under a watchdog, `guarded_campaigns`: a rank
+failing alone in there costs the line `campaigns`, never the headline).  What the reference's own profile prints is as small
 (libs/nox-py/src/profile.rs:14-59: build, h2d, kernel_invoke, d2h, tick, real-time factor).
 
 Everything else — the 4 M-body HBM roofline, fused ticks, n-body, sparse edges, telemetry commit, the campaigns on one GPU,
@@ -239,6 +240,45 @@ def campaign_numbers(rank, world, local_rank, comm, barrier):
     return out
 
 
+def guarded_campaigns(rank, leg, finish, line):
+    """The campaign leg at N > 1 under a watchdog.  It is the one part of the line that runs collectives inside library code
+    (plan broadcast, result gather) on ranks that have never met on real hardware: if a rank fails alone, the others wait in a
+    collective for ever and the WHOLE line — the headline the driver's scaling curve is made of — would be lost with it.  So:
+    an exception on this rank is recorded instead of raised, and when leg + closing barrier have not finished within
+    SIXDOF_BENCH_CAMPAIGN_TIMEOUT seconds (default 300) rank 0 prints the headline with `campaigns: {"error": ...}` and every
+    rank leaves.  `line(campaigns)` -> the text rank 0 prints; `finish()` = closing barrier + group teardown.
+    Returns the campaigns object (numbers, or {"error": ...})."""
+    import threading
+    limit = float(os.environ.get("SIXDOF_BENCH_CAMPAIGN_TIMEOUT", "300"))
+    state = {"error": None}
+
+    def bail():
+        why = state["error"] or f"the campaign leg did not finish within {limit:.0f} s on every rank"
+        print(f"bench.py: rank {rank}: {why}; the headline is printed without the campaign numbers", file=sys.stderr, flush=True)
+        if rank == 0:
+            print(line({"error": why}), flush=True)
+        sys.stdout.flush()
+        os._exit(0)             # the other ranks sit in a collective that will never complete: no orderly teardown exists
+
+    timer = threading.Timer(limit, bail)
+    timer.daemon = True
+    timer.start()
+    try:
+        out = leg()
+    except Exception as e:  # noqa: BLE001 — recorded in the line and on stderr, never fatal to the headline
+        state["error"] = f"{type(e).__name__}: {e}"[:300]
+        print(f"bench.py: rank {rank}: campaign leg FAILED: {state['error']}", file=sys.stderr, flush=True)
+        out = {"error": state["error"]}
+    try:
+        finish()                # still under the watchdog: a rank that failed alone leaves the others inside a collective
+    except Exception as e:  # noqa: BLE001 — a peer that left early breaks the closing barrier; the line is still owed
+        print(f"bench.py: rank {rank}: closing barrier after the campaign leg failed: {type(e).__name__}: {e}"[:400], file=sys.stderr, flush=True)
+        if isinstance(out, dict) and "error" not in out:
+            out = dict(out, closing_barrier_error=f"{type(e).__name__}"[:80])
+    timer.cancel()
+    return out
+
+
 def compose_line(args, world, n, K, elapsed, elapsed_incl, tm, *, roofline, parity, cpu=None, rccl=None, campaigns=None,
                  shared_gpu=False, data="synthetic"):
     """The one object the driver parses.  Kept flat and small; `fit_line` enforces the size."""
@@ -435,10 +475,6 @@ def main(argv=None):
                                       "frac": round(BYTES_PER_ENTITY_STEP_F64 * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
     ex.close()
 
-    campaigns = None
-    if (world > 1 and not args.no_campaigns) or args.campaigns:
-        campaigns = campaign_numbers(rank, world, local_rank, rank_device if distributed else "cpu", barrier)
-
     extras_errors = {}
     if args.extras:
         if world != 1:
@@ -458,11 +494,20 @@ def main(argv=None):
         parity = {"skipped": "--no-cpu-baseline"} if args.no_cpu_baseline else parity_figure(local_rank)
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(w, eff)
-    finish()
+
+    def line(campaigns):
+        return fit_line(compose_line(args, world, n, K, elapsed, elapsed_incl, tmd, roofline=roofline, parity=parity, cpu=cpu, rccl=attest,
+                                     campaigns=campaigns, shared_gpu=shared_gpu))
+
+    # the campaign numbers come LAST and under a watchdog: the headline above is complete before any of their collectives run
+    if (world > 1 and not args.no_campaigns) or args.campaigns:
+        campaigns = guarded_campaigns(
+            rank, lambda: campaign_numbers(rank, world, local_rank, rank_device if distributed else "cpu", barrier), finish, line)
+    else:
+        campaigns = None
+        finish()
     if rank == 0:
-        out = compose_line(args, world, n, K, elapsed, elapsed_incl, tmd, roofline=roofline, parity=parity, cpu=cpu, rccl=attest,
-                           campaigns=campaigns, shared_gpu=shared_gpu)
-        print(fit_line(out), flush=True)
+        print(line(campaigns), flush=True)
     if extras_errors:
         print("bench.py --extras: FAILED legs: " + json.dumps(extras_errors), file=sys.stderr, flush=True)
         return 1
@@ -495,27 +540,46 @@ def dry_run(args, rank, world, distributed, n, K):
         box = [None] * world
         dist.all_gather_object(box, f"dry-run#{rank}")
         rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": None, "distinct_devices": False, "devices": box}
-        dist.barrier()
-        dist.destroy_process_group()
     else:
         rccl = {"backend": None, "world_size": 1, "devices": ["dry-run"]}
-    if rank == 0:
-        parity = {"max_rel_err": 0.0, "by_column": {f: 0.0 for f in ("world_pos", "world_vel", "world_accel", "force")},
-                  "max_rel_err_elementwise": 0.0, "by_column_elementwise": {f: 0.0 for f in ("world_pos", "world_vel", "world_accel", "force")},
-                  "tolerance": 1e-9, "entity_rows_bit_exact": None, "rows": 0, "ticks": 0, "vs": "DRY RUN: nothing was compared"}
-        camp = None
-        if (world > 1 and not args.no_campaigns) or args.campaigns:
-            camp = {"unit": "rollout-steps/s", "totals": CAMPAIGN_TOTALS}
-            for which in CAMPAIGN_TOTALS:
-                for s in (("strong",) if world == 1 else ("strong", "weak")):
-                    camp.setdefault(which, {})[s] = 0.0
-                    camp[which][s + "_seconds"] = 0.0
-        out = compose_line(args, world, n, K, elapsed, elapsed_incl, tmd,
-                           roofline=roofline_from(tmd["kernel_device_ms"] / max(1, tmd["launches"]), n, tmd["launches"], "DRY RUN: fake timings"),
-                           parity=parity, cpu=cpu, rccl=rccl, campaigns=camp, data="DRY RUN (no GPU, fake timings): not a measurement")
-        print(fit_line(out), flush=True)
-    return 0
+    parity = {"max_rel_err": 0.0, "by_column": {f: 0.0 for f in ("world_pos", "world_vel", "world_accel", "force")},
+              "max_rel_err_elementwise": 0.0, "by_column_elementwise": {f: 0.0 for f in ("world_pos", "world_vel", "world_accel", "force")},
+              "tolerance": 1e-9, "entity_rows_bit_exact": None, "rows": 0, "ticks": 0, "vs": "DRY RUN: nothing was compared"}
 
+    def line(campaigns):
+        return fit_line(compose_line(args, world, n, K, elapsed, elapsed_incl, tmd,
+                                     roofline=roofline_from(tmd["kernel_device_ms"] / max(1, tmd["launches"]), n, tmd["launches"], "DRY RUN: fake timings"),
+                                     parity=parity, cpu=cpu, rccl=rccl, campaigns=campaigns, data="DRY RUN (no GPU, fake timings): not a measurement"))
+
+    def finish():
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+
+    def fake_campaigns():
+        # SIXDOF_BENCH_DRYRUN_FAULT = "hang:<rank>" | "raise:<rank>": what a rank failing alone inside the leg looks like
+        kind, _, who = os.environ.get("SIXDOF_BENCH_DRYRUN_FAULT", "").partition(":")
+        if kind and int(who) == rank:
+            if kind == "raise":
+                raise RuntimeError("dry-run fault injected on this rank")
+            time.sleep(3600)
+        if distributed:
+            dist.barrier()          # the leg's collectives
+        camp = {"unit": "rollout-steps/s", "totals": CAMPAIGN_TOTALS}
+        for which in CAMPAIGN_TOTALS:
+            for s in (("strong",) if world == 1 else ("strong", "weak")):
+                camp.setdefault(which, {})[s] = 0.0
+                camp[which][s + "_seconds"] = 0.0
+        return camp
+
+    if (world > 1 and not args.no_campaigns) or args.campaigns:
+        camp = guarded_campaigns(rank, fake_campaigns, finish, line)
+    else:
+        camp = None
+        finish()
+    if rank == 0:
+        print(line(camp), flush=True)
+    return 0
 
 if __name__ == "__main__":
     sys.exit(main())

@@ -140,3 +140,20 @@ def test_real_sized_lines_fit_with_margin():
     raw = json.dumps(out, separators=(", ", ": "))
     assert len(raw) < 3800, len(raw)
     assert json.loads(bench.fit_line(out)) == json.loads(raw)            # nothing had to be dropped
+
+
+@pytest.mark.parametrize("fault", ["hang:1", "raise:1", "raise:0"])
+def test_a_rank_failing_alone_in_the_campaign_leg_does_not_cost_the_headline(fault):
+    """The campaign numbers are the one part of the N > 1 line that runs collectives inside library code.  A rank that hangs or
+    raises there alone must not take the headline — what the driver's scaling curve is made of — with it: the leg runs last,
+    under a watchdog, and the line then carries `campaigns: {"error": ...}`."""
+    env = _env()
+    env["SIXDOF_BENCH_DRYRUN_FAULT"] = fault
+    env["SIXDOF_BENCH_CAMPAIGN_TIMEOUT"] = "8"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=str(ROOT))
+    doc = _check(r.stdout, 2, 20, 5)
+    assert doc["value"] > 0 and doc["rccl"]["world_size"] == 2
+    assert "error" in doc["campaigns"] or "closing_barrier_error" in doc["campaigns"], doc["campaigns"]
+    assert "campaign" in r.stderr
