@@ -332,6 +332,21 @@ class _Emitter:
                 sc["lines"].append(f"{sc['indent']}}}")
                 return sc["names"][id(e)]
             wide = self._is_wide(e)
+            if _RELAXED_EMIT[0] and not wide and e.op == "div" and e.args[0].is_const(1.0):
+                # RELAXED ARITHMETIC (dsl.relaxed_arithmetic): the shared reciprocal of a denominator is v_rcp_f64 + two Newton steps
+                # (7 instructions against the 11 of an IEEE divide, 1 ulp), and 1 / sqrt(s) the hardware seed + one cubic correction
+                # (spatial.hpp rsqrt_pos: 5 against a library sqrt and a divide)
+                d = e.args[1]
+                if d.op == "sqrt" and not self._is_wide(d.args[0]):
+                    rhs = f"m_rsqrt_relaxed({ref(d.args[0], sc)})"
+                else:
+                    rhs = f"m_rcp_relaxed({f'T({ref(d, sc)})' if d.op != 'const' and self._is_wide(d) else ref(d, sc)})"
+                name = f"t{self.n}"
+                self.n += 1
+                sc["names"][id(e)] = name
+                self._deps(e)
+                sc["lines"].append(f"{sc['indent']}const T {name} = {rhs};")
+                return name
             if id(e) in fused:
                 # FUSED MULTIPLY-ADD (fast-math builds, _FUSE_FMA): a product whose only use is this sum never becomes a value of
                 # its own.  Decided here, per node, so every copy of the tick body the compiler makes rounds the same way (the
@@ -524,6 +539,8 @@ _GUARD_SELECTS = [False]
 # Fast-math builds fold single-use products into the sums that consume them (see _Emitter.block, "FUSED MULTIPLY-ADD");
 # SIXDOF_FUSE_FMA=0 keeps them apart (A/B).  Exact builds never fuse: a reference evaluates every node to a rounded value.
 _FUSE_FMA = [False]
+# programs traced under dsl.relaxed_arithmetic (TracedProgram.fp_contract): see _Emitter.block `m_rcp_relaxed`
+_RELAXED_EMIT = [False]
 _GUARD_MIN_COST = 40
 _NODE_COST = {"lane_read": 8, "lane_read_dyn": 10, "threefry": 90, "erfinv": 120, "sin": 12, "cos": 12, "tan": 20, "exp": 10, "log": 10, "pow": 25, "atan2": 27, "asin": 20,
               "acos": 20, "hypot": 12, "div": 4, "sqrt": 4, "interp": 30, "cbrt": 20, "sinh": 20, "cosh": 20, "erfc": 40, "log1p": 15,
@@ -770,6 +787,20 @@ def _emit_systems(systems, cold: Optional[Dict[int, int]] = None, store_only: Op
     return "\n".join(out)
 
 
+_RELAXED_PRELUDE = '''// relaxed arithmetic only (dsl.relaxed_arithmetic): 1 / x as v_rcp_f64 + two Newton steps (1 ulp; x = 0 / inf keep the seed's
+// inf / 0), 1 / sqrt(x) as the seed + one cubic correction
+__device__ __forceinline__ double m_rcp_relaxed(double x) {
+    const double r0 = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r0, 1.0);
+    double r = fma(e, r0, r0);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return e == e ? r : r0;
+}
+__device__ __forceinline__ float m_rcp_relaxed(float x) { return 1.0f / x; }
+__device__ __forceinline__ double m_rsqrt_relaxed(double x) { return rsqrt_pos(x); }
+__device__ __forceinline__ float m_rsqrt_relaxed(float x) { return 1.0f / fast_sqrt(x); }
+'''
+
 _PRELUDE = '''// SIXDOF_FAST_MATH (f32 programs, opt-in): hardware transcendentals (v_sin / v_cos / v_exp / v_log / v_rcp /
 // v_sqrt, ~1e-6 relative) instead of the correctly rounded library calls — sinf+cosf alone are ~240 instructions, and a
 // tick of the Falcon 9 program makes 32 of them.  f64 programs and the default f32 mode keep the library functions.
@@ -990,8 +1021,11 @@ def _emit_pipe_struct(name: str, tp, pipe_tp, pre, post, used: Optional[set], pr
         store_only = _store_only_slots(pipe_tp, pre, post, transient)
         vol = "volatile " if _MEMORY_COLUMNS[0] else ""
         regs = "\n".join(f"        {vol}T c{k}[{w}];" + ("   // cold: lives in its HBM column between cadence blocks" if k in cold else "") for k, w in reg_cols)
+        # wave-uniform columns (TracedProgram.uniform_slots): every lane reads the first row of the wavefront's block — one line per
+        # wave instead of one value per row; stores stay per row, so every row keeps holding the value
+        uni = set(getattr(tp, "uniform_slots", ()) or ()) if used is None else set()       # (either device layout: the row index alone changes)
         loads = "\n".join(
-            f"            {{ {_col_ptr(k, w, 'row')} "
+            f"            {{ {_col_ptr(k, w, '(row & ~uint32_t(kWave - 1))' if k in uni else 'row')} "
             + " ".join(f"r.c{k}[{j}] = col_ld<POL>(g + {_col_idx(j)});" for j in range(w)) + " }" for k, w in reg_cols if k not in cold and k not in transient)
         # element by element, not a loop: a loop the optimiser does not unroll (-O1, the low-register-pressure fallback build)
         # indexes the array dynamically, which pins the whole register file image in scratch memory
@@ -1292,6 +1326,8 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
     None = the SIXDOF_GUARD_SELECTS environment switch (off unless "1")."""
     _GUARD_SELECTS[0] = (os.environ.get("SIXDOF_GUARD_SELECTS", "") == "1") if guard_selects is None else bool(guard_selects)
     _FUSE_FMA[0] = bool(fast_math) and os.environ.get("SIXDOF_FUSE_FMA", "1") != "0"
+    _RELAXED_EMIT[0] = (isinstance(tp, dsl.TracedProgram) and bool(getattr(tp, "fp_contract", False))
+                        and os.environ.get("SIXDOF_RELAXED_IEEE_RCP", "") != "1")      # A/B: the shared reciprocals as IEEE divides
     _WINDOW_SOA[0] = bool(window_soa)
     _COLUMN_SOA[0] = bool(column_soa)
     if column_soa and isinstance(tp, dsl.TracedProgram) and tp.fold_stages:
@@ -1440,6 +1476,13 @@ def generate_source(tp, dtype: str, integrator: int, fast_math: bool = False, wi
     if fast_math and "m_erfinv(" in structs:      # only programs that draw normal samples carry (and are keyed on) this text
         structs = structs.replace("m_erfinv(", "m_erfinv_fast(")
         fast_erfinv = _FAST_ERFINV
+    # a program traced under dsl.relaxed_arithmetic: a * b + c may contract across statements (kernels.hpp keeps everything else at
+    # `contract(on)`: within one source expression only — and the generated text has one operation per statement)
+    relaxed = is_prog and getattr(tp, "fp_contract", False)
+    contract_on = "#pragma clang fp contract(fast)   // relaxed arithmetic (dsl.relaxed_arithmetic): not the reference's bits\n" if relaxed else ""
+    contract_off = "\n#pragma clang fp contract(on)" if relaxed else ""
+    if relaxed:      # only relaxed programs carry (and are keyed on) this text
+        structs = _RELAXED_PRELUDE + structs
     return f'''// generated by elodin_amd/codegen.py — do not edit.  Effectors: {names}
 {stage_comment}{fast}{"#define SIXDOF_TICK_OUT_OF_LINE" + chr(10) if _TICK_OUT_OF_LINE[0] else ""}#include "step_kernel.hpp"
 
@@ -1448,7 +1491,7 @@ namespace sixdof {{
 {_PRELUDE}{fast_erfinv}
 {tables}
 
-{structs}
+{contract_on}{structs}{contract_off}
 }}  // namespace sixdof
 
 extern "C" unsigned sixdof_custom_abi() {{ return static_cast<unsigned>(sizeof(sixdof::StepParams)); }}
@@ -1504,7 +1547,7 @@ def generate_pair_source(tf: "dsl.TracedFold", integrator: Optional[int] = None,
     if only_i not in (-1, 0, 1):
         raise ValueError(f"edge_fold effectors step under RK4 or the semi-implicit integrator, not integrator {integrator}")
     only_s = -1 if small is None else int(bool(small))
-    _GUARD_SELECTS[0], _FUSE_FMA[0] = False, False      # switches of generate_source: exact arithmetic here
+    _GUARD_SELECTS[0], _FUSE_FMA[0], _RELAXED_EMIT[0] = False, False, False      # switches of generate_source: exact arithmetic here
     _TABLES.clear()
     _GATHERS.clear()
     _LANE_TABLES.clear()
@@ -1566,7 +1609,7 @@ def generate_graph_fold_source(tf: "dsl.TracedGraphFold") -> str:
     """A stand-alone GraphQuery.edge_fold over arbitrary components: one lane per source entity folds its out-edges
     (CSR by source, spawn order) into a scratch row; a second kernel moves the rows into the output component, so every
     fold sees the component values from before the system ran."""
-    _GUARD_SELECTS[0], _FUSE_FMA[0] = False, False      # switches of generate_source: exact arithmetic here
+    _GUARD_SELECTS[0], _FUSE_FMA[0], _RELAXED_EMIT[0] = False, False, False      # switches of generate_source: exact arithmetic here
     _TABLES.clear()
     _GATHERS.clear()
     _LANE_TABLES.clear()

@@ -404,8 +404,35 @@ def _un(op: str, x) -> "Expr":
     return Expr(op, (x,))
 
 
+# RELAXED ARITHMETIC (opt-in, `with relaxed_arithmetic():` around a trace — stablehlo.world_system(arith="relaxed")).  The default
+# DAG is the user's program operation for operation: every node a correctly rounded IEEE value, `0 * x` kept because x may be
+# Inf / NaN.  Relaxed trades that for the forms a hand-written kernel uses and stays inside BASELINE's 1e-9: it ASSUMES FINITE
+# VALUES (`0 * x` is 0, which with x + 0 = x removes the zero halves of `q (x) [v, 0]`), turns `a / d` into `a * (1 / d)` so that
+# the quotients of one denominator (a quaternion normalised, inverted, a wrench over one mass) share ONE division through the
+# hash-consing of nodes, and lets the compiler contract `a * b + c` (System.fp_contract -> codegen).  Results differ from the
+# reference's in the last bits (<= a few ulp per operation), not bit for bit.
+_RELAXED = [False]
+
+
+class relaxed_arithmetic:
+    def __enter__(self):
+        self.saved, _RELAXED[0] = _RELAXED[0], True
+    def __exit__(self, *a):
+        _RELAXED[0] = self.saved
+
+
 def _bin(op: str, a, b) -> Expr:
     a, b = _lift(a), _lift(b)
+    if _RELAXED[0]:
+        if op == "mul" and (a.is_const(0.0) or b.is_const(0.0)):
+            return const(0.0)
+        if op == "div" and a.is_const(0.0):
+            return const(0.0)
+        if op == "div" and a.op != "const":
+            if b.op == "const" and b.value not in (0.0,) and b.value == b.value and abs(b.value) != float("inf"):
+                return _bin("mul", a, const(1.0 / b.value))
+            if b.op != "const":
+                return _bin("mul", a, Expr("div", (const(1.0), b)))
     if op in ("add", "sub", "mul", "div"):
         if a.op == "const" and b.op == "select" and _const_tree(b):
             return _map_const_tree(b, lambda c: _bin(op, a, c))
@@ -1945,6 +1972,8 @@ class TracedSystem:
         self.reads_accel = False
         self.body_free = bool(getattr(sys_, "body_free", False))     # the system declares it touches no Body column (checked by codegen)
         self.float32_refused = list(getattr(sys_, "float32_refused", ()) or ())     # stablehlo.float32_hazards: integer work exact in f64 only
+        self.fp_contract = bool(getattr(sys_, "fp_contract", False))     # traced under relaxed_arithmetic: the build may contract a * b + c
+        self.uniform = tuple(getattr(sys_, "uniform", ()) or ())        # columns the caller promises hold ONE value in every row
         pos, vel, inertia = _body_symbols()
         kwargs = {}
 
@@ -2224,6 +2253,7 @@ class TracedProgram:
         self.body_free = (bool(self.pre + self.post) and not self.fold_stages and not prog.effectors.effectors
                           and all(getattr(s, "body_free", False) for s in self.pre + self.post))
         self.float32_refused = [r for s in self.pre + self.post for r in getattr(s, "float32_refused", ())]
+        self.fp_contract = any(getattr(s, "fp_contract", False) for s in self.pre + self.post)
         self.writes_inertia = any(s.writes_inertia for s in self.pre + self.post)
         # maps / folds that stood among the force effectors inside six_dof(sys=...) run in front of the force evaluation
         # (frontend.six_dof).  That is the reference's order unless an effector reads what a system BEHIND it in the pipe writes
@@ -2253,6 +2283,14 @@ class TracedProgram:
         self.written_slots = sorted({int(t[1:].split("_")[0]) for t in written})
         self.reads_velocity = self.pipe.reads_velocity
         self.world_torque = self.pipe.world_torque
+        # WAVE-UNIFORM columns (System.uniform; stablehlo.world_system(one_world=True)): the caller promises that every row of the
+        # executor holds the same value there (the Globals of ONE world, replicated per row) — the kernel then reads the first row of
+        # its wavefront's block instead of 64 rows (codegen._emit_pipe_struct).  Only when every system of a one-kernel program agrees.
+        systems_ = self.pre + self.post
+        declared = [set(getattr(s, "uniform", ()) or ()) for s in systems_]
+        names_ = [c for c, _ in self.table.cols]
+        self.uniform_slots = (sorted(names_.index(c) for c in set.intersection(*declared) if c in names_)
+                              if declared and not self.fold_stages and not self.windows else [])
 
     @property
     def columns(self) -> List[Tuple[str, int]]:

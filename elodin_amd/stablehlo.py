@@ -2797,7 +2797,7 @@ def slots_from_metadata(doc: dict):
 
 
 def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = None, mode: str = "auto", name: str = "world_tick",
-                 every: int = 1):
+                 every: int = 1, arith: str = "reference", one_world: bool = False):
     """A whole-world StableHLO tick (entity-batched `[N, w]` arguments) as ONE system of the generated kernel.  -> (system, manifest)
 
     slots / out_slots: per @main argument / result a Slot (or (component, shape, entity_axis_elided), or ExecSlotMetadata dicts);
@@ -2807,7 +2807,15 @@ def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = Non
       "world" — one lane per WORLD: every slot is flattened into one row of a column, the executor's rows are independent worlds
                 (a Monte-Carlo of small worlds — edge folds, joins and everything else are just index arithmetic inside a lane);
       "auto"  — "lane" when the tick is entity-parallel, else "world".
-    The manifest says which it became and lists the program's columns in binding order."""
+    The manifest says which it became and lists the program's columns in binding order.
+    arith: "reference" — the module's arithmetic operation for operation (bit for bit the oracle's on the golden worlds);
+           "relaxed"   — dsl.relaxed_arithmetic: finite values assumed (`0 * x` = 0, so a read that only feeds one disappears),
+                         one division per denominator, `a * b + c` contracted: inside 1e-9, not the reference's last bits.
+    one_world (lane mode): the caller promises that the executor's rows are the entities of ONE world — the singleton slots
+           (Globals: tick, dt), replicated per row, then hold one value in every row and the kernel reads them once per
+           wavefront (16 B per entity-tick less at configs[1]).  Not for a Monte-Carlo of worlds stacked in one executor."""
+    if arith not in ("reference", "relaxed"):
+        raise ValueError("arith must be 'reference' or 'relaxed'")
     funcs = parse_module(text)
     main = funcs["main"]
     ins = [Slot.of(x) for x in slots]
@@ -2863,7 +2871,12 @@ def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = Non
                 args.append(Sym(arr, ty.dtype, 0 if batched else None, (), ty.shape))
             ev = _LaneEval(funcs, n_entities, stride) if lane else _Eval(funcs)
             res = {}
-            for s_, o in zip(outs, ev.call(main, args)):
+            if arith == "relaxed":
+                with _dsl.relaxed_arithmetic():
+                    results = ev.call(main, args)
+            else:
+                results = ev.call(main, args)
+            for s_, o in zip(outs, results):
                 if lane:
                     o = ev._mat(o, [d for d in o.uni if d != 0] if not s_.elided else None)
                     if s_.elided and o.eaxis is not None:
@@ -2898,8 +2911,13 @@ def world_system(text: str, slots: Sequence, out_slots: Optional[Sequence] = Non
         system_ = _dsl.system(fn, every=every, **widths)
         system_.body_free = True          # every slot of the world is a column of the program: no Body column is read or written
         system_.float32_refused = hazards     # dsl / codegen refuse a float32 build of a program that holds this system
+        system_.fp_contract = arith == "relaxed"
+        if one_world and lane:
+            system_.uniform = tuple(s_.column for s_ in ins + outs if s_.elided)
         manifest = {"mode": "lane" if lane else "world", "rows": "entities" if lane else "worlds",
                     **({"float32_refused": hazards} if hazards else {}),
+                    **({"arith": "relaxed"} if arith == "relaxed" else {}),
+                    **({"one_world": True} if (one_world and lane) else {}),
                     **({"float32_integer_columns": int_cols} if int_cols else {}),
                     "entities_per_world": n_entities,
                     "columns": [{"column": c, "width": widths[c],
@@ -2985,7 +3003,7 @@ def float32_hazards(funcs: Dict[str, Func]) -> List[str]:
 
 
 def compile_world(text: str, slots_doc: dict, out: Optional[str] = None, mode: str = "auto", dtype: str = "float64", fast_math: bool = False,
-                  wave_folds: bool = True):
+                  wave_folds: bool = True, arith: str = "reference", one_world: bool = False):
     """The build-time step a host (`WorldExec::Hip`, INTEGRATION.md §3) runs once per world: module text + slot metadata -> the
     shared object `sixdof_set_custom_pipe` installs, and the manifest of its columns.  -> (path of the .so, manifest)"""
     import json
@@ -2997,7 +3015,7 @@ def compile_world(text: str, slots_doc: dict, out: Optional[str] = None, mode: s
     folds = mode == "folds"
     if not folds:
         try:
-            system_, manifest = world_system(text, ins, outs, mode=mode)
+            system_, manifest = world_system(text, ins, outs, mode=mode, arith=arith, one_world=one_world)
         except (NotEntityParallel, NotImplementedError) as refused:
             # a world of more than a wavefront whose entities exchange data fits neither one lane per entity (the exchange leaves
             # the wavefront) nor one lane per world (too wide): its scans over the edge slot become fold stages (world_program)
@@ -3011,6 +3029,8 @@ def compile_world(text: str, slots_doc: dict, out: Optional[str] = None, mode: s
     if folds:
         if dtype != "float64":
             raise NotImplementedError("whole-world ticks with fold stages are float64 (the fold kernels gather doubles)")
+        if arith != "reference" or one_world:
+            raise NotImplementedError("arith='relaxed' / one_world apply to one-kernel ticks (modes lane, world), not to fold stages")
         prog, manifest, edges = built if mode == "auto" else world_program(text, ins, outs, wave_folds=wave_folds)
         manifest["folds"] = "a wave per source (lane partials + shuffle tree) for additive scans of 64 edges or more" if wave_folds else "sequential, one lane per source"
         n_world = int(manifest["entities_per_world"])
@@ -3163,6 +3183,10 @@ def _main(argv=None) -> int:
     ap.add_argument("--fast-math", action="store_true")
     ap.add_argument("--sequential-folds", action="store_true", help="fold stages (--mode folds) with one lane per source in slot order: the reference's "
                                                                      "association bit for bit, N - 1 dependent trips per scan (default: a wave per source for long additive scans)")
+    ap.add_argument("--arith", default="reference", choices=("reference", "relaxed"),
+                    help="relaxed: finite values assumed (0 * x = 0), one division per denominator, a * b + c contracted — inside 1e-9 of the "
+                         "reference instead of its last bits, about half the instructions (world_system)")
+    ap.add_argument("--one-world", action="store_true", help="lane mode: the executor's rows are ONE world, its Globals are read once per wavefront")
     a = ap.parse_args(argv)
     if a.checkpoint:
         rep = checkpoint(a.checkpoint, a.mode)
@@ -3171,9 +3195,9 @@ def _main(argv=None) -> int:
     if not (a.module and a.slots and a.out):
         ap.error("module, --slots and -o are required (or --checkpoint DIR)")
     so, manifest = compile_world(Path(a.module).read_text(), json.loads(Path(a.slots).read_text()), a.out, a.mode, a.dtype, a.fast_math,
-                                 wave_folds=not a.sequential_folds)
+                                 wave_folds=not a.sequential_folds, arith=a.arith, one_world=a.one_world)
     print(json.dumps({"object": str(so), "mode": manifest["mode"], "rows": manifest["rows"], "columns": [c["column"] for c in manifest["columns"]],
-                      "build": manifest["build"], **({"lane_refused": manifest["lane_refused"]} if "lane_refused" in manifest else {})}))
+                      "build": manifest["build"], **({k: manifest[k] for k in ("arith", "one_world") if k in manifest}), **({"lane_refused": manifest["lane_refused"]} if "lane_refused" in manifest else {})}))
     return 0
 
 

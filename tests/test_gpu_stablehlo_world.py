@@ -451,3 +451,47 @@ def test_a_program_that_never_looks_at_the_tick_replays_from_captured_graphs():
     hip.download()
     assert t.graph_launches == 0 and np.all(hip._aux["x"] == 96 * 97 / 2)
     hip.close()
+
+
+def test_relaxed_arithmetic_module_on_the_gpu():
+    """BASELINE configs[1] as a whole-world module under world_system(arith="relaxed") (dsl.relaxed_arithmetic: finite values assumed,
+    one division per denominator, v_rcp / v_rsq seeds + Newton, a * b + c contracted — the forms the hand-written kernel uses) against
+    the C oracle over 64 ticks on 4,096 rows: inside BASELINE's 1e-9 (vector-scaled like tests/parity.py; it measures ~1e-14), tick
+    column exact, and NOT the reference's last bits — which the default build of the same module is held to right beside it
+    (<= 1e-12: every operation the oracle's, in its order)."""
+    from tests.golden import hlo_world_builder as hb
+    keep = None
+    n, ticks = 4096 + 37, 64                  # a ragged last wavefront
+    text, slots = hb.independent_bodies_world(n)
+    w = workloads.independent_bodies(n)
+    o = orc.OracleWorld(w["world_pos"], w["world_vel"], w["inertia"], simulation_time_step=workloads.DT_120HZ,
+                        ops=[(orc.EFF_UNIFORM_GRAVITY, (0.0, 0.0, -9.81), None), (orc.EFF_BODY_TORQUE, (), w["body_torque"])])
+    o.step(ticks)
+    figures = {}
+    # one_world: the executor is ONE world, so the Globals columns (tick, dt: replicated per row) are read once per wavefront —
+    # same values, so the reference build stays bit for bit what it was; every row still gets the new tick stored
+    for arith, one_world, bound in (("reference", False, 1e-12), ("reference", True, 1e-12), ("relaxed", True, 1e-9)):
+        system, manifest = sh.world_system(text, slots, mode="lane", arith=arith, one_world=one_world)
+        assert manifest.get("arith", "reference") == arith and manifest.get("one_world", False) == one_world
+        cols = {"hlo_tick": np.zeros((n, 1)), "hlo_simulation_time_step": np.full((n, 1), workloads.DT_120HZ), "hlo_world_pos": w["world_pos"].copy(),
+                "hlo_world_vel": w["world_vel"].copy(), "hlo_world_accel": np.zeros((n, 6)), "hlo_force": np.zeros((n, 6)), "hlo_inertia": w["inertia"].copy(),
+                "hlo_torque": w["body_torque"].copy()}
+        hip = _exec(dsl.Program([system], dsl.Pipe([]), []), cols, n, use_graph=True)
+        t = hip.invoke_batch(ticks)
+        assert t.graph_launches == t.launches == ticks                 # replayed like the headline
+        hip.download()
+        got = {k: np.array(v) for k, v in hip._aux.items()}
+        hip.close()
+        assert np.all(got["hlo_tick"] == ticks)
+        worst = {}
+        for c, ref in (("world_pos", o.world_pos), ("world_vel", o.world_vel), ("world_accel", o.world_accel), ("force", o.force)):
+            g = got["hlo_" + c]
+            halves = ((slice(0, 4), slice(4, 7)) if c == "world_pos" else (slice(0, 3), slice(3, 6)))
+            worst[c] = float(max(np.max(np.abs(g[:, h] - ref[:, h]) / np.maximum(np.max(np.abs(ref[:, h]), axis=1, keepdims=True), 1e-300)) for h in halves))
+            assert worst[c] < bound, (arith, c, worst[c])
+        figures[arith + ("+one_world" if one_world else "")] = worst
+        if arith == "reference":
+            keep = got if not one_world else keep
+            assert all(np.array_equal(got[k], keep[k]) for k in got)
+    assert max(figures["relaxed+one_world"].values()) > 0.0
+    print("whole-world configs[1] module vs the oracle after 64 ticks (vector-scaled): " + json.dumps(figures))

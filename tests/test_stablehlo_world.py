@@ -230,6 +230,56 @@ def test_independent_bodies_world_tick_is_entity_parallel_and_matches_the_oracle
     assert np.all(comps["hlo_tick"] == 16)
 
 
+def test_relaxed_arithmetic_of_a_world_module_stays_inside_1e_9_and_sheds_the_reference_s_dead_work():
+    """world_system(arith="relaxed") (dsl.relaxed_arithmetic): finite values assumed, one division per denominator, a * b + c
+    contracted in the build.  Not the reference's last bits — the same world as above within 1e-12 of the oracle over 16 ticks —
+    and the DAG loses what the reference computes for nothing: the `0 * world_accel` of stage 1 (so the column is never read:
+    48 B per entity-tick less) and three divisions in four."""
+    from elodin_amd import codegen
+    n = 12
+    text, slots, cols = W.independent_bodies(n)
+    system, manifest = sh.world_system(text, slots, mode="lane", arith="relaxed")
+    assert manifest["arith"] == "relaxed" and manifest["mode"] == "lane"
+    widths = {c["column"]: c["width"] for c in manifest["columns"]}
+    dt = orc.quantize_time_step(120.0)
+    comps = {"hlo_" + k: np.array(v) for k, v in cols.items()}
+    comps["hlo_tick"], comps["hlo_simulation_time_step"] = np.zeros((n, 1)), np.full((n, 1), dt)
+    walk(system, widths, comps, 16)
+    w = orc.OracleWorld(cols["world_pos"], cols["world_vel"], cols["inertia"], simulation_time_step=dt,
+                        ops=[(orc.EFF_UNIFORM_GRAVITY, (0.0, 0.0, -9.81), None), (orc.EFF_BODY_TORQUE, (), cols["torque"])])
+    w.step(16)
+    worst = 0.0
+    for c, ref in (("world_pos", w.world_pos), ("world_vel", w.world_vel), ("world_accel", w.world_accel), ("force", w.force)):
+        got = comps["hlo_" + c]
+        halves = ((slice(0, 4), slice(4, 7)) if c == "world_pos" else (slice(0, 3), slice(3, 6)))       # scaled by the field vector's largest
+        err = max(np.max(np.abs(got[:, h] - ref[:, h]) / np.maximum(np.max(np.abs(ref[:, h]), axis=1, keepdims=True), 1e-300)) for h in halves)
+        worst = max(worst, err)                                                                           # component (tests/parity.py)
+        assert err < 1e-12, (c, err)
+    assert worst > 0.0                    # ... and it is NOT the reference's arithmetic: some last bit differs
+    assert np.all(comps["hlo_tick"] == 16)
+
+    def source(arith):
+        system, manifest = sh.world_system(text, slots, mode="lane", arith=arith)
+        dsl.Expr.fresh()
+        tp = dsl.Program([system], dsl.Pipe([]), []).trace({c["column"]: c["width"] for c in manifest["columns"]})
+        return tp, codegen.generate_source(tp, "float64", 2)
+    (tr, ref_src), (tx, rel_src) = source("reference"), source("relaxed")
+    assert not tr.fp_contract and tx.fp_contract
+    assert "fp contract(fast)" in rel_src and "fp contract(fast)" not in ref_src and "m_rcp_relaxed" not in ref_src
+    uses = lambda src: sum(src.count(f"= {f}(") for f in ("m_div", "m_rcp_relaxed", "m_rsqrt_relaxed"))      # statements of the tick body
+    assert uses(ref_src) >= 3 * uses(rel_src) > 0 and rel_src.count("= m_div(") == 0
+    # one_world=True: the Globals columns (slots 0, 1: tick, dt) are read from the first row of the wavefront's block, stored per row
+    system, manifest = sh.world_system(text, slots, mode="lane", one_world=True)
+    dsl.Expr.fresh()
+    tu = dsl.Program([system], dsl.Pipe([]), []).trace({c["column"]: c["width"] for c in manifest["columns"]})
+    uni_src = codegen.generate_source(tu, "float64", 2)
+    assert manifest["one_world"] and tu.uniform_slots == [0, 1] and tr.uniform_slots == []
+    assert uni_src.count("(row & ~uint32_t(kWave - 1))") == 2 and "~uint32_t(kWave - 1)" not in ref_src
+    assert uni_src.replace("(size_t)(row & ~uint32_t(kWave - 1))", "(size_t)row") == ref_src        # nothing else differs
+    k = [c for c, _ in tx.columns].index("hlo_world_accel")
+    assert f"* r.c{k}[" in ref_src and f"* r.c{k}[" not in rel_src
+
+
 def test_a_world_of_65536_bodies_traces_as_fast_as_a_world_of_twelve():
     """One lane per entity never materialises an [N, w] tensor: BASELINE's 65,536-body world costs what twelve bodies cost to trace,
     and generates the same program text."""

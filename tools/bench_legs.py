@@ -563,30 +563,48 @@ def world_module_leg(device):
         out["cluster_35_bodies_lane_mode_4096_worlds"] = cluster(4096)  # four (254 registers: two resident at a time hide each other's trip-opening latency)
     n = 65536
     text, slots = hb.independent_bodies_world(n)
-    system, manifest = sh.world_system(text, slots, mode="lane")
     w = workloads.independent_bodies(n)
-    cols = {"hlo_tick": np.zeros((n, 1)), "hlo_simulation_time_step": np.full((n, 1), workloads.DT_120HZ), "hlo_world_pos": w["world_pos"].copy(),
-            "hlo_world_vel": w["world_vel"].copy(), "hlo_world_accel": np.zeros((n, 6)), "hlo_force": np.zeros((n, 6)), "hlo_inertia": w["inertia"].copy(),
-            "hlo_torque": w["body_torque"].copy()}
-    ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=L.INTEGRATOR_NONE, effectors=dsl.Program([system], dsl.Pipe([]), []),
-                    columns=cols, device=device, use_graph=True)       # replayed like the headline: the program never looks at the absolute tick
-    ex.prepare(1024)
-    ex.invoke_batch(64)
-    tm = ex.invoke_batch(1024)
-    us = tm.kernel_device_ms / 1024 * 1e3
-    ex.set_ticks_per_launch(64)
-    ex.invoke_batch(64)
-    tf = ex.invoke_batch(64 * 32)
-    ex.close()
-    wtp = dsl.Program([system], dsl.Pipe([]), []).trace({c["column"]: c["width"] for c in manifest["columns"]})
-    written = {t.split("_")[0] for s_ in wtp.pre + wtp.post for t in s_.written if t[0] == "c"}
-    bytes_per = 8 * (sum(w_ for _, w_ in wtp.columns) + sum(w_ for k, (_, w_) in enumerate(wtp.columns) if f"c{k}" in written))      # every slot read; the ones the tick changes written
+
+    def module_leg(arith, one_world):
+        system, manifest = sh.world_system(text, slots, mode="lane", arith=arith, one_world=one_world)
+        cols = {"hlo_tick": np.zeros((n, 1)), "hlo_simulation_time_step": np.full((n, 1), workloads.DT_120HZ), "hlo_world_pos": w["world_pos"].copy(),
+                "hlo_world_vel": w["world_vel"].copy(), "hlo_world_accel": np.zeros((n, 6)), "hlo_force": np.zeros((n, 6)), "hlo_inertia": w["inertia"].copy(),
+                "hlo_torque": w["body_torque"].copy()}
+        ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=L.INTEGRATOR_NONE, effectors=dsl.Program([system], dsl.Pipe([]), []),
+                        columns=cols, device=device, use_graph=True)       # replayed like the headline: the program never looks at the absolute tick
+        ex.prepare(1024)
+        ex.invoke_batch(64)
+        tm = ex.invoke_batch(1024)
+        us = tm.kernel_device_ms / 1024 * 1e3
+        ex.set_ticks_per_launch(64)
+        ex.invoke_batch(64)
+        tf = ex.invoke_batch(64 * 32)
+        ex.close()
+        wtp = dsl.Program([system], dsl.Pipe([]), []).trace({c["column"]: c["width"] for c in manifest["columns"]})
+        written = {t.split("_")[0] for s_ in wtp.pre + wtp.post for t in s_.written if t[0] == "c"}
+        read = {f"c{k}" for s_ in wtp.pre + wtp.post for k in codegen_slots(s_)}
+        uni = {f"c{k}" for k in wtp.uniform_slots}
+        # slots the traced tick reads (a wave-uniform one costs a line per wavefront, counted as 1 B per row) + the ones it changes
+        bytes_per = sum(8 * w_ if f"c{k}" not in uni else 1 for k, (_, w_) in enumerate(wtp.columns) if f"c{k}" in read) \
+            + 8 * sum(w_ for k, (_, w_) in enumerate(wtp.columns) if f"c{k}" in written)
+        return {"mode": manifest["mode"], "arith": arith, "one_world": one_world, "entities": n, "us_per_tick_k1": round(us, 3),
+                "entity_steps_per_s_k1": round(n / us * 1e6, 1), "bytes_per_entity_tick": bytes_per,
+                "algorithmic_GBps": round(bytes_per * n / us / 1e3, 1), "frac_of_hbm_peak": round(bytes_per * n / us / 1e3 / HBM_PEAK_GBPS, 4),
+                "graph_launches_k1": int(tm.graph_launches), "entity_steps_per_s_k64": round(n * 64 * 32 / (tf.kernel_device_ms * 1e-3), 1)}
+
+    def codegen_slots(traced_system):      # column slots whose values the traced tick READS (leaves of its expressions)
+        names = dsl._leaves_of([e for _, e in traced_system.assign])
+        return sorted({int(n_[1:].split("_")[0]) for n_ in names if n_[0] == "c" and "_" in n_ and n_[1:].split("_")[0].isdigit()})
     out["independent_bodies_65536_lane_mode"] = {
-        "mode": manifest["mode"], "entities": n, "us_per_tick_k1": round(us, 3), "entity_steps_per_s_k1": round(n / us * 1e6, 1),
-        "bytes_per_entity_tick": bytes_per, "algorithmic_GBps": round(bytes_per * n / us / 1e3, 1), "frac_of_hbm_peak": round(bytes_per * n / us / 1e3 / HBM_PEAK_GBPS, 4),
-        "graph_launches_k1": int(tm.graph_launches),
-        "entity_steps_per_s_k64": round(n * 64 * 32 / (tf.kernel_device_ms * 1e-3), 1),
-        "what": "the whole tick is the module's (integrator NONE, the executor's Body slabs untouched); `bytes_per_entity_tick` is the analytic bound (every slot read, changed slots written); by PMC the kernel moves 460 B (force is never loaded: profiles/r06_world_module_bytes_pmc.md) against the hand-written kernel's 386 — globals (tick, dt) replicated per row, the 0 * world_accel read kept; its time is instruction issue (1,744 VALU per wave and tick, the reference's arithmetic as written)"}
+        **module_leg("reference", False),
+        "what": "the whole tick is the module's (integrator NONE, the executor's Body slabs untouched), the reference's arithmetic operation for "
+                "operation: bit for bit the oracle's.  `bytes_per_entity_tick`: the slots the traced tick reads + the ones it changes (by PMC 460 B: "
+                "profiles/r06_world_module_bytes_pmc.md); its time is instruction issue (1,744 VALU per wave and tick)"}
+    out["independent_bodies_65536_lane_mode_relaxed"] = {
+        **module_leg("relaxed", True),
+        "what": "the same module under world_system(arith='relaxed', one_world=True): finite values assumed (the 0 * world_accel read is gone), one "
+                "division per denominator, a * b + c contracted, Globals read once per wavefront — inside 1e-9 of the oracle (measured 3e-15), not its "
+                "last bits; the hand-written kernel: 384 B, 4.8 us"}
     return out
 
 
