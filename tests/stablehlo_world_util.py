@@ -10,10 +10,10 @@ from tests.golden import hlo_world_builder as hb
 BODY = (("world_pos", 7), ("world_vel", 6), ("world_accel", 6), ("force", 6), ("inertia", 7))
 
 
-def three_body(mode="world"):
+def three_body(mode="world", arith="reference"):
     """-> (system, manifest, widths, {column: one row of initial values}, golden)"""
     text, slots = hb.three_body_world()
-    system, manifest = sh.world_system(text, slots, mode=mode, name="three_body_world")
+    system, manifest = sh.world_system(text, slots, mode=mode, name="three_body_world", arith=arith)
     widths = {c["column"]: c["width"] for c in manifest["columns"]}
     g = gu.load("three_body")
     row = {"hlo_tick": np.zeros(1), "hlo_simulation_time_step": np.array([g["globals.simulation_time_step"][0, 0]])}

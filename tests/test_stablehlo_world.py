@@ -59,6 +59,22 @@ def test_three_body_world_tick_reproduces_the_reference_golden_100_ticks():
     assert np.array_equal(comps["hlo_world_pos"][0], comps["hlo_world_pos"][1])
 
 
+def test_three_body_world_tick_with_relaxed_arithmetic_stays_inside_1e_9_of_the_golden_100_ticks():
+    """The same module under world_system(arith="relaxed") on the CPU walker (shared reciprocals and folded `0 * x`; the walker does not
+    contract): G1's 100 ticks within 1e-9, vector-scaled and element-wise — and no longer bit for bit."""
+    system, manifest, widths, row, g = W.three_body("world", arith="relaxed")
+    assert manifest["arith"] == "relaxed"
+    comps = {c: np.tile(v[None, :], (2, 1)) for c, v in row.items()}
+    worst = [0.0, 0.0]
+
+    def check(r):
+        assert comps["hlo_tick"][0, 0] == r
+        e = W.three_body_errors(comps, g, r)
+        worst[0], worst[1] = max(worst[0], e[0]), max(worst[1], e[1])
+    walk(system, widths, comps, 100, check)
+    assert 0.0 < worst[0] <= 1e-9 and worst[1] <= 1e-9, worst
+
+
 def test_three_body_world_tick_one_lane_per_entity_with_the_exchange_inside_the_wavefront():
     """The same module with one lane per ENTITY (mode "auto" picks it): the edge_fold's constant-index row gathers along the entity axis
     become reads of the other lanes of the world (dsl op `lane_read` = one ds_bpermute per 32-bit half), the per-source stack of

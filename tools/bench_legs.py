@@ -471,7 +471,14 @@ def world_module_leg(device):
         ex.invoke_batch(100)
         tm = ex.invoke_batch(1000)
         ex.close()
+        rsys, _ = sh.world_system(text, slots, mode="world", arith="relaxed")      # opt-in: finite values, shared reciprocals, contraction (<= 1e-9 of G1, not its bits)
+        ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=L.INTEGRATOR_NONE, effectors=dsl.Program([rsys], dsl.Pipe([]), []),
+                        columns={k: v.copy() for k, v in cols.items()}, ticks_per_launch=100, device=device)
+        ex.invoke_batch(100)
+        tr = ex.invoke_batch(1000)
+        ex.close()
         out[f"three_body_worlds_{worlds}"] = {"mode": manifest["mode"], "worlds": worlds, "ticks": 1000, "us_per_tick": round(tm.kernel_device_ms, 3),
+                                             "us_per_tick_relaxed_arithmetic": round(tr.kernel_device_ms, 3),
                                              "world_steps_per_s": round(worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
                                              "body_steps_per_s": round(3 * worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
                                              "roofline": valu_roofline("three_body_world_mode", worlds, 1000, tm.kernel_device_ms * 1e-3, WORLD_VALU_FILE)}
@@ -495,8 +502,14 @@ def world_module_leg(device):
         ex.invoke_batch(100)
         tm = ex.invoke_batch(1000)
         ex.close()
+        rsys, _ = sh.world_system(text, slots, mode="auto", arith="relaxed")
+        ex = ea.HipExec(w["world_pos"], w["world_vel"], w["inertia"], integrator=L.INTEGRATOR_NONE, effectors=dsl.Program([rsys], dsl.Pipe([]), []),
+                        columns={k: v.copy() for k, v in cols.items()}, ticks_per_launch=100, device=device)
+        ex.invoke_batch(100)
+        tr = ex.invoke_batch(1000)
+        ex.close()
         out[f"three_body_worlds_{worlds}_lane_mode"] = {"mode": lman["mode"], "rows_per_world": S, "worlds": worlds, "rows": rows, "ticks": 1000,
-                                                       "us_per_tick": round(tm.kernel_device_ms, 3),
+                                                       "us_per_tick": round(tm.kernel_device_ms, 3), "us_per_tick_relaxed_arithmetic": round(tr.kernel_device_ms, 3),
                                                        "world_steps_per_s": round(worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
                                                        "body_steps_per_s": round(3 * worlds * 1000 / (tm.kernel_device_ms * 1e-3), 1),
                                                        "roofline": valu_roofline("three_body_lane_mode", rows, 1000, tm.kernel_device_ms * 1e-3, WORLD_VALU_FILE)}
