@@ -879,7 +879,23 @@ class _Eval:
         return text[:cut]
 
     def _binary(self, short, a: Sym):
-        """The element function of a binary op on tensors of `a`'s type, integer results wrapped to the type's width."""
+        """The element function of a binary op on tensors of `a`'s type, integer results wrapped to the type's width.
+        INTEGER tensors are carried as integral floats and their semantics (truncating division, remainders, wrap-around, shifts)
+        are spelled with float divisions that must be EXACT: relaxed arithmetic (dsl.relaxed_arithmetic: a / b as a * (1 / b),
+        49 * (1 / 49) = 0.9999999999999999) is suspended inside them."""
+        f = self._binary_any(short, a)
+        if not (a.is_int() or a.is_bool()):
+            return f
+
+        def exact(x, y):
+            saved, _dsl._RELAXED[0] = _dsl._RELAXED[0], False
+            try:
+                return f(x, y)
+            finally:
+                _dsl._RELAXED[0] = saved
+        return exact
+
+    def _binary_any(self, short, a: Sym):
         if a.dtype == "ui64":
             return _u64_binary(short)
         f = self._binary_raw(short, a)

@@ -338,3 +338,41 @@ module @module {{
     assert np.array_equal(run(module("UNIFORM", 5), -2.0, 6.0), [-2.0 + (i / 4.0) * 8.0 for i in range(5)])
     assert np.array_equal(run(module("UNIFORM", 1), 3.0, 5.0), [4.0])
     assert np.array_equal(run(module("NORMAL", 4), 0.0, 2.0), [0.0 + ((i + 0.5) / 4.0) * 2.0 for i in range(4)])
+
+
+def test_relaxed_arithmetic_keeps_integer_semantics_exact_and_the_known_answers_inside_tolerance():
+    """dsl.relaxed_arithmetic (world_system(arith="relaxed")) turns a / b into a * (1 / b) — 49 * (1 / 49) = 0.9999999999999999, whose
+    truncation is 0.  Integer tensors are integral floats whose division, remainder, wrap-around and shifts are spelled with float
+    divisions: the evaluator suspends the relaxation inside every integer op (stablehlo._Eval._binary).  (a) i64 quotients and
+    remainders of pairs that the reciprocal form gets wrong stay exact; (b) every known answer of the reference's op tests and world
+    fragments holds under relaxed arithmetic too — integer results exactly, floats to 1e-9."""
+    pairs = [(a * b, b) for a in (1, 2, 3, 7, 100) for b in (49, 98, 103, 107, 161, 187, 196, 197, 206, 214)]
+    assert any(np.trunc(x * (1.0 / y)) != x // y for x, y in pairs)                       # the hazard is real
+    n = len(pairs)
+    text = f"""
+module @m {{
+  func.func public @main(%arg0: tensor<{n}xi64>, %arg1: tensor<{n}xi64>, %arg2: tensor<{n}xf64>, %arg3: tensor<{n}xf64>) -> (tensor<{n}xi64>, tensor<{n}xi64>, tensor<{n}xf64>) {{
+    %0 = stablehlo.divide %arg0, %arg1 : tensor<{n}xi64>
+    %1 = stablehlo.remainder %arg0, %arg1 : tensor<{n}xi64>
+    %2 = stablehlo.divide %arg2, %arg3 : tensor<{n}xf64>
+    return %0, %1, %2 : tensor<{n}xi64>, tensor<{n}xi64>, tensor<{n}xf64>
+  }}
+}}"""
+    system = sh.system(text, ["x", "y", "fx", "fy"], ["q", "r", "fq"])
+    xs, ys = np.array([p[0] for p in pairs], dtype=np.float64), np.array([p[1] for p in pairs], dtype=np.float64)
+    values = {"x": xs, "y": ys, "fx": xs, "fy": ys}
+    expect = {"q": (n, {}), "r": (n, {}), "fq": (n, {})}
+    with dsl.relaxed_arithmetic():
+        comps = walk(system, values, expect)
+    assert np.array_equal(comps["q"][0], xs // ys) and np.array_equal(comps["r"][0], np.zeros(n))
+    assert np.max(np.abs(comps["fq"][0] - xs / ys) / (xs / ys)) < 4e-16 and not np.array_equal(comps["fq"][0], xs / ys)      # floats ARE relaxed
+    for group, cases in (("ops", U.CASES), ("world", U.WORLD_CASES)):
+        for case in cases:
+            if case["name"] in U.UNSUPPORTED or case["name"] in U.BEYOND_F64_INTEGERS:
+                continue
+            system, values, expect = U.build(case)
+            with dsl.relaxed_arithmetic():
+                comps = walk(system, values, expect)
+            for nm, (w, exp) in expect.items():
+                integer = group == "world" and case["expected"].get(nm[len("out"):], {"type": "f64"})["type"] != "f64"
+                U.check(case["name"], comps[nm][0], w, exp, 0.0 if integer else 1e-9)
