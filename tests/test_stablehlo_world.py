@@ -683,3 +683,44 @@ def test_the_cli_builds_a_fold_stage_world_without_a_gpu(tmp_path):
         assert len(scratch) == 16 and "hlo_fold2_nbr" in scratch and "hlo_fold3_out#fold3" in scratch
         assert prog._traced.exact_rows == 3 * nb and [n_ for n_, _ in prog._traced.columns] == [c["column"] for c in manifest["columns"]]
         assert manifest["build"]["resources"]["vgpr_spills"] == 0
+
+
+def test_k9_rk4_pipeline_shape_singleton_slots_are_ingested_as_the_reference_declares_them():
+    """K9 (libs/nox-py/src/integrator/rk4.rs:175-227 `rk4_pipeline_shape`): a one-entity world integrated with `rk4::<X, V>` compiles
+    to a function whose inputs are {X, V, SimulationTimeStep}, whose outputs hold X, and whose X / V slots are ZERO-DIM with
+    `entity_axis_elided` (a scalar component on a singleton column: the batch axis is elided, system.rs:12-23).  That metadata is
+    what a WorldExec::Hip hands this front end (exec.rs:17-29): the same document — ids, names, arity = number of inputs — is read
+    back as three scalar, elided slots, and the RK4 tick of x' = v, v' = 0 over it moves x = 0, v = 10 by dt * v exactly."""
+    x_id, v_id, dt_id = 101, 102, 103
+    meta = {"arg_ids": [x_id, v_id, dt_id], "ret_ids": [x_id], "names": {str(x_id): "x", str(v_id): "v", str(dt_id): "simulation_time_step"},
+            "arg_slots": [{"component_id": x_id, "shape": [], "entity_axis_elided": True}, {"component_id": v_id, "shape": [], "entity_axis_elided": True},
+                          {"component_id": dt_id, "shape": [], "entity_axis_elided": True}]}
+    ins, outs = sh.slots_from_metadata(meta)
+    assert [s_.component for s_ in ins] == ["x", "v", "simulation_time_step"] and [s_.component for s_ in outs] == ["x"]
+    assert all(tuple(s_.shape) == () and s_.elided for s_ in ins + outs)
+    # the arithmetic Rk4::compile emits for U = {x}, DU = {v} with no force system: four stages that all see v, then x + dt/6 (v + 2v + 2v + v)
+    text = """
+module @module {
+  func.func public @main(%arg0: tensor<f64>, %arg1: tensor<f64>, %arg2: tensor<f64>) -> tensor<f64> {
+    %two = stablehlo.constant dense<2.0> : tensor<f64>
+    %sixth = stablehlo.constant dense<0.16666666666666666> : tensor<f64>
+    %k2 = stablehlo.multiply %two, %arg1 : tensor<f64>
+    %s0 = stablehlo.add %arg1, %k2 : tensor<f64>
+    %s1 = stablehlo.add %s0, %k2 : tensor<f64>
+    %s2 = stablehlo.add %s1, %arg1 : tensor<f64>
+    %g = stablehlo.multiply %arg2, %sixth : tensor<f64>
+    %dx = stablehlo.multiply %g, %s2 : tensor<f64>
+    %x1 = stablehlo.add %arg0, %dx : tensor<f64>
+    return %x1 : tensor<f64>
+  }
+}"""
+    funcs = sh.parse_module(text)
+    assert len(funcs["main"].args) == len(meta["arg_ids"])                       # arity = number of declared inputs (K9's last assertion)
+    system, manifest = sh.world_system(text, ins, outs, mode="auto")
+    widths = {c["column"]: c["width"] for c in manifest["columns"]}
+    assert widths == {"hlo_x": 1, "hlo_v": 1, "hlo_simulation_time_step": 1}
+    assert all(c["entity_axis_elided"] and c["shape"] == [] for c in manifest["columns"])
+    dt = orc.quantize_time_step(120.0)
+    comps = {"hlo_x": np.zeros((1, 1)), "hlo_v": np.full((1, 1), 10.0), "hlo_simulation_time_step": np.full((1, 1), dt)}
+    walk(system, widths, comps, 1)
+    assert comps["hlo_x"][0, 0] == 0.0 + (dt * (1.0 / 6.0)) * (10.0 + 20.0 + 20.0 + 10.0) and comps["hlo_v"][0, 0] == 10.0
