@@ -930,3 +930,48 @@ def test_window_component_through_world_build():
         c = c * 0.5 + logical[:, r]
     assert np.allclose(exec.column_array("sample_buffer"), logical.reshape(3, -1), rtol=1e-12, atol=1e-15)
     assert np.allclose(exec.column_array("sample_filtered"), c, rtol=1e-12)
+
+
+def test_query_rs_join_cases_by_name():
+    """The join cases libs/nox-py/src/query.rs tests by name (1046-1150), as WORLD behaviour through the HIP backend:
+    `cross_archetype_join_shape_intersects_entity_maps` (X on entities {1, 2, 3}, E on {2}: only the entity carrying both is touched),
+    `mixed_batch1_join_*_recovers_local_singleton` (a one-entity component joined with a batched one: that one entity),
+    `singleton_updates_rebatch_into_broader_world_buffer` (the update of one entity lands in the 3-row column, the other rows keep
+    their bits), `filtering_singleton_from_batched_query` (the rows a join leaves out are never written), and
+    `batch1_mismatched_joins_stay_structurally_valid` (components on DISJOINT entity sets: an empty join — nothing runs, nothing
+    breaks, every value keeps its bits)."""
+    @el.map
+    def add_effect(x: X, e: Effect) -> X:
+        return x + e
+
+    @el.system
+    def scale_all(q: el.Query[X]) -> el.Query[X]:
+        return q.map(X, lambda x: x * 2.0)
+
+    w = el.World()
+    w.spawn(el.C((X,), (np.array(1.0),)), "e1")
+    w.spawn(el.C((X, Effect), (np.array(10.0), np.array(0.5))), "e2")
+    w.spawn(el.C((X,), (np.array(100.0),)), "e3")
+    exec = w.build(add_effect)
+    exec.run(3)
+    df = exec.history(["e1.x", "e2.x", "e3.x", "e2.e"])
+    assert np.array_equal(df["e1.x"], [1.0] * 4) and np.array_equal(df["e3.x"], [100.0] * 4)          # untouched, bit for bit
+    assert np.array_equal(df["e2.x"], [10.0, 10.5, 11.0, 11.5]) and np.array_equal(df["e2.e"], [0.5] * 4)
+
+    w = el.World()                                                                                       # the join behind a batched system
+    w.spawn(el.C((X,), (np.array(1.0),)), "e1")
+    w.spawn(el.C((X, Effect), (np.array(10.0), np.array(0.5))), "e2")
+    w.spawn(el.C((X,), (np.array(100.0),)), "e3")
+    exec = w.build(scale_all | add_effect)
+    exec.run(2)
+    df = exec.history(["e1.x", "e2.x", "e3.x"])
+    assert np.array_equal(df["e1.x"], [1.0, 2.0, 4.0]) and np.array_equal(df["e3.x"], [100.0, 200.0, 400.0])
+    assert np.array_equal(df["e2.x"], [10.0, 20.5, 41.5])
+
+    w = el.World()                                                                                       # disjoint entity sets: an empty join
+    w.spawn(el.C((X,), (np.array(1.0),)), "e1")
+    w.spawn(el.C((Effect,), (np.array(0.5),)), "e2")
+    exec = w.build(scale_all | add_effect)
+    exec.run(2)
+    df = exec.history(["e1.x", "e2.e"])
+    assert np.array_equal(df["e1.x"], [1.0, 2.0, 4.0]) and np.array_equal(df["e2.e"], [0.5] * 3)
