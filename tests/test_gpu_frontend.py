@@ -975,3 +975,37 @@ def test_query_rs_join_cases_by_name():
     exec.run(2)
     df = exec.history(["e1.x", "e2.e"])
     assert np.array_equal(df["e1.x"], [1.0, 2.0, 4.0]) and np.array_equal(df["e2.e"], [0.5] * 3)
+
+
+def test_graph_rs_single_edge_groups_by_name():
+    """libs/nox-py/src/graph.rs:529-566 as world behaviour: `singleton_edge_groups_recover_local_singletons` — a graph of ONE edge
+    (one source, out-degree 1: the reference's group is a local singleton) — and `multi_source_single_edge_groups_rebatch_on_append`
+    — two sources with one edge each (a [2, 1, 3] gather in the reference).  fold = init + (from + to) per edge; the result replaces
+    the SOURCE rows only, entities without an out-edge keep their bits."""
+    @dataclass
+    class EdgeArchetype(el.Archetype):
+        edge: E
+
+    @el.system
+    def fold_test(graph: el.GraphQuery[E], x: el.Query[X]) -> el.Query[X]:
+        return graph.edge_fold(x, x, X, np.array(5.0), lambda acc, a, b: acc + a + b)
+
+    w = el.World()
+    a = w.spawn(OnlyX(np.array([1.0])), "e1")
+    b = w.spawn(OnlyX(np.array([2.0])), "e2")
+    w.spawn(OnlyX(np.array([7.0])), "e3")
+    w.spawn(EdgeArchetype(el.Edge(a, b)))
+    exec = w.build(fold_test)
+    exec.run(2)
+    frame_equal(exec.history(["e1.x", "e2.x", "e3.x"]), {"e1.x": [1.0, 8.0, 15.0], "e2.x": [2.0, 2.0, 2.0], "e3.x": [7.0, 7.0, 7.0]})
+
+    w = el.World()
+    a = w.spawn(OnlyX(np.array([1.0])), "e1")
+    b = w.spawn(OnlyX(np.array([2.0])), "e2")
+    w.spawn(OnlyX(np.array([7.0])), "e3")
+    w.spawn(EdgeArchetype(el.Edge(a, b)))
+    w.spawn(EdgeArchetype(el.Edge(b, a)))
+    exec = w.build(fold_test)
+    exec.run(2)
+    # every fold of a tick sees the values from before the tick: 5 + 1 + 2 on both sources, then 5 + 8 + 8
+    frame_equal(exec.history(["e1.x", "e2.x", "e3.x"]), {"e1.x": [1.0, 8.0, 21.0], "e2.x": [2.0, 8.0, 21.0], "e3.x": [7.0, 7.0, 7.0]})
