@@ -426,8 +426,6 @@ def _bin(op: str, a, b) -> Expr:
     if _RELAXED[0]:
         if op == "mul" and (a.is_const(0.0) or b.is_const(0.0)):
             return const(0.0)
-        if op == "div" and a.is_const(0.0):
-            return const(0.0)
         if op == "div" and a.op != "const":
             if b.op == "const" and b.value not in (0.0,) and b.value == b.value and abs(b.value) != float("inf"):
                 return _bin("mul", a, const(1.0 / b.value))
