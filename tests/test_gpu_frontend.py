@@ -1009,3 +1009,27 @@ def test_graph_rs_single_edge_groups_by_name():
     exec.run(2)
     # every fold of a tick sees the values from before the tick: 5 + 1 + 2 on both sources, then 5 + 8 + 8
     frame_equal(exec.history(["e1.x", "e2.x", "e3.x"]), {"e1.x": [1.0, 8.0, 21.0], "e2.x": [2.0, 8.0, 21.0], "e3.x": [7.0, 7.0, 7.0]})
+
+
+def test_external_control_waiting():  # test_all.py:381-418
+    """Exec.run with an external-control component (metadata {"external_control": "true"}) nobody writes: the ticks run, the system
+    sees the spawned value."""
+    ExternalControl = ty.Annotated[el.Array, el.Component("external_control", el.ComponentType.F64, metadata={"external_control": "true"})]
+
+    @el.map
+    def use_external_control(x: X, ext: ExternalControl) -> X:
+        return x + ext
+
+    @dataclass
+    class TestWithExternal(el.Archetype):
+        __test__ = False
+        x: X
+        external_control: ExternalControl
+
+    w = el.World()
+    w.spawn(TestWithExternal(np.array(1.0), np.array(0.0)), "e1")
+    exec = w.build(use_external_control)
+    exec.run(3)
+    df = exec.history("e1.x")
+    assert len(df["e1.x"]) >= 3
+    assert np.isclose(df["e1.x"][-1], 1.0)
