@@ -2640,7 +2640,8 @@ class _FoldEval(_LaneEval):
         return results
 
 
-def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = None, name: str = "world_tick", wave_folds: bool = True):
+def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = None, name: str = "world_tick", wave_folds: bool = True,
+                  arith: str = "reference"):
     """A whole-world tick whose entities exchange data across MORE than a wavefront (an edge_fold over a world of more than 64
     entities) as a PROGRAM: per-entity systems with the tick's scans over the edge slot between them as fold stages.
     -> (dsl.Program, manifest, graph_edges)
@@ -2651,7 +2652,11 @@ def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = No
     system 0 | fold 0 | system 1 | ... | fold K-1 | system K: system k recomputes from the world's columns and the earlier folds'
     outputs what fold k needs and stores it; the last one computes the tick's results.  `graph_edges` = {edge component of fold
     k: (source rows, target rows)} in slot order — rows of ONE world; hand them to the executor as entity ids of its rows
-    (HipExec graph_edges=, with graph_replicas=(worlds, N) for a Monte-Carlo of such worlds)."""
+    (HipExec graph_edges=, with graph_replicas=(worlds, N) for a Monte-Carlo of such worlds).
+    arith="relaxed": the systems AND the fold bodies are traced under dsl.relaxed_arithmetic (world_system's switch: finite values
+    assumed, one reciprocal per denominator, a * b + c contracted) — inside 1e-9 of the reference, not its last bits."""
+    if arith not in ("reference", "relaxed"):
+        raise ValueError("arith must be 'reference' or 'relaxed'")
     funcs = parse_module(text)
     main = funcs["main"]
     ins = [Slot.of(x) for x in slots]
@@ -2687,7 +2692,12 @@ def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = No
             args.append(Sym(arr, ty.dtype, None if s_.elided else 0, (), ty.shape))
         ev = _FoldEval(funcs, n_entities, fold_out_leaves)
         res = {}
-        for s_, o in zip(outs, ev.call(main, args)):
+        if arith == "relaxed":
+            with _dsl.relaxed_arithmetic():
+                results = ev.call(main, args)
+        else:
+            results = ev.call(main, args)
+        for s_, o in zip(outs, results):
             if isinstance(o, _Nbr):
                 raise NotEntityParallel(f"result {s_.component} is a stack of other entities' rows")
             o = ev._mat(o, [d for d in o.uni if d != 0] if not s_.elided else None)
@@ -2768,6 +2778,7 @@ def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = No
         system_ = _dsl.system(fn, **{c: widths[c] for c in all_cols})
         system_.float32_refused = ["a whole-world tick with fold stages is a float64 program (its fold kernels gather doubles)"]
         system_.body_free = True          # every slot of the world is a column of the program: no link of the chain touches a Body column
+        system_.fp_contract = arith == "relaxed"
         return system_
     pre = []
     for k in range(n_folds):
@@ -2775,6 +2786,7 @@ def world_program(text: str, slots: Sequence, out_slots: Optional[Sequence] = No
     pre.append(make_system(n_folds))
     prog = _dsl.Program(pre, _dsl.Pipe([]), [])
     manifest = {"mode": "folds", "rows": "entities", "entities_per_world": n_entities, "rows_per_world": n_entities, "fold_stages": n_folds,
+                **({"arith": "relaxed"} if arith == "relaxed" else {}),
                 "edges_per_fold": [sum(len(t_) for t_ in r.table) for r in probe.requests],
                 "columns": [{"column": c, "width": widths[c],
                              "component": next((s_.component for s_ in ins + outs if s_.column == c), None),
@@ -3038,16 +3050,16 @@ def compile_world(text: str, slots_doc: dict, out: Optional[str] = None, mode: s
             if mode != "auto":
                 raise
             try:
-                built = world_program(text, ins, outs, wave_folds=wave_folds)
+                built = world_program(text, ins, outs, wave_folds=wave_folds, arith=arith)
             except NotEntityParallel:
                 raise refused from None
             folds = True
     if folds:
         if dtype != "float64":
             raise NotImplementedError("whole-world ticks with fold stages are float64 (the fold kernels gather doubles)")
-        if arith != "reference" or one_world:
-            raise NotImplementedError("arith='relaxed' / one_world apply to one-kernel ticks (modes lane, world), not to fold stages")
-        prog, manifest, edges = built if mode == "auto" else world_program(text, ins, outs, wave_folds=wave_folds)
+        if one_world:
+            raise NotImplementedError("one_world applies to one-kernel ticks (mode lane), not to fold stages")
+        prog, manifest, edges = built if mode == "auto" else world_program(text, ins, outs, wave_folds=wave_folds, arith=arith)
         manifest["folds"] = "a wave per source (lane partials + shuffle tree) for additive scans of 64 edges or more" if wave_folds else "sequential, one lane per source"
         n_world = int(manifest["entities_per_world"])
         rows = int(slots_doc.get("rows", 0)) or n_world

@@ -254,3 +254,33 @@ def test_a_monte_carlo_of_large_worlds_shards_by_world_over_two_ranks():
         blk = got[w_ * nb:(w_ + 1) * nb]
         assert np.max(np.abs(blk[:, 4:7] - ref.world_pos[:, 4:7]) / np.maximum(np.max(np.abs(ref.world_pos[:, 4:7]), axis=1, keepdims=True), 1e-300)) <= 1e-12, w_
         assert np.max(np.abs(blk[:, 10:13] - ref.world_vel[:, 3:6]) / np.maximum(np.max(np.abs(ref.world_vel[:, 3:6]), axis=1, keepdims=True), 1e-300)) <= 1e-12, w_
+
+
+def test_a_fold_stage_world_with_relaxed_arithmetic_stays_inside_1e_9():
+    """world_program(arith="relaxed"): systems AND fold bodies traced under dsl.relaxed_arithmetic (the pair term's 1 / sqrt(r.r + eps)
+    becomes v_rsq_f64 + a cubic correction, quaternion quotients share their reciprocals, a * b + c contracts) — a 256-body world,
+    6 ticks against the CPU oracle's sequential fold: inside 1e-9 (it measures ~1e-14), tick exact, and not the default build's bits."""
+    nb, ticks = 256, 6
+    text, slots = hb.nbody_world(nb, K_SQ, EPS)
+    pos, vel, inertia = _world(nb)
+    ids = np.arange(1, nb + 1, dtype=np.uint64)
+    ref = orc.OracleWorld(pos, vel, inertia, simulation_time_step=0.5, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, (K_SQ, EPS), None)]).step(ticks)
+    got = {}
+    for arith in ("reference", "relaxed"):
+        prog, manifest, edges = sh.world_program(text, slots, arith=arith)
+        assert manifest.get("arith", "reference") == arith and manifest["fold_stages"] == 4
+        cols = _columns(manifest, nb, pos, vel, inertia, 0.5)
+        hip = ea.HipExec(np.tile([0, 0, 0, 1.0, 0, 0, 0], (nb, 1)), np.zeros((nb, 6)), np.ones((nb, 7)), entity_ids=ids, integrator=L.INTEGRATOR_NONE,
+                         effectors=prog, columns=cols, graph_edges=sh.edges_as_entity_ids(edges, ids))
+        hip.run(ticks)
+        t = hip.invoke_batch(50)
+        hip.download()
+        got[arith] = ({k: np.array(v) for k, v in hip._aux.items()}, _errors(hip._aux, orc.OracleWorld(pos, vel, inertia, simulation_time_step=0.5, ops=[(orc.EFF_ALLPAIRS_GRAVITY_SOFTENED, (K_SQ, EPS), None)]).step(ticks + 50)),
+                      t.kernel_device_ms / 50 * 1e3)
+        assert np.all(hip._aux["hlo_tick"] == ticks + 50)
+        hip.close()
+    print(f"256-body fold-stage world, {ticks + 50} ticks vs the oracle: default {got['reference'][1]:.2e} ({got['reference'][2]:.1f} us per tick), "
+          f"relaxed {got['relaxed'][1]:.2e} ({got['relaxed'][2]:.1f} us per tick)")
+    assert got["reference"][1] <= 1e-11 and 0.0 < got["relaxed"][1] <= 1e-9
+    assert not np.array_equal(got["reference"][0]["hlo_world_pos"], got["relaxed"][0]["hlo_world_pos"])
+    del ref

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A whole-world n-body tick of N bodies (default 2,048: a 232 MB module, 4.2 M edges per scan) as the reference would dump it, through
 stablehlo.world_program (the scans over the edge slot as fold stages over the implicit complete graph), a few ticks on the GPU against
-the CPU oracle's sequential softened fold.   python tools/fold_world_big.py [N] [ticks]      (needs a GPU; minutes of host time)"""
+the CPU oracle's sequential softened fold.   python tools/fold_world_big.py [N] [ticks] [wave|sequential] [reference|relaxed]      (needs a GPU; minutes of host time)"""
 import json
 import resource
 import sys
@@ -20,14 +20,15 @@ from tests.golden import hlo_world_builder as hb
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 wave = (sys.argv[3] if len(sys.argv) > 3 else "wave") != "sequential"      # a wave per source (default) or the one-lane sequential fold
+arith = sys.argv[4] if len(sys.argv) > 4 else "reference"      # world_program(arith=): the reference's arithmetic or dsl.relaxed_arithmetic
 K, EPS, DT = 2.9591220828e-4, 1e-6, 0.5
-out = {"bodies": nb, "ticks": ticks, "fold": "a wave per source" if wave else "sequential, one lane per source"}
+out = {"bodies": nb, "ticks": ticks, "fold": "a wave per source" if wave else "sequential, one lane per source", "arith": arith}
 t0 = time.perf_counter()
 text, slots = hb.nbody_world(nb, K, EPS)
 out["module_text_MB"] = round(len(text) / 1e6, 1)
 out["module_seconds"] = round(time.perf_counter() - t0, 1)
 t0 = time.perf_counter()
-prog, manifest, edges = sh.world_program(text, slots, wave_folds=wave)
+prog, manifest, edges = sh.world_program(text, slots, wave_folds=wave, arith=arith)
 del text
 out["world_program_seconds"] = round(time.perf_counter() - t0, 1)
 out["fold_stages"], out["edges_per_fold"], out["edges"] = manifest["fold_stages"], manifest["edges_per_fold"], [e[0] if isinstance(e[0], str) else "explicit" for e in edges.values()]
