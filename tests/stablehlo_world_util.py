@@ -47,10 +47,10 @@ def independent_bodies(n, seed=5):
     return text, slots, cols
 
 
-def ball(mode="auto"):
+def ball(mode="auto", arith="reference"):
     """examples/ball's singleton world as a whole-world module -> (system, manifest, widths, {column: initial row}, golden)"""
     text, slots = hb.ball_world()
-    system, manifest = sh.world_system(text, slots, mode=mode, name="ball_world")
+    system, manifest = sh.world_system(text, slots, mode=mode, name="ball_world", arith=arith)
     widths = {c["column"]: c["width"] for c in manifest["columns"]}
     g = gu.load("ball")
     row = {"hlo_tick": np.zeros(1), "hlo_seed": np.array([float(g["ball.seed"][0, 0])]), "hlo_wind": g["ball.wind"][0].copy(),

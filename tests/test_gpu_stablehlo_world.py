@@ -148,11 +148,14 @@ def test_the_build_time_cli_object_is_installed_as_it_is(tmp_path):
     hip.close()
 
 
-def test_ball_whole_world_module_with_jax_random_reproduces_g2_on_the_gpu():
+@pytest.mark.parametrize("arith", ["reference", "relaxed"])
+def test_ball_whole_world_module_with_jax_random_reproduces_g2_on_the_gpu(arith):
     """examples/ball's singleton world as the reference would dump it, jax.random's threefry in u32 arithmetic included (sample_wind runs
-    every tick): 100 ticks of G2 — wind, position, velocity, acceleration, force — through the generated kernel, <= 1e-9."""
-    system, manifest, widths, row, g = W.ball("auto")
-    assert manifest["mode"] == "world"
+    every tick): 100 ticks of G2 — wind, position, velocity, acceleration, force — through the generated kernel, <= 1e-9.  With
+    arith="relaxed" too: the integer pipeline of the draw stays exact inside a relaxed trace (the wind is the same draw), the
+    float state keeps the bound."""
+    system, manifest, widths, row, g = W.ball("auto", arith=arith)
+    assert manifest["mode"] == "world" and manifest.get("arith", "reference") == arith
     n = 70
     hip = _exec(dsl.Program([system], dsl.Pipe([]), []), {c: np.tile(v[None, :], (n, 1)) for c, v in row.items()}, n)
     worst = 0.0
@@ -160,7 +163,7 @@ def test_ball_whole_world_module_with_jax_random_reproduces_g2_on_the_gpu():
         hip.run(1)
         worst = max(worst, W.ball_errors(hip._aux, g, r))
         assert hip._aux["hlo_tick"][0, 0] == r
-    print(f"ball whole-world module (jax.random in the tick), 100 ticks vs G2: {worst:.2e}")
+    print(f"ball whole-world module (jax.random in the tick, arith = {arith}), 100 ticks vs G2: {worst:.2e}")
     assert worst <= 1e-9
     assert np.array_equal(hip._aux["hlo_world_pos"], np.repeat(hip._aux["hlo_world_pos"][:1], n, axis=0))
     hip.close()

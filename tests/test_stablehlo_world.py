@@ -486,6 +486,25 @@ def test_ball_world_tick_with_jax_random_reproduces_the_reference_golden_100_tic
     assert np.allclose(comps["hlo_wind"][0], [-0.2058421394796434, -0.7847657764467411, 1.8160866726679836], rtol=1e-13)   # test_uniform_pipeline.rs:152-156
 
 
+def test_ball_world_tick_with_relaxed_arithmetic_keeps_jax_random_exact():
+    """The ball module under arith="relaxed": the tick draws its wind with threefry2x32 in u32 arithmetic, 64 random bits -> mantissa ->
+    bitcast -> erf_inv — integer work spelled with float divisions, which the evaluator keeps EXACT inside a relaxed trace
+    (stablehlo._Eval._binary): the seed and the tick stay exact and the wind lands on the reference's own known answer
+    (test_uniform_pipeline.rs:152-156); the float state follows G2's 100 ticks within 1e-9 instead of 1e-12."""
+    system, manifest, widths, row, g = W.ball("auto", arith="relaxed")
+    assert manifest["mode"] == "world" and manifest["arith"] == "relaxed"
+    comps = {c: np.tile(v[None, :], (2, 1)) for c, v in row.items()}
+    worst = [0.0]
+
+    def check(r):
+        assert comps["hlo_tick"][0, 0] == r == int(g["globals.tick"][r, 0]) and comps["hlo_seed"][0, 0] == g["ball.seed"][r, 0]
+        worst[0] = max(worst[0], W.ball_errors(comps, g, r))
+    walk(system, widths, comps, 100, check)
+    print("ball whole-world module, relaxed arithmetic, vs G2, 100 ticks:", worst[0])
+    assert worst[0] < 1e-9
+    assert np.allclose(comps["hlo_wind"][0], [-0.2058421394796434, -0.7847657764467411, 1.8160866726679836], rtol=1e-13)
+
+
 @pytest.mark.parametrize("rolled_loops", [False, True], indirect=True, ids=["unrolled", "rolled"])
 @pytest.mark.parametrize("seed,n", [(s_, 3 + s_ % 3) for s_ in range(100, 116)])
 def test_random_modules_with_reads_between_entities_lane_exchange_equals_world_mode(seed, n, rolled_loops):
