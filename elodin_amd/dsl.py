@@ -2251,7 +2251,13 @@ class TracedProgram:
         self.body_free = (bool(self.pre + self.post) and not self.fold_stages and not prog.effectors.effectors
                           and all(getattr(s, "body_free", False) for s in self.pre + self.post))
         self.float32_refused = [r for s in self.pre + self.post for r in getattr(s, "float32_refused", ())]
-        self.fp_contract = any(getattr(s, "fp_contract", False) for s in self.pre + self.post)
+        # relaxed arithmetic is a property of the whole object (one contraction pragma, one reciprocal flavour): a program either
+        # holds only systems traced under relaxed_arithmetic or none (fold stages follow their systems)
+        relaxed_ = [bool(getattr(s, "fp_contract", False)) for s in self.pre + self.post if not isinstance(s, TracedFoldStage)]
+        if any(relaxed_) and not all(relaxed_):
+            raise ValueError("a program mixes systems traced under relaxed arithmetic with reference-arithmetic systems: build them as separate "
+                             "programs, or trace all of them the same way")
+        self.fp_contract = any(relaxed_)
         self.writes_inertia = any(s.writes_inertia for s in self.pre + self.post)
         # maps / folds that stood among the force effectors inside six_dof(sys=...) run in front of the force evaluation
         # (frontend.six_dof).  That is the reference's order unless an effector reads what a system BEHIND it in the pipe writes

@@ -292,6 +292,14 @@ def test_relaxed_arithmetic_of_a_world_module_stays_inside_1e_9_and_sheds_the_re
     assert manifest["one_world"] and tu.uniform_slots == [0, 1] and tr.uniform_slots == []
     assert uni_src.count("(row & ~uint32_t(kWave - 1))") == 2 and "~uint32_t(kWave - 1)" not in ref_src
     assert uni_src.replace("(size_t)(row & ~uint32_t(kWave - 1))", "(size_t)row") == ref_src        # nothing else differs
+    # relaxed arithmetic is a property of the whole object: a program cannot mix a relaxed system with a reference one
+    relaxed_sys, m_ = sh.world_system(text, slots, mode="lane", arith="relaxed")
+
+    @dsl.system(extra=1)
+    def other(extra):
+        return {"extra": extra / 3.0}
+    with pytest.raises(ValueError, match="mixes systems traced under relaxed arithmetic"):
+        dsl.Program([relaxed_sys, other], dsl.Pipe([]), []).trace({**{c["column"]: c["width"] for c in m_["columns"]}, "extra": 1})
     k = [c for c, _ in tx.columns].index("hlo_world_accel")
     assert f"* r.c{k}[" in ref_src and f"* r.c{k}[" not in rel_src
 
