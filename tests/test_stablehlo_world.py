@@ -751,3 +751,34 @@ module @module {
     comps = {"hlo_x": np.zeros((1, 1)), "hlo_v": np.full((1, 1), 10.0), "hlo_simulation_time_step": np.full((1, 1), dt)}
     walk(system, widths, comps, 1)
     assert comps["hlo_x"][0, 0] == 0.0 + (dt * (1.0 / 6.0)) * (10.0 + 20.0 + 20.0 + 10.0) and comps["hlo_v"][0, 0] == 10.0
+
+
+def test_the_cli_builds_the_relaxed_one_world_object_without_a_gpu(tmp_path):
+    """`python -m elodin_amd.stablehlo tick.mlir --slots slots.json -o pipe.so --mode lane --arith relaxed --one-world` (hipcc cross-compiles):
+    configs[1] as a whole-world module; the printed line and the manifest beside the object say what the host asked for, the object
+    installs like any other (`load_world`), it spills nothing and needs fewer registers than the default build of the same module."""
+    import subprocess
+    import sys
+    from elodin_amd import _lib as L
+    n = 4096
+    text, slots = hb.independent_bodies_world(n)
+    (tmp_path / "tick.mlir").write_text(text)
+    (tmp_path / "slots.json").write_text(json.dumps({"inputs": [{"component": c, "shape": s_, "entity_axis_elided": e_} for c, s_, e_ in slots], "rows": n}))
+    built = {}
+    for tag, flags in (("default", []), ("relaxed", ["--arith", "relaxed", "--one-world"])):
+        out = tmp_path / f"pipe_{tag}.so"
+        res = subprocess.run([sys.executable, "-m", "elodin_amd.stablehlo", str(tmp_path / "tick.mlir"), "--slots", str(tmp_path / "slots.json"), "-o", str(out),
+                              "--mode", "lane", *flags], capture_output=True, text=True, cwd=str(L.PKG.parent))
+        assert res.returncode == 0, res.stderr[-2000:]
+        line = json.loads(res.stdout.strip().splitlines()[-1])
+        prog, manifest = sh.load_world(str(out))
+        assert line["mode"] == manifest["mode"] == "lane" and out.exists()
+        built[tag] = (line, manifest)
+    assert "arith" not in built["default"][0] and "one_world" not in built["default"][1]
+    assert built["relaxed"][0]["arith"] == "relaxed" and built["relaxed"][0]["one_world"] is True
+    assert built["relaxed"][1]["arith"] == "relaxed" and built["relaxed"][1]["one_world"] is True
+    r0, r1 = built["default"][1]["build"]["resources"], built["relaxed"][1]["build"]["resources"]
+    assert r0["vgpr_spills"] == r1["vgpr_spills"] == 0 and r1["vgprs"] < r0["vgprs"]
+    with pytest.raises(NotImplementedError, match="one_world applies to one-kernel ticks"):
+        sh.compile_world(*((lambda t, s: (t, {"inputs": [{"component": c, "shape": sh_, "entity_axis_elided": e_} for c, sh_, e_ in s]}))(*hb.nbody_world(72, 2.9591220828e-4, 1e-6))),
+                         mode="folds", one_world=True)
