@@ -97,6 +97,14 @@ iw = workloads.independent_bodies(rows)
 run(isys, {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), workloads.DT_120HZ), "hlo_world_pos": iw["world_pos"].copy(),
            "hlo_world_vel": iw["world_vel"].copy(), "hlo_world_accel": np.zeros((rows, 6)), "hlo_force": np.zeros((rows, 6)), "hlo_inertia": iw["inertia"].copy(),
            "hlo_torque": iw["body_torque"].copy()}, rows, "independent_bodies_lane_mode")
+# ... and the same module under world_system(arith="relaxed", one_world=True): finite values assumed, shared reciprocals, contraction
+rows = 524288                                                      # a grid of its own
+rtext, rslots = hb.independent_bodies_world(rows)
+rsys, rman = sh.world_system(rtext, rslots, mode="lane", arith="relaxed", one_world=True)
+rw = workloads.independent_bodies(rows)
+run(rsys, {"hlo_tick": np.zeros((rows, 1)), "hlo_simulation_time_step": np.full((rows, 1), workloads.DT_120HZ), "hlo_world_pos": rw["world_pos"].copy(),
+           "hlo_world_vel": rw["world_vel"].copy(), "hlo_world_accel": np.zeros((rows, 6)), "hlo_force": np.zeros((rows, 6)), "hlo_inertia": rw["inertia"].copy(),
+           "hlo_torque": rw["body_torque"].copy()}, rows, "independent_bodies_lane_mode_relaxed")
 out = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / "world_keys.json"
 out.write_text(json.dumps({"ticks_per_launch": TICKS_PER_LAUNCH, "grids": keys}))
 print("done", keys)
