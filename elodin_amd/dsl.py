@@ -421,6 +421,45 @@ class relaxed_arithmetic:
         _RELAXED[0] = self.saved
 
 
+def _sum_of_squares(n: "Expr"):
+    """[t0, t1, ...] when n = (((t0 * t0) + t1 * t1) + t2 * t2) ... (signs of the t stripped), else None."""
+    terms = []
+    while n.op == "add" and len(n.args) == 2:
+        terms.append(n.args[1])
+        n = n.args[0]
+    terms.append(n)
+    out = []
+    for t in reversed(terms):
+        if t.op != "mul" or t.args[0] is not t.args[1]:
+            return None
+        x = t.args[0]
+        out.append(x.args[0] if x.op == "neg" else x)
+    return out if len(out) >= 2 else None
+
+
+def _unit_norm_squared(n: "Expr") -> bool:
+    """Relaxed arithmetic only: n is the squared norm of a vector that was just normalised — every component x_i * r with ONE
+    r = 1 / sqrt(S) and S the very node that sums the squares of those x_i (hash-consing makes that an identity test).  Then
+    n = 1 to rounding (a few 1e-16): the division by it is dropped, as the hand-written kernel drops it."""
+    comps = _sum_of_squares(n)
+    if comps is None:
+        return False
+    xs, r = [], None
+    for c in comps:
+        if c.op != "mul":
+            return False
+        a, b = c.args
+        cand = b if (b.op == "div" and b.args[0].is_const(1.0)) else (a if (a.op == "div" and a.args[0].is_const(1.0)) else None)
+        if cand is None or (r is not None and cand is not r):
+            return False
+        r = cand
+        xs.append(a if cand is b else b)
+    if r.args[1].op != "sqrt":
+        return False
+    base = _sum_of_squares(r.args[1].args[0])
+    return base is not None and len(base) == len(xs) and all(p is q for p, q in zip(base, xs))
+
+
 def _bin(op: str, a, b) -> Expr:
     a, b = _lift(a), _lift(b)
     if _RELAXED[0]:
@@ -430,6 +469,8 @@ def _bin(op: str, a, b) -> Expr:
             if b.op == "const" and b.value not in (0.0,) and b.value == b.value and abs(b.value) != float("inf"):
                 return _bin("mul", a, const(1.0 / b.value))
             if b.op != "const":
+                if _unit_norm_squared(b):      # a / |q^|^2 for q^ = q / |q|: the reference's `inverse` of a normalised quaternion (quaternion.rs:141-155)
+                    return a
                 return _bin("mul", a, Expr("div", (const(1.0), b)))
     if op in ("add", "sub", "mul", "div"):
         if a.op == "const" and b.op == "select" and _const_tree(b):

@@ -679,3 +679,36 @@ def test_lane_exchanges_never_land_in_a_guarded_arm_or_a_divergent_loop():
     tp2 = dsl.Program([bad], dsl.Pipe([]), []).trace({"a": 1, "b": 1})
     with pytest.raises(NotImplementedError, match="lane exchange"):
         codegen.generate_source(tp2, "float64", 2)
+
+
+def test_relaxed_arithmetic_rules_at_the_node_level():
+    """dsl.relaxed_arithmetic rewrites while the DAG is built: `0 * x` -> 0, `a / d` -> a * (1 / d) with ONE reciprocal node per
+    denominator, `a / c` -> a * (1 / c), and the division by the squared norm of a vector that was JUST normalised
+    (x_i * (1 / sqrt(sum x_i^2)), the very nodes) is dropped — the reference's `inverse` of a normalised quaternion
+    (quaternion.rs:141-155).  Nothing of it happens outside the context, and look-alikes keep their division."""
+    x = [dsl.leaf(f"x{k}") for k in range(4)]
+    y = dsl.leaf("y")
+
+    def norm2(v):
+        return ((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3]
+    with dsl.relaxed_arithmetic():
+        assert (x[0] * 0.0).is_const(0.0) and (0.0 * x[1]).is_const(0.0)
+        q1, q2 = x[0] / y, x[1] / y
+        assert q1.op == "mul" and q2.op == "mul" and q1.args[1] is q2.args[1] and q1.args[1].op == "div" and q1.args[1].args[0].is_const(1.0)
+        h = x[0] / 4.0
+        assert h.op == "mul" and h.args[1].is_const(0.25)
+        assert (3.0 / y).op == "div"                                     # a constant numerator keeps its IEEE divide
+        n = dsl.np.sqrt(norm2(x))
+        u = [c / n for c in x]                                            # normalise: x_i * (1 / sqrt(S))
+        inv = [(-u[0]) / norm2(u), (-u[1]) / norm2(u), (-u[2]) / norm2(u), u[3] / norm2(u)]      # conj / |u|^2
+        assert inv[3] is u[3] and inv[0].op == "neg" and inv[0].args[0] is u[0]            # the division is gone
+        inv2 = [(-inv[0]) / norm2(inv), inv[3] / norm2(inv)]             # the inverse of THAT (signs stripped inside the squares)
+        assert inv2[1] is u[3]
+        # look-alikes keep their division: another scale per component, a base that is not the normalised vector, three of four terms
+        w = [x[0] / n, x[1] / n, x[2] / n, x[3] / (n * 2.0)]
+        assert (y / norm2(w)).op == "mul" and (y / norm2(w)).args[1].op == "div"
+        m = dsl.np.sqrt(norm2([x[0], x[1], x[2], y]))
+        v = [c / m for c in x]
+        assert (y / norm2(v)).args[1].op == "div"
+        assert (y / ((u[0] * u[0] + u[1] * u[1]) + u[2] * u[2])).args[1].op == "div"
+    assert (x[0] * 0.0).op == "mul" and (x[0] / y).op == "div"          # outside the context: the program as written
